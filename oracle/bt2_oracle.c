@@ -1,0 +1,589 @@
+/*
+ * oracle/bt2_oracle.c -- TEST INFRASTRUCTURE ONLY (see bt2_oracle.h).
+ *
+ * Scalar plain-C restatement of the reference's FM-index rank/LF, exact
+ * sweep, exact seed search, offset resolution, reference fetch, RNG and the
+ * end-to-end u8 DP fixed point.  Written from the behaviour documented in
+ * SURVEY.md Appendix A-C; every function names the reference lines it follows.
+ * No code is copied: the reference's byte-LUT + SSE formulation is replaced by
+ * straight loops over 2-bit characters.
+ */
+#include "bt2_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* file helpers                                                        */
+/* ------------------------------------------------------------------ */
+static int rd_bytes(FILE *f, void *dst, size_t n) { return fread(dst, 1, n, f) == n ? 0 : -1; }
+
+static int rd_off(FILE *f, int off_size, uint64_t *v) {
+	if (off_size == 4) { uint32_t x; if (rd_bytes(f, &x, 4)) return -1; *v = x; return 0; }
+	return rd_bytes(f, v, 8);
+}
+
+static int rd_off_arr(FILE *f, int off_size, uint64_t n, uint64_t **out) {
+	uint64_t *a = (uint64_t *)malloc((size_t)(n ? n : 1) * 8);
+	if (!a) return -1;
+	if (off_size == 8) {
+		if (rd_bytes(f, a, (size_t)n * 8)) { free(a); return -1; }
+	} else {
+		uint32_t *t = (uint32_t *)malloc((size_t)(n ? n : 1) * 4);
+		if (!t || rd_bytes(f, t, (size_t)n * 4)) { free(t); free(a); return -1; }
+		for (uint64_t i = 0; i < n; i++) a[i] = t[i];
+		free(t);
+	}
+	*out = a;
+	return 0;
+}
+
+static int file_exists(const char *p) { FILE *f = fopen(p, "rb"); if (f) { fclose(f); return 1; } return 0; }
+
+/* Ebwt::readIntoMemory, bt2_io.cpp:39-633; header layout SURVEY.md Appendix B. */
+static int load_ebwt(bt2o_ebwt *e, const char *p1, const char *p2, int off_size, int fw,
+                     int load_sa, int load_rstarts, int load_names) {
+	memset(e, 0, sizeof(*e));
+	e->off_size = off_size;
+	e->off_mask = off_size == 4 ? 0xffffffffull : ~0ull;
+	e->fw = fw;
+	FILE *f = fopen(p1, "rb");
+	if (!f) return -1;
+	int32_t one, lps;
+	if (rd_bytes(f, &one, 4) || one != 1) { fclose(f); return -2; } /* little-endian only */
+	if (rd_off(f, off_size, &e->len)) goto bad;
+	if (rd_bytes(f, &e->line_rate, 4) || rd_bytes(f, &lps, 4) || rd_bytes(f, &e->off_rate, 4) ||
+	    rd_bytes(f, &e->ftab_chars, 4) || rd_bytes(f, &e->flags, 4)) goto bad;
+	/* EbwtParams::init, bt2_idx.h:133-167 */
+	e->side_sz = 1u << e->line_rate;
+	e->side_bwt_sz = e->side_sz - 4 * (uint32_t)off_size;
+	e->side_bwt_len = e->side_bwt_sz * 4;
+	if (e->side_bwt_len != (uint32_t)(48 * off_size)) goto bad; /* reference hard-codes 48*OFF_SIZE, bt2_idx.h:372 */
+	{
+		uint64_t bwt_sz = e->len / 4 + 1;
+		e->num_sides = (bwt_sz + e->side_bwt_sz - 1) / e->side_bwt_sz;
+		e->ebwt_tot_len = e->num_sides * e->side_sz;
+		e->ftab_len = (1ull << (2 * e->ftab_chars)) + 1;
+		e->eftab_len = (uint64_t)e->ftab_chars * 2;
+		e->offs_len = (e->len + 1 + (1ull << e->off_rate) - 1) >> e->off_rate;
+	}
+	if (rd_off(f, off_size, &e->n_pat)) goto bad;
+	if (rd_off_arr(f, off_size, e->n_pat, &e->plen)) goto bad;
+	if (rd_off(f, off_size, &e->n_frag)) goto bad;
+	if (load_rstarts) {
+		if (rd_off_arr(f, off_size, e->n_frag * 3, &e->rstarts)) goto bad;
+	} else {
+		if (fseeko(f, (off_t)(e->n_frag * 3 * off_size), SEEK_CUR)) goto bad;
+	}
+	e->ebwt = (uint8_t *)malloc((size_t)e->ebwt_tot_len);
+	if (!e->ebwt || rd_bytes(f, e->ebwt, (size_t)e->ebwt_tot_len)) goto bad;
+	if (rd_off(f, off_size, &e->zoff)) goto bad;
+	for (int i = 0; i < 5; i++) if (rd_off(f, off_size, &e->fchr[i])) goto bad;
+	if (rd_off_arr(f, off_size, e->ftab_len, &e->ftab)) goto bad;
+	if (rd_off_arr(f, off_size, e->eftab_len, &e->eftab)) goto bad;
+	if (load_names) {
+		/* '\n'-separated names ending in '\0' (bt2_io.cpp:468-484) */
+		size_t cap = 16, n = 0;
+		e->refnames = (char **)calloc(cap, sizeof(char *));
+		char buf[4096]; size_t bl = 0; int any = 0;
+		for (;;) {
+			int c = fgetc(f);
+			if (c == EOF || c == '\0' || c == '\n') {
+				if (any || bl > 0 || c == '\n') {
+					if (n == cap) { cap *= 2; e->refnames = (char **)realloc(e->refnames, cap * sizeof(char *)); }
+					buf[bl] = 0;
+					e->refnames[n++] = strdup(buf);
+					bl = 0; any = 0;
+				}
+				if (c != '\n') break;
+			} else {
+				if (bl + 1 < sizeof(buf)) buf[bl++] = (char)c;
+				any = 1;
+			}
+		}
+		e->n_refnames = n;
+	}
+	fclose(f);
+	if (load_sa) {
+		FILE *g = fopen(p2, "rb");
+		if (!g) return -3;
+		if (rd_bytes(g, &one, 4) || one != 1) { fclose(g); return -3; }
+		if (rd_off_arr(g, off_size, e->offs_len, &e->offs)) { fclose(g); return -3; }
+		fclose(g);
+	}
+	return 0;
+bad:
+	fclose(f);
+	return -4;
+}
+
+/* BitPairReference::BitPairReference, reference.cpp:30-264 */
+static int load_ref(bt2o_ref *r, const char *p3, const char *p4, int off_size) {
+	memset(r, 0, sizeof(*r));
+	FILE *f = fopen(p3, "rb");
+	if (!f) return -1;
+	int32_t one;
+	if (rd_bytes(f, &one, 4) || one != 1) { fclose(f); return -2; }
+	if (rd_off(f, off_size, &r->nrecs) || r->nrecs == 0) { fclose(f); return -2; }
+	r->rec_off = (uint64_t *)malloc(r->nrecs * 8);
+	r->rec_len = (uint64_t *)malloc(r->nrecs * 8);
+	r->rec_first = (uint8_t *)malloc(r->nrecs);
+	r->ref_rec_offs = (uint64_t *)malloc((r->nrecs + 1) * 8);
+	r->ref_offs = (uint64_t *)malloc((r->nrecs + 1) * 8);
+	r->ref_lens = (uint64_t *)malloc((r->nrecs + 1) * 8);
+	uint64_t cumsz = 0, cumlen = 0;
+	for (uint64_t i = 0; i < r->nrecs; i++) {
+		int c;
+		if (rd_off(f, off_size, &r->rec_off[i]) || rd_off(f, off_size, &r->rec_len[i]) || (c = fgetc(f)) == EOF) {
+			fclose(f); return -2;
+		}
+		r->rec_first[i] = c ? 1 : 0;
+		if (r->rec_first[i]) {
+			r->ref_rec_offs[r->nrefs] = i;
+			r->ref_offs[r->nrefs] = cumsz;
+			if (r->nrefs > 0) r->ref_lens[r->nrefs - 1] = cumlen;
+			cumlen = 0;
+			r->nrefs++;
+		} else if (i == 0) { fclose(f); return -2; }
+		cumsz += r->rec_len[i];
+		cumlen += r->rec_off[i] + r->rec_len[i];
+	}
+	fclose(f);
+	r->ref_rec_offs[r->nrefs] = r->nrecs;
+	r->ref_offs[r->nrefs] = cumsz;
+	r->ref_lens[r->nrefs - 1] = cumlen;
+	r->buf_sz = cumsz;
+	uint64_t nbytes = (cumsz + 3) / 4;
+	r->buf = (uint8_t *)malloc((size_t)(nbytes ? nbytes : 1));
+	FILE *g = fopen(p4, "rb");
+	if (!g) return -3;
+	if (rd_bytes(g, r->buf, (size_t)nbytes)) { fclose(g); return -3; }
+	fclose(g);
+	return 0;
+}
+
+int bt2o_index_load(bt2o_index *idx, const char *base) {
+	char p1[4096], p2[4096], p3[4096], p4[4096];
+	memset(idx, 0, sizeof(*idx));
+	const char *ext = "bt2"; int off_size = 4;
+	snprintf(p1, sizeof p1, "%s.1.bt2", base);
+	if (!file_exists(p1)) {
+		snprintf(p1, sizeof p1, "%s.1.bt2l", base);
+		if (!file_exists(p1)) return -1;
+		ext = "bt2l"; off_size = 8;
+	}
+	snprintf(p1, sizeof p1, "%s.1.%s", base, ext);
+	snprintf(p2, sizeof p2, "%s.2.%s", base, ext);
+	int rc = load_ebwt(&idx->fwd, p1, p2, off_size, 1, 1, 1, 1);
+	if (rc) return rc;
+	snprintf(p1, sizeof p1, "%s.rev.1.%s", base, ext);
+	if (file_exists(p1)) {
+		rc = load_ebwt(&idx->bwd, p1, NULL, off_size, 0, 0, 0, 0);
+		if (rc) return rc;
+		idx->has_bwd = 1;
+	}
+	snprintf(p3, sizeof p3, "%s.3.%s", base, ext);
+	snprintf(p4, sizeof p4, "%s.4.%s", base, ext);
+	if (file_exists(p3) && file_exists(p4)) {
+		rc = load_ref(&idx->ref, p3, p4, off_size);
+		if (rc) return rc;
+		idx->has_ref = 1;
+	}
+	return 0;
+}
+
+static void free_ebwt(bt2o_ebwt *e) {
+	free(e->plen); free(e->rstarts); free(e->ebwt); free(e->ftab); free(e->eftab); free(e->offs);
+	if (e->refnames) { for (size_t i = 0; i < e->n_refnames; i++) free(e->refnames[i]); free(e->refnames); }
+	memset(e, 0, sizeof(*e));
+}
+
+void bt2o_index_free(bt2o_index *idx) {
+	free_ebwt(&idx->fwd);
+	if (idx->has_bwd) free_ebwt(&idx->bwd);
+	if (idx->has_ref) {
+		bt2o_ref *r = &idx->ref;
+		free(r->rec_off); free(r->rec_len); free(r->rec_first); free(r->ref_rec_offs);
+		free(r->ref_offs); free(r->ref_lens); free(r->buf);
+	}
+	memset(idx, 0, sizeof(*idx));
+}
+
+/* ------------------------------------------------------------------ */
+/* rank / LF                                                           */
+/* ------------------------------------------------------------------ */
+static inline uint64_t side_occ(const bt2o_ebwt *e, const uint8_t *side, int c) {
+	const uint8_t *p = side + e->side_bwt_sz + (size_t)c * e->off_size;
+	if (e->off_size == 4) { uint32_t v; memcpy(&v, p, 4); return v; }
+	uint64_t v; memcpy(&v, p, 8); return v;
+}
+
+static inline int bwt_char(const uint8_t *side, uint32_t i) { return (side[i >> 2] >> ((i & 3) * 2)) & 3; }
+
+/* countBt2SideEx (bt2_idx.h:1887): counts in [0,charOff) of the side, '$' fix, + occ + fchr */
+void bt2o_rank4(const bt2o_ebwt *e, uint64_t row, uint64_t out[4]) {
+	uint64_t side_num = row / e->side_bwt_len;
+	uint32_t char_off = (uint32_t)(row % e->side_bwt_len);
+	const uint8_t *side = e->ebwt + side_num * e->side_sz;
+	uint64_t cnt[4] = {0, 0, 0, 0};
+	for (uint32_t i = 0; i < char_off; i++) cnt[bwt_char(side, i)]++;
+	/* '$' is stored as 'A' but must not count (bt2_idx.h:1891-1899) */
+	if (side_num == e->zoff / e->side_bwt_len && char_off > (uint32_t)(e->zoff % e->side_bwt_len)) cnt[0]--;
+	for (int c = 0; c < 4; c++) out[c] = cnt[c] + side_occ(e, side, c) + e->fchr[c];
+}
+
+uint64_t bt2o_rank(const bt2o_ebwt *e, uint64_t row, int c) {
+	uint64_t r[4];
+	bt2o_rank4(e, row, r);
+	return r[c];
+}
+
+int bt2o_row_l(const bt2o_ebwt *e, uint64_t row) {
+	uint64_t side_num = row / e->side_bwt_len;
+	uint32_t char_off = (uint32_t)(row % e->side_bwt_len);
+	return bwt_char(e->ebwt + side_num * e->side_sz, char_off);
+}
+
+uint64_t bt2o_map_lf(const bt2o_ebwt *e, uint64_t row) { return bt2o_rank(e, row, bt2o_row_l(e, row)); }
+
+uint64_t bt2o_map_lf1c(const bt2o_ebwt *e, uint64_t row, int c) {
+	if (bt2o_row_l(e, row) != c || row == e->zoff) return e->off_mask;
+	return bt2o_rank(e, row, c);
+}
+
+int bt2o_map_lf1(const bt2o_ebwt *e, uint64_t *row) {
+	if (*row == e->zoff) return -1;
+	int c = bt2o_row_l(e, *row);
+	*row = bt2o_rank(e, *row, c);
+	return c;
+}
+
+/* ftabHi/ftabLo with eftab indirection, bt2_idx.h:1428-1554 */
+static uint64_t ftab_hi(const bt2o_ebwt *e, uint64_t i) {
+	if (e->ftab[i] <= e->len) return e->ftab[i];
+	uint64_t ef = (e->ftab[i] ^ e->off_mask);
+	return e->eftab[ef * 2 + 1];
+}
+static uint64_t ftab_lo(const bt2o_ebwt *e, uint64_t i) {
+	if (e->ftab[i] <= e->len) return e->ftab[i];
+	uint64_t ef = (e->ftab[i] ^ e->off_mask);
+	return e->eftab[ef * 2];
+}
+void bt2o_ftab_lohi(const bt2o_ebwt *e, uint64_t key, uint64_t *top, uint64_t *bot) {
+	*top = ftab_hi(e, key);
+	*bot = ftab_lo(e, key + 1);
+}
+
+uint64_t bt2o_ftab_seq_to_int(const bt2o_ebwt *e, const uint8_t *seq, size_t off, int rev) {
+	int fc = e->ftab_chars;
+	size_t lo = off, hi = off + (size_t)fc;
+	uint64_t k = 0;
+	int fwex = e->fw ? 1 : 0;
+	if (rev) fwex = !fwex;
+	for (int i = 0; i < fc; i++) {
+		int c = fwex ? seq[lo + i] : seq[hi - i - 1];
+		if (c > 3) return UINT64_MAX;
+		k = (k << 2) | (uint64_t)c;
+	}
+	return k;
+}
+
+uint64_t bt2o_get_offset(const bt2o_ebwt *e, uint64_t row, uint64_t *nsteps) {
+	uint64_t jumps = 0;
+	uint64_t mask = (e->off_mask << e->off_rate) & e->off_mask;
+	for (;;) {
+		if (row == e->zoff) { if (nsteps) *nsteps = jumps; return jumps; }
+		if ((row & mask) == row) { if (nsteps) *nsteps = jumps; return jumps + e->offs[row >> e->off_rate]; }
+		row = bt2o_map_lf(e, row);
+		jumps++;
+	}
+}
+
+void bt2o_joined_to_text_off(const bt2o_ebwt *e, uint64_t qlen, uint64_t off,
+                             uint64_t *tidx, uint64_t *textoff, uint64_t *tlen,
+                             int reject_straddle, int *straddled) {
+	uint64_t top = 0, bot = e->n_frag;
+	*straddled = 0;
+	for (;;) {
+		uint64_t elt = top + ((bot - top) >> 1);
+		uint64_t lower = e->rstarts[elt * 3];
+		uint64_t upper = (elt == e->n_frag - 1) ? e->len : e->rstarts[(elt + 1) * 3];
+		uint64_t fraglen = upper - lower;
+		if (lower <= off) {
+			if (upper > off) {
+				if (off + qlen > upper) {
+					*straddled = 1;
+					if (reject_straddle) { *tidx = e->off_mask; return; }
+				}
+				*tidx = e->rstarts[elt * 3 + 1];
+				uint64_t fragoff = off - lower;
+				if (!e->fw) { fragoff = fraglen - fragoff - 1; fragoff -= (qlen - 1); }
+				*textoff = fragoff + e->rstarts[elt * 3 + 2];
+				break;
+			}
+			top = elt;
+		} else {
+			bot = elt;
+		}
+	}
+	*tlen = e->plen[*tidx];
+}
+
+/* ------------------------------------------------------------------ */
+/* exact sweep                                                         */
+/* ------------------------------------------------------------------ */
+/* One LF step on a (top,bot) pair for char c as exactSweepMapLF does
+ * (aligner_seed.cpp:793-824): 2 rank queries when bot-top>1, one when ==1. */
+static void pair_lf(const bt2o_ebwt *e, int c, uint64_t *top, uint64_t *bot, uint64_t *bwops, uint64_t *nrank) {
+	if (c > 3) { *top = *bot = 0; return; }
+	if (*bot - *top > 1) {
+		*bwops += 2;
+		/* SideLocus::initFromTopBot: one side read if both loci share a side (bt2_idx.h:339-348) */
+		*nrank += ((*top / e->side_bwt_len) == (*bot / e->side_bwt_len)) ? 1 : 2;
+		*top = bt2o_rank(e, *top, c);
+		*bot = bt2o_rank(e, *bot, c);
+	} else {
+		*bwops += 1; *nrank += 1;
+		uint64_t t = bt2o_map_lf1c(e, *top, c);
+		if (t == e->off_mask) { *top = *bot = 0; }
+		else { *top = t; *bot = t + 1; }
+	}
+}
+
+void bt2o_exact_sweep(const bt2o_ebwt *e, const uint8_t *seq_fw, const uint8_t *seq_rc,
+                      size_t len, int nofw, int norc, uint32_t mine_max, bt2o_sweep_out *out) {
+	memset(out, 0, sizeof(*out));
+	const int ftab_len = e->ftab_chars;
+	/* The reference interleaves fw and rc only to overlap prefetches
+	 * (aligner_seed.cpp:913); the two strands are independent, so do them in turn. */
+	for (int fwi = 0; fwi < 2; fwi++) {
+		if ((fwi == 0 && nofw) || (fwi == 1 && norc)) continue;
+		const uint8_t *seq = fwi == 0 ? seq_fw : seq_rc;
+		size_t dep = 0; uint32_t nedit = 0; int done = 0, do_init = 1;
+		uint64_t top = 0, bot = 0;
+		while (dep < len && !done) {
+			if (do_init) {
+				/* exactSweepInit :752-791 */
+				top = bot = 0;
+				size_t left = len - dep;
+				int do_ftab = ftab_len > 1 && left >= (size_t)ftab_len;
+				if (do_ftab) {
+					size_t endi = len - dep - 1;
+					for (int i = 0; i < ftab_len; i++) if (seq[endi - i] > 3) { do_ftab = 0; break; }
+				}
+				if (do_ftab) {
+					uint64_t key = bt2o_ftab_seq_to_int(e, seq, left - ftab_len, 0);
+					bt2o_ftab_lohi(e, key, &top, &bot);
+					dep += ftab_len;
+				} else {
+					int c = seq[len - dep - 1];
+					if (c < 4) { top = e->fchr[c]; bot = e->fchr[c + 1]; }
+					dep++;
+				}
+				/* exactSweepStep :826-848 */
+				if (bot <= top) {
+					nedit++;
+					if (nedit >= mine_max) { out->mine[fwi] = nedit; done = 1; }
+					continue;
+				}
+				do_init = 0;
+			}
+			if (dep < len) {
+				pair_lf(e, seq[len - dep - 1], &top, &bot, &out->bwops, &out->nrank);
+				if (bot <= top) {
+					nedit++;
+					if (nedit >= mine_max) { out->mine[fwi] = nedit; done = 1; }
+					do_init = 1;
+				}
+				dep++;
+			}
+		}
+		if (!done && dep >= len) {
+			out->mine[fwi] = nedit;
+			if (nedit == 0 && bot > top) {
+				out->hit[fwi] = 1;
+				out->top[fwi] = top; out->bot[fwi] = bot;
+				out->nelt += bot - top;
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* exact seed search                                                   */
+/* ------------------------------------------------------------------ */
+void bt2o_seed_search_exact(const bt2o_ebwt *fw, const bt2o_ebwt *bw,
+                            const uint8_t *seq, size_t len, bt2o_seed_hit *out) {
+	memset(out, 0, sizeof(*out));
+	const int ftab_len = fw->ftab_chars;
+	uint64_t topf, botf, topb, botb;
+	size_t step = 0;
+	/* steps[k] = -(len-k): right-to-left over the forward index (aligner_seed.cpp:256-262).
+	 * startSearchSeedBi :1638-1718: ftab jump when ftabChars <= maxjump (= len, no Ns). */
+	if (ftab_len > 1 && (size_t)ftab_len <= len) {
+		size_t off = len - ftab_len;
+		uint64_t fwi0 = bt2o_ftab_seq_to_int(fw, seq, off, 0);
+		bt2o_ftab_lohi(fw, fwi0, &topf, &botf);
+		if (botf - topf == 0) return;
+		uint64_t bwi0 = bt2o_ftab_seq_to_int(bw, seq, off, 0);
+		topb = ftab_hi(bw, bwi0);            /* NDEBUG branch :1678-1682 */
+		botb = topb + (botf - topf);
+		step = ftab_len;
+	} else {
+		int c = seq[len - 1];
+		topf = topb = fw->fchr[c];
+		botf = botb = fw->fchr[c + 1];
+		if (botf - topf == 0) return;
+		step = 1;
+	}
+	for (; step < len; step++) {
+		int c = seq[len - step - 1];
+		if (botf - topf > 1) {
+			/* mapBiLFEx (bt2_idx.h:2372): both ranks for all four chars + prefix sums in BWT' */
+			uint64_t t[4], b[4];
+			out->bwops++;
+			out->nrank += ((topf / fw->side_bwt_len) == (botf / fw->side_bwt_len)) ? 1 : 2;
+			bt2o_rank4(fw, topf, t);
+			bt2o_rank4(fw, botf, b);
+			uint64_t tp = topb;
+			for (int j = 0; j < c; j++) tp += b[j] - t[j];
+			if (b[c] == t[c]) { out->topf = out->botf = out->topb = out->botb = 0; return; }
+			topf = t[c]; botf = b[c];
+			topb = tp; botb = tp + (b[c] - t[c]);
+		} else {
+			out->bwops++; out->nrank++;
+			uint64_t t = bt2o_map_lf1c(fw, topf, c);
+			if (t == fw->off_mask) { out->topf = out->botf = out->topb = out->botb = 0; return; }
+			topf = t; botf = t + 1; /* topb/botb unchanged (:2003-2016) */
+		}
+	}
+	out->topf = topf; out->botf = botf; out->topb = topb; out->botb = botb;
+}
+
+/* ------------------------------------------------------------------ */
+/* reference fetch                                                     */
+/* ------------------------------------------------------------------ */
+int bt2o_ref_get_base(const bt2o_ref *r, uint64_t tidx, uint64_t toff) {
+	uint64_t reci = r->ref_rec_offs[tidx], recf = r->ref_rec_offs[tidx + 1];
+	uint64_t buf_off = r->ref_offs[tidx], off = 0;
+	for (uint64_t i = reci; i < recf; i++) {
+		off += r->rec_off[i];
+		if (toff < off) return 4;
+		uint64_t rec_end = off + r->rec_len[i];
+		if (toff < rec_end) {
+			uint64_t bo = buf_off + (toff - off);
+			return (r->buf[bo >> 2] >> ((bo & 3) << 1)) & 3;
+		}
+		buf_off += r->rec_len[i];
+		off = rec_end;
+	}
+	return 4;
+}
+
+void bt2o_ref_get_stretch(const bt2o_ref *r, uint8_t *dest, uint64_t tidx, int64_t toff, size_t count) {
+	for (size_t i = 0; i < count; i++) {
+		int64_t p = toff + (int64_t)i;
+		dest[i] = (p < 0 || (uint64_t)p >= r->ref_lens[tidx]) ? 4 : (uint8_t)bt2o_ref_get_base(r, tidx, (uint64_t)p);
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* RNG                                                                 */
+/* ------------------------------------------------------------------ */
+void bt2o_rng_init(bt2o_rng *r, uint32_t seed) { r->a = 1664525u; r->c = 1013904223u; r->last = seed; r->lastOff = 30; r->inited = 1; }
+uint32_t bt2o_rng_next_u32(bt2o_rng *r) {
+	r->last = r->a * r->last + r->c;
+	uint32_t ret = r->last >> 16;
+	r->last = r->a * r->last + r->c;
+	ret ^= r->last;
+	r->lastOff = 0;
+	return ret;
+}
+uint64_t bt2o_rng_next_u64(bt2o_rng *r) {
+	uint64_t hi = bt2o_rng_next_u32(r);
+	uint64_t lo = bt2o_rng_next_u32(r);
+	return (hi << 32) | lo;
+}
+uint32_t bt2o_rng_next_u2(bt2o_rng *r) {
+	if (r->lastOff > 30) bt2o_rng_next_u32(r);
+	uint32_t ret = (r->last >> r->lastOff) & 3;
+	r->lastOff += 2;
+	return ret;
+}
+int bt2o_rng_next_bool(bt2o_rng *r) {
+	if (r->lastOff > 31) bt2o_rng_next_u32(r);
+	uint32_t ret = (r->last >> r->lastOff) & 1;
+	r->lastOff++;
+	return (int)ret;
+}
+float bt2o_rng_next_float(bt2o_rng *r) { return (float)bt2o_rng_next_u32(r) / (float)0xffffffffu; }
+
+uint32_t bt2o_gen_rand_seed(const uint8_t *seq, const char *qual, size_t len,
+                            const char *name, size_t namelen, uint32_t seed) {
+	uint32_t rseed = (seed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
+	for (size_t i = 0; i < len; i++) rseed ^= ((uint32_t)seq[i] << ((i & 15) << 1));
+	for (size_t i = 0; i < len; i++) rseed ^= ((uint32_t)(int)qual[i] << ((i & 3) << 3));
+	for (size_t i = 0; i < namelen; i++) {
+		int p = (int)name[i];
+		if (p == '/') break;
+		rseed ^= ((uint32_t)p << ((i & 3) << 3));
+	}
+	return rseed;
+}
+
+/* ------------------------------------------------------------------ */
+/* scoring + end-to-end u8 DP fill                                     */
+/* ------------------------------------------------------------------ */
+void bt2o_scoring_default(bt2o_scoring *sc) {
+	sc->match_bonus = 0; sc->mm_pen_type = 3; sc->mm_max = 6; sc->mm_min = 2; sc->n_pen = 1;
+	sc->rd_gap_const = 5; sc->rd_gap_linear = 3; sc->rf_gap_const = 5; sc->rf_gap_linear = 3;
+	sc->gapbar = 4;
+}
+
+static int mm_pen(const bt2o_scoring *sc, int q) {
+	if (sc->mm_pen_type == 3) { /* COST_MODEL_QUAL, scoring.h:106-114 */
+		int ii = q < 40 ? q : 40;
+		float frac = (float)ii / 40.0f;
+		return sc->mm_min + (int)(frac * (float)(sc->mm_max - sc->mm_min));
+	}
+	return sc->mm_max;
+}
+
+int bt2o_score(const bt2o_scoring *sc, int rdc, int refmask, int q) {
+	if (q < 0) q = 0;
+	if (q > 255) q = 255;
+	if (rdc > 3 || refmask > 15) return -sc->n_pen;
+	if (refmask & (1 << rdc)) return sc->match_bonus;
+	return -mm_pen(sc, q);
+}
+
+static inline int subs(int a, int b) { int r = a - b; return r < 0 ? 0 : r; }
+static inline int max2(int a, int b) { return a > b ? a : b; }
+
+int bt2o_sw_fill_ee_u8(const bt2o_scoring *sc, const uint8_t *rd, const uint8_t *qu, int rows,
+                       const uint8_t *rf, int cols, uint8_t *H, uint8_t *E, uint8_t *F) {
+	const int rdgapo = sc->rd_gap_const + sc->rd_gap_linear, rdgape = sc->rd_gap_linear;
+	const int rfgapo = sc->rf_gap_const + sc->rf_gap_linear, rfgape = sc->rf_gap_linear;
+	int lrmax = 0;
+	for (int j = 0; j < cols; j++) {
+		/* the profile row is picked by the lowest set bit of the mask, N (16) -> row 4
+		 * (aligner_swsse_ee_u8.cpp:917-919, mask.cpp:31) */
+		int m = rf[j], refc = 4;
+		for (int b = 0; b < 5; b++) if (m & (1 << b)) { refc = b; break; }
+		int f = 0;
+		for (int i = 0; i < rows; i++) {
+			int veto = (i < sc->gapbar || rows - i - 1 < sc->gapbar) ? 0xff : 0;
+			int pen = -bt2o_score(sc, rd[i], 1 << refc, qu[i]);
+			int hdiag = (i == 0) ? 0xff : (j == 0 ? 0 : H[(i - 1) * cols + (j - 1)]);
+			int e = (j == 0) ? 0
+			      : max2(subs(E[i * cols + j - 1], rdgape),
+			             subs(subs(H[i * cols + j - 1], rdgapo), veto));
+			/* F[i] = max(F[i-1]-ext, H[i-1]-open) -sat veto_i ; F[0] = 0 */
+			f = (i == 0) ? 0 : subs(max2(subs(f, rfgape), subs(H[(i - 1) * cols + j], rfgapo)), veto);
+			int h = max2(max2(subs(hdiag, pen), e), f);
+			H[i * cols + j] = (uint8_t)h; E[i * cols + j] = (uint8_t)e; F[i * cols + j] = (uint8_t)f;
+		}
+		if (H[(rows - 1) * cols + j] > lrmax) lrmax = H[(rows - 1) * cols + j];
+	}
+	return lrmax - 0xff;
+}
