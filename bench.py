@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X multiseed hot path on synthetic 150 bp single-end reads.
+
+Contract (see DESIGN.md "Measurement"):
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+A "step" is one pass of the implemented hot-path stages over one resident batch of reads
+(inputs already in HBM).  Rank 0 prints ONE JSON line with metric/value plus `roofline`
+(dominant kernel, HBM-bound, timed with events on the launch stream) and `cpu_baseline`
+(the unmodified reference bowtie2-align-s from oracle/_ref, all host cores, bounded sample).
+
+hg38 is not available offline, so the workload is a deterministic synthetic genome (uniform
+random bases + planted repeats) indexed by the reference's own bowtie2-build from oracle/_ref;
+`config.workload` names it.  Reads shard across ranks with no data-path collective ("weak").
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def nproc():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def genome_path(mbp, seed):
+    d = os.environ.get("BT2_BENCH_CACHE", "/tmp/bt2_amd_bench")
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, "synth_%dmbp_s%d" % (mbp, seed))
+
+
+def make_genome(mbp, seed):
+    """Deterministic synthetic genome: 4 chromosomes of uniform random bases with planted repeats
+    (so that multi-element SA ranges and repeat seeds occur) and a few N stretches."""
+    import numpy as np
+    base = genome_path(mbp, seed)
+    fa = base + ".fa"
+    npy = base + ".npy"
+    if os.path.exists(fa) and os.path.exists(npy):
+        return base, np.load(npy, allow_pickle=True)
+    rng = np.random.default_rng(seed)
+    total = mbp * 1_000_000
+    nchr = 4
+    chroms = []
+    with open(fa + ".tmp", "wb") as f:
+        for c in range(nchr):
+            n = total // nchr
+            a = rng.integers(0, 4, size=n, dtype=np.uint8)
+            # planted repeats: copy segments elsewhere (2% of the chromosome, lengths 200-5000)
+            nrep = max(1, n // 100_000)
+            for _ in range(nrep):
+                ln = int(rng.integers(200, 5000))
+                src = int(rng.integers(0, n - ln))
+                dst = int(rng.integers(0, n - ln))
+                a[dst:dst + ln] = a[src:src + ln]
+            # N stretches
+            for _ in range(max(1, n // 2_000_000)):
+                ln = int(rng.integers(10, 2000))
+                p = int(rng.integers(0, n - ln))
+                a[p:p + ln] = 4
+            chroms.append(a)
+            s = np.frombuffer(b"ACGTN", dtype=np.uint8)[a]
+            f.write((">chr%d\n" % (c + 1)).encode())
+            full = n - n % 80
+            lines = s[:full].reshape(-1, 80)
+            nl = np.full((lines.shape[0], 1), 10, dtype=np.uint8)
+            f.write(np.hstack([lines, nl]).tobytes())
+            if n % 80:
+                f.write(s[full:].tobytes() + b"\n")
+    os.replace(fa + ".tmp", fa)
+    arr = np.empty(nchr, dtype=object)
+    for i, a in enumerate(chroms):
+        arr[i] = a
+    np.save(npy, arr, allow_pickle=True)
+    return base, arr
+
+
+def build_index(base, threads):
+    if os.path.exists(base + ".rev.2.bt2"):
+        return
+    exe = os.path.join(ROOT, "oracle", "_ref", "bowtie2-build-s")
+    if not os.path.exists(exe):
+        raise RuntimeError("oracle/_ref/bowtie2-build-s missing: run __graft_entry__.build() where /root/reference exists")
+    t0 = time.time()
+    subprocess.check_call([exe, "--threads", str(threads), "-q", base + ".fa", base], stdout=subprocess.DEVNULL)
+    log("[bench] index built in %.1fs" % (time.time() - t0))
+
+
+def synth_reads_gpu(chroms, n, length, seed, device):
+    """SURVEY.md 8d generator on the GPU: uniform position, 50/50 strand, 1% substitutions,
+    0.1% insertions + 0.1% deletions (at most one indel per read here), Phred from {38,38,38,30,20,12}."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lens = torch.tensor([len(c) for c in chroms], dtype=torch.int64)
+    starts = torch.cumsum(lens, 0) - lens
+    genome = torch.cat([torch.from_numpy(c) for c in chroms]).to(device)
+    ci = torch.randint(0, len(chroms), (n,), generator=g, device=device)
+    clen = lens.to(device)[ci]
+    pos = (torch.rand(n, generator=g, device=device, dtype=torch.float64) * (clen - length - 2).double()).long()
+    gpos = starts.to(device)[ci] + pos
+    idx = torch.arange(length, device=device).unsqueeze(0).expand(n, length)
+    # one indel per read with probability ~ length * 0.002
+    has_indel = torch.rand(n, generator=g, device=device) < length * 0.002
+    is_ins = torch.rand(n, generator=g, device=device) < 0.5
+    k = torch.randint(5, length - 5, (n,), generator=g, device=device).unsqueeze(1)
+    shift = torch.zeros(n, length, dtype=torch.int64, device=device)
+    dele = (has_indel & ~is_ins).unsqueeze(1)
+    ins = (has_indel & is_ins).unsqueeze(1)
+    shift = torch.where(dele & (idx >= k), torch.ones_like(shift), shift)
+    shift = torch.where(ins & (idx > k), -torch.ones_like(shift), shift)
+    seq = genome[gpos.unsqueeze(1) + idx + shift]
+    rnd_base = torch.randint(0, 4, (n, length), generator=g, device=device, dtype=torch.uint8)
+    seq = torch.where(ins & (idx == k), rnd_base, seq)
+    sub = torch.rand(n, length, generator=g, device=device) < 0.01
+    seq = torch.where(sub & (seq < 4), (seq + 1 + rnd_base % 3) % 4, seq)
+    seq = torch.where(seq > 3, rnd_base, seq)   # genome N -> random base, like a sequencer would call it
+    rc = torch.rand(n, generator=g, device=device) < 0.5
+    seq = torch.where(rc.unsqueeze(1), (3 - seq).flip(1), seq)
+    qtab = torch.tensor([ord(c) for c in "GGG?5-"], dtype=torch.uint8, device=device)
+    qual = qtab[torch.randint(0, 6, (n, length), generator=g, device=device)]
+    return seq.contiguous(), qual.contiguous()
+
+
+def write_fastq(path, seq, qual, n):
+    import numpy as np
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[seq[:n].cpu().numpy()]
+    q = qual[:n].cpu().numpy()
+    with open(path, "wb") as f:
+        for i in range(n):
+            f.write(b"@r%d\n" % i)
+            f.write(s[i].tobytes())
+            f.write(b"\n+\n")
+            f.write(q[i].tobytes())
+            f.write(b"\n")
+
+
+def cpu_baseline(base, seq, qual, sample, threads):
+    """Reference bowtie2-align-s (oracle/_ref, unmodified v2.5.5, SSE2 build) on a bounded sample."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "bowtie2-align-s")
+    if not os.path.exists(exe):
+        return None
+    fq = base + ".bench_sample.fq"
+    write_fastq(fq, seq, qual, sample)
+    cmd = [exe, "--sensitive", "-p", str(threads), "--reorder", "-t", "-x", base, "-U", fq, "-S", "/dev/null"]
+    t0 = time.time()
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    wall = time.time() - t0
+    if p.returncode != 0:
+        log("[bench] cpu baseline failed:", p.stderr[-500:])
+        return None
+    m = re.search(r"Multiseed full-index search: (\d+):(\d+):(\d+)", p.stderr)
+    search = wall
+    if m:
+        s = int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3))
+        if s >= 5:          # the -t line has 1 s resolution; only trust it when it is long enough
+            search = float(s)
+    al = re.search(r"([\d.]+)% overall alignment rate", p.stderr)
+    return {"value": sample / search, "unit": "reads/s", "cores": threads, "kind": "reference",
+            "sample": "%d of the same synthetic 150 bp reads, bowtie2-align-s v2.5.5 (oracle/_ref, -O3 -msse2) --sensitive -p %d -S /dev/null; "
+                      "time = %s; overall alignment rate %s%%" % (sample, threads, "'-t' search time" if search != wall else "wall incl. index load",
+                                                                  al.group(1) if al else "?")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BT2_BENCH_MBP", "64")))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BT2_BENCH_READS", "1000000")), help="reads per GPU per step")
+    ap.add_argument("--readlen", type=int, default=150)
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BT2_BENCH_CPU_SAMPLE", "200000")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import bowtie2_amd as b
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    threads = nproc()
+    # ---- workload: index (rank 0 builds, others wait) ----
+    if rank == 0:
+        base, chroms = make_genome(args.genome_mbp, 2)
+        build_index(base, threads)
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        base, chroms = make_genome(args.genome_mbp, 2)
+
+    ctx = b.Context(local_rank)
+    info = ctx.load_index(base)
+    # per-rank shard of reads (weak scaling: fixed reads per GPU)
+    seq, qual = synth_reads_gpu(chroms, args.reads, args.readlen, 1000 + rank, dev)
+    n = args.reads
+    off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * args.readlen)
+    batch = b.ReadBatch(seq.view(-1), qual.view(-1), off, n)
+
+    # --sensitive, 150 bp: -L 22, -i S,1,1.15 -> interval 1+1.15*sqrt(150) = 15 (bt2_search.cpp:3443-3450)
+    import math
+    L = 22
+    interval = max(1, int(1 + 1.15 * math.sqrt(args.readlen)))
+    max_seeds = 1 + (args.readlen - L) // interval
+    seedlen_t = torch.full((n,), L, dtype=torch.int32, device=dev)
+    interval_t = torch.full((n,), interval, dtype=torch.int32, device=dev)
+    offset_t = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    stage_events = []
+
+    def step(record):
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        sw = ctx.exact_sweep(batch, False, False, 2)
+        e1.record()
+        sd = ctx.seed_search_exact(batch, seedlen_t, interval_t, offset_t, max_seeds)
+        e2.record()
+        if record:
+            stage_events.append((e0, e1, e2))
+        return sw, sd
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync_all()
+    ctx.counters(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    cnt = ctx.counters()
+
+    sweep_ms = sum(a.elapsed_time(bb) for a, bb, _ in stage_events) / len(stage_events)
+    seed_ms = sum(bb.elapsed_time(c) for _, bb, c in stage_events) / len(stage_events)
+
+    if rank == 0:
+        # dominant kernel = the exact sweep (most rank queries).  Algorithmic bytes:
+        # side_sz per rank query; the device counters give the exact number of sides read.
+        steps = args.steps
+        # per-launch rank queries of each kernel are not separable from one counter; measure the split once
+        ctx.counters(reset=True)
+        ctx.exact_sweep(batch, False, False, 2)
+        c_sw = ctx.counters(reset=True)
+        ctx.seed_search_exact(batch, seedlen_t, interval_t, offset_t, max_seeds)
+        c_sd = ctx.counters(reset=True)
+        side = info.side_sz
+        off_sz = info.off_size
+        sw_bytes = c_sw.rank_queries * side + c_sw.ftab_lookups * 2 * off_sz + n * args.readlen + n * 48
+        sd_bytes = c_sd.rank_queries * side + c_sd.ftab_lookups * 2 * off_sz + n * args.readlen + n * 2 * max_seeds * 32
+        dom = ("k_exact_sweep", sw_bytes, sweep_ms) if sweep_ms >= seed_ms else ("k_seed_search_exact", sd_bytes, seed_ms)
+        achieved = dom[1] / (dom[2] * 1e-3) / 1e9
+        res = {
+            "metric": "aligned reads/sec (whole node), 150 bp SE, synthetic genome (hg38 unavailable offline)",
+            "value": world * n * steps / dt,
+            "unit": "reads/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32" if off_sz == 4 else "u64", "data": "synthetic",
+            "config": {
+                "workload": "synthetic %d Mbp genome (.bt2, built by reference bowtie2-build), %d x %d bp SE reads per GPU per step, --sensitive (-L 22 -i S,1,1.15)"
+                            % (args.genome_mbp, n, args.readlen),
+                "stages_timed": ["exact end-to-end sweep (SeedAligner::exactSweep)", "exact multiseed search round 0 (searchAllSeeds)"],
+                "stages_not_yet_on_gpu": ["1-mismatch e2e search", "seed extension / SW / reporting (extendSeeds)"],
+                "index_bytes_hbm": int(info.hbm_bytes), "side_sz": int(side),
+                "rank_queries_per_read": (c_sw.rank_queries + c_sd.rank_queries) / n,
+                "ms_exact_sweep": sweep_ms, "ms_seed_search": seed_ms,
+            },
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": int(dom[1]), "avg_launch_ms": dom[2]},
+        }
+        cb = None
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(base, seq, qual, min(args.cpu_sample, n), threads)
+        res["cpu_baseline"] = cb
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

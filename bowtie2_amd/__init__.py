@@ -1,0 +1,216 @@
+"""bowtie2_amd -- host-side Python mirror of the C ABI in include/bt2g.h.
+
+The product is libbt2g.so (HIP/gfx950, built in-tree by bowtie2_amd/csrc/Makefile).  This module
+is plumbing only: ctypes bindings plus helpers that keep batches in HBM as torch tensors and hand
+raw device pointers across the C ABI.  There is no CPU fallback: importing works anywhere, but
+every compute call raises Bt2gError if the shared library or a gfx950 device is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbt2g.so")
+
+BT2G_OK = 0
+ERRORS = {-1: "BT2G_ERR_NO_DEVICE", -2: "BT2G_ERR_IO", -3: "BT2G_ERR_FORMAT", -4: "BT2G_ERR_ARG",
+          -5: "BT2G_ERR_HIP", -6: "BT2G_ERR_NOMEM", -7: "BT2G_ERR_UNSUPPORTED"}
+
+
+class Bt2gError(RuntimeError):
+    pass
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("off_size", C.c_int32), ("line_rate", C.c_int32), ("off_rate", C.c_int32), ("ftab_chars", C.c_int32),
+                ("len", C.c_uint64), ("n_pat", C.c_uint64), ("n_frag", C.c_uint64),
+                ("zoff_fw", C.c_uint64), ("zoff_bw", C.c_uint64), ("ebwt_bytes", C.c_uint64),
+                ("offs_len", C.c_uint64), ("hbm_bytes", C.c_uint64), ("side_sz", C.c_uint32)]
+
+
+class Reads(C.Structure):
+    _fields_ = [("d_seq", C.c_void_p), ("d_qual", C.c_void_p), ("d_off", C.c_void_p), ("n_reads", C.c_uint32)]
+
+
+class SweepOut(C.Structure):
+    _fields_ = [("top", C.c_uint64 * 2), ("bot", C.c_uint64 * 2), ("mine", C.c_uint32 * 2),
+                ("hit", C.c_uint8 * 2), ("pad", C.c_uint8 * 6)]
+
+
+class SeedHit(C.Structure):
+    _fields_ = [("topf", C.c_uint64), ("botf", C.c_uint64), ("topb", C.c_uint64), ("botb", C.c_uint64)]
+
+
+class Resolved(C.Structure):
+    _fields_ = [("joined_off", C.c_uint64), ("tidx", C.c_uint64), ("toff", C.c_uint64), ("tlen", C.c_uint64),
+                ("straddled", C.c_uint32), ("steps", C.c_uint32)]
+
+
+class Scoring(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("match_bonus", "mm_pen_type", "mm_max", "mm_min", "n_pen",
+                                          "rd_gap_const", "rd_gap_linear", "rf_gap_const", "rf_gap_linear", "gapbar")]
+
+
+class DpProblem(C.Structure):
+    _fields_ = [("rd_off", C.c_uint64), ("rows", C.c_uint32), ("rf_off", C.c_uint64), ("cols", C.c_uint32),
+                ("mat_off", C.c_uint64)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("rank_queries", C.c_uint64), ("sa_lookups", C.c_uint64), ("ftab_lookups", C.c_uint64),
+                ("dp_cells", C.c_uint64), ("bwops", C.c_uint64)]
+
+
+# every symbol include/bt2g.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+ABI = [
+    ("bt2g_version", C.c_uint32, []),
+    ("bt2g_ctx_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("bt2g_ctx_destroy", None, [_vp]),
+    ("bt2g_last_error", C.c_char_p, [_vp]),
+    ("bt2g_index_load", C.c_int, [_vp, C.c_char_p]),
+    ("bt2g_index_info_get", C.c_int, [_vp, C.POINTER(IndexInfo)]),
+    ("bt2g_index_refname", C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]),
+    ("bt2g_exact_sweep", C.c_int, [_vp, C.POINTER(Reads), C.c_int, C.c_int, C.c_uint32, _vp, _vp]),
+    ("bt2g_seed_search_exact", C.c_int, [_vp, C.POINTER(Reads), _vp, _vp, _vp, C.c_uint32, _vp, _vp]),
+    ("bt2g_resolve_offsets", C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp]),
+    ("bt2g_scoring_default", None, [C.POINTER(Scoring)]),
+    ("bt2g_sw_fill_ee_u8", C.c_int, [_vp, C.POINTER(Scoring), _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("bt2g_counters_read", C.c_int, [_vp, C.POINTER(Counters), C.c_int, _vp]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libbt2g.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Bt2gError("libbt2g.so not built: run `make -C bowtie2_amd/csrc` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in ABI:
+            fn = getattr(L, name)   # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(ctx, rc, what):
+    if rc != 0:
+        msg = lib().bt2g_last_error(ctx)
+        raise Bt2gError("%s failed: %s (%s)" % (what, ERRORS.get(rc, rc), msg.decode() if msg else ""))
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Context:
+    """One per device: owns the HBM-resident index (bt2g_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        rc = lib().bt2g_ctx_create(device, C.byref(self._h))
+        if rc != 0:
+            raise Bt2gError("bt2g_ctx_create failed: %s" % ERRORS.get(rc, rc))
+        self.device = device
+        self.info = None
+
+    def close(self):
+        if self._h:
+            lib().bt2g_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_index(self, base):
+        _check(self._h, lib().bt2g_index_load(self._h, base.encode()), "bt2g_index_load")
+        info = IndexInfo()
+        _check(self._h, lib().bt2g_index_info_get(self._h, C.byref(info)), "bt2g_index_info_get")
+        self.info = info
+        return info
+
+    def refname(self, tidx):
+        nm = C.c_char_p()
+        ln = C.c_uint64()
+        _check(self._h, lib().bt2g_index_refname(self._h, tidx, C.byref(nm), C.byref(ln)), "bt2g_index_refname")
+        return nm.value.decode(), ln.value
+
+    # ---- batches -------------------------------------------------------------------
+    def upload_reads(self, seqs, quals=None):
+        """seqs: list of bytes with codes 0..4; quals: list of ASCII bytes.  Returns a ReadBatch in HBM."""
+        import numpy as np
+        import torch
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        seq = np.frombuffer(b"".join(seqs) + b"\x00", dtype=np.uint8)
+        if quals is None:
+            quals = [b"I" * len(s) for s in seqs]
+        qual = np.frombuffer(b"".join(quals) + b"\x00", dtype=np.uint8)
+        dev = torch.device("cuda", self.device)
+        return ReadBatch(torch.from_numpy(seq.copy()).to(dev), torch.from_numpy(qual.copy()).to(dev),
+                         torch.from_numpy(offs.view(np.int64).copy()).to(dev), len(seqs))
+
+    # ---- stages --------------------------------------------------------------------
+    def exact_sweep(self, batch, nofw=False, norc=False, mine_max=2):
+        import torch
+        out = torch.zeros(batch.n * C.sizeof(SweepOut), dtype=torch.uint8, device=batch.seq.device)
+        rd = batch.struct()
+        _check(self._h, lib().bt2g_exact_sweep(self._h, C.byref(rd), int(nofw), int(norc), mine_max,
+                                                out.data_ptr(), _stream_ptr()), "bt2g_exact_sweep")
+        return out
+
+    def seed_search_exact(self, batch, seedlen, interval, offset, max_seeds):
+        """seedlen/interval/offset: int32 torch tensors [n] on the device."""
+        import torch
+        out = torch.zeros(batch.n * 2 * max_seeds * C.sizeof(SeedHit), dtype=torch.uint8, device=batch.seq.device)
+        rd = batch.struct()
+        _check(self._h, lib().bt2g_seed_search_exact(self._h, C.byref(rd), seedlen.data_ptr(), interval.data_ptr(),
+                                                      offset.data_ptr(), max_seeds, out.data_ptr(), _stream_ptr()),
+               "bt2g_seed_search_exact")
+        return out
+
+    def resolve_offsets(self, rows, qlen, reject_straddle=False):
+        """rows: int64 tensor [n] (SA rows), qlen: int32 tensor [n]."""
+        import torch
+        n = rows.numel()
+        out = torch.zeros(n * C.sizeof(Resolved), dtype=torch.uint8, device=rows.device)
+        _check(self._h, lib().bt2g_resolve_offsets(self._h, rows.data_ptr(), qlen.data_ptr(), n, int(reject_straddle),
+                                                    out.data_ptr(), _stream_ptr()), "bt2g_resolve_offsets")
+        return out
+
+    def sw_fill_ee_u8(self, probs, rd, qu, rf, mat, best, scoring=None):
+        sc = scoring
+        if sc is None:
+            sc = Scoring()
+            lib().bt2g_scoring_default(C.byref(sc))
+        n = probs.numel() // C.sizeof(DpProblem)
+        _check(self._h, lib().bt2g_sw_fill_ee_u8(self._h, C.byref(sc), probs.data_ptr(), n, rd.data_ptr(), qu.data_ptr(),
+                                                  rf.data_ptr(), mat.data_ptr() if mat is not None else None,
+                                                  best.data_ptr(), _stream_ptr()), "bt2g_sw_fill_ee_u8")
+
+    def counters(self, reset=False):
+        c = Counters()
+        _check(self._h, lib().bt2g_counters_read(self._h, C.byref(c), int(reset), _stream_ptr()), "bt2g_counters_read")
+        return c
+
+
+class ReadBatch:
+    def __init__(self, seq, qual, off, n):
+        self.seq, self.qual, self.off, self.n = seq, qual, off, n
+
+    def struct(self):
+        return Reads(self.seq.data_ptr(), self.qual.data_ptr(), self.off.data_ptr(), self.n)
+
+
+def structs_from_tensor(t, ctype):
+    """Copy a uint8 device tensor holding an array of C structs to host and view it as ctypes array."""
+    b = t.cpu().numpy().tobytes()
+    n = len(b) // C.sizeof(ctype)
+    return (ctype * n).from_buffer_copy(b)

@@ -1,0 +1,276 @@
+// bt2g_capi.hip -- implementation of the C ABI declared in include/bt2g.h.
+//
+// Owns the HBM-resident index and the per-context device scratch; every compute entry point
+// is a thin, asynchronous launch of the kernels in bt2g_kernels.hip.  There is deliberately
+// no host fallback: without a usable gfx950 device every entry point returns
+// BT2G_ERR_NO_DEVICE.
+#include "../../include/bt2g.h"
+#include "bt2g_index.hpp"
+#include "bt2g_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace bt2g;
+
+struct bt2g_ctx {
+	int device = -1;
+	std::string err;
+	bool loaded = false;
+	int off_size = 0;
+	HostIndex* host = nullptr;           // header fields + names (bulk arrays are dropped after upload)
+	DevIndex<uint32_t> ix32;
+	DevIndex<uint64_t> ix64;
+	std::vector<void*> allocs;           // index allocations in HBM
+	uint64_t hbm_bytes = 0;
+	DevCounters* d_cnt = nullptr;
+	uint8_t* d_dp_scratch = nullptr;     // wavefront-layout DP scratch
+	uint64_t dp_scratch_bytes = 0;
+	uint32_t n_cu = 0;
+};
+
+namespace {
+
+int fail(bt2g_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+int hip_fail(bt2g_ctx* c, hipError_t e, const char* what) {
+	return fail(c, BT2G_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <typename T>
+int upload(bt2g_ctx* c, const void* src, uint64_t nbytes, const T** dst) {
+	void* p = nullptr;
+	const uint64_t alloc = nbytes ? ((nbytes + 255) & ~255ull) : 256;
+	hipError_t e = hipMalloc(&p, alloc);
+	if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(index)");
+	c->allocs.push_back(p);
+	c->hbm_bytes += alloc;
+	if (nbytes) {
+		e = hipMemcpy(p, src, nbytes, hipMemcpyHostToDevice);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMemcpy(index)");
+	}
+	*dst = reinterpret_cast<const T*>(p);
+	return 0;
+}
+
+template <typename TOff>
+int upload_ebwt(bt2g_ctx* c, const HostEbwt& h, bool fw, DevEbwt<TOff>& d) {
+	int rc;
+	if ((rc = upload(c, h.ebwt.data(), h.ebwt.size(), &d.ebwt))) return rc;
+	if ((rc = upload(c, h.ftab.data(), h.ftab.size(), &d.ftab))) return rc;
+	if ((rc = upload(c, h.eftab.data(), h.eftab.size(), &d.eftab))) return rc;
+	d.offs = nullptr;
+	if (fw && (rc = upload(c, h.offs.data(), h.offs.size(), &d.offs))) return rc;
+	d.len = (TOff)h.len; d.zoff = (TOff)h.zoff;
+	for (int i = 0; i < 5; i++) d.fchr[i] = (TOff)h.fchr[i];
+	d.ftab_chars = (uint32_t)h.ftab_chars; d.off_rate = (uint32_t)h.off_rate; d.is_fw = fw ? 1 : 0;
+	return 0;
+}
+
+template <typename TOff>
+int upload_index(bt2g_ctx* c, const HostIndex& h, DevIndex<TOff>& d) {
+	int rc;
+	if ((rc = upload_ebwt(c, h.fw, true, d.fw))) return rc;
+	if ((rc = upload_ebwt(c, h.bw, false, d.bw))) return rc;
+	if ((rc = upload(c, h.fw.rstarts.data(), h.fw.rstarts.size(), &d.rstarts))) return rc;
+	if ((rc = upload(c, h.fw.plen.data(), h.fw.plen.size(), &d.plen))) return rc;
+	d.n_frag = (TOff)h.fw.n_frag; d.n_pat = (TOff)h.fw.n_pat;
+	const HostRef& r = h.ref;
+	if ((rc = upload(c, r.rec_refpos.data(), r.rec_refpos.size() * 8, &d.ref.rec_refpos))) return rc;
+	if ((rc = upload(c, r.rec_bufpos.data(), r.rec_bufpos.size() * 8, &d.ref.rec_bufpos))) return rc;
+	if ((rc = upload(c, r.rec_len.data(), r.rec_len.size() * 8, &d.ref.rec_len))) return rc;
+	if ((rc = upload(c, r.ref_rec_offs.data(), r.ref_rec_offs.size() * 8, &d.ref.ref_rec_offs))) return rc;
+	if ((rc = upload(c, r.ref_lens.data(), r.ref_lens.size() * 8, &d.ref.ref_lens))) return rc;
+	if ((rc = upload(c, r.buf.data(), r.buf.size(), &d.ref.buf))) return rc;
+	d.ref.nrefs = r.nrefs;
+	return 0;
+}
+
+void free_index(bt2g_ctx* c) {
+	for (void* p : c->allocs) (void)hipFree(p);
+	c->allocs.clear();
+	c->hbm_bytes = 0;
+	c->loaded = false;
+	delete c->host; c->host = nullptr;
+}
+
+int need_loaded(bt2g_ctx* c) {
+	if (!c) return BT2G_ERR_ARG;
+	if (!c->loaded) return fail(c, BT2G_ERR_ARG, "no index loaded");
+	hipError_t e = hipSetDevice(c->device);
+	if (e != hipSuccess) return hip_fail(c, e, "hipSetDevice");
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t bt2g_version(void) { return (0u << 16) | 1u; }
+
+int bt2g_ctx_create(int device, bt2g_ctx** out) {
+	if (!out) return BT2G_ERR_ARG;
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BT2G_ERR_NO_DEVICE;
+	if (hipSetDevice(device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
+	// the fat binary only carries gfx950 code objects
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BT2G_ERR_NO_DEVICE;
+	bt2g_ctx* c = new (std::nothrow) bt2g_ctx();
+	if (!c) return BT2G_ERR_NOMEM;
+	c->device = device;
+	c->n_cu = (uint32_t)prop.multiProcessorCount;
+	if (hipMalloc((void**)&c->d_cnt, sizeof(DevCounters)) != hipSuccess) { delete c; return BT2G_ERR_HIP; }
+	(void)hipMemset(c->d_cnt, 0, sizeof(DevCounters));
+	*out = c;
+	return 0;
+}
+
+void bt2g_ctx_destroy(bt2g_ctx* c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	free_index(c);
+	if (c->d_cnt) (void)hipFree(c->d_cnt);
+	if (c->d_dp_scratch) (void)hipFree(c->d_dp_scratch);
+	delete c;
+}
+
+const char* bt2g_last_error(const bt2g_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int bt2g_index_load(bt2g_ctx* c, const char* base) {
+	if (!c || !base) return BT2G_ERR_ARG;
+	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
+	free_index(c);
+	c->host = new HostIndex();
+	std::string err;
+	int rc = load_index(base, *c->host, err);
+	if (rc) { fail(c, rc, err); delete c->host; c->host = nullptr; return rc; }
+	c->off_size = c->host->off_size;
+	rc = (c->off_size == 4) ? upload_index(c, *c->host, c->ix32) : upload_index(c, *c->host, c->ix64);
+	if (rc) { free_index(c); return rc; }
+	// keep only header fields, names and lengths on the host
+	HostIndex& h = *c->host;
+	for (HostEbwt* e : {&h.fw, &h.bw}) {
+		std::vector<uint8_t>().swap(e->ebwt); std::vector<uint8_t>().swap(e->ftab);
+		std::vector<uint8_t>().swap(e->offs); std::vector<uint8_t>().swap(e->rstarts);
+	}
+	std::vector<uint8_t>().swap(h.ref.buf);
+	c->loaded = true;
+	return 0;
+}
+
+int bt2g_index_info_get(const bt2g_ctx* c, bt2g_index_info* o) {
+	if (!c || !o || !c->loaded) return BT2G_ERR_ARG;
+	const HostIndex& h = *c->host;
+	o->off_size = h.off_size; o->line_rate = h.fw.line_rate; o->off_rate = h.fw.off_rate; o->ftab_chars = h.fw.ftab_chars;
+	o->len = h.fw.len; o->n_pat = h.fw.n_pat; o->n_frag = h.fw.n_frag;
+	o->zoff_fw = h.fw.zoff; o->zoff_bw = h.bw.zoff;
+	o->ebwt_bytes = h.fw.ebwt_tot_len; o->offs_len = h.fw.offs_len; o->hbm_bytes = c->hbm_bytes;
+	o->side_sz = h.fw.side_sz;
+	return 0;
+}
+
+int bt2g_index_refname(const bt2g_ctx* c, uint64_t tidx, const char** name, uint64_t* len) {
+	if (!c || !c->loaded || tidx >= c->host->fw.n_pat) return BT2G_ERR_ARG;
+	if (name) *name = tidx < c->host->fw.refnames.size() ? c->host->fw.refnames[tidx].c_str() : "";
+	if (len) *len = c->host->plen_at(tidx);
+	return 0;
+}
+
+int bt2g_exact_sweep(bt2g_ctx* c, const bt2g_reads* reads, int nofw, int norc, uint32_t mine_max,
+                     bt2g_sweep_out* d_out, void* stream) {
+	int rc = need_loaded(c);
+	if (rc) return rc;
+	if (!reads || !d_out || mine_max == 0) return fail(c, BT2G_ERR_ARG, "bad argument");
+	hipStream_t st = (hipStream_t)stream;
+	hipError_t e = (c->off_size == 4)
+		? launch_exact_sweep(c->ix32, *reads, nofw, norc, mine_max, d_out, c->d_cnt, st)
+		: launch_exact_sweep(c->ix64, *reads, nofw, norc, mine_max, d_out, c->d_cnt, st);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "k_exact_sweep");
+}
+
+int bt2g_seed_search_exact(bt2g_ctx* c, const bt2g_reads* reads, const uint32_t* d_seedlen, const uint32_t* d_interval,
+                           const uint32_t* d_offset, uint32_t max_seeds, bt2g_seed_hit* d_out, void* stream) {
+	int rc = need_loaded(c);
+	if (rc) return rc;
+	if (!reads || !d_out || !d_seedlen || !d_interval || !d_offset || max_seeds == 0) return fail(c, BT2G_ERR_ARG, "bad argument");
+	hipStream_t st = (hipStream_t)stream;
+	hipError_t e = (c->off_size == 4)
+		? launch_seed_search_exact(c->ix32, *reads, d_seedlen, d_interval, d_offset, max_seeds, d_out, c->d_cnt, st)
+		: launch_seed_search_exact(c->ix64, *reads, d_seedlen, d_interval, d_offset, max_seeds, d_out, c->d_cnt, st);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "k_seed_search_exact");
+}
+
+int bt2g_resolve_offsets(bt2g_ctx* c, const uint64_t* d_rows, const uint32_t* d_qlen, uint64_t n, int reject_straddle,
+                         bt2g_resolved* d_out, void* stream) {
+	int rc = need_loaded(c);
+	if (rc) return rc;
+	if ((!d_rows || !d_qlen || !d_out) && n) return fail(c, BT2G_ERR_ARG, "bad argument");
+	hipStream_t st = (hipStream_t)stream;
+	hipError_t e = (c->off_size == 4)
+		? launch_resolve_offsets(c->ix32, d_rows, d_qlen, n, reject_straddle, d_out, c->d_cnt, st)
+		: launch_resolve_offsets(c->ix64, d_rows, d_qlen, n, reject_straddle, d_out, c->d_cnt, st);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "k_resolve_offsets");
+}
+
+void bt2g_scoring_default(bt2g_scoring* sc) {
+	if (!sc) return;
+	sc->match_bonus = 0; sc->mm_pen_type = 3; sc->mm_max = 6; sc->mm_min = 2; sc->n_pen = 1;
+	sc->rd_gap_const = 5; sc->rd_gap_linear = 3; sc->rf_gap_const = 5; sc->rf_gap_linear = 3; sc->gapbar = 4;
+}
+
+int bt2g_sw_fill_ee_u8(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_problem* d_probs, uint32_t n,
+                       const uint8_t* d_rd, const uint8_t* d_qu, const uint8_t* d_rf, uint8_t* d_mat, int32_t* d_best,
+                       void* stream) {
+	if (!c) return BT2G_ERR_ARG;
+	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
+	if (!sc || (!d_probs && n) || !d_best) return fail(c, BT2G_ERR_ARG, "bad argument");
+	if (n == 0) return 0;
+	hipStream_t st = (hipStream_t)stream;
+	// size the per-wave scratch from the problem shapes (this entry point is the stand-alone /
+	// inspection form of the fill; the fused aligner sizes its scratch once per batch)
+	std::vector<bt2g_dp_problem> hp(n);
+	hipError_t e = hipMemcpyAsync(hp.data(), d_probs, sizeof(bt2g_dp_problem) * n, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) return hip_fail(c, e, "copy DP problems");
+	uint64_t per_wave = 0;
+	for (const auto& p : hp) {
+		if (p.rows > 512) return fail(c, BT2G_ERR_UNSUPPORTED, "DP rows > 512");
+		const uint64_t b = dp_scratch_bytes(p.rows ? p.rows : 1, p.cols ? p.cols : 1);
+		if (b > per_wave) per_wave = b;
+	}
+	per_wave = (per_wave + 255) & ~255ull;
+	uint32_t n_waves = c->n_cu * 8;
+	if (n_waves > n) n_waves = n;
+	const uint64_t need = per_wave * n_waves;
+	if (need > c->dp_scratch_bytes) {
+		if (c->d_dp_scratch) (void)hipFree(c->d_dp_scratch);
+		c->d_dp_scratch = nullptr; c->dp_scratch_bytes = 0;
+		e = hipMalloc((void**)&c->d_dp_scratch, need);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(dp scratch)");
+		c->dp_scratch_bytes = need;
+	}
+	e = launch_sw_fill_ee_u8(*sc, d_probs, n, d_rd, d_qu, d_rf, d_mat, d_best, c->d_dp_scratch, per_wave, n_waves, c->d_cnt, st);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "k_sw_fill_ee_u8");
+}
+
+int bt2g_counters_read(bt2g_ctx* c, bt2g_counters* out, int reset, void* stream) {
+	if (!c || !out) return BT2G_ERR_ARG;
+	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
+	hipStream_t st = (hipStream_t)stream;
+	DevCounters h;
+	hipError_t e = hipMemcpyAsync(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_cnt, 0, sizeof(h), st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) return hip_fail(c, e, "read counters");
+	out->rank_queries = h.rank_queries; out->sa_lookups = h.sa_lookups; out->ftab_lookups = h.ftab_lookups;
+	out->dp_cells = h.dp_cells; out->bwops = h.bwops;
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,489 @@
+// bt2g_kernels.hip -- stage kernels of the multiseed hot path for gfx950 (CDNA4).
+//
+//   k_exact_sweep        one lane per (read, strand): SeedAligner::exactSweep  (aligner_seed.cpp:856-970)
+//   k_seed_search_exact  one lane per (read, strand, seed): startSearchSeedBi + searchSeedBi for
+//                        SEED_TYPE_EXACT seeds (aligner_seed.cpp:1638-2037)
+//   k_resolve_offsets    one lane per SA row: Ebwt::getOffset + joinedToTextOff (bt2_idx.cpp:54-171)
+//   k_sw_fill_ee_u8      one wavefront per DP problem: the fixed point computed by
+//                        alignNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:775-1146)
+//
+// The FM kernels are latency/HBM-bound random 64/128-byte line reads: every lane owns an
+// independent backward-search chain so a wave keeps 64-128 line fetches in flight; no LDS
+// staging is used because no two lanes share a side except by accident.  The DP kernel is
+// VALU/shuffle-bound: the anti-diagonal wavefront is mapped onto the 64 lanes (lane = block
+// of consecutive read rows), H/F/ref-char flow lane-to-lane with __shfl_up, and the matrix
+// is written in "wavefront-major" order so that every store instruction writes 64 contiguous
+// bytes.
+#include "bt2g_kernels.hpp"
+
+namespace bt2g {
+
+// ------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int comp_base(int c) { return c < 4 ? 3 - c : 4; }
+
+// character p (0-based, Watson orientation) of the fw read or of its reverse complement
+__device__ __forceinline__ int read_char(const uint8_t* seq, uint32_t len, uint32_t p, bool rc) {
+	return rc ? comp_base(seq[len - 1 - p]) : seq[p];
+}
+
+__device__ __forceinline__ void wave_add_counter(unsigned long long* ctr, unsigned long long v) {
+	// sum over the wave with DPP-free shuffles, one atomic per wave
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+	if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
+}
+
+// key of the ftabChars-mer seq[off .. off+fc) read in text order (forward index) or reversed
+// (mirror index): Ebwt::ftabSeqToInt (bt2_idx.h:1374).  Returns false if an N is present.
+template <typename GetC>
+__device__ __forceinline__ bool ftab_key(GetC getc, uint32_t off, uint32_t fc, bool text_order, uint64_t& key) {
+	key = 0;
+	for (uint32_t i = 0; i < fc; i++) {
+		const int c = text_order ? getc(off + i) : getc(off + fc - 1 - i);
+		if (c > 3) return false;
+		key = (key << 2) | (uint64_t)c;
+	}
+	return true;
+}
+
+// ------------------------------------------------------------------------------------
+// exact end-to-end sweep
+// ------------------------------------------------------------------------------------
+template <typename TOff>
+__global__ void __launch_bounds__(256)
+k_exact_sweep(DevIndex<TOff> ix, bt2g_reads rd, int nofw, int norc, uint32_t mine_max,
+              bt2g_sweep_out* __restrict__ out, DevCounters* cnt) {
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t r = (uint32_t)(gid >> 1);
+	const int fwi = (int)(gid & 1);
+	unsigned long long nrank = 0, nftab = 0, bwops = 0;
+	if (r < rd.n_reads) {
+		const DevEbwt<TOff>& e = ix.fw;
+		const uint64_t o0 = rd.d_off[r];
+		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
+		const uint8_t* seq = rd.d_seq + o0;
+		const bool rc = fwi == 1;
+		const bool skip = (fwi == 0 && nofw) || (fwi == 1 && norc) || len == 0;
+		uint32_t mine = 0;
+		uint8_t hit = 0;
+		TOff top = 0, bot = 0;
+		if (!skip) {
+			const uint32_t ftab_len = e.ftab_chars;
+			uint32_t dep = 0, nedit = 0;
+			bool done = false, do_init = true;
+			auto getc = [&](uint32_t p) { return read_char(seq, len, p, rc); };
+			while (dep < len && !done) {
+				if (do_init) {
+					// exactSweepInit (aligner_seed.cpp:752-791)
+					top = bot = 0;
+					const uint32_t left = len - dep;
+					uint64_t key = 0;
+					const bool do_ftab = ftab_len > 1 && left >= ftab_len && ftab_key(getc, left - ftab_len, ftab_len, true, key);
+					if (do_ftab) {
+						top = ftab_hi(e, key);
+						bot = ftab_lo(e, key + 1);
+						nftab++;
+						dep += ftab_len;
+					} else {
+						const int c = getc(len - dep - 1);
+						if (c < 4) { top = e.fchr[c]; bot = e.fchr[c + 1]; }
+						dep++;
+					}
+					if (bot <= top) {           // exactSweepStep (:826-848)
+						nedit++;
+						if (nedit >= mine_max) { mine = nedit; done = true; }
+						continue;
+					}
+					do_init = false;
+				}
+				if (dep < len) {
+					// exactSweepMapLF (:793-824)
+					const int c = getc(len - dep - 1);
+					if (c > 3) {
+						top = bot = 0;
+					} else if (bot - top > 1) {
+						bwops += 2;
+						TOff nt, nb;
+						nrank += rank1_pair(e, top, bot, c, nt, nb);
+						top = nt; bot = nb;
+					} else {
+						bwops++; nrank++;
+						const TOff t = map_lf1c(e, top, c);
+						if (t == (TOff)OffTraits<TOff>::kMask) { top = bot = 0; }
+						else { top = t; bot = t + 1; }
+					}
+					if (bot <= top) {
+						nedit++;
+						if (nedit >= mine_max) { mine = nedit; done = true; }
+						do_init = true;
+					}
+					dep++;
+				}
+			}
+			if (!done) {
+				mine = nedit;
+				if (nedit == 0 && bot > top) hit = 1;
+			}
+		}
+		bt2g_sweep_out* o = out + r;
+		o->top[fwi] = hit ? (uint64_t)top : 0;
+		o->bot[fwi] = hit ? (uint64_t)bot : 0;
+		o->mine[fwi] = mine;
+		o->hit[fwi] = hit;
+		if (fwi == 0) { for (int i = 0; i < 6; i++) o->pad[i] = 0; }
+	}
+	wave_add_counter(&cnt->rank_queries, nrank);
+	wave_add_counter(&cnt->ftab_lookups, nftab);
+	wave_add_counter(&cnt->bwops, bwops);
+}
+
+template <typename TOff>
+hipError_t launch_exact_sweep(const DevIndex<TOff>& ix, const bt2g_reads& rd, int nofw, int norc, uint32_t mine_max,
+                              bt2g_sweep_out* d_out, DevCounters* d_cnt, hipStream_t st) {
+	if (rd.n_reads == 0) return hipSuccess;
+	const uint64_t nthreads = (uint64_t)rd.n_reads * 2;
+	const uint32_t block = 256;
+	const uint32_t grid = (uint32_t)((nthreads + block - 1) / block);
+	hipLaunchKernelGGL(k_exact_sweep<TOff>, dim3(grid), dim3(block), 0, st, ix, rd, nofw, norc, mine_max, d_out, d_cnt);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// exact (-N 0) multiseed search
+// ------------------------------------------------------------------------------------
+template <typename TOff>
+__global__ void __launch_bounds__(256)
+k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict__ d_seedlen,
+                    const uint32_t* __restrict__ d_interval, const uint32_t* __restrict__ d_offset,
+                    uint32_t max_seeds, bt2g_seed_hit* __restrict__ out, DevCounters* cnt) {
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
+	unsigned long long nrank = 0, nftab = 0, bwops = 0;
+	if (gid < total) {
+		// consecutive lanes take consecutive seeds of one (read, strand): their read bytes are adjacent
+		const uint32_t i = (uint32_t)(gid % max_seeds);
+		const uint64_t rs = gid / max_seeds;
+		const uint32_t r = (uint32_t)(rs >> 1);
+		const bool rc = (rs & 1) != 0;
+		const uint64_t o0 = rd.d_off[r];
+		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
+		const uint8_t* seq = rd.d_seq + o0;
+		uint32_t L = d_seedlen[r];
+		const uint32_t per = d_interval[r], off = d_offset[r];
+		if (L > len) L = len;   // Seed::instantiate shrinks the seed to the read (aligner_seed.cpp:226-230)
+		// instantiateSeeds (:523-526)
+		uint32_t nseeds = 0;
+		if (len > 0 && L > 0 && per > 0 && !(off > 0 && (uint64_t)L + off > len)) {
+			nseeds = 1;
+			if ((int64_t)len - (int64_t)off > (int64_t)L) nseeds += (len - off - L) / per;
+		}
+		TOff topf = 0, botf = 0, topb = 0, botb = 0;
+		bool ok = i < nseeds;
+		const uint32_t depth = i * per + off;          // seed's offset from the 5' end
+		if (ok && depth + L > len) ok = false;
+		if (ok) {
+			// Seed sequence as it aligns to the Watson strand: fw -> read[depth, depth+L);
+			// rc -> revcomp of that window (instantiateSeq :463-485), i.e. k-th char = comp(read[depth+L-1-k]).
+			auto getc = [&](uint32_t k) -> int {
+				return rc ? comp_base(seq[depth + L - 1 - k]) : (int)seq[depth + k];
+			};
+			// An N anywhere disqualifies an exact seed (Constraint::exact cannot absorb it, :338-347)
+			for (uint32_t k = 0; k < L; k++) if (getc(k) > 3) { ok = false; break; }
+			uint32_t step = 0;
+			const uint32_t fc = ix.fw.ftab_chars;
+			if (ok) {
+				if (fc > 1 && fc <= L) {
+					// startSearchSeedBi: ftab jump over the right-most fc characters (:1672-1692)
+					uint64_t kf = 0, kb = 0;
+					ftab_key(getc, L - fc, fc, true, kf);
+					ftab_key(getc, L - fc, fc, false, kb);
+					topf = ftab_hi(ix.fw, kf);
+					botf = ftab_lo(ix.fw, kf + 1);
+					nftab += 2;
+					if (botf <= topf) { ok = false; }
+					else { topb = ftab_hi(ix.bw, kb); botb = topb + (botf - topf); }
+					step = fc;
+				} else {
+					const int c = getc(L - 1);
+					topf = topb = ix.fw.fchr[c];
+					botf = botb = ix.fw.fchr[c + 1];
+					if (botf <= topf) ok = false;
+					step = 1;
+				}
+			}
+			// searchSeedBi main loop for steps[k] = -(L-k): right-to-left over the forward index
+			for (; ok && step < L; step++) {
+				const int c = getc(L - step - 1);
+				if (botf - topf > 1) {
+					TOff t[4], b[4];
+					bwops++;
+					nrank += rank4_pair(ix.fw, topf, botf, t, b);        // mapBiLFEx (bt2_idx.h:2372)
+					TOff tp = topb;
+					for (int j = 0; j < c; j++) tp += b[j] - t[j];
+					if (b[c] == t[c]) { ok = false; break; }
+					topf = t[c]; botf = b[c];
+					topb = tp; botb = tp + (b[c] - t[c]);
+				} else {
+					bwops++; nrank++;
+					const TOff t = map_lf1c(ix.fw, topf, c);                 // :2003-2016
+					if (t == (TOff)OffTraits<TOff>::kMask) { ok = false; break; }
+					topf = t; botf = t + 1;
+				}
+			}
+		}
+		bt2g_seed_hit h;
+		if (ok) { h.topf = topf; h.botf = botf; h.topb = topb; h.botb = botb; }
+		else    { h.topf = h.botf = h.topb = h.botb = 0; }
+		out[gid] = h;
+	}
+	wave_add_counter(&cnt->rank_queries, nrank);
+	wave_add_counter(&cnt->ftab_lookups, nftab);
+	wave_add_counter(&cnt->bwops, bwops);
+}
+
+template <typename TOff>
+hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& rd, const uint32_t* d_seedlen,
+                                    const uint32_t* d_interval, const uint32_t* d_offset, uint32_t max_seeds,
+                                    bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st) {
+	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
+	if (total == 0) return hipSuccess;
+	const uint32_t block = 256;
+	const uint64_t grid = (total + block - 1) / block;
+	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_seed_search_exact<TOff>, dim3((uint32_t)grid), dim3(block), 0, st, ix, rd, d_seedlen, d_interval,
+	                   d_offset, max_seeds, d_out, d_cnt);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// SA row -> (reference, offset)
+// ------------------------------------------------------------------------------------
+template <typename TOff>
+__global__ void __launch_bounds__(256)
+k_resolve_offsets(DevIndex<TOff> ix, const uint64_t* __restrict__ d_rows, const uint32_t* __restrict__ d_qlen,
+                  uint64_t n, int reject_straddle, bt2g_resolved* __restrict__ out, DevCounters* cnt) {
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long nrank = 0, nsa = 0;
+	if (gid < n) {
+		uint32_t steps = 0;
+		const TOff row = (TOff)d_rows[gid];
+		const TOff joff = get_offset(ix.fw, row, steps);
+		nrank += steps;
+		nsa += (row == ix.fw.zoff || steps > 0 || true) ? 1 : 0;
+		TOff tidx, toff, tlen;
+		bool straddled;
+		joined_to_text_off(ix, (TOff)d_qlen[gid], joff, tidx, toff, tlen, reject_straddle != 0, straddled);
+		bt2g_resolved o;
+		o.joined_off = joff;
+		o.tidx = (tidx == (TOff)OffTraits<TOff>::kMask) ? ~0ull : (uint64_t)tidx;
+		o.toff = toff; o.tlen = tlen;
+		o.straddled = straddled ? 1u : 0u;
+		o.steps = steps;
+		out[gid] = o;
+	}
+	wave_add_counter(&cnt->rank_queries, nrank);
+	wave_add_counter(&cnt->sa_lookups, nsa);
+}
+
+template <typename TOff>
+hipError_t launch_resolve_offsets(const DevIndex<TOff>& ix, const uint64_t* d_rows, const uint32_t* d_qlen, uint64_t n,
+                                  int reject_straddle, bt2g_resolved* d_out, DevCounters* d_cnt, hipStream_t st) {
+	if (n == 0) return hipSuccess;
+	const uint32_t block = 256;
+	const uint64_t grid = (n + block - 1) / block;
+	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_resolve_offsets<TOff>, dim3((uint32_t)grid), dim3(block), 0, st, ix, d_rows, d_qlen, n,
+	                   reject_straddle, d_out, d_cnt);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// end-to-end u8 DP fill, one wavefront per problem
+// ------------------------------------------------------------------------------------
+//
+// Lane l owns read rows [l*R, l*R+R); at step t it computes column j = t - l for its R rows.
+// Cross-lane inputs (last row of the lane above, previous step) arrive by __shfl_up:
+//   H[lR-1][j]   -> F / gap-open source for row lR
+//   F[lR-1][j]
+//   H[lR-1][j-1] -> diagonal for row lR   (what we received one step earlier)
+//   ref char j   -> handed down the lanes, lane 0 fetches rf[t]
+// Wavefront-major scratch layout (coalesced 64-byte stores):
+//   byte address of matrix m (0=H,1=E,2=F), row i, column j  =  ((t*3 + m)*R + (i%R))*64 + (i/R),  t = j + i/R
+//
+__host__ __device__ inline uint32_t dp_rows_per_lane(uint32_t rows) { return (rows + 63) / 64; }
+
+uint64_t dp_scratch_bytes(uint32_t rows, uint32_t cols) {
+	const uint32_t R = dp_rows_per_lane(rows);
+	const uint32_t lanes = (rows + R - 1) / R;
+	const uint64_t steps = (uint64_t)cols + lanes - 1;
+	return steps * 3 * R * 64;
+}
+
+struct DpScoring {
+	int mm_type, mm_max, mm_min, n_pen, rdgapo, rdgape, rfgapo, rfgape, gapbar, match_bonus;
+};
+
+__device__ __forceinline__ int subs_u8(int a, int b) { const int r = a - b; return r < 0 ? 0 : r; }
+
+template <int R>
+__device__ __forceinline__ int sw_fill_ee_u8_wave(const DpScoring& sc, const uint8_t* __restrict__ rd,
+                                                   const uint8_t* __restrict__ qu, uint32_t rows,
+                                                   const uint8_t* __restrict__ rf, uint32_t cols,
+                                                   uint8_t* __restrict__ scratch) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t nlanes = (rows + R - 1) / R;
+	// per-row constants
+	int rdc[R], mmp[R], veto[R];
+	bool valid[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const uint32_t i = (uint32_t)lane * R + r;
+		valid[r] = i < rows;
+		const int c = valid[r] ? rd[i] : 4;
+		int q = valid[r] ? qu[i] : 0;
+		rdc[r] = c;
+		if (sc.mm_type == 3) {   // COST_MODEL_QUAL (scoring.h:106-114)
+			const int qq = q < 40 ? q : 40;
+			const float frac = (float)qq / 40.0f;
+			mmp[r] = sc.mm_min + (int)(frac * (float)(sc.mm_max - sc.mm_min));
+		} else {
+			mmp[r] = sc.mm_max;
+		}
+		veto[r] = (valid[r] && ((int)i < sc.gapbar || (int)(rows - i - 1) < sc.gapbar)) ? 0xff : 0;
+	}
+	int Hprev[R], Eprev[R];     // column j-1 of my rows
+#pragma unroll
+	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
+	int myHlast = 0, myFlast = 0;      // my last row, previous step (column j-1 for me == column j for lane+1 ... see shuffles)
+	int upHdiag = 0;                   // H[lR-1][j-1]
+	int refm = 0;                      // reference mask of my current column
+	int best = 0;
+	const uint32_t steps = cols + nlanes - 1;
+	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
+	const int last_r = (int)((rows - 1) % R);
+	for (uint32_t t = 0; t < steps; t++) {
+		// hand values down one lane
+		const int upH = __shfl_up(myHlast, 1);
+		const int upF = __shfl_up(myFlast, 1);
+		int upRef = __shfl_up(refm, 1);
+		if (lane == 0) upRef = (t < cols) ? rf[t] : 16;
+		refm = upRef;
+		const int j = (int)t - lane;
+		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
+		int refc = 4;   // lowest set bit picks the profile row; N (16) -> 4 (mask.cpp:31)
+		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
+		int hdiag = (lane == 0) ? 0xff : (j == 0 ? 0 : upHdiag);
+		int fin_h = upH, fin_f = upF;   // row above my first row, same column
+		int Hnew[R], Enew[R], Fnew[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			// match / mismatch / N penalty for (row, ref char)
+			int pen;
+			if (rdc[r] > 3 || refc > 3) pen = sc.n_pen;
+			else pen = (rdc[r] == refc) ? -sc.match_bonus : mmp[r];
+			const int e = (j == 0) ? 0 : max(subs_u8(Eprev[r], sc.rdgape), subs_u8(subs_u8(Hprev[r], sc.rdgapo), veto[r]));
+			int f;
+			if (lane == 0 && r == 0) f = 0;
+			else f = subs_u8(max(subs_u8(fin_f, sc.rfgape), subs_u8(fin_h, sc.rfgapo)), veto[r]);
+			const int h = max(max(subs_u8(hdiag, pen), e), f);
+			Hnew[r] = h; Enew[r] = e; Fnew[r] = f;
+			hdiag = Hprev[r];      // diagonal for the next row = H[i][j-1]
+			fin_h = h; fin_f = f;
+		}
+		if (active) {
+			uint8_t* base = scratch + ((uint64_t)t * 3 * R) * 64 + lane;
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				base[(0 * R + r) * 64] = (uint8_t)Hnew[r];
+				base[(1 * R + r) * 64] = (uint8_t)Enew[r];
+				base[(2 * R + r) * 64] = (uint8_t)Fnew[r];
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
+			if (lane_has_last) best = max(best, Hnew[last_r]);
+		}
+		// what the lane below needs next step: my last row at this column, and (one step later) as its diagonal
+		upHdiag = upH;
+		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
+	}
+	// broadcast the best last-row score from the lane that owns the last row
+	best = __shfl(best, (int)((rows - 1) / R));
+	return best - 0xff;
+}
+
+__global__ void __launch_bounds__(64)
+k_sw_fill_ee_u8(DpScoring sc, const bt2g_dp_problem* __restrict__ probs, uint32_t n, const uint8_t* __restrict__ d_rd,
+                const uint8_t* __restrict__ d_qu, const uint8_t* __restrict__ d_rf, uint8_t* __restrict__ d_mat,
+                int32_t* __restrict__ d_best, uint8_t* __restrict__ d_scratch, uint64_t scratch_per_wave,
+                uint32_t n_waves, DevCounters* cnt) {
+	const int lane = threadIdx.x & 63;
+	unsigned long long cells = 0;
+	// persistent waves: wave w handles problems w, w+n_waves, ...
+	for (uint32_t p = blockIdx.x; p < n; p += n_waves) {
+		const bt2g_dp_problem pr = probs[p];
+		uint8_t* scratch = d_scratch + (uint64_t)blockIdx.x * scratch_per_wave;
+		const uint8_t* rd = d_rd + pr.rd_off;
+		const uint8_t* qu = d_qu + pr.rd_off;
+		const uint8_t* rf = d_rf + pr.rf_off;
+		const uint32_t R = dp_rows_per_lane(pr.rows);
+		int best = -0xff;
+		if (pr.rows > 0 && pr.cols > 0) {
+			switch (R) {
+				case 1: best = sw_fill_ee_u8_wave<1>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
+				case 2: best = sw_fill_ee_u8_wave<2>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
+				case 3: best = sw_fill_ee_u8_wave<3>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
+				case 4: best = sw_fill_ee_u8_wave<4>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
+				case 5: best = sw_fill_ee_u8_wave<5>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
+				case 6: best = sw_fill_ee_u8_wave<6>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
+				case 7: best = sw_fill_ee_u8_wave<7>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
+				default: best = sw_fill_ee_u8_wave<8>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
+			}
+		}
+		if (lane == 0) d_best[p] = best;
+		cells += (lane == 0) ? (unsigned long long)pr.rows * pr.cols : 0;
+		// export to canonical row-major H|E|F for inspection / parity tests
+		if (pr.mat_off != ~0ull && pr.rows > 0 && pr.cols > 0) {
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // other lanes' scratch stores -> visible
+			const uint64_t ncell = (uint64_t)pr.rows * pr.cols;
+			uint8_t* dst = d_mat + pr.mat_off;
+			for (uint64_t k = lane; k < ncell; k += 64) {
+				const uint32_t i = (uint32_t)(k / pr.cols), j = (uint32_t)(k % pr.cols);
+				const uint32_t l = i / R, r = i % R;
+				const uint64_t t = (uint64_t)j + l;
+				const uint8_t* src = scratch + (t * 3 * R) * 64 + l;
+				dst[k] = src[(0 * R + r) * 64];
+				dst[ncell + k] = src[(1 * R + r) * 64];
+				dst[2 * ncell + k] = src[(2 * R + r) * 64];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // reads done before the next problem overwrites
+		}
+	}
+	if (lane == 0 && cells) atomicAdd(&cnt->dp_cells, cells);
+}
+
+hipError_t launch_sw_fill_ee_u8(const bt2g_scoring& s, const bt2g_dp_problem* d_probs, uint32_t n, const uint8_t* d_rd,
+                                const uint8_t* d_qu, const uint8_t* d_rf, uint8_t* d_mat, int32_t* d_best,
+                                uint8_t* d_scratch, uint64_t scratch_per_wave, uint32_t n_waves,
+                                DevCounters* d_cnt, hipStream_t st) {
+	if (n == 0) return hipSuccess;
+	DpScoring sc;
+	sc.mm_type = s.mm_pen_type; sc.mm_max = s.mm_max; sc.mm_min = s.mm_min; sc.n_pen = s.n_pen;
+	sc.rdgapo = s.rd_gap_const + s.rd_gap_linear; sc.rdgape = s.rd_gap_linear;
+	sc.rfgapo = s.rf_gap_const + s.rf_gap_linear; sc.rfgape = s.rf_gap_linear;
+	sc.gapbar = s.gapbar; sc.match_bonus = s.match_bonus;
+	const uint32_t grid = n < n_waves ? n : n_waves;
+	hipLaunchKernelGGL(k_sw_fill_ee_u8, dim3(grid), dim3(64), 0, st, sc, d_probs, n, d_rd, d_qu, d_rf, d_mat, d_best,
+	                   d_scratch, scratch_per_wave, grid, d_cnt);
+	return hipGetLastError();
+}
+
+// explicit instantiations
+template hipError_t launch_exact_sweep<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, int, int, uint32_t, bt2g_sweep_out*, DevCounters*, hipStream_t);
+template hipError_t launch_exact_sweep<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, int, int, uint32_t, bt2g_sweep_out*, DevCounters*, hipStream_t);
+template hipError_t launch_seed_search_exact<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t);
+template hipError_t launch_seed_search_exact<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t);
+template hipError_t launch_resolve_offsets<uint32_t>(const DevIndex<uint32_t>&, const uint64_t*, const uint32_t*, uint64_t, int, bt2g_resolved*, DevCounters*, hipStream_t);
+template hipError_t launch_resolve_offsets<uint64_t>(const DevIndex<uint64_t>&, const uint64_t*, const uint32_t*, uint64_t, int, bt2g_resolved*, DevCounters*, hipStream_t);
+
+} // namespace bt2g

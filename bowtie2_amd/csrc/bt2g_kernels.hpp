@@ -1,0 +1,33 @@
+// bt2g_kernels.hpp -- launchers for the stage kernels (implemented in bt2g_kernels.hip).
+#ifndef BT2G_KERNELS_HPP_
+#define BT2G_KERNELS_HPP_
+
+#include <hip/hip_runtime.h>
+#include "bt2g_device.hpp"
+#include "../../include/bt2g.h"
+
+namespace bt2g {
+
+template <typename TOff>
+hipError_t launch_exact_sweep(const DevIndex<TOff>& ix, const bt2g_reads& rd, int nofw, int norc, uint32_t mine_max,
+                              bt2g_sweep_out* d_out, DevCounters* d_cnt, hipStream_t st);
+
+template <typename TOff>
+hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& rd, const uint32_t* d_seedlen,
+                                    const uint32_t* d_interval, const uint32_t* d_offset, uint32_t max_seeds,
+                                    bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st);
+
+template <typename TOff>
+hipError_t launch_resolve_offsets(const DevIndex<TOff>& ix, const uint64_t* d_rows, const uint32_t* d_qlen, uint64_t n,
+                                  int reject_straddle, bt2g_resolved* d_out, DevCounters* d_cnt, hipStream_t st);
+
+hipError_t launch_sw_fill_ee_u8(const bt2g_scoring& sc, const bt2g_dp_problem* d_probs, uint32_t n, const uint8_t* d_rd,
+                                const uint8_t* d_qu, const uint8_t* d_rf, uint8_t* d_mat, int32_t* d_best,
+                                uint8_t* d_scratch, uint64_t scratch_per_wave, uint32_t n_waves,
+                                DevCounters* d_cnt, hipStream_t st);
+
+// bytes of wavefront-layout DP scratch needed for one problem of the given shape
+uint64_t dp_scratch_bytes(uint32_t rows, uint32_t cols);
+
+} // namespace bt2g
+#endif

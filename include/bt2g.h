@@ -1,0 +1,196 @@
+/*
+ * include/bt2g.h -- C ABI of libbt2g.so, the MI355X (gfx950) implementation of
+ * bowtie2's per-read multiseed hot path.
+ *
+ * The reference (BenLangmead/bowtie2 v2.5.5) has no FFI / plugin seam for this
+ * path; its only boundaries are the bowtie2-align-{s,l} argv/SAM contract and
+ * `extern "C" int bowtie(int, const char**)` (bt2_search.cpp:5223-5386).  The
+ * seam where a GPU goes is the per-thread worker
+ * `static void multiseedSearchWorker(void*)` (bt2_search.cpp:3094-4254) with its
+ * file-static inputs multiseed_ebwtFw/ebwtBw/refs/sc (bt2_search.cpp:1910-1917).
+ * Each entry point below names the reference interface it stands in for; the
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: plain C, POD structs, caller-owned buffers, no exceptions.  All
+ * functions return 0 on success or a negative bt2g_status.  Pointers named d_*
+ * are DEVICE pointers (HBM, e.g. from hipMalloc or a torch tensor's data_ptr());
+ * h_* are host pointers.  `stream` is a hipStream_t passed as void* (NULL =
+ * default stream).  Calls are asynchronous w.r.t. the host unless stated; one
+ * ctx per device, external synchronisation per stream.  There is NO CPU
+ * fallback: every compute entry point fails with BT2G_ERR_NO_DEVICE if no
+ * gfx950 device is usable.
+ *
+ * Offsets (SA rows, text offsets) are uint64_t at this boundary regardless of
+ * index width; the kernels run 32-bit arithmetic internally for .bt2 indexes.
+ */
+#ifndef BT2G_H_
+#define BT2G_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	BT2G_OK = 0,
+	BT2G_ERR_NO_DEVICE = -1,   /* no HIP device / wrong arch                */
+	BT2G_ERR_IO = -2,          /* index file missing / unreadable           */
+	BT2G_ERR_FORMAT = -3,      /* not a bowtie2 index we understand          */
+	BT2G_ERR_ARG = -4,         /* bad argument                               */
+	BT2G_ERR_HIP = -5,         /* HIP runtime error (see bt2g_last_error)    */
+	BT2G_ERR_NOMEM = -6,
+	BT2G_ERR_UNSUPPORTED = -7  /* option outside the implemented hot path    */
+} bt2g_status;
+
+typedef struct bt2g_ctx bt2g_ctx;
+
+/* ---- lifecycle -------------------------------------------------------- */
+/* Create a context bound to HIP device `device`. */
+int  bt2g_ctx_create(int device, bt2g_ctx **out);
+void bt2g_ctx_destroy(bt2g_ctx *ctx);
+/* Human-readable text for the last error on this ctx (never NULL). */
+const char *bt2g_last_error(const bt2g_ctx *ctx);
+/* Library/ABI version: (major<<16)|minor. */
+uint32_t bt2g_version(void);
+
+/* ---- index ------------------------------------------------------------ */
+typedef struct {
+	int32_t  off_size;        /* 4 = .bt2, 8 = .bt2l                         */
+	int32_t  line_rate, off_rate, ftab_chars;
+	uint64_t len;             /* joined-text length                          */
+	uint64_t n_pat, n_frag;   /* # reference sequences, # N-free fragments   */
+	uint64_t zoff_fw, zoff_bw;
+	uint64_t ebwt_bytes;      /* per direction                               */
+	uint64_t offs_len;        /* # SA samples (forward index)                */
+	uint64_t hbm_bytes;       /* total HBM occupied by the index             */
+	uint32_t side_sz;         /* bytes per rank query: 64 (.bt2) / 128 (.bt2l) */
+} bt2g_index_info;
+
+/*
+ * Load <base>.{1,2,rev.1,3,4}.bt2 or .bt2l (auto-detected) and make it resident
+ * in HBM.  Replaces Ebwt::Ebwt + Ebwt::loadIntoMemory for both directions
+ * (bt2_search.cpp:4986,5155,4832-4854; bt2_io.cpp:39-633) and
+ * BitPairReference::BitPairReference (reference.cpp:30-264).  Synchronous.
+ */
+int bt2g_index_load(bt2g_ctx *ctx, const char *base);
+int bt2g_index_info_get(const bt2g_ctx *ctx, bt2g_index_info *out);
+/* Reference names / lengths (for the @SQ header lines); name pointer valid until ctx destroy. */
+int bt2g_index_refname(const bt2g_ctx *ctx, uint64_t tidx, const char **name, uint64_t *len);
+
+/* ---- reads in HBM ----------------------------------------------------- */
+/*
+ * A read batch resident in HBM.  d_seq: concatenated read characters, one
+ * byte per base, codes 0..4 = A,C,G,T,N (Read::patFw, read.h:39).  d_qual:
+ * ASCII (Phred+33) qualities, same layout.  d_off[n_reads+1]: start offset of
+ * each read in d_seq/d_qual (ragged; empty reads allowed).
+ */
+typedef struct {
+	const uint8_t  *d_seq;
+	const uint8_t  *d_qual;
+	const uint64_t *d_off;
+	uint32_t        n_reads;
+} bt2g_reads;
+
+/* ---- stage 1: exact end-to-end sweep ----------------------------------- */
+/* Per (read, strand) result of SeedAligner::exactSweep (aligner_seed.cpp:856-970). */
+typedef struct {
+	uint64_t top[2], bot[2];  /* [0] fw read, [1] rc read; valid iff hit     */
+	uint32_t mine[2];         /* lower bound on # edits (capped at mine_max) */
+	uint8_t  hit[2];          /* exact end-to-end hit recorded               */
+	uint8_t  pad[6];
+} bt2g_sweep_out;
+
+/*
+ * Replaces SeedAligner::exactSweep for a whole batch: d_out[n_reads].
+ * nofw/norc as in the reference; mine_max = 2 at the reference's call site
+ * (bt2_search.cpp:3514-3526).
+ */
+int bt2g_exact_sweep(bt2g_ctx *ctx, const bt2g_reads *reads, int nofw, int norc, uint32_t mine_max,
+                     bt2g_sweep_out *d_out, void *stream);
+
+/* ---- stage 2: exact multiseed search ----------------------------------- */
+typedef struct {
+	uint64_t topf, botf;      /* range in the forward index (botf==topf: no hit or seed contains N) */
+	uint64_t topb, botb;      /* range in the mirror index                   */
+} bt2g_seed_hit;
+
+/*
+ * One seeding round with -N 0 for a whole batch: Seed::mmSeeds(0,L) +
+ * SeedAligner::instantiateSeeds + searchAllSeeds (aligner_seed.cpp:498-720,
+ * 1638-2037).  For read r: nseeds = 1 + (len-offset-L)/interval when
+ * len-offset > L else 1 (:523-526); seeds whose window would run off the read
+ * are not produced when offset>0 and L+offset > len (bt2_search.cpp:3927).
+ * Per-read parameters come from d_seedlen/d_interval/d_offset (each [n_reads]);
+ * seedlen is clamped to the read length as the reference does (:229).
+ * Output slot for (read r, strand s (0 fw,1 rc), seed i) is
+ * d_out[(r*2+s)*max_seeds + i]; slots with i >= nseeds(r) are zeroed.
+ */
+int bt2g_seed_search_exact(bt2g_ctx *ctx, const bt2g_reads *reads,
+                           const uint32_t *d_seedlen, const uint32_t *d_interval, const uint32_t *d_offset,
+                           uint32_t max_seeds, bt2g_seed_hit *d_out, void *stream);
+
+/* ---- stage 3: SA-row -> text offset ------------------------------------ */
+typedef struct {
+	uint64_t joined_off;      /* Ebwt::getOffset(row) (bt2_idx.cpp:150)      */
+	uint64_t tidx, toff, tlen;/* Ebwt::joinedToTextOff (bt2_idx.cpp:54); tidx = UINT64_MAX if rejected */
+	uint32_t straddled;
+	uint32_t steps;           /* LF steps walked                              */
+} bt2g_resolved;
+
+/*
+ * Batched offset resolution: replaces GroupWalk2S::advanceElement's result
+ * (group_walk.h:1160) == Ebwt::getOffset + joinedToTextOff.  d_rows[n],
+ * d_qlen[n] (hit length, for the straddle test), reject_straddle as in the
+ * reference call (aligner_sw_driver.cpp:1135).
+ */
+int bt2g_resolve_offsets(bt2g_ctx *ctx, const uint64_t *d_rows, const uint32_t *d_qlen, uint64_t n,
+                         int reject_straddle, bt2g_resolved *d_out, void *stream);
+
+/* ---- stage 4: end-to-end u8 DP fill ------------------------------------ */
+typedef struct {
+	int32_t match_bonus;      /* 0 in end-to-end mode                         */
+	int32_t mm_pen_type;      /* 3 = quality-aware (default), 1 = constant    */
+	int32_t mm_max, mm_min;   /* --mp 6,2                                     */
+	int32_t n_pen;            /* --np 1                                       */
+	int32_t rd_gap_const, rd_gap_linear, rf_gap_const, rf_gap_linear; /* --rdg 5,3 --rfg 5,3 */
+	int32_t gapbar;           /* --gbar 4                                     */
+} bt2g_scoring;
+
+void bt2g_scoring_default(bt2g_scoring *sc);
+
+/* One DP problem: read rows in alignment orientation + reference masks. */
+typedef struct {
+	uint64_t rd_off;          /* offset into d_rd / d_qu (phred, i.e. ASCII-33) */
+	uint32_t rows;
+	uint64_t rf_off;          /* offset into d_rf (masks 1<<base, 16 = N)    */
+	uint32_t cols;
+	uint64_t mat_off;         /* offset (bytes) of this problem's H then E then F (each rows*cols, row-major) in d_mat; UINT64_MAX = don't export */
+} bt2g_dp_problem;
+
+/*
+ * Replaces SwAligner::align's end-to-end 8-bit fill,
+ * alignNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:775-1146): fills
+ * H/E/F to the same fixed point and returns per problem best = max last-row
+ * H - 0xff in d_best[n].  One wavefront per problem.  rows <= 512.
+ */
+int bt2g_sw_fill_ee_u8(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_problem *d_probs, uint32_t n,
+                       const uint8_t *d_rd, const uint8_t *d_qu, const uint8_t *d_rf,
+                       uint8_t *d_mat, int32_t *d_best, void *stream);
+
+/* ---- instrumentation ---------------------------------------------------- */
+typedef struct {
+	uint64_t rank_queries;    /* # sides read (SURVEY.md 8d unit)             */
+	uint64_t sa_lookups;      /* # offs[] reads                               */
+	uint64_t ftab_lookups;    /* # ftab jumps                                 */
+	uint64_t dp_cells;        /* # DP cells filled                            */
+	uint64_t bwops;           /* reference-compatible BW-op count             */
+} bt2g_counters;
+/* Copies device-side counters accumulated since the last reset (synchronises the stream). */
+int bt2g_counters_read(bt2g_ctx *ctx, bt2g_counters *out, int reset, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

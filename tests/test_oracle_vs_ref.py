@@ -1,0 +1,109 @@
+"""Differential check of the plain-C oracle against the reference's own classes (oracle/ref_shim.cpp)
+on a larger synthetic genome with default ftabChars=10.  Skipped where oracle/_ref is not built."""
+import ctypes as C
+import random
+
+import pytest
+
+from bt2test import (Index, Scoring, SeedHit, SweepOut, cached_synth_index, encode, have_ref, oracle, refshim,
+                     revcomp, synth_reads, u64)
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (no /root/reference)")
+
+
+@pytest.fixture(scope="module", params=[False, True], ids=["bt2", "bt2l"])
+def ctx(request):
+    large = request.param
+    base, refs = cached_synth_index(large=large)
+    L = oracle()
+    R = refshim(large)
+    idx = Index()
+    assert L.bt2o_index_load(C.byref(idx), base.encode()) == 0
+    h = R.ref_open(base.encode())
+    assert h
+    yield L, R, idx, h, refs
+    R.ref_close(h)
+
+
+def test_rank_lf_offsets(ctx):
+    L, R, idx, h, refs = ctx
+    n = idx.fwd.len
+    rnd = random.Random(1)
+    rows = [0, 1, n - 1, n, idx.fwd.zoff, idx.fwd.zoff + 1, idx.bwd.zoff, idx.bwd.zoff + 1] + [rnd.randrange(0, n + 1) for _ in range(4000)]
+    a = (u64 * 4)()
+    b = (u64 * 4)()
+    ns = u64()
+    for d, e in ((0, idx.fwd), (1, idx.bwd)):
+        for row in rows:
+            L.bt2o_rank4(C.byref(e), row, a)
+            R.ref_rank4(h, d, row, b)
+            assert list(a) == list(b)
+            for c in range(4):
+                x = L.bt2o_map_lf1c(C.byref(e), row, c)
+                y = R.ref_map_lf1c(h, d, row, c)
+                assert x == (y if y != 2**64 - 1 else e.off_mask)
+    for row in rows:
+        assert L.bt2o_get_offset(C.byref(idx.fwd), row, C.byref(ns)) == R.ref_get_offset(h, row)
+
+
+def test_sweep_and_seed_rounds(ctx):
+    L, R, idx, h, refs = ctx
+    reads = (synth_reads(refs, 150, 100, seed=3) + synth_reads(refs, 40, 150, seed=4, sub=0.0, ins=0, dele=0)
+             + synth_reads(refs, 40, 60, seed=5, n_rate=0.01) + synth_reads(refs, 10, 12, seed=6))
+    o = (u64 * 10)()
+    so = SweepOut()
+    out = (u64 * (5 * 2 * 64))()
+    bw = u64()
+    sh = SeedHit()
+    for nm, s, q in reads:
+        R.ref_exact_sweep(h, s.encode(), q.encode(), o)
+        L.bt2o_exact_sweep(C.byref(idx.fwd), encode(s), encode(revcomp(s)), len(s), 0, 0, 2, C.byref(so))
+        assert list(o) == [so.mine[0], so.mine[1], so.hit[0], so.hit[1], so.top[0], so.bot[0], so.top[1], so.bot[1], so.nelt, so.bwops]
+        for (sl, iv, off) in ((22, 12, 0), (20, 7, 3)):
+            if off > 0 and sl + off > len(s):
+                continue
+            ns_ = R.ref_seed_round(h, s.encode(), q.encode(), sl, iv, off, out, 5 * 2 * 64, C.byref(bw))
+            eff = min(sl, len(s))
+            mybw = 0
+            for fwi in range(2):
+                for i in range(ns_):
+                    depth = i * iv + off
+                    sub = s[depth:depth + eff]
+                    if fwi:
+                        sub = revcomp(sub)
+                    want = list(out[(fwi * ns_ + i) * 5:(fwi * ns_ + i) * 5 + 5])
+                    if "N" in sub:
+                        mine = [0] * 5
+                    else:
+                        L.bt2o_seed_search_exact(C.byref(idx.fwd), C.byref(idx.bwd), encode(sub), len(sub), C.byref(sh))
+                        mybw += sh.bwops
+                        mine = [1, sh.topf, sh.botf, sh.topb, sh.botb] if sh.botf > sh.topf else [0] * 5
+                    assert mine == want
+            assert mybw == bw.value
+
+
+def test_dp_fill_random(ctx):
+    L, R, idx, h, refs = ctx
+    sc = Scoring()
+    L.bt2o_scoring_default(C.byref(sc))
+    rnd = random.Random(8)
+    g = refs[0][1].replace("N", "A")
+    for t in range(25):
+        rows = rnd.choice([20, 50, 100, 150, 33])
+        cols = rows + rnd.choice([0, 12, 60])
+        pos = rnd.randrange(0, len(g) - cols - 2)
+        window = g[pos:pos + cols + 1]
+        rd = list(window[(cols - rows) // 2:(cols - rows) // 2 + rows])
+        for i in range(rows):
+            if rnd.random() < 0.04:
+                rd[i] = rnd.choice("ACGTN")
+        rd = "".join(rd)
+        qu = "".join(rnd.choice("GGG?5-I#") for _ in range(rows))
+        rf = bytes(1 << "ACGTN".index(c) for c in window)
+        bufs = [C.create_string_buffer(rows * cols) for _ in range(6)]
+        flag = C.c_int()
+        best_ref = R.ref_sw_fill_ee_u8(h, rd.encode(), qu.encode(), rf, cols, -250, bufs[0], bufs[1], bufs[2], C.byref(flag))
+        best = L.bt2o_sw_fill_ee_u8(C.byref(sc), encode(rd), bytes(ord(c) - 33 for c in qu), rows, rf, cols, bufs[3], bufs[4], bufs[5])
+        assert [b.raw for b in bufs[:3]] == [b.raw for b in bufs[3:]]
+        if flag.value == 0:
+            assert best == best_ref
