@@ -286,7 +286,11 @@ BT2_HD void joined_to_text_off(const DevIndex<TOff>& ix, TOff qlen, TOff off, TO
                                bool reject_straddle, bool& straddled) {
 	TOff top = 0, bot = ix.n_frag;
 	straddled = false;
-	for (;;) {
+	tidx = (TOff)OffTraits<TOff>::kMask; textoff = 0; tlen = 0;
+	// The reference is only ever asked about offsets inside the joined text; the row of the empty
+	// suffix resolves to off == len, which no fragment contains -- report it as rejected.
+	if (off >= ix.fw.len || ix.n_frag == 0) return;
+	for (int iter = 0; iter < 70; iter++) {
 		const TOff elt = top + ((bot - top) >> 1);
 		const TOff lower = ix.rstarts[(uint64_t)elt * 3];
 		const TOff upper = (elt == ix.n_frag - 1) ? ix.fw.len : ix.rstarts[((uint64_t)elt + 1) * 3];
@@ -305,7 +309,7 @@ BT2_HD void joined_to_text_off(const DevIndex<TOff>& ix, TOff qlen, TOff off, TO
 			bot = elt;
 		}
 	}
-	tlen = ix.plen[tidx];
+	if (tidx != (TOff)OffTraits<TOff>::kMask) tlen = ix.plen[tidx];
 }
 
 // BitPairReference::getBase / getStretch semantics (reference.cpp:330-579) with a binary

@@ -265,12 +265,16 @@ k_resolve_offsets(DevIndex<TOff> ix, const uint64_t* __restrict__ d_rows, const 
                   uint64_t n, int reject_straddle, bt2g_resolved* __restrict__ out, DevCounters* cnt) {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	unsigned long long nrank = 0, nsa = 0;
-	if (gid < n) {
+	if (gid < n && d_rows[gid] > (uint64_t)ix.fw.len) {
+		// not a row of this index: reject instead of walking garbage
+		bt2g_resolved z; z.joined_off = ~0ull; z.tidx = ~0ull; z.toff = 0; z.tlen = 0; z.straddled = 0; z.steps = 0;
+		out[gid] = z;
+	} else if (gid < n) {
 		uint32_t steps = 0;
 		const TOff row = (TOff)d_rows[gid];
 		const TOff joff = get_offset(ix.fw, row, steps);
 		nrank += steps;
-		nsa += (row == ix.fw.zoff || steps > 0 || true) ? 1 : 0;
+		nsa += (row == ix.fw.zoff) ? 0 : 1;
 		TOff tidx, toff, tlen;
 		bool straddled;
 		joined_to_text_off(ix, (TOff)d_qlen[gid], joff, tidx, toff, tlen, reject_straddle != 0, straddled);

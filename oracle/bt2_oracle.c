@@ -304,6 +304,8 @@ void bt2o_joined_to_text_off(const bt2o_ebwt *e, uint64_t qlen, uint64_t off,
                              int reject_straddle, int *straddled) {
 	uint64_t top = 0, bot = e->n_frag;
 	*straddled = 0;
+	*tidx = e->off_mask; *textoff = 0; *tlen = 0;
+	if (off >= e->len || e->n_frag == 0) return;   /* outside the joined text: the reference never asks */
 	for (;;) {
 		uint64_t elt = top + ((bot - top) >> 1);
 		uint64_t lower = e->rstarts[elt * 3];
