@@ -31,10 +31,18 @@ def log(*a):
 
 
 def nproc():
+    """Usable host cores: affinity mask, clipped by the cgroup CPU quota if there is one."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
 
 
 def genome_path(mbp, seed):
@@ -96,7 +104,8 @@ def build_index(base, threads):
     if not os.path.exists(exe):
         raise RuntimeError("oracle/_ref/bowtie2-build-s missing: run __graft_entry__.build() where /root/reference exists")
     t0 = time.time()
-    subprocess.check_call([exe, "--threads", str(threads), "-q", base + ".fa", base], stdout=subprocess.DEVNULL)
+    # bowtie2-build's blockwise suffix sorter scales poorly past a few dozen threads
+    subprocess.check_call([exe, "--threads", str(min(threads, 32)), "-q", base + ".fa", base], stdout=subprocess.DEVNULL)
     log("[bench] index built in %.1fs" % (time.time() - t0))
 
 

@@ -87,6 +87,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise Bt2gError("libbt2g.so not built: run `make -C bowtie2_amd/csrc` (or __graft_entry__.build())")
+        # torch ships its own HIP runtime; it must be the one already resident when libbt2g.so is
+        # mapped so that both share one runtime (device pointers and streams cross this boundary).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in ABI:
             fn = getattr(L, name)   # AttributeError if a declared symbol is missing
