@@ -1,0 +1,330 @@
+// bt2g_align.hpp -- the per-read multiseed worker, written once for the device.
+//
+// Execution model on MI355X: ONE WAVEFRONT PER READ.  All 64 lanes run this control code in
+// lock-step on identical values (it is wave-uniform, so the compiler keeps most of it on the
+// scalar unit); the lanes only take different roles inside the explicitly wave-parallel
+// sections (the DP fill, row zeroing).  Per-read working state lives in a per-wave arena in
+// HBM (`Work`), sized for 288 GB parts: nothing is allocated dynamically.
+//
+// What it restates (behaviour, not code) -- cited where each piece starts:
+//   multiseedSearchWorker            bt2_search.cpp:3094-4254
+//   SeedAligner::exactSweep/oneMmSearch/instantiateSeeds/searchAllSeeds   aligner_seed.cpp
+//   SeedResults::rankSeedHits        aligner_seed.h:1019
+//   SwDriver::eeSaTups/extend/prioritizeSATupsRands/extendSeeds           aligner_sw_driver.cpp
+//   Random1toN, RowSampler           random_util.h, aligner_sw_driver.h:179
+//   DynProgFramer::frameSeedExtensionRect   dp_framer.cpp:81
+//   SwAligner::initRef/align/nextAlignment/ungappedAlign, e2e u8 gather+backtrace
+//                                    aligner_sw.cpp, aligner_swsse_ee_u8.cpp
+//   RedundantAlns, EIvalMergeListBinned      aligner_result.cpp:929, ival_list.h
+//   AlnSinkWrap::report/finishRead/selectByScore, ReportingState          aln_sink.cpp
+//
+// Scope of this file: unpaired reads, end-to-end mode, -N 0, default -M
+// reporting (also -k N), reads up to kMaxLen.  Anything else is rejected up front by the host.
+//
+// The same source also compiles for the host (tests/hostsim) -- there the wave-parallel
+// sections fall back to plain loops -- which is how the control logic was debugged against the
+// reference without a GPU in the build container.  The host build is test-only.
+#ifndef BT2G_ALIGN_HPP_
+#define BT2G_ALIGN_HPP_
+
+#include "bt2g_device.hpp"
+
+namespace bt2g {
+
+constexpr int kMaxLen      = 512;   // longest read (DP rows)
+constexpr int kMaxOffs     = 64;    // seed offsets per strand
+constexpr int kMaxMm1      = 256;   // 1-mismatch end-to-end hits kept
+constexpr int kMaxRanges   = 2 * kMaxOffs;
+constexpr int kMaxSatpos   = 704;   // maxIters(400) + ranges + slack
+constexpr int kMaxEdits    = 200;
+constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at most 51)
+constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
+constexpr int kListArena   = 16384; // uint32 slots for Random1toN lists
+constexpr int kMaxCands    = 1024;  // DP backtrace candidates (<= DP columns)
+constexpr int kMaxCols     = kMaxLen + 4 * 15 + 1 + 4;
+
+enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
+enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMIT, EXT_HARD_LIMIT };
+enum { ERR_NONE = 0, ERR_OVERFLOW = 1 };   // per-read status: capacity of a fixed arena exceeded
+
+// ---------------------------------------------------------------------------------------
+// parameters (one per batch) -- everything the reference keeps in bt2_search.cpp's file statics
+struct AlignParams {
+	// scoring (Scoring, scoring.h)
+	int mm_type, mm_max, mm_min, n_pen, rdgapo, rdgape, rfgapo, rfgape, gapbar, match_bonus;
+	// effort / reporting (bt2_search.cpp:303-502)
+	int khits, mhits;           // -k, -M (mhits>0 => -M mode)
+	int max_dp_streak;          // -D
+	int max_ug, max_dp, max_iters;
+	int n_seed_rounds;          // -R + ... (nSeedRounds)
+	int seed_boost_thresh;      // 300
+	int tighten;                // 3
+	int maxhalf;                // --dpad 15
+	int nofw, norc;
+	int do_exact_upfront, do_1mm_upfront, do_ungapped, do_extend;
+	int large_index;            // RNG draws differ between -s and -l builds (aligner_sw_driver.cpp:103-109)
+};
+
+// per-read inputs computed on the host with the reference's own formulas (SimpleFunc::f uses
+// libm double math; keeping it on the host makes minsc/interval/nceil bit-identical by construction)
+struct ReadParams {
+	int32_t  minsc;      // scoreMin.f(len), clamped (bt2_search.cpp:3352-3372)
+	int32_t  interval;   // msIval.f(len) -> max(1, .) (:3443-3450)
+	int32_t  nceil;      // min(nCeil.f(len), len) (:3427)
+	int32_t  seedlen;    // multiseedLen
+	uint32_t seed;       // genRandSeed (pat.cpp:45)
+	uint32_t filt;       // bit0 nfilt, bit1 scfilt, bit2 lenfilt, bit3 qcfilt (1 = passes)
+};
+
+struct Edit {
+	uint16_t pos;
+	uint8_t  chr;    // reference char (ASCII) or '-'
+	uint8_t  qchr;   // read char (ASCII) or '-'
+	uint8_t  type;
+	uint8_t  pad;
+};
+
+struct AlnRes {
+	int64_t  refoff;
+	int64_t  reflen;
+	int32_t  refid;
+	int32_t  score;
+	int16_t  ns, gaps, edits, bases_aligned;
+	uint16_t refns;
+	uint16_t nned;
+	uint16_t rdlen, rdextent, rfextent;
+	uint16_t trim5p, trim3p;
+	uint8_t  fw;
+	uint8_t  pad[5];
+	Edit     ned[kMaxEdits];
+};
+
+// What the sink hands back to the host for one read (SAM formatting / MAPQ happen there).
+struct ReadResult {
+	uint8_t  status;        // ERR_*
+	uint8_t  aligned;       // nunpair1 > 0
+	uint8_t  maxed;         // unpair1Max (more than -M alignments)
+	uint8_t  filt;          // copy of ReadParams.filt
+	uint8_t  exhausted;     // exhaustive[0] (always false here, as in the reference call sites)
+	uint8_t  has_secbest;   // bestUnchosenUScore valid
+	uint8_t  pad[2];
+	int32_t  secbest;       // bestUnchosenUScore
+	int32_t  best;          // bestUScore
+	uint32_t nalns;         // alignments found (rs1u_.size())
+	uint32_t nreport;       // alignments to print (<= khits)
+	// metrics mirroring PerReadMetrics / SeedSearchMetrics for work-parity checks
+	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail_streak_max, n_bwops_seed, n_bwops_ext, n_redundants;
+	uint32_t n_bt_attempts;
+	AlnRes   alns[1];       // nreport entries follow (ReadResult is allocated with room for khits)
+};
+
+// ---------------------------------------------------------------------------------------
+// RandomSource (random_source.h:34-159)
+struct Rng {
+	uint32_t last, lastOff;
+	BT2_HD void init(uint32_t seed) { last = seed; lastOff = 30; }
+	BT2_HD uint32_t nextU32() {
+		last = 1664525u * last + 1013904223u;
+		uint32_t ret = last >> 16;
+		last = 1664525u * last + 1013904223u;
+		ret ^= last;
+		lastOff = 0;
+		return ret;
+	}
+	BT2_HD uint64_t nextU64() { uint64_t hi = nextU32(); uint64_t lo = nextU32(); return (hi << 32) | lo; }
+	BT2_HD bool nextBool() {
+		if (lastOff > 31) nextU32();
+		const uint32_t r = (last >> lastOff) & 1u;
+		lastOff++;
+		return r != 0;
+	}
+	BT2_HD float nextFloat() { return (float)nextU32() / (float)0xffffffffu; }
+};
+
+// ---------------------------------------------------------------------------------------
+// working state of one read (one wavefront)
+struct EEHit {            // end-to-end exact / 1-mismatch hit (aligner_seed.h:482)
+	uint64_t top, bot;
+	int32_t  score;
+	uint16_t epos;        // mismatch: offset from 5' end
+	uint8_t  echr, eqchr; // mismatch: reference char / read char (codes 0..4)
+	uint8_t  fw, has_edit;
+	uint8_t  pad[2];
+};
+
+struct SeedHitRec {       // one (strand, offidx): QVal with a single range (exact seeds)
+	uint64_t topf, botf, topb, botb;   // botf==topf: no hit
+};
+
+struct R1N {              // Random1toN (random_util.h:32)
+	uint32_t sz, n, cur, thresh;
+	uint32_t list_off, list_len;   // into Work::lists
+	uint32_t seen_off, seen_len;
+	uint8_t  swaplist, converted, inited, pad;
+};
+
+struct SatPos {           // SATupleAndPos (aligner_sw_driver.h:144)
+	uint64_t topf, topb;
+	uint32_t size;        // sat.size() (elements in this tuple)
+	uint32_t orig_sz;
+	uint32_t offidx, rdoff, seedlen;
+	uint32_t nlex, nrex;
+	uint8_t  fw, pad[3];
+	int32_t  ee;          // index into eehits (eeMode) or -1
+	R1N      rnd;         // rands_[i]
+};
+
+struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };
+
+struct RedAln {           // cells of one alignment, RedundantAlns (aligner_result.cpp:929)
+	int64_t refoff;
+	int32_t refid;
+	uint16_t start, len;
+	uint8_t fw, pad[7];
+	int8_t  left_rel[kMaxLen];
+	uint8_t width[kMaxLen];
+};
+
+struct BtCand { int32_t score; uint16_t row, col; };
+
+struct BtFrame {          // DpNucFrame
+	uint32_t nedsz, celsz;
+	uint16_t row, col;
+	uint16_t gaps, read_gaps, ref_gaps;
+	uint8_t  ct, pad;
+	int32_t  score, ns;
+};
+
+struct DPRect { int64_t refl, refr, refl_pretrim, refr_pretrim; uint32_t triml, trimr, corel, corer, maxgap; };
+
+struct Work {
+	// ---- read ----
+	uint32_t len;
+	uint8_t  seq[kMaxLen];     // codes 0..4, 5'->3'
+	uint8_t  qual[kMaxLen];    // ASCII
+	// ---- seed phase ----
+	EEHit    exact[2];         // [0] fw, [1] rc; top==bot => empty
+	EEHit    mm1[kMaxMm1];
+	uint32_t n_mm1;
+	uint64_t mm1_elt;
+	uint32_t num_offs;
+	uint32_t off_idx2off[kMaxOffs];
+	SeedHitRec hits[2][kMaxOffs];      // [0] fw seeds, [1] rc seeds
+	uint8_t  sorted[2][kMaxOffs];
+	uint32_t rank_offs[kMaxRanges];
+	uint8_t  rank_fw[kMaxRanges];
+	uint32_t n_rank;
+	uint32_t nonz_tot, nonz_fw, nonz_rc;
+	uint64_t num_elts;
+	// ---- extension phase ----
+	SatPos   satpos2[kMaxRanges];
+	R1N      rands2[kMaxRanges];
+	uint32_t n_satpos2;
+	SatPos   satpos[kMaxSatpos];
+	uint32_t n_satpos;
+	uint32_t lists[kListArena];
+	uint32_t lists_used;
+	double   masses[kMaxRanges];
+	uint8_t  elim[kMaxRanges];
+	double   mass;
+	uint32_t n_masses;
+	struct ExtRange { uint32_t off, len, sz; } ex_fw[kMaxRanges * 2], ex_rc[kMaxRanges * 2];
+	uint32_t n_ex_fw, n_ex_rc;
+	DiagIval diags[kMaxDiags];
+	uint32_t n_diags;
+	RedAln   red[kMaxAlns];
+	uint32_t n_red;
+	// ---- sink ----
+	AlnRes   alns[kMaxAlns];
+	uint32_t n_alns;
+	int64_t  best_unp1, best2_unp1;
+	uint8_t  done_unpair1;
+	uint8_t  exit_m, exit_k;
+	// ---- DP ----
+	uint8_t  rf[kMaxCols + 8];          // reference masks of the current window
+	BtCand   cands[kMaxCands];
+	uint32_t n_cands, cural;
+	uint16_t btcells[2 * (kMaxLen + 64)];
+	BtFrame  btstack[kMaxLen + kMaxCols];
+	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
+	// ---- status / metrics ----
+	uint32_t err;
+	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail, n_ug_fail, n_ee_fail, n_dp_fail_streak;
+	uint32_t n_redundants, n_bwops_seed, n_bwops_ext, n_bt_attempts;
+};
+
+// DP scratch of one wave: wavefront-major H/E/F matrix + per-cell backtrace masks + row flags
+struct DpScratch {
+	uint8_t*  mat;      // ((t*3+m)*R + r)*64 + lane
+	uint16_t* masks;    // [rows][cols]
+	uint8_t*  row_reset;// [rows]
+};
+
+// ---------------------------------------------------------------------------------------
+// small helpers
+BT2_HD int comp4(int c) { return c < 4 ? 3 - c : 4; }
+BT2_HD int imin(int a, int b) { return a < b ? a : b; }
+BT2_HD int imax(int a, int b) { return a > b ? a : b; }
+BT2_HD int subs0(int a, int b) { const int r = a - b; return r < 0 ? 0 : r; }
+
+BT2_HD int mm_penalty(const AlignParams& P, int q) {
+	if (P.mm_type == 3) {     // COST_MODEL_QUAL (scoring.h:106-114)
+		const int qq = q < 40 ? q : 40;
+		const float frac = (float)qq / 40.0f;
+		return P.mm_min + (int)(frac * (float)(P.mm_max - P.mm_min));
+	}
+	return P.mm_max;
+}
+
+// Scoring::score(rdc, refmask, q) (scoring.h:241)
+BT2_HD int sc_score(const AlignParams& P, int rdc, int refm, int q) {
+	if (q < 0) q = 0;
+	if (q > 255) q = 255;
+	if (rdc > 3 || refm > 15) return -P.n_pen;
+	if (refm & (1 << rdc)) return P.match_bonus;
+	return -mm_penalty(P, q);
+}
+// Scoring::mm(rdc, refm, q) (scoring.h:231)
+BT2_HD int sc_mm(const AlignParams& P, int rdc, int refm, int q) {
+	if (q < 0) q = 0;
+	if (q > 255) q = 255;
+	return (rdc > 3 || refm > 15) ? P.n_pen : mm_penalty(P, q);
+}
+
+// Scoring::maxReadGaps / maxRefGaps (scoring.cpp:42,73), monotone (match bonus 0 in e2e)
+BT2_HD int max_read_gaps(const AlignParams& P, int64_t minsc, uint32_t rdlen) {
+	int64_t sc = (int64_t)rdlen * P.match_bonus;
+	bool first = true;
+	int num = 0;
+	while (sc >= minsc) {
+		if (first) { first = false; sc -= P.rdgapo; } else sc -= P.rdgape;
+		num++;
+	}
+	return num - 1;
+}
+BT2_HD int max_ref_gaps(const AlignParams& P, int64_t minsc, uint32_t rdlen) {
+	int64_t sc = (int64_t)rdlen * P.match_bonus;
+	bool first = true;
+	int num = 0;
+	while (sc >= minsc) {
+		sc -= P.match_bonus;
+		if (first) { first = false; sc -= P.rfgapo; } else sc -= P.rfgape;
+		num++;
+	}
+	return num - 1;
+}
+
+// read accessors: patFw / patRc / qual / qualRev (read.h:73-128)
+BT2_HD int rd_char(const Work& w, bool fw, uint32_t i) { return fw ? w.seq[i] : comp4(w.seq[w.len - 1 - i]); }
+BT2_HD int rd_qual(const Work& w, bool fw, uint32_t i) { return fw ? w.qual[i] : w.qual[w.len - 1 - i]; }
+
+// DP scratch addressing (wavefront-major, see bt2g_kernels.hip)
+BT2_HD uint32_t dp_R(uint32_t rows) { return (rows + 63) / 64; }
+BT2_HD uint64_t dp_cell(uint32_t R, uint32_t m, uint32_t i, uint32_t j) {
+	const uint32_t l = i / R, r = i % R;
+	const uint64_t t = (uint64_t)j + l;
+	return ((t * 3 + m) * R + r) * 64 + l;
+}
+
+} // namespace bt2g
+#endif

@@ -1,0 +1,1454 @@
+// bt2g_align_core.hpp -- per-read worker logic (see bt2g_align.hpp for the execution model).
+//
+// `Plat` supplies the wave-parallel pieces:
+//    int  Plat::dp_fill_ee_u8(P, w, fw, rows, cols, scratch)  -> best last-row H (u8 encoded)
+//    void Plat::zero_u16(ptr, n) / sync()
+// Everything else is wave-uniform scalar code.
+#ifndef BT2G_ALIGN_CORE_HPP_
+#define BT2G_ALIGN_CORE_HPP_
+
+#include "bt2g_align.hpp"
+
+namespace bt2g {
+
+template <typename TOff, typename Plat>
+struct Aligner {
+	const DevIndex<TOff>& ix;
+	const AlignParams& P;
+	const ReadParams& rp;
+	Work& w;
+	DpScratch dp;
+	Rng rnd;
+	int64_t minsc;       // current (possibly tightened) minimum score
+	static constexpr TOff kOffMask = (TOff)OffTraits<TOff>::kMask;
+
+	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, const ReadParams& rp_, Work& w_, DpScratch dp_)
+		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_) {}
+
+	// =================================================================================
+	// A. end-to-end exact / 1-mismatch search and exact seeds
+	// =================================================================================
+
+	// One (top,bot) LF step as exactSweepMapLF does (aligner_seed.cpp:793-824)
+	BT2_HD void pair_lf(const DevEbwt<TOff>& e, int c, TOff& top, TOff& bot, uint32_t& bwops) {
+		if (c > 3) { top = bot = 0; return; }
+		if (bot - top > 1) {
+			bwops += 2;
+			TOff nt, nb;
+			rank1_pair(e, top, bot, c, nt, nb);
+			top = nt; bot = nb;
+		} else {
+			bwops++;
+			const TOff t = map_lf1c(e, top, c);
+			if (t == kOffMask) { top = bot = 0; } else { top = t; bot = t + 1; }
+		}
+	}
+
+	// SeedAligner::exactSweep (aligner_seed.cpp:856-970); returns nelt
+	BT2_HD uint64_t exact_sweep(uint32_t mine_max, uint32_t mine[2]) {
+		const DevEbwt<TOff>& e = ix.fw;
+		const uint32_t len = w.len, ftab_len = e.ftab_chars;
+		uint64_t nelt = 0;
+		w.exact[0].top = w.exact[0].bot = 0;
+		w.exact[1].top = w.exact[1].bot = 0;
+		mine[0] = mine[1] = 0;
+		for (int fwi = 0; fwi < 2; fwi++) {
+			const bool fw = fwi == 0;
+			if ((fw && P.nofw) || (!fw && P.norc)) continue;
+			uint32_t dep = 0, nedit = 0;
+			bool done = false, do_init = true;
+			TOff top = 0, bot = 0;
+			while (dep < len && !done) {
+				if (do_init) {
+					top = bot = 0;
+					const uint32_t left = len - dep;
+					bool do_ftab = ftab_len > 1 && left >= ftab_len;
+					uint64_t key = 0;
+					if (do_ftab) {
+						for (uint32_t i = 0; i < ftab_len; i++) {
+							const int c = rd_char(w, fw, left - ftab_len + i);
+							if (c > 3) { do_ftab = false; break; }
+							key = (key << 2) | (uint64_t)c;
+						}
+					}
+					if (do_ftab) {
+						top = ftab_hi(e, key);
+						bot = ftab_lo(e, key + 1);
+						dep += ftab_len;
+					} else {
+						const int c = rd_char(w, fw, len - dep - 1);
+						if (c < 4) { top = e.fchr[c]; bot = e.fchr[c + 1]; }
+						dep++;
+					}
+					if (bot <= top) {
+						nedit++;
+						if (nedit >= mine_max) { mine[fwi] = nedit; done = true; }
+						continue;
+					}
+					do_init = false;
+				}
+				if (dep < len) {
+					pair_lf(e, rd_char(w, fw, len - dep - 1), top, bot, w.n_bwops_seed);
+					if (bot <= top) {
+						nedit++;
+						if (nedit >= mine_max) { mine[fwi] = nedit; done = true; }
+						do_init = true;
+					}
+					dep++;
+				}
+			}
+			if (!done) {
+				mine[fwi] = nedit;
+				if (nedit == 0 && bot > top) {
+					EEHit& h = w.exact[fwi];
+					h.top = top; h.bot = bot; h.fw = fw ? 1 : 0; h.has_edit = 0;
+					h.score = (int32_t)((int64_t)len * P.match_bonus);
+					nelt += (uint64_t)(bot - top);
+				}
+			}
+		}
+		return nelt;
+	}
+
+	// mapBiLFEx (bt2_idx.h:2372): t/b for all chars in `e`, tp/bp prefix sums starting at topp
+	BT2_HD void bi_lf(const DevEbwt<TOff>& e, TOff top, TOff bot, TOff topp, TOff t[4], TOff b[4], TOff tp[4], TOff bp[4]) {
+		rank4_pair(e, top, bot, t, b);
+		tp[0] = topp;
+		bp[0] = tp[0] + (b[0] - t[0]);
+		tp[1] = bp[0]; bp[1] = tp[1] + (b[1] - t[1]);
+		tp[2] = bp[1]; bp[2] = tp[2] + (b[2] - t[2]);
+		tp[3] = bp[2]; bp[3] = tp[3] + (b[3] - t[3]);
+	}
+
+	// seq / qual views used by oneMmSearch (aligner_seed.cpp:1031-1040)
+	BT2_HD int mm1_seq(bool fw, bool ebwtfw, uint32_t i) const {
+		// fw: patFw | patFwRev ; rc: patRc | patRcRev
+		if (fw) return ebwtfw ? w.seq[i] : w.seq[w.len - 1 - i];
+		return ebwtfw ? comp4(w.seq[w.len - 1 - i]) : comp4(w.seq[i]);
+	}
+	BT2_HD int mm1_qual(bool fw, bool ebwtfw, uint32_t i) const {
+		// fw: qual | qualRev ; rc: qualRev | qual
+		const bool rev = fw ? !ebwtfw : ebwtfw;
+		return rev ? w.qual[w.len - 1 - i] : w.qual[i];
+	}
+
+	// SeedAligner::oneMmSearch with repex=false, rep1mm=true (aligner_seed.cpp:975-1325)
+	BT2_HD void one_mm_search(bool nofw, bool norc) {
+		const uint32_t len = w.len;
+		const int nceil = rp.nceil;    // sc.nCeil.f<int>(len); equal to the clamped value unless > len
+		w.n_mm1 = 0; w.mm1_elt = 0;
+		uint32_t ns = 0;
+		for (uint32_t i = 0; i < len; i++) if (w.seq[i] > 3) ns++;
+		if (ns > 1) return;
+		const uint32_t halfFw = len >> 1;
+		const uint32_t halfBw = (len >> 1) + ((len & 1) ? 1 : 0);
+		TOff t[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, tp[4] = {0, 0, 0, 0}, bp[4] = {0, 0, 0, 0};
+		for (int fwi = 0; fwi < 2; fwi++) {
+			const bool fw = fwi == 0;
+			if ((fw && nofw) || (!fw && norc)) continue;
+			for (int ebwtfwi = 0; ebwtfwi < 2; ebwtfwi++) {
+				const bool ebwtfw = ebwtfwi == 0;
+				const DevEbwt<TOff>& e = ebwtfw ? ix.fw : ix.bw;
+				const DevEbwt<TOff>& ep = ebwtfw ? ix.bw : ix.fw;
+				const uint32_t ftab_len = e.ftab_chars;
+				const uint32_t nea = ebwtfw ? halfFw : halfBw;
+				bool skip = false;
+				for (uint32_t dep = 0; dep < nea; dep++) if (mm1_seq(fw, ebwtfw, len - dep - 1) > 3) { skip = true; break; }
+				if (skip) continue;
+				uint32_t dep = 0;
+				TOff top = 0, bot = 0, topp = 0, botp = 0;
+				if (ftab_len > 1 && ftab_len <= nea) {
+					// both lookups read the window seq[len-ftab, len): text order in `e`, reversed in `ep`
+					uint64_t kt = 0, kr = 0;
+					for (uint32_t i = 0; i < ftab_len; i++) {
+						kt = (kt << 2) | (uint64_t)mm1_seq(fw, ebwtfw, len - ftab_len + i);
+						kr = (kr << 2) | (uint64_t)mm1_seq(fw, ebwtfw, len - 1 - i);
+					}
+					top = ftab_hi(e, kt); bot = ftab_lo(e, kt + 1);
+					topp = ftab_hi(ep, kr); botp = ftab_lo(ep, kr + 1);
+					if (bot - top == 0) continue;
+					dep = ftab_len;
+				} else {
+					const int c = mm1_seq(fw, ebwtfw, len - 1);
+					top = topp = e.fchr[c];
+					bot = botp = e.fchr[c + 1];
+					if (bot - top == 0) continue;
+					dep = 1;
+				}
+				bool do_continue = false;
+				for (; dep < nea; dep++) {
+					const int rdc = mm1_seq(fw, ebwtfw, len - dep - 1);
+					if (bot - top > 1) {
+						w.n_bwops_seed++;
+						bi_lf(e, top, bot, topp, t, b, tp, bp);
+						top = t[rdc]; bot = b[rdc];
+						if (bot <= top) { do_continue = true; break; }
+						topp = tp[rdc]; botp = bp[rdc];
+					} else {
+						w.n_bwops_seed++;
+						top = map_lf1c(e, top, rdc);
+						if (top == kOffMask) { do_continue = true; break; }
+						bot = top + 1;
+					}
+				}
+				if (do_continue) continue;
+				for (; dep < len; dep++) {
+					const int rdc = mm1_seq(fw, ebwtfw, len - dep - 1);
+					const int quc = mm1_qual(fw, ebwtfw, len - dep - 1);
+					if (rdc > 3 && nceil == 0) break;
+					int clo = 0, chi = 3;
+					bool match = true;
+					if (bot - top > 1) {
+						w.n_bwops_seed++;
+						bi_lf(e, top, bot, topp, t, b, tp, bp);
+						match = rdc < 4;
+						if (match) { top = t[rdc]; bot = b[rdc]; topp = tp[rdc]; botp = bp[rdc]; }
+						else { top = bot = 0; }
+					} else {
+						w.n_bwops_seed++;
+						TOff row = top;
+						clo = map_lf1(e, row);
+						match = (clo == rdc);
+						if (clo < 0) break;
+						top = row;
+						t[clo] = top; b[clo] = bot = top + 1;
+						bp[clo] = botp; tp[clo] = topp;
+						chi = clo;
+					}
+					if (ns == 0 || rdc > 3) {
+						for (int j = clo; j <= chi; j++) {
+							if (j == rdc || b[j] == t[j]) continue;
+							uint32_t depm = dep + 1;
+							TOff topm = t[j], botm = b[j], topmp = tp[j], botmp = bp[j];
+							TOff tm[4], bm[4], tmp[4], bmp[4];
+							for (; depm < len; depm++) {
+								const int rdcm = mm1_seq(fw, ebwtfw, len - depm - 1);
+								if (botm - topm > 1) {
+									w.n_bwops_seed++;
+									bi_lf(e, topm, botm, topmp, tm, bm, tmp, bmp);
+									if (rdcm > 3) { topm = botm = 0; break; }
+									topm = tm[rdcm]; botm = bm[rdcm];
+									topmp = tmp[rdcm]; botmp = bmp[rdcm];
+									if (botm <= topm) break;
+								} else {
+									w.n_bwops_seed++;
+									topm = map_lf1c(e, topm, rdcm);
+									if (topm == kOffMask) break;
+									botm = topm + 1;
+								}
+							}
+							if (depm == len) {
+								uint32_t off5p = dep;
+								if (fw == ebwtfw) off5p = len - off5p - 1;
+								int64_t score = (int64_t)(len - 1) * P.match_bonus;
+								score += sc_score(P, rdc, 1 << j, quc - 33);
+								if (score >= rp.minsc) {
+									if (w.n_mm1 >= (uint32_t)kMaxMm1) { w.err |= ERR_OVERFLOW; }
+									else {
+										EEHit& h = w.mm1[w.n_mm1++];
+										h.top = ebwtfw ? topm : topmp;
+										h.bot = ebwtfw ? botm : botmp;
+										h.score = (int32_t)score;
+										h.epos = (uint16_t)off5p; h.echr = (uint8_t)j; h.eqchr = (uint8_t)rdc;
+										h.fw = fw ? 1 : 0; h.has_edit = 1;
+										w.mm1_elt += (uint64_t)(h.bot - h.top);
+									}
+								}
+							}
+						}
+					}
+					if (bot > top && match) {
+						if (dep == len - 1) break;   // exact hit; not reported here (repex=false)
+					} else {
+						break;
+					}
+				}
+			}
+		}
+	}
+
+	// One -N 0 seeding round: Seed::mmSeeds + instantiateSeeds + searchAllSeeds
+	// (aligner_seed.cpp:498-720,1638-2037).  Returns # instantiated seeds.
+	BT2_HD uint32_t seed_round(uint32_t offset, uint32_t interval, uint32_t seedlen) {
+		const uint32_t len = w.len;
+		uint32_t L = seedlen < len ? seedlen : len;
+		uint32_t nseeds = 1;
+		if ((int64_t)len - (int64_t)offset > (int64_t)seedlen) nseeds += (len - offset - seedlen) / interval;
+		if (nseeds > (uint32_t)kMaxOffs) { w.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
+		w.num_offs = nseeds;
+		w.nonz_tot = w.nonz_fw = w.nonz_rc = 0; w.num_elts = 0;
+		w.n_rank = 0;
+		uint32_t ninst = 0;
+		for (uint32_t i = 0; i < nseeds; i++) w.off_idx2off[i] = interval * i + offset;
+		const uint32_t fc = ix.fw.ftab_chars;
+		for (int fwi = 0; fwi < 2; fwi++) {
+			const bool fw = fwi == 0;
+			for (uint32_t i = 0; i < nseeds; i++) {
+				SeedHitRec& h = w.hits[fwi][i];
+				h.topf = h.botf = h.topb = h.botb = 0;
+				w.sorted[fwi][i] = 0;
+			}
+			if ((fw && P.nofw) || (!fw && P.norc)) continue;
+			for (uint32_t i = 0; i < nseeds; i++) {
+				const uint32_t depth = i * interval + offset;
+				// seed char k as it aligns to the Watson strand (instantiateSeq :463-485)
+				auto getc = [&](uint32_t k) -> int { return fw ? (int)w.seq[depth + k] : comp4(w.seq[depth + L - 1 - k]); };
+				bool ok = true;
+				for (uint32_t k = 0; k < L; k++) if (getc(k) > 3) { ok = false; break; }
+				if (!ok) continue;      // Seed::instantiate fails: exact zones cannot absorb an N
+				ninst++;
+				TOff topf = 0, botf = 0, topb = 0, botb = 0;
+				uint32_t step = 0;
+				if (fc > 1 && fc <= L) {
+					uint64_t kf = 0, kb = 0;
+					for (uint32_t k = 0; k < fc; k++) {
+						kf = (kf << 2) | (uint64_t)getc(L - fc + k);
+						kb = (kb << 2) | (uint64_t)getc(L - 1 - k);
+					}
+					topf = ftab_hi(ix.fw, kf); botf = ftab_lo(ix.fw, kf + 1);
+					if (botf <= topf) continue;
+					topb = ftab_hi(ix.bw, kb); botb = topb + (botf - topf);
+					step = fc;
+				} else {
+					const int c = getc(L - 1);
+					topf = topb = ix.fw.fchr[c];
+					botf = botb = ix.fw.fchr[c + 1];
+					if (botf <= topf) continue;
+					step = 1;
+				}
+				for (; ok && step < L; step++) {
+					const int c = getc(L - step - 1);
+					if (botf - topf > 1) {
+						TOff t[4], b[4];
+						w.n_bwops_seed++;
+						rank4_pair(ix.fw, topf, botf, t, b);
+						TOff tp = topb;
+						for (int j = 0; j < c; j++) tp += b[j] - t[j];
+						if (b[c] == t[c]) { ok = false; break; }
+						topf = t[c]; botf = b[c]; topb = tp; botb = tp + (b[c] - t[c]);
+					} else {
+						w.n_bwops_seed++;
+						const TOff t = map_lf1c(ix.fw, topf, c);
+						if (t == kOffMask) { ok = false; break; }
+						topf = t; botf = t + 1;
+					}
+				}
+				if (!ok) continue;
+				SeedHitRec& h = w.hits[fwi][i];
+				h.topf = topf; h.botf = botf; h.topb = topb; h.botb = botb;
+				// SeedResults::add (aligner_seed.h:639-676)
+				w.nonz_tot++;
+				if (fw) w.nonz_fw++; else w.nonz_rc++;
+				w.num_elts += (uint64_t)(botf - topf);
+			}
+		}
+		return ninst;
+	}
+
+	BT2_HD uint64_t hit_elts(int fwi, uint32_t i) const { return w.hits[fwi][i].botf - w.hits[fwi][i].topf; }
+
+	// SeedResults::rankSeedHits, all=false (aligner_seed.h:1019-1080)
+	BT2_HD void rank_seed_hits() {
+		w.n_rank = 0;
+		while (w.n_rank < w.nonz_tot) {
+			uint64_t minsz = 0xffffffffull;      // MAX_U32 even for large indexes, as in the reference
+			uint32_t minidx = 0;
+			bool minfw = true;
+			const bool rb = rnd.nextBool();
+			for (int fwi = 0; fwi <= 1; fwi++) {
+				const bool fw = (fwi == (rb ? 1 : 0));
+				const int s = fw ? 0 : 1;
+				uint32_t i = rnd.nextU32() % w.num_offs;
+				for (uint32_t ii = 0; ii < w.num_offs; ii++) {
+					const uint64_t ne = hit_elts(s, i);
+					if (ne > 0 && !w.sorted[s][i] && (TOff)ne < (TOff)minsz) {
+						minsz = ne; minidx = i; minfw = fw;
+					}
+					if ((++i) == w.num_offs) i = 0;
+				}
+			}
+			w.sorted[minfw ? 0 : 1][minidx] = 1;
+			w.rank_offs[w.n_rank] = minidx;
+			w.rank_fw[w.n_rank] = minfw ? 1 : 0;
+			w.n_rank++;
+		}
+	}
+
+	// =================================================================================
+	// B. Random1toN / RowSampler
+	// =================================================================================
+	BT2_HD void r1n_init(R1N& r, uint32_t n, bool without_replacement) {
+		r.sz = r.n = n;
+		r.converted = 0;
+		r.swaplist = (n < 128 || without_replacement) ? 1 : 0;
+		r.cur = 0;
+		r.list_off = r.list_len = r.seen_off = r.seen_len = 0;
+		uint32_t th = (uint32_t)(0.10f * (float)n);
+		r.thresh = th > 16 ? th : 16;
+		r.inited = 1;
+	}
+	BT2_HD void r1n_reset(R1N& r) { r.sz = r.n = r.cur = 0; r.swaplist = r.converted = 0; r.list_len = r.seen_len = 0; r.thresh = 0; r.inited = 0; }
+	BT2_HD bool r1n_done(const R1N& r) const { return r.n > 0 && r.cur >= r.n; }
+	BT2_HD uint32_t lists_alloc(uint32_t n) {
+		if (w.lists_used + n > (uint32_t)kListArena) { w.err |= ERR_OVERFLOW; return 0; }
+		const uint32_t o = w.lists_used;
+		w.lists_used += n;
+		return o;
+	}
+	BT2_HD uint32_t r1n_next(R1N& r) {
+		if (r.cur == 0 && !r.converted) {
+			if (r.n == 1) { r.cur = 1; return 0; }
+			if (r.swaplist) {
+				r.list_off = lists_alloc(r.n);
+				r.list_len = r.n;
+				for (uint32_t i = 0; i < r.n; i++) w.lists[r.list_off + i] = i;
+			}
+		}
+		if (r.swaplist) {
+			const uint32_t rr = r.cur + (rnd.nextU32() % (r.n - r.cur));
+			uint32_t* l = w.lists + r.list_off;
+			if (rr != r.cur) { const uint32_t tmp = l[r.cur]; l[r.cur] = l[rr]; l[rr] = tmp; }
+			return l[r.cur++];
+		}
+		// seen-list mode (n >= 128)
+		if (r.seen_len == 0 && r.cur == 0) { r.seen_off = lists_alloc(r.thresh + 1); }
+		uint32_t* seen = w.lists + r.seen_off;
+		const uint32_t seen_sz = r.seen_len;
+		uint32_t rn = 0;
+		bool again = true;
+		while (again) {
+			rn = rnd.nextU32() % r.n;
+			again = false;
+			for (uint32_t i = 0; i < seen_sz; i++) if (seen[i] == rn) { again = true; break; }
+		}
+		seen[r.seen_len++] = rn;
+		r.cur++;
+		if (r.seen_len >= r.thresh && r.cur < r.n) {
+			// convert to a swap list of everything not yet seen
+			for (uint32_t i = 1; i < r.seen_len; i++) {       // sort seen ascending
+				const uint32_t v = seen[i];
+				uint32_t j = i;
+				while (j > 0 && seen[j - 1] > v) { seen[j] = seen[j - 1]; j--; }
+				seen[j] = v;
+			}
+			const uint32_t nl = r.n - r.cur;
+			r.list_off = lists_alloc(nl);
+			r.list_len = nl;
+			uint32_t* l = w.lists + r.list_off;
+			uint32_t prev = 0, cur = 0;
+			for (uint32_t i = 0; i <= seen_sz; i++) {
+				for (uint32_t j = prev; j < seen[i]; j++) l[cur++] = j;
+				prev = seen[i] + 1;
+			}
+			for (uint32_t j = prev; j < r.n; j++) l[cur++] = j;
+			r.seen_len = 0;
+			r.cur = 0;
+			r.n = nl;
+			r.converted = 1;
+			r.swaplist = 1;
+		}
+		return rn;
+	}
+
+	// =================================================================================
+	// C. seed-hit extension bookkeeping
+	// =================================================================================
+	// SwDriver::extend (aligner_sw_driver.cpp:299-484)
+	BT2_HD void extend_hit(TOff topf, TOff botf, TOff topb, TOff botb, bool fw, uint32_t off, uint32_t len,
+	                       uint32_t& nlex, uint32_t& nrex) {
+		const uint32_t rdlen = w.len;
+		TOff t[4], b[4], tp[4], bp[4];
+		nlex = nrex = 0;
+		uint32_t lim = fw ? off : rdlen - len - off;
+		if (lim > 0) {
+			const DevEbwt<TOff>& e = ix.fw;
+			TOff top = topf, bot = botf;
+			for (uint32_t ii = 0; ii < lim; ii++) {
+				const uint32_t i = fw ? off - ii - 1 : rdlen - off - len - 1 - ii;
+				const int rdc = rd_char(w, fw, i);
+				if (bot - top > 1) {
+					w.n_bwops_ext++;
+					bi_lf(e, top, bot, topb, t, b, tp, bp);
+					int nonz = -1;
+					bool abort = false;
+					const TOff orig = bot - top;
+					for (int j = 0; j < 4; j++) {
+						if (b[j] > t[j]) {
+							if (nonz >= 0) { abort = true; break; }
+							nonz = j; top = t[j]; bot = b[j];
+						}
+					}
+					if (abort || (nonz != rdc && rdc <= 3) || bot - top < orig) break;
+				} else {
+					w.n_bwops_ext++;
+					TOff row = top;
+					const int c = map_lf1(e, row);
+					top = row;
+					if (c != rdc && rdc <= 3) break;
+					bot = top + 1;
+				}
+				if (++nlex == 255) break;
+			}
+		}
+		lim = fw ? rdlen - len - off : off;
+		if (lim > 0) {
+			const DevEbwt<TOff>& e = ix.bw;
+			TOff top = topb, bot = botb;
+			for (uint32_t ii = 0; ii < lim; ii++) {
+				const uint32_t i = fw ? ii + len + off : rdlen - off + ii;
+				const int rdc = rd_char(w, fw, i);
+				if (bot - top > 1) {
+					w.n_bwops_ext++;
+					bi_lf(e, top, bot, topf, t, b, tp, bp);
+					int nonz = -1;
+					bool abort = false;
+					const TOff orig = bot - top;
+					for (int j = 0; j < 4; j++) {
+						if (b[j] > t[j]) {
+							if (nonz >= 0) { abort = true; break; }
+							nonz = j; top = t[j]; bot = b[j];
+						}
+					}
+					if (abort || (nonz != rdc && rdc <= 3) || bot - top < orig) break;
+				} else {
+					w.n_bwops_ext++;
+					TOff row = top;
+					const int c = map_lf1(e, row);
+					top = row;
+					if (c != rdc && rdc <= 3) break;
+					bot = top + 1;
+				}
+				if (++nrex == 255) break;
+			}
+		}
+	}
+
+	// SATupleAndPos::operator< (aligner_sw_driver.h:150-160)
+	BT2_HD static bool satpos_less(const SatPos& a, const SatPos& o) {
+		if (a.size < o.size) return true;
+		if (a.size > o.size) return false;
+		if (a.topf < o.topf) return true;
+		if (a.topf > o.topf) return false;
+		if (a.offidx < o.offidx) return true;
+		if (a.offidx > o.offidx) return false;
+		if (a.rdoff < o.rdoff) return true;
+		if (a.rdoff > o.rdoff) return false;
+		if (a.seedlen < o.seedlen) return true;
+		if (a.seedlen > o.seedlen) return false;
+		if (a.fw && !o.fw) return true;
+		return false;
+	}
+
+	// SwDriver::eeSaTups (aligner_sw_driver.cpp:66-291)
+	BT2_HD void ee_sa_tups(uint64_t& nelt_out, uint64_t maxelt) {
+		w.n_satpos = 0;
+		w.lists_used = 0;
+		nelt_out = 0;
+		const uint64_t szfw = w.exact[0].bot - w.exact[0].top, szrc = w.exact[1].bot - w.exact[1].top;
+		const uint64_t tot = szfw + szrc;
+		bool done = false;
+		auto add = [&](const EEHit& hit, int ee_idx, uint64_t top, uint64_t width) {
+			if (w.n_satpos >= (uint32_t)kMaxSatpos) { w.err |= ERR_OVERFLOW; done = true; return; }
+			SatPos& s = w.satpos[w.n_satpos++];
+			s.topf = top; s.topb = (uint64_t)kOffMask; s.size = (uint32_t)width; s.orig_sz = (uint32_t)width;
+			s.fw = hit.fw; s.offidx = 0; s.rdoff = 0; s.seedlen = w.len; s.nlex = s.nrex = 0;
+			s.ee = ee_idx;
+			r1n_init(s.rnd, (uint32_t)width, false);
+			nelt_out += width;
+			if (nelt_out >= maxelt) done = true;
+		};
+		auto add_trimmed = [&](const EEHit& hit, int ee_idx) {
+			uint64_t tops[2] = {hit.top, 0}, bots[2] = {hit.bot, 0};
+			const uint64_t width = hit.bot - hit.top;
+			if (nelt_out + width > maxelt) {
+				const uint64_t trim = (nelt_out + width) - maxelt;
+				const uint64_t rn = (P.large_index ? rnd.nextU64() : (uint64_t)rnd.nextU32()) % width;
+				const uint64_t newwidth = width - trim;
+				if (hit.top + rn + newwidth > hit.bot) {
+					tops[0] = hit.top + rn; bots[0] = hit.bot;
+					tops[1] = hit.top; bots[1] = hit.top + newwidth - (bots[0] - tops[0]);
+				} else {
+					tops[0] = hit.top + rn; bots[0] = tops[0] + newwidth;
+				}
+			}
+			for (int i = 0; i < 2 && !done; i++) {
+				if (bots[i] <= tops[i]) break;
+				add(hit, ee_idx, tops[i], bots[i] - tops[i]);
+			}
+		};
+		if (tot > 0) {
+			bool fw_first = true;
+			const uint64_t rn = (P.large_index ? rnd.nextU64() : (uint64_t)rnd.nextU32()) % tot;
+			if (rn >= szfw) fw_first = false;
+			for (int fwi = 0; fwi < 2 && !done; fwi++) {
+				const bool fw = ((fwi == 0) == fw_first);
+				const EEHit& hit = w.exact[fw ? 0 : 1];
+				if (hit.bot <= hit.top) continue;
+				add_trimmed(hit, fw ? -2 : -3);     // -2/-3: exact fw / rc hit
+			}
+		}
+		if (!done && w.n_mm1 > 0) {
+			// sort1mmEe: stable sort by score descending, then shuffle equal-score streaks (aligner_seed.h:1223)
+			for (uint32_t i = 1; i < w.n_mm1; i++) {
+				const EEHit v = w.mm1[i];
+				uint32_t j = i;
+				while (j > 0 && w.mm1[j - 1].score < v.score) { w.mm1[j] = w.mm1[j - 1]; j--; }
+				w.mm1[j] = v;
+			}
+			auto shuffle = [&](uint32_t begin, uint32_t num) {
+				if (num < 2) return;
+				uint32_t left = num;
+				for (uint32_t i = begin; i < begin + num - 1; i++) {
+					const uint64_t rndi = rnd.nextU64() % left;
+					if (rndi > 0) { const EEHit tmp = w.mm1[i]; w.mm1[i] = w.mm1[i + rndi]; w.mm1[i + rndi] = tmp; }
+					left--;
+				}
+			};
+			uint32_t streak = 0;
+			for (uint32_t i = 1; i < w.n_mm1; i++) {
+				if (w.mm1[i].score == w.mm1[i - 1].score) {
+					if (streak == 0) streak = 1;
+					streak++;
+				} else {
+					if (streak > 1) shuffle(i - streak, streak);
+					streak = 0;
+				}
+			}
+			if (streak > 1) shuffle(w.n_mm1 - streak, streak);
+			for (uint32_t i = 0; i < w.n_mm1 && !done; i++) add_trimmed(w.mm1[i], (int)i);
+		}
+	}
+
+	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? w.exact[0] : (idx == -3 ? w.exact[1] : w.mm1[idx]); }
+
+	// SwDriver::prioritizeSATupsRands (aligner_sw_driver.cpp:492-738)
+	BT2_HD void prioritize(int seedmms, uint64_t maxelt, uint64_t& nelt_out) {
+		const uint32_t nsm = 5;
+		w.n_satpos = 0; w.n_satpos2 = 0; w.lists_used = 0;
+		uint64_t nrange = 0, nelt = 0, nsmall = 0, nsmall_elts = 0;
+		for (uint32_t i = 0; i < w.n_rank; i++) {
+			const bool fw = w.rank_fw[i] != 0;
+			const uint32_t offidx = w.rank_offs[i];
+			const uint32_t rdoff = w.off_idx2off[offidx];
+			const uint32_t seedlen = rp.seedlen < (int32_t)w.len ? (uint32_t)rp.seedlen : w.len;
+			const SeedHitRec& h = w.hits[fw ? 0 : 1][offidx];
+			const uint64_t sz = h.botf - h.topf;
+			nrange++; nelt += sz;
+			if (seedmms == 0) {
+				const Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
+				const uint32_t nr = fw ? w.n_ex_fw : w.n_ex_rc;
+				bool skip = false;
+				for (uint32_t k = 0; k < nr; k++) {
+					if (range[k].off <= rdoff && range[k].off + range[k].len >= rdoff + seedlen) {
+						if (sz <= range[k].sz) { skip = true; break; }
+					}
+				}
+				if (skip) { nrange--; nelt -= sz; continue; }
+			}
+			if (w.n_satpos2 >= (uint32_t)kMaxRanges) { w.err |= ERR_OVERFLOW; break; }
+			SatPos& s = w.satpos2[w.n_satpos2++];
+			s.topf = h.topf; s.topb = h.topb; s.size = (uint32_t)sz; s.orig_sz = (uint32_t)sz;
+			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
+			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
+			uint32_t nlex = 0, nrex = 0;
+			if (P.do_extend) extend_hit((TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, seedlen, nlex, nrex);
+			s.nlex = nlex; s.nrex = nrex;
+			if (seedmms == 0 && (nlex > 0 || nrex > 0)) {
+				Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
+				uint32_t& nr = fw ? w.n_ex_fw : w.n_ex_rc;
+				if (nr < (uint32_t)(kMaxRanges * 2)) {
+					range[nr].off = rdoff - (fw ? nlex : nrex);
+					range[nr].len = seedlen + nlex + nrex;
+					range[nr].sz = (uint32_t)sz;
+					nr++;
+				} else w.err |= ERR_OVERFLOW;
+			}
+		}
+		nelt_out = nelt;
+		// satpos.sort()
+		for (uint32_t i = 1; i < w.n_satpos2; i++) {
+			const SatPos v = w.satpos2[i];
+			uint32_t j = i;
+			while (j > 0 && satpos_less(v, w.satpos2[j - 1])) { w.satpos2[j] = w.satpos2[j - 1]; j--; }
+			w.satpos2[j] = v;
+		}
+		uint64_t nelt_added = 0;
+		// 1. the smalls, whole
+		for (uint64_t j = 0; j < nsmall && nelt_added < maxelt; j++) {
+			if (w.n_satpos >= (uint32_t)kMaxSatpos) { w.err |= ERR_OVERFLOW; break; }
+			SatPos& s = w.satpos[w.n_satpos++];
+			s = w.satpos2[j];
+			r1n_init(s.rnd, s.size, false);
+			nelt_added += s.size;
+		}
+		if (nelt_added >= maxelt || nsmall == w.n_satpos2) { nelt_out = nelt_added; return; }
+		// 2. the non-smalls: RowSampler::init(satpos2_, nsmall, size, lensq=true, szsq=true)
+		const uint32_t sai = (uint32_t)nsmall, saf = w.n_satpos2;
+		w.n_masses = saf - sai;
+		w.mass = 0.0;
+		for (uint32_t i = sai; i < saf; i++) {
+			const uint32_t ln = w.satpos2[i].nlex + w.satpos2[i].nrex + 1;
+			double num = (double)ln; num *= num;
+			double denom = (double)w.satpos2[i].size; denom *= denom;
+			w.masses[i - sai] = num / denom;
+			w.elim[i - sai] = 0;
+			w.mass += w.masses[i - sai];
+		}
+		for (uint32_t j = 0; j < w.n_satpos2; j++) r1n_reset(w.rands2[j]);
+		while (nelt_added < maxelt && nelt_added < nelt) {
+			// RowSampler::next
+			const double rd = (double)(rnd.nextFloat() * w.mass);
+			double mass_sofar = 0.0;
+			uint32_t pick = 0xffffffffu, last_unelim = 0xffffffffu;
+			for (uint32_t i = 0; i < w.n_masses; i++) {
+				if (!w.elim[i]) {
+					last_unelim = i;
+					mass_sofar += w.masses[i];
+					if (rd < mass_sofar) { pick = i; break; }
+				}
+			}
+			if (pick == 0xffffffffu) pick = last_unelim;
+			const uint32_t ri = pick + sai;
+			R1N& r2 = w.rands2[ri];
+			if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, false);
+			const uint32_t r = r1n_next(r2);
+			if (r1n_done(r2)) { w.elim[ri - sai] = 1; w.mass -= w.masses[ri - sai]; }
+			if (w.n_satpos >= (uint32_t)kMaxSatpos) { w.err |= ERR_OVERFLOW; break; }
+			SatPos& s = w.satpos[w.n_satpos++];
+			s = w.satpos2[ri];
+			s.topf = w.satpos2[ri].topf + r;
+			s.topb = (uint64_t)kOffMask;
+			s.size = 1;
+			r1n_init(s.rnd, 1, false);
+			nelt_added++;
+		}
+		nelt_out = nelt_added;
+	}
+
+	// seenDiags1_: plain union-of-intervals semantics (EIvalMergeListBinned, ival_list.h:210)
+	BT2_HD bool diag_present(int32_t ref, int64_t off, bool fw) const {
+		const int orient = fw ? 1 : 0;
+		for (uint32_t i = 0; i < w.n_diags; i++) {
+			const DiagIval& d = w.diags[i];
+			if (d.ref == ref && d.orient == orient && off >= d.off && off < d.off + d.len) return true;
+		}
+		return false;
+	}
+	BT2_HD void diag_add(int32_t ref, int64_t off, bool fw, int64_t len) {
+		if (w.n_diags >= (uint32_t)kMaxDiags) { w.err |= ERR_OVERFLOW; return; }
+		DiagIval& d = w.diags[w.n_diags++];
+		d.ref = ref; d.off = off; d.orient = fw ? 1 : 0; d.len = len;
+	}
+
+	// RedundantAlns cell enumeration (aligner_result.cpp:929-1032): per read row, the half-open
+	// column range [left,right) the alignment occupies, edits taken w.r.t. the upstream end.
+	template <typename F>
+	BT2_HD void for_each_row_cells(const AlnRes& r, F f) const {
+		int64_t left = r.refoff;
+		const uint32_t len = r.rdextent;        // readExtentRows()
+		const uint32_t start = r.fw ? r.trim5p : r.trim3p;   // trimmedLeft(true)
+		// edits w.r.t. upstream end: for rc alignments positions are inverted (invertPoss) and order reversed
+		const uint32_t n = r.nned;
+		auto epos = [&](uint32_t k) -> uint32_t {
+			if (r.fw) return r.ned[k].pos;
+			const Edit& e = r.ned[n - 1 - k];
+			return (uint32_t)(r.rdextent - e.pos - (e.type == EDIT_READ_GAP ? 0 : 1));
+		};
+		auto etype = [&](uint32_t k) -> int { return r.fw ? r.ned[k].type : r.ned[n - 1 - k].type; };
+		uint32_t nedidx = 0;
+		for (uint32_t i = start; i < start + len; i++) {
+			int64_t diff = 1;
+			int64_t right = left + 1;
+			while (nedidx < n && epos(nedidx) == i) {
+				if (etype(nedidx) == EDIT_REF_GAP) diff = 0;
+				nedidx++;
+			}
+			if (i < start + len - 1) {
+				uint32_t nn = nedidx;
+				while (nn < n && epos(nn) == i + 1) {
+					if (etype(nn) == EDIT_READ_GAP) right++;
+					nn++;
+				}
+			}
+			if (!f(i, left, right)) return;
+			left = right + diff - 1;
+		}
+	}
+
+	BT2_HD bool red_overlap(const AlnRes& r) const {
+		bool olap = false;
+		for_each_row_cells(r, [&](uint32_t i, int64_t left, int64_t right) -> bool {
+			for (uint32_t a = 0; a < w.n_red && !olap; a++) {
+				const RedAln& ra = w.red[a];
+				if (ra.refid != r.refid || (ra.fw != 0) != (r.fw != 0)) continue;
+				if (i < ra.start || i >= (uint32_t)ra.start + ra.len) continue;
+				const int64_t l2 = ra.refoff + (int64_t)(i - ra.start) + ra.left_rel[i];
+				const int64_t r2 = l2 + ra.width[i];
+				if (left < r2 && l2 < right) olap = true;
+			}
+			return !olap;
+		});
+		return olap;
+	}
+	BT2_HD void red_add(const AlnRes& r) {
+		if (w.n_red >= (uint32_t)kMaxAlns) { w.err |= ERR_OVERFLOW; return; }
+		RedAln& ra = w.red[w.n_red++];
+		ra.refid = r.refid; ra.fw = r.fw; ra.refoff = r.refoff;
+		ra.start = (uint16_t)(r.fw ? r.trim5p : r.trim3p); ra.len = r.rdextent;
+		for_each_row_cells(r, [&](uint32_t i, int64_t left, int64_t right) -> bool {
+			ra.left_rel[i] = (int8_t)(left - (ra.refoff + (int64_t)(i - ra.start)));
+			ra.width[i] = (uint8_t)(right - left);
+			return true;
+		});
+	}
+
+	// =================================================================================
+	// D. sink (AlnSinkWrap::report, ReportingState::foundUnpaired; aln_sink.cpp:103-130,1395-1445)
+	// =================================================================================
+	BT2_HD bool sink_report(const AlnRes& r) {
+		if (w.n_alns < (uint32_t)kMaxAlns) w.alns[w.n_alns] = r; else w.err |= ERR_OVERFLOW;
+		w.n_alns++;
+		if (!w.done_unpair1) {
+			// ReportingState::areDone
+			if (P.mhits <= 0 && w.n_alns >= (uint32_t)P.khits) { w.done_unpair1 = 1; w.exit_k = 1; }
+			else if (P.mhits > 0 && w.n_alns > (uint32_t)P.mhits) { w.done_unpair1 = 1; w.exit_m = 1; }
+		}
+		const int64_t score = r.score;
+		if (score > w.best_unp1) { w.best2_unp1 = w.best_unp1; w.best_unp1 = score; }
+		else if (score > w.best2_unp1) w.best2_unp1 = score;
+		return w.done_unpair1 != 0;
+	}
+
+	// =================================================================================
+	// E. DP: reference window, fill, gather, backtrace
+	// =================================================================================
+	// SwAligner::initRef (aligner_sw.cpp:155-271): masks for [rect.refl, rect.refr+1], overhang = N
+	BT2_HD void fetch_ref_window(uint64_t tidx, int64_t rfi, uint32_t count) {
+		for (uint32_t i = 0; i < count; i++) {
+			const int c = ref_base(ix.ref, tidx, rfi + (int64_t)i);
+			w.rf[i] = (uint8_t)(1 << c);
+		}
+	}
+
+	BT2_HD uint8_t mat_get(uint32_t R, uint32_t m, uint32_t i, uint32_t j) const { return dp.mat[dp_cell(R, m, i, j)]; }
+
+	// masks_ helpers (aligner_swsse.h:255-330,418-490)
+	BT2_HD uint16_t& mask_at(uint32_t row, uint32_t col, uint32_t cols) { return dp.masks[(uint64_t)row * cols + col]; }
+
+	// gatherCellsNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1176-1208) + btncand_.sort()
+	BT2_HD void gather_cells(uint32_t rows, uint32_t cols, int64_t minsc_dp) {
+		const uint32_t R = dp_R(rows);
+		w.n_cands = 0; w.cural = 0;
+		for (uint32_t j = 0; j < cols; j++) {
+			const int sc = (int)mat_get(R, 0, rows - 1, j) - 0xff;
+			if (sc >= minsc_dp) {
+				if (w.n_cands >= (uint32_t)kMaxCands) { w.err |= ERR_OVERFLOW; break; }
+				BtCand c; c.score = sc; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)j;
+				// insertion keeps: score desc, row desc, col desc (DpBtCandidate::operator<)
+				uint32_t k = w.n_cands++;
+				while (k > 0 && (w.cands[k - 1].score < c.score || (w.cands[k - 1].score == c.score && w.cands[k - 1].col < c.col))) {
+					w.cands[k] = w.cands[k - 1]; k--;
+				}
+				w.cands[k] = c;
+			}
+		}
+		if (w.n_cands > 0) Plat::zero_u8(dp.row_reset, rows);   // SSEMatrix::initMasks
+	}
+
+	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
+	BT2_HD bool backtrace(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen,
+	                      int32_t escore, uint32_t row, uint32_t col, AlnRes& res) {
+		(void)escore;
+		const uint32_t R = dp_R(rows);
+		uint32_t nstack = 0, ncells = 0, nned = 0;
+		int32_t score = 0, ns = 0;
+		const uint32_t orig_col = col;
+		uint32_t gaps = 0, read_gaps = 0, ref_gaps = 0;
+		const uint32_t trim_end = rows - row - 1;
+		uint32_t trim_beg = 0;
+		int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
+		Edit* ned = res.ned;
+		const int offsetsc = -0xff;
+		w.n_bt_attempts++;
+		while ((int)row >= 0) {
+			const int readc = rd_char(w, fw, row);
+			const int refm = w.rf[col];
+			const int readq = rd_qual(w, fw, row);
+			bool empty = false, can_move_thru = true, branch = false;
+			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
+			if (!dp.row_reset[row]) { Plat::zero_u16(&mask_at(row, 0, cols), cols); dp.row_reset[row] = 1; }
+			const bool reported_thru = (mask_at(row, col, cols) & 1) != 0;
+			if (reported_thru) {
+				can_move_thru = false;
+			} else if (row > 0) {
+				const uint32_t row_from_end = rows - row - 1;
+				const bool gaps_allowed = !(row < (uint32_t)P.gapbar || row_from_end < (uint32_t)P.gapbar);
+				uint16_t& mk = mask_at(row, col, cols);
+				if (ct == 1) {          // E: came from the left
+					const int sc_cur = (int)mat_get(R, 1, row, col) + offsetsc;
+					int mask = 0;
+					const int sc_h_left = (int)mat_get(R, 0, row, col - 1) + offsetsc;
+					if (sc_h_left - P.rdgapo == sc_cur) mask |= 1;
+					const int sc_e_left = (int)mat_get(R, 1, row, col - 1) + offsetsc;
+					if (sc_e_left - P.rdgape == sc_cur) mask |= 2;
+					const int orig_mask = mask;
+					if (mk & (1 << 7)) mask = (mk >> 8) & 3;
+					if (mask == 3) { cur = 3; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7) | (2 << 8)); branch = true; }
+					else if (mask == 2) { cur = 4; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7)); }
+					else if (mask == 1) { cur = 3; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7)); }
+					else { empty = true; can_move_thru = (orig_mask == 0); }
+				} else if (ct == 2) {   // F: came from above
+					const int sc_h_up = (int)mat_get(R, 0, row - 1, col) + offsetsc;
+					const int sc_f_up = (int)mat_get(R, 2, row - 1, col) + offsetsc;
+					const int sc_cur = (int)mat_get(R, 2, row, col) + offsetsc;
+					int mask = 0;
+					if (sc_h_up - P.rfgapo == sc_cur) mask |= 1;
+					if (sc_f_up - P.rfgape == sc_cur) mask |= 2;
+					const int orig_mask = mask;
+					if (mk & (1 << 10)) mask = (mk >> 11) & 3;
+					if (mask == 3) { cur = 1; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10) | (2 << 11)); branch = true; }
+					else if (mask == 2) { cur = 2; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10)); }
+					else if (mask == 1) { cur = 1; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10)); }
+					else { empty = true; can_move_thru = (orig_mask == 0); }
+				} else {                // H
+					const int sc_cur = (int)mat_get(R, 0, row, col) + offsetsc;
+					const int sc_f_up = (int)mat_get(R, 2, row - 1, col) + offsetsc;
+					const int sc_h_up = (int)mat_get(R, 0, row - 1, col) + offsetsc;
+					const bool hasl = col > 0;
+					const int sc_h_left = hasl ? (int)mat_get(R, 0, row, col - 1) + offsetsc : 0;
+					const int sc_e_left = hasl ? (int)mat_get(R, 1, row, col - 1) + offsetsc : 0;
+					const int sc_h_upleft = hasl ? (int)mat_get(R, 0, row - 1, col - 1) + offsetsc : 0;
+					const int sc_diag = sc_score(P, readc, refm, readq - 33);
+					int mask = 0;
+					if (gaps_allowed) {
+						if (sc_cur == sc_h_up - P.rfgapo) mask |= 1;
+						if (hasl && sc_cur == sc_h_left - P.rdgapo) mask |= 2;
+						if (sc_cur == sc_f_up - P.rfgape) mask |= 4;
+						if (hasl && sc_cur == sc_e_left - P.rdgape) mask |= 8;
+					}
+					if (hasl && sc_cur == sc_h_upleft + sc_diag) mask |= 16;
+					const int orig_mask = mask;
+					if (mk & (1 << 1)) mask = (mk >> 2) & 31;
+					int opts = 0;
+					for (int q = 0; q < 5; q++) if (mask & (1 << q)) opts++;
+					int select = -1;
+					if (opts == 1) {
+						for (int q = 0; q < 5; q++) if (mask & (1 << q)) { select = q; break; }
+						mk = (uint16_t)((mk & ~(31 << 1)) | (1 << 1));
+					} else if (opts > 1) {
+						if (mask & 16) select = 4;
+						else if (mask & 1) select = 0;
+						else if (mask & 4) select = 2;
+						else if (mask & 2) select = 1;
+						else if (mask & 8) select = 3;
+						mask &= ~(1 << select);
+						mk = (uint16_t)((mk & ~(31 << 1)) | (1 << 1) | (mask << 2));
+						branch = true;
+					}
+					if (select == 4) cur = 0;
+					else if (select == 0) cur = 1;
+					else if (select == 1) cur = 3;
+					else if (select == 2) cur = 2;
+					else if (select == 3) cur = 4;
+					else { empty = true; can_move_thru = (orig_mask == 0); }
+				}
+			}
+			mask_at(row, col, cols) |= 1;    // setReportedThrough
+			if (!can_move_thru) {
+				if (nstack > 0) {
+					const BtFrame& f = w.btstack[--nstack];
+					ncells = f.celsz; nned = f.nedsz; row = f.row; col = f.col;
+					gaps = f.gaps; read_gaps = f.read_gaps; ref_gaps = f.ref_gaps;
+					score = f.score; ns = f.ns; ct = f.ct;
+					continue;
+				}
+				return false;
+			}
+			if (empty || row == 0) {
+				w.btcells[2 * ncells] = (uint16_t)row; w.btcells[2 * ncells + 1] = (uint16_t)col; ncells++;
+				trim_beg = row;
+				break;
+			}
+			if (branch) {
+				if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { w.err |= ERR_OVERFLOW; return false; }
+				BtFrame& f = w.btstack[nstack++];
+				f.nedsz = nned; f.celsz = ncells; f.row = (uint16_t)row; f.col = (uint16_t)col;
+				f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
+				f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
+			}
+			if (ncells >= (uint32_t)(kMaxLen + 64)) { w.err |= ERR_OVERFLOW; return false; }
+			w.btcells[2 * ncells] = (uint16_t)row; w.btcells[2 * ncells + 1] = (uint16_t)col; ncells++;
+			if (nned + 1 >= (uint32_t)kMaxEdits) { w.err |= ERR_OVERFLOW; return false; }
+			switch (cur) {
+				case 0: {   // diagonal
+					const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
+					ct = 0;
+					if (m != 1) {
+						Edit& e = ned[nned++];
+						e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_MM;
+						score -= sc_mm(P, readc, refm, readq - 33);
+					} else {
+						score += P.match_bonus;
+					}
+					if (m == -1) ns++;
+					row--; col--;
+					break;
+				}
+				case 1: case 2: {   // ref gap (move up): open from H / extend from F
+					Edit& e = ned[nned++];
+					e.pos = (uint16_t)row; e.chr = '-'; e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_REF_GAP;
+					row--;
+					ct = (cur == 1) ? 0 : 2;
+					score -= (cur == 1) ? P.rfgapo : P.rfgape;
+					gaps++; ref_gaps++;
+					break;
+				}
+				default: {          // read gap (move left): open from H / extend from E
+					Edit& e = ned[nned++];
+					e.pos = (uint16_t)(row + 1); e.chr = (uint8_t)mask2chr(refm); e.qchr = '-'; e.type = EDIT_READ_GAP;
+					col--;
+					ct = (cur == 3) ? 0 : 1;
+					score -= (cur == 3) ? P.rdgapo : P.rdgape;
+					gaps++; read_gaps++;
+					break;
+				}
+			}
+		}
+		// must touch a core diagonal of the untrimmed rectangle (:1764-1795)
+		bool overlapped = false;
+		for (uint32_t i = 0; i < ncells; i++) {
+			const int64_t diagi = (int64_t)w.btcells[2 * i + 1] - (int64_t)w.btcells[2 * i] + (int64_t)rect.triml;
+			if (diagi >= 0 && (uint64_t)diagi >= rect.corel && (uint64_t)diagi <= rect.corer) { overlapped = true; break; }
+		}
+		if (!overlapped) return false;
+		{
+			const int readc = rd_char(w, fw, row);
+			const int refm = w.rf[col];
+			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
+			if (m != 1) {
+				Edit& e = ned[nned++];
+				e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_MM;
+				score -= sc_mm(P, readc, refm, rd_qual(w, fw, row) - 33);
+			} else score += P.match_bonus;
+			if (m == -1) ns++;
+		}
+		if (ns > rp.nceil) return false;
+		// res.reverse()
+		for (uint32_t i = 0; i < nned / 2; i++) { const Edit t = ned[i]; ned[i] = ned[nned - 1 - i]; ned[nned - 1 - i] = t; }
+		res.nned = (uint16_t)nned;
+		res.score = score; res.ns = (int16_t)ns; res.gaps = (int16_t)gaps; res.edits = (int16_t)nned;
+		res.bases_aligned = (int16_t)((int)rows - (int)trim_beg - (int)trim_end - (int)nned);
+		uint32_t refns = 0;
+		for (uint32_t i = col; i <= orig_col; i++) if (w.rf[i] > 15) refns++;
+		res.refns = (uint16_t)refns;
+		set_shape(res, (int32_t)tidx, (int64_t)col + rect.refl, tlen, fw, rows, fw ? trim_beg : trim_end, fw ? trim_end : trim_beg);
+		return true;
+	}
+
+	BT2_HD static int mask2chr(int m) {
+		// mask2dna for single-bit masks and N (alphabet.cpp:71); IUPAC multi-bit masks cannot occur
+		// because the index only stores A/C/G/T and N
+		switch (m) { case 1: return 'A'; case 2: return 'C'; case 4: return 'G'; case 8: return 'T'; default: return 'N'; }
+	}
+
+	// AlnRes::setShape (aligner_result.cpp:72-122) -- edits arrive w.r.t. DP rows (upstream end)
+	BT2_HD void set_shape(AlnRes& r, int32_t id, int64_t off, int64_t reflen, bool fw, uint32_t rdlen, uint32_t trim5p, uint32_t trim3p) {
+		r.refid = id; r.refoff = off; r.reflen = reflen; r.fw = fw ? 1 : 0; r.rdlen = (uint16_t)rdlen;
+		r.trim5p = (uint16_t)trim5p; r.trim3p = (uint16_t)trim3p;
+		const uint32_t trim_beg = fw ? trim5p : trim3p;
+		if (trim_beg > 0) for (uint32_t i = 0; i < r.nned; i++) r.ned[i].pos = (uint16_t)(r.ned[i].pos - trim_beg);
+		r.rdextent = (uint16_t)(rdlen - trim5p - trim3p);
+		int rf = r.rdextent;
+		for (uint32_t i = 0; i < r.nned; i++) {
+			if (r.ned[i].type == EDIT_REF_GAP) rf--;
+			if (r.ned[i].type == EDIT_READ_GAP) rf++;
+		}
+		r.rfextent = (uint16_t)rf;
+	}
+
+	// Edit::invertPoss over the whole list (edit.cpp:50-88): reverse order, pos -> sz - pos - (readgap?0:1)
+	BT2_HD void invert_edits(AlnRes& r) {
+		const uint32_t n = r.nned, sz = r.rdextent;
+		for (uint32_t i = 0; i < n / 2; i++) { const Edit t = r.ned[i]; r.ned[i] = r.ned[n - 1 - i]; r.ned[n - 1 - i] = t; }
+		for (uint32_t i = 0; i < n; i++) r.ned[i].pos = (uint16_t)(sz - r.ned[i].pos - (r.ned[i].type == EDIT_READ_GAP ? 0 : 1));
+	}
+
+	// SwAligner::nextAlignment, end-to-end u8 branch (aligner_sw.cpp:737-1146)
+	BT2_HD bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, AlnRes& res) {
+		if (w.cural == w.n_cands) return false;
+		bool found = false;
+		while (w.cural < w.n_cands) {
+			const BtCand& c = w.cands[w.cural];
+			if (c.score < minsc) { w.cural++; continue; }
+			if (dp.row_reset[c.row] && (mask_at(c.row, c.col, cols) & 1)) { w.cural++; continue; }
+			const uint32_t reseed = rnd.nextU32() + 1;
+			rnd.init(reseed);
+			res.nned = 0;
+			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, c.score, c.row, c.col, res);
+			rnd.init(reseed + 1);
+			if (ret) { found = true; break; }
+			w.cural++;
+		}
+		if (!found) return false;
+		if (!fw) invert_edits(res);
+		w.cural++;
+		return true;
+	}
+
+	// SwAligner::ungappedAlign, monotone branch (aligner_sw.cpp:286-494); returns 0 / 1
+	BT2_HD int ungapped_align(bool fw, uint64_t tidx, int64_t refoff, int64_t reflen, AlnRes& res) {
+		const uint32_t len = w.len;
+		const int64_t rfi = refoff, rff = refoff + (int64_t)len;
+		if (rfi < 0) return 0;              // gReportOverhangs == false
+		if (rff > reflen) return 0;
+		int64_t score = 0;
+		int ns = 0;
+		for (uint32_t i = 0; i < len; i++) w.rf[i] = (uint8_t)ref_base(ix.ref, tidx, rfi + (int64_t)i);   // codes here, not masks
+		for (uint32_t i = 0; i < len; i++) {
+			const int rdc = rd_char(w, fw, i);
+			const int rfc = w.rf[i];
+			const int q = rd_qual(w, fw, i) - 33;
+			if (rdc > 3 || rfc > 3) { ns++; score -= P.n_pen; }
+			else if (rdc == rfc) score += P.match_bonus;
+			else score -= mm_penalty(P, q < 0 ? 0 : q);
+			if (score < minsc || ns > rp.nceil) return 0;
+		}
+		uint32_t nned = 0, refns = 0;
+		for (uint32_t i = 0; i < len; i++) {
+			const int rdc = rd_char(w, fw, i);
+			const int rfc = w.rf[i];
+			if (rfc > 3 || rdc != rfc) {
+				if (nned >= (uint32_t)kMaxEdits) { w.err |= ERR_OVERFLOW; return 0; }
+				Edit& e = res.ned[nned++];
+				e.pos = (uint16_t)i; e.chr = (uint8_t)"ACGTN"[rfc]; e.qchr = (uint8_t)"ACGTN"[rdc]; e.type = EDIT_MM;
+				if (rfc > 3) refns++;
+			}
+		}
+		res.nned = (uint16_t)nned;
+		res.score = (int32_t)score; res.ns = (int16_t)ns; res.gaps = 0; res.edits = (int16_t)nned;
+		res.bases_aligned = (int16_t)((int)len - (int)nned);
+		res.refns = (uint16_t)refns;
+		set_shape(res, (int32_t)tidx, refoff, reflen, fw, len, 0, 0);
+		if (!fw) invert_edits(res);
+		return 1;
+	}
+
+	// =================================================================================
+	// F. SwDriver::extendSeeds (aligner_sw_driver.cpp:921-1494)
+	// =================================================================================
+	BT2_HD int extend_seeds(int seedmms, int seedlen, int seedival) {
+		(void)seedlen; (void)seedival;
+		const uint32_t rdlen = w.len;
+		const int64_t perfect = (int64_t)rdlen * P.match_bonus * 0;   // monotone: perfectScore() == 0
+		const uint32_t nsm = 5;
+		const uint32_t nonz = w.nonz_tot;
+		const uint64_t ee_hits = (w.exact[0].bot - w.exact[0].top) + (w.exact[1].bot - w.exact[1].top) + w.mm1_elt;
+		bool ee_mode = ee_hits > 0;
+		bool first_ee = true, first_extend = true;
+		w.n_ee_fail = w.n_ug_fail = w.n_dp_fail = 0;
+		uint64_t nelt = 0, nelt_left = 0;
+		const uint32_t rows = rdlen;
+		const uint32_t max_iters = (uint32_t)P.max_iters;
+		AlnRes& res = w.res;
+		while (true) {
+			if (ee_mode) {
+				if (first_ee) {
+					first_ee = false;
+					ee_sa_tups(nelt, max_iters);
+					ee_mode = true;
+				} else ee_mode = false;
+			}
+			if (!ee_mode) {
+				if (nonz == 0) return EXT_EXHAUSTED;
+				if (minsc == perfect) return EXT_PERFECT_SCORE;
+				if (first_extend) {
+					nelt = 0;
+					prioritize(seedmms, max_iters, nelt);
+					nelt_left = nelt;
+					first_extend = false;
+				}
+				if (nelt_left == 0) break;
+			}
+			const uint32_t maxi = w.n_satpos;
+			for (uint32_t i = 0; i < maxi; i++) {
+				SatPos& sp = w.satpos[i];
+				const EEHit* eh = ee_mode ? &ee_hit(sp.ee) : nullptr;
+				if (ee_mode && eh->score < minsc) return EXT_PERFECT_SCORE;
+				const bool is_small = sp.size < nsm;
+				const bool fw = sp.fw != 0;
+				uint32_t rdoff = sp.rdoff;
+				const uint32_t seedhitlen = sp.seedlen;
+				if (!fw) rdoff = rdlen - rdoff - seedhitlen;
+				bool first = true;
+				while (!r1n_done(sp.rnd) && (first || is_small || ee_mode)) {
+					if (minsc == perfect) {
+						if (!ee_mode || eh->score < perfect) return EXT_PERFECT_SCORE;
+					} else if (ee_mode && eh->score < minsc) {
+						break;
+					}
+					if (w.n_ex_dps >= (uint32_t)P.max_dp) return EXT_HARD_LIMIT;
+					if (w.n_ex_ugs >= (uint32_t)P.max_ug) return EXT_HARD_LIMIT;
+					if (w.n_ex_iters >= max_iters) return EXT_HARD_LIMIT;
+					w.n_ex_iters++;
+					first = false;
+					const uint32_t elt = r1n_next(sp.rnd);
+					// GroupWalk2S::advanceElement == Ebwt::getOffset(topf + elt)
+					uint32_t steps = 0;
+					const TOff joff = get_offset(ix.fw, (TOff)(sp.topf + elt), steps);
+					w.n_bwops_ext += steps;
+					if (!ee_mode) nelt_left--;
+					TOff tidx = 0, toff = 0, tlen = 0;
+					bool straddled = false;
+					joined_to_text_off(ix, (TOff)seedhitlen, joff, tidx, toff, tlen, ee_mode, straddled);
+					if (tidx == kOffMask) continue;
+					const int64_t refoff = (int64_t)toff - (int64_t)rdoff;
+					if (diag_present((int32_t)tidx, refoff, fw)) { w.n_redundants++; continue; }
+					int read_gaps = 0, ref_gaps = 0;
+					bool ungapped = false;
+					if (!ee_mode) {
+						read_gaps = max_read_gaps(P, minsc, rdlen);
+						ref_gaps = max_ref_gaps(P, minsc, rdlen);
+						ungapped = (read_gaps == 0 && ref_gaps == 0);
+					}
+					int state = 0;   // 0 none, 1 ee, 2 ungapped
+					bool found = false;
+					DPRect rect;
+					rect.refl = rect.refr = rect.refl_pretrim = rect.refr_pretrim = 0;
+					rect.triml = rect.trimr = rect.corel = rect.corer = rect.maxgap = 0;
+					uint32_t cols = 0;
+					if (ee_mode) {
+						res.nned = 0;
+						const int mms = eh->has_edit ? 1 : 0;
+						int hns = 0, hrefns = 0;
+						if (mms) {
+							hns = (eh->echr == 4 || eh->eqchr == 4) ? 1 : 0;
+							hrefns = (eh->echr == 4) ? 1 : 0;
+						}
+						res.score = eh->score; res.bases_aligned = (int16_t)((int)rdlen - mms); res.edits = (int16_t)mms;
+						res.ns = (int16_t)hns; res.gaps = 0;
+						if (mms) {
+							Edit& e = res.ned[0];
+							e.pos = eh->epos; e.chr = (uint8_t)"ACGTN"[eh->echr]; e.qchr = (uint8_t)"ACGTN"[eh->eqchr]; e.type = EDIT_MM;
+							res.nned = 1;
+						}
+						// setShape with no trimming leaves the (already 5'-relative) edit untouched
+						set_shape(res, (int32_t)tidx, refoff, (int64_t)tlen, fw, rdlen, 0, 0);
+						res.refns = (uint16_t)hrefns;
+						state = 1; found = true;
+						diag_add((int32_t)tidx, refoff, fw, 1);
+					} else if (P.do_ungapped && ungapped) {
+						const int al = ungapped_align(fw, tidx, refoff, (int64_t)tlen, res);
+						diag_add((int32_t)tidx, refoff, fw, 1);
+						w.n_ex_ugs++;
+						if (al == 0) {
+							w.n_ug_fail++;
+							if (w.n_ug_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
+							continue;
+						}
+						w.n_ug_fail = 0;
+						found = true; state = 2;
+					}
+					if (state == 0) {
+						// DynProgFramer::frameSeedExtensionRect (dp_framer.cpp:81-129), trimToRef
+						uint32_t maxgap = (uint32_t)imax(read_gaps, ref_gaps);
+						if (maxgap > (uint32_t)P.maxhalf) maxgap = (uint32_t)P.maxhalf;
+						const int64_t refl = refoff - 2 * (int64_t)maxgap;
+						const int64_t refr = refoff + ((int64_t)rows - 1) + 2 * (int64_t)maxgap;
+						uint64_t triml = 0, trimr = 0;
+						if (refr >= (int64_t)tlen) trimr = (uint64_t)(refr - ((int64_t)tlen - 1));
+						if (refl < 0) triml = (uint64_t)(-refl);
+						rect.refl_pretrim = refl; rect.refr_pretrim = refr;
+						rect.refl = refl + (int64_t)triml; rect.refr = refr - (int64_t)trimr;
+						rect.triml = (uint32_t)triml; rect.trimr = (uint32_t)trimr; rect.maxgap = maxgap;
+						rect.corel = maxgap; rect.corer = rect.corel + 2 * maxgap;
+						found = !(rect.refr < rect.refl);
+						diag_add((int32_t)tidx, refoff, fw, 1);
+						if (!found) continue;
+						cols = (uint32_t)(rect.refr - rect.refl + 1);
+						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { w.err |= ERR_OVERFLOW; return EXT_HARD_LIMIT; }
+						fetch_ref_window(tidx, rect.refl, cols + 1);
+						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
+						// SwAligner::align (aligner_sw.cpp:500-729), end-to-end 8-bit path
+						const int best_u8 = Plat::dp_fill_ee_u8(P, w, fw, rows, cols, dp.mat);
+						const int64_t best = (int64_t)best_u8 - 0xff;
+						w.n_ex_dps++;
+						found = best >= minsc;
+						if (found) { gather_cells(rows, cols, minsc); found = w.n_cands > 0; }
+						if (!found) {
+							w.n_dp_fail++;
+							if (w.n_dp_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
+							continue;
+						}
+						if (w.n_dp_fail > w.n_dp_fail_streak) w.n_dp_fail_streak = w.n_dp_fail;
+						w.n_dp_fail = 0;
+					}
+					bool first_inner = true;
+					while (true) {
+						if (state == 1 || state == 2) {
+							if (!first_inner) break;
+						} else {
+							if (w.cural == w.n_cands) break;
+							if (!next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, res)) break;
+						}
+						first_inner = false;
+						// fell entirely outside the reference?
+						{
+							const int64_t a0 = res.refoff, a1 = res.refoff + res.rfextent;
+							const int64_t b0 = 0, b1 = (int64_t)tlen;
+							const bool ov = (b0 <= a0 && b1 > a0) || (b0 <= a1 && b1 > a1) || (a0 <= b0 && a1 > b0) || (a0 <= b1 && a1 > b1);
+							if (!ov) continue;
+						}
+						if (red_overlap(res)) continue;
+						red_add(res);
+						if (sink_report(res)) return EXT_POLICY_FULFILLED;
+						if (P.tighten > 0 && P.mhits > 0 && w.best2_unp1 != INT64_MIN) {
+							if (P.tighten == 1) {
+								if (w.best_unp1 >= minsc) {
+									minsc = w.best_unp1;
+									if (minsc < perfect && w.best_unp1 == w.best2_unp1) minsc++;
+								}
+							} else if (P.tighten == 2) {
+								if (w.best2_unp1 >= minsc) { minsc = w.best2_unp1; if (minsc < perfect) minsc++; }
+							} else {
+								const int64_t diff = w.best_unp1 - w.best2_unp1;
+								const int64_t bot = w.best2_unp1 + ((diff * 3) / 4);
+								if (bot >= minsc) { minsc = bot; if (minsc < perfect) minsc++; }
+							}
+						}
+					}
+				}
+			}
+		}
+		return EXT_EXHAUSTED;
+	}
+
+	// =================================================================================
+	// G. the per-read worker (multiseedSearchWorker, bt2_search.cpp:3094-4254, unpaired path)
+	// =================================================================================
+	BT2_HD void handle_ret(int ret, bool& done) {
+		if (ret == EXT_POLICY_FULFILLED) { if (w.done_unpair1) done = true; }
+		else if (ret == EXT_PERFECT_SCORE) done = true;
+		else if (ret == EXT_HARD_LIMIT) done = true;
+	}
+
+	BT2_HD void run(ReadResult& out) {
+		const uint32_t len = w.len;
+		w.err = 0;
+		w.n_alns = 0; w.best_unp1 = w.best2_unp1 = INT64_MIN; w.done_unpair1 = 0; w.exit_m = w.exit_k = 0;
+		w.n_diags = 0; w.n_red = 0; w.n_ex_fw = w.n_ex_rc = 0;
+		w.n_ex_iters = w.n_ex_dps = w.n_ex_ugs = w.n_dp_fail = w.n_ug_fail = w.n_ee_fail = w.n_dp_fail_streak = 0;
+		w.n_redundants = w.n_bwops_seed = w.n_bwops_ext = w.n_bt_attempts = 0;
+		w.n_mm1 = 0; w.mm1_elt = 0; w.nonz_tot = 0; w.n_rank = 0; w.num_offs = 0; w.num_elts = 0;
+		w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0;
+		minsc = rp.minsc;
+		const bool filt = (rp.filt & 15u) == 15u;
+		bool done = !filt;
+		const int64_t perfect = 0;
+		if (!done) {
+			rnd.init(rp.seed);
+			const uint32_t interval = (uint32_t)rp.interval;
+			uint32_t nrounds = (uint32_t)P.n_seed_rounds;
+			uint32_t mine[2] = {0, 0};
+			uint64_t nelt = 0;
+			if (P.do_exact_upfront) {
+				nelt = exact_sweep(2, mine);
+				if (nelt == 0) { w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0; }
+				else {
+					const int ret = extend_seeds(-1, 0, 0);
+					w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0;
+					handle_ret(ret, done);
+					if (!done && minsc == perfect) done = true;
+				}
+			}
+			if (P.do_1mm_upfront) {
+				if (!done) {
+					const bool yfw = mine[0] <= 1 && !P.nofw;
+					const bool yrc = mine[1] <= 1 && !P.norc;
+					nelt = 0;
+					if (yfw || yrc) { one_mm_search(!yfw, !yrc); nelt = w.mm1_elt; }
+					if (nelt > 0) {
+						const int ret = extend_seeds(-1, 0, 0);
+						w.n_mm1 = 0; w.mm1_elt = 0;
+						handle_ret(ret, done);
+						if (!done && minsc == perfect) done = true;
+					}
+				}
+				w.n_mm1 = 0; w.mm1_elt = 0;
+			}
+			if (nrounds > interval) nrounds = interval;
+			for (uint32_t roundi = 0; roundi < (uint32_t)P.n_seed_rounds; roundi++) {
+				w.nonz_tot = 0; w.n_rank = 0; w.num_elts = 0; w.num_offs = 0;
+				if (done || w.done_unpair1) { done = true; continue; }
+				if (roundi >= nrounds) continue;
+				if (interval <= roundi) continue;
+				const uint32_t offset = (interval * roundi) / nrounds;
+				if (offset > 0 && (uint32_t)rp.seedlen + offset > len) continue;
+				const uint32_t ninst = seed_round(offset, interval, (uint32_t)rp.seedlen);
+				if (ninst == 0) { done = true; w.nonz_tot = 0; continue; }
+				if (w.nonz_tot == 0) { done = true; continue; }
+				rank_seed_hits();
+				const int ret = extend_seeds(0, rp.seedlen, (int)interval);
+				handle_ret(ret, done);
+				if (!done && w.nonz_tot > 0 && (w.num_elts / w.nonz_tot) < (uint64_t)P.seed_boost_thresh) done = true;
+			}
+		}
+		finish(out);
+	}
+
+	// AlnSinkWrap::finishRead for an unpaired read (aln_sink.cpp:643-1384): ReportingState::finish,
+	// getReport, selectByScore (RNG!), and what the SAM line needs.
+	BT2_HD void finish(ReadResult& out) {
+		out.status = (uint8_t)w.err;
+		out.filt = (uint8_t)rp.filt;
+		out.exhausted = 0;
+		out.nalns = w.n_alns;
+		out.n_ex_iters = w.n_ex_iters; out.n_ex_dps = w.n_ex_dps; out.n_ex_ugs = w.n_ex_ugs;
+		out.n_dp_fail_streak_max = w.n_dp_fail_streak; out.n_bwops_seed = w.n_bwops_seed; out.n_bwops_ext = w.n_bwops_ext;
+		out.n_redundants = w.n_redundants; out.n_bt_attempts = w.n_bt_attempts;
+		uint32_t nunpair1 = 0;
+		bool maxed = false;
+		if (w.n_alns > 0) {
+			if (w.exit_k) nunpair1 = (uint32_t)P.khits;
+			else if (w.exit_m) { maxed = true; nunpair1 = 1; }
+			else nunpair1 = w.n_alns < (uint32_t)P.khits ? w.n_alns : (uint32_t)P.khits;
+		}
+		out.aligned = nunpair1 > 0 ? 1 : 0;
+		out.maxed = maxed ? 1 : 0;
+		out.has_secbest = 0; out.secbest = 0; out.best = 0; out.nreport = 0;
+		if (nunpair1 == 0) return;
+		// selectByScore: sort (score, index) ascending, reverse, shuffle equal-score streaks
+		const uint32_t sz = w.n_alns < (uint32_t)kMaxAlns ? w.n_alns : (uint32_t)kMaxAlns;
+		uint32_t num = nunpair1 < sz ? nunpair1 : sz;
+		uint32_t* idx = w.lists;      // scratch (Random1toN lists are dead by now)
+		for (uint32_t i = 0; i < sz; i++) idx[i] = i;
+		for (uint32_t i = 1; i < sz; i++) {          // descending by (score, index)
+			const uint32_t v = idx[i];
+			uint32_t j = i;
+			while (j > 0 && (w.alns[idx[j - 1]].score < w.alns[v].score ||
+			                 (w.alns[idx[j - 1]].score == w.alns[v].score && idx[j - 1] < v))) { idx[j] = idx[j - 1]; j--; }
+			idx[j] = v;
+		}
+		auto shuffle = [&](uint32_t begin, uint32_t n) {
+			if (n < 2) return;
+			uint32_t left = n;
+			for (uint32_t i = begin; i < begin + n - 1; i++) {
+				const uint64_t rndi = rnd.nextU64() % left;
+				if (rndi > 0) { const uint32_t t = idx[i]; idx[i] = idx[i + rndi]; idx[i + rndi] = t; }
+				left--;
+			}
+		};
+		uint32_t streak = 0;
+		for (uint32_t i = 1; i < sz; i++) {
+			if (w.alns[idx[i]].score == w.alns[idx[i - 1]].score) { if (streak == 0) streak = 1; streak++; }
+			else { if (streak > 1) shuffle(i - streak, streak); streak = 0; }
+		}
+		if (streak > 1) shuffle(sz - streak, streak);
+		out.best = w.alns[idx[0]].score;
+		if (sz > 1) { out.has_secbest = 1; out.secbest = w.alns[idx[1]].score; }
+		out.nreport = num;
+		for (uint32_t i = 0; i < num; i++) out.alns[i] = w.alns[idx[i]];
+	}
+};
+
+} // namespace bt2g
+#endif

@@ -1,0 +1,419 @@
+// bt2g_host.hpp -- host side of the drop-in: option handling, read ingest, per-read parameter
+// derivation and SAM emission.  None of this is on the GPU hot path; it exists so that the
+// per-read worker can be swapped under the reference's bowtie2-align-{s,l} contract
+// (argv in, SAM + stderr summary out).
+//
+// Reference behaviour restated here:
+//   option defaults / presets      bt2_search.cpp:303-502, presets.cpp:33-91, aligner_seed_policy.cpp:252-310
+//   SimpleFunc::f                  simple_func.h:89-112
+//   FASTQ parse, genRandSeed       pat.cpp:45-84,1136-1247
+//   filters, minsc, interval       bt2_search.cpp:3352-3450
+//   SAM record / flags / MAPQ      aln_sink.cpp:1889-2124, sam.cpp:30-420, unique.h:170-330,
+//                                  aligner_result.cpp:556-870 (StackedAln)
+//   alignment summary              aln_sink.cpp:349-560
+#ifndef BT2G_HOST_HPP_
+#define BT2G_HOST_HPP_
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "bt2g_align.hpp"
+
+namespace bt2g {
+
+struct SimpleFunc {
+	int type = 0;   // 1 const, 2 linear, 3 sqrt, 4 log
+	double I = 0, X = 0, C = 0, L = 0;
+	void init(int t, double c, double l) {
+		type = t; C = c; L = l; I = -std::numeric_limits<double>::max(); X = std::numeric_limits<double>::max();
+	}
+	void init(int t, double i, double x, double c, double l) { type = t; I = i; X = x; C = c; L = l; }
+	template <typename T> T f(double x) const {
+		double v = 0.0;
+		if (type == 2) v = x; else if (type == 3) v = std::sqrt(x); else if (type == 4) v = std::log(x);
+		const double ret = std::max(I, std::min(X, C + L * v));
+		if (ret == std::numeric_limits<double>::max()) return std::numeric_limits<T>::max();
+		if (ret == std::numeric_limits<double>::min()) return std::numeric_limits<T>::min();
+		return (T)ret;
+	}
+	// "L,-0.6,-0.6" style (SimpleFunc::parse)
+	bool parse(const std::string& s) {
+		std::vector<std::string> t;
+		size_t p = 0;
+		while (true) { size_t q = s.find(',', p); t.push_back(s.substr(p, q == std::string::npos ? q : q - p)); if (q == std::string::npos) break; p = q + 1; }
+		if (t.empty() || t[0].empty()) return false;
+		const char c = t[0][0];
+		if (c == 'C') type = 1; else if (c == 'L') type = 2; else if (c == 'S') type = 3; else if (c == 'G') type = 4; else return false;
+		if (t.size() >= 2) C = atof(t[1].c_str());
+		if (t.size() >= 3) L = atof(t[2].c_str());
+		if (t.size() >= 4) I = atof(t[3].c_str());
+		if (t.size() >= 5) X = atof(t[4].c_str());
+		return true;
+	}
+};
+
+struct Options {
+	// files
+	std::string index_base, reads_file, out_file;
+	// policy
+	SimpleFunc score_min, n_ceil, ms_ival;
+	int seed_len = 22, seed_mms = 0, n_seed_rounds = 2, max_dp_streak = 15;
+	int khits = 1, mhits = 50;
+	bool saw_k = false, all_hits = false, local = false;
+	bool nofw = false, norc = false;
+	bool qc_filter = false;
+	uint32_t seed = 0;
+	int threads = 1;
+	bool reorder = false, timing = false, no_unal = false, quiet = false, sam_no_hd = false, sam_no_sq = false;
+	uint64_t skip = 0, upto = std::numeric_limits<uint64_t>::max();
+	std::string cmdline;      // for @PG
+	std::string preset = "sensitive";
+
+	Options() {
+		score_min.init(2, (double)-0.6f, (double)-0.6f);
+		n_ceil.init(2, (double)0.0f, std::numeric_limits<double>::max(), (double)0.0f, (double)0.15f);
+		ms_ival.init(3, (double)1.0f, std::numeric_limits<double>::max(), (double)0.0f, (double)1.15f);
+		apply_preset("sensitive");
+	}
+	bool apply_preset(const std::string& p) {
+		// presets.cpp:33-91 (PresetsV0), end-to-end flavours
+		if (p == "very-fast")           { max_dp_streak = 5;  n_seed_rounds = 1; seed_mms = 0; seed_len = 22; ms_ival.type = 3; ms_ival.C = 0.0; ms_ival.L = 2.50; }
+		else if (p == "fast")           { max_dp_streak = 10; n_seed_rounds = 2; seed_mms = 0; seed_len = 22; ms_ival.type = 3; ms_ival.C = 0.0; ms_ival.L = 2.50; }
+		else if (p == "sensitive")      { max_dp_streak = 15; n_seed_rounds = 2; seed_mms = 0; seed_len = 22; ms_ival.type = 3; ms_ival.C = 1.0; ms_ival.L = 1.15; }
+		else if (p == "very-sensitive") { max_dp_streak = 20; n_seed_rounds = 3; seed_mms = 0; seed_len = 20; ms_ival.type = 3; ms_ival.C = 1.0; ms_ival.L = 0.50; }
+		else return false;
+		preset = p;
+		return true;
+	}
+	void to_params(AlignParams& P, bool large_index) const {
+		P.mm_type = 3; P.mm_max = 6; P.mm_min = 2; P.n_pen = 1;
+		P.rdgapo = 5 + 3; P.rdgape = 3; P.rfgapo = 5 + 3; P.rfgape = 3; P.gapbar = 4; P.match_bonus = 0;
+		P.khits = khits; P.mhits = (saw_k || all_hits) ? 0 : mhits;
+		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
+		if (khits > 1) {
+			// streak/limit scaling with -k (bt2_search.cpp:3452-3476): maxStreakIncr=10, maxItersIncr=20
+			P.max_dp_streak += (khits - 1) * 10;
+			P.max_ug += (khits - 1) * 20; P.max_dp += (khits - 1) * 20; P.max_iters += (khits - 1) * 20;
+		}
+		P.n_seed_rounds = n_seed_rounds; P.seed_boost_thresh = 300; P.tighten = 3; P.maxhalf = 15;
+		P.nofw = nofw; P.norc = norc;
+		P.do_exact_upfront = 1; P.do_1mm_upfront = 1; P.do_ungapped = 1; P.do_extend = 1;
+		P.large_index = large_index ? 1 : 0;
+	}
+};
+
+struct ReadRec {
+	std::string name;
+	std::string seq;    // codes 0..4
+	std::string qual;   // ASCII phred+33
+};
+
+// asc2dna (alphabet.cpp:142): A/C/G/T (either case) -> 0..3, every other letter -> 4
+inline int asc2code(int c) {
+	switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+
+// minimal FASTQ reader following FastqPatternSource::parse (4-line records, '.' -> N)
+class FastqReader {
+public:
+	explicit FastqReader(const std::string& path) { f_ = path == "-" ? stdin : fopen(path.c_str(), "rb"); }
+	~FastqReader() { if (f_ && f_ != stdin) fclose(f_); }
+	bool ok() const { return f_ != nullptr; }
+	bool next(ReadRec& r, uint64_t rdid) {
+		std::string l1, l2, l3, l4;
+		do { if (!getline(l1)) return false; } while (l1.empty());
+		if (l1[0] != '@') return false;
+		if (!getline(l2) || !getline(l3) || !getline(l4)) return false;
+		r.name = l1.substr(1);
+		r.seq.clear();
+		for (char c : l2) { if (c == '.') c = 'N'; if (isalpha((unsigned char)c)) r.seq.push_back((char)asc2code(c)); }
+		r.qual = l4;
+		if (r.qual.size() > r.seq.size()) r.qual.resize(r.seq.size());   // the reference errors out; we are lenient
+		while (r.qual.size() < r.seq.size()) r.qual.push_back('I');
+		if (r.name.empty()) r.name = std::to_string(rdid);
+		return true;
+	}
+private:
+	bool getline(std::string& s) {
+		s.clear();
+		int c;
+		bool any = false;
+		while ((c = fgetc(f_)) != EOF) { any = true; if (c == '\n') break; if (c != '\r') s.push_back((char)c); }
+		return any;
+	}
+	FILE* f_;
+};
+
+// genRandSeed (pat.cpp:45-84)
+inline uint32_t gen_rand_seed(const ReadRec& r, uint32_t seed) {
+	uint32_t rseed = (seed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
+	const size_t qlen = r.seq.size();
+	for (size_t i = 0; i < qlen; i++) rseed ^= ((uint32_t)(int)r.seq[i] << ((i & 15) << 1));
+	for (size_t i = 0; i < qlen; i++) rseed ^= (uint32_t)((int)r.qual[i] << ((i & 3) << 3));
+	for (size_t i = 0; i < r.name.size(); i++) {
+		const int p = (int)r.name[i];
+		if (p == '/') break;
+		rseed ^= (uint32_t)(p << ((i & 3) << 3));
+	}
+	return rseed;
+}
+
+// per-read derived parameters (bt2_search.cpp:3352-3450)
+inline ReadParams compute_read_params(const Options& o, const ReadRec& r) {
+	ReadParams p;
+	const size_t len = r.seq.size();
+	int64_t minsc = o.score_min.f<int64_t>((double)len);
+	if (!o.local && minsc > 0) minsc = 0;
+	p.minsc = (int32_t)minsc;
+	// N filter (Scoring::nFilter)
+	const size_t maxns = o.n_ceil.f<size_t>((double)len);
+	size_t ns = 0;
+	bool nfilt = true;
+	for (size_t i = 0; i < len; i++) if (r.seq[i] == 4) { ns++; if (ns > maxns) { nfilt = false; break; } }
+	// score filter: perfect score (0 in e2e) must reach minsc
+	const bool scfilt = (int64_t)0 >= minsc;
+	const bool lenfilt = !(len <= (size_t)o.seed_mms || len < 2);
+	const bool qcfilt = true;
+	p.filt = (nfilt ? 1u : 0u) | (scfilt ? 2u : 0u) | (lenfilt ? 4u : 0u) | (qcfilt ? 8u : 0u);
+	int nceil = o.n_ceil.f<int>((double)len);
+	if (nceil > (int)len) nceil = (int)len;
+	p.nceil = nceil;
+	int interval = o.ms_ival.f<int>((double)len);
+	if (interval < 1) interval = 1;
+	p.interval = interval;
+	p.seedlen = o.seed_len;
+	p.seed = gen_rand_seed(r, o.seed);
+	return p;
+}
+
+// ---------------------------------------------------------------------------------------
+// SAM
+struct RefInfo { std::vector<std::string> names; std::vector<uint64_t> lens; };
+
+inline void sam_print_name(std::string& o, const std::string& name, bool truncate) {
+	size_t n = name.size();
+	if (truncate && n > 255) n = 255;
+	for (size_t i = 0; i < n; i++) { if (truncate && isspace((unsigned char)name[i])) break; o.push_back(name[i]); }
+}
+
+inline void sam_header(std::string& o, const RefInfo& ref, const std::string& cmdline, bool hd = true, bool sq = true) {
+	if (hd) o += "@HD\tVN:1.5\tSO:unsorted\tGO:query\n";
+	if (sq) for (size_t i = 0; i < ref.names.size(); i++) {
+		o += "@SQ\tSN:";
+		sam_print_name(o, ref.names[i], true);
+		o += "\tLN:" + std::to_string(ref.lens[i]) + "\n";
+	}
+	o += "@PG\tID:bowtie2\tPN:bowtie2\tVN:2.5.5\tCL:\"" + cmdline + "\"\n";
+}
+
+// BowtieMapq2::mapq for an unpaired, primary, end-to-end alignment (unique.h:185-330)
+inline int mapq_v2(const Options& o, size_t rdlen, int64_t best, bool has_secbest, int64_t secbest_in) {
+	const int64_t scPer = 0;
+	const int64_t scMin = o.score_min.f<int64_t>((double)(float)rdlen);
+	int64_t secbest = scMin - 1;
+	const int64_t diff = std::max<int64_t>(1, scPer - scMin);
+	int ret = 0;
+	const int64_t bestOver = best - scMin;
+	if (!has_secbest) {
+		if      (bestOver >= diff * (double)0.8f) ret = 42;
+		else if (bestOver >= diff * (double)0.7f) ret = 40;
+		else if (bestOver >= diff * (double)0.6f) ret = 24;
+		else if (bestOver >= diff * (double)0.5f) ret = 23;
+		else if (bestOver >= diff * (double)0.4f) ret = 8;
+		else if (bestOver >= diff * (double)0.3f) ret = 3;
+		else ret = 0;
+	} else {
+		secbest = secbest_in;
+		const int64_t bestdiff = std::abs(std::abs(best) - std::abs(secbest));
+		if (bestdiff >= diff * (double)0.9f) ret = (bestOver == diff) ? 39 : 33;
+		else if (bestdiff >= diff * (double)0.8f) ret = (bestOver == diff) ? 38 : 27;
+		else if (bestdiff >= diff * (double)0.7f) ret = (bestOver == diff) ? 37 : 26;
+		else if (bestdiff >= diff * (double)0.6f) ret = (bestOver == diff) ? 36 : 22;
+		else if (bestdiff >= diff * (double)0.5f) {
+			if (bestOver == diff) ret = 35; else if (bestOver >= diff * (double)0.84f) ret = 25;
+			else if (bestOver >= diff * (double)0.68f) ret = 16; else ret = 5;
+		} else if (bestdiff >= diff * (double)0.4f) {
+			if (bestOver == diff) ret = 34; else if (bestOver >= diff * (double)0.84f) ret = 21;
+			else if (bestOver >= diff * (double)0.68f) ret = 14; else ret = 4;
+		} else if (bestdiff >= diff * (double)0.3f) {
+			if (bestOver == diff) ret = 32; else if (bestOver >= diff * (double)0.88f) ret = 18;
+			else if (bestOver >= diff * (double)0.67f) ret = 15; else ret = 3;
+		} else if (bestdiff >= diff * (double)0.2f) {
+			if (bestOver == diff) ret = 31; else if (bestOver >= diff * (double)0.88f) ret = 17;
+			else if (bestOver >= diff * (double)0.67f) ret = 11; else ret = 0;
+		} else if (bestdiff >= diff * (double)0.1f) {
+			if (bestOver == diff) ret = 30; else if (bestOver >= diff * (double)0.88f) ret = 12;
+			else if (bestOver >= diff * (double)0.67f) ret = 7; else ret = 0;
+		} else if (bestdiff > 0) {
+			ret = (bestOver >= diff * (double)0.67f) ? 6 : 2;
+		} else {
+			ret = (bestOver >= diff * (double)0.67f) ? 1 : 0;
+		}
+	}
+	return ret;
+}
+
+// One SAM record for an unpaired read (AlnSinkSam::appendMate + printAlignedOptFlags)
+inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, const ReadRec& rd,
+                       const ReadResult& rr, const AlnRes* aln, bool primary) {
+	static const char* DNA = "ACGTN";
+	const size_t len = rd.seq.size();
+	sam_print_name(o, rd.name, true);
+	o.push_back('\t');
+	int fl = 0;
+	if (!primary) fl |= 256;
+	if (aln && !aln->fw) fl |= 16;
+	if (!aln) fl |= 4;
+	o += std::to_string(fl); o.push_back('\t');
+	if (aln) { sam_print_name(o, ref.names[aln->refid], true); o.push_back('\t'); o += std::to_string(aln->refoff + 1); o.push_back('\t'); }
+	else o += "*\t0\t";
+	// stacked alignment (StackedAln::init / leftAlign / buildCigar / buildMdz)
+	std::string stRef, stRel, stRead;
+	if (aln) {
+		// edits w.r.t. the upstream end: invert for rc (AlnRes::initStacked)
+		std::vector<Edit> ed(aln->ned, aln->ned + aln->nned);
+		size_t trimLS = aln->trim5p, trimRS = aln->trim3p;
+		const size_t len_trimmed = len - trimLS - trimRS;
+		if (!aln->fw) {
+			for (size_t i = 0; i < ed.size() / 2; i++) std::swap(ed[i], ed[ed.size() - 1 - i]);
+			for (auto& e : ed) e.pos = (uint16_t)(len_trimmed - e.pos - (e.type == EDIT_READ_GAP ? 0 : 1));
+			std::swap(trimLS, trimRS);
+		}
+		auto s = [&](size_t i) -> int { return aln->fw ? (int)rd.seq[i] : comp4((int)rd.seq[len - 1 - i]); };
+		size_t rdoff = trimLS;
+		for (const auto& e : ed) {
+			const size_t pos = e.pos + trimLS;
+			while (rdoff < pos) { const int c = s(rdoff++); stRef.push_back(DNA[c]); stRel.push_back('='); stRead.push_back(DNA[c]); }
+			if (e.type == EDIT_MM) { const int c = s(rdoff++); stRef.push_back((char)e.chr); stRel.push_back('X'); stRead.push_back(DNA[c]); }
+			else if (e.type == EDIT_REF_GAP) { const int c = s(rdoff++); stRef.push_back('-'); stRel.push_back('I'); stRead.push_back(DNA[c]); }
+			else { stRef.push_back((char)e.chr); stRel.push_back('D'); stRead.push_back('-'); }
+		}
+		while (rdoff < len - trimRS) { const int c = s(rdoff++); stRef.push_back(DNA[c]); stRel.push_back('='); stRead.push_back(DNA[c]); }
+		// leftAlign(false)
+		const size_t ln = stRef.size();
+		for (size_t i = 0; i < ln; i++) {
+			const char rel = stRel[i];
+			if (rel != '=' && rel != 'X') {
+				size_t glen = 1;
+				for (size_t j = i + 1; j < ln; j++) { if (rel != stRel[j]) break; glen++; }
+				size_t l = i - 1, r = l + glen;
+				std::string& gp = (rel == 'I') ? stRef : stRead;
+				const std::string& ngp = (rel == 'I') ? stRead : stRef;
+				while (l > 0 && l < ln && ngp[l] == ngp[r]) {
+					if (stRel[l] == 'X') break;
+					std::swap(gp[l], gp[r]);
+					std::swap(stRel[l], stRel[r]);
+					l--; r--;
+				}
+				i += (glen - 1);
+			}
+		}
+		o += std::to_string(mapq_v2(opt, len, rr.best, rr.has_secbest != 0, rr.secbest));
+		o.push_back('\t');
+		// CIGAR
+		if (trimLS > 0) { o += std::to_string(trimLS); o.push_back('S'); }
+		for (size_t i = 0; i < ln; i++) {
+			char op = stRel[i];
+			if (op == 'X' || op == '=') op = 'M';
+			size_t run = 1;
+			for (; i + run < ln; run++) { char op2 = stRel[i + run]; if (op2 == 'X' || op2 == '=') op2 = 'M'; if (op2 != op) break; }
+			i += (run - 1);
+			o += std::to_string(run); o.push_back(op);
+		}
+		if (trimRS > 0) { o += std::to_string(trimRS); o.push_back('S'); }
+		o.push_back('\t');
+	} else {
+		o += "0\t*\t";
+	}
+	o += "*\t0\t0\t";
+	// SEQ / QUAL
+	if (len == 0) o.push_back('*');
+	else if (!aln || aln->fw) for (size_t i = 0; i < len; i++) o.push_back(DNA[(int)rd.seq[i]]);
+	else for (size_t i = 0; i < len; i++) o.push_back(DNA[comp4((int)rd.seq[len - 1 - i])]);
+	o.push_back('\t');
+	if (len == 0) o.push_back('*');
+	else if (!aln || aln->fw) o += rd.qual;
+	else o.append(rd.qual.rbegin(), rd.qual.rend());
+	o.push_back('\t');
+	// optional fields
+	if (aln) {
+		o += "AS:i:" + std::to_string(aln->score);
+		if (rr.has_secbest) o += "\tXS:i:" + std::to_string(rr.secbest);
+		o += "\tXN:i:" + std::to_string(aln->refns);
+		size_t num_mm = 0, num_go = 0, num_gx = 0;
+		for (size_t i = 0; i < aln->nned; i++) {
+			const Edit& e = aln->ned[i];
+			if (e.type == EDIT_MM) num_mm++;
+			else if (e.type == EDIT_READ_GAP) {
+				num_go++; num_gx++;
+				while (i + 1 < aln->nned && aln->ned[i + 1].pos == aln->ned[i].pos && aln->ned[i + 1].type == EDIT_READ_GAP) { i++; num_gx++; }
+			} else if (e.type == EDIT_REF_GAP) {
+				num_go++; num_gx++;
+				while (i + 1 < aln->nned && aln->ned[i + 1].pos == aln->ned[i].pos + 1 && aln->ned[i + 1].type == EDIT_REF_GAP) { i++; num_gx++; }
+			}
+		}
+		o += "\tXM:i:" + std::to_string(num_mm) + "\tXO:i:" + std::to_string(num_go) + "\tXG:i:" + std::to_string(num_gx);
+		o += "\tNM:i:" + std::to_string(aln->nned);
+		// YF would go here for filtered reads, but filtered reads never align
+		o += "\tYT:Z:UU";
+		// MD:Z (buildMdz + writeMdz) -- note the reference prints MD:Z before YT:Z? order checked in tests
+		std::string md;
+		{
+			bool mm_last = false, rdgap_last = false, first_print = true;
+			const size_t ln = stRef.size();
+			for (size_t i = 0; i < ln; i++) {
+				const char op = stRel[i];
+				if (op == '=') {
+					size_t run = 1, nins = 0;
+					for (; i + run < ln; run++) {
+						if (stRel[i + run] == '=') {} else if (stRel[i + run] == 'I') nins++; else break;
+					}
+					i += (run - 1);
+					if (run - nins > 0) { md += std::to_string(run - nins); first_print = false; mm_last = false; rdgap_last = false; }
+				} else if (op == 'X') {
+					if (rdgap_last || mm_last || first_print) md.push_back('0');
+					md.push_back(stRef[i]);
+					first_print = false; mm_last = true; rdgap_last = false;
+				} else if (op == 'D') {
+					if (mm_last || first_print) md.push_back('0');
+					if (!rdgap_last) md.push_back('^');
+					md.push_back(stRef[i]);
+					first_print = false; mm_last = false; rdgap_last = true;
+				}
+			}
+			if (mm_last || rdgap_last) md.push_back('0');
+		}
+		// reorder: the reference prints MD:Z before YT:Z -- splice it in
+		const size_t ytpos = o.rfind("\tYT:Z:UU");
+		o.insert(ytpos, "\tMD:Z:" + md);
+	} else {
+		o += "YT:Z:UU";
+		const uint32_t f = rr.filt;
+		const char* flag = "";
+		if (!(f & 4)) flag = "LN"; else if (!(f & 1)) flag = "NS"; else if (!(f & 2)) flag = "SC"; else if (!(f & 8)) flag = "QC";
+		if (flag[0]) { o += "\tYF:Z:"; o += flag; }
+	}
+	o.push_back('\n');
+}
+
+struct AlnSummary {
+	uint64_t nread = 0, n0 = 0, nuni = 0, nrep = 0;
+	void add(const ReadResult& r) { nread++; if (!r.aligned) n0++; else if (r.maxed) nrep++; else nuni++; }
+	void print(FILE* f) const {
+		auto pct = [](uint64_t a, uint64_t b) { char buf[32]; snprintf(buf, sizeof buf, "%.2f%%", b ? 100.0 * (double)a / (double)b : 0.0); return std::string(buf); };
+		fprintf(f, "%llu reads; of these:\n", (unsigned long long)nread);
+		fprintf(f, "  %llu (%s) were unpaired; of these:\n", (unsigned long long)nread, pct(nread, nread).c_str());
+		fprintf(f, "    %llu (%s) aligned 0 times\n", (unsigned long long)n0, pct(n0, nread).c_str());
+		fprintf(f, "    %llu (%s) aligned exactly 1 time\n", (unsigned long long)nuni, pct(nuni, nread).c_str());
+		fprintf(f, "    %llu (%s) aligned >1 times\n", (unsigned long long)nrep, pct(nrep, nread).c_str());
+		fprintf(f, "%s overall alignment rate\n", pct(nuni + nrep, nread).c_str());
+	}
+};
+
+} // namespace bt2g
+#endif

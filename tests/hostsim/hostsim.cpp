@@ -1,0 +1,157 @@
+// tests/hostsim/hostsim.cpp -- TEST-ONLY host build of the per-read worker.
+//
+// Compiles bowtie2_amd/csrc/bt2g_align_core.hpp for the CPU (the wave-parallel sections
+// replaced by plain loops writing the same wavefront-major scratch layout) so that the
+// control logic can be diffed against the reference's SAM in a container without a GPU.
+// It is never linked into libbt2g.so or the bowtie2-align-* drop-in: the product path is
+// the HIP kernel only.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../bowtie2_amd/csrc/bt2g_index.hpp"
+#include "../../bowtie2_amd/csrc/bt2g_align_core.hpp"
+#include "../../bowtie2_amd/csrc/bt2g_host.hpp"
+
+using namespace bt2g;
+
+struct HostPlat {
+	static void zero_u8(uint8_t* p, uint32_t n) { memset(p, 0, n); }
+	static void zero_u16(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
+	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
+	static int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint8_t* mat) {
+		const uint32_t R = dp_R(rows);
+		int lrmax = 0;
+		std::vector<int> Hp(rows, 0), Ep(rows, 0), Hc(rows), Ec(rows), Fc(rows);
+		for (uint32_t j = 0; j < cols; j++) {
+			const int m = w.rf[j];
+			int refc = 4;
+			for (int b = 0; b < 4; b++) if (m & (1 << b)) { refc = b; break; }
+			int f = 0;
+			for (uint32_t i = 0; i < rows; i++) {
+				const int veto = ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar) ? 0xff : 0;
+				const int rdc = rd_char(w, fw, i);
+				const int q = rd_qual(w, fw, i) - 33;
+				int pen;
+				if (rdc > 3 || refc > 3) pen = P.n_pen; else pen = (rdc == refc) ? -P.match_bonus : mm_penalty(P, q < 0 ? 0 : q);
+				const int hdiag = (i == 0) ? 0xff : (j == 0 ? 0 : Hp[i - 1]);
+				const int e = (j == 0) ? 0 : imax(subs0(Ep[i], P.rdgape), subs0(subs0(Hp[i], P.rdgapo), veto));
+				f = (i == 0) ? 0 : subs0(imax(subs0(f, P.rfgape), subs0(Hc[i - 1], P.rfgapo)), veto);
+				const int h = imax(imax(subs0(hdiag, pen), e), f);
+				Hc[i] = h; Ec[i] = e; Fc[i] = f;
+				mat[dp_cell(R, 0, i, j)] = (uint8_t)h;
+				mat[dp_cell(R, 1, i, j)] = (uint8_t)e;
+				mat[dp_cell(R, 2, i, j)] = (uint8_t)f;
+			}
+			if (Hc[rows - 1] > lrmax) lrmax = Hc[rows - 1];
+			Hp.swap(Hc); Ep.swap(Ec);
+		}
+		return lrmax;
+	}
+};
+
+template <typename TOff>
+static void make_dev_index(const HostIndex& h, DevIndex<TOff>& d) {
+	auto fill = [&](const HostEbwt& e, DevEbwt<TOff>& o, bool fw) {
+		o.ebwt = e.ebwt.data();
+		o.ftab = (const TOff*)e.ftab.data();
+		o.eftab = (const TOff*)e.eftab.data();
+		o.offs = fw ? (const TOff*)e.offs.data() : nullptr;
+		o.len = (TOff)e.len; o.zoff = (TOff)e.zoff;
+		for (int i = 0; i < 5; i++) o.fchr[i] = (TOff)e.fchr[i];
+		o.ftab_chars = e.ftab_chars; o.off_rate = e.off_rate; o.is_fw = fw;
+	};
+	fill(h.fw, d.fw, true);
+	fill(h.bw, d.bw, false);
+	d.rstarts = (const TOff*)h.fw.rstarts.data();
+	d.plen = (const TOff*)h.fw.plen.data();
+	d.n_frag = (TOff)h.fw.n_frag; d.n_pat = (TOff)h.fw.n_pat;
+	d.ref.rec_refpos = h.ref.rec_refpos.data(); d.ref.rec_bufpos = h.ref.rec_bufpos.data(); d.ref.rec_len = h.ref.rec_len.data();
+	d.ref.ref_rec_offs = h.ref.ref_rec_offs.data(); d.ref.ref_lens = h.ref.ref_lens.data(); d.ref.buf = h.ref.buf.data();
+	d.ref.nrefs = h.ref.nrefs;
+}
+
+template <typename TOff>
+static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metrics) {
+	DevIndex<TOff> ix;
+	make_dev_index(hidx, ix);
+	AlignParams P;
+	opt.to_params(P, sizeof(TOff) == 8);
+	RefInfo ref;
+	ref.names = hidx.fw.refnames;
+	for (uint64_t i = 0; i < hidx.fw.n_pat; i++) ref.lens.push_back(hidx.plen_at(i));
+	std::string o;
+	sam_header(o, ref, opt.cmdline);
+	fwrite(o.data(), 1, o.size(), out);
+	FastqReader fq(opt.reads_file);
+	if (!fq.ok()) { fprintf(stderr, "cannot open %s\n", opt.reads_file.c_str()); return 1; }
+	Work* w = new Work();
+	DpScratch dp;
+	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * 3 * dp_R(kMaxLen) * 64;
+	dp.mat = (uint8_t*)malloc(mat_bytes);
+	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
+	dp.row_reset = (uint8_t*)malloc(kMaxLen);
+	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(opt.khits + 1));
+	ReadRec rd;
+	AlnSummary summ;
+	uint64_t rdid = 0;
+	while (fq.next(rd, rdid)) {
+		if (rdid >= opt.upto) break;
+		if (rdid++ < opt.skip) continue;
+		ReadResult& rr = *(ReadResult*)resbuf.data();
+		if (rd.seq.size() > (size_t)kMaxLen) {
+			fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", rd.name.c_str(), kMaxLen);
+			return 1;
+		}
+		ReadParams rp = compute_read_params(opt, rd);
+		w->len = (uint32_t)rd.seq.size();
+		memcpy(w->seq, rd.seq.data(), rd.seq.size());
+		memcpy(w->qual, rd.qual.data(), rd.qual.size());
+		Aligner<TOff, HostPlat> al(ix, P, rp, *w, dp);
+		al.run(rr);
+		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d)\n", rd.name.c_str(), rr.status);
+		summ.add(rr);
+		o.clear();
+		if (rr.aligned) {
+			for (uint32_t i = 0; i < rr.nreport; i++) sam_record(o, opt, ref, rd, rr, &rr.alns[i], i == 0);
+		} else {
+			sam_record(o, opt, ref, rd, rr, nullptr, true);
+		}
+		fwrite(o.data(), 1, o.size(), out);
+		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u\n", rd.name.c_str(),
+		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns);
+	}
+	summ.print(stderr);
+	return 0;
+}
+
+int main(int argc, char** argv) {
+	Options opt;
+	bool metrics = false;
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		auto need = [&](const char* what) -> std::string { if (i + 1 >= argc) { fprintf(stderr, "%s needs an argument\n", what); exit(1); } return argv[++i]; };
+		if (a == "-x") opt.index_base = need("-x");
+		else if (a == "-U") opt.reads_file = need("-U");
+		else if (a == "-S") opt.out_file = need("-S");
+		else if (a == "-k") { opt.khits = atoi(need("-k").c_str()); opt.saw_k = true; }
+		else if (a == "-s") opt.skip = strtoull(need("-s").c_str(), nullptr, 10);
+		else if (a == "-u") opt.upto = strtoull(need("-u").c_str(), nullptr, 10);
+		else if (a == "--seed") opt.seed = (uint32_t)strtoul(need("--seed").c_str(), nullptr, 10);
+		else if (a == "--nofw") opt.nofw = true;
+		else if (a == "--norc") opt.norc = true;
+		else if (a == "--met") metrics = true;
+		else if (a.size() > 2 && a.substr(0, 2) == "--" && opt.apply_preset(a.substr(2))) {}
+		else { fprintf(stderr, "unsupported option %s\n", a.c_str()); return 1; }
+	}
+	opt.cmdline = "hostsim";
+	HostIndex hidx;
+	std::string err;
+	if (load_index(opt.index_base, hidx, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+	FILE* out = opt.out_file.empty() ? stdout : fopen(opt.out_file.c_str(), "wb");
+	int rc = hidx.off_size == 4 ? run<uint32_t>(hidx, opt, out, metrics) : run<uint64_t>(hidx, opt, out, metrics);
+	if (out != stdout) fclose(out);
+	return rc;
+}
