@@ -55,6 +55,43 @@ class DpProblem(C.Structure):
                 ("mat_off", C.c_uint64)]
 
 
+class AlignParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "mm_type", "mm_max", "mm_min", "n_pen", "rdgapo", "rdgape", "rfgapo", "rfgape", "gapbar", "match_bonus",
+        "khits", "mhits", "max_dp_streak", "max_ug", "max_dp", "max_iters", "n_seed_rounds", "seed_boost_thresh",
+        "tighten", "maxhalf", "nofw", "norc", "do_exact_upfront", "do_1mm_upfront", "do_ungapped", "do_extend",
+        "large_index")]
+
+
+class ReadParams(C.Structure):
+    _fields_ = [("minsc", C.c_int32), ("interval", C.c_int32), ("nceil", C.c_int32), ("seedlen", C.c_int32),
+                ("seed", C.c_uint32), ("filt", C.c_uint32)]
+
+
+MAX_EDITS = 200
+
+
+class Edit(C.Structure):
+    _fields_ = [("pos", C.c_uint16), ("chr", C.c_uint8), ("qchr", C.c_uint8), ("type", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class Aln(C.Structure):
+    _fields_ = [("refoff", C.c_int64), ("reflen", C.c_int64), ("refid", C.c_int32), ("score", C.c_int32),
+                ("ns", C.c_int16), ("gaps", C.c_int16), ("edits", C.c_int16), ("bases_aligned", C.c_int16),
+                ("refns", C.c_uint16), ("nned", C.c_uint16), ("rdlen", C.c_uint16), ("rdextent", C.c_uint16),
+                ("rfextent", C.c_uint16), ("trim5p", C.c_uint16), ("trim3p", C.c_uint16),
+                ("fw", C.c_uint8), ("pad", C.c_uint8 * 5), ("ned", Edit * MAX_EDITS)]
+
+
+class ReadResult(C.Structure):
+    _fields_ = [("status", C.c_uint8), ("aligned", C.c_uint8), ("maxed", C.c_uint8), ("filt", C.c_uint8),
+                ("exhausted", C.c_uint8), ("has_secbest", C.c_uint8), ("pad", C.c_uint8 * 2),
+                ("secbest", C.c_int32), ("best", C.c_int32), ("nalns", C.c_uint32), ("nreport", C.c_uint32),
+                ("n_ex_iters", C.c_uint32), ("n_ex_dps", C.c_uint32), ("n_ex_ugs", C.c_uint32),
+                ("n_dp_fail_streak_max", C.c_uint32), ("n_bwops_seed", C.c_uint32), ("n_bwops_ext", C.c_uint32),
+                ("n_redundants", C.c_uint32), ("n_bt_attempts", C.c_uint32), ("alns", Aln * 1)]
+
+
 class Counters(C.Structure):
     _fields_ = [("rank_queries", C.c_uint64), ("sa_lookups", C.c_uint64), ("ftab_lookups", C.c_uint64),
                 ("dp_cells", C.c_uint64), ("bwops", C.c_uint64)]
@@ -76,6 +113,8 @@ ABI = [
     ("bt2g_scoring_default", None, [C.POINTER(Scoring)]),
     ("bt2g_sw_fill_ee_u8", C.c_int, [_vp, C.POINTER(Scoring), _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("bt2g_counters_read", C.c_int, [_vp, C.POINTER(Counters), C.c_int, _vp]),
+    ("bt2g_align_result_stride", C.c_uint64, [C.c_uint32]),
+    ("bt2g_align_batch", C.c_int, [_vp, C.POINTER(Reads), _vp, C.POINTER(AlignParams), C.c_uint32, _vp, _vp]),
 ]
 
 _lib = None
@@ -200,6 +239,16 @@ class Context:
         _check(self._h, lib().bt2g_sw_fill_ee_u8(self._h, C.byref(sc), probs.data_ptr(), n, rd.data_ptr(), qu.data_ptr(),
                                                   rf.data_ptr(), mat.data_ptr() if mat is not None else None,
                                                   best.data_ptr(), _stream_ptr()), "bt2g_sw_fill_ee_u8")
+
+    def align_batch(self, batch, rparams, params, max_read_len):
+        """rparams: uint8 device tensor holding ReadParams[n]; returns a uint8 device tensor of result records."""
+        import torch
+        stride = lib().bt2g_align_result_stride(params.khits)
+        out = torch.zeros(batch.n * stride, dtype=torch.uint8, device=batch.seq.device)
+        rd = batch.struct()
+        _check(self._h, lib().bt2g_align_batch(self._h, C.byref(rd), rparams.data_ptr(), C.byref(params), max_read_len,
+                                                out.data_ptr(), _stream_ptr()), "bt2g_align_batch")
+        return out, stride
 
     def counters(self, reset=False):
         c = Counters()

@@ -28,6 +28,7 @@
 #define BT2G_ALIGN_HPP_
 
 #include "bt2g_device.hpp"
+#include "../../include/bt2g.h"
 
 namespace bt2g {
 
@@ -48,75 +49,14 @@ enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMI
 enum { ERR_NONE = 0, ERR_OVERFLOW = 1 };   // per-read status: capacity of a fixed arena exceeded
 
 // ---------------------------------------------------------------------------------------
-// parameters (one per batch) -- everything the reference keeps in bt2_search.cpp's file statics
-struct AlignParams {
-	// scoring (Scoring, scoring.h)
-	int mm_type, mm_max, mm_min, n_pen, rdgapo, rdgape, rfgapo, rfgape, gapbar, match_bonus;
-	// effort / reporting (bt2_search.cpp:303-502)
-	int khits, mhits;           // -k, -M (mhits>0 => -M mode)
-	int max_dp_streak;          // -D
-	int max_ug, max_dp, max_iters;
-	int n_seed_rounds;          // -R + ... (nSeedRounds)
-	int seed_boost_thresh;      // 300
-	int tighten;                // 3
-	int maxhalf;                // --dpad 15
-	int nofw, norc;
-	int do_exact_upfront, do_1mm_upfront, do_ungapped, do_extend;
-	int large_index;            // RNG draws differ between -s and -l builds (aligner_sw_driver.cpp:103-109)
-};
-
-// per-read inputs computed on the host with the reference's own formulas (SimpleFunc::f uses
-// libm double math; keeping it on the host makes minsc/interval/nceil bit-identical by construction)
-struct ReadParams {
-	int32_t  minsc;      // scoreMin.f(len), clamped (bt2_search.cpp:3352-3372)
-	int32_t  interval;   // msIval.f(len) -> max(1, .) (:3443-3450)
-	int32_t  nceil;      // min(nCeil.f(len), len) (:3427)
-	int32_t  seedlen;    // multiseedLen
-	uint32_t seed;       // genRandSeed (pat.cpp:45)
-	uint32_t filt;       // bit0 nfilt, bit1 scfilt, bit2 lenfilt, bit3 qcfilt (1 = passes)
-};
-
-struct Edit {
-	uint16_t pos;
-	uint8_t  chr;    // reference char (ASCII) or '-'
-	uint8_t  qchr;   // read char (ASCII) or '-'
-	uint8_t  type;
-	uint8_t  pad;
-};
-
-struct AlnRes {
-	int64_t  refoff;
-	int64_t  reflen;
-	int32_t  refid;
-	int32_t  score;
-	int16_t  ns, gaps, edits, bases_aligned;
-	uint16_t refns;
-	uint16_t nned;
-	uint16_t rdlen, rdextent, rfextent;
-	uint16_t trim5p, trim3p;
-	uint8_t  fw;
-	uint8_t  pad[5];
-	Edit     ned[kMaxEdits];
-};
-
-// What the sink hands back to the host for one read (SAM formatting / MAPQ happen there).
-struct ReadResult {
-	uint8_t  status;        // ERR_*
-	uint8_t  aligned;       // nunpair1 > 0
-	uint8_t  maxed;         // unpair1Max (more than -M alignments)
-	uint8_t  filt;          // copy of ReadParams.filt
-	uint8_t  exhausted;     // exhaustive[0] (always false here, as in the reference call sites)
-	uint8_t  has_secbest;   // bestUnchosenUScore valid
-	uint8_t  pad[2];
-	int32_t  secbest;       // bestUnchosenUScore
-	int32_t  best;          // bestUScore
-	uint32_t nalns;         // alignments found (rs1u_.size())
-	uint32_t nreport;       // alignments to print (<= khits)
-	// metrics mirroring PerReadMetrics / SeedSearchMetrics for work-parity checks
-	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail_streak_max, n_bwops_seed, n_bwops_ext, n_redundants;
-	uint32_t n_bt_attempts;
-	AlnRes   alns[1];       // nreport entries follow (ReadResult is allocated with room for khits)
-};
+// The batch parameters, per-read parameters and result records are the C-ABI structs of
+// include/bt2g.h (bt2g_align_params, bt2g_read_params, bt2g_edit, bt2g_aln, bt2g_read_result).
+using AlignParams = bt2g_align_params;
+using ReadParams  = bt2g_read_params;
+using Edit        = bt2g_edit;
+using AlnRes      = bt2g_aln;
+using ReadResult  = bt2g_read_result;
+static_assert(kMaxLen == BT2G_MAX_READ_LEN && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
 
 // ---------------------------------------------------------------------------------------
 // RandomSource (random_source.h:34-159)

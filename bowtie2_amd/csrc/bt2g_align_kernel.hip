@@ -1,0 +1,178 @@
+// bt2g_align_kernel.hip -- the per-read multiseed worker as one gfx950 kernel.
+//
+// One wavefront per read (see bt2g_align.hpp).  Waves are persistent: each pulls the next read
+// index from a device counter, so long reads / repetitive reads do not leave a tail of idle
+// CUs.  Per-wave working state (Work + DP scratch) lives in an HBM arena sized at launch.
+//
+// The wave-parallel pieces (DevPlat): the end-to-end u8 DP fill on the anti-diagonal wavefront
+// (lane = block of read rows, H/F/ref-char handed down the lanes with __shfl_up, wavefront-major
+// scratch so every store is one 64-byte line), and the zeroing of backtrace-mask rows.
+#include <hip/hip_runtime.h>
+#include "bt2g_align_core.hpp"
+#include "bt2g_align_kernel.hpp"
+
+namespace bt2g {
+
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+template <int R>
+__device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work& w, bool fw, uint32_t rows, uint32_t cols,
+                                               uint8_t* __restrict__ scratch) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t nlanes = (rows + R - 1) / R;
+	int rdc[R], mmp[R], veto[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const uint32_t i = (uint32_t)lane * R + r;
+		const bool valid = i < rows;
+		rdc[r] = valid ? rd_char(w, fw, i) : 4;
+		const int q = valid ? rd_qual(w, fw, i) - 33 : 0;
+		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
+		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 0xff : 0;
+	}
+	int Hprev[R], Eprev[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
+	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, best = 0;
+	const uint32_t steps = cols + nlanes - 1;
+	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
+	const int last_r = (int)((rows - 1) % R);
+	for (uint32_t t = 0; t < steps; t++) {
+		const int upH = __shfl_up(myHlast, 1);
+		const int upF = __shfl_up(myFlast, 1);
+		int upRef = __shfl_up(refm, 1);
+		if (lane == 0) upRef = (t < cols) ? w.rf[t] : 16;
+		refm = upRef;
+		const int j = (int)t - lane;
+		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
+		int refc = 4;
+		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
+		int hdiag = (lane == 0) ? 0xff : (j == 0 ? 0 : upHdiag);
+		int fin_h = upH, fin_f = upF;
+		int Hnew[R], Enew[R], Fnew[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			int pen;
+			if (rdc[r] > 3 || refc > 3) pen = P.n_pen; else pen = (rdc[r] == refc) ? -P.match_bonus : mmp[r];
+			const int e = (j == 0) ? 0 : imax(subs0(Eprev[r], P.rdgape), subs0(subs0(Hprev[r], P.rdgapo), veto[r]));
+			int f;
+			if (lane == 0 && r == 0) f = 0;
+			else f = subs0(imax(subs0(fin_f, P.rfgape), subs0(fin_h, P.rfgapo)), veto[r]);
+			const int h = imax(imax(subs0(hdiag, pen), e), f);
+			Hnew[r] = h; Enew[r] = e; Fnew[r] = f;
+			hdiag = Hprev[r];
+			fin_h = h; fin_f = f;
+		}
+		if (active) {
+			uint8_t* base = scratch + ((uint64_t)t * 3 * R) * 64 + lane;
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				base[(0 * R + r) * 64] = (uint8_t)Hnew[r];
+				base[(1 * R + r) * 64] = (uint8_t)Enew[r];
+				base[(2 * R + r) * 64] = (uint8_t)Fnew[r];
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
+			if (lane_has_last) best = imax(best, Hnew[last_r]);
+		}
+		upHdiag = upH;
+		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
+	}
+	return __shfl(best, (int)((rows - 1) / R));
+}
+
+struct DevPlat {
+	static __device__ __forceinline__ void zero_u8(uint8_t* p, uint32_t n) {
+		wave_fence();
+		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) p[i] = 0;
+		wave_fence();
+	}
+	static __device__ __forceinline__ void zero_u16(uint16_t* p, uint32_t n) {
+		wave_fence();
+		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) p[i] = 0;
+		wave_fence();
+	}
+	static __device__ __forceinline__ int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint8_t* mat) {
+		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
+		int best;
+		switch (dp_R(rows)) {
+			case 1: best = fill_ee_u8_wave<1>(P, w, fw, rows, cols, mat); break;
+			case 2: best = fill_ee_u8_wave<2>(P, w, fw, rows, cols, mat); break;
+			case 3: best = fill_ee_u8_wave<3>(P, w, fw, rows, cols, mat); break;
+			case 4: best = fill_ee_u8_wave<4>(P, w, fw, rows, cols, mat); break;
+			case 5: best = fill_ee_u8_wave<5>(P, w, fw, rows, cols, mat); break;
+			case 6: best = fill_ee_u8_wave<6>(P, w, fw, rows, cols, mat); break;
+			case 7: best = fill_ee_u8_wave<7>(P, w, fw, rows, cols, mat); break;
+			default: best = fill_ee_u8_wave<8>(P, w, fw, rows, cols, mat); break;
+		}
+		wave_fence();     // matrix written lane-parallel -> visible to the scalar backtrace
+		return best;
+	}
+};
+
+template <typename TOff>
+__global__ void __launch_bounds__(64)
+k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
+              uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
+              uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read) {
+	const int lane = threadIdx.x & 63;
+	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
+	Work& w = *reinterpret_cast<Work*>(base);
+	DpScratch dp;
+	dp.mat = base + ((sizeof(Work) + 255) & ~(uint64_t)255);
+	dp.masks = reinterpret_cast<uint16_t*>(dp.mat + mat_bytes);
+	dp.row_reset = reinterpret_cast<uint8_t*>(dp.masks) + mask_bytes;
+	for (;;) {
+		unsigned int r = 0;
+		if (lane == 0) r = atomicAdd(next_read, 1u);
+		r = __shfl(r, 0);
+		if (r >= rd.n_reads) break;
+		const uint64_t o0 = rd.d_off[r];
+		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
+		ReadResult& out = *reinterpret_cast<ReadResult*>(results + (uint64_t)r * result_stride);
+		if (len > (uint32_t)kMaxLen) {
+			if (lane == 0) { out.status = ERR_OVERFLOW; out.aligned = 0; out.nreport = 0; out.nalns = 0; out.filt = (uint8_t)rparams[r].filt; out.maxed = 0; out.has_secbest = 0; }
+			continue;
+		}
+		// stage the read into the work area (lane-parallel copy)
+		wave_fence();
+		w.len = len;
+		for (uint32_t i = lane; i < len; i += 64) { w.seq[i] = rd.d_seq[o0 + i]; w.qual[i] = rd.d_qual[o0 + i]; }
+		wave_fence();
+		const ReadParams rp = rparams[r];
+		Aligner<TOff, DevPlat> al(ix, P, rp, w, dp);
+		al.run(out);
+		wave_fence();
+	}
+}
+
+template <typename TOff>
+hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
+                        uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
+                        uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, hipStream_t st) {
+	if (rd.n_reads == 0) return hipSuccess;
+	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
+	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next);
+	return hipGetLastError();
+}
+
+void align_scratch_sizes(uint32_t max_len, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& arena_stride) {
+	const uint32_t rows = max_len ? max_len : 1;
+	const uint32_t R = dp_R(rows);
+	const uint32_t cols = rows + 4 * 15 + 1 + 4;
+	const uint32_t lanes = (rows + R - 1) / R;
+	mat_bytes = (((uint64_t)cols + lanes) * 3 * R * 64 + 255) & ~(uint64_t)255;
+	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
+	const uint64_t rr = ((uint64_t)rows + 255) & ~(uint64_t)255;
+	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + mat_bytes + mask_bytes + rr;
+	arena_stride = (arena_stride + 4095) & ~(uint64_t)4095;
+}
+
+uint64_t align_work_bytes() { return sizeof(Work); }
+
+template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, hipStream_t);
+template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, hipStream_t);
+
+} // namespace bt2g

@@ -1,0 +1,15 @@
+// bt2g_align_kernel.hpp -- launcher for the fused per-read worker kernel.
+#ifndef BT2G_ALIGN_KERNEL_HPP_
+#define BT2G_ALIGN_KERNEL_HPP_
+#include <hip/hip_runtime.h>
+#include "bt2g_align.hpp"
+#include "../../include/bt2g.h"
+namespace bt2g {
+template <typename TOff>
+hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
+                        uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
+                        uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, hipStream_t st);
+void align_scratch_sizes(uint32_t max_len, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& arena_stride);
+uint64_t align_work_bytes();
+}
+#endif

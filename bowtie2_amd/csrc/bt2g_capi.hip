@@ -7,6 +7,7 @@
 #include "../../include/bt2g.h"
 #include "bt2g_index.hpp"
 #include "bt2g_kernels.hpp"
+#include "bt2g_align_kernel.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -30,6 +31,9 @@ struct bt2g_ctx {
 	uint8_t* d_dp_scratch = nullptr;     // wavefront-layout DP scratch
 	uint64_t dp_scratch_bytes = 0;
 	uint32_t n_cu = 0;
+	uint8_t* d_arena = nullptr;          // per-wave Work + DP scratch of the fused worker
+	uint64_t arena_bytes = 0;
+	unsigned int* d_next = nullptr;      // work-queue head
 };
 
 namespace {
@@ -137,6 +141,8 @@ void bt2g_ctx_destroy(bt2g_ctx* c) {
 	free_index(c);
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
 	if (c->d_dp_scratch) (void)hipFree(c->d_dp_scratch);
+	if (c->d_arena) (void)hipFree(c->d_arena);
+	if (c->d_next) (void)hipFree(c->d_next);
 	delete c;
 }
 
@@ -257,6 +263,47 @@ int bt2g_sw_fill_ee_u8(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_proble
 	}
 	e = launch_sw_fill_ee_u8(*sc, d_probs, n, d_rd, d_qu, d_rf, d_mat, d_best, c->d_dp_scratch, per_wave, n_waves, c->d_cnt, st);
 	return e == hipSuccess ? 0 : hip_fail(c, e, "k_sw_fill_ee_u8");
+}
+
+uint64_t bt2g_align_result_stride(uint32_t khits) {
+	if (khits == 0) khits = 1;
+	const uint64_t b = sizeof(bt2g_read_result) + (uint64_t)(khits - 1) * sizeof(bt2g_aln);
+	return (b + 15) & ~(uint64_t)15;
+}
+
+int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_params* d_rparams,
+                     const bt2g_align_params* params, uint32_t max_read_len, void* d_results, void* stream) {
+	int rc = need_loaded(c);
+	if (rc) return rc;
+	if (!reads || !params || (!d_rparams && reads->n_reads) || (!d_results && reads->n_reads)) return fail(c, BT2G_ERR_ARG, "bad argument");
+	if (params->khits < 1 || params->khits > 64) return fail(c, BT2G_ERR_UNSUPPORTED, "-k outside [1,64]");
+	if (params->match_bonus != 0) return fail(c, BT2G_ERR_UNSUPPORTED, "--local scoring is not implemented on the device path");
+	if (reads->n_reads == 0) return 0;
+	if (max_read_len > BT2G_MAX_READ_LEN) max_read_len = BT2G_MAX_READ_LEN;
+	hipStream_t st = (hipStream_t)stream;
+	uint64_t mat_bytes, mask_bytes, arena_stride;
+	align_scratch_sizes(max_read_len, mat_bytes, mask_bytes, arena_stride);
+	// 256-VGPR kernel: 2 waves per SIMD -> 8 per CU resident; persistent waves pull reads from a queue
+	uint32_t n_waves = c->n_cu * 8;
+	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
+	const uint64_t need = arena_stride * n_waves;
+	hipError_t e;
+	if (need > c->arena_bytes) {
+		if (c->d_arena) (void)hipFree(c->d_arena);
+		c->d_arena = nullptr; c->arena_bytes = 0;
+		e = hipMalloc((void**)&c->d_arena, need);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(worker arena)");
+		c->arena_bytes = need;
+	}
+	if (!c->d_next) {
+		e = hipMalloc((void**)&c->d_next, 256);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(queue head)");
+	}
+	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
+	e = (c->off_size == 4)
+		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, st)
+		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, st);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "k_align_reads");
 }
 
 int bt2g_counters_read(bt2g_ctx* c, bt2g_counters* out, int reset, void* stream) {

@@ -1,0 +1,169 @@
+// bt2g_main.cpp -- `bowtie2-align-s` / `bowtie2-align-l` drop-in for the hot path.
+//
+// Accepts the argv the reference's Perl wrapper execs (bowtie2:482: "--wrapper basic-0 ..."),
+// reads FASTQ, runs the per-read worker on the GPU through the C ABI (include/bt2g.h) and
+// writes SAM + the stderr summary in the reference's format.  Options outside the
+// implemented hot path (paired-end, --local, -N 1, other input formats ...) are rejected with
+// an error rather than silently approximated.  There is no CPU alignment path in this binary.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bt2g.h"
+#include "bt2g_host.hpp"
+
+using namespace bt2g;
+
+static void die(const std::string& msg, int code = 1) {
+	fprintf(stderr, "Error: %s\n", msg.c_str());
+	exit(code);
+}
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) die(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct DevBuf {
+	void* p = nullptr; size_t cap = 0;
+	void ensure(size_t n) { if (n > cap) { if (p) (void)hipFree(p); HIP_OK(hipMalloc(&p, n)); cap = n; } }
+	~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+int main(int argc, char** argv) {
+	Options opt;
+	std::string cmdline;
+	for (int i = 0; i < argc; i++) { if (i) cmdline.push_back(' '); cmdline += argv[i]; }
+	opt.cmdline = cmdline;
+	int device = 0;
+	size_t batch_reads = 1u << 20;
+	for (int i = 1; i < argc; i++) {
+		const std::string a = argv[i];
+		auto need = [&](const char* what) -> std::string { if (i + 1 >= argc) die(std::string(what) + " needs an argument"); return argv[++i]; };
+		if (a == "--wrapper") { need("--wrapper"); }
+		else if (a == "-x") opt.index_base = need("-x");
+		else if (a == "-U") opt.reads_file = need("-U");
+		else if (a == "-S") opt.out_file = need("-S");
+		else if (a == "-q") {}
+		else if (a == "-p" || a == "--threads") { opt.threads = atoi(need("-p").c_str()); }
+		else if (a == "--reorder") opt.reorder = true;
+		else if (a == "-t" || a == "--time") opt.timing = true;
+		else if (a == "-k") { opt.khits = atoi(need("-k").c_str()); opt.saw_k = true; }
+		else if (a == "-s" || a == "--skip") opt.skip = strtoull(need("-s").c_str(), nullptr, 10);
+		else if (a == "-u" || a == "--upto") { opt.upto = strtoull(need("-u").c_str(), nullptr, 10); if (opt.upto == 0) opt.upto = UINT64_MAX; }
+		else if (a == "--seed") opt.seed = (uint32_t)strtoul(need("--seed").c_str(), nullptr, 10);
+		else if (a == "--nofw") opt.nofw = true;
+		else if (a == "--norc") opt.norc = true;
+		else if (a == "--end-to-end") {}
+		else if (a == "--no-hd") opt.sam_no_hd = true;
+		else if (a == "--no-sq") opt.sam_no_sq = true;
+		else if (a == "--gpu") device = atoi(need("--gpu").c_str());
+		else if (a == "--batch") batch_reads = strtoull(need("--batch").c_str(), nullptr, 10);
+		else if (a == "-D") opt.max_dp_streak = atoi(need("-D").c_str());
+		else if (a == "-R") opt.n_seed_rounds = atoi(need("-R").c_str());
+		else if (a == "-L") opt.seed_len = atoi(need("-L").c_str());
+		else if (a == "-i") { if (!opt.ms_ival.parse(need("-i"))) die("bad -i function"); }
+		else if (a == "--score-min") { if (!opt.score_min.parse(need("--score-min"))) die("bad --score-min function"); }
+		else if (a == "--n-ceil") { if (!opt.n_ceil.parse(need("--n-ceil"))) die("bad --n-ceil function"); }
+		else if (a.size() > 2 && a.substr(0, 2) == "--" && opt.apply_preset(a.substr(2))) {}
+		else if (a == "-1" || a == "-2" || a == "--local" || a == "-N" || a == "-f" || a == "-c" || a == "-b" || a == "--interleaved")
+			die("option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ, end-to-end, -N 0)", 1);
+		else die("unsupported option " + a);
+	}
+	if (opt.index_base.empty() || opt.reads_file.empty()) die("usage: bowtie2-align-s [options] -x <index> -U <reads.fq> [-S out.sam]");
+
+	bt2g_ctx* ctx = nullptr;
+	int rc = bt2g_ctx_create(device, &ctx);
+	if (rc) die("no usable MI355X (gfx950) device -- this build has no CPU alignment path", 1);
+	HIP_OK(hipSetDevice(device));
+	auto t0 = std::chrono::steady_clock::now();
+	rc = bt2g_index_load(ctx, opt.index_base.c_str());
+	if (rc) die(std::string("could not load index: ") + bt2g_last_error(ctx));
+	bt2g_index_info info;
+	bt2g_index_info_get(ctx, &info);
+	auto t1 = std::chrono::steady_clock::now();
+	RefInfo ref;
+	for (uint64_t i = 0; i < info.n_pat; i++) {
+		const char* nm; uint64_t ln;
+		bt2g_index_refname(ctx, i, &nm, &ln);
+		ref.names.push_back(nm); ref.lens.push_back(ln);
+	}
+	FILE* out = opt.out_file.empty() ? stdout : fopen(opt.out_file.c_str(), "wb");
+	if (!out) die("cannot open output " + opt.out_file);
+	std::string o;
+	sam_header(o, ref, opt.cmdline, !opt.sam_no_hd, !opt.sam_no_sq);
+	fwrite(o.data(), 1, o.size(), out);
+
+	AlignParams P;
+	opt.to_params(P, info.off_size == 8);
+	const uint64_t stride = bt2g_align_result_stride((uint32_t)P.khits);
+
+	FastqReader fq(opt.reads_file);
+	if (!fq.ok()) die("cannot open reads file " + opt.reads_file);
+	DevBuf d_seq, d_qual, d_off, d_rp, d_res;
+	std::vector<ReadRec> reads;
+	std::vector<uint8_t> h_seq, h_qual, h_res;
+	std::vector<uint64_t> h_off;
+	std::vector<ReadParams> h_rp;
+	AlnSummary summ;
+	uint64_t rdid = 0;
+	double align_s = 0;
+	bool eof = false;
+	while (!eof) {
+		reads.clear(); h_seq.clear(); h_qual.clear(); h_off.clear(); h_rp.clear();
+		h_off.push_back(0);
+		uint32_t max_len = 0;
+		while (reads.size() < batch_reads) {
+			ReadRec r;
+			if (!fq.next(r, rdid)) { eof = true; break; }
+			if (rdid >= opt.upto) { eof = true; break; }
+			if (rdid++ < opt.skip) continue;
+			if (r.seq.size() > (size_t)BT2G_MAX_READ_LEN) die("read " + r.name + " is longer than " + std::to_string(BT2G_MAX_READ_LEN) + " bp (not supported on the device path)");
+			h_rp.push_back(compute_read_params(opt, r));
+			h_seq.insert(h_seq.end(), r.seq.begin(), r.seq.end());
+			h_qual.insert(h_qual.end(), r.qual.begin(), r.qual.end());
+			h_off.push_back(h_seq.size());
+			if (r.seq.size() > max_len) max_len = (uint32_t)r.seq.size();
+			reads.push_back(std::move(r));
+		}
+		const size_t n = reads.size();
+		if (n == 0) break;
+		d_seq.ensure(h_seq.size() + 16); d_qual.ensure(h_qual.size() + 16);
+		d_off.ensure(h_off.size() * 8); d_rp.ensure(n * sizeof(ReadParams)); d_res.ensure(n * stride);
+		HIP_OK(hipMemcpy(d_seq.p, h_seq.data(), h_seq.size(), hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d_qual.p, h_qual.data(), h_qual.size(), hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d_off.p, h_off.data(), h_off.size() * 8, hipMemcpyHostToDevice));
+		HIP_OK(hipMemcpy(d_rp.p, h_rp.data(), n * sizeof(ReadParams), hipMemcpyHostToDevice));
+		bt2g_reads rd;
+		rd.d_seq = (const uint8_t*)d_seq.p; rd.d_qual = (const uint8_t*)d_qual.p; rd.d_off = (const uint64_t*)d_off.p; rd.n_reads = (uint32_t)n;
+		auto ta = std::chrono::steady_clock::now();
+		rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &P, max_len, d_res.p, nullptr);
+		if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
+		HIP_OK(hipDeviceSynchronize());
+		align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+		h_res.resize(n * stride);
+		HIP_OK(hipMemcpy(h_res.data(), d_res.p, n * stride, hipMemcpyDeviceToHost));
+		o.clear();
+		for (size_t i = 0; i < n; i++) {
+			const ReadResult& rr = *(const ReadResult*)(h_res.data() + i * stride);
+			if (rr.status) fprintf(stderr, "Warning: read %s exceeded a fixed device work buffer; its alignment may be incomplete\n", reads[i].name.c_str());
+			summ.add(rr);
+			if (rr.aligned) { for (uint32_t k = 0; k < rr.nreport; k++) sam_record(o, opt, ref, reads[i], rr, &rr.alns[k], k == 0); }
+			else sam_record(o, opt, ref, reads[i], rr, nullptr, true);
+			if (o.size() > (1u << 24)) { fwrite(o.data(), 1, o.size(), out); o.clear(); }
+		}
+		fwrite(o.data(), 1, o.size(), out);
+	}
+	if (out != stdout) fclose(out);
+	if (opt.timing) {
+		auto hms = [](double s) { char b[64]; int h = (int)(s / 3600); int m = (int)(s / 60) % 60; int sec = (int)s % 60; snprintf(b, sizeof b, "%02d:%02d:%02d", h, m, sec); return std::string(b); };
+		fprintf(stderr, "Time loading forward index: %s\n", hms(std::chrono::duration<double>(t1 - t0).count()).c_str());
+		fprintf(stderr, "Multiseed full-index search: %s\n", hms(align_s).c_str());
+		fprintf(stderr, "[bt2g] device search time %.3f s\n", align_s);
+	}
+	summ.print(stderr);
+	bt2g_ctx_destroy(ctx);
+	return 0;
+}

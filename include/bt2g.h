@@ -179,6 +179,76 @@ int bt2g_sw_fill_ee_u8(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_prob
                        const uint8_t *d_rd, const uint8_t *d_qu, const uint8_t *d_rf,
                        uint8_t *d_mat, int32_t *d_best, void *stream);
 
+
+/* ---- the fused per-read worker ------------------------------------------ */
+/*
+ * Replaces `static void multiseedSearchWorker(void*)` (bt2_search.cpp:3094-4254) for a whole
+ * batch of unpaired reads: exact end-to-end sweep, 1-mismatch end-to-end search, -N 0 seed
+ * rounds, seed-hit prioritisation, offset resolution, DP framing, end-to-end 8-bit SW fill,
+ * backtrace, redundancy checks, -M/-k reporting state and the final selection -- one
+ * wavefront per read, the reference's RNG draw order reproduced, so that the SAM written
+ * from these records is byte-identical to the reference's.  Scope (rejected otherwise by the
+ * host): unpaired, end-to-end, -N 0, reads <= BT2G_MAX_READ_LEN.
+ */
+#define BT2G_MAX_READ_LEN 512
+#define BT2G_MAX_EDITS    200
+
+/* what bt2_search.cpp keeps in file statics (:69-266), for the options that reach the worker */
+typedef struct {
+	int32_t mm_type, mm_max, mm_min, n_pen, rdgapo, rdgape, rfgapo, rfgape, gapbar, match_bonus;
+	int32_t khits, mhits;          /* -k ; -M (mhits > 0 => -M mode)                         */
+	int32_t max_dp_streak;         /* -D                                                     */
+	int32_t max_ug, max_dp, max_iters;
+	int32_t n_seed_rounds;         /* nSeedRounds (-R)                                       */
+	int32_t seed_boost_thresh, tighten, maxhalf;
+	int32_t nofw, norc;
+	int32_t do_exact_upfront, do_1mm_upfront, do_ungapped, do_extend;
+	int32_t large_index;           /* RNG draws differ in the 64-bit build (aligner_sw_driver.cpp:103-109) */
+} bt2g_align_params;
+
+/* per-read inputs the host derives with the reference's formulas (bt2_search.cpp:3352-3450, pat.cpp:45) */
+typedef struct {
+	int32_t  minsc, interval, nceil, seedlen;
+	uint32_t seed;
+	uint32_t filt;                 /* bit0 nfilt, bit1 scfilt, bit2 lenfilt, bit3 qcfilt (1 = passes) */
+} bt2g_read_params;
+
+typedef struct {                   /* Edit (edit.h:50): pos is w.r.t. the read's 5' end      */
+	uint16_t pos;
+	uint8_t  chr, qchr;            /* reference / read character (ASCII) or '-'              */
+	uint8_t  type;                 /* 1 read gap, 2 ref gap, 3 mismatch (EDIT_TYPE_*)        */
+	uint8_t  pad;
+} bt2g_edit;
+
+typedef struct {                   /* AlnRes (aligner_result.h:792), the fields SAM needs    */
+	int64_t  refoff, reflen;
+	int32_t  refid, score;
+	int16_t  ns, gaps, edits, bases_aligned;
+	uint16_t refns, nned, rdlen, rdextent, rfextent, trim5p, trim3p;
+	uint8_t  fw;
+	uint8_t  pad[5];
+	bt2g_edit ned[BT2G_MAX_EDITS];
+} bt2g_aln;
+
+typedef struct {
+	uint8_t  status;               /* 0 ok; 1 = a fixed-capacity work buffer overflowed      */
+	uint8_t  aligned, maxed, filt, exhausted, has_secbest, pad[2];
+	int32_t  secbest, best;        /* XS:i / MAPQ inputs                                      */
+	uint32_t nalns, nreport;
+	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail_streak_max, n_bwops_seed, n_bwops_ext, n_redundants, n_bt_attempts;
+	bt2g_aln alns[1];              /* nreport (<= khits) entries                              */
+} bt2g_read_result;
+
+/* bytes between consecutive result records for a given -k */
+uint64_t bt2g_align_result_stride(uint32_t khits);
+/*
+ * d_rparams[n_reads]; d_results: n_reads records of bt2g_align_result_stride(khits) bytes.
+ * max_read_len sizes the per-wave DP scratch (longer reads come back with status 1).
+ */
+int bt2g_align_batch(bt2g_ctx *ctx, const bt2g_reads *reads, const bt2g_read_params *d_rparams,
+                     const bt2g_align_params *params, uint32_t max_read_len,
+                     void *d_results, void *stream);
+
 /* ---- instrumentation ---------------------------------------------------- */
 typedef struct {
 	uint64_t rank_queries;    /* # sides read (SURVEY.md 8d unit)             */

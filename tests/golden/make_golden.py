@@ -155,8 +155,30 @@ def rng_golden():
     return out
 
 
+def align_golden(refs):
+    """End-to-end golden: the reference binary's SAM on a fixed read set against the tiny indexes."""
+    rnd = random.Random(31)
+    reads = (synth_reads(refs, 250, 60, seed=41) + synth_reads(refs, 120, 100, seed=42, sub=0.03, ins=0.004, dele=0.004)
+             + synth_reads(refs, 60, 40, seed=43, n_rate=0.02) + synth_reads(refs, 40, 150, seed=44, sub=0.02)
+             + synth_reads(refs, 30, 25, seed=45, len_jitter=10))
+    reads += [("rand%d" % i, "".join(rnd.choice("ACGT") for _ in range(70)), "I" * 70) for i in range(20)]
+    reads += [("polyA", "A" * 60, "I" * 60), ("oneN", "N", "I"), ("short", "ACG", "III")]
+    rnd.shuffle(reads)
+    fq = os.path.join(HERE, "align_reads.fq")
+    write_fastq(fq, reads)
+    for large in (False, True):
+        exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
+        base = os.path.join(HERE, "tiny_l" if large else "tiny_s")
+        for tag, args in (("sens", ["--sensitive"]), ("vfast", ["--very-fast"])):
+            out = os.path.join(HERE, "align_golden_%s_%s.sam" % ("l" if large else "s", tag))
+            subprocess.check_call([exe] + args + ["-x", base, "-U", fq, "-p", "1", "-S", out], stderr=subprocess.DEVNULL)
+            lines = [l for l in open(out) if not l.startswith("@PG")]
+            open(out, "w").writelines(lines)
+
+
 if __name__ == "__main__":
     refs = build_tiny()
+    align_golden(refs)
     for large in (False, True):
         with open(os.path.join(HERE, "fm_golden_%s.json" % ("l" if large else "s")), "w") as f:
             json.dump(fm_golden(large, refs), f, separators=(",", ":"))

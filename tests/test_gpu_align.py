@@ -1,0 +1,82 @@
+"""End-to-end parity of the fused per-read worker on the GPU: the drop-in binary
+(bowtie2_amd/bin/bowtie2-align-s -> libbt2g.so -> k_align_reads) must write SAM byte-identical to the
+reference's, on the committed golden read set and -- where oracle/_ref travelled along -- on a larger
+repeat-rich synthetic genome across presets and both index widths."""
+import os
+import random
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from bt2test import (CACHE_DIR, build_index, have_ref, ref_bin, synth_genome, synth_reads, write_fasta, write_fastq)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+EXE = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-s")
+
+
+def run_ours(args, timeout=300):
+    p = subprocess.run([EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return [l for l in p.stdout.splitlines() if not l.startswith("@PG")], p.stderr
+
+
+@pytest.mark.parametrize("idx,tag,args", [("tiny_s", "s_sens", ["--sensitive"]), ("tiny_s", "s_vfast", ["--very-fast"]),
+                                           ("tiny_l", "l_sens", ["--sensitive"]), ("tiny_l", "l_vfast", ["--very-fast"])])
+def test_golden_sam(idx, tag, args):
+    got, err = run_ours(args + ["-x", os.path.join(GOLD, idx), "-U", os.path.join(GOLD, "align_reads.fq")])
+    want = open(os.path.join(GOLD, "align_golden_%s.sam" % tag)).read().splitlines()
+    assert "Warning" not in err
+    assert got == want
+
+
+def repeat_genome():
+    rnd = random.Random(5)
+    refs = synth_genome(n_refs=3, total=200000, seed=21)
+    elem = "".join(rnd.choice("ACGT") for _ in range(300))
+    out = []
+    for name, s in refs:
+        s = list(s)
+        for _ in range(25):
+            p = rnd.randrange(0, len(s) - 400)
+            s[p:p + 300] = [c if rnd.random() > 0.02 else rnd.choice("ACGT") for c in elem]
+        p = rnd.randrange(0, len(s) - 400)
+        s[p:p + 200] = list("A" * 200)
+        p = rnd.randrange(0, len(s) - 400)
+        s[p:p + 200] = list("AC" * 100)
+        out.append((name, "".join(s)))
+    reads = (synth_reads(out, 2500, 100, seed=1) + synth_reads(out, 1200, 150, seed=2, sub=0.03, ins=0.005, dele=0.005)
+             + synth_reads(out, 600, 50, seed=3, n_rate=0.01) + synth_reads(out, 500, 250, seed=4, sub=0.02)
+             + synth_reads(out, 200, 30, seed=5, len_jitter=12))
+    reads += [("rand%d" % i, "".join(rnd.choice("ACGT") for _ in range(100)), "I" * 100) for i in range(100)]
+    for i in range(150):
+        p = rnd.randrange(0, 200)
+        s = "".join(c if rnd.random() > 0.01 else rnd.choice("ACGT") for c in elem[p:p + 100])
+        reads.append(("el%d" % i, s, "".join(rnd.choice("GGG?5-") for _ in s)))
+    reads += [("polyA", "A" * 100, "I" * 100), ("acac", "AC" * 50, "I" * 100)]
+    rnd.shuffle(reads)
+    return out, reads
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("large", [False, True], ids=["bt2", "bt2l"])
+def test_differential_vs_reference_binary(large):
+    d = os.path.join(CACHE_DIR, "rep_%s" % ("l" if large else "s"))
+    os.makedirs(d, exist_ok=True)
+    refs, reads = repeat_genome()
+    fa, fq, base = os.path.join(d, "rep.fa"), os.path.join(d, "rep.fq"), os.path.join(d, "rep")
+    write_fasta(fa, refs)
+    write_fastq(fq, reads)
+    build_index(fa, base, large)
+    ref_exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
+    for args in (["--sensitive"], ["--very-sensitive"], ["--very-fast"], ["--sensitive", "--norc"]):
+        rs = os.path.join(d, "ref.sam")
+        subprocess.check_call([ref_exe] + args + ["-x", base, "-U", fq, "-p", "8", "--reorder", "-S", rs], stderr=subprocess.DEVNULL)
+        want = [l.rstrip("\n") for l in open(rs) if not l.startswith("@PG")]
+        got, err = run_ours(args + ["-x", base, "-U", fq])
+        assert "Warning" not in err
+        assert len(got) == len(want)
+        bad = [i for i in range(len(got)) if got[i] != want[i]]
+        assert not bad, (args, len(bad), want[bad[0]], got[bad[0]])

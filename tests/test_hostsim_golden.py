@@ -1,0 +1,29 @@
+"""Host logic: the per-read worker's control code (compiled for the CPU by tests/hostsim, test-only)
+must reproduce the reference's SAM byte for byte on the committed golden read set."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+HS = os.path.join(ROOT, "tests", "hostsim")
+
+
+@pytest.fixture(scope="module")
+def hostsim():
+    exe = os.path.join(HS, "hostsim")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp")])
+    return exe
+
+
+@pytest.mark.parametrize("idx,tag,args", [("tiny_s", "s_sens", ["--sensitive"]), ("tiny_s", "s_vfast", ["--very-fast"]),
+                                           ("tiny_l", "l_sens", ["--sensitive"]), ("tiny_l", "l_vfast", ["--very-fast"])])
+def test_sam_identical_to_reference(hostsim, idx, tag, args):
+    p = subprocess.run([hostsim] + args + ["-x", os.path.join(GOLD, idx), "-U", os.path.join(GOLD, "align_reads.fq")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
+    got = [l for l in p.stdout.splitlines() if not l.startswith("@PG")]
+    want = open(os.path.join(GOLD, "align_golden_%s.sam" % tag)).read().splitlines()
+    assert got == want
+    assert "overall alignment rate" in p.stderr
