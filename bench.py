@@ -105,7 +105,7 @@ def build_index(base, threads):
         raise RuntimeError("oracle/_ref/bowtie2-build-s missing: run __graft_entry__.build() where /root/reference exists")
     t0 = time.time()
     # bowtie2-build's blockwise suffix sorter scales poorly past a few dozen threads
-    subprocess.check_call([exe, "--threads", str(min(threads, 32)), "-q", base + ".fa", base], stdout=subprocess.DEVNULL)
+    subprocess.check_call([exe, "--threads", str(min(threads, 16)), "-q", base + ".fa", base], stdout=subprocess.DEVNULL)
     log("[bench] index built in %.1fs" % (time.time() - t0))
 
 
@@ -190,8 +190,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BT2_BENCH_MBP", "64")))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("BT2_BENCH_READS", "1000000")), help="reads per GPU per step")
+    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BT2_BENCH_MBP", "32")))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BT2_BENCH_READS", "200000")), help="reads per GPU per step")
     ap.add_argument("--readlen", type=int, default=150)
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BT2_BENCH_CPU_SAMPLE", "200000")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,27 +232,34 @@ def main():
     batch = b.ReadBatch(seq.view(-1), qual.view(-1), off, n)
 
     # --sensitive, 150 bp: -L 22, -i S,1,1.15 -> interval 1+1.15*sqrt(150) = 15 (bt2_search.cpp:3443-3450)
+    import ctypes as C
     import math
+    import numpy as np
     L = 22
     interval = max(1, int(1 + 1.15 * math.sqrt(args.readlen)))
-    max_seeds = 1 + (args.readlen - L) // interval
-    seedlen_t = torch.full((n,), L, dtype=torch.int32, device=dev)
-    interval_t = torch.full((n,), interval, dtype=torch.int32, device=dev)
-    offset_t = torch.zeros(n, dtype=torch.int32, device=dev)
+    P = b.AlignParams(mm_type=3, mm_max=6, mm_min=2, n_pen=1, rdgapo=8, rdgape=3, rfgapo=8, rfgape=3, gapbar=4, match_bonus=0,
+                      khits=1, mhits=50, max_dp_streak=15, max_ug=300, max_dp=300, max_iters=400, n_seed_rounds=2,
+                      seed_boost_thresh=300, tighten=3, maxhalf=15, nofw=0, norc=0, do_exact_upfront=1, do_1mm_upfront=1,
+                      do_ungapped=1, do_extend=1, large_index=1 if info.off_size == 8 else 0)
+    # per-read parameters as the host derives them (minsc = (long)(-0.6 + -0.6*len), nceil = 0.15*len; seeds from read content)
+    minsc = int(-0.6 + -0.6 * args.readlen)
+    rp = np.zeros(n, dtype=[("minsc", "<i4"), ("interval", "<i4"), ("nceil", "<i4"), ("seedlen", "<i4"), ("seed", "<u4"), ("filt", "<u4")])
+    rp["minsc"] = minsc; rp["interval"] = interval; rp["nceil"] = int(0.15 * args.readlen); rp["seedlen"] = L; rp["filt"] = 15
+    rp["seed"] = np.random.default_rng(7 + rank).integers(0, 2**32, size=n, dtype=np.uint32)   # stands in for genRandSeed(name,seq,qual)
+    rp_t = torch.from_numpy(rp.view(np.uint8).copy()).to(dev)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     stage_events = []
+    last = {}
 
     def step(record):
-        e0, e1, e2 = ev(), ev(), ev()
+        e0, e1 = ev(), ev()
         e0.record()
-        sw = ctx.exact_sweep(batch, False, False, 2)
+        res, stride = ctx.align_batch(batch, rp_t, P, args.readlen)
         e1.record()
-        sd = ctx.seed_search_exact(batch, seedlen_t, interval_t, offset_t, max_seeds)
-        e2.record()
         if record:
-            stage_events.append((e0, e1, e2))
-        return sw, sd
+            stage_events.append((e0, e1))
+        last["res"], last["stride"] = res, stride
 
     def sync_all():
         torch.cuda.synchronize()
@@ -263,7 +270,6 @@ def main():
     for _ in range(args.warmup):
         step(False)
     sync_all()
-    ctx.counters(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -273,27 +279,32 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    cnt = ctx.counters()
+    kern_ms = sum(a.elapsed_time(bb) for a, bb in stage_events) / len(stage_events)
 
-    sweep_ms = sum(a.elapsed_time(bb) for a, bb, _ in stage_events) / len(stage_events)
-    seed_ms = sum(bb.elapsed_time(c) for _, bb, c in stage_events) / len(stage_events)
+    # per-read work counters come back in the result records
+    stride = last["stride"]
+    rec = last["res"].view(n, stride)[:, :C.sizeof(b.ReadResult) - C.sizeof(b.Aln)].cpu().numpy()
+    hdr = np.dtype([("status", "u1"), ("aligned", "u1"), ("maxed", "u1"), ("filt", "u1"), ("exhausted", "u1"), ("has_secbest", "u1"),
+                    ("pad", "u1", 2), ("secbest", "<i4"), ("best", "<i4"), ("nalns", "<u4"), ("nreport", "<u4"),
+                    ("n_ex_iters", "<u4"), ("n_ex_dps", "<u4"), ("n_ex_ugs", "<u4"), ("n_dp_fail_streak_max", "<u4"),
+                    ("n_bwops_seed", "<u4"), ("n_bwops_ext", "<u4"), ("n_redundants", "<u4"), ("n_bt_attempts", "<u4")])
+    h = np.frombuffer(rec.tobytes(), dtype=hdr)
+    aligned = int(h["aligned"].sum())
+    all_aligned = aligned
+    if dist is not None:
+        t = torch.tensor([aligned], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        all_aligned = int(t.item())
 
     if rank == 0:
-        # dominant kernel = the exact sweep (most rank queries).  Algorithmic bytes:
-        # side_sz per rank query; the device counters give the exact number of sides read.
         steps = args.steps
-        # per-launch rank queries of each kernel are not separable from one counter; measure the split once
-        ctx.counters(reset=True)
-        ctx.exact_sweep(batch, False, False, 2)
-        c_sw = ctx.counters(reset=True)
-        ctx.seed_search_exact(batch, seedlen_t, interval_t, offset_t, max_seeds)
-        c_sd = ctx.counters(reset=True)
         side = info.side_sz
         off_sz = info.off_size
-        sw_bytes = c_sw.rank_queries * side + c_sw.ftab_lookups * 2 * off_sz + n * args.readlen + n * 48
-        sd_bytes = c_sd.rank_queries * side + c_sd.ftab_lookups * 2 * off_sz + n * args.readlen + n * 2 * max_seeds * 32
-        dom = ("k_exact_sweep", sw_bytes, sweep_ms) if sweep_ms >= seed_ms else ("k_seed_search_exact", sd_bytes, seed_ms)
-        achieved = dom[1] / (dom[2] * 1e-3) / 1e9
+        rankq = float(h["n_bwops_seed"].sum() + h["n_bwops_ext"].sum())   # one BW op ~= one pair/quad query; sides read <= 2 per op
+        dp_cells = float(h["n_ex_dps"].sum()) * args.readlen * (args.readlen + 61)
+        # algorithmic bytes per launch: rank queries * side_sz + DP ref windows + reads in + results out
+        alg_bytes = rankq * 1.5 * side + h["n_ex_dps"].sum() * ((args.readlen + 61 + 3) // 4) + n * args.readlen * 2 + n * stride
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         res = {
             "metric": "aligned reads/sec (whole node), 150 bp SE, synthetic genome (hg38 unavailable offline)",
             "value": world * n * steps / dt,
@@ -301,19 +312,22 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32" if off_sz == 4 else "u64", "data": "synthetic",
+            "dtype": "u8/u32" if off_sz == 4 else "u8/u64", "data": "synthetic",
             "config": {
-                "workload": "synthetic %d Mbp genome (.bt2, built by reference bowtie2-build), %d x %d bp SE reads per GPU per step, --sensitive (-L 22 -i S,1,1.15)"
+                "workload": "synthetic %d Mbp genome (.bt2, built by reference bowtie2-build), %d x %d bp SE reads per GPU per step, --sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"
                             % (args.genome_mbp, n, args.readlen),
-                "stages_timed": ["exact end-to-end sweep (SeedAligner::exactSweep)", "exact multiseed search round 0 (searchAllSeeds)"],
-                "stages_not_yet_on_gpu": ["1-mismatch e2e search", "seed extension / SW / reporting (extendSeeds)"],
+                "stages_timed": "whole per-read worker: exact sweep, 1-mm e2e search, seed rounds, prioritise, offset resolution, SW fill + backtrace, -M reporting (k_align_reads)",
+                "not_in_timed_region": "FASTQ parse and SAM text formatting (host side, SURVEY.md 8f)",
+                "fraction_aligned": all_aligned / float(world * n),
                 "index_bytes_hbm": int(info.hbm_bytes), "side_sz": int(side),
-                "rank_queries_per_read": (c_sw.rank_queries + c_sd.rank_queries) / n,
-                "ms_exact_sweep": sweep_ms, "ms_seed_search": seed_ms,
+                "bw_ops_per_read": rankq / n, "dp_fills_per_read": float(h["n_ex_dps"].sum()) / n,
+                "backtraces_per_read": float(h["n_bt_attempts"].sum()) / n,
+                "reads_overflowed": int((h["status"] != 0).sum()),
             },
-            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_align_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": int(dom[1]), "avg_launch_ms": dom[2]},
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": kern_ms,
+                         "dp_gcups": dp_cells / (kern_ms * 1e-3) / 1e9},
         }
         cb = None
         if not args.no_cpu_baseline:
