@@ -270,6 +270,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     sync_all()
+    ctx.align_profile(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -280,6 +281,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = sum(a.elapsed_time(bb) for a, bb in stage_events) / len(stage_events)
+    prof = ctx.align_profile()
 
     # per-read work counters come back in the result records
     stride = last["stride"]
@@ -300,10 +302,11 @@ def main():
         steps = args.steps
         side = info.side_sz
         off_sz = info.off_size
-        rankq = float(h["n_bwops_seed"].sum() + h["n_bwops_ext"].sum())   # one BW op ~= one pair/quad query; sides read <= 2 per op
+        rankq = float(h["n_bwops_seed"].sum() + h["n_bwops_ext"].sum())
+        sides_per_launch = prof[8] / float(args.steps)
         dp_cells = float(h["n_ex_dps"].sum()) * args.readlen * (args.readlen + 61)
         # algorithmic bytes per launch: rank queries * side_sz + DP ref windows + reads in + results out
-        alg_bytes = rankq * 1.5 * side + h["n_ex_dps"].sum() * ((args.readlen + 61 + 3) // 4) + n * args.readlen * 2 + n * stride
+        alg_bytes = sides_per_launch * side + h["n_ex_dps"].sum() * ((args.readlen + 61 + 3) // 4) + n * args.readlen * 2 + n * stride
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         res = {
             "metric": "aligned reads/sec (whole node), 150 bp SE, synthetic genome (hg38 unavailable offline)",
@@ -323,6 +326,8 @@ def main():
                 "bw_ops_per_read": rankq / n, "dp_fills_per_read": float(h["n_ex_dps"].sum()) / n,
                 "backtraces_per_read": float(h["n_bt_attempts"].sum()) / n,
                 "reads_overflowed": int((h["status"] != 0).sum()),
+                "phase_us_per_read": dict(zip(["sweep", "mm1", "seeds", "rank_prioritise", "resolve", "dp_fill", "gather_backtrace", "whole_read"], [round(prof[i] / 100.0 / max(1, prof[9]), 1) for i in range(8)])),
+                "sides_per_read": prof[8] / max(1, prof[9]),
             },
             "roofline": {"bound": "hbm", "kernel": "k_align_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -113,6 +113,7 @@ ABI = [
     ("bt2g_scoring_default", None, [C.POINTER(Scoring)]),
     ("bt2g_sw_fill_ee_u8", C.c_int, [_vp, C.POINTER(Scoring), _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("bt2g_counters_read", C.c_int, [_vp, C.POINTER(Counters), C.c_int, _vp]),
+    ("bt2g_align_profile_read", C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
     ("bt2g_align_result_stride", C.c_uint64, [C.c_uint32]),
     ("bt2g_align_batch", C.c_int, [_vp, C.POINTER(Reads), _vp, C.POINTER(AlignParams), C.c_uint32, _vp, _vp]),
 ]
@@ -249,6 +250,11 @@ class Context:
         _check(self._h, lib().bt2g_align_batch(self._h, C.byref(rd), rparams.data_ptr(), C.byref(params), max_read_len,
                                                 out.data_ptr(), _stream_ptr()), "bt2g_align_batch")
         return out, stride
+
+    def align_profile(self, reset=False):
+        out = (C.c_uint64 * 16)()
+        _check(self._h, lib().bt2g_align_profile_read(self._h, out, int(reset), _stream_ptr()), "bt2g_align_profile_read")
+        return list(out)
 
     def counters(self, reset=False):
         c = Counters()

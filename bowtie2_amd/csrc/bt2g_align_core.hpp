@@ -13,6 +13,8 @@ namespace bt2g {
 
 template <typename TOff, typename Plat>
 struct Aligner {
+	BT2_HD static uint64_t now() { return Plat::clock(); }
+
 	const DevIndex<TOff>& ix;
 	const AlignParams& P;
 	const ReadParams& rp;
@@ -35,7 +37,7 @@ struct Aligner {
 		if (bot - top > 1) {
 			bwops += 2;
 			TOff nt, nb;
-			rank1_pair(e, top, bot, c, nt, nb);
+			w.n_sides += rank1_pair(e, top, bot, c, nt, nb);
 			top = nt; bot = nb;
 		} else {
 			bwops++;
@@ -112,7 +114,7 @@ struct Aligner {
 
 	// mapBiLFEx (bt2_idx.h:2372): t/b for all chars in `e`, tp/bp prefix sums starting at topp
 	BT2_HD void bi_lf(const DevEbwt<TOff>& e, TOff top, TOff bot, TOff topp, TOff t[4], TOff b[4], TOff tp[4], TOff bp[4]) {
-		rank4_pair(e, top, bot, t, b);
+		w.n_sides += rank4_pair(e, top, bot, t, b);
 		tp[0] = topp;
 		bp[0] = tp[0] + (b[0] - t[0]);
 		tp[1] = bp[0]; bp[1] = tp[1] + (b[1] - t[1]);
@@ -321,7 +323,7 @@ struct Aligner {
 					if (botf - topf > 1) {
 						TOff t[4], b[4];
 						w.n_bwops_seed++;
-						rank4_pair(ix.fw, topf, botf, t, b);
+						w.n_sides += rank4_pair(ix.fw, topf, botf, t, b);
 						TOff tp = topb;
 						for (int j = 0; j < c; j++) tp += b[j] - t[j];
 						if (b[c] == t[c]) { ok = false; break; }
@@ -1163,7 +1165,7 @@ struct Aligner {
 				if (minsc == perfect) return EXT_PERFECT_SCORE;
 				if (first_extend) {
 					nelt = 0;
-					prioritize(seedmms, max_iters, nelt);
+					{ const uint64_t t0_ = now(); prioritize(seedmms, max_iters, nelt); w.t_phase[3] += now() - t0_; }
 					nelt_left = nelt;
 					first_extend = false;
 				}
@@ -1194,8 +1196,10 @@ struct Aligner {
 					const uint32_t elt = r1n_next(sp.rnd);
 					// GroupWalk2S::advanceElement == Ebwt::getOffset(topf + elt)
 					uint32_t steps = 0;
+					const uint64_t tr_ = now();
 					const TOff joff = get_offset(ix.fw, (TOff)(sp.topf + elt), steps);
-					w.n_bwops_ext += steps;
+					w.t_phase[4] += now() - tr_;
+					w.n_bwops_ext += steps; w.n_sides += steps;
 					if (!ee_mode) nelt_left--;
 					TOff tidx = 0, toff = 0, tlen = 0;
 					bool straddled = false;
@@ -1266,14 +1270,16 @@ struct Aligner {
 						if (!found) continue;
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
 						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { w.err |= ERR_OVERFLOW; return EXT_HARD_LIMIT; }
-						fetch_ref_window(tidx, rect.refl, cols + 1);
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
 						// SwAligner::align (aligner_sw.cpp:500-729), end-to-end 8-bit path
+						const uint64_t td_ = now();
+						fetch_ref_window(tidx, rect.refl, cols + 1);
 						const int best_u8 = Plat::dp_fill_ee_u8(P, w, fw, rows, cols, dp.mat);
+						w.t_phase[5] += now() - td_;
 						const int64_t best = (int64_t)best_u8 - 0xff;
 						w.n_ex_dps++;
 						found = best >= minsc;
-						if (found) { gather_cells(rows, cols, minsc); found = w.n_cands > 0; }
+						if (found) { const uint64_t tg_ = now(); gather_cells(rows, cols, minsc); found = w.n_cands > 0; w.t_phase[6] += now() - tg_; }
 						if (!found) {
 							w.n_dp_fail++;
 							if (w.n_dp_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
@@ -1288,7 +1294,10 @@ struct Aligner {
 							if (!first_inner) break;
 						} else {
 							if (w.cural == w.n_cands) break;
-							if (!next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, res)) break;
+							const uint64_t tb_ = now();
+							const bool na_ = next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, res);
+							w.t_phase[6] += now() - tb_;
+							if (!na_) break;
 						}
 						first_inner = false;
 						// fell entirely outside the reference?
@@ -1337,7 +1346,9 @@ struct Aligner {
 		w.n_alns = 0; w.best_unp1 = w.best2_unp1 = INT64_MIN; w.done_unpair1 = 0; w.exit_m = w.exit_k = 0;
 		w.n_diags = 0; w.n_red = 0; w.n_ex_fw = w.n_ex_rc = 0;
 		w.n_ex_iters = w.n_ex_dps = w.n_ex_ugs = w.n_dp_fail = w.n_ug_fail = w.n_ee_fail = w.n_dp_fail_streak = 0;
-		w.n_redundants = w.n_bwops_seed = w.n_bwops_ext = w.n_bt_attempts = 0;
+		w.n_redundants = w.n_bwops_seed = w.n_bwops_ext = w.n_bt_attempts = 0; w.n_sides = 0;
+		for (int i_ = 0; i_ < 8; i_++) w.t_phase[i_] = 0;
+		const uint64_t t_run0_ = now();
 		w.n_mm1 = 0; w.mm1_elt = 0; w.nonz_tot = 0; w.n_rank = 0; w.num_offs = 0; w.num_elts = 0;
 		w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0;
 		minsc = rp.minsc;
@@ -1351,7 +1362,7 @@ struct Aligner {
 			uint32_t mine[2] = {0, 0};
 			uint64_t nelt = 0;
 			if (P.do_exact_upfront) {
-				nelt = exact_sweep(2, mine);
+				{ const uint64_t t0_ = now(); nelt = exact_sweep(2, mine); w.t_phase[0] += now() - t0_; }
 				if (nelt == 0) { w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0; }
 				else {
 					const int ret = extend_seeds(-1, 0, 0);
@@ -1365,7 +1376,7 @@ struct Aligner {
 					const bool yfw = mine[0] <= 1 && !P.nofw;
 					const bool yrc = mine[1] <= 1 && !P.norc;
 					nelt = 0;
-					if (yfw || yrc) { one_mm_search(!yfw, !yrc); nelt = w.mm1_elt; }
+					if (yfw || yrc) { const uint64_t t0_ = now(); one_mm_search(!yfw, !yrc); nelt = w.mm1_elt; w.t_phase[1] += now() - t0_; }
 					if (nelt > 0) {
 						const int ret = extend_seeds(-1, 0, 0);
 						w.n_mm1 = 0; w.mm1_elt = 0;
@@ -1383,16 +1394,19 @@ struct Aligner {
 				if (interval <= roundi) continue;
 				const uint32_t offset = (interval * roundi) / nrounds;
 				if (offset > 0 && (uint32_t)rp.seedlen + offset > len) continue;
+				const uint64_t ts_ = now();
 				const uint32_t ninst = seed_round(offset, interval, (uint32_t)rp.seedlen);
+				w.t_phase[2] += now() - ts_;
 				if (ninst == 0) { done = true; w.nonz_tot = 0; continue; }
 				if (w.nonz_tot == 0) { done = true; continue; }
-				rank_seed_hits();
+				{ const uint64_t t0_ = now(); rank_seed_hits(); w.t_phase[3] += now() - t0_; }
 				const int ret = extend_seeds(0, rp.seedlen, (int)interval);
 				handle_ret(ret, done);
 				if (!done && w.nonz_tot > 0 && (w.num_elts / w.nonz_tot) < (uint64_t)P.seed_boost_thresh) done = true;
 			}
 		}
 		finish(out);
+		w.t_phase[7] = now() - t_run0_;
 	}
 
 	// AlnSinkWrap::finishRead for an unpaired read (aln_sink.cpp:643-1384): ReportingState::finish,

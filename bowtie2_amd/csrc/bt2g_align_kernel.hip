@@ -82,6 +82,7 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 }
 
 struct DevPlat {
+	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
 	static __device__ __forceinline__ void zero_u8(uint8_t* p, uint32_t n) {
 		wave_fence();
 		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) p[i] = 0;
@@ -114,7 +115,7 @@ template <typename TOff>
 __global__ void __launch_bounds__(64)
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
-              uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read) {
+              uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	Work& w = *reinterpret_cast<Work*>(base);
@@ -143,18 +144,23 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		Aligner<TOff, DevPlat> al(ix, P, rp, w, dp);
 		al.run(out);
 		wave_fence();
+		if (lane == 0 && prof) {
+			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)w.t_phase[i]);
+			atomicAdd(&prof[8], (unsigned long long)w.n_sides);
+			atomicAdd(&prof[9], 1ull);
+		}
 	}
 }
 
 template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
-                        uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, hipStream_t st) {
+                        uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof, hipStream_t st) {
 	if (rd.n_reads == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
-	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next);
+	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof);
 	return hipGetLastError();
 }
 
@@ -172,7 +178,7 @@ void align_scratch_sizes(uint32_t max_len, uint64_t& mat_bytes, uint64_t& mask_b
 
 uint64_t align_work_bytes() { return sizeof(Work); }
 
-template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, hipStream_t);
-template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, hipStream_t);
+template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, hipStream_t);
+template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, hipStream_t);
 
 } // namespace bt2g

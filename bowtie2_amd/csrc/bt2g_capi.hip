@@ -298,12 +298,25 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (!c->d_next) {
 		e = hipMalloc((void**)&c->d_next, 256);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(queue head)");
+		(void)hipMemset(c->d_next, 0, 256);
 	}
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	e = (c->off_size == 4)
-		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, st)
-		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, st);
+		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), st)
+		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), st);
 	return e == hipSuccess ? 0 : hip_fail(c, e, "k_align_reads");
+}
+
+int bt2g_align_profile_read(bt2g_ctx* c, uint64_t* out16, int reset, void* stream) {
+	if (!c || !out16) return BT2G_ERR_ARG;
+	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
+	hipStream_t st = (hipStream_t)stream;
+	memset(out16, 0, 16 * 8);
+	if (!c->d_next) return 0;
+	hipError_t e = hipMemcpyAsync(out16, c->d_next + 16, 16 * 8, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_next + 16, 0, 16 * 8, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "read profile");
 }
 
 int bt2g_counters_read(bt2g_ctx* c, bt2g_counters* out, int reset, void* stream) {

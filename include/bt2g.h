@@ -249,6 +249,13 @@ int bt2g_align_batch(bt2g_ctx *ctx, const bt2g_reads *reads, const bt2g_read_par
                      const bt2g_align_params *params, uint32_t max_read_len,
                      void *d_results, void *stream);
 
+/*
+ * Device-clock ticks (100 MHz wall clock) the fused worker spent per phase, summed over reads since the last
+ * reset: [0] exact sweep [1] 1-mm search [2] seed search [3] rank+prioritise [4] offset resolution
+ * [5] ref fetch + DP fill [6] gather + backtrace [7] whole read; [8] sides read; [9] reads.
+ */
+int bt2g_align_profile_read(bt2g_ctx *ctx, uint64_t *out16, int reset, void *stream);
+
 /* ---- instrumentation ---------------------------------------------------- */
 typedef struct {
 	uint64_t rank_queries;    /* # sides read (SURVEY.md 8d unit)             */

@@ -18,6 +18,7 @@
 using namespace bt2g;
 
 struct HostPlat {
+	static uint64_t clock() { return 0; }
 	static void zero_u8(uint8_t* p, uint32_t n) { memset(p, 0, n); }
 	static void zero_u16(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
 	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
