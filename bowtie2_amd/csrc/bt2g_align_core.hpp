@@ -31,6 +31,9 @@ struct Aligner {
 	// A. end-to-end exact / 1-mismatch search and exact seeds
 	// =================================================================================
 
+	BT2_HD TOff lf1c(const DevEbwt<TOff>& e, TOff row, int c) { w.n_sides++; return map_lf1c(e, row, c); }
+	BT2_HD int lf1(const DevEbwt<TOff>& e, TOff& row) { if (row != e.zoff) w.n_sides++; return map_lf1(e, row); }
+
 	// One (top,bot) LF step as exactSweepMapLF does (aligner_seed.cpp:793-824)
 	BT2_HD void pair_lf(const DevEbwt<TOff>& e, int c, TOff& top, TOff& bot, uint32_t& bwops) {
 		if (c > 3) { top = bot = 0; return; }
@@ -41,13 +44,13 @@ struct Aligner {
 			top = nt; bot = nb;
 		} else {
 			bwops++;
-			const TOff t = map_lf1c(e, top, c);
+			const TOff t = lf1c(e, top, c);
 			if (t == kOffMask) { top = bot = 0; } else { top = t; bot = t + 1; }
 		}
 	}
 
 	// SeedAligner::exactSweep (aligner_seed.cpp:856-970); returns nelt
-	BT2_HD uint64_t exact_sweep(uint32_t mine_max, uint32_t mine[2]) {
+	BT2_HDN uint64_t exact_sweep(uint32_t mine_max, uint32_t mine[2]) {
 		const DevEbwt<TOff>& e = ix.fw;
 		const uint32_t len = w.len, ftab_len = e.ftab_chars;
 		uint64_t nelt = 0;
@@ -135,7 +138,7 @@ struct Aligner {
 	}
 
 	// SeedAligner::oneMmSearch with repex=false, rep1mm=true (aligner_seed.cpp:975-1325)
-	BT2_HD void one_mm_search(bool nofw, bool norc) {
+	BT2_HDN void one_mm_search(bool nofw, bool norc) {
 		const uint32_t len = w.len;
 		const int nceil = rp.nceil;    // sc.nCeil.f<int>(len); equal to the clamped value unless > len
 		w.n_mm1 = 0; w.mm1_elt = 0;
@@ -188,7 +191,7 @@ struct Aligner {
 						topp = tp[rdc]; botp = bp[rdc];
 					} else {
 						w.n_bwops_seed++;
-						top = map_lf1c(e, top, rdc);
+						top = lf1c(e, top, rdc);
 						if (top == kOffMask) { do_continue = true; break; }
 						bot = top + 1;
 					}
@@ -209,7 +212,7 @@ struct Aligner {
 					} else {
 						w.n_bwops_seed++;
 						TOff row = top;
-						clo = map_lf1(e, row);
+						clo = lf1(e, row);
 						match = (clo == rdc);
 						if (clo < 0) break;
 						top = row;
@@ -234,7 +237,7 @@ struct Aligner {
 									if (botm <= topm) break;
 								} else {
 									w.n_bwops_seed++;
-									topm = map_lf1c(e, topm, rdcm);
+									topm = lf1c(e, topm, rdcm);
 									if (topm == kOffMask) break;
 									botm = topm + 1;
 								}
@@ -271,7 +274,7 @@ struct Aligner {
 
 	// One -N 0 seeding round: Seed::mmSeeds + instantiateSeeds + searchAllSeeds
 	// (aligner_seed.cpp:498-720,1638-2037).  Returns # instantiated seeds.
-	BT2_HD uint32_t seed_round(uint32_t offset, uint32_t interval, uint32_t seedlen) {
+	BT2_HDN uint32_t seed_round(uint32_t offset, uint32_t interval, uint32_t seedlen) {
 		const uint32_t len = w.len;
 		uint32_t L = seedlen < len ? seedlen : len;
 		uint32_t nseeds = 1;
@@ -330,7 +333,7 @@ struct Aligner {
 						topf = t[c]; botf = b[c]; topb = tp; botb = tp + (b[c] - t[c]);
 					} else {
 						w.n_bwops_seed++;
-						const TOff t = map_lf1c(ix.fw, topf, c);
+						const TOff t = lf1c(ix.fw, topf, c);
 						if (t == kOffMask) { ok = false; break; }
 						topf = t; botf = t + 1;
 					}
@@ -350,7 +353,7 @@ struct Aligner {
 	BT2_HD uint64_t hit_elts(int fwi, uint32_t i) const { return w.hits[fwi][i].botf - w.hits[fwi][i].topf; }
 
 	// SeedResults::rankSeedHits, all=false (aligner_seed.h:1019-1080)
-	BT2_HD void rank_seed_hits() {
+	BT2_HDN void rank_seed_hits() {
 		w.n_rank = 0;
 		while (w.n_rank < w.nonz_tot) {
 			uint64_t minsz = 0xffffffffull;      // MAX_U32 even for large indexes, as in the reference
@@ -397,7 +400,7 @@ struct Aligner {
 		w.lists_used += n;
 		return o;
 	}
-	BT2_HD uint32_t r1n_next(R1N& r) {
+	BT2_HDN uint32_t r1n_next(R1N& r) {
 		if (r.cur == 0 && !r.converted) {
 			if (r.n == 1) { r.cur = 1; return 0; }
 			if (r.swaplist) {
@@ -456,7 +459,7 @@ struct Aligner {
 	// C. seed-hit extension bookkeeping
 	// =================================================================================
 	// SwDriver::extend (aligner_sw_driver.cpp:299-484)
-	BT2_HD void extend_hit(TOff topf, TOff botf, TOff topb, TOff botb, bool fw, uint32_t off, uint32_t len,
+	BT2_HDN void extend_hit(TOff topf, TOff botf, TOff topb, TOff botb, bool fw, uint32_t off, uint32_t len,
 	                       uint32_t& nlex, uint32_t& nrex) {
 		const uint32_t rdlen = w.len;
 		TOff t[4], b[4], tp[4], bp[4];
@@ -484,7 +487,7 @@ struct Aligner {
 				} else {
 					w.n_bwops_ext++;
 					TOff row = top;
-					const int c = map_lf1(e, row);
+					const int c = lf1(e, row);
 					top = row;
 					if (c != rdc && rdc <= 3) break;
 					bot = top + 1;
@@ -515,7 +518,7 @@ struct Aligner {
 				} else {
 					w.n_bwops_ext++;
 					TOff row = top;
-					const int c = map_lf1(e, row);
+					const int c = lf1(e, row);
 					top = row;
 					if (c != rdc && rdc <= 3) break;
 					bot = top + 1;
@@ -542,7 +545,7 @@ struct Aligner {
 	}
 
 	// SwDriver::eeSaTups (aligner_sw_driver.cpp:66-291)
-	BT2_HD void ee_sa_tups(uint64_t& nelt_out, uint64_t maxelt) {
+	BT2_HDN void ee_sa_tups(uint64_t& nelt_out, uint64_t maxelt) {
 		w.n_satpos = 0;
 		w.lists_used = 0;
 		nelt_out = 0;
@@ -624,7 +627,7 @@ struct Aligner {
 	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? w.exact[0] : (idx == -3 ? w.exact[1] : w.mm1[idx]); }
 
 	// SwDriver::prioritizeSATupsRands (aligner_sw_driver.cpp:492-738)
-	BT2_HD void prioritize(int seedmms, uint64_t maxelt, uint64_t& nelt_out) {
+	BT2_HDN void prioritize(int seedmms, uint64_t maxelt, uint64_t& nelt_out) {
 		const uint32_t nsm = 5;
 		w.n_satpos = 0; w.n_satpos2 = 0; w.lists_used = 0;
 		uint64_t nrange = 0, nelt = 0, nsmall = 0, nsmall_elts = 0;
@@ -777,7 +780,7 @@ struct Aligner {
 		}
 	}
 
-	BT2_HD bool red_overlap(const AlnRes& r) const {
+	BT2_HDN bool red_overlap(const AlnRes& r) const {
 		bool olap = false;
 		for_each_row_cells(r, [&](uint32_t i, int64_t left, int64_t right) -> bool {
 			for (uint32_t a = 0; a < w.n_red && !olap; a++) {
@@ -792,7 +795,7 @@ struct Aligner {
 		});
 		return olap;
 	}
-	BT2_HD void red_add(const AlnRes& r) {
+	BT2_HDN void red_add(const AlnRes& r) {
 		if (w.n_red >= (uint32_t)kMaxAlns) { w.err |= ERR_OVERFLOW; return; }
 		RedAln& ra = w.red[w.n_red++];
 		ra.refid = r.refid; ra.fw = r.fw; ra.refoff = r.refoff;
@@ -825,12 +828,7 @@ struct Aligner {
 	// E. DP: reference window, fill, gather, backtrace
 	// =================================================================================
 	// SwAligner::initRef (aligner_sw.cpp:155-271): masks for [rect.refl, rect.refr+1], overhang = N
-	BT2_HD void fetch_ref_window(uint64_t tidx, int64_t rfi, uint32_t count) {
-		for (uint32_t i = 0; i < count; i++) {
-			const int c = ref_base(ix.ref, tidx, rfi + (int64_t)i);
-			w.rf[i] = (uint8_t)(1 << c);
-		}
-	}
+	BT2_HD void fetch_ref_window(uint64_t tidx, int64_t rfi, uint32_t count) { Plat::fetch_ref(ix.ref, w, tidx, rfi, count); }
 
 	BT2_HD uint8_t mat_get(uint32_t R, uint32_t m, uint32_t i, uint32_t j) const { return dp.mat[dp_cell(R, m, i, j)]; }
 
@@ -838,7 +836,7 @@ struct Aligner {
 	BT2_HD uint16_t& mask_at(uint32_t row, uint32_t col, uint32_t cols) { return dp.masks[(uint64_t)row * cols + col]; }
 
 	// gatherCellsNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1176-1208) + btncand_.sort()
-	BT2_HD void gather_cells(uint32_t rows, uint32_t cols, int64_t minsc_dp) {
+	BT2_HDN void gather_cells(uint32_t rows, uint32_t cols, int64_t minsc_dp) {
 		const uint32_t R = dp_R(rows);
 		w.n_cands = 0; w.cural = 0;
 		for (uint32_t j = 0; j < cols; j++) {
@@ -858,7 +856,7 @@ struct Aligner {
 	}
 
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
-	BT2_HD bool backtrace(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen,
+	BT2_HDN bool backtrace(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen,
 	                      int32_t escore, uint32_t row, uint32_t col, AlnRes& res) {
 		(void)escore;
 		const uint32_t R = dp_R(rows);
@@ -1076,7 +1074,7 @@ struct Aligner {
 	}
 
 	// SwAligner::nextAlignment, end-to-end u8 branch (aligner_sw.cpp:737-1146)
-	BT2_HD bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, AlnRes& res) {
+	BT2_HDN bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, AlnRes& res) {
 		if (w.cural == w.n_cands) return false;
 		bool found = false;
 		while (w.cural < w.n_cands) {
@@ -1098,7 +1096,7 @@ struct Aligner {
 	}
 
 	// SwAligner::ungappedAlign, monotone branch (aligner_sw.cpp:286-494); returns 0 / 1
-	BT2_HD int ungapped_align(bool fw, uint64_t tidx, int64_t refoff, int64_t reflen, AlnRes& res) {
+	BT2_HDN int ungapped_align(bool fw, uint64_t tidx, int64_t refoff, int64_t reflen, AlnRes& res) {
 		const uint32_t len = w.len;
 		const int64_t rfi = refoff, rff = refoff + (int64_t)len;
 		if (rfi < 0) return 0;              // gReportOverhangs == false
@@ -1138,7 +1136,7 @@ struct Aligner {
 	// =================================================================================
 	// F. SwDriver::extendSeeds (aligner_sw_driver.cpp:921-1494)
 	// =================================================================================
-	BT2_HD int extend_seeds(int seedmms, int seedlen, int seedival) {
+	BT2_HDN int extend_seeds(int seedmms, int seedlen, int seedival) {
 		(void)seedlen; (void)seedival;
 		const uint32_t rdlen = w.len;
 		const int64_t perfect = (int64_t)rdlen * P.match_bonus * 0;   // monotone: perfectScore() == 0
@@ -1411,7 +1409,7 @@ struct Aligner {
 
 	// AlnSinkWrap::finishRead for an unpaired read (aln_sink.cpp:643-1384): ReportingState::finish,
 	// getReport, selectByScore (RNG!), and what the SAM line needs.
-	BT2_HD void finish(ReadResult& out) {
+	BT2_HDN void finish(ReadResult& out) {
 		out.status = (uint8_t)w.err;
 		out.filt = (uint8_t)rp.filt;
 		out.exhausted = 0;

@@ -93,7 +93,13 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) p[i] = 0;
 		wave_fence();
 	}
-	static __device__ __forceinline__ int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint8_t* mat) {
+	// reference window -> masks, one base per lane per pass (SwAligner::initRef, aligner_sw.cpp:155-271)
+	static __device__ __forceinline__ void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
+		wave_fence();
+		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) w.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
+		wave_fence();
+	}
+	static __device__ __attribute__((noinline)) int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint8_t* mat) {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
 		int best;
 		switch (dp_R(rows)) {
@@ -111,8 +117,11 @@ struct DevPlat {
 	}
 };
 
+#ifndef BT2G_WAVES_PER_EU
+#define BT2G_WAVES_PER_EU 2
+#endif
 template <typename TOff>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU)))
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof) {
@@ -177,6 +186,7 @@ void align_scratch_sizes(uint32_t max_len, uint64_t& mat_bytes, uint64_t& mask_b
 }
 
 uint64_t align_work_bytes() { return sizeof(Work); }
+uint32_t align_waves_per_cu() { return 4u * BT2G_WAVES_PER_EU; }
 
 template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, hipStream_t);
 template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, hipStream_t);

@@ -283,8 +283,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	hipStream_t st = (hipStream_t)stream;
 	uint64_t mat_bytes, mask_bytes, arena_stride;
 	align_scratch_sizes(max_read_len, mat_bytes, mask_bytes, arena_stride);
-	// 256-VGPR kernel: 2 waves per SIMD -> 8 per CU resident; persistent waves pull reads from a queue
-	uint32_t n_waves = c->n_cu * 8;
+	// persistent waves (one read at a time each) pull reads from a device-side queue
+	uint32_t n_waves = c->n_cu * align_waves_per_cu();
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
 	const uint64_t need = arena_stride * n_waves;
 	hipError_t e;

@@ -19,9 +19,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BT2_HD __host__ __device__ __forceinline__
+#define BT2_HDN __host__ __device__ __attribute__((noinline))   // large phase functions: real calls keep register pressure local
 #define BT2_D __device__ __forceinline__
 #else
 #define BT2_HD inline
+#define BT2_HDN
 #define BT2_D inline
 #endif
 

@@ -19,6 +19,9 @@ using namespace bt2g;
 
 struct HostPlat {
 	static uint64_t clock() { return 0; }
+	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
+		for (uint32_t i = 0; i < count; i++) w.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
+	}
 	static void zero_u8(uint8_t* p, uint32_t n) { memset(p, 0, n); }
 	static void zero_u16(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
 	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
