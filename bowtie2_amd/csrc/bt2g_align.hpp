@@ -137,11 +137,26 @@ struct BtFrame {          // DpNucFrame
 
 struct DPRect { int64_t refl, refr, refl_pretrim, refr_pretrim; uint32_t triml, trimr, corel, corer, maxgap; };
 
+// The hot, small part of the per-read state.  On the device it lives in LDS (one wavefront per
+// workgroup): these arrays are touched by almost every step of the scalar control code, and an
+// LDS access costs a few issue cycles where a wave-uniform global load occupies the vector
+// memory pipeline for a full 64-lane address pass.
+struct HotHit { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // exact seed hit: one range
+struct HotWork {
+	uint8_t  seq[kMaxLen];     // read, codes 0..4, 5'->3'
+	uint8_t  qual[kMaxLen];    // ASCII
+	uint8_t  rf[kMaxCols + 8]; // reference masks of the current DP window
+	HotHit   hits[2][kMaxOffs];// [0] fw seeds, [1] rc seeds; size==0 => no hit
+	uint8_t  sorted[2][kMaxOffs];
+	uint8_t  rank_offs[kMaxRanges];
+	uint8_t  rank_fw[kMaxRanges];
+	uint16_t btcells[2 * (kMaxLen + 64)];   // (row, col) of the backtrace in progress
+	Edit     ned[kMaxEdits];   // edits of the backtrace in progress
+};
+
 struct Work {
 	// ---- read ----
 	uint32_t len;
-	uint8_t  seq[kMaxLen];     // codes 0..4, 5'->3'
-	uint8_t  qual[kMaxLen];    // ASCII
 	// ---- seed phase ----
 	EEHit    exact[2];         // [0] fw, [1] rc; top==bot => empty
 	EEHit    mm1[kMaxMm1];
@@ -149,10 +164,6 @@ struct Work {
 	uint64_t mm1_elt;
 	uint32_t num_offs;
 	uint32_t off_idx2off[kMaxOffs];
-	SeedHitRec hits[2][kMaxOffs];      // [0] fw seeds, [1] rc seeds
-	uint8_t  sorted[2][kMaxOffs];
-	uint32_t rank_offs[kMaxRanges];
-	uint8_t  rank_fw[kMaxRanges];
 	uint32_t n_rank;
 	uint32_t nonz_tot, nonz_fw, nonz_rc;
 	uint64_t num_elts;
@@ -181,10 +192,8 @@ struct Work {
 	uint8_t  done_unpair1;
 	uint8_t  exit_m, exit_k;
 	// ---- DP ----
-	uint8_t  rf[kMaxCols + 8];          // reference masks of the current window
 	BtCand   cands[kMaxCands];
 	uint32_t n_cands, cural;
-	uint16_t btcells[2 * (kMaxLen + 64)];
 	BtFrame  btstack[kMaxLen + kMaxCols];
 	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
 	// ---- status / metrics ----
@@ -197,7 +206,7 @@ struct Work {
 
 // DP scratch of one wave: wavefront-major H/E/F matrix + per-cell backtrace masks + row flags
 struct DpScratch {
-	uint8_t*  mat;      // ((t*3+m)*R + r)*64 + lane
+	uint32_t* mat;      // packed cells, see dp_cell()
 	uint16_t* masks;    // [rows][cols]
 	uint8_t*  row_reset;// [rows]
 };
@@ -257,15 +266,16 @@ BT2_HD int max_ref_gaps(const AlignParams& P, int64_t minsc, uint32_t rdlen) {
 }
 
 // read accessors: patFw / patRc / qual / qualRev (read.h:73-128)
-BT2_HD int rd_char(const Work& w, bool fw, uint32_t i) { return fw ? w.seq[i] : comp4(w.seq[w.len - 1 - i]); }
-BT2_HD int rd_qual(const Work& w, bool fw, uint32_t i) { return fw ? w.qual[i] : w.qual[w.len - 1 - i]; }
+BT2_HD int rd_char(const HotWork& h, uint32_t len, bool fw, uint32_t i) { return fw ? h.seq[i] : comp4(h.seq[len - 1 - i]); }
+BT2_HD int rd_qual(const HotWork& h, uint32_t len, bool fw, uint32_t i) { return fw ? h.qual[i] : h.qual[len - 1 - i]; }
 
 // DP scratch addressing (wavefront-major, see bt2g_kernels.hip)
 BT2_HD uint32_t dp_R(uint32_t rows) { return (rows + 63) / 64; }
-BT2_HD uint64_t dp_cell(uint32_t R, uint32_t m, uint32_t i, uint32_t j) {
+// wavefront-major, one packed word per cell: H | E<<8 | F<<16 at word index (t*R + r)*64 + lane
+BT2_HD uint64_t dp_cell(uint32_t R, uint32_t i, uint32_t j) {
 	const uint32_t l = i / R, r = i % R;
 	const uint64_t t = (uint64_t)j + l;
-	return ((t * 3 + m) * R + r) * 64 + l;
+	return (t * R + r) * 64 + l;
 }
 
 } // namespace bt2g

@@ -13,6 +13,7 @@ namespace bt2g {
 
 template <typename TOff, typename Plat>
 struct Aligner {
+#define HOT (Plat::hot())
 	BT2_HD static uint64_t now() { return Plat::clock(); }
 
 	const DevIndex<TOff>& ix;
@@ -71,7 +72,7 @@ struct Aligner {
 					uint64_t key = 0;
 					if (do_ftab) {
 						for (uint32_t i = 0; i < ftab_len; i++) {
-							const int c = rd_char(w, fw, left - ftab_len + i);
+							const int c = rd_char(HOT, w.len, fw, left - ftab_len + i);
 							if (c > 3) { do_ftab = false; break; }
 							key = (key << 2) | (uint64_t)c;
 						}
@@ -81,7 +82,7 @@ struct Aligner {
 						bot = ftab_lo(e, key + 1);
 						dep += ftab_len;
 					} else {
-						const int c = rd_char(w, fw, len - dep - 1);
+						const int c = rd_char(HOT, w.len, fw, len - dep - 1);
 						if (c < 4) { top = e.fchr[c]; bot = e.fchr[c + 1]; }
 						dep++;
 					}
@@ -93,7 +94,7 @@ struct Aligner {
 					do_init = false;
 				}
 				if (dep < len) {
-					pair_lf(e, rd_char(w, fw, len - dep - 1), top, bot, w.n_bwops_seed);
+					pair_lf(e, rd_char(HOT, w.len, fw, len - dep - 1), top, bot, w.n_bwops_seed);
 					if (bot <= top) {
 						nedit++;
 						if (nedit >= mine_max) { mine[fwi] = nedit; done = true; }
@@ -128,13 +129,13 @@ struct Aligner {
 	// seq / qual views used by oneMmSearch (aligner_seed.cpp:1031-1040)
 	BT2_HD int mm1_seq(bool fw, bool ebwtfw, uint32_t i) const {
 		// fw: patFw | patFwRev ; rc: patRc | patRcRev
-		if (fw) return ebwtfw ? w.seq[i] : w.seq[w.len - 1 - i];
-		return ebwtfw ? comp4(w.seq[w.len - 1 - i]) : comp4(w.seq[i]);
+		if (fw) return ebwtfw ? HOT.seq[i] : HOT.seq[w.len - 1 - i];
+		return ebwtfw ? comp4(HOT.seq[w.len - 1 - i]) : comp4(HOT.seq[i]);
 	}
 	BT2_HD int mm1_qual(bool fw, bool ebwtfw, uint32_t i) const {
 		// fw: qual | qualRev ; rc: qualRev | qual
 		const bool rev = fw ? !ebwtfw : ebwtfw;
-		return rev ? w.qual[w.len - 1 - i] : w.qual[i];
+		return rev ? HOT.qual[w.len - 1 - i] : HOT.qual[i];
 	}
 
 	// SeedAligner::oneMmSearch with repex=false, rep1mm=true (aligner_seed.cpp:975-1325)
@@ -143,7 +144,7 @@ struct Aligner {
 		const int nceil = rp.nceil;    // sc.nCeil.f<int>(len); equal to the clamped value unless > len
 		w.n_mm1 = 0; w.mm1_elt = 0;
 		uint32_t ns = 0;
-		for (uint32_t i = 0; i < len; i++) if (w.seq[i] > 3) ns++;
+		for (uint32_t i = 0; i < len; i++) if (HOT.seq[i] > 3) ns++;
 		if (ns > 1) return;
 		const uint32_t halfFw = len >> 1;
 		const uint32_t halfBw = (len >> 1) + ((len & 1) ? 1 : 0);
@@ -289,15 +290,15 @@ struct Aligner {
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
 			for (uint32_t i = 0; i < nseeds; i++) {
-				SeedHitRec& h = w.hits[fwi][i];
-				h.topf = h.botf = h.topb = h.botb = 0;
-				w.sorted[fwi][i] = 0;
+				HotHit& h = HOT.hits[fwi][i];
+				h.topf = h.topb = 0; h.size = 0;
+				HOT.sorted[fwi][i] = 0;
 			}
 			if ((fw && P.nofw) || (!fw && P.norc)) continue;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				const uint32_t depth = i * interval + offset;
 				// seed char k as it aligns to the Watson strand (instantiateSeq :463-485)
-				auto getc = [&](uint32_t k) -> int { return fw ? (int)w.seq[depth + k] : comp4(w.seq[depth + L - 1 - k]); };
+				auto getc = [&](uint32_t k) -> int { return fw ? (int)HOT.seq[depth + k] : comp4(HOT.seq[depth + L - 1 - k]); };
 				bool ok = true;
 				for (uint32_t k = 0; k < L; k++) if (getc(k) > 3) { ok = false; break; }
 				if (!ok) continue;      // Seed::instantiate fails: exact zones cannot absorb an N
@@ -339,8 +340,8 @@ struct Aligner {
 					}
 				}
 				if (!ok) continue;
-				SeedHitRec& h = w.hits[fwi][i];
-				h.topf = topf; h.botf = botf; h.topb = topb; h.botb = botb;
+				HotHit& h = HOT.hits[fwi][i];
+				h.topf = topf; h.topb = topb; h.size = (uint32_t)(botf - topf);
 				// SeedResults::add (aligner_seed.h:639-676)
 				w.nonz_tot++;
 				if (fw) w.nonz_fw++; else w.nonz_rc++;
@@ -350,7 +351,7 @@ struct Aligner {
 		return ninst;
 	}
 
-	BT2_HD uint64_t hit_elts(int fwi, uint32_t i) const { return w.hits[fwi][i].botf - w.hits[fwi][i].topf; }
+	BT2_HD uint64_t hit_elts(int fwi, uint32_t i) const { return HOT.hits[fwi][i].size; }
 
 	// SeedResults::rankSeedHits, all=false (aligner_seed.h:1019-1080)
 	BT2_HDN void rank_seed_hits() {
@@ -366,15 +367,15 @@ struct Aligner {
 				uint32_t i = rnd.nextU32() % w.num_offs;
 				for (uint32_t ii = 0; ii < w.num_offs; ii++) {
 					const uint64_t ne = hit_elts(s, i);
-					if (ne > 0 && !w.sorted[s][i] && (TOff)ne < (TOff)minsz) {
+					if (ne > 0 && !HOT.sorted[s][i] && (TOff)ne < (TOff)minsz) {
 						minsz = ne; minidx = i; minfw = fw;
 					}
 					if ((++i) == w.num_offs) i = 0;
 				}
 			}
-			w.sorted[minfw ? 0 : 1][minidx] = 1;
-			w.rank_offs[w.n_rank] = minidx;
-			w.rank_fw[w.n_rank] = minfw ? 1 : 0;
+			HOT.sorted[minfw ? 0 : 1][minidx] = 1;
+			HOT.rank_offs[w.n_rank] = minidx;
+			HOT.rank_fw[w.n_rank] = minfw ? 1 : 0;
 			w.n_rank++;
 		}
 	}
@@ -470,7 +471,7 @@ struct Aligner {
 			TOff top = topf, bot = botf;
 			for (uint32_t ii = 0; ii < lim; ii++) {
 				const uint32_t i = fw ? off - ii - 1 : rdlen - off - len - 1 - ii;
-				const int rdc = rd_char(w, fw, i);
+				const int rdc = rd_char(HOT, w.len, fw, i);
 				if (bot - top > 1) {
 					w.n_bwops_ext++;
 					bi_lf(e, top, bot, topb, t, b, tp, bp);
@@ -501,7 +502,7 @@ struct Aligner {
 			TOff top = topb, bot = botb;
 			for (uint32_t ii = 0; ii < lim; ii++) {
 				const uint32_t i = fw ? ii + len + off : rdlen - off + ii;
-				const int rdc = rd_char(w, fw, i);
+				const int rdc = rd_char(HOT, w.len, fw, i);
 				if (bot - top > 1) {
 					w.n_bwops_ext++;
 					bi_lf(e, top, bot, topf, t, b, tp, bp);
@@ -632,12 +633,12 @@ struct Aligner {
 		w.n_satpos = 0; w.n_satpos2 = 0; w.lists_used = 0;
 		uint64_t nrange = 0, nelt = 0, nsmall = 0, nsmall_elts = 0;
 		for (uint32_t i = 0; i < w.n_rank; i++) {
-			const bool fw = w.rank_fw[i] != 0;
-			const uint32_t offidx = w.rank_offs[i];
+			const bool fw = HOT.rank_fw[i] != 0;
+			const uint32_t offidx = HOT.rank_offs[i];
 			const uint32_t rdoff = w.off_idx2off[offidx];
 			const uint32_t seedlen = rp.seedlen < (int32_t)w.len ? (uint32_t)rp.seedlen : w.len;
-			const SeedHitRec& h = w.hits[fw ? 0 : 1][offidx];
-			const uint64_t sz = h.botf - h.topf;
+			const HotHit& h = HOT.hits[fw ? 0 : 1][offidx];
+			const uint64_t sz = h.size;
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
 				const Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
@@ -656,7 +657,7 @@ struct Aligner {
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
 			uint32_t nlex = 0, nrex = 0;
-			if (P.do_extend) extend_hit((TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, seedlen, nlex, nrex);
+			if (P.do_extend) extend_hit((TOff)h.topf, (TOff)(h.topf + sz), (TOff)h.topb, (TOff)(h.topb + sz), fw, rdoff, seedlen, nlex, nrex);
 			s.nlex = nlex; s.nrex = nrex;
 			if (seedmms == 0 && (nlex > 0 || nrex > 0)) {
 				Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
@@ -830,7 +831,8 @@ struct Aligner {
 	// SwAligner::initRef (aligner_sw.cpp:155-271): masks for [rect.refl, rect.refr+1], overhang = N
 	BT2_HD void fetch_ref_window(uint64_t tidx, int64_t rfi, uint32_t count) { Plat::fetch_ref(ix.ref, w, tidx, rfi, count); }
 
-	BT2_HD uint8_t mat_get(uint32_t R, uint32_t m, uint32_t i, uint32_t j) const { return dp.mat[dp_cell(R, m, i, j)]; }
+	// packed cell (H | E<<8 | F<<16)
+	BT2_HD uint32_t cell_get(uint32_t R, uint32_t i, uint32_t j) const { return dp.mat[dp_cell(R, i, j)]; }
 
 	// masks_ helpers (aligner_swsse.h:255-330,418-490)
 	BT2_HD uint16_t& mask_at(uint32_t row, uint32_t col, uint32_t cols) { return dp.masks[(uint64_t)row * cols + col]; }
@@ -840,7 +842,7 @@ struct Aligner {
 		const uint32_t R = dp_R(rows);
 		w.n_cands = 0; w.cural = 0;
 		for (uint32_t j = 0; j < cols; j++) {
-			const int sc = (int)mat_get(R, 0, rows - 1, j) - 0xff;
+			const int sc = (int)(cell_get(R, rows - 1, j) & 0xff) - 0xff;
 			if (sc >= minsc_dp) {
 				if (w.n_cands >= (uint32_t)kMaxCands) { w.err |= ERR_OVERFLOW; break; }
 				BtCand c; c.score = sc; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)j;
@@ -867,13 +869,13 @@ struct Aligner {
 		const uint32_t trim_end = rows - row - 1;
 		uint32_t trim_beg = 0;
 		int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
-		Edit* ned = res.ned;
+		Edit* ned = HOT.ned;
 		const int offsetsc = -0xff;
 		w.n_bt_attempts++;
 		while ((int)row >= 0) {
-			const int readc = rd_char(w, fw, row);
-			const int refm = w.rf[col];
-			const int readq = rd_qual(w, fw, row);
+			const int readc = rd_char(HOT, w.len, fw, row);
+			const int refm = HOT.rf[col];
+			const int readq = rd_qual(HOT, w.len, fw, row);
 			bool empty = false, can_move_thru = true, branch = false;
 			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
 			if (!dp.row_reset[row]) { Plat::zero_u16(&mask_at(row, 0, cols), cols); dp.row_reset[row] = 1; }
@@ -884,12 +886,21 @@ struct Aligner {
 				const uint32_t row_from_end = rows - row - 1;
 				const bool gaps_allowed = !(row < (uint32_t)P.gapbar || row_from_end < (uint32_t)P.gapbar);
 				uint16_t& mk = mask_at(row, col, cols);
+				// the four packed cells this step can look at, fetched together (independent loads)
+				const bool hasl_ = col > 0;
+				const uint32_t c_cur = cell_get(R, row, col);
+				const uint32_t c_up = cell_get(R, row - 1, col);
+				const uint32_t c_left = hasl_ ? cell_get(R, row, col - 1) : 0u;
+				const uint32_t c_upleft = hasl_ ? cell_get(R, row - 1, col - 1) : 0u;
+				auto Hc = [](uint32_t c) -> int { return (int)(c & 0xff); };
+				auto Ec = [](uint32_t c) -> int { return (int)((c >> 8) & 0xff); };
+				auto Fc = [](uint32_t c) -> int { return (int)((c >> 16) & 0xff); };
 				if (ct == 1) {          // E: came from the left
-					const int sc_cur = (int)mat_get(R, 1, row, col) + offsetsc;
+					const int sc_cur = Ec(c_cur) + offsetsc;
 					int mask = 0;
-					const int sc_h_left = (int)mat_get(R, 0, row, col - 1) + offsetsc;
+					const int sc_h_left = Hc(c_left) + offsetsc;
 					if (sc_h_left - P.rdgapo == sc_cur) mask |= 1;
-					const int sc_e_left = (int)mat_get(R, 1, row, col - 1) + offsetsc;
+					const int sc_e_left = Ec(c_left) + offsetsc;
 					if (sc_e_left - P.rdgape == sc_cur) mask |= 2;
 					const int orig_mask = mask;
 					if (mk & (1 << 7)) mask = (mk >> 8) & 3;
@@ -898,9 +909,9 @@ struct Aligner {
 					else if (mask == 1) { cur = 3; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7)); }
 					else { empty = true; can_move_thru = (orig_mask == 0); }
 				} else if (ct == 2) {   // F: came from above
-					const int sc_h_up = (int)mat_get(R, 0, row - 1, col) + offsetsc;
-					const int sc_f_up = (int)mat_get(R, 2, row - 1, col) + offsetsc;
-					const int sc_cur = (int)mat_get(R, 2, row, col) + offsetsc;
+					const int sc_h_up = Hc(c_up) + offsetsc;
+					const int sc_f_up = Fc(c_up) + offsetsc;
+					const int sc_cur = Fc(c_cur) + offsetsc;
 					int mask = 0;
 					if (sc_h_up - P.rfgapo == sc_cur) mask |= 1;
 					if (sc_f_up - P.rfgape == sc_cur) mask |= 2;
@@ -911,13 +922,13 @@ struct Aligner {
 					else if (mask == 1) { cur = 1; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10)); }
 					else { empty = true; can_move_thru = (orig_mask == 0); }
 				} else {                // H
-					const int sc_cur = (int)mat_get(R, 0, row, col) + offsetsc;
-					const int sc_f_up = (int)mat_get(R, 2, row - 1, col) + offsetsc;
-					const int sc_h_up = (int)mat_get(R, 0, row - 1, col) + offsetsc;
+					const int sc_cur = Hc(c_cur) + offsetsc;
+					const int sc_f_up = Fc(c_up) + offsetsc;
+					const int sc_h_up = Hc(c_up) + offsetsc;
 					const bool hasl = col > 0;
-					const int sc_h_left = hasl ? (int)mat_get(R, 0, row, col - 1) + offsetsc : 0;
-					const int sc_e_left = hasl ? (int)mat_get(R, 1, row, col - 1) + offsetsc : 0;
-					const int sc_h_upleft = hasl ? (int)mat_get(R, 0, row - 1, col - 1) + offsetsc : 0;
+					const int sc_h_left = hasl ? Hc(c_left) + offsetsc : 0;
+					const int sc_e_left = hasl ? Ec(c_left) + offsetsc : 0;
+					const int sc_h_upleft = hasl ? Hc(c_upleft) + offsetsc : 0;
 					const int sc_diag = sc_score(P, readc, refm, readq - 33);
 					int mask = 0;
 					if (gaps_allowed) {
@@ -965,7 +976,7 @@ struct Aligner {
 				return false;
 			}
 			if (empty || row == 0) {
-				w.btcells[2 * ncells] = (uint16_t)row; w.btcells[2 * ncells + 1] = (uint16_t)col; ncells++;
+				HOT.btcells[2 * ncells] = (uint16_t)row; HOT.btcells[2 * ncells + 1] = (uint16_t)col; ncells++;
 				trim_beg = row;
 				break;
 			}
@@ -977,7 +988,7 @@ struct Aligner {
 				f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
 			}
 			if (ncells >= (uint32_t)(kMaxLen + 64)) { w.err |= ERR_OVERFLOW; return false; }
-			w.btcells[2 * ncells] = (uint16_t)row; w.btcells[2 * ncells + 1] = (uint16_t)col; ncells++;
+			HOT.btcells[2 * ncells] = (uint16_t)row; HOT.btcells[2 * ncells + 1] = (uint16_t)col; ncells++;
 			if (nned + 1 >= (uint32_t)kMaxEdits) { w.err |= ERR_OVERFLOW; return false; }
 			switch (cur) {
 				case 0: {   // diagonal
@@ -1017,29 +1028,29 @@ struct Aligner {
 		// must touch a core diagonal of the untrimmed rectangle (:1764-1795)
 		bool overlapped = false;
 		for (uint32_t i = 0; i < ncells; i++) {
-			const int64_t diagi = (int64_t)w.btcells[2 * i + 1] - (int64_t)w.btcells[2 * i] + (int64_t)rect.triml;
+			const int64_t diagi = (int64_t)HOT.btcells[2 * i + 1] - (int64_t)HOT.btcells[2 * i] + (int64_t)rect.triml;
 			if (diagi >= 0 && (uint64_t)diagi >= rect.corel && (uint64_t)diagi <= rect.corer) { overlapped = true; break; }
 		}
 		if (!overlapped) return false;
 		{
-			const int readc = rd_char(w, fw, row);
-			const int refm = w.rf[col];
+			const int readc = rd_char(HOT, w.len, fw, row);
+			const int refm = HOT.rf[col];
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) {
 				Edit& e = ned[nned++];
 				e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_MM;
-				score -= sc_mm(P, readc, refm, rd_qual(w, fw, row) - 33);
+				score -= sc_mm(P, readc, refm, rd_qual(HOT, w.len, fw, row) - 33);
 			} else score += P.match_bonus;
 			if (m == -1) ns++;
 		}
 		if (ns > rp.nceil) return false;
-		// res.reverse()
-		for (uint32_t i = 0; i < nned / 2; i++) { const Edit t = ned[i]; ned[i] = ned[nned - 1 - i]; ned[nned - 1 - i] = t; }
+		// res.reverse(), while copying the edits out of LDS
+		for (uint32_t i = 0; i < nned; i++) res.ned[i] = ned[nned - 1 - i];
 		res.nned = (uint16_t)nned;
 		res.score = score; res.ns = (int16_t)ns; res.gaps = (int16_t)gaps; res.edits = (int16_t)nned;
 		res.bases_aligned = (int16_t)((int)rows - (int)trim_beg - (int)trim_end - (int)nned);
 		uint32_t refns = 0;
-		for (uint32_t i = col; i <= orig_col; i++) if (w.rf[i] > 15) refns++;
+		for (uint32_t i = col; i <= orig_col; i++) if (HOT.rf[i] > 15) refns++;
 		res.refns = (uint16_t)refns;
 		set_shape(res, (int32_t)tidx, (int64_t)col + rect.refl, tlen, fw, rows, fw ? trim_beg : trim_end, fw ? trim_end : trim_beg);
 		return true;
@@ -1103,11 +1114,11 @@ struct Aligner {
 		if (rff > reflen) return 0;
 		int64_t score = 0;
 		int ns = 0;
-		for (uint32_t i = 0; i < len; i++) w.rf[i] = (uint8_t)ref_base(ix.ref, tidx, rfi + (int64_t)i);   // codes here, not masks
+		for (uint32_t i = 0; i < len; i++) HOT.rf[i] = (uint8_t)ref_base(ix.ref, tidx, rfi + (int64_t)i);   // codes here, not masks
 		for (uint32_t i = 0; i < len; i++) {
-			const int rdc = rd_char(w, fw, i);
-			const int rfc = w.rf[i];
-			const int q = rd_qual(w, fw, i) - 33;
+			const int rdc = rd_char(HOT, w.len, fw, i);
+			const int rfc = HOT.rf[i];
+			const int q = rd_qual(HOT, w.len, fw, i) - 33;
 			if (rdc > 3 || rfc > 3) { ns++; score -= P.n_pen; }
 			else if (rdc == rfc) score += P.match_bonus;
 			else score -= mm_penalty(P, q < 0 ? 0 : q);
@@ -1115,8 +1126,8 @@ struct Aligner {
 		}
 		uint32_t nned = 0, refns = 0;
 		for (uint32_t i = 0; i < len; i++) {
-			const int rdc = rd_char(w, fw, i);
-			const int rfc = w.rf[i];
+			const int rdc = rd_char(HOT, w.len, fw, i);
+			const int rfc = HOT.rf[i];
 			if (rfc > 3 || rdc != rfc) {
 				if (nned >= (uint32_t)kMaxEdits) { w.err |= ERR_OVERFLOW; return 0; }
 				Edit& e = res.ned[nned++];

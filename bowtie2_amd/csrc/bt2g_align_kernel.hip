@@ -13,11 +13,13 @@
 
 namespace bt2g {
 
+__shared__ HotWork g_hot;    // one wavefront per workgroup: the hot per-read state lives in LDS
+
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 template <int R>
 __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work& w, bool fw, uint32_t rows, uint32_t cols,
-                                               uint8_t* __restrict__ scratch) {
+                                               uint32_t* __restrict__ scratch) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t nlanes = (rows + R - 1) / R;
 	int rdc[R], mmp[R], veto[R];
@@ -25,8 +27,8 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 	for (int r = 0; r < R; r++) {
 		const uint32_t i = (uint32_t)lane * R + r;
 		const bool valid = i < rows;
-		rdc[r] = valid ? rd_char(w, fw, i) : 4;
-		const int q = valid ? rd_qual(w, fw, i) - 33 : 0;
+		rdc[r] = valid ? rd_char(g_hot, w.len, fw, i) : 4;
+		const int q = valid ? rd_qual(g_hot, w.len, fw, i) - 33 : 0;
 		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
 		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 0xff : 0;
 	}
@@ -41,7 +43,7 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 		const int upH = __shfl_up(myHlast, 1);
 		const int upF = __shfl_up(myFlast, 1);
 		int upRef = __shfl_up(refm, 1);
-		if (lane == 0) upRef = (t < cols) ? w.rf[t] : 16;
+		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
 		refm = upRef;
 		const int j = (int)t - lane;
 		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
@@ -64,13 +66,9 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 			fin_h = h; fin_f = f;
 		}
 		if (active) {
-			uint8_t* base = scratch + ((uint64_t)t * 3 * R) * 64 + lane;
+			uint32_t* base = scratch + ((uint64_t)t * R) * 64 + lane;     // 256 contiguous bytes per store
 #pragma unroll
-			for (int r = 0; r < R; r++) {
-				base[(0 * R + r) * 64] = (uint8_t)Hnew[r];
-				base[(1 * R + r) * 64] = (uint8_t)Enew[r];
-				base[(2 * R + r) * 64] = (uint8_t)Fnew[r];
-			}
+			for (int r = 0; r < R; r++) base[r * 64] = (uint32_t)Hnew[r] | ((uint32_t)Enew[r] << 8) | ((uint32_t)Fnew[r] << 16);
 #pragma unroll
 			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
 			if (lane_has_last) best = imax(best, Hnew[last_r]);
@@ -82,6 +80,7 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 }
 
 struct DevPlat {
+	static __device__ __forceinline__ HotWork& hot() { return g_hot; }
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
 	static __device__ __forceinline__ void zero_u8(uint8_t* p, uint32_t n) {
 		wave_fence();
@@ -96,10 +95,10 @@ struct DevPlat {
 	// reference window -> masks, one base per lane per pass (SwAligner::initRef, aligner_sw.cpp:155-271)
 	static __device__ __forceinline__ void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
 		wave_fence();
-		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) w.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
+		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
 		wave_fence();
 	}
-	static __device__ __attribute__((noinline)) int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint8_t* mat) {
+	static __device__ __attribute__((noinline)) int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat) {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
 		int best;
 		switch (dp_R(rows)) {
@@ -129,8 +128,8 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	Work& w = *reinterpret_cast<Work*>(base);
 	DpScratch dp;
-	dp.mat = base + ((sizeof(Work) + 255) & ~(uint64_t)255);
-	dp.masks = reinterpret_cast<uint16_t*>(dp.mat + mat_bytes);
+	dp.mat = reinterpret_cast<uint32_t*>(base + ((sizeof(Work) + 255) & ~(uint64_t)255));
+	dp.masks = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(dp.mat) + mat_bytes);
 	dp.row_reset = reinterpret_cast<uint8_t*>(dp.masks) + mask_bytes;
 	for (;;) {
 		unsigned int r = 0;
@@ -147,7 +146,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		// stage the read into the work area (lane-parallel copy)
 		wave_fence();
 		w.len = len;
-		for (uint32_t i = lane; i < len; i += 64) { w.seq[i] = rd.d_seq[o0 + i]; w.qual[i] = rd.d_qual[o0 + i]; }
+		for (uint32_t i = lane; i < len; i += 64) { g_hot.seq[i] = rd.d_seq[o0 + i]; g_hot.qual[i] = rd.d_qual[o0 + i]; }
 		wave_fence();
 		const ReadParams rp = rparams[r];
 		Aligner<TOff, DevPlat> al(ix, P, rp, w, dp);
@@ -178,7 +177,7 @@ void align_scratch_sizes(uint32_t max_len, uint64_t& mat_bytes, uint64_t& mask_b
 	const uint32_t R = dp_R(rows);
 	const uint32_t cols = rows + 4 * 15 + 1 + 4;
 	const uint32_t lanes = (rows + R - 1) / R;
-	mat_bytes = (((uint64_t)cols + lanes) * 3 * R * 64 + 255) & ~(uint64_t)255;
+	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 4 + 255) & ~(uint64_t)255;
 	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
 	const uint64_t rr = ((uint64_t)rows + 255) & ~(uint64_t)255;
 	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + mat_bytes + mask_bytes + rr;

@@ -17,27 +17,29 @@
 
 using namespace bt2g;
 
+static HotWork g_hot;
 struct HostPlat {
+	static HotWork& hot() { return g_hot; }
 	static uint64_t clock() { return 0; }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
-		for (uint32_t i = 0; i < count; i++) w.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
+		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
 	}
 	static void zero_u8(uint8_t* p, uint32_t n) { memset(p, 0, n); }
 	static void zero_u16(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
 	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
-	static int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint8_t* mat) {
+	static int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat) {
 		const uint32_t R = dp_R(rows);
 		int lrmax = 0;
 		std::vector<int> Hp(rows, 0), Ep(rows, 0), Hc(rows), Ec(rows), Fc(rows);
 		for (uint32_t j = 0; j < cols; j++) {
-			const int m = w.rf[j];
+			const int m = g_hot.rf[j];
 			int refc = 4;
 			for (int b = 0; b < 4; b++) if (m & (1 << b)) { refc = b; break; }
 			int f = 0;
 			for (uint32_t i = 0; i < rows; i++) {
 				const int veto = ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar) ? 0xff : 0;
-				const int rdc = rd_char(w, fw, i);
-				const int q = rd_qual(w, fw, i) - 33;
+				const int rdc = rd_char(g_hot, w.len, fw, i);
+				const int q = rd_qual(g_hot, w.len, fw, i) - 33;
 				int pen;
 				if (rdc > 3 || refc > 3) pen = P.n_pen; else pen = (rdc == refc) ? -P.match_bonus : mm_penalty(P, q < 0 ? 0 : q);
 				const int hdiag = (i == 0) ? 0xff : (j == 0 ? 0 : Hp[i - 1]);
@@ -45,9 +47,7 @@ struct HostPlat {
 				f = (i == 0) ? 0 : subs0(imax(subs0(f, P.rfgape), subs0(Hc[i - 1], P.rfgapo)), veto);
 				const int h = imax(imax(subs0(hdiag, pen), e), f);
 				Hc[i] = h; Ec[i] = e; Fc[i] = f;
-				mat[dp_cell(R, 0, i, j)] = (uint8_t)h;
-				mat[dp_cell(R, 1, i, j)] = (uint8_t)e;
-				mat[dp_cell(R, 2, i, j)] = (uint8_t)f;
+				mat[dp_cell(R, i, j)] = (uint32_t)h | ((uint32_t)e << 8) | ((uint32_t)f << 16);
 			}
 			if (Hc[rows - 1] > lrmax) lrmax = Hc[rows - 1];
 			Hp.swap(Hc); Ep.swap(Ec);
@@ -93,8 +93,8 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	if (!fq.ok()) { fprintf(stderr, "cannot open %s\n", opt.reads_file.c_str()); return 1; }
 	Work* w = new Work();
 	DpScratch dp;
-	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * 3 * dp_R(kMaxLen) * 64;
-	dp.mat = (uint8_t*)malloc(mat_bytes);
+	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 4;
+	dp.mat = (uint32_t*)malloc(mat_bytes);
 	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
 	dp.row_reset = (uint8_t*)malloc(kMaxLen);
 	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(opt.khits + 1));
@@ -111,8 +111,8 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		}
 		ReadParams rp = compute_read_params(opt, rd);
 		w->len = (uint32_t)rd.seq.size();
-		memcpy(w->seq, rd.seq.data(), rd.seq.size());
-		memcpy(w->qual, rd.qual.data(), rd.qual.size());
+		memcpy(g_hot.seq, rd.seq.data(), rd.seq.size());
+		memcpy(g_hot.qual, rd.qual.data(), rd.qual.size());
 		Aligner<TOff, HostPlat> al(ix, P, rp, *w, dp);
 		al.run(rr);
 		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d)\n", rd.name.c_str(), rr.status);
