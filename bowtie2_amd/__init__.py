@@ -89,7 +89,9 @@ class ReadResult(C.Structure):
                 ("secbest", C.c_int32), ("best", C.c_int32), ("nalns", C.c_uint32), ("nreport", C.c_uint32),
                 ("n_ex_iters", C.c_uint32), ("n_ex_dps", C.c_uint32), ("n_ex_ugs", C.c_uint32),
                 ("n_dp_fail_streak_max", C.c_uint32), ("n_bwops_seed", C.c_uint32), ("n_bwops_ext", C.c_uint32),
-                ("n_redundants", C.c_uint32), ("n_bt_attempts", C.c_uint32), ("alns", Aln * 1)]
+                ("n_redundants", C.c_uint32), ("n_bt_attempts", C.c_uint32),
+                ("n_ext_left", C.c_uint32), ("n_ext_right", C.c_uint32), ("n_resolve_steps", C.c_uint32), ("n_sides", C.c_uint32),
+                ("alns", Aln * 1)]
 
 
 class Counters(C.Structure):

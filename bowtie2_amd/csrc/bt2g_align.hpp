@@ -200,6 +200,7 @@ struct Work {
 	uint32_t err;
 	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail, n_ug_fail, n_ee_fail, n_dp_fail_streak;
 	uint32_t n_redundants, n_bwops_seed, n_bwops_ext, n_bt_attempts;
+	uint32_t n_ext_left, n_ext_right, n_resolve_steps;
 	uint32_t n_sides;           // sides (64/128-byte lines) actually read -- roofline accounting
 	uint64_t t_phase[8];        // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other
 };

@@ -659,6 +659,7 @@ struct Aligner {
 			uint32_t nlex = 0, nrex = 0;
 			if (P.do_extend) extend_hit((TOff)h.topf, (TOff)(h.topf + sz), (TOff)h.topb, (TOff)(h.topb + sz), fw, rdoff, seedlen, nlex, nrex);
 			s.nlex = nlex; s.nrex = nrex;
+			w.n_ext_left += nlex; w.n_ext_right += nrex;
 			if (seedmms == 0 && (nlex > 0 || nrex > 0)) {
 				Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
 				uint32_t& nr = fw ? w.n_ex_fw : w.n_ex_rc;
@@ -1208,7 +1209,7 @@ struct Aligner {
 					const uint64_t tr_ = now();
 					const TOff joff = get_offset(ix.fw, (TOff)(sp.topf + elt), steps);
 					w.t_phase[4] += now() - tr_;
-					w.n_bwops_ext += steps; w.n_sides += steps;
+					w.n_bwops_ext += steps; w.n_sides += steps; w.n_resolve_steps += steps;
 					if (!ee_mode) nelt_left--;
 					TOff tidx = 0, toff = 0, tlen = 0;
 					bool straddled = false;
@@ -1355,7 +1356,7 @@ struct Aligner {
 		w.n_alns = 0; w.best_unp1 = w.best2_unp1 = INT64_MIN; w.done_unpair1 = 0; w.exit_m = w.exit_k = 0;
 		w.n_diags = 0; w.n_red = 0; w.n_ex_fw = w.n_ex_rc = 0;
 		w.n_ex_iters = w.n_ex_dps = w.n_ex_ugs = w.n_dp_fail = w.n_ug_fail = w.n_ee_fail = w.n_dp_fail_streak = 0;
-		w.n_redundants = w.n_bwops_seed = w.n_bwops_ext = w.n_bt_attempts = 0; w.n_sides = 0;
+		w.n_redundants = w.n_bwops_seed = w.n_bwops_ext = w.n_bt_attempts = 0; w.n_sides = 0; w.n_ext_left = w.n_ext_right = w.n_resolve_steps = 0;
 		for (int i_ = 0; i_ < 8; i_++) w.t_phase[i_] = 0;
 		const uint64_t t_run0_ = now();
 		w.n_mm1 = 0; w.mm1_elt = 0; w.nonz_tot = 0; w.n_rank = 0; w.num_offs = 0; w.num_elts = 0;
@@ -1416,6 +1417,17 @@ struct Aligner {
 		}
 		finish(out);
 		w.t_phase[7] = now() - t_run0_;
+#ifdef BT2G_DEBUG_SATPOS
+		{
+			uint32_t* dbg = reinterpret_cast<uint32_t*>(out.alns[0].ned);
+			uint32_t k = 0;
+			dbg[k++] = w.n_satpos2;
+			for (uint32_t i = 0; i < w.n_satpos2 && k + 6 < 290; i++) {
+				const SatPos& s = w.satpos2[i];
+				dbg[k++] = (uint32_t)s.topf; dbg[k++] = (uint32_t)s.topb; dbg[k++] = s.size; dbg[k++] = s.nlex; dbg[k++] = s.nrex; dbg[k++] = s.offidx * 2 + s.fw;
+			}
+		}
+#endif
 	}
 
 	// AlnSinkWrap::finishRead for an unpaired read (aln_sink.cpp:643-1384): ReportingState::finish,
@@ -1428,6 +1440,7 @@ struct Aligner {
 		out.n_ex_iters = w.n_ex_iters; out.n_ex_dps = w.n_ex_dps; out.n_ex_ugs = w.n_ex_ugs;
 		out.n_dp_fail_streak_max = w.n_dp_fail_streak; out.n_bwops_seed = w.n_bwops_seed; out.n_bwops_ext = w.n_bwops_ext;
 		out.n_redundants = w.n_redundants; out.n_bt_attempts = w.n_bt_attempts;
+		out.n_ext_left = w.n_ext_left; out.n_ext_right = w.n_ext_right; out.n_resolve_steps = w.n_resolve_steps; out.n_sides = w.n_sides;
 		uint32_t nunpair1 = 0;
 		bool maxed = false;
 		if (w.n_alns > 0) {

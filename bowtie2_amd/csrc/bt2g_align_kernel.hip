@@ -152,6 +152,12 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		Aligner<TOff, DevPlat> al(ix, P, rp, w, dp);
 		al.run(out);
 		wave_fence();
+		{
+			// the control code must have stayed wave-uniform: compare a digest of the private state across lanes
+			const uint32_t dig = al.rnd.last ^ (uint32_t)al.minsc ^ (al.rnd.lastOff << 20);
+			const bool same = __shfl(dig, 0) == dig;
+			if (__ballot(!same) != 0ull) out.status |= 2;
+		}
 		if (lane == 0 && prof) {
 			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)w.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)w.n_sides);

@@ -19,7 +19,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BT2_HD __host__ __device__ __forceinline__
+#ifdef BT2G_INLINE_ALL
+#define BT2_HDN __host__ __device__ __forceinline__
+#else
 #define BT2_HDN __host__ __device__ __attribute__((noinline))   // large phase functions: real calls keep register pressure local
+#endif
 #define BT2_D __device__ __forceinline__
 #else
 #define BT2_HD inline

@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
 	for (int i = 0; i < argc; i++) { if (i) cmdline.push_back(' '); cmdline += argv[i]; }
 	opt.cmdline = cmdline;
 	int device = 0;
+	bool metrics = false;
 	size_t batch_reads = 1u << 20;
 	for (int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
@@ -60,6 +61,7 @@ int main(int argc, char** argv) {
 		else if (a == "--no-hd") opt.sam_no_hd = true;
 		else if (a == "--no-sq") opt.sam_no_sq = true;
 		else if (a == "--gpu") device = atoi(need("--gpu").c_str());
+		else if (a == "--met") metrics = true;
 		else if (a == "--batch") batch_reads = strtoull(need("--batch").c_str(), nullptr, 10);
 		else if (a == "-D") opt.max_dp_streak = atoi(need("-D").c_str());
 		else if (a == "-R") opt.n_seed_rounds = atoi(need("-R").c_str());
@@ -148,8 +150,13 @@ int main(int argc, char** argv) {
 		o.clear();
 		for (size_t i = 0; i < n; i++) {
 			const ReadResult& rr = *(const ReadResult*)(h_res.data() + i * stride);
-			if (rr.status) fprintf(stderr, "Warning: read %s exceeded a fixed device work buffer; its alignment may be incomplete\n", reads[i].name.c_str());
+			if (rr.status) fprintf(stderr, "Warning: read %s: device status %d (1 = work buffer overflow, 2 = lanes diverged)\n", reads[i].name.c_str(), (int)rr.status);
 			summ.add(rr);
+			if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", reads[i].name.c_str(),
+			                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
+#ifdef BT2G_DEBUG_SATPOS
+			{ const uint32_t* dbg = (const uint32_t*)rr.alns[0].ned; fprintf(stderr, "DBG\t%s", reads[i].name.c_str()); for (uint32_t k = 0; k < 1 + dbg[0] * 6 && k < 290; k++) fprintf(stderr, " %u", dbg[k]); fprintf(stderr, "\n"); }
+#endif
 			if (rr.aligned) { for (uint32_t k = 0; k < rr.nreport; k++) sam_record(o, opt, ref, reads[i], rr, &rr.alns[k], k == 0); }
 			else sam_record(o, opt, ref, reads[i], rr, nullptr, true);
 			if (o.size() > (1u << 24)) { fwrite(o.data(), 1, o.size(), out); o.clear(); }

@@ -236,6 +236,7 @@ typedef struct {
 	int32_t  secbest, best;        /* XS:i / MAPQ inputs                                      */
 	uint32_t nalns, nreport;
 	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail_streak_max, n_bwops_seed, n_bwops_ext, n_redundants, n_bt_attempts;
+	uint32_t n_ext_left, n_ext_right, n_resolve_steps, n_sides;   /* seed-hit extension steps, SA-walk steps, sides read */
 	bt2g_aln alns[1];              /* nreport (<= khits) entries                              */
 } bt2g_read_result;
 

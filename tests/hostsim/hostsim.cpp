@@ -124,8 +124,8 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 			sam_record(o, opt, ref, rd, rr, nullptr, true);
 		}
 		fwrite(o.data(), 1, o.size(), out);
-		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u\n", rd.name.c_str(),
-		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns);
+		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", rd.name.c_str(),
+		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
 	}
 	summ.print(stderr);
 	return 0;

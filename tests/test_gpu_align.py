@@ -80,3 +80,24 @@ def test_differential_vs_reference_binary(large):
         assert len(got) == len(want)
         bad = [i for i in range(len(got)) if got[i] != want[i]]
         assert not bad, (args, len(bad), want[bad[0]], got[bad[0]])
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("large", [False, True], ids=["bt2", "bt2l"])
+def test_run_to_run_determinism(large):
+    """The per-read work counters (BW ops, extension lengths, DP/backtrace counts) must be identical
+    across repeated runs -- a wave-level race would show up here long before it changes a SAM line."""
+    d = os.path.join(CACHE_DIR, "rep_%s" % ("l" if large else "s"))
+    os.makedirs(d, exist_ok=True)
+    refs, reads = repeat_genome()
+    fa, fq, base = os.path.join(d, "rep.fa"), os.path.join(d, "rep.fq"), os.path.join(d, "rep")
+    if not os.path.exists(fq):
+        write_fasta(fa, refs)
+        write_fastq(fq, reads)
+        build_index(fa, base, large)
+    outs = set()
+    for _ in range(8):
+        p = subprocess.run([EXE, "--met", "-x", base, "-U", fq, "-S", "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0
+        outs.add("\n".join(l for l in p.stderr.splitlines() if l.startswith("MET")))
+    assert len(outs) == 1
