@@ -8,6 +8,7 @@
 #define BT2G_ALIGN_CORE_HPP_
 
 #include "bt2g_align.hpp"
+#include "bt2g_fm_search.hpp"
 
 namespace bt2g {
 
@@ -25,8 +26,75 @@ struct Aligner {
 	int64_t minsc;       // current (possibly tightened) minimum score
 	static constexpr TOff kOffMask = (TOff)OffTraits<TOff>::kMask;
 
-	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, const ReadParams& rp_, Work& w_, DpScratch dp_)
-		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_) {}
+	const PreComp* pre;  // batch pre-computation (may be null)
+	uint32_t ridx;       // index of this read in the batch
+	bool ext_pre;        // HOT.hits came from pre->seeds, so pre->ext holds their extensions
+
+	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, const ReadParams& rp_, Work& w_, DpScratch dp_,
+	               const PreComp* pre_ = nullptr, uint32_t ridx_ = 0)
+		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_), pre(pre_), ridx(ridx_), ext_pre(false) {}
+
+	// exact_sweep() from the batch kernel's output
+	BT2_HD uint64_t exact_sweep_pre(uint32_t mine[2]) {
+		const bt2g_sweep_out& s = pre->sweep[ridx];
+		uint64_t nelt = 0;
+		for (int fwi = 0; fwi < 2; fwi++) {
+			mine[fwi] = s.mine[fwi];
+			EEHit& h = w.exact[fwi];
+			h.top = h.bot = 0;
+			if (s.hit[fwi]) {
+				h.top = s.top[fwi]; h.bot = s.bot[fwi]; h.fw = fwi == 0 ? 1 : 0; h.has_edit = 0;
+				h.score = (int32_t)((int64_t)w.len * P.match_bonus);
+				nelt += s.bot[fwi] - s.top[fwi];
+			}
+		}
+		return nelt;
+	}
+
+	// one_mm_search() from the batch kernel's output; false if a list overflowed
+	BT2_HD bool one_mm_pre(bool nofw, bool norc) {
+		const uint8_t* n = pre->mm1_n + (uint64_t)ridx * 4;
+		if ((!nofw && (n[0] == 255 || n[1] == 255)) || (!norc && (n[2] == 255 || n[3] == 255))) return false;
+		w.n_mm1 = 0; w.mm1_elt = 0;
+		for (int k = 0; k < 4; k++) {
+			const bool fw = k < 2;
+			if ((fw && nofw) || (!fw && norc)) continue;
+			const Mm1Hit* src = pre->mm1 + ((uint64_t)ridx * 4 + k) * pre->mm1_cap;
+			for (uint32_t i = 0; i < n[k]; i++) add_mm1(src[i], fw);
+		}
+		return true;
+	}
+
+	// seed_round(0, interval, seedlen) from the batch kernel's output
+	BT2_HD uint32_t seed_round_pre(uint32_t interval, uint32_t seedlen) {
+		const uint32_t len = w.len;
+		uint32_t nseeds = 1;
+		if ((int64_t)len > (int64_t)seedlen) nseeds += (len - seedlen) / interval;
+		if (nseeds > (uint32_t)kMaxOffs) { w.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
+		w.num_offs = nseeds;
+		w.nonz_tot = w.nonz_fw = w.nonz_rc = 0; w.num_elts = 0;
+		w.n_rank = 0;
+		for (uint32_t i = 0; i < nseeds; i++) w.off_idx2off[i] = interval * i;
+		for (int fwi = 0; fwi < 2; fwi++) {
+			const bool fw = fwi == 0;
+			const bool skip = (fw && P.nofw) || (!fw && P.norc);
+			const bt2g_seed_hit* src = pre->seeds + ((uint64_t)ridx * 2 + fwi) * pre->max_seeds;
+			for (uint32_t i = 0; i < nseeds; i++) {
+				HotHit& h = HOT.hits[fwi][i];
+				HOT.sorted[fwi][i] = 0;
+				h.topf = h.topb = 0; h.size = 0;
+				if (skip) continue;
+				const bt2g_seed_hit sh = src[i];
+				if (sh.botf > sh.topf) {
+					h.topf = sh.topf; h.topb = sh.topb; h.size = (uint32_t)(sh.botf - sh.topf);
+					w.nonz_tot++;
+					if (fw) w.nonz_fw++; else w.nonz_rc++;
+					w.num_elts += sh.botf - sh.topf;
+				}
+			}
+		}
+		return 1;   // # instantiated seeds only matters when no seed hit (run() ends the read either way)
+	}
 
 	// =================================================================================
 	// A. end-to-end exact / 1-mismatch search and exact seeds
@@ -126,151 +194,39 @@ struct Aligner {
 		tp[3] = bp[2]; bp[3] = tp[3] + (b[3] - t[3]);
 	}
 
-	// seq / qual views used by oneMmSearch (aligner_seed.cpp:1031-1040)
-	BT2_HD int mm1_seq(bool fw, bool ebwtfw, uint32_t i) const {
-		// fw: patFw | patFwRev ; rc: patRc | patRcRev
-		if (fw) return ebwtfw ? HOT.seq[i] : HOT.seq[w.len - 1 - i];
-		return ebwtfw ? comp4(HOT.seq[w.len - 1 - i]) : comp4(HOT.seq[i]);
-	}
-	BT2_HD int mm1_qual(bool fw, bool ebwtfw, uint32_t i) const {
-		// fw: qual | qualRev ; rc: qualRev | qual
-		const bool rev = fw ? !ebwtfw : ebwtfw;
-		return rev ? HOT.qual[w.len - 1 - i] : HOT.qual[i];
-	}
+	// read accessor for the shared FM search functions
+	struct HotRd {
+		BT2_HD int seq(uint32_t i) const { return Plat::hot().seq[i]; }
+		BT2_HD int qual(uint32_t i) const { return Plat::hot().qual[i]; }
+	};
 
 	// SeedAligner::oneMmSearch with repex=false, rep1mm=true (aligner_seed.cpp:975-1325)
 	BT2_HDN void one_mm_search(bool nofw, bool norc) {
 		const uint32_t len = w.len;
-		const int nceil = rp.nceil;    // sc.nCeil.f<int>(len); equal to the clamped value unless > len
 		w.n_mm1 = 0; w.mm1_elt = 0;
 		uint32_t ns = 0;
 		for (uint32_t i = 0; i < len; i++) if (HOT.seq[i] > 3) ns++;
 		if (ns > 1) return;
-		const uint32_t halfFw = len >> 1;
-		const uint32_t halfBw = (len >> 1) + ((len & 1) ? 1 : 0);
-		TOff t[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, tp[4] = {0, 0, 0, 0}, bp[4] = {0, 0, 0, 0};
+		FmCount cnt; cnt.bwops = 0; cnt.sides = 0;
+		HotRd rd;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
 			if ((fw && nofw) || (!fw && norc)) continue;
 			for (int ebwtfwi = 0; ebwtfwi < 2; ebwtfwi++) {
-				const bool ebwtfw = ebwtfwi == 0;
-				const DevEbwt<TOff>& e = ebwtfw ? ix.fw : ix.bw;
-				const DevEbwt<TOff>& ep = ebwtfw ? ix.bw : ix.fw;
-				const uint32_t ftab_len = e.ftab_chars;
-				const uint32_t nea = ebwtfw ? halfFw : halfBw;
-				bool skip = false;
-				for (uint32_t dep = 0; dep < nea; dep++) if (mm1_seq(fw, ebwtfw, len - dep - 1) > 3) { skip = true; break; }
-				if (skip) continue;
-				uint32_t dep = 0;
-				TOff top = 0, bot = 0, topp = 0, botp = 0;
-				if (ftab_len > 1 && ftab_len <= nea) {
-					// both lookups read the window seq[len-ftab, len): text order in `e`, reversed in `ep`
-					uint64_t kt = 0, kr = 0;
-					for (uint32_t i = 0; i < ftab_len; i++) {
-						kt = (kt << 2) | (uint64_t)mm1_seq(fw, ebwtfw, len - ftab_len + i);
-						kr = (kr << 2) | (uint64_t)mm1_seq(fw, ebwtfw, len - 1 - i);
-					}
-					top = ftab_hi(e, kt); bot = ftab_lo(e, kt + 1);
-					topp = ftab_hi(ep, kr); botp = ftab_lo(ep, kr + 1);
-					if (bot - top == 0) continue;
-					dep = ftab_len;
-				} else {
-					const int c = mm1_seq(fw, ebwtfw, len - 1);
-					top = topp = e.fchr[c];
-					bot = botp = e.fchr[c + 1];
-					if (bot - top == 0) continue;
-					dep = 1;
-				}
-				bool do_continue = false;
-				for (; dep < nea; dep++) {
-					const int rdc = mm1_seq(fw, ebwtfw, len - dep - 1);
-					if (bot - top > 1) {
-						w.n_bwops_seed++;
-						bi_lf(e, top, bot, topp, t, b, tp, bp);
-						top = t[rdc]; bot = b[rdc];
-						if (bot <= top) { do_continue = true; break; }
-						topp = tp[rdc]; botp = bp[rdc];
-					} else {
-						w.n_bwops_seed++;
-						top = lf1c(e, top, rdc);
-						if (top == kOffMask) { do_continue = true; break; }
-						bot = top + 1;
-					}
-				}
-				if (do_continue) continue;
-				for (; dep < len; dep++) {
-					const int rdc = mm1_seq(fw, ebwtfw, len - dep - 1);
-					const int quc = mm1_qual(fw, ebwtfw, len - dep - 1);
-					if (rdc > 3 && nceil == 0) break;
-					int clo = 0, chi = 3;
-					bool match = true;
-					if (bot - top > 1) {
-						w.n_bwops_seed++;
-						bi_lf(e, top, bot, topp, t, b, tp, bp);
-						match = rdc < 4;
-						if (match) { top = t[rdc]; bot = b[rdc]; topp = tp[rdc]; botp = bp[rdc]; }
-						else { top = bot = 0; }
-					} else {
-						w.n_bwops_seed++;
-						TOff row = top;
-						clo = lf1(e, row);
-						match = (clo == rdc);
-						if (clo < 0) break;
-						top = row;
-						t[clo] = top; b[clo] = bot = top + 1;
-						bp[clo] = botp; tp[clo] = topp;
-						chi = clo;
-					}
-					if (ns == 0 || rdc > 3) {
-						for (int j = clo; j <= chi; j++) {
-							if (j == rdc || b[j] == t[j]) continue;
-							uint32_t depm = dep + 1;
-							TOff topm = t[j], botm = b[j], topmp = tp[j], botmp = bp[j];
-							TOff tm[4], bm[4], tmp[4], bmp[4];
-							for (; depm < len; depm++) {
-								const int rdcm = mm1_seq(fw, ebwtfw, len - depm - 1);
-								if (botm - topm > 1) {
-									w.n_bwops_seed++;
-									bi_lf(e, topm, botm, topmp, tm, bm, tmp, bmp);
-									if (rdcm > 3) { topm = botm = 0; break; }
-									topm = tm[rdcm]; botm = bm[rdcm];
-									topmp = tmp[rdcm]; botmp = bmp[rdcm];
-									if (botm <= topm) break;
-								} else {
-									w.n_bwops_seed++;
-									topm = lf1c(e, topm, rdcm);
-									if (topm == kOffMask) break;
-									botm = topm + 1;
-								}
-							}
-							if (depm == len) {
-								uint32_t off5p = dep;
-								if (fw == ebwtfw) off5p = len - off5p - 1;
-								int64_t score = (int64_t)(len - 1) * P.match_bonus;
-								score += sc_score(P, rdc, 1 << j, quc - 33);
-								if (score >= rp.minsc) {
-									if (w.n_mm1 >= (uint32_t)kMaxMm1) { w.err |= ERR_OVERFLOW; }
-									else {
-										EEHit& h = w.mm1[w.n_mm1++];
-										h.top = ebwtfw ? topm : topmp;
-										h.bot = ebwtfw ? botm : botmp;
-										h.score = (int32_t)score;
-										h.epos = (uint16_t)off5p; h.echr = (uint8_t)j; h.eqchr = (uint8_t)rdc;
-										h.fw = fw ? 1 : 0; h.has_edit = 1;
-										w.mm1_elt += (uint64_t)(h.bot - h.top);
-									}
-								}
-							}
-						}
-					}
-					if (bot > top && match) {
-						if (dep == len - 1) break;   // exact hit; not reported here (repex=false)
-					} else {
-						break;
-					}
-				}
+				fm_one_mm_dir(ix, P, (int64_t)rp.minsc, rp.nceil, rd, len, ns, fw, ebwtfwi == 0,
+					[&](const Mm1Hit& m) { add_mm1(m, fw); }, cnt);
 			}
 		}
+		w.n_bwops_seed += cnt.bwops; w.n_sides += cnt.sides;
+	}
+
+	BT2_HD void add_mm1(const Mm1Hit& m, bool fw) {
+		if (w.n_mm1 >= (uint32_t)kMaxMm1) { w.err |= ERR_OVERFLOW; return; }
+		EEHit& h = w.mm1[w.n_mm1++];
+		h.top = m.top; h.bot = m.bot; h.score = m.score;
+		h.epos = m.epos; h.echr = m.echr; h.eqchr = m.eqchr;
+		h.fw = fw ? 1 : 0; h.has_edit = 1;
+		w.mm1_elt += (uint64_t)(m.bot - m.top);
 	}
 
 	// One -N 0 seeding round: Seed::mmSeeds + instantiateSeeds + searchAllSeeds
@@ -462,71 +418,10 @@ struct Aligner {
 	// SwDriver::extend (aligner_sw_driver.cpp:299-484)
 	BT2_HDN void extend_hit(TOff topf, TOff botf, TOff topb, TOff botb, bool fw, uint32_t off, uint32_t len,
 	                       uint32_t& nlex, uint32_t& nrex) {
-		const uint32_t rdlen = w.len;
-		TOff t[4], b[4], tp[4], bp[4];
-		nlex = nrex = 0;
-		uint32_t lim = fw ? off : rdlen - len - off;
-		if (lim > 0) {
-			const DevEbwt<TOff>& e = ix.fw;
-			TOff top = topf, bot = botf;
-			for (uint32_t ii = 0; ii < lim; ii++) {
-				const uint32_t i = fw ? off - ii - 1 : rdlen - off - len - 1 - ii;
-				const int rdc = rd_char(HOT, w.len, fw, i);
-				if (bot - top > 1) {
-					w.n_bwops_ext++;
-					bi_lf(e, top, bot, topb, t, b, tp, bp);
-					int nonz = -1;
-					bool abort = false;
-					const TOff orig = bot - top;
-					for (int j = 0; j < 4; j++) {
-						if (b[j] > t[j]) {
-							if (nonz >= 0) { abort = true; break; }
-							nonz = j; top = t[j]; bot = b[j];
-						}
-					}
-					if (abort || (nonz != rdc && rdc <= 3) || bot - top < orig) break;
-				} else {
-					w.n_bwops_ext++;
-					TOff row = top;
-					const int c = lf1(e, row);
-					top = row;
-					if (c != rdc && rdc <= 3) break;
-					bot = top + 1;
-				}
-				if (++nlex == 255) break;
-			}
-		}
-		lim = fw ? rdlen - len - off : off;
-		if (lim > 0) {
-			const DevEbwt<TOff>& e = ix.bw;
-			TOff top = topb, bot = botb;
-			for (uint32_t ii = 0; ii < lim; ii++) {
-				const uint32_t i = fw ? ii + len + off : rdlen - off + ii;
-				const int rdc = rd_char(HOT, w.len, fw, i);
-				if (bot - top > 1) {
-					w.n_bwops_ext++;
-					bi_lf(e, top, bot, topf, t, b, tp, bp);
-					int nonz = -1;
-					bool abort = false;
-					const TOff orig = bot - top;
-					for (int j = 0; j < 4; j++) {
-						if (b[j] > t[j]) {
-							if (nonz >= 0) { abort = true; break; }
-							nonz = j; top = t[j]; bot = b[j];
-						}
-					}
-					if (abort || (nonz != rdc && rdc <= 3) || bot - top < orig) break;
-				} else {
-					w.n_bwops_ext++;
-					TOff row = top;
-					const int c = lf1(e, row);
-					top = row;
-					if (c != rdc && rdc <= 3) break;
-					bot = top + 1;
-				}
-				if (++nrex == 255) break;
-			}
-		}
+		FmCount cnt; cnt.bwops = 0; cnt.sides = 0;
+		HotRd rd;
+		fm_extend_hit(ix, rd, w.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt);
+		w.n_bwops_ext += cnt.bwops; w.n_sides += cnt.sides;
 	}
 
 	// SATupleAndPos::operator< (aligner_sw_driver.h:150-160)
@@ -657,7 +552,12 @@ struct Aligner {
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
 			uint32_t nlex = 0, nrex = 0;
-			if (P.do_extend) extend_hit((TOff)h.topf, (TOff)(h.topf + sz), (TOff)h.topb, (TOff)(h.topb + sz), fw, rdoff, seedlen, nlex, nrex);
+			if (P.do_extend) {
+				if (ext_pre && seedmms == 0) {
+					const uint32_t e = pre->ext[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + offidx];
+					nlex = e & 0xffffu; nrex = e >> 16;
+				} else extend_hit((TOff)h.topf, (TOff)(h.topf + sz), (TOff)h.topb, (TOff)(h.topb + sz), fw, rdoff, seedlen, nlex, nrex);
+			}
 			s.nlex = nlex; s.nrex = nrex;
 			w.n_ext_left += nlex; w.n_ext_right += nrex;
 			if (seedmms == 0 && (nlex > 0 || nrex > 0)) {
@@ -1372,7 +1272,7 @@ struct Aligner {
 			uint32_t mine[2] = {0, 0};
 			uint64_t nelt = 0;
 			if (P.do_exact_upfront) {
-				{ const uint64_t t0_ = now(); nelt = exact_sweep(2, mine); w.t_phase[0] += now() - t0_; }
+				{ const uint64_t t0_ = now(); nelt = (pre && pre->sweep) ? exact_sweep_pre(mine) : exact_sweep(2, mine); w.t_phase[0] += now() - t0_; }
 				if (nelt == 0) { w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0; }
 				else {
 					const int ret = extend_seeds(-1, 0, 0);
@@ -1386,7 +1286,11 @@ struct Aligner {
 					const bool yfw = mine[0] <= 1 && !P.nofw;
 					const bool yrc = mine[1] <= 1 && !P.norc;
 					nelt = 0;
-					if (yfw || yrc) { const uint64_t t0_ = now(); one_mm_search(!yfw, !yrc); nelt = w.mm1_elt; w.t_phase[1] += now() - t0_; }
+					if (yfw || yrc) {
+						const uint64_t t0_ = now();
+						if (!(pre && pre->mm1 && one_mm_pre(!yfw, !yrc))) one_mm_search(!yfw, !yrc);
+						nelt = w.mm1_elt; w.t_phase[1] += now() - t0_;
+					}
 					if (nelt > 0) {
 						const int ret = extend_seeds(-1, 0, 0);
 						w.n_mm1 = 0; w.mm1_elt = 0;
@@ -1405,7 +1309,12 @@ struct Aligner {
 				const uint32_t offset = (interval * roundi) / nrounds;
 				if (offset > 0 && (uint32_t)rp.seedlen + offset > len) continue;
 				const uint64_t ts_ = now();
-				const uint32_t ninst = seed_round(offset, interval, (uint32_t)rp.seedlen);
+				ext_pre = false;
+				uint32_t ninst;
+				if (offset == 0 && pre && pre->seeds && 1 + (len > (uint32_t)rp.seedlen ? (len - (uint32_t)rp.seedlen) / interval : 0u) <= pre->max_seeds) {
+					ninst = seed_round_pre(interval, (uint32_t)rp.seedlen);
+					ext_pre = pre->ext != nullptr;
+				} else ninst = seed_round(offset, interval, (uint32_t)rp.seedlen);
 				w.t_phase[2] += now() - ts_;
 				if (ninst == 0) { done = true; w.nonz_tot = 0; continue; }
 				if (w.nonz_tot == 0) { done = true; continue; }

@@ -123,7 +123,8 @@ template <typename TOff>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU)))
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
-              uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof) {
+              uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
+              PreComp pre) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	Work& w = *reinterpret_cast<Work*>(base);
@@ -149,7 +150,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		for (uint32_t i = lane; i < len; i += 64) { g_hot.seq[i] = rd.d_seq[o0 + i]; g_hot.qual[i] = rd.d_qual[o0 + i]; }
 		wave_fence();
 		const ReadParams rp = rparams[r];
-		Aligner<TOff, DevPlat> al(ix, P, rp, w, dp);
+		Aligner<TOff, DevPlat> al(ix, P, rp, w, dp, &pre, r);
 		al.run(out);
 		wave_fence();
 		{
@@ -169,12 +170,13 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
-                        uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof, hipStream_t st) {
+                        uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
+                        const PreComp& pre, hipStream_t st) {
 	if (rd.n_reads == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
-	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof);
+	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre);
 	return hipGetLastError();
 }
 
@@ -193,7 +195,7 @@ void align_scratch_sizes(uint32_t max_len, uint64_t& mat_bytes, uint64_t& mask_b
 uint64_t align_work_bytes() { return sizeof(Work); }
 uint32_t align_waves_per_cu() { return 4u * BT2G_WAVES_PER_EU; }
 
-template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, hipStream_t);
-template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, hipStream_t);
+template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, hipStream_t);
+template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, hipStream_t);
 
 } // namespace bt2g

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -34,6 +35,9 @@ struct bt2g_ctx {
 	uint8_t* d_arena = nullptr;          // per-wave Work + DP scratch of the fused worker
 	uint64_t arena_bytes = 0;
 	unsigned int* d_next = nullptr;      // work-queue head
+	uint8_t* d_pre = nullptr;            // batch pre-computation (sweep, round-0 seed hits, extensions, 1-mm hits)
+	uint64_t pre_bytes = 0;
+	bool precomp = true;                 // BT2G_NO_PRECOMP=1: the worker computes every FM phase itself (A/B testing)
 };
 
 namespace {
@@ -129,6 +133,7 @@ int bt2g_ctx_create(int device, bt2g_ctx** out) {
 	if (!c) return BT2G_ERR_NOMEM;
 	c->device = device;
 	c->n_cu = (uint32_t)prop.multiProcessorCount;
+	{ const char* v = std::getenv("BT2G_NO_PRECOMP"); c->precomp = !(v && v[0] == '1'); }
 	if (hipMalloc((void**)&c->d_cnt, sizeof(DevCounters)) != hipSuccess) { delete c; return BT2G_ERR_HIP; }
 	(void)hipMemset(c->d_cnt, 0, sizeof(DevCounters));
 	*out = c;
@@ -142,6 +147,7 @@ void bt2g_ctx_destroy(bt2g_ctx* c) {
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
 	if (c->d_dp_scratch) (void)hipFree(c->d_dp_scratch);
 	if (c->d_arena) (void)hipFree(c->d_arena);
+	if (c->d_pre) (void)hipFree(c->d_pre);
 	if (c->d_next) (void)hipFree(c->d_next);
 	delete c;
 }
@@ -207,8 +213,8 @@ int bt2g_seed_search_exact(bt2g_ctx* c, const bt2g_reads* reads, const uint32_t*
 	if (!reads || !d_out || !d_seedlen || !d_interval || !d_offset || max_seeds == 0) return fail(c, BT2G_ERR_ARG, "bad argument");
 	hipStream_t st = (hipStream_t)stream;
 	hipError_t e = (c->off_size == 4)
-		? launch_seed_search_exact(c->ix32, *reads, d_seedlen, d_interval, d_offset, max_seeds, d_out, c->d_cnt, st)
-		: launch_seed_search_exact(c->ix64, *reads, d_seedlen, d_interval, d_offset, max_seeds, d_out, c->d_cnt, st);
+		? launch_seed_search_exact(c->ix32, *reads, d_seedlen, d_interval, d_offset, nullptr, max_seeds, d_out, c->d_cnt, st)
+		: launch_seed_search_exact(c->ix64, *reads, d_seedlen, d_interval, d_offset, nullptr, max_seeds, d_out, c->d_cnt, st);
 	return e == hipSuccess ? 0 : hip_fail(c, e, "k_seed_search_exact");
 }
 
@@ -300,10 +306,69 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(queue head)");
 		(void)hipMemset(c->d_next, 0, 256);
 	}
+	// The pure FM phases of every read (exact sweep, 1-mismatch search, seed round 0 and its seed-hit
+	// extension) run first as lane-per-task kernels; the per-read worker then consumes their output.
+	PreComp pre;
+	memset(&pre, 0, sizeof(pre));
+	if (c->precomp) {
+		unsigned int max_seeds = 0;
+		e = launch_max_seeds(*reads, d_rparams, c->d_next + 8, st);
+		if (e == hipSuccess) e = hipMemcpyAsync(&max_seeds, c->d_next + 8, sizeof(max_seeds), hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		if (e != hipSuccess) return hip_fail(c, e, "k_max_seeds");
+		if (max_seeds < 1) max_seeds = 1;
+		if (max_seeds > 64) max_seeds = 64;       // kMaxOffs: longer seed lists are flagged by the worker
+		const uint32_t cap = 8;
+		const uint64_t n = reads->n_reads;
+		auto al = [](uint64_t v) { return (v + 255) & ~255ull; };
+		const uint64_t b_sweep = al(n * sizeof(bt2g_sweep_out));
+		const uint64_t b_seeds = al(n * 2 * max_seeds * sizeof(bt2g_seed_hit));
+		const uint64_t b_ext = al(n * 2 * max_seeds * sizeof(uint32_t));
+		const uint64_t b_mm1 = al(n * 4 * cap * sizeof(Mm1Hit));
+		const uint64_t b_mm1n = al(n * 4);
+		const uint64_t tot = b_sweep + b_seeds + b_ext + b_mm1 + b_mm1n;
+		if (tot > c->pre_bytes) {
+			if (c->d_pre) (void)hipFree(c->d_pre);
+			c->d_pre = nullptr; c->pre_bytes = 0;
+			e = hipMalloc((void**)&c->d_pre, tot);
+			if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(pre-computation)");
+			c->pre_bytes = tot;
+		}
+		uint8_t* p = c->d_pre;
+		bt2g_sweep_out* d_sweep = (bt2g_sweep_out*)p; p += b_sweep;
+		bt2g_seed_hit* d_seeds = (bt2g_seed_hit*)p; p += b_seeds;
+		uint32_t* d_ext = (uint32_t*)p; p += b_ext;
+		Mm1Hit* d_mm1 = (Mm1Hit*)p; p += b_mm1;
+		uint8_t* d_mm1n = p;
+		const bool s = c->off_size == 4;
+		if (params->do_exact_upfront) {
+			e = s ? launch_exact_sweep(c->ix32, *reads, params->nofw, params->norc, 2, d_sweep, c->d_cnt, st)
+			      : launch_exact_sweep(c->ix64, *reads, params->nofw, params->norc, 2, d_sweep, c->d_cnt, st);
+			if (e != hipSuccess) return hip_fail(c, e, "k_exact_sweep");
+			pre.sweep = d_sweep;
+			if (params->do_1mm_upfront) {
+				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, c->d_cnt, st)
+				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, c->d_cnt, st);
+				if (e != hipSuccess) return hip_fail(c, e, "k_one_mm");
+				pre.mm1 = d_mm1; pre.mm1_n = d_mm1n;
+			}
+		}
+		e = s ? launch_seed_search_exact(c->ix32, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st)
+		      : launch_seed_search_exact(c->ix64, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st);
+		if (e != hipSuccess) return hip_fail(c, e, "k_seed_search_exact");
+		pre.seeds = d_seeds;
+		if (params->do_extend) {
+			e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, d_seeds, d_ext, c->d_cnt, st)
+			      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, d_seeds, d_ext, c->d_cnt, st);
+			if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits");
+			pre.ext = d_ext;
+		}
+		pre.max_seeds = max_seeds; pre.mm1_cap = cap;
+	}
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	e = (c->off_size == 4)
-		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), st)
-		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), st);
+		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, st)
+		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, st);
 	return e == hipSuccess ? 0 : hip_fail(c, e, "k_align_reads");
 }
 

@@ -1,0 +1,244 @@
+// bt2g_fm_search.hpp -- the pure FM-index phases of the worker as free functions.
+//
+// "Pure" = their result depends only on the read and the index, not on RNG state, limits or
+// what has been reported so far.  That makes them batchable: bt2g_kernels.hip runs them one
+// lane per task for a whole batch (thousands of independent backward-search chains in flight,
+// the HBM-bound shape), and the per-read worker consumes the results in the reference's order.
+// The same functions are also called inline by the worker for the cases that are not
+// pre-computed (re-seeding rounds, buffer overflow), so both paths share one implementation.
+//
+//   fm_extend_hit   SwDriver::extend            aligner_sw_driver.cpp:299-484
+//   fm_one_mm_dir   SeedAligner::oneMmSearch    aligner_seed.cpp:975-1325 (one fw/rc x BWT/BWT' combination)
+#ifndef BT2G_FM_SEARCH_HPP_
+#define BT2G_FM_SEARCH_HPP_
+
+#include "bt2g_device.hpp"
+#include "../../include/bt2g.h"
+
+namespace bt2g {
+
+struct FmCount { uint32_t bwops, sides; };
+
+BT2_HD int fm_comp(int c) { return c < 4 ? 3 - c : 4; }
+
+// mapBiLFEx (bt2_idx.h:2372): ranks of all four characters at top and bot of `e`, and the prefix
+// sums that update the range in the other index, starting at topp.
+template <typename TOff>
+BT2_HD void fm_bi_lf(const DevEbwt<TOff>& e, TOff top, TOff bot, TOff topp, TOff t[4], TOff b[4], TOff tp[4], TOff bp[4], FmCount& cnt) {
+	cnt.sides += (uint32_t)rank4_pair(e, top, bot, t, b);
+	tp[0] = topp;
+	bp[0] = tp[0] + (b[0] - t[0]);
+	tp[1] = bp[0]; bp[1] = tp[1] + (b[1] - t[1]);
+	tp[2] = bp[1]; bp[2] = tp[2] + (b[2] - t[2]);
+	tp[3] = bp[2]; bp[3] = tp[3] + (b[3] - t[3]);
+}
+
+// RD: struct with `int seq(uint32_t i) const` (fw read char, codes 0..4) and `int qual(uint32_t i) const` (ASCII)
+template <typename RD>
+BT2_HD int fm_rd_char(const RD& rd, uint32_t rdlen, bool fw, uint32_t i) { return fw ? rd.seq(i) : fm_comp(rd.seq(rdlen - 1 - i)); }
+
+// Extend a seed hit left (forward index) and right (mirror index) while the SA range keeps its
+// size and the read agrees; at most 255 positions each way.
+template <typename TOff, typename RD>
+BT2_HD void fm_extend_hit(const DevIndex<TOff>& ix, const RD& rd, uint32_t rdlen, TOff topf, TOff botf, TOff topb, TOff botb,
+                          bool fw, uint32_t off, uint32_t len, uint32_t& nlex, uint32_t& nrex, FmCount& cnt) {
+	TOff t[4], b[4], tp[4], bp[4];
+	nlex = nrex = 0;
+	for (int side = 0; side < 2; side++) {
+		const bool left = side == 0;
+		const uint32_t lim = left ? (fw ? off : rdlen - len - off) : (fw ? rdlen - len - off : off);
+		if (lim == 0) continue;
+		const DevEbwt<TOff>& e = left ? ix.fw : ix.bw;
+		TOff top = left ? topf : topb, bot = left ? botf : botb;
+		const TOff other = left ? topb : topf;
+		uint32_t n = 0;
+		for (uint32_t ii = 0; ii < lim; ii++) {
+			uint32_t i;
+			if (left) i = fw ? off - ii - 1 : rdlen - off - len - 1 - ii;
+			else      i = fw ? ii + len + off : rdlen - off + ii;
+			const int rdc = fm_rd_char(rd, rdlen, fw, i);
+			if (bot - top > 1) {
+				cnt.bwops++;
+				fm_bi_lf(e, top, bot, other, t, b, tp, bp, cnt);
+				int nonz = -1;
+				bool abort = false;
+				const TOff orig = bot - top;
+				for (int j = 0; j < 4; j++) {
+					if (b[j] > t[j]) {
+						if (nonz >= 0) { abort = true; break; }
+						nonz = j; top = t[j]; bot = b[j];
+					}
+				}
+				if (abort || (nonz != rdc && rdc <= 3) || bot - top < orig) break;
+			} else {
+				cnt.bwops++;
+				if (top != e.zoff) cnt.sides++;
+				TOff row = top;
+				const int c = map_lf1(e, row);
+				top = row;
+				if (c != rdc && rdc <= 3) break;
+				bot = top + 1;
+			}
+			if (++n == 255) break;
+		}
+		if (left) nlex = n; else nrex = n;
+	}
+}
+
+// 1-mismatch end-to-end hit as oneMmSearch reports it (EEHit with one Edit)
+struct Mm1Hit {
+	uint64_t top, bot;
+	int32_t  score;
+	uint16_t epos;         // offset from the 5' end
+	uint8_t  echr, eqchr;  // reference char / read char, codes 0..4
+};
+
+// Batch-wide results of the pure FM phases, computed by lane-per-task kernels before the fused
+// worker runs (bt2g_kernels.hip).  Any pointer may be null: the worker then computes that phase itself.
+struct PreComp {
+	const bt2g_sweep_out* sweep;   // [n_reads]                       exactSweep
+	const bt2g_seed_hit*  seeds;   // [n_reads][2][max_seeds]         seed round 0 (offset 0)
+	const uint32_t*       ext;     // [n_reads][2][max_seeds]         nlex | nrex << 16 of each non-empty seed hit
+	const Mm1Hit*         mm1;     // [n_reads][2 strands][2 dirs][mm1_cap]
+	const uint8_t*        mm1_n;   // [n_reads][4]   hits per list; 255 = list overflowed
+	uint32_t max_seeds, mm1_cap;
+};
+
+// One (read strand, index direction) combination of oneMmSearch with repex=false, rep1mm=true.
+// emit(const Mm1Hit&) is called for every valid 1-mismatch end-to-end hit, in discovery order.
+template <typename TOff, typename RD, typename Emit>
+BT2_HD void fm_one_mm_dir(const DevIndex<TOff>& ix, const bt2g_align_params& P, int64_t minsc, int nceil,
+                          const RD& rd, uint32_t len, uint32_t ns, bool fw, bool ebwtfw, Emit emit, FmCount& cnt) {
+	constexpr TOff kMask = (TOff)OffTraits<TOff>::kMask;
+	const DevEbwt<TOff>& e = ebwtfw ? ix.fw : ix.bw;
+	const DevEbwt<TOff>& ep = ebwtfw ? ix.bw : ix.fw;
+	// seq views (aligner_seed.cpp:1031-1040): fw: patFw | patFwRev ; rc: patRc | patRcRev
+	auto sq = [&](uint32_t i) -> int {
+		if (fw) return ebwtfw ? rd.seq(i) : rd.seq(len - 1 - i);
+		return ebwtfw ? fm_comp(rd.seq(len - 1 - i)) : fm_comp(rd.seq(i));
+	};
+	auto ql = [&](uint32_t i) -> int {
+		const bool rev = fw ? !ebwtfw : ebwtfw;
+		return rev ? rd.qual(len - 1 - i) : rd.qual(i);
+	};
+	const uint32_t halfFw = len >> 1;
+	const uint32_t halfBw = (len >> 1) + ((len & 1) ? 1 : 0);
+	const uint32_t ftab_len = e.ftab_chars;
+	const uint32_t nea = ebwtfw ? halfFw : halfBw;
+	for (uint32_t dep = 0; dep < nea; dep++) if (sq(len - dep - 1) > 3) return;
+	TOff t[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, tp[4] = {0, 0, 0, 0}, bp[4] = {0, 0, 0, 0};
+	uint32_t dep = 0;
+	TOff top = 0, bot = 0, topp = 0, botp = 0;
+	if (ftab_len > 1 && ftab_len <= nea) {
+		uint64_t kt = 0, kr = 0;   // the window seq[len-ftab, len): text order in `e`, reversed in `ep`
+		for (uint32_t i = 0; i < ftab_len; i++) {
+			kt = (kt << 2) | (uint64_t)sq(len - ftab_len + i);
+			kr = (kr << 2) | (uint64_t)sq(len - 1 - i);
+		}
+		top = ftab_hi(e, kt); bot = ftab_lo(e, kt + 1);
+		topp = ftab_hi(ep, kr); botp = ftab_lo(ep, kr + 1);
+		if (bot - top == 0) return;
+		dep = ftab_len;
+	} else {
+		const int c = sq(len - 1);
+		top = topp = e.fchr[c];
+		bot = botp = e.fchr[c + 1];
+		if (bot - top == 0) return;
+		dep = 1;
+	}
+	for (; dep < nea; dep++) {
+		const int rdc = sq(len - dep - 1);
+		if (bot - top > 1) {
+			cnt.bwops++;
+			fm_bi_lf(e, top, bot, topp, t, b, tp, bp, cnt);
+			top = t[rdc]; bot = b[rdc];
+			if (bot <= top) return;
+			topp = tp[rdc]; botp = bp[rdc];
+		} else {
+			cnt.bwops++; cnt.sides++;
+			top = map_lf1c(e, top, rdc);
+			if (top == kMask) return;
+			bot = top + 1;
+		}
+	}
+	for (; dep < len; dep++) {
+		const int rdc = sq(len - dep - 1);
+		const int quc = ql(len - dep - 1);
+		if (rdc > 3 && nceil == 0) break;
+		int clo = 0, chi = 3;
+		bool match = true;
+		if (bot - top > 1) {
+			cnt.bwops++;
+			fm_bi_lf(e, top, bot, topp, t, b, tp, bp, cnt);
+			match = rdc < 4;
+			if (match) { top = t[rdc]; bot = b[rdc]; topp = tp[rdc]; botp = bp[rdc]; }
+			else { top = bot = 0; }
+		} else {
+			cnt.bwops++;
+			if (top != e.zoff) cnt.sides++;
+			TOff row = top;
+			clo = map_lf1(e, row);
+			match = (clo == rdc);
+			if (clo < 0) break;
+			top = row;
+			t[clo] = top; b[clo] = bot = top + 1;
+			bp[clo] = botp; tp[clo] = topp;
+			chi = clo;
+		}
+		if (ns == 0 || rdc > 3) {
+			for (int j = clo; j <= chi; j++) {
+				if (j == rdc || b[j] == t[j]) continue;
+				uint32_t depm = dep + 1;
+				TOff topm = t[j], botm = b[j], topmp = tp[j], botmp = bp[j];
+				TOff tm[4], bm[4], tmp[4], bmp[4];
+				for (; depm < len; depm++) {
+					const int rdcm = sq(len - depm - 1);
+					if (botm - topm > 1) {
+						cnt.bwops++;
+						fm_bi_lf(e, topm, botm, topmp, tm, bm, tmp, bmp, cnt);
+						if (rdcm > 3) { topm = botm = 0; break; }
+						topm = tm[rdcm]; botm = bm[rdcm];
+						topmp = tmp[rdcm]; botmp = bmp[rdcm];
+						if (botm <= topm) break;
+					} else {
+						cnt.bwops++; cnt.sides++;
+						topm = map_lf1c(e, topm, rdcm);
+						if (topm == kMask) break;
+						botm = topm + 1;
+					}
+				}
+				if (depm == len) {
+					uint32_t off5p = dep;
+					if (fw == ebwtfw) off5p = len - off5p - 1;
+					int64_t score = (int64_t)(len - 1) * P.match_bonus;
+					int pen;   // Scoring::score(rdc, 1<<j, quc-33)
+					{
+						int q = quc - 33; if (q < 0) q = 0; if (q > 255) q = 255;
+						if (rdc > 3) pen = -P.n_pen;
+						else if (rdc == j) pen = P.match_bonus;
+						else {
+							if (P.mm_type == 3) { const int qq = q < 40 ? q : 40; const float frac = (float)qq / 40.0f; pen = -(P.mm_min + (int)(frac * (float)(P.mm_max - P.mm_min))); }
+							else pen = -P.mm_max;
+						}
+					}
+					score += pen;
+					if (score >= minsc) {
+						Mm1Hit h;
+						h.top = ebwtfw ? (uint64_t)topm : (uint64_t)topmp;
+						h.bot = ebwtfw ? (uint64_t)botm : (uint64_t)botmp;
+						h.score = (int32_t)score; h.epos = (uint16_t)off5p; h.echr = (uint8_t)j; h.eqchr = (uint8_t)rdc;
+						emit(h);
+					}
+				}
+			}
+		}
+		if (bot > top && match) {
+			if (dep == len - 1) break;   // exact end-to-end hit: not reported here (repex = false)
+		} else {
+			break;
+		}
+	}
+}
+
+} // namespace bt2g
+#endif

@@ -15,6 +15,7 @@
 // is written in "wavefront-major" order so that every store instruction writes 64 contiguous
 // bytes.
 #include "bt2g_kernels.hpp"
+#include "bt2g_fm_search.hpp"
 
 namespace bt2g {
 
@@ -156,6 +157,7 @@ template <typename TOff>
 __global__ void __launch_bounds__(256)
 k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict__ d_seedlen,
                     const uint32_t* __restrict__ d_interval, const uint32_t* __restrict__ d_offset,
+                    const bt2g_read_params* __restrict__ rparams,
                     uint32_t max_seeds, bt2g_seed_hit* __restrict__ out, DevCounters* cnt) {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
@@ -169,8 +171,8 @@ k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict
 		const uint64_t o0 = rd.d_off[r];
 		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
 		const uint8_t* seq = rd.d_seq + o0;
-		uint32_t L = d_seedlen[r];
-		const uint32_t per = d_interval[r], off = d_offset[r];
+		uint32_t L = rparams ? (uint32_t)rparams[r].seedlen : d_seedlen[r];
+		const uint32_t per = rparams ? (uint32_t)rparams[r].interval : d_interval[r], off = rparams ? 0u : d_offset[r];
 		if (L > len) L = len;   // Seed::instantiate shrinks the seed to the read (aligner_seed.cpp:226-230)
 		// instantiateSeeds (:523-526)
 		uint32_t nseeds = 0;
@@ -244,15 +246,15 @@ k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict
 
 template <typename TOff>
 hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& rd, const uint32_t* d_seedlen,
-                                    const uint32_t* d_interval, const uint32_t* d_offset, uint32_t max_seeds,
-                                    bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st) {
+                                    const uint32_t* d_interval, const uint32_t* d_offset, const bt2g_read_params* d_rparams,
+                                    uint32_t max_seeds, bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st) {
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	if (total == 0) return hipSuccess;
 	const uint32_t block = 256;
 	const uint64_t grid = (total + block - 1) / block;
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
 	hipLaunchKernelGGL(k_seed_search_exact<TOff>, dim3((uint32_t)grid), dim3(block), 0, st, ix, rd, d_seedlen, d_interval,
-	                   d_offset, max_seeds, d_out, d_cnt);
+	                   d_offset, d_rparams, max_seeds, d_out, d_cnt);
 	return hipGetLastError();
 }
 
@@ -482,11 +484,137 @@ hipError_t launch_sw_fill_ee_u8(const bt2g_scoring& s, const bt2g_dp_problem* d_
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// seed-hit extension (SwDriver::extend) for every non-empty round-0 seed hit, one lane per hit
+// ------------------------------------------------------------------------------------
+struct GlobRd {
+	const uint8_t* s; const uint8_t* q;
+	__device__ __forceinline__ int seq(uint32_t i) const { return s[i]; }
+	__device__ __forceinline__ int qual(uint32_t i) const { return q[i]; }
+};
+
+template <typename TOff>
+__global__ void __launch_bounds__(256)
+k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t max_seeds,
+              const bt2g_seed_hit* __restrict__ hits, uint32_t* __restrict__ ext, DevCounters* cnt) {
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
+	FmCount c; c.bwops = 0; c.sides = 0;
+	if (gid < total) {
+		const bt2g_seed_hit h = hits[gid];
+		uint32_t e = 0;
+		if (h.botf > h.topf) {
+			const uint32_t i = (uint32_t)(gid % max_seeds);
+			const uint64_t rs = gid / max_seeds;
+			const uint32_t r = (uint32_t)(rs >> 1);
+			const bool fw = (rs & 1) == 0;
+			const uint64_t o0 = rd.d_off[r];
+			const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
+			uint32_t L = (uint32_t)rparams[r].seedlen;
+			if (L > len) L = len;
+			const uint32_t rdoff = i * (uint32_t)rparams[r].interval;
+			GlobRd g; g.s = rd.d_seq + o0; g.q = rd.d_qual + o0;
+			uint32_t nlex = 0, nrex = 0;
+			fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c);
+			e = nlex | (nrex << 16);
+		}
+		ext[gid] = e;
+	}
+	wave_add_counter(&cnt->rank_queries, c.sides);
+	wave_add_counter(&cnt->bwops, c.bwops);
+}
+
+template <typename TOff>
+hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds,
+                              const bt2g_seed_hit* d_hits, uint32_t* d_ext, DevCounters* d_cnt, hipStream_t st) {
+	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
+	if (total == 0) return hipSuccess;
+	const uint64_t grid = (total + 255) / 256;
+	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, rd, d_rparams, max_seeds, d_hits, d_ext, d_cnt);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// 1-mismatch end-to-end search, one lane per (read, strand, index direction)
+// ------------------------------------------------------------------------------------
+template <typename TOff>
+__global__ void __launch_bounds__(256)
+k_one_mm(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams,
+         const bt2g_sweep_out* __restrict__ sweep, uint32_t cap, Mm1Hit* __restrict__ out, uint8_t* __restrict__ out_n,
+         DevCounters* cnt) {
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	FmCount c; c.bwops = 0; c.sides = 0;
+	if (gid < (uint64_t)rd.n_reads * 4) {
+		const uint32_t r = (uint32_t)(gid >> 2);
+		const bool fw = ((gid >> 1) & 1) == 0;
+		const bool ebwtfw = (gid & 1) == 0;
+		const uint64_t o0 = rd.d_off[r];
+		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
+		uint32_t n = 0;
+		const bt2g_read_params rp = rparams[r];
+		// the worker only searches a strand whose exact sweep proved <= 1 edit possible (bt2_search.cpp:3704-3706)
+		const bool want = (rp.filt & 15u) == 15u && len >= 2 && sweep[r].mine[fw ? 0 : 1] <= 1 && !(fw ? P.nofw : P.norc);
+		if (want) {
+			GlobRd g; g.s = rd.d_seq + o0; g.q = rd.d_qual + o0;
+			uint32_t ns = 0;
+			for (uint32_t i = 0; i < len; i++) if (g.s[i] > 3) ns++;
+			if (ns <= 1) {
+				Mm1Hit* dst = out + gid * cap;
+				fm_one_mm_dir(ix, P, (int64_t)rp.minsc, rp.nceil, g, len, ns, fw, ebwtfw,
+					[&](const Mm1Hit& m) { if (n < cap) dst[n] = m; n++; }, c);
+			}
+		}
+		out_n[gid] = n > cap ? (uint8_t)255 : (uint8_t)n;   // 255: more hits than the buffer holds -> the worker redoes this read inline
+	}
+	wave_add_counter(&cnt->rank_queries, c.sides);
+	wave_add_counter(&cnt->bwops, c.bwops);
+}
+
+template <typename TOff>
+hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, const bt2g_reads& rd, const bt2g_read_params* d_rparams,
+                         const bt2g_sweep_out* d_sweep, uint32_t cap, void* d_out, uint8_t* d_out_n, DevCounters* d_cnt, hipStream_t st) {
+	const uint64_t total = (uint64_t)rd.n_reads * 4;
+	if (total == 0) return hipSuccess;
+	const uint64_t grid = (total + 255) / 256;
+	hipLaunchKernelGGL(k_one_mm<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, P, rd, d_rparams, d_sweep, cap, (Mm1Hit*)d_out, d_out_n, d_cnt);
+	return hipGetLastError();
+}
+
+template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, const bt2g_seed_hit*, uint32_t*, DevCounters*, hipStream_t);
+template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, const bt2g_seed_hit*, uint32_t*, DevCounters*, hipStream_t);
+template hipError_t launch_one_mm<uint32_t>(const DevIndex<uint32_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, DevCounters*, hipStream_t);
+template hipError_t launch_one_mm<uint64_t>(const DevIndex<uint64_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, DevCounters*, hipStream_t);
+
+// ------------------------------------------------------------------------------------
+// max over the batch of the number of round-0 seeds per strand (sizes the pre-computation buffers)
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_max_seeds(bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, unsigned int* __restrict__ out) {
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned int n = 0;
+	if (r < rd.n_reads) {
+		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - rd.d_off[r]);
+		const uint32_t L = (uint32_t)rparams[r].seedlen, per = (uint32_t)rparams[r].interval;
+		n = 1;
+		if (len > L && per > 0) n += (len - L) / per;
+	}
+	for (int o = 32; o > 0; o >>= 1) { const unsigned int v = __shfl_down(n, o); n = v > n ? v : n; }
+	if ((threadIdx.x & 63) == 0 && n) atomicMax(out, n);
+}
+
+hipError_t launch_max_seeds(const bt2g_reads& rd, const bt2g_read_params* d_rparams, unsigned int* d_out, hipStream_t st) {
+	hipError_t e = hipMemsetAsync(d_out, 0, sizeof(unsigned int), st);
+	if (e != hipSuccess || rd.n_reads == 0) return e;
+	hipLaunchKernelGGL(k_max_seeds, dim3((rd.n_reads + 255) / 256), dim3(256), 0, st, rd, d_rparams, d_out);
+	return hipGetLastError();
+}
+
 // explicit instantiations
 template hipError_t launch_exact_sweep<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, int, int, uint32_t, bt2g_sweep_out*, DevCounters*, hipStream_t);
 template hipError_t launch_exact_sweep<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, int, int, uint32_t, bt2g_sweep_out*, DevCounters*, hipStream_t);
-template hipError_t launch_seed_search_exact<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t);
-template hipError_t launch_seed_search_exact<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t);
+template hipError_t launch_seed_search_exact<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, const bt2g_read_params*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t);
+template hipError_t launch_seed_search_exact<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, const bt2g_read_params*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t);
 template hipError_t launch_resolve_offsets<uint32_t>(const DevIndex<uint32_t>&, const uint64_t*, const uint32_t*, uint64_t, int, bt2g_resolved*, DevCounters*, hipStream_t);
 template hipError_t launch_resolve_offsets<uint64_t>(const DevIndex<uint64_t>&, const uint64_t*, const uint32_t*, uint64_t, int, bt2g_resolved*, DevCounters*, hipStream_t);
 

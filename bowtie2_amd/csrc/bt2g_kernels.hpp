@@ -14,8 +14,18 @@ hipError_t launch_exact_sweep(const DevIndex<TOff>& ix, const bt2g_reads& rd, in
 
 template <typename TOff>
 hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& rd, const uint32_t* d_seedlen,
-                                    const uint32_t* d_interval, const uint32_t* d_offset, uint32_t max_seeds,
-                                    bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st);
+                                    const uint32_t* d_interval, const uint32_t* d_offset, const bt2g_read_params* d_rparams,
+                                    uint32_t max_seeds, bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st);
+
+hipError_t launch_max_seeds(const bt2g_reads& rd, const bt2g_read_params* d_rparams, unsigned int* d_out, hipStream_t st);
+
+// batch pre-computation for the fused worker (round-0 seed-hit extension, 1-mismatch e2e search)
+template <typename TOff>
+hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds,
+                              const bt2g_seed_hit* d_hits, uint32_t* d_ext, DevCounters* d_cnt, hipStream_t st);
+template <typename TOff>
+hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, const bt2g_reads& rd, const bt2g_read_params* d_rparams,
+                         const bt2g_sweep_out* d_sweep, uint32_t cap, void* d_out, uint8_t* d_out_n, DevCounters* d_cnt, hipStream_t st);
 
 template <typename TOff>
 hipError_t launch_resolve_offsets(const DevIndex<TOff>& ix, const uint64_t* d_rows, const uint32_t* d_qlen, uint64_t n,
