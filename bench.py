@@ -252,6 +252,8 @@ def main():
     stage_events = []
     last = {}
 
+    kern_times = []
+
     def step(record):
         e0, e1 = ev(), ev()
         e0.record()
@@ -259,6 +261,7 @@ def main():
         e1.record()
         if record:
             stage_events.append((e0, e1))
+            kern_times.append(ctx.align_timing())      # HIP events recorded by the library around each kernel
         last["res"], last["stride"] = res, stride
 
     def sync_all():
@@ -271,6 +274,7 @@ def main():
         step(False)
     sync_all()
     ctx.align_profile(reset=True)
+    ctx.counters(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -280,8 +284,11 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern_ms = sum(a.elapsed_time(bb) for a, bb in stage_events) / len(stage_events)
+    batch_ms = sum(a.elapsed_time(bb) for a, bb in stage_events) / len(stage_events)
+    kavg = {k: sum(t[k] for t in kern_times) / len(kern_times) for k in kern_times[0]}
+    kern_ms = kavg["k_align_reads"]
     prof = ctx.align_profile()
+    cnt = ctx.counters()
 
     # per-read work counters come back in the result records
     stride = last["stride"]
@@ -327,7 +334,12 @@ def main():
                 "bw_ops_per_read": rankq / n, "dp_fills_per_read": float(h["n_ex_dps"].sum()) / n,
                 "backtraces_per_read": float(h["n_bt_attempts"].sum()) / n,
                 "reads_overflowed": int((h["status"] != 0).sum()),
-                "phase_us_per_read": dict(zip(["sweep", "mm1", "seeds", "rank_prioritise", "resolve", "dp_fill", "gather_backtrace", "whole_read"], [round(prof[i] / 100.0 / max(1, prof[9]), 1) for i in range(8)])),
+                "worker_phase_us_per_read": dict(zip(["sweep", "mm1", "seeds", "rank_prioritise", "resolve", "dp_fill", "backtrace", "whole_read", "gather_cells", "report", "ungapped",
+                                                      "bt_tile_fetch", "gather_lastrow", "gather_zero_masks", "red_overlap", "red_add", "sink_report"],
+                                                     [round(prof[i] / 100.0 / max(1, prof[9]), 1) for i in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 16, 17, 18, 19, 20, 21)])),
+                "worker_counts_per_read": {"bt_steps": prof[13] / max(1, prof[9]), "bt_tiles": prof[14] / max(1, prof[9]), "cand_cells": prof[15] / max(1, prof[9])},
+                "kernel_ms_per_step": {k: round(v, 3) for k, v in kavg.items()}, "batch_ms_events": round(batch_ms, 3),
+                "fm_kernels_sides_per_read": cnt.rank_queries / float(n * args.steps),
                 "sides_per_read": prof[8] / max(1, prof[9]),
             },
             "roofline": {"bound": "hbm", "kernel": "k_align_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -116,6 +116,7 @@ ABI = [
     ("bt2g_sw_fill_ee_u8", C.c_int, [_vp, C.POINTER(Scoring), _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("bt2g_counters_read", C.c_int, [_vp, C.POINTER(Counters), C.c_int, _vp]),
     ("bt2g_align_profile_read", C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
+    ("bt2g_align_timing_read", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("bt2g_align_result_stride", C.c_uint64, [C.c_uint32]),
     ("bt2g_align_batch", C.c_int, [_vp, C.POINTER(Reads), _vp, C.POINTER(AlignParams), C.c_uint32, _vp, _vp]),
 ]
@@ -135,7 +136,7 @@ def lib():
             import torch  # noqa: F401
         except Exception:
             pass
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("BT2G_LIB", LIB_PATH))    # BT2G_LIB: try an alternative build of the same library
         for name, res, args in ABI:
             fn = getattr(L, name)   # AttributeError if a declared symbol is missing
             fn.restype = res
@@ -253,8 +254,14 @@ class Context:
                                                 out.data_ptr(), _stream_ptr()), "bt2g_align_batch")
         return out, stride
 
+    def align_timing(self):
+        """ms per kernel of the last align batch: dict(sweep, one_mm, seeds, extend, align)"""
+        out = (C.c_float * 5)()
+        _check(self._h, lib().bt2g_align_timing_read(self._h, out), "bt2g_align_timing_read")
+        return dict(zip(["k_exact_sweep", "k_one_mm", "k_seed_search_exact", "k_extend_hits", "k_align_reads"], [float(x) for x in out]))
+
     def align_profile(self, reset=False):
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 24)()
         _check(self._h, lib().bt2g_align_profile_read(self._h, out, int(reset), _stream_ptr()), "bt2g_align_profile_read")
         return list(out)
 

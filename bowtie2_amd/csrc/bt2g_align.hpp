@@ -121,6 +121,7 @@ struct RedAln {           // cells of one alignment, RedundantAlns (aligner_resu
 	int32_t refid;
 	uint16_t start, len;
 	uint8_t fw, pad[7];
+	int64_t dmin, dmax;       // bounds on (column - row) over the alignment's cells: a cheap disjointness test
 	int8_t  left_rel[kMaxLen];
 	uint8_t width[kMaxLen];
 };
@@ -128,7 +129,7 @@ struct RedAln {           // cells of one alignment, RedundantAlns (aligner_resu
 struct BtCand { int32_t score; uint16_t row, col; };
 
 struct BtFrame {          // DpNucFrame
-	uint32_t nedsz, celsz;
+	uint32_t nedsz, celsz;    // celsz: # cells on the path so far | core-diagonal-touched flag << 31
 	uint16_t row, col;
 	uint16_t gaps, read_gaps, ref_gaps;
 	uint8_t  ct, pad;
@@ -150,9 +151,16 @@ struct HotWork {
 	uint8_t  sorted[2][kMaxOffs];
 	uint8_t  rank_offs[kMaxRanges];
 	uint8_t  rank_fw[kMaxRanges];
-	uint16_t btcells[2 * (kMaxLen + 64)];   // (row, col) of the backtrace in progress
 	Edit     ned[kMaxEdits];   // edits of the backtrace in progress
+	// backtrace tile: the cells a run of kBtTile diagonal steps starting at (row, col) can look at,
+	// gathered with one lane-parallel load (Plat::bt_tile): d-th entry is for cell (row-d, col-d)
+	uint32_t bt_cur[16];       // cell(row-d,   col-d)
+	uint32_t bt_up[16];        // cell(row-d-1, col-d)
+	uint32_t bt_left[16];      // cell(row-d,   col-d-1)
+	uint16_t bt_mask[16];      // mask(row-d,   col-d)
+	uint8_t  lastrow[kMaxCols + 8];   // H of the last DP row (gatherCells)
 };
+constexpr uint32_t kBtTile = 15;
 
 struct Work {
 	// ---- read ----
@@ -202,14 +210,13 @@ struct Work {
 	uint32_t n_redundants, n_bwops_seed, n_bwops_ext, n_bt_attempts;
 	uint32_t n_ext_left, n_ext_right, n_resolve_steps;
 	uint32_t n_sides;           // sides (64/128-byte lines) actually read -- roofline accounting
-	uint64_t t_phase[8];        // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other
+	uint64_t t_phase[22];       // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other
 };
 
 // DP scratch of one wave: wavefront-major H/E/F matrix + per-cell backtrace masks + row flags
 struct DpScratch {
 	uint32_t* mat;      // packed cells, see dp_cell()
-	uint16_t* masks;    // [rows][cols]
-	uint8_t*  row_reset;// [rows]
+	uint16_t* masks;    // [rows][cols], zeroed after every fill that has candidate cells
 };
 
 // ---------------------------------------------------------------------------------------
@@ -219,7 +226,7 @@ BT2_HD int imin(int a, int b) { return a < b ? a : b; }
 BT2_HD int imax(int a, int b) { return a > b ? a : b; }
 BT2_HD int subs0(int a, int b) { const int r = a - b; return r < 0 ? 0 : r; }
 
-BT2_HD int mm_penalty(const AlignParams& P, int q) {
+template <typename SP> BT2_HD int mm_penalty(const SP& P, int q) {
 	if (P.mm_type == 3) {     // COST_MODEL_QUAL (scoring.h:106-114)
 		const int qq = q < 40 ? q : 40;
 		const float frac = (float)qq / 40.0f;
@@ -229,7 +236,7 @@ BT2_HD int mm_penalty(const AlignParams& P, int q) {
 }
 
 // Scoring::score(rdc, refmask, q) (scoring.h:241)
-BT2_HD int sc_score(const AlignParams& P, int rdc, int refm, int q) {
+template <typename SP> BT2_HD int sc_score(const SP& P, int rdc, int refm, int q) {
 	if (q < 0) q = 0;
 	if (q > 255) q = 255;
 	if (rdc > 3 || refm > 15) return -P.n_pen;
@@ -237,7 +244,7 @@ BT2_HD int sc_score(const AlignParams& P, int rdc, int refm, int q) {
 	return -mm_penalty(P, q);
 }
 // Scoring::mm(rdc, refm, q) (scoring.h:231)
-BT2_HD int sc_mm(const AlignParams& P, int rdc, int refm, int q) {
+template <typename SP> BT2_HD int sc_mm(const SP& P, int rdc, int refm, int q) {
 	if (q < 0) q = 0;
 	if (q > 255) q = 255;
 	return (rdc > 3 || refm > 15) ? P.n_pen : mm_penalty(P, q);

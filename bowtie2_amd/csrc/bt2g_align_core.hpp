@@ -29,6 +29,8 @@ struct Aligner {
 	const PreComp* pre;  // batch pre-computation (may be null)
 	uint32_t ridx;       // index of this read in the batch
 	bool ext_pre;        // HOT.hits came from pre->seeds, so pre->ext holds their extensions
+	uint32_t pf_steps = 0, pf_tiles = 0;   // profile: backtrace steps / tile fetches of this read
+	uint64_t pf_tile_t = 0;
 
 	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, const ReadParams& rp_, Work& w_, DpScratch dp_,
 	               const PreComp* pre_ = nullptr, uint32_t ridx_ = 0)
@@ -682,7 +684,27 @@ struct Aligner {
 		}
 	}
 
+	// conservative bounds on (column - row) over the cells of r
+	BT2_HD void diag_bounds(const AlnRes& r, int64_t& dmin, int64_t& dmax) const {
+		const int64_t d0 = r.refoff - (int64_t)(r.fw ? r.trim5p : r.trim3p);
+		int64_t nrd = 0, nrf = 0;
+		for (uint32_t k = 0; k < r.nned; k++) { const int t = r.ned[k].type; if (t == EDIT_READ_GAP) nrd++; else if (t == EDIT_REF_GAP) nrf++; }
+		dmin = d0 - nrf - 1; dmax = d0 + nrd + 1;
+	}
+
 	BT2_HDN bool red_overlap(const AlnRes& r) const {
+		if (w.n_red == 0) return false;
+		{
+			// alignments whose diagonal ranges are disjoint share no cell
+			int64_t dmin, dmax;
+			diag_bounds(r, dmin, dmax);
+			bool any = false;
+			for (uint32_t a = 0; a < w.n_red; a++) {
+				const RedAln& ra = w.red[a];
+				if (ra.refid == r.refid && (ra.fw != 0) == (r.fw != 0) && dmin <= ra.dmax && ra.dmin <= dmax) { any = true; break; }
+			}
+			if (!any) return false;
+		}
 		bool olap = false;
 		for_each_row_cells(r, [&](uint32_t i, int64_t left, int64_t right) -> bool {
 			for (uint32_t a = 0; a < w.n_red && !olap; a++) {
@@ -702,6 +724,7 @@ struct Aligner {
 		RedAln& ra = w.red[w.n_red++];
 		ra.refid = r.refid; ra.fw = r.fw; ra.refoff = r.refoff;
 		ra.start = (uint16_t)(r.fw ? r.trim5p : r.trim3p); ra.len = r.rdextent;
+		diag_bounds(r, ra.dmin, ra.dmax);
 		for_each_row_cells(r, [&](uint32_t i, int64_t left, int64_t right) -> bool {
 			ra.left_rel[i] = (int8_t)(left - (ra.refoff + (int64_t)(i - ra.start)));
 			ra.width[i] = (uint8_t)(right - left);
@@ -742,27 +765,38 @@ struct Aligner {
 	BT2_HDN void gather_cells(uint32_t rows, uint32_t cols, int64_t minsc_dp) {
 		const uint32_t R = dp_R(rows);
 		w.n_cands = 0; w.cural = 0;
-		for (uint32_t j = 0; j < cols; j++) {
-			const int sc = (int)(cell_get(R, rows - 1, j) & 0xff) - 0xff;
-			if (sc >= minsc_dp) {
-				if (w.n_cands >= (uint32_t)kMaxCands) { w.err |= ERR_OVERFLOW; break; }
-				BtCand c; c.score = sc; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)j;
-				// insertion keeps: score desc, row desc, col desc (DpBtCandidate::operator<)
-				uint32_t k = w.n_cands++;
-				while (k > 0 && (w.cands[k - 1].score < c.score || (w.cands[k - 1].score == c.score && w.cands[k - 1].col < c.col))) {
-					w.cands[k] = w.cands[k - 1]; k--;
-				}
-				w.cands[k] = c;
-			}
-		}
-		if (w.n_cands > 0) Plat::zero_u8(dp.row_reset, rows);   // SSEMatrix::initMasks
+		const uint64_t tl_ = now();
+		Plat::load_last_row(dp.mat, R, rows, cols);
+		w.t_phase[15] += now() - tl_;
+		// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
+		const uint32_t nc = Plat::gather_sort(w.cands, (uint32_t)kMaxCands, rows, cols, minsc_dp);
+		if (nc > (uint32_t)kMaxCands) { w.err |= ERR_OVERFLOW; w.n_cands = kMaxCands; } else w.n_cands = nc;
+		w.t_phase[13] += w.n_cands;      // profile: candidate cells
+		if (w.n_cands > 0) { const uint64_t tz_ = now(); Plat::zero_masks(dp.masks, rows * cols); w.t_phase[16] += now() - tz_; }   // SSEMatrix::initMasks, eagerly
 	}
 
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
-	BT2_HDN bool backtrace(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen,
-	                      int32_t escore, uint32_t row, uint32_t col, AlnRes& res) {
+	BT2_HDN bool backtrace(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen,
+	                      int32_t escore, uint32_t row_, uint32_t col_, AlnRes& res) {
 		(void)escore;
+		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
+		const bool fw = Plat::uni((int)fw_) != 0;
+		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
+		uint32_t row = Plat::uni(row_), col = Plat::uni(col_);
+		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
+		S.gapbar = Plat::uni(P.gapbar); S.rdgapo = Plat::uni(P.rdgapo); S.rdgape = Plat::uni(P.rdgape);
+		S.rfgapo = Plat::uni(P.rfgapo); S.rfgape = Plat::uni(P.rfgape); S.match_bonus = Plat::uni(P.match_bonus);
+		S.mm_type = Plat::uni(P.mm_type); S.mm_max = Plat::uni(P.mm_max); S.mm_min = Plat::uni(P.mm_min); S.n_pen = Plat::uni(P.n_pen);
+		const int64_t r_triml = (int64_t)Plat::uni(rect.triml);
+		const uint64_t r_corel = Plat::uni(rect.corel), r_corer = Plat::uni(rect.corer);
 		const uint32_t R = dp_R(rows);
+		uint32_t td = 0;     // the caller fetched the tile anchored at (row, col); td = steps taken along its diagonal
+		const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
+		bool olap = false;   // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
+		auto in_core = [&](uint32_t r_, uint32_t c_) -> bool {
+			const int64_t diagi = (int64_t)c_ - (int64_t)r_ + r_triml;
+			return diagi >= 0 && (uint64_t)diagi >= r_corel && (uint64_t)diagi <= r_corer;
+		};
 		uint32_t nstack = 0, ncells = 0, nned = 0;
 		int32_t score = 0, ns = 0;
 		const uint32_t orig_col = col;
@@ -774,25 +808,26 @@ struct Aligner {
 		const int offsetsc = -0xff;
 		w.n_bt_attempts++;
 		while ((int)row >= 0) {
-			const int readc = rd_char(HOT, w.len, fw, row);
-			const int refm = HOT.rf[col];
-			const int readq = rd_qual(HOT, w.len, fw, row);
+			const int readc = Plat::uni(rd_char(HOT, rdlen, fw, row));
+			const int refm = Plat::uni((int)HOT.rf[col]);
+			const int readq = Plat::uni(rd_qual(HOT, rdlen, fw, row));
 			bool empty = false, can_move_thru = true, branch = false;
 			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
-			if (!dp.row_reset[row]) { Plat::zero_u16(&mask_at(row, 0, cols), cols); dp.row_reset[row] = 1; }
-			const bool reported_thru = (mask_at(row, col, cols) & 1) != 0;
+			pf_steps++;
+			if (td >= kBtTile) { const uint64_t tt_ = now(); Plat::bt_tile(dp, R, cols, row, col); td = 0; pf_tiles++; pf_tile_t += now() - tt_; }
+			const uint16_t mk0 = (uint16_t)Plat::uni((uint32_t)HOT.bt_mask[td]);
+			uint16_t mk = mk0;
+			const bool reported_thru = (mk0 & 1) != 0;
 			if (reported_thru) {
 				can_move_thru = false;
 			} else if (row > 0) {
 				const uint32_t row_from_end = rows - row - 1;
-				const bool gaps_allowed = !(row < (uint32_t)P.gapbar || row_from_end < (uint32_t)P.gapbar);
-				uint16_t& mk = mask_at(row, col, cols);
-				// the four packed cells this step can look at, fetched together (independent loads)
-				const bool hasl_ = col > 0;
-				const uint32_t c_cur = cell_get(R, row, col);
-				const uint32_t c_up = cell_get(R, row - 1, col);
-				const uint32_t c_left = hasl_ ? cell_get(R, row, col - 1) : 0u;
-				const uint32_t c_upleft = hasl_ ? cell_get(R, row - 1, col - 1) : 0u;
+				const bool gaps_allowed = !(row < (uint32_t)S.gapbar || row_from_end < (uint32_t)S.gapbar);
+				// the four packed cells this step can look at (out-of-matrix entries of the tile are 0)
+				const uint32_t c_cur = Plat::uni(HOT.bt_cur[td]);
+				const uint32_t c_up = Plat::uni(HOT.bt_up[td]);
+				const uint32_t c_left = Plat::uni(HOT.bt_left[td]);
+				const uint32_t c_upleft = Plat::uni(HOT.bt_cur[td + 1]);
 				auto Hc = [](uint32_t c) -> int { return (int)(c & 0xff); };
 				auto Ec = [](uint32_t c) -> int { return (int)((c >> 8) & 0xff); };
 				auto Fc = [](uint32_t c) -> int { return (int)((c >> 16) & 0xff); };
@@ -800,9 +835,9 @@ struct Aligner {
 					const int sc_cur = Ec(c_cur) + offsetsc;
 					int mask = 0;
 					const int sc_h_left = Hc(c_left) + offsetsc;
-					if (sc_h_left - P.rdgapo == sc_cur) mask |= 1;
+					if (sc_h_left - S.rdgapo == sc_cur) mask |= 1;
 					const int sc_e_left = Ec(c_left) + offsetsc;
-					if (sc_e_left - P.rdgape == sc_cur) mask |= 2;
+					if (sc_e_left - S.rdgape == sc_cur) mask |= 2;
 					const int orig_mask = mask;
 					if (mk & (1 << 7)) mask = (mk >> 8) & 3;
 					if (mask == 3) { cur = 3; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7) | (2 << 8)); branch = true; }
@@ -814,8 +849,8 @@ struct Aligner {
 					const int sc_f_up = Fc(c_up) + offsetsc;
 					const int sc_cur = Fc(c_cur) + offsetsc;
 					int mask = 0;
-					if (sc_h_up - P.rfgapo == sc_cur) mask |= 1;
-					if (sc_f_up - P.rfgape == sc_cur) mask |= 2;
+					if (sc_h_up - S.rfgapo == sc_cur) mask |= 1;
+					if (sc_f_up - S.rfgape == sc_cur) mask |= 2;
 					const int orig_mask = mask;
 					if (mk & (1 << 10)) mask = (mk >> 11) & 3;
 					if (mask == 3) { cur = 1; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10) | (2 << 11)); branch = true; }
@@ -830,13 +865,13 @@ struct Aligner {
 					const int sc_h_left = hasl ? Hc(c_left) + offsetsc : 0;
 					const int sc_e_left = hasl ? Ec(c_left) + offsetsc : 0;
 					const int sc_h_upleft = hasl ? Hc(c_upleft) + offsetsc : 0;
-					const int sc_diag = sc_score(P, readc, refm, readq - 33);
+					const int sc_diag = sc_score(S, readc, refm, readq - 33);
 					int mask = 0;
 					if (gaps_allowed) {
-						if (sc_cur == sc_h_up - P.rfgapo) mask |= 1;
-						if (hasl && sc_cur == sc_h_left - P.rdgapo) mask |= 2;
-						if (sc_cur == sc_f_up - P.rfgape) mask |= 4;
-						if (hasl && sc_cur == sc_e_left - P.rdgape) mask |= 8;
+						if (sc_cur == sc_h_up - S.rfgapo) mask |= 1;
+						if (hasl && sc_cur == sc_h_left - S.rdgapo) mask |= 2;
+						if (sc_cur == sc_f_up - S.rfgape) mask |= 4;
+						if (hasl && sc_cur == sc_e_left - S.rdgape) mask |= 8;
 					}
 					if (hasl && sc_cur == sc_h_upleft + sc_diag) mask |= 16;
 					const int orig_mask = mask;
@@ -865,31 +900,35 @@ struct Aligner {
 					else { empty = true; can_move_thru = (orig_mask == 0); }
 				}
 			}
-			mask_at(row, col, cols) |= 1;    // setReportedThrough
+			mk |= 1;                         // setReportedThrough
+			if (mk != mk0) mask_at(row, col, cols) = mk;
 			if (!can_move_thru) {
 				if (nstack > 0) {
+					td = kBtTile;            // resume elsewhere: the tile is stale
 					const BtFrame& f = w.btstack[--nstack];
-					ncells = f.celsz; nned = f.nedsz; row = f.row; col = f.col;
-					gaps = f.gaps; read_gaps = f.read_gaps; ref_gaps = f.ref_gaps;
-					score = f.score; ns = f.ns; ct = f.ct;
+					const uint32_t cz_ = Plat::uni(f.celsz);
+					ncells = cz_ & 0x7fffffffu; olap = (cz_ >> 31) != 0; nned = Plat::uni(f.nedsz);
+					row = Plat::uni((uint32_t)f.row); col = Plat::uni((uint32_t)f.col);
+					gaps = Plat::uni((uint32_t)f.gaps); read_gaps = Plat::uni((uint32_t)f.read_gaps); ref_gaps = Plat::uni((uint32_t)f.ref_gaps);
+					score = Plat::uni(f.score); ns = Plat::uni(f.ns); ct = Plat::uni((int)f.ct);
 					continue;
 				}
 				return false;
 			}
 			if (empty || row == 0) {
-				HOT.btcells[2 * ncells] = (uint16_t)row; HOT.btcells[2 * ncells + 1] = (uint16_t)col; ncells++;
+				olap = olap || in_core(row, col); ncells++;
 				trim_beg = row;
 				break;
 			}
 			if (branch) {
 				if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { w.err |= ERR_OVERFLOW; return false; }
 				BtFrame& f = w.btstack[nstack++];
-				f.nedsz = nned; f.celsz = ncells; f.row = (uint16_t)row; f.col = (uint16_t)col;
+				f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
 				f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
 				f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
 			}
 			if (ncells >= (uint32_t)(kMaxLen + 64)) { w.err |= ERR_OVERFLOW; return false; }
-			HOT.btcells[2 * ncells] = (uint16_t)row; HOT.btcells[2 * ncells + 1] = (uint16_t)col; ncells++;
+			olap = olap || in_core(row, col); ncells++;
 			if (nned + 1 >= (uint32_t)kMaxEdits) { w.err |= ERR_OVERFLOW; return false; }
 			switch (cur) {
 				case 0: {   // diagonal
@@ -898,20 +937,22 @@ struct Aligner {
 					if (m != 1) {
 						Edit& e = ned[nned++];
 						e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_MM;
-						score -= sc_mm(P, readc, refm, readq - 33);
+						score -= sc_mm(S, readc, refm, readq - 33);
 					} else {
-						score += P.match_bonus;
+						score += S.match_bonus;
 					}
 					if (m == -1) ns++;
 					row--; col--;
+					td++;
 					break;
 				}
 				case 1: case 2: {   // ref gap (move up): open from H / extend from F
 					Edit& e = ned[nned++];
 					e.pos = (uint16_t)row; e.chr = '-'; e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_REF_GAP;
 					row--;
+					td = kBtTile;
 					ct = (cur == 1) ? 0 : 2;
-					score -= (cur == 1) ? P.rfgapo : P.rfgape;
+					score -= (cur == 1) ? S.rfgapo : S.rfgape;
 					gaps++; ref_gaps++;
 					break;
 				}
@@ -919,29 +960,24 @@ struct Aligner {
 					Edit& e = ned[nned++];
 					e.pos = (uint16_t)(row + 1); e.chr = (uint8_t)mask2chr(refm); e.qchr = '-'; e.type = EDIT_READ_GAP;
 					col--;
+					td = kBtTile;
 					ct = (cur == 3) ? 0 : 1;
-					score -= (cur == 3) ? P.rdgapo : P.rdgape;
+					score -= (cur == 3) ? S.rdgapo : S.rdgape;
 					gaps++; read_gaps++;
 					break;
 				}
 			}
 		}
-		// must touch a core diagonal of the untrimmed rectangle (:1764-1795)
-		bool overlapped = false;
-		for (uint32_t i = 0; i < ncells; i++) {
-			const int64_t diagi = (int64_t)HOT.btcells[2 * i + 1] - (int64_t)HOT.btcells[2 * i] + (int64_t)rect.triml;
-			if (diagi >= 0 && (uint64_t)diagi >= rect.corel && (uint64_t)diagi <= rect.corer) { overlapped = true; break; }
-		}
-		if (!overlapped) return false;
+		if (!olap) return false;
 		{
-			const int readc = rd_char(HOT, w.len, fw, row);
-			const int refm = HOT.rf[col];
+			const int readc = Plat::uni(rd_char(HOT, rdlen, fw, row));
+			const int refm = Plat::uni((int)HOT.rf[col]);
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) {
 				Edit& e = ned[nned++];
 				e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_MM;
-				score -= sc_mm(P, readc, refm, rd_qual(HOT, w.len, fw, row) - 33);
-			} else score += P.match_bonus;
+				score -= sc_mm(S, readc, refm, Plat::uni(rd_qual(HOT, rdlen, fw, row)) - 33);
+			} else score += S.match_bonus;
 			if (m == -1) ns++;
 		}
 		if (ns > rp.nceil) return false;
@@ -992,7 +1028,8 @@ struct Aligner {
 		while (w.cural < w.n_cands) {
 			const BtCand& c = w.cands[w.cural];
 			if (c.score < minsc) { w.cural++; continue; }
-			if (dp.row_reset[c.row] && (mask_at(c.row, c.col, cols) & 1)) { w.cural++; continue; }
+			{ const uint64_t tt_ = now(); Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col); pf_tiles++; pf_tile_t += now() - tt_; }    // also the first tile of the backtrace
+			if (HOT.bt_mask[0] & 1) { w.cural++; continue; }
 			const uint32_t reseed = rnd.nextU32() + 1;
 			rnd.init(reseed);
 			res.nned = 0;
@@ -1151,7 +1188,9 @@ struct Aligner {
 						state = 1; found = true;
 						diag_add((int32_t)tidx, refoff, fw, 1);
 					} else if (P.do_ungapped && ungapped) {
+						const uint64_t tu_ = now();
 						const int al = ungapped_align(fw, tidx, refoff, (int64_t)tlen, res);
+						w.t_phase[10] += now() - tu_;
 						diag_add((int32_t)tidx, refoff, fw, 1);
 						w.n_ex_ugs++;
 						if (al == 0) {
@@ -1189,7 +1228,7 @@ struct Aligner {
 						const int64_t best = (int64_t)best_u8 - 0xff;
 						w.n_ex_dps++;
 						found = best >= minsc;
-						if (found) { const uint64_t tg_ = now(); gather_cells(rows, cols, minsc); found = w.n_cands > 0; w.t_phase[6] += now() - tg_; }
+						if (found) { const uint64_t tg_ = now(); gather_cells(rows, cols, minsc); found = w.n_cands > 0; w.t_phase[8] += now() - tg_; }
 						if (!found) {
 							w.n_dp_fail++;
 							if (w.n_dp_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
@@ -1210,6 +1249,8 @@ struct Aligner {
 							if (!na_) break;
 						}
 						first_inner = false;
+						const uint64_t tp_ = now();
+						struct PostTimer { uint64_t t0; uint64_t& acc; BT2_HD ~PostTimer() { acc += Plat::clock() - t0; } } post_timer_{tp_, w.t_phase[9]};
 						// fell entirely outside the reference?
 						{
 							const int64_t a0 = res.refoff, a1 = res.refoff + res.rfextent;
@@ -1217,9 +1258,9 @@ struct Aligner {
 							const bool ov = (b0 <= a0 && b1 > a0) || (b0 <= a1 && b1 > a1) || (a0 <= b0 && a1 > b0) || (a0 <= b1 && a1 > b1);
 							if (!ov) continue;
 						}
-						if (red_overlap(res)) continue;
-						red_add(res);
-						if (sink_report(res)) return EXT_POLICY_FULFILLED;
+						{ const uint64_t t1_ = now(); const bool ro_ = red_overlap(res); w.t_phase[17] += now() - t1_; if (ro_) continue; }
+						{ const uint64_t t1_ = now(); red_add(res); w.t_phase[18] += now() - t1_; }
+						{ const uint64_t t1_ = now(); const bool sr_ = sink_report(res); w.t_phase[19] += now() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
 						if (P.tighten > 0 && P.mhits > 0 && w.best2_unp1 != INT64_MIN) {
 							if (P.tighten == 1) {
 								if (w.best_unp1 >= minsc) {
@@ -1257,7 +1298,7 @@ struct Aligner {
 		w.n_diags = 0; w.n_red = 0; w.n_ex_fw = w.n_ex_rc = 0;
 		w.n_ex_iters = w.n_ex_dps = w.n_ex_ugs = w.n_dp_fail = w.n_ug_fail = w.n_ee_fail = w.n_dp_fail_streak = 0;
 		w.n_redundants = w.n_bwops_seed = w.n_bwops_ext = w.n_bt_attempts = 0; w.n_sides = 0; w.n_ext_left = w.n_ext_right = w.n_resolve_steps = 0;
-		for (int i_ = 0; i_ < 8; i_++) w.t_phase[i_] = 0;
+		for (int i_ = 0; i_ < 22; i_++) w.t_phase[i_] = 0;
 		const uint64_t t_run0_ = now();
 		w.n_mm1 = 0; w.mm1_elt = 0; w.nonz_tot = 0; w.n_rank = 0; w.num_offs = 0; w.num_elts = 0;
 		w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0;
@@ -1325,6 +1366,7 @@ struct Aligner {
 			}
 		}
 		finish(out);
+		w.t_phase[11] = pf_steps; w.t_phase[12] = pf_tiles; w.t_phase[14] = pf_tile_t;
 		w.t_phase[7] = now() - t_run0_;
 #ifdef BT2G_DEBUG_SATPOS
 		{

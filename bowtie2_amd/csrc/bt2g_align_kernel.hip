@@ -82,14 +82,65 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 struct DevPlat {
 	static __device__ __forceinline__ HotWork& hot() { return g_hot; }
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
-	static __device__ __forceinline__ void zero_u8(uint8_t* p, uint32_t n) {
+	// The worker's control code computes the same value in every lane; uni() moves such a value into a
+	// scalar register so that what is derived from it runs on the scalar ALU instead of 64 redundant lanes.
+	static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+	static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+	static __device__ __forceinline__ uint64_t uni(uint64_t v) {
+		return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+	}
+	static __device__ __forceinline__ int64_t uni(int64_t v) { return (int64_t)uni((uint64_t)v); }
+	// SSEMatrix::initMasks for the whole rectangle: 16 bytes per lane per store (the region is 256-byte padded)
+	static __device__ __forceinline__ void zero_masks(uint16_t* p, uint32_t n) {
 		wave_fence();
-		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) p[i] = 0;
+		uint4* q = reinterpret_cast<uint4*>(p);
+		const uint32_t n16 = (n + 7) / 8;
+		const uint4 z = make_uint4(0, 0, 0, 0);
+		for (uint32_t i = threadIdx.x & 63; i < n16; i += 64) q[i] = z;
 		wave_fence();
 	}
-	static __device__ __forceinline__ void zero_u16(uint16_t* p, uint32_t n) {
+	// H of the last DP row -> LDS
+	static __device__ __forceinline__ void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols) {
 		wave_fence();
-		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) p[i] = 0;
+		for (uint32_t j = threadIdx.x & 63; j < cols; j += 64) g_hot.lastrow[j] = (uint8_t)(mat[dp_cell(R, rows - 1, j)] & 0xff);
+		wave_fence();
+	}
+	// Candidate cells of the last row, sorted by (score desc, col desc): every lane ranks its own cells
+	// against the whole row (LDS broadcast reads) and writes them straight to their final slot.
+	static __device__ __forceinline__ uint32_t gather_sort(BtCand* cands, uint32_t cap, uint32_t rows, uint32_t cols, int64_t minsc_dp) {
+		const uint32_t lane = threadIdx.x & 63;
+		const int thr = (int)minsc_dp + 0xff;          // H byte >= thr  <=>  score >= minsc
+		uint32_t total = 0;
+		for (uint32_t base = 0; base < cols; base += 64) {
+			const uint32_t j = base + lane;
+			const int sc = j < cols ? (int)g_hot.lastrow[j] : -1;
+			const bool is = j < cols && sc >= thr;
+			if (__ballot(is) == 0ull) continue;
+			uint32_t rank = 0;
+			for (uint32_t k = 0; k < cols; k++) {
+				const int s2 = (int)g_hot.lastrow[k];
+				if (s2 >= thr && (s2 > sc || (s2 == sc && k > j))) rank++;
+			}
+			if (is && rank < cap) { BtCand c; c.score = sc - 0xff; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)j; cands[rank] = c; }
+			total += (uint32_t)__popcll(__ballot(is));
+		}
+		wave_fence();
+		return total;
+	}
+	// Backtrace tile anchored at (row, col): lanes 0-15 cell(row-d, col-d), 16-31 cell(row-d-1, col-d),
+	// 32-47 cell(row-d, col-d-1), 48-63 mask(row-d, col-d); one load instruction per array, one latency.
+	static __device__ __forceinline__ void bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col) {
+		wave_fence();
+		const uint32_t lane = threadIdx.x & 63, d = lane & 15, g = lane >> 4;
+		const int r = (int)row - (int)d - (g == 1 ? 1 : 0);
+		const int c = (int)col - (int)d - (g == 2 ? 1 : 0);
+		const bool ok = r >= 0 && c >= 0;
+		uint32_t v = 0;
+		if (ok) {
+			if (g < 3) v = dp.mat[dp_cell(R, (uint32_t)r, (uint32_t)c)];
+			else v = dp.masks[(uint64_t)r * cols + (uint32_t)c];
+		}
+		if (g == 0) g_hot.bt_cur[d] = v; else if (g == 1) g_hot.bt_up[d] = v; else if (g == 2) g_hot.bt_left[d] = v; else g_hot.bt_mask[d] = (uint16_t)v;
 		wave_fence();
 	}
 	// reference window -> masks, one base per lane per pass (SwAligner::initRef, aligner_sw.cpp:155-271)
@@ -131,7 +182,6 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	DpScratch dp;
 	dp.mat = reinterpret_cast<uint32_t*>(base + ((sizeof(Work) + 255) & ~(uint64_t)255));
 	dp.masks = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(dp.mat) + mat_bytes);
-	dp.row_reset = reinterpret_cast<uint8_t*>(dp.masks) + mask_bytes;
 	for (;;) {
 		unsigned int r = 0;
 		if (lane == 0) r = atomicAdd(next_read, 1u);
@@ -161,6 +211,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		}
 		if (lane == 0 && prof) {
 			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)w.t_phase[i]);
+			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)w.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)w.n_sides);
 			atomicAdd(&prof[9], 1ull);
 		}

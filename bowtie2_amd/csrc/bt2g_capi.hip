@@ -37,6 +37,8 @@ struct bt2g_ctx {
 	unsigned int* d_next = nullptr;      // work-queue head
 	uint8_t* d_pre = nullptr;            // batch pre-computation (sweep, round-0 seed hits, extensions, 1-mm hits)
 	uint64_t pre_bytes = 0;
+	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel boundaries of the last align batch
+	bool ev_valid = false;
 	bool precomp = true;                 // BT2G_NO_PRECOMP=1: the worker computes every FM phase itself (A/B testing)
 };
 
@@ -148,6 +150,7 @@ void bt2g_ctx_destroy(bt2g_ctx* c) {
 	if (c->d_dp_scratch) (void)hipFree(c->d_dp_scratch);
 	if (c->d_arena) (void)hipFree(c->d_arena);
 	if (c->d_pre) (void)hipFree(c->d_pre);
+	for (int i = 0; i < 7; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->d_next) (void)hipFree(c->d_next);
 	delete c;
 }
@@ -310,6 +313,10 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	// extension) run first as lane-per-task kernels; the per-read worker then consumes their output.
 	PreComp pre;
 	memset(&pre, 0, sizeof(pre));
+	if (!c->ev[0]) for (int i = 0; i < 7; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(c, BT2G_ERR_HIP, "hipEventCreate");
+	c->ev_valid = false;
+	auto mark = [&](int i) { (void)hipEventRecord(c->ev[i], st); };
+	mark(0);
 	if (c->precomp) {
 		unsigned int max_seeds = 0;
 		e = launch_max_seeds(*reads, d_rparams, c->d_next + 8, st);
@@ -341,22 +348,26 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		Mm1Hit* d_mm1 = (Mm1Hit*)p; p += b_mm1;
 		uint8_t* d_mm1n = p;
 		const bool s = c->off_size == 4;
+		mark(0);
 		if (params->do_exact_upfront) {
 			e = s ? launch_exact_sweep(c->ix32, *reads, params->nofw, params->norc, 2, d_sweep, c->d_cnt, st)
 			      : launch_exact_sweep(c->ix64, *reads, params->nofw, params->norc, 2, d_sweep, c->d_cnt, st);
 			if (e != hipSuccess) return hip_fail(c, e, "k_exact_sweep");
 			pre.sweep = d_sweep;
+			mark(1);
 			if (params->do_1mm_upfront) {
 				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, c->d_cnt, st)
 				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, c->d_cnt, st);
 				if (e != hipSuccess) return hip_fail(c, e, "k_one_mm");
 				pre.mm1 = d_mm1; pre.mm1_n = d_mm1n;
 			}
-		}
+		} else mark(1);
+		mark(2);
 		e = s ? launch_seed_search_exact(c->ix32, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st)
 		      : launch_seed_search_exact(c->ix64, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st);
 		if (e != hipSuccess) return hip_fail(c, e, "k_seed_search_exact");
 		pre.seeds = d_seeds;
+		mark(3);
 		if (params->do_extend) {
 			e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, d_seeds, d_ext, c->d_cnt, st)
 			      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, d_seeds, d_ext, c->d_cnt, st);
@@ -364,22 +375,43 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			pre.ext = d_ext;
 		}
 		pre.max_seeds = max_seeds; pre.mm1_cap = cap;
-	}
+		mark(4);
+	} else { for (int i = 1; i <= 4; i++) mark(i); }
+	mark(5);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	e = (c->off_size == 4)
 		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, st)
 		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, st);
-	return e == hipSuccess ? 0 : hip_fail(c, e, "k_align_reads");
+	if (e != hipSuccess) return hip_fail(c, e, "k_align_reads");
+	mark(6);
+	c->ev_valid = true;
+	return 0;
 }
 
-int bt2g_align_profile_read(bt2g_ctx* c, uint64_t* out16, int reset, void* stream) {
-	if (!c || !out16) return BT2G_ERR_ARG;
+int bt2g_align_timing_read(bt2g_ctx* c, float* out_ms5) {
+	if (!c || !out_ms5) return BT2G_ERR_ARG;
+	for (int i = 0; i < 5; i++) out_ms5[i] = 0.f;
+	if (!c->ev_valid) return fail(c, BT2G_ERR_ARG, "no align batch has been launched");
+	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
+	hipError_t e = hipEventSynchronize(c->ev[6]);
+	if (e != hipSuccess) return hip_fail(c, e, "hipEventSynchronize");
+	// k_exact_sweep, k_one_mm, k_seed_search_exact, k_extend_hits, k_align_reads
+	const int a[5] = {0, 1, 2, 3, 5}, b[5] = {1, 2, 3, 4, 6};
+	for (int i = 0; i < 5; i++) {
+		e = hipEventElapsedTime(&out_ms5[i], c->ev[a[i]], c->ev[b[i]]);
+		if (e != hipSuccess) return hip_fail(c, e, "hipEventElapsedTime");
+	}
+	return 0;
+}
+
+int bt2g_align_profile_read(bt2g_ctx* c, uint64_t* out24, int reset, void* stream) {
+	if (!c || !out24) return BT2G_ERR_ARG;
 	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
 	hipStream_t st = (hipStream_t)stream;
-	memset(out16, 0, 16 * 8);
+	memset(out24, 0, 24 * 8);
 	if (!c->d_next) return 0;
-	hipError_t e = hipMemcpyAsync(out16, c->d_next + 16, 16 * 8, hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_next + 16, 0, 16 * 8, st);
+	hipError_t e = hipMemcpyAsync(out24, c->d_next + 16, 24 * 8, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_next + 16, 0, 24 * 8, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	return e == hipSuccess ? 0 : hip_fail(c, e, "read profile");
 }

@@ -251,11 +251,18 @@ int bt2g_align_batch(bt2g_ctx *ctx, const bt2g_reads *reads, const bt2g_read_par
                      void *d_results, void *stream);
 
 /*
+ * Device time (ms, HIP events on `stream`) of each kernel of the most recent bt2g_align_batch:
+ * [0] k_exact_sweep [1] k_one_mm [2] k_seed_search_exact [3] k_extend_hits [4] k_align_reads.
+ * Blocks until that batch has finished.  Measurement aid (bench.py's roofline), no reference counterpart.
+ */
+int bt2g_align_timing_read(bt2g_ctx *ctx, float *out_ms5);
+
+/*
  * Device-clock ticks (100 MHz wall clock) the fused worker spent per phase, summed over reads since the last
  * reset: [0] exact sweep [1] 1-mm search [2] seed search [3] rank+prioritise [4] offset resolution
  * [5] ref fetch + DP fill [6] gather + backtrace [7] whole read; [8] sides read; [9] reads.
  */
-int bt2g_align_profile_read(bt2g_ctx *ctx, uint64_t *out16, int reset, void *stream);
+int bt2g_align_profile_read(bt2g_ctx *ctx, uint64_t *out24, int reset, void *stream);
 
 /* ---- instrumentation ---------------------------------------------------- */
 typedef struct {

@@ -21,11 +21,37 @@ static HotWork g_hot;
 struct HostPlat {
 	static HotWork& hot() { return g_hot; }
 	static uint64_t clock() { return 0; }
+	template <typename T> static T uni(T v) { return v; }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
 		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
 	}
-	static void zero_u8(uint8_t* p, uint32_t n) { memset(p, 0, n); }
-	static void zero_u16(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
+	static void zero_masks(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
+	static void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols) {
+		for (uint32_t j = 0; j < cols; j++) g_hot.lastrow[j] = (uint8_t)(mat[dp_cell(R, rows - 1, j)] & 0xff);
+	}
+	static uint32_t gather_sort(BtCand* cands, uint32_t cap, uint32_t rows, uint32_t cols, int64_t minsc_dp) {
+		uint32_t n = 0, total = 0;
+		for (uint32_t j = 0; j < cols; j++) {
+			const int sc = (int)g_hot.lastrow[j] - 0xff;
+			if (sc < minsc_dp) continue;
+			total++;
+			if (n >= cap) continue;
+			BtCand c; c.score = sc; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)j;
+			uint32_t k = n++;      // insertion keeps: score desc, col desc
+			while (k > 0 && (cands[k - 1].score < c.score || (cands[k - 1].score == c.score && cands[k - 1].col < c.col))) { cands[k] = cands[k - 1]; k--; }
+			cands[k] = c;
+		}
+		return total;
+	}
+	static void bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col) {
+		for (uint32_t d = 0; d < 16; d++) {
+			const int r = (int)row - (int)d, c = (int)col - (int)d;
+			g_hot.bt_cur[d]  = (r >= 0 && c >= 0) ? dp.mat[dp_cell(R, r, c)] : 0;
+			g_hot.bt_up[d]   = (r >= 1 && c >= 0) ? dp.mat[dp_cell(R, r - 1, c)] : 0;
+			g_hot.bt_left[d] = (r >= 0 && c >= 1) ? dp.mat[dp_cell(R, r, c - 1)] : 0;
+			g_hot.bt_mask[d] = (r >= 0 && c >= 0) ? dp.masks[(uint64_t)r * cols + c] : 0;
+		}
+	}
 	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
 	static int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat) {
 		const uint32_t R = dp_R(rows);
@@ -96,7 +122,6 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 4;
 	dp.mat = (uint32_t*)malloc(mat_bytes);
 	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
-	dp.row_reset = (uint8_t*)malloc(kMaxLen);
 	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(opt.khits + 1));
 	ReadRec rd;
 	AlnSummary summ;
@@ -124,8 +149,9 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 			sam_record(o, opt, ref, rd, rr, nullptr, true);
 		}
 		fwrite(o.data(), 1, o.size(), out);
-		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", rd.name.c_str(),
-		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
+		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u btsteps=%llu tiles=%llu cands=%llu\n", rd.name.c_str(),
+		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps,
+		                     (unsigned long long)w->t_phase[11], (unsigned long long)w->t_phase[12], (unsigned long long)w->t_phase[13]);
 	}
 	summ.print(stderr);
 	return 0;
