@@ -116,16 +116,6 @@ struct SatPos {           // SATupleAndPos (aligner_sw_driver.h:144)
 
 struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };
 
-struct RedAln {           // cells of one alignment, RedundantAlns (aligner_result.cpp:929)
-	int64_t refoff;
-	int32_t refid;
-	uint16_t start, len;
-	uint8_t fw, pad[7];
-	int64_t dmin, dmax;       // bounds on (column - row) over the alignment's cells: a cheap disjointness test
-	int8_t  left_rel[kMaxLen];
-	uint8_t width[kMaxLen];
-};
-
 struct BtCand { int32_t score; uint16_t row, col; };
 
 struct BtFrame {          // DpNucFrame
@@ -191,8 +181,7 @@ struct Work {
 	uint32_t n_ex_fw, n_ex_rc;
 	DiagIval diags[kMaxDiags];
 	uint32_t n_diags;
-	RedAln   red[kMaxAlns];
-	uint32_t n_red;
+	int64_t  red_dmin[kMaxAlns], red_dmax[kMaxAlns];   // RedundantAlns prefilter: (column - row) bounds of alns[k]
 	// ---- sink ----
 	AlnRes   alns[kMaxAlns];
 	uint32_t n_alns;

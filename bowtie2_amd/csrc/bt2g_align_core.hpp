@@ -651,38 +651,37 @@ struct Aligner {
 
 	// RedundantAlns cell enumeration (aligner_result.cpp:929-1032): per read row, the half-open
 	// column range [left,right) the alignment occupies, edits taken w.r.t. the upstream end.
-	template <typename F>
-	BT2_HD void for_each_row_cells(const AlnRes& r, F f) const {
-		int64_t left = r.refoff;
-		const uint32_t len = r.rdextent;        // readExtentRows()
-		const uint32_t start = r.fw ? r.trim5p : r.trim3p;   // trimmedLeft(true)
-		// edits w.r.t. upstream end: for rc alignments positions are inverted (invertPoss) and order reversed
-		const uint32_t n = r.nned;
-		auto epos = [&](uint32_t k) -> uint32_t {
-			if (r.fw) return r.ned[k].pos;
+	struct RowIt {
+		const AlnRes& r;
+		uint32_t n, nedidx, i, end;
+		int64_t left;
+		bool fw;
+		BT2_HD explicit RowIt(const AlnRes& r_) : r(r_) {
+			fw = r.fw != 0; n = r.nned; nedidx = 0;
+			i = fw ? r.trim5p : r.trim3p;           // trimmedLeft(true)
+			end = i + r.rdextent;                   // readExtentRows()
+			left = r.refoff;
+		}
+		// edits w.r.t. the upstream end: for rc alignments positions are inverted (invertPoss) and the order reversed
+		BT2_HD uint32_t epos(uint32_t k) const {
+			if (fw) return r.ned[k].pos;
 			const Edit& e = r.ned[n - 1 - k];
 			return (uint32_t)(r.rdextent - e.pos - (e.type == EDIT_READ_GAP ? 0 : 1));
-		};
-		auto etype = [&](uint32_t k) -> int { return r.fw ? r.ned[k].type : r.ned[n - 1 - k].type; };
-		uint32_t nedidx = 0;
-		for (uint32_t i = start; i < start + len; i++) {
-			int64_t diff = 1;
-			int64_t right = left + 1;
-			while (nedidx < n && epos(nedidx) == i) {
-				if (etype(nedidx) == EDIT_REF_GAP) diff = 0;
-				nedidx++;
-			}
-			if (i < start + len - 1) {
-				uint32_t nn = nedidx;
-				while (nn < n && epos(nn) == i + 1) {
-					if (etype(nn) == EDIT_READ_GAP) right++;
-					nn++;
-				}
-			}
-			if (!f(i, left, right)) return;
-			left = right + diff - 1;
 		}
-	}
+		BT2_HD int etype(uint32_t k) const { return fw ? r.ned[k].type : r.ned[n - 1 - k].type; }
+		BT2_HD bool done() const { return i >= end; }
+		BT2_HD void next(int64_t& l, int64_t& rgt) {   // range of row i, then step to row i+1
+			int64_t diff = 1, right = left + 1;
+			while (nedidx < n && epos(nedidx) == i) { if (etype(nedidx) == EDIT_REF_GAP) diff = 0; nedidx++; }
+			if (i < end - 1) {
+				uint32_t nn = nedidx;
+				while (nn < n && epos(nn) == i + 1) { if (etype(nn) == EDIT_READ_GAP) right++; nn++; }
+			}
+			l = left; rgt = right;
+			left = right + diff - 1;
+			i++;
+		}
+	};
 
 	// conservative bounds on (column - row) over the cells of r
 	BT2_HD void diag_bounds(const AlnRes& r, int64_t& dmin, int64_t& dmax) const {
@@ -692,51 +691,39 @@ struct Aligner {
 		dmin = d0 - nrf - 1; dmax = d0 + nrd + 1;
 	}
 
+	// RedundantAlns::overlap against every alignment reported so far (they are all kept in w.alns)
 	BT2_HDN bool red_overlap(const AlnRes& r) const {
-		if (w.n_red == 0) return false;
-		{
+		const uint32_t nst = w.n_alns < (uint32_t)kMaxAlns ? w.n_alns : (uint32_t)kMaxAlns;
+		if (nst == 0) return false;
+		int64_t dmin, dmax;
+		diag_bounds(r, dmin, dmax);
+		for (uint32_t a = 0; a < nst; a++) {
+			const AlnRes& o = w.alns[a];
+			if (o.refid != r.refid || (o.fw != 0) != (r.fw != 0)) continue;
 			// alignments whose diagonal ranges are disjoint share no cell
-			int64_t dmin, dmax;
-			diag_bounds(r, dmin, dmax);
-			bool any = false;
-			for (uint32_t a = 0; a < w.n_red; a++) {
-				const RedAln& ra = w.red[a];
-				if (ra.refid == r.refid && (ra.fw != 0) == (r.fw != 0) && dmin <= ra.dmax && ra.dmin <= dmax) { any = true; break; }
+			if (dmin > w.red_dmax[a] || w.red_dmin[a] > dmax) continue;
+			RowIt ia(o), ir(r);
+			int64_t l1 = 0, r1 = 0, l2 = 0, r2 = 0;
+			while (!ia.done() && !ir.done()) {
+				if (ia.i < ir.i) { ia.next(l2, r2); continue; }
+				if (ir.i < ia.i) { ir.next(l1, r1); continue; }
+				ia.next(l2, r2); ir.next(l1, r1);
+				if (l1 < r2 && l2 < r1) return true;
 			}
-			if (!any) return false;
 		}
-		bool olap = false;
-		for_each_row_cells(r, [&](uint32_t i, int64_t left, int64_t right) -> bool {
-			for (uint32_t a = 0; a < w.n_red && !olap; a++) {
-				const RedAln& ra = w.red[a];
-				if (ra.refid != r.refid || (ra.fw != 0) != (r.fw != 0)) continue;
-				if (i < ra.start || i >= (uint32_t)ra.start + ra.len) continue;
-				const int64_t l2 = ra.refoff + (int64_t)(i - ra.start) + ra.left_rel[i];
-				const int64_t r2 = l2 + ra.width[i];
-				if (left < r2 && l2 < right) olap = true;
-			}
-			return !olap;
-		});
-		return olap;
+		return false;
 	}
+	// RedundantAlns::add: the cells are re-derived from w.alns[k] on demand; only the prefilter bounds are kept
 	BT2_HDN void red_add(const AlnRes& r) {
-		if (w.n_red >= (uint32_t)kMaxAlns) { w.err |= ERR_OVERFLOW; return; }
-		RedAln& ra = w.red[w.n_red++];
-		ra.refid = r.refid; ra.fw = r.fw; ra.refoff = r.refoff;
-		ra.start = (uint16_t)(r.fw ? r.trim5p : r.trim3p); ra.len = r.rdextent;
-		diag_bounds(r, ra.dmin, ra.dmax);
-		for_each_row_cells(r, [&](uint32_t i, int64_t left, int64_t right) -> bool {
-			ra.left_rel[i] = (int8_t)(left - (ra.refoff + (int64_t)(i - ra.start)));
-			ra.width[i] = (uint8_t)(right - left);
-			return true;
-		});
+		if (w.n_alns >= (uint32_t)kMaxAlns) return;      // sink_report flags the overflow
+		diag_bounds(r, w.red_dmin[w.n_alns], w.red_dmax[w.n_alns]);
 	}
 
 	// =================================================================================
 	// D. sink (AlnSinkWrap::report, ReportingState::foundUnpaired; aln_sink.cpp:103-130,1395-1445)
 	// =================================================================================
 	BT2_HD bool sink_report(const AlnRes& r) {
-		if (w.n_alns < (uint32_t)kMaxAlns) w.alns[w.n_alns] = r; else w.err |= ERR_OVERFLOW;
+		if (w.n_alns < (uint32_t)kMaxAlns) Plat::copy_aln(w.alns[w.n_alns], r); else w.err |= ERR_OVERFLOW;
 		w.n_alns++;
 		if (!w.done_unpair1) {
 			// ReportingState::areDone
@@ -790,6 +777,14 @@ struct Aligner {
 		const int64_t r_triml = (int64_t)Plat::uni(rect.triml);
 		const uint64_t r_corel = Plat::uni(rect.corel), r_corer = Plat::uni(rect.corer);
 		const uint32_t R = dp_R(rows);
+		// `this` lives in private memory: read what the loop needs once, into scalar registers
+		DpScratch dpl;
+		dpl.mat = Plat::uni_ptr(dp.mat); dpl.masks = Plat::uni_ptr(dp.masks);
+		BtFrame* const btstack = Plat::uni_ptr(&w.btstack[0]);
+		struct Prof {      // profile counters stay in registers until the function returns
+			Aligner& a; uint32_t steps, tiles; uint64_t tile_t;
+			BT2_HD ~Prof() { a.pf_steps += steps; a.pf_tiles += tiles; a.pf_tile_t += tile_t; }
+		} prof{*this, 0, 0, 0};
 		uint32_t td = 0;     // the caller fetched the tile anchored at (row, col); td = steps taken along its diagonal
 		const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
 		bool olap = false;   // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
@@ -813,8 +808,8 @@ struct Aligner {
 			const int readq = Plat::uni(rd_qual(HOT, rdlen, fw, row));
 			bool empty = false, can_move_thru = true, branch = false;
 			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
-			pf_steps++;
-			if (td >= kBtTile) { const uint64_t tt_ = now(); Plat::bt_tile(dp, R, cols, row, col); td = 0; pf_tiles++; pf_tile_t += now() - tt_; }
+			prof.steps++;
+			if (td >= kBtTile) { const uint64_t tt_ = now(); Plat::bt_tile(dpl, R, cols, row, col); td = 0; prof.tiles++; prof.tile_t += now() - tt_; }
 			const uint16_t mk0 = (uint16_t)Plat::uni((uint32_t)HOT.bt_mask[td]);
 			uint16_t mk = mk0;
 			const bool reported_thru = (mk0 & 1) != 0;
@@ -901,11 +896,11 @@ struct Aligner {
 				}
 			}
 			mk |= 1;                         // setReportedThrough
-			if (mk != mk0) mask_at(row, col, cols) = mk;
+			if (mk != mk0) dpl.masks[(uint64_t)row * cols + col] = mk;
 			if (!can_move_thru) {
 				if (nstack > 0) {
 					td = kBtTile;            // resume elsewhere: the tile is stale
-					const BtFrame& f = w.btstack[--nstack];
+					const BtFrame& f = btstack[--nstack];
 					const uint32_t cz_ = Plat::uni(f.celsz);
 					ncells = cz_ & 0x7fffffffu; olap = (cz_ >> 31) != 0; nned = Plat::uni(f.nedsz);
 					row = Plat::uni((uint32_t)f.row); col = Plat::uni((uint32_t)f.col);
@@ -922,7 +917,7 @@ struct Aligner {
 			}
 			if (branch) {
 				if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { w.err |= ERR_OVERFLOW; return false; }
-				BtFrame& f = w.btstack[nstack++];
+				BtFrame& f = btstack[nstack++];
 				f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
 				f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
 				f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
@@ -1295,7 +1290,7 @@ struct Aligner {
 		const uint32_t len = w.len;
 		w.err = 0;
 		w.n_alns = 0; w.best_unp1 = w.best2_unp1 = INT64_MIN; w.done_unpair1 = 0; w.exit_m = w.exit_k = 0;
-		w.n_diags = 0; w.n_red = 0; w.n_ex_fw = w.n_ex_rc = 0;
+		w.n_diags = 0; w.n_ex_fw = w.n_ex_rc = 0;
 		w.n_ex_iters = w.n_ex_dps = w.n_ex_ugs = w.n_dp_fail = w.n_ug_fail = w.n_ee_fail = w.n_dp_fail_streak = 0;
 		w.n_redundants = w.n_bwops_seed = w.n_bwops_ext = w.n_bt_attempts = 0; w.n_sides = 0; w.n_ext_left = w.n_ext_right = w.n_resolve_steps = 0;
 		for (int i_ = 0; i_ < 22; i_++) w.t_phase[i_] = 0;
@@ -1433,7 +1428,7 @@ struct Aligner {
 		out.best = w.alns[idx[0]].score;
 		if (sz > 1) { out.has_secbest = 1; out.secbest = w.alns[idx[1]].score; }
 		out.nreport = num;
-		for (uint32_t i = 0; i < num; i++) out.alns[i] = w.alns[idx[i]];
+		for (uint32_t i = 0; i < num; i++) Plat::copy_aln(out.alns[i], w.alns[idx[i]]);
 	}
 };
 

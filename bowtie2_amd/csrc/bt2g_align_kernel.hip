@@ -8,6 +8,7 @@
 // (lane = block of read rows, H/F/ref-char handed down the lanes with __shfl_up, wavefront-major
 // scratch so every store is one 64-byte line), and the zeroing of backtrace-mask rows.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include "bt2g_align_core.hpp"
 #include "bt2g_align_kernel.hpp"
 
@@ -90,6 +91,7 @@ struct DevPlat {
 		return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 	}
 	static __device__ __forceinline__ int64_t uni(int64_t v) { return (int64_t)uni((uint64_t)v); }
+	template <typename T> static __device__ __forceinline__ T* uni_ptr(T* p) { return reinterpret_cast<T*>(uni((uint64_t)reinterpret_cast<uintptr_t>(p))); }
 	// SSEMatrix::initMasks for the whole rectangle: 16 bytes per lane per store (the region is 256-byte padded)
 	static __device__ __forceinline__ void zero_masks(uint16_t* p, uint32_t n) {
 		wave_fence();
@@ -103,6 +105,15 @@ struct DevPlat {
 	static __device__ __forceinline__ void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols) {
 		wave_fence();
 		for (uint32_t j = threadIdx.x & 63; j < cols; j += 64) g_hot.lastrow[j] = (uint8_t)(mat[dp_cell(R, rows - 1, j)] & 0xff);
+		wave_fence();
+	}
+	// AlnRes copy, one 32-bit word per lane per pass; only the header and the edits in use move
+	static __device__ __forceinline__ void copy_aln(AlnRes& dst, const AlnRes& src) {
+		wave_fence();
+		const uint32_t nw = ((uint32_t)offsetof(AlnRes, ned) + (uint32_t)uni((uint32_t)src.nned) * (uint32_t)sizeof(Edit) + 3u) / 4u;
+		const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
+		uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+		for (uint32_t i = threadIdx.x & 63; i < nw; i += 64) d[i] = s[i];
 		wave_fence();
 	}
 	// Candidate cells of the last row, sorted by (score desc, col desc): every lane ranks its own cells

@@ -22,6 +22,7 @@ struct HostPlat {
 	static HotWork& hot() { return g_hot; }
 	static uint64_t clock() { return 0; }
 	template <typename T> static T uni(T v) { return v; }
+	template <typename T> static T* uni_ptr(T* p) { return p; }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
 		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
 	}
@@ -29,6 +30,7 @@ struct HostPlat {
 	static void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols) {
 		for (uint32_t j = 0; j < cols; j++) g_hot.lastrow[j] = (uint8_t)(mat[dp_cell(R, rows - 1, j)] & 0xff);
 	}
+	static void copy_aln(AlnRes& dst, const AlnRes& src) { memcpy(&dst, &src, offsetof(AlnRes, ned) + (size_t)src.nned * sizeof(Edit)); }
 	static uint32_t gather_sort(BtCand* cands, uint32_t cap, uint32_t rows, uint32_t cols, int64_t minsc_dp) {
 		uint32_t n = 0, total = 0;
 		for (uint32_t j = 0; j < cols; j++) {
