@@ -215,6 +215,9 @@ BT2_HD int imin(int a, int b) { return a < b ? a : b; }
 BT2_HD int imax(int a, int b) { return a > b ? a : b; }
 BT2_HD int subs0(int a, int b) { const int r = a - b; return r < 0 ? 0 : r; }
 
+// "ACGTN"[c] without a table in memory
+BT2_HD uint8_t code2chr(int c) { return (uint8_t)((0x4E54474341ull >> (8 * (c > 4 ? 4 : c))) & 0xff); }
+
 template <typename SP> BT2_HD int mm_penalty(const SP& P, int q) {
 	if (P.mm_type == 3) {     // COST_MODEL_QUAL (scoring.h:106-114)
 		const int qq = q < 40 ? q : 40;

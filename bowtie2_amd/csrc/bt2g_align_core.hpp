@@ -931,7 +931,7 @@ struct Aligner {
 					ct = 0;
 					if (m != 1) {
 						Edit& e = ned[nned++];
-						e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_MM;
+						e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = code2chr(readc); e.type = EDIT_MM;
 						score -= sc_mm(S, readc, refm, readq - 33);
 					} else {
 						score += S.match_bonus;
@@ -943,7 +943,7 @@ struct Aligner {
 				}
 				case 1: case 2: {   // ref gap (move up): open from H / extend from F
 					Edit& e = ned[nned++];
-					e.pos = (uint16_t)row; e.chr = '-'; e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_REF_GAP;
+					e.pos = (uint16_t)row; e.chr = '-'; e.qchr = code2chr(readc); e.type = EDIT_REF_GAP;
 					row--;
 					td = kBtTile;
 					ct = (cur == 1) ? 0 : 2;
@@ -970,7 +970,7 @@ struct Aligner {
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) {
 				Edit& e = ned[nned++];
-				e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = (uint8_t)"ACGTN"[readc]; e.type = EDIT_MM;
+				e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = code2chr(readc); e.type = EDIT_MM;
 				score -= sc_mm(S, readc, refm, Plat::uni(rd_qual(HOT, rdlen, fw, row)) - 33);
 			} else score += S.match_bonus;
 			if (m == -1) ns++;
@@ -1064,7 +1064,7 @@ struct Aligner {
 			if (rfc > 3 || rdc != rfc) {
 				if (nned >= (uint32_t)kMaxEdits) { w.err |= ERR_OVERFLOW; return 0; }
 				Edit& e = res.ned[nned++];
-				e.pos = (uint16_t)i; e.chr = (uint8_t)"ACGTN"[rfc]; e.qchr = (uint8_t)"ACGTN"[rdc]; e.type = EDIT_MM;
+				e.pos = (uint16_t)i; e.chr = code2chr(rfc); e.qchr = code2chr(rdc); e.type = EDIT_MM;
 				if (rfc > 3) refns++;
 			}
 		}
@@ -1174,7 +1174,7 @@ struct Aligner {
 						res.ns = (int16_t)hns; res.gaps = 0;
 						if (mms) {
 							Edit& e = res.ned[0];
-							e.pos = eh->epos; e.chr = (uint8_t)"ACGTN"[eh->echr]; e.qchr = (uint8_t)"ACGTN"[eh->eqchr]; e.type = EDIT_MM;
+							e.pos = eh->epos; e.chr = code2chr(eh->echr); e.qchr = code2chr(eh->eqchr); e.type = EDIT_MM;
 							res.nned = 1;
 						}
 						// setShape with no trimming leaves the (already 5'-relative) edit untouched

@@ -9,6 +9,7 @@
 // scratch so every store is one 64-byte line), and the zeroing of backtrace-mask rows.
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <new>
 #include "bt2g_align_core.hpp"
 #include "bt2g_align_kernel.hpp"
 
@@ -193,6 +194,13 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	DpScratch dp;
 	dp.mat = reinterpret_cast<uint32_t*>(base + ((sizeof(Work) + 255) & ~(uint64_t)255));
 	dp.masks = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(dp.mat) + mat_bytes);
+	__shared__ DevIndex<TOff> s_ix;
+	__shared__ AlignParams s_P;
+	__shared__ ReadParams s_rp;
+	__shared__ PreComp s_pre;
+	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
+	s_ix = ix; s_P = P; s_pre = pre;
+	wave_fence();
 	for (;;) {
 		unsigned int r = 0;
 		if (lane == 0) r = atomicAdd(next_read, 1u);
@@ -210,16 +218,14 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		w.len = len;
 		for (uint32_t i = lane; i < len; i += 64) { g_hot.seq[i] = rd.d_seq[o0 + i]; g_hot.qual[i] = rd.d_qual[o0 + i]; }
 		wave_fence();
-		const ReadParams rp = rparams[r];
-		Aligner<TOff, DevPlat> al(ix, P, rp, w, dp, &pre, r);
+		// The control state (`this`, the parameter blocks) is kept in LDS: the worker's member functions
+		// are real calls, and anything they reach through a pointer would otherwise be a private-memory load.
+		s_rp = rparams[r];
+		wave_fence();
+		Aligner<TOff, DevPlat>& al = *new (s_al) Aligner<TOff, DevPlat>(s_ix, s_P, s_rp, w, dp, &s_pre, r);
+		wave_fence();
 		al.run(out);
 		wave_fence();
-		{
-			// the control code must have stayed wave-uniform: compare a digest of the private state across lanes
-			const uint32_t dig = al.rnd.last ^ (uint32_t)al.minsc ^ (al.rnd.lastOff << 20);
-			const bool same = __shfl(dig, 0) == dig;
-			if (__ballot(!same) != 0ull) out.status |= 2;
-		}
 		if (lane == 0 && prof) {
 			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)w.t_phase[i]);
 			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)w.t_phase[i]);
