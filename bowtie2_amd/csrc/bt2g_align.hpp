@@ -149,15 +149,9 @@ struct HotWork {
 	uint32_t bt_left[16];      // cell(row-d,   col-d-1)
 	uint16_t bt_mask[16];      // mask(row-d,   col-d)
 	uint8_t  lastrow[kMaxCols + 8];   // H of the last DP row (gatherCells)
-};
-constexpr uint32_t kBtTile = 15;
-
-struct Work {
-	// ---- read ----
+	// ---- scalar control state of the read in flight (everything the control code touches often) ----
 	uint32_t len;
-	// ---- seed phase ----
 	EEHit    exact[2];         // [0] fw, [1] rc; top==bot => empty
-	EEHit    mm1[kMaxMm1];
 	uint32_t n_mm1;
 	uint64_t mm1_elt;
 	uint32_t num_offs;
@@ -165,41 +159,48 @@ struct Work {
 	uint32_t n_rank;
 	uint32_t nonz_tot, nonz_fw, nonz_rc;
 	uint64_t num_elts;
-	// ---- extension phase ----
-	SatPos   satpos2[kMaxRanges];
-	R1N      rands2[kMaxRanges];
 	uint32_t n_satpos2;
-	SatPos   satpos[kMaxSatpos];
 	uint32_t n_satpos;
-	uint32_t lists[kListArena];
 	uint32_t lists_used;
-	double   masses[kMaxRanges];
-	uint8_t  elim[kMaxRanges];
 	double   mass;
 	uint32_t n_masses;
-	struct ExtRange { uint32_t off, len, sz; } ex_fw[kMaxRanges * 2], ex_rc[kMaxRanges * 2];
 	uint32_t n_ex_fw, n_ex_rc;
-	DiagIval diags[kMaxDiags];
 	uint32_t n_diags;
-	int64_t  red_dmin[kMaxAlns], red_dmax[kMaxAlns];   // RedundantAlns prefilter: (column - row) bounds of alns[k]
-	// ---- sink ----
-	AlnRes   alns[kMaxAlns];
 	uint32_t n_alns;
 	int64_t  best_unp1, best2_unp1;
 	uint8_t  done_unpair1;
 	uint8_t  exit_m, exit_k;
-	// ---- DP ----
-	BtCand   cands[kMaxCands];
 	uint32_t n_cands, cural;
-	BtFrame  btstack[kMaxLen + kMaxCols];
-	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
-	// ---- status / metrics ----
 	uint32_t err;
 	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail, n_ug_fail, n_ee_fail, n_dp_fail_streak;
 	uint32_t n_redundants, n_bwops_seed, n_bwops_ext, n_bt_attempts;
 	uint32_t n_ext_left, n_ext_right, n_resolve_steps;
 	uint32_t n_sides;           // sides (64/128-byte lines) actually read -- roofline accounting
 	uint64_t t_phase[22];       // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other
+};
+constexpr uint32_t kBtTile = 15;
+
+struct Work {
+	// ---- read ----
+	// ---- seed phase ----
+	EEHit    mm1[kMaxMm1];
+	// ---- extension phase ----
+	SatPos   satpos2[kMaxRanges];
+	R1N      rands2[kMaxRanges];
+	SatPos   satpos[kMaxSatpos];
+	uint32_t lists[kListArena];
+	double   masses[kMaxRanges];
+	uint8_t  elim[kMaxRanges];
+	struct ExtRange { uint32_t off, len, sz; } ex_fw[kMaxRanges * 2], ex_rc[kMaxRanges * 2];
+	DiagIval diags[kMaxDiags];
+	int64_t  red_dmin[kMaxAlns], red_dmax[kMaxAlns];   // RedundantAlns prefilter: (column - row) bounds of alns[k]
+	// ---- sink ----
+	AlnRes   alns[kMaxAlns];
+	// ---- DP ----
+	BtCand   cands[kMaxCands];
+	BtFrame  btstack[kMaxLen + kMaxCols];
+	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
+	// ---- status / metrics ----
 };
 
 // DP scratch of one wave: wavefront-major H/E/F matrix + per-cell backtrace masks + row flags

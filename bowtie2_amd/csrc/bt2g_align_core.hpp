@@ -42,11 +42,11 @@ struct Aligner {
 		uint64_t nelt = 0;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			mine[fwi] = s.mine[fwi];
-			EEHit& h = w.exact[fwi];
+			EEHit& h = HOT.exact[fwi];
 			h.top = h.bot = 0;
 			if (s.hit[fwi]) {
 				h.top = s.top[fwi]; h.bot = s.bot[fwi]; h.fw = fwi == 0 ? 1 : 0; h.has_edit = 0;
-				h.score = (int32_t)((int64_t)w.len * P.match_bonus);
+				h.score = (int32_t)((int64_t)HOT.len * P.match_bonus);
 				nelt += s.bot[fwi] - s.top[fwi];
 			}
 		}
@@ -57,7 +57,7 @@ struct Aligner {
 	BT2_HD bool one_mm_pre(bool nofw, bool norc) {
 		const uint8_t* n = pre->mm1_n + (uint64_t)ridx * 4;
 		if ((!nofw && (n[0] == 255 || n[1] == 255)) || (!norc && (n[2] == 255 || n[3] == 255))) return false;
-		w.n_mm1 = 0; w.mm1_elt = 0;
+		HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 		for (int k = 0; k < 4; k++) {
 			const bool fw = k < 2;
 			if ((fw && nofw) || (!fw && norc)) continue;
@@ -69,14 +69,14 @@ struct Aligner {
 
 	// seed_round(0, interval, seedlen) from the batch kernel's output
 	BT2_HD uint32_t seed_round_pre(uint32_t interval, uint32_t seedlen) {
-		const uint32_t len = w.len;
+		const uint32_t len = HOT.len;
 		uint32_t nseeds = 1;
 		if ((int64_t)len > (int64_t)seedlen) nseeds += (len - seedlen) / interval;
-		if (nseeds > (uint32_t)kMaxOffs) { w.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
-		w.num_offs = nseeds;
-		w.nonz_tot = w.nonz_fw = w.nonz_rc = 0; w.num_elts = 0;
-		w.n_rank = 0;
-		for (uint32_t i = 0; i < nseeds; i++) w.off_idx2off[i] = interval * i;
+		if (nseeds > (uint32_t)kMaxOffs) { HOT.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
+		HOT.num_offs = nseeds;
+		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
+		HOT.n_rank = 0;
+		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
 			const bool skip = (fw && P.nofw) || (!fw && P.norc);
@@ -89,9 +89,9 @@ struct Aligner {
 				const bt2g_seed_hit sh = src[i];
 				if (sh.botf > sh.topf) {
 					h.topf = sh.topf; h.topb = sh.topb; h.size = (uint32_t)(sh.botf - sh.topf);
-					w.nonz_tot++;
-					if (fw) w.nonz_fw++; else w.nonz_rc++;
-					w.num_elts += sh.botf - sh.topf;
+					HOT.nonz_tot++;
+					if (fw) HOT.nonz_fw++; else HOT.nonz_rc++;
+					HOT.num_elts += sh.botf - sh.topf;
 				}
 			}
 		}
@@ -102,8 +102,8 @@ struct Aligner {
 	// A. end-to-end exact / 1-mismatch search and exact seeds
 	// =================================================================================
 
-	BT2_HD TOff lf1c(const DevEbwt<TOff>& e, TOff row, int c) { w.n_sides++; return map_lf1c(e, row, c); }
-	BT2_HD int lf1(const DevEbwt<TOff>& e, TOff& row) { if (row != e.zoff) w.n_sides++; return map_lf1(e, row); }
+	BT2_HD TOff lf1c(const DevEbwt<TOff>& e, TOff row, int c) { HOT.n_sides++; return map_lf1c(e, row, c); }
+	BT2_HD int lf1(const DevEbwt<TOff>& e, TOff& row) { if (row != e.zoff) HOT.n_sides++; return map_lf1(e, row); }
 
 	// One (top,bot) LF step as exactSweepMapLF does (aligner_seed.cpp:793-824)
 	BT2_HD void pair_lf(const DevEbwt<TOff>& e, int c, TOff& top, TOff& bot, uint32_t& bwops) {
@@ -111,7 +111,7 @@ struct Aligner {
 		if (bot - top > 1) {
 			bwops += 2;
 			TOff nt, nb;
-			w.n_sides += rank1_pair(e, top, bot, c, nt, nb);
+			HOT.n_sides += rank1_pair(e, top, bot, c, nt, nb);
 			top = nt; bot = nb;
 		} else {
 			bwops++;
@@ -123,10 +123,10 @@ struct Aligner {
 	// SeedAligner::exactSweep (aligner_seed.cpp:856-970); returns nelt
 	BT2_HDN uint64_t exact_sweep(uint32_t mine_max, uint32_t mine[2]) {
 		const DevEbwt<TOff>& e = ix.fw;
-		const uint32_t len = w.len, ftab_len = e.ftab_chars;
+		const uint32_t len = HOT.len, ftab_len = e.ftab_chars;
 		uint64_t nelt = 0;
-		w.exact[0].top = w.exact[0].bot = 0;
-		w.exact[1].top = w.exact[1].bot = 0;
+		HOT.exact[0].top = HOT.exact[0].bot = 0;
+		HOT.exact[1].top = HOT.exact[1].bot = 0;
 		mine[0] = mine[1] = 0;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
@@ -142,7 +142,7 @@ struct Aligner {
 					uint64_t key = 0;
 					if (do_ftab) {
 						for (uint32_t i = 0; i < ftab_len; i++) {
-							const int c = rd_char(HOT, w.len, fw, left - ftab_len + i);
+							const int c = rd_char(HOT, HOT.len, fw, left - ftab_len + i);
 							if (c > 3) { do_ftab = false; break; }
 							key = (key << 2) | (uint64_t)c;
 						}
@@ -152,7 +152,7 @@ struct Aligner {
 						bot = ftab_lo(e, key + 1);
 						dep += ftab_len;
 					} else {
-						const int c = rd_char(HOT, w.len, fw, len - dep - 1);
+						const int c = rd_char(HOT, HOT.len, fw, len - dep - 1);
 						if (c < 4) { top = e.fchr[c]; bot = e.fchr[c + 1]; }
 						dep++;
 					}
@@ -164,7 +164,7 @@ struct Aligner {
 					do_init = false;
 				}
 				if (dep < len) {
-					pair_lf(e, rd_char(HOT, w.len, fw, len - dep - 1), top, bot, w.n_bwops_seed);
+					pair_lf(e, rd_char(HOT, HOT.len, fw, len - dep - 1), top, bot, HOT.n_bwops_seed);
 					if (bot <= top) {
 						nedit++;
 						if (nedit >= mine_max) { mine[fwi] = nedit; done = true; }
@@ -176,7 +176,7 @@ struct Aligner {
 			if (!done) {
 				mine[fwi] = nedit;
 				if (nedit == 0 && bot > top) {
-					EEHit& h = w.exact[fwi];
+					EEHit& h = HOT.exact[fwi];
 					h.top = top; h.bot = bot; h.fw = fw ? 1 : 0; h.has_edit = 0;
 					h.score = (int32_t)((int64_t)len * P.match_bonus);
 					nelt += (uint64_t)(bot - top);
@@ -188,7 +188,7 @@ struct Aligner {
 
 	// mapBiLFEx (bt2_idx.h:2372): t/b for all chars in `e`, tp/bp prefix sums starting at topp
 	BT2_HD void bi_lf(const DevEbwt<TOff>& e, TOff top, TOff bot, TOff topp, TOff t[4], TOff b[4], TOff tp[4], TOff bp[4]) {
-		w.n_sides += rank4_pair(e, top, bot, t, b);
+		HOT.n_sides += rank4_pair(e, top, bot, t, b);
 		tp[0] = topp;
 		bp[0] = tp[0] + (b[0] - t[0]);
 		tp[1] = bp[0]; bp[1] = tp[1] + (b[1] - t[1]);
@@ -204,8 +204,8 @@ struct Aligner {
 
 	// SeedAligner::oneMmSearch with repex=false, rep1mm=true (aligner_seed.cpp:975-1325)
 	BT2_HDN void one_mm_search(bool nofw, bool norc) {
-		const uint32_t len = w.len;
-		w.n_mm1 = 0; w.mm1_elt = 0;
+		const uint32_t len = HOT.len;
+		HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 		uint32_t ns = 0;
 		for (uint32_t i = 0; i < len; i++) if (HOT.seq[i] > 3) ns++;
 		if (ns > 1) return;
@@ -219,31 +219,31 @@ struct Aligner {
 					[&](const Mm1Hit& m) { add_mm1(m, fw); }, cnt);
 			}
 		}
-		w.n_bwops_seed += cnt.bwops; w.n_sides += cnt.sides;
+		HOT.n_bwops_seed += cnt.bwops; HOT.n_sides += cnt.sides;
 	}
 
 	BT2_HD void add_mm1(const Mm1Hit& m, bool fw) {
-		if (w.n_mm1 >= (uint32_t)kMaxMm1) { w.err |= ERR_OVERFLOW; return; }
-		EEHit& h = w.mm1[w.n_mm1++];
+		if (HOT.n_mm1 >= (uint32_t)kMaxMm1) { HOT.err |= ERR_OVERFLOW; return; }
+		EEHit& h = w.mm1[HOT.n_mm1++];
 		h.top = m.top; h.bot = m.bot; h.score = m.score;
 		h.epos = m.epos; h.echr = m.echr; h.eqchr = m.eqchr;
 		h.fw = fw ? 1 : 0; h.has_edit = 1;
-		w.mm1_elt += (uint64_t)(m.bot - m.top);
+		HOT.mm1_elt += (uint64_t)(m.bot - m.top);
 	}
 
 	// One -N 0 seeding round: Seed::mmSeeds + instantiateSeeds + searchAllSeeds
 	// (aligner_seed.cpp:498-720,1638-2037).  Returns # instantiated seeds.
 	BT2_HDN uint32_t seed_round(uint32_t offset, uint32_t interval, uint32_t seedlen) {
-		const uint32_t len = w.len;
+		const uint32_t len = HOT.len;
 		uint32_t L = seedlen < len ? seedlen : len;
 		uint32_t nseeds = 1;
 		if ((int64_t)len - (int64_t)offset > (int64_t)seedlen) nseeds += (len - offset - seedlen) / interval;
-		if (nseeds > (uint32_t)kMaxOffs) { w.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
-		w.num_offs = nseeds;
-		w.nonz_tot = w.nonz_fw = w.nonz_rc = 0; w.num_elts = 0;
-		w.n_rank = 0;
+		if (nseeds > (uint32_t)kMaxOffs) { HOT.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
+		HOT.num_offs = nseeds;
+		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
+		HOT.n_rank = 0;
 		uint32_t ninst = 0;
-		for (uint32_t i = 0; i < nseeds; i++) w.off_idx2off[i] = interval * i + offset;
+		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i + offset;
 		const uint32_t fc = ix.fw.ftab_chars;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
@@ -284,14 +284,14 @@ struct Aligner {
 					const int c = getc(L - step - 1);
 					if (botf - topf > 1) {
 						TOff t[4], b[4];
-						w.n_bwops_seed++;
-						w.n_sides += rank4_pair(ix.fw, topf, botf, t, b);
+						HOT.n_bwops_seed++;
+						HOT.n_sides += rank4_pair(ix.fw, topf, botf, t, b);
 						TOff tp = topb;
 						for (int j = 0; j < c; j++) tp += b[j] - t[j];
 						if (b[c] == t[c]) { ok = false; break; }
 						topf = t[c]; botf = b[c]; topb = tp; botb = tp + (b[c] - t[c]);
 					} else {
-						w.n_bwops_seed++;
+						HOT.n_bwops_seed++;
 						const TOff t = lf1c(ix.fw, topf, c);
 						if (t == kOffMask) { ok = false; break; }
 						topf = t; botf = t + 1;
@@ -301,9 +301,9 @@ struct Aligner {
 				HotHit& h = HOT.hits[fwi][i];
 				h.topf = topf; h.topb = topb; h.size = (uint32_t)(botf - topf);
 				// SeedResults::add (aligner_seed.h:639-676)
-				w.nonz_tot++;
-				if (fw) w.nonz_fw++; else w.nonz_rc++;
-				w.num_elts += (uint64_t)(botf - topf);
+				HOT.nonz_tot++;
+				if (fw) HOT.nonz_fw++; else HOT.nonz_rc++;
+				HOT.num_elts += (uint64_t)(botf - topf);
 			}
 		}
 		return ninst;
@@ -313,8 +313,8 @@ struct Aligner {
 
 	// SeedResults::rankSeedHits, all=false (aligner_seed.h:1019-1080)
 	BT2_HDN void rank_seed_hits() {
-		w.n_rank = 0;
-		while (w.n_rank < w.nonz_tot) {
+		HOT.n_rank = 0;
+		while (HOT.n_rank < HOT.nonz_tot) {
 			uint64_t minsz = 0xffffffffull;      // MAX_U32 even for large indexes, as in the reference
 			uint32_t minidx = 0;
 			bool minfw = true;
@@ -322,19 +322,19 @@ struct Aligner {
 			for (int fwi = 0; fwi <= 1; fwi++) {
 				const bool fw = (fwi == (rb ? 1 : 0));
 				const int s = fw ? 0 : 1;
-				uint32_t i = rnd.nextU32() % w.num_offs;
-				for (uint32_t ii = 0; ii < w.num_offs; ii++) {
+				uint32_t i = rnd.nextU32() % HOT.num_offs;
+				for (uint32_t ii = 0; ii < HOT.num_offs; ii++) {
 					const uint64_t ne = hit_elts(s, i);
 					if (ne > 0 && !HOT.sorted[s][i] && (TOff)ne < (TOff)minsz) {
 						minsz = ne; minidx = i; minfw = fw;
 					}
-					if ((++i) == w.num_offs) i = 0;
+					if ((++i) == HOT.num_offs) i = 0;
 				}
 			}
 			HOT.sorted[minfw ? 0 : 1][minidx] = 1;
-			HOT.rank_offs[w.n_rank] = minidx;
-			HOT.rank_fw[w.n_rank] = minfw ? 1 : 0;
-			w.n_rank++;
+			HOT.rank_offs[HOT.n_rank] = minidx;
+			HOT.rank_fw[HOT.n_rank] = minfw ? 1 : 0;
+			HOT.n_rank++;
 		}
 	}
 
@@ -354,9 +354,9 @@ struct Aligner {
 	BT2_HD void r1n_reset(R1N& r) { r.sz = r.n = r.cur = 0; r.swaplist = r.converted = 0; r.list_len = r.seen_len = 0; r.thresh = 0; r.inited = 0; }
 	BT2_HD bool r1n_done(const R1N& r) const { return r.n > 0 && r.cur >= r.n; }
 	BT2_HD uint32_t lists_alloc(uint32_t n) {
-		if (w.lists_used + n > (uint32_t)kListArena) { w.err |= ERR_OVERFLOW; return 0; }
-		const uint32_t o = w.lists_used;
-		w.lists_used += n;
+		if (HOT.lists_used + n > (uint32_t)kListArena) { HOT.err |= ERR_OVERFLOW; return 0; }
+		const uint32_t o = HOT.lists_used;
+		HOT.lists_used += n;
 		return o;
 	}
 	BT2_HDN uint32_t r1n_next(R1N& r) {
@@ -422,8 +422,8 @@ struct Aligner {
 	                       uint32_t& nlex, uint32_t& nrex) {
 		FmCount cnt; cnt.bwops = 0; cnt.sides = 0;
 		HotRd rd;
-		fm_extend_hit(ix, rd, w.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt);
-		w.n_bwops_ext += cnt.bwops; w.n_sides += cnt.sides;
+		fm_extend_hit(ix, rd, HOT.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt);
+		HOT.n_bwops_ext += cnt.bwops; HOT.n_sides += cnt.sides;
 	}
 
 	// SATupleAndPos::operator< (aligner_sw_driver.h:150-160)
@@ -444,17 +444,17 @@ struct Aligner {
 
 	// SwDriver::eeSaTups (aligner_sw_driver.cpp:66-291)
 	BT2_HDN void ee_sa_tups(uint64_t& nelt_out, uint64_t maxelt) {
-		w.n_satpos = 0;
-		w.lists_used = 0;
+		HOT.n_satpos = 0;
+		HOT.lists_used = 0;
 		nelt_out = 0;
-		const uint64_t szfw = w.exact[0].bot - w.exact[0].top, szrc = w.exact[1].bot - w.exact[1].top;
+		const uint64_t szfw = HOT.exact[0].bot - HOT.exact[0].top, szrc = HOT.exact[1].bot - HOT.exact[1].top;
 		const uint64_t tot = szfw + szrc;
 		bool done = false;
 		auto add = [&](const EEHit& hit, int ee_idx, uint64_t top, uint64_t width) {
-			if (w.n_satpos >= (uint32_t)kMaxSatpos) { w.err |= ERR_OVERFLOW; done = true; return; }
-			SatPos& s = w.satpos[w.n_satpos++];
+			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; done = true; return; }
+			SatPos& s = w.satpos[HOT.n_satpos++];
 			s.topf = top; s.topb = (uint64_t)kOffMask; s.size = (uint32_t)width; s.orig_sz = (uint32_t)width;
-			s.fw = hit.fw; s.offidx = 0; s.rdoff = 0; s.seedlen = w.len; s.nlex = s.nrex = 0;
+			s.fw = hit.fw; s.offidx = 0; s.rdoff = 0; s.seedlen = HOT.len; s.nlex = s.nrex = 0;
 			s.ee = ee_idx;
 			r1n_init(s.rnd, (uint32_t)width, false);
 			nelt_out += width;
@@ -485,14 +485,14 @@ struct Aligner {
 			if (rn >= szfw) fw_first = false;
 			for (int fwi = 0; fwi < 2 && !done; fwi++) {
 				const bool fw = ((fwi == 0) == fw_first);
-				const EEHit& hit = w.exact[fw ? 0 : 1];
+				const EEHit& hit = HOT.exact[fw ? 0 : 1];
 				if (hit.bot <= hit.top) continue;
 				add_trimmed(hit, fw ? -2 : -3);     // -2/-3: exact fw / rc hit
 			}
 		}
-		if (!done && w.n_mm1 > 0) {
+		if (!done && HOT.n_mm1 > 0) {
 			// sort1mmEe: stable sort by score descending, then shuffle equal-score streaks (aligner_seed.h:1223)
-			for (uint32_t i = 1; i < w.n_mm1; i++) {
+			for (uint32_t i = 1; i < HOT.n_mm1; i++) {
 				const EEHit v = w.mm1[i];
 				uint32_t j = i;
 				while (j > 0 && w.mm1[j - 1].score < v.score) { w.mm1[j] = w.mm1[j - 1]; j--; }
@@ -508,7 +508,7 @@ struct Aligner {
 				}
 			};
 			uint32_t streak = 0;
-			for (uint32_t i = 1; i < w.n_mm1; i++) {
+			for (uint32_t i = 1; i < HOT.n_mm1; i++) {
 				if (w.mm1[i].score == w.mm1[i - 1].score) {
 					if (streak == 0) streak = 1;
 					streak++;
@@ -517,29 +517,29 @@ struct Aligner {
 					streak = 0;
 				}
 			}
-			if (streak > 1) shuffle(w.n_mm1 - streak, streak);
-			for (uint32_t i = 0; i < w.n_mm1 && !done; i++) add_trimmed(w.mm1[i], (int)i);
+			if (streak > 1) shuffle(HOT.n_mm1 - streak, streak);
+			for (uint32_t i = 0; i < HOT.n_mm1 && !done; i++) add_trimmed(w.mm1[i], (int)i);
 		}
 	}
 
-	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? w.exact[0] : (idx == -3 ? w.exact[1] : w.mm1[idx]); }
+	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? HOT.exact[0] : (idx == -3 ? HOT.exact[1] : w.mm1[idx]); }
 
 	// SwDriver::prioritizeSATupsRands (aligner_sw_driver.cpp:492-738)
 	BT2_HDN void prioritize(int seedmms, uint64_t maxelt, uint64_t& nelt_out) {
 		const uint32_t nsm = 5;
-		w.n_satpos = 0; w.n_satpos2 = 0; w.lists_used = 0;
+		HOT.n_satpos = 0; HOT.n_satpos2 = 0; HOT.lists_used = 0;
 		uint64_t nrange = 0, nelt = 0, nsmall = 0, nsmall_elts = 0;
-		for (uint32_t i = 0; i < w.n_rank; i++) {
+		for (uint32_t i = 0; i < HOT.n_rank; i++) {
 			const bool fw = HOT.rank_fw[i] != 0;
 			const uint32_t offidx = HOT.rank_offs[i];
-			const uint32_t rdoff = w.off_idx2off[offidx];
-			const uint32_t seedlen = rp.seedlen < (int32_t)w.len ? (uint32_t)rp.seedlen : w.len;
+			const uint32_t rdoff = HOT.off_idx2off[offidx];
+			const uint32_t seedlen = rp.seedlen < (int32_t)HOT.len ? (uint32_t)rp.seedlen : HOT.len;
 			const HotHit& h = HOT.hits[fw ? 0 : 1][offidx];
 			const uint64_t sz = h.size;
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
 				const Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
-				const uint32_t nr = fw ? w.n_ex_fw : w.n_ex_rc;
+				const uint32_t nr = fw ? HOT.n_ex_fw : HOT.n_ex_rc;
 				bool skip = false;
 				for (uint32_t k = 0; k < nr; k++) {
 					if (range[k].off <= rdoff && range[k].off + range[k].len >= rdoff + seedlen) {
@@ -548,8 +548,8 @@ struct Aligner {
 				}
 				if (skip) { nrange--; nelt -= sz; continue; }
 			}
-			if (w.n_satpos2 >= (uint32_t)kMaxRanges) { w.err |= ERR_OVERFLOW; break; }
-			SatPos& s = w.satpos2[w.n_satpos2++];
+			if (HOT.n_satpos2 >= (uint32_t)kMaxRanges) { HOT.err |= ERR_OVERFLOW; break; }
+			SatPos& s = w.satpos2[HOT.n_satpos2++];
 			s.topf = h.topf; s.topb = h.topb; s.size = (uint32_t)sz; s.orig_sz = (uint32_t)sz;
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
@@ -561,21 +561,21 @@ struct Aligner {
 				} else extend_hit((TOff)h.topf, (TOff)(h.topf + sz), (TOff)h.topb, (TOff)(h.topb + sz), fw, rdoff, seedlen, nlex, nrex);
 			}
 			s.nlex = nlex; s.nrex = nrex;
-			w.n_ext_left += nlex; w.n_ext_right += nrex;
+			HOT.n_ext_left += nlex; HOT.n_ext_right += nrex;
 			if (seedmms == 0 && (nlex > 0 || nrex > 0)) {
 				Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
-				uint32_t& nr = fw ? w.n_ex_fw : w.n_ex_rc;
+				uint32_t& nr = fw ? HOT.n_ex_fw : HOT.n_ex_rc;
 				if (nr < (uint32_t)(kMaxRanges * 2)) {
 					range[nr].off = rdoff - (fw ? nlex : nrex);
 					range[nr].len = seedlen + nlex + nrex;
 					range[nr].sz = (uint32_t)sz;
 					nr++;
-				} else w.err |= ERR_OVERFLOW;
+				} else HOT.err |= ERR_OVERFLOW;
 			}
 		}
 		nelt_out = nelt;
 		// satpos.sort()
-		for (uint32_t i = 1; i < w.n_satpos2; i++) {
+		for (uint32_t i = 1; i < HOT.n_satpos2; i++) {
 			const SatPos v = w.satpos2[i];
 			uint32_t j = i;
 			while (j > 0 && satpos_less(v, w.satpos2[j - 1])) { w.satpos2[j] = w.satpos2[j - 1]; j--; }
@@ -584,32 +584,32 @@ struct Aligner {
 		uint64_t nelt_added = 0;
 		// 1. the smalls, whole
 		for (uint64_t j = 0; j < nsmall && nelt_added < maxelt; j++) {
-			if (w.n_satpos >= (uint32_t)kMaxSatpos) { w.err |= ERR_OVERFLOW; break; }
-			SatPos& s = w.satpos[w.n_satpos++];
+			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; break; }
+			SatPos& s = w.satpos[HOT.n_satpos++];
 			s = w.satpos2[j];
 			r1n_init(s.rnd, s.size, false);
 			nelt_added += s.size;
 		}
-		if (nelt_added >= maxelt || nsmall == w.n_satpos2) { nelt_out = nelt_added; return; }
+		if (nelt_added >= maxelt || nsmall == HOT.n_satpos2) { nelt_out = nelt_added; return; }
 		// 2. the non-smalls: RowSampler::init(satpos2_, nsmall, size, lensq=true, szsq=true)
-		const uint32_t sai = (uint32_t)nsmall, saf = w.n_satpos2;
-		w.n_masses = saf - sai;
-		w.mass = 0.0;
+		const uint32_t sai = (uint32_t)nsmall, saf = HOT.n_satpos2;
+		HOT.n_masses = saf - sai;
+		HOT.mass = 0.0;
 		for (uint32_t i = sai; i < saf; i++) {
 			const uint32_t ln = w.satpos2[i].nlex + w.satpos2[i].nrex + 1;
 			double num = (double)ln; num *= num;
 			double denom = (double)w.satpos2[i].size; denom *= denom;
 			w.masses[i - sai] = num / denom;
 			w.elim[i - sai] = 0;
-			w.mass += w.masses[i - sai];
+			HOT.mass += w.masses[i - sai];
 		}
-		for (uint32_t j = 0; j < w.n_satpos2; j++) r1n_reset(w.rands2[j]);
+		for (uint32_t j = 0; j < HOT.n_satpos2; j++) r1n_reset(w.rands2[j]);
 		while (nelt_added < maxelt && nelt_added < nelt) {
 			// RowSampler::next
-			const double rd = (double)(rnd.nextFloat() * w.mass);
+			const double rd = (double)(rnd.nextFloat() * HOT.mass);
 			double mass_sofar = 0.0;
 			uint32_t pick = 0xffffffffu, last_unelim = 0xffffffffu;
-			for (uint32_t i = 0; i < w.n_masses; i++) {
+			for (uint32_t i = 0; i < HOT.n_masses; i++) {
 				if (!w.elim[i]) {
 					last_unelim = i;
 					mass_sofar += w.masses[i];
@@ -621,9 +621,9 @@ struct Aligner {
 			R1N& r2 = w.rands2[ri];
 			if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, false);
 			const uint32_t r = r1n_next(r2);
-			if (r1n_done(r2)) { w.elim[ri - sai] = 1; w.mass -= w.masses[ri - sai]; }
-			if (w.n_satpos >= (uint32_t)kMaxSatpos) { w.err |= ERR_OVERFLOW; break; }
-			SatPos& s = w.satpos[w.n_satpos++];
+			if (r1n_done(r2)) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; }
+			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; break; }
+			SatPos& s = w.satpos[HOT.n_satpos++];
 			s = w.satpos2[ri];
 			s.topf = w.satpos2[ri].topf + r;
 			s.topb = (uint64_t)kOffMask;
@@ -637,15 +637,15 @@ struct Aligner {
 	// seenDiags1_: plain union-of-intervals semantics (EIvalMergeListBinned, ival_list.h:210)
 	BT2_HD bool diag_present(int32_t ref, int64_t off, bool fw) const {
 		const int orient = fw ? 1 : 0;
-		for (uint32_t i = 0; i < w.n_diags; i++) {
+		for (uint32_t i = 0; i < HOT.n_diags; i++) {
 			const DiagIval& d = w.diags[i];
 			if (d.ref == ref && d.orient == orient && off >= d.off && off < d.off + d.len) return true;
 		}
 		return false;
 	}
 	BT2_HD void diag_add(int32_t ref, int64_t off, bool fw, int64_t len) {
-		if (w.n_diags >= (uint32_t)kMaxDiags) { w.err |= ERR_OVERFLOW; return; }
-		DiagIval& d = w.diags[w.n_diags++];
+		if (HOT.n_diags >= (uint32_t)kMaxDiags) { HOT.err |= ERR_OVERFLOW; return; }
+		DiagIval& d = w.diags[HOT.n_diags++];
 		d.ref = ref; d.off = off; d.orient = fw ? 1 : 0; d.len = len;
 	}
 
@@ -693,7 +693,7 @@ struct Aligner {
 
 	// RedundantAlns::overlap against every alignment reported so far (they are all kept in w.alns)
 	BT2_HDN bool red_overlap(const AlnRes& r) const {
-		const uint32_t nst = w.n_alns < (uint32_t)kMaxAlns ? w.n_alns : (uint32_t)kMaxAlns;
+		const uint32_t nst = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;
 		if (nst == 0) return false;
 		int64_t dmin, dmax;
 		diag_bounds(r, dmin, dmax);
@@ -715,25 +715,25 @@ struct Aligner {
 	}
 	// RedundantAlns::add: the cells are re-derived from w.alns[k] on demand; only the prefilter bounds are kept
 	BT2_HDN void red_add(const AlnRes& r) {
-		if (w.n_alns >= (uint32_t)kMaxAlns) return;      // sink_report flags the overflow
-		diag_bounds(r, w.red_dmin[w.n_alns], w.red_dmax[w.n_alns]);
+		if (HOT.n_alns >= (uint32_t)kMaxAlns) return;      // sink_report flags the overflow
+		diag_bounds(r, w.red_dmin[HOT.n_alns], w.red_dmax[HOT.n_alns]);
 	}
 
 	// =================================================================================
 	// D. sink (AlnSinkWrap::report, ReportingState::foundUnpaired; aln_sink.cpp:103-130,1395-1445)
 	// =================================================================================
 	BT2_HD bool sink_report(const AlnRes& r) {
-		if (w.n_alns < (uint32_t)kMaxAlns) Plat::copy_aln(w.alns[w.n_alns], r); else w.err |= ERR_OVERFLOW;
-		w.n_alns++;
-		if (!w.done_unpair1) {
+		if (HOT.n_alns < (uint32_t)kMaxAlns) Plat::copy_aln(w.alns[HOT.n_alns], r); else HOT.err |= ERR_OVERFLOW;
+		HOT.n_alns++;
+		if (!HOT.done_unpair1) {
 			// ReportingState::areDone
-			if (P.mhits <= 0 && w.n_alns >= (uint32_t)P.khits) { w.done_unpair1 = 1; w.exit_k = 1; }
-			else if (P.mhits > 0 && w.n_alns > (uint32_t)P.mhits) { w.done_unpair1 = 1; w.exit_m = 1; }
+			if (P.mhits <= 0 && HOT.n_alns >= (uint32_t)P.khits) { HOT.done_unpair1 = 1; HOT.exit_k = 1; }
+			else if (P.mhits > 0 && HOT.n_alns > (uint32_t)P.mhits) { HOT.done_unpair1 = 1; HOT.exit_m = 1; }
 		}
 		const int64_t score = r.score;
-		if (score > w.best_unp1) { w.best2_unp1 = w.best_unp1; w.best_unp1 = score; }
-		else if (score > w.best2_unp1) w.best2_unp1 = score;
-		return w.done_unpair1 != 0;
+		if (score > HOT.best_unp1) { HOT.best2_unp1 = HOT.best_unp1; HOT.best_unp1 = score; }
+		else if (score > HOT.best2_unp1) HOT.best2_unp1 = score;
+		return HOT.done_unpair1 != 0;
 	}
 
 	// =================================================================================
@@ -751,15 +751,15 @@ struct Aligner {
 	// gatherCellsNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1176-1208) + btncand_.sort()
 	BT2_HDN void gather_cells(uint32_t rows, uint32_t cols, int64_t minsc_dp) {
 		const uint32_t R = dp_R(rows);
-		w.n_cands = 0; w.cural = 0;
+		HOT.n_cands = 0; HOT.cural = 0;
 		const uint64_t tl_ = now();
 		Plat::load_last_row(dp.mat, R, rows, cols);
-		w.t_phase[15] += now() - tl_;
+		HOT.t_phase[15] += now() - tl_;
 		// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
 		const uint32_t nc = Plat::gather_sort(w.cands, (uint32_t)kMaxCands, rows, cols, minsc_dp);
-		if (nc > (uint32_t)kMaxCands) { w.err |= ERR_OVERFLOW; w.n_cands = kMaxCands; } else w.n_cands = nc;
-		w.t_phase[13] += w.n_cands;      // profile: candidate cells
-		if (w.n_cands > 0) { const uint64_t tz_ = now(); Plat::zero_masks(dp.masks, rows * cols); w.t_phase[16] += now() - tz_; }   // SSEMatrix::initMasks, eagerly
+		if (nc > (uint32_t)kMaxCands) { HOT.err |= ERR_OVERFLOW; HOT.n_cands = kMaxCands; } else HOT.n_cands = nc;
+		HOT.t_phase[13] += HOT.n_cands;      // profile: candidate cells
+		if (HOT.n_cands > 0) { const uint64_t tz_ = now(); Plat::zero_masks(dp.masks, rows * cols); HOT.t_phase[16] += now() - tz_; }   // SSEMatrix::initMasks, eagerly
 	}
 
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
@@ -801,7 +801,7 @@ struct Aligner {
 		int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
 		Edit* ned = HOT.ned;
 		const int offsetsc = -0xff;
-		w.n_bt_attempts++;
+		HOT.n_bt_attempts++;
 		while ((int)row >= 0) {
 			const int readc = Plat::uni(rd_char(HOT, rdlen, fw, row));
 			const int refm = Plat::uni((int)HOT.rf[col]);
@@ -916,15 +916,15 @@ struct Aligner {
 				break;
 			}
 			if (branch) {
-				if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { w.err |= ERR_OVERFLOW; return false; }
+				if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { HOT.err |= ERR_OVERFLOW; return false; }
 				BtFrame& f = btstack[nstack++];
 				f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
 				f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
 				f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
 			}
-			if (ncells >= (uint32_t)(kMaxLen + 64)) { w.err |= ERR_OVERFLOW; return false; }
+			if (ncells >= (uint32_t)(kMaxLen + 64)) { HOT.err |= ERR_OVERFLOW; return false; }
 			olap = olap || in_core(row, col); ncells++;
-			if (nned + 1 >= (uint32_t)kMaxEdits) { w.err |= ERR_OVERFLOW; return false; }
+			if (nned + 1 >= (uint32_t)kMaxEdits) { HOT.err |= ERR_OVERFLOW; return false; }
 			switch (cur) {
 				case 0: {   // diagonal
 					const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
@@ -1018,30 +1018,30 @@ struct Aligner {
 
 	// SwAligner::nextAlignment, end-to-end u8 branch (aligner_sw.cpp:737-1146)
 	BT2_HDN bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, AlnRes& res) {
-		if (w.cural == w.n_cands) return false;
+		if (HOT.cural == HOT.n_cands) return false;
 		bool found = false;
-		while (w.cural < w.n_cands) {
-			const BtCand& c = w.cands[w.cural];
-			if (c.score < minsc) { w.cural++; continue; }
+		while (HOT.cural < HOT.n_cands) {
+			const BtCand& c = w.cands[HOT.cural];
+			if (c.score < minsc) { HOT.cural++; continue; }
 			{ const uint64_t tt_ = now(); Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col); pf_tiles++; pf_tile_t += now() - tt_; }    // also the first tile of the backtrace
-			if (HOT.bt_mask[0] & 1) { w.cural++; continue; }
+			if (HOT.bt_mask[0] & 1) { HOT.cural++; continue; }
 			const uint32_t reseed = rnd.nextU32() + 1;
 			rnd.init(reseed);
 			res.nned = 0;
 			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, c.score, c.row, c.col, res);
 			rnd.init(reseed + 1);
 			if (ret) { found = true; break; }
-			w.cural++;
+			HOT.cural++;
 		}
 		if (!found) return false;
 		if (!fw) invert_edits(res);
-		w.cural++;
+		HOT.cural++;
 		return true;
 	}
 
 	// SwAligner::ungappedAlign, monotone branch (aligner_sw.cpp:286-494); returns 0 / 1
 	BT2_HDN int ungapped_align(bool fw, uint64_t tidx, int64_t refoff, int64_t reflen, AlnRes& res) {
-		const uint32_t len = w.len;
+		const uint32_t len = HOT.len;
 		const int64_t rfi = refoff, rff = refoff + (int64_t)len;
 		if (rfi < 0) return 0;              // gReportOverhangs == false
 		if (rff > reflen) return 0;
@@ -1049,9 +1049,9 @@ struct Aligner {
 		int ns = 0;
 		for (uint32_t i = 0; i < len; i++) HOT.rf[i] = (uint8_t)ref_base(ix.ref, tidx, rfi + (int64_t)i);   // codes here, not masks
 		for (uint32_t i = 0; i < len; i++) {
-			const int rdc = rd_char(HOT, w.len, fw, i);
+			const int rdc = rd_char(HOT, HOT.len, fw, i);
 			const int rfc = HOT.rf[i];
-			const int q = rd_qual(HOT, w.len, fw, i) - 33;
+			const int q = rd_qual(HOT, HOT.len, fw, i) - 33;
 			if (rdc > 3 || rfc > 3) { ns++; score -= P.n_pen; }
 			else if (rdc == rfc) score += P.match_bonus;
 			else score -= mm_penalty(P, q < 0 ? 0 : q);
@@ -1059,10 +1059,10 @@ struct Aligner {
 		}
 		uint32_t nned = 0, refns = 0;
 		for (uint32_t i = 0; i < len; i++) {
-			const int rdc = rd_char(HOT, w.len, fw, i);
+			const int rdc = rd_char(HOT, HOT.len, fw, i);
 			const int rfc = HOT.rf[i];
 			if (rfc > 3 || rdc != rfc) {
-				if (nned >= (uint32_t)kMaxEdits) { w.err |= ERR_OVERFLOW; return 0; }
+				if (nned >= (uint32_t)kMaxEdits) { HOT.err |= ERR_OVERFLOW; return 0; }
 				Edit& e = res.ned[nned++];
 				e.pos = (uint16_t)i; e.chr = code2chr(rfc); e.qchr = code2chr(rdc); e.type = EDIT_MM;
 				if (rfc > 3) refns++;
@@ -1082,14 +1082,14 @@ struct Aligner {
 	// =================================================================================
 	BT2_HDN int extend_seeds(int seedmms, int seedlen, int seedival) {
 		(void)seedlen; (void)seedival;
-		const uint32_t rdlen = w.len;
+		const uint32_t rdlen = HOT.len;
 		const int64_t perfect = (int64_t)rdlen * P.match_bonus * 0;   // monotone: perfectScore() == 0
 		const uint32_t nsm = 5;
-		const uint32_t nonz = w.nonz_tot;
-		const uint64_t ee_hits = (w.exact[0].bot - w.exact[0].top) + (w.exact[1].bot - w.exact[1].top) + w.mm1_elt;
+		const uint32_t nonz = HOT.nonz_tot;
+		const uint64_t ee_hits = (HOT.exact[0].bot - HOT.exact[0].top) + (HOT.exact[1].bot - HOT.exact[1].top) + HOT.mm1_elt;
 		bool ee_mode = ee_hits > 0;
 		bool first_ee = true, first_extend = true;
-		w.n_ee_fail = w.n_ug_fail = w.n_dp_fail = 0;
+		HOT.n_ee_fail = HOT.n_ug_fail = HOT.n_dp_fail = 0;
 		uint64_t nelt = 0, nelt_left = 0;
 		const uint32_t rows = rdlen;
 		const uint32_t max_iters = (uint32_t)P.max_iters;
@@ -1107,13 +1107,13 @@ struct Aligner {
 				if (minsc == perfect) return EXT_PERFECT_SCORE;
 				if (first_extend) {
 					nelt = 0;
-					{ const uint64_t t0_ = now(); prioritize(seedmms, max_iters, nelt); w.t_phase[3] += now() - t0_; }
+					{ const uint64_t t0_ = now(); prioritize(seedmms, max_iters, nelt); HOT.t_phase[3] += now() - t0_; }
 					nelt_left = nelt;
 					first_extend = false;
 				}
 				if (nelt_left == 0) break;
 			}
-			const uint32_t maxi = w.n_satpos;
+			const uint32_t maxi = HOT.n_satpos;
 			for (uint32_t i = 0; i < maxi; i++) {
 				SatPos& sp = w.satpos[i];
 				const EEHit* eh = ee_mode ? &ee_hit(sp.ee) : nullptr;
@@ -1130,25 +1130,25 @@ struct Aligner {
 					} else if (ee_mode && eh->score < minsc) {
 						break;
 					}
-					if (w.n_ex_dps >= (uint32_t)P.max_dp) return EXT_HARD_LIMIT;
-					if (w.n_ex_ugs >= (uint32_t)P.max_ug) return EXT_HARD_LIMIT;
-					if (w.n_ex_iters >= max_iters) return EXT_HARD_LIMIT;
-					w.n_ex_iters++;
+					if (HOT.n_ex_dps >= (uint32_t)P.max_dp) return EXT_HARD_LIMIT;
+					if (HOT.n_ex_ugs >= (uint32_t)P.max_ug) return EXT_HARD_LIMIT;
+					if (HOT.n_ex_iters >= max_iters) return EXT_HARD_LIMIT;
+					HOT.n_ex_iters++;
 					first = false;
 					const uint32_t elt = r1n_next(sp.rnd);
 					// GroupWalk2S::advanceElement == Ebwt::getOffset(topf + elt)
 					uint32_t steps = 0;
 					const uint64_t tr_ = now();
 					const TOff joff = get_offset(ix.fw, (TOff)(sp.topf + elt), steps);
-					w.t_phase[4] += now() - tr_;
-					w.n_bwops_ext += steps; w.n_sides += steps; w.n_resolve_steps += steps;
+					HOT.t_phase[4] += now() - tr_;
+					HOT.n_bwops_ext += steps; HOT.n_sides += steps; HOT.n_resolve_steps += steps;
 					if (!ee_mode) nelt_left--;
 					TOff tidx = 0, toff = 0, tlen = 0;
 					bool straddled = false;
 					joined_to_text_off(ix, (TOff)seedhitlen, joff, tidx, toff, tlen, ee_mode, straddled);
 					if (tidx == kOffMask) continue;
 					const int64_t refoff = (int64_t)toff - (int64_t)rdoff;
-					if (diag_present((int32_t)tidx, refoff, fw)) { w.n_redundants++; continue; }
+					if (diag_present((int32_t)tidx, refoff, fw)) { HOT.n_redundants++; continue; }
 					int read_gaps = 0, ref_gaps = 0;
 					bool ungapped = false;
 					if (!ee_mode) {
@@ -1185,15 +1185,15 @@ struct Aligner {
 					} else if (P.do_ungapped && ungapped) {
 						const uint64_t tu_ = now();
 						const int al = ungapped_align(fw, tidx, refoff, (int64_t)tlen, res);
-						w.t_phase[10] += now() - tu_;
+						HOT.t_phase[10] += now() - tu_;
 						diag_add((int32_t)tidx, refoff, fw, 1);
-						w.n_ex_ugs++;
+						HOT.n_ex_ugs++;
 						if (al == 0) {
-							w.n_ug_fail++;
-							if (w.n_ug_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
+							HOT.n_ug_fail++;
+							if (HOT.n_ug_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
 							continue;
 						}
-						w.n_ug_fail = 0;
+						HOT.n_ug_fail = 0;
 						found = true; state = 2;
 					}
 					if (state == 0) {
@@ -1213,39 +1213,39 @@ struct Aligner {
 						diag_add((int32_t)tidx, refoff, fw, 1);
 						if (!found) continue;
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
-						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { w.err |= ERR_OVERFLOW; return EXT_HARD_LIMIT; }
+						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { HOT.err |= ERR_OVERFLOW; return EXT_HARD_LIMIT; }
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
 						// SwAligner::align (aligner_sw.cpp:500-729), end-to-end 8-bit path
 						const uint64_t td_ = now();
 						fetch_ref_window(tidx, rect.refl, cols + 1);
 						const int best_u8 = Plat::dp_fill_ee_u8(P, w, fw, rows, cols, dp.mat);
-						w.t_phase[5] += now() - td_;
+						HOT.t_phase[5] += now() - td_;
 						const int64_t best = (int64_t)best_u8 - 0xff;
-						w.n_ex_dps++;
+						HOT.n_ex_dps++;
 						found = best >= minsc;
-						if (found) { const uint64_t tg_ = now(); gather_cells(rows, cols, minsc); found = w.n_cands > 0; w.t_phase[8] += now() - tg_; }
+						if (found) { const uint64_t tg_ = now(); gather_cells(rows, cols, minsc); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
 						if (!found) {
-							w.n_dp_fail++;
-							if (w.n_dp_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
+							HOT.n_dp_fail++;
+							if (HOT.n_dp_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
 							continue;
 						}
-						if (w.n_dp_fail > w.n_dp_fail_streak) w.n_dp_fail_streak = w.n_dp_fail;
-						w.n_dp_fail = 0;
+						if (HOT.n_dp_fail > HOT.n_dp_fail_streak) HOT.n_dp_fail_streak = HOT.n_dp_fail;
+						HOT.n_dp_fail = 0;
 					}
 					bool first_inner = true;
 					while (true) {
 						if (state == 1 || state == 2) {
 							if (!first_inner) break;
 						} else {
-							if (w.cural == w.n_cands) break;
+							if (HOT.cural == HOT.n_cands) break;
 							const uint64_t tb_ = now();
 							const bool na_ = next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, res);
-							w.t_phase[6] += now() - tb_;
+							HOT.t_phase[6] += now() - tb_;
 							if (!na_) break;
 						}
 						first_inner = false;
 						const uint64_t tp_ = now();
-						struct PostTimer { uint64_t t0; uint64_t& acc; BT2_HD ~PostTimer() { acc += Plat::clock() - t0; } } post_timer_{tp_, w.t_phase[9]};
+						struct PostTimer { uint64_t t0; uint64_t& acc; BT2_HD ~PostTimer() { acc += Plat::clock() - t0; } } post_timer_{tp_, HOT.t_phase[9]};
 						// fell entirely outside the reference?
 						{
 							const int64_t a0 = res.refoff, a1 = res.refoff + res.rfextent;
@@ -1253,20 +1253,20 @@ struct Aligner {
 							const bool ov = (b0 <= a0 && b1 > a0) || (b0 <= a1 && b1 > a1) || (a0 <= b0 && a1 > b0) || (a0 <= b1 && a1 > b1);
 							if (!ov) continue;
 						}
-						{ const uint64_t t1_ = now(); const bool ro_ = red_overlap(res); w.t_phase[17] += now() - t1_; if (ro_) continue; }
-						{ const uint64_t t1_ = now(); red_add(res); w.t_phase[18] += now() - t1_; }
-						{ const uint64_t t1_ = now(); const bool sr_ = sink_report(res); w.t_phase[19] += now() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
-						if (P.tighten > 0 && P.mhits > 0 && w.best2_unp1 != INT64_MIN) {
+						{ const uint64_t t1_ = now(); const bool ro_ = red_overlap(res); HOT.t_phase[17] += now() - t1_; if (ro_) continue; }
+						{ const uint64_t t1_ = now(); red_add(res); HOT.t_phase[18] += now() - t1_; }
+						{ const uint64_t t1_ = now(); const bool sr_ = sink_report(res); HOT.t_phase[19] += now() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
+						if (P.tighten > 0 && P.mhits > 0 && HOT.best2_unp1 != INT64_MIN) {
 							if (P.tighten == 1) {
-								if (w.best_unp1 >= minsc) {
-									minsc = w.best_unp1;
-									if (minsc < perfect && w.best_unp1 == w.best2_unp1) minsc++;
+								if (HOT.best_unp1 >= minsc) {
+									minsc = HOT.best_unp1;
+									if (minsc < perfect && HOT.best_unp1 == HOT.best2_unp1) minsc++;
 								}
 							} else if (P.tighten == 2) {
-								if (w.best2_unp1 >= minsc) { minsc = w.best2_unp1; if (minsc < perfect) minsc++; }
+								if (HOT.best2_unp1 >= minsc) { minsc = HOT.best2_unp1; if (minsc < perfect) minsc++; }
 							} else {
-								const int64_t diff = w.best_unp1 - w.best2_unp1;
-								const int64_t bot = w.best2_unp1 + ((diff * 3) / 4);
+								const int64_t diff = HOT.best_unp1 - HOT.best2_unp1;
+								const int64_t bot = HOT.best2_unp1 + ((diff * 3) / 4);
 								if (bot >= minsc) { minsc = bot; if (minsc < perfect) minsc++; }
 							}
 						}
@@ -1281,22 +1281,22 @@ struct Aligner {
 	// G. the per-read worker (multiseedSearchWorker, bt2_search.cpp:3094-4254, unpaired path)
 	// =================================================================================
 	BT2_HD void handle_ret(int ret, bool& done) {
-		if (ret == EXT_POLICY_FULFILLED) { if (w.done_unpair1) done = true; }
+		if (ret == EXT_POLICY_FULFILLED) { if (HOT.done_unpair1) done = true; }
 		else if (ret == EXT_PERFECT_SCORE) done = true;
 		else if (ret == EXT_HARD_LIMIT) done = true;
 	}
 
 	BT2_HD void run(ReadResult& out) {
-		const uint32_t len = w.len;
-		w.err = 0;
-		w.n_alns = 0; w.best_unp1 = w.best2_unp1 = INT64_MIN; w.done_unpair1 = 0; w.exit_m = w.exit_k = 0;
-		w.n_diags = 0; w.n_ex_fw = w.n_ex_rc = 0;
-		w.n_ex_iters = w.n_ex_dps = w.n_ex_ugs = w.n_dp_fail = w.n_ug_fail = w.n_ee_fail = w.n_dp_fail_streak = 0;
-		w.n_redundants = w.n_bwops_seed = w.n_bwops_ext = w.n_bt_attempts = 0; w.n_sides = 0; w.n_ext_left = w.n_ext_right = w.n_resolve_steps = 0;
-		for (int i_ = 0; i_ < 22; i_++) w.t_phase[i_] = 0;
+		const uint32_t len = HOT.len;
+		HOT.err = 0;
+		HOT.n_alns = 0; HOT.best_unp1 = HOT.best2_unp1 = INT64_MIN; HOT.done_unpair1 = 0; HOT.exit_m = HOT.exit_k = 0;
+		HOT.n_diags = 0; HOT.n_ex_fw = HOT.n_ex_rc = 0;
+		HOT.n_ex_iters = HOT.n_ex_dps = HOT.n_ex_ugs = HOT.n_dp_fail = HOT.n_ug_fail = HOT.n_ee_fail = HOT.n_dp_fail_streak = 0;
+		HOT.n_redundants = HOT.n_bwops_seed = HOT.n_bwops_ext = HOT.n_bt_attempts = 0; HOT.n_sides = 0; HOT.n_ext_left = HOT.n_ext_right = HOT.n_resolve_steps = 0;
+		for (int i_ = 0; i_ < 22; i_++) HOT.t_phase[i_] = 0;
 		const uint64_t t_run0_ = now();
-		w.n_mm1 = 0; w.mm1_elt = 0; w.nonz_tot = 0; w.n_rank = 0; w.num_offs = 0; w.num_elts = 0;
-		w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0;
+		HOT.n_mm1 = 0; HOT.mm1_elt = 0; HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_offs = 0; HOT.num_elts = 0;
+		HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
 		minsc = rp.minsc;
 		const bool filt = (rp.filt & 15u) == 15u;
 		bool done = !filt;
@@ -1308,11 +1308,11 @@ struct Aligner {
 			uint32_t mine[2] = {0, 0};
 			uint64_t nelt = 0;
 			if (P.do_exact_upfront) {
-				{ const uint64_t t0_ = now(); nelt = (pre && pre->sweep) ? exact_sweep_pre(mine) : exact_sweep(2, mine); w.t_phase[0] += now() - t0_; }
-				if (nelt == 0) { w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0; }
+				{ const uint64_t t0_ = now(); nelt = (pre && pre->sweep) ? exact_sweep_pre(mine) : exact_sweep(2, mine); HOT.t_phase[0] += now() - t0_; }
+				if (nelt == 0) { HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0; }
 				else {
 					const int ret = extend_seeds(-1, 0, 0);
-					w.exact[0].top = w.exact[0].bot = w.exact[1].top = w.exact[1].bot = 0;
+					HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
 					handle_ret(ret, done);
 					if (!done && minsc == perfect) done = true;
 				}
@@ -1325,21 +1325,21 @@ struct Aligner {
 					if (yfw || yrc) {
 						const uint64_t t0_ = now();
 						if (!(pre && pre->mm1 && one_mm_pre(!yfw, !yrc))) one_mm_search(!yfw, !yrc);
-						nelt = w.mm1_elt; w.t_phase[1] += now() - t0_;
+						nelt = HOT.mm1_elt; HOT.t_phase[1] += now() - t0_;
 					}
 					if (nelt > 0) {
 						const int ret = extend_seeds(-1, 0, 0);
-						w.n_mm1 = 0; w.mm1_elt = 0;
+						HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 						handle_ret(ret, done);
 						if (!done && minsc == perfect) done = true;
 					}
 				}
-				w.n_mm1 = 0; w.mm1_elt = 0;
+				HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 			}
 			if (nrounds > interval) nrounds = interval;
 			for (uint32_t roundi = 0; roundi < (uint32_t)P.n_seed_rounds; roundi++) {
-				w.nonz_tot = 0; w.n_rank = 0; w.num_elts = 0; w.num_offs = 0;
-				if (done || w.done_unpair1) { done = true; continue; }
+				HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_elts = 0; HOT.num_offs = 0;
+				if (done || HOT.done_unpair1) { done = true; continue; }
 				if (roundi >= nrounds) continue;
 				if (interval <= roundi) continue;
 				const uint32_t offset = (interval * roundi) / nrounds;
@@ -1351,24 +1351,24 @@ struct Aligner {
 					ninst = seed_round_pre(interval, (uint32_t)rp.seedlen);
 					ext_pre = pre->ext != nullptr;
 				} else ninst = seed_round(offset, interval, (uint32_t)rp.seedlen);
-				w.t_phase[2] += now() - ts_;
-				if (ninst == 0) { done = true; w.nonz_tot = 0; continue; }
-				if (w.nonz_tot == 0) { done = true; continue; }
-				{ const uint64_t t0_ = now(); rank_seed_hits(); w.t_phase[3] += now() - t0_; }
+				HOT.t_phase[2] += now() - ts_;
+				if (ninst == 0) { done = true; HOT.nonz_tot = 0; continue; }
+				if (HOT.nonz_tot == 0) { done = true; continue; }
+				{ const uint64_t t0_ = now(); rank_seed_hits(); HOT.t_phase[3] += now() - t0_; }
 				const int ret = extend_seeds(0, rp.seedlen, (int)interval);
 				handle_ret(ret, done);
-				if (!done && w.nonz_tot > 0 && (w.num_elts / w.nonz_tot) < (uint64_t)P.seed_boost_thresh) done = true;
+				if (!done && HOT.nonz_tot > 0 && (HOT.num_elts / HOT.nonz_tot) < (uint64_t)P.seed_boost_thresh) done = true;
 			}
 		}
 		finish(out);
-		w.t_phase[11] = pf_steps; w.t_phase[12] = pf_tiles; w.t_phase[14] = pf_tile_t;
-		w.t_phase[7] = now() - t_run0_;
+		HOT.t_phase[11] = pf_steps; HOT.t_phase[12] = pf_tiles; HOT.t_phase[14] = pf_tile_t;
+		HOT.t_phase[7] = now() - t_run0_;
 #ifdef BT2G_DEBUG_SATPOS
 		{
 			uint32_t* dbg = reinterpret_cast<uint32_t*>(out.alns[0].ned);
 			uint32_t k = 0;
-			dbg[k++] = w.n_satpos2;
-			for (uint32_t i = 0; i < w.n_satpos2 && k + 6 < 290; i++) {
+			dbg[k++] = HOT.n_satpos2;
+			for (uint32_t i = 0; i < HOT.n_satpos2 && k + 6 < 290; i++) {
 				const SatPos& s = w.satpos2[i];
 				dbg[k++] = (uint32_t)s.topf; dbg[k++] = (uint32_t)s.topb; dbg[k++] = s.size; dbg[k++] = s.nlex; dbg[k++] = s.nrex; dbg[k++] = s.offidx * 2 + s.fw;
 			}
@@ -1379,27 +1379,27 @@ struct Aligner {
 	// AlnSinkWrap::finishRead for an unpaired read (aln_sink.cpp:643-1384): ReportingState::finish,
 	// getReport, selectByScore (RNG!), and what the SAM line needs.
 	BT2_HDN void finish(ReadResult& out) {
-		out.status = (uint8_t)w.err;
+		out.status = (uint8_t)HOT.err;
 		out.filt = (uint8_t)rp.filt;
 		out.exhausted = 0;
-		out.nalns = w.n_alns;
-		out.n_ex_iters = w.n_ex_iters; out.n_ex_dps = w.n_ex_dps; out.n_ex_ugs = w.n_ex_ugs;
-		out.n_dp_fail_streak_max = w.n_dp_fail_streak; out.n_bwops_seed = w.n_bwops_seed; out.n_bwops_ext = w.n_bwops_ext;
-		out.n_redundants = w.n_redundants; out.n_bt_attempts = w.n_bt_attempts;
-		out.n_ext_left = w.n_ext_left; out.n_ext_right = w.n_ext_right; out.n_resolve_steps = w.n_resolve_steps; out.n_sides = w.n_sides;
+		out.nalns = HOT.n_alns;
+		out.n_ex_iters = HOT.n_ex_iters; out.n_ex_dps = HOT.n_ex_dps; out.n_ex_ugs = HOT.n_ex_ugs;
+		out.n_dp_fail_streak_max = HOT.n_dp_fail_streak; out.n_bwops_seed = HOT.n_bwops_seed; out.n_bwops_ext = HOT.n_bwops_ext;
+		out.n_redundants = HOT.n_redundants; out.n_bt_attempts = HOT.n_bt_attempts;
+		out.n_ext_left = HOT.n_ext_left; out.n_ext_right = HOT.n_ext_right; out.n_resolve_steps = HOT.n_resolve_steps; out.n_sides = HOT.n_sides;
 		uint32_t nunpair1 = 0;
 		bool maxed = false;
-		if (w.n_alns > 0) {
-			if (w.exit_k) nunpair1 = (uint32_t)P.khits;
-			else if (w.exit_m) { maxed = true; nunpair1 = 1; }
-			else nunpair1 = w.n_alns < (uint32_t)P.khits ? w.n_alns : (uint32_t)P.khits;
+		if (HOT.n_alns > 0) {
+			if (HOT.exit_k) nunpair1 = (uint32_t)P.khits;
+			else if (HOT.exit_m) { maxed = true; nunpair1 = 1; }
+			else nunpair1 = HOT.n_alns < (uint32_t)P.khits ? HOT.n_alns : (uint32_t)P.khits;
 		}
 		out.aligned = nunpair1 > 0 ? 1 : 0;
 		out.maxed = maxed ? 1 : 0;
 		out.has_secbest = 0; out.secbest = 0; out.best = 0; out.nreport = 0;
 		if (nunpair1 == 0) return;
 		// selectByScore: sort (score, index) ascending, reverse, shuffle equal-score streaks
-		const uint32_t sz = w.n_alns < (uint32_t)kMaxAlns ? w.n_alns : (uint32_t)kMaxAlns;
+		const uint32_t sz = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;
 		uint32_t num = nunpair1 < sz ? nunpair1 : sz;
 		uint32_t* idx = w.lists;      // scratch (Random1toN lists are dead by now)
 		for (uint32_t i = 0; i < sz; i++) idx[i] = i;

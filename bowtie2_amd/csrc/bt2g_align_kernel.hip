@@ -29,8 +29,8 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 	for (int r = 0; r < R; r++) {
 		const uint32_t i = (uint32_t)lane * R + r;
 		const bool valid = i < rows;
-		rdc[r] = valid ? rd_char(g_hot, w.len, fw, i) : 4;
-		const int q = valid ? rd_qual(g_hot, w.len, fw, i) - 33 : 0;
+		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
 		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
 		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 0xff : 0;
 	}
@@ -215,7 +215,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		}
 		// stage the read into the work area (lane-parallel copy)
 		wave_fence();
-		w.len = len;
+		g_hot.len = len;
 		for (uint32_t i = lane; i < len; i += 64) { g_hot.seq[i] = rd.d_seq[o0 + i]; g_hot.qual[i] = rd.d_qual[o0 + i]; }
 		wave_fence();
 		// The control state (`this`, the parameter blocks) is kept in LDS: the worker's member functions
@@ -227,9 +227,9 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		al.run(out);
 		wave_fence();
 		if (lane == 0 && prof) {
-			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)w.t_phase[i]);
-			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)w.t_phase[i]);
-			atomicAdd(&prof[8], (unsigned long long)w.n_sides);
+			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)g_hot.t_phase[i]);
+			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)g_hot.t_phase[i]);
+			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
 			atomicAdd(&prof[9], 1ull);
 		}
 	}

@@ -66,8 +66,8 @@ struct HostPlat {
 			int f = 0;
 			for (uint32_t i = 0; i < rows; i++) {
 				const int veto = ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar) ? 0xff : 0;
-				const int rdc = rd_char(g_hot, w.len, fw, i);
-				const int q = rd_qual(g_hot, w.len, fw, i) - 33;
+				const int rdc = rd_char(g_hot, g_hot.len, fw, i);
+				const int q = rd_qual(g_hot, g_hot.len, fw, i) - 33;
 				int pen;
 				if (rdc > 3 || refc > 3) pen = P.n_pen; else pen = (rdc == refc) ? -P.match_bonus : mm_penalty(P, q < 0 ? 0 : q);
 				const int hdiag = (i == 0) ? 0xff : (j == 0 ? 0 : Hp[i - 1]);
@@ -137,7 +137,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 			return 1;
 		}
 		ReadParams rp = compute_read_params(opt, rd);
-		w->len = (uint32_t)rd.seq.size();
+		g_hot.len = (uint32_t)rd.seq.size();
 		memcpy(g_hot.seq, rd.seq.data(), rd.seq.size());
 		memcpy(g_hot.qual, rd.qual.data(), rd.qual.size());
 		Aligner<TOff, HostPlat> al(ix, P, rp, *w, dp);
@@ -153,7 +153,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		fwrite(o.data(), 1, o.size(), out);
 		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u btsteps=%llu tiles=%llu cands=%llu\n", rd.name.c_str(),
 		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps,
-		                     (unsigned long long)w->t_phase[11], (unsigned long long)w->t_phase[12], (unsigned long long)w->t_phase[13]);
+		                     (unsigned long long)g_hot.t_phase[11], (unsigned long long)g_hot.t_phase[12], (unsigned long long)g_hot.t_phase[13]);
 	}
 	summ.print(stderr);
 	return 0;
