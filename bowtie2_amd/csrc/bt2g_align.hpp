@@ -142,12 +142,6 @@ struct HotWork {
 	uint8_t  rank_offs[kMaxRanges];
 	uint8_t  rank_fw[kMaxRanges];
 	Edit     ned[kMaxEdits];   // edits of the backtrace in progress
-	// backtrace tile: the cells a run of kBtTile diagonal steps starting at (row, col) can look at,
-	// gathered with one lane-parallel load (Plat::bt_tile): d-th entry is for cell (row-d, col-d)
-	uint32_t bt_cur[16];       // cell(row-d,   col-d)
-	uint32_t bt_up[16];        // cell(row-d-1, col-d)
-	uint32_t bt_left[16];      // cell(row-d,   col-d-1)
-	uint16_t bt_mask[16];      // mask(row-d,   col-d)
 	uint8_t  lastrow[kMaxCols + 8];   // H of the last DP row (gatherCells)
 	// ---- scalar control state of the read in flight (everything the control code touches often) ----
 	uint32_t len;
@@ -178,6 +172,9 @@ struct HotWork {
 	uint32_t n_sides;           // sides (64/128-byte lines) actually read -- roofline accounting
 	uint64_t t_phase[22];       // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other
 };
+// Backtrace tile: the cells a run of kBtTile diagonal steps starting at (row, col) can look at, gathered with one
+// lane-parallel load into a per-lane register (Plat::bt_tile): lanes 0-15 cell(row-d, col-d), 16-31 cell(row-d-1, col-d),
+// 32-47 cell(row-d, col-d-1), 48-63 mask(row-d, col-d), d = lane & 15.
 constexpr uint32_t kBtTile = 15;
 
 struct Work {

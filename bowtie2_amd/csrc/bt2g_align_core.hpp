@@ -764,7 +764,7 @@ struct Aligner {
 
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
 	BT2_HDN bool backtrace(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen,
-	                      int32_t escore, uint32_t row_, uint32_t col_, AlnRes& res) {
+	                      int32_t escore, uint32_t row_, uint32_t col_, typename Plat::LaneReg tile, AlnRes& res) {
 		(void)escore;
 		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
 		const bool fw = Plat::uni((int)fw_) != 0;
@@ -785,6 +785,18 @@ struct Aligner {
 			Aligner& a; uint32_t steps, tiles; uint64_t tile_t;
 			BT2_HD ~Prof() { a.pf_steps += steps; a.pf_tiles += tiles; a.pf_tile_t += tile_t; }
 		} prof{*this, 0, 0, 0};
+		// read, qualities and reference window as per-lane registers (4 bytes per lane per register): the step
+		// loop then reads them with v_readlane instead of going to LDS
+		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
+		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
+		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64);
+		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
+			const uint32_t word = idx >> 2;
+			uint32_t v = Plat::lane(arr[0], word & 63);
+			if (nreg > 1 && (word >> 6) == 1) v = Plat::lane(arr[1], word & 63);
+			if (nreg > 2 && (word >> 6) == 2) v = Plat::lane(arr[2], word & 63);
+			return (int)((v >> ((idx & 3) * 8)) & 0xff);
+		};
 		uint32_t td = 0;     // the caller fetched the tile anchored at (row, col); td = steps taken along its diagonal
 		const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
 		bool olap = false;   // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
@@ -803,14 +815,14 @@ struct Aligner {
 		const int offsetsc = -0xff;
 		HOT.n_bt_attempts++;
 		while ((int)row >= 0) {
-			const int readc = Plat::uni(rd_char(HOT, rdlen, fw, row));
-			const int refm = Plat::uni((int)HOT.rf[col]);
-			const int readq = Plat::uni(rd_qual(HOT, rdlen, fw, row));
+			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
+			const int refm = byte_of(rfw, 3, col);
+			const int readq = byte_of(qlw, 2, fw ? row : rdlen - 1 - row);
 			bool empty = false, can_move_thru = true, branch = false;
 			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
 			prof.steps++;
-			if (td >= kBtTile) { const uint64_t tt_ = now(); Plat::bt_tile(dpl, R, cols, row, col); td = 0; prof.tiles++; prof.tile_t += now() - tt_; }
-			const uint16_t mk0 = (uint16_t)Plat::uni((uint32_t)HOT.bt_mask[td]);
+			if (td >= kBtTile) { const uint64_t tt_ = now(); tile = Plat::bt_tile(dpl, R, cols, row, col); td = 0; prof.tiles++; prof.tile_t += now() - tt_; }
+			const uint16_t mk0 = (uint16_t)Plat::lane(tile, 48 + td);
 			uint16_t mk = mk0;
 			const bool reported_thru = (mk0 & 1) != 0;
 			if (reported_thru) {
@@ -819,10 +831,10 @@ struct Aligner {
 				const uint32_t row_from_end = rows - row - 1;
 				const bool gaps_allowed = !(row < (uint32_t)S.gapbar || row_from_end < (uint32_t)S.gapbar);
 				// the four packed cells this step can look at (out-of-matrix entries of the tile are 0)
-				const uint32_t c_cur = Plat::uni(HOT.bt_cur[td]);
-				const uint32_t c_up = Plat::uni(HOT.bt_up[td]);
-				const uint32_t c_left = Plat::uni(HOT.bt_left[td]);
-				const uint32_t c_upleft = Plat::uni(HOT.bt_cur[td + 1]);
+				const uint32_t c_cur = Plat::lane(tile, td);
+				const uint32_t c_up = Plat::lane(tile, 16 + td);
+				const uint32_t c_left = Plat::lane(tile, 32 + td);
+				const uint32_t c_upleft = Plat::lane(tile, td + 1);
 				auto Hc = [](uint32_t c) -> int { return (int)(c & 0xff); };
 				auto Ec = [](uint32_t c) -> int { return (int)((c >> 8) & 0xff); };
 				auto Fc = [](uint32_t c) -> int { return (int)((c >> 16) & 0xff); };
@@ -965,13 +977,13 @@ struct Aligner {
 		}
 		if (!olap) return false;
 		{
-			const int readc = Plat::uni(rd_char(HOT, rdlen, fw, row));
-			const int refm = Plat::uni((int)HOT.rf[col]);
+			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
+			const int refm = byte_of(rfw, 3, col);
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) {
 				Edit& e = ned[nned++];
 				e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = code2chr(readc); e.type = EDIT_MM;
-				score -= sc_mm(S, readc, refm, Plat::uni(rd_qual(HOT, rdlen, fw, row)) - 33);
+				score -= sc_mm(S, readc, refm, byte_of(qlw, 2, fw ? row : rdlen - 1 - row) - 33);
 			} else score += S.match_bonus;
 			if (m == -1) ns++;
 		}
@@ -1023,12 +1035,13 @@ struct Aligner {
 		while (HOT.cural < HOT.n_cands) {
 			const BtCand& c = w.cands[HOT.cural];
 			if (c.score < minsc) { HOT.cural++; continue; }
-			{ const uint64_t tt_ = now(); Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col); pf_tiles++; pf_tile_t += now() - tt_; }    // also the first tile of the backtrace
-			if (HOT.bt_mask[0] & 1) { HOT.cural++; continue; }
+			typename Plat::LaneReg tile;
+			{ const uint64_t tt_ = now(); tile = Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col); pf_tiles++; pf_tile_t += now() - tt_; }    // also the first tile of the backtrace
+			if (Plat::lane(tile, 48) & 1) { HOT.cural++; continue; }
 			const uint32_t reseed = rnd.nextU32() + 1;
 			rnd.init(reseed);
 			res.nned = 0;
-			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, c.score, c.row, c.col, res);
+			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, c.score, c.row, c.col, tile, res);
 			rnd.init(reseed + 1);
 			if (ret) { found = true; break; }
 			HOT.cural++;

@@ -139,21 +139,27 @@ struct DevPlat {
 		wave_fence();
 		return total;
 	}
+	// A value per lane, kept in a vector register; lane(r, i) reads lane i's copy into a scalar register.
+	using LaneReg = uint32_t;
+	static __device__ __forceinline__ uint32_t lane(LaneReg r, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane((int)r, (int)uni(i)); }
+	// lane i <- the 4 bytes at base[(word0 + i) * 4 ...] (0 past the end of the array); base is an LDS array
+	static __device__ __forceinline__ LaneReg lanes_load(const uint8_t* base, uint32_t nbytes, uint32_t word0) {
+		const uint32_t wd = word0 + (threadIdx.x & 63);
+		return (wd * 4 + 4 <= nbytes) ? *reinterpret_cast<const uint32_t*>(base + wd * 4) : 0u;
+	}
 	// Backtrace tile anchored at (row, col): lanes 0-15 cell(row-d, col-d), 16-31 cell(row-d-1, col-d),
 	// 32-47 cell(row-d, col-d-1), 48-63 mask(row-d, col-d); one load instruction per array, one latency.
-	static __device__ __forceinline__ void bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col) {
-		wave_fence();
-		const uint32_t lane = threadIdx.x & 63, d = lane & 15, g = lane >> 4;
+	static __device__ __forceinline__ LaneReg bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col) {
+		wave_fence();        // mask stores of earlier steps -> visible to whichever lane re-reads them
+		const uint32_t ln = threadIdx.x & 63, d = ln & 15, g = ln >> 4;
 		const int r = (int)row - (int)d - (g == 1 ? 1 : 0);
 		const int c = (int)col - (int)d - (g == 2 ? 1 : 0);
-		const bool ok = r >= 0 && c >= 0;
 		uint32_t v = 0;
-		if (ok) {
+		if (r >= 0 && c >= 0) {
 			if (g < 3) v = dp.mat[dp_cell(R, (uint32_t)r, (uint32_t)c)];
 			else v = dp.masks[(uint64_t)r * cols + (uint32_t)c];
 		}
-		if (g == 0) g_hot.bt_cur[d] = v; else if (g == 1) g_hot.bt_up[d] = v; else if (g == 2) g_hot.bt_left[d] = v; else g_hot.bt_mask[d] = (uint16_t)v;
-		wave_fence();
+		return v;
 	}
 	// reference window -> masks, one base per lane per pass (SwAligner::initRef, aligner_sw.cpp:155-271)
 	static __device__ __forceinline__ void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {

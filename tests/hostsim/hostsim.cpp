@@ -45,14 +45,29 @@ struct HostPlat {
 		}
 		return total;
 	}
-	static void bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col) {
-		for (uint32_t d = 0; d < 16; d++) {
-			const int r = (int)row - (int)d, c = (int)col - (int)d;
-			g_hot.bt_cur[d]  = (r >= 0 && c >= 0) ? dp.mat[dp_cell(R, r, c)] : 0;
-			g_hot.bt_up[d]   = (r >= 1 && c >= 0) ? dp.mat[dp_cell(R, r - 1, c)] : 0;
-			g_hot.bt_left[d] = (r >= 0 && c >= 1) ? dp.mat[dp_cell(R, r, c - 1)] : 0;
-			g_hot.bt_mask[d] = (r >= 0 && c >= 0) ? dp.masks[(uint64_t)r * cols + c] : 0;
+	struct LaneReg { uint32_t v[64]; };
+	static uint32_t lane(const LaneReg& r, uint32_t i) { return r.v[i]; }
+	static LaneReg lanes_load(const uint8_t* base, uint32_t nbytes, uint32_t word0) {
+		LaneReg r;
+		for (uint32_t l = 0; l < 64; l++) {
+			const uint32_t wd = word0 + l;
+			uint32_t v = 0;
+			if (wd * 4 + 4 <= nbytes) memcpy(&v, base + wd * 4, 4);
+			r.v[l] = v;
 		}
+		return r;
+	}
+	static LaneReg bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col) {
+		LaneReg t;
+		for (uint32_t ln = 0; ln < 64; ln++) {
+			const uint32_t d = ln & 15, g = ln >> 4;
+			const int r = (int)row - (int)d - (g == 1 ? 1 : 0);
+			const int c = (int)col - (int)d - (g == 2 ? 1 : 0);
+			uint32_t v = 0;
+			if (r >= 0 && c >= 0) v = g < 3 ? dp.mat[dp_cell(R, (uint32_t)r, (uint32_t)c)] : (uint32_t)dp.masks[(uint64_t)r * cols + (uint32_t)c];
+			t.v[ln] = v;
+		}
+		return t;
 	}
 	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
 	static int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat) {
