@@ -190,6 +190,24 @@ def cpu_baseline(base, seq, qual, sample, threads, repeat=1):
                                                                   al.group(1) if al else "?")}
 
 
+def pmc_traffic(kernel, reads_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, KiB),
+    scaled from the reads-per-launch of that profile run to this run's.  PMC collection needs rocprofv3 around the
+    process, so it cannot be taken inside the timed run; profiles/README.md has the recipe."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        k = d["kernels"][kernel]
+        per_read = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / (d["reads_per_launch"] * d["launches"])
+        return int(per_read * reads_per_launch), "profiles/%s (FETCH_SIZE+WRITE_SIZE per read x %d reads)" % (os.path.basename(files[-1]), reads_per_launch)
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,6 +346,7 @@ def main():
         fm_ms = sum(v for k, v in kavg.items() if k != "k_align_reads")
         fm_bytes = (cnt.rank_queries * side + cnt.ftab_lookups * 2 * off_sz + cnt.sa_lookups * off_sz) / float(args.steps) + n * args.readlen * 2
         fm_achieved = fm_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("k_align_reads", n)
         res = {
             "metric": "aligned reads/sec (whole node), 150 bp SE, synthetic genome (hg38 unavailable offline)",
             "value": world * n * steps / dt,
@@ -356,7 +375,7 @@ def main():
                 "sides_per_read": prof[8] / max(1, prof[9]),
             },
             "roofline": {"bound": "hbm", "kernel": "k_align_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": kern_ms,
                          "dp_gcups": dp_cells / (kern_ms * 1e-3) / 1e9,
                          "note": "k_align_reads is bound by scalar-instruction issue of its wave-uniform control code, not by HBM (DESIGN.md 6); "

@@ -36,7 +36,7 @@ constexpr int kMaxLen      = 512;   // longest read (DP rows)
 constexpr int kMaxOffs     = 64;    // seed offsets per strand
 constexpr int kMaxMm1      = 256;   // 1-mismatch end-to-end hits kept
 constexpr int kMaxRanges   = 2 * kMaxOffs;
-constexpr int kMaxSatpos   = 704;   // maxIters(400) + ranges + slack
+constexpr int kMaxSatpos   = 1856;  // maxIters(400 + 20*(k-1), k <= 64) + ranges + slack
 constexpr int kMaxEdits    = 200;
 constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at most 51)
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
@@ -46,7 +46,7 @@ constexpr int kMaxCols     = kMaxLen + 4 * 15 + 1 + 4;
 
 enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
 enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMIT, EXT_HARD_LIMIT };
-enum { ERR_NONE = 0, ERR_OVERFLOW = 1 };   // per-read status: capacity of a fixed arena exceeded
+enum { ERR_NONE = 0, ERR_OVERFLOW = 1, ERR_NEED_I16 = 4 };   // per-read status bits: a fixed arena overflowed; the read needs the 16-bit DP (minsc < -254)
 
 // ---------------------------------------------------------------------------------------
 // The batch parameters, per-read parameters and result records are the C-ABI structs of

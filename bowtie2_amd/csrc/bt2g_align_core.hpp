@@ -1228,7 +1228,9 @@ struct Aligner {
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
 						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { HOT.err |= ERR_OVERFLOW; return EXT_HARD_LIMIT; }
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
-						// SwAligner::align (aligner_sw.cpp:500-729), end-to-end 8-bit path
+						// SwAligner::align (aligner_sw.cpp:500-729), end-to-end 8-bit path; the reference switches to its
+						// 16-bit kernels when minsc < -254 (:517), which this build does not have: flag the read
+						if (minsc < -254) { HOT.err |= ERR_NEED_I16; return EXT_HARD_LIMIT; }
 						const uint64_t td_ = now();
 						fetch_ref_window(tidx, rect.refl, cols + 1);
 						const int best_u8 = Plat::dp_fill_ee_u8(P, w, fw, rows, cols, dp.mat);

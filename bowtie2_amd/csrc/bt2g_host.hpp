@@ -313,7 +313,11 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 				i += (glen - 1);
 			}
 		}
-		o += std::to_string(mapq_v2(opt, len, rr.best, rr.has_secbest != 0, rr.secbest));
+		// unique.h:199-205: a secondary line, or "one alignment found without looking for a second" (-k: canMax is
+		// false, and the reference never sets `exhausted`), reports 255
+		const bool can_max = !(opt.saw_k || opt.all_hits) && opt.mhits > 0;
+		if (!primary || (!can_max && !rr.has_secbest)) o += "255";
+		else o += std::to_string(mapq_v2(opt, len, rr.best, rr.has_secbest != 0, rr.secbest));
 		o.push_back('\t');
 		// CIGAR
 		if (trimLS > 0) { o += std::to_string(trimLS); o.push_back('S'); }

@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
 	opt.cmdline = cmdline;
 	int device = 0;
 	bool metrics = false;
+	unsigned long long n_flagged = 0;
 	size_t batch_reads = 1u << 20;
 	for (int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
@@ -150,7 +151,8 @@ int main(int argc, char** argv) {
 		o.clear();
 		for (size_t i = 0; i < n; i++) {
 			const ReadResult& rr = *(const ReadResult*)(h_res.data() + i * stride);
-			if (rr.status) fprintf(stderr, "Warning: read %s: device status %d (1 = work buffer overflow, 2 = lanes diverged)\n", reads[i].name.c_str(), (int)rr.status);
+			if (rr.status) n_flagged++;
+			if (rr.status) fprintf(stderr, "Warning: read %s: device status %d (bit 0 = work buffer overflow, bit 2 = needs the 16-bit DP: min score < -254)\n", reads[i].name.c_str(), (int)rr.status);
 			summ.add(rr);
 			if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", reads[i].name.c_str(),
 			                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
@@ -172,5 +174,10 @@ int main(int argc, char** argv) {
 	}
 	summ.print(stderr);
 	bt2g_ctx_destroy(ctx);
+	if (n_flagged) {
+		// never pass off a capacity-limited result as the reference's
+		fprintf(stderr, "Error: %llu read(s) exceeded a limit of this build (see the warnings above); their SAM records may differ from bowtie2's\n", (unsigned long long)n_flagged);
+		return 1;
+	}
 	return 0;
 }
