@@ -225,18 +225,13 @@ def main():
     import torch
     import bowtie2_amd as b
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from bowtie2_amd import shard
+    rank, local_rank, world = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+    dist = shard.init("nccl", dev)      # RCCL; None when WORLD_SIZE == 1
 
     threads = nproc()
     # ---- workload: index (rank 0 builds, others wait) ----
@@ -251,7 +246,7 @@ def main():
     ctx = b.Context(local_rank)
     info = ctx.load_index(base)
     # per-rank shard of reads (weak scaling: fixed reads per GPU)
-    seq, qual = synth_reads_gpu(chroms, args.reads, args.readlen, 1000 + rank, dev)
+    seq, qual = synth_reads_gpu(chroms, args.reads, args.readlen, shard.shard_seed(1000, rank), dev)
     n = args.reads
     off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * args.readlen)
     batch = b.ReadBatch(seq.view(-1), qual.view(-1), off, n)
@@ -305,10 +300,7 @@ def main():
         step(True)
     sync_all()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.reduce_max(dist, dt, dev)      # the slowest rank defines the step time
     batch_ms = sum(a.elapsed_time(bb) for a, bb in stage_events) / len(stage_events)
     kavg = {k: sum(t[k] for t in kern_times) / len(kern_times) for k in kern_times[0]}
     kern_ms = kavg["k_align_reads"]
@@ -325,11 +317,7 @@ def main():
                     ("n_ext_left", "<u4"), ("n_ext_right", "<u4"), ("n_resolve_steps", "<u4"), ("n_sides", "<u4")])
     h = np.frombuffer(rec.tobytes(), dtype=hdr)
     aligned = int(h["aligned"].sum())
-    all_aligned = aligned
-    if dist is not None:
-        t = torch.tensor([aligned], dtype=torch.float64, device=dev)
-        dist.all_reduce(t)
-        all_aligned = int(t.item())
+    all_aligned = shard.reduce_sum(dist, [aligned], dev)[0]
 
     if rank == 0:
         steps = args.steps
@@ -349,7 +337,7 @@ def main():
         traffic, traffic_src = pmc_traffic("k_align_reads", n)
         res = {
             "metric": "aligned reads/sec (whole node), 150 bp SE, synthetic genome (hg38 unavailable offline)",
-            "value": world * n * steps / dt,
+            "value": shard.throughput(world, n, steps, dt),
             "unit": "reads/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3,
@@ -385,7 +373,7 @@ def main():
                                         "achieved": fm_achieved, "unit": "GB/s", "frac": fm_achieved / HBM_PEAK_GBS}},
         }
         cb = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
             cb = cpu_baseline(base, seq, qual, min(args.cpu_sample, n), threads, args.cpu_repeat)
         res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
