@@ -46,7 +46,7 @@ constexpr int kMaxCols     = kMaxLen + 4 * 15 + 1 + 4;
 
 enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
 enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMIT, EXT_HARD_LIMIT };
-enum { ERR_NONE = 0, ERR_OVERFLOW = 1, ERR_NEED_I16 = 4 };   // per-read status bits: a fixed arena overflowed; the read needs the 16-bit DP (minsc < -254)
+enum { ERR_NONE = 0, ERR_OVERFLOW = 1 };   // per-read status: capacity of a fixed arena exceeded
 
 // ---------------------------------------------------------------------------------------
 // The batch parameters, per-read parameters and result records are the C-ABI structs of
@@ -142,7 +142,7 @@ struct HotWork {
 	uint8_t  rank_offs[kMaxRanges];
 	uint8_t  rank_fw[kMaxRanges];
 	Edit     ned[kMaxEdits];   // edits of the backtrace in progress
-	uint8_t  lastrow[kMaxCols + 8];   // H of the last DP row (gatherCells)
+	int16_t  lastrow[kMaxCols + 8];   // scores of the last DP row, clamped at -32768 (gatherCells)
 	// ---- scalar control state of the read in flight (everything the control code touches often) ----
 	uint32_t len;
 	EEHit    exact[2];         // [0] fw, [1] rc; top==bot => empty

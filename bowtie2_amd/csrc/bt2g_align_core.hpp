@@ -1,7 +1,7 @@
 // bt2g_align_core.hpp -- per-read worker logic (see bt2g_align.hpp for the execution model).
 //
 // `Plat` supplies the wave-parallel pieces:
-//    int  Plat::dp_fill_ee_u8(P, w, fw, rows, cols, scratch)  -> best last-row H (u8 encoded)
+//    int64 Plat::dp_fill_ee(P, w, fw, rows, cols, scratch, wide)  -> best last-row score
 //    void Plat::zero_u16(ptr, n) / sync()
 // Everything else is wave-uniform scalar code.
 #ifndef BT2G_ALIGN_CORE_HPP_
@@ -749,11 +749,11 @@ struct Aligner {
 	BT2_HD uint16_t& mask_at(uint32_t row, uint32_t col, uint32_t cols) { return dp.masks[(uint64_t)row * cols + col]; }
 
 	// gatherCellsNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1176-1208) + btncand_.sort()
-	BT2_HDN void gather_cells(uint32_t rows, uint32_t cols, int64_t minsc_dp) {
+	BT2_HDN void gather_cells(uint32_t rows, uint32_t cols, int64_t minsc_dp, bool wide) {
 		const uint32_t R = dp_R(rows);
 		HOT.n_cands = 0; HOT.cural = 0;
 		const uint64_t tl_ = now();
-		Plat::load_last_row(dp.mat, R, rows, cols);
+		Plat::load_last_row(dp.mat, R, rows, cols, wide);
 		HOT.t_phase[15] += now() - tl_;
 		// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
 		const uint32_t nc = Plat::gather_sort(w.cands, (uint32_t)kMaxCands, rows, cols, minsc_dp);
@@ -764,10 +764,12 @@ struct Aligner {
 
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
 	BT2_HDN bool backtrace(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen,
-	                      int32_t escore, uint32_t row_, uint32_t col_, typename Plat::LaneReg tile, AlnRes& res) {
+	                      int32_t escore, uint32_t row_, uint32_t col_, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi,
+	                      bool wide_, AlnRes& res) {
 		(void)escore;
 		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
 		const bool fw = Plat::uni((int)fw_) != 0;
+		const bool wide = Plat::uni((int)wide_) != 0;     // 16-bit cells (H | E<<16 in the low word, F in the high word), bias 0x7fff
 		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
 		uint32_t row = Plat::uni(row_), col = Plat::uni(col_);
 		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
@@ -812,7 +814,7 @@ struct Aligner {
 		uint32_t trim_beg = 0;
 		int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
 		Edit* ned = HOT.ned;
-		const int offsetsc = -0xff;
+		const int offsetsc = wide ? -0x7fff : -0xff;
 		HOT.n_bt_attempts++;
 		while ((int)row >= 0) {
 			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
@@ -821,7 +823,7 @@ struct Aligner {
 			bool empty = false, can_move_thru = true, branch = false;
 			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
 			prof.steps++;
-			if (td >= kBtTile) { const uint64_t tt_ = now(); tile = Plat::bt_tile(dpl, R, cols, row, col); td = 0; prof.tiles++; prof.tile_t += now() - tt_; }
+			if (td >= kBtTile) { const uint64_t tt_ = now(); Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi); td = 0; prof.tiles++; prof.tile_t += now() - tt_; }
 			const uint16_t mk0 = (uint16_t)Plat::lane(tile, 48 + td);
 			uint16_t mk = mk0;
 			const bool reported_thru = (mk0 & 1) != 0;
@@ -831,13 +833,15 @@ struct Aligner {
 				const uint32_t row_from_end = rows - row - 1;
 				const bool gaps_allowed = !(row < (uint32_t)S.gapbar || row_from_end < (uint32_t)S.gapbar);
 				// the four packed cells this step can look at (out-of-matrix entries of the tile are 0)
-				const uint32_t c_cur = Plat::lane(tile, td);
-				const uint32_t c_up = Plat::lane(tile, 16 + td);
-				const uint32_t c_left = Plat::lane(tile, 32 + td);
-				const uint32_t c_upleft = Plat::lane(tile, td + 1);
-				auto Hc = [](uint32_t c) -> int { return (int)(c & 0xff); };
-				auto Ec = [](uint32_t c) -> int { return (int)((c >> 8) & 0xff); };
-				auto Fc = [](uint32_t c) -> int { return (int)((c >> 16) & 0xff); };
+				// cells as 64-bit values: low word from `tile`, high word (16-bit mode only) from `tile_hi`
+				auto cell = [&](uint32_t ln) -> uint64_t { return (uint64_t)Plat::lane(tile, ln) | (wide ? (uint64_t)Plat::lane(tile_hi, ln) << 32 : 0ull); };
+				const uint64_t c_cur = cell(td);
+				const uint64_t c_up = cell(16 + td);
+				const uint64_t c_left = cell(32 + td);
+				const uint64_t c_upleft = cell(td + 1);
+				auto Hc = [&](uint64_t c) -> int { return wide ? (int)(int16_t)(uint16_t)(c & 0xffff) : (int)(c & 0xff); };
+				auto Ec = [&](uint64_t c) -> int { return wide ? (int)(int16_t)(uint16_t)((c >> 16) & 0xffff) : (int)((c >> 8) & 0xff); };
+				auto Fc = [&](uint64_t c) -> int { return wide ? (int)(int16_t)(uint16_t)((c >> 32) & 0xffff) : (int)((c >> 16) & 0xff); };
 				if (ct == 1) {          // E: came from the left
 					const int sc_cur = Ec(c_cur) + offsetsc;
 					int mask = 0;
@@ -1029,20 +1033,22 @@ struct Aligner {
 	}
 
 	// SwAligner::nextAlignment, end-to-end u8 branch (aligner_sw.cpp:737-1146)
-	BT2_HDN bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, AlnRes& res) {
+	BT2_HDN bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, bool wide, AlnRes& res) {
 		if (HOT.cural == HOT.n_cands) return false;
 		bool found = false;
 		while (HOT.cural < HOT.n_cands) {
 			const BtCand& c = w.cands[HOT.cural];
 			if (c.score < minsc) { HOT.cural++; continue; }
-			typename Plat::LaneReg tile;
-			{ const uint64_t tt_ = now(); tile = Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col); pf_tiles++; pf_tile_t += now() - tt_; }    // also the first tile of the backtrace
+			typename Plat::LaneReg tile, tile_hi;
+			{ const uint64_t tt_ = now(); Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col, wide, tile, tile_hi); pf_tiles++; pf_tile_t += now() - tt_; }    // also the first tile of the backtrace
 			if (Plat::lane(tile, 48) & 1) { HOT.cural++; continue; }
+			// reseeding protocol: 8-bit path init(reseed) ... init(reseed+1); 16-bit path only init(reseed) afterwards
+			// (aligner_sw.cpp:796-876 vs :877-933)
 			const uint32_t reseed = rnd.nextU32() + 1;
-			rnd.init(reseed);
+			if (!wide) rnd.init(reseed);
 			res.nned = 0;
-			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, c.score, c.row, c.col, tile, res);
-			rnd.init(reseed + 1);
+			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, c.score, c.row, c.col, tile, tile_hi, wide, res);
+			rnd.init(wide ? reseed : reseed + 1);
 			if (ret) { found = true; break; }
 			HOT.cural++;
 		}
@@ -1170,6 +1176,7 @@ struct Aligner {
 						ungapped = (read_gaps == 0 && ref_gaps == 0);
 					}
 					int state = 0;   // 0 none, 1 ee, 2 ungapped
+					bool wide = false;   // this DP used the 16-bit cells
 					bool found = false;
 					DPRect rect;
 					rect.refl = rect.refr = rect.refl_pretrim = rect.refr_pretrim = 0;
@@ -1228,17 +1235,15 @@ struct Aligner {
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
 						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { HOT.err |= ERR_OVERFLOW; return EXT_HARD_LIMIT; }
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
-						// SwAligner::align (aligner_sw.cpp:500-729), end-to-end 8-bit path; the reference switches to its
-						// 16-bit kernels when minsc < -254 (:517), which this build does not have: flag the read
-						if (minsc < -254) { HOT.err |= ERR_NEED_I16; return EXT_HARD_LIMIT; }
+						// SwAligner::align (aligner_sw.cpp:500-729): end-to-end 8-bit kernel while minsc >= -254, else 16-bit (:517)
+						wide = minsc < -254;
 						const uint64_t td_ = now();
 						fetch_ref_window(tidx, rect.refl, cols + 1);
-						const int best_u8 = Plat::dp_fill_ee_u8(P, w, fw, rows, cols, dp.mat);
+						const int64_t best = Plat::dp_fill_ee(P, w, fw, rows, cols, dp.mat, wide);
 						HOT.t_phase[5] += now() - td_;
-						const int64_t best = (int64_t)best_u8 - 0xff;
 						HOT.n_ex_dps++;
 						found = best >= minsc;
-						if (found) { const uint64_t tg_ = now(); gather_cells(rows, cols, minsc); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
+						if (found) { const uint64_t tg_ = now(); gather_cells(rows, cols, minsc, wide); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
 						if (!found) {
 							HOT.n_dp_fail++;
 							if (HOT.n_dp_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
@@ -1254,7 +1259,7 @@ struct Aligner {
 						} else {
 							if (HOT.cural == HOT.n_cands) break;
 							const uint64_t tb_ = now();
-							const bool na_ = next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, res);
+							const bool na_ = next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, wide, res);
 							HOT.t_phase[6] += now() - tb_;
 							if (!na_) break;
 						}

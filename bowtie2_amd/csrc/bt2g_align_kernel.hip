@@ -81,6 +81,73 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 	return __shfl(best, (int)((rows - 1) / R));
 }
 
+// The same recurrence in the reference's 16-bit representation (alignNucleotidesEnd2EndSseI16, aligner_swsse_ee_i16.cpp:780-1146):
+// scores biased by 0x7fff, -32768 = minus infinity, saturating subtraction, barrier rows veto gap opens/extensions.
+constexpr int kLo = -32768;
+__device__ __forceinline__ int subs16(int a, int b) { const int v = a - b; return v < kLo ? kLo : v; }
+
+template <int R>
+__device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, const Work& w, bool fw, uint32_t rows, uint32_t cols,
+                                               uint64_t* __restrict__ scratch) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t nlanes = (rows + R - 1) / R;
+	int rdc[R], mmp[R], veto[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const uint32_t i = (uint32_t)lane * R + r;
+		const bool valid = i < rows;
+		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
+		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
+		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 1 : 0;
+	}
+	int Hprev[R], Eprev[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) { Hprev[r] = kLo; Eprev[r] = kLo; }
+	int myHlast = kLo, myFlast = kLo, upHdiag = kLo, refm = 0, best = kLo;
+	const uint32_t steps = cols + nlanes - 1;
+	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
+	const int last_r = (int)((rows - 1) % R);
+	for (uint32_t t = 0; t < steps; t++) {
+		const int upH = __shfl_up(myHlast, 1);
+		const int upF = __shfl_up(myFlast, 1);
+		int upRef = __shfl_up(refm, 1);
+		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
+		refm = upRef;
+		const int j = (int)t - lane;
+		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
+		int refc = 4;
+		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
+		int hdiag = (lane == 0) ? 0x7fff : (j == 0 ? kLo : upHdiag);
+		int fin_h = upH, fin_f = upF;
+		int Hnew[R], Enew[R], Fnew[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			int pen;
+			if (rdc[r] > 3 || refc > 3) pen = P.n_pen; else pen = (rdc[r] == refc) ? -P.match_bonus : mmp[r];
+			const int e = (j == 0) ? kLo : imax(subs16(Eprev[r], P.rdgape), veto[r] ? kLo : subs16(Hprev[r], P.rdgapo));
+			int f;
+			if (lane == 0 && r == 0) f = kLo;
+			else f = veto[r] ? kLo : imax(subs16(fin_f, P.rfgape), subs16(fin_h, P.rfgapo));
+			const int h = imax(imax(subs16(hdiag, pen), e), f);
+			Hnew[r] = h; Enew[r] = e; Fnew[r] = f;
+			hdiag = Hprev[r];
+			fin_h = h; fin_f = f;
+		}
+		if (active) {
+			uint64_t* base = scratch + ((uint64_t)t * R) * 64 + lane;     // 512 contiguous bytes per store
+#pragma unroll
+			for (int r = 0; r < R; r++) base[r * 64] = (uint64_t)(uint16_t)Hnew[r] | ((uint64_t)(uint16_t)Enew[r] << 16) | ((uint64_t)(uint16_t)Fnew[r] << 32);
+#pragma unroll
+			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
+			if (lane_has_last) best = imax(best, Hnew[last_r]);
+		}
+		upHdiag = upH;
+		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
+	}
+	return __shfl(best, (int)((rows - 1) / R));
+}
+
 struct DevPlat {
 	static __device__ __forceinline__ HotWork& hot() { return g_hot; }
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
@@ -102,10 +169,15 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < n16; i += 64) q[i] = z;
 		wave_fence();
 	}
-	// H of the last DP row -> LDS
-	static __device__ __forceinline__ void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols) {
+	// scores of the last DP row -> LDS (clamped at -32768; only scores >= minsc matter afterwards)
+	static __device__ __forceinline__ void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols, bool wide) {
 		wave_fence();
-		for (uint32_t j = threadIdx.x & 63; j < cols; j += 64) g_hot.lastrow[j] = (uint8_t)(mat[dp_cell(R, rows - 1, j)] & 0xff);
+		for (uint32_t j = threadIdx.x & 63; j < cols; j += 64) {
+			int sc;
+			if (wide) sc = (int)(int16_t)(uint16_t)(reinterpret_cast<const uint64_t*>(mat)[dp_cell(R, rows - 1, j)] & 0xffff) - 0x7fff;
+			else sc = (int)(mat[dp_cell(R, rows - 1, j)] & 0xff) - 0xff;
+			g_hot.lastrow[j] = (int16_t)(sc < -32768 ? -32768 : sc);
+		}
 		wave_fence();
 	}
 	// AlnRes copy, one 32-bit word per lane per pass; only the header and the edits in use move
@@ -121,11 +193,11 @@ struct DevPlat {
 	// against the whole row (LDS broadcast reads) and writes them straight to their final slot.
 	static __device__ __forceinline__ uint32_t gather_sort(BtCand* cands, uint32_t cap, uint32_t rows, uint32_t cols, int64_t minsc_dp) {
 		const uint32_t lane = threadIdx.x & 63;
-		const int thr = (int)minsc_dp + 0xff;          // H byte >= thr  <=>  score >= minsc
+		const int thr = minsc_dp < -32768 ? -32768 : (int)minsc_dp;
 		uint32_t total = 0;
 		for (uint32_t base = 0; base < cols; base += 64) {
 			const uint32_t j = base + lane;
-			const int sc = j < cols ? (int)g_hot.lastrow[j] : -1;
+			const int sc = j < cols ? (int)g_hot.lastrow[j] : -65536;
 			const bool is = j < cols && sc >= thr;
 			if (__ballot(is) == 0ull) continue;
 			uint32_t rank = 0;
@@ -133,7 +205,7 @@ struct DevPlat {
 				const int s2 = (int)g_hot.lastrow[k];
 				if (s2 >= thr && (s2 > sc || (s2 == sc && k > j))) rank++;
 			}
-			if (is && rank < cap) { BtCand c; c.score = sc - 0xff; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)j; cands[rank] = c; }
+			if (is && rank < cap) { BtCand c; c.score = sc; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)j; cands[rank] = c; }
 			total += (uint32_t)__popcll(__ballot(is));
 		}
 		wave_fence();
@@ -149,17 +221,20 @@ struct DevPlat {
 	}
 	// Backtrace tile anchored at (row, col): lanes 0-15 cell(row-d, col-d), 16-31 cell(row-d-1, col-d),
 	// 32-47 cell(row-d, col-d-1), 48-63 mask(row-d, col-d); one load instruction per array, one latency.
-	static __device__ __forceinline__ LaneReg bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col) {
+	static __device__ __forceinline__ void bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col, bool wide,
+	                                               LaneReg& lo, LaneReg& hi) {
 		wave_fence();        // mask stores of earlier steps -> visible to whichever lane re-reads them
 		const uint32_t ln = threadIdx.x & 63, d = ln & 15, g = ln >> 4;
 		const int r = (int)row - (int)d - (g == 1 ? 1 : 0);
 		const int c = (int)col - (int)d - (g == 2 ? 1 : 0);
-		uint32_t v = 0;
+		uint32_t v = 0, vh = 0;
 		if (r >= 0 && c >= 0) {
-			if (g < 3) v = dp.mat[dp_cell(R, (uint32_t)r, (uint32_t)c)];
-			else v = dp.masks[(uint64_t)r * cols + (uint32_t)c];
+			if (g < 3) {
+				if (wide) { const uint64_t x = reinterpret_cast<const uint64_t*>(dp.mat)[dp_cell(R, (uint32_t)r, (uint32_t)c)]; v = (uint32_t)x; vh = (uint32_t)(x >> 32); }
+				else v = dp.mat[dp_cell(R, (uint32_t)r, (uint32_t)c)];
+			} else v = dp.masks[(uint64_t)r * cols + (uint32_t)c];
 		}
-		return v;
+		lo = v; hi = vh;
 	}
 	// reference window -> masks, one base per lane per pass (SwAligner::initRef, aligner_sw.cpp:155-271)
 	static __device__ __forceinline__ void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
@@ -167,21 +242,38 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
 		wave_fence();
 	}
-	static __device__ __attribute__((noinline)) int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat) {
+	// returns the best last-row score (de-biased)
+	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide) {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
 		int best;
-		switch (dp_R(rows)) {
-			case 1: best = fill_ee_u8_wave<1>(P, w, fw, rows, cols, mat); break;
-			case 2: best = fill_ee_u8_wave<2>(P, w, fw, rows, cols, mat); break;
-			case 3: best = fill_ee_u8_wave<3>(P, w, fw, rows, cols, mat); break;
-			case 4: best = fill_ee_u8_wave<4>(P, w, fw, rows, cols, mat); break;
-			case 5: best = fill_ee_u8_wave<5>(P, w, fw, rows, cols, mat); break;
-			case 6: best = fill_ee_u8_wave<6>(P, w, fw, rows, cols, mat); break;
-			case 7: best = fill_ee_u8_wave<7>(P, w, fw, rows, cols, mat); break;
-			default: best = fill_ee_u8_wave<8>(P, w, fw, rows, cols, mat); break;
+		if (!wide) {
+			switch (dp_R(rows)) {
+				case 1: best = fill_ee_u8_wave<1>(P, w, fw, rows, cols, mat); break;
+				case 2: best = fill_ee_u8_wave<2>(P, w, fw, rows, cols, mat); break;
+				case 3: best = fill_ee_u8_wave<3>(P, w, fw, rows, cols, mat); break;
+				case 4: best = fill_ee_u8_wave<4>(P, w, fw, rows, cols, mat); break;
+				case 5: best = fill_ee_u8_wave<5>(P, w, fw, rows, cols, mat); break;
+				case 6: best = fill_ee_u8_wave<6>(P, w, fw, rows, cols, mat); break;
+				case 7: best = fill_ee_u8_wave<7>(P, w, fw, rows, cols, mat); break;
+				default: best = fill_ee_u8_wave<8>(P, w, fw, rows, cols, mat); break;
+			}
+			best -= 0xff;
+		} else {
+			uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
+			switch (dp_R(rows)) {
+				case 1: best = fill_ee_i16_wave<1>(P, w, fw, rows, cols, m64); break;
+				case 2: best = fill_ee_i16_wave<2>(P, w, fw, rows, cols, m64); break;
+				case 3: best = fill_ee_i16_wave<3>(P, w, fw, rows, cols, m64); break;
+				case 4: best = fill_ee_i16_wave<4>(P, w, fw, rows, cols, m64); break;
+				case 5: best = fill_ee_i16_wave<5>(P, w, fw, rows, cols, m64); break;
+				case 6: best = fill_ee_i16_wave<6>(P, w, fw, rows, cols, m64); break;
+				case 7: best = fill_ee_i16_wave<7>(P, w, fw, rows, cols, m64); break;
+				default: best = fill_ee_i16_wave<8>(P, w, fw, rows, cols, m64); break;
+			}
+			best -= 0x7fff;
 		}
 		wave_fence();     // matrix written lane-parallel -> visible to the scalar backtrace
-		return best;
+		return (int64_t)best;
 	}
 };
 
@@ -259,7 +351,7 @@ void align_scratch_sizes(uint32_t max_len, uint64_t& mat_bytes, uint64_t& mask_b
 	const uint32_t R = dp_R(rows);
 	const uint32_t cols = rows + 4 * 15 + 1 + 4;
 	const uint32_t lanes = (rows + R - 1) / R;
-	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 4 + 255) & ~(uint64_t)255;
+	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 8 + 255) & ~(uint64_t)255;    // 8 B per cell: the 16-bit path packs H|E|F into 64 bits
 	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
 	const uint64_t rr = ((uint64_t)rows + 255) & ~(uint64_t)255;
 	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + mat_bytes + mask_bytes + rr;

@@ -152,7 +152,7 @@ int main(int argc, char** argv) {
 		for (size_t i = 0; i < n; i++) {
 			const ReadResult& rr = *(const ReadResult*)(h_res.data() + i * stride);
 			if (rr.status) n_flagged++;
-			if (rr.status) fprintf(stderr, "Warning: read %s: device status %d (bit 0 = work buffer overflow, bit 2 = needs the 16-bit DP: min score < -254)\n", reads[i].name.c_str(), (int)rr.status);
+			if (rr.status) fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", reads[i].name.c_str(), (int)rr.status);
 			summ.add(rr);
 			if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", reads[i].name.c_str(),
 			                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);

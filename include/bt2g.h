@@ -231,8 +231,7 @@ typedef struct {                   /* AlnRes (aligner_result.h:792), the fields 
 } bt2g_aln;
 
 typedef struct {
-	uint8_t  status;               /* 0 ok; bit 0 = a fixed-capacity work buffer overflowed; bit 2 = the read needs the
-	                                  16-bit DP (min score < -254, i.e. > 423 bp at the default --score-min): not aligned */
+	uint8_t  status;               /* 0 ok; bit 0 = a fixed-capacity work buffer overflowed (result not reference-identical) */
 	uint8_t  aligned, maxed, filt, exhausted, has_secbest, pad[2];
 	int32_t  secbest, best;        /* XS:i / MAPQ inputs                                      */
 	uint32_t nalns, nreport;

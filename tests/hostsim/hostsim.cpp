@@ -27,14 +27,19 @@ struct HostPlat {
 		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
 	}
 	static void zero_masks(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
-	static void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols) {
-		for (uint32_t j = 0; j < cols; j++) g_hot.lastrow[j] = (uint8_t)(mat[dp_cell(R, rows - 1, j)] & 0xff);
+	static void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols, bool wide) {
+		for (uint32_t j = 0; j < cols; j++) {
+			int sc;
+			if (wide) sc = (int)(int16_t)(uint16_t)(reinterpret_cast<const uint64_t*>(mat)[dp_cell(R, rows - 1, j)] & 0xffff) - 0x7fff;
+			else sc = (int)(mat[dp_cell(R, rows - 1, j)] & 0xff) - 0xff;
+			g_hot.lastrow[j] = (int16_t)(sc < -32768 ? -32768 : sc);
+		}
 	}
 	static void copy_aln(AlnRes& dst, const AlnRes& src) { memcpy(&dst, &src, offsetof(AlnRes, ned) + (size_t)src.nned * sizeof(Edit)); }
 	static uint32_t gather_sort(BtCand* cands, uint32_t cap, uint32_t rows, uint32_t cols, int64_t minsc_dp) {
 		uint32_t n = 0, total = 0;
 		for (uint32_t j = 0; j < cols; j++) {
-			const int sc = (int)g_hot.lastrow[j] - 0xff;
+			const int sc = (int)g_hot.lastrow[j];
 			if (sc < minsc_dp) continue;
 			total++;
 			if (n >= cap) continue;
@@ -57,45 +62,53 @@ struct HostPlat {
 		}
 		return r;
 	}
-	static LaneReg bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col) {
-		LaneReg t;
+	static void bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col, bool wide, LaneReg& lo, LaneReg& hi) {
 		for (uint32_t ln = 0; ln < 64; ln++) {
 			const uint32_t d = ln & 15, g = ln >> 4;
 			const int r = (int)row - (int)d - (g == 1 ? 1 : 0);
 			const int c = (int)col - (int)d - (g == 2 ? 1 : 0);
-			uint32_t v = 0;
-			if (r >= 0 && c >= 0) v = g < 3 ? dp.mat[dp_cell(R, (uint32_t)r, (uint32_t)c)] : (uint32_t)dp.masks[(uint64_t)r * cols + (uint32_t)c];
-			t.v[ln] = v;
+			uint32_t v = 0, vh = 0;
+			if (r >= 0 && c >= 0) {
+				if (g < 3) {
+					if (wide) { const uint64_t x = reinterpret_cast<const uint64_t*>(dp.mat)[dp_cell(R, (uint32_t)r, (uint32_t)c)]; v = (uint32_t)x; vh = (uint32_t)(x >> 32); }
+					else v = dp.mat[dp_cell(R, (uint32_t)r, (uint32_t)c)];
+				} else v = dp.masks[(uint64_t)r * cols + (uint32_t)c];
+			}
+			lo.v[ln] = v; hi.v[ln] = vh;
 		}
-		return t;
 	}
 	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
-	static int dp_fill_ee_u8(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat) {
+	// scalar fill of either representation; returns the best last-row score (de-biased)
+	static int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide) {
 		const uint32_t R = dp_R(rows);
-		int lrmax = 0;
-		std::vector<int> Hp(rows, 0), Ep(rows, 0), Hc(rows), Ec(rows), Fc(rows);
+		const int lo = wide ? -32768 : 0, hi = wide ? 0x7fff : 0xff;
+		auto subs = [&](int a, int b) { const int v = a - b; return v < lo ? lo : v; };
+		int lrmax = lo;
+		std::vector<int> Hp(rows, lo), Ep(rows, lo), Hc(rows), Ec(rows), Fc(rows);
+		uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
 		for (uint32_t j = 0; j < cols; j++) {
 			const int m = g_hot.rf[j];
 			int refc = 4;
 			for (int b = 0; b < 4; b++) if (m & (1 << b)) { refc = b; break; }
-			int f = 0;
+			int f = lo;
 			for (uint32_t i = 0; i < rows; i++) {
-				const int veto = ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar) ? 0xff : 0;
+				const bool veto = ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar);
 				const int rdc = rd_char(g_hot, g_hot.len, fw, i);
 				const int q = rd_qual(g_hot, g_hot.len, fw, i) - 33;
 				int pen;
 				if (rdc > 3 || refc > 3) pen = P.n_pen; else pen = (rdc == refc) ? -P.match_bonus : mm_penalty(P, q < 0 ? 0 : q);
-				const int hdiag = (i == 0) ? 0xff : (j == 0 ? 0 : Hp[i - 1]);
-				const int e = (j == 0) ? 0 : imax(subs0(Ep[i], P.rdgape), subs0(subs0(Hp[i], P.rdgapo), veto));
-				f = (i == 0) ? 0 : subs0(imax(subs0(f, P.rfgape), subs0(Hc[i - 1], P.rfgapo)), veto);
-				const int h = imax(imax(subs0(hdiag, pen), e), f);
+				const int hdiag = (i == 0) ? hi : (j == 0 ? lo : Hp[i - 1]);
+				const int e = (j == 0) ? lo : imax(subs(Ep[i], P.rdgape), veto ? lo : subs(Hp[i], P.rdgapo));
+				f = (i == 0) ? lo : (veto ? lo : imax(subs(f, P.rfgape), subs(Hc[i - 1], P.rfgapo)));
+				const int h = imax(imax(subs(hdiag, pen), e), f);
 				Hc[i] = h; Ec[i] = e; Fc[i] = f;
-				mat[dp_cell(R, i, j)] = (uint32_t)h | ((uint32_t)e << 8) | ((uint32_t)f << 16);
+				if (wide) m64[dp_cell(R, i, j)] = (uint64_t)(uint16_t)h | ((uint64_t)(uint16_t)e << 16) | ((uint64_t)(uint16_t)f << 32);
+				else mat[dp_cell(R, i, j)] = (uint32_t)h | ((uint32_t)e << 8) | ((uint32_t)f << 16);
 			}
 			if (Hc[rows - 1] > lrmax) lrmax = Hc[rows - 1];
 			Hp.swap(Hc); Ep.swap(Ec);
 		}
-		return lrmax;
+		return (int64_t)lrmax - hi;
 	}
 };
 
@@ -136,7 +149,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	if (!fq.ok()) { fprintf(stderr, "cannot open %s\n", opt.reads_file.c_str()); return 1; }
 	Work* w = new Work();
 	DpScratch dp;
-	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 4;
+	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 8;
 	dp.mat = (uint32_t*)malloc(mat_bytes);
 	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
 	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(opt.khits + 1));

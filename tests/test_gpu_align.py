@@ -86,6 +86,32 @@ def test_differential_vs_reference_binary(large):
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 @pytest.mark.parametrize("large", [False, True], ids=["bt2", "bt2l"])
+def test_long_reads_16bit_dp(large):
+    """Reads of 300-512 bp: above 423 bp the default --score-min drops below -254 and the reference switches to its
+    16-bit DP kernels (aligner_sw.cpp:517), with a different RNG reseeding protocol in nextAlignment."""
+    d = os.path.join(CACHE_DIR, "long_%s" % ("l" if large else "s"))
+    os.makedirs(d, exist_ok=True)
+    refs, _ = repeat_genome()
+    reads = (synth_reads(refs, 300, 500, seed=11, sub=0.02, ins=0.002, dele=0.002) + synth_reads(refs, 300, 460, seed=12, sub=0.04, ins=0.004, dele=0.004)
+             + synth_reads(refs, 200, 430, seed=13, sub=0.01, len_jitter=80) + synth_reads(refs, 100, 500, seed=14, sub=0.08)
+             + synth_reads(refs, 100, 424, seed=15, n_rate=0.01))
+    fa, fq, base = os.path.join(d, "rep.fa"), os.path.join(d, "long.fq"), os.path.join(d, "rep")
+    write_fasta(fa, refs)
+    write_fastq(fq, reads)
+    build_index(fa, base, large)
+    ref_exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
+    for args in (["--sensitive"], ["--very-sensitive"], ["-k", "3"]):
+        rs = os.path.join(d, "ref.sam")
+        subprocess.check_call([ref_exe] + args + ["-x", base, "-U", fq, "-p", "8", "--reorder", "-S", rs], stderr=subprocess.DEVNULL)
+        want = [l.rstrip("\n") for l in open(rs) if not l.startswith("@PG")]
+        got, err = run_ours(args + ["-x", base, "-U", fq])
+        assert "Warning" not in err
+        bad = [i for i in range(len(got)) if got[i] != want[i]]
+        assert len(got) == len(want) and not bad, (args, len(bad), want[bad[0]][:300], got[bad[0]][:300])
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("large", [False, True], ids=["bt2", "bt2l"])
 def test_run_to_run_determinism(large):
     """The per-read work counters (BW ops, extension lengths, DP/backtrace counts) must be identical
     across repeated runs -- a wave-level race would show up here long before it changes a SAM line."""
