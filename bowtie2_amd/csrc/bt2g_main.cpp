@@ -16,6 +16,7 @@
 
 #include "../../include/bt2g.h"
 #include "bt2g_host.hpp"
+#include "bt2g_pipeline.hpp"
 
 using namespace bt2g;
 
@@ -40,7 +41,7 @@ int main(int argc, char** argv) {
 	int device = 0;
 	bool metrics = false;
 	unsigned long long n_flagged = 0;
-	size_t batch_reads = 1u << 20;
+	size_t batch_reads = 1u << 18;
 	for (int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
 		auto need = [&](const char* what) -> std::string { if (i + 1 >= argc) die(std::string(what) + " needs an argument"); return argv[++i]; };
@@ -103,68 +104,74 @@ int main(int argc, char** argv) {
 	opt.to_params(P, info.off_size == 8);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)P.khits);
 
-	FastqReader fq(opt.reads_file);
+	// -p: host threads for FASTQ parsing and SAM formatting (the alignment itself is on the device)
+	const unsigned host_threads = opt.threads > 0 ? (unsigned)opt.threads : 1u;
+	FastqBatcher fq(opt.reads_file, opt, host_threads);
 	if (!fq.ok()) die("cannot open reads file " + opt.reads_file);
-	DevBuf d_seq, d_qual, d_off, d_rp, d_res;
-	std::vector<ReadRec> reads;
-	std::vector<uint8_t> h_seq, h_qual, h_res;
-	std::vector<uint64_t> h_off;
-	std::vector<ReadParams> h_rp;
 	AlnSummary summ;
-	uint64_t rdid = 0;
 	double align_s = 0;
-	bool eof = false;
-	while (!eof) {
-		reads.clear(); h_seq.clear(); h_qual.clear(); h_off.clear(); h_rp.clear();
-		h_off.push_back(0);
-		uint32_t max_len = 0;
-		while (reads.size() < batch_reads) {
-			ReadRec r;
-			if (!fq.next(r, rdid)) { eof = true; break; }
-			if (rdid >= opt.upto) { eof = true; break; }
-			if (rdid++ < opt.skip) continue;
-			if (r.seq.size() > (size_t)BT2G_MAX_READ_LEN) die("read " + r.name + " is longer than " + std::to_string(BT2G_MAX_READ_LEN) + " bp (not supported on the device path)");
-			h_rp.push_back(compute_read_params(opt, r));
-			h_seq.insert(h_seq.end(), r.seq.begin(), r.seq.end());
-			h_qual.insert(h_qual.end(), r.qual.begin(), r.qual.end());
-			h_off.push_back(h_seq.size());
-			if (r.seq.size() > max_len) max_len = (uint32_t)r.seq.size();
-			reads.push_back(std::move(r));
+	typedef std::unique_ptr<HostBatch> BatchPtr;
+	BoundedQueue<BatchPtr> q_in(2), q_out(2);
+
+	std::thread reader([&]() {
+		for (;;) {
+			BatchPtr b(new HostBatch());
+			fq.next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
+			const bool last = b->last;
+			q_in.push(std::move(b));
+			if (last) break;
 		}
-		const size_t n = reads.size();
-		if (n == 0) break;
-		d_seq.ensure(h_seq.size() + 16); d_qual.ensure(h_qual.size() + 16);
-		d_off.ensure(h_off.size() * 8); d_rp.ensure(n * sizeof(ReadParams)); d_res.ensure(n * stride);
-		HIP_OK(hipMemcpy(d_seq.p, h_seq.data(), h_seq.size(), hipMemcpyHostToDevice));
-		HIP_OK(hipMemcpy(d_qual.p, h_qual.data(), h_qual.size(), hipMemcpyHostToDevice));
-		HIP_OK(hipMemcpy(d_off.p, h_off.data(), h_off.size() * 8, hipMemcpyHostToDevice));
-		HIP_OK(hipMemcpy(d_rp.p, h_rp.data(), n * sizeof(ReadParams), hipMemcpyHostToDevice));
-		bt2g_reads rd;
-		rd.d_seq = (const uint8_t*)d_seq.p; rd.d_qual = (const uint8_t*)d_qual.p; rd.d_off = (const uint64_t*)d_off.p; rd.n_reads = (uint32_t)n;
-		auto ta = std::chrono::steady_clock::now();
-		rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &P, max_len, d_res.p, nullptr);
-		if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
-		HIP_OK(hipDeviceSynchronize());
-		align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
-		h_res.resize(n * stride);
-		HIP_OK(hipMemcpy(h_res.data(), d_res.p, n * stride, hipMemcpyDeviceToHost));
-		o.clear();
-		for (size_t i = 0; i < n; i++) {
-			const ReadResult& rr = *(const ReadResult*)(h_res.data() + i * stride);
-			if (rr.status) n_flagged++;
-			if (rr.status) fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", reads[i].name.c_str(), (int)rr.status);
-			summ.add(rr);
-			if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", reads[i].name.c_str(),
-			                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
-#ifdef BT2G_DEBUG_SATPOS
-			{ const uint32_t* dbg = (const uint32_t*)rr.alns[0].ned; fprintf(stderr, "DBG\t%s", reads[i].name.c_str()); for (uint32_t k = 0; k < 1 + dbg[0] * 6 && k < 290; k++) fprintf(stderr, " %u", dbg[k]); fprintf(stderr, "\n"); }
-#endif
-			if (rr.aligned) { for (uint32_t k = 0; k < rr.nreport; k++) sam_record(o, opt, ref, reads[i], rr, &rr.alns[k], k == 0); }
-			else sam_record(o, opt, ref, reads[i], rr, nullptr, true);
-			if (o.size() > (1u << 24)) { fwrite(o.data(), 1, o.size(), out); o.clear(); }
+	});
+	std::thread writer([&]() {
+		std::vector<std::string> parts;
+		for (;;) {
+			BatchPtr b = q_out.pop();
+			const size_t n = b->reads.size();
+			for (size_t i = 0; i < n; i++) {
+				const ReadResult& rr = *(const ReadResult*)(b->res.data() + i * b->stride);
+				if (rr.status) {
+					n_flagged++;
+					fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", b->reads[i].name.c_str(), (int)rr.status);
+				}
+				summ.add(rr);
+				if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", b->reads[i].name.c_str(),
+				                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
+			}
+			format_batch(*b, opt, ref, host_threads, parts);
+			for (const std::string& part : parts) fwrite(part.data(), 1, part.size(), out);
+			if (b->last) break;
 		}
-		fwrite(o.data(), 1, o.size(), out);
+	});
+
+	DevBuf d_seq, d_qual, d_off, d_rp, d_res;
+	for (;;) {
+		BatchPtr b = q_in.pop();
+		if (!b->too_long.empty()) die("read " + b->too_long + " is longer than " + std::to_string(BT2G_MAX_READ_LEN) + " bp (not supported on the device path)");
+		const size_t n = b->reads.size();
+		b->stride = stride;
+		if (n > 0) {
+			d_seq.ensure(b->seq.size() + 16); d_qual.ensure(b->qual.size() + 16);
+			d_off.ensure(b->off.size() * 8); d_rp.ensure(n * sizeof(ReadParams)); d_res.ensure(n * stride);
+			HIP_OK(hipMemcpy(d_seq.p, b->seq.data(), b->seq.size(), hipMemcpyHostToDevice));
+			HIP_OK(hipMemcpy(d_qual.p, b->qual.data(), b->qual.size(), hipMemcpyHostToDevice));
+			HIP_OK(hipMemcpy(d_off.p, b->off.data(), b->off.size() * 8, hipMemcpyHostToDevice));
+			HIP_OK(hipMemcpy(d_rp.p, b->rp.data(), n * sizeof(ReadParams), hipMemcpyHostToDevice));
+			bt2g_reads rd;
+			rd.d_seq = (const uint8_t*)d_seq.p; rd.d_qual = (const uint8_t*)d_qual.p; rd.d_off = (const uint64_t*)d_off.p; rd.n_reads = (uint32_t)n;
+			auto ta = std::chrono::steady_clock::now();
+			rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &P, b->max_len, d_res.p, nullptr);
+			if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
+			HIP_OK(hipDeviceSynchronize());
+			align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+			b->res.resize(n * stride);
+			HIP_OK(hipMemcpy(b->res.data(), d_res.p, n * stride, hipMemcpyDeviceToHost));
+		}
+		const bool last = b->last;
+		q_out.push(std::move(b));
+		if (last) break;
 	}
+	reader.join();
+	writer.join();
 	if (out != stdout) fclose(out);
 	if (opt.timing) {
 		auto hms = [](double s) { char b[64]; int h = (int)(s / 3600); int m = (int)(s / 60) % 60; int sec = (int)s % 60; snprintf(b, sizeof b, "%02d:%02d:%02d", h, m, sec); return std::string(b); };

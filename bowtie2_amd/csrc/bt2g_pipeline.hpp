@@ -1,0 +1,243 @@
+// bt2g_pipeline.hpp -- host side of the drop-in binary: read ingest and SAM output as a three-stage
+// pipeline around the device batch.
+//
+//   stage 1  reader thread   gz/plain FASTQ -> raw records (memchr line splitting), then a parallel pass that
+//                            builds ReadRec + per-read parameters and packs the device arrays
+//   stage 2  caller's thread H2D, bt2g_align_batch, D2H
+//   stage 3  writer thread   parallel SAM formatting per chunk, ordered write, alignment summary
+//
+// Batches flow through bounded queues, so parsing batch i+1 and formatting batch i-1 overlap the device
+// work on batch i.  Output order is input order regardless of -p (always a valid answer to --reorder).
+#ifndef BT2G_PIPELINE_HPP_
+#define BT2G_PIPELINE_HPP_
+
+#include <zlib.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bt2g_host.hpp"
+
+namespace bt2g {
+
+// cores this process may actually use: min(affinity mask, cgroup cpu.max quota)
+inline unsigned usable_cores() {
+	unsigned n = std::thread::hardware_concurrency();
+	if (n == 0) n = 1;
+	std::ifstream f("/sys/fs/cgroup/cpu.max");
+	std::string quota, period;
+	if (f >> quota >> period) {
+		if (quota != "max") {
+			const double q = atof(quota.c_str()), p = atof(period.c_str());
+			if (q > 0 && p > 0) { const unsigned c = (unsigned)(q / p + 0.5); if (c >= 1 && c < n) n = c; }
+		}
+	}
+	return n;
+}
+
+// run fn(chunk_index) for chunk_index in [0, nchunks) on up to `threads` threads
+inline void parallel_for(size_t nchunks, unsigned threads, const std::function<void(size_t)>& fn) {
+	if (threads <= 1 || nchunks <= 1) { for (size_t i = 0; i < nchunks; i++) fn(i); return; }
+	std::mutex m;
+	size_t next = 0;
+	auto body = [&]() {
+		for (;;) {
+			size_t i;
+			{ std::lock_guard<std::mutex> g(m); if (next >= nchunks) return; i = next++; }
+			fn(i);
+		}
+	};
+	std::vector<std::thread> pool;
+	const unsigned nt = (unsigned)std::min<size_t>(threads, nchunks);
+	for (unsigned t = 1; t < nt; t++) pool.emplace_back(body);
+	body();
+	for (auto& t : pool) t.join();
+}
+
+template <typename T>
+class BoundedQueue {
+public:
+	explicit BoundedQueue(size_t cap) : cap_(cap) {}
+	void push(T v) {
+		std::unique_lock<std::mutex> l(m_);
+		not_full_.wait(l, [&] { return q_.size() < cap_; });
+		q_.push_back(std::move(v));
+		not_empty_.notify_one();
+	}
+	T pop() {
+		std::unique_lock<std::mutex> l(m_);
+		not_empty_.wait(l, [&] { return !q_.empty(); });
+		T v = std::move(q_.front());
+		q_.pop_front();
+		not_full_.notify_one();
+		return v;
+	}
+private:
+	size_t cap_;
+	std::mutex m_;
+	std::condition_variable not_full_, not_empty_;
+	std::deque<T> q_;
+};
+
+// One batch travelling through the pipeline
+struct HostBatch {
+	std::vector<ReadRec> reads;
+	std::vector<uint8_t> seq, qual;       // packed device arrays
+	std::vector<uint64_t> off;
+	std::vector<ReadParams> rp;
+	uint32_t max_len = 0;
+	std::vector<uint8_t> res;             // result records, filled by stage 2
+	uint64_t stride = 0;
+	std::string too_long;                 // name of a read over the length limit (fatal), if any
+	bool last = false;                    // end-of-input marker (may still carry reads)
+};
+
+// Line-oriented reader over gz or plain input (gzread handles both)
+class LineSource {
+public:
+	explicit LineSource(const std::string& path) {
+		f_ = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+		if (f_) gzbuffer(f_, 1 << 20);
+	}
+	~LineSource() { if (f_) gzclose(f_); }
+	bool ok() const { return f_ != nullptr; }
+	// next line without its terminator ('\n' or "\r\n"); false at end of input.  The view is valid until the next call.
+	bool next(const char*& p, size_t& n) {
+		for (;;) {
+			const char* base = buf_.data() + pos_;
+			const size_t avail = buf_.size() - pos_;
+			const char* nl = avail ? (const char*)memchr(base, '\n', avail) : nullptr;
+			if (nl) {
+				p = base; n = (size_t)(nl - base);
+				pos_ += n + 1;
+				if (n && p[n - 1] == '\r') n--;
+				return true;
+			}
+			if (eof_) {
+				if (avail == 0) return false;
+				p = base; n = avail; pos_ = buf_.size();
+				if (n && p[n - 1] == '\r') n--;
+				return true;
+			}
+			refill();
+		}
+	}
+private:
+	void refill() {
+		if (pos_ > 0) { buf_.erase(0, pos_); pos_ = 0; }
+		const size_t old = buf_.size(), want = 8u << 20;
+		buf_.resize(old + want);
+		const int got = gzread(f_, &buf_[old], (unsigned)want);
+		buf_.resize(old + (got > 0 ? (size_t)got : 0));
+		if (got <= 0) eof_ = true;
+	}
+	gzFile f_ = nullptr;
+	std::string buf_;
+	size_t pos_ = 0;
+	bool eof_ = false;
+};
+
+// FASTQ records following FastqPatternSource::parse (pat.cpp): 4-line records, '.' -> N, non-letters dropped
+class FastqBatcher {
+public:
+	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(path), opt_(opt), threads_(threads) {}
+	bool ok() const { return src_.ok(); }
+
+	// Fill `b` with up to max_reads reads; sets b.last at end of input (or at -u).
+	void next(HostBatch& b, size_t max_reads, size_t max_read_len) {
+		// ---- serial part: split the text into records (three line copies per record into one arena)
+		arena_.clear(); recs_.clear();
+		while (recs_.size() < max_reads) {
+			const char* p; size_t n;
+			bool got;
+			do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
+			if (!got || p[0] != '@') { b.last = true; break; }
+			if (rdid_ >= opt_.upto) { b.last = true; break; }
+			Raw r;
+			r.rdid = rdid_;
+			r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
+			if (!src_.next(p, n)) { b.last = true; break; }
+			r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
+			if (!src_.next(p, n)) { b.last = true; break; }            // '+' line
+			if (!src_.next(p, n)) { b.last = true; break; }
+			r.qual_off = arena_.size(); r.qual_len = n; arena_.append(p, n);
+			if (rdid_++ < opt_.skip) continue;
+			recs_.push_back(r);
+		}
+		// ---- parallel part: records -> ReadRec + per-read parameters
+		const size_t nrec = recs_.size();
+		b.reads.assign(nrec, ReadRec());
+		b.rp.resize(nrec);
+		const size_t chunk = 4096, nchunks = (nrec + chunk - 1) / chunk;
+		parallel_for(nchunks, threads_, [&](size_t c) {
+			const size_t e = std::min(nrec, (c + 1) * chunk);
+			for (size_t i = c * chunk; i < e; i++) {
+				const Raw& r = recs_[i];
+				ReadRec& rd = b.reads[i];
+				rd.name.assign(arena_.data() + r.name_off, r.name_len);
+				rd.seq.reserve(r.seq_len);
+				const char* s = arena_.data() + r.seq_off;
+				for (size_t k = 0; k < r.seq_len; k++) { char ch = s[k]; if (ch == '.') ch = 'N'; if (isalpha((unsigned char)ch)) rd.seq.push_back((char)asc2code(ch)); }
+				rd.qual.assign(arena_.data() + r.qual_off, r.qual_len);
+				if (rd.qual.size() > rd.seq.size()) rd.qual.resize(rd.seq.size());   // the reference errors out; we are lenient
+				while (rd.qual.size() < rd.seq.size()) rd.qual.push_back('I');
+				if (rd.name.empty()) rd.name = std::to_string(r.rdid);
+				b.rp[i] = compute_read_params(opt_, rd);
+			}
+		});
+		// ---- pack the device arrays
+		b.off.resize(nrec + 1);
+		b.off[0] = 0;
+		b.max_len = 0;
+		for (size_t i = 0; i < nrec; i++) {
+			const size_t L = b.reads[i].seq.size();
+			if (L > max_read_len && b.too_long.empty()) b.too_long = b.reads[i].name;
+			if (L > b.max_len) b.max_len = (uint32_t)L;
+			b.off[i + 1] = b.off[i] + L;
+		}
+		b.seq.resize(b.off[nrec]); b.qual.resize(b.off[nrec]);
+		parallel_for(nchunks, threads_, [&](size_t c) {
+			const size_t e = std::min(nrec, (c + 1) * chunk);
+			for (size_t i = c * chunk; i < e; i++) {
+				const ReadRec& rd = b.reads[i];
+				if (!rd.seq.empty()) { memcpy(&b.seq[b.off[i]], rd.seq.data(), rd.seq.size()); memcpy(&b.qual[b.off[i]], rd.qual.data(), rd.qual.size()); }
+			}
+		});
+	}
+private:
+	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; };
+	LineSource src_;
+	const Options& opt_;
+	unsigned threads_;
+	std::string arena_;
+	std::vector<Raw> recs_;
+	uint64_t rdid_ = 0;
+};
+
+// SAM text of one batch, formatted in parallel chunks and concatenated in read order into `out`
+inline void format_batch(const HostBatch& b, const Options& opt, const RefInfo& ref, unsigned threads, std::vector<std::string>& parts) {
+	const size_t n = b.reads.size(), chunk = 2048, nchunks = (n + chunk - 1) / chunk;
+	parts.assign(nchunks, std::string());
+	parallel_for(nchunks, threads, [&](size_t c) {
+		std::string& o = parts[c];
+		o.reserve(chunk * 400);
+		const size_t e = std::min(n, (c + 1) * chunk);
+		for (size_t i = c * chunk; i < e; i++) {
+			const ReadResult& rr = *(const ReadResult*)(b.res.data() + i * b.stride);
+			if (rr.aligned) { for (uint32_t k = 0; k < rr.nreport; k++) sam_record(o, opt, ref, b.reads[i], rr, &rr.alns[k], k == 0); }
+			else sam_record(o, opt, ref, b.reads[i], rr, nullptr, true);
+		}
+	});
+}
+
+} // namespace bt2g
+#endif
