@@ -422,7 +422,7 @@ struct Aligner {
 	                       uint32_t& nlex, uint32_t& nrex) {
 		FmCount cnt; cnt.bwops = 0; cnt.sides = 0;
 		HotRd rd;
-		fm_extend_hit(ix, rd, HOT.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt);
+		fm_extend_hit(ix, rd, HOT.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt, (P.do_extend & 2) == 0);
 		HOT.n_bwops_ext += cnt.bwops; HOT.n_sides += cnt.sides;
 	}
 

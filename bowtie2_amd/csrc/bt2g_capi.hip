@@ -369,8 +369,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		pre.seeds = d_seeds;
 		mark(3);
 		if (params->do_extend) {
-			e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, d_seeds, d_ext, c->d_cnt, st)
-			      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, d_seeds, d_ext, c->d_cnt, st);
+			e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, c->d_cnt, st)
+			      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, c->d_cnt, st);
 			if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits");
 			pre.ext = d_ext;
 		}

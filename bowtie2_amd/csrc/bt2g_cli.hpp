@@ -1,0 +1,127 @@
+// bt2g_cli.hpp -- command-line options of bowtie2-align-{s,l} that this build implements (bt2_search.cpp:1040-1620).
+// Shared by the drop-in binary and by the host-compiled test harness so both parse argv the same way.  Anything
+// outside the implemented path is refused with a message (never silently approximated).
+#ifndef BT2G_CLI_HPP_
+#define BT2G_CLI_HPP_
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "bt2g_host.hpp"
+
+namespace bt2g {
+
+struct CliExtra {
+	int device = 0;
+	bool metrics = false;          // --met: per-read work counters on stderr (test aid)
+	bool arg_desc = false;         // --arg-desc
+	size_t batch_reads = 1u << 18;
+};
+
+inline bool split_ints(const std::string& s, char sep, std::vector<int>& out) {
+	out.clear();
+	size_t p = 0;
+	while (p <= s.size()) {
+		size_t q = s.find(sep, p);
+		if (q == std::string::npos) q = s.size();
+		if (q == p) return false;
+		char* end = nullptr;
+		const std::string t = s.substr(p, q - p);
+		const long v = strtol(t.c_str(), &end, 10);
+		if (*end) return false;
+		out.push_back((int)v);
+		p = q + 1;
+	}
+	return !out.empty();
+}
+
+// Returns "" on success, else the error text (exit code 1).
+inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) {
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		std::string inline_val;
+		bool has_inline = false;
+		if (a.size() > 2 && a[0] == '-' && a[1] == '-') {           // --opt=value
+			const size_t eq = a.find('=');
+			if (eq != std::string::npos) { inline_val = a.substr(eq + 1); a = a.substr(0, eq); has_inline = true; }
+		}
+		std::string err;
+		auto need = [&]() -> std::string {
+			if (has_inline) return inline_val;
+			if (i + 1 >= argc) { err = a + " needs an argument"; return ""; }
+			return argv[++i];
+		};
+		std::vector<int> iv;
+		if (a == "--wrapper") { need(); }
+		else if (a == "--arg-desc") ex.arg_desc = true;
+		else if (a == "-x") opt.index_base = need();
+		else if (a == "-U") opt.reads_file = need();
+		else if (a == "-S" || a == "--output") opt.out_file = need();
+		else if (a == "-q") opt.format = 0;
+		else if (a == "-f") opt.format = 1;
+		else if (a == "-r") opt.format = 2;
+		else if (a == "-p" || a == "--threads") opt.threads = atoi(need().c_str());
+		else if (a == "--reorder") opt.reorder = true;
+		else if (a == "-t" || a == "--time") opt.timing = true;
+		else if (a == "--quiet") opt.quiet = true;
+		else if (a == "-k") { opt.khits = atoi(need().c_str()); opt.saw_k = true; if (opt.khits < 1) err = "-k arg must be at least 1"; }
+		else if (a == "-M") { opt.mhits = atoi(need().c_str()); opt.saw_k = false; opt.khits = 1; fprintf(stderr, "Warning: -M is deprecated.  Use -D and -R to adjust effort instead.\n"); }
+		else if (a == "-s" || a == "--skip") opt.skip = strtoull(need().c_str(), nullptr, 10);
+		else if (a == "-u" || a == "--upto" || a == "--qupto") { opt.upto = strtoull(need().c_str(), nullptr, 10); if (opt.upto == 0) opt.upto = UINT64_MAX; }
+		else if (a == "-5" || a == "--trim5") opt.trim5 = atoi(need().c_str());
+		else if (a == "-3" || a == "--trim3") opt.trim3 = atoi(need().c_str());
+		else if (a == "--phred33" || a == "--phred33-quals") opt.phred64 = false;
+		else if (a == "--phred64" || a == "--phred64-quals") opt.phred64 = true;
+		else if (a == "--seed") opt.seed = (uint32_t)strtoul(need().c_str(), nullptr, 10);
+		else if (a == "--nofw") opt.nofw = true;
+		else if (a == "--norc") opt.norc = true;
+		else if (a == "--end-to-end") {}
+		else if (a == "--ignore-quals") opt.ignore_quals = true;
+		else if (a == "--qc-filter") opt.qc_filter = true;
+		else if (a == "--no-1mm-upfront") opt.no_1mm_upfront = true;
+		else if (a == "--no-unal") opt.no_unal = true;
+		else if (a == "--xeq") opt.xeq = true;
+		else if (a == "--omit-sec-seq" || a == "--sam-omit-sec-seq") opt.omit_sec_seq = true;
+		else if (a == "--no-hd" || a == "--no-head" || a == "--sam-no-hd" || a == "--sam-nohead" || a == "--sam-no-head" || a == "--sam-noHD" || a == "--no-HD") opt.sam_no_hd = true;
+		else if (a == "--no-sq" || a == "--sam-no-sq" || a == "--sam-nosq" || a == "--sam-noSQ" || a == "--no-SQ") opt.sam_no_sq = true;
+		else if (a == "--rg-id" || a == "--sam-rg-id") { const std::string v = need(); opt.rg_id = "\tID:" + v; opt.rg_optflag = "RG:Z:" + v; }
+		else if (a == "--rg" || a == "--sam-rg" || a == "--sam-RG" || a == "--RG") {
+			const std::string v = need();
+			if (v.substr(0, 3) == "ID:") { opt.rg_id = "\t" + v; opt.rg_optflag = "RG:Z:" + v.substr(3); } else { opt.rgs += "\t" + v; }
+		}
+		else if (a == "--gpu") ex.device = atoi(need().c_str());
+		else if (a == "--met") ex.metrics = true;
+		else if (a == "--batch") ex.batch_reads = strtoull(need().c_str(), nullptr, 10);
+		else if (a == "-D") opt.max_dp_streak = atoi(need().c_str());
+		else if (a == "-R") opt.n_seed_rounds = atoi(need().c_str());
+		else if (a == "-L") { opt.seed_len = atoi(need().c_str()); if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }
+		else if (a == "-N") { if (atoi(need().c_str()) != 0) err = "-N 1 is outside the MI355X hot path implemented so far"; }
+		else if (a == "-i") { if (!opt.ms_ival.parse(need())) err = "bad -i function"; }
+		else if (a == "--score-min" || a == "--min-score") { if (!opt.score_min.parse(need())) err = "bad --score-min function"; }
+		else if (a == "--n-ceil") { if (!opt.n_ceil.parse(need())) err = "bad --n-ceil function"; }
+		else if (a == "--dpad") opt.maxhalf = atoi(need().c_str());
+		else if (a == "--gbar") { opt.gbar = atoi(need().c_str()); if (opt.gbar < 1) err = "--gbar must be no less than 1"; }
+		else if (a == "--ma") { if (atoi(need().c_str()) != 0) fprintf(stderr, "Warning: Match bonus always = 0 in --end-to-end mode; ignoring user setting\n"); }
+		else if (a == "--mp") {
+			if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "expected 1 or 2 comma-separated arguments to --mp";
+			else { opt.mp_max = iv[0]; opt.mp_min = iv.size() > 1 ? iv[1] : 2; if (opt.mp_min > opt.mp_max) err = "Maximum mismatch penalty is less than minimum penalty"; }
+		}
+		else if (a == "--np") opt.np = atoi(need().c_str());
+		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; if (iv.size() > 1) opt.rdg_linear = iv[1]; } }
+		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
+		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
+		else if (a == "-1" || a == "-2" || a == "--local" || a == "-c" || a == "-b" || a == "--interleaved" || a == "-a" || a == "--all" ||
+		         a == "--tab5" || a == "--tab6" || a == "--qseq" || a == "-F" || a == "--int-quals" || a == "--solexa-quals" || a == "--trim-to" ||
+		         a == "-I" || a == "-X" || a == "--minins" || a == "--maxins" || a == "--very-fast-local" || a == "--fast-local" ||
+		         a == "--sensitive-local" || a == "--very-sensitive-local")
+			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, end-to-end, -N 0, -k <= 64)";
+		else return "unsupported option " + a;
+		if (!err.empty()) return err;
+	}
+	if (opt.khits > 64) return "-k above 64 is not supported by this build";
+	return "";
+}
+
+} // namespace bt2g
+#endif

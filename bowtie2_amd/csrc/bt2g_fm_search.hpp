@@ -41,11 +41,12 @@ BT2_HD int fm_rd_char(const RD& rd, uint32_t rdlen, bool fw, uint32_t i) { retur
 // size and the read agrees; at most 255 positions each way.
 template <typename TOff, typename RD>
 BT2_HD void fm_extend_hit(const DevIndex<TOff>& ix, const RD& rd, uint32_t rdlen, TOff topf, TOff botf, TOff topb, TOff botb,
-                          bool fw, uint32_t off, uint32_t len, uint32_t& nlex, uint32_t& nrex, FmCount& cnt) {
+                          bool fw, uint32_t off, uint32_t len, uint32_t& nlex, uint32_t& nrex, FmCount& cnt, bool right = true) {
 	TOff t[4], b[4], tp[4], bp[4];
 	nlex = nrex = 0;
 	for (int side = 0; side < 2; side++) {
 		const bool left = side == 0;
+		if (!left && !right) continue;     // the reference only extends to the right when the mirror index is loaded (:403)
 		const uint32_t lim = left ? (fw ? off : rdlen - len - off) : (fw ? rdlen - len - off : off);
 		if (lim == 0) continue;
 		const DevEbwt<TOff>& e = left ? ix.fw : ix.bw;

@@ -66,7 +66,11 @@ struct Options {
 	int khits = 1, mhits = 50;
 	bool saw_k = false, all_hits = false, local = false;
 	bool nofw = false, norc = false;
-	bool qc_filter = false;
+	bool qc_filter = false, ignore_quals = false, no_1mm_upfront = false, xeq = false, omit_sec_seq = false, phred64 = false;
+	int format = 0;               // 0 FASTQ, 1 FASTA (-f), 2 raw (-r)
+	int trim5 = 0, trim3 = 0;
+	int mp_max = 6, mp_min = 2, np = 1, rdg_const = 5, rdg_linear = 3, rfg_const = 5, rfg_linear = 3, gbar = 4, maxhalf = 15;
+	std::string rg_id, rgs, rg_optflag;   // @RG header pieces and the per-record RG:Z: flag (bt2_search.cpp:1418-1436)
 	uint32_t seed = 0;
 	int threads = 1;
 	bool reorder = false, timing = false, no_unal = false, quiet = false, sam_no_hd = false, sam_no_sq = false;
@@ -91,8 +95,11 @@ struct Options {
 		return true;
 	}
 	void to_params(AlignParams& P, bool large_index) const {
-		P.mm_type = 3; P.mm_max = 6; P.mm_min = 2; P.n_pen = 1;
-		P.rdgapo = 5 + 3; P.rdgape = 3; P.rfgapo = 5 + 3; P.rfgape = 3; P.gapbar = 4; P.match_bonus = 0;
+		// Scoring (scoring.h:60-170): type 3 = Phred-scaled mismatch penalty, anything else = constant mm_max;
+		// gap of length n costs const + n * linear
+		P.mm_type = ignore_quals ? 1 : 3; P.mm_max = mp_max; P.mm_min = ignore_quals ? mp_max : mp_min; P.n_pen = np;
+		P.rdgapo = rdg_const + rdg_linear; P.rdgape = rdg_linear; P.rfgapo = rfg_const + rfg_linear; P.rfgape = rfg_linear;
+		P.gapbar = gbar; P.match_bonus = 0;
 		P.khits = khits; P.mhits = (saw_k || all_hits) ? 0 : mhits;
 		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
 		if (khits > 1) {
@@ -100,9 +107,12 @@ struct Options {
 			P.max_dp_streak += (khits - 1) * 10;
 			P.max_ug += (khits - 1) * 20; P.max_dp += (khits - 1) * 20; P.max_iters += (khits - 1) * 20;
 		}
-		P.n_seed_rounds = n_seed_rounds; P.seed_boost_thresh = 300; P.tighten = 3; P.maxhalf = 15;
+		P.n_seed_rounds = n_seed_rounds; P.seed_boost_thresh = 300; P.tighten = 3; P.maxhalf = maxhalf;
 		P.nofw = nofw; P.norc = norc;
-		P.do_exact_upfront = 1; P.do_1mm_upfront = 1; P.do_ungapped = 1; P.do_extend = 1;
+		P.do_exact_upfront = 1; P.do_1mm_upfront = no_1mm_upfront ? 0 : 1; P.do_ungapped = 1;
+		// bit 0: extend seed hits; bit 1: left only -- the reference loads the mirror index only for -N > 0 or the 1-mm
+		// up-front search (bt2_search.cpp:4841) and SwDriver::extend skips the right extension without it (:403)
+		P.do_extend = 1 | ((seed_mms == 0 && no_1mm_upfront) ? 2 : 0);
 		P.large_index = large_index ? 1 : 0;
 	}
 };
@@ -201,13 +211,15 @@ inline void sam_print_name(std::string& o, const std::string& name, bool truncat
 	for (size_t i = 0; i < n; i++) { if (truncate && isspace((unsigned char)name[i])) break; o.push_back(name[i]); }
 }
 
-inline void sam_header(std::string& o, const RefInfo& ref, const std::string& cmdline, bool hd = true, bool sq = true) {
+inline void sam_header(std::string& o, const RefInfo& ref, const std::string& cmdline, bool hd = true, bool sq = true,
+                       const std::string& rg_id = "", const std::string& rgs = "") {
 	if (hd) o += "@HD\tVN:1.5\tSO:unsorted\tGO:query\n";
 	if (sq) for (size_t i = 0; i < ref.names.size(); i++) {
 		o += "@SQ\tSN:";
 		sam_print_name(o, ref.names[i], true);
 		o += "\tLN:" + std::to_string(ref.lens[i]) + "\n";
 	}
+	if (!rg_id.empty()) o += "@RG" + rg_id + rgs + "\n";       // SamConfig::printHeader (sam.cpp)
 	o += "@PG\tID:bowtie2\tPN:bowtie2\tVN:2.5.5\tCL:\"" + cmdline + "\"\n";
 }
 
@@ -323,9 +335,9 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		if (trimLS > 0) { o += std::to_string(trimLS); o.push_back('S'); }
 		for (size_t i = 0; i < ln; i++) {
 			char op = stRel[i];
-			if (op == 'X' || op == '=') op = 'M';
+			if (!opt.xeq && (op == 'X' || op == '=')) op = 'M';
 			size_t run = 1;
-			for (; i + run < ln; run++) { char op2 = stRel[i + run]; if (op2 == 'X' || op2 == '=') op2 = 'M'; if (op2 != op) break; }
+			for (; i + run < ln; run++) { char op2 = stRel[i + run]; if (!opt.xeq && (op2 == 'X' || op2 == '=')) op2 = 'M'; if (op2 != op) break; }
 			i += (run - 1);
 			o += std::to_string(run); o.push_back(op);
 		}
@@ -337,10 +349,12 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	o += "*\t0\t0\t";
 	// SEQ / QUAL
 	if (len == 0) o.push_back('*');
+	else if (!primary && opt.omit_sec_seq) o.push_back('*');
 	else if (!aln || aln->fw) for (size_t i = 0; i < len; i++) o.push_back(DNA[(int)rd.seq[i]]);
 	else for (size_t i = 0; i < len; i++) o.push_back(DNA[comp4((int)rd.seq[len - 1 - i])]);
 	o.push_back('\t');
 	if (len == 0) o.push_back('*');
+	else if (!primary && opt.omit_sec_seq) o.push_back('*');
 	else if (!aln || aln->fw) o += rd.qual;
 	else o.append(rd.qual.rbegin(), rd.qual.rend());
 	o.push_back('\t');
@@ -402,12 +416,14 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		if (!(f & 4)) flag = "LN"; else if (!(f & 1)) flag = "NS"; else if (!(f & 2)) flag = "SC"; else if (!(f & 8)) flag = "QC";
 		if (flag[0]) { o += "\tYF:Z:"; o += flag; }
 	}
+	if (!opt.rg_optflag.empty()) { o.push_back('\t'); o += opt.rg_optflag; }
 	o.push_back('\n');
 }
 
 struct AlnSummary {
 	uint64_t nread = 0, n0 = 0, nuni = 0, nrep = 0;
-	void add(const ReadResult& r) { nread++; if (!r.aligned) n0++; else if (r.maxed) nrep++; else nuni++; }
+	// aln_sink.cpp:985-1013,486-512: "exactly 1 time" = one alignment found and not over the -M ceiling
+	void add(const ReadResult& r) { nread++; if (!r.aligned) n0++; else if (r.maxed || r.nalns > 1) nrep++; else nuni++; }
 	void print(FILE* f) const {
 		auto pct = [](uint64_t a, uint64_t b) { char buf[32]; snprintf(buf, sizeof buf, "%.2f%%", b ? 100.0 * (double)a / (double)b : 0.0); return std::string(buf); };
 		fprintf(f, "%llu reads; of these:\n", (unsigned long long)nread);

@@ -495,7 +495,7 @@ struct GlobRd {
 
 template <typename TOff>
 __global__ void __launch_bounds__(256)
-k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t max_seeds,
+k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t max_seeds, int right,
               const bt2g_seed_hit* __restrict__ hits, uint32_t* __restrict__ ext, DevCounters* cnt) {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
@@ -515,7 +515,7 @@ k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restri
 			const uint32_t rdoff = i * (uint32_t)rparams[r].interval;
 			GlobRd g; g.s = rd.d_seq + o0; g.q = rd.d_qual + o0;
 			uint32_t nlex = 0, nrex = 0;
-			fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c);
+			fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c, right != 0);
 			e = nlex | (nrex << 16);
 		}
 		ext[gid] = e;
@@ -525,13 +525,13 @@ k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restri
 }
 
 template <typename TOff>
-hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds,
+hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds, int right,
                               const bt2g_seed_hit* d_hits, uint32_t* d_ext, DevCounters* d_cnt, hipStream_t st) {
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	if (total == 0) return hipSuccess;
 	const uint64_t grid = (total + 255) / 256;
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, rd, d_rparams, max_seeds, d_hits, d_ext, d_cnt);
+	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, rd, d_rparams, max_seeds, right, d_hits, d_ext, d_cnt);
 	return hipGetLastError();
 }
 
@@ -581,8 +581,8 @@ hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, c
 	return hipGetLastError();
 }
 
-template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, const bt2g_seed_hit*, uint32_t*, DevCounters*, hipStream_t);
-template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, const bt2g_seed_hit*, uint32_t*, DevCounters*, hipStream_t);
+template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, DevCounters*, hipStream_t);
+template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, DevCounters*, hipStream_t);
 template hipError_t launch_one_mm<uint32_t>(const DevIndex<uint32_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, DevCounters*, hipStream_t);
 template hipError_t launch_one_mm<uint64_t>(const DevIndex<uint64_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, DevCounters*, hipStream_t);
 

@@ -21,7 +21,7 @@ hipError_t launch_max_seeds(const bt2g_reads& rd, const bt2g_read_params* d_rpar
 
 // batch pre-computation for the fused worker (round-0 seed-hit extension, 1-mismatch e2e search)
 template <typename TOff>
-hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds,
+hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds, int right,
                               const bt2g_seed_hit* d_hits, uint32_t* d_ext, DevCounters* d_cnt, hipStream_t st);
 template <typename TOff>
 hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, const bt2g_reads& rd, const bt2g_read_params* d_rparams,

@@ -17,6 +17,7 @@
 #include "../../include/bt2g.h"
 #include "bt2g_host.hpp"
 #include "bt2g_pipeline.hpp"
+#include "bt2g_cli.hpp"
 
 using namespace bt2g;
 
@@ -81,45 +82,16 @@ int main(int argc, char** argv) {
 	std::string cmdline;
 	for (int i = 0; i < argc; i++) { if (i) cmdline.push_back(' '); cmdline += argv[i]; }
 	opt.cmdline = cmdline;
-	int device = 0;
-	bool metrics = false;
-	unsigned long long n_flagged = 0;
-	size_t batch_reads = 1u << 18;
-	for (int i = 1; i < argc; i++) {
-		const std::string a = argv[i];
-		auto need = [&](const char* what) -> std::string { if (i + 1 >= argc) die(std::string(what) + " needs an argument"); return argv[++i]; };
-		if (a == "--wrapper") { need("--wrapper"); }
-		else if (a == "--arg-desc") { print_arg_desc(); return 0; }
-		else if (a == "-x") opt.index_base = need("-x");
-		else if (a == "-U") opt.reads_file = need("-U");
-		else if (a == "-S") opt.out_file = need("-S");
-		else if (a == "-q") {}
-		else if (a == "-p" || a == "--threads") { opt.threads = atoi(need("-p").c_str()); }
-		else if (a == "--reorder") opt.reorder = true;
-		else if (a == "-t" || a == "--time") opt.timing = true;
-		else if (a == "-k") { opt.khits = atoi(need("-k").c_str()); opt.saw_k = true; }
-		else if (a == "-s" || a == "--skip") opt.skip = strtoull(need("-s").c_str(), nullptr, 10);
-		else if (a == "-u" || a == "--upto") { opt.upto = strtoull(need("-u").c_str(), nullptr, 10); if (opt.upto == 0) opt.upto = UINT64_MAX; }
-		else if (a == "--seed") opt.seed = (uint32_t)strtoul(need("--seed").c_str(), nullptr, 10);
-		else if (a == "--nofw") opt.nofw = true;
-		else if (a == "--norc") opt.norc = true;
-		else if (a == "--end-to-end") {}
-		else if (a == "--no-hd") opt.sam_no_hd = true;
-		else if (a == "--no-sq") opt.sam_no_sq = true;
-		else if (a == "--gpu") device = atoi(need("--gpu").c_str());
-		else if (a == "--met") metrics = true;
-		else if (a == "--batch") batch_reads = strtoull(need("--batch").c_str(), nullptr, 10);
-		else if (a == "-D") opt.max_dp_streak = atoi(need("-D").c_str());
-		else if (a == "-R") opt.n_seed_rounds = atoi(need("-R").c_str());
-		else if (a == "-L") opt.seed_len = atoi(need("-L").c_str());
-		else if (a == "-i") { if (!opt.ms_ival.parse(need("-i"))) die("bad -i function"); }
-		else if (a == "--score-min") { if (!opt.score_min.parse(need("--score-min"))) die("bad --score-min function"); }
-		else if (a == "--n-ceil") { if (!opt.n_ceil.parse(need("--n-ceil"))) die("bad --n-ceil function"); }
-		else if (a.size() > 2 && a.substr(0, 2) == "--" && opt.apply_preset(a.substr(2))) {}
-		else if (a == "-1" || a == "-2" || a == "--local" || a == "-N" || a == "-f" || a == "-c" || a == "-b" || a == "--interleaved")
-			die("option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ, end-to-end, -N 0)", 1);
-		else die("unsupported option " + a);
+	CliExtra ex;
+	{
+		const std::string err = parse_cli(argc, argv, opt, ex);
+		if (ex.arg_desc) { print_arg_desc(); return 0; }
+		if (!err.empty()) die(err, 1);
 	}
+	const int device = ex.device;
+	const bool metrics = ex.metrics;
+	const size_t batch_reads = ex.batch_reads;
+	unsigned long long n_flagged = 0;
 	if (opt.index_base.empty() || opt.reads_file.empty()) die("usage: bowtie2-align-s [options] -x <index> -U <reads.fq> [-S out.sam]");
 
 	bt2g_ctx* ctx = nullptr;
@@ -141,7 +113,7 @@ int main(int argc, char** argv) {
 	FILE* out = opt.out_file.empty() ? stdout : fopen(opt.out_file.c_str(), "wb");
 	if (!out) die("cannot open output " + opt.out_file);
 	std::string o;
-	sam_header(o, ref, opt.cmdline, !opt.sam_no_hd, !opt.sam_no_sq);
+	if (!opt.sam_no_hd) sam_header(o, ref, opt.cmdline, true, !opt.sam_no_sq, opt.rg_id, opt.rgs);   // --no-hd drops every header line (bt2_search.cpp:5126-5130)
 	fwrite(o.data(), 1, o.size(), out);
 
 	AlignParams P;

@@ -154,22 +154,44 @@ public:
 
 	// Fill `b` with up to max_reads reads; sets b.last at end of input (or at -u).
 	void next(HostBatch& b, size_t max_reads, size_t max_read_len) {
-		// ---- serial part: split the text into records (three line copies per record into one arena)
+		// ---- serial part: split the text into records (line copies into one arena)
 		arena_.clear(); recs_.clear();
 		while (recs_.size() < max_reads) {
 			const char* p; size_t n;
-			bool got;
-			do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
-			if (!got || p[0] != '@') { b.last = true; break; }
-			if (rdid_ >= opt_.upto) { b.last = true; break; }
 			Raw r;
+			r.qual_off = r.qual_len = 0;
+			if (opt_.format == 0) {                    // FASTQ: 4-line records
+				bool got;
+				do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
+				if (!got || p[0] != '@') { b.last = true; break; }
+				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
+				if (!src_.next(p, n)) { b.last = true; break; }
+				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
+				if (!src_.next(p, n)) { b.last = true; break; }            // '+' line
+				if (!src_.next(p, n)) { b.last = true; break; }
+				r.qual_off = arena_.size(); r.qual_len = n; arena_.append(p, n);
+			} else if (opt_.format == 1) {             // FASTA: '>' name, sequence possibly over several lines
+				bool got = true;
+				if (!have_pending_) { do { got = src_.next(p, n); } while (got && (n == 0 || p[0] != '>')); if (got) pending_.assign(p, n); }
+				if (!got) { b.last = true; break; }
+				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				have_pending_ = false;
+				r.name_off = arena_.size(); r.name_len = pending_.size() - 1; arena_.append(pending_.data() + 1, pending_.size() - 1);
+				r.seq_off = arena_.size(); r.seq_len = 0;
+				while (src_.next(p, n)) {
+					if (n && p[0] == '>') { pending_.assign(p, n); have_pending_ = true; break; }
+					arena_.append(p, n); r.seq_len += n;
+				}
+			} else {                                   // raw: one sequence per line, named by its index
+				bool got;
+				do { got = src_.next(p, n); } while (got && n == 0);
+				if (!got) { b.last = true; break; }
+				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				r.name_off = arena_.size(); r.name_len = 0;
+				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
+			}
 			r.rdid = rdid_;
-			r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
-			if (!src_.next(p, n)) { b.last = true; break; }
-			r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
-			if (!src_.next(p, n)) { b.last = true; break; }            // '+' line
-			if (!src_.next(p, n)) { b.last = true; break; }
-			r.qual_off = arena_.size(); r.qual_len = n; arena_.append(p, n);
 			if (rdid_++ < opt_.skip) continue;
 			recs_.push_back(r);
 		}
@@ -187,9 +209,19 @@ public:
 				rd.seq.reserve(r.seq_len);
 				const char* s = arena_.data() + r.seq_off;
 				for (size_t k = 0; k < r.seq_len; k++) { char ch = s[k]; if (ch == '.') ch = 'N'; if (isalpha((unsigned char)ch)) rd.seq.push_back((char)asc2code(ch)); }
-				rd.qual.assign(arena_.data() + r.qual_off, r.qual_len);
-				if (rd.qual.size() > rd.seq.size()) rd.qual.resize(rd.seq.size());   // the reference errors out; we are lenient
-				while (rd.qual.size() < rd.seq.size()) rd.qual.push_back('I');
+				if (opt_.format == 0) {
+					rd.qual.assign(arena_.data() + r.qual_off, r.qual_len);
+					if (opt_.phred64) for (char& q : rd.qual) q = (char)((int)q - 64 + 33 < 33 ? 33 : (int)q - 64 + 33);
+					if (rd.qual.size() > rd.seq.size()) rd.qual.resize(rd.seq.size());   // the reference errors out; we are lenient
+					while (rd.qual.size() < rd.seq.size()) rd.qual.push_back('I');
+				} else rd.qual.assign(rd.seq.size(), 'I');
+				// -5/-3 hard trimming (pat.cpp:726-765)
+				if (opt_.trim5 > 0 || opt_.trim3 > 0) {
+					const size_t t5 = std::min<size_t>((size_t)opt_.trim5, rd.seq.size());
+					rd.seq.erase(0, t5); rd.qual.erase(0, t5);
+					const size_t t3 = std::min<size_t>((size_t)opt_.trim3, rd.seq.size());
+					rd.seq.resize(rd.seq.size() - t3); rd.qual.resize(rd.qual.size() - t3);
+				}
 				if (rd.name.empty()) rd.name = std::to_string(r.rdid);
 				b.rp[i] = compute_read_params(opt_, rd);
 			}
@@ -218,7 +250,8 @@ private:
 	LineSource src_;
 	const Options& opt_;
 	unsigned threads_;
-	std::string arena_;
+	std::string arena_, pending_;
+	bool have_pending_ = false;
 	std::vector<Raw> recs_;
 	uint64_t rdid_ = 0;
 };
@@ -234,7 +267,7 @@ inline void format_batch(const HostBatch& b, const Options& opt, const RefInfo& 
 		for (size_t i = c * chunk; i < e; i++) {
 			const ReadResult& rr = *(const ReadResult*)(b.res.data() + i * b.stride);
 			if (rr.aligned) { for (uint32_t k = 0; k < rr.nreport; k++) sam_record(o, opt, ref, b.reads[i], rr, &rr.alns[k], k == 0); }
-			else sam_record(o, opt, ref, b.reads[i], rr, nullptr, true);
+			else if (!opt.no_unal) sam_record(o, opt, ref, b.reads[i], rr, nullptr, true);
 		}
 	});
 }

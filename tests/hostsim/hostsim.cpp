@@ -14,6 +14,8 @@
 #include "../../bowtie2_amd/csrc/bt2g_index.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_align_core.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_host.hpp"
+#include "../../bowtie2_amd/csrc/bt2g_pipeline.hpp"
+#include "../../bowtie2_amd/csrc/bt2g_cli.hpp"
 
 using namespace bt2g;
 
@@ -143,9 +145,9 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	ref.names = hidx.fw.refnames;
 	for (uint64_t i = 0; i < hidx.fw.n_pat; i++) ref.lens.push_back(hidx.plen_at(i));
 	std::string o;
-	sam_header(o, ref, opt.cmdline);
+	if (!opt.sam_no_hd) sam_header(o, ref, opt.cmdline, true, !opt.sam_no_sq, opt.rg_id, opt.rgs);   // --no-hd drops every header line (bt2_search.cpp:5126-5130)
 	fwrite(o.data(), 1, o.size(), out);
-	FastqReader fq(opt.reads_file);
+	FastqBatcher fq(opt.reads_file, opt, 1);       // the product's reader, single-threaded
 	if (!fq.ok()) { fprintf(stderr, "cannot open %s\n", opt.reads_file.c_str()); return 1; }
 	Work* w = new Work();
 	DpScratch dp;
@@ -153,18 +155,20 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	dp.mat = (uint32_t*)malloc(mat_bytes);
 	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
 	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(opt.khits + 1));
-	ReadRec rd;
 	AlnSummary summ;
-	uint64_t rdid = 0;
-	while (fq.next(rd, rdid)) {
-		if (rdid >= opt.upto) break;
-		if (rdid++ < opt.skip) continue;
+	HostBatch hb;
+	for (bool last = false; !last; ) {
+	hb = HostBatch();
+	fq.next(hb, 4096, (size_t)1 << 30);
+	last = hb.last;
+	for (size_t ri = 0; ri < hb.reads.size(); ri++) {
+		const ReadRec& rd = hb.reads[ri];
 		ReadResult& rr = *(ReadResult*)resbuf.data();
 		if (rd.seq.size() > (size_t)kMaxLen) {
 			fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", rd.name.c_str(), kMaxLen);
 			return 1;
 		}
-		ReadParams rp = compute_read_params(opt, rd);
+		ReadParams rp = hb.rp[ri];
 		g_hot.len = (uint32_t)rd.seq.size();
 		memcpy(g_hot.seq, rd.seq.data(), rd.seq.size());
 		memcpy(g_hot.qual, rd.qual.data(), rd.qual.size());
@@ -175,7 +179,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		o.clear();
 		if (rr.aligned) {
 			for (uint32_t i = 0; i < rr.nreport; i++) sam_record(o, opt, ref, rd, rr, &rr.alns[i], i == 0);
-		} else {
+		} else if (!opt.no_unal) {
 			sam_record(o, opt, ref, rd, rr, nullptr, true);
 		}
 		fwrite(o.data(), 1, o.size(), out);
@@ -183,29 +187,17 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps,
 		                     (unsigned long long)g_hot.t_phase[11], (unsigned long long)g_hot.t_phase[12], (unsigned long long)g_hot.t_phase[13]);
 	}
+	}
 	summ.print(stderr);
 	return 0;
 }
 
 int main(int argc, char** argv) {
 	Options opt;
-	bool metrics = false;
-	for (int i = 1; i < argc; i++) {
-		std::string a = argv[i];
-		auto need = [&](const char* what) -> std::string { if (i + 1 >= argc) { fprintf(stderr, "%s needs an argument\n", what); exit(1); } return argv[++i]; };
-		if (a == "-x") opt.index_base = need("-x");
-		else if (a == "-U") opt.reads_file = need("-U");
-		else if (a == "-S") opt.out_file = need("-S");
-		else if (a == "-k") { opt.khits = atoi(need("-k").c_str()); opt.saw_k = true; }
-		else if (a == "-s") opt.skip = strtoull(need("-s").c_str(), nullptr, 10);
-		else if (a == "-u") opt.upto = strtoull(need("-u").c_str(), nullptr, 10);
-		else if (a == "--seed") opt.seed = (uint32_t)strtoul(need("--seed").c_str(), nullptr, 10);
-		else if (a == "--nofw") opt.nofw = true;
-		else if (a == "--norc") opt.norc = true;
-		else if (a == "--met") metrics = true;
-		else if (a.size() > 2 && a.substr(0, 2) == "--" && opt.apply_preset(a.substr(2))) {}
-		else { fprintf(stderr, "unsupported option %s\n", a.c_str()); return 1; }
-	}
+	CliExtra ex;
+	const std::string perr = parse_cli(argc, argv, opt, ex);
+	if (!perr.empty()) { fprintf(stderr, "%s\n", perr.c_str()); return 1; }
+	const bool metrics = ex.metrics;
 	opt.cmdline = "hostsim";
 	HostIndex hidx;
 	std::string err;

@@ -1,0 +1,86 @@
+"""Option coverage of the drop-in command line (bt2_search.cpp:1040-1620): for each option set the SAM and the
+stderr summary must equal the reference binary's.  CPU: the host-compiled worker (tests/hostsim, same parser, same
+reader, same SAM writer as the product).  GPU: the product binary itself (marked gpu)."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from bt2test import have_ref, ref_bin
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+HS = os.path.join(ROOT, "tests", "hostsim")
+EXE = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-s")
+FQ = os.path.join(GOLD, "align_reads.fq")
+
+OPTION_SETS = [
+    ["--mp", "4,2"], ["--mp", "5"], ["--np", "3"], ["--rdg", "4,2", "--rfg", "6,4"], ["--ignore-quals"], ["--ignore-quals", "--mp", "4,1"],
+    ["--gbar", "10"], ["--dpad", "5"], ["--no-1mm-upfront"], ["--no-unal"], ["--xeq"], ["-k", "4", "--omit-sec-seq"],
+    ["--rg-id", "grp1", "--rg", "SM:x", "--rg", "PL:illumina"], ["-5", "7", "-3", "11"], ["-3", "200"], ["--no-hd"], ["--no-sq"],
+    ["-s", "100", "-u", "200"], ["-M", "3"], ["-D", "5", "-R", "1", "-L", "18", "-i", "C,10,0"],
+    ["--score-min", "L,-1,-0.3", "--n-ceil", "L,0,0.5"], ["--seed", "77"], ["--very-sensitive", "--nofw"], ["--fast", "--norc"],
+]
+
+
+@pytest.fixture(scope="module")
+def hostsim():
+    exe = os.path.join(HS, "hostsim")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    return exe
+
+
+def run(exe, args, tmp):
+    out = os.path.join(tmp, "o.sam")
+    p = subprocess.run([exe] + args + ["-S", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-1500:]
+    sam = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    summ = [l for l in p.stderr.splitlines() if not l.startswith("Warning") and "amdgpu.ids" not in l]
+    return sam, summ
+
+
+def input_variants(tmp):
+    """the golden reads as FASTA, raw, phred64 FASTQ and gzipped FASTQ"""
+    lines = open(FQ).read().splitlines()
+    recs = [(lines[i][1:], lines[i + 1], lines[i + 3]) for i in range(0, len(lines), 4)]
+    fa, raw, p64, gz = (os.path.join(tmp, n) for n in ("r.fa", "r.raw", "r64.fq", "r.fq.gz"))
+    open(fa, "w").write("".join(">%s\n%s\n" % (n, s) for n, s, _ in recs))
+    open(raw, "w").write("".join("%s\n" % s for _, s, _ in recs if s))
+    open(p64, "w").write("".join("@%s\n%s\n+\n%s\n" % (n, s, "".join(chr(ord(c) + 31) for c in q)) for n, s, q in recs))
+    with gzip.open(gz, "wt") as f:
+        f.write(open(FQ).read())
+    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), ([], gz)]
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("idx", ["tiny_s", "tiny_l"])
+def test_options_match_reference_hostsim(hostsim, idx, tmp_path):
+    ref = ref_bin("bowtie2-align-l" if idx.endswith("_l") else "bowtie2-align-s")
+    base = os.path.join(GOLD, idx)
+    for opts in OPTION_SETS:
+        args = opts + ["-x", base, "-U", FQ]
+        assert run(hostsim, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts
+    for opts, path in input_variants(str(tmp_path)):
+        args = opts + ["-x", base, "-U", path]
+        assert run(hostsim, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts
+
+
+def test_unsupported_options_are_refused(hostsim):
+    for opts in (["--local"], ["-1", "a.fq", "-2", "b.fq"], ["-N", "1"], ["-a"], ["-k", "100"], ["--frobnicate"]):
+        p = subprocess.run([hostsim] + opts + ["-x", os.path.join(GOLD, "tiny_s"), "-U", FQ], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode != 0 and p.stdout == "", opts
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+def test_options_match_reference_gpu(tmp_path):
+    ref = ref_bin("bowtie2-align-s")
+    base = os.path.join(GOLD, "tiny_s")
+    for opts in OPTION_SETS:
+        args = opts + ["-x", base, "-U", FQ]
+        assert run(EXE, args + ["-p", "4"], str(tmp_path)) == run(ref, args, str(tmp_path)), opts
+    for opts, path in input_variants(str(tmp_path)):
+        args = opts + ["-x", base, "-U", path]
+        assert run(EXE, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts

@@ -14,7 +14,7 @@ HS = os.path.join(ROOT, "tests", "hostsim")
 def hostsim():
     exe = os.path.join(HS, "hostsim")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp")])
+                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
     return exe
 
 
