@@ -41,7 +41,7 @@ constexpr int kMaxEdits    = 200;
 constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at most 51)
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 16384; // uint32 slots for Random1toN lists
-constexpr int kMaxCands    = 1024;  // DP backtrace candidates (<= DP columns)
+constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
 constexpr int kMaxCols     = kMaxLen + 4 * 15 + 1 + 4;
 
 enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
@@ -117,6 +117,7 @@ struct SatPos {           // SATupleAndPos (aligner_sw_driver.h:144)
 struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };
 
 struct BtCand { int32_t score; uint16_t row, col; };
+constexpr int32_t kCandDone = 1 << 30;   // local mode: candidate already tried (btncanddone_); local scores are small and non-negative
 
 struct BtFrame {          // DpNucFrame
 	uint32_t nedsz, celsz;    // celsz: # cells on the path so far | core-diagonal-touched flag << 31

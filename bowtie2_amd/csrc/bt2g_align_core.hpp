@@ -749,14 +749,23 @@ struct Aligner {
 	BT2_HD uint16_t& mask_at(uint32_t row, uint32_t col, uint32_t cols) { return dp.masks[(uint64_t)row * cols + col]; }
 
 	// gatherCellsNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1176-1208) + btncand_.sort()
-	BT2_HDN void gather_cells(uint32_t rows, uint32_t cols, int64_t minsc_dp, bool wide) {
+	BT2_HDN void gather_cells(bool fw, uint32_t rows, uint32_t cols, int64_t minsc_dp, int mode, uint32_t lastsolcol) {
 		const uint32_t R = dp_R(rows);
 		HOT.n_cands = 0; HOT.cural = 0;
 		const uint64_t tl_ = now();
-		Plat::load_last_row(dp.mat, R, rows, cols, wide);
-		HOT.t_phase[15] += now() - tl_;
-		// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
-		const uint32_t nc = Plat::gather_sort(w.cands, (uint32_t)kMaxCands, rows, cols, minsc_dp);
+		uint32_t nc;
+		if (mode != 2) {
+			Plat::load_last_row(dp.mat, R, rows, cols, mode != 0);
+			HOT.t_phase[15] += now() - tl_;
+			// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
+			nc = Plat::gather_sort(w.cands, (uint32_t)kMaxCands, rows, cols, minsc_dp);
+		} else {
+			// gatherCellsNucleotidesLocalSseU8/I16 (aligner_swsse_loc_u8.cpp:1389-1496): every cell with score >= minsc, at or
+			// below the first row that can reach minsc, that is a match whose diagonal successor is not; columns <= lastsolcol
+			const int64_t bonus = P.match_bonus;
+			const uint32_t minrow = (uint32_t)(((minsc_dp + bonus - 1) / bonus) - 1);
+			nc = Plat::gather_local(dp.mat, w.cands, (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow);
+		}
 		if (nc > (uint32_t)kMaxCands) { HOT.err |= ERR_OVERFLOW; HOT.n_cands = kMaxCands; } else HOT.n_cands = nc;
 		HOT.t_phase[13] += HOT.n_cands;      // profile: candidate cells
 		if (HOT.n_cands > 0) { const uint64_t tz_ = now(); Plat::zero_masks(dp.masks, rows * cols); HOT.t_phase[16] += now() - tz_; }   // SSEMatrix::initMasks, eagerly
@@ -765,11 +774,13 @@ struct Aligner {
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
 	BT2_HDN bool backtrace(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen,
 	                      int32_t escore, uint32_t row_, uint32_t col_, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi,
-	                      bool wide_, AlnRes& res) {
+	                      int mode_, AlnRes& res) {
 		(void)escore;
 		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
 		const bool fw = Plat::uni((int)fw_) != 0;
-		const bool wide = Plat::uni((int)wide_) != 0;     // 16-bit cells (H | E<<16 in the low word, F in the high word), bias 0x7fff
+		// cell format: 0 = e2e 8-bit (bias 0xff), 1 = e2e 16-bit (bias 0x7fff), 2 = local (16-bit fields holding plain scores, floor 0)
+		const int mode = Plat::uni(mode_);
+		const bool wide = mode != 0, local = mode == 2;
 		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
 		uint32_t row = Plat::uni(row_), col = Plat::uni(col_);
 		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
@@ -814,7 +825,8 @@ struct Aligner {
 		uint32_t trim_beg = 0;
 		int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
 		Edit* ned = HOT.ned;
-		const int offsetsc = wide ? -0x7fff : -0xff;
+		const int offsetsc = local ? 0 : (wide ? -0x7fff : -0xff);
+		auto fl = [&](int v) -> bool { return !local || v > 0; };     // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
 		HOT.n_bt_attempts++;
 		while ((int)row >= 0) {
 			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
@@ -839,16 +851,16 @@ struct Aligner {
 				const uint64_t c_up = cell(16 + td);
 				const uint64_t c_left = cell(32 + td);
 				const uint64_t c_upleft = cell(td + 1);
-				auto Hc = [&](uint64_t c) -> int { return wide ? (int)(int16_t)(uint16_t)(c & 0xffff) : (int)(c & 0xff); };
-				auto Ec = [&](uint64_t c) -> int { return wide ? (int)(int16_t)(uint16_t)((c >> 16) & 0xffff) : (int)((c >> 8) & 0xff); };
-				auto Fc = [&](uint64_t c) -> int { return wide ? (int)(int16_t)(uint16_t)((c >> 32) & 0xffff) : (int)((c >> 16) & 0xff); };
+				auto Hc = [&](uint64_t c) -> int { return local ? (int)(c & 0xffff) : wide ? (int)(int16_t)(uint16_t)(c & 0xffff) : (int)(c & 0xff); };
+				auto Ec = [&](uint64_t c) -> int { return local ? (int)((c >> 16) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 16) & 0xffff) : (int)((c >> 8) & 0xff); };
+				auto Fc = [&](uint64_t c) -> int { return local ? (int)((c >> 32) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 32) & 0xffff) : (int)((c >> 16) & 0xff); };
 				if (ct == 1) {          // E: came from the left
 					const int sc_cur = Ec(c_cur) + offsetsc;
 					int mask = 0;
 					const int sc_h_left = Hc(c_left) + offsetsc;
-					if (sc_h_left - S.rdgapo == sc_cur) mask |= 1;
+					if (fl(sc_h_left) && sc_h_left - S.rdgapo == sc_cur) mask |= 1;
 					const int sc_e_left = Ec(c_left) + offsetsc;
-					if (sc_e_left - S.rdgape == sc_cur) mask |= 2;
+					if (fl(sc_e_left) && sc_e_left - S.rdgape == sc_cur) mask |= 2;
 					const int orig_mask = mask;
 					if (mk & (1 << 7)) mask = (mk >> 8) & 3;
 					if (mask == 3) { cur = 3; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7) | (2 << 8)); branch = true; }
@@ -860,8 +872,8 @@ struct Aligner {
 					const int sc_f_up = Fc(c_up) + offsetsc;
 					const int sc_cur = Fc(c_cur) + offsetsc;
 					int mask = 0;
-					if (sc_h_up - S.rfgapo == sc_cur) mask |= 1;
-					if (sc_f_up - S.rfgape == sc_cur) mask |= 2;
+					if (fl(sc_h_up) && sc_h_up - S.rfgapo == sc_cur) mask |= 1;
+					if (fl(sc_f_up) && sc_f_up - S.rfgape == sc_cur) mask |= 2;
 					const int orig_mask = mask;
 					if (mk & (1 << 10)) mask = (mk >> 11) & 3;
 					if (mask == 3) { cur = 1; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10) | (2 << 11)); branch = true; }
@@ -879,12 +891,12 @@ struct Aligner {
 					const int sc_diag = sc_score(S, readc, refm, readq - 33);
 					int mask = 0;
 					if (gaps_allowed) {
-						if (sc_cur == sc_h_up - S.rfgapo) mask |= 1;
-						if (hasl && sc_cur == sc_h_left - S.rdgapo) mask |= 2;
-						if (sc_cur == sc_f_up - S.rfgape) mask |= 4;
-						if (hasl && sc_cur == sc_e_left - S.rdgape) mask |= 8;
+						if (fl(sc_h_up) && sc_cur == sc_h_up - S.rfgapo) mask |= 1;
+						if (hasl && fl(sc_h_left) && sc_cur == sc_h_left - S.rdgapo) mask |= 2;
+						if (fl(sc_f_up) && sc_cur == sc_f_up - S.rfgape) mask |= 4;
+						if (hasl && fl(sc_e_left) && sc_cur == sc_e_left - S.rdgape) mask |= 8;
 					}
-					if (hasl && sc_cur == sc_h_upleft + sc_diag) mask |= 16;
+					if (hasl && fl(sc_h_upleft) && sc_cur == sc_h_upleft + sc_diag) mask |= 16;
 					const int orig_mask = mask;
 					if (mk & (1 << 1)) mask = (mk >> 2) & 31;
 					int opts = 0;
@@ -1033,22 +1045,39 @@ struct Aligner {
 	}
 
 	// SwAligner::nextAlignment, end-to-end u8 branch (aligner_sw.cpp:737-1146)
-	BT2_HDN bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, bool wide, AlnRes& res) {
+	BT2_HDN bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, int mode, bool sse16, AlnRes& res) {
+		const bool wide = mode != 0;
 		if (HOT.cural == HOT.n_cands) return false;
 		bool found = false;
 		while (HOT.cural < HOT.n_cands) {
-			const BtCand& c = w.cands[HOT.cural];
+			BtCand c = w.cands[HOT.cural];
+			if (mode == 2) c.score &= ~kCandDone;
 			if (c.score < minsc) { HOT.cural++; continue; }
+			if (mode == 2) {
+				// local: skip candidates "dominated" by one already tried -- within SQ = rows/16 rows and columns of it
+				// (aligner_sw.cpp:754-755,936-960)
+				uint32_t SQ = rows >> 4; if (SQ == 0) SQ = 1;
+				bool dom = false;
+				for (uint32_t k = 0; k < HOT.cural && !dom; k++) {
+					const BtCand& o = w.cands[k];
+					if (!(o.score & kCandDone)) continue;
+					const uint32_t rhi = c.row > o.row ? c.row - o.row : o.row - c.row, chi = c.col > o.col ? c.col - o.col : o.col - c.col;
+					if (chi <= SQ && rhi <= SQ) dom = true;
+				}
+				if (dom) { HOT.cural++; continue; }
+			}
 			typename Plat::LaneReg tile, tile_hi;
 			{ const uint64_t tt_ = now(); Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col, wide, tile, tile_hi); pf_tiles++; pf_tile_t += now() - tt_; }    // also the first tile of the backtrace
 			if (Plat::lane(tile, 48) & 1) { HOT.cural++; continue; }
-			// reseeding protocol: 8-bit path init(reseed) ... init(reseed+1); 16-bit path only init(reseed) afterwards
-			// (aligner_sw.cpp:796-876 vs :877-933)
+			// reseeding protocol: 8-bit kernels init(reseed) ... init(reseed+1); 16-bit kernels only init(reseed) afterwards
+			// (aligner_sw.cpp:796-933 end-to-end, :962-1110 local)
 			const uint32_t reseed = rnd.nextU32() + 1;
-			if (!wide) rnd.init(reseed);
+			if (!sse16) rnd.init(reseed);
 			res.nned = 0;
-			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, c.score, c.row, c.col, tile, tile_hi, wide, res);
-			rnd.init(wide ? reseed : reseed + 1);
+			const int32_t cscore = c.score;
+			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, mode, res);
+			rnd.init(sse16 ? reseed : reseed + 1);
+			if (mode == 2) w.cands[HOT.cural].score = cscore | kCandDone;       // btncanddone_: tried, succeeded or not
 			if (ret) { found = true; break; }
 			HOT.cural++;
 		}
@@ -1067,17 +1096,39 @@ struct Aligner {
 		int64_t score = 0;
 		int ns = 0;
 		for (uint32_t i = 0; i < len; i++) HOT.rf[i] = (uint8_t)ref_base(ix.ref, tidx, rfi + (int64_t)i);   // codes here, not masks
-		for (uint32_t i = 0; i < len; i++) {
+		uint32_t rowi = 0, rowf = len - 1;
+		auto step = [&](uint32_t i) {
 			const int rdc = rd_char(HOT, HOT.len, fw, i);
 			const int rfc = HOT.rf[i];
 			const int q = rd_qual(HOT, HOT.len, fw, i) - 33;
 			if (rdc > 3 || rfc > 3) { ns++; score -= P.n_pen; }
 			else if (rdc == rfc) score += P.match_bonus;
 			else score -= mm_penalty(P, q < 0 ? 0 : q);
-			if (score < minsc || ns > rp.nceil) return 0;
+		};
+		if (P.match_bonus == 0) {
+			for (uint32_t i = 0; i < len; i++) {
+				step(i);
+				if (score < minsc || ns > rp.nceil) return 0;
+			}
+		} else {
+			// local flavour (aligner_sw.cpp:400-436): best-scoring stretch of the diagonal; more than one -> leave it to the DP
+			int64_t score_max = 0;
+			uint32_t lastfloor = 0, sols = 0;
+			rowi = 0xffffffffu;
+			for (uint32_t i = 0; i < len; i++) {
+				step(i);
+				if (score >= minsc && score >= score_max) {
+					score_max = score; rowf = i;
+					if (rowi != lastfloor) { rowi = lastfloor; sols++; }
+				}
+				if (score <= 0) { score = 0; lastfloor = i + 1; }
+			}
+			if (ns > rp.nceil || score_max < minsc) return 0;
+			if (sols > 1) return -1;
+			score = score_max;
 		}
 		uint32_t nned = 0, refns = 0;
-		for (uint32_t i = 0; i < len; i++) {
+		for (uint32_t i = rowi; i <= rowf; i++) {
 			const int rdc = rd_char(HOT, HOT.len, fw, i);
 			const int rfc = HOT.rf[i];
 			if (rfc > 3 || rdc != rfc) {
@@ -1091,7 +1142,8 @@ struct Aligner {
 		res.score = (int32_t)score; res.ns = (int16_t)ns; res.gaps = 0; res.edits = (int16_t)nned;
 		res.bases_aligned = (int16_t)((int)len - (int)nned);
 		res.refns = (uint16_t)refns;
-		set_shape(res, (int32_t)tidx, refoff, reflen, fw, len, 0, 0);
+		const uint32_t trim_end = (len - 1) - rowf;
+		set_shape(res, (int32_t)tidx, refoff + (int64_t)rowi, reflen, fw, len, fw ? rowi : trim_end, fw ? trim_end : rowi);
 		if (!fw) invert_edits(res);
 		return 1;
 	}
@@ -1102,7 +1154,7 @@ struct Aligner {
 	BT2_HDN int extend_seeds(int seedmms, int seedlen, int seedival) {
 		(void)seedlen; (void)seedival;
 		const uint32_t rdlen = HOT.len;
-		const int64_t perfect = (int64_t)rdlen * P.match_bonus * 0;   // monotone: perfectScore() == 0
+		const int64_t perfect = (int64_t)rdlen * P.match_bonus;       // Scoring::perfectScore: 0 end to end
 		const uint32_t nsm = 5;
 		const uint32_t nonz = HOT.nonz_tot;
 		const uint64_t ee_hits = (HOT.exact[0].bot - HOT.exact[0].top) + (HOT.exact[1].bot - HOT.exact[1].top) + HOT.mm1_elt;
@@ -1176,7 +1228,9 @@ struct Aligner {
 						ungapped = (read_gaps == 0 && ref_gaps == 0);
 					}
 					int state = 0;   // 0 none, 1 ee, 2 ungapped
-					bool wide = false;   // this DP used the 16-bit cells
+					int mode = 0;        // cell format of this DP (see backtrace)
+					bool sse16 = false;  // the reference's 16-bit kernel produced this matrix (RNG protocol of nextAlignment)
+					uint32_t lastsolcol = 0;
 					bool found = false;
 					DPRect rect;
 					rect.refl = rect.refr = rect.refl_pretrim = rect.refr_pretrim = 0;
@@ -1213,8 +1267,13 @@ struct Aligner {
 							if (HOT.n_ug_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
 							continue;
 						}
-						HOT.n_ug_fail = 0;
-						found = true; state = 2;
+						if (al == -1) {           // several equally good stretches on this diagonal: count a failure, let the DP decide (:1250-1256)
+							HOT.n_ug_fail++;
+							if (HOT.n_ug_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
+						} else {
+							HOT.n_ug_fail = 0;
+							found = true; state = 2;
+						}
 					}
 					if (state == 0) {
 						// DynProgFramer::frameSeedExtensionRect (dp_framer.cpp:81-129), trimToRef
@@ -1235,15 +1294,26 @@ struct Aligner {
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
 						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { HOT.err |= ERR_OVERFLOW; return EXT_HARD_LIMIT; }
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
-						// SwAligner::align (aligner_sw.cpp:500-729): end-to-end 8-bit kernel while minsc >= -254, else 16-bit (:517)
-						wide = minsc < -254;
+						// SwAligner::align (aligner_sw.cpp:500-729).  End to end: 8-bit kernel while minsc >= -254, else 16-bit (:517).
+						// Local: the 8-bit kernel unless it saturates, then the 16-bit one (:568-600); the fill below is exact and
+						// reports whether the 8-bit kernel would have saturated, which only matters for the RNG protocol.
 						const uint64_t td_ = now();
 						fetch_ref_window(tidx, rect.refl, cols + 1);
-						const int64_t best = Plat::dp_fill_ee(P, w, fw, rows, cols, dp.mat, wide);
+						int64_t best;
+						if (P.match_bonus > 0) {
+							mode = 2;
+							uint32_t sat8 = 0;
+							best = Plat::dp_fill_local(P, w, fw, rows, cols, dp.mat, minsc, lastsolcol, sat8);
+							sse16 = sat8 != 0;
+						} else {
+							mode = minsc < -254 ? 1 : 0;
+							sse16 = mode == 1;
+							best = Plat::dp_fill_ee(P, w, fw, rows, cols, dp.mat, mode != 0);
+						}
 						HOT.t_phase[5] += now() - td_;
 						HOT.n_ex_dps++;
 						found = best >= minsc;
-						if (found) { const uint64_t tg_ = now(); gather_cells(rows, cols, minsc, wide); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
+						if (found) { const uint64_t tg_ = now(); gather_cells(fw, rows, cols, minsc, mode, lastsolcol); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
 						if (!found) {
 							HOT.n_dp_fail++;
 							if (HOT.n_dp_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
@@ -1259,7 +1329,7 @@ struct Aligner {
 						} else {
 							if (HOT.cural == HOT.n_cands) break;
 							const uint64_t tb_ = now();
-							const bool na_ = next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, wide, res);
+							const bool na_ = next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, mode, sse16, res);
 							HOT.t_phase[6] += now() - tb_;
 							if (!na_) break;
 						}
@@ -1320,7 +1390,7 @@ struct Aligner {
 		minsc = rp.minsc;
 		const bool filt = (rp.filt & 15u) == 15u;
 		bool done = !filt;
-		const int64_t perfect = 0;
+		const int64_t perfect = (int64_t)len * P.match_bonus;
 		if (!done) {
 			rnd.init(rp.seed);
 			const uint32_t interval = (uint32_t)rp.interval;

@@ -76,7 +76,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--seed") opt.seed = (uint32_t)strtoul(need().c_str(), nullptr, 10);
 		else if (a == "--nofw") opt.nofw = true;
 		else if (a == "--norc") opt.norc = true;
-		else if (a == "--end-to-end") {}
+		else if (a == "--end-to-end") opt.local = false;
 		else if (a == "--ignore-quals") opt.ignore_quals = true;
 		else if (a == "--qc-filter") opt.qc_filter = true;
 		else if (a == "--no-1mm-upfront") opt.no_1mm_upfront = true;
@@ -93,16 +93,17 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--gpu") ex.device = atoi(need().c_str());
 		else if (a == "--met") ex.metrics = true;
 		else if (a == "--batch") ex.batch_reads = strtoull(need().c_str(), nullptr, 10);
-		else if (a == "-D") opt.max_dp_streak = atoi(need().c_str());
-		else if (a == "-R") opt.n_seed_rounds = atoi(need().c_str());
-		else if (a == "-L") { opt.seed_len = atoi(need().c_str()); if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }
+		else if (a == "-D") { opt.max_dp_streak = atoi(need().c_str()); opt.set_D = true; }
+		else if (a == "-R") { opt.n_seed_rounds = atoi(need().c_str()); opt.set_R = true; }
+		else if (a == "-L") { opt.seed_len = atoi(need().c_str()); opt.set_L = true; if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }
+		else if (a == "--local") opt.local = true;
 		else if (a == "-N") { if (atoi(need().c_str()) != 0) err = "-N 1 is outside the MI355X hot path implemented so far"; }
-		else if (a == "-i") { if (!opt.ms_ival.parse(need())) err = "bad -i function"; }
-		else if (a == "--score-min" || a == "--min-score") { if (!opt.score_min.parse(need())) err = "bad --score-min function"; }
+		else if (a == "-i") { opt.set_i = true; if (!opt.ms_ival.parse(need())) err = "bad -i function"; }
+		else if (a == "--score-min" || a == "--min-score") { opt.set_score_min = true; if (!opt.score_min.parse(need())) err = "bad --score-min function"; }
 		else if (a == "--n-ceil") { if (!opt.n_ceil.parse(need())) err = "bad --n-ceil function"; }
 		else if (a == "--dpad") opt.maxhalf = atoi(need().c_str());
 		else if (a == "--gbar") { opt.gbar = atoi(need().c_str()); if (opt.gbar < 1) err = "--gbar must be no less than 1"; }
-		else if (a == "--ma") { if (atoi(need().c_str()) != 0) fprintf(stderr, "Warning: Match bonus always = 0 in --end-to-end mode; ignoring user setting\n"); }
+		else if (a == "--ma") { opt.ma = atoi(need().c_str()); opt.set_ma = true; }
 		else if (a == "--mp") {
 			if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "expected 1 or 2 comma-separated arguments to --mp";
 			else { opt.mp_max = iv[0]; opt.mp_min = iv.size() > 1 ? iv[1] : 2; if (opt.mp_min > opt.mp_max) err = "Maximum mismatch penalty is less than minimum penalty"; }
@@ -111,15 +112,17 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; if (iv.size() > 1) opt.rdg_linear = iv[1]; } }
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
-		else if (a == "-1" || a == "-2" || a == "--local" || a == "-c" || a == "-b" || a == "--interleaved" || a == "-a" || a == "--all" ||
+		else if (a == "-1" || a == "-2" || a == "-c" || a == "-b" || a == "--interleaved" || a == "-a" || a == "--all" ||
 		         a == "--tab5" || a == "--tab6" || a == "--qseq" || a == "-F" || a == "--int-quals" || a == "--solexa-quals" || a == "--trim-to" ||
-		         a == "-I" || a == "-X" || a == "--minins" || a == "--maxins" || a == "--very-fast-local" || a == "--fast-local" ||
-		         a == "--sensitive-local" || a == "--very-sensitive-local")
-			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, end-to-end, -N 0, -k <= 64)";
+		         a == "-I" || a == "-X" || a == "--minins" || a == "--maxins")
+			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -N 0, -k <= 64)";
 		else return "unsupported option " + a;
 		if (!err.empty()) return err;
 	}
 	if (opt.khits > 64) return "-k above 64 is not supported by this build";
+	if (opt.set_ma && !opt.local && opt.ma != 0) fprintf(stderr, "Warning: Match bonus always = 0 in --end-to-end mode; ignoring user setting\n");
+	if (opt.local && opt.set_ma && opt.ma <= 0) return "--local needs a positive --ma in this build";
+	opt.resolve_preset();
 	return "";
 }
 

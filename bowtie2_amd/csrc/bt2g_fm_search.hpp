@@ -223,7 +223,17 @@ BT2_HD void fm_one_mm_dir(const DevIndex<TOff>& ix, const bt2g_align_params& P, 
 						}
 					}
 					score += pen;
-					if (score >= minsc) {
+					bool valid = true;
+					if (P.match_bonus > 0) {
+						// --local: the end-to-end hit must also be a legal local alignment, i.e. its running score may not
+						// touch 0 at the mismatch from either end (aligner_seed.cpp:1231-1260)
+						int64_t fwsc = 0, bwsc = 0;
+						for (uint32_t i = 0; i < len; i++) {
+							if (i == dep) { if (fwsc + pen <= 0) { valid = false; break; } fwsc += pen; } else fwsc += P.match_bonus;
+							if (len - i - 1 == dep) { if (bwsc + pen <= 0) { valid = false; break; } bwsc += pen; } else bwsc += P.match_bonus;
+						}
+					}
+					if (valid && score >= minsc) {
 						Mm1Hit h;
 						h.top = ebwtfw ? (uint64_t)topm : (uint64_t)topmp;
 						h.bot = ebwtfw ? (uint64_t)botm : (uint64_t)botmp;

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -70,6 +71,8 @@ struct Options {
 	int format = 0;               // 0 FASTQ, 1 FASTA (-f), 2 raw (-r)
 	int trim5 = 0, trim3 = 0;
 	int mp_max = 6, mp_min = 2, np = 1, rdg_const = 5, rdg_linear = 3, rfg_const = 5, rfg_linear = 3, gbar = 4, maxhalf = 15;
+	int ma = 0;                   // match bonus (--ma; 2 in --local mode, always 0 end to end)
+	bool set_D = false, set_R = false, set_L = false, set_i = false, set_score_min = false, set_ma = false;
 	std::string rg_id, rgs, rg_optflag;   // @RG header pieces and the per-record RG:Z: flag (bt2_search.cpp:1418-1436)
 	uint32_t seed = 0;
 	int threads = 1;
@@ -82,24 +85,39 @@ struct Options {
 		score_min.init(2, (double)-0.6f, (double)-0.6f);
 		n_ceil.init(2, (double)0.0f, std::numeric_limits<double>::max(), (double)0.0f, (double)0.15f);
 		ms_ival.init(3, (double)1.0f, std::numeric_limits<double>::max(), (double)0.0f, (double)1.15f);
-		apply_preset("sensitive");
+		resolve_preset();
 	}
 	bool apply_preset(const std::string& p) {
-		// presets.cpp:33-91 (PresetsV0), end-to-end flavours
-		if (p == "very-fast")           { max_dp_streak = 5;  n_seed_rounds = 1; seed_mms = 0; seed_len = 22; ms_ival.type = 3; ms_ival.C = 0.0; ms_ival.L = 2.50; }
-		else if (p == "fast")           { max_dp_streak = 10; n_seed_rounds = 2; seed_mms = 0; seed_len = 22; ms_ival.type = 3; ms_ival.C = 0.0; ms_ival.L = 2.50; }
-		else if (p == "sensitive")      { max_dp_streak = 15; n_seed_rounds = 2; seed_mms = 0; seed_len = 22; ms_ival.type = 3; ms_ival.C = 1.0; ms_ival.L = 1.15; }
-		else if (p == "very-sensitive") { max_dp_streak = 20; n_seed_rounds = 3; seed_mms = 0; seed_len = 20; ms_ival.type = 3; ms_ival.C = 1.0; ms_ival.L = 0.50; }
-		else return false;
-		preset = p;
-		return true;
+		// presets.cpp:33-91 (PresetsV0); the *-local flavours are selected by --local (the "%LOCAL%" substitution, bt2_search.cpp:1031)
+		static const char* names[] = {"very-fast", "fast", "sensitive", "very-sensitive"};
+		for (const char* n : names) if (p == n) { preset = p; return true; }
+		for (const char* n : names) if (p == std::string(n) + "-local") { preset = n; local = true; return true; }
+		return false;
+	}
+	// called once after all options are parsed
+	void resolve_preset() {
+		const std::string p = preset + (local ? "-local" : "");
+		struct Row { const char* name; int dps, rounds, seedlen; double c, l; };
+		static const Row rows[] = {
+			{"very-fast", 5, 1, 22, 0.0, 2.50}, {"fast", 10, 2, 22, 0.0, 2.50}, {"sensitive", 15, 2, 22, 1.0, 1.15}, {"very-sensitive", 20, 3, 20, 1.0, 0.50},
+			{"very-fast-local", 5, 1, 25, 1.0, 2.00}, {"fast-local", 10, 2, 22, 1.0, 1.75}, {"sensitive-local", 15, 2, 20, 1.0, 0.75}, {"very-sensitive-local", 20, 3, 20, 1.0, 0.50}};
+		for (const Row& r : rows) if (p == r.name) {
+			if (!set_D) max_dp_streak = r.dps;
+			if (!set_R) n_seed_rounds = r.rounds;
+			if (!set_L) seed_len = r.seedlen;
+			if (!set_i) { ms_ival.type = 3; ms_ival.C = r.c; ms_ival.L = r.l; }
+		}
+		if (local) {
+			if (!set_score_min) score_min.init(4, (double)20.0f, (double)8.0f);     // G,20,8 (DEFAULT_MIN_*_LOCAL)
+			if (!set_ma) ma = 2;                                                    // DEFAULT_MATCH_BONUS_LOCAL
+		} else ma = 0;
 	}
 	void to_params(AlignParams& P, bool large_index) const {
 		// Scoring (scoring.h:60-170): type 3 = Phred-scaled mismatch penalty, anything else = constant mm_max;
 		// gap of length n costs const + n * linear
 		P.mm_type = ignore_quals ? 1 : 3; P.mm_max = mp_max; P.mm_min = ignore_quals ? mp_max : mp_min; P.n_pen = np;
 		P.rdgapo = rdg_const + rdg_linear; P.rdgape = rdg_linear; P.rfgapo = rfg_const + rfg_linear; P.rfgape = rfg_linear;
-		P.gapbar = gbar; P.match_bonus = 0;
+		P.gapbar = gbar; P.match_bonus = local ? ma : 0;
 		P.khits = khits; P.mhits = (saw_k || all_hits) ? 0 : mhits;
 		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
 		if (khits > 1) {
@@ -178,7 +196,7 @@ inline ReadParams compute_read_params(const Options& o, const ReadRec& r) {
 	ReadParams p;
 	const size_t len = r.seq.size();
 	int64_t minsc = o.score_min.f<int64_t>((double)len);
-	if (!o.local && minsc > 0) minsc = 0;
+	if (o.local) { if (minsc < 0) minsc = 0; } else if (minsc > 0) minsc = 0;          // bt2_search.cpp:3352-3372
 	p.minsc = (int32_t)minsc;
 	// N filter (Scoring::nFilter)
 	const size_t maxns = o.n_ceil.f<size_t>((double)len);
@@ -186,7 +204,7 @@ inline ReadParams compute_read_params(const Options& o, const ReadRec& r) {
 	bool nfilt = true;
 	for (size_t i = 0; i < len; i++) if (r.seq[i] == 4) { ns++; if (ns > maxns) { nfilt = false; break; } }
 	// score filter: perfect score (0 in e2e) must reach minsc
-	const bool scfilt = (int64_t)0 >= minsc;
+	const bool scfilt = (int64_t)len * (o.local ? o.ma : 0) >= minsc;       // Scoring::scoreFilter: perfect score must reach minsc
 	const bool lenfilt = !(len <= (size_t)o.seed_mms || len < 2);
 	const bool qcfilt = true;
 	p.filt = (nfilt ? 1u : 0u) | (scfilt ? 2u : 0u) | (lenfilt ? 4u : 0u) | (qcfilt ? 8u : 0u);
@@ -225,7 +243,34 @@ inline void sam_header(std::string& o, const RefInfo& ref, const std::string& cm
 
 // BowtieMapq2::mapq for an unpaired, primary, end-to-end alignment (unique.h:185-330)
 inline int mapq_v2(const Options& o, size_t rdlen, int64_t best, bool has_secbest, int64_t secbest_in) {
-	const int64_t scPer = 0;
+	const int64_t scPer = o.local ? (int64_t)rdlen * o.ma : 0;
+	if (o.local) {
+		// non-monotone branch (unique.h:333-383)
+		const int64_t scMin = o.score_min.f<int64_t>((double)(float)rdlen);
+		const int64_t diff = std::max<int64_t>(1, scPer - scMin);
+		const int64_t bestOver = best - scMin;
+		if (!has_secbest) {
+			if      (bestOver >= diff * (double)0.8f) return 44;
+			else if (bestOver >= diff * (double)0.7f) return 42;
+			else if (bestOver >= diff * (double)0.6f) return 41;
+			else if (bestOver >= diff * (double)0.5f) return 36;
+			else if (bestOver >= diff * (double)0.4f) return 28;
+			else if (bestOver >= diff * (double)0.3f) return 24;
+			return 22;
+		}
+		const int64_t bestdiff = std::llabs(std::llabs(best) - std::llabs(secbest_in));
+		if      (bestdiff >= diff * (double)0.9f) return 40;
+		else if (bestdiff >= diff * (double)0.8f) return 39;
+		else if (bestdiff >= diff * (double)0.7f) return 38;
+		else if (bestdiff >= diff * (double)0.6f) return 37;
+		else if (bestdiff >= diff * (double)0.5f) return bestOver == diff ? 35 : (bestOver >= diff * (double)0.50f ? 25 : 20);
+		else if (bestdiff >= diff * (double)0.4f) return bestOver == diff ? 34 : (bestOver >= diff * (double)0.50f ? 21 : 19);
+		else if (bestdiff >= diff * (double)0.3f) return bestOver == diff ? 33 : (bestOver >= diff * (double)0.5f ? 18 : 16);
+		else if (bestdiff >= diff * (double)0.2f) return bestOver == diff ? 32 : (bestOver >= diff * (double)0.5f ? 17 : 12);
+		else if (bestdiff >= diff * (double)0.1f) return bestOver == diff ? 31 : (bestOver >= diff * (double)0.5f ? 14 : 9);
+		else if (bestdiff > 0) return bestOver >= diff * (double)0.5f ? 11 : 2;
+		return bestOver >= diff * (double)0.5f ? 1 : 0;
+	}
 	const int64_t scMin = o.score_min.f<int64_t>((double)(float)rdlen);
 	int64_t secbest = scMin - 1;
 	const int64_t diff = std::max<int64_t>(1, scPer - scMin);

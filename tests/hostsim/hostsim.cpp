@@ -5,6 +5,7 @@
 // control logic can be diffed against the reference's SAM in a container without a GPU.
 // It is never linked into libbt2g.so or the bowtie2-align-* drop-in: the product path is
 // the HIP kernel only.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,6 +81,83 @@ struct HostPlat {
 		}
 	}
 	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
+	// Local-mode fill (alignNucleotidesLocalSseU8 / ...I16 agree wherever the 8-bit kernel does not saturate): plain
+	// scores in 16-bit fields, floor 0.  Returns the best score; lastsolcol = last column whose maximum reaches minsc;
+	// sat8 = the 8-bit kernel would have saturated (some column maximum + bias >= 255 before its bail-out point).
+	static int64_t dp_fill_local(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, int64_t minsc,
+	                             uint32_t& lastsolcol, uint32_t& sat8) {
+		const uint32_t R = dp_R(rows);
+		uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
+		auto subs = [](int a, int b) { const int v = a - b; return v < 0 ? 0 : v; };
+		// bias of the 8-bit query profile: the largest penalty any (read position, reference character) pair can incur
+		int bias = P.n_pen;
+		for (uint32_t i = 0; i < rows; i++) {
+			const int rdc = rd_char(g_hot, g_hot.len, fw, i);
+			const int q = rd_qual(g_hot, g_hot.len, fw, i) - 33;
+			if (rdc <= 3) { const int mp = mm_penalty(P, q < 0 ? 0 : q); if (mp > bias) bias = mp; }
+		}
+		std::vector<int> Hp(rows, 0), Ep(rows, 0), Hc(rows), Ec(rows), Fc(rows);
+		int vmax = 0;
+		bool bailed = false;
+		lastsolcol = 0; sat8 = 0;
+		for (uint32_t j = 0; j < cols; j++) {
+			const int m = g_hot.rf[j];
+			int refc = 4;
+			for (int b = 0; b < 4; b++) if (m & (1 << b)) { refc = b; break; }
+			int f = 0, colmax = 0;
+			for (uint32_t i = 0; i < rows; i++) {
+				const bool veto = ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar);
+				const int rdc = rd_char(g_hot, g_hot.len, fw, i);
+				const int q = rd_qual(g_hot, g_hot.len, fw, i) - 33;
+				int sc;
+				if (rdc > 3 || refc > 3) sc = -P.n_pen; else sc = (rdc == refc) ? P.match_bonus : -mm_penalty(P, q < 0 ? 0 : q);
+				const int hdiag = (i == 0 || j == 0) ? 0 : Hp[i - 1];
+				const int e = (j == 0) ? 0 : imax(subs(Ep[i], P.rdgape), veto ? 0 : subs(Hp[i], P.rdgapo));
+				f = (i == 0) ? 0 : (veto ? 0 : imax(subs(f, P.rfgape), subs(Hc[i - 1], P.rfgapo)));
+				int h = hdiag + sc; if (h < 0) h = 0;
+				h = imax(imax(h, e), f);
+				Hc[i] = h; Ec[i] = e; Fc[i] = f;
+				if (h > colmax) colmax = h;
+				m64[dp_cell(R, i, j)] = (uint64_t)(uint16_t)h | ((uint64_t)(uint16_t)e << 16) | ((uint64_t)(uint16_t)f << 32);
+			}
+			if (!bailed) {
+				if (colmax > vmax) vmax = colmax;
+				if (colmax + bias >= 255) sat8 = 1;
+				if (colmax < minsc) {
+					if ((int64_t)colmax + (int64_t)(cols - j - 1) * P.match_bonus < minsc) bailed = true;   // the kernels stop here
+				} else lastsolcol = j;
+			}
+			Hp.swap(Hc); Ep.swap(Ec);
+		}
+		return (int64_t)vmax;
+	}
+	// Candidate cells of a local fill, sorted score desc, row desc, col desc
+	static uint32_t gather_local(const uint32_t* mat, BtCand* cands, uint32_t cap, bool fw, uint32_t R, uint32_t rows, uint32_t ncol,
+	                             int64_t minsc, uint32_t minrow) {
+		const uint64_t* m64 = reinterpret_cast<const uint64_t*>(mat);
+		uint32_t n = 0, total = 0;
+		for (uint32_t j = 0; j < ncol; j++) {
+			for (uint32_t i = minrow; i < rows; i++) {
+				const int sc = (int)(m64[dp_cell(R, i, j)] & 0xffff);
+				if (sc < minsc) continue;
+				const int rdc = rd_char(g_hot, g_hot.len, fw, i);
+				const bool match = (g_hot.rf[j] & (1 << rdc)) != 0;        // as the reference: a read N "matches" a reference N mask (16)
+				bool match_succ = false;
+				if (i < rows - 1) { const int rs = rd_char(g_hot, g_hot.len, fw, i + 1); match_succ = (g_hot.rf[j + 1] & (1 << rs)) != 0; }
+				if (!match || match_succ) continue;
+				total++;
+				if (n >= cap) continue;
+				BtCand c; c.score = sc; c.row = (uint16_t)i; c.col = (uint16_t)j;
+				cands[n++] = c;
+			}
+		}
+		std::sort(cands, cands + n, [](const BtCand& a, const BtCand& b) {      // score desc, row desc, col desc
+			if (a.score != b.score) return a.score > b.score;
+			if (a.row != b.row) return a.row > b.row;
+			return a.col > b.col;
+		});
+		return total;
+	}
 	// scalar fill of either representation; returns the best last-row score (de-biased)
 	static int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide) {
 		const uint32_t R = dp_R(rows);
