@@ -117,6 +117,7 @@ struct SatPos {           // SATupleAndPos (aligner_sw_driver.h:144)
 struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };
 
 struct BtCand { int32_t score; uint16_t row, col; };
+constexpr int kMaxLocalScore = 2047;      // counting-sort table of the local candidate gather (scores above share the top bucket)
 constexpr int32_t kCandDone = 1 << 30;   // local mode: candidate already tried (btncanddone_); local scores are small and non-negative
 
 struct BtFrame {          // DpNucFrame
@@ -196,6 +197,7 @@ struct Work {
 	AlnRes   alns[kMaxAlns];
 	// ---- DP ----
 	BtCand   cands[kMaxCands];
+	uint32_t cand_hist[2 * (kMaxLocalScore + 1)];   // scratch of the local gather's counting sort
 	BtFrame  btstack[kMaxLen + kMaxCols];
 	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
 	// ---- status / metrics ----

@@ -764,7 +764,7 @@ struct Aligner {
 			// below the first row that can reach minsc, that is a match whose diagonal successor is not; columns <= lastsolcol
 			const int64_t bonus = P.match_bonus;
 			const uint32_t minrow = (uint32_t)(((minsc_dp + bonus - 1) / bonus) - 1);
-			nc = Plat::gather_local(dp.mat, w.cands, (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow);
+			nc = Plat::gather_local(dp.mat, w.cands, (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow, w.cand_hist);
 		}
 		if (nc > (uint32_t)kMaxCands) { HOT.err |= ERR_OVERFLOW; HOT.n_cands = kMaxCands; } else HOT.n_cands = nc;
 		HOT.t_phase[13] += HOT.n_cands;      // profile: candidate cells
@@ -1052,7 +1052,7 @@ struct Aligner {
 		while (HOT.cural < HOT.n_cands) {
 			BtCand c = w.cands[HOT.cural];
 			if (mode == 2) c.score &= ~kCandDone;
-			if (c.score < minsc) { HOT.cural++; continue; }
+			if (c.score < minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
 			if (mode == 2) {
 				// local: skip candidates "dominated" by one already tried -- within SQ = rows/16 rows and columns of it
 				// (aligner_sw.cpp:754-755,936-960)

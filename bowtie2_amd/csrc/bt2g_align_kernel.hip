@@ -148,6 +148,89 @@ __device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, const Work
 	return __shfl(best, (int)((rows - 1) / R));
 }
 
+// Local-mode fill (alignNucleotidesLocalSseU8 / ...I16; they agree wherever the 8-bit kernel does not saturate):
+// plain scores in 16-bit fields, floor 0.  The column maximum travels down the lanes with the column; the lane that
+// owns the last rows sees every column complete, in order, and replays the kernels' per-column bookkeeping
+// (best score, lastsolcol, bail-out point, "the 8-bit kernel would have saturated").
+template <int R>
+__device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint64_t* __restrict__ scratch,
+                                               int minsc, uint32_t& lastsolcol, uint32_t& sat8) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t nlanes = (rows + R - 1) / R;
+	int rdc[R], mmp[R], veto[R];
+	int bias = P.n_pen;
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const uint32_t i = (uint32_t)lane * R + r;
+		const bool valid = i < rows;
+		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
+		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
+		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 1 : 0;
+		if (valid && rdc[r] <= 3 && mmp[r] > bias) bias = mmp[r];
+	}
+	for (int o = 32; o > 0; o >>= 1) bias = imax(bias, __shfl_xor(bias, o));     // bias of the 8-bit query profile
+	int Hprev[R], Eprev[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
+	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, mycolmax = 0;
+	int vmax = 0, lastsol = 0, sat = 0, bailed = 0;
+	const uint32_t steps = cols + nlanes - 1;
+	const bool last_lane = (uint32_t)lane == nlanes - 1;
+	for (uint32_t t = 0; t < steps; t++) {
+		const int upH = __shfl_up(myHlast, 1);
+		const int upF = __shfl_up(myFlast, 1);
+		const int upMax = __shfl_up(mycolmax, 1);
+		int upRef = __shfl_up(refm, 1);
+		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
+		refm = upRef;
+		const int j = (int)t - lane;
+		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
+		int refc = 4;
+		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
+		int hdiag = (lane == 0 || j == 0) ? 0 : upHdiag;
+		int fin_h = upH, fin_f = upF;
+		int cm = (lane == 0) ? 0 : upMax;
+		int Hnew[R], Enew[R], Fnew[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			int sc;
+			if (rdc[r] > 3 || refc > 3) sc = -P.n_pen; else sc = (rdc[r] == refc) ? P.match_bonus : -mmp[r];
+			const int e = (j == 0) ? 0 : imax(subs0(Eprev[r], P.rdgape), veto[r] ? 0 : subs0(Hprev[r], P.rdgapo));
+			int f;
+			if (lane == 0 && r == 0) f = 0;
+			else f = veto[r] ? 0 : imax(subs0(fin_f, P.rfgape), subs0(fin_h, P.rfgapo));
+			int h = hdiag + sc; if (h < 0) h = 0;
+			h = imax(imax(h, e), f);
+			Hnew[r] = h; Enew[r] = e; Fnew[r] = f;
+			hdiag = Hprev[r];
+			fin_h = h; fin_f = f;
+			if ((uint32_t)lane * R + r < rows) cm = imax(cm, h);
+		}
+		if (active) {
+			uint64_t* base = scratch + ((uint64_t)t * R) * 64 + lane;
+#pragma unroll
+			for (int r = 0; r < R; r++) base[r * 64] = (uint64_t)(uint16_t)Hnew[r] | ((uint64_t)(uint16_t)Enew[r] << 16) | ((uint64_t)(uint16_t)Fnew[r] << 32);
+#pragma unroll
+			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
+			mycolmax = cm;
+			if (last_lane && !bailed) {
+				// end of column j (aligner_swsse_loc_u8.cpp:1305-1335)
+				if (cm > vmax) vmax = cm;
+				if (cm + bias >= 255) sat = 1;
+				if (cm < minsc) { if (cm + (int)(cols - (uint32_t)j - 1) * P.match_bonus < minsc) bailed = 1; }
+				else lastsol = j;
+			}
+		}
+		upHdiag = upH;
+		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
+	}
+	const int src = (int)nlanes - 1;
+	lastsolcol = (uint32_t)__shfl(lastsol, src);
+	sat8 = (uint32_t)__shfl(sat, src);
+	return __shfl(vmax, src);
+}
+
 struct DevPlat {
 	static __device__ __forceinline__ HotWork& hot() { return g_hot; }
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
@@ -241,6 +324,86 @@ struct DevPlat {
 		wave_fence();
 		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
 		wave_fence();
+	}
+	static __device__ __attribute__((noinline)) int64_t dp_fill_local(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat,
+	                                                                  int64_t minsc, uint32_t& lastsolcol, uint32_t& sat8) {
+		wave_fence();
+		uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
+		const int ms = minsc > 0x7fff ? 0x7fff : (int)minsc;
+		int best;
+		switch (dp_R(rows)) {
+			case 1: best = fill_local_wave<1>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+			case 2: best = fill_local_wave<2>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+			case 3: best = fill_local_wave<3>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+			case 4: best = fill_local_wave<4>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+			case 5: best = fill_local_wave<5>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+			case 6: best = fill_local_wave<6>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+			case 7: best = fill_local_wave<7>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+			default: best = fill_local_wave<8>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+		}
+		wave_fence();
+		return (int64_t)best;
+	}
+	// Candidate cells of a local fill (gatherCellsNucleotidesLocalSseU8), ordered score desc, row desc, col desc.
+	// Lanes scan columns; a counting sort on the score places each candidate in its score bucket, then every bucket
+	// (a handful of cells) is ordered by insertion.  hist: 2 * kMaxLocalScore + 2 words of per-wave scratch.
+	static __device__ __attribute__((noinline)) uint32_t gather_local(const uint32_t* mat, BtCand* cands, uint32_t cap, bool fw, uint32_t R, uint32_t rows,
+	                                                                  uint32_t ncol, int64_t minsc, uint32_t minrow, uint32_t* hist) {
+		const uint64_t* m64 = reinterpret_cast<const uint64_t*>(mat);
+		const uint32_t lane = threadIdx.x & 63;
+		const uint32_t nb = (uint32_t)kMaxLocalScore + 1;
+		uint32_t* start = hist + nb;
+		wave_fence();
+		for (uint32_t i = lane; i < 2 * nb; i += 64) hist[i] = 0;
+		wave_fence();
+		auto is_cand = [&](uint32_t i, uint32_t j, int& sc) -> bool {
+			sc = (int)(m64[dp_cell(R, i, j)] & 0xffff);
+			if (sc < minsc) return false;
+			const int rdc = rd_char(g_hot, g_hot.len, fw, i);
+			if ((g_hot.rf[j] & (1 << rdc)) == 0) return false;            // as the reference: a read N "matches" the N mask
+			if (i < rows - 1) { const int rs = rd_char(g_hot, g_hot.len, fw, i + 1); if ((g_hot.rf[j + 1] & (1 << rs)) != 0) return false; }
+			return true;
+		};
+		// pass 1: histogram
+		for (uint32_t j = lane; j < ncol; j += 64)
+			for (uint32_t i = minrow; i < rows; i++) { int sc; if (is_cand(i, j, sc)) atomicAdd(&hist[sc > kMaxLocalScore ? kMaxLocalScore : sc], 1u); }
+		wave_fence();
+		// bucket starts, highest score first (one lane; ~1k adds)
+		uint32_t total = 0;
+		if (lane == 0) { uint32_t acc = 0; for (int sc = kMaxLocalScore; sc >= 0; sc--) { start[sc] = acc; acc += hist[sc]; } total = acc; }
+		total = __shfl(total, 0);
+		wave_fence();
+		if (total > cap) return total;          // the caller flags the overflow
+		// pass 2: scatter (order inside a bucket is arbitrary here); hist[] becomes the per-bucket cursor
+		for (uint32_t i = lane; i < nb; i += 64) hist[i] = 0;
+		wave_fence();
+		for (uint32_t j = lane; j < ncol; j += 64)
+			for (uint32_t i = minrow; i < rows; i++) {
+				int sc;
+				if (!is_cand(i, j, sc)) continue;
+				const int b = sc > kMaxLocalScore ? kMaxLocalScore : sc;
+				const uint32_t pos = start[b] + atomicAdd(&hist[b], 1u);
+				BtCand c; c.score = sc; c.row = (uint16_t)i; c.col = (uint16_t)j;
+				cands[pos] = c;
+			}
+		wave_fence();
+		// pass 3: order every bucket by (row desc, col desc); the top bucket also by score (scores above the table share it)
+		for (uint32_t b = lane; b < nb; b += 64) {
+			const uint32_t s0 = start[b], m = hist[b];
+			for (uint32_t x = 1; x < m; x++) {
+				const BtCand v = cands[s0 + x];
+				uint32_t y = x;
+				while (y > 0) {
+					const BtCand o = cands[s0 + y - 1];
+					const bool o_later = o.score != v.score ? o.score < v.score : (o.row != v.row ? o.row < v.row : o.col < v.col);
+					if (!o_later) break;
+					cands[s0 + y] = o; y--;
+				}
+				cands[s0 + y] = v;
+			}
+		}
+		wave_fence();
+		return total;
 	}
 	// returns the best last-row score (de-biased)
 	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide) {

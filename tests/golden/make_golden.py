@@ -169,7 +169,7 @@ def align_golden(refs):
     for large in (False, True):
         exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
         base = os.path.join(HERE, "tiny_l" if large else "tiny_s")
-        for tag, args in (("sens", ["--sensitive"]), ("vfast", ["--very-fast"]), ("k5", ["-k", "5"])):
+        for tag, args in (("sens", ["--sensitive"]), ("vfast", ["--very-fast"]), ("k5", ["-k", "5"]), ("local", ["--local"])):
             out = os.path.join(HERE, "align_golden_%s_%s.sam" % ("l" if large else "s", tag))
             subprocess.check_call([exe] + args + ["-x", base, "-U", fq, "-p", "1", "-S", out], stderr=subprocess.DEVNULL)
             lines = [l for l in open(out) if not l.startswith("@PG")]

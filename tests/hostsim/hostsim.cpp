@@ -133,7 +133,7 @@ struct HostPlat {
 	}
 	// Candidate cells of a local fill, sorted score desc, row desc, col desc
 	static uint32_t gather_local(const uint32_t* mat, BtCand* cands, uint32_t cap, bool fw, uint32_t R, uint32_t rows, uint32_t ncol,
-	                             int64_t minsc, uint32_t minrow) {
+	                             int64_t minsc, uint32_t minrow, uint32_t* /*hist*/) {
 		const uint64_t* m64 = reinterpret_cast<const uint64_t*>(mat);
 		uint32_t n = 0, total = 0;
 		for (uint32_t j = 0; j < ncol; j++) {

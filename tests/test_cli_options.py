@@ -21,6 +21,8 @@ OPTION_SETS = [
     ["--rg-id", "grp1", "--rg", "SM:x", "--rg", "PL:illumina"], ["-5", "7", "-3", "11"], ["-3", "200"], ["--no-hd"], ["--no-sq"],
     ["-s", "100", "-u", "200"], ["-M", "3"], ["-D", "5", "-R", "1", "-L", "18", "-i", "C,10,0"],
     ["--score-min", "L,-1,-0.3", "--n-ceil", "L,0,0.5"], ["--seed", "77"], ["--very-sensitive", "--nofw"], ["--fast", "--norc"],
+    ["--local"], ["--very-fast-local"], ["--very-sensitive-local", "-k", "3"], ["--local", "--ma", "3", "--mp", "4,2"], ["--local", "--score-min", "G,1,10"],
+    ["--sensitive-local", "--no-unal", "--xeq"],
 ]
 
 
@@ -68,7 +70,7 @@ def test_options_match_reference_hostsim(hostsim, idx, tmp_path):
 
 
 def test_unsupported_options_are_refused(hostsim):
-    for opts in (["--local"], ["-1", "a.fq", "-2", "b.fq"], ["-N", "1"], ["-a"], ["-k", "100"], ["--frobnicate"]):
+    for opts in (["-1", "a.fq", "-2", "b.fq"], ["-N", "1"], ["-a"], ["-k", "100"], ["--frobnicate"]):
         p = subprocess.run([hostsim] + opts + ["-x", os.path.join(GOLD, "tiny_s"), "-U", FQ], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert p.returncode != 0 and p.stdout == "", opts
 

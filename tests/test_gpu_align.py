@@ -25,7 +25,8 @@ def run_ours(args, timeout=300):
 
 @pytest.mark.parametrize("idx,tag,args", [("tiny_s", "s_sens", ["--sensitive"]), ("tiny_s", "s_vfast", ["--very-fast"]),
                                            ("tiny_l", "l_sens", ["--sensitive"]), ("tiny_l", "l_vfast", ["--very-fast"]),
-                                           ("tiny_s", "s_k5", ["-k", "5"]), ("tiny_l", "l_k5", ["-k", "5"])])
+                                           ("tiny_s", "s_k5", ["-k", "5"]), ("tiny_l", "l_k5", ["-k", "5"]),
+                                           ("tiny_s", "s_local", ["--local"]), ("tiny_l", "l_local", ["--local"])])
 def test_golden_sam(idx, tag, args):
     got, err = run_ours(args + ["-x", os.path.join(GOLD, idx), "-U", os.path.join(GOLD, "align_reads.fq")])
     want = open(os.path.join(GOLD, "align_golden_%s.sam" % tag)).read().splitlines()
@@ -73,7 +74,7 @@ def test_differential_vs_reference_binary(large):
     build_index(fa, base, large)
     ref_exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
     for args in (["--sensitive"], ["--very-sensitive"], ["--very-fast"], ["--sensitive", "--norc"], ["--nofw"], ["-k", "5"],
-                 ["-k", "20", "--very-fast"]):
+                 ["-k", "20", "--very-fast"], ["--local"], ["--very-fast-local"], ["--very-sensitive-local", "-k", "3"]):
         rs = os.path.join(d, "ref.sam")
         subprocess.check_call([ref_exe] + args + ["-x", base, "-U", fq, "-p", "8", "--reorder", "-S", rs], stderr=subprocess.DEVNULL)
         want = [l.rstrip("\n") for l in open(rs) if not l.startswith("@PG")]
@@ -100,7 +101,7 @@ def test_long_reads_16bit_dp(large):
     write_fastq(fq, reads)
     build_index(fa, base, large)
     ref_exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
-    for args in (["--sensitive"], ["--very-sensitive"], ["-k", "3"]):
+    for args in (["--sensitive"], ["--very-sensitive"], ["-k", "3"], ["--local"]):
         rs = os.path.join(d, "ref.sam")
         subprocess.check_call([ref_exe] + args + ["-x", base, "-U", fq, "-p", "8", "--reorder", "-S", rs], stderr=subprocess.DEVNULL)
         want = [l.rstrip("\n") for l in open(rs) if not l.startswith("@PG")]

@@ -20,7 +20,8 @@ def hostsim():
 
 @pytest.mark.parametrize("idx,tag,args", [("tiny_s", "s_sens", ["--sensitive"]), ("tiny_s", "s_vfast", ["--very-fast"]),
                                            ("tiny_l", "l_sens", ["--sensitive"]), ("tiny_l", "l_vfast", ["--very-fast"]),
-                                           ("tiny_s", "s_k5", ["-k", "5"]), ("tiny_l", "l_k5", ["-k", "5"])])
+                                           ("tiny_s", "s_k5", ["-k", "5"]), ("tiny_l", "l_k5", ["-k", "5"]),
+                                           ("tiny_s", "s_local", ["--local"]), ("tiny_l", "l_local", ["--local"])])
 def test_sam_identical_to_reference(hostsim, idx, tag, args):
     p = subprocess.run([hostsim] + args + ["-x", os.path.join(GOLD, idx), "-U", os.path.join(GOLD, "align_reads.fq")],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
