@@ -286,7 +286,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (rc) return rc;
 	if (!reads || !params || (!d_rparams && reads->n_reads) || (!d_results && reads->n_reads)) return fail(c, BT2G_ERR_ARG, "bad argument");
 	if (params->khits < 1 || params->khits > 64) return fail(c, BT2G_ERR_UNSUPPORTED, "-k outside [1,64]");
-	if (params->match_bonus != 0) return fail(c, BT2G_ERR_UNSUPPORTED, "--local scoring is not implemented on the device path");
+	if (params->match_bonus < 0) return fail(c, BT2G_ERR_ARG, "negative match bonus");
 	if (reads->n_reads == 0) return 0;
 	if (max_read_len > BT2G_MAX_READ_LEN) max_read_len = BT2G_MAX_READ_LEN;
 	hipStream_t st = (hipStream_t)stream;
