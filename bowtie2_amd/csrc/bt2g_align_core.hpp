@@ -772,15 +772,15 @@ struct Aligner {
 	}
 
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
+	template <int MODE>
 	BT2_HDN bool backtrace(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen,
 	                      int32_t escore, uint32_t row_, uint32_t col_, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi,
-	                      int mode_, AlnRes& res) {
+	                      AlnRes& res) {
 		(void)escore;
 		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
 		const bool fw = Plat::uni((int)fw_) != 0;
 		// cell format: 0 = e2e 8-bit (bias 0xff), 1 = e2e 16-bit (bias 0x7fff), 2 = local (16-bit fields holding plain scores, floor 0)
-		const int mode = Plat::uni(mode_);
-		const bool wide = mode != 0, local = mode == 2;
+		constexpr bool wide = MODE != 0, local = MODE == 2;
 		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
 		uint32_t row = Plat::uni(row_), col = Plat::uni(col_);
 		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
@@ -1075,7 +1075,10 @@ struct Aligner {
 			if (!sse16) rnd.init(reseed);
 			res.nned = 0;
 			const int32_t cscore = c.score;
-			const bool ret = backtrace(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, mode, res);
+			bool ret;
+			if (mode == 0) ret = backtrace<0>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
+			else if (mode == 1) ret = backtrace<1>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
+			else ret = backtrace<2>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
 			rnd.init(sse16 ? reseed : reseed + 1);
 			if (mode == 2) w.cands[HOT.cural].score = cscore | kCandDone;       // btncanddone_: tried, succeeded or not
 			if (ret) { found = true; break; }
