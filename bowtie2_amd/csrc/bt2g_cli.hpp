@@ -13,7 +13,7 @@
 namespace bt2g {
 
 struct CliExtra {
-	int device = 0;
+	std::vector<int> devices;      // --gpu a[,b,...]
 	bool metrics = false;          // --met: per-read work counters on stderr (test aid)
 	bool arg_desc = false;         // --arg-desc
 	size_t batch_reads = 1u << 18;
@@ -90,7 +90,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 			const std::string v = need();
 			if (v.substr(0, 3) == "ID:") { opt.rg_id = "\t" + v; opt.rg_optflag = "RG:Z:" + v.substr(3); } else { opt.rgs += "\t" + v; }
 		}
-		else if (a == "--gpu") ex.device = atoi(need().c_str());
+		else if (a == "--gpu") { if (!split_ints(need(), ',', ex.devices)) err = "--gpu needs a comma-separated list of device indexes"; }
 		else if (a == "--met") ex.metrics = true;
 		else if (a == "--batch") ex.batch_reads = strtoull(need().c_str(), nullptr, 10);
 		else if (a == "-D") { opt.max_dp_streak = atoi(need().c_str()); opt.set_D = true; }

@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bt2g.h"
@@ -88,26 +91,35 @@ int main(int argc, char** argv) {
 		if (ex.arg_desc) { print_arg_desc(); return 0; }
 		if (!err.empty()) die(err, 1);
 	}
-	const int device = ex.device;
 	const bool metrics = ex.metrics;
 	const size_t batch_reads = ex.batch_reads;
 	unsigned long long n_flagged = 0;
 	if (opt.index_base.empty() || opt.reads_file.empty()) die("usage: bowtie2-align-s [options] -x <index> -U <reads.fq> [-S out.sam]");
 
-	bt2g_ctx* ctx = nullptr;
-	int rc = bt2g_ctx_create(device, &ctx);
-	if (rc) die("no usable MI355X (gfx950) device -- this build has no CPU alignment path", 1);
-	HIP_OK(hipSetDevice(device));
+	// --gpu a[,b,...]: one context (full index replica) per listed device; read batches are dealt to whichever device
+	// is free and the writer puts them back in input order (reads are independent: SURVEY.md 8e)
+	std::vector<int> devices = ex.devices;
+	if (devices.empty()) devices.push_back(0);
+	const size_t ndev = devices.size();
+	std::vector<bt2g_ctx*> ctxs(ndev, nullptr);
 	auto t0 = std::chrono::steady_clock::now();
-	rc = bt2g_index_load(ctx, opt.index_base.c_str());
-	if (rc) die(std::string("could not load index: ") + bt2g_last_error(ctx));
+	{
+		std::vector<std::thread> loaders;
+		std::vector<std::string> errs(ndev);
+		for (size_t d = 0; d < ndev; d++) loaders.emplace_back([&, d]() {
+			if (bt2g_ctx_create(devices[d], &ctxs[d])) { errs[d] = "no usable MI355X (gfx950) device " + std::to_string(devices[d]) + " -- this build has no CPU alignment path"; return; }
+			if (bt2g_index_load(ctxs[d], opt.index_base.c_str())) errs[d] = std::string("could not load index: ") + bt2g_last_error(ctxs[d]);
+		});
+		for (auto& t : loaders) t.join();
+		for (const std::string& e : errs) if (!e.empty()) die(e, 1);
+	}
 	bt2g_index_info info;
-	bt2g_index_info_get(ctx, &info);
+	bt2g_index_info_get(ctxs[0], &info);
 	auto t1 = std::chrono::steady_clock::now();
 	RefInfo ref;
 	for (uint64_t i = 0; i < info.n_pat; i++) {
 		const char* nm; uint64_t ln;
-		bt2g_index_refname(ctx, i, &nm, &ln);
+		bt2g_index_refname(ctxs[0], i, &nm, &ln);
 		ref.names.push_back(nm); ref.lens.push_back(ln);
 	}
 	FILE* out = opt.out_file.empty() ? stdout : fopen(opt.out_file.c_str(), "wb");
@@ -125,66 +137,93 @@ int main(int argc, char** argv) {
 	FastqBatcher fq(opt.reads_file, opt, host_threads);
 	if (!fq.ok()) die("cannot open reads file " + opt.reads_file);
 	AlnSummary summ;
+	std::mutex align_mu;
 	double align_s = 0;
 	typedef std::unique_ptr<HostBatch> BatchPtr;
-	BoundedQueue<BatchPtr> q_in(2), q_out(2);
+	BoundedQueue<BatchPtr> q_in(ndev + 1), q_out(ndev + 1);
 
 	std::thread reader([&]() {
+		uint64_t seq = 0;
 		for (;;) {
 			BatchPtr b(new HostBatch());
 			fq.next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
+			b->seqno = seq++;
 			const bool last = b->last;
 			q_in.push(std::move(b));
 			if (last) break;
 		}
+		for (size_t d = 0; d < ndev; d++) { BatchPtr stop(new HostBatch()); stop->terminator = true; q_in.push(std::move(stop)); }
 	});
 	std::thread writer([&]() {
 		std::vector<std::string> parts;
-		for (;;) {
-			BatchPtr b = q_out.pop();
-			const size_t n = b->reads.size();
-			for (size_t i = 0; i < n; i++) {
-				const ReadResult& rr = *(const ReadResult*)(b->res.data() + i * b->stride);
-				if (rr.status) {
-					n_flagged++;
-					fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", b->reads[i].name.c_str(), (int)rr.status);
+		std::map<uint64_t, BatchPtr> pending;       // batches that finished ahead of their turn
+		uint64_t next_seq = 0;
+		bool done = false;
+		while (!done) {
+			BatchPtr got = q_out.pop();
+			pending[got->seqno] = std::move(got);
+			while (!pending.empty() && pending.begin()->first == next_seq) {
+				BatchPtr b = std::move(pending.begin()->second);
+				pending.erase(pending.begin());
+				next_seq++;
+				const size_t n = b->reads.size();
+				for (size_t i = 0; i < n; i++) {
+					const ReadResult& rr = *(const ReadResult*)(b->res.data() + i * b->stride);
+					if (rr.status) {
+						n_flagged++;
+						fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", b->reads[i].name.c_str(), (int)rr.status);
+					}
+					summ.add(rr);
+					if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", b->reads[i].name.c_str(),
+					                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
 				}
-				summ.add(rr);
-				if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", b->reads[i].name.c_str(),
-				                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
+				format_batch(*b, opt, ref, host_threads, parts);
+				for (const std::string& part : parts) fwrite(part.data(), 1, part.size(), out);
+				if (b->last) { done = true; break; }
 			}
-			format_batch(*b, opt, ref, host_threads, parts);
-			for (const std::string& part : parts) fwrite(part.data(), 1, part.size(), out);
-			if (b->last) break;
 		}
 	});
 
-	DevBuf d_seq, d_qual, d_off, d_rp, d_res;
-	for (;;) {
-		BatchPtr b = q_in.pop();
-		if (!b->too_long.empty()) die("read " + b->too_long + " is longer than " + std::to_string(BT2G_MAX_READ_LEN) + " bp (not supported on the device path)");
-		const size_t n = b->reads.size();
-		b->stride = stride;
-		if (n > 0) {
-			d_seq.ensure(b->seq.size() + 16); d_qual.ensure(b->qual.size() + 16);
-			d_off.ensure(b->off.size() * 8); d_rp.ensure(n * sizeof(ReadParams)); d_res.ensure(n * stride);
-			HIP_OK(hipMemcpy(d_seq.p, b->seq.data(), b->seq.size(), hipMemcpyHostToDevice));
-			HIP_OK(hipMemcpy(d_qual.p, b->qual.data(), b->qual.size(), hipMemcpyHostToDevice));
-			HIP_OK(hipMemcpy(d_off.p, b->off.data(), b->off.size() * 8, hipMemcpyHostToDevice));
-			HIP_OK(hipMemcpy(d_rp.p, b->rp.data(), n * sizeof(ReadParams), hipMemcpyHostToDevice));
-			bt2g_reads rd;
-			rd.d_seq = (const uint8_t*)d_seq.p; rd.d_qual = (const uint8_t*)d_qual.p; rd.d_off = (const uint64_t*)d_off.p; rd.n_reads = (uint32_t)n;
-			auto ta = std::chrono::steady_clock::now();
-			rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &P, b->max_len, d_res.p, nullptr);
-			if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
-			HIP_OK(hipDeviceSynchronize());
-			align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
-			b->res.resize(n * stride);
-			HIP_OK(hipMemcpy(b->res.data(), d_res.p, n * stride, hipMemcpyDeviceToHost));
+	auto device_worker = [&](size_t d) {
+		HIP_OK(hipSetDevice(devices[d]));
+		bt2g_ctx* ctx = ctxs[d];
+		hipStream_t st;
+		HIP_OK(hipStreamCreate(&st));
+		DevBuf d_seq, d_qual, d_off, d_rp, d_res;
+		for (;;) {
+			BatchPtr b = q_in.pop();
+			if (b->terminator) break;
+			if (!b->too_long.empty()) die("read " + b->too_long + " is longer than " + std::to_string(BT2G_MAX_READ_LEN) + " bp (not supported on the device path)");
+			const size_t n = b->reads.size();
+			b->stride = stride;
+			if (n > 0) {
+				d_seq.ensure(b->seq.size() + 16); d_qual.ensure(b->qual.size() + 16);
+				d_off.ensure(b->off.size() * 8); d_rp.ensure(n * sizeof(ReadParams)); d_res.ensure(n * stride);
+				HIP_OK(hipMemcpyAsync(d_seq.p, b->seq.data(), b->seq.size(), hipMemcpyHostToDevice, st));
+				HIP_OK(hipMemcpyAsync(d_qual.p, b->qual.data(), b->qual.size(), hipMemcpyHostToDevice, st));
+				HIP_OK(hipMemcpyAsync(d_off.p, b->off.data(), b->off.size() * 8, hipMemcpyHostToDevice, st));
+				HIP_OK(hipMemcpyAsync(d_rp.p, b->rp.data(), n * sizeof(ReadParams), hipMemcpyHostToDevice, st));
+				bt2g_reads rd;
+				rd.d_seq = (const uint8_t*)d_seq.p; rd.d_qual = (const uint8_t*)d_qual.p; rd.d_off = (const uint64_t*)d_off.p; rd.n_reads = (uint32_t)n;
+				HIP_OK(hipStreamSynchronize(st));
+				auto ta = std::chrono::steady_clock::now();
+				const int rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &P, b->max_len, d_res.p, st);
+				if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
+				HIP_OK(hipStreamSynchronize(st));
+				{ std::lock_guard<std::mutex> g(align_mu); align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(); }
+				b->res.resize(n * stride);
+				HIP_OK(hipMemcpyAsync(b->res.data(), d_res.p, n * stride, hipMemcpyDeviceToHost, st));
+				HIP_OK(hipStreamSynchronize(st));
+			}
+			q_out.push(std::move(b));
 		}
-		const bool last = b->last;
-		q_out.push(std::move(b));
-		if (last) break;
+		(void)hipStreamDestroy(st);
+	};
+	{
+		std::vector<std::thread> workers;
+		for (size_t d = 1; d < ndev; d++) workers.emplace_back(device_worker, d);
+		device_worker(0);
+		for (auto& t : workers) t.join();
 	}
 	reader.join();
 	writer.join();
@@ -196,7 +235,7 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "[bt2g] device search time %.3f s\n", align_s);
 	}
 	summ.print(stderr);
-	bt2g_ctx_destroy(ctx);
+	for (bt2g_ctx* c : ctxs) bt2g_ctx_destroy(c);
 	if (n_flagged) {
 		// never pass off a capacity-limited result as the reference's
 		fprintf(stderr, "Error: %llu read(s) exceeded a limit of this build (see the warnings above); their SAM records may differ from bowtie2's\n", (unsigned long long)n_flagged);

@@ -99,6 +99,8 @@ struct HostBatch {
 	uint64_t stride = 0;
 	std::string too_long;                 // name of a read over the length limit (fatal), if any
 	bool last = false;                    // end-of-input marker (may still carry reads)
+	bool terminator = false;              // tells one device worker to stop (carries nothing)
+	uint64_t seqno = 0;                   // position in the input, for ordered output with several devices
 };
 
 // Line-oriented reader over gz or plain input (gzread handles both)

@@ -130,3 +130,14 @@ def test_run_to_run_determinism(large):
         assert p.returncode == 0
         outs.add("\n".join(l for l in p.stderr.splitlines() if l.startswith("MET")))
     assert len(outs) == 1
+
+
+def test_two_device_workers_keep_input_order():
+    """--gpu a,b runs one worker (context + index replica) per listed device and deals batches to whichever is free;
+    the SAM must come out in input order and unchanged.  A single-GPU box lists its device twice."""
+    base = os.path.join(GOLD, "tiny_s")
+    fq = os.path.join(GOLD, "align_reads.fq")
+    want = open(os.path.join(GOLD, "align_golden_s_sens.sam")).read().splitlines()
+    for extra in (["--gpu", "0,0", "--batch", "7", "-p", "3"], ["--gpu", "0,0,0", "--batch", "64"], ["--batch", "1"]):
+        got, err = run_ours(["--sensitive"] + extra + ["-x", base, "-U", fq])
+        assert got == want, extra
