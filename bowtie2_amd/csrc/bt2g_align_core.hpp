@@ -832,20 +832,19 @@ struct Aligner {
 			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
 			const int refm = byte_of(rfw, 3, col);
 			const int readq = byte_of(qlw, 2, fw ? row : rdlen - 1 - row);
-			bool empty = false, can_move_thru = true, branch = false;
+			// Flags are ints combined with & and |: the control code is wave-uniform and this keeps it on 32-bit scalar
+			// compares/selects instead of 64-bit lane-mask juggling.
+			int empty = 0, can_move_thru = 1, branch = 0;
 			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
 			prof.steps++;
 			if (td >= kBtTile) { const uint64_t tt_ = now(); Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi); td = 0; prof.tiles++; prof.tile_t += now() - tt_; }
-			const uint16_t mk0 = (uint16_t)Plat::lane(tile, 48 + td);
-			uint16_t mk = mk0;
-			const bool reported_thru = (mk0 & 1) != 0;
-			if (reported_thru) {
-				can_move_thru = false;
+			const uint32_t mk0 = Plat::lane(tile, 48 + td) & 0xffffu;
+			uint32_t mk = mk0;
+			if (mk0 & 1) {                    // reportedThrough
+				can_move_thru = 0;
 			} else if (row > 0) {
 				const uint32_t row_from_end = rows - row - 1;
-				const bool gaps_allowed = !(row < (uint32_t)S.gapbar || row_from_end < (uint32_t)S.gapbar);
-				// the four packed cells this step can look at (out-of-matrix entries of the tile are 0)
-				// cells as 64-bit values: low word from `tile`, high word (16-bit mode only) from `tile_hi`
+				const int ga = (int)(row >= (uint32_t)S.gapbar) & (int)(row_from_end >= (uint32_t)S.gapbar);     // gaps allowed
 				auto cell = [&](uint32_t ln) -> uint64_t { return (uint64_t)Plat::lane(tile, ln) | (wide ? (uint64_t)Plat::lane(tile_hi, ln) << 32 : 0ull); };
 				const uint64_t c_cur = cell(td);
 				const uint64_t c_up = cell(16 + td);
@@ -854,77 +853,48 @@ struct Aligner {
 				auto Hc = [&](uint64_t c) -> int { return local ? (int)(c & 0xffff) : wide ? (int)(int16_t)(uint16_t)(c & 0xffff) : (int)(c & 0xff); };
 				auto Ec = [&](uint64_t c) -> int { return local ? (int)((c >> 16) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 16) & 0xffff) : (int)((c >> 8) & 0xff); };
 				auto Fc = [&](uint64_t c) -> int { return local ? (int)((c >> 32) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 32) & 0xffff) : (int)((c >> 16) & 0xff); };
-				if (ct == 1) {          // E: came from the left
-					const int sc_cur = Ec(c_cur) + offsetsc;
-					int mask = 0;
-					const int sc_h_left = Hc(c_left) + offsetsc;
-					if (fl(sc_h_left) && sc_h_left - S.rdgapo == sc_cur) mask |= 1;
-					const int sc_e_left = Ec(c_left) + offsetsc;
-					if (fl(sc_e_left) && sc_e_left - S.rdgape == sc_cur) mask |= 2;
-					const int orig_mask = mask;
-					if (mk & (1 << 7)) mask = (mk >> 8) & 3;
-					if (mask == 3) { cur = 3; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7) | (2 << 8)); branch = true; }
-					else if (mask == 2) { cur = 4; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7)); }
-					else if (mask == 1) { cur = 3; mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7)); }
-					else { empty = true; can_move_thru = (orig_mask == 0); }
-				} else if (ct == 2) {   // F: came from above
-					const int sc_h_up = Hc(c_up) + offsetsc;
-					const int sc_f_up = Fc(c_up) + offsetsc;
-					const int sc_cur = Fc(c_cur) + offsetsc;
-					int mask = 0;
-					if (fl(sc_h_up) && sc_h_up - S.rfgapo == sc_cur) mask |= 1;
-					if (fl(sc_f_up) && sc_f_up - S.rfgape == sc_cur) mask |= 2;
-					const int orig_mask = mask;
-					if (mk & (1 << 10)) mask = (mk >> 11) & 3;
-					if (mask == 3) { cur = 1; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10) | (2 << 11)); branch = true; }
-					else if (mask == 2) { cur = 2; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10)); }
-					else if (mask == 1) { cur = 1; mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10)); }
-					else { empty = true; can_move_thru = (orig_mask == 0); }
-				} else {                // H
+				auto fl = [&](int v) -> int { return local ? (int)(v > 0) : 1; };    // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
+				const int hasl = (int)(col > 0);
+				int mask, orig_mask, sel = -1;
+				if (ct == 1) {          // E: came from the left (H-left open = bit 0, E-left extend = bit 1)
+					const int sc_cur = Ec(c_cur) + offsetsc, sc_h_left = Hc(c_left) + offsetsc, sc_e_left = Ec(c_left) + offsetsc;
+					mask = (fl(sc_h_left) & (int)(sc_h_left - S.rdgapo == sc_cur)) | ((fl(sc_e_left) & (int)(sc_e_left - S.rdgape == sc_cur)) << 1);
+					orig_mask = mask;
+					if (mk & (1u << 7)) mask = (int)((mk >> 8) & 3);
+					// both -> take the open (cur 3) and leave the extension for later; else the one there is
+					branch = (int)(mask == 3);
+					if (mask != 0) { cur = (mask == 2) ? 4 : 3; mk = (mk & ~(7u << 7)) | (1u << 7) | (branch ? (2u << 8) : 0u); sel = 0; }
+				} else if (ct == 2) {   // F: came from above (H-up open = bit 0, F-up extend = bit 1)
+					const int sc_cur = Fc(c_cur) + offsetsc, sc_h_up = Hc(c_up) + offsetsc, sc_f_up = Fc(c_up) + offsetsc;
+					mask = (fl(sc_h_up) & (int)(sc_h_up - S.rfgapo == sc_cur)) | ((fl(sc_f_up) & (int)(sc_f_up - S.rfgape == sc_cur)) << 1);
+					orig_mask = mask;
+					if (mk & (1u << 10)) mask = (int)((mk >> 11) & 3);
+					branch = (int)(mask == 3);
+					if (mask != 0) { cur = (mask == 2) ? 2 : 1; mk = (mk & ~(7u << 10)) | (1u << 10) | (branch ? (2u << 11) : 0u); sel = 0; }
+				} else {                // H: bit 0 ref-gap open, 1 read-gap open, 2 ref-gap extend, 3 read-gap extend, 4 diagonal
 					const int sc_cur = Hc(c_cur) + offsetsc;
-					const int sc_f_up = Fc(c_up) + offsetsc;
-					const int sc_h_up = Hc(c_up) + offsetsc;
-					const bool hasl = col > 0;
-					const int sc_h_left = hasl ? Hc(c_left) + offsetsc : 0;
-					const int sc_e_left = hasl ? Ec(c_left) + offsetsc : 0;
-					const int sc_h_upleft = hasl ? Hc(c_upleft) + offsetsc : 0;
+					const int sc_f_up = Fc(c_up) + offsetsc, sc_h_up = Hc(c_up) + offsetsc;
+					const int sc_h_left = Hc(c_left) + offsetsc, sc_e_left = Ec(c_left) + offsetsc, sc_h_upleft = Hc(c_upleft) + offsetsc;
 					const int sc_diag = sc_score(S, readc, refm, readq - 33);
-					int mask = 0;
-					if (gaps_allowed) {
-						if (fl(sc_h_up) && sc_cur == sc_h_up - S.rfgapo) mask |= 1;
-						if (hasl && fl(sc_h_left) && sc_cur == sc_h_left - S.rdgapo) mask |= 2;
-						if (fl(sc_f_up) && sc_cur == sc_f_up - S.rfgape) mask |= 4;
-						if (hasl && fl(sc_e_left) && sc_cur == sc_e_left - S.rdgape) mask |= 8;
+					mask = (ga & fl(sc_h_up) & (int)(sc_cur == sc_h_up - S.rfgapo))
+					     | ((ga & hasl & fl(sc_h_left) & (int)(sc_cur == sc_h_left - S.rdgapo)) << 1)
+					     | ((ga & fl(sc_f_up) & (int)(sc_cur == sc_f_up - S.rfgape)) << 2)
+					     | ((ga & hasl & fl(sc_e_left) & (int)(sc_cur == sc_e_left - S.rdgape)) << 3)
+					     | ((hasl & fl(sc_h_upleft) & (int)(sc_cur == sc_h_upleft + sc_diag)) << 4);
+					orig_mask = mask;
+					if (mk & (1u << 1)) mask = (int)((mk >> 2) & 31);
+					if (mask != 0) {
+						// preference: diagonal, ref-gap open, ref-gap extend, read-gap open, read-gap extend (the only option if there is one)
+						sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
+						branch = (int)((mask & (mask - 1)) != 0);           // more than one option: remember the others
+						mk = (mk & ~(31u << 1)) | (1u << 1) | (branch ? (uint32_t)(mask & ~(1 << sel)) << 2 : 0u);
+						cur = (int)((0x04231u >> (4 * sel)) & 7);          // sel 0,1,2,3,4 -> cur 1,3,2,4,0
 					}
-					if (hasl && fl(sc_h_upleft) && sc_cur == sc_h_upleft + sc_diag) mask |= 16;
-					const int orig_mask = mask;
-					if (mk & (1 << 1)) mask = (mk >> 2) & 31;
-					int opts = 0;
-					for (int q = 0; q < 5; q++) if (mask & (1 << q)) opts++;
-					int select = -1;
-					if (opts == 1) {
-						for (int q = 0; q < 5; q++) if (mask & (1 << q)) { select = q; break; }
-						mk = (uint16_t)((mk & ~(31 << 1)) | (1 << 1));
-					} else if (opts > 1) {
-						if (mask & 16) select = 4;
-						else if (mask & 1) select = 0;
-						else if (mask & 4) select = 2;
-						else if (mask & 2) select = 1;
-						else if (mask & 8) select = 3;
-						mask &= ~(1 << select);
-						mk = (uint16_t)((mk & ~(31 << 1)) | (1 << 1) | (mask << 2));
-						branch = true;
-					}
-					if (select == 4) cur = 0;
-					else if (select == 0) cur = 1;
-					else if (select == 1) cur = 3;
-					else if (select == 2) cur = 2;
-					else if (select == 3) cur = 4;
-					else { empty = true; can_move_thru = (orig_mask == 0); }
 				}
+				if (sel < 0) { empty = 1; can_move_thru = (int)(orig_mask == 0); }
 			}
 			mk |= 1;                         // setReportedThrough
-			if (mk != mk0) dpl.masks[(uint64_t)row * cols + col] = mk;
+			if (mk != mk0) dpl.masks[(uint64_t)row * cols + col] = (uint16_t)mk;
 			if (!can_move_thru) {
 				if (nstack > 0) {
 					td = kBtTile;            // resume elsewhere: the tile is stale
