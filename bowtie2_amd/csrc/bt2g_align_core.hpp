@@ -787,8 +787,7 @@ struct Aligner {
 		S.gapbar = Plat::uni(P.gapbar); S.rdgapo = Plat::uni(P.rdgapo); S.rdgape = Plat::uni(P.rdgape);
 		S.rfgapo = Plat::uni(P.rfgapo); S.rfgape = Plat::uni(P.rfgape); S.match_bonus = Plat::uni(P.match_bonus);
 		S.mm_type = Plat::uni(P.mm_type); S.mm_max = Plat::uni(P.mm_max); S.mm_min = Plat::uni(P.mm_min); S.n_pen = Plat::uni(P.n_pen);
-		const int64_t r_triml = (int64_t)Plat::uni(rect.triml);
-		const uint64_t r_corel = Plat::uni(rect.corel), r_corer = Plat::uni(rect.corer);
+		const int r_triml = (int)Plat::uni(rect.triml), r_corel = (int)Plat::uni(rect.corel), r_corer = (int)Plat::uni(rect.corer);
 		const uint32_t R = dp_R(rows);
 		// `this` lives in private memory: read what the loop needs once, into scalar registers
 		DpScratch dpl;
@@ -812,10 +811,10 @@ struct Aligner {
 		};
 		uint32_t td = 0;     // the caller fetched the tile anchored at (row, col); td = steps taken along its diagonal
 		const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
-		bool olap = false;   // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
-		auto in_core = [&](uint32_t r_, uint32_t c_) -> bool {
-			const int64_t diagi = (int64_t)c_ - (int64_t)r_ + r_triml;
-			return diagi >= 0 && (uint64_t)diagi >= r_corel && (uint64_t)diagi <= r_corer;
+		int olap = 0;        // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
+		auto in_core = [&](uint32_t r_, uint32_t c_) -> int {
+			const int diagi = (int)c_ - (int)r_ + r_triml;          // rows, columns and trims are all < 2^16
+			return (int)(diagi >= r_corel) & (int)(diagi <= r_corer);     // corel >= 0, so diagi >= 0 is implied
 		};
 		uint32_t nstack = 0, ncells = 0, nned = 0;
 		int32_t score = 0, ns = 0;
@@ -900,7 +899,7 @@ struct Aligner {
 					td = kBtTile;            // resume elsewhere: the tile is stale
 					const BtFrame& f = btstack[--nstack];
 					const uint32_t cz_ = Plat::uni(f.celsz);
-					ncells = cz_ & 0x7fffffffu; olap = (cz_ >> 31) != 0; nned = Plat::uni(f.nedsz);
+					ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31); nned = Plat::uni(f.nedsz);
 					row = Plat::uni((uint32_t)f.row); col = Plat::uni((uint32_t)f.col);
 					gaps = Plat::uni((uint32_t)f.gaps); read_gaps = Plat::uni((uint32_t)f.read_gaps); ref_gaps = Plat::uni((uint32_t)f.ref_gaps);
 					score = Plat::uni(f.score); ns = Plat::uni(f.ns); ct = Plat::uni((int)f.ct);
@@ -909,7 +908,7 @@ struct Aligner {
 				return false;
 			}
 			if (empty || row == 0) {
-				olap = olap || in_core(row, col); ncells++;
+				olap |= in_core(row, col); ncells++;
 				trim_beg = row;
 				break;
 			}
@@ -921,7 +920,7 @@ struct Aligner {
 				f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
 			}
 			if (ncells >= (uint32_t)(kMaxLen + 64)) { HOT.err |= ERR_OVERFLOW; return false; }
-			olap = olap || in_core(row, col); ncells++;
+			olap |= in_core(row, col); ncells++;
 			if (nned + 1 >= (uint32_t)kMaxEdits) { HOT.err |= ERR_OVERFLOW; return false; }
 			switch (cur) {
 				case 0: {   // diagonal
@@ -989,7 +988,7 @@ struct Aligner {
 	BT2_HD static int mask2chr(int m) {
 		// mask2dna for single-bit masks and N (alphabet.cpp:71); IUPAC multi-bit masks cannot occur
 		// because the index only stores A/C/G/T and N
-		switch (m) { case 1: return 'A'; case 2: return 'C'; case 4: return 'G'; case 8: return 'T'; default: return 'N'; }
+		return (m == 1 || m == 2 || m == 4 || m == 8) ? (int)code2chr(__builtin_ctz((unsigned)m)) : 'N';
 	}
 
 	// AlnRes::setShape (aligner_result.cpp:72-122) -- edits arrive w.r.t. DP rows (upstream end)
@@ -1183,7 +1182,7 @@ struct Aligner {
 					// GroupWalk2S::advanceElement == Ebwt::getOffset(topf + elt)
 					uint32_t steps = 0;
 					const uint64_t tr_ = now();
-					const TOff joff = get_offset(ix.fw, (TOff)(sp.topf + elt), steps);
+					const TOff joff = Plat::get_offset(ix.fw, (TOff)(sp.topf + elt), steps);
 					HOT.t_phase[4] += now() - tr_;
 					HOT.n_bwops_ext += steps; HOT.n_sides += steps; HOT.n_resolve_steps += steps;
 					if (!ee_mode) nelt_left--;

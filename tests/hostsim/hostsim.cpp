@@ -26,6 +26,7 @@ struct HostPlat {
 	static uint64_t clock() { return 0; }
 	template <typename T> static T uni(T v) { return v; }
 	template <typename T> static T* uni_ptr(T* p) { return p; }
+	template <typename TOff> static TOff get_offset(const DevEbwt<TOff>& e, TOff row, uint32_t& nsteps) { return bt2g::get_offset(e, row, nsteps); }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
 		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
 	}
