@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01b/pmc
+O=$R/gpurun_out/r01c/pmc
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
@@ -12,7 +12,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 cd $R
 python - <<'PY'
 import csv, glob, collections, os
-O=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/r01b/pmc'
+O=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/r01c/pmc'
 out=open(O+'/summary.csv','w')
 out.write('pass,kernel,counter,dispatches,sum\n')
 for p in 'abcd':
