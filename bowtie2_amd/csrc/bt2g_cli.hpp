@@ -61,6 +61,8 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "-q") opt.format = 0;
 		else if (a == "-f") opt.format = 1;
 		else if (a == "-r") opt.format = 2;
+		else if (a == "-c") opt.format = 3;
+		else if (a == "--tab5" || a == "--tab6") { opt.format = 4; opt.reads_file = need(); }
 		else if (a == "-p" || a == "--threads") opt.threads = atoi(need().c_str());
 		else if (a == "--reorder") opt.reorder = true;
 		else if (a == "-t" || a == "--time") opt.timing = true;
@@ -112,8 +114,8 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; if (iv.size() > 1) opt.rdg_linear = iv[1]; } }
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
-		else if (a == "-1" || a == "-2" || a == "-c" || a == "-b" || a == "--interleaved" || a == "-a" || a == "--all" ||
-		         a == "--tab5" || a == "--tab6" || a == "--qseq" || a == "-F" || a == "--int-quals" || a == "--solexa-quals" || a == "--trim-to" ||
+		else if (a == "-1" || a == "-2" || a == "-b" || a == "--interleaved" || a == "-a" || a == "--all" ||
+		         a == "--qseq" || a == "-F" || a == "--int-quals" || a == "--solexa-quals" || a == "--trim-to" ||
 		         a == "-I" || a == "-X" || a == "--minins" || a == "--maxins")
 			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -N 0, -k <= 64)";
 		else return "unsupported option " + a;

@@ -193,6 +193,7 @@ int main(int argc, char** argv) {
 		for (;;) {
 			BatchPtr b = q_in.pop();
 			if (b->terminator) break;
+			if (!b->bad_input.empty()) die(b->bad_input);
 			if (!b->too_long.empty()) die("read " + b->too_long + " is longer than " + std::to_string(BT2G_MAX_READ_LEN) + " bp (not supported on the device path)");
 			const size_t n = b->reads.size();
 			b->stride = stride;

@@ -98,6 +98,7 @@ struct HostBatch {
 	std::vector<uint8_t> res;             // result records, filled by stage 2
 	uint64_t stride = 0;
 	std::string too_long;                 // name of a read over the length limit (fatal), if any
+	std::string bad_input;                // malformed or unsupported input record (fatal), if any
 	bool last = false;                    // end-of-input marker (may still carry reads)
 	bool terminator = false;              // tells one device worker to stop (carries nothing)
 	uint64_t seqno = 0;                   // position in the input, for ordered output with several devices
@@ -151,7 +152,7 @@ private:
 // FASTQ records following FastqPatternSource::parse (pat.cpp): 4-line records, '.' -> N, non-letters dropped
 class FastqBatcher {
 public:
-	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(path), opt_(opt), threads_(threads) {}
+	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(opt.format == 3 ? std::string("/dev/null") : path), opt_(opt), threads_(threads) {}
 	bool ok() const { return src_.ok(); }
 
 	// Fill `b` with up to max_reads reads; sets b.last at end of input (or at -u).
@@ -161,7 +162,7 @@ public:
 		while (recs_.size() < max_reads) {
 			const char* p; size_t n;
 			Raw r;
-			r.qual_off = r.qual_len = 0;
+			r.qual_off = r.qual_len = 0; r.has_qual = false;
 			if (opt_.format == 0) {                    // FASTQ: 4-line records
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
@@ -172,7 +173,7 @@ public:
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
 				if (!src_.next(p, n)) { b.last = true; break; }            // '+' line
 				if (!src_.next(p, n)) { b.last = true; break; }
-				r.qual_off = arena_.size(); r.qual_len = n; arena_.append(p, n);
+				r.qual_off = arena_.size(); r.qual_len = n; arena_.append(p, n); r.has_qual = true;
 			} else if (opt_.format == 1) {             // FASTA: '>' name, sequence possibly over several lines
 				bool got = true;
 				if (!have_pending_) { do { got = src_.next(p, n); } while (got && (n == 0 || p[0] != '>')); if (got) pending_.assign(p, n); }
@@ -185,6 +186,29 @@ public:
 					if (n && p[0] == '>') { pending_.assign(p, n); have_pending_ = true; break; }
 					arena_.append(p, n); r.seq_len += n;
 				}
+			} else if (opt_.format == 3) {             // -c: reads given on the command line, "SEQ[:QUALS]" separated by commas
+				if (cmd_pos_ > opt_.reads_file.size() || opt_.reads_file.empty()) { b.last = true; break; }
+				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				size_t e = opt_.reads_file.find(',', cmd_pos_);
+				if (e == std::string::npos) e = opt_.reads_file.size();
+				const std::string tok = opt_.reads_file.substr(cmd_pos_, e - cmd_pos_);
+				cmd_pos_ = e + 1;
+				const size_t colon = tok.find(':');
+				r.name_off = arena_.size(); r.name_len = 0;
+				r.seq_off = arena_.size(); r.seq_len = colon == std::string::npos ? tok.size() : colon; arena_.append(tok.data(), r.seq_len);
+				if (colon != std::string::npos) { r.qual_off = arena_.size(); r.qual_len = tok.size() - colon - 1; arena_.append(tok.data() + colon + 1, r.qual_len); r.has_qual = true; }
+			} else if (opt_.format == 4) {             // --tab5 / --tab6, unpaired form: name <tab> seq <tab> quals
+				bool got;
+				do { got = src_.next(p, n); } while (got && n == 0);
+				if (!got) { b.last = true; break; }
+				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				const char* t1 = (const char*)memchr(p, '\t', n);
+				const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(p + n - t1 - 1)) : nullptr;
+				if (!t1 || !t2) { b.bad_input = "malformed tab-delimited read record"; b.last = true; break; }
+				if (memchr(t2 + 1, '\t', (size_t)(p + n - t2 - 1))) { b.bad_input = "paired tab-delimited records are outside the hot path implemented so far"; b.last = true; break; }
+				r.name_off = arena_.size(); r.name_len = (size_t)(t1 - p); arena_.append(p, r.name_len);
+				r.seq_off = arena_.size(); r.seq_len = (size_t)(t2 - t1 - 1); arena_.append(t1 + 1, r.seq_len);
+				r.qual_off = arena_.size(); r.qual_len = (size_t)(p + n - t2 - 1); arena_.append(t2 + 1, r.qual_len); r.has_qual = true;
 			} else {                                   // raw: one sequence per line, named by its index
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
@@ -211,7 +235,7 @@ public:
 				rd.seq.reserve(r.seq_len);
 				const char* s = arena_.data() + r.seq_off;
 				for (size_t k = 0; k < r.seq_len; k++) { char ch = s[k]; if (ch == '.') ch = 'N'; if (isalpha((unsigned char)ch)) rd.seq.push_back((char)asc2code(ch)); }
-				if (opt_.format == 0) {
+				if (r.has_qual) {
 					rd.qual.assign(arena_.data() + r.qual_off, r.qual_len);
 					if (opt_.phred64) for (char& q : rd.qual) q = (char)((int)q - 64 + 33 < 33 ? 33 : (int)q - 64 + 33);
 					if (rd.qual.size() > rd.seq.size()) rd.qual.resize(rd.seq.size());   // the reference errors out; we are lenient
@@ -248,12 +272,13 @@ public:
 		});
 	}
 private:
-	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; };
+	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; };
 	LineSource src_;
 	const Options& opt_;
 	unsigned threads_;
 	std::string arena_, pending_;
 	bool have_pending_ = false;
+	size_t cmd_pos_ = 0;
 	std::vector<Raw> recs_;
 	uint64_t rdid_ = 0;
 };

@@ -240,6 +240,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	hb = HostBatch();
 	fq.next(hb, 4096, (size_t)1 << 30);
 	last = hb.last;
+	if (!hb.bad_input.empty()) { fprintf(stderr, "Error: %s\n", hb.bad_input.c_str()); return 1; }
 	for (size_t ri = 0; ri < hb.reads.size(); ri++) {
 		const ReadRec& rd = hb.reads[ri];
 		ReadResult& rr = *(ReadResult*)resbuf.data();

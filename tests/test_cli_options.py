@@ -53,7 +53,10 @@ def input_variants(tmp):
     open(p64, "w").write("".join("@%s\n%s\n+\n%s\n" % (n, s, "".join(chr(ord(c) + 31) for c in q)) for n, s, q in recs))
     with gzip.open(gz, "wt") as f:
         f.write(open(FQ).read())
-    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), ([], gz)]
+    tab = os.path.join(tmp, "r.tab5")
+    open(tab, "w").write("".join("%s\t%s\t%s\n" % (n, s, q) for n, s, q in recs if s))
+    cmdline = ",".join("%s:%s" % (s, q) if i % 2 else s for i, (_, s, q) in enumerate(recs[:12]) if len(s) > 20 and ":" not in q and "," not in q)
+    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), ([], gz), (["--tab5"], tab), (["--tab6"], tab), (["-c"], cmdline)]
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
@@ -65,7 +68,7 @@ def test_options_match_reference_hostsim(hostsim, idx, tmp_path):
         args = opts + ["-x", base, "-U", FQ]
         assert run(hostsim, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts
     for opts, path in input_variants(str(tmp_path)):
-        args = opts + ["-x", base, "-U", path]
+        args = (opts + [path, "-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path])
         assert run(hostsim, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts
 
 
@@ -84,5 +87,5 @@ def test_options_match_reference_gpu(tmp_path):
         args = opts + ["-x", base, "-U", FQ]
         assert run(EXE, args + ["-p", "4"], str(tmp_path)) == run(ref, args, str(tmp_path)), opts
     for opts, path in input_variants(str(tmp_path)):
-        args = opts + ["-x", base, "-U", path]
+        args = (opts + [path, "-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path])
         assert run(EXE, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts
