@@ -314,6 +314,16 @@ struct Aligner {
 	// SeedResults::rankSeedHits, all=false (aligner_seed.h:1019-1080)
 	BT2_HDN void rank_seed_hits() {
 		HOT.n_rank = 0;
+		if (P.all_hits) {
+			// rankSeedHits(all = true): no random draws; offsets 1.. first (fw then rc), offset 0 last (aligner_seed.h:1020-1038)
+			auto push = [&](uint32_t i, bool fw) {
+				if (HOT.n_rank >= (uint32_t)kMaxRanges) { HOT.err |= ERR_OVERFLOW; return; }
+				HOT.rank_offs[HOT.n_rank] = (uint8_t)i; HOT.rank_fw[HOT.n_rank] = fw ? 1 : 0; HOT.n_rank++;
+			};
+			for (uint32_t i = 1; i < HOT.num_offs; i++) for (int fwi = 0; fwi < 2; fwi++) if (HOT.hits[fwi][i].size > 0) push(i, fwi == 0);
+			if (HOT.num_offs > 0) { if (HOT.hits[0][0].size > 0) push(0, true); if (HOT.hits[1][0].size > 0) push(0, false); }
+			return;
+		}
 		while (HOT.n_rank < HOT.nonz_tot) {
 			uint64_t minsz = 0xffffffffull;      // MAX_U32 even for large indexes, as in the reference
 			uint32_t minidx = 0;
@@ -456,7 +466,7 @@ struct Aligner {
 			s.topf = top; s.topb = (uint64_t)kOffMask; s.size = (uint32_t)width; s.orig_sz = (uint32_t)width;
 			s.fw = hit.fw; s.offidx = 0; s.rdoff = 0; s.seedlen = HOT.len; s.nlex = s.nrex = 0;
 			s.ee = ee_idx;
-			r1n_init(s.rnd, (uint32_t)width, false);
+			r1n_init(s.rnd, (uint32_t)width, P.all_hits != 0);
 			nelt_out += width;
 			if (nelt_out >= maxelt) done = true;
 		};
@@ -587,7 +597,7 @@ struct Aligner {
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; break; }
 			SatPos& s = w.satpos[HOT.n_satpos++];
 			s = w.satpos2[j];
-			r1n_init(s.rnd, s.size, false);
+			r1n_init(s.rnd, s.size, P.all_hits != 0);
 			nelt_added += s.size;
 		}
 		if (nelt_added >= maxelt || nsmall == HOT.n_satpos2) { nelt_out = nelt_added; return; }
@@ -619,7 +629,7 @@ struct Aligner {
 			if (pick == 0xffffffffu) pick = last_unelim;
 			const uint32_t ri = pick + sai;
 			R1N& r2 = w.rands2[ri];
-			if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, false);
+			if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, P.all_hits != 0);
 			const uint32_t r = r1n_next(r2);
 			if (r1n_done(r2)) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; }
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; break; }
@@ -628,7 +638,7 @@ struct Aligner {
 			s.topf = w.satpos2[ri].topf + r;
 			s.topb = (uint64_t)kOffMask;
 			s.size = 1;
-			r1n_init(s.rnd, 1, false);
+			r1n_init(s.rnd, 1, P.all_hits != 0);
 			nelt_added++;
 		}
 		nelt_out = nelt_added;
@@ -727,7 +737,7 @@ struct Aligner {
 		HOT.n_alns++;
 		if (!HOT.done_unpair1) {
 			// ReportingState::areDone
-			if (P.mhits <= 0 && HOT.n_alns >= (uint32_t)P.khits) { HOT.done_unpair1 = 1; HOT.exit_k = 1; }
+			if (P.mhits <= 0 && !P.all_hits && HOT.n_alns >= (uint32_t)P.khits) { HOT.done_unpair1 = 1; HOT.exit_k = 1; }
 			else if (P.mhits > 0 && HOT.n_alns > (uint32_t)P.mhits) { HOT.done_unpair1 = 1; HOT.exit_m = 1; }
 		}
 		const int64_t score = r.score;

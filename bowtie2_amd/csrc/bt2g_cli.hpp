@@ -68,6 +68,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "-t" || a == "--time") opt.timing = true;
 		else if (a == "--quiet") opt.quiet = true;
 		else if (a == "-k") { opt.khits = atoi(need().c_str()); opt.saw_k = true; if (opt.khits < 1) err = "-k arg must be at least 1"; }
+		else if (a == "-a" || a == "--all") { opt.all_hits = true; opt.saw_k = false; }
 		else if (a == "-M") { opt.mhits = atoi(need().c_str()); opt.saw_k = false; opt.khits = 1; fprintf(stderr, "Warning: -M is deprecated.  Use -D and -R to adjust effort instead.\n"); }
 		else if (a == "-s" || a == "--skip") opt.skip = strtoull(need().c_str(), nullptr, 10);
 		else if (a == "-u" || a == "--upto" || a == "--qupto") { opt.upto = strtoull(need().c_str(), nullptr, 10); if (opt.upto == 0) opt.upto = UINT64_MAX; }
@@ -114,7 +115,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; if (iv.size() > 1) opt.rdg_linear = iv[1]; } }
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
-		else if (a == "-1" || a == "-2" || a == "-b" || a == "--interleaved" || a == "-a" || a == "--all" ||
+		else if (a == "-1" || a == "-2" || a == "-b" || a == "--interleaved" ||
 		         a == "--qseq" || a == "-F" || a == "--int-quals" || a == "--solexa-quals" || a == "--trim-to" ||
 		         a == "-I" || a == "-X" || a == "--minins" || a == "--maxins")
 			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -N 0, -k <= 64)";

@@ -118,9 +118,12 @@ struct Options {
 		P.mm_type = ignore_quals ? 1 : 3; P.mm_max = mp_max; P.mm_min = ignore_quals ? mp_max : mp_min; P.n_pen = np;
 		P.rdgapo = rdg_const + rdg_linear; P.rdgape = rdg_linear; P.rfgapo = rfg_const + rfg_linear; P.rfgape = rfg_linear;
 		P.gapbar = gbar; P.match_bonus = local ? ma : 0;
-		P.khits = khits; P.mhits = (saw_k || all_hits) ? 0 : mhits;
+		P.khits = all_hits ? 64 : khits; P.mhits = (saw_k || all_hits) ? 0 : mhits; P.all_hits = all_hits ? 1 : 0;
 		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
-		if (khits > 1) {
+		if (all_hits) {
+			// -a lifts every effort limit (bt2_search.cpp:3457-3463)
+			P.max_dp_streak = P.max_ug = P.max_dp = P.max_iters = 0x7fffffff;
+		} else if (khits > 1) {
 			// streak/limit scaling with -k (bt2_search.cpp:3452-3476): maxStreakIncr=10, maxItersIncr=20
 			P.max_dp_streak += (khits - 1) * 10;
 			P.max_ug += (khits - 1) * 20; P.max_dp += (khits - 1) * 20; P.max_iters += (khits - 1) * 20;

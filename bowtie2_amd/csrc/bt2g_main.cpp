@@ -92,7 +92,6 @@ int main(int argc, char** argv) {
 		if (!err.empty()) die(err, 1);
 	}
 	const bool metrics = ex.metrics;
-	const size_t batch_reads = ex.batch_reads;
 	unsigned long long n_flagged = 0;
 	if (opt.index_base.empty() || opt.reads_file.empty()) die("usage: bowtie2-align-s [options] -x <index> -U <reads.fq> [-S out.sam]");
 
@@ -131,6 +130,8 @@ int main(int argc, char** argv) {
 	AlignParams P;
 	opt.to_params(P, info.off_size == 8);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)P.khits);
+	// keep the result records of one batch within ~2 GB (a record holds up to -k alignments of 1.2 KB each)
+	const size_t batch_reads = std::max<size_t>(1024, std::min<size_t>(ex.batch_reads, (size_t)((2ull << 30) / stride)));
 
 	// -p: host threads for FASTQ parsing and SAM formatting (the alignment itself is on the device)
 	const unsigned host_threads = opt.threads > 0 ? (unsigned)opt.threads : 1u;

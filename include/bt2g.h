@@ -204,6 +204,8 @@ typedef struct {
 	int32_t nofw, norc;
 	int32_t do_exact_upfront, do_1mm_upfront, do_ungapped, do_extend;
 	int32_t large_index;           /* RNG draws differ in the 64-bit build (aligner_sw_driver.cpp:103-109) */
+	int32_t all_hits;              /* -a: no limit on alignments, effort limits lifted, deterministic seed order (khits is then
+	                                  only the capacity of the result record; more alignments than that flag the read) */
 } bt2g_align_params;
 
 /* per-read inputs the host derives with the reference's formulas (bt2_search.cpp:3352-3450, pat.cpp:45) */

@@ -233,7 +233,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 8;
 	dp.mat = (uint32_t*)malloc(mat_bytes);
 	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
-	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(opt.khits + 1));
+	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(P.khits + 1));
 	AlnSummary summ;
 	HostBatch hb;
 	for (bool last = false; !last; ) {
