@@ -103,7 +103,37 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "-N") { if (atoi(need().c_str()) != 0) err = "-N 1 is outside the MI355X hot path implemented so far"; }
 		else if (a == "-i") { opt.set_i = true; if (!opt.ms_ival.parse(need())) err = "bad -i function"; }
 		else if (a == "--score-min" || a == "--min-score") { opt.set_score_min = true; if (!opt.score_min.parse(need())) err = "bad --score-min function"; }
-		else if (a == "--n-ceil") { if (!opt.n_ceil.parse(need())) err = "bad --n-ceil function"; }
+		else if (a == "--n-ceil") {
+			// 3 tokens: a function; 1-2 tokens: linear, "L,<const>[,<coeff>]" (bt2_search.cpp:1565-1588)
+			std::string v = need();
+			size_t ncomma = 0; for (char ch : v) if (ch == ',') ncomma++;
+			if (ncomma < 2) v = "L," + v;
+			if (ncomma > 2 || !opt.n_ceil.parse(v)) err = "bad --n-ceil function";
+		}
+		else if (a == "--multiseed") {
+			// N,L,F,C,L: seed mismatches, seed length, interval function (bt2_search.cpp:1545-1564)
+			const std::string v = need();
+			std::vector<std::string> t; size_t p0 = 0;
+			while (true) { const size_t q = v.find(',', p0); t.push_back(v.substr(p0, q == std::string::npos ? q : q - p0)); if (q == std::string::npos) break; p0 = q + 1; }
+			if (t.empty() || t.size() > 5 || t[0].empty()) err = "expected 5 or fewer comma-separated arguments to --multiseed";
+			else {
+				if (atoi(t[0].c_str()) != 0) err = "-N 1 is outside the MI355X hot path implemented so far";
+				if (t.size() > 1) { opt.seed_len = atoi(t[1].c_str()); opt.set_L = true; if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }
+				if (t.size() > 2) {
+					std::string f = t[2];
+					for (size_t k = 3; k < t.size(); k++) f += "," + t[k];
+					opt.set_i = true;
+					if (!opt.ms_ival.parse(f)) err = "bad --multiseed interval function";
+				}
+			}
+		}
+		else if (a == "--trim-to") {
+			const std::string v = need();
+			const size_t colon = v.find(':');
+			if (colon == std::string::npos) { opt.trim_to_side = 3; opt.trim_to_len = atoi(v.c_str()); }
+			else { opt.trim_to_side = atoi(v.substr(0, colon).c_str()); opt.trim_to_len = atoi(v.substr(colon + 1).c_str()); }
+			if ((opt.trim_to_side != 3 && opt.trim_to_side != 5) || opt.trim_to_len < 0) err = "--trim-to: trim position must be either 3 or 5 and the length non-negative";
+		}
 		else if (a == "--dpad") opt.maxhalf = atoi(need().c_str());
 		else if (a == "--gbar") { opt.gbar = atoi(need().c_str()); if (opt.gbar < 1) err = "--gbar must be no less than 1"; }
 		else if (a == "--ma") { opt.ma = atoi(need().c_str()); opt.set_ma = true; }
@@ -116,13 +146,14 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
 		else if (a == "-1" || a == "-2" || a == "-b" || a == "--interleaved" ||
-		         a == "--qseq" || a == "-F" || a == "--int-quals" || a == "--solexa-quals" || a == "--trim-to" ||
+		         a == "--qseq" || a == "-F" || a == "--int-quals" || a == "--solexa-quals" ||
 		         a == "-I" || a == "-X" || a == "--minins" || a == "--maxins")
 			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -N 0, -k <= 64)";
 		else return "unsupported option " + a;
 		if (!err.empty()) return err;
 	}
 	if (opt.khits > 64) return "-k above 64 is not supported by this build";
+	if (opt.trim_to_len >= 0 && (opt.trim5 > 0 || opt.trim3 > 0)) return "--trim-to and -3/-5 are mutually exclusive";
 	if (opt.set_ma && !opt.local && opt.ma != 0) fprintf(stderr, "Warning: Match bonus always = 0 in --end-to-end mode; ignoring user setting\n");
 	if (opt.local && opt.set_ma && opt.ma <= 0) return "--local needs a positive --ma in this build";
 	opt.resolve_preset();

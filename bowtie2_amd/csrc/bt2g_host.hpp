@@ -70,6 +70,7 @@ struct Options {
 	bool qc_filter = false, ignore_quals = false, no_1mm_upfront = false, xeq = false, omit_sec_seq = false, phred64 = false;
 	int format = 0;               // 0 FASTQ, 1 FASTA (-f), 2 raw (-r)
 	int trim5 = 0, trim3 = 0;
+	int trim_to_side = 3, trim_to_len = -1;   // --trim-to [3:|5:]<len>
 	int mp_max = 6, mp_min = 2, np = 1, rdg_const = 5, rdg_linear = 3, rfg_const = 5, rfg_linear = 3, gbar = 4, maxhalf = 15;
 	int ma = 0;                   // match bonus (--ma; 2 in --local mode, always 0 end to end)
 	bool set_D = false, set_R = false, set_L = false, set_i = false, set_score_min = false, set_ma = false;

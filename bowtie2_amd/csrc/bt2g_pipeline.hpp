@@ -128,6 +128,7 @@ public:
 			if (eof_) {
 				if (avail == 0) return false;
 				p = base; n = avail; pos_ = buf_.size();
+				unterminated_ = true;          // last line of the input has no newline
 				if (n && p[n - 1] == '\r') n--;
 				return true;
 			}
@@ -143,6 +144,10 @@ private:
 		buf_.resize(old + (got > 0 ? (size_t)got : 0));
 		if (got <= 0) eof_ = true;
 	}
+	bool unterminated_ = false;
+public:
+	bool last_line_unterminated() const { return unterminated_; }
+private:
 	gzFile f_ = nullptr;
 	std::string buf_;
 	size_t pos_ = 0;
@@ -184,6 +189,8 @@ public:
 				r.seq_off = arena_.size(); r.seq_len = 0;
 				while (src_.next(p, n)) {
 					if (n && p[0] == '>') { pending_.assign(p, n); have_pending_ = true; break; }
+					// the reference's FASTA parser drops the last character of a final line that lacks its newline
+					if (src_.last_line_unterminated() && n > 0) n--;
 					arena_.append(p, n); r.seq_len += n;
 				}
 			} else if (opt_.format == 3) {             // -c: reads given on the command line, "SEQ[:QUALS]" separated by commas
@@ -247,6 +254,12 @@ public:
 					rd.seq.erase(0, t5); rd.qual.erase(0, t5);
 					const size_t t3 = std::min<size_t>((size_t)opt_.trim3, rd.seq.size());
 					rd.seq.resize(rd.seq.size() - t3); rd.qual.resize(rd.qual.size() - t3);
+				}
+				// --trim-to: cut reads longer than the limit from the chosen end (read.h, pat.cpp trimTo)
+				if (opt_.trim_to_len >= 0 && rd.seq.size() > (size_t)opt_.trim_to_len) {
+					const size_t cut = rd.seq.size() - (size_t)opt_.trim_to_len;
+					if (opt_.trim_to_side == 5) { rd.seq.erase(0, cut); rd.qual.erase(0, cut); }
+					else { rd.seq.resize(opt_.trim_to_len); rd.qual.resize(opt_.trim_to_len); }
 				}
 				if (rd.name.empty()) rd.name = std::to_string(r.rdid);
 				b.rp[i] = compute_read_params(opt_, rd);

@@ -1,0 +1,76 @@
+"""The reference's own regression table, re-hosted: tests/golden/simple_tests.json holds the unpaired cases of
+scripts/test/simple_tests.pl (reference sequences, reads, arguments) together with the SAM the *reference* binaries
+print for them (tools/make_simple_tests_fixture.py).  Our binaries must print the same SAM, byte for byte, on both
+index widths -- or refuse the option set outright.  CPU: the host-compiled worker; GPU: the product binary."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from bt2test import have_ref, ref_bin
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HS = os.path.join(ROOT, "tests", "hostsim")
+FIXTURE = os.path.join(ROOT, "tests", "golden", "simple_tests.json")
+# Option sets this build refuses (exit != 0, nothing on stdout) instead of aligning: -N 1 (20), --bwa-sw-like (12), --overhang (12),
+# --policy (4), -X (4)
+MAX_REFUSED = 60
+
+
+@pytest.fixture(scope="module")
+def hostsim():
+    exe = os.path.join(HS, "hostsim")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    return exe
+
+
+def run_cases(exe_s, exe_l, tmp):
+    cases = json.load(open(FIXTURE))
+    assert len(cases) > 150
+    refused, compared, bad = [], 0, []
+    built = {}
+    for rec in cases:
+        for width, exe in (("s", exe_s), ("l", exe_l)):
+            key = (tuple(rec["ref"]), width)
+            if key not in built:
+                d = os.path.join(tmp, "idx%d" % len(built))
+                os.makedirs(d)
+                fa = os.path.join(d, "ref.fa")
+                open(fa, "w").write("".join(">%d\n%s\n" % (i, s) for i, s in enumerate(rec["ref"])))
+                subprocess.check_call([ref_bin("bowtie2-build-l" if width == "l" else "bowtie2-build-s"), "--quiet", fa, os.path.join(d, "idx")],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                built[key] = os.path.join(d, "idx")
+            cmd = [exe] + rec["args"] + ["-x", built[key]]
+            if rec["flag"] == "-c":
+                cmd += ["-c", "-U", rec["input"].strip()]
+            else:
+                rf = os.path.join(tmp, "reads.txt")
+                open(rf, "w").write(rec["input"])
+                cmd += ([rec["flag"], rf] if rec["flag"] == "--tab5" else [rec["flag"], "-U", rf])
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            got = [l for l in p.stdout.splitlines() if not l.startswith("@PG")]
+            if p.returncode != 0 and not got:
+                refused.append((rec["name"], " ".join(rec["args"]), p.stderr.strip().splitlines()[-1:] if p.stderr.strip() else ""))
+                continue
+            compared += 1
+            if got != rec["sam"][width]:
+                bad.append((rec["name"], rec["fw"], width, " ".join(rec["args"])))
+    return compared, refused, bad
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref (bowtie2-build) not present")
+def test_reference_regression_table_hostsim(hostsim, tmp_path):
+    compared, refused, bad = run_cases(hostsim, hostsim, str(tmp_path))
+    assert not bad, (len(bad), bad[:5])
+    assert compared >= 300 and len(refused) <= MAX_REFUSED, (compared, len(refused), refused[:5])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref (bowtie2-build) not present")
+def test_reference_regression_table_gpu(tmp_path):
+    b = os.path.join(ROOT, "bowtie2_amd", "bin")
+    compared, refused, bad = run_cases(os.path.join(b, "bowtie2-align-s"), os.path.join(b, "bowtie2-align-l"), str(tmp_path))
+    assert not bad, (len(bad), bad[:5])
+    assert compared >= 300 and len(refused) <= MAX_REFUSED, (compared, len(refused), refused[:5])
