@@ -62,6 +62,9 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "-f") opt.format = 1;
 		else if (a == "-r") opt.format = 2;
 		else if (a == "-c") opt.format = 3;
+		else if (a == "--qseq") opt.format = 5;
+		else if (a == "--qc-filter") opt.qc_filter = true;
+		else if (a == "--sam-no-qname-trunc") opt.sam_no_qname_trunc = true;
 		else if (a == "--tab5" || a == "--tab6") { opt.format = 4; opt.reads_file = need(); }
 		else if (a == "-p" || a == "--threads") opt.threads = atoi(need().c_str());
 		else if (a == "--reorder") opt.reorder = true;
@@ -81,7 +84,6 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--norc") opt.norc = true;
 		else if (a == "--end-to-end") opt.local = false;
 		else if (a == "--ignore-quals") opt.ignore_quals = true;
-		else if (a == "--qc-filter") opt.qc_filter = true;
 		else if (a == "--no-1mm-upfront") opt.no_1mm_upfront = true;
 		else if (a == "--no-unal") opt.no_unal = true;
 		else if (a == "--xeq") opt.xeq = true;
@@ -146,7 +148,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
 		else if (a == "-1" || a == "-2" || a == "-b" || a == "--interleaved" ||
-		         a == "--qseq" || a == "-F" || a == "--int-quals" || a == "--solexa-quals" ||
+		         a == "-F" || a == "--int-quals" || a == "--solexa-quals" ||
 		         a == "-I" || a == "-X" || a == "--minins" || a == "--maxins")
 			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -N 0, -k <= 64)";
 		else return "unsupported option " + a;

@@ -67,6 +67,7 @@ struct Options {
 	int khits = 1, mhits = 50;
 	bool saw_k = false, all_hits = false, local = false;
 	bool nofw = false, norc = false;
+	bool sam_no_qname_trunc = false;
 	bool qc_filter = false, ignore_quals = false, no_1mm_upfront = false, xeq = false, omit_sec_seq = false, phred64 = false;
 	int format = 0;               // 0 FASTQ, 1 FASTA (-f), 2 raw (-r)
 	int trim5 = 0, trim3 = 0;
@@ -143,6 +144,7 @@ struct ReadRec {
 	std::string name;
 	std::string seq;    // codes 0..4
 	std::string qual;   // ASCII phred+33
+	char filter = '1';  // QSEQ filter field ('0' = failed the instrument's QC; --qc-filter)
 };
 
 // asc2dna (alphabet.cpp:142): A/C/G/T (either case) -> 0..3, every other letter -> 4
@@ -210,7 +212,7 @@ inline ReadParams compute_read_params(const Options& o, const ReadRec& r) {
 	// score filter: perfect score (0 in e2e) must reach minsc
 	const bool scfilt = (int64_t)len * (o.local ? o.ma : 0) >= minsc;       // Scoring::scoreFilter: perfect score must reach minsc
 	const bool lenfilt = !(len <= (size_t)o.seed_mms || len < 2);
-	const bool qcfilt = true;
+	const bool qcfilt = !(o.qc_filter && r.filter == '0');
 	p.filt = (nfilt ? 1u : 0u) | (scfilt ? 2u : 0u) | (lenfilt ? 4u : 0u) | (qcfilt ? 8u : 0u);
 	int nceil = o.n_ceil.f<int>((double)len);
 	if (nceil > (int)len) nceil = (int)len;
@@ -324,7 +326,7 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
                        const ReadResult& rr, const AlnRes* aln, bool primary) {
 	static const char* DNA = "ACGTN";
 	const size_t len = rd.seq.size();
-	sam_print_name(o, rd.name, true);
+	sam_print_name(o, rd.name, !opt.sam_no_qname_trunc);
 	o.push_back('\t');
 	int fl = 0;
 	if (!primary) fl |= 256;

@@ -167,7 +167,7 @@ public:
 		while (recs_.size() < max_reads) {
 			const char* p; size_t n;
 			Raw r;
-			r.qual_off = r.qual_len = 0; r.has_qual = false;
+			r.qual_off = r.qual_len = 0; r.has_qual = false; r.filter = '1';
 			if (opt_.format == 0) {                    // FASTQ: 4-line records
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
@@ -216,6 +216,26 @@ public:
 				r.name_off = arena_.size(); r.name_len = (size_t)(t1 - p); arena_.append(p, r.name_len);
 				r.seq_off = arena_.size(); r.seq_len = (size_t)(t2 - t1 - 1); arena_.append(t1 + 1, r.seq_len);
 				r.qual_off = arena_.size(); r.qual_len = (size_t)(p + n - t2 - 1); arena_.append(t2 + 1, r.qual_len); r.has_qual = true;
+			} else if (opt_.format == 5) {             // --qseq: 11 tab-separated fields (read_qseq.cpp:83-233)
+				bool got;
+				do { got = src_.next(p, n); } while (got && n == 0);
+				if (!got) { b.last = true; break; }
+				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				const char* f[12]; int nf = 0; f[nf++] = p;
+				for (size_t k = 0; k < n && nf < 12; k++) if (p[k] == '\t') f[nf++] = p + k + 1;
+				if (nf != 11) { b.bad_input = "malformed QSEQ record (expected 11 fields)"; b.last = true; break; }
+				f[11] = p + n + 1;
+				auto fld = [&](int k) { return std::string(f[k], (size_t)(f[k + 1] - f[k] - 1)); };
+				// name = machine_run_lane_tile_x_y_index/read
+				std::string nm;
+				for (int k = 0; k < 7; k++) { nm += fld(k); nm.push_back(k == 6 ? '/' : '_'); }
+				nm += fld(7);
+				const std::string sq = fld(8), ql = fld(9), fl = fld(10);
+				if (fl != "0" && fl != "1") { b.bad_input = "Bad value '" + fl + "' for qseq filter flag"; b.last = true; break; }
+				r.name_off = arena_.size(); r.name_len = nm.size(); arena_.append(nm);
+				r.seq_off = arena_.size(); r.seq_len = sq.size(); arena_.append(sq);
+				r.qual_off = arena_.size(); r.qual_len = ql.size(); arena_.append(ql); r.has_qual = true;
+				r.filter = fl[0];
 			} else {                                   // raw: one sequence per line, named by its index
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
@@ -239,6 +259,7 @@ public:
 				const Raw& r = recs_[i];
 				ReadRec& rd = b.reads[i];
 				rd.name.assign(arena_.data() + r.name_off, r.name_len);
+				rd.filter = r.filter;
 				rd.seq.reserve(r.seq_len);
 				const char* s = arena_.data() + r.seq_off;
 				for (size_t k = 0; k < r.seq_len; k++) { char ch = s[k]; if (ch == '.') ch = 'N'; if (isalpha((unsigned char)ch)) rd.seq.push_back((char)asc2code(ch)); }
@@ -285,7 +306,7 @@ public:
 		});
 	}
 private:
-	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; };
+	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; };
 	LineSource src_;
 	const Options& opt_;
 	unsigned threads_;

@@ -17,7 +17,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 SRC = "/root/reference/scripts/test/simple_tests.pl"
 PAIRED_KEYS = {"mate1s", "mate2s", "pairhits", "pairhits_orig", "fastq1", "fastq2", "fasta1", "fasta2", "raw1", "raw2", "qseq1", "qseq2",
                "cline_reads1", "cline_reads2", "tabbed1", "tabbed2", "paired", "mate1fw", "mate2fw", "tlen_map", "pnext_map", "rnext_map"}
-SKIP_KEYS = {"qseq", "cont_fasta_reads", "should_abort"}
+SKIP_KEYS = {"cont_fasta_reads", "should_abort"}
 
 
 def dump_cases():
@@ -51,7 +51,7 @@ def case_inputs(c, fw):
         return "-q", "".join(recs)
     if not fw:
         return None                     # file-based cases run forward only (simple_tests.pl: `next unless $fw`)
-    for key, flag in (("fastq", "-q"), ("fasta", "-f"), ("raw", "-r"), ("tabbed", "--tab5"), ("cline_reads", "-c")):
+    for key, flag in (("fastq", "-q"), ("fasta", "-f"), ("raw", "-r"), ("tabbed", "--tab5"), ("cline_reads", "-c"), ("qseq", "--qseq")):
         if c.get(key) is not None:
             if key == "tabbed" and any(len(l.split("\t")) > 3 for l in c[key].splitlines() if l.strip()):
                 return None             # paired tab5 records
