@@ -140,10 +140,24 @@ struct Options {
 	}
 };
 
+// Non-owning view of characters that live in a batch-level arena (no per-read allocations on the hot host path)
+struct StrView {
+	const char* p = nullptr;
+	uint32_t n = 0;
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	char operator[](size_t i) const { return p[i]; }
+	const char* data() const { return p; }
+	const char* begin() const { return p; }
+	const char* end() const { return p + n; }
+	std::string str() const { return std::string(p, n); }
+	void set(const char* p_, size_t n_) { p = p_; n = (uint32_t)n_; }
+};
+
 struct ReadRec {
-	std::string name;
-	std::string seq;    // codes 0..4
-	std::string qual;   // ASCII phred+33
+	StrView name;
+	StrView seq;        // codes 0..4
+	StrView qual;       // ASCII phred+33
 	char filter = '1';  // QSEQ filter field ('0' = failed the instrument's QC; --qc-filter)
 };
 
@@ -151,37 +165,6 @@ struct ReadRec {
 inline int asc2code(int c) {
 	switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
 }
-
-// minimal FASTQ reader following FastqPatternSource::parse (4-line records, '.' -> N)
-class FastqReader {
-public:
-	explicit FastqReader(const std::string& path) { f_ = path == "-" ? stdin : fopen(path.c_str(), "rb"); }
-	~FastqReader() { if (f_ && f_ != stdin) fclose(f_); }
-	bool ok() const { return f_ != nullptr; }
-	bool next(ReadRec& r, uint64_t rdid) {
-		std::string l1, l2, l3, l4;
-		do { if (!getline(l1)) return false; } while (l1.empty());
-		if (l1[0] != '@') return false;
-		if (!getline(l2) || !getline(l3) || !getline(l4)) return false;
-		r.name = l1.substr(1);
-		r.seq.clear();
-		for (char c : l2) { if (c == '.') c = 'N'; if (isalpha((unsigned char)c)) r.seq.push_back((char)asc2code(c)); }
-		r.qual = l4;
-		if (r.qual.size() > r.seq.size()) r.qual.resize(r.seq.size());   // the reference errors out; we are lenient
-		while (r.qual.size() < r.seq.size()) r.qual.push_back('I');
-		if (r.name.empty()) r.name = std::to_string(rdid);
-		return true;
-	}
-private:
-	bool getline(std::string& s) {
-		s.clear();
-		int c;
-		bool any = false;
-		while ((c = fgetc(f_)) != EOF) { any = true; if (c == '\n') break; if (c != '\r') s.push_back((char)c); }
-		return any;
-	}
-	FILE* f_;
-};
 
 // genRandSeed (pat.cpp:45-84)
 inline uint32_t gen_rand_seed(const ReadRec& r, uint32_t seed) {
@@ -229,7 +212,8 @@ inline ReadParams compute_read_params(const Options& o, const ReadRec& r) {
 // SAM
 struct RefInfo { std::vector<std::string> names; std::vector<uint64_t> lens; };
 
-inline void sam_print_name(std::string& o, const std::string& name, bool truncate) {
+template <typename Str>
+inline void sam_print_name(std::string& o, const Str& name, bool truncate) {
 	size_t n = name.size();
 	if (truncate && n > 255) n = 255;
 	for (size_t i = 0; i < n; i++) { if (truncate && isspace((unsigned char)name[i])) break; o.push_back(name[i]); }
@@ -322,6 +306,16 @@ inline int mapq_v2(const Options& o, size_t rdlen, int64_t best, bool has_secbes
 }
 
 // One SAM record for an unpaired read (AlnSinkSam::appendMate + printAlignedOptFlags)
+// decimal append without the std::to_string temporaries
+inline void app_int(std::string& o, int64_t v) {
+	char buf[24];
+	int n = 0;
+	uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v;
+	do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+	if (v < 0) o.push_back('-');
+	while (n) o.push_back(buf[--n]);
+}
+
 inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, const ReadRec& rd,
                        const ReadResult& rr, const AlnRes* aln, bool primary) {
 	static const char* DNA = "ACGTN";
@@ -332,14 +326,16 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	if (!primary) fl |= 256;
 	if (aln && !aln->fw) fl |= 16;
 	if (!aln) fl |= 4;
-	o += std::to_string(fl); o.push_back('\t');
-	if (aln) { sam_print_name(o, ref.names[aln->refid], true); o.push_back('\t'); o += std::to_string(aln->refoff + 1); o.push_back('\t'); }
+	app_int(o, (int64_t)(fl)); o.push_back('\t');
+	if (aln) { sam_print_name(o, ref.names[aln->refid], true); o.push_back('\t'); app_int(o, (int64_t)(aln->refoff + 1)); o.push_back('\t'); }
 	else o += "*\t0\t";
 	// stacked alignment (StackedAln::init / leftAlign / buildCigar / buildMdz)
-	std::string stRef, stRel, stRead;
+	static thread_local std::string stRef, stRel, stRead, md;
+	static thread_local std::vector<Edit> ed;
+	stRef.clear(); stRel.clear(); stRead.clear();
 	if (aln) {
 		// edits w.r.t. the upstream end: invert for rc (AlnRes::initStacked)
-		std::vector<Edit> ed(aln->ned, aln->ned + aln->nned);
+		ed.assign(aln->ned, aln->ned + aln->nned);
 		size_t trimLS = aln->trim5p, trimRS = aln->trim3p;
 		const size_t len_trimmed = len - trimLS - trimRS;
 		if (!aln->fw) {
@@ -380,19 +376,19 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		// false, and the reference never sets `exhausted`), reports 255
 		const bool can_max = !(opt.saw_k || opt.all_hits) && opt.mhits > 0;
 		if (!primary || (!can_max && !rr.has_secbest)) o += "255";
-		else o += std::to_string(mapq_v2(opt, len, rr.best, rr.has_secbest != 0, rr.secbest));
+		else app_int(o, (int64_t)(mapq_v2(opt, len, rr.best, rr.has_secbest != 0, rr.secbest)));
 		o.push_back('\t');
 		// CIGAR
-		if (trimLS > 0) { o += std::to_string(trimLS); o.push_back('S'); }
+		if (trimLS > 0) { app_int(o, (int64_t)(trimLS)); o.push_back('S'); }
 		for (size_t i = 0; i < ln; i++) {
 			char op = stRel[i];
 			if (!opt.xeq && (op == 'X' || op == '=')) op = 'M';
 			size_t run = 1;
 			for (; i + run < ln; run++) { char op2 = stRel[i + run]; if (!opt.xeq && (op2 == 'X' || op2 == '=')) op2 = 'M'; if (op2 != op) break; }
 			i += (run - 1);
-			o += std::to_string(run); o.push_back(op);
+			app_int(o, (int64_t)(run)); o.push_back(op);
 		}
-		if (trimRS > 0) { o += std::to_string(trimRS); o.push_back('S'); }
+		if (trimRS > 0) { app_int(o, (int64_t)(trimRS)); o.push_back('S'); }
 		o.push_back('\t');
 	} else {
 		o += "0\t*\t";
@@ -406,14 +402,14 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	o.push_back('\t');
 	if (len == 0) o.push_back('*');
 	else if (!primary && opt.omit_sec_seq) o.push_back('*');
-	else if (!aln || aln->fw) o += rd.qual;
-	else o.append(rd.qual.rbegin(), rd.qual.rend());
+	else if (!aln || aln->fw) o.append(rd.qual.data(), rd.qual.size());
+	else for (size_t i = len; i > 0; i--) o.push_back(rd.qual[i - 1]);
 	o.push_back('\t');
 	// optional fields
 	if (aln) {
-		o += "AS:i:" + std::to_string(aln->score);
-		if (rr.has_secbest) o += "\tXS:i:" + std::to_string(rr.secbest);
-		o += "\tXN:i:" + std::to_string(aln->refns);
+		o += "AS:i:"; app_int(o, aln->score);
+		if (rr.has_secbest) { o += "\tXS:i:"; app_int(o, rr.secbest); }
+		o += "\tXN:i:"; app_int(o, aln->refns);
 		size_t num_mm = 0, num_go = 0, num_gx = 0;
 		for (size_t i = 0; i < aln->nned; i++) {
 			const Edit& e = aln->ned[i];
@@ -426,12 +422,10 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 				while (i + 1 < aln->nned && aln->ned[i + 1].pos == aln->ned[i].pos + 1 && aln->ned[i + 1].type == EDIT_REF_GAP) { i++; num_gx++; }
 			}
 		}
-		o += "\tXM:i:" + std::to_string(num_mm) + "\tXO:i:" + std::to_string(num_go) + "\tXG:i:" + std::to_string(num_gx);
-		o += "\tNM:i:" + std::to_string(aln->nned);
-		// YF would go here for filtered reads, but filtered reads never align
-		o += "\tYT:Z:UU";
-		// MD:Z (buildMdz + writeMdz) -- note the reference prints MD:Z before YT:Z? order checked in tests
-		std::string md;
+		o += "\tXM:i:"; app_int(o, (int64_t)num_mm); o += "\tXO:i:"; app_int(o, (int64_t)num_go); o += "\tXG:i:"; app_int(o, (int64_t)num_gx);
+		o += "\tNM:i:"; app_int(o, aln->nned);
+		// MD:Z (buildMdz + writeMdz); the reference prints it before YT:Z
+		md.clear();
 		{
 			bool mm_last = false, rdgap_last = false, first_print = true;
 			const size_t ln = stRef.size();
@@ -443,7 +437,7 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 						if (stRel[i + run] == '=') {} else if (stRel[i + run] == 'I') nins++; else break;
 					}
 					i += (run - 1);
-					if (run - nins > 0) { md += std::to_string(run - nins); first_print = false; mm_last = false; rdgap_last = false; }
+					if (run - nins > 0) { app_int(md, (int64_t)(run - nins)); first_print = false; mm_last = false; rdgap_last = false; }
 				} else if (op == 'X') {
 					if (rdgap_last || mm_last || first_print) md.push_back('0');
 					md.push_back(stRef[i]);
@@ -457,9 +451,9 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 			}
 			if (mm_last || rdgap_last) md.push_back('0');
 		}
-		// reorder: the reference prints MD:Z before YT:Z -- splice it in
-		const size_t ytpos = o.rfind("\tYT:Z:UU");
-		o.insert(ytpos, "\tMD:Z:" + md);
+		o += "\tMD:Z:"; o += md;
+		// YF would go here for filtered reads, but filtered reads never align
+		o += "\tYT:Z:UU";
 	} else {
 		o += "YT:Z:UU";
 		const uint32_t f = rr.filt;

@@ -139,7 +139,7 @@ int main(int argc, char** argv) {
 	if (!fq.ok()) die("cannot open reads file " + opt.reads_file);
 	AlnSummary summ;
 	std::mutex align_mu;
-	double align_s = 0;
+	double align_s = 0, t_format = 0, t_write = 0;
 	typedef std::unique_ptr<HostBatch> BatchPtr;
 	BoundedQueue<BatchPtr> q_in(ndev + 1), q_out(ndev + 1);
 
@@ -172,14 +172,18 @@ int main(int argc, char** argv) {
 					const ReadResult& rr = *(const ReadResult*)(b->res.data() + i * b->stride);
 					if (rr.status) {
 						n_flagged++;
-						fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", b->reads[i].name.c_str(), (int)rr.status);
+						fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", b->reads[i].name.str().c_str(), (int)rr.status);
 					}
 					summ.add(rr);
-					if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", b->reads[i].name.c_str(),
+					if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", b->reads[i].name.str().c_str(),
 					                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
 				}
+				const auto tf0_ = std::chrono::steady_clock::now();
 				format_batch(*b, opt, ref, host_threads, parts);
+				const auto tf1_ = std::chrono::steady_clock::now();
 				for (const std::string& part : parts) fwrite(part.data(), 1, part.size(), out);
+				t_format += std::chrono::duration<double>(tf1_ - tf0_).count();
+				t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf1_).count();
 				if (b->last) { done = true; break; }
 			}
 		}
@@ -235,6 +239,7 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "Time loading forward index: %s\n", hms(std::chrono::duration<double>(t1 - t0).count()).c_str());
 		fprintf(stderr, "Multiseed full-index search: %s\n", hms(align_s).c_str());
 		fprintf(stderr, "[bt2g] device search time %.3f s\n", align_s);
+		fprintf(stderr, "[bt2g] host stages: split %.3f s, parse %.3f s, pack %.3f s, format %.3f s, write %.3f s\n", fq.t_split, fq.t_parse, fq.t_pack, t_format, t_write);
 	}
 	summ.print(stderr);
 	for (bt2g_ctx* c : ctxs) bt2g_ctx_destroy(c);

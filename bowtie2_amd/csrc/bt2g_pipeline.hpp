@@ -13,6 +13,7 @@
 
 #include <zlib.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -90,7 +91,9 @@ private:
 
 // One batch travelling through the pipeline
 struct HostBatch {
-	std::vector<ReadRec> reads;
+	struct Chunk { std::string names, seq, qual; };   // arenas of 4096 reads: names stay here, seq/qual are copied to the packed arrays
+	std::vector<Chunk> chunks;
+	std::vector<ReadRec> reads;                       // views into `chunks` (names) and `seq`/`qual` (packed arrays)
 	std::vector<uint8_t> seq, qual;       // packed device arrays
 	std::vector<uint64_t> off;
 	std::vector<ReadParams> rp;
@@ -160,8 +163,11 @@ public:
 	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(opt.format == 3 ? std::string("/dev/null") : path), opt_(opt), threads_(threads) {}
 	bool ok() const { return src_.ok(); }
 
+	double t_split = 0, t_parse = 0, t_pack = 0;      // seconds spent in each part of next() (-t)
 	// Fill `b` with up to max_reads reads; sets b.last at end of input (or at -u).
 	void next(HostBatch& b, size_t max_reads, size_t max_read_len) {
+		auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t0_ = tnow();
 		// ---- serial part: split the text into records (line copies into one arena)
 		arena_.clear(); recs_.clear();
 		while (recs_.size() < max_reads) {
@@ -248,62 +254,78 @@ public:
 			if (rdid_++ < opt_.skip) continue;
 			recs_.push_back(r);
 		}
-		// ---- parallel part: records -> ReadRec + per-read parameters
+		const double t1_ = tnow();
+		t_split += t1_ - t0_;
+		// ---- parallel part 1: records -> names, codes and qualities in per-chunk arenas (no per-read allocations)
 		const size_t nrec = recs_.size();
+		const size_t chunk = 4096, nchunks = (nrec + chunk - 1) / chunk;
 		b.reads.assign(nrec, ReadRec());
 		b.rp.resize(nrec);
-		const size_t chunk = 4096, nchunks = (nrec + chunk - 1) / chunk;
+		b.chunks.assign(nchunks, HostBatch::Chunk());
+		std::vector<uint32_t> name_off(nrec), name_len(nrec), rlen(nrec);
 		parallel_for(nchunks, threads_, [&](size_t c) {
+			HostBatch::Chunk& ch = b.chunks[c];
+			std::string tseq, tqual;
 			const size_t e = std::min(nrec, (c + 1) * chunk);
 			for (size_t i = c * chunk; i < e; i++) {
 				const Raw& r = recs_[i];
-				ReadRec& rd = b.reads[i];
-				rd.name.assign(arena_.data() + r.name_off, r.name_len);
-				rd.filter = r.filter;
-				rd.seq.reserve(r.seq_len);
+				tseq.clear(); tqual.clear();
 				const char* s = arena_.data() + r.seq_off;
-				for (size_t k = 0; k < r.seq_len; k++) { char ch = s[k]; if (ch == '.') ch = 'N'; if (isalpha((unsigned char)ch)) rd.seq.push_back((char)asc2code(ch)); }
+				for (size_t k = 0; k < r.seq_len; k++) { char chh = s[k]; if (chh == '.') chh = 'N'; if (isalpha((unsigned char)chh)) tseq.push_back((char)asc2code(chh)); }
 				if (r.has_qual) {
-					rd.qual.assign(arena_.data() + r.qual_off, r.qual_len);
-					if (opt_.phred64) for (char& q : rd.qual) q = (char)((int)q - 64 + 33 < 33 ? 33 : (int)q - 64 + 33);
-					if (rd.qual.size() > rd.seq.size()) rd.qual.resize(rd.seq.size());   // the reference errors out; we are lenient
-					while (rd.qual.size() < rd.seq.size()) rd.qual.push_back('I');
-				} else rd.qual.assign(rd.seq.size(), 'I');
+					tqual.assign(arena_.data() + r.qual_off, r.qual_len);
+					if (opt_.phred64) for (char& q : tqual) q = (char)((int)q - 64 + 33 < 33 ? 33 : (int)q - 64 + 33);
+					if (tqual.size() > tseq.size()) tqual.resize(tseq.size());   // the reference errors out; we are lenient
+					while (tqual.size() < tseq.size()) tqual.push_back('I');
+				} else tqual.assign(tseq.size(), 'I');
 				// -5/-3 hard trimming (pat.cpp:726-765)
 				if (opt_.trim5 > 0 || opt_.trim3 > 0) {
-					const size_t t5 = std::min<size_t>((size_t)opt_.trim5, rd.seq.size());
-					rd.seq.erase(0, t5); rd.qual.erase(0, t5);
-					const size_t t3 = std::min<size_t>((size_t)opt_.trim3, rd.seq.size());
-					rd.seq.resize(rd.seq.size() - t3); rd.qual.resize(rd.qual.size() - t3);
+					const size_t t5 = std::min<size_t>((size_t)opt_.trim5, tseq.size());
+					tseq.erase(0, t5); tqual.erase(0, t5);
+					const size_t t3 = std::min<size_t>((size_t)opt_.trim3, tseq.size());
+					tseq.resize(tseq.size() - t3); tqual.resize(tqual.size() - t3);
 				}
-				// --trim-to: cut reads longer than the limit from the chosen end (read.h, pat.cpp trimTo)
-				if (opt_.trim_to_len >= 0 && rd.seq.size() > (size_t)opt_.trim_to_len) {
-					const size_t cut = rd.seq.size() - (size_t)opt_.trim_to_len;
-					if (opt_.trim_to_side == 5) { rd.seq.erase(0, cut); rd.qual.erase(0, cut); }
-					else { rd.seq.resize(opt_.trim_to_len); rd.qual.resize(opt_.trim_to_len); }
+				// --trim-to: cut reads longer than the limit from the chosen end
+				if (opt_.trim_to_len >= 0 && tseq.size() > (size_t)opt_.trim_to_len) {
+					const size_t cut = tseq.size() - (size_t)opt_.trim_to_len;
+					if (opt_.trim_to_side == 5) { tseq.erase(0, cut); tqual.erase(0, cut); }
+					else { tseq.resize(opt_.trim_to_len); tqual.resize(opt_.trim_to_len); }
 				}
-				if (rd.name.empty()) rd.name = std::to_string(r.rdid);
-				b.rp[i] = compute_read_params(opt_, rd);
+				name_off[i] = (uint32_t)ch.names.size();
+				if (r.name_len) ch.names.append(arena_.data() + r.name_off, r.name_len);
+				else ch.names += std::to_string(r.rdid);
+				name_len[i] = (uint32_t)ch.names.size() - name_off[i];
+				rlen[i] = (uint32_t)tseq.size();
+				ch.seq += tseq; ch.qual += tqual;
+				b.reads[i].filter = r.filter;
 			}
 		});
-		// ---- pack the device arrays
+		const double t2_ = tnow();
+		t_parse += t2_ - t1_;
+		// ---- pack the device arrays: a chunk's arenas are already the packed layout of its reads
 		b.off.resize(nrec + 1);
 		b.off[0] = 0;
 		b.max_len = 0;
 		for (size_t i = 0; i < nrec; i++) {
-			const size_t L = b.reads[i].seq.size();
-			if (L > max_read_len && b.too_long.empty()) b.too_long = b.reads[i].name;
+			const size_t L = rlen[i];
 			if (L > b.max_len) b.max_len = (uint32_t)L;
 			b.off[i + 1] = b.off[i] + L;
 		}
 		b.seq.resize(b.off[nrec]); b.qual.resize(b.off[nrec]);
 		parallel_for(nchunks, threads_, [&](size_t c) {
-			const size_t e = std::min(nrec, (c + 1) * chunk);
-			for (size_t i = c * chunk; i < e; i++) {
-				const ReadRec& rd = b.reads[i];
-				if (!rd.seq.empty()) { memcpy(&b.seq[b.off[i]], rd.seq.data(), rd.seq.size()); memcpy(&b.qual[b.off[i]], rd.qual.data(), rd.qual.size()); }
+			const HostBatch::Chunk& ch = b.chunks[c];
+			const size_t i0 = c * chunk, e = std::min(nrec, (c + 1) * chunk);
+			if (!ch.seq.empty()) { memcpy(&b.seq[b.off[i0]], ch.seq.data(), ch.seq.size()); memcpy(&b.qual[b.off[i0]], ch.qual.data(), ch.qual.size()); }
+			for (size_t i = i0; i < e; i++) {
+				ReadRec& rd = b.reads[i];
+				rd.name.set(ch.names.data() + name_off[i], name_len[i]);
+				rd.seq.set((const char*)b.seq.data() + b.off[i], rlen[i]);
+				rd.qual.set((const char*)b.qual.data() + b.off[i], rlen[i]);
+				b.rp[i] = compute_read_params(opt_, rd);
 			}
 		});
+		for (size_t i = 0; i < nrec; i++) if (rlen[i] > max_read_len) { b.too_long = b.reads[i].name.str(); break; }
+		t_pack += tnow() - t2_;
 	}
 private:
 	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; };

@@ -245,7 +245,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		const ReadRec& rd = hb.reads[ri];
 		ReadResult& rr = *(ReadResult*)resbuf.data();
 		if (rd.seq.size() > (size_t)kMaxLen) {
-			fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", rd.name.c_str(), kMaxLen);
+			fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", rd.name.str().c_str(), kMaxLen);
 			return 1;
 		}
 		ReadParams rp = hb.rp[ri];
@@ -254,7 +254,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		memcpy(g_hot.qual, rd.qual.data(), rd.qual.size());
 		Aligner<TOff, HostPlat> al(ix, P, rp, *w, dp);
 		al.run(rr);
-		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d)\n", rd.name.c_str(), rr.status);
+		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d)\n", rd.name.str().c_str(), rr.status);
 		summ.add(rr);
 		o.clear();
 		if (rr.aligned) {
@@ -263,7 +263,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 			sam_record(o, opt, ref, rd, rr, nullptr, true);
 		}
 		fwrite(o.data(), 1, o.size(), out);
-		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u btsteps=%llu tiles=%llu cands=%llu\n", rd.name.c_str(),
+		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u btsteps=%llu tiles=%llu cands=%llu\n", rd.name.str().c_str(),
 		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps,
 		                     (unsigned long long)g_hot.t_phase[11], (unsigned long long)g_hot.t_phase[12], (unsigned long long)g_hot.t_phase[13]);
 	}
