@@ -119,6 +119,7 @@ ABI = [
     ("bt2g_align_timing_read", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("bt2g_align_result_stride", C.c_uint64, [C.c_uint32]),
     ("bt2g_align_batch", C.c_int, [_vp, C.POINTER(Reads), _vp, C.POINTER(AlignParams), C.c_uint32, _vp, _vp]),
+    ("bt2g_results_pack", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
 ]
 
 _lib = None
@@ -253,6 +254,15 @@ class Context:
         _check(self._h, lib().bt2g_align_batch(self._h, C.byref(rd), rparams.data_ptr(), C.byref(params), max_read_len,
                                                 out.data_ptr(), _stream_ptr()), "bt2g_align_batch")
         return out, stride
+
+    def results_pack(self, results, n, khits):
+        """Packed copy of align_batch's records: (uint8 tensor, int64 offsets tensor [n+1]); see bt2g_results_pack."""
+        import torch
+        packed = torch.zeros(results.numel(), dtype=torch.uint8, device=results.device)
+        offs = torch.zeros(n + 1, dtype=torch.int64, device=results.device)
+        _check(self._h, lib().bt2g_results_pack(self._h, results.data_ptr(), n, khits, packed.data_ptr(), offs.data_ptr(),
+                                                 _stream_ptr()), "bt2g_results_pack")
+        return packed, offs
 
     def align_timing(self):
         """ms per kernel of the last align batch: dict(sweep, one_mm, seeds, extend, align)"""

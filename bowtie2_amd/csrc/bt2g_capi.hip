@@ -388,6 +388,15 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	return 0;
 }
 
+int bt2g_results_pack(bt2g_ctx* c, const void* d_results, uint32_t n_reads, uint32_t khits, void* d_packed, uint64_t* d_offsets, void* stream) {
+	if (!c) return BT2G_ERR_ARG;
+	if (!d_results || !d_packed || !d_offsets) return fail(c, BT2G_ERR_ARG, "bt2g_results_pack: null buffer");
+	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
+	if (khits == 0) khits = 1;
+	hipError_t e = launch_pack_results(d_results, bt2g_align_result_stride(khits), n_reads, khits, d_packed, d_offsets, (hipStream_t)stream);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "k_pack_results");
+}
+
 int bt2g_align_timing_read(bt2g_ctx* c, float* out_ms5) {
 	if (!c || !out_ms5) return BT2G_ERR_ARG;
 	for (int i = 0; i < 5; i++) out_ms5[i] = 0.f;

@@ -468,6 +468,7 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 struct AlnSummary {
 	uint64_t nread = 0, n0 = 0, nuni = 0, nrep = 0;
 	// aln_sink.cpp:985-1013,486-512: "exactly 1 time" = one alignment found and not over the -M ceiling
+	void merge(const AlnSummary& o) { nread += o.nread; n0 += o.n0; nuni += o.nuni; nrep += o.nrep; }
 	void add(const ReadResult& r) { nread++; if (!r.aligned) n0++; else if (r.maxed || r.nalns > 1) nrep++; else nuni++; }
 	void print(FILE* f) const {
 		auto pct = [](uint64_t a, uint64_t b) { char buf[32]; snprintf(buf, sizeof buf, "%.2f%%", b ? 100.0 * (double)a / (double)b : 0.0); return std::string(buf); };

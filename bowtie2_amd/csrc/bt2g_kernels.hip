@@ -610,6 +610,76 @@ hipError_t launch_max_seeds(const bt2g_reads& rd, const bt2g_read_params* d_rpar
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// Result packing for the trip to the host: the fixed-stride records (sized for BT2G_MAX_EDITS edits per
+// alignment, ~1.3 KB) are cut to the edits actually present (~0.15 KB for a typical read).
+//   k_pack_sizes : offs[i+1] = bytes of packed record i (offs[0] = 0)
+//   k_pack_scan  : in-place inclusive scan of offs[0..n] (one block; 2 MB of u64 for a 262144-read batch)
+//   k_pack_copy  : one wavefront per read copies header + trimmed alignments as 32-bit words
+// ------------------------------------------------------------------------------------
+static constexpr uint32_t kResHead = (uint32_t)offsetof(bt2g_read_result, alns);
+static constexpr uint32_t kAlnHead = (uint32_t)offsetof(bt2g_aln, ned);
+static_assert(kResHead % 8 == 0 && sizeof(bt2g_aln) % 8 == 0 && sizeof(bt2g_edit) == 6, "packed record layout");
+__device__ __forceinline__ uint32_t packed_aln_bytes(uint32_t nned) { return (kAlnHead + nned * (uint32_t)sizeof(bt2g_edit) + 7u) & ~7u; }
+
+__global__ void __launch_bounds__(256)
+k_pack_sizes(const uint8_t* __restrict__ res, uint64_t stride, uint32_t n, uint32_t khits, uint64_t* __restrict__ offs) {
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r == 0) offs[0] = 0;
+	if (r >= n) return;
+	const bt2g_read_result* rr = (const bt2g_read_result*)(res + (uint64_t)r * stride);
+	uint32_t bytes = kResHead;
+	const uint32_t na = rr->aligned ? min(rr->nreport, khits) : 0u;
+	for (uint32_t k = 0; k < na; k++) bytes += packed_aln_bytes(min((uint32_t)rr->alns[k].nned, (uint32_t)BT2G_MAX_EDITS));
+	offs[r + 1] = bytes;
+}
+
+__global__ void __launch_bounds__(1024)
+k_pack_scan(uint64_t* __restrict__ offs, uint32_t n1) {
+	__shared__ uint64_t part[1024];
+	const uint32_t t = threadIdx.x, per = (n1 + 1023) / 1024;
+	const uint32_t b = min(n1, t * per), e = min(n1, b + per);
+	uint64_t sum = 0;
+	for (uint32_t i = b; i < e; i++) sum += offs[i];
+	part[t] = sum;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) {
+		const uint64_t v = t >= d ? part[t - d] : 0;
+		__syncthreads();
+		part[t] += v;
+		__syncthreads();
+	}
+	uint64_t run = part[t] - sum;     // exclusive prefix of this thread's slice
+	for (uint32_t i = b; i < e; i++) { run += offs[i]; offs[i] = run; }
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_copy(const uint8_t* __restrict__ res, uint64_t stride, uint32_t n, uint32_t khits, const uint64_t* __restrict__ offs, uint8_t* __restrict__ out) {
+	const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (r >= n) return;
+	const uint8_t* src = res + (uint64_t)r * stride;
+	uint8_t* dst = out + offs[r];
+	const bt2g_read_result* rr = (const bt2g_read_result*)src;
+	const uint32_t na = rr->aligned ? min(rr->nreport, khits) : 0u;
+	if (lane < kResHead / 4) ((uint32_t*)dst)[lane] = ((const uint32_t*)src)[lane];
+	if (lane == 0 && na != rr->nreport) ((bt2g_read_result*)dst)->nreport = na;
+	dst += kResHead;
+	for (uint32_t k = 0; k < na; k++) {
+		const uint32_t* a = (const uint32_t*)&rr->alns[k];
+		const uint32_t words = packed_aln_bytes(min((uint32_t)rr->alns[k].nned, (uint32_t)BT2G_MAX_EDITS)) / 4;
+		for (uint32_t w = lane; w < words; w += 64) ((uint32_t*)dst)[w] = a[w];
+		dst += words * 4;
+	}
+}
+
+hipError_t launch_pack_results(const void* d_results, uint64_t stride, uint32_t n, uint32_t khits, void* d_packed, uint64_t* d_offsets, hipStream_t st) {
+	if (n == 0) return hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), st);
+	hipLaunchKernelGGL(k_pack_sizes, dim3((n + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_results, stride, n, khits, d_offsets);
+	hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, d_offsets, n + 1);
+	hipLaunchKernelGGL(k_pack_copy, dim3((n + 3) / 4), dim3(256), 0, st, (const uint8_t*)d_results, stride, n, khits, (const uint64_t*)d_offsets, (uint8_t*)d_packed);
+	return hipGetLastError();
+}
+
 // explicit instantiations
 template hipError_t launch_exact_sweep<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, int, int, uint32_t, bt2g_sweep_out*, DevCounters*, hipStream_t);
 template hipError_t launch_exact_sweep<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, int, int, uint32_t, bt2g_sweep_out*, DevCounters*, hipStream_t);

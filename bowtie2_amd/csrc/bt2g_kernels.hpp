@@ -17,6 +17,7 @@ hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& 
                                     const uint32_t* d_interval, const uint32_t* d_offset, const bt2g_read_params* d_rparams,
                                     uint32_t max_seeds, bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st);
 
+hipError_t launch_pack_results(const void* d_results, uint64_t stride, uint32_t n, uint32_t khits, void* d_packed, uint64_t* d_offsets, hipStream_t st);
 hipError_t launch_max_seeds(const bt2g_reads& rd, const bt2g_read_params* d_rparams, unsigned int* d_out, hipStream_t st);
 
 // batch pre-computation for the fused worker (round-0 seed-hit extension, 1-mismatch e2e search)

@@ -37,6 +37,26 @@ struct DevBuf {
 	~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+// Page-locked host buffers for the result records, recycled from batch to batch (a fresh pageable buffer per
+// batch costs more in page faults and staging copies than the alignment itself).
+class PinnedPool {
+public:
+	std::shared_ptr<void> get(size_t n) {
+		void* p = nullptr; size_t cap = 0;
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			for (size_t i = 0; i < free_.size(); i++) if (free_[i].second >= n) { p = free_[i].first; cap = free_[i].second; free_.erase(free_.begin() + (long)i); break; }
+			if (!p && !free_.empty()) { (void)hipHostFree(free_.back().first); free_.pop_back(); }   // too small: replace it
+		}
+		if (!p) { cap = n + n / 4 + (1u << 20); HIP_OK(hipHostMalloc(&p, cap, hipHostMallocPortable)); }
+		return std::shared_ptr<void>(p, [this, cap](void* q) { std::lock_guard<std::mutex> g(mu_); free_.emplace_back(q, cap); });
+	}
+	~PinnedPool() { for (auto& f : free_) (void)hipHostFree(f.first); }
+private:
+	std::mutex mu_;
+	std::vector<std::pair<void*, size_t>> free_;
+};
+
 // The option interface of bowtie2-align (name:takes-argument), in the order `--arg-desc` lists it
 // (printArgDesc, bt2_search.cpp:710-747).  The Perl wrapper asks for this table (`--wrapper basic-0 --arg-desc`,
 // bowtie2:104) to tell the aligner's options from its own, so a drop-in has to answer with the same names --
@@ -141,7 +161,8 @@ int main(int argc, char** argv) {
 	std::mutex align_mu;
 	double align_s = 0, t_format = 0, t_write = 0;
 	typedef std::unique_ptr<HostBatch> BatchPtr;
-	BoundedQueue<BatchPtr> q_in(ndev + 1), q_out(ndev + 1);
+	const size_t kWorkersPerDev = 3;
+	BoundedQueue<BatchPtr> q_in(ndev * kWorkersPerDev + 1), q_out(ndev * kWorkersPerDev + 1);
 
 	std::thread reader([&]() {
 		uint64_t seq = 0;
@@ -153,7 +174,7 @@ int main(int argc, char** argv) {
 			q_in.push(std::move(b));
 			if (last) break;
 		}
-		for (size_t d = 0; d < ndev; d++) { BatchPtr stop(new HostBatch()); stop->terminator = true; q_in.push(std::move(stop)); }
+		for (size_t d = 0; d < ndev * kWorkersPerDev; d++) { BatchPtr stop(new HostBatch()); stop->terminator = true; q_in.push(std::move(stop)); }
 	});
 	std::thread writer([&]() {
 		std::vector<std::string> parts;
@@ -167,19 +188,19 @@ int main(int argc, char** argv) {
 				BatchPtr b = std::move(pending.begin()->second);
 				pending.erase(pending.begin());
 				next_seq++;
-				const size_t n = b->reads.size();
-				for (size_t i = 0; i < n; i++) {
-					const ReadResult& rr = *(const ReadResult*)(b->res.data() + i * b->stride);
-					if (rr.status) {
-						n_flagged++;
-						fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", b->reads[i].name.str().c_str(), (int)rr.status);
-					}
-					summ.add(rr);
-					if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", b->reads[i].name.str().c_str(),
-					                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
-				}
 				const auto tf0_ = std::chrono::steady_clock::now();
-				format_batch(*b, opt, ref, host_threads, parts);
+				BatchTally tally;
+				format_batch(*b, opt, ref, host_threads, parts, tally);
+				summ.merge(tally.summ);
+				for (size_t i : tally.flagged) {
+					n_flagged++;
+					fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", b->reads[i].name.str().c_str(), (int)b->result(i).status);
+				}
+				if (metrics) for (size_t i = 0; i < b->reads.size(); i++) {
+					const ReadResult& rr = b->result(i);
+					fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u\n", b->reads[i].name.str().c_str(),
+					        rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
+				}
 				const auto tf1_ = std::chrono::steady_clock::now();
 				for (const std::string& part : parts) fwrite(part.data(), 1, part.size(), out);
 				t_format += std::chrono::duration<double>(tf1_ - tf0_).count();
@@ -189,22 +210,28 @@ int main(int argc, char** argv) {
 		}
 	});
 
+	// Device stage: kWorkersPerDev threads per device, each with its own stream and buffers, so that one batch's
+	// upload and another's download overlap the alignment of a third.  The context (its work arenas) is used by
+	// one thread at a time; the writer puts the batches back in input order.
+	PinnedPool pinned;
+	std::vector<std::mutex> ctx_mu(ndev);
 	auto device_worker = [&](size_t d) {
 		HIP_OK(hipSetDevice(devices[d]));
 		bt2g_ctx* ctx = ctxs[d];
 		hipStream_t st;
 		HIP_OK(hipStreamCreate(&st));
-		DevBuf d_seq, d_qual, d_off, d_rp, d_res;
+		DevBuf d_seq, d_qual, d_off, d_rp, d_res, d_packed, d_poff;
 		for (;;) {
 			BatchPtr b = q_in.pop();
 			if (b->terminator) break;
 			if (!b->bad_input.empty()) die(b->bad_input);
 			if (!b->too_long.empty()) die("read " + b->too_long + " is longer than " + std::to_string(BT2G_MAX_READ_LEN) + " bp (not supported on the device path)");
 			const size_t n = b->reads.size();
-			b->stride = stride;
+			b->res_off.assign(n + 1, 0);
 			if (n > 0) {
 				d_seq.ensure(b->seq.size() + 16); d_qual.ensure(b->qual.size() + 16);
-				d_off.ensure(b->off.size() * 8); d_rp.ensure(n * sizeof(ReadParams)); d_res.ensure(n * stride);
+				d_off.ensure(b->off.size() * 8); d_rp.ensure(n * sizeof(ReadParams));
+				d_res.ensure(n * stride); d_packed.ensure(n * stride); d_poff.ensure((n + 1) * 8);
 				HIP_OK(hipMemcpyAsync(d_seq.p, b->seq.data(), b->seq.size(), hipMemcpyHostToDevice, st));
 				HIP_OK(hipMemcpyAsync(d_qual.p, b->qual.data(), b->qual.size(), hipMemcpyHostToDevice, st));
 				HIP_OK(hipMemcpyAsync(d_off.p, b->off.data(), b->off.size() * 8, hipMemcpyHostToDevice, st));
@@ -212,13 +239,23 @@ int main(int argc, char** argv) {
 				bt2g_reads rd;
 				rd.d_seq = (const uint8_t*)d_seq.p; rd.d_qual = (const uint8_t*)d_qual.p; rd.d_off = (const uint64_t*)d_off.p; rd.n_reads = (uint32_t)n;
 				HIP_OK(hipStreamSynchronize(st));
-				auto ta = std::chrono::steady_clock::now();
-				const int rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &P, b->max_len, d_res.p, st);
-				if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
+				{
+					std::lock_guard<std::mutex> g(ctx_mu[d]);
+					auto ta = std::chrono::steady_clock::now();
+					int rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &P, b->max_len, d_res.p, st);
+					if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
+					rc = bt2g_results_pack(ctx, d_res.p, (uint32_t)n, (uint32_t)P.khits, d_packed.p, (uint64_t*)d_poff.p, st);
+					if (rc) die(std::string("bt2g_results_pack: ") + bt2g_last_error(ctx));
+					HIP_OK(hipStreamSynchronize(st));
+					std::lock_guard<std::mutex> g2(align_mu);
+					align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+				}
+				HIP_OK(hipMemcpyAsync(b->res_off.data(), d_poff.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
 				HIP_OK(hipStreamSynchronize(st));
-				{ std::lock_guard<std::mutex> g(align_mu); align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(); }
-				b->res.resize(n * stride);
-				HIP_OK(hipMemcpyAsync(b->res.data(), d_res.p, n * stride, hipMemcpyDeviceToHost, st));
+				const size_t total = (size_t)b->res_off[n];
+				b->res_hold = pinned.get(total);
+				b->res = (const uint8_t*)b->res_hold.get();
+				HIP_OK(hipMemcpyAsync(b->res_hold.get(), d_packed.p, total, hipMemcpyDeviceToHost, st));
 				HIP_OK(hipStreamSynchronize(st));
 			}
 			q_out.push(std::move(b));
@@ -227,8 +264,7 @@ int main(int argc, char** argv) {
 	};
 	{
 		std::vector<std::thread> workers;
-		for (size_t d = 1; d < ndev; d++) workers.emplace_back(device_worker, d);
-		device_worker(0);
+		for (size_t d = 0; d < ndev; d++) for (size_t w = 0; w < kWorkersPerDev; w++) workers.emplace_back(device_worker, d);
 		for (auto& t : workers) t.join();
 	}
 	reader.join();

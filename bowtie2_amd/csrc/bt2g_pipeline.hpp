@@ -15,6 +15,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -98,8 +99,14 @@ struct HostBatch {
 	std::vector<uint64_t> off;
 	std::vector<ReadParams> rp;
 	uint32_t max_len = 0;
-	std::vector<uint8_t> res;             // result records, filled by stage 2
-	uint64_t stride = 0;
+	// packed result records (bt2g_results_pack), filled by the device stage: record i starts at res + res_off[i]
+	const uint8_t* res = nullptr;
+	std::vector<uint64_t> res_off;
+	std::shared_ptr<void> res_hold;       // keeps the (pinned, pooled) buffer behind `res` until the batch is written
+	const ReadResult& result(size_t i) const { return *(const ReadResult*)(res + res_off[i]); }
+	static const AlnRes* next_aln(const AlnRes* a) {
+		return (const AlnRes*)((const uint8_t*)a + ((offsetof(AlnRes, ned) + (size_t)a->nned * sizeof(Edit) + 7) & ~(size_t)7));
+	}
 	std::string too_long;                 // name of a read over the length limit (fatal), if any
 	std::string bad_input;                // malformed or unsupported input record (fatal), if any
 	bool last = false;                    // end-of-input marker (may still carry reads)
@@ -339,20 +346,32 @@ private:
 	uint64_t rdid_ = 0;
 };
 
-// SAM text of one batch, formatted in parallel chunks and concatenated in read order into `out`
-inline void format_batch(const HostBatch& b, const Options& opt, const RefInfo& ref, unsigned threads, std::vector<std::string>& parts) {
+// SAM text of one batch, formatted in parallel chunks (concatenate `parts` in order), plus the batch's share of the
+// alignment summary and the reads the device flagged.  `parts` keeps its capacity from batch to batch.
+struct BatchTally {
+	AlnSummary summ;
+	std::vector<size_t> flagged;
+};
+inline void format_batch(const HostBatch& b, const Options& opt, const RefInfo& ref, unsigned threads, std::vector<std::string>& parts, BatchTally& tally) {
 	const size_t n = b.reads.size(), chunk = 2048, nchunks = (n + chunk - 1) / chunk;
-	parts.assign(nchunks, std::string());
+	if (parts.size() < nchunks) parts.resize(nchunks);
+	for (std::string& o : parts) o.clear();
+	std::vector<BatchTally> tl(nchunks);
 	parallel_for(nchunks, threads, [&](size_t c) {
 		std::string& o = parts[c];
-		o.reserve(chunk * 400);
+		if (o.capacity() < chunk * 400) o.reserve(chunk * 400);
 		const size_t e = std::min(n, (c + 1) * chunk);
 		for (size_t i = c * chunk; i < e; i++) {
-			const ReadResult& rr = *(const ReadResult*)(b.res.data() + i * b.stride);
-			if (rr.aligned) { for (uint32_t k = 0; k < rr.nreport; k++) sam_record(o, opt, ref, b.reads[i], rr, &rr.alns[k], k == 0); }
-			else if (!opt.no_unal) sam_record(o, opt, ref, b.reads[i], rr, nullptr, true);
+			const ReadResult& rr = b.result(i);
+			tl[c].summ.add(rr);
+			if (rr.status) tl[c].flagged.push_back(i);
+			if (rr.aligned) {
+				const AlnRes* a = &rr.alns[0];
+				for (uint32_t k = 0; k < rr.nreport; k++, a = HostBatch::next_aln(a)) sam_record(o, opt, ref, b.reads[i], rr, a, k == 0);
+			} else if (!opt.no_unal) sam_record(o, opt, ref, b.reads[i], rr, nullptr, true);
 		}
 	});
+	for (const BatchTally& t : tl) { tally.summ.merge(t.summ); tally.flagged.insert(tally.flagged.end(), t.flagged.begin(), t.flagged.end()); }
 }
 
 } // namespace bt2g

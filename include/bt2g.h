@@ -253,6 +253,19 @@ int bt2g_align_batch(bt2g_ctx *ctx, const bt2g_reads *reads, const bt2g_read_par
                      void *d_results, void *stream);
 
 /*
+ * Cuts the fixed-stride records of a finished batch down to what the host needs before they cross PCIe
+ * (a record is sized for BT2G_MAX_EDITS edits per alignment; a typical read carries a handful).  Packed record
+ * i starts at d_packed + d_offsets[i] (d_offsets has n_reads + 1 entries; the last one is the total size) and
+ * is the bt2g_read_result header followed by its nreport alignments, each cut after ned[nned - 1] and padded
+ * to 8 bytes -- so alns[0] is still addressable through the struct, later ones by walking.  d_packed needs
+ * room for n_reads * bt2g_align_result_stride(khits) bytes in the worst case.  Runs on `stream` after
+ * bt2g_align_batch.  The reference formats AlnRes objects in place (AlnSinkWrap::finishRead,
+ * aln_sink.cpp:620); this is the device-to-host leg of the same hand-over.
+ */
+int bt2g_results_pack(bt2g_ctx *ctx, const void *d_results, uint32_t n_reads, uint32_t khits,
+                      void *d_packed, uint64_t *d_offsets, void *stream);
+
+/*
  * Device time (ms, HIP events on `stream`) of each kernel of the most recent bt2g_align_batch:
  * [0] k_exact_sweep [1] k_one_mm [2] k_seed_search_exact [3] k_extend_hits [4] k_align_reads.
  * Blocks until that batch has finished.  Measurement aid (bench.py's roofline), no reference counterpart.
