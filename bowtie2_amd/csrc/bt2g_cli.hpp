@@ -36,6 +36,58 @@ inline bool split_ints(const std::string& s, char sep, std::vector<int>& out) {
 	return !out.empty();
 }
 
+// One ';'-separated TAG=VALUE list in the reference's internal policy syntax (--policy; SeedAlignmentPolicy::parseString,
+// aligner_seed_policy.cpp:245-640).  Returns "" or the error text.
+inline std::string apply_policy_string(Options& opt, const std::string& pol) {
+	size_t p = 0;
+	while (p <= pol.size()) {
+		size_t q = pol.find(';', p);
+		if (q == std::string::npos) q = pol.size();
+		const std::string tok = pol.substr(p, q - p);
+		p = q + 1;
+		if (tok.empty()) continue;
+		const size_t eq = tok.find('=');
+		if (eq == std::string::npos || tok.find('=', eq + 1) != std::string::npos) return "Error parsing alignment policy setting; must be bisected by = sign";
+		const std::string tag = tok.substr(0, eq), val = tok.substr(eq + 1);
+		std::vector<std::string> c;
+		for (size_t a = 0; a <= val.size();) { size_t b = val.find(',', a); if (b == std::string::npos) b = val.size(); c.push_back(val.substr(a, b - a)); a = b + 1; }
+		if (val.empty() || c.empty()) return "Error parsing alignment policy setting; RHS must have at least 1 token";
+		for (const std::string& t : c) if (t.empty()) return "Error parsing alignment policy setting; empty token on RHS";
+		if (tag == "MA") { opt.ma = atoi(c[0].c_str()); opt.set_ma = true; }
+		else if (tag == "MMP") {
+			if (c.size() > 3) return "MMP: RHS must have at most 3 tokens";
+			if (c[0][0] == 'C') { opt.mp_max = opt.mp_min = atoi(c[0].c_str() + 1); opt.mm_const = true; }
+			else if (c[0][0] == 'Q') {
+				opt.mp_max = c.size() >= 2 ? atoi(c[1].c_str()) : 6;
+				opt.mp_min = c.size() >= 3 ? atoi(c[2].c_str()) : 2;
+				if (opt.mp_min > opt.mp_max) return "Maximum mismatch penalty is less than minimum penalty";
+				opt.mm_const = false;
+			} else return "MMP=" + c[0] + " is not supported by this build (C or Q only)";
+		}
+		else if (tag == "NP") {
+			if (c.size() != 1) return "NP: RHS must have 1 token";
+			if (c[0][0] != 'C') return "NP=" + c[0] + " is not supported by this build (constant only)";
+			opt.np = atoi(c[0].c_str() + 1);
+		}
+		else if (tag == "RDG") { opt.rdg_const = atoi(c[0].c_str()); opt.rdg_linear = c.size() >= 2 ? atoi(c[1].c_str()) : 3; }
+		else if (tag == "RFG") { opt.rfg_const = atoi(c[0].c_str()); opt.rfg_linear = c.size() >= 2 ? atoi(c[1].c_str()) : 3; }
+		else if (tag == "MIN") { opt.set_score_min = true; if (!opt.score_min.parse(val)) return "bad MIN function"; }
+		else if (tag == "NCEIL") { if (!opt.n_ceil.parse(val)) return "bad NCEIL function"; }
+		else if (tag == "SEED") {
+			if (c.size() > 1) return "SEED: RHS must have 1 token";
+			const int mms = atoi(c[0].c_str());
+			if (mms < 0 || mms > 1) return "Error: -N was set to " + c[0] + ", but cannot be set higher than 1 or less than 0";
+			opt.seed_mms = mms;
+		}
+		else if (tag == "SEEDLEN") { opt.seed_len = atoi(c[0].c_str()); opt.set_L = true; }
+		else if (tag == "DPS") { opt.max_dp_streak = atoi(c[0].c_str()); opt.set_D = true; }
+		else if (tag == "ROUNDS") { opt.n_seed_rounds = atoi(c[0].c_str()); opt.set_R = true; }
+		else if (tag == "IVAL") { opt.set_i = true; if (!opt.ms_ival.parse(val)) return "bad IVAL function"; }
+		else return "Unexpected alignment policy setting '" + tag + "'";
+	}
+	return "";
+}
+
 // Returns "" on success, else the error text (exit code 1).
 inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) {
 	for (int i = 1; i < argc; i++) {
@@ -102,7 +154,17 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "-R") { opt.n_seed_rounds = atoi(need().c_str()); opt.set_R = true; }
 		else if (a == "-L") { opt.seed_len = atoi(need().c_str()); opt.set_L = true; if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }
 		else if (a == "--local") opt.local = true;
-		else if (a == "-N") { if (atoi(need().c_str()) != 0) err = "-N 1 is outside the MI355X hot path implemented so far"; }
+		else if (a == "--policy") err = apply_policy_string(opt, need());
+		else if (a == "--bwa-sw-like") {
+			// bt2_search.cpp:1114-1126: local mode, BWA-SW's scoring, and its length-dependent score threshold
+			opt.local = true; opt.bwa_sw_like = true;
+			err = apply_policy_string(opt, "MA=1;MMP=C3;RDG=5,2;RFG=5,2");
+		}
+		// mate-pair geometry and pairing policy: accepted, and without effect on unpaired reads (-1/-2 are refused below)
+		else if (a == "-I" || a == "-X" || a == "--minins" || a == "--maxins") need();
+		else if (a == "--fr" || a == "--rf" || a == "--ff" || a == "--no-mixed" || a == "--no-discordant" || a == "--dovetail" ||
+		         a == "--no-contain" || a == "--no-overlap") {}
+		else if (a == "-N") { const std::string v = need(); opt.seed_mms = atoi(v.c_str()); if (opt.seed_mms < 0 || opt.seed_mms > 1) err = "Error: -N was set to " + v + ", but cannot be set higher than 1 or less than 0"; }
 		else if (a == "-i") { opt.set_i = true; if (!opt.ms_ival.parse(need())) err = "bad -i function"; }
 		else if (a == "--score-min" || a == "--min-score") { opt.set_score_min = true; if (!opt.score_min.parse(need())) err = "bad --score-min function"; }
 		else if (a == "--n-ceil") {
@@ -119,7 +181,8 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 			while (true) { const size_t q = v.find(',', p0); t.push_back(v.substr(p0, q == std::string::npos ? q : q - p0)); if (q == std::string::npos) break; p0 = q + 1; }
 			if (t.empty() || t.size() > 5 || t[0].empty()) err = "expected 5 or fewer comma-separated arguments to --multiseed";
 			else {
-				if (atoi(t[0].c_str()) != 0) err = "-N 1 is outside the MI355X hot path implemented so far";
+				opt.seed_mms = atoi(t[0].c_str());
+				if (opt.seed_mms < 0 || opt.seed_mms > 1) err = "Error: -N was set to " + t[0] + ", but cannot be set higher than 1 or less than 0";
 				if (t.size() > 1) { opt.seed_len = atoi(t[1].c_str()); opt.set_L = true; if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }
 				if (t.size() > 2) {
 					std::string f = t[2];
@@ -148,13 +211,13 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
 		else if (a == "-1" || a == "-2" || a == "-b" || a == "--interleaved" ||
-		         a == "-F" || a == "--int-quals" || a == "--solexa-quals" ||
-		         a == "-I" || a == "-X" || a == "--minins" || a == "--maxins")
+		         a == "-F" || a == "--int-quals" || a == "--solexa-quals")
 			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -N 0, -k <= 64)";
 		else return "unsupported option " + a;
 		if (!err.empty()) return err;
 	}
 	if (opt.khits > 64) return "-k above 64 is not supported by this build";
+	if (opt.seed_mms != 0) return "-N 1 is outside the MI355X hot path implemented so far";
 	if (opt.trim_to_len >= 0 && (opt.trim5 > 0 || opt.trim3 > 0)) return "--trim-to and -3/-5 are mutually exclusive";
 	if (opt.set_ma && !opt.local && opt.ma != 0) fprintf(stderr, "Warning: Match bonus always = 0 in --end-to-end mode; ignoring user setting\n");
 	if (opt.local && opt.set_ma && opt.ma <= 0) return "--local needs a positive --ma in this build";

@@ -75,6 +75,9 @@ struct Options {
 	int mp_max = 6, mp_min = 2, np = 1, rdg_const = 5, rdg_linear = 3, rfg_const = 5, rfg_linear = 3, gbar = 4, maxhalf = 15;
 	int ma = 0;                   // match bonus (--ma; 2 in --local mode, always 0 end to end)
 	bool set_D = false, set_R = false, set_L = false, set_i = false, set_score_min = false, set_ma = false;
+	bool mm_const = false;        // MMP=Cxx: constant mismatch penalty (policy string / --bwa-sw-like)
+	bool bwa_sw_like = false;     // --bwa-sw-like: minimum score = a*max(T, c*ln(len)) (bt2_search.cpp:3341-3350)
+	bool report_overhangs = false;
 	std::string rg_id, rgs, rg_optflag;   // @RG header pieces and the per-record RG:Z: flag (bt2_search.cpp:1418-1436)
 	uint32_t seed = 0;
 	int threads = 1;
@@ -117,7 +120,8 @@ struct Options {
 	void to_params(AlignParams& P, bool large_index) const {
 		// Scoring (scoring.h:60-170): type 3 = Phred-scaled mismatch penalty, anything else = constant mm_max;
 		// gap of length n costs const + n * linear
-		P.mm_type = ignore_quals ? 1 : 3; P.mm_max = mp_max; P.mm_min = ignore_quals ? mp_max : mp_min; P.n_pen = np;
+		const bool cmm = ignore_quals || mm_const;
+		P.mm_type = cmm ? 1 : 3; P.mm_max = mp_max; P.mm_min = cmm ? mp_max : mp_min; P.n_pen = np;
 		P.rdgapo = rdg_const + rdg_linear; P.rdgape = rdg_linear; P.rfgapo = rfg_const + rfg_linear; P.rfgape = rfg_linear;
 		P.gapbar = gbar; P.match_bonus = local ? ma : 0;
 		P.khits = all_hits ? 64 : khits; P.mhits = (saw_k || all_hits) ? 0 : mhits; P.all_hits = all_hits ? 1 : 0;
@@ -184,8 +188,16 @@ inline uint32_t gen_rand_seed(const ReadRec& r, uint32_t seed) {
 inline ReadParams compute_read_params(const Options& o, const ReadRec& r) {
 	ReadParams p;
 	const size_t len = r.seq.size();
-	int64_t minsc = o.score_min.f<int64_t>((double)len);
-	if (o.local) { if (minsc < 0) minsc = 0; } else if (minsc > 0) minsc = 0;          // bt2_search.cpp:3352-3372
+	int64_t minsc;
+	if (o.bwa_sw_like) {
+		// "a*max{T,c*log(l)}" in float, as the reference evaluates it (bt2_search.cpp:3341-3350; T = 30, c = 5.5)
+		const float a = (float)o.ma, T = 30.0f, c = 5.5f;
+		const float v1 = a * T, v2 = (float)((double)(a * c) * std::log((double)len));
+		minsc = (int64_t)std::max(v1, v2);
+	} else {
+		minsc = o.score_min.f<int64_t>((double)len);
+		if (o.local) { if (minsc < 0) minsc = 0; } else if (minsc > 0) minsc = 0;          // bt2_search.cpp:3352-3372
+	}
 	p.minsc = (int32_t)minsc;
 	// N filter (Scoring::nFilter)
 	const size_t maxns = o.n_ceil.f<size_t>((double)len);

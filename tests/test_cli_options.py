@@ -23,6 +23,8 @@ OPTION_SETS = [
     ["--score-min", "L,-1,-0.3", "--n-ceil", "L,0,0.5"], ["--seed", "77"], ["--very-sensitive", "--nofw"], ["--fast", "--norc"],
     ["--local"], ["--very-fast-local"], ["--very-sensitive-local", "-k", "3"], ["--local", "--ma", "3", "--mp", "4,2"], ["--local", "--score-min", "G,1,10"],
     ["--sensitive-local", "--no-unal", "--xeq"], ["-a"], ["-a", "--local"], ["--all", "--very-fast"],
+    ["--bwa-sw-like"], ["--bwa-sw-like", "-k", "3"], ["--policy", "MMP=C4;NP=C2;RDG=4,2;MIN=L,-2,-0.4;SEEDLEN=18;IVAL=C,8,0;DPS=8;ROUNDS=1"],
+    ["--policy", "MMP=Q,5,1;NCEIL=L,0,0.4", "-X", "300", "-I", "10", "--fr", "--no-mixed"],
 ]
 
 
