@@ -35,7 +35,8 @@ namespace bt2g {
 constexpr int kMaxLen      = 512;   // longest read (DP rows)
 constexpr int kMaxOffs     = 64;    // seed offsets per strand
 constexpr int kMaxMm1      = 256;   // 1-mismatch end-to-end hits kept
-constexpr int kMaxRanges   = 2 * kMaxOffs;
+constexpr int kMaxRanges   = 2 * kMaxOffs;   // seed positions (both strands)
+constexpr int kMaxSat2     = 4096;  // seed-hit ranges of one round: one per position with -N 0, up to ~100 per position with -N 1
 constexpr int kMaxSatpos   = 1856;  // maxIters(400 + 20*(k-1), k <= 64) + ranges + slack
 constexpr int kMaxEdits    = 200;
 constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at most 51)
@@ -134,7 +135,8 @@ struct DPRect { int64_t refl, refr, refl_pretrim, refr_pretrim; uint32_t triml, 
 // workgroup): these arrays are touched by almost every step of the scalar control code, and an
 // LDS access costs a few issue cycles where a wave-uniform global load occupies the vector
 // memory pipeline for a full 64-lane address pass.
-struct HotHit { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // exact seed hit: one range
+struct HotHit { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // exact seed hit: one range.  With -N 1: topf = first entry in Work::sranges, topb = # ranges, size = total elements
+struct SeedRange { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // one BW range of a 1-mismatch seed (SATuple, aligner_cache.h:370)
 struct HotWork {
 	uint8_t  seq[kMaxLen];     // read, codes 0..4, 5'->3'
 	uint8_t  qual[kMaxLen];    // ASCII
@@ -184,12 +186,13 @@ struct Work {
 	// ---- seed phase ----
 	EEHit    mm1[kMaxMm1];
 	// ---- extension phase ----
-	SatPos   satpos2[kMaxRanges];
-	R1N      rands2[kMaxRanges];
+	SeedRange sranges[kMaxSat2];       // -N 1: the ranges behind HotWork::hits
+	SatPos   satpos2[kMaxSat2];
+	R1N      rands2[kMaxSat2];
 	SatPos   satpos[kMaxSatpos];
 	uint32_t lists[kListArena];
-	double   masses[kMaxRanges];
-	uint8_t  elim[kMaxRanges];
+	double   masses[kMaxSat2];
+	uint8_t  elim[kMaxSat2];
 	struct ExtRange { uint32_t off, len, sz; } ex_fw[kMaxRanges * 2], ex_rc[kMaxRanges * 2];
 	DiagIval diags[kMaxDiags];
 	int64_t  red_dmin[kMaxAlns], red_dmax[kMaxAlns];   // RedundantAlns prefilter: (column - row) bounds of alns[k]

@@ -309,6 +309,166 @@ struct Aligner {
 		return ninst;
 	}
 
+	// One -N 1 seeding round: Seed::oneMmSeeds (aligner_seed.cpp:380-399) instantiated at every offset and searched with
+	// searchSeedBi (:1858-2037).  Two half-and-half policies per (strand, offset): left-to-right on the mirror index,
+	// exact over the left ceil(L/2) characters and up to one mismatch over the rest; right-to-left on the forward
+	// index, exact over the right floor(L/2) characters and exactly one mismatch over the rest.  Every hit (one BW
+	// range per distinct reference string) is kept; HOT.hits[..] then indexes a run of Work::sranges.
+	// An N may only fall in a policy's mismatch zone, where it stands for the one mismatch (Seed::instantiate :325-345).
+	BT2_HDN uint32_t seed_round_mm1(uint32_t offset, uint32_t interval, uint32_t seedlen) {
+		const uint32_t len = HOT.len;
+		const uint32_t L = seedlen < len ? seedlen : len;
+		uint32_t nseeds = 1;
+		if ((int64_t)len - (int64_t)offset > (int64_t)seedlen) nseeds += (len - offset - seedlen) / interval;
+		if (nseeds > (uint32_t)kMaxOffs) { HOT.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
+		HOT.num_offs = nseeds;
+		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
+		HOT.n_rank = 0;
+		uint32_t ninst = 0, nsr = 0;
+		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i + offset;
+		const uint32_t fc = ix.fw.ftab_chars;
+		for (int fwi = 0; fwi < 2; fwi++) {
+			const bool fw = fwi == 0;
+			for (uint32_t i = 0; i < nseeds; i++) {
+				HotHit& h = HOT.hits[fwi][i];
+				h.topf = h.topb = 0; h.size = 0;
+				HOT.sorted[fwi][i] = 0;
+			}
+			if ((fw && P.nofw) || (!fw && P.norc)) continue;
+			for (uint32_t i = 0; i < nseeds; i++) {
+				const uint32_t depth = i * interval + offset;
+				auto getc = [&](uint32_t k) -> int { return fw ? (int)HOT.seq[depth + k] : comp4(HOT.seq[depth + L - 1 - k]); };
+				const uint32_t first = nsr;
+				uint64_t elts = 0;
+				auto report = [&](TOff topf, TOff botf, TOff topb) {
+					if (nsr >= (uint32_t)kMaxSat2) { HOT.err |= ERR_OVERFLOW; return; }
+					SeedRange& r = w.sranges[nsr++];
+					r.topf = topf; r.topb = topb; r.size = (uint32_t)(botf - topf);
+					elts += (uint64_t)(botf - topf);
+				};
+				for (int pol = 0; pol < 2; pol++) {
+					const bool ltr = pol == 0;
+					// step k reads seed character pos(k); zone(k) = 1 once past the exact half (Seed::instantiate :256-276)
+					auto pos = [&](uint32_t k) -> uint32_t { return ltr ? k : L - 1 - k; };
+					const uint32_t z0 = ltr ? (L + 1) / 2 : L / 2;       // steps [0, z0) are zone 0, except that the last step always closes zone 1
+					auto zone1 = [&](uint32_t k) -> bool { return k >= z0 || k == L - 1; };
+					const int ceil1 = ltr ? 0x7fffffff : 0;               // mmsCeil of zone 1: the right-to-left policy must have spent its mismatch
+					int mms = 1;
+					bool inst = true;
+					for (uint32_t k = 0; k < L && inst; k++) {
+						if (getc(pos(k)) > 3) { if (zone1(k) && mms > 0) mms--; else inst = false; }
+					}
+					if (!inst) continue;
+					ninst++;
+					// maxjump: leading steps that stay in zone 0 (for the right-to-left seed the insertion zone changes at the same step)
+					uint32_t maxjump = 0;
+					while (maxjump < L && !zone1(maxjump)) maxjump++;
+					const DevEbwt<TOff>& e = ltr ? ix.bw : ix.fw;
+					TOff topf = 0, botf = 0, topb = 0, botb = 0;
+					uint32_t step = 0;
+					if (fc > 1 && fc <= maxjump) {
+						const uint32_t off = ltr ? 0 : L - fc;
+						uint64_t kf = 0, kb = 0;
+						for (uint32_t k = 0; k < fc; k++) {
+							kf = (kf << 2) | (uint64_t)getc(off + k);
+							kb = (kb << 2) | (uint64_t)getc(off + fc - 1 - k);
+						}
+						topf = ftab_hi(ix.fw, kf); botf = ftab_lo(ix.fw, kf + 1);
+						if (botf <= topf) continue;
+						topb = ftab_hi(ix.bw, kb); botb = topb + (botf - topf);
+						step = fc;
+					} else if (maxjump > 0) {
+						const int c = getc(pos(0));
+						topf = topb = ix.fw.fchr[c];
+						botf = botb = ix.fw.fchr[c + 1];
+						if (botf <= topf) continue;
+						step = 1;
+					} else {
+						topf = topb = 0;
+						botf = botb = ix.fw.fchr[4];
+					}
+					if (step == L) { report(topf, botf, topb); continue; }
+					// exact continuation after the mismatch (the recursive searchSeedBi call: every zone is used up)
+					auto finish_exact = [&](uint32_t st, TOff tf_, TOff bf_, TOff tb_, TOff bb_) {
+						for (; st < L; st++) {
+							const int c = getc(pos(st));
+							TOff& top = ltr ? tb_ : tf_; TOff& bot = ltr ? bb_ : bf_;
+							TOff& topp = ltr ? tf_ : tb_; TOff& botp = ltr ? bf_ : bb_;
+							HOT.n_bwops_seed++;
+							if (bot - top > 1) {
+								TOff t[4], b[4], tp[4], bp[4];
+								bi_lf(e, top, bot, topp, t, b, tp, bp);
+								if (b[c] == t[c]) return;
+								top = t[c]; bot = b[c]; topp = tp[c]; botp = bp[c];
+							} else {
+								const TOff t = lf1c(e, top, c);
+								if (t == kOffMask) return;
+								top = t; bot = t + 1;
+							}
+						}
+						report(tf_, bf_, tb_);
+					};
+					bool alive = true;
+					for (; alive && step < L; step++) {
+						const uint32_t k = step;
+						const int c = getc(pos(k));
+						const bool z1 = zone1(k), leave = k == L - 1;
+						TOff& top = ltr ? topb : topf; TOff& bot = ltr ? botb : botf;      // range in the index being walked
+						TOff& topp = ltr ? topf : topb; TOff& botp = ltr ? botf : botb;    // and in the other one
+						TOff t[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, tp[4], bp[4];
+						tp[0] = tp[1] = tp[2] = tp[3] = topp; bp[0] = bp[1] = bp[2] = bp[3] = botp;
+						const bool wide = bot - top > 1;
+						if (wide) { HOT.n_bwops_seed++; bi_lf(e, top, bot, topp, t, b, tp, bp); }
+						bool probed = false;     // single-row range whose character was looked up by the edit branch
+						TOff row1 = top;
+						if ((z1 && mms > 0) || c > 3) {
+							bool bail = false;
+							if (!wide) {
+								HOT.n_bwops_seed++;
+								const int cc = lf1(e, row1);
+								if (cc < 0) bail = true; else { t[cc] = row1; b[cc] = row1 + 1; probed = true; }
+							}
+							if (!bail) {
+								const int after = c > 3 ? mms : mms - 1;
+								if (!leave || after <= ceil1) {
+									for (int j = 0; j < 4; j++) {
+										if (j == c || b[j] == t[j]) continue;
+										const TOff jt = t[j], jb = b[j], jtp = tp[j], jbp = bp[j];
+										if (ltr) finish_exact(k + 1, jtp, jbp, jt, jb); else finish_exact(k + 1, jt, jb, jtp, jbp);
+									}
+								}
+							}
+						}
+						if (c > 3) { alive = false; break; }
+						if (leave && z1 && mms > ceil1) { alive = false; break; }
+						if (!wide) {
+							HOT.n_bwops_seed++;
+							if (probed) {
+								// mapLF1(ntop, tloc, c) after mapLF1(ntop&, tloc): the row test sees the already-advanced row (:1995 after :1918)
+								if (t[c] == b[c] || row1 == e.zoff) { alive = false; break; }
+							} else {
+								const TOff r = lf1c(e, top, c);
+								if (r == kOffMask) { alive = false; break; }
+								t[c] = r; b[c] = r + 1;
+							}
+						}
+						if (b[c] == t[c]) { alive = false; break; }
+						top = t[c]; bot = b[c]; topp = tp[c]; botp = bp[c];
+					}
+					if (alive) report(topf, botf, topb);
+				}
+				if (nsr > first && elts > 0) {
+					HotHit& h = HOT.hits[fwi][i];
+					h.topf = first; h.topb = nsr - first; h.size = (uint32_t)elts;
+					HOT.nonz_tot++;
+					if (fw) HOT.nonz_fw++; else HOT.nonz_rc++;
+					HOT.num_elts += elts;
+				}
+			}
+		}
+		return ninst;
+	}
+
 	BT2_HD uint64_t hit_elts(int fwi, uint32_t i) const { return HOT.hits[fwi][i].size; }
 
 	// SeedResults::rankSeedHits, all=false (aligner_seed.h:1019-1080)
@@ -545,7 +705,10 @@ struct Aligner {
 			const uint32_t rdoff = HOT.off_idx2off[offidx];
 			const uint32_t seedlen = rp.seedlen < (int32_t)HOT.len ? (uint32_t)rp.seedlen : HOT.len;
 			const HotHit& h = HOT.hits[fw ? 0 : 1][offidx];
-			const uint64_t sz = h.size;
+			const uint32_t nr_here = seedmms > 0 ? (uint32_t)h.topb : 1u;      // ca.queryQval: one SATuple per reference string
+			for (uint32_t ri = 0; ri < nr_here; ri++) {
+			uint64_t h_topf = h.topf, h_topb = h.topb, sz = h.size;
+			if (seedmms > 0) { const SeedRange& sr = w.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.size; }
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
 				const Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
@@ -558,9 +721,9 @@ struct Aligner {
 				}
 				if (skip) { nrange--; nelt -= sz; continue; }
 			}
-			if (HOT.n_satpos2 >= (uint32_t)kMaxRanges) { HOT.err |= ERR_OVERFLOW; break; }
+			if (HOT.n_satpos2 >= (uint32_t)kMaxSat2) { HOT.err |= ERR_OVERFLOW; break; }
 			SatPos& s = w.satpos2[HOT.n_satpos2++];
-			s.topf = h.topf; s.topb = h.topb; s.size = (uint32_t)sz; s.orig_sz = (uint32_t)sz;
+			s.topf = h_topf; s.topb = h_topb; s.size = (uint32_t)sz; s.orig_sz = (uint32_t)sz;
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
 			uint32_t nlex = 0, nrex = 0;
@@ -568,7 +731,7 @@ struct Aligner {
 				if (ext_pre && seedmms == 0) {
 					const uint32_t e = pre->ext[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + offidx];
 					nlex = e & 0xffffu; nrex = e >> 16;
-				} else extend_hit((TOff)h.topf, (TOff)(h.topf + sz), (TOff)h.topb, (TOff)(h.topb + sz), fw, rdoff, seedlen, nlex, nrex);
+				} else extend_hit((TOff)h_topf, (TOff)(h_topf + sz), (TOff)h_topb, (TOff)(h_topb + sz), fw, rdoff, seedlen, nlex, nrex);
 			}
 			s.nlex = nlex; s.nrex = nrex;
 			HOT.n_ext_left += nlex; HOT.n_ext_right += nrex;
@@ -583,13 +746,22 @@ struct Aligner {
 				} else HOT.err |= ERR_OVERFLOW;
 			}
 		}
+		}
 		nelt_out = nelt;
 		// satpos.sort()
-		for (uint32_t i = 1; i < HOT.n_satpos2; i++) {
-			const SatPos v = w.satpos2[i];
-			uint32_t j = i;
-			while (j > 0 && satpos_less(v, w.satpos2[j - 1])) { w.satpos2[j] = w.satpos2[j - 1]; j--; }
-			w.satpos2[j] = v;
+		// (operator< is a total order over the ranges of one read, so any sorting algorithm gives the reference's order;
+		// -N 1 can produce thousands of ranges, hence the gapped passes before the final insertion pass)
+		const uint32_t gaps[9] = {1750u, 701u, 301u, 132u, 57u, 23u, 10u, 4u, 1u};
+		for (int gi = 0; gi < 9; gi++) {
+			const uint32_t gap = gaps[gi];
+			if (gap >= HOT.n_satpos2) continue;
+			for (uint32_t i = gap; i < HOT.n_satpos2; i++) {
+				if (!satpos_less(w.satpos2[i], w.satpos2[i - gap])) continue;
+				const SatPos v = w.satpos2[i];
+				uint32_t j = i;
+				while (j >= gap && satpos_less(v, w.satpos2[j - gap])) { w.satpos2[j] = w.satpos2[j - gap]; j -= gap; }
+				w.satpos2[j] = v;
+			}
 		}
 		uint64_t nelt_added = 0;
 		// 1. the smalls, whole
@@ -1419,7 +1591,8 @@ struct Aligner {
 				const uint64_t ts_ = now();
 				ext_pre = false;
 				uint32_t ninst;
-				if (offset == 0 && pre && pre->seeds && 1 + (len > (uint32_t)rp.seedlen ? (len - (uint32_t)rp.seedlen) / interval : 0u) <= pre->max_seeds) {
+				if (P.seed_mms > 0) ninst = seed_round_mm1(offset, interval, (uint32_t)rp.seedlen);
+				else if (offset == 0 && pre && pre->seeds && 1 + (len > (uint32_t)rp.seedlen ? (len - (uint32_t)rp.seedlen) / interval : 0u) <= pre->max_seeds) {
 					ninst = seed_round_pre(interval, (uint32_t)rp.seedlen);
 					ext_pre = pre->ext != nullptr;
 				} else ninst = seed_round(offset, interval, (uint32_t)rp.seedlen);
@@ -1427,7 +1600,7 @@ struct Aligner {
 				if (ninst == 0) { done = true; HOT.nonz_tot = 0; continue; }
 				if (HOT.nonz_tot == 0) { done = true; continue; }
 				{ const uint64_t t0_ = now(); rank_seed_hits(); HOT.t_phase[3] += now() - t0_; }
-				const int ret = extend_seeds(0, rp.seedlen, (int)interval);
+				const int ret = extend_seeds(P.seed_mms, rp.seedlen, (int)interval);
 				handle_ret(ret, done);
 				if (!done && HOT.nonz_tot > 0 && (HOT.num_elts / HOT.nonz_tot) < (uint64_t)P.seed_boost_thresh) done = true;
 			}

@@ -363,17 +363,19 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			}
 		} else mark(1);
 		mark(2);
-		e = s ? launch_seed_search_exact(c->ix32, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st)
-		      : launch_seed_search_exact(c->ix64, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st);
-		if (e != hipSuccess) return hip_fail(c, e, "k_seed_search_exact");
-		pre.seeds = d_seeds;
-		mark(3);
-		if (params->do_extend) {
-			e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, c->d_cnt, st)
-			      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, c->d_cnt, st);
-			if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits");
-			pre.ext = d_ext;
-		}
+		if (params->seed_mms == 0) {   // -N 1 seeds are searched by the worker itself (several ranges per seed)
+			e = s ? launch_seed_search_exact(c->ix32, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st)
+			      : launch_seed_search_exact(c->ix64, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st);
+			if (e != hipSuccess) return hip_fail(c, e, "k_seed_search_exact");
+			pre.seeds = d_seeds;
+			mark(3);
+			if (params->do_extend) {
+				e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, c->d_cnt, st)
+				      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, c->d_cnt, st);
+				if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits");
+				pre.ext = d_ext;
+			}
+		} else { mark(3); }
 		pre.max_seeds = max_seeds; pre.mm1_cap = cap;
 		mark(4);
 	} else { for (int i = 1; i <= 4; i++) mark(i); }

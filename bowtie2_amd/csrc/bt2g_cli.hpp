@@ -212,12 +212,11 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
 		else if (a == "-1" || a == "-2" || a == "-b" || a == "--interleaved" ||
 		         a == "-F" || a == "--int-quals" || a == "--solexa-quals")
-			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -N 0, -k <= 64)";
+			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -k <= 64)";
 		else return "unsupported option " + a;
 		if (!err.empty()) return err;
 	}
 	if (opt.khits > 64) return "-k above 64 is not supported by this build";
-	if (opt.seed_mms != 0) return "-N 1 is outside the MI355X hot path implemented so far";
 	if (opt.trim_to_len >= 0 && (opt.trim5 > 0 || opt.trim3 > 0)) return "--trim-to and -3/-5 are mutually exclusive";
 	if (opt.set_ma && !opt.local && opt.ma != 0) fprintf(stderr, "Warning: Match bonus always = 0 in --end-to-end mode; ignoring user setting\n");
 	if (opt.local && opt.set_ma && opt.ma <= 0) return "--local needs a positive --ma in this build";

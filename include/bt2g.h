@@ -183,12 +183,12 @@ int bt2g_sw_fill_ee_u8(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_prob
 /* ---- the fused per-read worker ------------------------------------------ */
 /*
  * Replaces `static void multiseedSearchWorker(void*)` (bt2_search.cpp:3094-4254) for a whole
- * batch of unpaired reads: exact end-to-end sweep, 1-mismatch end-to-end search, -N 0 seed
- * rounds, seed-hit prioritisation, offset resolution, DP framing, end-to-end 8-bit SW fill,
+ * batch of unpaired reads: exact end-to-end sweep, 1-mismatch end-to-end search, -N 0 / -N 1 seed
+ * rounds, seed-hit prioritisation, offset resolution, DP framing, end-to-end and local SW fill (8/16-bit semantics),
  * backtrace, redundancy checks, -M/-k reporting state and the final selection -- one
  * wavefront per read, the reference's RNG draw order reproduced, so that the SAM written
  * from these records is byte-identical to the reference's.  Scope (rejected otherwise by the
- * host): unpaired, end-to-end, -N 0, reads <= BT2G_MAX_READ_LEN.
+ * host): unpaired reads <= BT2G_MAX_READ_LEN, at most 64 alignments per read.
  */
 #define BT2G_MAX_READ_LEN 512
 #define BT2G_MAX_EDITS    200
@@ -206,6 +206,7 @@ typedef struct {
 	int32_t large_index;           /* RNG draws differ in the 64-bit build (aligner_sw_driver.cpp:103-109) */
 	int32_t all_hits;              /* -a: no limit on alignments, effort limits lifted, deterministic seed order (khits is then
 	                                  only the capacity of the result record; more alignments than that flag the read) */
+	int32_t seed_mms;              /* -N: 0 = exact seeds, 1 = one mismatch per seed (Seed::oneMmSeeds)          */
 } bt2g_align_params;
 
 /* per-read inputs the host derives with the reference's formulas (bt2_search.cpp:3352-3450, pat.cpp:45) */

@@ -25,6 +25,9 @@ OPTION_SETS = [
     ["--sensitive-local", "--no-unal", "--xeq"], ["-a"], ["-a", "--local"], ["--all", "--very-fast"],
     ["--bwa-sw-like"], ["--bwa-sw-like", "-k", "3"], ["--policy", "MMP=C4;NP=C2;RDG=4,2;MIN=L,-2,-0.4;SEEDLEN=18;IVAL=C,8,0;DPS=8;ROUNDS=1"],
     ["--policy", "MMP=Q,5,1;NCEIL=L,0,0.4", "-X", "300", "-I", "10", "--fr", "--no-mixed"],
+    ["-N", "1"], ["-N", "1", "--local", "-k", "3"], ["-N", "1", "-L", "10", "-i", "C,3,0"], ["--multiseed", "1,18,S,1,0.5"],
+    ["-N", "1", "-L", "32", "--very-fast", "--nofw"], ["-N", "1", "--no-1mm-upfront", "-L", "12"], ["-N", "1", "-a", "-L", "25"],
+    ["--policy", "SEED=1;SEEDLEN=16", "--very-sensitive"],
 ]
 
 
@@ -78,7 +81,7 @@ def test_options_match_reference_hostsim(hostsim, idx, tmp_path):
 
 
 def test_unsupported_options_are_refused(hostsim):
-    for opts in (["-1", "a.fq", "-2", "b.fq"], ["-N", "1"], ["-k", "100"], ["--frobnicate"]):
+    for opts in (["-1", "a.fq", "-2", "b.fq"], ["-N", "2"], ["-k", "100"], ["--frobnicate"], ["--overhang"]):
         p = subprocess.run([hostsim] + opts + ["-x", os.path.join(GOLD, "tiny_s"), "-U", FQ], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert p.returncode != 0 and p.stdout == "", opts
 

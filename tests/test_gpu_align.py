@@ -74,7 +74,8 @@ def test_differential_vs_reference_binary(large):
     build_index(fa, base, large)
     ref_exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
     for args in (["--sensitive"], ["--very-sensitive"], ["--very-fast"], ["--sensitive", "--norc"], ["--nofw"], ["-k", "5"],
-                 ["-k", "20", "--very-fast"], ["--local"], ["--very-fast-local"], ["--very-sensitive-local", "-k", "3"]):
+                 ["-k", "20", "--very-fast"], ["--local"], ["--very-fast-local"], ["--very-sensitive-local", "-k", "3"],
+                 ["-N", "1"], ["-N", "1", "-L", "12", "-i", "C,6,0", "-k", "3"], ["-N", "1", "--very-sensitive-local"]):
         rs = os.path.join(d, "ref.sam")
         subprocess.check_call([ref_exe] + args + ["-x", base, "-U", fq, "-p", "8", "--reorder", "-S", rs], stderr=subprocess.DEVNULL)
         want = [l.rstrip("\n") for l in open(rs) if not l.startswith("@PG")]
