@@ -60,7 +60,7 @@ class AlignParams(C.Structure):
         "mm_type", "mm_max", "mm_min", "n_pen", "rdgapo", "rdgape", "rfgapo", "rfgape", "gapbar", "match_bonus",
         "khits", "mhits", "max_dp_streak", "max_ug", "max_dp", "max_iters", "n_seed_rounds", "seed_boost_thresh",
         "tighten", "maxhalf", "nofw", "norc", "do_exact_upfront", "do_1mm_upfront", "do_ungapped", "do_extend",
-        "large_index", "all_hits", "seed_mms")]
+        "large_index", "all_hits", "seed_mms", "overhang")]
 
 
 class ReadParams(C.Structure):

@@ -1195,6 +1195,51 @@ struct Aligner {
 		for (uint32_t i = 0; i < n; i++) r.ned[i].pos = (uint16_t)(sz - r.ned[i].pos - (r.ned[i].type == EDIT_READ_GAP ? 0 : 1));
 	}
 
+	// AlnRes::clipOutside / clipLeft / clipRight with soft clipping (aligner_result.cpp:208-303); Edit::clipLo / clipHi
+	// (edit.cpp:438-471).  Clipping is counted in read characters: reference gaps inside the overhang widen it.
+	BT2_HD void clip_edits_lo(AlnRes& r, uint32_t amt) {
+		uint32_t nrm = 0;
+		for (uint32_t i = 0; i < r.nned; i++) { if (r.ned[i].pos < amt) nrm++; else r.ned[i].pos = (uint16_t)(r.ned[i].pos - amt); }
+		for (uint32_t i = nrm; i < r.nned; i++) r.ned[i - nrm] = r.ned[i];
+		r.nned = (uint16_t)(r.nned - nrm);
+	}
+	BT2_HD void clip_edits_hi(AlnRes& r, uint32_t len, uint32_t amt) {
+		const uint32_t mx = len - amt;
+		while (r.nned > 0) {
+			const Edit& e = r.ned[r.nned - 1];
+			if (e.pos > mx || (e.pos == mx && e.type != EDIT_READ_GAP)) r.nned--; else break;
+		}
+	}
+	BT2_HD uint32_t clip_read_chars(AlnRes& r, bool from_left, uint32_t rf_amt) {
+		// walk the edits from the clipped end (positions w.r.t. that end of the Watson-oriented read)
+		const bool inv = from_left ? !r.fw : (r.fw != 0);
+		uint32_t rf_i = rf_amt;
+		if (inv) invert_edits(r);
+		for (uint32_t i = 0; i < r.nned; i++) { if (r.ned[i].pos > rf_i) break; if (r.ned[i].type == EDIT_REF_GAP) rf_i++; }
+		if (inv) invert_edits(r);
+		return rf_i < r.rdextent ? rf_i : r.rdextent;
+	}
+	BT2_HDN void clip_outside(AlnRes& r, int64_t refi, int64_t reff) {
+		if (r.refoff < refi) {
+			uint32_t rf_amt = (uint32_t)(refi - r.refoff);
+			if (rf_amt > r.rfextent) rf_amt = r.rfextent;
+			const uint32_t rd_amt = clip_read_chars(r, true, rf_amt);
+			if (r.fw) { r.trim5p = (uint16_t)(r.trim5p + rd_amt); clip_edits_lo(r, rd_amt); }
+			else { r.trim3p = (uint16_t)(r.trim3p + rd_amt); clip_edits_hi(r, r.rdextent, rd_amt); }
+			r.rdextent = (uint16_t)(r.rdextent - rd_amt); r.rfextent = (uint16_t)(r.rfextent - rf_amt);
+			r.refoff += rf_amt;
+		}
+		const int64_t right = r.refoff + (int64_t)r.rfextent;
+		if (right > reff) {
+			uint32_t rf_amt = (uint32_t)(right - reff);
+			if (rf_amt > r.rfextent) rf_amt = r.rfextent;
+			const uint32_t rd_amt = clip_read_chars(r, false, rf_amt);
+			if (r.fw) { r.trim3p = (uint16_t)(r.trim3p + rd_amt); clip_edits_hi(r, r.rdextent, rd_amt); }
+			else { r.trim5p = (uint16_t)(r.trim5p + rd_amt); clip_edits_lo(r, rd_amt); }
+			r.rdextent = (uint16_t)(r.rdextent - rd_amt); r.rfextent = (uint16_t)(r.rfextent - rf_amt);
+		}
+	}
+
 	// SwAligner::nextAlignment, end-to-end u8 branch (aligner_sw.cpp:737-1146)
 	BT2_HDN bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, int mode, bool sse16, AlnRes& res) {
 		const bool wide = mode != 0;
@@ -1245,8 +1290,9 @@ struct Aligner {
 	BT2_HDN int ungapped_align(bool fw, uint64_t tidx, int64_t refoff, int64_t reflen, AlnRes& res) {
 		const uint32_t len = HOT.len;
 		const int64_t rfi = refoff, rff = refoff + (int64_t)len;
-		if (rfi < 0) return 0;              // gReportOverhangs == false
-		if (rff > reflen) return 0;
+		// overhanging ends are only scored (as Ns) with --overhang, and count against the N ceiling (aligner_sw.cpp:306-325)
+		if ((rfi < 0 || rff > reflen) && !P.overhang) return 0;
+		if ((rfi < 0 ? -rfi : 0) + (rff > reflen ? rff - reflen : 0) > (int64_t)rp.nceil) return 0;
 		int64_t score = 0;
 		int ns = 0;
 		for (uint32_t i = 0; i < len; i++) HOT.rf[i] = (uint8_t)ref_base(ix.ref, tidx, rfi + (int64_t)i);   // codes here, not masks
@@ -1436,8 +1482,11 @@ struct Aligner {
 						const int64_t refl = refoff - 2 * (int64_t)maxgap;
 						const int64_t refr = refoff + ((int64_t)rows - 1) + 2 * (int64_t)maxgap;
 						uint64_t triml = 0, trimr = 0;
-						if (refr >= (int64_t)tlen) trimr = (uint64_t)(refr - ((int64_t)tlen - 1));
-						if (refl < 0) triml = (uint64_t)(-refl);
+						// trimToRef_ = !gReportOverhangs; otherwise up to nceil columns of N past either end stay in the window
+						int64_t maxns = 0;
+						if (P.overhang) { maxns = rp.nceil; if (maxns == (int64_t)rows) maxns--; }
+						if (refr >= (int64_t)tlen + maxns) trimr = (uint64_t)(refr - ((int64_t)tlen + maxns - 1));
+						if (refl < -maxns) triml = (uint64_t)(-refl) - (uint64_t)maxns;
 						rect.refl_pretrim = refl; rect.refr_pretrim = refr;
 						rect.refl = refl + (int64_t)triml; rect.refr = refr - (int64_t)trimr;
 						rect.triml = (uint32_t)triml; rect.trimr = (uint32_t)trimr; rect.maxgap = maxgap;
@@ -1490,6 +1539,11 @@ struct Aligner {
 						first_inner = false;
 						const uint64_t tp_ = now();
 						struct PostTimer { uint64_t t0; uint64_t& acc; BT2_HD ~PostTimer() { acc += Plat::clock() - t0; } } post_timer_{tp_, HOT.t_phase[9]};
+						// --overhang: soft-clip what hangs off either end (aligner_sw_driver.cpp:1396-1403)
+						if (P.overhang && (res.refoff < 0 || res.refoff + (int64_t)res.rfextent > (int64_t)tlen)) {
+							clip_outside(res, 0, (int64_t)tlen);
+							if (res.rfextent == 0) continue;
+						}
 						// fell entirely outside the reference?
 						{
 							const int64_t a0 = res.refoff, a1 = res.refoff + res.rfextent;

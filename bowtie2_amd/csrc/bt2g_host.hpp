@@ -124,7 +124,7 @@ struct Options {
 		P.mm_type = cmm ? 1 : 3; P.mm_max = mp_max; P.mm_min = cmm ? mp_max : mp_min; P.n_pen = np;
 		P.rdgapo = rdg_const + rdg_linear; P.rdgape = rdg_linear; P.rfgapo = rfg_const + rfg_linear; P.rfgape = rfg_linear;
 		P.gapbar = gbar; P.match_bonus = local ? ma : 0;
-		P.khits = all_hits ? 64 : khits; P.mhits = (saw_k || all_hits) ? 0 : mhits; P.all_hits = all_hits ? 1 : 0; P.seed_mms = seed_mms;
+		P.khits = all_hits ? 64 : khits; P.mhits = (saw_k || all_hits) ? 0 : mhits; P.all_hits = all_hits ? 1 : 0; P.seed_mms = seed_mms; P.overhang = report_overhangs ? 1 : 0;
 		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
 		if (all_hits) {
 			// -a lifts every effort limit (bt2_search.cpp:3457-3463)

@@ -207,6 +207,8 @@ typedef struct {
 	int32_t all_hits;              /* -a: no limit on alignments, effort limits lifted, deterministic seed order (khits is then
 	                                  only the capacity of the result record; more alignments than that flag the read) */
 	int32_t seed_mms;              /* -N: 0 = exact seeds, 1 = one mismatch per seed (Seed::oneMmSeeds)          */
+	int32_t overhang;              /* --overhang (gReportOverhangs): DP windows may run past the reference ends by
+	                                  the N ceiling, overhanging read ends come back soft-clipped                    */
 } bt2g_align_params;
 
 /* per-read inputs the host derives with the reference's formulas (bt2_search.cpp:3352-3450, pat.cpp:45) */
