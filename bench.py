@@ -314,7 +314,8 @@ def main():
                     ("pad", "u1", 2), ("secbest", "<i4"), ("best", "<i4"), ("nalns", "<u4"), ("nreport", "<u4"),
                     ("n_ex_iters", "<u4"), ("n_ex_dps", "<u4"), ("n_ex_ugs", "<u4"), ("n_dp_fail_streak_max", "<u4"),
                     ("n_bwops_seed", "<u4"), ("n_bwops_ext", "<u4"), ("n_redundants", "<u4"), ("n_bt_attempts", "<u4"),
-                    ("n_ext_left", "<u4"), ("n_ext_right", "<u4"), ("n_resolve_steps", "<u4"), ("n_sides", "<u4")])
+                    ("n_ext_left", "<u4"), ("n_ext_right", "<u4"), ("n_resolve_steps", "<u4"), ("n_sides", "<u4"),
+                    ("pair_best", "<i4"), ("pair_secbest", "<i4"), ("n_mate_dps", "<u4"), ("pad2", "<u4")])
     h = np.frombuffer(rec.tobytes(), dtype=hdr)
     aligned = int(h["aligned"].sum())
     all_aligned = shard.reduce_sum(dist, [aligned], dev)[0]

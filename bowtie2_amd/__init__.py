@@ -60,7 +60,8 @@ class AlignParams(C.Structure):
         "mm_type", "mm_max", "mm_min", "n_pen", "rdgapo", "rdgape", "rfgapo", "rfgape", "gapbar", "match_bonus",
         "khits", "mhits", "max_dp_streak", "max_ug", "max_dp", "max_iters", "n_seed_rounds", "seed_boost_thresh",
         "tighten", "maxhalf", "nofw", "norc", "do_exact_upfront", "do_1mm_upfront", "do_ungapped", "do_extend",
-        "large_index", "all_hits", "seed_mms", "overhang")]
+        "large_index", "all_hits", "seed_mms", "overhang", "paired", "pe_policy", "pe_maxfrag", "pe_minfrag", "pe_flags",
+        "max_mate_streak")]
 
 
 class ReadParams(C.Structure):
@@ -85,12 +86,13 @@ class Aln(C.Structure):
 
 class ReadResult(C.Structure):
     _fields_ = [("status", C.c_uint8), ("aligned", C.c_uint8), ("maxed", C.c_uint8), ("filt", C.c_uint8),
-                ("exhausted", C.c_uint8), ("has_secbest", C.c_uint8), ("pad", C.c_uint8 * 2),
+                ("exhausted", C.c_uint8), ("has_secbest", C.c_uint8), ("pair_type", C.c_uint8), ("pair_flags", C.c_uint8),
                 ("secbest", C.c_int32), ("best", C.c_int32), ("nalns", C.c_uint32), ("nreport", C.c_uint32),
                 ("n_ex_iters", C.c_uint32), ("n_ex_dps", C.c_uint32), ("n_ex_ugs", C.c_uint32),
                 ("n_dp_fail_streak_max", C.c_uint32), ("n_bwops_seed", C.c_uint32), ("n_bwops_ext", C.c_uint32),
                 ("n_redundants", C.c_uint32), ("n_bt_attempts", C.c_uint32),
                 ("n_ext_left", C.c_uint32), ("n_ext_right", C.c_uint32), ("n_resolve_steps", C.c_uint32), ("n_sides", C.c_uint32),
+                ("pair_best", C.c_int32), ("pair_secbest", C.c_int32), ("n_mate_dps", C.c_uint32), ("pad2", C.c_uint32),
                 ("alns", Aln * 1)]
 
 

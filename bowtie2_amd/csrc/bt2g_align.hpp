@@ -39,11 +39,12 @@ constexpr int kMaxRanges   = 2 * kMaxOffs;   // seed positions (both strands)
 constexpr int kMaxSat2     = 4096;  // seed-hit ranges of one round: one per position with -N 0, up to ~100 per position with -N 1
 constexpr int kMaxSatpos   = 1856;  // maxIters(400 + 20*(k-1), k <= 64) + ranges + slack
 constexpr int kMaxEdits    = 200;
+constexpr int kMaxRedAnchor = 192;  // alignments remembered by the paired-end redundancy set
 constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at most 51)
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 16384; // uint32 slots for Random1toN lists
 constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
-constexpr int kMaxCols     = kMaxLen + 4 * 15 + 1 + 4;
+constexpr int kMaxCols     = 1000;  // DP columns: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*15
 
 enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
 enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMIT, EXT_HARD_LIMIT };
@@ -135,6 +136,19 @@ struct DPRect { int64_t refl, refr, refl_pretrim, refr_pretrim; uint32_t triml, 
 // workgroup): these arrays are touched by almost every step of the scalar control code, and an
 // LDS access costs a few issue cycles where a wave-uniform global load occupies the vector
 // memory pipeline for a full 64-lane address pass.
+// ReportingState of a pair (aln_sink.h:380-580) and the running bests of AlnSinkWrap (aln_sink.cpp:1395-1452)
+enum { PE_EXIT_DID_NOT_ENTER = 1, PE_EXIT_DID_NOT_EXIT, PE_EXIT_K, PE_EXIT_M, PE_EXIT_TRUMPED, PE_EXIT_CONVERTED, PE_EXIT_NO_ALNS, PE_EXIT_WITH_ALNS };
+struct PeHot {
+	uint8_t  cur;                       // mate whose read and seed state are loaded
+	uint8_t  done_concord, done_discord, done_unp[2], done_all;
+	uint8_t  exit_concord, exit_discord, exit_unp[2];
+	uint32_t n_concord, n_discord, n_unp[2];
+	int64_t  best_pair, best2_pair, best_unp[2], best2_unp[2];
+	uint32_t n_red_anchor;
+	uint32_t n_ex_fw2, n_ex_rc2;        // mate 2's covered-range lists (HotWork::n_ex_fw/rc are mate 1's)
+	uint32_t n_mate_dps, n_mate_ugs;
+	uint32_t olen;                      // length of the mate that is not loaded
+};
 struct HotHit { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // exact seed hit: one range.  With -N 1: topf = first entry in Work::sranges, topb = # ranges, size = total elements
 struct SeedRange { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // one BW range of a 1-mismatch seed (SATuple, aligner_cache.h:370)
 struct HotWork {
@@ -174,6 +188,8 @@ struct HotWork {
 	uint32_t n_redundants, n_bwops_seed, n_bwops_ext, n_bt_attempts;
 	uint32_t n_ext_left, n_ext_right, n_resolve_steps;
 	uint32_t n_sides;           // sides (64/128-byte lines) actually read -- roofline accounting
+	uint32_t n_sranges;         // -N 1: entries of Work::sranges in use
+	PeHot    pe;                // paired-end reporting state (unused for unpaired reads)
 	uint64_t t_phase[22];       // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other
 };
 // Backtrace tile: the cells a run of kBtTile diagonal steps starting at (row, col) can look at, gathered with one
@@ -193,7 +209,8 @@ struct Work {
 	uint32_t lists[kListArena];
 	double   masses[kMaxSat2];
 	uint8_t  elim[kMaxSat2];
-	struct ExtRange { uint32_t off, len, sz; } ex_fw[kMaxRanges * 2], ex_rc[kMaxRanges * 2];
+	struct ExtRange { uint32_t off, len, sz; } ex_fw[kMaxRanges * 2], ex_rc[kMaxRanges * 2];   // seedExRangeFw_/Rc_[0]
+	ExtRange ex_fw2[kMaxRanges * 2], ex_rc2[kMaxRanges * 2];                                   // ... [1]: mate 2 of a pair
 	DiagIval diags[kMaxDiags];
 	int64_t  red_dmin[kMaxAlns], red_dmax[kMaxAlns];   // RedundantAlns prefilter: (column - row) bounds of alns[k]
 	// ---- sink ----
@@ -203,6 +220,26 @@ struct Work {
 	uint32_t cand_hist[2 * (kMaxLocalScore + 1)];   // scratch of the local gather's counting sort
 	BtFrame  btstack[kMaxLen + kMaxCols];
 	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
+	// ---- paired-end (extendSeedsPaired; unused for unpaired reads) ----
+	// seed-phase state of the mate that is not loaded (both mates are searched before either is extended)
+	struct MateSave {
+		uint32_t len;
+		EEHit    exact[2];
+		uint32_t n_mm1; uint64_t mm1_elt;
+		uint32_t num_offs, nonz_tot, nonz_fw, nonz_rc, n_sranges; uint64_t num_elts;
+		uint32_t off_idx2off[kMaxOffs];
+		HotHit   hits[2][kMaxOffs];
+		EEHit    mm1[kMaxMm1];
+		SeedRange sranges[kMaxSat2];
+	} ms[2];
+	AlnRes   alns_u[2][kMaxAlns];       // rs1u_ / rs2u_: unpaired alignments per mate (also redMate1_/redMate2_)
+	AlnRes   alns_p[2][kMaxAlns];       // rs1_ / rs2_: concordant (or the one discordant) pair, same index
+	int64_t  redu_dmin[2][kMaxAlns], redu_dmax[2][kMaxAlns];
+	AlnRes   red_anchor[kMaxRedAnchor]; // redAnchor_: every alignment found for either mate while it was the anchor or the rescued mate
+	int64_t  reda_dmin[kMaxRedAnchor], reda_dmax[kMaxRedAnchor];
+	AlnRes   ores;                      // oresGap_
+	BtCand   cands2[kMaxCands];         // candidates of the opposite-mate DP (the anchor's stay live in `cands`)
+	uint32_t mate_streaks[kMaxSatpos];  // mateStreaks_
 	// ---- status / metrics ----
 };
 

@@ -19,7 +19,7 @@ struct Aligner {
 
 	const DevIndex<TOff>& ix;
 	const AlignParams& P;
-	const ReadParams& rp;
+	ReadParams& rp;      // per-read parameters of the loaded read (paired-end mode swaps the mate's in)
 	Work& w;
 	DpScratch dp;
 	Rng rnd;
@@ -32,9 +32,11 @@ struct Aligner {
 	uint32_t pf_steps = 0, pf_tiles = 0;   // profile: backtrace steps / tile fetches of this read
 	uint64_t pf_tile_t = 0;
 
-	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, const ReadParams& rp_, Work& w_, DpScratch dp_,
+	uint8_t m_nofw, m_norc;   // --nofw / --norc as they apply to the loaded read (mate 2 of an --fr pair sees them swapped)
+
+	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, ReadParams& rp_, Work& w_, DpScratch dp_,
 	               const PreComp* pre_ = nullptr, uint32_t ridx_ = 0)
-		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_), pre(pre_), ridx(ridx_), ext_pre(false) {}
+		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_), pre(pre_), ridx(ridx_), ext_pre(false), m_nofw(P_.nofw != 0), m_norc(P_.norc != 0), cands_cur(nullptr) {}
 
 	// exact_sweep() from the batch kernel's output
 	BT2_HD uint64_t exact_sweep_pre(uint32_t mine[2]) {
@@ -62,7 +64,8 @@ struct Aligner {
 			const bool fw = k < 2;
 			if ((fw && nofw) || (!fw && norc)) continue;
 			const Mm1Hit* src = pre->mm1 + ((uint64_t)ridx * 4 + k) * pre->mm1_cap;
-			for (uint32_t i = 0; i < n[k]; i++) add_mm1(src[i], fw);
+			// the batch kernel searched with the read's original minimum score; the worker's may have been tightened since
+			for (uint32_t i = 0; i < n[k]; i++) if ((int64_t)src[i].score >= minsc) add_mm1(src[i], fw);
 		}
 		return true;
 	}
@@ -79,7 +82,7 @@ struct Aligner {
 		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
-			const bool skip = (fw && P.nofw) || (!fw && P.norc);
+			const bool skip = (fw && m_nofw) || (!fw && m_norc);
 			const bt2g_seed_hit* src = pre->seeds + ((uint64_t)ridx * 2 + fwi) * pre->max_seeds;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				HotHit& h = HOT.hits[fwi][i];
@@ -130,7 +133,7 @@ struct Aligner {
 		mine[0] = mine[1] = 0;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
-			if ((fw && P.nofw) || (!fw && P.norc)) continue;
+			if ((fw && m_nofw) || (!fw && m_norc)) continue;
 			uint32_t dep = 0, nedit = 0;
 			bool done = false, do_init = true;
 			TOff top = 0, bot = 0;
@@ -215,7 +218,7 @@ struct Aligner {
 			const bool fw = fwi == 0;
 			if ((fw && nofw) || (!fw && norc)) continue;
 			for (int ebwtfwi = 0; ebwtfwi < 2; ebwtfwi++) {
-				fm_one_mm_dir(ix, P, (int64_t)rp.minsc, rp.nceil, rd, len, ns, fw, ebwtfwi == 0,
+				fm_one_mm_dir(ix, P, minsc, rp.nceil, rd, len, ns, fw, ebwtfwi == 0,   // minsc[mate] as tightened so far (bt2_search.cpp:3712)
 					[&](const Mm1Hit& m) { add_mm1(m, fw); }, cnt);
 			}
 		}
@@ -252,7 +255,7 @@ struct Aligner {
 				h.topf = h.topb = 0; h.size = 0;
 				HOT.sorted[fwi][i] = 0;
 			}
-			if ((fw && P.nofw) || (!fw && P.norc)) continue;
+			if ((fw && m_nofw) || (!fw && m_norc)) continue;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				const uint32_t depth = i * interval + offset;
 				// seed char k as it aligns to the Watson strand (instantiateSeq :463-485)
@@ -334,7 +337,7 @@ struct Aligner {
 				h.topf = h.topb = 0; h.size = 0;
 				HOT.sorted[fwi][i] = 0;
 			}
-			if ((fw && P.nofw) || (!fw && P.norc)) continue;
+			if ((fw && m_nofw) || (!fw && m_norc)) continue;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				const uint32_t depth = i * interval + offset;
 				auto getc = [&](uint32_t k) -> int { return fw ? (int)HOT.seq[depth + k] : comp4(HOT.seq[depth + L - 1 - k]); };
@@ -466,6 +469,7 @@ struct Aligner {
 				}
 			}
 		}
+		HOT.n_sranges = nsr;
 		return ninst;
 	}
 
@@ -523,6 +527,7 @@ struct Aligner {
 	}
 	BT2_HD void r1n_reset(R1N& r) { r.sz = r.n = r.cur = 0; r.swaplist = r.converted = 0; r.list_len = r.seen_len = 0; r.thresh = 0; r.inited = 0; }
 	BT2_HD bool r1n_done(const R1N& r) const { return r.n > 0 && r.cur >= r.n; }
+	BT2_HD void r1n_set_done(R1N& r) { r.cur = r.n; }
 	BT2_HD uint32_t lists_alloc(uint32_t n) {
 		if (HOT.lists_used + n > (uint32_t)kListArena) { HOT.err |= ERR_OVERFLOW; return 0; }
 		const uint32_t o = HOT.lists_used;
@@ -711,8 +716,9 @@ struct Aligner {
 			if (seedmms > 0) { const SeedRange& sr = w.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.size; }
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
-				const Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
-				const uint32_t nr = fw ? HOT.n_ex_fw : HOT.n_ex_rc;
+				const bool m2 = P.paired && HOT.pe.cur == 1;     // seedExRangeFw_[matei] / seedExRangeRc_[matei]
+				const Work::ExtRange* range = m2 ? (fw ? w.ex_fw2 : w.ex_rc2) : (fw ? w.ex_fw : w.ex_rc);
+				const uint32_t nr = m2 ? (fw ? HOT.pe.n_ex_fw2 : HOT.pe.n_ex_rc2) : (fw ? HOT.n_ex_fw : HOT.n_ex_rc);
 				bool skip = false;
 				for (uint32_t k = 0; k < nr; k++) {
 					if (range[k].off <= rdoff && range[k].off + range[k].len >= rdoff + seedlen) {
@@ -736,8 +742,9 @@ struct Aligner {
 			s.nlex = nlex; s.nrex = nrex;
 			HOT.n_ext_left += nlex; HOT.n_ext_right += nrex;
 			if (seedmms == 0 && (nlex > 0 || nrex > 0)) {
-				Work::ExtRange* range = fw ? w.ex_fw : w.ex_rc;
-				uint32_t& nr = fw ? HOT.n_ex_fw : HOT.n_ex_rc;
+				const bool m2 = P.paired && HOT.pe.cur == 1;
+				Work::ExtRange* range = m2 ? (fw ? w.ex_fw2 : w.ex_rc2) : (fw ? w.ex_fw : w.ex_rc);
+				uint32_t& nr = m2 ? (fw ? HOT.pe.n_ex_fw2 : HOT.pe.n_ex_rc2) : (fw ? HOT.n_ex_fw : HOT.n_ex_rc);
 				if (nr < (uint32_t)(kMaxRanges * 2)) {
 					range[nr].off = rdoff - (fw ? nlex : nrex);
 					range[nr].len = seedlen + nlex + nrex;
@@ -817,18 +824,21 @@ struct Aligner {
 	}
 
 	// seenDiags1_: plain union-of-intervals semantics (EIvalMergeListBinned, ival_list.h:210)
-	BT2_HD bool diag_present(int32_t ref, int64_t off, bool fw) const {
-		const int orient = fw ? 1 : 0;
+	BT2_HD bool diag_present(int32_t ref, int64_t off, bool fw) const { return diag_present_m(ref, off, fw, 0); }
+	BT2_HD void diag_add(int32_t ref, int64_t off, bool fw, int64_t len) { diag_add_m(ref, off, fw, len, 0); }
+	// seenDiags1_ / seenDiags2_ share the list; the mate rides in bit 1 of the orientation
+	BT2_HD bool diag_present_m(int32_t ref, int64_t off, bool fw, int mate) const {
+		const int orient = (fw ? 1 : 0) | (mate << 1);
 		for (uint32_t i = 0; i < HOT.n_diags; i++) {
 			const DiagIval& d = w.diags[i];
 			if (d.ref == ref && d.orient == orient && off >= d.off && off < d.off + d.len) return true;
 		}
 		return false;
 	}
-	BT2_HD void diag_add(int32_t ref, int64_t off, bool fw, int64_t len) {
+	BT2_HD void diag_add_m(int32_t ref, int64_t off, bool fw, int64_t len, int mate) {
 		if (HOT.n_diags >= (uint32_t)kMaxDiags) { HOT.err |= ERR_OVERFLOW; return; }
 		DiagIval& d = w.diags[HOT.n_diags++];
-		d.ref = ref; d.off = off; d.orient = fw ? 1 : 0; d.len = len;
+		d.ref = ref; d.off = off; d.orient = (fw ? 1 : 0) | (mate << 1); d.len = len;
 	}
 
 	// RedundantAlns cell enumeration (aligner_result.cpp:929-1032): per read row, the half-open
@@ -940,13 +950,13 @@ struct Aligner {
 			Plat::load_last_row(dp.mat, R, rows, cols, mode != 0);
 			HOT.t_phase[15] += now() - tl_;
 			// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
-			nc = Plat::gather_sort(w.cands, (uint32_t)kMaxCands, rows, cols, minsc_dp);
+			nc = Plat::gather_sort(cand_list(), (uint32_t)kMaxCands, rows, cols, minsc_dp);
 		} else {
 			// gatherCellsNucleotidesLocalSseU8/I16 (aligner_swsse_loc_u8.cpp:1389-1496): every cell with score >= minsc, at or
 			// below the first row that can reach minsc, that is a match whose diagonal successor is not; columns <= lastsolcol
 			const int64_t bonus = P.match_bonus;
 			const uint32_t minrow = (uint32_t)(((minsc_dp + bonus - 1) / bonus) - 1);
-			nc = Plat::gather_local(dp.mat, w.cands, (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow, w.cand_hist);
+			nc = Plat::gather_local(dp.mat, cand_list(), (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow, w.cand_hist);
 		}
 		if (nc > (uint32_t)kMaxCands) { HOT.err |= ERR_OVERFLOW; HOT.n_cands = kMaxCands; } else HOT.n_cands = nc;
 		HOT.t_phase[13] += HOT.n_cands;      // profile: candidate cells
@@ -983,7 +993,10 @@ struct Aligner {
 		// loop then reads them with v_readlane instead of going to LDS
 		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
 		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
-		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64);
+		// the walk moves left from the start column by at most rows + gaps columns: three registers (768 columns) ending
+		// at the start column cover it even when an opposite-mate window is wider than that
+		const uint32_t rf_c0 = (col + 1 > 768u) ? ((col + 1 - 768u + 3u) & ~3u) : 0u;   // `col` is still the start column here
+		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64 + (rf_c0 >> 2));
 		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
 			const uint32_t word = idx >> 2;
 			uint32_t v = Plat::lane(arr[0], word & 63);
@@ -1011,7 +1024,8 @@ struct Aligner {
 		HOT.n_bt_attempts++;
 		while ((int)row >= 0) {
 			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
-			const int refm = byte_of(rfw, 3, col);
+			if (col < rf_c0) { HOT.err |= ERR_OVERFLOW; return false; }
+			const int refm = byte_of(rfw, 3, col - rf_c0);
 			const int readq = byte_of(qlw, 2, fw ? row : rdlen - 1 - row);
 			// Flags are ints combined with & and |: the control code is wave-uniform and this keeps it on 32-bit scalar
 			// compares/selects instead of 64-bit lane-mask juggling.
@@ -1145,7 +1159,8 @@ struct Aligner {
 		if (!olap) return false;
 		{
 			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
-			const int refm = byte_of(rfw, 3, col);
+			if (col < rf_c0) { HOT.err |= ERR_OVERFLOW; return false; }
+			const int refm = byte_of(rfw, 3, col - rf_c0);
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) {
 				Edit& e = ned[nned++];
@@ -1246,7 +1261,7 @@ struct Aligner {
 		if (HOT.cural == HOT.n_cands) return false;
 		bool found = false;
 		while (HOT.cural < HOT.n_cands) {
-			BtCand c = w.cands[HOT.cural];
+			BtCand c = cand_list()[HOT.cural];
 			if (mode == 2) c.score &= ~kCandDone;
 			if (c.score < minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
 			if (mode == 2) {
@@ -1255,7 +1270,7 @@ struct Aligner {
 				uint32_t SQ = rows >> 4; if (SQ == 0) SQ = 1;
 				bool dom = false;
 				for (uint32_t k = 0; k < HOT.cural && !dom; k++) {
-					const BtCand& o = w.cands[k];
+					const BtCand& o = cand_list()[k];
 					if (!(o.score & kCandDone)) continue;
 					const uint32_t rhi = c.row > o.row ? c.row - o.row : o.row - c.row, chi = c.col > o.col ? c.col - o.col : o.col - c.col;
 					if (chi <= SQ && rhi <= SQ) dom = true;
@@ -1276,7 +1291,10 @@ struct Aligner {
 			else if (mode == 1) ret = backtrace<1>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
 			else ret = backtrace<2>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
 			rnd.init(sse16 ? reseed : reseed + 1);
-			if (mode == 2) w.cands[HOT.cural].score = cscore | kCandDone;       // btncanddone_: tried, succeeded or not
+			if (mode == 2) cand_list()[HOT.cural].score = cscore | kCandDone;       // btncanddone_: tried, succeeded or not
+#ifdef PE_DEBUG
+			if (cands_cur) fprintf(stderr, "     cand %u row %u col %u score %d ret %d nned %u refoff %lld resscore %d\n", HOT.cural, c.row, c.col, cscore, (int)ret, res.nned, (long long)res.refoff, res.score);
+#endif
 			if (ret) { found = true; break; }
 			HOT.cural++;
 		}
@@ -1617,8 +1635,8 @@ struct Aligner {
 			}
 			if (P.do_1mm_upfront) {
 				if (!done) {
-					const bool yfw = mine[0] <= 1 && !P.nofw;
-					const bool yrc = mine[1] <= 1 && !P.norc;
+					const bool yfw = mine[0] <= 1 && !m_nofw;
+					const bool yrc = mine[1] <= 1 && !m_norc;
 					nelt = 0;
 					if (yfw || yrc) {
 						const uint64_t t0_ = now();
@@ -1729,6 +1747,8 @@ struct Aligner {
 		out.nreport = num;
 		for (uint32_t i = 0; i < num; i++) Plat::copy_aln(out.alns[i], w.alns[idx[i]]);
 	}
+
+#include "bt2g_align_pe.inc"
 };
 
 } // namespace bt2g

@@ -17,6 +17,7 @@ struct CliExtra {
 	bool metrics = false;          // --met: per-read work counters on stderr (test aid)
 	bool arg_desc = false;         // --arg-desc
 	size_t batch_reads = 1u << 18;
+	bool allow_paired = false;     // set by the caller before parsing: this front end can run pairs
 };
 
 inline bool split_ints(const std::string& s, char sep, std::vector<int>& out) {
@@ -161,10 +162,19 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 			opt.local = true; opt.bwa_sw_like = true;
 			err = apply_policy_string(opt, "MA=1;MMP=C3;RDG=5,2;RFG=5,2");
 		}
-		// mate-pair geometry and pairing policy: accepted, and without effect on unpaired reads (-1/-2 are refused below)
-		else if (a == "-I" || a == "-X" || a == "--minins" || a == "--maxins") need();
-		else if (a == "--fr" || a == "--rf" || a == "--ff" || a == "--no-mixed" || a == "--no-discordant" || a == "--dovetail" ||
-		         a == "--no-contain" || a == "--no-overlap") {}
+		// paired-end input and policy (bt2_search.cpp:1185-1215); without -1/-2 the policy options have no effect
+		else if (a == "-1") opt.mate1_file = need();
+		else if (a == "-2") opt.mate2_file = need();
+		else if (a == "-I" || a == "--minins") opt.min_insert = atoi(need().c_str());
+		else if (a == "-X" || a == "--maxins") opt.max_insert = atoi(need().c_str());
+		else if (a == "--fr") { opt.mate1fw = true; opt.mate2fw = false; }
+		else if (a == "--rf") { opt.mate1fw = false; opt.mate2fw = true; }
+		else if (a == "--ff") { opt.mate1fw = true; opt.mate2fw = true; }
+		else if (a == "--no-mixed") opt.no_mixed = true;
+		else if (a == "--no-discordant") opt.no_discordant = true;
+		else if (a == "--dovetail") opt.dovetail = true;
+		else if (a == "--no-contain") opt.no_contain = true;
+		else if (a == "--no-overlap") opt.no_overlap = true;
 		else if (a == "-N") { const std::string v = need(); opt.seed_mms = atoi(v.c_str()); if (opt.seed_mms < 0 || opt.seed_mms > 1) err = "Error: -N was set to " + v + ", but cannot be set higher than 1 or less than 0"; }
 		else if (a == "-i") { opt.set_i = true; if (!opt.ms_ival.parse(need())) err = "bad -i function"; }
 		else if (a == "--score-min" || a == "--min-score") { opt.set_score_min = true; if (!opt.score_min.parse(need())) err = "bad --score-min function"; }
@@ -211,13 +221,18 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; if (iv.size() > 1) opt.rdg_linear = iv[1]; } }
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
-		else if (a == "-1" || a == "-2" || a == "-b" || a == "--interleaved" ||
+		else if (a == "-b" || a == "--interleaved" ||
 		         a == "-F" || a == "--int-quals" || a == "--solexa-quals")
 			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -k <= 64)";
 		else return "unsupported option " + a;
 		if (!err.empty()) return err;
 	}
 	if (opt.khits > 64) return "-k above 64 is not supported by this build";
+	if (opt.mate1_file.empty() != opt.mate2_file.empty()) return "-1 and -2 must be specified together";
+	opt.paired = !opt.mate1_file.empty();
+	if (opt.paired && !opt.reads_file.empty()) return "mixing paired (-1/-2) and unpaired (-U) inputs in one run is not supported by this build";
+	if (opt.paired && !ex.allow_paired) return "paired-end input (-1/-2) is not enabled in this build of the device path yet";
+	if (opt.paired && opt.max_insert < opt.min_insert) return "-X must not be smaller than -I";
 	if (opt.trim_to_len >= 0 && (opt.trim5 > 0 || opt.trim3 > 0)) return "--trim-to and -3/-5 are mutually exclusive";
 	if (opt.set_ma && !opt.local && opt.ma != 0) fprintf(stderr, "Warning: Match bonus always = 0 in --end-to-end mode; ignoring user setting\n");
 	if (opt.local && opt.set_ma && opt.ma <= 0) return "--local needs a positive --ma in this build";

@@ -78,6 +78,12 @@ struct Options {
 	bool mm_const = false;        // MMP=Cxx: constant mismatch penalty (policy string / --bwa-sw-like)
 	bool bwa_sw_like = false;     // --bwa-sw-like: minimum score = a*max(T, c*ln(len)) (bt2_search.cpp:3341-3350)
 	bool report_overhangs = false;
+	// paired-end input and policy (bt2_search.cpp:1185-1215; PairedEndPolicy pe.h:169)
+	std::string mate1_file, mate2_file, interleaved_file;
+	bool paired = false;
+	int min_insert = 0, max_insert = 500;
+	bool mate1fw = true, mate2fw = false;         // --fr (default) / --rf / --ff
+	bool no_mixed = false, no_discordant = false, dovetail = false, no_contain = false, no_overlap = false;
 	std::string rg_id, rgs, rg_optflag;   // @RG header pieces and the per-record RG:Z: flag (bt2_search.cpp:1418-1436)
 	uint32_t seed = 0;
 	int threads = 1;
@@ -125,13 +131,19 @@ struct Options {
 		P.rdgapo = rdg_const + rdg_linear; P.rdgape = rdg_linear; P.rfgapo = rfg_const + rfg_linear; P.rfgape = rfg_linear;
 		P.gapbar = gbar; P.match_bonus = local ? ma : 0;
 		P.khits = all_hits ? 64 : khits; P.mhits = (saw_k || all_hits) ? 0 : mhits; P.all_hits = all_hits ? 1 : 0; P.seed_mms = seed_mms; P.overhang = report_overhangs ? 1 : 0;
+		P.paired = paired ? 1 : 0;
+		P.pe_policy = (mate1fw && mate2fw) ? 1 : ((!mate1fw && !mate2fw) ? 2 : (mate1fw ? 3 : 4));   // gMate1fw/gMate2fw -> PE_POLICY_* (bt2_search.cpp:1841-1851)
+		P.pe_maxfrag = max_insert; P.pe_minfrag = min_insert;
+		P.pe_flags = (dovetail ? BT2G_PE_DOVETAIL_OK : 0) | (no_contain ? 0 : BT2G_PE_CONTAIN_OK) | (no_overlap ? 0 : BT2G_PE_OLAP_OK) | BT2G_PE_EXPAND |
+		             (no_discordant ? 0 : BT2G_PE_DISCORD) | (no_mixed ? 0 : BT2G_PE_MIXED) | (mate1fw ? BT2G_PE_MATE1FW : 0) | (mate2fw ? BT2G_PE_MATE2FW : 0);
+		P.max_mate_streak = 10;
 		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
 		if (all_hits) {
 			// -a lifts every effort limit (bt2_search.cpp:3457-3463)
-			P.max_dp_streak = P.max_ug = P.max_dp = P.max_iters = 0x7fffffff;
+			P.max_dp_streak = P.max_ug = P.max_dp = P.max_iters = P.max_mate_streak = 0x7fffffff;
 		} else if (khits > 1) {
 			// streak/limit scaling with -k (bt2_search.cpp:3452-3476): maxStreakIncr=10, maxItersIncr=20
-			P.max_dp_streak += (khits - 1) * 10;
+			P.max_dp_streak += (khits - 1) * 10; P.max_mate_streak += (khits - 1) * 10;
 			P.max_ug += (khits - 1) * 20; P.max_dp += (khits - 1) * 20; P.max_iters += (khits - 1) * 20;
 		}
 		P.n_seed_rounds = n_seed_rounds; P.seed_boost_thresh = 300; P.tighten = 3; P.maxhalf = maxhalf;
@@ -244,11 +256,14 @@ inline void sam_header(std::string& o, const RefInfo& ref, const std::string& cm
 }
 
 // BowtieMapq2::mapq for an unpaired, primary, end-to-end alignment (unique.h:185-330)
-inline int mapq_v2(const Options& o, size_t rdlen, int64_t best, bool has_secbest, int64_t secbest_in) {
-	const int64_t scPer = o.local ? (int64_t)rdlen * o.ma : 0;
+inline int mapq_v2(const Options& o, size_t rdlen, int64_t best, bool has_secbest, int64_t secbest_in, bool pair = false, size_t ordlen = 0) {
+	// a concordant / discordant pair is rated on the sum of both mates' scores (unique.h:207-215)
+	int64_t scPer = o.local ? (int64_t)rdlen * o.ma : 0;
+	if (pair && o.local) scPer += (int64_t)ordlen * o.ma;
 	if (o.local) {
 		// non-monotone branch (unique.h:333-383)
-		const int64_t scMin = o.score_min.f<int64_t>((double)(float)rdlen);
+		int64_t scMin = o.score_min.f<int64_t>((double)(float)rdlen);
+		if (pair) scMin += o.score_min.f<int64_t>((double)(float)ordlen);
 		const int64_t diff = std::max<int64_t>(1, scPer - scMin);
 		const int64_t bestOver = best - scMin;
 		if (!has_secbest) {
@@ -273,7 +288,8 @@ inline int mapq_v2(const Options& o, size_t rdlen, int64_t best, bool has_secbes
 		else if (bestdiff > 0) return bestOver >= diff * (double)0.5f ? 11 : 2;
 		return bestOver >= diff * (double)0.5f ? 1 : 0;
 	}
-	const int64_t scMin = o.score_min.f<int64_t>((double)(float)rdlen);
+	int64_t scMin = o.score_min.f<int64_t>((double)(float)rdlen);
+	if (pair) scMin += o.score_min.f<int64_t>((double)(float)ordlen);
 	int64_t secbest = scMin - 1;
 	const int64_t diff = std::max<int64_t>(1, scPer - scMin);
 	int ret = 0;
@@ -328,18 +344,59 @@ inline void app_int(std::string& o, int64_t v) {
 	while (n) o.push_back(buf[--n]);
 }
 
+// What AlnSinkSam::appendMate needs to know about the other mate (aln_sink.cpp:1889-2124; AlnFlags aligner_result.h:1580)
+struct MateOut {
+	bool mate1 = true;
+	int kind = 0;                       // 0 mate reported on its own (YT:Z:UP), 1 concordant (CP), 2 discordant (DP)
+	bool opp_aligned = false, opp_fw = true;
+	const AlnRes* rso = nullptr;        // the other mate's alignment that goes with this line
+	int64_t orefid = -1, orefoff = -1;  // unaligned mate: where the other mate went
+	size_t ordlen = 0;
+	int64_t pair_best = 0, pair_secbest = 0;
+	bool pair_has_secbest = false;
+};
+
+// TLEN (AlnRes::setFragmentLength, aligner_result.h:1311-1345): extents include soft-trimmed bases
+inline int64_t sam_fragment_length(const AlnRes& a, const AlnRes& b, bool a_is_mate1) {
+	auto ext = [](const AlnRes& r, int64_t& st, int64_t& en) {
+		st = r.refoff; en = r.refoff + (int64_t)r.rfextent - 1;
+		st -= r.fw ? r.trim5p : r.trim3p;
+		en += r.fw ? r.trim3p : r.trim5p;
+	};
+	int64_t st, en, ost, oen;
+	ext(a, st, en); ext(b, ost, oen);
+	bool up;
+	if (st == ost) up = (a.fw && b.fw && a_is_mate1) || (a.fw && !b.fw);
+	else up = st < ost;
+	const int64_t lo = std::min(st, ost), hi = std::max(en, oen);
+	const int64_t fl = 1 + hi - lo;
+	return up ? fl : -fl;
+}
+
 inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, const ReadRec& rd,
-                       const ReadResult& rr, const AlnRes* aln, bool primary) {
+                       const ReadResult& rr, const AlnRes* aln, bool primary, const MateOut* mo = nullptr) {
 	static const char* DNA = "ACGTN";
 	const size_t len = rd.seq.size();
 	sam_print_name(o, rd.name, !opt.sam_no_qname_trunc);
+	if (mo) {   // printReadName(omitSlashMate): a trailing /1, /2 or /3 is dropped for mates (sam.h:329-336)
+		const size_t ol = o.size();
+		if (ol >= 2 && o[ol - 2] == '/' && (o[ol - 1] == '1' || o[ol - 1] == '2' || o[ol - 1] == '3')) o.resize(ol - 2);
+	}
 	o.push_back('\t');
 	int fl = 0;
+	if (mo) {
+		fl |= 1;
+		if (mo->kind == 1) fl |= 2;
+		if (!mo->opp_aligned) fl |= 8;
+		fl |= mo->mate1 ? 64 : 128;
+		if (mo->opp_aligned) { const bool ofw = mo->rso ? mo->rso->fw != 0 : mo->opp_fw; if (!ofw) fl |= 32; }
+	}
 	if (!primary) fl |= 256;
 	if (aln && !aln->fw) fl |= 16;
 	if (!aln) fl |= 4;
 	app_int(o, (int64_t)(fl)); o.push_back('\t');
 	if (aln) { sam_print_name(o, ref.names[aln->refid], true); o.push_back('\t'); app_int(o, (int64_t)(aln->refoff + 1)); o.push_back('\t'); }
+	else if (mo && mo->orefid != -1) { sam_print_name(o, ref.names[mo->orefid], true); o.push_back('\t'); app_int(o, mo->orefoff + 1); o.push_back('\t'); }
 	else o += "*\t0\t";
 	// stacked alignment (StackedAln::init / leftAlign / buildCigar / buildMdz)
 	static thread_local std::string stRef, stRel, stRead, md;
@@ -387,7 +444,10 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		// unique.h:199-205: a secondary line, or "one alignment found without looking for a second" (-k: canMax is
 		// false, and the reference never sets `exhausted`), reports 255
 		const bool can_max = !(opt.saw_k || opt.all_hits) && opt.mhits > 0;
-		if (!primary || (!can_max && !rr.has_secbest)) o += "255";
+		const bool summ_paired = mo && mo->kind != 0;
+		const bool has_sec = summ_paired ? mo->pair_has_secbest : rr.has_secbest != 0;
+		if (!primary || (!can_max && !has_sec)) o += "255";
+		else if (summ_paired) app_int(o, (int64_t)mapq_v2(opt, len, mo->pair_best, has_sec, mo->pair_secbest, true, mo->ordlen));
 		else app_int(o, (int64_t)(mapq_v2(opt, len, rr.best, rr.has_secbest != 0, rr.secbest)));
 		o.push_back('\t');
 		// CIGAR
@@ -405,7 +465,16 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	} else {
 		o += "0\t*\t";
 	}
-	o += "*\t0\t0\t";
+	// RNEXT / PNEXT / TLEN
+	if (aln && mo) {
+		if (mo->rso && aln->refid != mo->rso->refid) { sam_print_name(o, ref.names[mo->rso->refid], true); o.push_back('\t'); } else o += "=\t";
+		app_int(o, (mo->rso ? mo->rso->refoff : aln->refoff) + 1); o.push_back('\t');
+		// fragment length only for pairs (setMateParams with the other mate), on the same reference or concordant
+		if (mo->kind != 0 && mo->rso && (aln->refid == mo->rso->refid || mo->kind == 1)) app_int(o, sam_fragment_length(*aln, *mo->rso, mo->mate1));
+		else o.push_back('0');
+		o.push_back('\t');
+	} else if (mo && mo->orefid != -1) { o += "=\t"; app_int(o, mo->orefoff + 1); o += "\t0\t"; }
+	else o += "*\t0\t0\t";
 	// SEQ / QUAL
 	if (len == 0) o.push_back('*');
 	else if (!primary && opt.omit_sec_seq) o.push_back('*');
@@ -420,7 +489,9 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	// optional fields
 	if (aln) {
 		o += "AS:i:"; app_int(o, aln->score);
-		if (rr.has_secbest) { o += "\tXS:i:"; app_int(o, rr.secbest); }
+		// XS:i: for mates the best alignment of this mate at another locus than the chosen pair's; a mate reported
+		// on its own (UP) never carries it -- the reference looks up the pair fields, which only pairs fill (sam.cpp:144-150)
+		if (rr.has_secbest && (!mo || mo->kind != 0)) { o += "\tXS:i:"; app_int(o, rr.secbest); }
 		o += "\tXN:i:"; app_int(o, aln->refns);
 		size_t num_mm = 0, num_go = 0, num_gx = 0;
 		for (size_t i = 0; i < aln->nned; i++) {
@@ -464,10 +535,11 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 			if (mm_last || rdgap_last) md.push_back('0');
 		}
 		o += "\tMD:Z:"; o += md;
+		if (mo && mo->kind != 0 && mo->rso) { o += "\tYS:i:"; app_int(o, mo->rso->score); }
 		// YF would go here for filtered reads, but filtered reads never align
-		o += "\tYT:Z:UU";
+		o += mo ? (mo->kind == 1 ? "\tYT:Z:CP" : (mo->kind == 2 ? "\tYT:Z:DP" : "\tYT:Z:UP")) : "\tYT:Z:UU";
 	} else {
-		o += "YT:Z:UU";
+		o += mo ? "YT:Z:UP" : "YT:Z:UU";
 		const uint32_t f = rr.filt;
 		const char* flag = "";
 		if (!(f & 4)) flag = "LN"; else if (!(f & 1)) flag = "NS"; else if (!(f & 2)) flag = "SC"; else if (!(f & 8)) flag = "QC";
@@ -475,6 +547,49 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	}
 	if (!opt.rg_optflag.empty()) { o.push_back('\t'); o += opt.rg_optflag; }
 	o.push_back('\n');
+}
+
+// SAM lines of one pair, in the order AlnSinkWrap::finishRead / AlnSink::reportHits emit them (aln_sink.cpp:700-1390,
+// aln_sink.h:646-728).  a1 / a2: the nreport alignments of each mate's record.
+inline void sam_pair_records(std::string& o, const Options& opt, const RefInfo& ref, const ReadRec& rd1, const ReadRec& rd2,
+                             const ReadResult& rr1, const ReadResult& rr2, const AlnRes* const* a1, const AlnRes* const* a2) {
+	const ReadRec* rd[2] = {&rd1, &rd2};
+	const ReadResult* rr[2] = {&rr1, &rr2};
+	const AlnRes* const* al[2] = {a1, a2};
+	if (rr1.pair_type != 0) {
+		// concordant or discordant: alignment i of mate 1 goes with alignment i of mate 2
+		for (uint32_t i = 0; i < rr1.nreport; i++) {
+			for (int m = 0; m < 2; m++) {
+				MateOut mo;
+				mo.mate1 = m == 0; mo.kind = rr1.pair_type; mo.opp_aligned = true; mo.rso = al[m ^ 1][i]; mo.opp_fw = mo.rso->fw != 0;
+				mo.ordlen = rd[m ^ 1]->seq.size();
+				mo.pair_best = rr[m]->pair_best; mo.pair_secbest = rr[m]->pair_secbest; mo.pair_has_secbest = (rr[m]->pair_flags & 2) != 0;
+				sam_record(o, opt, ref, *rd[m], *rr[m], al[m][i], i == 0, &mo);
+			}
+		}
+		return;
+	}
+	// each mate on its own: all of mate 1's lines, then mate 2's; an unaligned mate borrows the other's primary position
+	const AlnRes* pri[2] = {rr1.aligned ? a1[0] : nullptr, rr2.aligned ? a2[0] : nullptr};
+	int64_t orefid = -1, orefoff = -1;
+	for (int m = 0; m < 2; m++) {
+		if (!rr[m]->aligned) continue;
+		for (uint32_t i = 0; i < rr[m]->nreport; i++) {
+			MateOut mo;
+			mo.mate1 = m == 0; mo.kind = 0; mo.opp_aligned = pri[m ^ 1] != nullptr; mo.rso = pri[m ^ 1]; mo.opp_fw = !pri[m ^ 1] || pri[m ^ 1]->fw != 0;
+			mo.ordlen = rd[m ^ 1]->seq.size();
+			sam_record(o, opt, ref, *rd[m], *rr[m], al[m][i], i == 0, &mo);
+		}
+		orefid = al[m][0]->refid; orefoff = al[m][0]->refoff;
+	}
+	for (int m = 0; m < 2; m++) {
+		if (rr[m]->aligned || opt.no_unal) continue;
+		MateOut mo;
+		mo.mate1 = m == 0; mo.kind = 0; mo.opp_aligned = pri[m ^ 1] != nullptr; mo.opp_fw = pri[m ^ 1] ? pri[m ^ 1]->fw != 0 : false;
+		if (rr[m ^ 1]->aligned) { mo.orefid = orefid; mo.orefoff = orefoff; }
+		mo.ordlen = rd[m ^ 1]->seq.size();
+		sam_record(o, opt, ref, *rd[m], *rr[m], nullptr, true, &mo);
+	}
 }
 
 struct AlnSummary {
@@ -490,6 +605,58 @@ struct AlnSummary {
 		fprintf(f, "    %llu (%s) aligned exactly 1 time\n", (unsigned long long)nuni, pct(nuni, nread).c_str());
 		fprintf(f, "    %llu (%s) aligned >1 times\n", (unsigned long long)nrep, pct(nrep, nread).c_str());
 		fprintf(f, "%s overall alignment rate\n", pct(nuni + nrep, nread).c_str());
+	}
+};
+
+// Alignment summary of a paired run (AlnSink::printAlSumm, aln_sink.cpp:377-528)
+struct PairSummary {
+	uint64_t npair = 0, conc0 = 0, conc_uni1 = 0, conc_uni2 = 0, conc_rep = 0, ndiscord = 0;
+	uint64_t unp00 = 0, unp0_uni1 = 0, unp0_uni2 = 0, unp0_rep = 0;
+	void merge(const PairSummary& o) {
+		npair += o.npair; conc0 += o.conc0; conc_uni1 += o.conc_uni1; conc_uni2 += o.conc_uni2; conc_rep += o.conc_rep; ndiscord += o.ndiscord;
+		unp00 += o.unp00; unp0_uni1 += o.unp0_uni1; unp0_uni2 += o.unp0_uni2; unp0_rep += o.unp0_rep;
+	}
+	void add(const ReadResult& r1, const ReadResult& r2) {
+		npair++;
+		if (r1.pair_type == 1) {
+			if (r1.pair_flags & 1) conc_rep++; else if (!(r1.pair_flags & 2)) conc_uni1++; else conc_uni2++;
+			return;
+		}
+		conc0++;
+		if (r1.pair_type == 2) { ndiscord++; return; }
+		const ReadResult* rr[2] = {&r1, &r2};
+		for (int m = 0; m < 2; m++) {
+			if (rr[m]->aligned) { if (rr[m]->maxed) unp0_rep++; else if (rr[m]->nalns == 1) unp0_uni1++; else unp0_uni2++; }
+			else if (rr[m]->maxed) unp0_rep++;
+			else unp00++;
+		}
+	}
+	void print(FILE* f, bool discord, bool mixed) const {
+		auto pct = [](uint64_t a, uint64_t b) { char buf[32]; snprintf(buf, sizeof buf, "%.2f%%", b ? 100.0 * (double)a / (double)b : 0.0); return std::string(buf); };
+		auto L = [](uint64_t v) { return (unsigned long long)v; };
+		if (npair > 0) fprintf(f, "%llu reads; of these:\n", L(npair)); else fprintf(f, "0 reads\n");
+		if (npair > 0) {
+			fprintf(f, "  %llu (%s) were paired; of these:\n", L(npair), pct(npair, npair).c_str());
+			fprintf(f, "    %llu (%s) aligned concordantly 0 times\n", L(conc0), pct(conc0, npair).c_str());
+			fprintf(f, "    %llu (%s) aligned concordantly exactly 1 time\n", L(conc_uni1), pct(conc_uni1, npair).c_str());
+			fprintf(f, "    %llu (%s) aligned concordantly >1 times\n", L(conc_uni2 + conc_rep), pct(conc_uni2 + conc_rep, npair).c_str());
+			if (discord) {
+				fprintf(f, "    ----\n");
+				fprintf(f, "    %llu pairs aligned concordantly 0 times; of these:\n", L(conc0));
+				fprintf(f, "      %llu (%s) aligned discordantly 1 time\n", L(ndiscord), pct(ndiscord, conc0).c_str());
+			}
+			const uint64_t ncd0 = conc0 - ndiscord;
+			if (mixed) {
+				fprintf(f, "    ----\n");
+				fprintf(f, "    %llu pairs aligned 0 times concordantly or discordantly; of these:\n", L(ncd0));
+				fprintf(f, "      %llu mates make up the pairs; of these:\n", L(ncd0 * 2));
+				fprintf(f, "        %llu (%s) aligned 0 times\n", L(unp00), pct(unp00, ncd0 * 2).c_str());
+				fprintf(f, "        %llu (%s) aligned exactly 1 time\n", L(unp0_uni1), pct(unp0_uni1, ncd0 * 2).c_str());
+				fprintf(f, "        %llu (%s) aligned >1 times\n", L(unp0_uni2 + unp0_rep), pct(unp0_uni2 + unp0_rep, ncd0 * 2).c_str());
+			}
+		}
+		const uint64_t tot_al = (conc_uni1 + conc_uni2 + conc_rep) * 2 + ndiscord * 2 + unp0_uni1 + unp0_uni2 + unp0_rep;
+		fprintf(f, "%s overall alignment rate\n", pct(tot_al, npair * 2).c_str());
 	}
 };
 

@@ -112,7 +112,45 @@ struct HostBatch {
 	bool last = false;                    // end-of-input marker (may still carry reads)
 	bool terminator = false;              // tells one device worker to stop (carries nothing)
 	uint64_t seqno = 0;                   // position in the input, for ordered output with several devices
+	// paired-end: reads[2i] / reads[2i+1] are the mates of pair i; their text lives in the two single-mate batches
+	bool paired = false;
+	std::unique_ptr<HostBatch> mate_src[2];
 };
+
+// Interleave two single-mate batches into one paired batch (mate 1 at even, mate 2 at odd positions), and apply the
+// pair-level adjustments of the per-read parameters (bt2_search.cpp:3427-3434: seed interval x1.2 when both mates pass
+// their filters).
+inline void merge_mate_batches(std::unique_ptr<HostBatch> b1, std::unique_ptr<HostBatch> b2, HostBatch& out, const Options& opt) {
+	out.paired = true;
+	out.last = b1->last || b2->last;
+	out.bad_input = !b1->bad_input.empty() ? b1->bad_input : b2->bad_input;
+	out.too_long = !b1->too_long.empty() ? b1->too_long : b2->too_long;
+	if (out.bad_input.empty() && b1->reads.size() != b2->reads.size())
+		out.bad_input = "fewer reads in file specified with -" + std::string(b1->reads.size() < b2->reads.size() ? "1" : "2") + " than in file specified with -" + (b1->reads.size() < b2->reads.size() ? "2" : "1");
+	const size_t n = std::min(b1->reads.size(), b2->reads.size());
+	out.reads.resize(2 * n); out.rp.resize(2 * n); out.off.resize(2 * n + 1);
+	out.off[0] = 0;
+	out.max_len = std::max(b1->max_len, b2->max_len);
+	for (size_t i = 0; i < n; i++) {
+		out.reads[2 * i] = b1->reads[i]; out.reads[2 * i + 1] = b2->reads[i];
+		out.rp[2 * i] = b1->rp[i]; out.rp[2 * i + 1] = b2->rp[i];
+		if ((out.rp[2 * i].filt & 15u) == 15u && (out.rp[2 * i + 1].filt & 15u) == 15u) {
+			for (int m = 0; m < 2; m++) {
+				int iv = opt.ms_ival.f<int>((double)out.reads[2 * i + m].seq.size());
+				iv = (int)(iv * 1.2 + 0.5);
+				out.rp[2 * i + m].interval = iv < 1 ? 1 : iv;
+			}
+		}
+		out.off[2 * i + 1] = out.off[2 * i] + b1->reads[i].seq.size();
+		out.off[2 * i + 2] = out.off[2 * i + 1] + b2->reads[i].seq.size();
+	}
+	out.seq.resize(out.off[2 * n]); out.qual.resize(out.off[2 * n]);
+	for (size_t i = 0; i < 2 * n; i++) {
+		const ReadRec& r = out.reads[i];
+		if (r.seq.size()) { memcpy(&out.seq[out.off[i]], r.seq.data(), r.seq.size()); memcpy(&out.qual[out.off[i]], r.qual.data(), r.qual.size()); }
+	}
+	out.mate_src[0] = std::move(b1); out.mate_src[1] = std::move(b2);
+}
 
 // Line-oriented reader over gz or plain input (gzread handles both)
 class LineSource {

@@ -209,7 +209,23 @@ typedef struct {
 	int32_t seed_mms;              /* -N: 0 = exact seeds, 1 = one mismatch per seed (Seed::oneMmSeeds)          */
 	int32_t overhang;              /* --overhang (gReportOverhangs): DP windows may run past the reference ends by
 	                                  the N ceiling, overhanging read ends come back soft-clipped                    */
+	/* paired-end mode (extendSeedsPaired, PairedEndPolicy pe.h:169).  With paired != 0 the batch holds mates
+	   interleaved (read 2i = mate 1, read 2i+1 = mate 2 of pair i) and result record 2i / 2i+1 belong together */
+	int32_t paired;
+	int32_t pe_policy;             /* PE_POLICY_FF 1, RR 2, FR 3 (default), RF 4 (pe.h:33-36)                   */
+	int32_t pe_maxfrag, pe_minfrag;/* -X / -I                                                                    */
+	int32_t pe_flags;              /* BT2G_PE_* below                                                            */
+	int32_t max_mate_streak;       /* maxMateStreak (10), scaled with -k like max_dp_streak                      */
 } bt2g_align_params;
+#define BT2G_PE_DOVETAIL_OK  1     /* --dovetail                       */
+#define BT2G_PE_CONTAIN_OK   2     /* cleared by --no-contain          */
+#define BT2G_PE_OLAP_OK      4     /* cleared by --no-overlap          */
+#define BT2G_PE_EXPAND       8     /* gExpandToFrag (always on)        */
+#define BT2G_PE_FLIP_OK     16     /* gFlippedMatesOK (always off)     */
+#define BT2G_PE_DISCORD     32     /* cleared by --no-discordant       */
+#define BT2G_PE_MIXED       64     /* cleared by --no-mixed            */
+#define BT2G_PE_MATE1FW    128     /* --fr/--ff: mate 1 forward        */
+#define BT2G_PE_MATE2FW    256     /* --ff/--rf                        */
 
 /* per-read inputs the host derives with the reference's formulas (bt2_search.cpp:3352-3450, pat.cpp:45) */
 typedef struct {
@@ -237,11 +253,15 @@ typedef struct {                   /* AlnRes (aligner_result.h:792), the fields 
 
 typedef struct {
 	uint8_t  status;               /* 0 ok; bit 0 = a fixed-capacity work buffer overflowed (result not reference-identical) */
-	uint8_t  aligned, maxed, filt, exhausted, has_secbest, pad[2];
+	uint8_t  aligned, maxed, filt, exhausted, has_secbest;
+	uint8_t  pair_type;            /* paired-end: 0 = this mate reported on its own (or unaligned), 1 = concordant, 2 = discordant */
+	uint8_t  pair_flags;           /* bit0 pair over the -M ceiling (pairMax), bit1 a second-best pair score exists     */
 	int32_t  secbest, best;        /* XS:i / MAPQ inputs                                      */
 	uint32_t nalns, nreport;
 	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail_streak_max, n_bwops_seed, n_bwops_ext, n_redundants, n_bt_attempts;
 	uint32_t n_ext_left, n_ext_right, n_resolve_steps, n_sides;   /* seed-hit extension steps, SA-walk steps, sides read */
+	int32_t  pair_best, pair_secbest;  /* paired-end MAPQ inputs: best / second-best concordant (or discordant) pair score   */
+	uint32_t n_mate_dps, pad2;         /* opposite-mate DPs run for this anchor mate                                          */
 	bt2g_aln alns[1];              /* nreport (<= khits) entries                              */
 } bt2g_read_result;
 

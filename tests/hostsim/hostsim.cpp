@@ -39,6 +39,7 @@ struct HostPlat {
 			g_hot.lastrow[j] = (int16_t)(sc < -32768 ? -32768 : sc);
 		}
 	}
+	static void load_read(const uint8_t* seq, const uint8_t* qual, uint32_t len) { memcpy(g_hot.seq, seq, len); memcpy(g_hot.qual, qual, len); }
 	static void copy_aln(AlnRes& dst, const AlnRes& src) { memcpy(&dst, &src, offsetof(AlnRes, ned) + (size_t)src.nned * sizeof(Edit)); }
 	static uint32_t gather_sort(BtCand* cands, uint32_t cap, uint32_t rows, uint32_t cols, int64_t minsc_dp) {
 		uint32_t n = 0, total = 0;
@@ -272,9 +273,71 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	return 0;
 }
 
+// paired-end flavour of run(): two single-mate readers, one pair at a time through Aligner::run_pair
+template <typename TOff>
+static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool metrics) {
+	DevIndex<TOff> ix;
+	make_dev_index(hidx, ix);
+	AlignParams P;
+	opt.to_params(P, sizeof(TOff) == 8);
+	RefInfo ref;
+	ref.names = hidx.fw.refnames;
+	for (uint64_t i = 0; i < hidx.fw.n_pat; i++) ref.lens.push_back(hidx.plen_at(i));
+	std::string o;
+	if (!opt.sam_no_hd) sam_header(o, ref, opt.cmdline, true, !opt.sam_no_sq, opt.rg_id, opt.rgs);
+	fwrite(o.data(), 1, o.size(), out);
+	FastqBatcher fq1(opt.mate1_file, opt, 1), fq2(opt.mate2_file, opt, 1);
+	if (!fq1.ok() || !fq2.ok()) { fprintf(stderr, "cannot open the mate files\n"); return 1; }
+	Work* w = new Work();
+	DpScratch dp, dp2;
+	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 8;
+	dp.mat = (uint32_t*)malloc(mat_bytes); dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
+	dp2.mat = (uint32_t*)malloc(mat_bytes); dp2.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
+	const size_t rec_bytes = sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(P.khits + 1);
+	std::vector<uint8_t> resbuf(2 * rec_bytes);
+	PairSummary summ;
+	uint32_t pair_no = 0;
+	for (bool last = false; !last; ) {
+		std::unique_ptr<HostBatch> b1(new HostBatch()), b2(new HostBatch());
+		fq1.next(*b1, 4096, (size_t)1 << 30);
+		fq2.next(*b2, 4096, (size_t)1 << 30);
+		HostBatch hb;
+		merge_mate_batches(std::move(b1), std::move(b2), hb, opt);
+		last = hb.last;
+		if (!hb.bad_input.empty()) { fprintf(stderr, "Error: %s\n", hb.bad_input.c_str()); return 1; }
+		for (size_t pi = 0; pi + 1 < hb.reads.size(); pi += 2, pair_no++) {
+			const ReadRec& r1 = hb.reads[pi]; const ReadRec& r2 = hb.reads[pi + 1];
+			if (r1.seq.size() > (size_t)kMaxLen || r2.seq.size() > (size_t)kMaxLen) { fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", r1.name.str().c_str(), kMaxLen); return 1; }
+			ReadResult& rr1 = *(ReadResult*)resbuf.data();
+			ReadResult& rr2 = *(ReadResult*)(resbuf.data() + rec_bytes);
+			ReadParams rp = hb.rp[pi];
+			Aligner<TOff, HostPlat> al(ix, P, rp, *w, dp);
+			al.dp_main = dp; al.dp_opp = dp2;
+			al.pe_seq[0] = (const uint8_t*)r1.seq.data(); al.pe_qual[0] = (const uint8_t*)r1.qual.data(); al.pe_len[0] = (uint32_t)r1.seq.size();
+			al.pe_seq[1] = (const uint8_t*)r2.seq.data(); al.pe_qual[1] = (const uint8_t*)r2.qual.data(); al.pe_len[1] = (uint32_t)r2.seq.size();
+			al.pe_rp[0] = hb.rp[pi]; al.pe_rp[1] = hb.rp[pi + 1];
+			al.pe_pair = 0;
+			al.run_pair(rr1, rr2);
+			if (rr1.status || rr2.status) fprintf(stderr, "Warning: pair %s overflowed a fixed-capacity buffer (status %d)\n", r1.name.str().c_str(), rr1.status | rr2.status);
+			summ.add(rr1, rr2);
+			std::vector<const AlnRes*> a1, a2;
+			for (uint32_t i = 0; i < rr1.nreport; i++) a1.push_back(&rr1.alns[i]);
+			for (uint32_t i = 0; i < rr2.nreport; i++) a2.push_back(&rr2.alns[i]);
+			o.clear();
+			sam_pair_records(o, opt, ref, r1, r2, rr1, rr2, a1.data(), a2.data());
+			fwrite(o.data(), 1, o.size(), out);
+			if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u matedps=%u ugs=%u red=%u bt=%u n1=%u n2=%u type=%u\n", r1.name.str().c_str(),
+			                     rr1.n_ex_iters, rr1.n_ex_dps, rr1.n_mate_dps, rr1.n_ex_ugs, rr1.n_redundants, rr1.n_bt_attempts, rr1.nalns, rr2.nalns, rr1.pair_type);
+		}
+	}
+	summ.print(stderr, !opt.no_discordant, !opt.no_mixed);
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	Options opt;
 	CliExtra ex;
+	ex.allow_paired = true;
 	const std::string perr = parse_cli(argc, argv, opt, ex);
 	if (!perr.empty()) { fprintf(stderr, "%s\n", perr.c_str()); return 1; }
 	const bool metrics = ex.metrics;
@@ -283,7 +346,9 @@ int main(int argc, char** argv) {
 	std::string err;
 	if (load_index(opt.index_base, hidx, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
 	FILE* out = opt.out_file.empty() ? stdout : fopen(opt.out_file.c_str(), "wb");
-	int rc = hidx.off_size == 4 ? run<uint32_t>(hidx, opt, out, metrics) : run<uint64_t>(hidx, opt, out, metrics);
+	int rc;
+	if (opt.paired) rc = hidx.off_size == 4 ? run_pairs<uint32_t>(hidx, opt, out, metrics) : run_pairs<uint64_t>(hidx, opt, out, metrics);
+	else rc = hidx.off_size == 4 ? run<uint32_t>(hidx, opt, out, metrics) : run<uint64_t>(hidx, opt, out, metrics);
 	if (out != stdout) fclose(out);
 	return rc;
 }
