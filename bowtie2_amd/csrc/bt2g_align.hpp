@@ -44,7 +44,7 @@ constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at 
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 16384; // uint32 slots for Random1toN lists
 constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
-constexpr int kMaxCols     = 1000;  // DP columns: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*15
+constexpr int kMaxCols     = 960;   // DP columns: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*15
 
 enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
 enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMIT, EXT_HARD_LIMIT };
@@ -167,7 +167,7 @@ struct HotWork {
 	uint32_t n_mm1;
 	uint64_t mm1_elt;
 	uint32_t num_offs;
-	uint32_t off_idx2off[kMaxOffs];
+	uint16_t off_idx2off[kMaxOffs];   // read offsets of the seed positions (< kMaxLen)
 	uint32_t n_rank;
 	uint32_t nonz_tot, nonz_fw, nonz_rc;
 	uint64_t num_elts;

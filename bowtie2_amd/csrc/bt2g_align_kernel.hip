@@ -264,6 +264,12 @@ struct DevPlat {
 		wave_fence();
 	}
 	// AlnRes copy, one 32-bit word per lane per pass; only the header and the edits in use move
+	// stage a read (bases + qualities) into the hot state, lane-parallel
+	static __device__ __forceinline__ void load_read(const uint8_t* seq, const uint8_t* qual, uint32_t len) {
+		wave_fence();
+		for (uint32_t i = threadIdx.x & 63; i < len; i += 64) { g_hot.seq[i] = seq[i]; g_hot.qual[i] = qual[i]; }
+		wave_fence();
+	}
 	static __device__ __forceinline__ void copy_aln(AlnRes& dst, const AlnRes& src) {
 		wave_fence();
 		const uint32_t nw = ((uint32_t)offsetof(AlnRes, ned) + (uint32_t)uni((uint32_t)src.nned) * (uint32_t)sizeof(Edit) + 3u) / 4u;
@@ -527,6 +533,66 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	}
 }
 
+// Paired-end flavour: one wavefront per pair (reads 2p and 2p+1, result records 2p and 2p+1).  A separate kernel so
+// that the unpaired kernel's register allocation and code layout do not carry the pair logic.
+template <typename TOff>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU)))
+k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
+              uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
+              uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
+              PreComp pre) {
+	const int lane = threadIdx.x & 63;
+	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
+	Work& w = *reinterpret_cast<Work*>(base);
+	DpScratch dp, dp2;
+	dp.mat = reinterpret_cast<uint32_t*>(base + ((sizeof(Work) + 255) & ~(uint64_t)255));
+	dp.masks = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(dp.mat) + mat_bytes);
+	dp2.mat = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(dp.masks) + mask_bytes);
+	dp2.masks = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(dp2.mat) + mat_bytes);
+	__shared__ DevIndex<TOff> s_ix;
+	__shared__ AlignParams s_P;
+	__shared__ ReadParams s_rp;
+	__shared__ PreComp s_pre;
+	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
+	s_ix = ix; s_P = P; s_pre = pre;
+	wave_fence();
+	const unsigned int n_pairs = rd.n_reads / 2;
+	for (;;) {
+		unsigned int r = 0;
+		if (lane == 0) r = atomicAdd(next_read, 1u);
+		r = __shfl(r, 0);
+		if (r >= n_pairs) break;
+		const uint64_t o0 = rd.d_off[2 * r], o1 = rd.d_off[2 * r + 1], o2 = rd.d_off[2 * r + 2];
+		const uint32_t len0 = (uint32_t)(o1 - o0), len1 = (uint32_t)(o2 - o1);
+		ReadResult& out0 = *reinterpret_cast<ReadResult*>(results + (uint64_t)(2 * r) * result_stride);
+		ReadResult& out1 = *reinterpret_cast<ReadResult*>(results + (uint64_t)(2 * r + 1) * result_stride);
+		if (len0 > (uint32_t)kMaxLen || len1 > (uint32_t)kMaxLen) {
+			if (lane == 0) {
+				ReadResult* o[2] = {&out0, &out1};
+				for (int m = 0; m < 2; m++) { o[m]->status = ERR_OVERFLOW; o[m]->aligned = 0; o[m]->nreport = 0; o[m]->nalns = 0; o[m]->filt = (uint8_t)rparams[2 * r + m].filt; o[m]->maxed = 0; o[m]->has_secbest = 0; o[m]->pair_type = 0; o[m]->pair_flags = 0; }
+			}
+			continue;
+		}
+		wave_fence();
+		s_rp = rparams[2 * r];
+		wave_fence();
+		Aligner<TOff, DevPlat>& al = *new (s_al) Aligner<TOff, DevPlat>(s_ix, s_P, s_rp, w, dp, &s_pre, 2 * r);
+		al.dp_main = dp; al.dp_opp = dp2;
+		al.pe_seq[0] = rd.d_seq + o0; al.pe_qual[0] = rd.d_qual + o0; al.pe_len[0] = len0;
+		al.pe_seq[1] = rd.d_seq + o1; al.pe_qual[1] = rd.d_qual + o1; al.pe_len[1] = len1;
+		al.pe_rp[0] = rparams[2 * r]; al.pe_rp[1] = rparams[2 * r + 1];
+		al.pe_pair = r;
+		wave_fence();
+		al.run_pair(out0, out1);
+		wave_fence();
+		if (lane == 0 && prof) {
+			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)g_hot.t_phase[i]);
+			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
+			atomicAdd(&prof[9], 2ull);
+		}
+	}
+}
+
 template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
@@ -535,20 +601,25 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 	if (rd.n_reads == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
+	if (P.paired)
+		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre);
+	else
 	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
 	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre);
 	return hipGetLastError();
 }
 
-void align_scratch_sizes(uint32_t max_len, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& arena_stride) {
+void align_scratch_sizes(uint32_t max_len, bool paired, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& arena_stride) {
 	const uint32_t rows = max_len ? max_len : 1;
 	const uint32_t R = dp_R(rows);
-	const uint32_t cols = rows + 4 * 15 + 1 + 4;
+	// unpaired: seed-extension windows only; paired: opposite-mate windows up to kMaxCols, and a second matrix for them
+	const uint32_t cols = paired ? (uint32_t)kMaxCols + 4 : rows + 4 * 15 + 1 + 4;
 	const uint32_t lanes = (rows + R - 1) / R;
 	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 8 + 255) & ~(uint64_t)255;    // 8 B per cell: the 16-bit path packs H|E|F into 64 bits
 	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
 	const uint64_t rr = ((uint64_t)rows + 255) & ~(uint64_t)255;
-	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + mat_bytes + mask_bytes + rr;
+	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + (paired ? 2 : 1) * (mat_bytes + mask_bytes) + rr;
 	arena_stride = (arena_stride + 4095) & ~(uint64_t)4095;
 }
 

@@ -291,7 +291,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (max_read_len > BT2G_MAX_READ_LEN) max_read_len = BT2G_MAX_READ_LEN;
 	hipStream_t st = (hipStream_t)stream;
 	uint64_t mat_bytes, mask_bytes, arena_stride;
-	align_scratch_sizes(max_read_len, mat_bytes, mask_bytes, arena_stride);
+	if (params->paired && (reads->n_reads & 1u)) return fail(c, BT2G_ERR_ARG, "paired mode needs an even number of reads (mates interleaved)");
+	align_scratch_sizes(max_read_len, params->paired != 0, mat_bytes, mask_bytes, arena_stride);
 	// persistent waves (one read at a time each) pull reads from a device-side queue
 	uint32_t n_waves = c->n_cu * align_waves_per_cu();
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;

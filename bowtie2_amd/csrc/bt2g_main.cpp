@@ -106,6 +106,7 @@ int main(int argc, char** argv) {
 	for (int i = 0; i < argc; i++) { if (i) cmdline.push_back(' '); cmdline += argv[i]; }
 	opt.cmdline = cmdline;
 	CliExtra ex;
+	ex.allow_paired = true;
 	{
 		const std::string err = parse_cli(argc, argv, opt, ex);
 		if (ex.arg_desc) { print_arg_desc(); return 0; }
@@ -155,8 +156,11 @@ int main(int argc, char** argv) {
 
 	// -p: host threads for FASTQ parsing and SAM formatting (the alignment itself is on the device)
 	const unsigned host_threads = opt.threads > 0 ? (unsigned)opt.threads : 1u;
-	FastqBatcher fq(opt.reads_file, opt, host_threads);
-	if (!fq.ok()) die("cannot open reads file " + opt.reads_file);
+	FastqBatcher fq(opt.paired ? opt.mate1_file : opt.reads_file, opt, host_threads);
+	if (!fq.ok()) die("cannot open reads file " + (opt.paired ? opt.mate1_file : opt.reads_file));
+	std::unique_ptr<FastqBatcher> fq2;
+	if (opt.paired) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die("cannot open reads file " + opt.mate2_file); }
+	PairSummary psumm;
 	AlnSummary summ;
 	std::mutex align_mu;
 	double align_s = 0, t_format = 0, t_write = 0;
@@ -168,6 +172,13 @@ int main(int argc, char** argv) {
 		uint64_t seq = 0;
 		for (;;) {
 			BatchPtr b(new HostBatch());
+			if (opt.paired) {
+				// one batch per mate file in lockstep, interleaved into a batch of pairs
+				BatchPtr b1(new HostBatch()), b2(new HostBatch());
+				fq.next(*b1, batch_reads / 2, (size_t)BT2G_MAX_READ_LEN);
+				fq2->next(*b2, batch_reads / 2, (size_t)BT2G_MAX_READ_LEN);
+				merge_mate_batches(std::move(b1), std::move(b2), *b, opt);
+			} else
 			fq.next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
 			b->seqno = seq++;
 			const bool last = b->last;
@@ -191,7 +202,7 @@ int main(int argc, char** argv) {
 				const auto tf0_ = std::chrono::steady_clock::now();
 				BatchTally tally;
 				format_batch(*b, opt, ref, host_threads, parts, tally);
-				summ.merge(tally.summ);
+				summ.merge(tally.summ); psumm.merge(tally.psumm);
 				for (size_t i : tally.flagged) {
 					n_flagged++;
 					fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed)\n", b->reads[i].name.str().c_str(), (int)b->result(i).status);
@@ -277,7 +288,7 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "[bt2g] device search time %.3f s\n", align_s);
 		fprintf(stderr, "[bt2g] host stages: split %.3f s, parse %.3f s, pack %.3f s, format %.3f s, write %.3f s\n", fq.t_split, fq.t_parse, fq.t_pack, t_format, t_write);
 	}
-	summ.print(stderr);
+	if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr);
 	for (bt2g_ctx* c : ctxs) bt2g_ctx_destroy(c);
 	if (n_flagged) {
 		// never pass off a capacity-limited result as the reference's

@@ -388,6 +388,7 @@ private:
 // alignment summary and the reads the device flagged.  `parts` keeps its capacity from batch to batch.
 struct BatchTally {
 	AlnSummary summ;
+	PairSummary psumm;
 	std::vector<size_t> flagged;
 };
 inline void format_batch(const HostBatch& b, const Options& opt, const RefInfo& ref, unsigned threads, std::vector<std::string>& parts, BatchTally& tally) {
@@ -399,6 +400,22 @@ inline void format_batch(const HostBatch& b, const Options& opt, const RefInfo& 
 		std::string& o = parts[c];
 		if (o.capacity() < chunk * 400) o.reserve(chunk * 400);
 		const size_t e = std::min(n, (c + 1) * chunk);
+		if (b.paired) {
+			// mates travel together: chunk boundaries are even, records 2p / 2p+1 make pair p
+			std::vector<const AlnRes*> a1, a2;
+			for (size_t i = c * chunk; i + 1 < e; i += 2) {
+				const ReadResult& r1 = b.result(i); const ReadResult& r2 = b.result(i + 1);
+				tl[c].psumm.add(r1, r2);
+				if (r1.status || r2.status) tl[c].flagged.push_back(i);
+				a1.clear(); a2.clear();
+				const AlnRes* a = &r1.alns[0];
+				for (uint32_t k = 0; k < r1.nreport; k++, a = HostBatch::next_aln(a)) a1.push_back(a);
+				a = &r2.alns[0];
+				for (uint32_t k = 0; k < r2.nreport; k++, a = HostBatch::next_aln(a)) a2.push_back(a);
+				sam_pair_records(o, opt, ref, b.reads[i], b.reads[i + 1], r1, r2, a1.data(), a2.data());
+			}
+			return;
+		}
 		for (size_t i = c * chunk; i < e; i++) {
 			const ReadResult& rr = b.result(i);
 			tl[c].summ.add(rr);
@@ -409,7 +426,7 @@ inline void format_batch(const HostBatch& b, const Options& opt, const RefInfo& 
 			} else if (!opt.no_unal) sam_record(o, opt, ref, b.reads[i], rr, nullptr, true);
 		}
 	});
-	for (const BatchTally& t : tl) { tally.summ.merge(t.summ); tally.flagged.insert(tally.flagged.end(), t.flagged.begin(), t.flagged.end()); }
+	for (const BatchTally& t : tl) { tally.summ.merge(t.summ); tally.psumm.merge(t.psumm); tally.flagged.insert(tally.flagged.end(), t.flagged.begin(), t.flagged.end()); }
 }
 
 } // namespace bt2g
