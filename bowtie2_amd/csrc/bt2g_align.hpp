@@ -159,8 +159,10 @@ struct HotWork {
 	uint8_t  sorted[2][kMaxOffs];
 	uint8_t  rank_offs[kMaxRanges];
 	uint8_t  rank_fw[kMaxRanges];
-	Edit     ned[kMaxEdits];   // edits of the backtrace in progress
-	int16_t  lastrow[kMaxCols + 8];   // scores of the last DP row, clamped at -32768 (gatherCells)
+	union {                    // never live at the same time: the gather reads `lastrow` before any backtrace writes `ned`
+		Edit     ned[kMaxEdits];   // edits of the backtrace in progress
+		int16_t  lastrow[kMaxCols + 8];   // scores of the last DP row, clamped at -32768 (gatherCells)
+	};
 	// ---- scalar control state of the read in flight (everything the control code touches often) ----
 	uint32_t len;
 	EEHit    exact[2];         // [0] fw, [1] rc; top==bot => empty

@@ -36,7 +36,7 @@ struct Aligner {
 
 	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, ReadParams& rp_, Work& w_, DpScratch dp_,
 	               const PreComp* pre_ = nullptr, uint32_t ridx_ = 0)
-		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_), pre(pre_), ridx(ridx_), ext_pre(false), m_nofw(P_.nofw != 0), m_norc(P_.norc != 0), cands_cur(nullptr) {}
+		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_), pre(pre_), ridx(ridx_), ext_pre(false), m_nofw(P_.nofw != 0), m_norc(P_.norc != 0), cands_cur(w_.cands) {}
 
 	// exact_sweep() from the batch kernel's output
 	BT2_HD uint64_t exact_sweep_pre(uint32_t mine[2]) {
@@ -964,7 +964,9 @@ struct Aligner {
 	}
 
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
-	template <int MODE>
+	// WIN: the start column lies past the 768 columns the reference-window registers hold (opposite-mate windows only),
+	// so the registers are loaded from a later base column; unpaired windows never need it
+	template <int MODE, bool WIN = false>
 	BT2_HDN bool backtrace(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen,
 	                      int32_t escore, uint32_t row_, uint32_t col_, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi,
 	                      AlnRes& res) {
@@ -995,7 +997,8 @@ struct Aligner {
 		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
 		// the walk moves left from the start column by at most rows + gaps columns: three registers (768 columns) ending
 		// at the start column cover it even when an opposite-mate window is wider than that
-		const uint32_t rf_c0 = (col + 1 > 768u) ? ((col + 1 - 768u + 3u) & ~3u) : 0u;   // `col` is still the start column here
+		const uint32_t rf_c0 = WIN ? ((col + 1 - 768u + 3u) & ~3u) : 0u;   // `col` is still the start column here
+		if (rf_c0 > 0 && rows + 250u > 764u) { HOT.err |= ERR_OVERFLOW; return false; }   // the walk could leave the 768-column window (rows + read gaps)
 		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64 + (rf_c0 >> 2));
 		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
 			const uint32_t word = idx >> 2;
@@ -1024,7 +1027,6 @@ struct Aligner {
 		HOT.n_bt_attempts++;
 		while ((int)row >= 0) {
 			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
-			if (col < rf_c0) { HOT.err |= ERR_OVERFLOW; return false; }
 			const int refm = byte_of(rfw, 3, col - rf_c0);
 			const int readq = byte_of(qlw, 2, fw ? row : rdlen - 1 - row);
 			// Flags are ints combined with & and |: the control code is wave-uniform and this keeps it on 32-bit scalar
@@ -1287,13 +1289,18 @@ struct Aligner {
 			res.nned = 0;
 			const int32_t cscore = c.score;
 			bool ret;
+			if (c.col + 1u > 768u) {
+				if (mode == 0) ret = backtrace<0, true>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
+				else if (mode == 1) ret = backtrace<1, true>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
+				else ret = backtrace<2, true>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
+			} else
 			if (mode == 0) ret = backtrace<0>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
 			else if (mode == 1) ret = backtrace<1>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
 			else ret = backtrace<2>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
 			rnd.init(sse16 ? reseed : reseed + 1);
 			if (mode == 2) cand_list()[HOT.cural].score = cscore | kCandDone;       // btncanddone_: tried, succeeded or not
 #ifdef PE_DEBUG
-			if (cands_cur) fprintf(stderr, "     cand %u row %u col %u score %d ret %d nned %u refoff %lld resscore %d\n", HOT.cural, c.row, c.col, cscore, (int)ret, res.nned, (long long)res.refoff, res.score);
+			if (cands_cur != w.cands) fprintf(stderr, "     cand %u row %u col %u score %d ret %d nned %u refoff %lld resscore %d\n", HOT.cural, c.row, c.col, cscore, (int)ret, res.nned, (long long)res.refoff, res.score);
 #endif
 			if (ret) { found = true; break; }
 			HOT.cural++;
@@ -1714,6 +1721,7 @@ struct Aligner {
 		out.aligned = nunpair1 > 0 ? 1 : 0;
 		out.maxed = maxed ? 1 : 0;
 		out.has_secbest = 0; out.secbest = 0; out.best = 0; out.nreport = 0;
+		out.pair_type = 0; out.pair_flags = 0; out.pair_best = 0; out.pair_secbest = 0; out.n_mate_dps = 0; out.pad2 = 0;
 		if (nunpair1 == 0) return;
 		// selectByScore: sort (score, index) ascending, reverse, shuffle equal-score streaks
 		const uint32_t sz = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;

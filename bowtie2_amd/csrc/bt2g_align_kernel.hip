@@ -481,7 +481,7 @@ struct DevPlat {
 #define BT2G_WAVES_PER_EU 2
 #endif
 template <typename TOff>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(128)))
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
@@ -536,7 +536,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 // Paired-end flavour: one wavefront per pair (reads 2p and 2p+1, result records 2p and 2p+1).  A separate kernel so
 // that the unpaired kernel's register allocation and code layout do not carry the pair logic.
 template <typename TOff>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(128)))
 k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,

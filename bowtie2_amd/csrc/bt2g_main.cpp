@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
 	}
 	const bool metrics = ex.metrics;
 	unsigned long long n_flagged = 0;
-	if (opt.index_base.empty() || opt.reads_file.empty()) die("usage: bowtie2-align-s [options] -x <index> -U <reads.fq> [-S out.sam]");
+	if (opt.index_base.empty() || (opt.reads_file.empty() && !opt.paired)) die("usage: bowtie2-align-s [options] -x <index> {-U <reads.fq> | -1 <m1.fq> -2 <m2.fq>} [-S out.sam]");
 
 	// --gpu a[,b,...]: one context (full index replica) per listed device; read batches are dealt to whichever device
 	// is free and the writer puts them back in input order (reads are independent: SURVEY.md 8e)

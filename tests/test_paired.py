@@ -105,4 +105,4 @@ def test_paired_hostsim():
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 def test_paired_gpu():
     b = os.path.join(ROOT, "bowtie2_amd", "bin")
-    check(os.path.join(b, "bowtie2-align-s"), os.path.join(b, "bowtie2-align-l"), 1500, OPTION_SETS, extra=("-p", "4"))
+    check(os.path.join(b, "bowtie2-align-s"), os.path.join(b, "bowtie2-align-l"), 1000, OPTION_SETS, extra=("-p", "4"))
