@@ -44,7 +44,7 @@ constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at 
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 16384; // uint32 slots for Random1toN lists
 constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
-constexpr int kMaxCols     = 960;   // DP columns: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*15
+constexpr int kMaxCols     = 1100;  // DP columns: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*15
 
 enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
 enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMIT, EXT_HARD_LIMIT };

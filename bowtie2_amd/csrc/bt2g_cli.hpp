@@ -173,6 +173,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--no-mixed") opt.no_mixed = true;
 		else if (a == "--no-discordant") opt.no_discordant = true;
 		else if (a == "--dovetail") opt.dovetail = true;
+		else if (a == "--no-dovetail") opt.dovetail = false;
 		else if (a == "--no-contain") opt.no_contain = true;
 		else if (a == "--no-overlap") opt.no_overlap = true;
 		else if (a == "-N") { const std::string v = need(); opt.seed_mms = atoi(v.c_str()); if (opt.seed_mms < 0 || opt.seed_mms > 1) err = "Error: -N was set to " + v + ", but cannot be set higher than 1 or less than 0"; }

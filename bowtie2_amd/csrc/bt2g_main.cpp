@@ -288,7 +288,7 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "[bt2g] device search time %.3f s\n", align_s);
 		fprintf(stderr, "[bt2g] host stages: split %.3f s, parse %.3f s, pack %.3f s, format %.3f s, write %.3f s\n", fq.t_split, fq.t_parse, fq.t_pack, t_format, t_write);
 	}
-	if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr);
+	if (!opt.quiet) { if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198)
 	for (bt2g_ctx* c : ctxs) bt2g_ctx_destroy(c);
 	if (n_flagged) {
 		// never pass off a capacity-limited result as the reference's

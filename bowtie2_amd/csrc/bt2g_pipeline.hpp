@@ -205,7 +205,7 @@ private:
 // FASTQ records following FastqPatternSource::parse (pat.cpp): 4-line records, '.' -> N, non-letters dropped
 class FastqBatcher {
 public:
-	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(opt.format == 3 ? std::string("/dev/null") : path), opt_(opt), threads_(threads) {}
+	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(opt.format == 3 ? std::string("/dev/null") : path), cmd_(path), opt_(opt), threads_(threads) {}
 	bool ok() const { return src_.ok(); }
 
 	double t_split = 0, t_parse = 0, t_pack = 0;      // seconds spent in each part of next() (-t)
@@ -245,11 +245,11 @@ public:
 					arena_.append(p, n); r.seq_len += n;
 				}
 			} else if (opt_.format == 3) {             // -c: reads given on the command line, "SEQ[:QUALS]" separated by commas
-				if (cmd_pos_ > opt_.reads_file.size() || opt_.reads_file.empty()) { b.last = true; break; }
+				if (cmd_pos_ > cmd_.size() || cmd_.empty()) { b.last = true; break; }
 				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
-				size_t e = opt_.reads_file.find(',', cmd_pos_);
-				if (e == std::string::npos) e = opt_.reads_file.size();
-				const std::string tok = opt_.reads_file.substr(cmd_pos_, e - cmd_pos_);
+				size_t e = cmd_.find(',', cmd_pos_);
+				if (e == std::string::npos) e = cmd_.size();
+				const std::string tok = cmd_.substr(cmd_pos_, e - cmd_pos_);
 				cmd_pos_ = e + 1;
 				const size_t colon = tok.find(':');
 				r.name_off = arena_.size(); r.name_len = 0;
@@ -380,6 +380,7 @@ private:
 	std::string arena_, pending_;
 	bool have_pending_ = false;
 	size_t cmd_pos_ = 0;
+	std::string cmd_;            // -c: the comma-separated reads of this source (the -U, -1 or -2 argument)
 	std::vector<Raw> recs_;
 	uint64_t rdid_ = 0;
 };

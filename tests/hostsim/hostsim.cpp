@@ -269,7 +269,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		                     (unsigned long long)g_hot.t_phase[11], (unsigned long long)g_hot.t_phase[12], (unsigned long long)g_hot.t_phase[13]);
 	}
 	}
-	summ.print(stderr);
+	if (!opt.quiet) summ.print(stderr);
 	return 0;
 }
 
@@ -330,7 +330,7 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 			                     rr1.n_ex_iters, rr1.n_ex_dps, rr1.n_mate_dps, rr1.n_ex_ugs, rr1.n_redundants, rr1.n_bt_attempts, rr1.nalns, rr2.nalns, rr1.pair_type);
 		}
 	}
-	summ.print(stderr, !opt.no_discordant, !opt.no_mixed);
+	if (!opt.quiet) summ.print(stderr, !opt.no_discordant, !opt.no_mixed);
 	return 0;
 }
 

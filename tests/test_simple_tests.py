@@ -1,4 +1,4 @@
-"""The reference's own regression table, re-hosted: tests/golden/simple_tests.json holds the unpaired cases of
+"""The reference's own regression table, re-hosted: tests/golden/simple_tests.json holds the unpaired and paired cases of
 scripts/test/simple_tests.pl (reference sequences, reads, arguments) together with the SAM the *reference* binaries
 print for them (tools/make_simple_tests_fixture.py).  Our binaries must print the same SAM, byte for byte, on both
 index widths -- or refuse the option set outright.  CPU: the host-compiled worker; GPU: the product binary."""
@@ -42,7 +42,15 @@ def run_cases(exe_s, exe_l, tmp):
                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 built[key] = os.path.join(d, "idx")
             cmd = [exe] + rec["args"] + ["-x", built[key]]
-            if rec["flag"] == "-c":
+            if "m1" in rec:             # paired case
+                if rec["flag"] == "-c":
+                    cmd += ["-c", "-1", rec["m1"].strip(), "-2", rec["m2"].strip()]
+                else:
+                    f1, f2 = os.path.join(tmp, "m1.txt"), os.path.join(tmp, "m2.txt")
+                    open(f1, "w").write(rec["m1"])
+                    open(f2, "w").write(rec["m2"])
+                    cmd += [rec["flag"], "-1", f1, "-2", f2]
+            elif rec["flag"] == "-c":
                 cmd += ["-c", "-U", rec["input"].strip()]
             else:
                 rf = os.path.join(tmp, "reads.txt")
@@ -63,7 +71,7 @@ def run_cases(exe_s, exe_l, tmp):
 def test_reference_regression_table_hostsim(hostsim, tmp_path):
     compared, refused, bad = run_cases(hostsim, hostsim, str(tmp_path))
     assert not bad, (len(bad), bad[:5])
-    assert compared >= 410 and len(refused) <= MAX_REFUSED, (compared, len(refused), refused[:5])
+    assert compared >= 640 and len(refused) <= MAX_REFUSED, (compared, len(refused), refused[:5])
 
 
 @pytest.mark.gpu
@@ -72,4 +80,4 @@ def test_reference_regression_table_gpu(tmp_path):
     b = os.path.join(ROOT, "bowtie2_amd", "bin")
     compared, refused, bad = run_cases(os.path.join(b, "bowtie2-align-s"), os.path.join(b, "bowtie2-align-l"), str(tmp_path))
     assert not bad, (len(bad), bad[:5])
-    assert compared >= 410 and len(refused) <= MAX_REFUSED, (compared, len(refused), refused[:5])
+    assert compared >= 640 and len(refused) <= MAX_REFUSED, (compared, len(refused), refused[:5])

@@ -59,6 +59,57 @@ def case_inputs(c, fw):
     return None
 
 
+def pair_inputs(c, fw):
+    """-> (format flag, mate-1 text, mate-2 text, extra args) for a paired case, or None if out of scope"""
+    m1fw = c.get("mate1fw", 1)
+    m2fw = c.get("mate2fw", 0)
+    extra = ["--" + ("f" if m1fw else "r") + ("f" if m2fw else "r")]
+    if c.get("mate1s") is not None:
+        m1, m2 = list(c["mate1s"]), list(c["mate2s"])
+        q1, q2 = list(c.get("qual1s") or []), list(c.get("qual2s") or [])
+        names = c.get("names") or []
+        if not fw:      # simple_tests.pl:4895-4921: mates swap roles; same-strand policies also reverse-complement them
+            if bool(m1fw) == bool(m2fw):
+                m1, m2 = [revcomp(x) for x in m1], [revcomp(x) for x in m2]
+                q1, q2 = [x[::-1] for x in q1], [x[::-1] for x in q2]
+            m1, m2, q1, q2 = m2, m1, q2, q1
+        if any(x == "" for x in m1 + m2):
+            return None
+        f1 = f2 = ""
+        for i in range(len(m1)):
+            nm = names[i] if i < len(names) and names[i] else "r%d" % i
+            a = q1[i] if i < len(q1) and q1[i] else "I" * len(m1[i])
+            b = q2[i] if i < len(q2) and q2[i] else "I" * len(m2[i])
+            f1 += "@%s/1\n%s\n+\n%s\n" % (nm, m1[i], a)
+            f2 += "@%s/2\n%s\n+\n%s\n" % (nm, m2[i], b)
+        return "-q", f1, f2, extra
+    if not fw:
+        return None
+    for key, flag in (("fastq", "-q"), ("fasta", "-f"), ("raw", "-r"), ("cline_reads", "-c")):
+        if c.get(key + "1") is not None and c.get(key + "2") is not None:
+            return flag, c[key + "1"], c[key + "2"], extra
+    return None
+
+
+def run_ref_pair(exe, large, fa_text, flag, p1, p2, args, tmp):
+    fa = os.path.join(tmp, "ref.fa")
+    open(fa, "w").write(fa_text)
+    base = os.path.join(tmp, "idx")
+    subprocess.check_call([os.path.join(REF, "bowtie2-build-l" if large else "bowtie2-build-s"), "--quiet", fa, base], stdout=subprocess.DEVNULL)
+    cmd = [os.path.join(REF, exe)] + args + ["-x", base]
+    if flag == "-c":
+        cmd += ["-c", "-1", p1.strip(), "-2", p2.strip()]
+    else:
+        f1, f2 = os.path.join(tmp, "m1.txt"), os.path.join(tmp, "m2.txt")
+        open(f1, "w").write(p1)
+        open(f2, "w").write(p2)
+        cmd += [flag, "-1", f1, "-2", f2]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    if p.returncode != 0:
+        return None
+    return [l for l in p.stdout.splitlines() if not l.startswith("@PG")]
+
+
 def run_ref(exe, large, fa_text, flag, payload, args, tmp):
     fa = os.path.join(tmp, "ref.fa")
     open(fa, "w").write(fa_text)
@@ -82,11 +133,38 @@ def main():
     out = []
     skipped = 0
     for ci, c in enumerate(cases):
-        if PAIRED_KEYS & set(c) or SKIP_KEYS & set(c):
+        if SKIP_KEYS & set(c):
             skipped += 1
             continue
         args = (c.get("args") or "").split() + ["--quiet"] + (c["report"].split() if c.get("report") else ["-a"])
         fa_text = "".join(">%d\n%s\n" % (i, s) for i, s in enumerate(c["ref"]))
+        if PAIRED_KEYS & set(c):
+            # paired cases: mate lists (forward and role-swapped) or mate files (forward only)
+            if any(c.get(k) is not None for k in ("tabbed1", "tabbed2", "qseq1", "qseq2", "tabbed", "reads", "fastq", "fasta", "raw", "cline_reads")):
+                skipped += 1
+                continue
+            n_here = 0
+            for fw in (True, False):
+                inp = pair_inputs(c, fw)
+                if inp is None:
+                    continue
+                flag, p1, p2, extra = inp
+                rec = {"case": ci, "name": c.get("name", "case%d" % ci), "fw": fw, "ref": c["ref"], "flag": flag, "m1": p1, "m2": p2,
+                       "args": args + extra, "sam": {}}
+                ok = True
+                for large in (False, True):
+                    with tempfile.TemporaryDirectory() as tmp:
+                        sam = run_ref_pair("bowtie2-align-l" if large else "bowtie2-align-s", large, fa_text, flag, p1, p2, args + extra, tmp)
+                    if sam is None:
+                        ok = False
+                        break
+                    rec["sam"]["l" if large else "s"] = sam
+                if ok:
+                    out.append(rec)
+                    n_here += 1
+            if n_here == 0:
+                skipped += 1
+            continue
         for fw in ([True] if c.get("norc") else []) + ([False] if not c.get("nofw") else []) if (c.get("norc") or c.get("nofw")) else (True, False):
             inp = case_inputs(c, fw)
             if inp is None:
