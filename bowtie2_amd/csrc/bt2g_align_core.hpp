@@ -528,6 +528,7 @@ struct Aligner {
 	BT2_HD void r1n_reset(R1N& r) { r.sz = r.n = r.cur = 0; r.swaplist = r.converted = 0; r.list_len = r.seen_len = 0; r.thresh = 0; r.inited = 0; }
 	BT2_HD bool r1n_done(const R1N& r) const { return r.n > 0 && r.cur >= r.n; }
 	BT2_HD void r1n_set_done(R1N& r) { r.cur = r.n; }
+	BT2_HD void r1n_init_seq(R1N& r, uint32_t n) { r1n_reset(r); r.sz = r.n = n; r.swaplist = 2; r.inited = 1; }
 	BT2_HD uint32_t lists_alloc(uint32_t n) {
 		if (HOT.lists_used + n > (uint32_t)kListArena) { HOT.err |= ERR_OVERFLOW; return 0; }
 		const uint32_t o = HOT.lists_used;
@@ -535,6 +536,7 @@ struct Aligner {
 		return o;
 	}
 	BT2_HDN uint32_t r1n_next(R1N& r) {
+		if (r.swaplist == 2) return r.cur++;          // -d: rows in index order (currIdx++, aligner_sw_driver.cpp:1120)
 		if (r.cur == 0 && !r.converted) {
 			if (r.n == 1) { r.cur = 1; return 0; }
 			if (r.swaplist) {
@@ -769,6 +771,19 @@ struct Aligner {
 				while (j >= gap && satpos_less(v, w.satpos2[j - gap])) { w.satpos2[j] = w.satpos2[j - gap]; j -= gap; }
 				w.satpos2[j] = v;
 			}
+		}
+		if (P.det_seeds) {
+			// prioritizeSATupsIdxs (aligner_sw_driver.cpp:741-866): every range in sorted order until maxelt elements are in
+			uint64_t added = 0;
+			for (uint32_t j = 0; j < HOT.n_satpos2 && added < maxelt; j++) {
+				if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; break; }
+				SatPos& s = w.satpos[HOT.n_satpos++];
+				s = w.satpos2[j];
+				r1n_init_seq(s.rnd, s.size);
+				added += s.size;
+			}
+			nelt_out = added;
+			return;
 		}
 		uint64_t nelt_added = 0;
 		// 1. the smalls, whole
@@ -1414,7 +1429,7 @@ struct Aligner {
 				SatPos& sp = w.satpos[i];
 				const EEHit* eh = ee_mode ? &ee_hit(sp.ee) : nullptr;
 				if (ee_mode && eh->score < minsc) return EXT_PERFECT_SCORE;
-				const bool is_small = sp.size < nsm;
+				const bool is_small = P.det_seeds ? true : sp.size < nsm;
 				const bool fw = sp.fw != 0;
 				uint32_t rdoff = sp.rdoff;
 				const uint32_t seedhitlen = sp.seedlen;
@@ -1596,6 +1611,7 @@ struct Aligner {
 					}
 				}
 			}
+			if (P.det_seeds) break;      // useCurrIdx: always one pass (aligner_sw_driver.cpp:1490)
 		}
 		return EXT_EXHAUSTED;
 	}

@@ -138,6 +138,11 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--end-to-end") opt.local = false;
 		else if (a == "--ignore-quals") opt.ignore_quals = true;
 		else if (a == "--no-1mm-upfront") opt.no_1mm_upfront = true;
+		else if (a == "--1mm-upfront") opt.no_1mm_upfront = false;
+		else if (a == "--no-exact-upfront") opt.no_exact_upfront = true;
+		else if (a == "--exact-upfront") opt.no_exact_upfront = false;
+		else if (a == "-d" || a == "--deterministic-seeds") opt.det_seeds = true;
+		else if (a == "--no-deterministic-seeds") opt.det_seeds = false;
 		else if (a == "--no-unal") opt.no_unal = true;
 		else if (a == "--xeq") opt.xeq = true;
 		else if (a == "--omit-sec-seq" || a == "--sam-omit-sec-seq") opt.omit_sec_seq = true;
@@ -229,6 +234,10 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		if (!err.empty()) return err;
 	}
 	if (opt.khits > 64) return "-k above 64 is not supported by this build";
+	if (opt.det_seeds) {      // bt2_search.cpp:1778-1791
+		if (!opt.no_exact_upfront || !opt.no_1mm_upfront) return "Error: -d must be used with --no-exact-upfront and --no-1mm-upfront.";
+		if (!opt.all_hits) return "Error: -d can only be used with -a.";
+	}
 	if (opt.mate1_file.empty() != opt.mate2_file.empty()) return "-1 and -2 must be specified together";
 	opt.paired = !opt.mate1_file.empty();
 	if (opt.paired && !opt.reads_file.empty()) return "mixing paired (-1/-2) and unpaired (-U) inputs in one run is not supported by this build";

@@ -78,6 +78,8 @@ struct Options {
 	bool mm_const = false;        // MMP=Cxx: constant mismatch penalty (policy string / --bwa-sw-like)
 	bool bwa_sw_like = false;     // --bwa-sw-like: minimum score = a*max(T, c*ln(len)) (bt2_search.cpp:3341-3350)
 	bool report_overhangs = false;
+	bool det_seeds = false;       // -d / --deterministic-seeds
+	bool no_exact_upfront = false;
 	// paired-end input and policy (bt2_search.cpp:1185-1215; PairedEndPolicy pe.h:169)
 	std::string mate1_file, mate2_file, interleaved_file;
 	bool paired = false;
@@ -137,6 +139,7 @@ struct Options {
 		P.pe_flags = (dovetail ? BT2G_PE_DOVETAIL_OK : 0) | (no_contain ? 0 : BT2G_PE_CONTAIN_OK) | (no_overlap ? 0 : BT2G_PE_OLAP_OK) | BT2G_PE_EXPAND |
 		             (no_discordant ? 0 : BT2G_PE_DISCORD) | (no_mixed ? 0 : BT2G_PE_MIXED) | (mate1fw ? BT2G_PE_MATE1FW : 0) | (mate2fw ? BT2G_PE_MATE2FW : 0);
 		P.max_mate_streak = 10;
+		P.det_seeds = det_seeds ? 1 : 0;
 		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
 		if (all_hits) {
 			// -a lifts every effort limit (bt2_search.cpp:3457-3463)
@@ -148,7 +151,7 @@ struct Options {
 		}
 		P.n_seed_rounds = n_seed_rounds; P.seed_boost_thresh = 300; P.tighten = 3; P.maxhalf = maxhalf;
 		P.nofw = nofw; P.norc = norc;
-		P.do_exact_upfront = 1; P.do_1mm_upfront = no_1mm_upfront ? 0 : 1; P.do_ungapped = 1;
+		P.do_exact_upfront = no_exact_upfront ? 0 : 1; P.do_1mm_upfront = no_1mm_upfront ? 0 : 1; P.do_ungapped = 1;
 		// bit 0: extend seed hits; bit 1: left only -- the reference loads the mirror index only for -N > 0 or the 1-mm
 		// up-front search (bt2_search.cpp:4841) and SwDriver::extend skips the right extension without it (:403)
 		P.do_extend = 1 | ((seed_mms == 0 && no_1mm_upfront) ? 2 : 0);

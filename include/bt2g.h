@@ -216,6 +216,7 @@ typedef struct {
 	int32_t pe_maxfrag, pe_minfrag;/* -X / -I                                                                    */
 	int32_t pe_flags;              /* BT2G_PE_* below                                                            */
 	int32_t max_mate_streak;       /* maxMateStreak (10), scaled with -k like max_dp_streak                      */
+	int32_t det_seeds;             /* -d: seed-hit ranges in sorted order, rows in index order, no sampling (prioritizeSATupsIdxs) */
 } bt2g_align_params;
 #define BT2G_PE_DOVETAIL_OK  1     /* --dovetail                       */
 #define BT2G_PE_CONTAIN_OK   2     /* cleared by --no-contain          */

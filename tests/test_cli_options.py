@@ -28,6 +28,8 @@ OPTION_SETS = [
     ["-N", "1"], ["-N", "1", "--local", "-k", "3"], ["-N", "1", "-L", "10", "-i", "C,3,0"], ["--multiseed", "1,18,S,1,0.5"],
     ["-N", "1", "-L", "32", "--very-fast", "--nofw"], ["-N", "1", "--no-1mm-upfront", "-L", "12"], ["-N", "1", "-a", "-L", "25"],
     ["--policy", "SEED=1;SEEDLEN=16", "--very-sensitive"],
+    ["-d", "-a", "--no-exact-upfront", "--no-1mm-upfront"], ["-d", "-a", "--no-exact-upfront", "--no-1mm-upfront", "--local", "-N", "1", "-L", "20"],
+    ["--no-exact-upfront"], ["--no-exact-upfront", "--no-1mm-upfront", "-k", "2"],
 ]
 
 
@@ -81,7 +83,7 @@ def test_options_match_reference_hostsim(hostsim, idx, tmp_path):
 
 
 def test_unsupported_options_are_refused(hostsim):
-    for opts in (["-1", "a.fq", "-2", "b.fq"], ["-N", "2"], ["-k", "100"], ["--frobnicate"], ["-d"]):
+    for opts in (["-1", "a.fq", "-2", "b.fq"], ["-N", "2"], ["-k", "100"], ["--frobnicate"], ["-d"], ["-d", "-k", "2", "--no-exact-upfront", "--no-1mm-upfront"]):
         p = subprocess.run([hostsim] + opts + ["-x", os.path.join(GOLD, "tiny_s"), "-U", FQ], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert p.returncode != 0 and p.stdout == "", opts
 
