@@ -168,6 +168,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 			err = apply_policy_string(opt, "MA=1;MMP=C3;RDG=5,2;RFG=5,2");
 		}
 		// paired-end input and policy (bt2_search.cpp:1185-1215); without -1/-2 the policy options have no effect
+		else if (a == "--interleaved") opt.interleaved_file = need();
 		else if (a == "-1") opt.mate1_file = need();
 		else if (a == "-2") opt.mate2_file = need();
 		else if (a == "-I" || a == "--minins") opt.min_insert = atoi(need().c_str());
@@ -227,7 +228,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; if (iv.size() > 1) opt.rdg_linear = iv[1]; } }
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
-		else if (a == "-b" || a == "--interleaved" ||
+		else if (a == "-b" ||
 		         a == "-F" || a == "--int-quals" || a == "--solexa-quals")
 			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -k <= 64)";
 		else return "unsupported option " + a;
@@ -239,7 +240,8 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		if (!opt.all_hits) return "Error: -d can only be used with -a.";
 	}
 	if (opt.mate1_file.empty() != opt.mate2_file.empty()) return "-1 and -2 must be specified together";
-	opt.paired = !opt.mate1_file.empty();
+	opt.paired = !opt.mate1_file.empty() || !opt.interleaved_file.empty();
+	if (!opt.interleaved_file.empty() && !opt.mate1_file.empty()) return "--interleaved and -1/-2 in one run are not supported by this build";
 	if (opt.paired && !opt.reads_file.empty()) return "mixing paired (-1/-2) and unpaired (-U) inputs in one run is not supported by this build";
 	if (opt.paired && !ex.allow_paired) return "paired-end input (-1/-2) is not enabled in this build of the device path yet";
 	if (opt.paired && opt.max_insert < opt.min_insert) return "-X must not be smaller than -I";

@@ -156,10 +156,12 @@ int main(int argc, char** argv) {
 
 	// -p: host threads for FASTQ parsing and SAM formatting (the alignment itself is on the device)
 	const unsigned host_threads = opt.threads > 0 ? (unsigned)opt.threads : 1u;
-	FastqBatcher fq(opt.paired ? opt.mate1_file : opt.reads_file, opt, host_threads);
-	if (!fq.ok()) die("cannot open reads file " + (opt.paired ? opt.mate1_file : opt.reads_file));
+	const bool inter = !opt.interleaved_file.empty();
+	const std::string src1 = inter ? opt.interleaved_file : (opt.paired ? opt.mate1_file : opt.reads_file);
+	FastqBatcher fq(src1, opt, host_threads);
+	if (!fq.ok()) die("cannot open reads file " + src1);
 	std::unique_ptr<FastqBatcher> fq2;
-	if (opt.paired) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die("cannot open reads file " + opt.mate2_file); }
+	if (opt.paired && !inter) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die("cannot open reads file " + opt.mate2_file); }
 	PairSummary psumm;
 	AlnSummary summ;
 	std::mutex align_mu;
@@ -172,7 +174,8 @@ int main(int argc, char** argv) {
 		uint64_t seq = 0;
 		for (;;) {
 			BatchPtr b(new HostBatch());
-			if (opt.paired) {
+			if (inter) { fq.next(*b, batch_reads & ~(size_t)1, (size_t)BT2G_MAX_READ_LEN); finalize_interleaved(*b, opt); }
+			else if (opt.paired) {
 				// one batch per mate file in lockstep, interleaved into a batch of pairs
 				BatchPtr b1(new HostBatch()), b2(new HostBatch());
 				fq.next(*b1, batch_reads / 2, (size_t)BT2G_MAX_READ_LEN);

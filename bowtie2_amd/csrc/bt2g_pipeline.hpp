@@ -205,7 +205,7 @@ private:
 // FASTQ records following FastqPatternSource::parse (pat.cpp): 4-line records, '.' -> N, non-letters dropped
 class FastqBatcher {
 public:
-	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(opt.format == 3 ? std::string("/dev/null") : path), cmd_(path), opt_(opt), threads_(threads) {}
+	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(opt.format == 3 ? std::string("/dev/null") : path), cmd_(path), opt_(opt), threads_(threads) { unit_ = (!opt.interleaved_file.empty() && path == opt.interleaved_file) ? 2 : 1; }
 	bool ok() const { return src_.ok(); }
 
 	double t_split = 0, t_parse = 0, t_pack = 0;      // seconds spent in each part of next() (-t)
@@ -223,7 +223,7 @@ public:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
 				if (!got || p[0] != '@') { b.last = true; break; }
-				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
 				if (!src_.next(p, n)) { b.last = true; break; }
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
@@ -234,7 +234,7 @@ public:
 				bool got = true;
 				if (!have_pending_) { do { got = src_.next(p, n); } while (got && (n == 0 || p[0] != '>')); if (got) pending_.assign(p, n); }
 				if (!got) { b.last = true; break; }
-				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				have_pending_ = false;
 				r.name_off = arena_.size(); r.name_len = pending_.size() - 1; arena_.append(pending_.data() + 1, pending_.size() - 1);
 				r.seq_off = arena_.size(); r.seq_len = 0;
@@ -246,7 +246,7 @@ public:
 				}
 			} else if (opt_.format == 3) {             // -c: reads given on the command line, "SEQ[:QUALS]" separated by commas
 				if (cmd_pos_ > cmd_.size() || cmd_.empty()) { b.last = true; break; }
-				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				size_t e = cmd_.find(',', cmd_pos_);
 				if (e == std::string::npos) e = cmd_.size();
 				const std::string tok = cmd_.substr(cmd_pos_, e - cmd_pos_);
@@ -259,7 +259,7 @@ public:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				const char* t1 = (const char*)memchr(p, '\t', n);
 				const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(p + n - t1 - 1)) : nullptr;
 				if (!t1 || !t2) { b.bad_input = "malformed tab-delimited read record"; b.last = true; break; }
@@ -271,7 +271,7 @@ public:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				const char* f[12]; int nf = 0; f[nf++] = p;
 				for (size_t k = 0; k < n && nf < 12; k++) if (p[k] == '\t') f[nf++] = p + k + 1;
 				if (nf != 11) { b.bad_input = "malformed QSEQ record (expected 11 fields)"; b.last = true; break; }
@@ -291,12 +291,12 @@ public:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ - std::min<uint64_t>(rdid_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				r.name_off = arena_.size(); r.name_len = 0;
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
 			}
-			r.rdid = rdid_;
-			if (rdid_++ < opt_.skip) continue;
+			r.rdid = rdid_ / unit_;
+			if ((rdid_++) / unit_ < opt_.skip) continue;
 			recs_.push_back(r);
 		}
 		const double t1_ = tnow();
@@ -383,7 +383,23 @@ private:
 	std::string cmd_;            // -c: the comma-separated reads of this source (the -U, -1 or -2 argument)
 	std::vector<Raw> recs_;
 	uint64_t rdid_ = 0;
+	uint64_t unit_ = 1;          // records per read id: 2 for --interleaved mates (-s/-u and default names count pairs)
 };
+
+// --interleaved: the batch already holds mate 1 / mate 2 alternating; mark it paired and apply the pair-level interval adjustment
+inline void finalize_interleaved(HostBatch& b, const Options& opt) {
+	b.paired = true;
+	if (b.bad_input.empty() && (b.reads.size() & 1)) b.bad_input = "odd number of records in the --interleaved input";
+	for (size_t i = 0; i + 1 < b.reads.size(); i += 2) {
+		if ((b.rp[i].filt & 15u) == 15u && (b.rp[i + 1].filt & 15u) == 15u) {
+			for (int m = 0; m < 2; m++) {
+				int iv = opt.ms_ival.f<int>((double)b.reads[i + m].seq.size());
+				iv = (int)(iv * 1.2 + 0.5);
+				b.rp[i + m].interval = iv < 1 ? 1 : iv;
+			}
+		}
+	}
+}
 
 // SAM text of one batch, formatted in parallel chunks (concatenate `parts` in order), plus the batch's share of the
 // alignment summary and the reads the device flagged.  `parts` keeps its capacity from batch to batch.

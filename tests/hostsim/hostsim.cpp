@@ -286,7 +286,8 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 	std::string o;
 	if (!opt.sam_no_hd) sam_header(o, ref, opt.cmdline, true, !opt.sam_no_sq, opt.rg_id, opt.rgs);
 	fwrite(o.data(), 1, o.size(), out);
-	FastqBatcher fq1(opt.mate1_file, opt, 1), fq2(opt.mate2_file, opt, 1);
+	const bool inter = !opt.interleaved_file.empty();
+	FastqBatcher fq1(inter ? opt.interleaved_file : opt.mate1_file, opt, 1), fq2(inter ? std::string("/dev/null") : opt.mate2_file, opt, 1);
 	if (!fq1.ok() || !fq2.ok()) { fprintf(stderr, "cannot open the mate files\n"); return 1; }
 	Work* w = new Work();
 	DpScratch dp, dp2;
@@ -298,11 +299,14 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 	PairSummary summ;
 	uint32_t pair_no = 0;
 	for (bool last = false; !last; ) {
-		std::unique_ptr<HostBatch> b1(new HostBatch()), b2(new HostBatch());
-		fq1.next(*b1, 4096, (size_t)1 << 30);
-		fq2.next(*b2, 4096, (size_t)1 << 30);
 		HostBatch hb;
-		merge_mate_batches(std::move(b1), std::move(b2), hb, opt);
+		if (inter) { fq1.next(hb, 4096, (size_t)1 << 30); finalize_interleaved(hb, opt); }
+		else {
+			std::unique_ptr<HostBatch> b1(new HostBatch()), b2(new HostBatch());
+			fq1.next(*b1, 4096, (size_t)1 << 30);
+			fq2.next(*b2, 4096, (size_t)1 << 30);
+			merge_mate_batches(std::move(b1), std::move(b2), hb, opt);
+		}
 		last = hb.last;
 		if (!hb.bad_input.empty()) { fprintf(stderr, "Error: %s\n", hb.bad_input.c_str()); return 1; }
 		for (size_t pi = 0; pi + 1 < hb.reads.size(); pi += 2, pair_no++) {

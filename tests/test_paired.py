@@ -91,6 +91,16 @@ def check(exe_s, exe_l, n, option_sets, extra=()):
             assert keep(p.stderr) == keep(pr.stderr), (large, args)      # the paired alignment summary
             kinds.update(l.rsplit("YT:Z:", 1)[1][:2] for l in want if "YT:Z:" in l)
     assert {"CP", "DP", "UP"} <= kinds
+    # --interleaved: the same pairs from one file; -s/-u count pairs
+    fi = os.path.join(d, "inter.fq")
+    l1, l2 = open(f1).read().splitlines(), open(f2).read().splitlines()
+    open(fi, "w").write("".join("\n".join(l1[i:i + 4] + l2[i:i + 4]) + "\n" for i in range(0, len(l1), 4)))
+    base = os.path.join(d, "gs")
+    for args in ([], ["-s", "10", "-u", "50"], ["--local", "-k", "2"]):
+        a = subprocess.run([ref_bin("bowtie2-align-s")] + args + ["-x", base, "--interleaved", fi, "--reorder", "-p", "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        b = subprocess.run([exe_s] + list(extra) + args + ["-x", base, "--interleaved", fi], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        body = lambda t: [l for l in t.splitlines() if not l.startswith("@PG")]
+        assert body(a.stdout) == body(b.stdout), args
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
