@@ -176,9 +176,58 @@ def align_golden(refs):
             open(out, "w").writelines(lines)
 
 
+def pair_golden(refs):
+    """Paired-end golden: the reference binary's SAM for a fixed set of pairs (proper, over-long, wrong orientation, junk
+    mate, different sequences) against the tiny indexes."""
+    rnd = random.Random(77)
+    comp = str.maketrans("ACGTN", "TGCAN")
+    rc = lambda x: x.translate(comp)[::-1]
+    r1, r2 = [], []
+    for i in range(160):
+        _, s = refs[rnd.randrange(len(refs))]
+        L1, L2 = rnd.randrange(30, 101), rnd.randrange(30, 101)
+        kind = rnd.random()
+        frag = max(int(rnd.gauss(220, 30)), max(L1, L2) + 5)
+        if kind < 0.06:
+            frag = rnd.randrange(560, 900)
+        frag = min(frag, len(s) - 2)
+        p = rnd.randrange(0, len(s) - frag - 1)
+        f = s[p:p + frag]
+        m1, m2 = f[:L1], rc(f[-L2:])
+        if kind > 0.94:
+            m2 = rc(m2)
+        if 0.88 < kind <= 0.94:
+            m2 = "".join(rnd.choice("ACGT") for _ in range(L2))
+        if 0.82 < kind <= 0.88:
+            _, s2 = refs[rnd.randrange(len(refs))]
+            q = rnd.randrange(0, len(s2) - L2 - 1)
+            m2 = rc(s2[q:q + L2])
+        if rnd.random() < 0.5:
+            m1, m2 = m2, m1
+        mut = lambda x: "".join(c if rnd.random() > 0.015 else rnd.choice("ACGT") for c in x)
+        m1, m2 = mut(m1), mut(m2)
+        r1.append(("p%d/1" % i, m1, "".join(rnd.choice("IIIIHH?5") for _ in m1)))
+        r2.append(("p%d/2" % i, m2, "".join(rnd.choice("IIIIHH?5") for _ in m2)))
+    f1, f2 = os.path.join(HERE, "pe_reads_1.fq"), os.path.join(HERE, "pe_reads_2.fq")
+    write_fastq(f1, r1)
+    write_fastq(f2, r2)
+    for large in (False, True):
+        exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
+        base = os.path.join(HERE, "tiny_l" if large else "tiny_s")
+        for tag, args in (("sens", ["--sensitive"]), ("local", ["--local", "-k", "2"])):
+            out = os.path.join(HERE, "pe_golden_%s_%s.sam" % ("l" if large else "s", tag))
+            subprocess.check_call([exe] + args + ["-x", base, "-1", f1, "-2", f2, "-p", "1", "-S", out], stderr=subprocess.DEVNULL)
+            lines = [l for l in open(out) if not l.startswith("@PG")]
+            open(out, "w").writelines(lines)
+
+
 if __name__ == "__main__":
     refs = build_tiny()
+    if len(sys.argv) > 1 and sys.argv[1] == "pairs":      # only the paired-end fixtures
+        pair_golden(refs)
+        sys.exit(0)
     align_golden(refs)
+    pair_golden(refs)
     for large in (False, True):
         with open(os.path.join(HERE, "fm_golden_%s.json" % ("l" if large else "s")), "w") as f:
             json.dump(fm_golden(large, refs), f, separators=(",", ":"))

@@ -34,6 +34,15 @@ def test_golden_sam(idx, tag, args):
     assert got == want
 
 
+@pytest.mark.parametrize("idx,tag,args", [("tiny_s", "s_sens", ["--sensitive"]), ("tiny_l", "l_sens", ["--sensitive"]),
+                                           ("tiny_s", "s_local", ["--local", "-k", "2"]), ("tiny_l", "l_local", ["--local", "-k", "2"])])
+def test_golden_sam_paired(idx, tag, args):
+    got, err = run_ours(args + ["-x", os.path.join(GOLD, idx), "-1", os.path.join(GOLD, "pe_reads_1.fq"), "-2", os.path.join(GOLD, "pe_reads_2.fq")])
+    want = open(os.path.join(GOLD, "pe_golden_%s.sam" % tag)).read().splitlines()
+    assert "Warning" not in err
+    assert got == want
+
+
 def repeat_genome():
     rnd = random.Random(5)
     refs = synth_genome(n_refs=3, total=200000, seed=21)

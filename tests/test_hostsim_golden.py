@@ -29,3 +29,14 @@ def test_sam_identical_to_reference(hostsim, idx, tag, args):
     want = open(os.path.join(GOLD, "align_golden_%s.sam" % tag)).read().splitlines()
     assert got == want
     assert "overall alignment rate" in p.stderr
+
+
+@pytest.mark.parametrize("idx,tag,args", [("tiny_s", "s_sens", ["--sensitive"]), ("tiny_l", "l_sens", ["--sensitive"]),
+                                           ("tiny_s", "s_local", ["--local", "-k", "2"]), ("tiny_l", "l_local", ["--local", "-k", "2"])])
+def test_paired_sam_identical_to_reference(hostsim, idx, tag, args):
+    p = subprocess.run([hostsim] + args + ["-x", os.path.join(GOLD, idx), "-1", os.path.join(GOLD, "pe_reads_1.fq"), "-2", os.path.join(GOLD, "pe_reads_2.fq")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
+    got = [l for l in p.stdout.splitlines() if not l.startswith("@PG")]
+    want = open(os.path.join(GOLD, "pe_golden_%s.sam" % tag)).read().splitlines()
+    assert got == want
+    assert "were paired; of these:" in p.stderr
