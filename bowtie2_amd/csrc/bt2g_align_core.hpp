@@ -1314,9 +1314,6 @@ struct Aligner {
 			else ret = backtrace<2>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
 			rnd.init(sse16 ? reseed : reseed + 1);
 			if (mode == 2) cand_list()[HOT.cural].score = cscore | kCandDone;       // btncanddone_: tried, succeeded or not
-#ifdef PE_DEBUG
-			if (cands_cur != w.cands) fprintf(stderr, "     cand %u row %u col %u score %d ret %d nned %u refoff %lld resscore %d\n", HOT.cural, c.row, c.col, cscore, (int)ret, res.nned, (long long)res.refoff, res.score);
-#endif
 			if (ret) { found = true; break; }
 			HOT.cural++;
 		}
