@@ -239,6 +239,21 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		if (!opt.no_exact_upfront || !opt.no_1mm_upfront) return "Error: -d must be used with --no-exact-upfront and --no-1mm-upfront.";
 		if (!opt.all_hits) return "Error: -d can only be used with -a.";
 	}
+	if (opt.format == 4 && !opt.reads_file.empty()) {
+		// --tab5/--tab6: a file of 5- or 6-field records holds pairs (pat.cpp:1545); it is then read like an interleaved source
+		FILE* tf = fopen(opt.reads_file.c_str(), "rb");
+		if (tf) {
+			char line[1 << 16];
+			while (fgets(line, sizeof line, tf)) {
+				int tabs = 0; bool blank = true;
+				for (const char* q = line; *q; q++) { if (*q == '\t') tabs++; if (*q != '\n' && *q != '\r' && *q != ' ') blank = false; }
+				if (blank) continue;
+				if (tabs >= 4) { opt.interleaved_file = opt.reads_file; opt.reads_file.clear(); }
+				break;
+			}
+			fclose(tf);
+		}
+	}
 	if (opt.mate1_file.empty() != opt.mate2_file.empty()) return "-1 and -2 must be specified together";
 	opt.paired = !opt.mate1_file.empty() || !opt.interleaved_file.empty();
 	if (!opt.interleaved_file.empty() && !opt.mate1_file.empty()) return "--interleaved and -1/-2 in one run are not supported by this build";

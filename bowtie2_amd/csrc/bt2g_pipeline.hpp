@@ -217,8 +217,10 @@ public:
 		arena_.clear(); recs_.clear();
 		while (recs_.size() < max_reads) {
 			const char* p; size_t n;
-			Raw r;
+			Raw r, r2;
+			bool have_r2 = false;
 			r.qual_off = r.qual_len = 0; r.has_qual = false; r.filter = '1';
+			r2 = r;
 			if (opt_.format == 0) {                    // FASTQ: 4-line records
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
@@ -263,10 +265,31 @@ public:
 				const char* t1 = (const char*)memchr(p, '\t', n);
 				const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(p + n - t1 - 1)) : nullptr;
 				if (!t1 || !t2) { b.bad_input = "malformed tab-delimited read record"; b.last = true; break; }
-				if (memchr(t2 + 1, '\t', (size_t)(p + n - t2 - 1))) { b.bad_input = "paired tab-delimited records are outside the hot path implemented so far"; b.last = true; break; }
+				const char* t3 = (const char*)memchr(t2 + 1, '\t', (size_t)(p + n - t2 - 1));
 				r.name_off = arena_.size(); r.name_len = (size_t)(t1 - p); arena_.append(p, r.name_len);
 				r.seq_off = arena_.size(); r.seq_len = (size_t)(t2 - t1 - 1); arena_.append(t1 + 1, r.seq_len);
-				r.qual_off = arena_.size(); r.qual_len = (size_t)(p + n - t2 - 1); arena_.append(t2 + 1, r.qual_len); r.has_qual = true;
+				if (!t3) {
+					if (unit_ == 2) { b.bad_input = "unpaired record in a paired tab-delimited file (mixing is not supported by this build)"; b.last = true; break; }
+					r.qual_off = arena_.size(); r.qual_len = (size_t)(p + n - t2 - 1); arena_.append(t2 + 1, r.qual_len); r.has_qual = true;
+				} else {
+					// paired record: name seq1 qual1 seq2 qual2 (--tab5) or name1 seq1 qual1 name2 seq2 qual2 (--tab6)
+					// (TabbedPatternSource::parse, pat.cpp:1545-1660)
+					if (unit_ != 2) { b.bad_input = "paired record in an unpaired tab-delimited file (mixing is not supported by this build)"; b.last = true; break; }
+					r.qual_off = arena_.size(); r.qual_len = (size_t)(t3 - t2 - 1); arena_.append(t2 + 1, r.qual_len); r.has_qual = true;
+					const char* f[4]; int nf = 0; f[nf++] = t3 + 1;
+					for (const char* q = t3 + 1; q < p + n && nf < 4; q++) if (*q == '\t') f[nf++] = q + 1;
+					const char* end = p + n;
+					r2 = r; have_r2 = true;
+					if (nf == 2) {            // seq2 qual2, name shared
+						r2.name_off = r.name_off; r2.name_len = r.name_len;
+						r2.seq_off = arena_.size(); r2.seq_len = (size_t)(f[1] - 1 - f[0]); arena_.append(f[0], r2.seq_len);
+						r2.qual_off = arena_.size(); r2.qual_len = (size_t)(end - f[1]); arena_.append(f[1], r2.qual_len); r2.has_qual = true;
+					} else if (nf == 3) {     // name2 seq2 qual2
+						r2.name_off = arena_.size(); r2.name_len = (size_t)(f[1] - 1 - f[0]); arena_.append(f[0], r2.name_len);
+						r2.seq_off = arena_.size(); r2.seq_len = (size_t)(f[2] - 1 - f[1]); arena_.append(f[1], r2.seq_len);
+						r2.qual_off = arena_.size(); r2.qual_len = (size_t)(end - f[2]); arena_.append(f[2], r2.qual_len); r2.has_qual = true;
+					} else { b.bad_input = "malformed paired tab-delimited read record"; b.last = true; break; }
+				}
 			} else if (opt_.format == 5) {             // --qseq: 11 tab-separated fields (read_qseq.cpp:83-233)
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
@@ -296,8 +319,14 @@ public:
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
 			}
 			r.rdid = rdid_ / unit_;
-			if ((rdid_++) / unit_ < opt_.skip) continue;
-			recs_.push_back(r);
+			const bool skip1 = (rdid_++) / unit_ < opt_.skip;
+			if (!skip1) recs_.push_back(r);
+			if (have_r2) {
+				have_r2 = false;
+				r2.rdid = rdid_ / unit_;
+				if (!((rdid_++) / unit_ < opt_.skip)) recs_.push_back(r2);
+			}
+			if (skip1) continue;
 		}
 		const double t1_ = tnow();
 		t_split += t1_ - t0_;

@@ -53,9 +53,7 @@ def case_inputs(c, fw):
         return None                     # file-based cases run forward only (simple_tests.pl: `next unless $fw`)
     for key, flag in (("fastq", "-q"), ("fasta", "-f"), ("raw", "-r"), ("tabbed", "--tab5"), ("cline_reads", "-c"), ("qseq", "--qseq")):
         if c.get(key) is not None:
-            if key == "tabbed" and any(len(l.split("\t")) > 3 for l in c[key].splitlines() if l.strip()):
-                return None             # paired tab5 records
-            return flag, c[key]
+            return flag, c[key]        # --tab5 files may hold paired (5-field) records
     return None
 
 
@@ -138,7 +136,11 @@ def main():
             continue
         args = (c.get("args") or "").split() + ["--quiet"] + (c["report"].split() if c.get("report") else ["-a"])
         fa_text = "".join(">%d\n%s\n" % (i, s) for i, s in enumerate(c["ref"]))
-        if PAIRED_KEYS & set(c):
+        # a paired case given as one --tab5 file goes through the single-file path below (pair policy arguments appended)
+        tab_only = c.get("tabbed") is not None and not any(c.get(k) is not None for k in ("mate1s", "fastq1", "fasta1", "raw1", "cline_reads1", "reads", "fastq", "fasta", "raw", "cline_reads"))
+        if tab_only and (PAIRED_KEYS & set(c)):
+            args = args + ["--" + ("f" if c.get("mate1fw", 1) else "r") + ("f" if c.get("mate2fw", 0) else "r")]
+        if (PAIRED_KEYS & set(c)) and not tab_only:
             # paired cases: mate lists (forward and role-swapped) or mate files (forward only)
             if any(c.get(k) is not None for k in ("tabbed1", "tabbed2", "qseq1", "qseq2", "tabbed", "reads", "fastq", "fasta", "raw", "cline_reads")):
                 skipped += 1
