@@ -155,9 +155,11 @@ inline void merge_mate_batches(std::unique_ptr<HostBatch> b1, std::unique_ptr<Ho
 // Line-oriented reader over gz or plain input (gzread handles both)
 class LineSource {
 public:
+	// `path` may be a comma-separated list of files (as -U / -1 / -2 accept, bt2_search.cpp:1185-1199); they are read one after the other
 	explicit LineSource(const std::string& path) {
-		f_ = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
-		if (f_) gzbuffer(f_, 1 << 20);
+		for (size_t a = 0; a <= path.size();) { size_t b = path.find(',', a); if (b == std::string::npos) b = path.size(); if (b > a) paths_.push_back(path.substr(a, b - a)); a = b + 1; }
+		if (paths_.empty()) paths_.push_back(path);
+		open_next();
 	}
 	~LineSource() { if (f_) gzclose(f_); }
 	bool ok() const { return f_ != nullptr; }
@@ -188,10 +190,25 @@ private:
 		if (pos_ > 0) { buf_.erase(0, pos_); pos_ = 0; }
 		const size_t old = buf_.size(), want = 8u << 20;
 		buf_.resize(old + want);
-		const int got = gzread(f_, &buf_[old], (unsigned)want);
+		int got = gzread(f_, &buf_[old], (unsigned)want);
 		buf_.resize(old + (got > 0 ? (size_t)got : 0));
-		if (got <= 0) eof_ = true;
+		if (got <= 0) {
+			if (next_path_ < paths_.size()) {
+				// next file of the list: the previous one ends a line even if its last newline is missing
+				if (!buf_.empty() && buf_.back() != '\n') buf_.push_back('\n');
+				gzclose(f_); f_ = nullptr;
+				if (!open_next()) eof_ = true;
+			} else eof_ = true;
+		}
 	}
+	bool open_next() {
+		const std::string& p = paths_[next_path_++];
+		f_ = p == "-" ? gzdopen(0, "rb") : gzopen(p.c_str(), "rb");
+		if (f_) gzbuffer(f_, 1 << 20);
+		return f_ != nullptr;
+	}
+	std::vector<std::string> paths_;
+	size_t next_path_ = 0;
 	bool unterminated_ = false;
 public:
 	bool last_line_unterminated() const { return unterminated_; }

@@ -66,7 +66,10 @@ def input_variants(tmp):
     tab = os.path.join(tmp, "r.tab5")
     open(tab, "w").write("".join("%s\t%s\t%s\n" % (n, s, q) for n, s, q in recs if s))
     cmdline = ",".join("%s:%s" % (s, q) if i % 2 else s for i, (_, s, q) in enumerate(recs[:12]) if len(s) > 20 and ":" not in q and "," not in q)
-    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), ([], gz), (["--tab5"], tab), (["--tab6"], tab), (["-c"], cmdline)]
+    # a comma-separated list of inputs, plain and gzipped mixed
+    half = os.path.join(tmp, "half.fq")
+    open(half, "w").write("".join("@%s\n%s\n+\n%s\n" % r for r in recs[:len(recs) // 2]))
+    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), ([], gz), (["--tab5"], tab), (["--tab6"], tab), (["-c"], cmdline), ([], half + "," + gz)]
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
