@@ -161,6 +161,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "-L") { opt.seed_len = atoi(need().c_str()); opt.set_L = true; if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }
 		else if (a == "--local") opt.local = true;
 		else if (a == "--overhang") opt.report_overhangs = true;
+		else if (a == "--passthrough") opt.passthrough = true;
 		else if (a == "--policy") err = apply_policy_string(opt, need());
 		else if (a == "--bwa-sw-like") {
 			// bt2_search.cpp:1114-1126: local mode, BWA-SW's scoring, and its length-dependent score threshold

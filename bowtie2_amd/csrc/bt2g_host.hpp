@@ -79,6 +79,7 @@ struct Options {
 	bool bwa_sw_like = false;     // --bwa-sw-like: minimum score = a*max(T, c*ln(len)) (bt2_search.cpp:3341-3350)
 	bool report_overhangs = false;
 	bool det_seeds = false;       // -d / --deterministic-seeds
+	bool passthrough = false;     // --passthrough: every SAM line is followed by the read's original text (the Perl wrapper's --un/--al/--un-conc/--al-conc)
 	bool no_exact_upfront = false;
 	// paired-end input and policy (bt2_search.cpp:1185-1215; PairedEndPolicy pe.h:169)
 	std::string mate1_file, mate2_file, interleaved_file;
@@ -177,6 +178,7 @@ struct ReadRec {
 	StrView name;
 	StrView seq;        // codes 0..4
 	StrView qual;       // ASCII phred+33
+	StrView orig;       // --passthrough: the record's original text (Read::readOrigBuf)
 	char filter = '1';  // QSEQ filter field ('0' = failed the instrument's QC; --qc-filter)
 };
 
@@ -550,6 +552,14 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	}
 	if (!opt.rg_optflag.empty()) { o.push_back('\t'); o += opt.rg_optflag; }
 	o.push_back('\n');
+	if (opt.passthrough) {      // samc_.passthrough() (aln_sink.cpp:2118): newlines and '%' percent-encoded (sam.h:290)
+		for (size_t i = 0; i < rd.orig.size(); i++) {
+			const unsigned char ch = (unsigned char)rd.orig[i];
+			if (ch == 10 || ch == 13 || ch == '%') { o.push_back('%'); o.push_back("0123456789ABCDEF"[ch >> 4]); o.push_back("0123456789ABCDEF"[ch & 15]); }
+			else o.push_back((char)ch);
+		}
+		o.push_back('\n');
+	}
 }
 
 // SAM lines of one pair, in the order AlnSinkWrap::finishRead / AlnSink::reportHits emit them (aln_sink.cpp:700-1390,

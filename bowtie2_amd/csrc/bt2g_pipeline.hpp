@@ -92,7 +92,7 @@ private:
 
 // One batch travelling through the pipeline
 struct HostBatch {
-	struct Chunk { std::string names, seq, qual; };   // arenas of 4096 reads: names stay here, seq/qual are copied to the packed arrays
+	struct Chunk { std::string names, seq, qual, orig; };   // arenas of 4096 reads: names stay here, seq/qual are copied to the packed arrays
 	std::vector<Chunk> chunks;
 	std::vector<ReadRec> reads;                       // views into `chunks` (names) and `seq`/`qual` (packed arrays)
 	std::vector<uint8_t> seq, qual;       // packed device arrays
@@ -172,12 +172,14 @@ public:
 			if (nl) {
 				p = base; n = (size_t)(nl - base);
 				pos_ += n + 1;
+				raw_len_ = n + 1;
 				if (n && p[n - 1] == '\r') n--;
 				return true;
 			}
 			if (eof_) {
 				if (avail == 0) return false;
 				p = base; n = avail; pos_ = buf_.size();
+				raw_len_ = n;
 				unterminated_ = true;          // last line of the input has no newline
 				if (n && p[n - 1] == '\r') n--;
 				return true;
@@ -212,7 +214,9 @@ private:
 	bool unterminated_ = false;
 public:
 	bool last_line_unterminated() const { return unterminated_; }
+	size_t last_raw_len() const { return raw_len_; }      // length of the last line including its terminator (--passthrough)
 private:
+	size_t raw_len_ = 0;
 	gzFile f_ = nullptr;
 	std::string buf_;
 	size_t pos_ = 0;
@@ -231,12 +235,14 @@ public:
 		auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 		const double t0_ = tnow();
 		// ---- serial part: split the text into records (line copies into one arena)
-		arena_.clear(); recs_.clear();
+		arena_.clear(); recs_.clear(); orig_.clear();
+		const bool pt = opt_.passthrough;
 		while (recs_.size() < max_reads) {
 			const char* p; size_t n;
 			Raw r, r2;
 			bool have_r2 = false;
 			r.qual_off = r.qual_len = 0; r.has_qual = false; r.filter = '1';
+			r.orig_off = orig_.size(); r.orig_len = 0;
 			r2 = r;
 			if (opt_.format == 0) {                    // FASTQ: 4-line records
 				bool got;
@@ -244,21 +250,27 @@ public:
 				if (!got || p[0] != '@') { b.last = true; break; }
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
+				if (pt) orig_.append(p, src_.last_raw_len());
 				if (!src_.next(p, n)) { b.last = true; break; }
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
+				if (pt) orig_.append(p, src_.last_raw_len());
 				if (!src_.next(p, n)) { b.last = true; break; }            // '+' line
+				if (pt) orig_.append(p, src_.last_raw_len());
 				if (!src_.next(p, n)) { b.last = true; break; }
 				r.qual_off = arena_.size(); r.qual_len = n; arena_.append(p, n); r.has_qual = true;
+				if (pt) orig_.append(p, src_.last_raw_len());
 			} else if (opt_.format == 1) {             // FASTA: '>' name, sequence possibly over several lines
 				bool got = true;
-				if (!have_pending_) { do { got = src_.next(p, n); } while (got && (n == 0 || p[0] != '>')); if (got) pending_.assign(p, n); }
+				if (!have_pending_) { do { got = src_.next(p, n); } while (got && (n == 0 || p[0] != '>')); if (got) { pending_.assign(p, n); if (pt) pending_raw_.assign(p, src_.last_raw_len()); } }
 				if (!got) { b.last = true; break; }
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				have_pending_ = false;
 				r.name_off = arena_.size(); r.name_len = pending_.size() - 1; arena_.append(pending_.data() + 1, pending_.size() - 1);
 				r.seq_off = arena_.size(); r.seq_len = 0;
+				if (pt) orig_ += pending_raw_;
 				while (src_.next(p, n)) {
-					if (n && p[0] == '>') { pending_.assign(p, n); have_pending_ = true; break; }
+					if (n && p[0] == '>') { pending_.assign(p, n); have_pending_ = true; if (pt) pending_raw_.assign(p, src_.last_raw_len()); break; }
+					if (pt) orig_.append(p, src_.last_raw_len());
 					// the reference's FASTA parser drops the last character of a final line that lacks its newline
 					if (src_.last_line_unterminated() && n > 0) n--;
 					arena_.append(p, n); r.seq_len += n;
@@ -274,11 +286,13 @@ public:
 				r.name_off = arena_.size(); r.name_len = 0;
 				r.seq_off = arena_.size(); r.seq_len = colon == std::string::npos ? tok.size() : colon; arena_.append(tok.data(), r.seq_len);
 				if (colon != std::string::npos) { r.qual_off = arena_.size(); r.qual_len = tok.size() - colon - 1; arena_.append(tok.data() + colon + 1, r.qual_len); r.has_qual = true; }
+				if (pt) { orig_ += std::to_string(rdid_ / unit_); orig_.push_back('\t'); orig_.append(tok.data(), r.seq_len); orig_.push_back('\t'); if (r.has_qual) orig_.append(tok.data() + colon + 1, r.qual_len); else orig_.append(r.seq_len, 'I'); }
 			} else if (opt_.format == 4) {             // --tab5 / --tab6, unpaired form: name <tab> seq <tab> quals
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (pt) orig_.append(p, n);
 				const char* t1 = (const char*)memchr(p, '\t', n);
 				const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(p + n - t1 - 1)) : nullptr;
 				if (!t1 || !t2) { b.bad_input = "malformed tab-delimited read record"; b.last = true; break; }
@@ -334,7 +348,9 @@ public:
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				r.name_off = arena_.size(); r.name_len = 0;
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
+				if (pt) orig_.append(p, n);
 			}
+			r.orig_len = orig_.size() - r.orig_off;
 			r.rdid = rdid_ / unit_;
 			const bool skip1 = (rdid_++) / unit_ < opt_.skip;
 			if (!skip1) recs_.push_back(r);
@@ -353,7 +369,7 @@ public:
 		b.reads.assign(nrec, ReadRec());
 		b.rp.resize(nrec);
 		b.chunks.assign(nchunks, HostBatch::Chunk());
-		std::vector<uint32_t> name_off(nrec), name_len(nrec), rlen(nrec);
+		std::vector<uint32_t> name_off(nrec), name_len(nrec), rlen(nrec), orig_off(pt ? nrec : 0), orig_len(pt ? nrec : 0);
 		parallel_for(nchunks, threads_, [&](size_t c) {
 			HostBatch::Chunk& ch = b.chunks[c];
 			std::string tseq, tqual;
@@ -388,6 +404,7 @@ public:
 				name_len[i] = (uint32_t)ch.names.size() - name_off[i];
 				rlen[i] = (uint32_t)tseq.size();
 				ch.seq += tseq; ch.qual += tqual;
+				if (pt) { orig_off[i] = (uint32_t)ch.orig.size(); ch.orig.append(orig_.data() + r.orig_off, r.orig_len); orig_len[i] = (uint32_t)r.orig_len; }
 				b.reads[i].filter = r.filter;
 			}
 		});
@@ -410,6 +427,7 @@ public:
 			for (size_t i = i0; i < e; i++) {
 				ReadRec& rd = b.reads[i];
 				rd.name.set(ch.names.data() + name_off[i], name_len[i]);
+				if (pt) rd.orig.set(ch.orig.data() + orig_off[i], orig_len[i]);
 				rd.seq.set((const char*)b.seq.data() + b.off[i], rlen[i]);
 				rd.qual.set((const char*)b.qual.data() + b.off[i], rlen[i]);
 				b.rp[i] = compute_read_params(opt_, rd);
@@ -419,7 +437,8 @@ public:
 		t_pack += tnow() - t2_;
 	}
 private:
-	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; };
+	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; };
+	std::string orig_, pending_raw_;   // --passthrough: the records' original text (Read::readOrigBuf)
 	LineSource src_;
 	const Options& opt_;
 	unsigned threads_;

@@ -30,6 +30,7 @@ OPTION_SETS = [
     ["--policy", "SEED=1;SEEDLEN=16", "--very-sensitive"],
     ["-d", "-a", "--no-exact-upfront", "--no-1mm-upfront"], ["-d", "-a", "--no-exact-upfront", "--no-1mm-upfront", "--local", "-N", "1", "-L", "20"],
     ["--no-exact-upfront"], ["--no-exact-upfront", "--no-1mm-upfront", "-k", "2"],
+    ["--passthrough"], ["--passthrough", "-k", "3", "--local"],
 ]
 
 
@@ -69,7 +70,8 @@ def input_variants(tmp):
     # a comma-separated list of inputs, plain and gzipped mixed
     half = os.path.join(tmp, "half.fq")
     open(half, "w").write("".join("@%s\n%s\n+\n%s\n" % r for r in recs[:len(recs) // 2]))
-    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), ([], gz), (["--tab5"], tab), (["--tab6"], tab), (["-c"], cmdline), ([], half + "," + gz)]
+    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), ([], gz), (["--tab5"], tab), (["--tab6"], tab), (["-c"], cmdline), ([], half + "," + gz),
+            (["-f", "--passthrough"], fa), (["--tab5", "--passthrough"], tab), (["-c", "--passthrough"], cmdline)]
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
@@ -81,7 +83,7 @@ def test_options_match_reference_hostsim(hostsim, idx, tmp_path):
         args = opts + ["-x", base, "-U", FQ]
         assert run(hostsim, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts
     for opts, path in input_variants(str(tmp_path)):
-        args = (opts + [path, "-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path])
+        args = (opts[:1] + [path] + opts[1:] + ["-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path])
         assert run(hostsim, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts
 
 
@@ -100,5 +102,5 @@ def test_options_match_reference_gpu(tmp_path):
         args = opts + ["-x", base, "-U", FQ]
         assert run(EXE, args + ["-p", "4"], str(tmp_path)) == run(ref, args, str(tmp_path)), opts
     for opts, path in input_variants(str(tmp_path)):
-        args = (opts + [path, "-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path])
+        args = (opts[:1] + [path] + opts[1:] + ["-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path])
         assert run(EXE, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HS = os.path.join(ROOT, "tests", "hostsim")
 OPTION_SETS = ([], ["--local"], ["-k", "3"], ["--no-mixed"], ["--no-discordant"], ["-I", "200", "-X", "350"], ["--ff"],
                ["--very-sensitive", "--dovetail"], ["--no-contain", "--no-overlap"], ["-N", "1", "-L", "18"],
-               ["--very-sensitive-local", "-k", "4"], ["--rf", "-X", "700"], ["--no-unal", "--xeq", "-3", "5"])
+               ["--very-sensitive-local", "-k", "4"], ["--rf", "-X", "700"], ["--no-unal", "--xeq", "-3", "5"], ["--passthrough"])
 
 
 def make_pairs(n, seed):
