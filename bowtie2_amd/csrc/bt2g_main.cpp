@@ -57,49 +57,6 @@ private:
 	std::vector<std::pair<void*, size_t>> free_;
 };
 
-// The option interface of bowtie2-align (name:takes-argument), in the order `--arg-desc` lists it
-// (printArgDesc, bt2_search.cpp:710-747).  The Perl wrapper asks for this table (`--wrapper basic-0 --arg-desc`,
-// bowtie2:104) to tell the aligner's options from its own, so a drop-in has to answer with the same names --
-// including the options this build goes on to reject.
-static const char kArgDesc[] =
-	"verbose:0 startverbose:0 quiet:0 sanity:0 pause:0 orig:1 all:0 solexa-quals:0 integer-quals:0 "
-	"int-quals:0 metrics:1 metrics-file:1 metrics-stderr:0 metrics-per-read:0 met-read:0 met:1 met-file:1 "
-	"met-stderr:0 time:0 trim3:1 trim5:1 seed:1 qupto:1 upto:1 version:0 reads-per-batch:1 filepar:0 "
-	"help:0 threads:1 khits:1 lowseeds:1 minins:1 maxins:1 quals:1 Q1:1 Q2:1 refidx:0 partition:1 ff:0 "
-	"fr:0 rf:0 cachelim:1 cachesz:1 nofw:0 norc:0 skip:1 12:1 tab5:1 tab6:1 interleaved:1 phred33-quals:0 "
-	"phred64-quals:0 phred33:0 phred64:0 solexa1.3-quals:0 mm:0 shmem:0 mmsweep:0 hadoopout:0 fullref:0 "
-	"usage:0 sam-no-qname-trunc:0 sam-omit-sec-seq:0 omit-sec-seq:0 sam-no-head:0 sam-nohead:0 sam-noHD:0 "
-	"sam-no-hd:0 sam-nosq:0 sam-no-sq:0 sam-noSQ:0 no-head:0 no-hd:0 no-sq:0 no-HD:0 no-SQ:0 no-unal:0 "
-	"sam-RG:1 sam-rg:1 sam-rg-id:1 RG:1 rg:1 rg-id:1 snpphred:1 snpfrac:1 gbar:1 qseq:0 policy:1 preset:1 "
-	"seed-summ:0 seed-summary:0 overhang:0 no-cache:0 cache:0 454:0 ion-torrent:0 no-mixed:0 "
-	"no-discordant:0 local:0 end-to-end:0 ungapped:0 no-ungapped:0 sse8:0 no-sse8:0 scan-narrowed:0 "
-	"qc-filter:0 bwa-sw-like:0 multiseed:1 ma:1 mp:1 np:1 rdg:1 rfg:1 score-min:1 min-score:1 n-ceil:1 "
-	"dpad:1 mapq-print-inputs:0 very-fast:0 fast:0 sensitive:0 very-sensitive:0 very-fast-local:0 "
-	"fast-local:0 sensitive-local:0 very-sensitive-local:0 seedlen:1 seedmms:1 seedival:1 ignore-quals:0 "
-	"index:1 arg-desc:0 wrapper:1 unpaired:1 output:1 mapq-v:1 dovetail:0 no-dovetail:0 contain:0 "
-	"no-contain:0 overlap:0 no-overlap:0 tighten:1 exact-upfront:0 1mm-upfront:0 no-exact-upfront:0 "
-	"no-1mm-upfront:0 1mm-minlen:1 deterministic-seeds:0 no-deterministic-seeds:0 seed-off:1 seed-boost:1 "
-	"read-times:0 show-rand-seed:0 dp-fail-streak:1 ee-fail-streak:1 ug-fail-streak:1 fail-streak:1 "
-	"dp-fails:1 ug-fails:1 extends:1 no-extend:0 mapq-extra:0 seed-rounds:1 reorder:0 passthrough:0 "
-	"sample:1 cp-min:1 cp-ival:1 tri:0 nondeterministic:0 non-deterministic:0 local-seed-cache-sz:1 "
-	"seed-cache-sz:1 no-unal:0 test-25:0 desc-kb:1 desc-landing:1 desc-exp:1 desc-prioritize:0 "
-	"desc-fmops:1 log-dp:1 log-dp-opp:1 soft-clipped-unmapped-tlen:0 xeq:0 thread-ceiling:1 "
-	"thread-piddir:1 trim-to:1 preserve-tags:0 align-paired-reads:0 sam-append-comment:0 sam-opt-config:1 "
-	"b:0 f:0 F:1 q:0 b:0 z:0 h:0 c:0 u:1 r:0 v:1 s:1 a:0 d:0 P:1 t:0 3:1 5:1 w:1 p:1 k:1 l:1 M:1 1:1 2:1 "
-	"I:1 X:1 C:0 Q:1 N:1 i:1 L:1 U:1 x:1 S:1 g:1 O:1 D:1 R:1 ";
-
-static void print_arg_desc() {
-	std::string tok;
-	for (const char* p = kArgDesc; ; p++) {
-		if (*p == ' ' || *p == 0) {
-			const size_t c = tok.rfind(':');
-			if (c != std::string::npos) printf("%s\t%s\n", tok.substr(0, c).c_str(), tok.substr(c + 1).c_str());
-			tok.clear();
-			if (*p == 0) break;
-		} else tok.push_back(*p);
-	}
-}
-
 int main(int argc, char** argv) {
 	Options opt;
 	std::string cmdline;

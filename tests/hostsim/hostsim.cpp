@@ -343,6 +343,7 @@ int main(int argc, char** argv) {
 	CliExtra ex;
 	ex.allow_paired = true;
 	const std::string perr = parse_cli(argc, argv, opt, ex);
+	if (ex.arg_desc) { print_arg_desc(); return 0; }
 	if (!perr.empty()) { fprintf(stderr, "%s\n", perr.c_str()); return 1; }
 	const bool metrics = ex.metrics;
 	opt.cmdline = "hostsim";

@@ -57,3 +57,31 @@ def test_perl_wrapper_execs_our_binary(tmp_path):
     else:
         assert p.returncode != 0
         assert "no usable MI355X" in p.stderr          # our binary was reached, and it has no CPU path
+
+
+@pytest.mark.skipif(not os.path.exists(WRAPPER) or shutil.which("perl") is None or not have_ref(), reason="reference wrapper, perl or oracle/_ref not available")
+def test_perl_wrapper_un_al_conc_with_host_build(tmp_path):
+    """The wrapper's --un-conc / --al-conc / --un / --al work through `--passthrough` (bowtie2:567-620).  The reference
+    wrapper is run twice on the same pairs -- once over the reference binaries, once over our host-compiled worker standing in
+    as bowtie2-align-s/-l (test infrastructure; the product binary needs a GPU) -- and every output file must be identical."""
+    hs = os.path.join(ROOT, "tests", "hostsim", "hostsim")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", hs,
+                           os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    outs = {}
+    for tag in ("ref", "ours"):
+        d = tmp_path / tag
+        d.mkdir()
+        shutil.copy(WRAPPER, d / "bowtie2")
+        for n in ("bowtie2-align-s", "bowtie2-align-l"):
+            shutil.copy(ref_bin(n) if tag == "ref" else hs, d / n)
+        for mode, extra in (("pe", ["-1", os.path.join(GOLD, "pe_reads_1.fq"), "-2", os.path.join(GOLD, "pe_reads_2.fq"),
+                                     "--un-conc", str(d / "unc_%.fq"), "--al-conc", str(d / "alc_%.fq")]),
+                            ("se", ["-U", os.path.join(GOLD, "align_reads.fq"), "--un", str(d / "un.fq"), "--al", str(d / "al.fq"), "--no-unal"])):
+            p = subprocess.run(["perl", str(d / "bowtie2"), "--sensitive", "-x", os.path.join(GOLD, "tiny_s")] + extra + ["-S", str(d / (mode + ".sam"))],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-1000:]
+        outs[tag] = {f: [l for l in open(d / f).read().splitlines() if not l.startswith("@PG")] for f in sorted(os.listdir(d)) if f.endswith((".fq", ".sam"))}
+    assert set(outs["ref"]) == set(outs["ours"]) and len(outs["ref"]) == 8, sorted(outs["ours"])
+    for f in outs["ref"]:
+        assert outs["ref"][f] == outs["ours"][f], f
+        assert outs["ref"][f], f        # none of the files is empty in this case
