@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the worker source against the reference binaries (oracle/_ref): random genomes (repeats, N runs,
+low-complexity stretches), random unpaired or paired reads (substitutions, indels, junk and mis-oriented mates), a random
+subset of options, either index width.  Runs the host-compiled worker (tests/hostsim -- build it first, e.g. by running
+pytest tests/test_hostsim_golden.py) and the reference on the same input and logs every case whose SAM differs and that
+our side did not flag as over a capacity limit.  usage: fuzz_vs_reference.py <seed> <iterations>   (scratch under /tmp/fuzz)"""
+import sys, os, subprocess, random, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bt2test import ref_bin, write_fasta, write_fastq, build_index, revcomp
+HS = os.environ.get('BT2G_HOSTSIM', os.path.join(ROOT, 'tests', 'hostsim', 'hostsim'))
+os.makedirs('/tmp/fuzz', exist_ok=True)
+seed0=int(sys.argv[1]); nit=int(sys.argv[2])
+out=open('/tmp/fuzz/fail_%d.log'%seed0,'w')
+def rnd_genome(rnd):
+    nref=rnd.randrange(1,4)
+    refs=[]
+    elem="".join(rnd.choice("ACGT") for _ in range(rnd.randrange(60,400)))
+    for i in range(nref):
+        L=rnd.randrange(300,20000)
+        s=[rnd.choice("ACGT") for _ in range(L)]
+        for _ in range(rnd.randrange(0,6)):
+            p=rnd.randrange(0,max(1,L-len(elem)-1))
+            s[p:p+len(elem)]=[c if rnd.random()>0.03 else rnd.choice("ACGT") for c in elem]
+        if rnd.random()<0.3:
+            p=rnd.randrange(0,L-50); s[p:p+rnd.randrange(5,40)]=list("N"*rnd.randrange(5,40))
+        if rnd.random()<0.3:
+            p=rnd.randrange(0,L-100); s[p:p+80]=list(("AC" if rnd.random()<0.5 else "A")*80)[:80]
+        refs.append(("c%d"%i,"".join(s)))
+    return refs
+def mut(rnd,s,sub,indel):
+    o=[]
+    for c in s:
+        r=rnd.random()
+        if r<sub: o.append(rnd.choice("ACGTN" if rnd.random()<0.05 else "ACGT"))
+        elif r<sub+indel: continue
+        elif r<sub+2*indel: o.append(c); o.append(rnd.choice("ACGT"))
+        else: o.append(c)
+    return "".join(o) or "A"
+POOL_SE=[[],["--local"],["-k","2"],["-k","7"],["-a"],["--very-fast"],["--very-sensitive"],["--fast-local"],["--very-sensitive-local"],["-N","1"],["-L","12"],["-L","28"],["-i","C,5,0"],["-i","L,2,0.1"],
+ ["--ignore-quals"],["--mp","4,1"],["--np","3"],["--rdg","3,2"],["--rfg","7,4"],["--score-min","L,-3,-0.3"],["--n-ceil","L,2,0.3"],["--nofw"],["--norc"],["--no-1mm-upfront"],["--no-exact-upfront"],
+ ["-D","4"],["-R","1"],["-R","3"],["--gbar","8"],["--dpad","6"],["-5","3"],["-3","4"],["--overhang"],["--seed","17"],["-M","2"],["--xeq"],["--no-unal"]]
+POOL_PE=[["--ff"],["--rf"],["--no-mixed"],["--no-discordant"],["--dovetail"],["--no-contain"],["--no-overlap"],["-I","80"],["-X","300"],["-X","700"]]
+def conflicts(a):
+    flat=" ".join(" ".join(x) for x in a)
+    if "--local" in flat or "-local" in flat:
+        if "--score-min" in flat: return True
+    if flat.count("-k ")+flat.count("-a")+flat.count("-M ")>1: return True
+    if ("--very" in flat)+("--fast-local" in flat)>1: return True
+    if "-5" in flat and "-3" in flat: pass
+    return False
+nfail=0; t0=time.time()
+for it in range(nit):
+    rnd=random.Random(seed0*100003+it)
+    d='/tmp/fuzz/w%d'%seed0; os.makedirs(d,exist_ok=True)
+    refs=rnd_genome(rnd)
+    large=rnd.random()<0.3
+    fa=d+"/g.fa"; base=d+"/g"
+    for f in os.listdir(d):
+        if f.startswith("g."): os.unlink(d+"/"+f)
+    write_fasta(fa,refs); build_index(fa,base,large)
+    paired=rnd.random()<0.5
+    n=rnd.randrange(20,120)
+    sub=rnd.choice([0.0,0.01,0.03,0.08]); indel=rnd.choice([0.0,0.002,0.01])
+    opts=[]
+    for _ in range(rnd.randrange(0,4)):
+        o=rnd.choice(POOL_SE+(POOL_PE if paired else []))
+        if o not in opts: opts.append(o)
+    if conflicts(opts): continue
+    args=[x for o in opts for x in o]
+    exe=ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
+    if paired:
+        r1=[];r2=[]
+        for i in range(n):
+            _,s=refs[rnd.randrange(len(refs))]
+            L1=rnd.randrange(20,200); L2=rnd.randrange(20,200)
+            frag=max(int(rnd.gauss(250,60)),max(L1,L2)+1); frag=min(frag,len(s)-1)
+            if frag<max(L1,L2)+1: L1=L2=max(5,frag-1)
+            p=rnd.randrange(0,len(s)-frag) if len(s)>frag else 0
+            f=s[p:p+frag]; m1=f[:L1]; m2=revcomp(f[-L2:])
+            k=rnd.random()
+            if k>0.93: m2=revcomp(m2)
+            elif k>0.86: m2="".join(rnd.choice("ACGT") for _ in range(L2))
+            if rnd.random()<0.5: m1,m2=m2,m1
+            m1=mut(rnd,m1,sub,indel); m2=mut(rnd,m2,sub,indel)
+            r1.append(("p%d/1"%i,m1,"".join(rnd.choice("IIIH?5#") for _ in m1))); r2.append(("p%d/2"%i,m2,"".join(rnd.choice("IIIH?5#") for _ in m2)))
+        write_fastq(d+"/1.fq",r1); write_fastq(d+"/2.fq",r2)
+        inp=["-1",d+"/1.fq","-2",d+"/2.fq"]
+    else:
+        rs=[]
+        for i in range(n):
+            _,s=refs[rnd.randrange(len(refs))]
+            L=rnd.randrange(1,260); L=min(L,len(s)-1)
+            p=rnd.randrange(0,len(s)-L); m=s[p:p+L]
+            if rnd.random()<0.5: m=revcomp(m)
+            if rnd.random()<0.05: m="".join(rnd.choice("ACGT") for _ in range(L))
+            m=mut(rnd,m,sub,indel)
+            rs.append(("r%d"%i,m,"".join(rnd.choice("IIIH?5#") for _ in m)))
+        write_fastq(d+"/r.fq",rs); inp=["-U",d+"/r.fq"]
+    a=subprocess.run([exe]+args+["-x",base]+inp+["-p","2","--reorder"],capture_output=True,text=True)
+    b=subprocess.run([HS]+args+["-x",base]+inp,capture_output=True,text=True)
+    body=lambda t:[l for l in t.splitlines() if not l.startswith("@PG")]
+    if a.returncode!=0: continue
+    warn="Warning: " in b.stderr and ("overflow" in b.stderr or "exceeded" in b.stderr)
+    if body(a.stdout)!=body(b.stdout) and not warn:
+        nfail+=1
+        keep='/tmp/fuzz/case_%d_%d'%(seed0,it); os.system("rm -rf %s; cp -r %s %s"%(keep,d,keep))
+        out.write(json.dumps({"it":it,"args":args,"paired":paired,"large":large,"rc":b.returncode,"err":b.stderr[-300:]})+"\n"); out.flush()
+print("seed",seed0,"iters",nit,"fails",nfail,"%.0fs"%(time.time()-t0))
