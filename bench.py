@@ -208,6 +208,36 @@ def pmc_traffic(kernel, reads_per_launch):
         return None, None
 
 
+def synth_pairs_gpu(chroms, npairs, length, seed, device):
+    """Pairs for --paired: fragment length N(300,30) clipped to [length+1, 450], mate 1 = fragment start (forward), mate 2 = reverse
+    complement of the fragment end, 1 % substitutions, half of the pairs with the roles of the mates swapped.  Returns [2*npairs, length]."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lens = torch.tensor([len(c) for c in chroms], dtype=torch.int64)
+    starts = torch.cumsum(lens, 0) - lens
+    genome = torch.cat([torch.from_numpy(c) for c in chroms]).to(device)
+    ci = torch.randint(0, len(chroms), (npairs,), generator=g, device=device)
+    clen = lens.to(device)[ci]
+    frag = (300.0 + 30.0 * torch.randn(npairs, generator=g, device=device)).long().clamp(length + 1, 450)
+    pos = (torch.rand(npairs, generator=g, device=device, dtype=torch.float64) * (clen - 460).double()).long()
+    gpos = starts.to(device)[ci] + pos
+    idx = torch.arange(length, device=device).unsqueeze(0).expand(npairs, length)
+    m1 = genome[gpos.unsqueeze(1) + idx]
+    m2 = (3 - genome[(gpos + frag - length).unsqueeze(1) + idx].clamp(max=3)).flip(1)
+    both = torch.stack([m1, m2], dim=1)                               # [npairs, 2, length]
+    swap = torch.rand(npairs, generator=g, device=device) < 0.5
+    both = torch.where(swap.view(-1, 1, 1), both.flip(1), both)
+    seq = both.reshape(2 * npairs, length).to(torch.uint8)
+    rnd_base = torch.randint(0, 4, seq.shape, generator=g, device=device, dtype=torch.uint8)
+    sub = torch.rand(seq.shape, generator=g, device=device) < 0.01
+    seq = torch.where(sub & (seq < 4), (seq + 1 + rnd_base % 3) % 4, seq)
+    seq = torch.where(seq > 3, rnd_base, seq)
+    qtab = torch.tensor([ord(c) for c in "GGG?5-"], dtype=torch.uint8, device=device)
+    qual = qtab[torch.randint(0, 6, seq.shape, generator=g, device=device)]
+    return seq.contiguous(), qual.contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +250,8 @@ def main():
     ap.add_argument("--cpu-repeat", type=int, default=int(os.environ.get("BT2_BENCH_CPU_REPEAT", "12")),
                     help="passes over the CPU sample, so that the reference runs for ~10 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--paired", action="store_true",
+                    help="measure the paired-end kernel instead: --reads/2 pairs of 2 x --readlen, fragments N(300,30), --fr (not the headline metric)")
     args = ap.parse_args()
 
     import torch
@@ -248,6 +280,10 @@ def main():
     # per-rank shard of reads (weak scaling: fixed reads per GPU)
     seq, qual = synth_reads_gpu(chroms, args.reads, args.readlen, shard.shard_seed(1000, rank), dev)
     n = args.reads
+    if args.paired:
+        # mates interleaved: read 2i = forward mate at the fragment start, read 2i+1 = reverse-complemented mate at its end
+        seq, qual = synth_pairs_gpu(chroms, n // 2, args.readlen, shard.shard_seed(2000, rank), dev)
+        n = seq.shape[0]
     off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * args.readlen)
     batch = b.ReadBatch(seq.view(-1), qual.view(-1), off, n)
 
@@ -261,6 +297,10 @@ def main():
                       khits=1, mhits=50, max_dp_streak=15, max_ug=300, max_dp=300, max_iters=400, n_seed_rounds=2,
                       seed_boost_thresh=300, tighten=3, maxhalf=15, nofw=0, norc=0, do_exact_upfront=1, do_1mm_upfront=1,
                       do_ungapped=1, do_extend=1, large_index=1 if info.off_size == 8 else 0)
+    if args.paired:
+        # default pair policy: --fr, -I 0 -X 500, mixed + discordant reporting, containment and overlap allowed (bt2_search.cpp:303-502)
+        P.paired, P.pe_policy, P.pe_maxfrag, P.pe_minfrag, P.pe_flags, P.max_mate_streak = 1, 3, 500, 0, 2 | 4 | 8 | 32 | 64 | 128, 10
+        interval = max(1, int(interval * 1.2 + 0.5))       # both mates pass their filters (bt2_search.cpp:3427-3434)
     # per-read parameters as the host derives them (minsc = (long)(-0.6 + -0.6*len), nceil = 0.15*len; seeds from read content)
     minsc = int(-0.6 + -0.6 * args.readlen)
     rp = np.zeros(n, dtype=[("minsc", "<i4"), ("interval", "<i4"), ("nceil", "<i4"), ("seedlen", "<i4"), ("seed", "<u4"), ("filt", "<u4")])
@@ -337,7 +377,8 @@ def main():
         fm_achieved = fm_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic("k_align_reads", n)
         res = {
-            "metric": "aligned reads/sec (whole node), 150 bp SE, synthetic genome (hg38 unavailable offline)",
+            "metric": ("aligned reads/sec (whole node), 2 x 150 bp PE (mates counted as reads), synthetic genome" if args.paired else
+                       "aligned reads/sec (whole node), 150 bp SE, synthetic genome (hg38 unavailable offline)"),
             "value": shard.throughput(world, n, steps, dt),
             "unit": "reads/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -374,7 +415,7 @@ def main():
                                         "achieved": fm_achieved, "unit": "GB/s", "frac": fm_achieved / HBM_PEAK_GBS}},
         }
         cb = None
-        if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
+        if not args.no_cpu_baseline and world == 1 and not args.paired:      # reported at N=1 only (the paired mode is a kernel study, no CPU leg)
             cb = cpu_baseline(base, seq, qual, min(args.cpu_sample, n), threads, args.cpu_repeat)
         res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)

@@ -32,7 +32,8 @@ BLOCK = 1 << 16   # reads per dealt block: big enough to fill the persistent wav
 
 def blocks_of(n_reads, rank, world, block=BLOCK):
     """Strong-scaling partition of reads [0, n_reads): contiguous blocks dealt round-robin to the ranks
-    (equivalent to the reference's -s/-u windows).  Returns [(begin, end), ...] for this rank."""
+    (equivalent to the reference's -s/-u windows).  Returns [(begin, end), ...] for this rank.
+    Paired batches hold the mates interleaved (read 2i, 2i+1): with an even `block` (the default is) a pair is never split."""
     out = []
     nblocks = (n_reads + block - 1) // block
     for b in range(rank, nblocks, world):

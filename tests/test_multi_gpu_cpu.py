@@ -88,3 +88,20 @@ def test_two_ranks_gloo(tmp_path):
     assert outs[0]["seed"] != outs[1]["seed"]
     assert outs[0]["value"] == 2 * 1000 * 5 / 2.0                     # whole-job throughput over the slowest rank
     assert outs[0]["in_order"] and outs[0]["from_both"] == [0, 1]
+
+
+def test_blocks_keep_mates_together():
+    """Paired batches are interleaved (mate 1 at even, mate 2 at odd read indexes): every dealt block starts and ends on a pair."""
+    from bowtie2_amd import shard
+    n = 2 * 123457
+    seen = 0
+    for world in (1, 2, 3, 8):
+        cover = []
+        for rank in range(world):
+            for b, e in shard.blocks_of(n, rank, world):
+                assert b % 2 == 0 and e % 2 == 0
+                cover.append((b, e))
+        cover.sort()
+        assert cover[0][0] == 0 and cover[-1][1] == n and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+        seen += 1
+    assert seen == 4
