@@ -5,6 +5,7 @@
 #define BT2G_CLI_HPP_
 
 #include <cstdio>
+#include <sys/types.h>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -18,6 +19,7 @@ struct CliExtra {
 	bool metrics = false;          // --met: per-read work counters on stderr (test aid)
 	bool arg_desc = false;         // --arg-desc
 	size_t batch_reads = 1u << 18;
+	bool version = false, help = false;   // --version / -h
 	bool allow_paired = false;     // set by the caller before parsing: this front end can run pairs
 };
 
@@ -79,6 +81,23 @@ inline void print_arg_desc() {
 			if (*p == 0) break;
 		} else tok.push_back(*p);
 	}
+}
+
+// --version in the reference's layout (bt2_search.cpp:5296-5320: "<argv0> version <v>" first, which is what wrappers and report
+// tools parse); the version is the reference release whose behaviour this build reproduces
+inline void print_version(const char* argv0) {
+	printf("%s version 2.5.5\n64-bit\nBuilt for AMD MI355X (gfx950): bowtie2_amd, the multiseed hot path on the device; no CPU alignment path\n", argv0);
+	printf("Sizeof {int, long, long long, void*, size_t, off_t}: {%zu, %zu, %zu, %zu, %zu, %zu}\n", sizeof(int), sizeof(long), sizeof(long long), sizeof(void*), sizeof(size_t), sizeof(off_t));
+}
+inline void print_usage(const char* argv0) {
+	printf("Usage: %s [options] -x <bt2-idx> {-1 <m1> -2 <m2> | -U <r> | --interleaved <i> | --tab5/--tab6 <f>} [-S <sam>]\n", argv0);
+	printf("  inputs: -q -f -r -c --qseq (plain or gzipped, comma-separated lists)   -s/-u -5/-3 --trim-to --phred33/--phred64\n"
+	       "  presets: --very-fast --fast --sensitive --very-sensitive (and -local)   --end-to-end | --local\n"
+	       "  alignment: -N 0|1 -L -i --n-ceil --dpad --gbar --ignore-quals --nofw --norc --no-1mm-upfront --no-exact-upfront -d --overhang\n"
+	       "  scoring: --ma --mp --np --rdg --rfg --score-min --policy --bwa-sw-like      effort: -D -R     reporting: -k <=64 | -a | -M\n"
+	       "  pairs: -I -X --fr/--rf/--ff --no-mixed --no-discordant --dovetail --no-contain --no-overlap\n"
+	       "  SAM: --no-unal --no-hd --no-sq --rg-id --rg --omit-sec-seq --sam-no-qname-trunc --xeq --passthrough   other: -p --reorder -t --quiet --seed --qc-filter --gpu a,b --batch n\n"
+	       "  Options of bowtie2 outside this list are refused, never approximated.\n");
 }
 
 // One ';'-separated TAG=VALUE list in the reference's internal policy syntax (--policy; SeedAlignmentPolicy::parseString,
@@ -152,6 +171,8 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		std::vector<int> iv;
 		if (a == "--wrapper") { need(); }
 		else if (a == "--arg-desc") ex.arg_desc = true;
+		else if (a == "--version") { ex.version = true; return ""; }
+		else if (a == "-h" || a == "--help") { ex.help = true; return ""; }
 		else if (a == "-x") opt.index_base = need();
 		else if (a == "-U") opt.reads_file = need();
 		else if (a == "-S" || a == "--output") opt.out_file = need();

@@ -67,6 +67,10 @@ int main(int argc, char** argv) {
 	{
 		const std::string err = parse_cli(argc, argv, opt, ex);
 		if (ex.arg_desc) { print_arg_desc(); return 0; }
+	if (ex.version) { print_version(argv[0]); return 0; }
+	if (ex.help) { print_usage(argv[0]); return 0; }
+		if (ex.version) { print_version(argv[0]); return 0; }
+		if (ex.help) { print_usage(argv[0]); return 0; }
 		if (!err.empty()) die(err, 1);
 	}
 	const bool metrics = ex.metrics;

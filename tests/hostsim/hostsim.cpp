@@ -344,6 +344,8 @@ int main(int argc, char** argv) {
 	ex.allow_paired = true;
 	const std::string perr = parse_cli(argc, argv, opt, ex);
 	if (ex.arg_desc) { print_arg_desc(); return 0; }
+	if (ex.version) { print_version(argv[0]); return 0; }
+	if (ex.help) { print_usage(argv[0]); return 0; }
 	if (!perr.empty()) { fprintf(stderr, "%s\n", perr.c_str()); return 1; }
 	const bool metrics = ex.metrics;
 	opt.cmdline = "hostsim";
