@@ -288,11 +288,12 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--ma") { opt.ma = atoi(need().c_str()); opt.set_ma = true; }
 		else if (a == "--mp") {
 			if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "expected 1 or 2 comma-separated arguments to --mp";
-			else { opt.mp_max = iv[0]; opt.mp_min = iv.size() > 1 ? iv[1] : 2; if (opt.mp_min > opt.mp_max) err = "Maximum mismatch penalty is less than minimum penalty"; }
+			else { opt.mp_max = iv[0]; opt.mp_min = iv.size() > 1 ? iv[1] : 2; opt.mm_const = false;    // "MMP=Q,max[,min]" appended to the policy string (bt2_search.cpp:1591-1608): a later --mp undoes an earlier MMP=C
+			       if (opt.mp_min > opt.mp_max) err = "Maximum mismatch penalty is less than minimum penalty"; }
 		}
 		else if (a == "--np") opt.np = atoi(need().c_str());
-		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; if (iv.size() > 1) opt.rdg_linear = iv[1]; } }
-		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; if (iv.size() > 1) opt.rfg_linear = iv[1]; } }
+		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; opt.rdg_linear = iv.size() > 1 ? iv[1] : 3; } }   // a missing extension penalty falls back to the default (aligner_seed_policy.cpp:490-500)
+		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; opt.rfg_linear = iv.size() > 1 ? iv[1] : 3; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
 		else if (a == "-b" ||
 		         a == "-F" || a == "--int-quals" || a == "--solexa-quals")
