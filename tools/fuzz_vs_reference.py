@@ -11,15 +11,16 @@ from bt2test import ref_bin, write_fasta, write_fastq, build_index, revcomp
 HS = os.environ.get('BT2G_HOSTSIM', os.path.join(ROOT, 'tests', 'hostsim', 'hostsim'))
 os.makedirs('/tmp/fuzz', exist_ok=True)
 seed0=int(sys.argv[1]); nit=int(sys.argv[2])
+MODE=int(os.environ.get('FUZZ_MODE','1'))     # 2: small repeat-dense genomes, short reads, more options per case
 out=open('/tmp/fuzz/fail_%d.log'%seed0,'w')
 def rnd_genome(rnd):
     nref=rnd.randrange(1,4)
     refs=[]
-    elem="".join(rnd.choice("ACGT") for _ in range(rnd.randrange(60,400)))
+    elem="".join(rnd.choice("ACGT") for _ in range(rnd.randrange(60,400) if MODE==1 else rnd.randrange(20,150)))
     for i in range(nref):
-        L=rnd.randrange(300,20000)
+        L=rnd.randrange(300,20000) if MODE==1 else rnd.randrange(200,3000)
         s=[rnd.choice("ACGT") for _ in range(L)]
-        for _ in range(rnd.randrange(0,6)):
+        for _ in range(rnd.randrange(0,6) if MODE==1 else rnd.randrange(3,12)):
             p=rnd.randrange(0,max(1,L-len(elem)-1))
             s[p:p+len(elem)]=[c if rnd.random()>0.03 else rnd.choice("ACGT") for c in elem]
         if rnd.random()<0.3:
@@ -68,7 +69,7 @@ for it in range(nit):
     n=rnd.randrange(20,120)
     sub=rnd.choice([0.0,0.01,0.03,0.08]); indel=rnd.choice([0.0,0.002,0.01])
     opts=[]
-    for _ in range(rnd.randrange(0,4)):
+    for _ in range(rnd.randrange(0,4) if MODE==1 else rnd.randrange(1,7)):
         o=rnd.choice(POOL_SE+(POOL_PE if paired else []))
         if o not in opts: opts.append(o)
     if conflicts(opts): continue
@@ -78,8 +79,8 @@ for it in range(nit):
         r1=[];r2=[]
         for i in range(n):
             _,s=refs[rnd.randrange(len(refs))]
-            L1=rnd.randrange(20,200); L2=rnd.randrange(20,200)
-            frag=max(int(rnd.gauss(250,60)),max(L1,L2)+1); frag=min(frag,len(s)-1)
+            L1=rnd.randrange(20,200) if MODE==1 else rnd.randrange(12,90); L2=rnd.randrange(20,200) if MODE==1 else rnd.randrange(12,90)
+            frag=max(int(rnd.gauss(250,60) if MODE==1 else rnd.gauss(120,40)),max(L1,L2)+1); frag=min(frag,len(s)-1)
             if frag<max(L1,L2)+1: L1=L2=max(5,frag-1)
             p=rnd.randrange(0,len(s)-frag) if len(s)>frag else 0
             f=s[p:p+frag]; m1=f[:L1]; m2=revcomp(f[-L2:])
@@ -95,7 +96,7 @@ for it in range(nit):
         rs=[]
         for i in range(n):
             _,s=refs[rnd.randrange(len(refs))]
-            L=rnd.randrange(1,260); L=min(L,len(s)-1)
+            L=rnd.randrange(1,260) if MODE==1 else rnd.randrange(1,80); L=min(L,len(s)-1)
             p=rnd.randrange(0,len(s)-L); m=s[p:p+L]
             if rnd.random()<0.5: m=revcomp(m)
             if rnd.random()<0.05: m="".join(rnd.choice("ACGT") for _ in range(L))
