@@ -181,6 +181,14 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "-r") opt.format = 2;
 		else if (a == "-c") opt.format = 3;
 		else if (a == "--qseq") opt.format = 5;
+		else if (a == "-F") {
+			// -F k:<int>,i:<int> (bt2_search.cpp:1104-1112)
+			const std::string v = need();
+			int k = 0, iv2 = 0;
+			if (sscanf(v.c_str(), "%d,%d", &k, &iv2) != 2) err = "-F expects <length>,<interval> (the aligner binary parses a plain pair, bt2_search.cpp:1109)";
+			else if (k < 1 || k > 1024 || iv2 < 1) err = "-F: k must be in [1, 1024] and i positive";
+			else { opt.format = 6; opt.fc_len = k; opt.fc_freq = iv2; }
+		}
 		else if (a == "--qc-filter") opt.qc_filter = true;
 		else if (a == "--sam-no-qname-trunc") opt.sam_no_qname_trunc = true;
 		else if (a == "--tab5" || a == "--tab6") { opt.format = 4; opt.reads_file = need(); }
@@ -296,7 +304,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; opt.rfg_linear = iv.size() > 1 ? iv[1] : 3; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
 		else if (a == "-b" ||
-		         a == "-F" || a == "--int-quals" || a == "--solexa-quals")
+		         a == "--int-quals" || a == "--solexa-quals")
 			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -k <= 64)";
 		else return "unsupported option " + a;
 		if (!err.empty()) return err;

@@ -69,7 +69,8 @@ struct Options {
 	bool nofw = false, norc = false;
 	bool sam_no_qname_trunc = false;
 	bool qc_filter = false, ignore_quals = false, no_1mm_upfront = false, xeq = false, omit_sec_seq = false, phred64 = false;
-	int format = 0;               // 0 FASTQ, 1 FASTA (-f), 2 raw (-r)
+	int format = 0;               // 0 FASTQ, 1 FASTA (-f), 2 raw (-r), 3 -c, 4 tab5/6, 5 qseq, 6 FASTA-continuous (-F)
+	int fc_len = 0, fc_freq = 1;  // -F k:<len>,i:<freq>
 	int trim5 = 0, trim3 = 0;
 	int trim_to_side = 3, trim_to_len = -1;   // --trim-to [3:|5:]<len>
 	int mp_max = 6, mp_min = 2, np = 1, rdg_const = 5, rdg_linear = 3, rfg_const = 5, rfg_linear = 3, gbar = 4, maxhalf = 15;

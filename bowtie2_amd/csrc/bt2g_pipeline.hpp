@@ -341,6 +341,43 @@ public:
 				r.seq_off = arena_.size(); r.seq_len = sq.size(); arena_.append(sq);
 				r.qual_off = arena_.size(); r.qual_len = ql.size(); arena_.append(ql); r.has_qual = true;
 				r.filter = fl[0];
+			} else if (opt_.format == 6) {             // -F k:<len>,i:<freq>: every <freq>-th <len>-mer of a FASTA file (FastaContinuousPatternSource, pat.cpp:913-1036)
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				bool emitted = false;
+				while (!emitted) {
+					if (fc_pos_ >= fc_line_.size()) {
+						if (!src_.next(p, n)) break;
+						if (n && p[0] == '>') {
+							size_t k = 1;
+							fc_prefix_.clear();
+							while (k < n && !isspace((unsigned char)p[k])) fc_prefix_.push_back(p[k++]);
+							fc_prefix_.push_back('_');
+							fc_eat_ = (size_t)opt_.fc_len - 1; fc_beginning_ = true; fc_win_.clear(); fc_last_ = fc_cur_;
+							fc_line_.clear(); fc_pos_ = 0;
+							continue;
+						}
+						fc_line_.assign(p, n); fc_pos_ = 0;
+						continue;
+					}
+					const unsigned char ch = (unsigned char)fc_line_[fc_pos_++];
+					int cat = 0;
+					switch (toupper(ch)) {
+						case 'A': case 'C': case 'G': case 'T': cat = 1; break;
+						case 'B': case 'D': case 'H': case 'K': case 'M': case 'N': case 'R': case 'S': case 'V': case 'W': case 'X': case 'Y': case '-': cat = 2; break;
+						default: cat = 0;
+					}
+					if (cat == 0) continue;
+					fc_win_.push_back(cat >= 2 ? 'N' : (char)ch);
+					if (fc_win_.size() > (size_t)opt_.fc_len) fc_win_.erase(0, fc_win_.size() - (size_t)opt_.fc_len);
+					if (fc_eat_ > 0) { fc_eat_--; if (!fc_beginning_) fc_cur_++; continue; }
+					const std::string nm = fc_prefix_ + std::to_string(fc_cur_ - fc_last_);
+					r.name_off = arena_.size(); r.name_len = nm.size(); arena_.append(nm);
+					r.seq_off = arena_.size(); r.seq_len = fc_win_.size(); arena_.append(fc_win_);
+					if (pt) { orig_ += nm; orig_.push_back('\t'); orig_ += fc_win_; }
+					fc_eat_ = (size_t)opt_.fc_freq - 1; fc_cur_++; fc_beginning_ = false;
+					emitted = true;
+				}
+				if (!emitted) { b.last = true; break; }
 			} else {                                   // raw: one sequence per line, named by its index
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
@@ -438,6 +475,8 @@ public:
 	}
 private:
 	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; };
+	std::string fc_line_, fc_prefix_, fc_win_;     // -F state
+	size_t fc_pos_ = 0, fc_eat_ = 0; uint64_t fc_cur_ = 0, fc_last_ = 0; bool fc_beginning_ = true;
 	std::string orig_, pending_raw_;   // --passthrough: the records' original text (Read::readOrigBuf)
 	LineSource src_;
 	const Options& opt_;

@@ -17,7 +17,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 SRC = "/root/reference/scripts/test/simple_tests.pl"
 PAIRED_KEYS = {"mate1s", "mate2s", "pairhits", "pairhits_orig", "fastq1", "fastq2", "fasta1", "fasta2", "raw1", "raw2", "qseq1", "qseq2",
                "cline_reads1", "cline_reads2", "tabbed1", "tabbed2", "paired", "mate1fw", "mate2fw", "tlen_map", "pnext_map", "rnext_map"}
-SKIP_KEYS = {"cont_fasta_reads", "should_abort"}
+SKIP_KEYS = {"should_abort"}
 
 
 def dump_cases():
@@ -51,6 +51,8 @@ def case_inputs(c, fw):
         return "-q", "".join(recs)
     if not fw:
         return None                     # file-based cases run forward only (simple_tests.pl: `next unless $fw`)
+    if c.get("cont_fasta_reads") is not None:
+        return "", c["cont_fasta_reads"]       # the case's own arguments carry -F <len>,<freq>
     for key, flag in (("fastq", "-q"), ("fasta", "-f"), ("raw", "-r"), ("tabbed", "--tab5"), ("cline_reads", "-c"), ("qseq", "--qseq")):
         if c.get(key) is not None:
             return flag, c[key]        # --tab5 files may hold paired (5-field) records
@@ -119,7 +121,7 @@ def run_ref(exe, large, fa_text, flag, payload, args, tmp):
     else:
         rf = os.path.join(tmp, "reads.txt")
         open(rf, "w").write(payload)
-        cmd += ([flag, rf] if flag == "--tab5" else [flag, "-U", rf])
+        cmd += ([flag, rf] if flag == "--tab5" else ([flag, "-U", rf] if flag else ["-U", rf]))
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     if p.returncode != 0:
         return None

@@ -28,7 +28,7 @@ with tempfile.TemporaryDirectory() as tmp:
             elif rec["flag"] == "-c": cmd += ["-c", "-U", rec["input"].strip()]
             else:
                 open(tmp + "/r", "w").write(rec["input"])
-                cmd += ([rec["flag"], tmp + "/r"] if rec["flag"] == "--tab5" else [rec["flag"], "-U", tmp + "/r"])
+                cmd += ([rec["flag"], tmp + "/r"] if rec["flag"] == "--tab5" else ([rec["flag"], "-U", tmp + "/r"] if rec["flag"] else ["-U", tmp + "/r"]))
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
             got = [l for l in p.stdout.splitlines() if not l.startswith("@PG")]
             n += 1
