@@ -130,8 +130,10 @@ inline std::string apply_policy_string(Options& opt, const std::string& pol) {
 		}
 		else if (tag == "NP") {
 			if (c.size() != 1) return "NP: RHS must have 1 token";
-			if (c[0][0] != 'C') return "NP=" + c[0] + " is not supported by this build (constant only)";
-			opt.np = atoi(c[0].c_str() + 1);
+			// NP=Q keeps the current constant: the N table is built with min = max = penN, so the quality model degenerates (scoring.h:113-119)
+			if (c[0][0] == 'Q') {}
+			else if (c[0][0] != 'C') return "NP=" + c[0] + " is not supported by this build (constant or Q only)";
+			else opt.np = atoi(c[0].c_str() + 1);
 		}
 		else if (tag == "RDG") { opt.rdg_const = atoi(c[0].c_str()); opt.rdg_linear = c.size() >= 2 ? atoi(c[1].c_str()) : 3; }
 		else if (tag == "RFG") { opt.rfg_const = atoi(c[0].c_str()); opt.rfg_linear = c.size() >= 2 ? atoi(c[1].c_str()) : 3; }

@@ -8,6 +8,7 @@ records the SAM they print.  tests/test_simple_tests.py then demands the same SA
 Writes tests/golden/simple_tests.json.  Needs /root/reference and oracle/_ref (run where the reference exists)."""
 import json
 import os
+import shlex
 import subprocess
 import sys
 import tempfile
@@ -136,7 +137,8 @@ def main():
         if SKIP_KEYS & set(c):
             skipped += 1
             continue
-        args = (c.get("args") or "").split() + ["--quiet"] + (c["report"].split() if c.get("report") else ["-a"])
+        # the Perl harness hands the argument string to sh: quotes group, and inside double quotes a backslash before ";" stays
+        args = shlex.split(c.get("args") or "") + ["--quiet"] + (shlex.split(c["report"]) if c.get("report") else ["-a"])
         fa_text = "".join(">%d\n%s\n" % (i, s) for i, s in enumerate(c["ref"]))
         # a paired case given as one --tab5 file goes through the single-file path below (pair policy arguments appended)
         tab_only = c.get("tabbed") is not None and not any(c.get(k) is not None for k in ("mate1s", "fastq1", "fasta1", "raw1", "cline_reads1", "reads", "fastq", "fasta", "raw", "cline_reads"))
