@@ -86,7 +86,7 @@ def pair_inputs(c, fw):
         return "-q", f1, f2, extra
     if not fw:
         return None
-    for key, flag in (("fastq", "-q"), ("fasta", "-f"), ("raw", "-r"), ("cline_reads", "-c")):
+    for key, flag in (("fastq", "-q"), ("fasta", "-f"), ("raw", "-r"), ("cline_reads", "-c"), ("qseq", "--qseq")):
         if c.get(key + "1") is not None and c.get(key + "2") is not None:
             return flag, c[key + "1"], c[key + "2"], extra
     return None
@@ -146,7 +146,7 @@ def main():
             args = args + ["--" + ("f" if c.get("mate1fw", 1) else "r") + ("f" if c.get("mate2fw", 0) else "r")]
         if (PAIRED_KEYS & set(c)) and not tab_only:
             # paired cases: mate lists (forward and role-swapped) or mate files (forward only)
-            if any(c.get(k) is not None for k in ("tabbed1", "tabbed2", "qseq1", "qseq2", "tabbed", "reads", "fastq", "fasta", "raw", "cline_reads")):
+            if any(c.get(k) is not None for k in ("tabbed1", "tabbed2", "tabbed", "reads", "fastq", "fasta", "raw", "cline_reads")):
                 skipped += 1
                 continue
             n_here = 0
