@@ -92,7 +92,7 @@ private:
 
 // One batch travelling through the pipeline
 struct HostBatch {
-	struct Chunk { std::string names, seq, qual, orig; };   // arenas of 4096 reads: names stay here, seq/qual are copied to the packed arrays
+	struct Chunk { std::string names, seq, qual, orig, error; };   // arenas of 4096 reads: names stay here, seq/qual are copied to the packed arrays
 	std::vector<Chunk> chunks;
 	std::vector<ReadRec> reads;                       // views into `chunks` (names) and `seq`/`qual` (packed arrays)
 	std::vector<uint8_t> seq, qual;       // packed device arrays
@@ -247,7 +247,8 @@ public:
 			if (opt_.format == 0) {                    // FASTQ: 4-line records
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
-				if (!got || p[0] != '@') { b.last = true; break; }
+				if (!got) { b.last = true; break; }
+				if (p[0] != '@') { b.bad_input = "reads file does not look like a FASTQ file"; b.last = true; break; }   // pat.cpp:1070
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
 				if (pt) orig_.append(p, src_.last_raw_len());
@@ -261,7 +262,11 @@ public:
 				if (pt) orig_.append(p, src_.last_raw_len());
 			} else if (opt_.format == 1) {             // FASTA: '>' name, sequence possibly over several lines
 				bool got = true;
-				if (!have_pending_) { do { got = src_.next(p, n); } while (got && (n == 0 || p[0] != '>')); if (got) { pending_.assign(p, n); if (pt) pending_raw_.assign(p, src_.last_raw_len()); } }
+				if (!have_pending_) {
+					do { got = src_.next(p, n); } while (got && n == 0);
+					if (got && p[0] != '>') { b.bad_input = "reads file does not look like a FASTA file"; b.last = true; break; }   // pat.cpp:794
+					if (got) { pending_.assign(p, n); if (pt) pending_raw_.assign(p, src_.last_raw_len()); }
+				}
 				if (!got) { b.last = true; break; }
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				have_pending_ = false;
@@ -419,7 +424,13 @@ public:
 				if (r.has_qual) {
 					tqual.assign(arena_.data() + r.qual_off, r.qual_len);
 					if (opt_.phred64) for (char& q : tqual) q = (char)((int)q - 64 + 33 < 33 ? 33 : (int)q - 64 + 33);
-					if (tqual.size() > tseq.size()) tqual.resize(tseq.size());   // the reference errors out; we are lenient
+					// tooFewQualities / tooManyQualities (pat.cpp:1736-1748): the reference aborts, and so do we
+					if (tqual.size() != tseq.size() && ch.error.empty()) {
+						const std::string nm = r.name_len ? std::string(arena_.data() + r.name_off, r.name_len) : std::to_string(r.rdid);
+						ch.error = tqual.size() < tseq.size() ? "Read " + nm + " has more read characters than quality values."
+						                                      : "Read " + nm + " has more quality values than read characters.";
+					}
+					if (tqual.size() > tseq.size()) tqual.resize(tseq.size());
 					while (tqual.size() < tseq.size()) tqual.push_back('I');
 				} else tqual.assign(tseq.size(), 'I');
 				// -5/-3 hard trimming (pat.cpp:726-765)
@@ -471,6 +482,7 @@ public:
 			}
 		});
 		for (size_t i = 0; i < nrec; i++) if (rlen[i] > max_read_len) { b.too_long = b.reads[i].name.str(); break; }
+		if (b.bad_input.empty()) for (const HostBatch::Chunk& ch : b.chunks) if (!ch.error.empty()) { b.bad_input = ch.error; break; }
 		t_pack += tnow() - t2_;
 	}
 private:

@@ -64,6 +64,11 @@ def run_cases(exe_s, exe_l, tmp, thin=False):
                 cmd += ([rec["flag"], rf] if rec["flag"] == "--tab5" else ([rec["flag"], "-U", rf] if rec["flag"] else ["-U", rf]))
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
             got = [l for l in p.stdout.splitlines() if not l.startswith("@PG")]
+            if rec.get("abort"):        # malformed input or invalid arguments: the reference aborts, we must exit non-zero without alignments
+                compared += 1
+                if p.returncode == 0 or any(l and not l.startswith("@") for l in got):
+                    bad.append((rec["name"], rec["fw"], width, "should abort"))
+                continue
             if p.returncode != 0 and not got:
                 refused.append((rec["name"], " ".join(rec["args"]), p.stderr.strip().splitlines()[-1:] if p.stderr.strip() else ""))
                 continue
@@ -77,7 +82,7 @@ def run_cases(exe_s, exe_l, tmp, thin=False):
 def test_reference_regression_table_hostsim(hostsim, tmp_path):
     compared, refused, bad = run_cases(hostsim, hostsim, str(tmp_path))
     assert not bad, (len(bad), bad[:5])
-    assert compared >= 830 and len(refused) <= MAX_REFUSED, (compared, len(refused), refused[:5])
+    assert compared >= 855 and len(refused) <= MAX_REFUSED, (compared, len(refused), refused[:5])
 
 
 @pytest.mark.gpu

@@ -18,7 +18,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 SRC = "/root/reference/scripts/test/simple_tests.pl"
 PAIRED_KEYS = {"mate1s", "mate2s", "pairhits", "pairhits_orig", "fastq1", "fastq2", "fasta1", "fasta2", "raw1", "raw2", "qseq1", "qseq2",
                "cline_reads1", "cline_reads2", "tabbed1", "tabbed2", "paired", "mate1fw", "mate2fw", "tlen_map", "pnext_map", "rnext_map"}
-SKIP_KEYS = {"should_abort"}
+SKIP_KEYS = set()
 
 
 def dump_cases():
@@ -185,7 +185,11 @@ def main():
                     ok = False
                     break
                 rec["sam"]["l" if large else "s"] = sam
-            if ok:
+            if ok and not c.get("should_abort"):
+                out.append(rec)
+            elif not ok and c.get("should_abort"):
+                rec["sam"] = {}
+                rec["abort"] = True         # the reference refuses / aborts on this input: so must we
                 out.append(rec)
     dst = os.path.join(ROOT, "tests", "golden", "simple_tests.json")
     json.dump(out, open(dst, "w"), indent=0, sort_keys=True)
