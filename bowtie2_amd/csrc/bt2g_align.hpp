@@ -267,6 +267,7 @@ template <typename SP> BT2_HD int mm_penalty(const SP& P, int q) {
 		const float frac = (float)qq / 40.0f;
 		return P.mm_min + (int)(frac * (float)(P.mm_max - P.mm_min));
 	}
+	if (P.mm_type == 2) return q < 5 ? 0 : (q < 15 ? 10 : (q < 25 ? 20 : 30));   // COST_MODEL_ROUNDED_QUAL: qualRounds[] (qual.cpp:23)
 	return P.mm_max;
 }
 

@@ -120,13 +120,14 @@ inline std::string apply_policy_string(Options& opt, const std::string& pol) {
 		if (tag == "MA") { opt.ma = atoi(c[0].c_str()); opt.set_ma = true; }
 		else if (tag == "MMP") {
 			if (c.size() > 3) return "MMP: RHS must have at most 3 tokens";
-			if (c[0][0] == 'C') { opt.mp_max = opt.mp_min = atoi(c[0].c_str() + 1); opt.mm_const = true; }
+			if (c[0][0] == 'C') { opt.mp_max = opt.mp_min = atoi(c[0].c_str() + 1); opt.mm_const = true; opt.mm_rounded = false; }
+			else if (c[0][0] == 'R') { opt.mm_rounded = true; opt.mm_const = false; }
 			else if (c[0][0] == 'Q') {
 				opt.mp_max = c.size() >= 2 ? atoi(c[1].c_str()) : 6;
 				opt.mp_min = c.size() >= 3 ? atoi(c[2].c_str()) : 2;
 				if (opt.mp_min > opt.mp_max) return "Maximum mismatch penalty is less than minimum penalty";
-				opt.mm_const = false;
-			} else return "MMP=" + c[0] + " is not supported by this build (C or Q only)";
+				opt.mm_const = false; opt.mm_rounded = false;
+			} else return "MMP=" + c[0] + ": RHS must start with C, Q or R";
 		}
 		else if (tag == "NP") {
 			if (c.size() != 1) return "NP: RHS must have 1 token";
@@ -298,7 +299,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--ma") { opt.ma = atoi(need().c_str()); opt.set_ma = true; }
 		else if (a == "--mp") {
 			if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "expected 1 or 2 comma-separated arguments to --mp";
-			else { opt.mp_max = iv[0]; opt.mp_min = iv.size() > 1 ? iv[1] : 2; opt.mm_const = false;    // "MMP=Q,max[,min]" appended to the policy string (bt2_search.cpp:1591-1608): a later --mp undoes an earlier MMP=C
+			else { opt.mp_max = iv[0]; opt.mp_min = iv.size() > 1 ? iv[1] : 2; opt.mm_const = false; opt.mm_rounded = false;    // "MMP=Q,max[,min]" appended to the policy string (bt2_search.cpp:1591-1608): a later --mp undoes an earlier MMP=C
 			       if (opt.mp_min > opt.mp_max) err = "Maximum mismatch penalty is less than minimum penalty"; }
 		}
 		else if (a == "--np") opt.np = atoi(need().c_str());

@@ -219,6 +219,7 @@ BT2_HD void fm_one_mm_dir(const DevIndex<TOff>& ix, const bt2g_align_params& P, 
 						else if (rdc == j) pen = P.match_bonus;
 						else {
 							if (P.mm_type == 3) { const int qq = q < 40 ? q : 40; const float frac = (float)qq / 40.0f; pen = -(P.mm_min + (int)(frac * (float)(P.mm_max - P.mm_min))); }
+							else if (P.mm_type == 2) pen = -(q < 5 ? 0 : (q < 15 ? 10 : (q < 25 ? 20 : 30)));
 							else pen = -P.mm_max;
 						}
 					}

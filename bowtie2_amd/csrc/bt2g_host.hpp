@@ -77,6 +77,7 @@ struct Options {
 	int ma = 0;                   // match bonus (--ma; 2 in --local mode, always 0 end to end)
 	bool set_D = false, set_R = false, set_L = false, set_i = false, set_score_min = false, set_ma = false;
 	bool mm_const = false;        // MMP=Cxx: constant mismatch penalty (policy string / --bwa-sw-like)
+	bool mm_rounded = false;      // MMP=R: Maq-style rounded quality (0/10/20/30)
 	bool bwa_sw_like = false;     // --bwa-sw-like: minimum score = a*max(T, c*ln(len)) (bt2_search.cpp:3341-3350)
 	bool report_overhangs = false;
 	bool det_seeds = false;       // -d / --deterministic-seeds
@@ -131,7 +132,7 @@ struct Options {
 		// Scoring (scoring.h:60-170): type 3 = Phred-scaled mismatch penalty, anything else = constant mm_max;
 		// gap of length n costs const + n * linear
 		const bool cmm = ignore_quals || mm_const;
-		P.mm_type = cmm ? 1 : 3; P.mm_max = mp_max; P.mm_min = cmm ? mp_max : mp_min; P.n_pen = np;
+		P.mm_type = mm_rounded ? 2 : (cmm ? 1 : 3); P.mm_max = mp_max; P.mm_min = (cmm && !mm_rounded) ? mp_max : mp_min; P.n_pen = np;
 		P.rdgapo = rdg_const + rdg_linear; P.rdgape = rdg_linear; P.rfgapo = rfg_const + rfg_linear; P.rfgape = rfg_linear;
 		P.gapbar = gbar; P.match_bonus = local ? ma : 0;
 		P.khits = all_hits ? 64 : khits; P.mhits = (saw_k || all_hits) ? 0 : mhits; P.all_hits = all_hits ? 1 : 0; P.seed_mms = seed_mms; P.overhang = report_overhangs ? 1 : 0;

@@ -31,6 +31,7 @@ OPTION_SETS = [
     ["-d", "-a", "--no-exact-upfront", "--no-1mm-upfront"], ["-d", "-a", "--no-exact-upfront", "--no-1mm-upfront", "--local", "-N", "1", "-L", "20"],
     ["--no-exact-upfront"], ["--no-exact-upfront", "--no-1mm-upfront", "-k", "2"],
     ["--passthrough"], ["--passthrough", "-k", "3", "--local"],
+    ["--policy", "MMP=R"], ["--policy", "MMP=R;NP=Q", "--local", "-k", "2"],
 ]
 
 
