@@ -41,7 +41,7 @@ def mut(rnd,s,sub,indel):
 POOL_SE=[[],["--local"],["-k","2"],["-k","7"],["-a"],["--very-fast"],["--very-sensitive"],["--fast-local"],["--very-sensitive-local"],["-N","1"],["-L","12"],["-L","28"],["-i","C,5,0"],["-i","L,2,0.1"],
  ["--ignore-quals"],["--mp","4,1"],["--np","3"],["--rdg","3,2"],["--rfg","7,4"],["--score-min","L,-3,-0.3"],["--n-ceil","L,2,0.3"],["--nofw"],["--norc"],["--no-1mm-upfront"],["--no-exact-upfront"],
  ["-D","4"],["-R","1"],["-R","3"],["--gbar","8"],["--dpad","6"],["-5","3"],["-3","4"],["--overhang"],["--seed","17"],["-M","2"],["--xeq"],["--no-unal"],
- ["-d","-a","--no-exact-upfront","--no-1mm-upfront"],["--bwa-sw-like"],["--policy","MMP=C3;NP=C2"],["--trim-to","5:40"],["--trim-to","60"],["--passthrough"],["--omit-sec-seq","-k","3"],["--ma","3","--local"],["--qc-filter"],["--phred64"]]
+ ["-d","-a","--no-exact-upfront","--no-1mm-upfront"],["--bwa-sw-like"],["--policy","MMP=C3;NP=C2"],["--trim-to","5:40"],["--trim-to","60"],["--passthrough"],["--omit-sec-seq","-k","3"],["--ma","3","--local"],["--qc-filter"],["--phred64"],["--policy","MMP=R"],["--policy","NP=Q;RDG=4"],["-F","30,7"]]
 POOL_PE=[["--ff"],["--rf"],["--no-mixed"],["--no-discordant"],["--dovetail"],["--no-contain"],["--no-overlap"],["-I","80"],["-X","300"],["-X","700"]]
 def conflicts(a):
     flat=" ".join(" ".join(x) for x in a)
@@ -54,6 +54,8 @@ def conflicts(a):
     if "--bwa-sw-like" in flat and ("--ma" in flat or "--mp" in flat or "--rdg" in flat or "--rfg" in flat or "--score-min" in flat or "--policy" in flat): return True
     if "-d " in flat+" " and ("--no-1mm-upfront" not in flat): return True
     if "--phred64" in flat: return True      # the generated qualities are phred33
+    if "-F " in flat+" ": return True         # needs FASTA input (covered by the regression table)
+    if flat.count("--policy")>1: return True
     return False
 nfail=0; t0=time.time()
 for it in range(nit):
