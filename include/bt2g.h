@@ -183,12 +183,13 @@ int bt2g_sw_fill_ee_u8(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_prob
 /* ---- the fused per-read worker ------------------------------------------ */
 /*
  * Replaces `static void multiseedSearchWorker(void*)` (bt2_search.cpp:3094-4254) for a whole
- * batch of unpaired reads: exact end-to-end sweep, 1-mismatch end-to-end search, -N 0 / -N 1 seed
+ * batch of unpaired reads, or of pairs (params.paired: mates interleaved, see bt2g_align_params): exact end-to-end sweep, 1-mismatch end-to-end search, -N 0 / -N 1 seed
  * rounds, seed-hit prioritisation, offset resolution, DP framing, end-to-end and local SW fill (8/16-bit semantics),
  * backtrace, redundancy checks, -M/-k reporting state and the final selection -- one
  * wavefront per read, the reference's RNG draw order reproduced, so that the SAM written
  * from these records is byte-identical to the reference's.  Scope (rejected otherwise by the
- * host): unpaired reads <= BT2G_MAX_READ_LEN, at most 64 alignments per read.
+ * host): reads <= BT2G_MAX_READ_LEN, at most 64 alignments per read, opposite-mate windows <= 1100 columns (a read or pair
+ * over a limit comes back with status bit 0 set).
  */
 #define BT2G_MAX_READ_LEN 512
 #define BT2G_MAX_EDITS    200
