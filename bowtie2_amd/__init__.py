@@ -101,6 +101,16 @@ class Counters(C.Structure):
                 ("dp_cells", C.c_uint64), ("bwops", C.c_uint64)]
 
 
+class BuildParams(C.Structure):
+    _fields_ = [("large_index", C.c_int32), ("off_rate", C.c_int32), ("ftab_chars", C.c_int32), ("write_ref", C.c_int32), ("device", C.c_int32)]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [("len", C.c_uint64), ("n_pat", C.c_uint64), ("n_frag", C.c_uint64), ("rounds_fw", C.c_uint32), ("rounds_bw", C.c_uint32),
+                ("tied_fw", C.c_uint64), ("tied_bw", C.c_uint64), ("t_parse", C.c_double), ("t_fw", C.c_double), ("t_bw", C.c_double),
+                ("t_write", C.c_double)]
+
+
 # every symbol include/bt2g.h declares: (name, restype, argtypes)
 _vp = C.c_void_p
 ABI = [
@@ -122,6 +132,10 @@ ABI = [
     ("bt2g_align_result_stride", C.c_uint64, [C.c_uint32]),
     ("bt2g_align_batch", C.c_int, [_vp, C.POINTER(Reads), _vp, C.POINTER(AlignParams), C.c_uint32, _vp, _vp]),
     ("bt2g_results_pack", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    ("bt2g_build_params_default", None, [C.POINTER(BuildParams)]),
+    ("bt2g_index_build", C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.POINTER(BuildParams), C.POINTER(BuildStats)]),
+    ("bt2g_index_build_mem", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_char_p,
+                                       C.POINTER(BuildParams), C.POINTER(BuildStats)]),
 ]
 
 _lib = None
@@ -281,6 +295,39 @@ class Context:
         c = Counters()
         _check(self._h, lib().bt2g_counters_read(self._h, C.byref(c), int(reset), _stream_ptr()), "bt2g_counters_read")
         return c
+
+
+def _build_params(large, off_rate, ftab_chars, device):
+    bp = BuildParams()
+    lib().bt2g_build_params_default(C.byref(bp))
+    bp.large_index, bp.off_rate, bp.ftab_chars, bp.device = int(bool(large)), off_rate, ftab_chars, device
+    return bp
+
+
+def build_index(fasta_paths, out_base, large=False, off_rate=4, ftab_chars=10, device=0):
+    """bowtie2-build on the GPU (bt2g_index_build): FASTA files -> <out_base>.{1,2,3,4,rev.1,rev.2}.bt2[l]."""
+    bp = _build_params(large, off_rate, ftab_chars, device)
+    st = BuildStats()
+    arr = (C.c_char_p * len(fasta_paths))(*[p.encode() for p in fasta_paths])
+    rc = lib().bt2g_index_build(arr, len(fasta_paths), out_base.encode(), C.byref(bp), C.byref(st))
+    if rc != 0:
+        raise Bt2gError("bt2g_index_build failed: %s" % ERRORS.get(rc, rc))
+    return st
+
+
+def build_index_mem(names, seqs, out_base, large=False, off_rate=4, ftab_chars=10, device=0):
+    """bt2g_index_build_mem: seqs = bytes / numpy uint8 arrays of ASCII sequence characters held in host memory."""
+    import numpy as np
+    bp = _build_params(large, off_rate, ftab_chars, device)
+    st = BuildStats()
+    keep = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+    ptrs = (_vp * len(keep))(*[k.ctypes.data for k in keep])
+    lens = (C.c_uint64 * len(keep))(*[k.size for k in keep])
+    nm = (C.c_char_p * len(keep))(*[n.encode() for n in names]) if names is not None else None
+    rc = lib().bt2g_index_build_mem(nm, ptrs, lens, len(keep), out_base.encode(), C.byref(bp), C.byref(st))
+    if rc != 0:
+        raise Bt2gError("bt2g_index_build_mem failed: %s" % ERRORS.get(rc, rc))
+    return st
 
 
 class ReadBatch:

@@ -304,6 +304,34 @@ int bt2g_align_timing_read(bt2g_ctx *ctx, float *out_ms5);
  */
 int bt2g_align_profile_read(bt2g_ctx *ctx, uint64_t *out24, int reset, void *stream);
 
+/* ---- index construction ---------------------------------- */
+/*
+ * Replaces bowtie2-build-{s,l}: the driver (bt2_build.cpp:364-547), KarkkainenBlockwiseSA (blockwise_sa.h) and
+ * Ebwt::buildToDisk (bt2_idx.h:2829-3174).  Suffix sorting, BWT/Occ emission, the SA sample and the ftab run on the
+ * GPU (radix sort + prefix doubling, bt2g_build_core.hpp); the files <out_base>.{1,2,3,4,rev.1,rev.2}.bt2[l] come out
+ * byte-identical to the reference builder's.  Needs no ctx; `device` picks the GPU.  Synchronous.
+ */
+typedef struct {
+	int32_t large_index;      /* 0: .bt2 (32-bit offsets), 1: .bt2l (bowtie2-build --large-index)        */
+	int32_t off_rate;         /* -o/--offrate, default 4                                                */
+	int32_t ftab_chars;       /* -t/--ftabchars, default 10                                             */
+	int32_t write_ref;        /* also write <base>.3 / <base>.4 (default 1; 0 = -r/--noref)              */
+	int32_t device;
+} bt2g_build_params;
+typedef struct {
+	uint64_t len, n_pat, n_frag;          /* joined-text length, sequences, N-free fragments              */
+	uint32_t rounds_fw, rounds_bw;        /* prefix-doubling rounds per direction                          */
+	uint64_t tied_fw, tied_bw;            /* suffixes still tied after the first 29-base sort              */
+	double   t_parse, t_fw, t_bw, t_write;/* seconds: input scan, forward index, mirror index, file output  */
+} bt2g_build_stats;
+void bt2g_build_params_default(bt2g_build_params *p);
+/* FASTA files (plain or gzip).  stats may be NULL. */
+int bt2g_index_build(const char *const *fasta_paths, uint32_t n_paths, const char *out_base,
+                     const bt2g_build_params *params, bt2g_build_stats *stats);
+/* Sequences already in host memory (ASCII, any case, IUPAC codes / '-' count as N); names may be NULL ("0","1",...). */
+int bt2g_index_build_mem(const char *const *names, const char *const *seqs, const uint64_t *lens, uint32_t n_seqs,
+                         const char *out_base, const bt2g_build_params *params, bt2g_build_stats *stats);
+
 /* ---- instrumentation ---------------------------------------------------- */
 typedef struct {
 	uint64_t rank_queries;    /* # sides read (SURVEY.md 8d unit)             */
