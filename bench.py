@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X multiseed hot path on synthetic 150 bp single-end reads.
+"""bench.py -- throughput of the MI355X multiseed hot path on the headline configuration of BASELINE.json:
+150 bp single-end reads, --sensitive, end-to-end, against a genome-scale LARGE (.bt2l: 128-byte sides, 64-bit
+offsets) index that cannot sit in the 256 MiB Infinity Cache.
 
-Contract (see DESIGN.md "Measurement"):
+Contract (DESIGN.md "Measurement"):
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
-A "step" is one pass of the implemented hot-path stages over one resident batch of reads
-(inputs already in HBM).  Rank 0 prints ONE JSON line with metric/value plus `roofline`
-(dominant kernel, HBM-bound, timed with events on the launch stream) and `cpu_baseline`
-(the unmodified reference bowtie2-align-s from oracle/_ref, all host cores, bounded sample).
+A "step" is one bt2g_align_batch over one resident batch of reads (inputs already in HBM).  Rank 0 prints ONE JSON
+line with metric/value plus
+  roofline      dominant kernel, HBM-bound, timed with HIP events on the launch stream;
+  cpu_baseline  the unmodified reference (oracle/_ref/bowtie2-align-l-v256: the AVX2 build users run), all host cores,
+                bounded sample, wall clock minus a measured index-load run, median of 3;
+  config.parity_checked_reads   SAM of the CPU-baseline sample written by the product binary (GPU) compared with the
+                reference's, byte for byte, in this same run.
 
-hg38 is not available offline, so the workload is a deterministic synthetic genome (uniform
-random bases + planted repeats) indexed by the reference's own bowtie2-build from oracle/_ref;
-`config.workload` names it.  Reads shard across ranks with no data-path collective ("weak").
+hg38 itself is not available offline.  The stand-in is a deterministic synthetic genome with hg38-like repeat
+content (see synth_genome_gpu): diverged interspersed-repeat families, simple repeats, low-divergence segmental
+duplications and N gaps over ~45 % of the sequence.  The index is built in this run by the GPU index builder
+(bt2g_index_build_mem; byte-identical to bowtie2-build's, tests/test_index_build.py).  Reads shard across ranks with
+no data-path collective ("weak").
 """
 import argparse
 import json
+import math
 import os
 import re
 import subprocess
@@ -45,85 +53,151 @@ def nproc():
     return n
 
 
-def genome_path(mbp, seed):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cache_dir():
     d = os.environ.get("BT2_BENCH_CACHE", "/tmp/bt2_amd_bench")
     os.makedirs(d, exist_ok=True)
-    return os.path.join(d, "synth_%dmbp_s%d" % (mbp, seed))
+    return d
 
 
-def make_genome(mbp, seed):
-    """Deterministic synthetic genome: 4 chromosomes of uniform random bases with planted repeats
-    (so that multi-element SA ranges and repeat seeds occur) and a few N stretches."""
-    import numpy as np
-    base = genome_path(mbp, seed)
-    fa = base + ".fa"
-    npy = base + ".npy"
-    if os.path.exists(fa) and os.path.exists(npy):
-        return base, np.load(npy, allow_pickle=True)
-    rng = np.random.default_rng(seed)
-    total = mbp * 1_000_000
-    nchr = 4
-    chroms = []
-    with open(fa + ".tmp", "wb") as f:
-        for c in range(nchr):
-            n = total // nchr
-            a = rng.integers(0, 4, size=n, dtype=np.uint8)
-            # planted repeats: copy segments elsewhere (2% of the chromosome, lengths 200-5000)
-            nrep = max(1, n // 100_000)
-            for _ in range(nrep):
-                ln = int(rng.integers(200, 5000))
-                src = int(rng.integers(0, n - ln))
-                dst = int(rng.integers(0, n - ln))
-                a[dst:dst + ln] = a[src:src + ln]
-            # N stretches
-            for _ in range(max(1, n // 2_000_000)):
-                ln = int(rng.integers(10, 2000))
-                p = int(rng.integers(0, n - ln))
-                a[p:p + ln] = 4
-            chroms.append(a)
-            s = np.frombuffer(b"ACGTN", dtype=np.uint8)[a]
-            f.write((">chr%d\n" % (c + 1)).encode())
-            full = n - n % 80
-            lines = s[:full].reshape(-1, 80)
-            nl = np.full((lines.shape[0], 1), 10, dtype=np.uint8)
-            f.write(np.hstack([lines, nl]).tobytes())
-            if n % 80:
-                f.write(s[full:].tobytes() + b"\n")
-    os.replace(fa + ".tmp", fa)
-    arr = np.empty(nchr, dtype=object)
-    for i, a in enumerate(chroms):
-        arr[i] = a
-    np.save(npy, arr, allow_pickle=True)
-    return base, arr
+# ------------------------------------------------------------------------------------------------ genome ----
+N_CHROMS = 8
 
 
-def build_index(base, threads):
-    if os.path.exists(base + ".rev.2.bt2"):
-        return
-    exe = os.path.join(ROOT, "oracle", "_ref", "bowtie2-build-s")
-    if not os.path.exists(exe):
-        raise RuntimeError("oracle/_ref/bowtie2-build-s missing: run __graft_entry__.build() where /root/reference exists")
-    t0 = time.time()
-    # bowtie2-build's blockwise suffix sorter scales poorly past a few dozen threads
-    subprocess.check_call([exe, "--threads", str(min(threads, 16)), "-q", base + ".fa", base], stdout=subprocess.DEVNULL)
-    log("[bench] index built in %.1fs" % (time.time() - t0))
+def synth_genome_gpu(mbp, seed, device):
+    """Deterministic hg38-like synthetic genome as one uint8 tensor of codes 0..3 (4 = N) + chromosome lengths.
 
-
-def synth_reads_gpu(chroms, n, length, seed, device):
-    """SURVEY.md 8d generator on the GPU: uniform position, 50/50 strand, 1% substitutions,
-    0.1% insertions + 0.1% deletions (at most one indel per read here), Phred from {38,38,38,30,20,12}."""
+    Composition (fractions of the sequence; hg38 for comparison: ~10 % Alu, ~17 % L1, ~20 % other interspersed
+    repeats, ~3 % simple repeats, ~5 % segmental duplications, ~5 % N):
+      * "Alu-like":  one 300 bp consensus, full-length copies, 4-16 % substitutions each          -> 10 %
+      * "L1-like":   one 6 kbp consensus, 3'-anchored truncated copies of 400-6000 bp, 3-20 %     -> 17 %
+      * "old" families: eight consensi of 150-1200 bp, 15-28 % substitutions                      -> 12 %
+      * simple repeats: units of 1-6 bp, tracts of 20-300 bp                                      ->  2 %
+      * segmental duplications: 5-40 kbp copies of earlier sequence with 0.5-2 % substitutions    ->  4 %
+      * N: a 0.25 % gap at either end of every chromosome + scattered 100-5000 bp gaps            -> ~0.75 %
+    Later classes overwrite earlier ones where they collide."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    lens = torch.tensor([len(c) for c in chroms], dtype=torch.int64)
-    starts = torch.cumsum(lens, 0) - lens
-    genome = torch.cat([torch.from_numpy(c) for c in chroms]).to(device)
-    ci = torch.randint(0, len(chroms), (n,), generator=g, device=device)
-    clen = lens.to(device)[ci]
-    pos = (torch.rand(n, generator=g, device=device, dtype=torch.float64) * (clen - length - 2).double()).long()
-    gpos = starts.to(device)[ci] + pos
+    n = mbp * 1_000_000
+    per = n // N_CHROMS
+    n = per * N_CHROMS
+    G = torch.randint(0, 4, (n,), generator=g, device=device, dtype=torch.uint8)
+
+    def rnd(shape):
+        return torch.rand(shape, generator=g, device=device)
+
+    def plant(consensus, frac, div_lo, div_hi, min_len=None):
+        L = consensus.numel()
+        mean_len = L if min_len is None else (L + min_len) / 2.0
+        k = max(1, int(n * frac / mean_len))
+        for c0 in range(0, k, 200_000):                     # chunks bound the index tensors
+            kk = min(200_000, k - c0)
+            start = (rnd((kk,)).double() * (n - L - 1)).long()
+            ln = torch.full((kk,), L, device=device, dtype=torch.long) if min_len is None else \
+                (min_len + (rnd((kk,)) * (L - min_len)).long())
+            div = div_lo + rnd((kk,)) * (div_hi - div_lo)
+            off = torch.arange(L, device=device).unsqueeze(0)                # [1, L]
+            keep = off < ln.unsqueeze(1)                                     # 3'-anchored: the last ln bases of the consensus
+            src = (L - ln).unsqueeze(1) + off                                # consensus position
+            src = torch.where(keep, src, torch.zeros_like(src))
+            vals = consensus[src]
+            mut = rnd((kk, L)) < div.unsqueeze(1)
+            rb = torch.randint(1, 4, (kk, L), generator=g, device=device, dtype=torch.uint8)
+            vals = torch.where(mut, (vals + rb) % 4, vals)
+            dst = start.unsqueeze(1) + off
+            G[dst[keep]] = vals[keep]
+
+    def cons(L):
+        return torch.randint(0, 4, (L,), generator=g, device=device, dtype=torch.uint8)
+
+    for _ in range(8):
+        L = int(150 + rnd((1,)).item() * 1050)
+        plant(cons(L), 0.12 / 8, 0.15, 0.28)
+    plant(cons(6000), 0.17, 0.03, 0.20, min_len=400)
+    plant(cons(300), 0.10, 0.04, 0.16)
+    # simple repeats
+    k = int(n * 0.02 / 160)
+    start = (rnd((k,)).double() * (n - 400)).long()
+    ln = 20 + (rnd((k,)) * 280).long()
+    unit = 1 + (rnd((k,)) * 6).long().clamp(max=5)
+    ub = torch.randint(0, 4, (k, 6), generator=g, device=device, dtype=torch.uint8)
+    off = torch.arange(300, device=device).unsqueeze(0)
+    keep = off < ln.unsqueeze(1)
+    vals = torch.gather(ub, 1, off.expand(k, 300) % unit.unsqueeze(1))
+    G[(start.unsqueeze(1) + off)[keep]] = vals[keep]
+    # segmental duplications (copied from the current state of the sequence)
+    k = max(1, int(n * 0.04 / 22_500))
+    for _ in range(k):
+        L = int(5000 + rnd((1,)).item() * 35_000)
+        a = int(rnd((1,)).item() * (n - L - 1)); b = int(rnd((1,)).item() * (n - L - 1))
+        seg = G[a:a + L].clone()
+        mut = rnd((L,)) < (0.005 + rnd((1,)).item() * 0.015)
+        rb = torch.randint(1, 4, (L,), generator=g, device=device, dtype=torch.uint8)
+        G[b:b + L] = torch.where(mut, (seg + rb) % 4, seg)
+    # N gaps
+    for c in range(N_CHROMS):
+        G[c * per:c * per + per // 400] = 4
+        G[(c + 1) * per - per // 400:(c + 1) * per] = 4
+    k = max(1, n // 1_000_000)
+    start = (rnd((k,)).double() * (n - 6000)).long()
+    ln = 100 + (rnd((k,)) * 4900).long()
+    off = torch.arange(5000, device=device).unsqueeze(0)
+    G[(start.unsqueeze(1) + off)[off < ln.unsqueeze(1)]] = 4
+    return G, [per] * N_CHROMS
+
+
+def build_index_gpu(base, G, chrom_lens, large, device_index):
+    """The GPU index builder on the in-memory genome -> <base>.{1,2,3,4,rev.1,rev.2}.bt2[l]; returns its stats."""
+    import numpy as np
+    import torch
+    import bowtie2_amd as b
+    lut = torch.tensor([ord(c) for c in "ACGTN"], dtype=torch.uint8, device=G.device)
+    asc = lut[G.long()].cpu().numpy()
+    names, seqs, o = [], [], 0
+    for i, L in enumerate(chrom_lens):
+        names.append("chr%d" % (i + 1))
+        seqs.append(asc[o:o + L])
+        o += L
+    t0 = time.time()
+    st = b.build_index_mem(names, seqs, base, large=large, device=device_index)
+    log("[bench] index built on the GPU in %.1fs (scan %.1f, forward %.1f [%d tied, %d rounds], mirror %.1f [%d rounds], files %.1f)"
+        % (time.time() - t0, st.t_parse, st.t_fw, st.tied_fw, st.rounds_fw, st.t_bw, st.rounds_bw, st.t_write))
+    return {"seconds": round(time.time() - t0, 2), "scan_s": round(st.t_parse, 2), "forward_s": round(st.t_fw, 2), "mirror_s": round(st.t_bw, 2),
+            "files_s": round(st.t_write, 2), "tied_after_first_sort": int(st.tied_fw), "doubling_rounds": int(st.rounds_fw), "text_len": int(st.len)}
+
+
+# ------------------------------------------------------------------------------------------------- reads ----
+def synth_reads_gpu(G, n, length, seed, device):
+    """SURVEY.md 8d generator on the GPU: uniform position over windows with at most 2 Ns, 50/50 strand, 1 % substitutions,
+    0.1 % insertions + 0.1 % deletions (at most one indel per read here), Phred from {38,38,38,30,20,12}."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    ntot = G.numel()
+    isn = (G > 3)
+    cum = torch.zeros(ntot + 1, dtype=torch.int32, device=device)
+    cum[1:] = torch.cumsum(isn.to(torch.int32), 0)
+    pos_parts = []
+    have = 0
+    while have < n:
+        cand = (torch.rand(int((n - have) * 1.3) + 1024, generator=g, device=device, dtype=torch.float64) * (ntot - length - 4)).long()
+        okm = (cum[cand + length + 2] - cum[cand]) <= 2
+        cand = cand[okm]
+        pos_parts.append(cand)
+        have += cand.numel()
+    gpos = torch.cat(pos_parts)[:n]
+    del cum
     idx = torch.arange(length, device=device).unsqueeze(0).expand(n, length)
-    # one indel per read with probability ~ length * 0.002
     has_indel = torch.rand(n, generator=g, device=device) < length * 0.002
     is_ins = torch.rand(n, generator=g, device=device) < 0.5
     k = torch.randint(5, length - 5, (n,), generator=g, device=device).unsqueeze(1)
@@ -132,7 +206,8 @@ def synth_reads_gpu(chroms, n, length, seed, device):
     ins = (has_indel & is_ins).unsqueeze(1)
     shift = torch.where(dele & (idx >= k), torch.ones_like(shift), shift)
     shift = torch.where(ins & (idx > k), -torch.ones_like(shift), shift)
-    seq = genome[gpos.unsqueeze(1) + idx + shift]
+    seq = G[gpos.unsqueeze(1) + idx + shift]
+    del shift
     rnd_base = torch.randint(0, 4, (n, length), generator=g, device=device, dtype=torch.uint8)
     seq = torch.where(ins & (idx == k), rnd_base, seq)
     sub = torch.rand(n, length, generator=g, device=device) < 0.01
@@ -145,49 +220,117 @@ def synth_reads_gpu(chroms, n, length, seed, device):
     return seq.contiguous(), qual.contiguous()
 
 
-def write_fastq(path, seq, qual, n, repeat=1):
-    """FASTQ of the first n reads; the same block is written `repeat` times (read names repeat too)."""
+def read_names(n0, n, width=9):
+    """Fixed-width names r000000123 as a [n, width+1] uint8 array."""
     import numpy as np
-    s = np.frombuffer(b"ACGT", dtype=np.uint8)[seq[:n].cpu().numpy()]
-    q = qual[:n].cpu().numpy()
-    parts = []
-    for i in range(n):
-        parts.append(b"@r%d\n" % i)
-        parts.append(s[i].tobytes())
-        parts.append(b"\n+\n")
-        parts.append(q[i].tobytes())
-        parts.append(b"\n")
-    block = b"".join(parts)
+    ids = np.arange(n0, n0 + n, dtype=np.int64)
+    out = np.empty((n, width + 1), dtype=np.uint8)
+    out[:, 0] = ord("r")
+    for d in range(width):
+        out[:, width - d] = ord("0") + (ids // (10 ** d)) % 10
+    return out
+
+
+def gen_rand_seeds(seq, qual, names_t):
+    """genRandSeed (pat.cpp:45-84) with the default --seed 0, vectorised: what the drop-in binary derives per read."""
+    import torch
+    n, L = seq.shape
+    dev = seq.device
+    base = 101 * 59 * 61 * 67 * 71 * 73 * 79 * 83 % (1 << 32)
+    acc = torch.full((n,), base, dtype=torch.int64, device=dev)
+    for j in range(L):      # XOR-reduction over columns (no xor-reduce primitive); L is 150
+        acc ^= (seq[:, j].long() << ((j & 15) << 1)) & 0xffffffff
+        acc ^= (qual[:, j].long() << ((j & 3) << 3)) & 0xffffffff
+    for j in range(names_t.shape[1]):
+        acc ^= (names_t[:, j].long() << ((j & 3) << 3)) & 0xffffffff
+    return (acc & 0xffffffff)
+
+
+def write_fastq_fixed(path, seq, qual, names):
+    """FASTQ of equal-length reads, assembled as one 2-D byte array."""
+    import numpy as np
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[seq.cpu().numpy()]
+    q = qual.cpu().numpy()
+    n, L = s.shape
+    w = names.shape[1]
+    rec = np.empty((n, 1 + w + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1:1 + w] = names; rec[:, 1 + w] = 10
+    o = 2 + w
+    rec[:, o:o + L] = s; rec[:, o + L] = 10; rec[:, o + L + 1] = ord("+"); rec[:, o + L + 2] = 10
+    o2 = o + L + 3
+    rec[:, o2:o2 + L] = q; rec[:, o2 + L] = 10
     with open(path, "wb") as f:
-        for _ in range(repeat):
-            f.write(block)
+        f.write(rec.tobytes())
 
 
-def cpu_baseline(base, seq, qual, sample, threads, repeat=1):
-    """Reference bowtie2-align-s (oracle/_ref, unmodified v2.5.5, SSE2 build) on a bounded sample."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "bowtie2-align-s")
-    if not os.path.exists(exe):
-        return None
-    fq = base + ".bench_sample.fq"
-    write_fastq(fq, seq, qual, sample, repeat)
-    cmd = [exe, "--sensitive", "-p", str(threads), "--reorder", "-t", "-x", base, "-U", fq, "-S", "/dev/null"]
-    t0 = time.time()
+# ---------------------------------------------------------------------------------- CPU baseline + parity ----
+def run_timed(cmd):
+    t0 = time.perf_counter()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    wall = time.time() - t0
+    return time.perf_counter() - t0, p
+
+
+def sam_body(path):
+    with open(path, "rb") as f:
+        return [l for l in f if not l.startswith(b"@PG")]
+
+
+def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, threads, preset, work):
+    """Reference bowtie2-align (AVX2 build when present) on the sample: reads/s from wall clock minus the wall clock of
+    an index-load-dominated run (n_tiny reads), median of 3.  The first pass writes SAM; the product binary aligns the
+    same FASTQ on the GPU and the two SAM files are compared byte for byte (minus @PG)."""
+    sfx = "l" if large else "s"
+    exe = os.path.join(ROOT, "oracle", "_ref", "bowtie2-align-%s-v256" % sfx)
+    simd = "AVX2 (-march=x86-64-v3 -DSSE_AVX2)"
+    if not os.path.exists(exe):
+        exe = os.path.join(ROOT, "oracle", "_ref", "bowtie2-align-%s" % sfx)
+        simd = "SSE2"
+    if not os.path.exists(exe):
+        return None, None
+    common = [preset, "-p", str(threads), "--reorder", "-x", base]
+    ref_sam = os.path.join(work, "sample.ref.sam")
+    t_load = []
+    for _ in range(2):
+        t, p = run_timed([exe] + common + ["-U", fq_tiny, "-S", "/dev/null"])
+        if p.returncode != 0:
+            log("[bench] cpu baseline failed:", p.stderr[-500:]); return None, None
+        t_load.append(t)
+    t_full = []
+    al = None
+    for k in range(3):
+        t, p = run_timed([exe] + common + ["-U", fq_all, "-S", ref_sam if k == 0 else "/dev/null"])
+        if p.returncode != 0:
+            log("[bench] cpu baseline failed:", p.stderr[-500:]); return None, None
+        t_full.append(t)
+        al = re.search(r"([\d.]+)% overall alignment rate", p.stderr)
+    t_full.sort(); tl = min(t_load)
+    search = t_full[1] - tl
+    cb = {"value": (n_sample - n_tiny) / search, "unit": "reads/s", "cores": threads, "kind": "reference",
+          "sample": "%d of the same synthetic 150 bp reads, unmodified bowtie2-align-%s v2.5.5 (oracle/_ref, -O3, %s) %s -p %d --reorder; "
+                    "time = wall clock (median of 3: %s s) minus the wall clock of a %d-read run that is all index load (%.2f s); CPU: %s; "
+                    "overall alignment rate %s%%" % (n_sample, sfx, simd, preset, threads, "/".join("%.2f" % x for x in t_full), n_tiny, tl, cpu_model(),
+                                                     al.group(1) if al else "?")}
+    # parity: the product binary (GPU) on the same FASTQ
+    ours = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-%s" % sfx)
+    our_sam = os.path.join(work, "sample.gpu.sam")
+    t, p = run_timed([ours] + common + ["-U", fq_all, "-S", our_sam])
+    par = {"parity_checked_reads": 0, "parity_identical": False}
     if p.returncode != 0:
-        log("[bench] cpu baseline failed:", p.stderr[-500:])
-        return None
-    m = re.search(r"Multiseed full-index search: (\d+):(\d+):(\d+)", p.stderr)
-    search = wall
-    if m:
-        s = int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3))
-        if s >= 5:          # the -t line has 1 s resolution; only trust it when it is long enough
-            search = float(s)
-    al = re.search(r"([\d.]+)% overall alignment rate", p.stderr)
-    return {"value": sample * repeat / search, "unit": "reads/s", "cores": threads, "kind": "reference",
-            "sample": "%d of the same synthetic 150 bp reads x %d passes, bowtie2-align-s v2.5.5 (oracle/_ref, -O3 -msse2) --sensitive -p %d -S /dev/null; "
-                      "time = %s; overall alignment rate %s%%" % (sample, repeat, threads, "'-t' search time" if search != wall else "wall incl. index load",
-                                                                  al.group(1) if al else "?")}
+        log("[bench] product binary failed on the parity sample:", p.stderr[-800:])
+        par["parity_error"] = p.stderr[-300:]
+    else:
+        a, b_ = sam_body(ref_sam), sam_body(our_sam)
+        ndiff = sum(1 for x, y in zip(a, b_) if x != y) + abs(len(a) - len(b_))
+        par = {"parity_checked_reads": n_sample, "parity_identical": ndiff == 0, "parity_differing_sam_lines": ndiff,
+               "parity_product_binary_wall_s": round(t, 2)}
+        aligned_ref = sum(1 for l in a if not l.startswith(b"@") and not (int(l.split(b"\t", 2)[1]) & 4))
+        par["parity_sample_aligned_reads"] = aligned_ref
+    for f in (ref_sam, our_sam):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    return cb, par
 
 
 def pmc_traffic(kernel, reads_per_launch):
@@ -208,23 +351,18 @@ def pmc_traffic(kernel, reads_per_launch):
         return None, None
 
 
-def synth_pairs_gpu(chroms, npairs, length, seed, device):
+def synth_pairs_gpu(G, npairs, length, seed, device):
     """Pairs for --paired: fragment length N(300,30) clipped to [length+1, 450], mate 1 = fragment start (forward), mate 2 = reverse
     complement of the fragment end, 1 % substitutions, half of the pairs with the roles of the mates swapped.  Returns [2*npairs, length]."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    lens = torch.tensor([len(c) for c in chroms], dtype=torch.int64)
-    starts = torch.cumsum(lens, 0) - lens
-    genome = torch.cat([torch.from_numpy(c) for c in chroms]).to(device)
-    ci = torch.randint(0, len(chroms), (npairs,), generator=g, device=device)
-    clen = lens.to(device)[ci]
+    ntot = G.numel()
     frag = (300.0 + 30.0 * torch.randn(npairs, generator=g, device=device)).long().clamp(length + 1, 450)
-    pos = (torch.rand(npairs, generator=g, device=device, dtype=torch.float64) * (clen - 460).double()).long()
-    gpos = starts.to(device)[ci] + pos
+    gpos = (torch.rand(npairs, generator=g, device=device, dtype=torch.float64) * (ntot - 460)).long()
     idx = torch.arange(length, device=device).unsqueeze(0).expand(npairs, length)
-    m1 = genome[gpos.unsqueeze(1) + idx]
-    m2 = (3 - genome[(gpos + frag - length).unsqueeze(1) + idx].clamp(max=3)).flip(1)
+    m1 = G[gpos.unsqueeze(1) + idx]
+    m2 = (3 - G[(gpos + frag - length).unsqueeze(1) + idx].clamp(max=3)).flip(1)
     both = torch.stack([m1, m2], dim=1)                               # [npairs, 2, length]
     swap = torch.rand(npairs, generator=g, device=device) < 0.5
     both = torch.where(swap.view(-1, 1, 1), both.flip(1), both)
@@ -243,17 +381,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BT2_BENCH_MBP", "32")))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("BT2_BENCH_READS", "200000")), help="reads per GPU per step")
+    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BT2_BENCH_MBP", "1024")))
+    ap.add_argument("--small-index", action="store_true", help="build a .bt2 (32-bit) index instead of the headline .bt2l")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BT2_BENCH_READS", "2000000")), help="reads per GPU per step")
     ap.add_argument("--readlen", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BT2_BENCH_CPU_SAMPLE", "200000")))
-    ap.add_argument("--cpu-repeat", type=int, default=int(os.environ.get("BT2_BENCH_CPU_REPEAT", "12")),
-                    help="passes over the CPU sample, so that the reference runs for ~10 s")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BT2_BENCH_CPU_SAMPLE", "1000000")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--paired", action="store_true",
                     help="measure the paired-end kernel instead: --reads/2 pairs of 2 x --readlen, fragments N(300,30), --fr (not the headline metric)")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import bowtie2_amd as b
 
@@ -266,31 +404,42 @@ def main():
     dist = shard.init("nccl", dev)      # RCCL; None when WORLD_SIZE == 1
 
     threads = nproc()
-    # ---- workload: index (rank 0 builds, others wait) ----
-    if rank == 0:
-        base, chroms = make_genome(args.genome_mbp, 2)
-        build_index(base, threads)
+    large = not args.small_index
+    ext = "bt2l" if large else "bt2"
+    base = os.path.join(cache_dir(), "hg38like_%dmbp_s2_%s" % (args.genome_mbp, ext))
+    # ---- workload: genome (every rank, same seed) + index (rank 0 builds it on its GPU, the others wait) ----
+    t0 = time.time()
+    G, chrom_lens = synth_genome_gpu(args.genome_mbp, 2, dev)
+    torch.cuda.synchronize()
+    log("[bench] genome: %d Mbp generated in %.1fs" % (args.genome_mbp, time.time() - t0))
+    build_info = None
+    if rank == 0 and not os.path.exists(base + ".rev.2." + ext):
+        torch.cuda.empty_cache()       # the builder allocates ~30 bytes per base with hipMalloc, next to torch's caching allocator
+        build_info = build_index_gpu(base, G, chrom_lens, large, local_rank)
     if dist is not None:
         dist.barrier()
-    if rank != 0:
-        base, chroms = make_genome(args.genome_mbp, 2)
 
     ctx = b.Context(local_rank)
+    t0 = time.time()
     info = ctx.load_index(base)
+    log("[bench] index loaded into HBM in %.1fs (%.2f GB)" % (time.time() - t0, info.hbm_bytes / 1e9))
     # per-rank shard of reads (weak scaling: fixed reads per GPU)
-    seq, qual = synth_reads_gpu(chroms, args.reads, args.readlen, shard.shard_seed(1000, rank), dev)
     n = args.reads
     if args.paired:
         # mates interleaved: read 2i = forward mate at the fragment start, read 2i+1 = reverse-complemented mate at its end
-        seq, qual = synth_pairs_gpu(chroms, n // 2, args.readlen, shard.shard_seed(2000, rank), dev)
+        seq, qual = synth_pairs_gpu(G, n // 2, args.readlen, shard.shard_seed(2000, rank), dev)
         n = seq.shape[0]
+    else:
+        seq, qual = synth_reads_gpu(G, n, args.readlen, shard.shard_seed(1000, rank), dev)
+    del G
+    torch.cuda.empty_cache()
+    names = read_names(rank * n, n)
+    names_t = torch.from_numpy(names).to(dev)
     off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * args.readlen)
     batch = b.ReadBatch(seq.view(-1), qual.view(-1), off, n)
 
     # --sensitive, 150 bp: -L 22, -i S,1,1.15 -> interval 1+1.15*sqrt(150) = 15 (bt2_search.cpp:3443-3450)
     import ctypes as C
-    import math
-    import numpy as np
     L = 22
     interval = max(1, int(1 + 1.15 * math.sqrt(args.readlen)))
     P = b.AlignParams(mm_type=3, mm_max=6, mm_min=2, n_pen=1, rdgapo=8, rdgape=3, rfgapo=8, rfgape=3, gapbar=4, match_bonus=0,
@@ -301,17 +450,17 @@ def main():
         # default pair policy: --fr, -I 0 -X 500, mixed + discordant reporting, containment and overlap allowed (bt2_search.cpp:303-502)
         P.paired, P.pe_policy, P.pe_maxfrag, P.pe_minfrag, P.pe_flags, P.max_mate_streak = 1, 3, 500, 0, 2 | 4 | 8 | 32 | 64 | 128, 10
         interval = max(1, int(interval * 1.2 + 0.5))       # both mates pass their filters (bt2_search.cpp:3427-3434)
-    # per-read parameters as the host derives them (minsc = (long)(-0.6 + -0.6*len), nceil = 0.15*len; seeds from read content)
+    # per-read parameters exactly as the drop-in binary derives them for these reads: minsc = (long)(-0.6 + -0.6*len),
+    # nceil = 0.15*len, seed = genRandSeed(name, seq, qual) -- so the timed batch is the verified configuration
     minsc = int(-0.6 + -0.6 * args.readlen)
     rp = np.zeros(n, dtype=[("minsc", "<i4"), ("interval", "<i4"), ("nceil", "<i4"), ("seedlen", "<i4"), ("seed", "<u4"), ("filt", "<u4")])
     rp["minsc"] = minsc; rp["interval"] = interval; rp["nceil"] = int(0.15 * args.readlen); rp["seedlen"] = L; rp["filt"] = 15
-    rp["seed"] = np.random.default_rng(7 + rank).integers(0, 2**32, size=n, dtype=np.uint32)   # stands in for genRandSeed(name,seq,qual)
+    rp["seed"] = gen_rand_seeds(seq, qual, names_t).cpu().numpy().astype(np.uint32)
     rp_t = torch.from_numpy(rp.view(np.uint8).copy()).to(dev)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     stage_events = []
     last = {}
-
     kern_times = []
 
     def step(record):
@@ -376,9 +525,21 @@ def main():
         fm_bytes = (cnt.rank_queries * side + cnt.ftab_lookups * 2 * off_sz + cnt.sa_lookups * off_sz) / float(args.steps) + n * args.readlen * 2
         fm_achieved = fm_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic("k_align_reads", n)
+        cb, par = None, None
+        if not args.no_cpu_baseline and world == 1 and not args.paired:      # reported at N=1 only (the paired mode is a kernel study, no CPU leg)
+            ns = min(args.cpu_sample, n)
+            ntiny = 1000
+            work = cache_dir()
+            fq_all, fq_tiny = os.path.join(work, "sample.fq"), os.path.join(work, "tiny.fq")
+            write_fastq_fixed(fq_all, seq[:ns], qual[:ns], names[:ns])
+            write_fastq_fixed(fq_tiny, seq[:ntiny], qual[:ntiny], names[:ntiny])
+            cb, par = cpu_baseline_and_parity(base, large, fq_all, fq_tiny, ns, ntiny, threads, "--sensitive", work)
+            if par is not None and "parity_sample_aligned_reads" in par:
+                # the timed batch starts with the same reads, same parameters, same per-read seeds: its records must agree
+                par["timed_batch_aligned_reads_same_sample"] = int(h["aligned"][:ns].sum())
         res = {
-            "metric": ("aligned reads/sec (whole node), 2 x 150 bp PE (mates counted as reads), synthetic genome" if args.paired else
-                       "aligned reads/sec (whole node), 150 bp SE, synthetic genome (hg38 unavailable offline)"),
+            "metric": ("aligned reads/sec (whole node), 2 x 150 bp PE (mates counted as reads), hg38-like synthetic genome" if args.paired else
+                       "aligned reads/sec (whole node), 150 bp SE vs hg38-like synthetic genome (hg38 unavailable offline), large index"),
             "value": shard.throughput(world, n, steps, dt),
             "unit": "reads/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -386,13 +547,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32" if off_sz == 4 else "u8/u64", "data": "synthetic",
             "config": {
-                "workload": "synthetic %d Mbp genome (.bt2, built by reference bowtie2-build), %d x %d bp SE reads per GPU per step, --sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"
-                            % (args.genome_mbp, n, args.readlen),
+                "workload": "hg38-like synthetic %d Mbp genome (%d chromosomes; ~45 %% repeats: Alu-/L1-like and older diverged families, simple repeats, segmental duplications; N gaps), "
+                            ".%s index (side %d B, %d-byte offsets) built in this run by the GPU index builder, %d x %d bp SE reads per GPU per step, "
+                            "--sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"
+                            % (args.genome_mbp, N_CHROMS, ext, side, off_sz, n, args.readlen),
                 "stages_timed": "one bt2g_align_batch per step = the whole per-read worker: k_exact_sweep, k_one_mm, k_seed_search_exact, k_extend_hits (lane-per-task FM kernels) then k_align_reads "
                                 "(rank+prioritise, offset resolution, re-seeding, SW fill + backtrace, -M reporting)",
                 "not_in_timed_region": "FASTQ parse and SAM text formatting (host side, SURVEY.md 8f)",
                 "fraction_aligned": all_aligned / float(world * n),
-                "index_bytes_hbm": int(info.hbm_bytes), "side_sz": int(side),
+                "index_bytes_hbm": int(info.hbm_bytes), "side_sz": int(side), "off_size": int(off_sz),
+                "index_build": build_info,
                 "bw_ops_per_read": rankq / n, "dp_fills_per_read": float(h["n_ex_dps"].sum()) / n,
                 "backtraces_per_read": float(h["n_bt_attempts"].sum()) / n,
                 "reads_overflowed": int((h["status"] != 0).sum()),
@@ -408,15 +572,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": kern_ms,
                          "dp_gcups": dp_cells / (kern_ms * 1e-3) / 1e9,
-                         "note": "k_align_reads is bound by scalar-instruction issue of its wave-uniform control code, not by HBM (DESIGN.md 6); "
-                                 "the FM kernels below are the HBM-shaped part of the path",
                          "fm_kernels": {"kernels": ["k_exact_sweep", "k_one_mm", "k_seed_search_exact", "k_extend_hits"], "bound": "hbm",
                                         "ms_per_launch_sum": fm_ms, "algorithmic_bytes_per_launch": int(fm_bytes),
                                         "achieved": fm_achieved, "unit": "GB/s", "frac": fm_achieved / HBM_PEAK_GBS}},
         }
-        cb = None
-        if not args.no_cpu_baseline and world == 1 and not args.paired:      # reported at N=1 only (the paired mode is a kernel study, no CPU leg)
-            cb = cpu_baseline(base, seq, qual, min(args.cpu_sample, n), threads, args.cpu_repeat)
+        if par:
+            res["config"].update(par)
         res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -477,6 +477,10 @@ struct DevPlat {
 	}
 };
 
+// per-read parameters the host derives (seed length 1..32 as -L allows, positive seed interval); anything else would index
+// past the seed tables
+__device__ __forceinline__ bool read_params_ok(const ReadParams& rp) { return rp.seedlen >= 1 && rp.seedlen <= 32 && rp.interval >= 1 && rp.nceil >= 0; }
+
 #ifndef BT2G_WAVES_PER_EU
 #define BT2G_WAVES_PER_EU 2
 #endif
@@ -485,7 +489,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre) {
+              PreComp pre, uint32_t max_read_len) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	Work& w = *reinterpret_cast<Work*>(base);
@@ -507,7 +511,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		const uint64_t o0 = rd.d_off[r];
 		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
 		ReadResult& out = *reinterpret_cast<ReadResult*>(results + (uint64_t)r * result_stride);
-		if (len > (uint32_t)kMaxLen) {
+		if (len > max_read_len || !read_params_ok(rparams[r])) {      // the DP scratch of this launch is sized for max_read_len rows
 			if (lane == 0) { out.status = ERR_OVERFLOW; out.aligned = 0; out.nreport = 0; out.nalns = 0; out.filt = (uint8_t)rparams[r].filt; out.maxed = 0; out.has_secbest = 0; }
 			continue;
 		}
@@ -540,7 +544,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre) {
+              PreComp pre, uint32_t max_read_len) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	Work& w = *reinterpret_cast<Work*>(base);
@@ -566,7 +570,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		const uint32_t len0 = (uint32_t)(o1 - o0), len1 = (uint32_t)(o2 - o1);
 		ReadResult& out0 = *reinterpret_cast<ReadResult*>(results + (uint64_t)(2 * r) * result_stride);
 		ReadResult& out1 = *reinterpret_cast<ReadResult*>(results + (uint64_t)(2 * r + 1) * result_stride);
-		if (len0 > (uint32_t)kMaxLen || len1 > (uint32_t)kMaxLen) {
+		if (len0 > max_read_len || len1 > max_read_len || !read_params_ok(rparams[2 * r]) || !read_params_ok(rparams[2 * r + 1])) {
 			if (lane == 0) {
 				ReadResult* o[2] = {&out0, &out1};
 				for (int m = 0; m < 2; m++) { o[m]->status = ERR_OVERFLOW; o[m]->aligned = 0; o[m]->nreport = 0; o[m]->nalns = 0; o[m]->filt = (uint8_t)rparams[2 * r + m].filt; o[m]->maxed = 0; o[m]->has_secbest = 0; o[m]->pair_type = 0; o[m]->pair_flags = 0; }
@@ -597,24 +601,26 @@ template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
                         uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
-                        const PreComp& pre, hipStream_t st) {
+                        const PreComp& pre, uint32_t max_read_len, hipStream_t st) {
 	if (rd.n_reads == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
 	if (P.paired)
 		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
-		                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre);
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre, max_read_len);
 	else
 	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
-	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre);
+	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre, max_read_len);
 	return hipGetLastError();
 }
 
-void align_scratch_sizes(uint32_t max_len, bool paired, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& arena_stride) {
+void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& arena_stride) {
 	const uint32_t rows = max_len ? max_len : 1;
 	const uint32_t R = dp_R(rows);
-	// unpaired: seed-extension windows only; paired: opposite-mate windows up to kMaxCols, and a second matrix for them
-	const uint32_t cols = paired ? (uint32_t)kMaxCols + 4 : rows + 4 * 15 + 1 + 4;
+	// unpaired: seed-extension windows only (rows + 4 * min(gaps, maxhalf) columns, dp_framer.cpp:81-129; the framer flags windows
+	// past kMaxCols); paired: opposite-mate windows up to kMaxCols, and a second matrix for them
+	uint32_t cols = paired ? (uint32_t)kMaxCols + 4 : rows + 4 * maxhalf + 1 + 4;
+	if (cols > (uint32_t)kMaxCols + 4) cols = (uint32_t)kMaxCols + 4;
 	const uint32_t lanes = (rows + R - 1) / R;
 	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 8 + 255) & ~(uint64_t)255;    // 8 B per cell: the 16-bit path packs H|E|F into 64 bits
 	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
@@ -626,7 +632,7 @@ void align_scratch_sizes(uint32_t max_len, bool paired, uint64_t& mat_bytes, uin
 uint64_t align_work_bytes() { return sizeof(Work); }
 uint32_t align_waves_per_cu() { return 4u * BT2G_WAVES_PER_EU; }
 
-template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, hipStream_t);
-template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, hipStream_t);
+template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, hipStream_t);
+template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, hipStream_t);
 
 } // namespace bt2g

@@ -287,12 +287,16 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (!reads || !params || (!d_rparams && reads->n_reads) || (!d_results && reads->n_reads)) return fail(c, BT2G_ERR_ARG, "bad argument");
 	if (params->khits < 1 || params->khits > 64) return fail(c, BT2G_ERR_UNSUPPORTED, "-k outside [1,64]");
 	if (params->match_bonus < 0) return fail(c, BT2G_ERR_ARG, "negative match bonus");
+	if (params->maxhalf < 0 || params->maxhalf > 255 || params->gapbar < 1 || params->rdgapo < 0 || params->rdgape < 0 || params->rfgapo < 0 || params->rfgape < 0 ||
+	    params->max_dp_streak < 0 || params->n_seed_rounds < 0 || params->seed_mms < 0 || params->seed_mms > 1)
+		return fail(c, BT2G_ERR_ARG, "alignment parameter out of range (maxhalf 0..255, gapbar >= 1, gap penalties >= 0, -N 0/1)");
+	if (max_read_len == 0) max_read_len = 1;
 	if (reads->n_reads == 0) return 0;
 	if (max_read_len > BT2G_MAX_READ_LEN) max_read_len = BT2G_MAX_READ_LEN;
 	hipStream_t st = (hipStream_t)stream;
 	uint64_t mat_bytes, mask_bytes, arena_stride;
 	if (params->paired && (reads->n_reads & 1u)) return fail(c, BT2G_ERR_ARG, "paired mode needs an even number of reads (mates interleaved)");
-	align_scratch_sizes(max_read_len, params->paired != 0, mat_bytes, mask_bytes, arena_stride);
+	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, mat_bytes, mask_bytes, arena_stride);
 	// persistent waves (one read at a time each) pull reads from a device-side queue
 	uint32_t n_waves = c->n_cu * align_waves_per_cu();
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
@@ -383,8 +387,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	mark(5);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	e = (c->off_size == 4)
-		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, st)
-		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, st);
+		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, max_read_len, st)
+		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, max_read_len, st);
 	if (e != hipSuccess) return hip_fail(c, e, "k_align_reads");
 	mark(6);
 	c->ev_valid = true;

@@ -4,6 +4,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <sys/stat.h>
 
 namespace bt2g {
@@ -22,8 +24,15 @@ struct File {
 		return read(&v, 8);
 	}
 	bool raw(std::vector<uint8_t>& v, uint64_t nbytes) {
+		if (nbytes > remaining()) return false;      // a corrupt header must not turn into a huge allocation
 		v.resize(nbytes);
 		return read(v.data(), nbytes);
+	}
+	uint64_t remaining() {
+		const off_t cur = ftello(f);
+		struct stat st;
+		if (cur < 0 || fstat(fileno(f), &st) != 0 || st.st_size < cur) return 0;
+		return (uint64_t)(st.st_size - cur);
 	}
 };
 
@@ -42,6 +51,7 @@ int load_ebwt(const std::string& p1, const std::string& p2, int off_size, bool f
 	}
 	// Colorspace indexes (flags & 2) and pre-2.0 "each stretch reversed" mirrors are not supported.
 	if (e.flags < 0 && ((-e.flags) & 2)) { err = p1 + ": colorspace index"; return BT2G_ERR_UNSUPPORTED; }
+	if (!fw && !(e.flags < 0 && ((-e.flags) & 4))) { err = p1 + ": mirror index is not an entire-reverse index (built by bowtie2 < 2.0?)"; return BT2G_ERR_UNSUPPORTED; }
 	e.side_sz = 1u << e.line_rate;
 	e.side_bwt_sz = e.side_sz - 4u * (uint32_t)off_size;
 	e.side_bwt_len = e.side_bwt_sz * 4u;
@@ -52,8 +62,8 @@ int load_ebwt(const std::string& p1, const std::string& p2, int off_size, bool f
 	e.ftab_len = (1ull << (2 * e.ftab_chars)) + 1;
 	e.eftab_len = 2ull * (uint64_t)e.ftab_chars;
 	e.offs_len = (e.len + 1 + (1ull << e.off_rate) - 1) >> e.off_rate;
-	if (!f.off(off_size, e.n_pat) || !f.raw(e.plen, e.n_pat * off_size)) { err = p1 + ": truncated plen"; return BT2G_ERR_FORMAT; }
-	if (!f.off(off_size, e.n_frag)) { err = p1 + ": truncated"; return BT2G_ERR_FORMAT; }
+	if (!f.off(off_size, e.n_pat) || e.n_pat > f.remaining() / (uint64_t)off_size || !f.raw(e.plen, e.n_pat * off_size)) { err = p1 + ": truncated plen"; return BT2G_ERR_FORMAT; }
+	if (!f.off(off_size, e.n_frag) || e.n_frag > f.remaining() / (3ull * (uint64_t)off_size)) { err = p1 + ": truncated"; return BT2G_ERR_FORMAT; }
 	if (fw) {
 		if (!f.raw(e.rstarts, e.n_frag * 3 * off_size)) { err = p1 + ": truncated rstarts"; return BT2G_ERR_FORMAT; }
 	} else if (!f.skip(e.n_frag * 3 * off_size)) { err = p1 + ": truncated"; return BT2G_ERR_FORMAT; }
@@ -88,6 +98,7 @@ int load_ref(const std::string& p3, const std::string& p4, int off_size, HostRef
 	if (!f.read(&one, 4) || one != 1 || !f.off(off_size, r.nrecs) || r.nrecs == 0) {
 		err = p3 + ": bad header"; return BT2G_ERR_FORMAT;
 	}
+	if (r.nrecs > f.remaining() / (2ull * (uint64_t)off_size + 1)) { err = p3 + ": truncated"; return BT2G_ERR_FORMAT; }
 	r.rec_refpos.resize(r.nrecs); r.rec_bufpos.resize(r.nrecs); r.rec_len.resize(r.nrecs);
 	uint64_t cumsz = 0, cumlen = 0;
 	for (uint64_t i = 0; i < r.nrecs; i++) {
@@ -122,7 +133,16 @@ uint64_t HostIndex::plen_at(uint64_t i) const {
 	uint64_t v; memcpy(&v, fw.plen.data() + i * 8, 8); return v;
 }
 
+static int load_index_impl(const std::string& base, HostIndex& out, std::string& err);
+
 int load_index(const std::string& base, HostIndex& out, std::string& err) {
+	// no exception may cross the C ABI (bt2g_index_load): allocation failures and length errors become status codes
+	try { return load_index_impl(base, out, err); }
+	catch (const std::bad_alloc&) { err = "out of host memory while reading the index"; return BT2G_ERR_NOMEM; }
+	catch (const std::exception& e) { err = std::string("malformed index: ") + e.what(); return BT2G_ERR_FORMAT; }
+}
+
+static int load_index_impl(const std::string& base, HostIndex& out, std::string& err) {
 	std::string ext = "bt2";
 	out.off_size = 4;
 	if (!exists(base + ".1.bt2")) {

@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
 	opt.to_params(P, info.off_size == 8);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)P.khits);
 	// keep the result records of one batch within ~2 GB (a record holds up to -k alignments of 1.2 KB each)
-	const size_t batch_reads = std::max<size_t>(1024, std::min<size_t>(ex.batch_reads, (size_t)((2ull << 30) / stride)));
+	const size_t batch_reads = std::max<size_t>(2, std::min<size_t>(ex.batch_reads, (size_t)((2ull << 30) / stride)) & ~(size_t)1);   // even: pairs stay together
 
 	// -p: host threads for FASTQ parsing and SAM formatting (the alignment itself is on the device)
 	const unsigned host_threads = opt.threads > 0 ? (unsigned)opt.threads : 1u;

@@ -194,6 +194,7 @@ private:
 		buf_.resize(old + want);
 		int got = gzread(f_, &buf_[old], (unsigned)want);
 		buf_.resize(old + (got > 0 ? (size_t)got : 0));
+		if (got < 0) io_error_ = true;          // corrupt / truncated .gz: the run must fail, not end early (the reference aborts too)
 		if (got <= 0) {
 			if (next_path_ < paths_.size()) {
 				// next file of the list: the previous one ends a line even if its last newline is missing
@@ -212,8 +213,10 @@ private:
 	std::vector<std::string> paths_;
 	size_t next_path_ = 0;
 	bool unterminated_ = false;
+	bool io_error_ = false;
 public:
 	bool last_line_unterminated() const { return unterminated_; }
+	bool io_error() const { return io_error_; }
 	size_t last_raw_len() const { return raw_len_; }      // length of the last line including its terminator (--passthrough)
 private:
 	size_t raw_len_ = 0;
@@ -252,12 +255,14 @@ public:
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
 				if (pt) orig_.append(p, src_.last_raw_len());
-				if (!src_.next(p, n)) { b.last = true; break; }
+				// a record cut short by the end of the file is malformed input (the reference aborts: pat.cpp:1100-1180), not the end of the run
+				const char* trunc = "reads file ends in the middle of a FASTQ record";
+				if (!src_.next(p, n)) { b.bad_input = trunc; b.last = true; break; }
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
 				if (pt) orig_.append(p, src_.last_raw_len());
-				if (!src_.next(p, n)) { b.last = true; break; }            // '+' line
+				if (!src_.next(p, n)) { b.bad_input = trunc; b.last = true; break; }            // '+' line
 				if (pt) orig_.append(p, src_.last_raw_len());
-				if (!src_.next(p, n)) { b.last = true; break; }
+				if (!src_.next(p, n)) { b.bad_input = trunc; b.last = true; break; }
 				r.qual_off = arena_.size(); r.qual_len = n; arena_.append(p, n); r.has_qual = true;
 				if (pt) orig_.append(p, src_.last_raw_len());
 			} else if (opt_.format == 1) {             // FASTA: '>' name, sequence possibly over several lines
@@ -483,6 +488,7 @@ public:
 		});
 		for (size_t i = 0; i < nrec; i++) if (rlen[i] > max_read_len) { b.too_long = b.reads[i].name.str(); break; }
 		if (b.bad_input.empty()) for (const HostBatch::Chunk& ch : b.chunks) if (!ch.error.empty()) { b.bad_input = ch.error; break; }
+		if (b.bad_input.empty() && src_.io_error()) b.bad_input = "error while reading the reads file (corrupt or truncated compressed input?)";
 		t_pack += tnow() - t2_;
 	}
 private:
