@@ -467,6 +467,10 @@ def main():
         e0, e1 = ev(), ev()
         e0.record()
         res, stride = ctx.align_batch(batch, rp_t, P, args.readlen)
+        if dist is not None:
+            # N-GPU path: the per-GPU result records are cut to size and merged on rank 0 over RCCL (the only exchange of the job)
+            packed, offs = ctx.results_pack(res, n, P.khits)
+            last["gathered"] = shard.gather_packed(dist, packed, int(offs[n].item()), dev)
         e1.record()
         if record:
             stage_events.append((e0, e1))
@@ -554,6 +558,7 @@ def main():
                 "stages_timed": "one bt2g_align_batch per step = the whole per-read worker: k_exact_sweep, k_one_mm, k_seed_search_exact, k_extend_hits (lane-per-task FM kernels) then k_align_reads "
                                 "(rank+prioritise, offset resolution, re-seeding, SW fill + backtrace, -M reporting)",
                 "not_in_timed_region": "FASTQ parse and SAM text formatting (host side, SURVEY.md 8f)",
+                "n_gpu_merge": None if world == 1 else "every step also packs the result records (bt2g_results_pack) and gathers them to rank 0 over RCCL: %d bytes arrived on rank 0 in the last step" % sum(int(t.numel()) for t in last["gathered"]),
                 "fraction_aligned": all_aligned / float(world * n),
                 "index_bytes_hbm": int(info.hbm_bytes), "side_sz": int(side), "off_size": int(off_sz),
                 "index_build": build_info,
@@ -561,7 +566,7 @@ def main():
                 "backtraces_per_read": float(h["n_bt_attempts"].sum()) / n,
                 "reads_overflowed": int((h["status"] != 0).sum()),
                 "worker_phase_us_per_read": dict(zip(["sweep", "mm1", "seeds", "rank_prioritise", "resolve", "dp_fill", "backtrace", "whole_read", "gather_cells", "report", "ungapped",
-                                                      "bt_tile_fetch", "gather_lastrow", "gather_zero_masks", "red_overlap", "red_add", "sink_report"],
+                                                      "bt_tile_fetch", "gather_lastrow", "gather_zero_masks", "prioritize_collect_extend", "prioritize_row_sampling", "sink_report"],
                                                      [round(prof[i] / 100.0 / max(1, prof[9]), 1) for i in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 16, 17, 18, 19, 20, 21)])),
                 "worker_counts_per_read": {"bt_steps": prof[13] / max(1, prof[9]), "bt_tiles": prof[14] / max(1, prof[9]), "cand_cells": prof[15] / max(1, prof[9])},
                 "kernel_ms_per_step": {k: round(v, 3) for k, v in kavg.items()}, "batch_ms_events": round(batch_ms, 3),

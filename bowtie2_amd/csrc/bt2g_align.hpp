@@ -42,7 +42,7 @@ constexpr int kMaxEdits    = 200;
 constexpr int kMaxRedAnchor = 192;  // alignments remembered by the paired-end redundancy set
 constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at most 51)
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
-constexpr int kListArena   = 16384; // uint32 slots for Random1toN lists
+constexpr int kListArena   = 65536; // uint32 slots for Random1toN lists (swap lists of small ranges, seen lists bounded by max_iters, converted lists)
 constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
 constexpr int kMaxCols     = 1100;  // DP columns: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*15
 
@@ -159,9 +159,10 @@ struct HotWork {
 	uint8_t  sorted[2][kMaxOffs];
 	uint8_t  rank_offs[kMaxRanges];
 	uint8_t  rank_fw[kMaxRanges];
-	union {                    // never live at the same time: the gather reads `lastrow` before any backtrace writes `ned`
+	union {                    // never live at the same time: the gather reads `lastrow` before any backtrace writes `ned`; RowSampler state only exists inside prioritize()
 		Edit     ned[kMaxEdits];   // edits of the backtrace in progress
 		int16_t  lastrow[kMaxCols + 8];   // scores of the last DP row, clamped at -32768 (gatherCells)
+		struct { double prefix[kMaxRanges]; uint8_t elim[kMaxRanges]; } samp;   // RowSampler: running sums of the masses not yet eliminated
 	};
 	// ---- scalar control state of the read in flight (everything the control code touches often) ----
 	uint32_t len;
@@ -245,11 +246,29 @@ struct Work {
 	// ---- status / metrics ----
 };
 
-// DP scratch of one wave: wavefront-major H/E/F matrix + per-cell backtrace masks + row flags
+// DP scratch of one wave.  Two matrix formats:
+//  * end-to-end 8-bit mode (the common case): ONE BYTE per cell holding which predecessors are score-consistent
+//    (PB_* below), computed while the cell is filled -- the backtrace never looks at scores again.  Diagonal-major
+//    (pred_idx): a run of diagonal steps reads consecutive bytes.  Its per-cell backtrace masks (`pmask`, 32 bits) carry an
+//    epoch tag instead of being cleared for every DP;
+//  * 16-bit end-to-end and local mode: wavefront-major packed H|E|F cells (dp_cell) + a 16-bit mask plane that is zeroed
+//    after every fill that has candidate cells.
 struct DpScratch {
-	uint32_t* mat;      // packed cells, see dp_cell()
-	uint16_t* masks;    // [rows][cols], zeroed after every fill that has candidate cells
+	uint32_t* mat;      // pred bytes (8-bit end-to-end) or packed cells
+	uint16_t* masks;    // [rows][cols] masks of the packed-cell formats
+	uint32_t* pmask;    // masks of the pred format: bits 0-12 as SSEMatrix::masks_, bits 13-31 = epoch of the DP that wrote them
+	uint32_t* epoch;    // -> epoch of the DP currently in this scratch (lives in the arena, survives launches)
+	uint32_t  pmask_words;
 };
+// predecessor bits of one cell (aligner_swsse_ee_u8.cpp:1330-1520 asks these questions during the backtrace):
+//  HD: H came diagonally;  HE / HF: H equals E / F of the cell and gaps are allowed in this row;
+//  EO / EE: E opens from H-left / extends E-left;  FO / FE: F opens from H-up / extends F-up
+enum { PB_HD = 1, PB_HE = 2, PB_HF = 4, PB_EO = 8, PB_EE = 16, PB_FO = 32, PB_FE = 64 };
+constexpr uint32_t kEpochShift = 13, kEpochMax = (1u << 19) - 1;
+constexpr uint32_t kPredTile = 64;   // diagonal steps one tile fetch covers
+BT2_HD uint32_t pred_rp(uint32_t rows) { return (rows + 63u) & ~63u; }
+BT2_HD uint64_t pred_idx(uint32_t rows, uint32_t i, uint32_t j) { return (uint64_t)(j + rows - 1 - i) * pred_rp(rows) + i; }
+BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { return (uint64_t)(rows + cols) * pred_rp(rows); }
 
 // ---------------------------------------------------------------------------------------
 // small helpers

@@ -29,6 +29,8 @@ struct Aligner {
 	const PreComp* pre;  // batch pre-computation (may be null)
 	uint32_t ridx;       // index of this read in the batch
 	bool ext_pre;        // HOT.hits came from pre->seeds, so pre->ext holds their extensions
+	const uint32_t* pre_ext_cur = nullptr;    // extension / resolved-offset tables of the seed round in HOT.hits
+	const uint64_t* pre_joff_cur = nullptr;
 	uint32_t pf_steps = 0, pf_tiles = 0;   // profile: backtrace steps / tile fetches of this read
 	uint64_t pf_tile_t = 0;
 
@@ -37,6 +39,10 @@ struct Aligner {
 	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, ReadParams& rp_, Work& w_, DpScratch dp_,
 	               const PreComp* pre_ = nullptr, uint32_t ridx_ = 0)
 		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_), pre(pre_), ridx(ridx_), ext_pre(false), m_nofw(P_.nofw != 0), m_norc(P_.norc != 0), cands_cur(w_.cands) {}
+
+	// a fixed-capacity buffer is full: flag the read (its result is not passed off as the reference's) and remember which site
+	// noticed first (result record field pad2: diagnostics only)
+	BT2_HD void ovf(uint32_t site) { if (!(HOT.err & ERR_OVERFLOW)) HOT.err |= site << 8; HOT.err |= ERR_OVERFLOW; }
 
 	// exact_sweep() from the batch kernel's output
 	BT2_HD uint64_t exact_sweep_pre(uint32_t mine[2]) {
@@ -70,20 +76,20 @@ struct Aligner {
 		return true;
 	}
 
-	// seed_round(0, interval, seedlen) from the batch kernel's output
-	BT2_HD uint32_t seed_round_pre(uint32_t interval, uint32_t seedlen) {
+	// seed_round(offset, interval, seedlen) from the batch kernels' output (`src_all`: the [n_reads][2][max_seeds] table of this round)
+	BT2_HD uint32_t seed_round_pre(const bt2g_seed_hit* src_all, uint32_t offset, uint32_t interval, uint32_t seedlen) {
 		const uint32_t len = HOT.len;
 		uint32_t nseeds = 1;
-		if ((int64_t)len > (int64_t)seedlen) nseeds += (len - seedlen) / interval;
-		if (nseeds > (uint32_t)kMaxOffs) { HOT.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
+		if ((int64_t)len - (int64_t)offset > (int64_t)seedlen) nseeds += (len - offset - seedlen) / interval;
+		if (nseeds > (uint32_t)kMaxOffs) { ovf(1); nseeds = kMaxOffs; }
 		HOT.num_offs = nseeds;
 		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
 		HOT.n_rank = 0;
-		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i;
+		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i + offset;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
 			const bool skip = (fw && m_nofw) || (!fw && m_norc);
-			const bt2g_seed_hit* src = pre->seeds + ((uint64_t)ridx * 2 + fwi) * pre->max_seeds;
+			const bt2g_seed_hit* src = src_all + ((uint64_t)ridx * 2 + fwi) * pre->max_seeds;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				HotHit& h = HOT.hits[fwi][i];
 				HOT.sorted[fwi][i] = 0;
@@ -226,7 +232,7 @@ struct Aligner {
 	}
 
 	BT2_HD void add_mm1(const Mm1Hit& m, bool fw) {
-		if (HOT.n_mm1 >= (uint32_t)kMaxMm1) { HOT.err |= ERR_OVERFLOW; return; }
+		if (HOT.n_mm1 >= (uint32_t)kMaxMm1) { ovf(2); return; }
 		EEHit& h = w.mm1[HOT.n_mm1++];
 		h.top = m.top; h.bot = m.bot; h.score = m.score;
 		h.epos = m.epos; h.echr = m.echr; h.eqchr = m.eqchr;
@@ -241,7 +247,7 @@ struct Aligner {
 		uint32_t L = seedlen < len ? seedlen : len;
 		uint32_t nseeds = 1;
 		if ((int64_t)len - (int64_t)offset > (int64_t)seedlen) nseeds += (len - offset - seedlen) / interval;
-		if (nseeds > (uint32_t)kMaxOffs) { HOT.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
+		if (nseeds > (uint32_t)kMaxOffs) { ovf(3); nseeds = kMaxOffs; }
 		HOT.num_offs = nseeds;
 		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
 		HOT.n_rank = 0;
@@ -323,7 +329,7 @@ struct Aligner {
 		const uint32_t L = seedlen < len ? seedlen : len;
 		uint32_t nseeds = 1;
 		if ((int64_t)len - (int64_t)offset > (int64_t)seedlen) nseeds += (len - offset - seedlen) / interval;
-		if (nseeds > (uint32_t)kMaxOffs) { HOT.err |= ERR_OVERFLOW; nseeds = kMaxOffs; }
+		if (nseeds > (uint32_t)kMaxOffs) { ovf(4); nseeds = kMaxOffs; }
 		HOT.num_offs = nseeds;
 		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
 		HOT.n_rank = 0;
@@ -344,7 +350,7 @@ struct Aligner {
 				const uint32_t first = nsr;
 				uint64_t elts = 0;
 				auto report = [&](TOff topf, TOff botf, TOff topb) {
-					if (nsr >= (uint32_t)kMaxSat2) { HOT.err |= ERR_OVERFLOW; return; }
+					if (nsr >= (uint32_t)kMaxSat2) { ovf(5); return; }
 					SeedRange& r = w.sranges[nsr++];
 					r.topf = topf; r.topb = topb; r.size = (uint32_t)(botf - topf);
 					elts += (uint64_t)(botf - topf);
@@ -481,7 +487,7 @@ struct Aligner {
 		if (P.all_hits) {
 			// rankSeedHits(all = true): no random draws; offsets 1.. first (fw then rc), offset 0 last (aligner_seed.h:1020-1038)
 			auto push = [&](uint32_t i, bool fw) {
-				if (HOT.n_rank >= (uint32_t)kMaxRanges) { HOT.err |= ERR_OVERFLOW; return; }
+				if (HOT.n_rank >= (uint32_t)kMaxRanges) { ovf(6); return; }
 				HOT.rank_offs[HOT.n_rank] = (uint8_t)i; HOT.rank_fw[HOT.n_rank] = fw ? 1 : 0; HOT.n_rank++;
 			};
 			for (uint32_t i = 1; i < HOT.num_offs; i++) for (int fwi = 0; fwi < 2; fwi++) if (HOT.hits[fwi][i].size > 0) push(i, fwi == 0);
@@ -530,7 +536,7 @@ struct Aligner {
 	BT2_HD void r1n_set_done(R1N& r) { r.cur = r.n; }
 	BT2_HD void r1n_init_seq(R1N& r, uint32_t n) { r1n_reset(r); r.sz = r.n = n; r.swaplist = 2; r.inited = 1; }
 	BT2_HD uint32_t lists_alloc(uint32_t n) {
-		if (HOT.lists_used + n > (uint32_t)kListArena) { HOT.err |= ERR_OVERFLOW; return 0; }
+		if (HOT.lists_used + n > (uint32_t)kListArena) { ovf(7); return 0; }
 		const uint32_t o = HOT.lists_used;
 		HOT.lists_used += n;
 		return o;
@@ -552,7 +558,9 @@ struct Aligner {
 			return l[r.cur++];
 		}
 		// seen-list mode (n >= 128)
-		if (r.seen_len == 0 && r.cur == 0) { r.seen_off = lists_alloc(r.thresh + 1); }
+		// the seen list can never hold more entries than rows are drawn for one read (max_iters), however large the range:
+		// a 100 000-row repeat range has thresh = 10 000 but is asked for a few hundred rows at most
+		if (r.seen_len == 0 && r.cur == 0) { const uint32_t cap = (uint32_t)P.max_iters + 2; r.seen_off = lists_alloc(r.thresh + 1 < cap ? r.thresh + 1 : cap); }
 		uint32_t* seen = w.lists + r.seen_off;
 		const uint32_t seen_sz = r.seen_len;
 		uint32_t rn = 0;
@@ -562,6 +570,7 @@ struct Aligner {
 			again = false;
 			for (uint32_t i = 0; i < seen_sz; i++) if (seen[i] == rn) { again = true; break; }
 		}
+		{ const uint32_t cap = (uint32_t)P.max_iters + 2; if (r.seen_len >= (r.thresh + 1 < cap ? r.thresh + 1 : cap)) { ovf(29); r.cur++; return rn; } }
 		seen[r.seen_len++] = rn;
 		r.cur++;
 		if (r.seen_len >= r.thresh && r.cur < r.n) {
@@ -601,6 +610,17 @@ struct Aligner {
 		HotRd rd;
 		fm_extend_hit(ix, rd, HOT.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt, (P.do_extend & 2) == 0);
 		HOT.n_bwops_ext += cnt.bwops; HOT.n_sides += cnt.sides;
+#ifdef BT2G_CHECK_EXTEND_TEXT
+		// test builds: the text-comparison form the batch kernel uses for one-row hits must agree with the LF walk
+		if (botf - topf == 1) {
+			uint32_t st_ = 0, l2 = 0, r2 = 0;
+			const TOff jo = get_offset(ix.fw, topf, st_);
+			if ((uint64_t)jo < (uint64_t)ix.fw.len) {
+				fm_extend_hit_text(ix, rd, HOT.len, (uint64_t)jo, fw, off, len, l2, r2, (P.do_extend & 2) == 0);
+				if (l2 != nlex || r2 != nrex) { fprintf(stderr, "extend mismatch: LF %u/%u text %u/%u\n", nlex, nrex, l2, r2); abort(); }
+			}
+		}
+#endif
 	}
 
 	// SATupleAndPos::operator< (aligner_sw_driver.h:150-160)
@@ -628,7 +648,7 @@ struct Aligner {
 		const uint64_t tot = szfw + szrc;
 		bool done = false;
 		auto add = [&](const EEHit& hit, int ee_idx, uint64_t top, uint64_t width) {
-			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; done = true; return; }
+			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(8); done = true; return; }
 			SatPos& s = w.satpos[HOT.n_satpos++];
 			s.topf = top; s.topb = (uint64_t)kOffMask; s.size = (uint32_t)width; s.orig_sz = (uint32_t)width;
 			s.fw = hit.fw; s.offidx = 0; s.rdoff = 0; s.seedlen = HOT.len; s.nlex = s.nrex = 0;
@@ -706,6 +726,7 @@ struct Aligner {
 		const uint32_t nsm = 5;
 		HOT.n_satpos = 0; HOT.n_satpos2 = 0; HOT.lists_used = 0;
 		uint64_t nrange = 0, nelt = 0, nsmall = 0, nsmall_elts = 0;
+		const uint64_t th_ = now();
 		for (uint32_t i = 0; i < HOT.n_rank; i++) {
 			const bool fw = HOT.rank_fw[i] != 0;
 			const uint32_t offidx = HOT.rank_offs[i];
@@ -729,7 +750,7 @@ struct Aligner {
 				}
 				if (skip) { nrange--; nelt -= sz; continue; }
 			}
-			if (HOT.n_satpos2 >= (uint32_t)kMaxSat2) { HOT.err |= ERR_OVERFLOW; break; }
+			if (HOT.n_satpos2 >= (uint32_t)kMaxSat2) { ovf(9); break; }
 			SatPos& s = w.satpos2[HOT.n_satpos2++];
 			s.topf = h_topf; s.topb = h_topb; s.size = (uint32_t)sz; s.orig_sz = (uint32_t)sz;
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
@@ -737,7 +758,7 @@ struct Aligner {
 			uint32_t nlex = 0, nrex = 0;
 			if (P.do_extend) {
 				if (ext_pre && seedmms == 0) {
-					const uint32_t e = pre->ext[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + offidx];
+					const uint32_t e = pre_ext_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + offidx];
 					nlex = e & 0xffffu; nrex = e >> 16;
 				} else extend_hit((TOff)h_topf, (TOff)(h_topf + sz), (TOff)h_topb, (TOff)(h_topb + sz), fw, rdoff, seedlen, nlex, nrex);
 			}
@@ -752,11 +773,12 @@ struct Aligner {
 					range[nr].len = seedlen + nlex + nrex;
 					range[nr].sz = (uint32_t)sz;
 					nr++;
-				} else HOT.err |= ERR_OVERFLOW;
+				} else ovf(10);
 			}
 		}
 		}
 		nelt_out = nelt;
+		HOT.t_phase[17] += now() - th_;       // profile: range collection incl. seed-hit extension that was not pre-computed
 		// satpos.sort()
 		// (operator< is a total order over the ranges of one read, so any sorting algorithm gives the reference's order;
 		// -N 1 can produce thousands of ranges, hence the gapped passes before the final insertion pass)
@@ -776,7 +798,7 @@ struct Aligner {
 			// prioritizeSATupsIdxs (aligner_sw_driver.cpp:741-866): every range in sorted order until maxelt elements are in
 			uint64_t added = 0;
 			for (uint32_t j = 0; j < HOT.n_satpos2 && added < maxelt; j++) {
-				if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; break; }
+				if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(11); break; }
 				SatPos& s = w.satpos[HOT.n_satpos++];
 				s = w.satpos2[j];
 				r1n_init_seq(s.rnd, s.size);
@@ -788,7 +810,7 @@ struct Aligner {
 		uint64_t nelt_added = 0;
 		// 1. the smalls, whole
 		for (uint64_t j = 0; j < nsmall && nelt_added < maxelt; j++) {
-			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; break; }
+			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(12); break; }
 			SatPos& s = w.satpos[HOT.n_satpos++];
 			s = w.satpos2[j];
 			r1n_init(s.rnd, s.size, P.all_hits != 0);
@@ -808,25 +830,39 @@ struct Aligner {
 			HOT.mass += w.masses[i - sai];
 		}
 		for (uint32_t j = 0; j < HOT.n_satpos2; j++) r1n_reset(w.rands2[j]);
+		// With at most kMaxRanges candidates (always, for -N 0) the sampler keeps the running sums of the masses that are still
+		// in play on chip: the sums are formed by the same left-to-right additions as RowSampler::next's scan, so "first index
+		// whose running sum exceeds rd" is the same index -- found by all lanes at once instead of a chain of dependent loads.
+		const bool fast = HOT.n_masses <= (uint32_t)kMaxRanges;
+		auto rebuild = [&]() {
+			double acc = 0.0;
+			for (uint32_t i = 0; i < HOT.n_masses; i++) { if (!w.elim[i]) acc += w.masses[i]; HOT.samp.prefix[i] = acc; HOT.samp.elim[i] = w.elim[i]; }
+		};
+		if (fast) rebuild();
+		const uint64_t ts_ = now();
 		while (nelt_added < maxelt && nelt_added < nelt) {
 			// RowSampler::next
 			const double rd = (double)(rnd.nextFloat() * HOT.mass);
-			double mass_sofar = 0.0;
-			uint32_t pick = 0xffffffffu, last_unelim = 0xffffffffu;
-			for (uint32_t i = 0; i < HOT.n_masses; i++) {
-				if (!w.elim[i]) {
-					last_unelim = i;
-					mass_sofar += w.masses[i];
-					if (rd < mass_sofar) { pick = i; break; }
+			uint32_t pick = 0xffffffffu;
+			if (fast) pick = Plat::pick_mass(HOT.samp.prefix, HOT.samp.elim, HOT.n_masses, rd);
+			else {
+				double mass_sofar = 0.0;
+				uint32_t last_unelim = 0xffffffffu;
+				for (uint32_t i = 0; i < HOT.n_masses; i++) {
+					if (!w.elim[i]) {
+						last_unelim = i;
+						mass_sofar += w.masses[i];
+						if (rd < mass_sofar) { pick = i; break; }
+					}
 				}
+				if (pick == 0xffffffffu) pick = last_unelim;
 			}
-			if (pick == 0xffffffffu) pick = last_unelim;
 			const uint32_t ri = pick + sai;
 			R1N& r2 = w.rands2[ri];
 			if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, P.all_hits != 0);
 			const uint32_t r = r1n_next(r2);
-			if (r1n_done(r2)) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; }
-			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { HOT.err |= ERR_OVERFLOW; break; }
+			if (r1n_done(r2)) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; if (fast) rebuild(); }
+			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(13); break; }
 			SatPos& s = w.satpos[HOT.n_satpos++];
 			s = w.satpos2[ri];
 			s.topf = w.satpos2[ri].topf + r;
@@ -835,6 +871,7 @@ struct Aligner {
 			r1n_init(s.rnd, 1, P.all_hits != 0);
 			nelt_added++;
 		}
+		HOT.t_phase[18] += now() - ts_;       // profile: the row-sampling loop
 		nelt_out = nelt_added;
 	}
 
@@ -851,7 +888,7 @@ struct Aligner {
 		return false;
 	}
 	BT2_HD void diag_add_m(int32_t ref, int64_t off, bool fw, int64_t len, int mate) {
-		if (HOT.n_diags >= (uint32_t)kMaxDiags) { HOT.err |= ERR_OVERFLOW; return; }
+		if (HOT.n_diags >= (uint32_t)kMaxDiags) { ovf(14); return; }
 		DiagIval& d = w.diags[HOT.n_diags++];
 		d.ref = ref; d.off = off; d.orient = (fw ? 1 : 0) | (mate << 1); d.len = len;
 	}
@@ -930,7 +967,7 @@ struct Aligner {
 	// D. sink (AlnSinkWrap::report, ReportingState::foundUnpaired; aln_sink.cpp:103-130,1395-1445)
 	// =================================================================================
 	BT2_HD bool sink_report(const AlnRes& r) {
-		if (HOT.n_alns < (uint32_t)kMaxAlns) Plat::copy_aln(w.alns[HOT.n_alns], r); else HOT.err |= ERR_OVERFLOW;
+		if (HOT.n_alns < (uint32_t)kMaxAlns) Plat::copy_aln(w.alns[HOT.n_alns], r); else ovf(15);
 		HOT.n_alns++;
 		if (!HOT.done_unpair1) {
 			// ReportingState::areDone
@@ -962,7 +999,7 @@ struct Aligner {
 		const uint64_t tl_ = now();
 		uint32_t nc;
 		if (mode != 2) {
-			Plat::load_last_row(dp.mat, R, rows, cols, mode != 0);
+			if (mode != 0) Plat::load_last_row(dp.mat, R, rows, cols, true);      // the 8-bit fill leaves the last row in HOT.lastrow itself
 			HOT.t_phase[15] += now() - tl_;
 			// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
 			nc = Plat::gather_sort(cand_list(), (uint32_t)kMaxCands, rows, cols, minsc_dp);
@@ -973,9 +1010,18 @@ struct Aligner {
 			const uint32_t minrow = (uint32_t)(((minsc_dp + bonus - 1) / bonus) - 1);
 			nc = Plat::gather_local(dp.mat, cand_list(), (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow, w.cand_hist);
 		}
-		if (nc > (uint32_t)kMaxCands) { HOT.err |= ERR_OVERFLOW; HOT.n_cands = kMaxCands; } else HOT.n_cands = nc;
+		if (nc > (uint32_t)kMaxCands) { ovf(16); HOT.n_cands = kMaxCands; } else HOT.n_cands = nc;
 		HOT.t_phase[13] += HOT.n_cands;      // profile: candidate cells
-		if (HOT.n_cands > 0) { const uint64_t tz_ = now(); Plat::zero_masks(dp.masks, rows * cols); HOT.t_phase[16] += now() - tz_; }   // SSEMatrix::initMasks, eagerly
+		if (HOT.n_cands > 0) {      // SSEMatrix::initMasks
+			const uint64_t tz_ = now();
+			if (mode == 0) {
+				// pred format: a new epoch invalidates every mask word of earlier DPs; the plane is only cleared when the tag wraps
+				uint32_t e = Plat::uni(*dp.epoch) + 1;
+				if (e > kEpochMax) { Plat::zero_u32(dp.pmask, dp.pmask_words); e = 1; }
+				Plat::set_epoch(dp.epoch, e);
+			} else Plat::zero_masks(dp.masks, rows * cols);
+			HOT.t_phase[16] += now() - tz_;
+		}
 	}
 
 	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
@@ -990,6 +1036,8 @@ struct Aligner {
 		const bool fw = Plat::uni((int)fw_) != 0;
 		// cell format: 0 = e2e 8-bit (bias 0xff), 1 = e2e 16-bit (bias 0x7fff), 2 = local (16-bit fields holding plain scores, floor 0)
 		constexpr bool wide = MODE != 0, local = MODE == 2;
+		constexpr bool pred = MODE == 0;                 // 8-bit end-to-end: one byte of predecessor bits per cell (PB_*), tile = kPredTile diagonal steps
+		constexpr uint32_t tile_len = pred ? kPredTile : kBtTile;
 		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
 		uint32_t row = Plat::uni(row_), col = Plat::uni(col_);
 		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
@@ -1000,7 +1048,8 @@ struct Aligner {
 		const uint32_t R = dp_R(rows);
 		// `this` lives in private memory: read what the loop needs once, into scalar registers
 		DpScratch dpl;
-		dpl.mat = Plat::uni_ptr(dp.mat); dpl.masks = Plat::uni_ptr(dp.masks);
+		dpl.mat = Plat::uni_ptr(dp.mat); dpl.masks = Plat::uni_ptr(dp.masks); dpl.pmask = Plat::uni_ptr(dp.pmask); dpl.epoch = Plat::uni_ptr(dp.epoch); dpl.pmask_words = 0;
+		const uint32_t epoch = pred ? Plat::uni(*dpl.epoch) : 0u;
 		BtFrame* const btstack = Plat::uni_ptr(&w.btstack[0]);
 		struct Prof {      // profile counters stay in registers until the function returns
 			Aligner& a; uint32_t steps, tiles; uint64_t tile_t;
@@ -1013,7 +1062,7 @@ struct Aligner {
 		// the walk moves left from the start column by at most rows + gaps columns: three registers (768 columns) ending
 		// at the start column cover it even when an opposite-mate window is wider than that
 		const uint32_t rf_c0 = WIN ? ((col + 1 - 768u + 3u) & ~3u) : 0u;   // `col` is still the start column here
-		if (rf_c0 > 0 && rows + 250u > 764u) { HOT.err |= ERR_OVERFLOW; return false; }   // the walk could leave the 768-column window (rows + read gaps)
+		if (rf_c0 > 0 && rows + 250u > 764u) { ovf(17); return false; }   // the walk could leave the 768-column window (rows + read gaps)
 		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64 + (rf_c0 >> 2));
 		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
 			const uint32_t word = idx >> 2;
@@ -1049,12 +1098,45 @@ struct Aligner {
 			int empty = 0, can_move_thru = 1, branch = 0;
 			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
 			prof.steps++;
-			if (td >= kBtTile) { const uint64_t tt_ = now(); Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi); td = 0; prof.tiles++; prof.tile_t += now() - tt_; }
-			const uint32_t mk0 = Plat::lane(tile, 48 + td) & 0xffffu;
+			if (td >= tile_len) {
+				const uint64_t tt_ = now();
+				if (pred) Plat::bt_tile_pred(dpl, rows, row, col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
+				td = 0; prof.tiles++; prof.tile_t += now() - tt_;
+			}
+			const uint32_t mk0 = pred ? Plat::lane(tile_hi, td) : (Plat::lane(tile, 48 + td) & 0xffffu);
 			uint32_t mk = mk0;
 			if (mk0 & 1) {                    // reportedThrough
 				can_move_thru = 0;
 			} else if (row > 0) {
+				int mask, orig_mask, sel = -1;
+				if (pred) {
+					// the fill already answered "which predecessors are score-consistent" (PB_* bits, gap barrier folded in)
+					const int pb = (int)Plat::lane(tile, td);
+					if (ct == 1) {
+						mask = (pb >> 3) & 3;
+						orig_mask = mask;
+						if (mk & (1u << 7)) mask = (int)((mk >> 8) & 3);
+						branch = (int)(mask == 3);
+						if (mask != 0) { cur = (mask == 2) ? 4 : 3; mk = (mk & ~(7u << 7)) | (1u << 7) | (branch ? (2u << 8) : 0u); sel = 0; }
+					} else if (ct == 2) {
+						mask = (pb >> 5) & 3;
+						orig_mask = mask;
+						if (mk & (1u << 10)) mask = (int)((mk >> 11) & 3);
+						branch = (int)(mask == 3);
+						if (mask != 0) { cur = (mask == 2) ? 2 : 1; mk = (mk & ~(7u << 10)) | (1u << 10) | (branch ? (2u << 11) : 0u); sel = 0; }
+					} else {
+						const int he = (pb >> 1) & 1, hf = (pb >> 2) & 1;
+						mask = (hf & (pb >> 5) & 1) | ((he & (pb >> 3) & 1) << 1) | ((hf & (pb >> 6) & 1) << 2) | ((he & (pb >> 4) & 1) << 3) | ((pb & 1) << 4);
+						orig_mask = mask;
+						if (mk & (1u << 1)) mask = (int)((mk >> 2) & 31);
+						if (mask != 0) {
+							sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
+							branch = (int)((mask & (mask - 1)) != 0);
+							mk = (mk & ~(31u << 1)) | (1u << 1) | (branch ? (uint32_t)(mask & ~(1 << sel)) << 2 : 0u);
+							cur = (int)((0x04231u >> (4 * sel)) & 7);
+						}
+					}
+				} else {
 				const uint32_t row_from_end = rows - row - 1;
 				const int ga = (int)(row >= (uint32_t)S.gapbar) & (int)(row_from_end >= (uint32_t)S.gapbar);     // gaps allowed
 				auto cell = [&](uint32_t ln) -> uint64_t { return (uint64_t)Plat::lane(tile, ln) | (wide ? (uint64_t)Plat::lane(tile_hi, ln) << 32 : 0ull); };
@@ -1067,7 +1149,6 @@ struct Aligner {
 				auto Fc = [&](uint64_t c) -> int { return local ? (int)((c >> 32) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 32) & 0xffff) : (int)((c >> 16) & 0xff); };
 				auto fl = [&](int v) -> int { return local ? (int)(v > 0) : 1; };    // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
 				const int hasl = (int)(col > 0);
-				int mask, orig_mask, sel = -1;
 				if (ct == 1) {          // E: came from the left (H-left open = bit 0, E-left extend = bit 1)
 					const int sc_cur = Ec(c_cur) + offsetsc, sc_h_left = Hc(c_left) + offsetsc, sc_e_left = Ec(c_left) + offsetsc;
 					mask = (fl(sc_h_left) & (int)(sc_h_left - S.rdgapo == sc_cur)) | ((fl(sc_e_left) & (int)(sc_e_left - S.rdgape == sc_cur)) << 1);
@@ -1103,13 +1184,17 @@ struct Aligner {
 						cur = (int)((0x04231u >> (4 * sel)) & 7);          // sel 0,1,2,3,4 -> cur 1,3,2,4,0
 					}
 				}
+				}
 				if (sel < 0) { empty = 1; can_move_thru = (int)(orig_mask == 0); }
 			}
 			mk |= 1;                         // setReportedThrough
-			if (mk != mk0) dpl.masks[(uint64_t)row * cols + col] = (uint16_t)mk;
+			if (mk != mk0) {
+				if (pred) dpl.pmask[pred_idx(rows, row, col)] = mk | (epoch << kEpochShift);
+				else dpl.masks[(uint64_t)row * cols + col] = (uint16_t)mk;
+			}
 			if (!can_move_thru) {
 				if (nstack > 0) {
-					td = kBtTile;            // resume elsewhere: the tile is stale
+					td = tile_len;           // resume elsewhere: the tile is stale
 					const BtFrame& f = btstack[--nstack];
 					const uint32_t cz_ = Plat::uni(f.celsz);
 					ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31); nned = Plat::uni(f.nedsz);
@@ -1126,15 +1211,15 @@ struct Aligner {
 				break;
 			}
 			if (branch) {
-				if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { HOT.err |= ERR_OVERFLOW; return false; }
+				if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { ovf(18); return false; }
 				BtFrame& f = btstack[nstack++];
 				f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
 				f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
 				f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
 			}
-			if (ncells >= (uint32_t)(kMaxLen + 64)) { HOT.err |= ERR_OVERFLOW; return false; }
+			if (ncells >= (uint32_t)(kMaxLen + 64)) { ovf(19); return false; }
 			olap |= in_core(row, col); ncells++;
-			if (nned + 1 >= (uint32_t)kMaxEdits) { HOT.err |= ERR_OVERFLOW; return false; }
+			if (nned + 1 >= (uint32_t)kMaxEdits) { ovf(20); return false; }
 			switch (cur) {
 				case 0: {   // diagonal
 					const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
@@ -1155,7 +1240,7 @@ struct Aligner {
 					Edit& e = ned[nned++];
 					e.pos = (uint16_t)row; e.chr = '-'; e.qchr = code2chr(readc); e.type = EDIT_REF_GAP;
 					row--;
-					td = kBtTile;
+					td = tile_len;
 					ct = (cur == 1) ? 0 : 2;
 					score -= (cur == 1) ? S.rfgapo : S.rfgape;
 					gaps++; ref_gaps++;
@@ -1165,7 +1250,7 @@ struct Aligner {
 					Edit& e = ned[nned++];
 					e.pos = (uint16_t)(row + 1); e.chr = (uint8_t)mask2chr(refm); e.qchr = '-'; e.type = EDIT_READ_GAP;
 					col--;
-					td = kBtTile;
+					td = tile_len;
 					ct = (cur == 3) ? 0 : 1;
 					score -= (cur == 3) ? S.rdgapo : S.rdgape;
 					gaps++; read_gaps++;
@@ -1176,7 +1261,7 @@ struct Aligner {
 		if (!olap) return false;
 		{
 			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
-			if (col < rf_c0) { HOT.err |= ERR_OVERFLOW; return false; }
+			if (col < rf_c0) { ovf(21); return false; }
 			const int refm = byte_of(rfw, 3, col - rf_c0);
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) {
@@ -1295,8 +1380,12 @@ struct Aligner {
 				if (dom) { HOT.cural++; continue; }
 			}
 			typename Plat::LaneReg tile, tile_hi;
-			{ const uint64_t tt_ = now(); Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col, wide, tile, tile_hi); pf_tiles++; pf_tile_t += now() - tt_; }    // also the first tile of the backtrace
-			if (Plat::lane(tile, 48) & 1) { HOT.cural++; continue; }
+			{
+				const uint64_t tt_ = now();      // also the first tile of the backtrace
+				if (mode == 0) Plat::bt_tile_pred(dp, rows, c.row, c.col, Plat::uni(*dp.epoch), tile, tile_hi); else Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col, wide, tile, tile_hi);
+				pf_tiles++; pf_tile_t += now() - tt_;
+			}
+			if ((mode == 0 ? Plat::lane(tile_hi, 0) : Plat::lane(tile, 48)) & 1) { HOT.cural++; continue; }
 			// reseeding protocol: 8-bit kernels init(reseed) ... init(reseed+1); 16-bit kernels only init(reseed) afterwards
 			// (aligner_sw.cpp:796-933 end-to-end, :962-1110 local)
 			const uint32_t reseed = rnd.nextU32() + 1;
@@ -1332,7 +1421,7 @@ struct Aligner {
 		if ((rfi < 0 ? -rfi : 0) + (rff > reflen ? rff - reflen : 0) > (int64_t)rp.nceil) return 0;
 		int64_t score = 0;
 		int ns = 0;
-		for (uint32_t i = 0; i < len; i++) HOT.rf[i] = (uint8_t)ref_base(ix.ref, tidx, rfi + (int64_t)i);   // codes here, not masks
+		Plat::fetch_ref_codes(ix.ref, tidx, rfi, len);   // codes here, not masks
 		uint32_t rowi = 0, rowf = len - 1;
 		auto step = [&](uint32_t i) {
 			const int rdc = rd_char(HOT, HOT.len, fw, i);
@@ -1369,7 +1458,7 @@ struct Aligner {
 			const int rdc = rd_char(HOT, HOT.len, fw, i);
 			const int rfc = HOT.rf[i];
 			if (rfc > 3 || rdc != rfc) {
-				if (nned >= (uint32_t)kMaxEdits) { HOT.err |= ERR_OVERFLOW; return 0; }
+				if (nned >= (uint32_t)kMaxEdits) { ovf(22); return 0; }
 				Edit& e = res.ned[nned++];
 				e.pos = (uint16_t)i; e.chr = code2chr(rfc); e.qchr = code2chr(rdc); e.type = EDIT_MM;
 				if (rfc > 3) refns++;
@@ -1447,9 +1536,15 @@ struct Aligner {
 					// GroupWalk2S::advanceElement == Ebwt::getOffset(topf + elt)
 					uint32_t steps = 0;
 					const uint64_t tr_ = now();
-					const TOff joff = Plat::get_offset(ix.fw, (TOff)(sp.topf + elt), steps);
+					TOff joff;
+					uint64_t jc = kJoffNone;
+					// a one-row hit of the pre-computed seed round was resolved by the batch kernel that extended it
+					if (!ee_mode && ext_pre && seedmms == 0 && sp.orig_sz == 1 && pre_joff_cur)
+						jc = pre_joff_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + sp.offidx];
+					if (jc != kJoffNone) { joff = (TOff)(jc & 0xffffffffffffull); steps = (uint32_t)(jc >> 48); }
+					else { joff = Plat::get_offset(ix.fw, (TOff)(sp.topf + elt), steps); HOT.n_sides += steps; }
 					HOT.t_phase[4] += now() - tr_;
-					HOT.n_bwops_ext += steps; HOT.n_sides += steps; HOT.n_resolve_steps += steps;
+					HOT.n_bwops_ext += steps; HOT.n_resolve_steps += steps;
 					if (!ee_mode) nelt_left--;
 					TOff tidx = 0, toff = 0, tlen = 0;
 					bool straddled = false;
@@ -1532,7 +1627,7 @@ struct Aligner {
 						diag_add((int32_t)tidx, refoff, fw, 1);
 						if (!found) continue;
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
-						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { HOT.err |= ERR_OVERFLOW; return EXT_HARD_LIMIT; }
+						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { ovf(23); return EXT_HARD_LIMIT; }
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
 						// SwAligner::align (aligner_sw.cpp:500-729).  End to end: 8-bit kernel while minsc >= -254, else 16-bit (:517).
 						// Local: the 8-bit kernel unless it saturates, then the 16-bit one (:568-600); the fill below is exact and
@@ -1588,8 +1683,8 @@ struct Aligner {
 							const bool ov = (b0 <= a0 && b1 > a0) || (b0 <= a1 && b1 > a1) || (a0 <= b0 && a1 > b0) || (a0 <= b1 && a1 > b1);
 							if (!ov) continue;
 						}
-						{ const uint64_t t1_ = now(); const bool ro_ = red_overlap(res); HOT.t_phase[17] += now() - t1_; if (ro_) continue; }
-						{ const uint64_t t1_ = now(); red_add(res); HOT.t_phase[18] += now() - t1_; }
+						if (red_overlap(res)) continue;
+						red_add(res);
 						{ const uint64_t t1_ = now(); const bool sr_ = sink_report(res); HOT.t_phase[19] += now() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
 						if (P.tighten > 0 && P.mhits > 0 && HOT.best2_unp1 != INT64_MIN) {
 							if (P.tighten == 1) {
@@ -1685,8 +1780,13 @@ struct Aligner {
 				uint32_t ninst;
 				if (P.seed_mms > 0) ninst = seed_round_mm1(offset, interval, (uint32_t)rp.seedlen);
 				else if (offset == 0 && pre && pre->seeds && 1 + (len > (uint32_t)rp.seedlen ? (len - (uint32_t)rp.seedlen) / interval : 0u) <= pre->max_seeds) {
-					ninst = seed_round_pre(interval, (uint32_t)rp.seedlen);
-					ext_pre = pre->ext != nullptr;
+					ninst = seed_round_pre(pre->seeds, 0, interval, (uint32_t)rp.seedlen);
+					ext_pre = pre->ext != nullptr; pre_ext_cur = pre->ext; pre_joff_cur = pre->joff;
+				} else if (roundi > 0 && roundi < kMaxPreRounds && pre && pre->seeds_r[roundi] && pre->seeds_r[roundi][(uint64_t)ridx * 2 * pre->max_seeds].topf != ~0ull) {
+					// a re-seeding round the batch kernels searched (they saw the same "previous round was repetitive" condition:
+					// a read only gets here when it held); fewer seeds than round 0, so they fit the table
+					ninst = seed_round_pre(pre->seeds_r[roundi], offset, interval, (uint32_t)rp.seedlen);
+					ext_pre = pre->ext_r[roundi] != nullptr; pre_ext_cur = pre->ext_r[roundi]; pre_joff_cur = pre->joff_r[roundi];
 				} else ninst = seed_round(offset, interval, (uint32_t)rp.seedlen);
 				HOT.t_phase[2] += now() - ts_;
 				if (ninst == 0) { done = true; HOT.nonz_tot = 0; continue; }
@@ -1734,7 +1834,7 @@ struct Aligner {
 		out.aligned = nunpair1 > 0 ? 1 : 0;
 		out.maxed = maxed ? 1 : 0;
 		out.has_secbest = 0; out.secbest = 0; out.best = 0; out.nreport = 0;
-		out.pair_type = 0; out.pair_flags = 0; out.pair_best = 0; out.pair_secbest = 0; out.n_mate_dps = 0; out.pad2 = 0;
+		out.pair_type = 0; out.pair_flags = 0; out.pair_best = 0; out.pair_secbest = 0; out.n_mate_dps = 0; out.pad2 = HOT.err >> 8;
 		if (nunpair1 == 0) return;
 		// selectByScore: sort (score, index) ascending, reverse, shuffle equal-score streaks
 		const uint32_t sz = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;

@@ -81,6 +81,87 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 	return __shfl(best, (int)((rows - 1) / R));
 }
 
+// End-to-end 8-bit fill, compact output: the same recurrence as above, but what goes to memory is ONE BYTE per cell saying
+// which predecessors are score-consistent (PB_* in bt2g_align.hpp) -- exactly the questions the reference's backtrace asks
+// of H/E/F (aligner_swsse_ee_u8.cpp:1330-1520), answered here while the neighbours are still in registers.  Identities
+// used to fold the five H options into two flags (gaps allowed in the row, so no veto applies):
+//   H == H_up - rfgapo  <=>  H == F and F == H_up - rfgapo      (F >= H_up - rfgapo and H >= F);  likewise for the
+//   extension F_up - rfgape and for E with H_left / E_left.
+// Cells are stored diagonal-major (pred_idx) so that the backtrace's diagonal runs read consecutive bytes; the last row's
+// scores go straight to HOT.lastrow for the candidate gather.  Traffic: 1 B per cell instead of 4 B + a 2 B mask plane.
+template <int R>
+__device__ __forceinline__ int fill_ee_u8_pred_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t nlanes = (rows + R - 1) / R;
+	const uint32_t rp = pred_rp(rows);
+	int rdc[R], mmp[R], veto[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const uint32_t i = (uint32_t)lane * R + r;
+		const bool valid = i < rows;
+		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
+		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
+		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 0xff : 0;
+	}
+	int Hprev[R], Eprev[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
+	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, best = 0;
+	const uint32_t steps = cols + nlanes - 1;
+	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
+	const int last_r = (int)((rows - 1) % R);
+	const int rdgapo = P.rdgapo, rdgape = P.rdgape, rfgapo = P.rfgapo, rfgape = P.rfgape, npen = P.n_pen, bonus = P.match_bonus;
+	for (uint32_t t = 0; t < steps; t++) {
+		const int upH = __shfl_up(myHlast, 1);
+		const int upF = __shfl_up(myFlast, 1);
+		int upRef = __shfl_up(refm, 1);
+		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
+		refm = upRef;
+		const int j = (int)t - lane;
+		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
+		int refc = 4;
+		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
+		int hdiag = (lane == 0) ? 0xff : (j == 0 ? 0 : upHdiag);
+		int fin_h = upH, fin_f = upF;
+		const bool jl = j > 0;
+		int Hnew[R], Enew[R], Fnew[R], code[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			int pen;
+			if (rdc[r] > 3 || refc > 3) pen = npen; else pen = (rdc[r] == refc) ? -bonus : mmp[r];
+			const int hl = Hprev[r], el = Eprev[r];
+			const int e = jl ? imax(subs0(el, rdgape), subs0(subs0(hl, rdgapo), veto[r])) : 0;
+			const bool row0 = lane == 0 && r == 0;
+			const int f = row0 ? 0 : subs0(imax(subs0(fin_f, rfgape), subs0(fin_h, rfgapo)), veto[r]);
+			const int h = imax(imax(subs0(hdiag, pen), e), f);
+			const bool ga = veto[r] == 0;
+			int c = (jl && hdiag - pen == h) ? PB_HD : 0;
+			c |= (ga && jl && h == e) ? PB_HE : 0;
+			c |= (ga && h == f) ? PB_HF : 0;
+			c |= (jl && hl - rdgapo == e) ? PB_EO : 0;
+			c |= (jl && el - rdgape == e) ? PB_EE : 0;
+			c |= (!row0 && fin_h - rfgapo == f) ? PB_FO : 0;
+			c |= (!row0 && fin_f - rfgape == f) ? PB_FE : 0;
+			Hnew[r] = h; Enew[r] = e; Fnew[r] = f; code[r] = c;
+			hdiag = hl;
+			fin_h = h; fin_f = f;
+		}
+		if (active) {
+			// cell (i, j) lives at ((j + rows - 1 - i) * rp + i)
+			uint8_t* base = pm + (uint64_t)((uint32_t)j + rows - 1 - (uint32_t)lane * R) * rp + (uint32_t)lane * R;
+#pragma unroll
+			for (int r = 0; r < R; r++) if ((uint32_t)lane * R + r < rows) base[(int64_t)r - (int64_t)r * (int64_t)rp] = (uint8_t)code[r];
+#pragma unroll
+			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
+			if (lane_has_last) { best = imax(best, Hnew[last_r]); g_hot.lastrow[j] = (int16_t)(Hnew[last_r] - 0xff); }
+		}
+		upHdiag = upH;
+		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
+	}
+	return __shfl(best, (int)((rows - 1) / R));
+}
+
 // The same recurrence in the reference's 16-bit representation (alignNucleotidesEnd2EndSseI16, aligner_swsse_ee_i16.cpp:780-1146):
 // scores biased by 0x7fff, -32768 = minus infinity, saturating subtraction, barrier rows veto gap opens/extensions.
 constexpr int kLo = -32768;
@@ -252,6 +333,44 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < n16; i += 64) q[i] = z;
 		wave_fence();
 	}
+	static __device__ __forceinline__ void zero_u32(uint32_t* p, uint32_t n) {
+		wave_fence();
+		uint4* q = reinterpret_cast<uint4*>(p);
+		const uint4 z = make_uint4(0, 0, 0, 0);
+		for (uint32_t i = threadIdx.x & 63; i < (n + 3) / 4; i += 64) q[i] = z;
+		wave_fence();
+	}
+	// RowSampler::next over running sums kept in LDS: first candidate still in play whose running sum exceeds rd, else the last
+	// one in play (aligner_sw_driver.h:215-240)
+	static __device__ __forceinline__ uint32_t pick_mass(const double* prefix, const uint8_t* elim, uint32_t n, double rd) {
+		const uint32_t lane = threadIdx.x & 63;
+		uint32_t last = 0xffffffffu;
+		for (uint32_t base = 0; base < n; base += 64) {
+			const uint32_t i = base + lane;
+			const bool live = i < n && !elim[i];
+			const unsigned long long hit = __ballot(live && rd < prefix[i]);
+			if (hit) return base + (uint32_t)__builtin_ctzll(hit);
+			const unsigned long long lv = __ballot(live);
+			if (lv) last = base + 63u - (uint32_t)__builtin_clzll(lv);
+		}
+		return last;
+	}
+	static __device__ __forceinline__ void set_epoch(uint32_t* p, uint32_t e) { if ((threadIdx.x & 63) == 0) *p = e; wave_fence(); }
+	// Tile of the pred format anchored at (row, col): lane d <- predecessor byte and (epoch-checked) mask of cell (row-d, col-d).
+	// Diagonal-major storage makes both one contiguous 64-byte / 256-byte read.
+	static __device__ __forceinline__ void bt_tile_pred(const DpScratch& dp, uint32_t rows, uint32_t row, uint32_t col, uint32_t epoch,
+	                                                    uint32_t& pr, uint32_t& mk) {
+		wave_fence();        // mask stores of earlier steps -> visible to whichever lane re-reads them
+		const uint32_t d = threadIdx.x & 63;
+		uint32_t p = 0, m = 0;
+		if (d <= row && d <= col) {
+			const uint64_t idx = pred_idx(rows, row, col) - d;
+			p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
+			const uint32_t w = dp.pmask[idx];
+			m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
+		}
+		pr = p; mk = m;
+	}
 	// scores of the last DP row -> LDS (clamped at -32768; only scores >= minsc matter afterwards)
 	static __device__ __forceinline__ void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols, bool wide) {
 		wave_fence();
@@ -359,7 +478,15 @@ struct DevPlat {
 	// reference window -> masks, one base per lane per pass (SwAligner::initRef, aligner_sw.cpp:155-271)
 	static __device__ __forceinline__ void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
 		wave_fence();
-		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
+		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);      // the window's first record: one search for the whole window
+		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)(1 << ref_base_at(ref, tidx, rfi + (int64_t)i, rec0));
+		wave_fence();
+	}
+	// the same window as base codes 0..4 (ungappedAlign compares characters, aligner_sw.cpp:330-380)
+	static __device__ __forceinline__ void fetch_ref_codes(const DevRef& ref, uint64_t tidx, int64_t rfi, uint32_t count) {
+		wave_fence();
+		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);
+		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)ref_base_at(ref, tidx, rfi + (int64_t)i, rec0);
 		wave_fence();
 	}
 	static __device__ __attribute__((noinline)) int64_t dp_fill_local(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat,
@@ -447,15 +574,16 @@ struct DevPlat {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
 		int best;
 		if (!wide) {
+			uint8_t* pm = reinterpret_cast<uint8_t*>(mat);
 			switch (dp_R(rows)) {
-				case 1: best = fill_ee_u8_wave<1>(P, w, fw, rows, cols, mat); break;
-				case 2: best = fill_ee_u8_wave<2>(P, w, fw, rows, cols, mat); break;
-				case 3: best = fill_ee_u8_wave<3>(P, w, fw, rows, cols, mat); break;
-				case 4: best = fill_ee_u8_wave<4>(P, w, fw, rows, cols, mat); break;
-				case 5: best = fill_ee_u8_wave<5>(P, w, fw, rows, cols, mat); break;
-				case 6: best = fill_ee_u8_wave<6>(P, w, fw, rows, cols, mat); break;
-				case 7: best = fill_ee_u8_wave<7>(P, w, fw, rows, cols, mat); break;
-				default: best = fill_ee_u8_wave<8>(P, w, fw, rows, cols, mat); break;
+				case 1: best = fill_ee_u8_pred_wave<1>(P, fw, rows, cols, pm); break;
+				case 2: best = fill_ee_u8_pred_wave<2>(P, fw, rows, cols, pm); break;
+				case 3: best = fill_ee_u8_pred_wave<3>(P, fw, rows, cols, pm); break;
+				case 4: best = fill_ee_u8_pred_wave<4>(P, fw, rows, cols, pm); break;
+				case 5: best = fill_ee_u8_pred_wave<5>(P, fw, rows, cols, pm); break;
+				case 6: best = fill_ee_u8_pred_wave<6>(P, fw, rows, cols, pm); break;
+				case 7: best = fill_ee_u8_pred_wave<7>(P, fw, rows, cols, pm); break;
+				default: best = fill_ee_u8_pred_wave<8>(P, fw, rows, cols, pm); break;
 			}
 			best -= 0xff;
 		} else {
@@ -477,6 +605,16 @@ struct DevPlat {
 	}
 };
 
+// one DP scratch inside a wave's arena: [matrix][16-bit masks][256 B header holding the epoch][32-bit epoch-tagged masks]
+__device__ __forceinline__ uint8_t* carve_scratch(DpScratch& dp, uint8_t* p, uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes) {
+	dp.mat = reinterpret_cast<uint32_t*>(p); p += mat_bytes;
+	dp.masks = reinterpret_cast<uint16_t*>(p); p += mask_bytes;
+	dp.epoch = reinterpret_cast<uint32_t*>(p);
+	dp.pmask = reinterpret_cast<uint32_t*>(p + 256);
+	dp.pmask_words = (uint32_t)((pmask_bytes - 256) / 4);
+	return p + pmask_bytes;
+}
+
 // per-read parameters the host derives (seed length 1..32 as -L allows, positive seed interval); anything else would index
 // past the seed tables
 __device__ __forceinline__ bool read_params_ok(const ReadParams& rp) { return rp.seedlen >= 1 && rp.seedlen <= 32 && rp.interval >= 1 && rp.nceil >= 0; }
@@ -488,14 +626,13 @@ template <typename TOff>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(128)))
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
-              uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
+              uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
               PreComp pre, uint32_t max_read_len) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	Work& w = *reinterpret_cast<Work*>(base);
 	DpScratch dp;
-	dp.mat = reinterpret_cast<uint32_t*>(base + ((sizeof(Work) + 255) & ~(uint64_t)255));
-	dp.masks = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(dp.mat) + mat_bytes);
+	carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes);
 	__shared__ DevIndex<TOff> s_ix;
 	__shared__ AlignParams s_P;
 	__shared__ ReadParams s_rp;
@@ -543,16 +680,13 @@ template <typename TOff>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(128)))
 k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
-              uint64_t mat_bytes, uint64_t mask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
+              uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
               PreComp pre, uint32_t max_read_len) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	Work& w = *reinterpret_cast<Work*>(base);
 	DpScratch dp, dp2;
-	dp.mat = reinterpret_cast<uint32_t*>(base + ((sizeof(Work) + 255) & ~(uint64_t)255));
-	dp.masks = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(dp.mat) + mat_bytes);
-	dp2.mat = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(dp.masks) + mask_bytes);
-	dp2.masks = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(dp2.mat) + mat_bytes);
+	carve_scratch(dp2, carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes), mat_bytes, mask_bytes, pmask_bytes);
 	__shared__ DevIndex<TOff> s_ix;
 	__shared__ AlignParams s_P;
 	__shared__ ReadParams s_rp;
@@ -600,21 +734,21 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
-                        uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
+                        uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
                         const PreComp& pre, uint32_t max_read_len, hipStream_t st) {
 	if (rd.n_reads == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
 	if (P.paired)
 		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
-		                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre, max_read_len);
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len);
 	else
 	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
-	                   d_arena, arena_stride, mat_bytes, mask_bytes, d_next, d_prof, pre, max_read_len);
+	                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len);
 	return hipGetLastError();
 }
 
-void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& arena_stride) {
+void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& pmask_bytes, uint64_t& arena_stride) {
 	const uint32_t rows = max_len ? max_len : 1;
 	const uint32_t R = dp_R(rows);
 	// unpaired: seed-extension windows only (rows + 4 * min(gaps, maxhalf) columns, dp_framer.cpp:81-129; the framer flags windows
@@ -622,17 +756,20 @@ void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64
 	uint32_t cols = paired ? (uint32_t)kMaxCols + 4 : rows + 4 * maxhalf + 1 + 4;
 	if (cols > (uint32_t)kMaxCols + 4) cols = (uint32_t)kMaxCols + 4;
 	const uint32_t lanes = (rows + R - 1) / R;
-	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 8 + 255) & ~(uint64_t)255;    // 8 B per cell: the 16-bit path packs H|E|F into 64 bits
+	// packed cells (16-bit end-to-end, local): 8 B per cell, wavefront-major; pred format (8-bit end-to-end): 1 B per cell, diagonal-major
+	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 8 + 255) & ~(uint64_t)255;
+	const uint64_t pred_bytes = (pred_cells(rows, cols) + 255) & ~(uint64_t)255;
+	if (pred_bytes > mat_bytes) mat_bytes = pred_bytes;
 	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
-	const uint64_t rr = ((uint64_t)rows + 255) & ~(uint64_t)255;
-	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + (paired ? 2 : 1) * (mat_bytes + mask_bytes) + rr;
+	pmask_bytes = 256 + ((pred_cells(rows, cols) * 4 + 255) & ~(uint64_t)255);
+	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + (paired ? 2 : 1) * (mat_bytes + mask_bytes + pmask_bytes);
 	arena_stride = (arena_stride + 4095) & ~(uint64_t)4095;
 }
 
 uint64_t align_work_bytes() { return sizeof(Work); }
 uint32_t align_waves_per_cu() { return 4u * BT2G_WAVES_PER_EU; }
 
-template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, hipStream_t);
-template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, hipStream_t);
+template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, hipStream_t);
+template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, hipStream_t);
 
 } // namespace bt2g

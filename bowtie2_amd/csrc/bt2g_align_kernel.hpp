@@ -9,9 +9,9 @@ namespace bt2g {
 template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
-                        uint64_t mat_bytes, uint64_t mask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
+                        uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
                         const PreComp& pre, uint32_t max_read_len, hipStream_t st);
-void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& arena_stride);
+void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& pmask_bytes, uint64_t& arena_stride);
 uint64_t align_work_bytes();
 uint32_t align_waves_per_cu();
 }

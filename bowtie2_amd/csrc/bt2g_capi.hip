@@ -34,6 +34,7 @@ struct bt2g_ctx {
 	uint32_t n_cu = 0;
 	uint8_t* d_arena = nullptr;          // per-wave Work + DP scratch of the fused worker
 	uint64_t arena_bytes = 0;
+	uint64_t arena_layout = 0;           // fingerprint of the arena's carving (epoch-tagged masks are only valid within one)
 	unsigned int* d_next = nullptr;      // work-queue head
 	uint8_t* d_pre = nullptr;            // batch pre-computation (sweep, round-0 seed hits, extensions, 1-mm hits)
 	uint64_t pre_bytes = 0;
@@ -294,9 +295,9 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (reads->n_reads == 0) return 0;
 	if (max_read_len > BT2G_MAX_READ_LEN) max_read_len = BT2G_MAX_READ_LEN;
 	hipStream_t st = (hipStream_t)stream;
-	uint64_t mat_bytes, mask_bytes, arena_stride;
+	uint64_t mat_bytes, mask_bytes, pmask_bytes, arena_stride;
 	if (params->paired && (reads->n_reads & 1u)) return fail(c, BT2G_ERR_ARG, "paired mode needs an even number of reads (mates interleaved)");
-	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, mat_bytes, mask_bytes, arena_stride);
+	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
 	// persistent waves (one read at a time each) pull reads from a device-side queue
 	uint32_t n_waves = c->n_cu * align_waves_per_cu();
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
@@ -308,6 +309,14 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		e = hipMalloc((void**)&c->d_arena, need);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(worker arena)");
 		c->arena_bytes = need;
+		c->arena_layout = 0;
+	}
+	// the epoch-tagged backtrace masks live in the arena across launches: (re)start from zero whenever its layout changes
+	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0);
+	if (layout != c->arena_layout) {
+		e = hipMemsetAsync(c->d_arena, 0, c->arena_bytes, st);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(worker arena)");
+		c->arena_layout = layout;
 	}
 	if (!c->d_next) {
 		e = hipMalloc((void**)&c->d_next, 256);
@@ -336,9 +345,13 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		const uint64_t b_sweep = al(n * sizeof(bt2g_sweep_out));
 		const uint64_t b_seeds = al(n * 2 * max_seeds * sizeof(bt2g_seed_hit));
 		const uint64_t b_ext = al(n * 2 * max_seeds * sizeof(uint32_t));
+		const uint64_t b_joff = al(n * 2 * max_seeds * sizeof(uint64_t));
 		const uint64_t b_mm1 = al(n * 4 * cap * sizeof(Mm1Hit));
 		const uint64_t b_mm1n = al(n * 4);
-		const uint64_t tot = b_sweep + b_seeds + b_ext + b_mm1 + b_mm1n;
+		// re-seeding rounds are pre-computed for unpaired batches (the pair worker keeps searching them itself)
+		uint32_t pre_rounds = 1;
+		if (params->seed_mms == 0 && !params->paired && params->n_seed_rounds > 1) pre_rounds = (uint32_t)params->n_seed_rounds < kMaxPreRounds ? (uint32_t)params->n_seed_rounds : kMaxPreRounds;
+		const uint64_t tot = b_sweep + (b_seeds + b_ext + b_joff) * pre_rounds + b_mm1 + b_mm1n;
 		if (tot > c->pre_bytes) {
 			if (c->d_pre) (void)hipFree(c->d_pre);
 			c->d_pre = nullptr; c->pre_bytes = 0;
@@ -349,6 +362,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		uint8_t* p = c->d_pre;
 		bt2g_sweep_out* d_sweep = (bt2g_sweep_out*)p; p += b_sweep;
 		bt2g_seed_hit* d_seeds = (bt2g_seed_hit*)p; p += b_seeds;
+		uint64_t* d_joff = (uint64_t*)p; p += b_joff;
 		uint32_t* d_ext = (uint32_t*)p; p += b_ext;
 		Mm1Hit* d_mm1 = (Mm1Hit*)p; p += b_mm1;
 		uint8_t* d_mm1n = p;
@@ -375,10 +389,30 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			pre.seeds = d_seeds;
 			mark(3);
 			if (params->do_extend) {
-				e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, c->d_cnt, st)
-				      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, c->d_cnt, st);
+				e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, d_joff, c->d_cnt, st)
+				      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, d_joff, c->d_cnt, st);
 				if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits");
-				pre.ext = d_ext;
+				pre.ext = d_ext; pre.joff = d_joff;
+			}
+			// rounds 1..: the same kernels on the shifted seeds, for the reads repetitive enough to be re-seeded
+			const bt2g_seed_hit* prev = d_seeds;
+			uint8_t* q = d_mm1n + b_mm1n;
+			for (uint32_t ri = 1; ri < pre_rounds; ri++) {
+				bt2g_seed_hit* sr = (bt2g_seed_hit*)q; q += b_seeds;
+				uint64_t* jr = (uint64_t*)q; q += b_joff;
+				uint32_t* er = (uint32_t*)q; q += b_ext;
+				ReseedCtl ctl; ctl.prev = prev; ctl.n_seed_rounds = (uint32_t)params->n_seed_rounds; ctl.boost_thresh = (uint32_t)params->seed_boost_thresh; ctl.nofw = params->nofw; ctl.norc = params->norc;
+				e = s ? launch_seed_search_exact(c->ix32, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, sr, c->d_cnt, st, ri, &ctl)
+				      : launch_seed_search_exact(c->ix64, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, sr, c->d_cnt, st, ri, &ctl);
+				if (e != hipSuccess) return hip_fail(c, e, "k_seed_search_exact (re-seed)");
+				pre.seeds_r[ri] = sr;
+				if (params->do_extend) {
+					e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, sr, er, jr, c->d_cnt, st, ri, (uint32_t)params->n_seed_rounds)
+					      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, sr, er, jr, c->d_cnt, st, ri, (uint32_t)params->n_seed_rounds);
+					if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits (re-seed)");
+					pre.ext_r[ri] = er; pre.joff_r[ri] = jr;
+				}
+				prev = sr;
 			}
 		} else { mark(3); }
 		pre.max_seeds = max_seeds; pre.mm1_cap = cap;
@@ -387,8 +421,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	mark(5);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	e = (c->off_size == 4)
-		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, max_read_len, st)
-		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, max_read_len, st);
+		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, max_read_len, st)
+		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, max_read_len, st);
 	if (e != hipSuccess) return hip_fail(c, e, "k_align_reads");
 	mark(6);
 	c->ev_valid = true;

@@ -21,6 +21,12 @@ struct CliExtra {
 	size_t batch_reads = 1u << 18;
 	bool version = false, help = false;   // --version / -h
 	bool allow_paired = false;     // set by the caller before parsing: this front end can run pairs
+	// --shard r/N: this process is rank r of N (one process per GPU).  The input is cut into blocks of --batch
+	// reads (pairs stay together) dealt round-robin; the process aligns blocks r, r+N, ... only, writes their SAM in block order
+	// and lists "block_id bytes" per block plus its summary counters in --shard-index FILE, from which rank 0 reassembles
+	// the ordered SAM (bowtie2_amd/mgpu.py gathers the pieces over RCCL).
+	int shard_rank = 0, shard_world = 1;
+	std::string shard_index;
 };
 
 inline bool split_ints(const std::string& s, char sep, std::vector<int>& out) {
@@ -232,6 +238,11 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--gpu") { if (!split_ints(need(), ',', ex.devices)) err = "--gpu needs a comma-separated list of device indexes"; }
 		else if (a == "--met") ex.metrics = true;
 		else if (a == "--batch") ex.batch_reads = strtoull(need().c_str(), nullptr, 10);
+		else if (a == "--shard") {
+			const std::string v = need();
+			if (sscanf(v.c_str(), "%d/%d", &ex.shard_rank, &ex.shard_world) != 2 || ex.shard_world < 1 || ex.shard_rank < 0 || ex.shard_rank >= ex.shard_world) err = "--shard needs r/N with 0 <= r < N";
+		}
+		else if (a == "--shard-index") ex.shard_index = need();
 		else if (a == "-D") { opt.max_dp_streak = atoi(need().c_str()); opt.set_D = true; }
 		else if (a == "-R") { opt.n_seed_rounds = atoi(need().c_str()); opt.set_R = true; }
 		else if (a == "-L") { opt.seed_len = atoi(need().c_str()); opt.set_L = true; if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }

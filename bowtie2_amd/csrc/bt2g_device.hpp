@@ -335,5 +335,27 @@ BT2_HD int ref_base(const DevRef& r, uint64_t tidx, int64_t toff) {
 	return (r.buf[bo >> 2] >> ((bo & 3) << 1)) & 3;
 }
 
+// The same lookup for a run of consecutive positions: ref_rec_find() locates the record for the first position once (one
+// binary search per DP window instead of one per base); ref_base_at() then only steps forward from that record.
+BT2_HD uint64_t ref_rec_find(const DevRef& r, uint64_t tidx, int64_t toff) {
+	uint64_t lo = r.ref_rec_offs[tidx], hi = r.ref_rec_offs[tidx + 1];
+	if (toff < 0) return lo;
+	while (hi - lo > 1) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (r.rec_refpos[mid] <= (uint64_t)toff) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+BT2_HD int ref_base_at(const DevRef& r, uint64_t tidx, int64_t toff, uint64_t rec) {
+	if (toff < 0 || (uint64_t)toff >= r.ref_lens[tidx]) return 4;
+	const uint64_t hi = r.ref_rec_offs[tidx + 1];
+	if (rec >= hi) return 4;
+	while (rec + 1 < hi && r.rec_refpos[rec + 1] <= (uint64_t)toff) rec++;      // last record starting at or before toff
+	const uint64_t p = r.rec_refpos[rec];
+	if ((uint64_t)toff < p || (uint64_t)toff >= p + r.rec_len[rec]) return 4;
+	const uint64_t bo = r.rec_bufpos[rec] + ((uint64_t)toff - p);
+	return (r.buf[bo >> 2] >> ((bo & 3) << 1)) & 3;
+}
+
 } // namespace bt2g
 #endif

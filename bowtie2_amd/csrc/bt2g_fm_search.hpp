@@ -86,6 +86,42 @@ BT2_HD void fm_extend_hit(const DevIndex<TOff>& ix, const RD& rd, uint32_t rdlen
 	}
 }
 
+// The joined text (every unambiguous reference base, in index order) is what <base>.4 stores, two bits per base.
+BT2_HD int joined_char(const DevRef& r, uint64_t p) { return (r.buf[p >> 2] >> ((p & 3) << 1)) & 3; }
+
+// fm_extend_hit for a range of exactly ONE row whose joined-text offset p is known.  A one-row range cannot shrink, so the LF
+// walk of SwDriver::extend degenerates into comparing the read with the text on either side of the hit; it ends where the walk
+// ends: at a mismatch (a read N never mismatches, as in the walk), after 255 characters, at the read's end, or at either end
+// of the joined text, where mapLF1 fails.  ~lim/4 bytes of contiguous text instead of lim dependent side reads.
+template <typename TOff, typename RD>
+BT2_HD void fm_extend_hit_text(const DevIndex<TOff>& ix, const RD& rd, uint32_t rdlen, uint64_t p, bool fw, uint32_t off, uint32_t len,
+                               uint32_t& nlex, uint32_t& nrex, bool right = true) {
+	const uint64_t n = (uint64_t)ix.fw.len;
+	nlex = nrex = 0;
+	for (int side = 0; side < 2; side++) {
+		const bool left = side == 0;
+		if (!left && !right) continue;
+		const uint32_t lim = left ? (fw ? off : rdlen - len - off) : (fw ? rdlen - len - off : off);
+		uint32_t cnt = 0;
+		for (uint32_t ii = 0; ii < lim; ii++) {
+			uint32_t i;
+			if (left) i = fw ? off - ii - 1 : rdlen - off - len - 1 - ii;
+			else      i = fw ? ii + len + off : rdlen - off + ii;
+			const int rdc = fm_rd_char(rd, rdlen, fw, i);
+			int c = -1;
+			if (left) { if (p >= (uint64_t)ii + 1) c = joined_char(ix.ref, p - ii - 1); }
+			else { const uint64_t q = p + len + ii; if (q < n) c = joined_char(ix.ref, q); }
+			if (c != rdc && rdc <= 3) break;
+			if (++cnt == 255) break;
+		}
+		if (left) nlex = cnt; else nrex = cnt;
+	}
+}
+
+// cached offset resolution of a one-row seed hit: joined offset in the low 48 bits, LF steps it took in the high 16
+constexpr uint64_t kJoffNone = ~0ull;
+BT2_HD uint64_t joff_pack(uint64_t joff, uint32_t steps) { return (joff >> 48) == 0 && steps < 0xffffu ? (joff | ((uint64_t)steps << 48)) : kJoffNone; }
+
 // 1-mismatch end-to-end hit as oneMmSearch reports it (EEHit with one Edit)
 struct Mm1Hit {
 	uint64_t top, bot;
@@ -100,10 +136,28 @@ struct PreComp {
 	const bt2g_sweep_out* sweep;   // [n_reads]                       exactSweep
 	const bt2g_seed_hit*  seeds;   // [n_reads][2][max_seeds]         seed round 0 (offset 0)
 	const uint32_t*       ext;     // [n_reads][2][max_seeds]         nlex | nrex << 16 of each non-empty seed hit
+	const uint64_t*       joff;    // [n_reads][2][max_seeds]         joff_pack() of every one-row seed hit (kJoffNone otherwise): resolved while extending
 	const Mm1Hit*         mm1;     // [n_reads][2 strands][2 dirs][mm1_cap]
 	const uint8_t*        mm1_n;   // [n_reads][4]   hits per list; 255 = list overflowed
 	uint32_t max_seeds, mm1_cap;
+	// re-seeding rounds 1..kMaxPreRounds-1 (bt2_search.cpp:3881-4160: same seeds shifted by interval*round/nrounds), computed
+	// only for reads whose previous round averaged >= seed_boost_thresh hits per seed -- the one condition for a further round
+	// that does not depend on what the worker has reported by then.  [round][...] with the layout of seeds/ext/joff above.
+	const bt2g_seed_hit*  seeds_r[4];
+	const uint32_t*       ext_r[4];
+	const uint64_t*       joff_r[4];
 };
+constexpr uint32_t kMaxPreRounds = 4;
+
+// offset of re-seeding round `roundi` for a read (multiseedSearchWorker, bt2_search.cpp:3885-3930); false = the round does not run
+BT2_HD bool reseed_offset(uint32_t roundi, uint32_t n_seed_rounds, uint32_t interval, uint32_t seedlen, uint32_t len, uint32_t& offset) {
+	uint32_t nrounds = n_seed_rounds;
+	if (nrounds > interval) nrounds = interval;
+	if (roundi >= nrounds || interval <= roundi) return false;
+	offset = (interval * roundi) / nrounds;
+	if (offset > 0 && seedlen + offset > len) return false;
+	return true;
+}
 
 // One (read strand, index direction) combination of oneMmSearch with repex=false, rep1mm=true.
 // emit(const Mm1Hit&) is called for every valid 1-mismatch end-to-end hit, in discovery order.

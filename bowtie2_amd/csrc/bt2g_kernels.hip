@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(256)
 k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict__ d_seedlen,
                     const uint32_t* __restrict__ d_interval, const uint32_t* __restrict__ d_offset,
                     const bt2g_read_params* __restrict__ rparams,
-                    uint32_t max_seeds, bt2g_seed_hit* __restrict__ out, DevCounters* cnt) {
+                    uint32_t max_seeds, bt2g_seed_hit* __restrict__ out, DevCounters* cnt,
+                    uint32_t roundi, ReseedCtl rc_) {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	unsigned long long nrank = 0, nftab = 0, bwops = 0;
@@ -172,11 +173,26 @@ k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict
 		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
 		const uint8_t* seq = rd.d_seq + o0;
 		uint32_t L = rparams ? (uint32_t)rparams[r].seedlen : d_seedlen[r];
-		const uint32_t per = rparams ? (uint32_t)rparams[r].interval : d_interval[r], off = rparams ? 0u : d_offset[r];
+		const uint32_t per = rparams ? (uint32_t)rparams[r].interval : d_interval[r];
+		uint32_t off = rparams ? 0u : d_offset[r];
+		bool want = true;
+		if (roundi > 0) {
+			// a re-seeding round: its offset, and whether the previous round was repetitive enough to ask for it
+			want = rparams != nullptr && per > 0 && reseed_offset(roundi, rc_.n_seed_rounds, per, (uint32_t)rparams[r].seedlen, len, off);
+			if (want) {
+				uint64_t elts = 0; uint32_t nonz = 0;
+				for (uint32_t s_ = 0; s_ < 2; s_++) {
+					if (s_ == 0 ? rc_.nofw : rc_.norc) continue;
+					const bt2g_seed_hit* ph = rc_.prev + ((uint64_t)r * 2 + s_) * max_seeds;
+					for (uint32_t k = 0; k < max_seeds; k++) if (ph[k].botf > ph[k].topf) { nonz++; elts += ph[k].botf - ph[k].topf; }
+				}
+				want = nonz > 0 && elts / nonz >= (uint64_t)rc_.boost_thresh;
+			}
+		}
 		if (L > len) L = len;   // Seed::instantiate shrinks the seed to the read (aligner_seed.cpp:226-230)
 		// instantiateSeeds (:523-526)
 		uint32_t nseeds = 0;
-		if (len > 0 && L > 0 && per > 0 && !(off > 0 && (uint64_t)L + off > len)) {
+		if (want && len > 0 && L > 0 && per > 0 && !(off > 0 && (uint64_t)L + off > len)) {
 			nseeds = 1;
 			if ((int64_t)len - (int64_t)off > (int64_t)L) nseeds += (len - off - L) / per;
 		}
@@ -237,6 +253,7 @@ k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict
 		bt2g_seed_hit h;
 		if (ok) { h.topf = topf; h.botf = botf; h.topb = topb; h.botb = botb; }
 		else    { h.topf = h.botf = h.topb = h.botb = 0; }
+		if (!want) h.topf = ~0ull;       // "this round was not searched for this read": the worker searches it itself should it get there
 		out[gid] = h;
 	}
 	wave_add_counter(&cnt->rank_queries, nrank);
@@ -247,14 +264,17 @@ k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict
 template <typename TOff>
 hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& rd, const uint32_t* d_seedlen,
                                     const uint32_t* d_interval, const uint32_t* d_offset, const bt2g_read_params* d_rparams,
-                                    uint32_t max_seeds, bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st) {
+                                    uint32_t max_seeds, bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st,
+                                    uint32_t roundi, const ReseedCtl* rc) {
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	if (total == 0) return hipSuccess;
+	ReseedCtl ctl; ctl.prev = nullptr; ctl.n_seed_rounds = 0; ctl.boost_thresh = 0; ctl.nofw = ctl.norc = 0;
+	if (rc) ctl = *rc;
 	const uint32_t block = 256;
 	const uint64_t grid = (total + block - 1) / block;
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
 	hipLaunchKernelGGL(k_seed_search_exact<TOff>, dim3((uint32_t)grid), dim3(block), 0, st, ix, rd, d_seedlen, d_interval,
-	                   d_offset, d_rparams, max_seeds, d_out, d_cnt);
+	                   d_offset, d_rparams, max_seeds, d_out, d_cnt, roundi, ctl);
 	return hipGetLastError();
 }
 
@@ -496,13 +516,16 @@ struct GlobRd {
 template <typename TOff>
 __global__ void __launch_bounds__(256)
 k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t max_seeds, int right,
-              const bt2g_seed_hit* __restrict__ hits, uint32_t* __restrict__ ext, DevCounters* cnt) {
+              const bt2g_seed_hit* __restrict__ hits, uint32_t* __restrict__ ext, uint64_t* __restrict__ joffs, DevCounters* cnt,
+              uint32_t roundi, uint32_t n_seed_rounds) {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	FmCount c; c.bwops = 0; c.sides = 0;
+	uint32_t sa = 0;
 	if (gid < total) {
 		const bt2g_seed_hit h = hits[gid];
 		uint32_t e = 0;
+		uint64_t jo = kJoffNone;
 		if (h.botf > h.topf) {
 			const uint32_t i = (uint32_t)(gid % max_seeds);
 			const uint64_t rs = gid / max_seeds;
@@ -512,26 +535,39 @@ k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restri
 			const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
 			uint32_t L = (uint32_t)rparams[r].seedlen;
 			if (L > len) L = len;
-			const uint32_t rdoff = i * (uint32_t)rparams[r].interval;
+			uint32_t roff = 0;
+			if (roundi > 0) reseed_offset(roundi, n_seed_rounds, (uint32_t)rparams[r].interval, (uint32_t)rparams[r].seedlen, len, roff);
+			const uint32_t rdoff = i * (uint32_t)rparams[r].interval + roff;
 			GlobRd g; g.s = rd.d_seq + o0; g.q = rd.d_qual + o0;
 			uint32_t nlex = 0, nrex = 0;
-			fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c, right != 0);
+			if (h.botf - h.topf == 1) {
+				// a unique seed hit: resolve its text offset (the worker needs it anyway) and extend by comparing with the text
+				uint32_t steps = 0;
+				const TOff joff = get_offset(ix.fw, (TOff)h.topf, steps);
+				c.sides += steps; c.bwops += steps; sa++;
+				jo = joff_pack((uint64_t)joff, steps);
+				if ((uint64_t)joff < (uint64_t)ix.fw.len) fm_extend_hit_text(ix, g, len, (uint64_t)joff, fw, rdoff, L, nlex, nrex, right != 0);
+				else fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c, right != 0);
+			} else fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c, right != 0);
 			e = nlex | (nrex << 16);
 		}
 		ext[gid] = e;
+		joffs[gid] = jo;
 	}
+	wave_add_counter(&cnt->sa_lookups, sa);
 	wave_add_counter(&cnt->rank_queries, c.sides);
 	wave_add_counter(&cnt->bwops, c.bwops);
 }
 
 template <typename TOff>
 hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds, int right,
-                              const bt2g_seed_hit* d_hits, uint32_t* d_ext, DevCounters* d_cnt, hipStream_t st) {
+                              const bt2g_seed_hit* d_hits, uint32_t* d_ext, uint64_t* d_joff, DevCounters* d_cnt, hipStream_t st,
+                              uint32_t roundi, uint32_t n_seed_rounds) {
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	if (total == 0) return hipSuccess;
 	const uint64_t grid = (total + 255) / 256;
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, rd, d_rparams, max_seeds, right, d_hits, d_ext, d_cnt);
+	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, rd, d_rparams, max_seeds, right, d_hits, d_ext, d_joff, d_cnt, roundi, n_seed_rounds);
 	return hipGetLastError();
 }
 
@@ -581,8 +617,8 @@ hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, c
 	return hipGetLastError();
 }
 
-template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, DevCounters*, hipStream_t);
-template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, DevCounters*, hipStream_t);
+template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t);
+template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t);
 template hipError_t launch_one_mm<uint32_t>(const DevIndex<uint32_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, DevCounters*, hipStream_t);
 template hipError_t launch_one_mm<uint64_t>(const DevIndex<uint64_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, DevCounters*, hipStream_t);
 
@@ -683,8 +719,8 @@ hipError_t launch_pack_results(const void* d_results, uint64_t stride, uint32_t 
 // explicit instantiations
 template hipError_t launch_exact_sweep<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, int, int, uint32_t, bt2g_sweep_out*, DevCounters*, hipStream_t);
 template hipError_t launch_exact_sweep<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, int, int, uint32_t, bt2g_sweep_out*, DevCounters*, hipStream_t);
-template hipError_t launch_seed_search_exact<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, const bt2g_read_params*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t);
-template hipError_t launch_seed_search_exact<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, const bt2g_read_params*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t);
+template hipError_t launch_seed_search_exact<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, const bt2g_read_params*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t, uint32_t, const ReseedCtl*);
+template hipError_t launch_seed_search_exact<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const uint32_t*, const uint32_t*, const uint32_t*, const bt2g_read_params*, uint32_t, bt2g_seed_hit*, DevCounters*, hipStream_t, uint32_t, const ReseedCtl*);
 template hipError_t launch_resolve_offsets<uint32_t>(const DevIndex<uint32_t>&, const uint64_t*, const uint32_t*, uint64_t, int, bt2g_resolved*, DevCounters*, hipStream_t);
 template hipError_t launch_resolve_offsets<uint64_t>(const DevIndex<uint64_t>&, const uint64_t*, const uint32_t*, uint64_t, int, bt2g_resolved*, DevCounters*, hipStream_t);
 

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include "bt2g_device.hpp"
+#include "bt2g_fm_search.hpp"
 #include "../../include/bt2g.h"
 
 namespace bt2g {
@@ -12,10 +13,14 @@ template <typename TOff>
 hipError_t launch_exact_sweep(const DevIndex<TOff>& ix, const bt2g_reads& rd, int nofw, int norc, uint32_t mine_max,
                               bt2g_sweep_out* d_out, DevCounters* d_cnt, hipStream_t st);
 
+// re-seeding round r > 0 of the batch pre-computation: seeds shifted by reseed_offset(), only for reads whose previous
+// round (`prev`: its seed hits) averaged >= boost_thresh elements per non-empty seed
+struct ReseedCtl { const bt2g_seed_hit* prev; uint32_t n_seed_rounds, boost_thresh; int nofw, norc; };
 template <typename TOff>
 hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& rd, const uint32_t* d_seedlen,
                                     const uint32_t* d_interval, const uint32_t* d_offset, const bt2g_read_params* d_rparams,
-                                    uint32_t max_seeds, bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st);
+                                    uint32_t max_seeds, bt2g_seed_hit* d_out, DevCounters* d_cnt, hipStream_t st,
+                                    uint32_t roundi = 0, const ReseedCtl* rc = nullptr);
 
 hipError_t launch_pack_results(const void* d_results, uint64_t stride, uint32_t n, uint32_t khits, void* d_packed, uint64_t* d_offsets, hipStream_t st);
 hipError_t launch_max_seeds(const bt2g_reads& rd, const bt2g_read_params* d_rparams, unsigned int* d_out, hipStream_t st);
@@ -23,7 +28,8 @@ hipError_t launch_max_seeds(const bt2g_reads& rd, const bt2g_read_params* d_rpar
 // batch pre-computation for the fused worker (round-0 seed-hit extension, 1-mismatch e2e search)
 template <typename TOff>
 hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds, int right,
-                              const bt2g_seed_hit* d_hits, uint32_t* d_ext, DevCounters* d_cnt, hipStream_t st);
+                              const bt2g_seed_hit* d_hits, uint32_t* d_ext, uint64_t* d_joff, DevCounters* d_cnt, hipStream_t st,
+                              uint32_t roundi = 0, uint32_t n_seed_rounds = 0);
 template <typename TOff>
 hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, const bt2g_reads& rd, const bt2g_read_params* d_rparams,
                          const bt2g_sweep_out* d_sweep, uint32_t cap, void* d_out, uint8_t* d_out_n, DevCounters* d_cnt, hipStream_t st);

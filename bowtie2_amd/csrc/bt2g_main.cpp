@@ -131,8 +131,10 @@ int main(int argc, char** argv) {
 	const size_t kWorkersPerDev = 3;
 	BoundedQueue<BatchPtr> q_in(ndev * kWorkersPerDev + 1), q_out(ndev * kWorkersPerDev + 1);
 
+	FILE* shard_idx = nullptr;
+	if (!ex.shard_index.empty()) { shard_idx = fopen(ex.shard_index.c_str(), "w"); if (!shard_idx) die("cannot open " + ex.shard_index); }
 	std::thread reader([&]() {
-		uint64_t seq = 0;
+		uint64_t seq = 0, blk = 0;
 		for (;;) {
 			BatchPtr b(new HostBatch());
 			if (inter) { fq.next(*b, batch_reads & ~(size_t)1, (size_t)BT2G_MAX_READ_LEN); finalize_interleaved(*b, opt); }
@@ -144,6 +146,13 @@ int main(int argc, char** argv) {
 				merge_mate_batches(std::move(b1), std::move(b2), *b, opt);
 			} else
 			fq.next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
+			// --shard r/N: batch k is block k of the input; this rank keeps blocks r, r+N, ... (an emptied batch still carries
+			// the end-of-input marker and any input error)
+			b->block_id = blk++;
+			if (ex.shard_world > 1 && (int)(b->block_id % (uint64_t)ex.shard_world) != ex.shard_rank) {
+				if (!b->last && b->bad_input.empty()) continue;
+				b->clear_reads();
+			}
 			b->seqno = seq++;
 			const bool last = b->last;
 			q_in.push(std::move(b));
@@ -177,7 +186,9 @@ int main(int argc, char** argv) {
 					        rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps);
 				}
 				const auto tf1_ = std::chrono::steady_clock::now();
-				for (const std::string& part : parts) fwrite(part.data(), 1, part.size(), out);
+				uint64_t nbytes = 0;
+				for (const std::string& part : parts) { fwrite(part.data(), 1, part.size(), out); nbytes += part.size(); }
+				if (shard_idx && !b->reads.empty()) fprintf(shard_idx, "B %llu %llu %llu\n", (unsigned long long)b->block_id, (unsigned long long)nbytes, (unsigned long long)b->reads.size());
 				t_format += std::chrono::duration<double>(tf1_ - tf0_).count();
 				t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf1_).count();
 				if (b->last) { done = true; break; }
@@ -252,7 +263,16 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "[bt2g] device search time %.3f s\n", align_s);
 		fprintf(stderr, "[bt2g] host stages: split %.3f s, parse %.3f s, pack %.3f s, format %.3f s, write %.3f s\n", fq.t_split, fq.t_parse, fq.t_pack, t_format, t_write);
 	}
-	if (!opt.quiet) { if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198)
+	if (shard_idx) {
+		// summary counters of this shard, for the cross-rank sum (the reference merges per-thread ReportingMetrics the same way, aln_sink.cpp:33-101)
+		fprintf(shard_idx, "S %llu %llu %llu %llu\n", (unsigned long long)summ.nread, (unsigned long long)summ.n0, (unsigned long long)summ.nuni, (unsigned long long)summ.nrep);
+		fprintf(shard_idx, "P %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", (unsigned long long)psumm.npair, (unsigned long long)psumm.conc0, (unsigned long long)psumm.conc_uni1,
+		        (unsigned long long)psumm.conc_uni2, (unsigned long long)psumm.conc_rep, (unsigned long long)psumm.ndiscord, (unsigned long long)psumm.unp00,
+		        (unsigned long long)psumm.unp0_uni1, (unsigned long long)psumm.unp0_uni2, (unsigned long long)psumm.unp0_rep);
+		fprintf(shard_idx, "F %llu\n", n_flagged);
+		fclose(shard_idx);
+	}
+	if (!opt.quiet && ex.shard_world == 1) { if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198); sharded: rank 0 of the driver prints the merged summary
 	for (bt2g_ctx* c : ctxs) bt2g_ctx_destroy(c);
 	if (n_flagged) {
 		// never pass off a capacity-limited result as the reference's

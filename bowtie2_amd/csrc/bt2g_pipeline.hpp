@@ -112,6 +112,8 @@ struct HostBatch {
 	bool last = false;                    // end-of-input marker (may still carry reads)
 	bool terminator = false;              // tells one device worker to stop (carries nothing)
 	uint64_t seqno = 0;                   // position in the input, for ordered output with several devices
+	uint64_t block_id = 0;                // --shard: which block of the input this batch is
+	void clear_reads() { chunks.clear(); reads.clear(); seq.clear(); qual.clear(); off.assign(1, 0); rp.clear(); max_len = 0; too_long.clear(); mate_src[0].reset(); mate_src[1].reset(); }
 	// paired-end: reads[2i] / reads[2i+1] are the mates of pair i; their text lives in the two single-mate batches
 	bool paired = false;
 	std::unique_ptr<HostBatch> mate_src[2];

@@ -89,3 +89,24 @@ def gather_in_read_order(dist, my_blocks, my_records, n_reads, record_bytes, dev
             out[b:e] = recs[pos:pos + (e - b)]
             pos += e - b
     return out
+
+
+def gather_packed(dist, packed, nbytes, device):
+    """The per-step merge of the N-GPU path: every rank's packed result records (bt2g_results_pack: a uint8 tensor in HBM, the
+    first `nbytes` bytes valid) gathered to rank 0 over the process group (RCCL over xGMI on GPUs).  Returns the list of
+    per-rank tensors on rank 0, None elsewhere.  dist.gather wants equal shapes: pieces are padded to the largest."""
+    import torch
+    rank, _, world = env_rank()
+    if dist is None:
+        return [packed[:nbytes]]
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([nbytes], dtype=torch.int64, device=device))
+    sizes = [int(s.item()) for s in sizes]
+    width = max(sizes)
+    if packed.numel() < width:
+        packed = torch.cat([packed, torch.zeros(width - packed.numel(), dtype=torch.uint8, device=device)])
+    got = [torch.empty(width, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+    dist.gather(packed[:width], got, dst=0)
+    if rank != 0:
+        return None
+    return [g[:sz] for g, sz in zip(got, sizes)]

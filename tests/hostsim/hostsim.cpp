@@ -21,6 +21,8 @@
 using namespace bt2g;
 
 static HotWork g_hot;
+static CliExtra g_ex;
+
 struct HostPlat {
 	static HotWork& hot() { return g_hot; }
 	static uint64_t clock() { return 0; }
@@ -28,9 +30,21 @@ struct HostPlat {
 	template <typename T> static T* uni_ptr(T* p) { return p; }
 	template <typename TOff> static TOff get_offset(const DevEbwt<TOff>& e, TOff row, uint32_t& nsteps) { return bt2g::get_offset(e, row, nsteps); }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
-		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)(1 << ref_base(ref, tidx, rfi + (int64_t)i));
+		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);
+		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)(1 << ref_base_at(ref, tidx, rfi + (int64_t)i, rec0));
+	}
+	static void fetch_ref_codes(const DevRef& ref, uint64_t tidx, int64_t rfi, uint32_t count) {
+		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);
+		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)ref_base_at(ref, tidx, rfi + (int64_t)i, rec0);
 	}
 	static void zero_masks(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
+	static void zero_u32(uint32_t* p, uint32_t n) { memset(p, 0, (size_t)n * 4); }
+	static void set_epoch(uint32_t* p, uint32_t e) { *p = e; }
+	static uint32_t pick_mass(const double* prefix, const uint8_t* elim, uint32_t n, double rd) {
+		uint32_t last = 0xffffffffu;
+		for (uint32_t i = 0; i < n; i++) if (!elim[i]) { last = i; if (rd < prefix[i]) return i; }
+		return last;
+	}
 	static void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols, bool wide) {
 		for (uint32_t j = 0; j < cols; j++) {
 			int sc;
@@ -80,6 +94,18 @@ struct HostPlat {
 				} else v = dp.masks[(uint64_t)r * cols + (uint32_t)c];
 			}
 			lo.v[ln] = v; hi.v[ln] = vh;
+		}
+	}
+	static void bt_tile_pred(const DpScratch& dp, uint32_t rows, uint32_t row, uint32_t col, uint32_t epoch, LaneReg& pr, LaneReg& mk) {
+		for (uint32_t d = 0; d < 64; d++) {
+			uint32_t p = 0, m = 0;
+			if (d <= row && d <= col) {
+				const uint64_t idx = pred_idx(rows, row, col) - d;
+				p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
+				const uint32_t w = dp.pmask[idx];
+				m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
+			}
+			pr.v[d] = p; mk.v[d] = m;
 		}
 	}
 	// scalar fill of the reference recurrence into the wavefront-major layout; returns best last-row H
@@ -183,9 +209,22 @@ struct HostPlat {
 				const int e = (j == 0) ? lo : imax(subs(Ep[i], P.rdgape), veto ? lo : subs(Hp[i], P.rdgapo));
 				f = (i == 0) ? lo : (veto ? lo : imax(subs(f, P.rfgape), subs(Hc[i - 1], P.rfgapo)));
 				const int h = imax(imax(subs(hdiag, pen), e), f);
-				Hc[i] = h; Ec[i] = e; Fc[i] = f;
 				if (wide) m64[dp_cell(R, i, j)] = (uint64_t)(uint16_t)h | ((uint64_t)(uint16_t)e << 16) | ((uint64_t)(uint16_t)f << 32);
-				else mat[dp_cell(R, i, j)] = (uint32_t)h | ((uint32_t)e << 8) | ((uint32_t)f << 16);
+				else {
+					// 8-bit end-to-end: predecessor bits (PB_*), diagonal-major; last row -> HOT.lastrow
+					const bool jl = j > 0, ga = !veto, row0 = i == 0;
+					const int hl = Hp[i], el = Ep[i], hu = row0 ? 0 : Hc[i - 1], fu = row0 ? 0 : Fc[i - 1];
+					int c = (jl && hdiag - pen == h) ? PB_HD : 0;
+					c |= (ga && jl && h == e) ? PB_HE : 0;
+					c |= (ga && h == f) ? PB_HF : 0;
+					c |= (jl && hl - P.rdgapo == e) ? PB_EO : 0;
+					c |= (jl && el - P.rdgape == e) ? PB_EE : 0;
+					c |= (!row0 && hu - P.rfgapo == f) ? PB_FO : 0;
+					c |= (!row0 && fu - P.rfgape == f) ? PB_FE : 0;
+					reinterpret_cast<uint8_t*>(mat)[pred_idx(rows, i, j)] = (uint8_t)c;
+					if (i == rows - 1) g_hot.lastrow[j] = (int16_t)(h - hi);
+				}
+				Hc[i] = h; Ec[i] = e; Fc[i] = f;
 			}
 			if (Hc[rows - 1] > lrmax) lrmax = Hc[rows - 1];
 			Hp.swap(Hc); Ep.swap(Ec);
@@ -234,14 +273,22 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 8;
 	dp.mat = (uint32_t*)malloc(mat_bytes);
 	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
+	dp.pmask_words = (uint32_t)pred_cells(kMaxLen, kMaxCols + 8);
+	dp.pmask = (uint32_t*)calloc(dp.pmask_words, 4); dp.epoch = (uint32_t*)calloc(64, 4);
 	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(P.khits + 1));
 	AlnSummary summ;
 	HostBatch hb;
+	// --shard r/N as in the product binary: batch k = block k of the input, this rank keeps blocks r, r+N, ...
+	FILE* shard_idx = g_ex.shard_index.empty() ? nullptr : fopen(g_ex.shard_index.c_str(), "w");
+	uint64_t blk = 0;
 	for (bool last = false; !last; ) {
 	hb = HostBatch();
-	fq.next(hb, 4096, (size_t)1 << 30);
+	fq.next(hb, std::min<size_t>(g_ex.batch_reads, 4096), (size_t)1 << 30);
 	last = hb.last;
 	if (!hb.bad_input.empty()) { fprintf(stderr, "Error: %s\n", hb.bad_input.c_str()); return 1; }
+	const uint64_t block_id = blk++;
+	if (g_ex.shard_world > 1 && (int)(block_id % (uint64_t)g_ex.shard_world) != g_ex.shard_rank) continue;
+	uint64_t nbytes = 0;
 	for (size_t ri = 0; ri < hb.reads.size(); ri++) {
 		const ReadRec& rd = hb.reads[ri];
 		ReadResult& rr = *(ReadResult*)resbuf.data();
@@ -255,7 +302,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		memcpy(g_hot.qual, rd.qual.data(), rd.qual.size());
 		Aligner<TOff, HostPlat> al(ix, P, rp, *w, dp);
 		al.run(rr);
-		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d)\n", rd.name.str().c_str(), rr.status);
+		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d, site %u)\n", rd.name.str().c_str(), rr.status, rr.pad2);
 		summ.add(rr);
 		o.clear();
 		if (rr.aligned) {
@@ -264,12 +311,18 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 			sam_record(o, opt, ref, rd, rr, nullptr, true);
 		}
 		fwrite(o.data(), 1, o.size(), out);
+		nbytes += o.size();
 		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u btsteps=%llu tiles=%llu cands=%llu\n", rd.name.str().c_str(),
 		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps,
 		                     (unsigned long long)g_hot.t_phase[11], (unsigned long long)g_hot.t_phase[12], (unsigned long long)g_hot.t_phase[13]);
 	}
+	if (shard_idx && !hb.reads.empty()) fprintf(shard_idx, "B %llu %llu %llu\n", (unsigned long long)block_id, (unsigned long long)nbytes, (unsigned long long)hb.reads.size());
 	}
-	if (!opt.quiet) summ.print(stderr);
+	if (shard_idx) {
+		fprintf(shard_idx, "S %llu %llu %llu %llu\nP 0 0 0 0 0 0 0 0 0 0\nF 0\n", (unsigned long long)summ.nread, (unsigned long long)summ.n0, (unsigned long long)summ.nuni, (unsigned long long)summ.nrep);
+		fclose(shard_idx);
+	}
+	if (!opt.quiet && g_ex.shard_world == 1) summ.print(stderr);
 	return 0;
 }
 
@@ -294,6 +347,9 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 8;
 	dp.mat = (uint32_t*)malloc(mat_bytes); dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
 	dp2.mat = (uint32_t*)malloc(mat_bytes); dp2.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
+	dp.pmask_words = dp2.pmask_words = (uint32_t)pred_cells(kMaxLen, kMaxCols + 8);
+	dp.pmask = (uint32_t*)calloc(dp.pmask_words, 4); dp.epoch = (uint32_t*)calloc(64, 4);
+	dp2.pmask = (uint32_t*)calloc(dp2.pmask_words, 4); dp2.epoch = (uint32_t*)calloc(64, 4);
 	const size_t rec_bytes = sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(P.khits + 1);
 	std::vector<uint8_t> resbuf(2 * rec_bytes);
 	PairSummary summ;
@@ -340,7 +396,7 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 
 int main(int argc, char** argv) {
 	Options opt;
-	CliExtra ex;
+	CliExtra& ex = g_ex;
 	ex.allow_paired = true;
 	const std::string perr = parse_cli(argc, argv, opt, ex);
 	if (ex.arg_desc) { print_arg_desc(); return 0; }

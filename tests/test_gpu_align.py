@@ -151,3 +151,30 @@ def test_two_device_workers_keep_input_order():
     for extra in (["--gpu", "0,0", "--batch", "7", "-p", "3"], ["--gpu", "0,0,0", "--batch", "64"], ["--batch", "1"]):
         got, err = run_ours(["--sensitive"] + extra + ["-x", base, "-U", fq])
         assert got == want, extra
+
+
+def test_sharded_driver_on_gpu(tmp_path):
+    """bowtie2_amd.mgpu with the product executable as the engine: two ranks (both on this box's one GPU, so the process
+    group is gloo; on an N-GPU node it is RCCL) each align their --shard of the input; the merged SAM must equal the golden
+    SAM recorded from the reference, and the merged summary the single-process one."""
+    import socket
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    common = ["--sensitive", "--batch", "64", "--gpu", "0", "-x", os.path.join(GOLD, "tiny_s"), "-U", os.path.join(GOLD, "align_reads.fq")]
+    one, one_err = run_ours(common)
+    out = tmp_path / "merged.sam"
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GLOO_SOCKET_IFNAME="lo", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-m", "bowtie2_amd.mgpu", "--backend", "gloo", "--"] + common + ["-S", str(out)],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        errs.append(se)
+    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    assert got == open(os.path.join(GOLD, "align_golden_s_sens.sam")).read().splitlines()
+    assert got == one
+    assert errs[0].strip().splitlines()[-6:] == one_err.strip().splitlines()[-6:]

@@ -31,12 +31,15 @@ for b, e in blocks:
 dt = shard.reduce_max(dist, 1.0 + rank, dev)               # rank 1 is the slow one
 aligned, total = shard.reduce_sum(dist, [mine - rank, mine], dev)
 allrec = shard.gather_in_read_order(dist, blocks, recs, n_reads, rec, dev)
+# per-step merge of packed records (ragged sizes): rank r sends 1000 + 37 * r bytes of value r + 1
+pk = shard.gather_packed(dist, torch.full((5000,), rank + 1, dtype=torch.uint8), 1000 + 37 * rank, dev)
 out = {"rank": rank, "world": world, "dt": dt, "aligned": aligned, "total": total, "mine": mine,
        "seed": shard.shard_seed(1000, rank), "value": shard.throughput(world, 1000, 5, dt)}
 if rank == 0:
     ids = allrec[:, :8].contiguous().view(torch.int64).view(-1)
     out["in_order"] = bool((ids == torch.arange(n_reads)).all())
     out["from_both"] = sorted(set(allrec[:, 8].tolist()))
+    out["packed"] = [[int(t.numel()), int(t.min()), int(t.max())] for t in pk]
 dist.barrier()
 print("RESULT " + json.dumps(out), flush=True)
 dist.destroy_process_group()
@@ -88,6 +91,7 @@ def test_two_ranks_gloo(tmp_path):
     assert outs[0]["seed"] != outs[1]["seed"]
     assert outs[0]["value"] == 2 * 1000 * 5 / 2.0                     # whole-job throughput over the slowest rank
     assert outs[0]["in_order"] and outs[0]["from_both"] == [0, 1]
+    assert outs[0]["packed"] == [[1000, 1, 1], [1037, 2, 2]]
 
 
 def test_blocks_keep_mates_together():
@@ -105,3 +109,35 @@ def test_blocks_keep_mates_together():
         assert cover[0][0] == 0 and cover[-1][1] == n and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
         seen += 1
     assert seen == 4
+
+
+def test_sharded_driver_two_ranks_sam_identical(tmp_path):
+    """bowtie2_amd.mgpu (the N-GPU driver: the product executable per rank with --shard r/N, SAM pieces gathered and
+    counters all-reduced over the process group) with world size 2 on gloo.  The engine here is the CPU twin of the
+    worker (tests/hostsim, test-only, same command line and reader); the merged SAM and the merged summary must be
+    byte-identical to the reference's golden SAM / the 1-rank run."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    hs = os.path.join(ROOT, "tests", "hostsim", "hostsim")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", hs,
+                           os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    common = ["--sensitive", "--batch", "64", "-x", os.path.join(gold, "tiny_s"), "-U", os.path.join(gold, "align_reads.fq")]
+    one = subprocess.run([hs] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
+    port = free_port()
+    out = tmp_path / "merged.sam"
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-m", "bowtie2_amd.mgpu", "--engine", hs, "--backend", "gloo", "--"] + common + ["-S", str(out)],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        errs.append(se)
+    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    want = open(os.path.join(gold, "align_golden_s_sens.sam")).read().splitlines()
+    assert got == want
+    assert got == [l for l in one.stdout.splitlines() if not l.startswith("@PG")]
+    # the merged summary (rank 0) equals the single-process summary
+    assert errs[0].strip().splitlines()[-6:] == one.stderr.strip().splitlines()[-6:]
