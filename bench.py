@@ -321,6 +321,23 @@ def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, thre
     else:
         a, b_ = sam_body(ref_sam), sam_body(our_sam)
         ndiff = sum(1 for x, y in zip(a, b_) if x != y) + abs(len(a) - len(b_))
+        if ndiff:
+            # keep the evidence: differing lines (reference first) and the reads behind them, next to the bench output
+            dd = os.path.join(ROOT, "gpurun_out", "parity_diff")
+            os.makedirs(dd, exist_ok=True)
+            names = set()
+            with open(os.path.join(dd, "diff.txt"), "wb") as f:
+                for x, y in zip(a, b_):
+                    if x != y and len(names) < 200:
+                        f.write(b"REF " + x + b"GPU " + y)
+                        names.add(x.split(b"\t", 1)[0]); names.add(y.split(b"\t", 1)[0])
+            with open(fq_all, "rb") as f, open(os.path.join(dd, "reads.fq"), "wb") as g:
+                while True:
+                    rec = [f.readline() for _ in range(4)]
+                    if not rec[0]:
+                        break
+                    if rec[0][1:].strip() in names:
+                        g.write(b"".join(rec))
         par = {"parity_checked_reads": n_sample, "parity_identical": ndiff == 0, "parity_differing_sam_lines": ndiff,
                "parity_product_binary_wall_s": round(t, 2)}
         aligned_ref = sum(1 for l in a if not l.startswith(b"@") and not (int(l.split(b"\t", 2)[1]) & 4))

@@ -49,6 +49,9 @@ public:
 	virtual ~ByteSource() {}
 	int get() { if (cur_ == n_ && !fill()) return -1; return buf_[cur_++]; }
 	bool at_end() { if (cur_ == n_) fill(); return cur_ == n_; }
+	// bulk access for the base-reading loop: the bytes buffered right now (0 at the end of input), and a way to consume them
+	size_t window(const uint8_t*& p) { if (cur_ == n_ && !fill()) return 0; p = buf_ + cur_; return n_ - cur_; }
+	void advance(size_t k) { cur_ += k; }
 protected:
 	virtual size_t read_some(uint8_t* dst, size_t cap) = 0;
 private:
@@ -122,11 +125,27 @@ inline bool scan_fasta(ByteSource& in, RefInput& out, uint64_t& seqs_read, std::
 			}
 		}
 		if (!finished) {
-			while (c != -1 && c != '>') {
-				const int cat = dna_cat(c);
-				if (cat == 1) { out.joined.push_back((uint8_t)dna_code(c)); len++; }
-				else if (cat >= 2) break;
-				c = in.get();
+			// c holds the stretch's first base.  Bulk loop over the buffered bytes: 0-3 = base code, 4 = ignored inside a
+			// sequence (whitespace, digits, ...), 5 = ends the stretch ('>' or an ambiguous character)
+			static const struct Lut { uint8_t t[256]; Lut() { for (int i = 0; i < 256; i++) { const int cat = dna_cat(i); t[i] = cat == 1 ? (uint8_t)dna_code(i) : (cat >= 2 || i == '>') ? 5 : 4; } } } lut;
+			out.joined.push_back((uint8_t)dna_code(c)); len++;
+			c = -1;
+			for (bool stop = false; !stop; ) {
+				const uint8_t* p;
+				const size_t n = in.window(p);
+				if (n == 0) { c = -1; break; }
+				const size_t base = out.joined.size();
+				out.joined.resize(base + n);
+				uint8_t* dst = out.joined.data() + base;
+				size_t k = 0, m = 0;
+				for (; k < n; k++) {
+					const uint8_t v = lut.t[p[k]];
+					if (v < 4) dst[m++] = v;
+					else if (v == 5) { c = p[k]; stop = true; k++; break; }
+				}
+				out.joined.resize(base + m);
+				len += m;
+				in.advance(k);
 			}
 			lastc = c;
 		}
