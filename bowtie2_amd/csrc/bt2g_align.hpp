@@ -34,13 +34,14 @@ namespace bt2g {
 
 constexpr int kMaxLen      = 512;   // longest read (DP rows)
 constexpr int kMaxOffs     = 64;    // seed offsets per strand
-constexpr int kMaxMm1      = 256;   // 1-mismatch end-to-end hits kept
+constexpr int kMaxMm1      = 1024;  // 1-mismatch end-to-end hits kept (a simple-repeat read has hundreds)
 constexpr int kMaxRanges   = 2 * kMaxOffs;   // seed positions (both strands)
 constexpr int kMaxSat2     = 4096;  // seed-hit ranges of one round: one per position with -N 0, up to ~100 per position with -N 1
 constexpr int kMaxSatpos   = 1856;  // maxIters(400 + 20*(k-1), k <= 64) + ranges + slack
 constexpr int kMaxEdits    = 200;
-constexpr int kMaxRedAnchor = 192;  // alignments remembered by the paired-end redundancy set
-constexpr int kMaxAlns     = 64;    // alignments kept by the sink (-M 50 -> at most 51)
+constexpr int kMaxRedAnchor = 1280;  // alignments remembered by the paired-end redundancy set
+constexpr int kMaxAlnsU    = 640;   // unpaired alignments kept per mate of a pair: every distinct opposite-mate alignment found during mate rescue lands here
+constexpr int kMaxAlns     = 160;   // alignments kept by the sink (-M 50 -> at most 51)
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 65536; // uint32 slots for Random1toN lists (swap lists of small ranges, seen lists bounded by max_iters, converted lists)
 constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
@@ -149,7 +150,25 @@ struct PeHot {
 	uint32_t n_mate_dps, n_mate_ugs;
 	uint32_t olen;                      // length of the mate that is not loaded
 };
-struct HotHit { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // exact seed hit: one range.  With -N 1: topf = first entry in Work::sranges, topb = # ranges, size = total elements
+// The reference keeps the seed hits of one seeding round in an AlignmentCache whose memory is a fixed pool of 16 KB pages
+// (--seed-cache-sz, 20 MB: aligner_cache.h:66,466-480, ds.h:3067-3150).  Every SA range is stored with one pool slot PER
+// ELEMENT (AlignmentCache::addOnTheFlyImpl, aligner_cache.cpp:53-105), so a read whose seeds hit millions of rows --
+// simple repeats, the commonest Alu words -- exhausts the pool: the range being stored is cut to what fitted, the seed
+// that was being added is dropped (SeedAligner::searchAllSeeds counts an "oom" and skips sr.add, aligner_seed.cpp:672-690),
+// later seeds with a new sequence are dropped too, and later seeds with an already-stored sequence see the cut range.
+// SAM parity needs exactly that, so the worker replays the pool accounting per seeding round: pages handed to the QKey map,
+// the SAKey list, the SAKey map and the element list, in seed order (fw offsets, then rc offsets).
+constexpr int kCacheKeys = 2 * kMaxOffs * 2;      // distinct seed sequences of one round (both mates of a pair)
+struct CacheModel {
+	uint32_t pool_total, pool_used;
+	uint32_t qn, ql, san;          // nodes in the QKey map, entries in the SAKey list, nodes in the SAKey map
+	uint64_t sl;                   // elements in the element list
+	uint32_t nkeys;
+};
+
+// `size` = elements the seed search found (what SeedResults tallies and ranks by); `esize` = elements of the range as the
+// per-read seed cache holds it: smaller when the cache's page pool ran out while the range was stored (struct CacheModel)
+struct HotHit { uint64_t topf, topb; uint32_t size; uint32_t esize; };   // exact seed hit: one range.  With -N 1: topf = first entry in Work::sranges, topb = # ranges, size = total elements
 struct SeedRange { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // one BW range of a 1-mismatch seed (SATuple, aligner_cache.h:370)
 struct HotWork {
 	uint8_t  seq[kMaxLen];     // read, codes 0..4, 5'->3'
@@ -192,6 +211,7 @@ struct HotWork {
 	uint32_t n_ext_left, n_ext_right, n_resolve_steps;
 	uint32_t n_sides;           // sides (64/128-byte lines) actually read -- roofline accounting
 	uint32_t n_sranges;         // -N 1: entries of Work::sranges in use
+	CacheModel cm;              // seed cache pool of the current seeding round
 	PeHot    pe;                // paired-end reporting state (unused for unpaired reads)
 	uint64_t t_phase[22];       // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other
 };
@@ -201,6 +221,11 @@ struct HotWork {
 constexpr uint32_t kBtTile = 15;
 
 struct Work {
+	// per-round seed cache model (CacheModel): one entry per distinct seed sequence
+	uint64_t ck_key[kCacheKeys];
+	uint32_t ck_eff[kCacheKeys];   // elements the stored range holds (after a possible cut)
+	uint8_t  ck_len[kCacheKeys];
+	uint8_t  ck_flags[kCacheKeys]; // bit 0: in the QKey map, bit 1: in the SAKey map
 	// ---- read ----
 	// ---- seed phase ----
 	EEHit    mm1[kMaxMm1];
@@ -235,9 +260,9 @@ struct Work {
 		EEHit    mm1[kMaxMm1];
 		SeedRange sranges[kMaxSat2];
 	} ms[2];
-	AlnRes   alns_u[2][kMaxAlns];       // rs1u_ / rs2u_: unpaired alignments per mate (also redMate1_/redMate2_)
+	AlnRes   alns_u[2][kMaxAlnsU];       // rs1u_ / rs2u_: unpaired alignments per mate (also redMate1_/redMate2_)
 	AlnRes   alns_p[2][kMaxAlns];       // rs1_ / rs2_: concordant (or the one discordant) pair, same index
-	int64_t  redu_dmin[2][kMaxAlns], redu_dmax[2][kMaxAlns];
+	int64_t  redu_dmin[2][kMaxAlnsU], redu_dmax[2][kMaxAlnsU];
 	AlnRes   red_anchor[kMaxRedAnchor]; // redAnchor_: every alignment found for either mate while it was the anchor or the rescued mate
 	int64_t  reda_dmin[kMaxRedAnchor], reda_dmax[kMaxRedAnchor];
 	AlnRes   ores;                      // oresGap_

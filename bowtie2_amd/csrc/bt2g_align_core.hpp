@@ -93,18 +93,96 @@ struct Aligner {
 			for (uint32_t i = 0; i < nseeds; i++) {
 				HotHit& h = HOT.hits[fwi][i];
 				HOT.sorted[fwi][i] = 0;
-				h.topf = h.topb = 0; h.size = 0;
+				h.topf = h.topb = 0; h.size = h.esize = 0;
 				if (skip) continue;
 				const bt2g_seed_hit sh = src[i];
-				if (sh.botf > sh.topf) {
-					h.topf = sh.topf; h.topb = sh.topb; h.size = (uint32_t)(sh.botf - sh.topf);
-					HOT.nonz_tot++;
-					if (fw) HOT.nonz_fw++; else HOT.nonz_rc++;
-					HOT.num_elts += sh.botf - sh.topf;
-				}
+				if (sh.botf > sh.topf) { h.topf = sh.topf; h.topb = sh.topb; h.size = h.esize = (uint32_t)(sh.botf - sh.topf); }
 			}
 		}
+		cache_filter(interval, offset, seedlen);
 		return 1;   // # instantiated seeds only matters when no seed hit (run() ends the read either way)
+	}
+
+	// ---- the reference's per-round seed cache (see struct CacheModel) ----
+	BT2_HD void cache_reset() {
+		CacheModel& c = HOT.cm;
+		const uint64_t bytes = (uint64_t)(P.seed_cache_mb > 0 ? P.seed_cache_mb : 20) * 1024 * 1024;
+		c.pool_total = (uint32_t)((bytes + 16383) / 16384 + 1);       // Pool::Pool (ds.h:3078)
+		c.pool_used = 0; c.qn = c.ql = c.san = 0; c.sl = 0; c.nkeys = 0;
+	}
+	BT2_HD bool cache_page() { CacheModel& c = HOT.cm; if (c.pool_used == c.pool_total) return false; c.pool_used++; return true; }
+	// Seeds of the round in HOT.hits (size = what the search found) -> what SeedResults ends up holding: hits of dropped seeds
+	// cleared, esize set, tallies (nonz_*, num_elts) formed.  Exact seeds only: a -N 1 round is tallied unmodelled.
+	BT2_HDN void cache_filter(uint32_t interval, uint32_t offset, uint32_t seedlen) {
+		CacheModel& c = HOT.cm;
+		const uint32_t len = HOT.len, L = seedlen < len ? seedlen : len;
+		constexpr uint32_t q_per = sizeof(TOff) == 4 ? 256u : 227u;     // 16 KB / sizeof(RedBlackNode<QKey,QVal>)  (64 / 72 bytes)
+		constexpr uint32_t sa_per = sizeof(TOff) == 4 ? 256u : 204u;    // 16 KB / sizeof(RedBlackNode<SAKey,SAVal>) (64 / 80 bytes)
+		constexpr uint32_t ql_per = 1024u;                              // 16 KB / sizeof(SAKey)
+		constexpr uint64_t sl_per = 16384u / sizeof(TOff);              // 16 KB / sizeof(TIndexOffU)
+		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
+		for (int fwi = 0; fwi < 2; fwi++) {
+			const bool fw = fwi == 0;
+			if ((fw && m_nofw) || (!fw && m_norc)) continue;
+			for (uint32_t i = 0; i < HOT.num_offs; i++) {
+				HotHit& h = HOT.hits[fwi][i];
+				const uint32_t depth = i * interval + offset;
+				// the seed as it aligns to the Watson strand, packed; a seed with an N is never instantiated (no cache traffic)
+				uint64_t key = 0;
+				bool inst = L <= 32;
+				for (uint32_t k = 0; k < L && inst; k++) {
+					const int ch = fw ? (int)HOT.seq[depth + k] : comp4(HOT.seq[depth + L - 1 - k]);
+					if (ch > 3) inst = false; else key = (key << 2) | (uint64_t)ch;
+				}
+				if (!inst) { if (L > 32) { /* uncacheable keys (-L > 32 cannot occur) */ } h.size = h.esize = 0; continue; }
+				uint32_t e = 0;
+				while (e < c.nkeys && !(w.ck_key[e] == key && w.ck_len[e] == (uint8_t)L)) e++;
+				bool drop = false;
+				// beginAlign: the seed sequence enters the QKey map
+				if (e == c.nkeys || !(w.ck_flags[e] & 1)) {
+					if (c.qn % q_per == 0 && !cache_page()) drop = true;
+					else {
+						c.qn++;
+						if (e == c.nkeys) {
+							if (c.nkeys >= (uint32_t)kCacheKeys) { ovf(30); h.size = h.esize = 0; continue; }
+							w.ck_key[e] = key; w.ck_len[e] = (uint8_t)L; w.ck_flags[e] = 0; w.ck_eff[e] = 0; c.nkeys++;
+						}
+						w.ck_flags[e] |= 1;
+					}
+				}
+				if (!drop && h.size > 0) {
+					// addOnTheFly: SAKey list entry, SAKey map node, one element-list slot per row
+					if (c.ql % ql_per == 0 && !cache_page()) drop = true;
+					else {
+						c.ql++;
+						if (!(w.ck_flags[e] & 2)) {
+							if (c.san % sa_per == 0 && !cache_page()) drop = true;
+							else {
+								c.san++;
+								w.ck_flags[e] |= 2;
+								const uint64_t full = h.size;
+								const uint64_t room = (sl_per - c.sl % sl_per) % sl_per + (uint64_t)(c.pool_total - c.pool_used) * sl_per;
+								if (full <= room) {
+									const uint64_t in_page = (sl_per - c.sl % sl_per) % sl_per;
+									if (full > in_page) c.pool_used += (uint32_t)((full - in_page + sl_per - 1) / sl_per);
+									c.sl += full; w.ck_eff[e] = (uint32_t)full;
+								} else {
+									c.sl += room; c.pool_used = c.pool_total; w.ck_eff[e] = (uint32_t)room;      // the range is cut, this seed is dropped
+									drop = true;
+								}
+							}
+						}
+					}
+				}
+				if (drop || h.size == 0) { h.size = h.esize = 0; continue; }
+				h.esize = w.ck_eff[e];
+				// (esize 0: the pool was already empty when the sequence's range was first stored.  The seed still counts and is
+				// ranked, but AlignmentCache::queryQvalImpl hands out no range for it, aligner_cache.h:646)
+				HOT.nonz_tot++;
+				if (fw) HOT.nonz_fw++; else HOT.nonz_rc++;
+				HOT.num_elts += (uint64_t)h.size;
+			}
+		}
 	}
 
 	// =================================================================================
@@ -258,7 +336,7 @@ struct Aligner {
 			const bool fw = fwi == 0;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				HotHit& h = HOT.hits[fwi][i];
-				h.topf = h.topb = 0; h.size = 0;
+				h.topf = h.topb = 0; h.size = h.esize = 0;
 				HOT.sorted[fwi][i] = 0;
 			}
 			if ((fw && m_nofw) || (!fw && m_norc)) continue;
@@ -308,13 +386,10 @@ struct Aligner {
 				}
 				if (!ok) continue;
 				HotHit& h = HOT.hits[fwi][i];
-				h.topf = topf; h.topb = topb; h.size = (uint32_t)(botf - topf);
-				// SeedResults::add (aligner_seed.h:639-676)
-				HOT.nonz_tot++;
-				if (fw) HOT.nonz_fw++; else HOT.nonz_rc++;
-				HOT.num_elts += (uint64_t)(botf - topf);
+				h.topf = topf; h.topb = topb; h.size = h.esize = (uint32_t)(botf - topf);
 			}
 		}
+		cache_filter(interval, offset, seedlen);      // SeedResults::add (aligner_seed.h:639-676) after the cache has had its say
 		return ninst;
 	}
 
@@ -340,7 +415,7 @@ struct Aligner {
 			const bool fw = fwi == 0;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				HotHit& h = HOT.hits[fwi][i];
-				h.topf = h.topb = 0; h.size = 0;
+				h.topf = h.topb = 0; h.size = h.esize = 0;
 				HOT.sorted[fwi][i] = 0;
 			}
 			if ((fw && m_nofw) || (!fw && m_norc)) continue;
@@ -468,7 +543,7 @@ struct Aligner {
 				}
 				if (nsr > first && elts > 0) {
 					HotHit& h = HOT.hits[fwi][i];
-					h.topf = first; h.topb = nsr - first; h.size = (uint32_t)elts;
+					h.topf = first; h.topb = nsr - first; h.size = h.esize = (uint32_t)elts;
 					HOT.nonz_tot++;
 					if (fw) HOT.nonz_fw++; else HOT.nonz_rc++;
 					HOT.num_elts += elts;
@@ -735,8 +810,9 @@ struct Aligner {
 			const HotHit& h = HOT.hits[fw ? 0 : 1][offidx];
 			const uint32_t nr_here = seedmms > 0 ? (uint32_t)h.topb : 1u;      // ca.queryQval: one SATuple per reference string
 			for (uint32_t ri = 0; ri < nr_here; ri++) {
-			uint64_t h_topf = h.topf, h_topb = h.topb, sz = h.size;
+			uint64_t h_topf = h.topf, h_topb = h.topb, sz = h.esize;      // the range as the seed cache holds it
 			if (seedmms > 0) { const SeedRange& sr = w.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.size; }
+			else if (sz == 0) continue;
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
 				const bool m2 = P.paired && HOT.pe.cur == 1;     // seedExRangeFw_[matei] / seedExRangeRc_[matei]
@@ -757,7 +833,7 @@ struct Aligner {
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
 			uint32_t nlex = 0, nrex = 0;
 			if (P.do_extend) {
-				if (ext_pre && seedmms == 0) {
+				if (ext_pre && seedmms == 0 && h.esize == h.size) {      // (a range the cache cut short is extended as the shorter range)
 					const uint32_t e = pre_ext_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + offidx];
 					nlex = e & 0xffffu; nrex = e >> 16;
 				} else extend_hit((TOff)h_topf, (TOff)(h_topf + sz), (TOff)h_topb, (TOff)(h_topb + sz), fw, rdoff, seedlen, nlex, nrex);
@@ -1777,6 +1853,7 @@ struct Aligner {
 				if (offset > 0 && (uint32_t)rp.seedlen + offset > len) continue;
 				const uint64_t ts_ = now();
 				ext_pre = false;
+				cache_reset();          // ca.nextRead() (bt2_search.cpp:3882)
 				uint32_t ninst;
 				if (P.seed_mms > 0) ninst = seed_round_mm1(offset, interval, (uint32_t)rp.seedlen);
 				else if (offset == 0 && pre && pre->seeds && 1 + (len > (uint32_t)rp.seedlen ? (len - (uint32_t)rp.seedlen) / interval : 0u) <= pre->max_seeds) {

@@ -225,6 +225,8 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--exact-upfront") opt.no_exact_upfront = false;
 		else if (a == "-d" || a == "--deterministic-seeds") opt.det_seeds = true;
 		else if (a == "--no-deterministic-seeds") opt.det_seeds = false;
+		else if (a == "--seed-cache-sz") { opt.seed_cache_mb = atoi(need().c_str()); if (opt.seed_cache_mb < 1) err = "--seed-cache-sz arg must be at least 1"; }
+		else if (a == "--local-seed-cache-sz") { (void)need(); }      // across-read cache: not used by the reference either (msNoCache)
 		else if (a == "--no-unal") opt.no_unal = true;
 		else if (a == "--xeq") opt.xeq = true;
 		else if (a == "--omit-sec-seq" || a == "--sam-omit-sec-seq") opt.omit_sec_seq = true;

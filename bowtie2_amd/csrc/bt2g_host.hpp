@@ -81,6 +81,7 @@ struct Options {
 	bool bwa_sw_like = false;     // --bwa-sw-like: minimum score = a*max(T, c*ln(len)) (bt2_search.cpp:3341-3350)
 	bool report_overhangs = false;
 	bool det_seeds = false;       // -d / --deterministic-seeds
+	int seed_cache_mb = 20;       // --seed-cache-sz (bt2_search.cpp:457,1184)
 	bool passthrough = false;     // --passthrough: every SAM line is followed by the read's original text (the Perl wrapper's --un/--al/--un-conc/--al-conc)
 	bool no_exact_upfront = false;
 	// paired-end input and policy (bt2_search.cpp:1185-1215; PairedEndPolicy pe.h:169)
@@ -143,6 +144,7 @@ struct Options {
 		             (no_discordant ? 0 : BT2G_PE_DISCORD) | (no_mixed ? 0 : BT2G_PE_MIXED) | (mate1fw ? BT2G_PE_MATE1FW : 0) | (mate2fw ? BT2G_PE_MATE2FW : 0);
 		P.max_mate_streak = 10;
 		P.det_seeds = det_seeds ? 1 : 0;
+		P.seed_cache_mb = seed_cache_mb;
 		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
 		if (all_hits) {
 			// -a lifts every effort limit (bt2_search.cpp:3457-3463)

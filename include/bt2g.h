@@ -218,6 +218,8 @@ typedef struct {
 	int32_t pe_flags;              /* BT2G_PE_* below                                                            */
 	int32_t max_mate_streak;       /* maxMateStreak (10), scaled with -k like max_dp_streak                      */
 	int32_t det_seeds;             /* -d: seed-hit ranges in sorted order, rows in index order, no sampling (prioritizeSATupsIdxs) */
+	int32_t seed_cache_mb;         /* --seed-cache-sz (default 20): size of the reference's per-read seed-hit cache, whose exhaustion on
+	                                  reads with millions of seed-hit rows is part of its output (0 = 20)                       */
 } bt2g_align_params;
 #define BT2G_PE_DOVETAIL_OK  1     /* --dovetail                       */
 #define BT2G_PE_CONTAIN_OK   2     /* cleared by --no-contain          */

@@ -378,7 +378,7 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 			al.pe_rp[0] = hb.rp[pi]; al.pe_rp[1] = hb.rp[pi + 1];
 			al.pe_pair = 0;
 			al.run_pair(rr1, rr2);
-			if (rr1.status || rr2.status) fprintf(stderr, "Warning: pair %s overflowed a fixed-capacity buffer (status %d)\n", r1.name.str().c_str(), rr1.status | rr2.status);
+			if (rr1.status || rr2.status) fprintf(stderr, "Warning: pair %s overflowed a fixed-capacity buffer (status %d, site %u %u)\n", r1.name.str().c_str(), rr1.status | rr2.status, rr1.pad2, rr2.pad2);
 			summ.add(rr1, rr2);
 			std::vector<const AlnRes*> a1, a2;
 			for (uint32_t i = 0; i < rr1.nreport; i++) a1.push_back(&rr1.alns[i]);

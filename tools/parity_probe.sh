@@ -1,7 +1,7 @@
 #!/bin/bash
 # After a bench run that found SAM differences (gpurun_out/parity_diff): align just those reads again -- product with and
 # without the batch pre-computation kernels, and the reference -- so that the culprit stage can be told apart.
-R=$GRAFT_REPO_ROOT; D=$R/gpurun_out/parity_diff
+R=$GRAFT_REPO_ROOT; D=$R/gpurun_out/parity_diff; mkdir -p $D; [ -s $D/reads.fq ] || cp $R/tools/probe/reads.fq $D/reads.fq
 IDX=${1:-/tmp/bt2_amd_bench/hg38like_1024mbp_s2_bt2l}
 [ -s $D/reads.fq ] || { echo "no differing reads"; exit 0; }
 cd $R
