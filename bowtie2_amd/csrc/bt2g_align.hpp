@@ -117,6 +117,14 @@ struct SatPos {           // SATupleAndPos (aligner_sw_driver.h:144)
 	R1N      rnd;         // rands_[i]
 };
 
+// A row drawn by the RowSampler: which range (Work::satpos2 index) and which row.  prioritize() draws up to max_iters of
+// them per call but the extension loop consumes a few dozen, so only the consumed ones are expanded to a SatPos.
+struct SampRow { uint64_t topf; uint32_t src; uint32_t done; };
+
+// Random1toN of a sampled range, kept in LDS while prioritize() runs (same fields as R1N, narrower where the values allow)
+struct R1C { uint32_t n, cur, list_off, seen_off; uint16_t seen_len, thresh; uint8_t swaplist, converted, inited, pad; };
+constexpr int kFastSamp = 64;      // ranges the on-chip sampler state holds
+
 struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };
 
 struct BtCand { int32_t score; uint16_t row, col; };
@@ -181,7 +189,7 @@ struct HotWork {
 	union {                    // never live at the same time: the gather reads `lastrow` before any backtrace writes `ned`; RowSampler state only exists inside prioritize()
 		Edit     ned[kMaxEdits];   // edits of the backtrace in progress
 		int16_t  lastrow[kMaxCols + 8];   // scores of the last DP row, clamped at -32768 (gatherCells)
-		struct { double prefix[kMaxRanges]; uint8_t elim[kMaxRanges]; } samp;   // RowSampler: running sums of the masses not yet eliminated
+		struct { double prefix[kFastSamp]; R1C r[kFastSamp]; uint8_t elim[kFastSamp]; } samp;   // RowSampler + Random1toN state of the ranges being sampled
 	};
 	// ---- scalar control state of the read in flight (everything the control code touches often) ----
 	uint32_t len;
@@ -195,6 +203,8 @@ struct HotWork {
 	uint64_t num_elts;
 	uint32_t n_satpos2;
 	uint32_t n_satpos;
+	uint32_t n_resolved;        // sampled rows [n_satpos_full, n_resolved) have their offset in Work::srow_joff
+	uint32_t n_satpos_full;     // entries [0, n_satpos_full) of the extension list are whole SatPos records, the rest sampled rows (Work::srows)
 	uint32_t lists_used;
 	double   mass;
 	uint32_t n_masses;
@@ -234,6 +244,9 @@ struct Work {
 	SatPos   satpos2[kMaxSat2];
 	R1N      rands2[kMaxSat2];
 	SatPos   satpos[kMaxSatpos];
+	SampRow  srows[kMaxSatpos];
+	uint64_t srow_joff[kMaxSatpos];     // their text offsets (joff_pack), resolved 64 rows at a time by all lanes
+	SatPos   sp_view;                   // the sampled row being extended, expanded
 	uint32_t lists[kListArena];
 	double   masses[kMaxSat2];
 	uint8_t  elim[kMaxSat2];
@@ -273,9 +286,9 @@ struct Work {
 
 // DP scratch of one wave.  Two matrix formats:
 //  * end-to-end 8-bit mode (the common case): ONE BYTE per cell holding which predecessors are score-consistent
-//    (PB_* below), computed while the cell is filled -- the backtrace never looks at scores again.  Diagonal-major
-//    (pred_idx): a run of diagonal steps reads consecutive bytes.  Its per-cell backtrace masks (`pmask`, 32 bits) carry an
-//    epoch tag instead of being cleared for every DP;
+//    (PB_* below), computed while the cell is filled -- the backtrace never looks at scores again.  Wavefront-major
+//    (pred_idx) so that the fill's stores are whole 64-byte lines; the backtrace gathers 64 diagonal steps per fetch.  Its
+//    per-cell backtrace masks (`pmask`, 32 bits) carry an epoch tag instead of being cleared for every DP;
 //  * 16-bit end-to-end and local mode: wavefront-major packed H|E|F cells (dp_cell) + a 16-bit mask plane that is zeroed
 //    after every fill that has candidate cells.
 struct DpScratch {
@@ -291,9 +304,13 @@ struct DpScratch {
 enum { PB_HD = 1, PB_HE = 2, PB_HF = 4, PB_EO = 8, PB_EE = 16, PB_FO = 32, PB_FE = 64 };
 constexpr uint32_t kEpochShift = 13, kEpochMax = (1u << 19) - 1;
 constexpr uint32_t kPredTile = 64;   // diagonal steps one tile fetch covers
-BT2_HD uint32_t pred_rp(uint32_t rows) { return (rows + 63u) & ~63u; }
-BT2_HD uint64_t pred_idx(uint32_t rows, uint32_t i, uint32_t j) { return (uint64_t)(j + rows - 1 - i) * pred_rp(rows) + i; }
-BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { return (uint64_t)(rows + cols) * pred_rp(rows); }
+// cell (i, j) of the pred format: wavefront-major like the packed cells (lane l = i / R owns rows l*R .. l*R+R-1 and reaches
+// column j at fill step t = j + l), one byte per cell -- every fill step stores R runs of 64 consecutive bytes
+BT2_HD uint64_t pred_idx(uint32_t rows, uint32_t i, uint32_t j) {
+	const uint32_t R = (rows + 63) / 64, l = i / R, r = i % R;
+	return ((uint64_t)(j + l) * R + r) * 64 + l;
+}
+BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { const uint32_t R = (rows + 63) / 64; return ((uint64_t)cols + (rows + R - 1) / R) * R * 64; }
 
 // ---------------------------------------------------------------------------------------
 // small helpers

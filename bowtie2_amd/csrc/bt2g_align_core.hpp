@@ -675,6 +675,75 @@ struct Aligner {
 		return rn;
 	}
 
+	// Random1toN with its state in LDS (R1C) -- the same draws as r1n_next, with the seen-list scan and the swap-list fill done
+	// by all lanes at once
+	BT2_HD void r1c_init(R1C& r, uint32_t n, bool without_replacement) {
+		r.n = n; r.converted = 0;
+		r.swaplist = (n < 128 || without_replacement) ? 1 : 0;
+		r.cur = 0; r.list_off = r.seen_off = 0; r.seen_len = 0;
+		uint32_t th = (uint32_t)(0.10f * (float)n);
+		th = th > 16 ? th : 16;
+		r.thresh = (uint16_t)(th > 0xffffu ? 0xffffu : th);      // only ever compared with seen_len <= max_iters
+		r.inited = 1;
+	}
+	BT2_HDN uint32_t r1c_next(R1C& r) {
+		if (r.cur == 0 && !r.converted) {
+			if (r.n == 1) { r.cur = 1; return 0; }
+			if (r.swaplist) { r.list_off = lists_alloc(r.n); Plat::iota_u32(w.lists + r.list_off, r.n); }
+		}
+		if (r.swaplist) {
+			const uint32_t rr = r.cur + (rnd.nextU32() % (r.n - r.cur));
+			uint32_t* l = w.lists + r.list_off;
+			const uint32_t a = l[r.cur], b = l[rr];
+			if (rr != r.cur) { l[r.cur] = b; l[rr] = a; }
+			r.cur++;
+			return b;
+		}
+		const uint32_t cap = (uint32_t)P.max_iters + 2, room = (uint32_t)r.thresh + 1 < cap ? (uint32_t)r.thresh + 1 : cap;
+		if (r.seen_len == 0 && r.cur == 0) r.seen_off = lists_alloc(room);
+		uint32_t* seen = w.lists + r.seen_off;
+		const uint32_t seen_sz = r.seen_len;
+		uint32_t rn;
+		do { rn = rnd.nextU32() % r.n; } while (Plat::contains_u32(seen, seen_sz, rn));
+		if (r.seen_len >= room) { ovf(29); r.cur++; return rn; }
+		seen[r.seen_len++] = rn;
+		r.cur++;
+		if (r.seen_len >= r.thresh && r.cur < r.n) {
+			// convert to a swap list of everything not yet seen (rare: a mid-sized range asked for >= thresh rows)
+			for (uint32_t i = 1; i < r.seen_len; i++) {
+				const uint32_t v = seen[i];
+				uint32_t j = i;
+				while (j > 0 && seen[j - 1] > v) { seen[j] = seen[j - 1]; j--; }
+				seen[j] = v;
+			}
+			const uint32_t nl = r.n - r.cur;
+			r.list_off = lists_alloc(nl);
+			uint32_t* l = w.lists + r.list_off;
+			uint32_t prev = 0, cur = 0;
+			for (uint32_t i = 0; i < seen_sz + 1; i++) {
+				for (uint32_t j = prev; j < seen[i]; j++) l[cur++] = j;
+				prev = seen[i] + 1;
+			}
+			for (uint32_t j = prev; j < r.n; j++) l[cur++] = j;
+			r.seen_len = 0; r.cur = 0; r.n = nl; r.converted = 1; r.swaplist = 1;
+		}
+		return rn;
+	}
+
+	// Entry i of the extension list for the consumer loops: whole records as they are, sampled rows expanded into w.sp_view
+	// (satpos_commit() remembers that the row has been taken)
+	BT2_HD bool satpos_taken(uint32_t i) const { return i >= HOT.n_satpos_full && w.srows[i - HOT.n_satpos_full].done != 0; }
+	BT2_HD SatPos& satpos_view(uint32_t i) {
+		if (i < HOT.n_satpos_full) return w.satpos[i];
+		const SampRow sr = w.srows[i - HOT.n_satpos_full];
+		SatPos& s = w.sp_view;
+		Plat::copy_words(&s, &w.satpos2[sr.src], (uint32_t)(sizeof(SatPos) / 4));
+		s.topf = sr.topf; s.topb = (uint64_t)kOffMask; s.size = 1;
+		r1n_init(s.rnd, 1, P.all_hits != 0);
+		return s;
+	}
+	BT2_HD void satpos_commit(uint32_t i, const SatPos& sp) { if (i >= HOT.n_satpos_full) w.srows[i - HOT.n_satpos_full].done = r1n_done(sp.rnd) ? 1u : 0u; }
+
 	// =================================================================================
 	// C. seed-hit extension bookkeeping
 	// =================================================================================
@@ -792,6 +861,7 @@ struct Aligner {
 			if (streak > 1) shuffle(HOT.n_mm1 - streak, streak);
 			for (uint32_t i = 0; i < HOT.n_mm1 && !done; i++) add_trimmed(w.mm1[i], (int)i);
 		}
+		HOT.n_satpos_full = HOT.n_resolved = HOT.n_satpos;
 	}
 
 	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? HOT.exact[0] : (idx == -3 ? HOT.exact[1] : w.mm1[idx]); }
@@ -881,6 +951,7 @@ struct Aligner {
 				added += s.size;
 			}
 			nelt_out = added;
+			HOT.n_satpos_full = HOT.n_resolved = HOT.n_satpos;
 			return;
 		}
 		uint64_t nelt_added = 0;
@@ -892,6 +963,7 @@ struct Aligner {
 			r1n_init(s.rnd, s.size, P.all_hits != 0);
 			nelt_added += s.size;
 		}
+		HOT.n_satpos_full = HOT.n_resolved = HOT.n_satpos;
 		if (nelt_added >= maxelt || nsmall == HOT.n_satpos2) { nelt_out = nelt_added; return; }
 		// 2. the non-smalls: RowSampler::init(satpos2_, nsmall, size, lensq=true, szsq=true)
 		const uint32_t sai = (uint32_t)nsmall, saf = HOT.n_satpos2;
@@ -909,7 +981,8 @@ struct Aligner {
 		// With at most kMaxRanges candidates (always, for -N 0) the sampler keeps the running sums of the masses that are still
 		// in play on chip: the sums are formed by the same left-to-right additions as RowSampler::next's scan, so "first index
 		// whose running sum exceeds rd" is the same index -- found by all lanes at once instead of a chain of dependent loads.
-		const bool fast = HOT.n_masses <= (uint32_t)kMaxRanges;
+		const bool fast = HOT.n_masses <= (uint32_t)kFastSamp;
+		if (fast) for (uint32_t j = 0; j < HOT.n_masses; j++) { R1C& r = HOT.samp.r[j]; r.n = r.cur = 0; r.swaplist = r.converted = r.inited = 0; r.seen_len = 0; r.thresh = 0; r.list_off = r.seen_off = 0; }
 		auto rebuild = [&]() {
 			double acc = 0.0;
 			for (uint32_t i = 0; i < HOT.n_masses; i++) { if (!w.elim[i]) acc += w.masses[i]; HOT.samp.prefix[i] = acc; HOT.samp.elim[i] = w.elim[i]; }
@@ -934,17 +1007,24 @@ struct Aligner {
 				if (pick == 0xffffffffu) pick = last_unelim;
 			}
 			const uint32_t ri = pick + sai;
-			R1N& r2 = w.rands2[ri];
-			if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, P.all_hits != 0);
-			const uint32_t r = r1n_next(r2);
-			if (r1n_done(r2)) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; if (fast) rebuild(); }
+			uint32_t r;
+			bool exhausted;
+			if (fast) {
+				R1C& r2 = HOT.samp.r[pick];
+				if (!r2.inited) r1c_init(r2, w.satpos2[ri].size, P.all_hits != 0);
+				r = r1c_next(r2);
+				exhausted = r2.n > 0 && r2.cur >= r2.n;
+			} else {
+				R1N& r2 = w.rands2[ri];
+				if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, P.all_hits != 0);
+				r = r1n_next(r2);
+				exhausted = r1n_done(r2);
+			}
+			if (exhausted) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; if (fast) rebuild(); }
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(13); break; }
-			SatPos& s = w.satpos[HOT.n_satpos++];
-			s = w.satpos2[ri];
-			s.topf = w.satpos2[ri].topf + r;
-			s.topb = (uint64_t)kOffMask;
-			s.size = 1;
-			r1n_init(s.rnd, 1, P.all_hits != 0);
+			SampRow& sr = w.srows[HOT.n_satpos - HOT.n_satpos_full];
+			HOT.n_satpos++;
+			sr.topf = w.satpos2[ri].topf + r; sr.src = ri; sr.done = 0;
 			nelt_added++;
 		}
 		HOT.t_phase[18] += now() - ts_;       // profile: the row-sampling loop
@@ -1588,7 +1668,8 @@ struct Aligner {
 			}
 			const uint32_t maxi = HOT.n_satpos;
 			for (uint32_t i = 0; i < maxi; i++) {
-				SatPos& sp = w.satpos[i];
+				if (satpos_taken(i)) continue;
+				SatPos& sp = satpos_view(i);
 				const EEHit* eh = ee_mode ? &ee_hit(sp.ee) : nullptr;
 				if (ee_mode && eh->score < minsc) return EXT_PERFECT_SCORE;
 				const bool is_small = P.det_seeds ? true : sp.size < nsm;
@@ -1617,6 +1698,17 @@ struct Aligner {
 					// a one-row hit of the pre-computed seed round was resolved by the batch kernel that extended it
 					if (!ee_mode && ext_pre && seedmms == 0 && sp.orig_sz == 1 && pre_joff_cur)
 						jc = pre_joff_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + sp.offidx];
+					if (jc == kJoffNone && !ee_mode && i >= HOT.n_satpos_full) {
+						// a sampled row: the walks to the SA sample of this row and the next 63 run side by side, one per lane
+						// (the extension loop takes the rows in list order, so the look-ahead is rarely wasted)
+						if (i >= HOT.n_resolved) {
+							const uint32_t k0 = i - HOT.n_satpos_full, cnt = HOT.n_satpos - i < 64u ? HOT.n_satpos - i : 64u;
+							Plat::resolve_rows(ix.fw, &w.srows[k0], cnt, &w.srow_joff[k0]);
+							HOT.n_resolved = i + cnt;
+						}
+						jc = w.srow_joff[i - HOT.n_satpos_full];
+						if (jc != kJoffNone) HOT.n_sides += (uint32_t)(jc >> 48);
+					}
 					if (jc != kJoffNone) { joff = (TOff)(jc & 0xffffffffffffull); steps = (uint32_t)(jc >> 48); }
 					else { joff = Plat::get_offset(ix.fw, (TOff)(sp.topf + elt), steps); HOT.n_sides += steps; }
 					HOT.t_phase[4] += now() - tr_;
@@ -1778,6 +1870,7 @@ struct Aligner {
 						}
 					}
 				}
+				satpos_commit(i, sp);
 			}
 			if (P.det_seeds) break;      // useCurrIdx: always one pass (aligner_sw_driver.cpp:1490)
 		}

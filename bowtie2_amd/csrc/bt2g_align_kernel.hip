@@ -87,13 +87,12 @@ __device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work&
 // used to fold the five H options into two flags (gaps allowed in the row, so no veto applies):
 //   H == H_up - rfgapo  <=>  H == F and F == H_up - rfgapo      (F >= H_up - rfgapo and H >= F);  likewise for the
 //   extension F_up - rfgape and for E with H_left / E_left.
-// Cells are stored diagonal-major (pred_idx) so that the backtrace's diagonal runs read consecutive bytes; the last row's
-// scores go straight to HOT.lastrow for the candidate gather.  Traffic: 1 B per cell instead of 4 B + a 2 B mask plane.
+// Cells are stored wavefront-major (pred_idx): whole 64-byte lines per store; the last row's scores go straight to
+// HOT.lastrow for the candidate gather.  Traffic: 1 B per cell instead of 4 B + a 2 B mask plane.
 template <int R>
 __device__ __forceinline__ int fill_ee_u8_pred_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t nlanes = (rows + R - 1) / R;
-	const uint32_t rp = pred_rp(rows);
 	int rdc[R], mmp[R], veto[R];
 #pragma unroll
 	for (int r = 0; r < R; r++) {
@@ -148,10 +147,9 @@ __device__ __forceinline__ int fill_ee_u8_pred_wave(const AlignParams& P, bool f
 			fin_h = h; fin_f = f;
 		}
 		if (active) {
-			// cell (i, j) lives at ((j + rows - 1 - i) * rp + i)
-			uint8_t* base = pm + (uint64_t)((uint32_t)j + rows - 1 - (uint32_t)lane * R) * rp + (uint32_t)lane * R;
+			uint8_t* base = pm + ((uint64_t)t * R) * 64 + lane;       // pred_idx(): 64 consecutive bytes per (step, row-in-lane)
 #pragma unroll
-			for (int r = 0; r < R; r++) if ((uint32_t)lane * R + r < rows) base[(int64_t)r - (int64_t)r * (int64_t)rp] = (uint8_t)code[r];
+			for (int r = 0; r < R; r++) base[r * 64] = (uint8_t)code[r];
 #pragma unroll
 			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
 			if (lane_has_last) { best = imax(best, Hnew[last_r]); g_hot.lastrow[j] = (int16_t)(Hnew[last_r] - 0xff); }
@@ -355,16 +353,50 @@ struct DevPlat {
 		}
 		return last;
 	}
+	// Ebwt::getOffset for up to 64 rows at once, one LF walk per lane (joff_pack: offset + steps taken)
+	template <typename TOff>
+	static __device__ __forceinline__ void resolve_rows(const DevEbwt<TOff>& e, const SampRow* rows, uint32_t n, uint64_t* out) {
+		wave_fence();
+		const uint32_t lane = threadIdx.x & 63;
+		if (lane < n) {
+			uint32_t steps = 0;
+			const TOff joff = bt2g::get_offset(e, (TOff)rows[lane].topf, steps);
+			out[lane] = joff_pack((uint64_t)joff, steps);
+		}
+		wave_fence();
+	}
+	// is v among p[0..n)?  all lanes look at once (seen list of Random1toN)
+	static __device__ __forceinline__ bool contains_u32(const uint32_t* p, uint32_t n, uint32_t v) {
+		wave_fence();
+		const uint32_t lane = threadIdx.x & 63;
+		for (uint32_t base = 0; base < n; base += 64) {
+			const uint32_t i = base + lane;
+			if (__ballot(i < n && p[i] == v)) return true;
+		}
+		return false;
+	}
+	static __device__ __forceinline__ void iota_u32(uint32_t* p, uint32_t n) {
+		wave_fence();
+		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) p[i] = i;
+		wave_fence();
+	}
+	static __device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t nwords) {
+		wave_fence();
+		const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+		uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+		for (uint32_t i = threadIdx.x & 63; i < nwords; i += 64) d[i] = s[i];
+		wave_fence();
+	}
 	static __device__ __forceinline__ void set_epoch(uint32_t* p, uint32_t e) { if ((threadIdx.x & 63) == 0) *p = e; wave_fence(); }
 	// Tile of the pred format anchored at (row, col): lane d <- predecessor byte and (epoch-checked) mask of cell (row-d, col-d).
-	// Diagonal-major storage makes both one contiguous 64-byte / 256-byte read.
+	// One gather per plane: a single memory latency for up to 64 diagonal steps.
 	static __device__ __forceinline__ void bt_tile_pred(const DpScratch& dp, uint32_t rows, uint32_t row, uint32_t col, uint32_t epoch,
 	                                                    uint32_t& pr, uint32_t& mk) {
 		wave_fence();        // mask stores of earlier steps -> visible to whichever lane re-reads them
 		const uint32_t d = threadIdx.x & 63;
 		uint32_t p = 0, m = 0;
 		if (d <= row && d <= col) {
-			const uint64_t idx = pred_idx(rows, row, col) - d;
+			const uint64_t idx = pred_idx(rows, row - d, col - d);
 			p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
 			const uint32_t w = dp.pmask[idx];
 			m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;

@@ -40,6 +40,12 @@ struct HostPlat {
 	static void zero_masks(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
 	static void zero_u32(uint32_t* p, uint32_t n) { memset(p, 0, (size_t)n * 4); }
 	static void set_epoch(uint32_t* p, uint32_t e) { *p = e; }
+	template <typename TOff> static void resolve_rows(const DevEbwt<TOff>& e, const SampRow* rows, uint32_t n, uint64_t* out) {
+		for (uint32_t l = 0; l < n; l++) { uint32_t steps = 0; const TOff joff = bt2g::get_offset(e, (TOff)rows[l].topf, steps); out[l] = joff_pack((uint64_t)joff, steps); }
+	}
+	static bool contains_u32(const uint32_t* p, uint32_t n, uint32_t v) { for (uint32_t i = 0; i < n; i++) if (p[i] == v) return true; return false; }
+	static void iota_u32(uint32_t* p, uint32_t n) { for (uint32_t i = 0; i < n; i++) p[i] = i; }
+	static void copy_words(void* dst, const void* src, uint32_t nwords) { memcpy(dst, src, (size_t)nwords * 4); }
 	static uint32_t pick_mass(const double* prefix, const uint8_t* elim, uint32_t n, double rd) {
 		uint32_t last = 0xffffffffu;
 		for (uint32_t i = 0; i < n; i++) if (!elim[i]) { last = i; if (rd < prefix[i]) return i; }
@@ -100,7 +106,7 @@ struct HostPlat {
 		for (uint32_t d = 0; d < 64; d++) {
 			uint32_t p = 0, m = 0;
 			if (d <= row && d <= col) {
-				const uint64_t idx = pred_idx(rows, row, col) - d;
+				const uint64_t idx = pred_idx(rows, row - d, col - d);
 				p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
 				const uint32_t w = dp.pmask[idx];
 				m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
