@@ -1811,7 +1811,7 @@ struct Aligner {
 						} else {
 							mode = minsc < -254 ? 1 : 0;
 							sse16 = mode == 1;
-							best = Plat::dp_fill_ee(P, w, fw, rows, cols, dp.mat, mode != 0);
+							best = Plat::dp_fill_ee(P, w, fw, rows, cols, dp.mat, mode != 0, minsc);
 						}
 						HOT.t_phase[5] += now() - td_;
 						HOT.n_ex_dps++;

@@ -160,6 +160,68 @@ __device__ __forceinline__ int fill_ee_u8_pred_wave(const AlignParams& P, bool f
 	return __shfl(best, (int)((rows - 1) / R));
 }
 
+// Score-only pass of the same recurrence: nothing is stored, no predecessor bits are formed -- just the best last-row score.
+// Most DP problems of a repeat-rich read fail (best < minsc: up to -D of them in a row), and a failed problem is never
+// backtraced, so the full fill (fill_ee_u8_pred_wave, 2.5x the arithmetic plus the stores) only runs for the ones that pass.
+template <int R>
+__device__ __forceinline__ int fill_ee_u8_score_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t nlanes = (rows + R - 1) / R;
+	int rdc[R], mmp[R], veto[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const uint32_t i = (uint32_t)lane * R + r;
+		const bool valid = i < rows;
+		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
+		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
+		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 0xff : 0;
+	}
+	int Hprev[R], Eprev[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
+	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, best = 0;
+	const uint32_t steps = cols + nlanes - 1;
+	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
+	const int last_r = (int)((rows - 1) % R);
+	const int rdgapo = P.rdgapo, rdgape = P.rdgape, rfgapo = P.rfgapo, rfgape = P.rfgape, npen = P.n_pen, bonus = P.match_bonus;
+	for (uint32_t t = 0; t < steps; t++) {
+		const int upH = __shfl_up(myHlast, 1);
+		const int upF = __shfl_up(myFlast, 1);
+		int upRef = __shfl_up(refm, 1);
+		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
+		refm = upRef;
+		const int j = (int)t - lane;
+		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
+		int refc = 4;
+		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
+		int hdiag = (lane == 0) ? 0xff : (j == 0 ? 0 : upHdiag);
+		int fin_h = upH, fin_f = upF;
+		int Hnew[R], Enew[R], flast = 0;
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			int pen;
+			if (rdc[r] > 3 || refc > 3) pen = npen; else pen = (rdc[r] == refc) ? -bonus : mmp[r];
+			const int e = (j == 0) ? 0 : imax(subs0(Eprev[r], rdgape), subs0(subs0(Hprev[r], rdgapo), veto[r]));
+			int f;
+			if (lane == 0 && r == 0) f = 0;
+			else f = subs0(imax(subs0(fin_f, rfgape), subs0(fin_h, rfgapo)), veto[r]);
+			const int h = imax(imax(subs0(hdiag, pen), e), f);
+			Hnew[r] = h; Enew[r] = e;
+			hdiag = Hprev[r];
+			fin_h = h; fin_f = f; flast = f;
+		}
+		if (active) {
+#pragma unroll
+			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
+			if (lane_has_last) best = imax(best, Hnew[last_r]);
+			myHlast = Hnew[R - 1]; myFlast = flast;
+		}
+		upHdiag = upH;
+	}
+	return __shfl(best, (int)((rows - 1) / R));
+}
+
 // The same recurrence in the reference's 16-bit representation (alignNucleotidesEnd2EndSseI16, aligner_swsse_ee_i16.cpp:780-1146):
 // scores biased by 0x7fff, -32768 = minus infinity, saturating subtraction, barrier rows veto gap opens/extensions.
 constexpr int kLo = -32768;
@@ -602,11 +664,23 @@ struct DevPlat {
 		return total;
 	}
 	// returns the best last-row score (de-biased)
-	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide) {
+	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide, int64_t minsc) {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
 		int best;
 		if (!wide) {
 			uint8_t* pm = reinterpret_cast<uint8_t*>(mat);
+			// pass 1: can any end-to-end alignment in this window reach the minimum score at all?
+			switch (dp_R(rows)) {
+				case 1: best = fill_ee_u8_score_wave<1>(P, fw, rows, cols); break;
+				case 2: best = fill_ee_u8_score_wave<2>(P, fw, rows, cols); break;
+				case 3: best = fill_ee_u8_score_wave<3>(P, fw, rows, cols); break;
+				case 4: best = fill_ee_u8_score_wave<4>(P, fw, rows, cols); break;
+				case 5: best = fill_ee_u8_score_wave<5>(P, fw, rows, cols); break;
+				case 6: best = fill_ee_u8_score_wave<6>(P, fw, rows, cols); break;
+				case 7: best = fill_ee_u8_score_wave<7>(P, fw, rows, cols); break;
+				default: best = fill_ee_u8_score_wave<8>(P, fw, rows, cols); break;
+			}
+			if ((int64_t)best - 0xff < minsc) { wave_fence(); return (int64_t)best - 0xff; }
 			switch (dp_R(rows)) {
 				case 1: best = fill_ee_u8_pred_wave<1>(P, fw, rows, cols, pm); break;
 				case 2: best = fill_ee_u8_pred_wave<2>(P, fw, rows, cols, pm); break;

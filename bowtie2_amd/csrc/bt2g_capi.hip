@@ -348,10 +348,15 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		const uint64_t b_joff = al(n * 2 * max_seeds * sizeof(uint64_t));
 		const uint64_t b_mm1 = al(n * 4 * cap * sizeof(Mm1Hit));
 		const uint64_t b_mm1n = al(n * 4);
+		// 1-mismatch search: per-list hit counters and the queue of deferred branches (16 per read on average; beyond that
+		// the scan kernel follows branches itself)
+		const uint64_t b_mm1c = al(n * 4 * sizeof(unsigned int));
+		const uint64_t qcap64 = n * 16 < 0xfffffff0ull ? n * 16 : 0xfffffff0ull;
+		const uint64_t b_mm1q = al(qcap64 * one_mm_task_bytes(c->off_size));
 		// re-seeding rounds are pre-computed for unpaired batches (the pair worker keeps searching them itself)
 		uint32_t pre_rounds = 1;
 		if (params->seed_mms == 0 && !params->paired && params->n_seed_rounds > 1) pre_rounds = (uint32_t)params->n_seed_rounds < kMaxPreRounds ? (uint32_t)params->n_seed_rounds : kMaxPreRounds;
-		const uint64_t tot = b_sweep + (b_seeds + b_ext + b_joff) * pre_rounds + b_mm1 + b_mm1n;
+		const uint64_t tot = b_sweep + (b_seeds + b_ext + b_joff) * pre_rounds + b_mm1 + b_mm1n + b_mm1c + b_mm1q;
 		if (tot > c->pre_bytes) {
 			if (c->d_pre) (void)hipFree(c->d_pre);
 			c->d_pre = nullptr; c->pre_bytes = 0;
@@ -375,8 +380,10 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			pre.sweep = d_sweep;
 			mark(1);
 			if (params->do_1mm_upfront) {
-				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, c->d_cnt, st)
-				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, c->d_cnt, st);
+				unsigned int* d_mm1c = (unsigned int*)(d_mm1n + b_mm1n);
+				void* d_mm1q = d_mm1n + b_mm1n + b_mm1c;
+				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, c->d_cnt, st)
+				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, c->d_cnt, st);
 				if (e != hipSuccess) return hip_fail(c, e, "k_one_mm");
 				pre.mm1 = d_mm1; pre.mm1_n = d_mm1n;
 			}
@@ -396,7 +403,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			}
 			// rounds 1..: the same kernels on the shifted seeds, for the reads repetitive enough to be re-seeded
 			const bt2g_seed_hit* prev = d_seeds;
-			uint8_t* q = d_mm1n + b_mm1n;
+			uint8_t* q = d_mm1n + b_mm1n + b_mm1c + b_mm1q;
 			for (uint32_t ri = 1; ri < pre_rounds; ri++) {
 				bt2g_seed_hit* sr = (bt2g_seed_hit*)q; q += b_seeds;
 				uint64_t* jr = (uint64_t*)q; q += b_joff;

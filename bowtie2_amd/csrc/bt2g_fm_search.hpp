@@ -159,15 +159,15 @@ BT2_HD bool reseed_offset(uint32_t roundi, uint32_t n_seed_rounds, uint32_t inte
 	return true;
 }
 
-// One (read strand, index direction) combination of oneMmSearch with repex=false, rep1mm=true.
-// emit(const Mm1Hit&) is called for every valid 1-mismatch end-to-end hit, in discovery order.
+// The continuation of one 1-mismatch branch of oneMmSearch (aligner_seed.cpp:1189-1300): position `dep` (from the 3' end of the
+// search direction) was matched with reference character j instead of the read's; the rest of the read must match exactly.
+// emit() is called if it does and the hit is valid.  A free function so that the batch kernels can run the branches of
+// all reads as one flat list of tasks (bt2g_kernels.hip: k_one_mm_cont) instead of nested, divergent loops.
 template <typename TOff, typename RD, typename Emit>
-BT2_HD void fm_one_mm_dir(const DevIndex<TOff>& ix, const bt2g_align_params& P, int64_t minsc, int nceil,
-                          const RD& rd, uint32_t len, uint32_t ns, bool fw, bool ebwtfw, Emit emit, FmCount& cnt) {
+BT2_HD void fm_one_mm_cont(const DevIndex<TOff>& ix, const bt2g_align_params& P, int64_t minsc, const RD& rd, uint32_t len, bool fw, bool ebwtfw,
+                           uint32_t dep, int j, TOff topm, TOff botm, TOff topmp, TOff botmp, Emit emit, FmCount& cnt) {
 	constexpr TOff kMask = (TOff)OffTraits<TOff>::kMask;
 	const DevEbwt<TOff>& e = ebwtfw ? ix.fw : ix.bw;
-	const DevEbwt<TOff>& ep = ebwtfw ? ix.bw : ix.fw;
-	// seq views (aligner_seed.cpp:1031-1040): fw: patFw | patFwRev ; rc: patRc | patRcRev
 	auto sq = [&](uint32_t i) -> int {
 		if (fw) return ebwtfw ? rd.seq(i) : rd.seq(len - 1 - i);
 		return ebwtfw ? fm_comp(rd.seq(len - 1 - i)) : fm_comp(rd.seq(i));
@@ -175,6 +175,77 @@ BT2_HD void fm_one_mm_dir(const DevIndex<TOff>& ix, const bt2g_align_params& P, 
 	auto ql = [&](uint32_t i) -> int {
 		const bool rev = fw ? !ebwtfw : ebwtfw;
 		return rev ? rd.qual(len - 1 - i) : rd.qual(i);
+	};
+	const int rdc = sq(len - dep - 1);
+	const int quc = ql(len - dep - 1);
+	uint32_t depm = dep + 1;
+	TOff tm[4], bm[4], tmp[4], bmp[4];
+	for (; depm < len; depm++) {
+		const int rdcm = sq(len - depm - 1);
+		if (botm - topm > 1) {
+			cnt.bwops++;
+			fm_bi_lf(e, topm, botm, topmp, tm, bm, tmp, bmp, cnt);
+			if (rdcm > 3) { topm = botm = 0; break; }
+			topm = tm[rdcm]; botm = bm[rdcm];
+			topmp = tmp[rdcm]; botmp = bmp[rdcm];
+			if (botm <= topm) break;
+		} else {
+			cnt.bwops++; cnt.sides++;
+			topm = map_lf1c(e, topm, rdcm);
+			if (topm == kMask) break;
+			botm = topm + 1;
+		}
+	}
+	if (depm != len) return;
+	uint32_t off5p = dep;
+	if (fw == ebwtfw) off5p = len - off5p - 1;
+	int64_t score = (int64_t)(len - 1) * P.match_bonus;
+	int pen;   // Scoring::score(rdc, 1<<j, quc-33)
+	{
+		int q = quc - 33; if (q < 0) q = 0; if (q > 255) q = 255;
+		if (rdc > 3) pen = -P.n_pen;
+		else if (rdc == j) pen = P.match_bonus;
+		else {
+			if (P.mm_type == 3) { const int qq = q < 40 ? q : 40; const float frac = (float)qq / 40.0f; pen = -(P.mm_min + (int)(frac * (float)(P.mm_max - P.mm_min))); }
+			else if (P.mm_type == 2) pen = -(q < 5 ? 0 : (q < 15 ? 10 : (q < 25 ? 20 : 30)));
+			else pen = -P.mm_max;
+		}
+	}
+	score += pen;
+	bool valid = true;
+	if (P.match_bonus > 0) {
+		// --local: the end-to-end hit must also be a legal local alignment, i.e. its running score may not
+		// touch 0 at the mismatch from either end (aligner_seed.cpp:1231-1260)
+		int64_t fwsc = 0, bwsc = 0;
+		for (uint32_t i = 0; i < len; i++) {
+			if (i == dep) { if (fwsc + pen <= 0) { valid = false; break; } fwsc += pen; } else fwsc += P.match_bonus;
+			if (len - i - 1 == dep) { if (bwsc + pen <= 0) { valid = false; break; } bwsc += pen; } else bwsc += P.match_bonus;
+		}
+	}
+	if (valid && score >= minsc) {
+		Mm1Hit h;
+		h.top = ebwtfw ? (uint64_t)topm : (uint64_t)topmp;
+		h.bot = ebwtfw ? (uint64_t)botm : (uint64_t)botmp;
+		h.score = (int32_t)score; h.epos = (uint16_t)off5p; h.echr = (uint8_t)j; h.eqchr = (uint8_t)rdc;
+		emit(h);
+	}
+}
+
+// One (read strand, index direction) combination of oneMmSearch with repex=false, rep1mm=true.
+// emit(const Mm1Hit&) is called for every valid 1-mismatch end-to-end hit, in discovery order.
+// defer(dep, j, top, bot, topp, botp) -> bool may take a branch's continuation away (the batch kernels queue it); when it
+// returns false the branch is finished here.
+struct Mm1NoDefer { template <typename TOff> BT2_HD bool operator()(uint32_t, int, TOff, TOff, TOff, TOff) const { return false; } };
+template <typename TOff, typename RD, typename Emit, typename Defer = Mm1NoDefer>
+BT2_HD void fm_one_mm_dir(const DevIndex<TOff>& ix, const bt2g_align_params& P, int64_t minsc, int nceil,
+                          const RD& rd, uint32_t len, uint32_t ns, bool fw, bool ebwtfw, Emit emit, FmCount& cnt, Defer defer = Defer()) {
+	constexpr TOff kMask = (TOff)OffTraits<TOff>::kMask;
+	const DevEbwt<TOff>& e = ebwtfw ? ix.fw : ix.bw;
+	const DevEbwt<TOff>& ep = ebwtfw ? ix.bw : ix.fw;
+	// seq views (aligner_seed.cpp:1031-1040): fw: patFw | patFwRev ; rc: patRc | patRcRev
+	auto sq = [&](uint32_t i) -> int {
+		if (fw) return ebwtfw ? rd.seq(i) : rd.seq(len - 1 - i);
+		return ebwtfw ? fm_comp(rd.seq(len - 1 - i)) : fm_comp(rd.seq(i));
 	};
 	const uint32_t halfFw = len >> 1;
 	const uint32_t halfBw = (len >> 1) + ((len & 1) ? 1 : 0);
@@ -218,7 +289,6 @@ BT2_HD void fm_one_mm_dir(const DevIndex<TOff>& ix, const bt2g_align_params& P, 
 	}
 	for (; dep < len; dep++) {
 		const int rdc = sq(len - dep - 1);
-		const int quc = ql(len - dep - 1);
 		if (rdc > 3 && nceil == 0) break;
 		int clo = 0, chi = 3;
 		bool match = true;
@@ -243,59 +313,8 @@ BT2_HD void fm_one_mm_dir(const DevIndex<TOff>& ix, const bt2g_align_params& P, 
 		if (ns == 0 || rdc > 3) {
 			for (int j = clo; j <= chi; j++) {
 				if (j == rdc || b[j] == t[j]) continue;
-				uint32_t depm = dep + 1;
-				TOff topm = t[j], botm = b[j], topmp = tp[j], botmp = bp[j];
-				TOff tm[4], bm[4], tmp[4], bmp[4];
-				for (; depm < len; depm++) {
-					const int rdcm = sq(len - depm - 1);
-					if (botm - topm > 1) {
-						cnt.bwops++;
-						fm_bi_lf(e, topm, botm, topmp, tm, bm, tmp, bmp, cnt);
-						if (rdcm > 3) { topm = botm = 0; break; }
-						topm = tm[rdcm]; botm = bm[rdcm];
-						topmp = tmp[rdcm]; botmp = bmp[rdcm];
-						if (botm <= topm) break;
-					} else {
-						cnt.bwops++; cnt.sides++;
-						topm = map_lf1c(e, topm, rdcm);
-						if (topm == kMask) break;
-						botm = topm + 1;
-					}
-				}
-				if (depm == len) {
-					uint32_t off5p = dep;
-					if (fw == ebwtfw) off5p = len - off5p - 1;
-					int64_t score = (int64_t)(len - 1) * P.match_bonus;
-					int pen;   // Scoring::score(rdc, 1<<j, quc-33)
-					{
-						int q = quc - 33; if (q < 0) q = 0; if (q > 255) q = 255;
-						if (rdc > 3) pen = -P.n_pen;
-						else if (rdc == j) pen = P.match_bonus;
-						else {
-							if (P.mm_type == 3) { const int qq = q < 40 ? q : 40; const float frac = (float)qq / 40.0f; pen = -(P.mm_min + (int)(frac * (float)(P.mm_max - P.mm_min))); }
-							else if (P.mm_type == 2) pen = -(q < 5 ? 0 : (q < 15 ? 10 : (q < 25 ? 20 : 30)));
-							else pen = -P.mm_max;
-						}
-					}
-					score += pen;
-					bool valid = true;
-					if (P.match_bonus > 0) {
-						// --local: the end-to-end hit must also be a legal local alignment, i.e. its running score may not
-						// touch 0 at the mismatch from either end (aligner_seed.cpp:1231-1260)
-						int64_t fwsc = 0, bwsc = 0;
-						for (uint32_t i = 0; i < len; i++) {
-							if (i == dep) { if (fwsc + pen <= 0) { valid = false; break; } fwsc += pen; } else fwsc += P.match_bonus;
-							if (len - i - 1 == dep) { if (bwsc + pen <= 0) { valid = false; break; } bwsc += pen; } else bwsc += P.match_bonus;
-						}
-					}
-					if (valid && score >= minsc) {
-						Mm1Hit h;
-						h.top = ebwtfw ? (uint64_t)topm : (uint64_t)topmp;
-						h.bot = ebwtfw ? (uint64_t)botm : (uint64_t)botmp;
-						h.score = (int32_t)score; h.epos = (uint16_t)off5p; h.echr = (uint8_t)j; h.eqchr = (uint8_t)rdc;
-						emit(h);
-					}
-				}
+				if (dep + 1 < len && defer(dep, j, t[j], b[j], tp[j], bp[j])) continue;
+				fm_one_mm_cont(ix, P, minsc, rd, len, fw, ebwtfw, dep, j, t[j], b[j], tp[j], bp[j], emit, cnt);
 			}
 		}
 		if (bot > top && match) {

@@ -574,11 +574,19 @@ hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, co
 // ------------------------------------------------------------------------------------
 // 1-mismatch end-to-end search, one lane per (read, strand, index direction)
 // ------------------------------------------------------------------------------------
+// Three kernels.  (1) k_one_mm_scan: one lane per (read, strand, index direction) walks the exact part of oneMmSearch and,
+// wherever a mismatching reference character keeps a non-empty range, queues that branch (Mm1Task) instead of following it.
+// (2) k_one_mm_cont: one lane per queued branch finishes it (exact match of the rest of the read).  (3) k_one_mm_fin: per list,
+// restore discovery order (increasing depth, then reference character) and publish the count.  On repeat-rich reads the
+// branches outnumber the scans by two orders of magnitude and have very uneven lengths: as one flat task list they fill
+// the machine; nested inside the scan they left most lanes of a wave waiting for the slowest.
+template <typename TOff> struct Mm1Task { uint32_t list; uint16_t dep; uint8_t j, pad; TOff top, bot, topp, botp; };
+
 template <typename TOff>
 __global__ void __launch_bounds__(256)
-k_one_mm(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams,
-         const bt2g_sweep_out* __restrict__ sweep, uint32_t cap, Mm1Hit* __restrict__ out, uint8_t* __restrict__ out_n,
-         DevCounters* cnt) {
+k_one_mm_scan(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams,
+              const bt2g_sweep_out* __restrict__ sweep, uint32_t cap, Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt,
+              Mm1Task<TOff>* __restrict__ queue, unsigned int* __restrict__ qcount, uint32_t qcap, DevCounters* cnt) {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	FmCount c; c.bwops = 0; c.sides = 0;
 	if (gid < (uint64_t)rd.n_reads * 4) {
@@ -587,7 +595,6 @@ k_one_mm(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_
 		const bool ebwtfw = (gid & 1) == 0;
 		const uint64_t o0 = rd.d_off[r];
 		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
-		uint32_t n = 0;
 		const bt2g_read_params rp = rparams[r];
 		// the worker only searches a strand whose exact sweep proved <= 1 edit possible (bt2_search.cpp:3704-3706)
 		const bool want = (rp.filt & 15u) == 15u && len >= 2 && sweep[r].mine[fw ? 0 : 1] <= 1 && !(fw ? P.nofw : P.norc);
@@ -597,30 +604,99 @@ k_one_mm(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_
 			for (uint32_t i = 0; i < len; i++) if (g.s[i] > 3) ns++;
 			if (ns <= 1) {
 				Mm1Hit* dst = out + gid * cap;
-				fm_one_mm_dir(ix, P, (int64_t)rp.minsc, rp.nceil, g, len, ns, fw, ebwtfw,
-					[&](const Mm1Hit& m) { if (n < cap) dst[n] = m; n++; }, c);
+				auto emit = [&](const Mm1Hit& m) { const unsigned int pos = atomicAdd(&out_cnt[gid], 1u); if (pos < cap) dst[pos] = m; };
+				auto defer = [&](uint32_t dep, int j, TOff t, TOff b, TOff tp, TOff bp) -> bool {
+					// one atomic per group of lanes that arrive here together
+					const unsigned long long act = __ballot(1);
+					const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)act) - 1;
+					unsigned int base = 0;
+					if (lane == leader) base = atomicAdd(qcount, (unsigned int)__popcll(act));
+					base = (unsigned int)__shfl((int)base, leader);
+					const unsigned int idx = base + (unsigned int)__popcll(act & ((1ull << lane) - 1ull));
+					if (idx >= qcap) return false;          // queue full: this branch is followed right here
+					Mm1Task<TOff> tk; tk.list = (uint32_t)gid; tk.dep = (uint16_t)dep; tk.j = (uint8_t)j; tk.pad = 0; tk.top = t; tk.bot = b; tk.topp = tp; tk.botp = bp;
+					queue[idx] = tk;
+					return true;
+				};
+				fm_one_mm_dir(ix, P, (int64_t)rp.minsc, rp.nceil, g, len, ns, fw, ebwtfw, emit, c, defer);
 			}
 		}
-		out_n[gid] = n > cap ? (uint8_t)255 : (uint8_t)n;   // 255: more hits than the buffer holds -> the worker redoes this read inline
 	}
 	wave_add_counter(&cnt->rank_queries, c.sides);
 	wave_add_counter(&cnt->bwops, c.bwops);
 }
 
 template <typename TOff>
+__global__ void __launch_bounds__(256)
+k_one_mm_cont(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t cap,
+              Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt, const Mm1Task<TOff>* __restrict__ queue,
+              const unsigned int* __restrict__ qcount, uint32_t qcap, DevCounters* cnt) {
+	FmCount c; c.bwops = 0; c.sides = 0;
+	const unsigned int nq = *qcount < qcap ? *qcount : qcap;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
+		const Mm1Task<TOff> tk = queue[i];
+		const uint32_t r = tk.list >> 2;
+		const bool fw = ((tk.list >> 1) & 1) == 0, ebwtfw = (tk.list & 1) == 0;
+		const uint64_t o0 = rd.d_off[r];
+		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
+		GlobRd g; g.s = rd.d_seq + o0; g.q = rd.d_qual + o0;
+		Mm1Hit* dst = out + (uint64_t)tk.list * cap;
+		fm_one_mm_cont(ix, P, (int64_t)rparams[r].minsc, g, len, fw, ebwtfw, (uint32_t)tk.dep, (int)tk.j, tk.top, tk.bot, tk.topp, tk.botp,
+			[&](const Mm1Hit& m) { const unsigned int pos = atomicAdd(&out_cnt[tk.list], 1u); if (pos < cap) dst[pos] = m; }, c);
+	}
+	wave_add_counter(&cnt->rank_queries, c.sides);
+	wave_add_counter(&cnt->bwops, c.bwops);
+}
+
+// discovery order of a list = increasing depth from the end the search direction starts at, then reference character; the
+// depth is epos or len-1-epos depending on the (strand, direction) combination, so sorting by epos in the right sense restores it
+__global__ void __launch_bounds__(256)
+k_one_mm_fin(uint32_t n_lists, uint32_t cap, Mm1Hit* __restrict__ out, const unsigned int* __restrict__ out_cnt, uint8_t* __restrict__ out_n) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= n_lists) return;
+	const unsigned int n = out_cnt[gid];
+	if (n > cap) { out_n[gid] = 255; return; }      // more hits than the buffer holds -> the worker redoes this read inline
+	out_n[gid] = (uint8_t)n;
+	const bool fw = ((gid >> 1) & 1) == 0, ebwtfw = (gid & 1) == 0;
+	const bool desc = fw == ebwtfw;                  // depth = len-1-epos: deeper = smaller epos
+	Mm1Hit* l = out + (uint64_t)gid * cap;
+	for (unsigned int a = 1; a < n; a++) {
+		const Mm1Hit v = l[a];
+		unsigned int k = a;
+		while (k > 0) {
+			const Mm1Hit o = l[k - 1];
+			const bool o_after = o.epos != v.epos ? (desc ? o.epos < v.epos : o.epos > v.epos) : o.echr > v.echr;
+			if (!o_after) break;
+			l[k] = o; k--;
+		}
+		l[k] = v;
+	}
+}
+
+template <typename TOff>
 hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, const bt2g_reads& rd, const bt2g_read_params* d_rparams,
-                         const bt2g_sweep_out* d_sweep, uint32_t cap, void* d_out, uint8_t* d_out_n, DevCounters* d_cnt, hipStream_t st) {
+                         const bt2g_sweep_out* d_sweep, uint32_t cap, void* d_out, uint8_t* d_out_n, unsigned int* d_out_cnt,
+                         void* d_queue, uint32_t qcap, unsigned int* d_qcount, DevCounters* d_cnt, hipStream_t st) {
 	const uint64_t total = (uint64_t)rd.n_reads * 4;
 	if (total == 0) return hipSuccess;
+	hipError_t e = hipMemsetAsync(d_out_cnt, 0, total * sizeof(unsigned int), st);
+	if (e == hipSuccess) e = hipMemsetAsync(d_qcount, 0, sizeof(unsigned int), st);
+	if (e != hipSuccess) return e;
 	const uint64_t grid = (total + 255) / 256;
-	hipLaunchKernelGGL(k_one_mm<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, P, rd, d_rparams, d_sweep, cap, (Mm1Hit*)d_out, d_out_n, d_cnt);
+	hipLaunchKernelGGL(k_one_mm_scan<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, P, rd, d_rparams, d_sweep, cap, (Mm1Hit*)d_out, d_out_cnt,
+	                   (Mm1Task<TOff>*)d_queue, d_qcount, qcap, d_cnt);
+	hipLaunchKernelGGL(k_one_mm_cont<TOff>, dim3(256 * 32), dim3(256), 0, st, ix, P, rd, d_rparams, cap, (Mm1Hit*)d_out, d_out_cnt,
+	                   (const Mm1Task<TOff>*)d_queue, (const unsigned int*)d_qcount, qcap, d_cnt);
+	hipLaunchKernelGGL(k_one_mm_fin, dim3((uint32_t)grid), dim3(256), 0, st, (uint32_t)total, cap, (Mm1Hit*)d_out, (const unsigned int*)d_out_cnt, d_out_n);
 	return hipGetLastError();
 }
+uint64_t one_mm_task_bytes(int off_size) { return off_size == 4 ? sizeof(Mm1Task<uint32_t>) : sizeof(Mm1Task<uint64_t>); }
 
 template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t);
 template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t);
-template hipError_t launch_one_mm<uint32_t>(const DevIndex<uint32_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, DevCounters*, hipStream_t);
-template hipError_t launch_one_mm<uint64_t>(const DevIndex<uint64_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, DevCounters*, hipStream_t);
+template hipError_t launch_one_mm<uint32_t>(const DevIndex<uint32_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, unsigned int*, void*, uint32_t, unsigned int*, DevCounters*, hipStream_t);
+template hipError_t launch_one_mm<uint64_t>(const DevIndex<uint64_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, unsigned int*, void*, uint32_t, unsigned int*, DevCounters*, hipStream_t);
 
 // ------------------------------------------------------------------------------------
 // max over the batch of the number of round-0 seeds per strand (sizes the pre-computation buffers)

@@ -193,7 +193,7 @@ struct HostPlat {
 		return total;
 	}
 	// scalar fill of either representation; returns the best last-row score (de-biased)
-	static int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide) {
+	static int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide, int64_t /*minsc: the device build skips the matrix of a problem that cannot reach it*/) {
 		const uint32_t R = dp_R(rows);
 		const int lo = wide ? -32768 : 0, hi = wide ? 0x7fff : 0xff;
 		auto subs = [&](int a, int b) { const int v = a - b; return v < lo ? lo : v; };
