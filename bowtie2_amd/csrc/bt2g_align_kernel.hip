@@ -19,98 +19,68 @@ __shared__ HotWork g_hot;    // one wavefront per workgroup: the hot per-read st
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-template <int R>
-__device__ __forceinline__ int fill_ee_u8_wave(const AlignParams& P, const Work& w, bool fw, uint32_t rows, uint32_t cols,
-                                               uint32_t* __restrict__ scratch) {
-	const int lane = threadIdx.x & 63;
-	const uint32_t nlanes = (rows + R - 1) / R;
-	int rdc[R], mmp[R], veto[R];
-#pragma unroll
-	for (int r = 0; r < R; r++) {
-		const uint32_t i = (uint32_t)lane * R + r;
-		const bool valid = i < rows;
-		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
-		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
-		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
-		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 0xff : 0;
-	}
-	int Hprev[R], Eprev[R];
-#pragma unroll
-	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
-	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, best = 0;
-	const uint32_t steps = cols + nlanes - 1;
-	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
-	const int last_r = (int)((rows - 1) % R);
-	for (uint32_t t = 0; t < steps; t++) {
-		const int upH = __shfl_up(myHlast, 1);
-		const int upF = __shfl_up(myFlast, 1);
-		int upRef = __shfl_up(refm, 1);
-		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
-		refm = upRef;
-		const int j = (int)t - lane;
-		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
-		int refc = 4;
-		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
-		int hdiag = (lane == 0) ? 0xff : (j == 0 ? 0 : upHdiag);
-		int fin_h = upH, fin_f = upF;
-		int Hnew[R], Enew[R], Fnew[R];
-#pragma unroll
-		for (int r = 0; r < R; r++) {
-			int pen;
-			if (rdc[r] > 3 || refc > 3) pen = P.n_pen; else pen = (rdc[r] == refc) ? -P.match_bonus : mmp[r];
-			const int e = (j == 0) ? 0 : imax(subs0(Eprev[r], P.rdgape), subs0(subs0(Hprev[r], P.rdgapo), veto[r]));
-			int f;
-			if (lane == 0 && r == 0) f = 0;
-			else f = subs0(imax(subs0(fin_f, P.rfgape), subs0(fin_h, P.rfgapo)), veto[r]);
-			const int h = imax(imax(subs0(hdiag, pen), e), f);
-			Hnew[r] = h; Enew[r] = e; Fnew[r] = f;
-			hdiag = Hprev[r];
-			fin_h = h; fin_f = f;
-		}
-		if (active) {
-			uint32_t* base = scratch + ((uint64_t)t * R) * 64 + lane;     // 256 contiguous bytes per store
-#pragma unroll
-			for (int r = 0; r < R; r++) base[r * 64] = (uint32_t)Hnew[r] | ((uint32_t)Enew[r] << 8) | ((uint32_t)Fnew[r] << 16);
-#pragma unroll
-			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
-			if (lane_has_last) best = imax(best, Hnew[last_r]);
-		}
-		upHdiag = upH;
-		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
-	}
-	return __shfl(best, (int)((rows - 1) / R));
-}
-
-// End-to-end 8-bit fill, compact output: the same recurrence as above, but what goes to memory is ONE BYTE per cell saying
-// which predecessors are score-consistent (PB_* in bt2g_align.hpp) -- exactly the questions the reference's backtrace asks
-// of H/E/F (aligner_swsse_ee_u8.cpp:1330-1520), answered here while the neighbours are still in registers.  Identities
-// used to fold the five H options into two flags (gaps allowed in the row, so no veto applies):
+// ---------------------------------------------------------------------------------------------------------------------
+// End-to-end 8-bit fill (alignNucleotidesEnd2EndSseU8's fixed point, aligner_swsse_ee_u8.cpp:775-1146) on the anti-diagonal
+// wavefront: lane l owns read rows l*R .. l*R+R-1 and is at column t - l in step t; H, F and the reference character travel
+// down the lanes with __shfl_up.  Scores are kept as unsigned 16-bit values TWO ROWS PER REGISTER: everything that does not
+// depend on the row above in the same column -- the substitution penalty, H_diag - pen, and E -- is computed for a pair of
+// rows with one packed instruction (v_pk_sub_u16 clamp = the reference's saturating subtraction, v_pk_max_u16, ...); only
+// the F/H chain down the rows is sequential (5 operations per row).
+//
+// PRED = false: score-only pass, nothing is stored -- just the best last-row score.  Most DP problems of a repeat-rich read
+// fail (best < minsc: up to -D of them in a row) and a failed problem is never backtraced.
+// PRED = true: the full fill.  What goes to memory is ONE BYTE per cell saying which predecessors are score-consistent (PB_*
+// in bt2g_align.hpp) -- exactly the questions the reference's backtrace asks of H/E/F (:1330-1520), answered while the
+// neighbours are in registers, as equalities on packed pairs ((a ^ b) == 0  <=>  min(a ^ b, 1) == 0).  Identities used to
+// fold the five H options into two flags (gaps allowed in the row, so no veto applies):
 //   H == H_up - rfgapo  <=>  H == F and F == H_up - rfgapo      (F >= H_up - rfgapo and H >= F);  likewise for the
 //   extension F_up - rfgape and for E with H_left / E_left.
 // Cells are stored wavefront-major (pred_idx): whole 64-byte lines per store; the last row's scores go straight to
-// HOT.lastrow for the candidate gather.  Traffic: 1 B per cell instead of 4 B + a 2 B mask plane.
-template <int R>
-__device__ __forceinline__ int fill_ee_u8_pred_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm) {
+// HOT.lastrow for the candidate gather.  Traffic: 1 B per cell of a PASSING problem instead of 4 B + a 2 B mask plane for all.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 p_splat(int v) { return (u16x2)((unsigned short)v); }
+__device__ __forceinline__ u16x2 p_subs(u16x2 a, u16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ u16x2 p_max(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ u16x2 p_min(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ u16x2 p_eq(u16x2 a, u16x2 b) { return p_splat(1) - p_min(a ^ b, p_splat(1)); }     // 1 where equal, else 0
+__device__ __forceinline__ unsigned short s_subs(unsigned short a, unsigned short b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ unsigned short s_max(unsigned short a, unsigned short b) { return a > b ? a : b; }
+
+template <int R, bool PRED>
+__device__ __forceinline__ int fill_ee_u8_packed(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm) {
+	constexpr int RP = (R + 1) / 2;
 	const int lane = threadIdx.x & 63;
 	const uint32_t nlanes = (rows + R - 1) / R;
-	int rdc[R], mmp[R], veto[R];
+	u16x2 rdcP[RP], mmpP[RP], vetoP[RP], gaP[RP];
+	unsigned short veto[2 * RP];
 #pragma unroll
-	for (int r = 0; r < R; r++) {
-		const uint32_t i = (uint32_t)lane * R + r;
-		const bool valid = i < rows;
-		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
-		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
-		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
-		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 0xff : 0;
+	for (int k = 0; k < RP; k++) {
+		unsigned short rc[2], mp[2], vt[2], ga[2];
+#pragma unroll
+		for (int hh = 0; hh < 2; hh++) {
+			const int r = 2 * k + hh;
+			const uint32_t i = (uint32_t)lane * R + r;
+			const bool valid = r < R && i < rows;
+			const int c = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+			const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
+			rc[hh] = (unsigned short)(c > 3 ? 5 : c);                         // 5: a read N never equals a reference code
+			mp[hh] = (unsigned short)(c > 3 ? P.n_pen : mm_penalty(P, q < 0 ? 0 : q));
+			const bool bar = valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar);
+			vt[hh] = bar ? 0xff : 0;
+			ga[hh] = (valid && !bar) ? 1 : 0;
+			veto[r] = vt[hh];
+		}
+		rdcP[k] = (u16x2)(rc[0], rc[1]); mmpP[k] = (u16x2)(mp[0], mp[1]); vetoP[k] = (u16x2)(vt[0], vt[1]); gaP[k] = (u16x2)(ga[0], ga[1]);
 	}
-	int Hprev[R], Eprev[R];
+	u16x2 HprevP[RP], EprevP[RP];
 #pragma unroll
-	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
+	for (int k = 0; k < RP; k++) { HprevP[k] = p_splat(0); EprevP[k] = p_splat(0); }
 	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, best = 0;
 	const uint32_t steps = cols + nlanes - 1;
 	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
 	const int last_r = (int)((rows - 1) % R);
-	const int rdgapo = P.rdgapo, rdgape = P.rdgape, rfgapo = P.rfgapo, rfgape = P.rfgape, npen = P.n_pen, bonus = P.match_bonus;
+	const u16x2 rdgapoP = p_splat(P.rdgapo), rdgapeP = p_splat(P.rdgape), rfgapoP = p_splat(P.rfgapo), rfgapeP = p_splat(P.rfgape), npenP = p_splat(P.n_pen);
+	const unsigned short rfgapo = (unsigned short)P.rfgapo, rfgape = (unsigned short)P.rfgape;
 	for (uint32_t t = 0; t < steps; t++) {
 		const int upH = __shfl_up(myHlast, 1);
 		const int upF = __shfl_up(myFlast, 1);
@@ -121,101 +91,62 @@ __device__ __forceinline__ int fill_ee_u8_pred_wave(const AlignParams& P, bool f
 		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
 		int refc = 4;
 		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
-		int hdiag = (lane == 0) ? 0xff : (j == 0 ? 0 : upHdiag);
-		int fin_h = upH, fin_f = upF;
 		const bool jl = j > 0;
-		int Hnew[R], Enew[R], Fnew[R], code[R];
+		const unsigned short hdiag0 = (unsigned short)((lane == 0) ? 0xff : (jl ? upHdiag : 0));
+		const u16x2 refcP = p_splat(refc);
+		// ---- independent of the row above: two rows per instruction ----
+		u16x2 penP[RP], hdP[RP], dP[RP], eP[RP];
 #pragma unroll
-		for (int r = 0; r < R; r++) {
-			int pen;
-			if (rdc[r] > 3 || refc > 3) pen = npen; else pen = (rdc[r] == refc) ? -bonus : mmp[r];
-			const int hl = Hprev[r], el = Eprev[r];
-			const int e = jl ? imax(subs0(el, rdgape), subs0(subs0(hl, rdgapo), veto[r])) : 0;
-			const bool row0 = lane == 0 && r == 0;
-			const int f = row0 ? 0 : subs0(imax(subs0(fin_f, rfgape), subs0(fin_h, rfgapo)), veto[r]);
-			const int h = imax(imax(subs0(hdiag, pen), e), f);
-			const bool ga = veto[r] == 0;
-			int c = (jl && hdiag - pen == h) ? PB_HD : 0;
-			c |= (ga && jl && h == e) ? PB_HE : 0;
-			c |= (ga && h == f) ? PB_HF : 0;
-			c |= (jl && hl - rdgapo == e) ? PB_EO : 0;
-			c |= (jl && el - rdgape == e) ? PB_EE : 0;
-			c |= (!row0 && fin_h - rfgapo == f) ? PB_FO : 0;
-			c |= (!row0 && fin_f - rfgape == f) ? PB_FE : 0;
-			Hnew[r] = h; Enew[r] = e; Fnew[r] = f; code[r] = c;
-			hdiag = hl;
+		for (int k = 0; k < RP; k++) {
+			const u16x2 neq = p_min(rdcP[k] ^ refcP, p_splat(1));
+			penP[k] = neq * (refc > 3 ? npenP : mmpP[k]);
+			hdP[k] = (u16x2)(k == 0 ? hdiag0 : HprevP[k > 0 ? k - 1 : 0].y, HprevP[k].x);            // H of (row - 1, column - 1)
+			dP[k] = p_subs(hdP[k], penP[k]);
+			const u16x2 e = p_max(p_subs(EprevP[k], rdgapeP), p_subs(p_subs(HprevP[k], rdgapoP), vetoP[k]));
+			eP[k] = jl ? e : p_splat(0);
+		}
+		// ---- the F / H chain down the rows ----
+		u16x2 HnewP[RP], FnewP[RP];
+		unsigned short fin_h = (unsigned short)upH, fin_f = (unsigned short)upF;
+#pragma unroll
+		for (int r = 0; r < 2 * RP; r++) {
+			const int k = r >> 1;
+			const unsigned short d = (r & 1) ? dP[k].y : dP[k].x, e = (r & 1) ? eP[k].y : eP[k].x;
+			unsigned short f = s_subs(s_max(s_subs(fin_f, rfgape), s_subs(fin_h, rfgapo)), veto[r]);
+			if (r == 0 && lane == 0) f = 0;
+			const unsigned short h = s_max(s_max(d, e), f);
+			if (r & 1) { HnewP[k].y = h; FnewP[k].y = f; } else { HnewP[k].x = h; FnewP[k].x = f; }
 			fin_h = h; fin_f = f;
 		}
 		if (active) {
-			uint8_t* base = pm + ((uint64_t)t * R) * 64 + lane;       // pred_idx(): 64 consecutive bytes per (step, row-in-lane)
+			if (PRED) {
+				uint8_t* base = pm + ((uint64_t)t * R) * 64 + lane;       // pred_idx(): 64 consecutive bytes per (step, row-in-lane)
+				const u16x2 jmask = p_splat(jl ? 0x7f : 0x64);            // column 0 has no left / diagonal neighbour: HD, HE, EO, EE off
 #pragma unroll
-			for (int r = 0; r < R; r++) base[r * 64] = (uint8_t)code[r];
+				for (int k = 0; k < RP; k++) {
+					const u16x2 h = HnewP[k], e = eP[k], f = FnewP[k];
+					const u16x2 huP = (u16x2)(k == 0 ? (unsigned short)upH : HnewP[k > 0 ? k - 1 : 0].y, HnewP[k].x);     // H of the row above, same column
+					const u16x2 fuP = (u16x2)(k == 0 ? (unsigned short)upF : FnewP[k > 0 ? k - 1 : 0].y, FnewP[k].x);
+					u16x2 up_ok = p_splat(1);
+					if (k == 0 && lane == 0) up_ok.x = 0;                   // read row 0 has no row above
+					u16x2 c = p_eq(h + penP[k], hdP[k]);                                     // PB_HD
+					c |= (p_eq(h, e) & gaP[k]) << 1;                                         // PB_HE
+					c |= (p_eq(h, f) & gaP[k]) << 2;                                         // PB_HF
+					c |= p_eq(e + rdgapoP, HprevP[k]) << 3;                                  // PB_EO
+					c |= p_eq(e + rdgapeP, EprevP[k]) << 4;                                  // PB_EE
+					c |= (p_eq(f + rfgapoP, huP) & up_ok) << 5;                              // PB_FO
+					c |= (p_eq(f + rfgapeP, fuP) & up_ok) << 6;                              // PB_FE
+					c &= jmask;
+					if (2 * k < R) base[(2 * k) * 64] = (uint8_t)c.x;
+					if (2 * k + 1 < R) base[(2 * k + 1) * 64] = (uint8_t)c.y;
+				}
+			}
+			const unsigned short hl_ = (last_r & 1) ? HnewP[last_r >> 1].y : HnewP[last_r >> 1].x;
+			if (lane_has_last) { best = imax(best, (int)hl_); if (PRED) g_hot.lastrow[j] = (int16_t)((int)hl_ - 0xff); }
 #pragma unroll
-			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
-			if (lane_has_last) { best = imax(best, Hnew[last_r]); g_hot.lastrow[j] = (int16_t)(Hnew[last_r] - 0xff); }
-		}
-		upHdiag = upH;
-		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
-	}
-	return __shfl(best, (int)((rows - 1) / R));
-}
-
-// Score-only pass of the same recurrence: nothing is stored, no predecessor bits are formed -- just the best last-row score.
-// Most DP problems of a repeat-rich read fail (best < minsc: up to -D of them in a row), and a failed problem is never
-// backtraced, so the full fill (fill_ee_u8_pred_wave, 2.5x the arithmetic plus the stores) only runs for the ones that pass.
-template <int R>
-__device__ __forceinline__ int fill_ee_u8_score_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols) {
-	const int lane = threadIdx.x & 63;
-	const uint32_t nlanes = (rows + R - 1) / R;
-	int rdc[R], mmp[R], veto[R];
-#pragma unroll
-	for (int r = 0; r < R; r++) {
-		const uint32_t i = (uint32_t)lane * R + r;
-		const bool valid = i < rows;
-		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
-		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
-		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
-		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 0xff : 0;
-	}
-	int Hprev[R], Eprev[R];
-#pragma unroll
-	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
-	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, best = 0;
-	const uint32_t steps = cols + nlanes - 1;
-	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
-	const int last_r = (int)((rows - 1) % R);
-	const int rdgapo = P.rdgapo, rdgape = P.rdgape, rfgapo = P.rfgapo, rfgape = P.rfgape, npen = P.n_pen, bonus = P.match_bonus;
-	for (uint32_t t = 0; t < steps; t++) {
-		const int upH = __shfl_up(myHlast, 1);
-		const int upF = __shfl_up(myFlast, 1);
-		int upRef = __shfl_up(refm, 1);
-		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
-		refm = upRef;
-		const int j = (int)t - lane;
-		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
-		int refc = 4;
-		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
-		int hdiag = (lane == 0) ? 0xff : (j == 0 ? 0 : upHdiag);
-		int fin_h = upH, fin_f = upF;
-		int Hnew[R], Enew[R], flast = 0;
-#pragma unroll
-		for (int r = 0; r < R; r++) {
-			int pen;
-			if (rdc[r] > 3 || refc > 3) pen = npen; else pen = (rdc[r] == refc) ? -bonus : mmp[r];
-			const int e = (j == 0) ? 0 : imax(subs0(Eprev[r], rdgape), subs0(subs0(Hprev[r], rdgapo), veto[r]));
-			int f;
-			if (lane == 0 && r == 0) f = 0;
-			else f = subs0(imax(subs0(fin_f, rfgape), subs0(fin_h, rfgapo)), veto[r]);
-			const int h = imax(imax(subs0(hdiag, pen), e), f);
-			Hnew[r] = h; Enew[r] = e;
-			hdiag = Hprev[r];
-			fin_h = h; fin_f = f; flast = f;
-		}
-		if (active) {
-#pragma unroll
-			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
-			if (lane_has_last) best = imax(best, Hnew[last_r]);
-			myHlast = Hnew[R - 1]; myFlast = flast;
+			for (int k = 0; k < RP; k++) { HprevP[k] = HnewP[k]; EprevP[k] = eP[k]; }
+			myHlast = (int)(((R - 1) & 1) ? HnewP[(R - 1) >> 1].y : HnewP[(R - 1) >> 1].x);
+			myFlast = (int)(((R - 1) & 1) ? FnewP[(R - 1) >> 1].y : FnewP[(R - 1) >> 1].x);
 		}
 		upHdiag = upH;
 	}
@@ -671,25 +602,26 @@ struct DevPlat {
 			uint8_t* pm = reinterpret_cast<uint8_t*>(mat);
 			// pass 1: can any end-to-end alignment in this window reach the minimum score at all?
 			switch (dp_R(rows)) {
-				case 1: best = fill_ee_u8_score_wave<1>(P, fw, rows, cols); break;
-				case 2: best = fill_ee_u8_score_wave<2>(P, fw, rows, cols); break;
-				case 3: best = fill_ee_u8_score_wave<3>(P, fw, rows, cols); break;
-				case 4: best = fill_ee_u8_score_wave<4>(P, fw, rows, cols); break;
-				case 5: best = fill_ee_u8_score_wave<5>(P, fw, rows, cols); break;
-				case 6: best = fill_ee_u8_score_wave<6>(P, fw, rows, cols); break;
-				case 7: best = fill_ee_u8_score_wave<7>(P, fw, rows, cols); break;
-				default: best = fill_ee_u8_score_wave<8>(P, fw, rows, cols); break;
+				case 1: best = fill_ee_u8_packed<1, false>(P, fw, rows, cols, pm); break;
+				case 2: best = fill_ee_u8_packed<2, false>(P, fw, rows, cols, pm); break;
+				case 3: best = fill_ee_u8_packed<3, false>(P, fw, rows, cols, pm); break;
+				case 4: best = fill_ee_u8_packed<4, false>(P, fw, rows, cols, pm); break;
+				case 5: best = fill_ee_u8_packed<5, false>(P, fw, rows, cols, pm); break;
+				case 6: best = fill_ee_u8_packed<6, false>(P, fw, rows, cols, pm); break;
+				case 7: best = fill_ee_u8_packed<7, false>(P, fw, rows, cols, pm); break;
+				default: best = fill_ee_u8_packed<8, false>(P, fw, rows, cols, pm); break;
 			}
 			if ((int64_t)best - 0xff < minsc) { wave_fence(); return (int64_t)best - 0xff; }
+			// pass 2: the matrix of predecessor bits (same scores, so `best` is unchanged)
 			switch (dp_R(rows)) {
-				case 1: best = fill_ee_u8_pred_wave<1>(P, fw, rows, cols, pm); break;
-				case 2: best = fill_ee_u8_pred_wave<2>(P, fw, rows, cols, pm); break;
-				case 3: best = fill_ee_u8_pred_wave<3>(P, fw, rows, cols, pm); break;
-				case 4: best = fill_ee_u8_pred_wave<4>(P, fw, rows, cols, pm); break;
-				case 5: best = fill_ee_u8_pred_wave<5>(P, fw, rows, cols, pm); break;
-				case 6: best = fill_ee_u8_pred_wave<6>(P, fw, rows, cols, pm); break;
-				case 7: best = fill_ee_u8_pred_wave<7>(P, fw, rows, cols, pm); break;
-				default: best = fill_ee_u8_pred_wave<8>(P, fw, rows, cols, pm); break;
+				case 1: best = fill_ee_u8_packed<1, true>(P, fw, rows, cols, pm); break;
+				case 2: best = fill_ee_u8_packed<2, true>(P, fw, rows, cols, pm); break;
+				case 3: best = fill_ee_u8_packed<3, true>(P, fw, rows, cols, pm); break;
+				case 4: best = fill_ee_u8_packed<4, true>(P, fw, rows, cols, pm); break;
+				case 5: best = fill_ee_u8_packed<5, true>(P, fw, rows, cols, pm); break;
+				case 6: best = fill_ee_u8_packed<6, true>(P, fw, rows, cols, pm); break;
+				case 7: best = fill_ee_u8_packed<7, true>(P, fw, rows, cols, pm); break;
+				default: best = fill_ee_u8_packed<8, true>(P, fw, rows, cols, pm); break;
 			}
 			best -= 0xff;
 		} else {
