@@ -38,7 +38,8 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 // Cells are stored wavefront-major (pred_idx): whole 64-byte lines per store; the last row's scores go straight to
 // HOT.lastrow for the candidate gather.  Traffic: 1 B per cell of a PASSING problem instead of 4 B + a 2 B mask plane for all.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u16x2 p_splat(int v) { return (u16x2)((unsigned short)v); }
+__device__ __forceinline__ u16x2 p_make(unsigned short lo, unsigned short hi) { u16x2 v; v.x = lo; v.y = hi; return v; }     // (C++: `(u16x2)(a, b)` would be a comma expression)
+__device__ __forceinline__ u16x2 p_splat(int v) { return p_make((unsigned short)v, (unsigned short)v); }
 __device__ __forceinline__ u16x2 p_subs(u16x2 a, u16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
 __device__ __forceinline__ u16x2 p_max(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ u16x2 p_min(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
@@ -70,7 +71,7 @@ __device__ __forceinline__ int fill_ee_u8_packed(const AlignParams& P, bool fw, 
 			ga[hh] = (valid && !bar) ? 1 : 0;
 			veto[r] = vt[hh];
 		}
-		rdcP[k] = (u16x2)(rc[0], rc[1]); mmpP[k] = (u16x2)(mp[0], mp[1]); vetoP[k] = (u16x2)(vt[0], vt[1]); gaP[k] = (u16x2)(ga[0], ga[1]);
+		rdcP[k] = p_make(rc[0], rc[1]); mmpP[k] = p_make(mp[0], mp[1]); vetoP[k] = p_make(vt[0], vt[1]); gaP[k] = p_make(ga[0], ga[1]);
 	}
 	u16x2 HprevP[RP], EprevP[RP];
 #pragma unroll
@@ -100,7 +101,7 @@ __device__ __forceinline__ int fill_ee_u8_packed(const AlignParams& P, bool fw, 
 		for (int k = 0; k < RP; k++) {
 			const u16x2 neq = p_min(rdcP[k] ^ refcP, p_splat(1));
 			penP[k] = neq * (refc > 3 ? npenP : mmpP[k]);
-			hdP[k] = (u16x2)(k == 0 ? hdiag0 : HprevP[k > 0 ? k - 1 : 0].y, HprevP[k].x);            // H of (row - 1, column - 1)
+			hdP[k] = p_make(k == 0 ? hdiag0 : HprevP[k > 0 ? k - 1 : 0].y, HprevP[k].x);            // H of (row - 1, column - 1)
 			dP[k] = p_subs(hdP[k], penP[k]);
 			const u16x2 e = p_max(p_subs(EprevP[k], rdgapeP), p_subs(p_subs(HprevP[k], rdgapoP), vetoP[k]));
 			eP[k] = jl ? e : p_splat(0);
@@ -125,8 +126,8 @@ __device__ __forceinline__ int fill_ee_u8_packed(const AlignParams& P, bool fw, 
 #pragma unroll
 				for (int k = 0; k < RP; k++) {
 					const u16x2 h = HnewP[k], e = eP[k], f = FnewP[k];
-					const u16x2 huP = (u16x2)(k == 0 ? (unsigned short)upH : HnewP[k > 0 ? k - 1 : 0].y, HnewP[k].x);     // H of the row above, same column
-					const u16x2 fuP = (u16x2)(k == 0 ? (unsigned short)upF : FnewP[k > 0 ? k - 1 : 0].y, FnewP[k].x);
+					const u16x2 huP = p_make(k == 0 ? (unsigned short)upH : HnewP[k > 0 ? k - 1 : 0].y, HnewP[k].x);     // H of the row above, same column
+					const u16x2 fuP = p_make(k == 0 ? (unsigned short)upF : FnewP[k > 0 ? k - 1 : 0].y, FnewP[k].x);
 					u16x2 up_ok = p_splat(1);
 					if (k == 0 && lane == 0) up_ok.x = 0;                   // read row 0 has no row above
 					u16x2 c = p_eq(h + penP[k], hdP[k]);                                     // PB_HD
