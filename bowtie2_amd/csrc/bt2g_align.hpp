@@ -286,16 +286,17 @@ struct Work {
 
 // DP scratch of one wave.  Two matrix formats:
 //  * end-to-end 8-bit mode (the common case): ONE BYTE per cell holding which predecessors are score-consistent
-//    (PB_* below), computed while the cell is filled -- the backtrace never looks at scores again.  Wavefront-major
-//    (pred_idx) so that the fill's stores are whole 64-byte lines; the backtrace gathers 64 diagonal steps per fetch.  Its
-//    per-cell backtrace masks (`pmask`, 32 bits) carry an epoch tag instead of being cleared for every DP;
+//    (PB_* below), computed while the cell is filled -- the backtrace never looks at scores again.  Only the band of
+//    diagonals a valid alignment can touch exists (EeBand / pred_idx), row-major over diagonals; the backtrace gathers 64
+//    diagonal steps per fetch.  Its per-cell backtrace masks (`pmask`, 32 bits) carry an epoch tag instead of being cleared
+//    for every DP;
 //  * 16-bit end-to-end and local mode: wavefront-major packed H|E|F cells (dp_cell) + a 16-bit mask plane that is zeroed
 //    after every fill that has candidate cells.
 struct DpScratch {
 	uint32_t* mat;      // pred bytes (8-bit end-to-end) or packed cells
 	uint16_t* masks;    // [rows][cols] masks of the packed-cell formats
 	uint32_t* pmask;    // masks of the pred format: bits 0-12 as SSEMatrix::masks_, bits 13-31 = epoch of the DP that wrote them
-	uint32_t* epoch;    // -> epoch of the DP currently in this scratch (lives in the arena, survives launches)
+	uint32_t* epoch;    // -> [0] epoch of the DP currently in this scratch (lives in the arena, survives launches), [1] band lo, [2] band row width
 	uint32_t  pmask_words;
 };
 // predecessor bits of one cell (aligner_swsse_ee_u8.cpp:1330-1520 asks these questions during the backtrace):
@@ -304,13 +305,35 @@ struct DpScratch {
 enum { PB_HD = 1, PB_HE = 2, PB_HF = 4, PB_EO = 8, PB_EE = 16, PB_FO = 32, PB_FE = 64 };
 constexpr uint32_t kEpochShift = 13, kEpochMax = (1u << 19) - 1;
 constexpr uint32_t kPredTile = 64;   // diagonal steps one tile fetch covers
-// cell (i, j) of the pred format: wavefront-major like the packed cells (lane l = i / R owns rows l*R .. l*R+R-1 and reaches
-// column j at fill step t = j + l), one byte per cell -- every fill step stores R runs of 64 consecutive bytes
-BT2_HD uint64_t pred_idx(uint32_t rows, uint32_t i, uint32_t j) {
-	const uint32_t R = (rows + 63) / 64, l = i / R, r = i % R;
-	return ((uint64_t)(j + l) * R + r) * 64 + l;
+// Geometry of the pred format.  Only a BAND of diagonals of the DP rectangle is ever filled: an end-to-end alignment that
+// scores >= minsc starts in row 0 at a column >= 0, ends in the last row at a column < cols, and makes at most G vertical
+// moves (reference gaps: the first costs rfgapo, each further one rfgape, and the perfect score is 0), so every cell (i, j)
+// on such a path has  -G <= j - i <= cols - rows + G.  Cells outside the band can only lie on paths that score < minsc;
+// treating them as "minus infinity" changes neither the last-row scores >= minsc nor any predecessor bit of a cell the
+// backtrace can visit (a predecessor that is consistent with a visited cell lies on a valid path itself, and a valid path
+// never leaves the band).  Cell (i, j) is stored at byte i * w + (j - i + lo): row-major over diagonals, one lane of the
+// fill owns 2 * RP consecutive diagonals (w = 128 * RP).  lo/w live in the scratch header next to the epoch.
+struct EeBand { int32_t lo; uint32_t nd; };      // diagonal index dd = j - i + lo, 0 <= dd < nd
+BT2_HD bool ee_band(int rfgapo, int rfgape, uint32_t rows, uint32_t cols, int64_t minsc, EeBand& b) {
+	const int64_t budget = -minsc;
+	if (budget < 0 || rows == 0 || cols == 0) return false;
+	int64_t g;
+	if (budget < rfgapo) g = 0; else if (rfgape <= 0) g = rows; else g = (budget - rfgapo) / rfgape + 1;
+	if (g > (int64_t)rows - 1) g = (int64_t)rows - 1;
+	int64_t dhi = (int64_t)cols - (int64_t)rows + g;
+	if (dhi > (int64_t)cols - 1) dhi = (int64_t)cols - 1;
+	if (dhi < -g) return false;
+	b.lo = (int32_t)g; b.nd = (uint32_t)(dhi + g + 1);
+	return true;
 }
-BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { const uint32_t R = (rows + 63) / 64; return ((uint64_t)cols + (rows + R - 1) / R) * R * 64; }
+// pairs of diagonals per lane the fill is instantiated for (0: more than 2048 diagonals -- cannot happen within kMaxLen / kMaxCols)
+BT2_HD uint32_t ee_band_rp(uint32_t nd) {
+	const uint32_t need = (nd + 127) / 128;
+	return need <= 4 ? need : need <= 6 ? 6u : need <= 8 ? 8u : need <= 12 ? 12u : need <= 16 ? 16u : 0u;
+}
+BT2_HD uint64_t pred_idx(int32_t lo, uint32_t w, uint32_t i, uint32_t j) { return (uint64_t)i * w + (uint32_t)((int32_t)j - (int32_t)i + lo); }
+// bytes of the widest band a rows x cols problem can have (every diagonal of the rectangle)
+BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { uint32_t rp = ee_band_rp(rows + cols); if (rp == 0) rp = 16; return (uint64_t)rows * rp * 128; }
 
 // ---------------------------------------------------------------------------------------
 // small helpers

@@ -1012,7 +1012,10 @@ struct Aligner {
 			if (fast) {
 				R1C& r2 = HOT.samp.r[pick];
 				if (!r2.inited) r1c_init(r2, w.satpos2[ri].size, P.all_hits != 0);
+				const uint64_t tn_ = now();
+				HOT.t_phase[21] += r2.swaplist ? 1ull : (1ull | (1ull << 32));      // profile: draws | draws on the seen-list path << 32
 				r = r1c_next(r2);
+				HOT.t_phase[20] += now() - tn_;      // profile: Random1toN::next
 				exhausted = r2.n > 0 && r2.cur >= r2.n;
 			} else {
 				R1N& r2 = w.rands2[ri];
@@ -1206,6 +1209,8 @@ struct Aligner {
 		DpScratch dpl;
 		dpl.mat = Plat::uni_ptr(dp.mat); dpl.masks = Plat::uni_ptr(dp.masks); dpl.pmask = Plat::uni_ptr(dp.pmask); dpl.epoch = Plat::uni_ptr(dp.epoch); dpl.pmask_words = 0;
 		const uint32_t epoch = pred ? Plat::uni(*dpl.epoch) : 0u;
+		const int32_t band_lo = pred ? (int32_t)Plat::uni(dpl.epoch[1]) : 0;       // geometry of the band the fill stored (pred_idx)
+		const uint32_t band_w = pred ? Plat::uni(dpl.epoch[2]) : 0u;
 		BtFrame* const btstack = Plat::uni_ptr(&w.btstack[0]);
 		struct Prof {      // profile counters stay in registers until the function returns
 			Aligner& a; uint32_t steps, tiles; uint64_t tile_t;
@@ -1256,7 +1261,7 @@ struct Aligner {
 			prof.steps++;
 			if (td >= tile_len) {
 				const uint64_t tt_ = now();
-				if (pred) Plat::bt_tile_pred(dpl, rows, row, col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
+				if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
 				td = 0; prof.tiles++; prof.tile_t += now() - tt_;
 			}
 			const uint32_t mk0 = pred ? Plat::lane(tile_hi, td) : (Plat::lane(tile, 48 + td) & 0xffffu);
@@ -1345,7 +1350,7 @@ struct Aligner {
 			}
 			mk |= 1;                         // setReportedThrough
 			if (mk != mk0) {
-				if (pred) dpl.pmask[pred_idx(rows, row, col)] = mk | (epoch << kEpochShift);
+				if (pred) dpl.pmask[pred_idx(band_lo, band_w, row, col)] = mk | (epoch << kEpochShift);
 				else dpl.masks[(uint64_t)row * cols + col] = (uint16_t)mk;
 			}
 			if (!can_move_thru) {
@@ -1538,7 +1543,7 @@ struct Aligner {
 			typename Plat::LaneReg tile, tile_hi;
 			{
 				const uint64_t tt_ = now();      // also the first tile of the backtrace
-				if (mode == 0) Plat::bt_tile_pred(dp, rows, c.row, c.col, Plat::uni(*dp.epoch), tile, tile_hi); else Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col, wide, tile, tile_hi);
+				if (mode == 0) Plat::bt_tile_pred(dp, (int32_t)Plat::uni(dp.epoch[1]), Plat::uni(dp.epoch[2]), c.row, c.col, Plat::uni(*dp.epoch), tile, tile_hi); else Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col, wide, tile, tile_hi);
 				pf_tiles++; pf_tile_t += now() - tt_;
 			}
 			if ((mode == 0 ? Plat::lane(tile_hi, 0) : Plat::lane(tile, 48)) & 1) { HOT.cural++; continue; }
@@ -1811,7 +1816,8 @@ struct Aligner {
 						} else {
 							mode = minsc < -254 ? 1 : 0;
 							sse16 = mode == 1;
-							best = Plat::dp_fill_ee(P, w, fw, rows, cols, dp.mat, mode != 0, minsc);
+							best = Plat::dp_fill_ee(P, w, fw, rows, cols, dp, mode != 0, minsc);
+							if (best == INT64_MIN) { ovf(30); return EXT_HARD_LIMIT; }
 						}
 						HOT.t_phase[5] += now() - td_;
 						HOT.n_ex_dps++;

@@ -20,138 +20,201 @@ __shared__ HotWork g_hot;    // one wavefront per workgroup: the hot per-read st
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// End-to-end 8-bit fill (alignNucleotidesEnd2EndSseU8's fixed point, aligner_swsse_ee_u8.cpp:775-1146) on the anti-diagonal
-// wavefront: lane l owns read rows l*R .. l*R+R-1 and is at column t - l in step t; H, F and the reference character travel
-// down the lanes with __shfl_up.  Scores are kept as unsigned 16-bit values TWO ROWS PER REGISTER: everything that does not
-// depend on the row above in the same column -- the substitution penalty, H_diag - pen, and E -- is computed for a pair of
-// rows with one packed instruction (v_pk_sub_u16 clamp = the reference's saturating subtraction, v_pk_max_u16, ...); only
-// the F/H chain down the rows is sequential (5 operations per row).
+// End-to-end 8-bit fill (alignNucleotidesEnd2EndSseU8's fixed point, aligner_swsse_ee_u8.cpp:775-1146), band form.
+//
+// Only the diagonals a valid alignment can touch are computed (EeBand, bt2g_align.hpp).  Lane l owns the 2 * RP consecutive
+// diagonals dd = l * 2RP ..., the wave walks down the rows: in row i the lane's cells are the columns j = i + dd - lo.
+//  * the diagonal predecessor of a cell is the lane's own value of the previous row (no shuffle);
+//  * the cell above is the next diagonal of the previous row: a register shift inside the lane, one DPP wave shift across;
+//  * the cell to the left is the previous diagonal of the SAME row.  E(dd) = max(E(dd-1) - rdgape, H(dd-1) - rdgapo) is a
+//    max-plus prefix over the row; because rdgapo >= rdgape, opening from an H that itself came from E never beats extending
+//    that E, so E is a scan over Hd = max(diagonal, F) alone: lane-local chain, then a 6-step DPP scan of the lane carries
+//    (row_shr 1/2/4/8, row_bcast 15/31) with the per-lane decay 2RP * rdgape, then one more local pass.
+// Scores are unsigned 16-bit values, two diagonals per register (v_pk_sub_u16 clamp = the reference's saturating subtract).
+// The substitution penalty is one v_perm_b32: the lane keeps its reference characters as byte selectors (code | 0x0c00 per
+// half) into the row's 5-entry penalty table, which is wave-uniform (A,C,G,T in one scalar register, N in another).
 //
 // PRED = false: score-only pass, nothing is stored -- just the best last-row score.  Most DP problems of a repeat-rich read
-// fail (best < minsc: up to -D of them in a row) and a failed problem is never backtraced.
+// fail (best < minsc: up to -D of them in a row) and a failed problem is never backtraced.  The pass stops at the first row
+// (checked every 4th) in which no cell still holds minsc: end to end there is no match bonus, so scores only fall.
 // PRED = true: the full fill.  What goes to memory is ONE BYTE per cell saying which predecessors are score-consistent (PB_*
 // in bt2g_align.hpp) -- exactly the questions the reference's backtrace asks of H/E/F (:1330-1520), answered while the
-// neighbours are in registers, as equalities on packed pairs ((a ^ b) == 0  <=>  min(a ^ b, 1) == 0).  Identities used to
-// fold the five H options into two flags (gaps allowed in the row, so no veto applies):
+// neighbours are in registers.  Identities used to fold the five H options into two flags (gaps allowed in the row):
 //   H == H_up - rfgapo  <=>  H == F and F == H_up - rfgapo      (F >= H_up - rfgapo and H >= F);  likewise for the
 //   extension F_up - rfgape and for E with H_left / E_left.
-// Cells are stored wavefront-major (pred_idx): whole 64-byte lines per store; the last row's scores go straight to
-// HOT.lastrow for the candidate gather.  Traffic: 1 B per cell of a PASSING problem instead of 4 B + a 2 B mask plane for all.
+// A cell left of column 0 has only zero inputs and stays zero, so column 0 needs no special case: with H_left = E_left =
+// H_diag = 0 none of HD/HE/EO/EE can be set on a cell whose score is a real one (> 0).  Cells right of the last column hold
+// junk that never flows back (every dependency points to a smaller or equal column).
+// Row i of the matrix is bytes [i * 128RP, (i + 1) * 128RP): lane l stores its 2RP bytes at offset l * 2RP.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 p_make(unsigned short lo, unsigned short hi) { u16x2 v; v.x = lo; v.y = hi; return v; }     // (C++: `(u16x2)(a, b)` would be a comma expression)
 __device__ __forceinline__ u16x2 p_splat(int v) { return p_make((unsigned short)v, (unsigned short)v); }
 __device__ __forceinline__ u16x2 p_subs(u16x2 a, u16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
 __device__ __forceinline__ u16x2 p_max(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ u16x2 p_min(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ u16x2 p_eq(u16x2 a, u16x2 b) { return p_splat(1) - p_min(a ^ b, p_splat(1)); }     // 1 where equal, else 0
+__device__ __forceinline__ u16x2 p_ne(u16x2 a, u16x2 b) { return p_min(a ^ b, p_splat(1)); }     // 1 where different, else 0
 __device__ __forceinline__ unsigned short s_subs(unsigned short a, unsigned short b) { return __builtin_elementwise_sub_sat(a, b); }
 __device__ __forceinline__ unsigned short s_max(unsigned short a, unsigned short b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t p_bits(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ u16x2 p_from(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+// (lo.y, hi.x): the pair one diagonal further along
+__device__ __forceinline__ uint32_t shift_in(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+// DPP moves: lanes without a source get 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true); }
+constexpr int kDppRowShr = 0x110, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
 
-template <int R, bool PRED>
-__device__ __forceinline__ int fill_ee_u8_packed(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm) {
-	constexpr int RP = (R + 1) / 2;
+template <int RP, bool PRED>
+__device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, int lo, int thr, uint8_t* __restrict__ pm) {
+	constexpr int N2 = 2 * RP;
+	constexpr uint32_t W = 128u * RP;
 	const int lane = threadIdx.x & 63;
-	const uint32_t nlanes = (rows + R - 1) / R;
-	u16x2 rdcP[RP], mmpP[RP], vetoP[RP], gaP[RP];
-	unsigned short veto[2 * RP];
+	const int dd0 = lane * N2;
+	const int j00 = dd0 - lo;                 // column of the lane's first diagonal in row 0
+	uint32_t refS[RP];                        // reference characters of the lane's cells as v_perm selectors
+	u16x2 Hp[RP], Fp[RP];                     // H and F of the previous row
 #pragma unroll
 	for (int k = 0; k < RP; k++) {
-		unsigned short rc[2], mp[2], vt[2], ga[2];
+		uint32_t sel = 0, h = 0;
 #pragma unroll
 		for (int hh = 0; hh < 2; hh++) {
-			const int r = 2 * k + hh;
-			const uint32_t i = (uint32_t)lane * R + r;
-			const bool valid = r < R && i < rows;
-			const int c = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
-			const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
-			rc[hh] = (unsigned short)(c > 3 ? 5 : c);                         // 5: a read N never equals a reference code
-			mp[hh] = (unsigned short)(c > 3 ? P.n_pen : mm_penalty(P, q < 0 ? 0 : q));
-			const bool bar = valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar);
-			vt[hh] = bar ? 0xff : 0;
-			ga[hh] = (valid && !bar) ? 1 : 0;
-			veto[r] = vt[hh];
+			const int j = j00 + 2 * k + hh;
+			const bool real = (uint32_t)j < cols;
+			const uint32_t code = real ? (uint32_t)__builtin_ctz((uint32_t)g_hot.rf[real ? j : 0] | 16u) : 4u;
+			sel |= (code | 0x0c00u) << (16 * hh);
+			h |= (real ? 0xffu : 0u) << (16 * hh);       // "row -1": an alignment may start in any column of row 0
 		}
-		rdcP[k] = p_make(rc[0], rc[1]); mmpP[k] = p_make(mp[0], mp[1]); vetoP[k] = p_make(vt[0], vt[1]); gaP[k] = p_make(ga[0], ga[1]);
+		refS[k] = sel; Hp[k] = p_from(h); Fp[k] = p_splat(0);
 	}
-	u16x2 HprevP[RP], EprevP[RP];
+	if (PRED) for (uint32_t j = (uint32_t)lane; j < cols; j += 64) g_hot.lastrow[j] = (int16_t)-0xff;      // columns the band does not reach in the last row
+	int jin = j00 + N2;                       // column that enters the lane's last diagonal in the next row
+	const int rdgape = P.rdgape, rdgapo = P.rdgapo;
+	const u16x2 rdoP = p_splat(rdgapo), rfoP = p_splat(P.rfgapo), rfeP = p_splat(P.rfgape);
+	const uint32_t npen_word = (uint32_t)P.n_pen & 0xffu;
+	auto cap = [](uint32_t v) -> unsigned short { return (unsigned short)(v > 1023u ? 1023u : v); };     // scores are <= 255: any larger decay is "to zero"
+	const uint32_t D = (uint32_t)N2 * (uint32_t)rdgape;
+	const unsigned short d1 = cap(D), d2 = cap(2 * D), d4 = cap(4 * D), d8 = cap(8 * D);
+	const unsigned short c15 = cap(((uint32_t)(lane & 15) + 1u) * D), c31 = cap((uint32_t)(lane > 31 ? lane - 31 : 0) * D);
+	u16x2 decP[RP];                           // decay of the carry-in on its way to each of the lane's diagonals
 #pragma unroll
-	for (int k = 0; k < RP; k++) { HprevP[k] = p_splat(0); EprevP[k] = p_splat(0); }
-	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, best = 0;
-	const uint32_t steps = cols + nlanes - 1;
-	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
-	const int last_r = (int)((rows - 1) % R);
-	const u16x2 rdgapoP = p_splat(P.rdgapo), rdgapeP = p_splat(P.rdgape), rfgapoP = p_splat(P.rfgapo), rfgapeP = p_splat(P.rfgape), npenP = p_splat(P.n_pen);
-	const unsigned short rfgapo = (unsigned short)P.rfgapo, rfgape = (unsigned short)P.rfgape;
-	for (uint32_t t = 0; t < steps; t++) {
-		const int upH = __shfl_up(myHlast, 1);
-		const int upF = __shfl_up(myFlast, 1);
-		int upRef = __shfl_up(refm, 1);
-		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
-		refm = upRef;
-		const int j = (int)t - lane;
-		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
-		int refc = 4;
-		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
-		const bool jl = j > 0;
-		const unsigned short hdiag0 = (unsigned short)((lane == 0) ? 0xff : (jl ? upHdiag : 0));
-		const u16x2 refcP = p_splat(refc);
-		// ---- independent of the row above: two rows per instruction ----
-		u16x2 penP[RP], hdP[RP], dP[RP], eP[RP];
+	for (int k = 0; k < RP; k++) decP[k] = p_make(cap((uint32_t)(2 * k) * (uint32_t)rdgape), cap((uint32_t)(2 * k + 1) * (uint32_t)rdgape));
+	u16x2 HP[RP];
 #pragma unroll
-		for (int k = 0; k < RP; k++) {
-			const u16x2 neq = p_min(rdcP[k] ^ refcP, p_splat(1));
-			penP[k] = neq * (refc > 3 ? npenP : mmpP[k]);
-			hdP[k] = p_make(k == 0 ? hdiag0 : HprevP[k > 0 ? k - 1 : 0].y, HprevP[k].x);            // H of (row - 1, column - 1)
-			dP[k] = p_subs(hdP[k], penP[k]);
-			const u16x2 e = p_max(p_subs(EprevP[k], rdgapeP), p_subs(p_subs(HprevP[k], rdgapoP), vetoP[k]));
-			eP[k] = jl ? e : p_splat(0);
+	for (int k = 0; k < RP; k++) HP[k] = p_splat(0);
+	for (uint32_t c0 = 0; c0 < rows; c0 += 64) {
+		// the penalty tables of rows c0 .. c0+63, one per lane: byte b = penalty against reference character b
+		uint32_t tab = 0;
+		{
+			const uint32_t ri = c0 + (uint32_t)lane;
+			if (ri < rows) {
+				const int c = rd_char(g_hot, g_hot.len, fw, ri);
+				const int q = rd_qual(g_hot, g_hot.len, fw, ri) - 33;
+				const uint32_t mm = (uint32_t)(c > 3 ? P.n_pen : mm_penalty(P, q < 0 ? 0 : q)) & 0xffu;
+				tab = mm * 0x01010101u;
+				if (c <= 3) tab &= ~(0xffu << (8 * c));
+			}
 		}
-		// ---- the F / H chain down the rows ----
-		u16x2 HnewP[RP], FnewP[RP];
-		unsigned short fin_h = (unsigned short)upH, fin_f = (unsigned short)upF;
+		const uint32_t nrow = rows - c0 < 64u ? rows - c0 : 64u;
+		for (uint32_t ii = 0; ii < nrow; ii++) {
+			const uint32_t i = c0 + ii;
+			const uint32_t T1 = (uint32_t)__builtin_amdgcn_readlane((int)tab, (int)ii);
+			const bool bar = (int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar;       // no gaps this close to either end of the read
+			const u16x2 fvetoP = p_splat((bar || i == 0) ? 0xffff : 0);
+			// ---- diagonal and vertical predecessors ----
+			const uint32_t nxtH = dpp0<kDppWaveShl1, 0xf>(p_bits(Hp[0])), nxtF = dpp0<kDppWaveShl1, 0xf>(p_bits(Fp[0]));
+			u16x2 penP[RP], HupP[RP], FupP[RP], fP[RP], HdP[RP];
 #pragma unroll
-		for (int r = 0; r < 2 * RP; r++) {
-			const int k = r >> 1;
-			const unsigned short d = (r & 1) ? dP[k].y : dP[k].x, e = (r & 1) ? eP[k].y : eP[k].x;
-			unsigned short f = s_subs(s_max(s_subs(fin_f, rfgape), s_subs(fin_h, rfgapo)), veto[r]);
-			if (r == 0 && lane == 0) f = 0;
-			const unsigned short h = s_max(s_max(d, e), f);
-			if (r & 1) { HnewP[k].y = h; FnewP[k].y = f; } else { HnewP[k].x = h; FnewP[k].x = f; }
-			fin_h = h; fin_f = f;
-		}
-		if (active) {
+			for (int k = 0; k < RP; k++) {
+				penP[k] = p_from(__builtin_amdgcn_perm(npen_word, T1, refS[k]));
+				HupP[k] = p_from(shift_in(p_bits(Hp[k]), k + 1 < RP ? p_bits(Hp[k + 1 < RP ? k + 1 : 0]) : nxtH));
+				FupP[k] = p_from(shift_in(p_bits(Fp[k]), k + 1 < RP ? p_bits(Fp[k + 1 < RP ? k + 1 : 0]) : nxtF));
+				fP[k] = p_subs(p_max(p_subs(FupP[k], rfeP), p_subs(HupP[k], rfoP)), fvetoP);
+				HdP[k] = p_max(p_subs(Hp[k], penP[k]), fP[k]);
+			}
+			// ---- horizontal: E as a max-plus scan over the row ----
+			u16x2 EP[RP];
+			if (!bar) {
+				unsigned short e0[N2];
+				unsigned short carry = 0;
+#pragma unroll
+				for (int c = 0; c < N2; c++) {
+					const u16x2 u = p_subs(HdP[c >> 1], rdoP);
+					e0[c] = carry;
+					carry = s_max(s_subs(carry, (unsigned short)rdgape), (c & 1) ? u.y : u.x);
+				}
+				uint32_t X = carry;
+				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppRowShr + 1, 0xf>(X), d1));
+				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppRowShr + 2, 0xf>(X), d2));
+				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppRowShr + 4, 0xf>(X), d4));
+				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppRowShr + 8, 0xf>(X), d8));
+				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppBcast15, 0xa>(X), c15));
+				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppBcast31, 0xc>(X), c31));
+				const u16x2 einP = p_splat((int)dpp0<kDppWaveShr1, 0xf>(X));
+#pragma unroll
+				for (int k = 0; k < RP; k++) EP[k] = p_max(p_make(e0[2 * k], e0[2 * k + 1]), p_subs(einP, decP[k]));
+			} else {
+#pragma unroll
+				for (int k = 0; k < RP; k++) EP[k] = p_splat(0);
+			}
+#pragma unroll
+			for (int k = 0; k < RP; k++) HP[k] = p_max(HdP[k], EP[k]);
 			if (PRED) {
-				uint8_t* base = pm + ((uint64_t)t * R) * 64 + lane;       // pred_idx(): 64 consecutive bytes per (step, row-in-lane)
-				const u16x2 jmask = p_splat(jl ? 0x7f : 0x64);            // column 0 has no left / diagonal neighbour: HD, HE, EO, EE off
+				// left neighbours: the previous diagonal of this row
+				const uint32_t prvH = dpp0<kDppWaveShr1, 0xf>(p_bits(HP[RP - 1])), prvE = dpp0<kDppWaveShr1, 0xf>(p_bits(EP[RP - 1]));
+				const u16x2 gaP = p_splat(bar ? 0 : 1);
+				const u16x2 rdeP = p_splat(rdgape);
+				uint8_t* rowp = pm + (uint64_t)i * W + (uint32_t)dd0;
 #pragma unroll
 				for (int k = 0; k < RP; k++) {
-					const u16x2 h = HnewP[k], e = eP[k], f = FnewP[k];
-					const u16x2 huP = p_make(k == 0 ? (unsigned short)upH : HnewP[k > 0 ? k - 1 : 0].y, HnewP[k].x);     // H of the row above, same column
-					const u16x2 fuP = p_make(k == 0 ? (unsigned short)upF : FnewP[k > 0 ? k - 1 : 0].y, FnewP[k].x);
-					u16x2 up_ok = p_splat(1);
-					if (k == 0 && lane == 0) up_ok.x = 0;                   // read row 0 has no row above
-					u16x2 c = p_eq(h + penP[k], hdP[k]);                                     // PB_HD
-					c |= (p_eq(h, e) & gaP[k]) << 1;                                         // PB_HE
-					c |= (p_eq(h, f) & gaP[k]) << 2;                                         // PB_HF
-					c |= p_eq(e + rdgapoP, HprevP[k]) << 3;                                  // PB_EO
-					c |= p_eq(e + rdgapeP, EprevP[k]) << 4;                                  // PB_EE
-					c |= (p_eq(f + rfgapoP, huP) & up_ok) << 5;                              // PB_FO
-					c |= (p_eq(f + rfgapeP, fuP) & up_ok) << 6;                              // PB_FE
-					c &= jmask;
-					if (2 * k < R) base[(2 * k) * 64] = (uint8_t)c.x;
-					if (2 * k + 1 < R) base[(2 * k + 1) * 64] = (uint8_t)c.y;
+					const u16x2 hlP = p_from(shift_in(k > 0 ? p_bits(HP[k > 0 ? k - 1 : 0]) : prvH, p_bits(HP[k])));
+					const u16x2 elP = p_from(shift_in(k > 0 ? p_bits(EP[k > 0 ? k - 1 : 0]) : prvE, p_bits(EP[k])));
+					const u16x2 h = HP[k], e = EP[k], f = fP[k];
+					// bits of "differs": inverted at the end
+					u16x2 n = p_ne(h + penP[k], Hp[k]);                                      // PB_HD
+					n |= (p_ne(h, e) | (gaP ^ p_splat(1))) << 1;                             // PB_HE
+					n |= (p_ne(h, f) | (gaP ^ p_splat(1))) << 2;                             // PB_HF
+					n |= p_ne(e + rdoP, hlP) << 3;                                           // PB_EO
+					n |= p_ne(e + rdeP, elP) << 4;                                           // PB_EE
+					n |= p_ne(f + rfoP, HupP[k]) << 5;                                       // PB_FO
+					n |= p_ne(f + rfeP, FupP[k]) << 6;                                       // PB_FE
+					const u16x2 c = n ^ p_splat(0x7f);
+					*reinterpret_cast<uint16_t*>(rowp + 2 * k) = (uint16_t)(c.x | (c.y << 8));
 				}
 			}
-			const unsigned short hl_ = (last_r & 1) ? HnewP[last_r >> 1].y : HnewP[last_r >> 1].x;
-			if (lane_has_last) { best = imax(best, (int)hl_); if (PRED) g_hot.lastrow[j] = (int16_t)((int)hl_ - 0xff); }
+			// ---- next row ----
 #pragma unroll
-			for (int k = 0; k < RP; k++) { HprevP[k] = HnewP[k]; EprevP[k] = eP[k]; }
-			myHlast = (int)(((R - 1) & 1) ? HnewP[(R - 1) >> 1].y : HnewP[(R - 1) >> 1].x);
-			myFlast = (int)(((R - 1) & 1) ? FnewP[(R - 1) >> 1].y : FnewP[(R - 1) >> 1].x);
+			for (int k = 0; k < RP; k++) { Hp[k] = HP[k]; Fp[k] = fP[k]; }
+			if (!PRED && (i & 3u) == 3u) {
+				// scores only fall along a path (no match bonus end to end): once no cell of a row reaches minsc, no alignment will
+				u16x2 m = HP[0];
+#pragma unroll
+				for (int k = 1; k < RP; k++) m = p_max(m, HP[k]);
+				if (!__any((int)s_max(m.x, m.y) >= thr)) return 0;
+			}
+			{
+				int jc = jin < 0 ? 0 : jin; if (jc > (int)cols) jc = (int)cols;      // outside the window: any character will do (see above)
+				const uint32_t newel = (uint32_t)__builtin_ctz((uint32_t)g_hot.rf[jc] | 16u) | 0x0c00u;
+#pragma unroll
+				for (int k = 0; k < RP; k++) refS[k] = shift_in(refS[k], k + 1 < RP ? refS[k + 1 < RP ? k + 1 : 0] : newel);
+				jin++;
+			}
 		}
-		upHdiag = upH;
 	}
-	return __shfl(best, (int)((rows - 1) / R));
+	// HP = the last row: best score over the window's columns; the scores themselves go to HOT.lastrow for the candidate gather
+	int best = 0;
+	const int jl0 = (int)rows - 1 + j00;
+#pragma unroll
+	for (int k = 0; k < RP; k++) {
+#pragma unroll
+		for (int hh = 0; hh < 2; hh++) {
+			const int j = jl0 + 2 * k + hh;
+			const int h = hh ? (int)HP[k].y : (int)HP[k].x;
+			if ((uint32_t)j < cols) { best = imax(best, h); if (PRED) g_hot.lastrow[j] = (int16_t)(h - 0xff); }
+		}
+	}
+#pragma unroll
+	for (int s = 32; s > 0; s >>= 1) best = imax(best, __shfl_xor(best, s));
+	return best;
 }
 
 // The same recurrence in the reference's 16-bit representation (alignNucleotidesEnd2EndSseI16, aligner_swsse_ee_i16.cpp:780-1146):
@@ -384,13 +447,14 @@ struct DevPlat {
 	static __device__ __forceinline__ void set_epoch(uint32_t* p, uint32_t e) { if ((threadIdx.x & 63) == 0) *p = e; wave_fence(); }
 	// Tile of the pred format anchored at (row, col): lane d <- predecessor byte and (epoch-checked) mask of cell (row-d, col-d).
 	// One gather per plane: a single memory latency for up to 64 diagonal steps.
-	static __device__ __forceinline__ void bt_tile_pred(const DpScratch& dp, uint32_t rows, uint32_t row, uint32_t col, uint32_t epoch,
+	static __device__ __forceinline__ void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch,
 	                                                    uint32_t& pr, uint32_t& mk) {
 		wave_fence();        // mask stores of earlier steps -> visible to whichever lane re-reads them
 		const uint32_t d = threadIdx.x & 63;
 		uint32_t p = 0, m = 0;
-		if (d <= row && d <= col) {
-			const uint64_t idx = pred_idx(rows, row - d, col - d);
+		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo);      // the tile runs along one diagonal
+		if (d <= row && d <= col && dd < band_w) {
+			const uint64_t idx = (uint64_t)(row - d) * band_w + dd;
 			p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
 			const uint32_t w = dp.pmask[idx];
 			m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
@@ -596,33 +660,41 @@ struct DevPlat {
 		return total;
 	}
 	// returns the best last-row score (de-biased)
-	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide, int64_t minsc) {
+	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, const DpScratch& dp, bool wide, int64_t minsc) {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
+		uint32_t* mat = dp.mat;
 		int best;
 		if (!wide) {
 			uint8_t* pm = reinterpret_cast<uint8_t*>(mat);
+			EeBand band;
+			if (!ee_band(P.rfgapo, P.rfgape, rows, cols, minsc, band)) return -0xff;      // no cell can lie on an alignment that reaches minsc
+			const uint32_t rp = ee_band_rp(band.nd);
+			if (rp == 0) return INT64_MIN;
+			const int lo = band.lo;
+			const int thr = (int)(minsc + 0xff);      // biased score an alignment must keep (>= 1: the 8-bit kernel is only used while minsc >= -254)
 			// pass 1: can any end-to-end alignment in this window reach the minimum score at all?
-			switch (dp_R(rows)) {
-				case 1: best = fill_ee_u8_packed<1, false>(P, fw, rows, cols, pm); break;
-				case 2: best = fill_ee_u8_packed<2, false>(P, fw, rows, cols, pm); break;
-				case 3: best = fill_ee_u8_packed<3, false>(P, fw, rows, cols, pm); break;
-				case 4: best = fill_ee_u8_packed<4, false>(P, fw, rows, cols, pm); break;
-				case 5: best = fill_ee_u8_packed<5, false>(P, fw, rows, cols, pm); break;
-				case 6: best = fill_ee_u8_packed<6, false>(P, fw, rows, cols, pm); break;
-				case 7: best = fill_ee_u8_packed<7, false>(P, fw, rows, cols, pm); break;
-				default: best = fill_ee_u8_packed<8, false>(P, fw, rows, cols, pm); break;
+			switch (rp) {
+				case 1: best = fill_ee_u8_band<1, false>(P, fw, rows, cols, lo, thr, pm); break;
+				case 2: best = fill_ee_u8_band<2, false>(P, fw, rows, cols, lo, thr, pm); break;
+				case 3: best = fill_ee_u8_band<3, false>(P, fw, rows, cols, lo, thr, pm); break;
+				case 4: best = fill_ee_u8_band<4, false>(P, fw, rows, cols, lo, thr, pm); break;
+				case 6: best = fill_ee_u8_band<6, false>(P, fw, rows, cols, lo, thr, pm); break;
+				case 8: best = fill_ee_u8_band<8, false>(P, fw, rows, cols, lo, thr, pm); break;
+				case 12: best = fill_ee_u8_band<12, false>(P, fw, rows, cols, lo, thr, pm); break;
+				default: best = fill_ee_u8_band<16, false>(P, fw, rows, cols, lo, thr, pm); break;
 			}
 			if ((int64_t)best - 0xff < minsc) { wave_fence(); return (int64_t)best - 0xff; }
 			// pass 2: the matrix of predecessor bits (same scores, so `best` is unchanged)
-			switch (dp_R(rows)) {
-				case 1: best = fill_ee_u8_packed<1, true>(P, fw, rows, cols, pm); break;
-				case 2: best = fill_ee_u8_packed<2, true>(P, fw, rows, cols, pm); break;
-				case 3: best = fill_ee_u8_packed<3, true>(P, fw, rows, cols, pm); break;
-				case 4: best = fill_ee_u8_packed<4, true>(P, fw, rows, cols, pm); break;
-				case 5: best = fill_ee_u8_packed<5, true>(P, fw, rows, cols, pm); break;
-				case 6: best = fill_ee_u8_packed<6, true>(P, fw, rows, cols, pm); break;
-				case 7: best = fill_ee_u8_packed<7, true>(P, fw, rows, cols, pm); break;
-				default: best = fill_ee_u8_packed<8, true>(P, fw, rows, cols, pm); break;
+			if ((threadIdx.x & 63) == 0) { dp.epoch[1] = (uint32_t)lo; dp.epoch[2] = 128u * rp; }
+			switch (rp) {
+				case 1: best = fill_ee_u8_band<1, true>(P, fw, rows, cols, lo, thr, pm); break;
+				case 2: best = fill_ee_u8_band<2, true>(P, fw, rows, cols, lo, thr, pm); break;
+				case 3: best = fill_ee_u8_band<3, true>(P, fw, rows, cols, lo, thr, pm); break;
+				case 4: best = fill_ee_u8_band<4, true>(P, fw, rows, cols, lo, thr, pm); break;
+				case 6: best = fill_ee_u8_band<6, true>(P, fw, rows, cols, lo, thr, pm); break;
+				case 8: best = fill_ee_u8_band<8, true>(P, fw, rows, cols, lo, thr, pm); break;
+				case 12: best = fill_ee_u8_band<12, true>(P, fw, rows, cols, lo, thr, pm); break;
+				default: best = fill_ee_u8_band<16, true>(P, fw, rows, cols, lo, thr, pm); break;
 			}
 			best -= 0xff;
 		} else {
@@ -795,7 +867,7 @@ void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64
 	uint32_t cols = paired ? (uint32_t)kMaxCols + 4 : rows + 4 * maxhalf + 1 + 4;
 	if (cols > (uint32_t)kMaxCols + 4) cols = (uint32_t)kMaxCols + 4;
 	const uint32_t lanes = (rows + R - 1) / R;
-	// packed cells (16-bit end-to-end, local): 8 B per cell, wavefront-major; pred format (8-bit end-to-end): 1 B per cell, diagonal-major
+	// packed cells (16-bit end-to-end, local): 8 B per cell, wavefront-major; pred format (8-bit end-to-end): 1 B per cell of the band
 	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 8 + 255) & ~(uint64_t)255;
 	const uint64_t pred_bytes = (pred_cells(rows, cols) + 255) & ~(uint64_t)255;
 	if (pred_bytes > mat_bytes) mat_bytes = pred_bytes;

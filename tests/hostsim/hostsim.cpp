@@ -102,11 +102,12 @@ struct HostPlat {
 			lo.v[ln] = v; hi.v[ln] = vh;
 		}
 	}
-	static void bt_tile_pred(const DpScratch& dp, uint32_t rows, uint32_t row, uint32_t col, uint32_t epoch, LaneReg& pr, LaneReg& mk) {
+	static void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, LaneReg& pr, LaneReg& mk) {
+		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo);
 		for (uint32_t d = 0; d < 64; d++) {
 			uint32_t p = 0, m = 0;
-			if (d <= row && d <= col) {
-				const uint64_t idx = pred_idx(rows, row - d, col - d);
+			if (d <= row && d <= col && dd < band_w) {
+				const uint64_t idx = pred_idx(band_lo, band_w, row - d, col - d);
 				p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
 				const uint32_t w = dp.pmask[idx];
 				m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
@@ -192,10 +193,64 @@ struct HostPlat {
 		});
 		return total;
 	}
+	// 8-bit end-to-end, pred format: the band of diagonals a valid alignment can touch (EeBand), everything outside it "minus
+	// infinity" (0) -- the exactness argument is in bt2g_align.hpp; this scalar form is what the differential tests pin it with
+	static int64_t fill_ee_u8_band(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, const DpScratch& dp, int64_t minsc) {
+		EeBand band;
+		if (!ee_band(P.rfgapo, P.rfgape, rows, cols, minsc, band)) return -0xff;
+		const uint32_t rp = ee_band_rp(band.nd);
+		if (rp == 0) return INT64_MIN;
+		const int32_t lo = band.lo;
+		const uint32_t W = 128u * rp;
+		dp.epoch[1] = (uint32_t)lo; dp.epoch[2] = W;
+		uint8_t* pm = reinterpret_cast<uint8_t*>(dp.mat);
+		auto subs = [](int a, int b) { const int v = a - b; return v < 0 ? 0 : v; };
+		// previous / current row, indexed by column + 1 (index 0 = the column left of the window)
+		std::vector<int> Hp(cols + 2, 0), Fp(cols + 2, 0), Hc(cols + 2, 0), Ec(cols + 2, 0), Fc(cols + 2, 0);
+		for (uint32_t j = 0; j < cols; j++) g_hot.lastrow[j] = (int16_t)-0xff;
+		int lrmax = 0;
+		for (uint32_t i = 0; i < rows; i++) {
+			const bool veto = ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar);
+			const int rdc = rd_char(g_hot, g_hot.len, fw, i);
+			const int q = rd_qual(g_hot, g_hot.len, fw, i) - 33;
+			std::fill(Hc.begin(), Hc.end(), 0); std::fill(Ec.begin(), Ec.end(), 0); std::fill(Fc.begin(), Fc.end(), 0);
+			// columns of this row inside the band
+			const int64_t jlo = (int64_t)i - lo, jhi = (int64_t)i - lo + (int64_t)band.nd - 1;
+			for (int64_t jj = jlo < 0 ? 0 : jlo; jj <= jhi && jj < (int64_t)cols; jj++) {
+				const uint32_t j = (uint32_t)jj;
+				const int m = g_hot.rf[j];
+				int refc = 4;
+				for (int b = 0; b < 4; b++) if (m & (1 << b)) { refc = b; break; }
+				int pen;
+				if (rdc > 3 || refc > 3) pen = P.n_pen; else pen = (rdc == refc) ? 0 : mm_penalty(P, q < 0 ? 0 : q);
+				const int hdiag = (i == 0) ? 0xff : Hp[j];          // Hp[j] = H(i-1, j-1); column -1 and cells outside the band hold 0
+				const int hl = Hc[j], el = Ec[j];                   // (i, j-1)
+				const int hu = (i == 0) ? 0 : Hp[j + 1], fu = (i == 0) ? 0 : Fp[j + 1];
+				const int e = veto ? 0 : imax(subs(el, P.rdgape), subs(hl, P.rdgapo));
+				const int f = (i == 0 || veto) ? 0 : imax(subs(fu, P.rfgape), subs(hu, P.rfgapo));
+				const int h = imax(imax(subs(hdiag, pen), e), f);
+				const bool ga = !veto;
+				int c = (hdiag - pen == h) ? PB_HD : 0;
+				c |= (ga && h == e) ? PB_HE : 0;
+				c |= (ga && h == f) ? PB_HF : 0;
+				c |= (hl - P.rdgapo == e) ? PB_EO : 0;
+				c |= (el - P.rdgape == e) ? PB_EE : 0;
+				c |= (hu - P.rfgapo == f) ? PB_FO : 0;
+				c |= (fu - P.rfgape == f) ? PB_FE : 0;
+				pm[pred_idx(lo, W, i, j)] = (uint8_t)c;
+				Hc[j + 1] = h; Ec[j + 1] = e; Fc[j + 1] = f;
+				if (i == rows - 1) { g_hot.lastrow[j] = (int16_t)(h - 0xff); if (h > lrmax) lrmax = h; }
+			}
+			Hp.swap(Hc); Fp.swap(Fc);
+		}
+		return (int64_t)lrmax - 0xff;
+	}
 	// scalar fill of either representation; returns the best last-row score (de-biased)
-	static int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, bool wide, int64_t /*minsc: the device build skips the matrix of a problem that cannot reach it*/) {
+	static int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, const DpScratch& dp, bool wide, int64_t minsc) {
+		if (!wide) return fill_ee_u8_band(P, fw, rows, cols, dp, minsc);
+		uint32_t* mat = dp.mat;
 		const uint32_t R = dp_R(rows);
-		const int lo = wide ? -32768 : 0, hi = wide ? 0x7fff : 0xff;
+		const int lo = -32768, hi = 0x7fff;
 		auto subs = [&](int a, int b) { const int v = a - b; return v < lo ? lo : v; };
 		int lrmax = lo;
 		std::vector<int> Hp(rows, lo), Ep(rows, lo), Hc(rows), Ec(rows), Fc(rows);
@@ -215,21 +270,7 @@ struct HostPlat {
 				const int e = (j == 0) ? lo : imax(subs(Ep[i], P.rdgape), veto ? lo : subs(Hp[i], P.rdgapo));
 				f = (i == 0) ? lo : (veto ? lo : imax(subs(f, P.rfgape), subs(Hc[i - 1], P.rfgapo)));
 				const int h = imax(imax(subs(hdiag, pen), e), f);
-				if (wide) m64[dp_cell(R, i, j)] = (uint64_t)(uint16_t)h | ((uint64_t)(uint16_t)e << 16) | ((uint64_t)(uint16_t)f << 32);
-				else {
-					// 8-bit end-to-end: predecessor bits (PB_*), diagonal-major; last row -> HOT.lastrow
-					const bool jl = j > 0, ga = !veto, row0 = i == 0;
-					const int hl = Hp[i], el = Ep[i], hu = row0 ? 0 : Hc[i - 1], fu = row0 ? 0 : Fc[i - 1];
-					int c = (jl && hdiag - pen == h) ? PB_HD : 0;
-					c |= (ga && jl && h == e) ? PB_HE : 0;
-					c |= (ga && h == f) ? PB_HF : 0;
-					c |= (jl && hl - P.rdgapo == e) ? PB_EO : 0;
-					c |= (jl && el - P.rdgape == e) ? PB_EE : 0;
-					c |= (!row0 && hu - P.rfgapo == f) ? PB_FO : 0;
-					c |= (!row0 && fu - P.rfgape == f) ? PB_FE : 0;
-					reinterpret_cast<uint8_t*>(mat)[pred_idx(rows, i, j)] = (uint8_t)c;
-					if (i == rows - 1) g_hot.lastrow[j] = (int16_t)(h - hi);
-				}
+				m64[dp_cell(R, i, j)] = (uint64_t)(uint16_t)h | ((uint64_t)(uint16_t)e << 16) | ((uint64_t)(uint16_t)f << 32);
 				Hc[i] = h; Ec[i] = e; Fc[i] = f;
 			}
 			if (Hc[rows - 1] > lrmax) lrmax = Hc[rows - 1];
