@@ -122,7 +122,7 @@ struct SatPos {           // SATupleAndPos (aligner_sw_driver.h:144)
 struct SampRow { uint64_t topf; uint32_t src; uint32_t done; };
 
 // Random1toN of a sampled range, kept in LDS while prioritize() runs (same fields as R1N, narrower where the values allow)
-struct R1C { uint32_t n, cur, list_off, seen_off; uint16_t seen_len, thresh; uint8_t swaplist, converted, inited, pad; };
+struct R1C { uint64_t topf; uint32_t n, cur, list_off, seen_off; uint16_t seen_len, thresh; uint8_t swaplist, converted, inited, pad; };      // topf: first row of the range being sampled
 constexpr int kFastSamp = 64;      // ranges the on-chip sampler state holds
 
 struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };

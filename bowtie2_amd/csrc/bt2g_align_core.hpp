@@ -15,18 +15,21 @@ namespace bt2g {
 template <typename TOff, typename Plat>
 struct Aligner {
 #define HOT (Plat::hot())
+// The index descriptor, the parameter blocks and the batch pre-computation are objects in LDS that the platform hands out
+// by name (never through a member reference: an access through a generic pointer is a FLAT instruction, and the wait for a
+// FLAT load also waits for every global-memory store still in flight)
+#define PRM (Plat::params())                      // const AlignParams&
+#define RPR (Plat::rparams())                     // ReadParams& of the loaded read (paired-end mode swaps the mate's in)
+#define IX  (Plat::template index<TOff>())        // const DevIndex<TOff>&
+#define PRE (Plat::pre())                         // const PreComp*: batch pre-computation (may be null)
 	BT2_HD static uint64_t now() { return Plat::clock(); }
 
-	const DevIndex<TOff>& ix;
-	const AlignParams& P;
-	ReadParams& rp;      // per-read parameters of the loaded read (paired-end mode swaps the mate's in)
 	Work& w;
 	DpScratch dp;
 	Rng rnd;
 	int64_t minsc;       // current (possibly tightened) minimum score
 	static constexpr TOff kOffMask = (TOff)OffTraits<TOff>::kMask;
 
-	const PreComp* pre;  // batch pre-computation (may be null)
 	uint32_t ridx;       // index of this read in the batch
 	bool ext_pre;        // HOT.hits came from pre->seeds, so pre->ext holds their extensions
 	const uint32_t* pre_ext_cur = nullptr;    // extension / resolved-offset tables of the seed round in HOT.hits
@@ -36,9 +39,8 @@ struct Aligner {
 
 	uint8_t m_nofw, m_norc;   // --nofw / --norc as they apply to the loaded read (mate 2 of an --fr pair sees them swapped)
 
-	BT2_HD Aligner(const DevIndex<TOff>& ix_, const AlignParams& P_, ReadParams& rp_, Work& w_, DpScratch dp_,
-	               const PreComp* pre_ = nullptr, uint32_t ridx_ = 0)
-		: ix(ix_), P(P_), rp(rp_), w(w_), dp(dp_), pre(pre_), ridx(ridx_), ext_pre(false), m_nofw(P_.nofw != 0), m_norc(P_.norc != 0), cands_cur(w_.cands) {}
+	BT2_HD Aligner(Work& w_, DpScratch dp_, uint32_t ridx_ = 0)
+		: w(w_), dp(dp_), ridx(ridx_), ext_pre(false), m_nofw(PRM.nofw != 0), m_norc(PRM.norc != 0), cands_cur(w_.cands) {}
 
 	// a fixed-capacity buffer is full: flag the read (its result is not passed off as the reference's) and remember which site
 	// noticed first (result record field pad2: diagnostics only)
@@ -46,7 +48,7 @@ struct Aligner {
 
 	// exact_sweep() from the batch kernel's output
 	BT2_HD uint64_t exact_sweep_pre(uint32_t mine[2]) {
-		const bt2g_sweep_out& s = pre->sweep[ridx];
+		const bt2g_sweep_out& s = PRE->sweep[ridx];
 		uint64_t nelt = 0;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			mine[fwi] = s.mine[fwi];
@@ -54,7 +56,7 @@ struct Aligner {
 			h.top = h.bot = 0;
 			if (s.hit[fwi]) {
 				h.top = s.top[fwi]; h.bot = s.bot[fwi]; h.fw = fwi == 0 ? 1 : 0; h.has_edit = 0;
-				h.score = (int32_t)((int64_t)HOT.len * P.match_bonus);
+				h.score = (int32_t)((int64_t)HOT.len * PRM.match_bonus);
 				nelt += s.bot[fwi] - s.top[fwi];
 			}
 		}
@@ -63,13 +65,13 @@ struct Aligner {
 
 	// one_mm_search() from the batch kernel's output; false if a list overflowed
 	BT2_HD bool one_mm_pre(bool nofw, bool norc) {
-		const uint8_t* n = pre->mm1_n + (uint64_t)ridx * 4;
+		const uint8_t* n = PRE->mm1_n + (uint64_t)ridx * 4;
 		if ((!nofw && (n[0] == 255 || n[1] == 255)) || (!norc && (n[2] == 255 || n[3] == 255))) return false;
 		HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 		for (int k = 0; k < 4; k++) {
 			const bool fw = k < 2;
 			if ((fw && nofw) || (!fw && norc)) continue;
-			const Mm1Hit* src = pre->mm1 + ((uint64_t)ridx * 4 + k) * pre->mm1_cap;
+			const Mm1Hit* src = PRE->mm1 + ((uint64_t)ridx * 4 + k) * PRE->mm1_cap;
 			// the batch kernel searched with the read's original minimum score; the worker's may have been tightened since
 			for (uint32_t i = 0; i < n[k]; i++) if ((int64_t)src[i].score >= minsc) add_mm1(src[i], fw);
 		}
@@ -89,7 +91,7 @@ struct Aligner {
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
 			const bool skip = (fw && m_nofw) || (!fw && m_norc);
-			const bt2g_seed_hit* src = src_all + ((uint64_t)ridx * 2 + fwi) * pre->max_seeds;
+			const bt2g_seed_hit* src = src_all + ((uint64_t)ridx * 2 + fwi) * PRE->max_seeds;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				HotHit& h = HOT.hits[fwi][i];
 				HOT.sorted[fwi][i] = 0;
@@ -106,7 +108,7 @@ struct Aligner {
 	// ---- the reference's per-round seed cache (see struct CacheModel) ----
 	BT2_HD void cache_reset() {
 		CacheModel& c = HOT.cm;
-		const uint64_t bytes = (uint64_t)(P.seed_cache_mb > 0 ? P.seed_cache_mb : 20) * 1024 * 1024;
+		const uint64_t bytes = (uint64_t)(PRM.seed_cache_mb > 0 ? PRM.seed_cache_mb : 20) * 1024 * 1024;
 		c.pool_total = (uint32_t)((bytes + 16383) / 16384 + 1);       // Pool::Pool (ds.h:3078)
 		c.pool_used = 0; c.qn = c.ql = c.san = 0; c.sl = 0; c.nkeys = 0;
 	}
@@ -209,7 +211,7 @@ struct Aligner {
 
 	// SeedAligner::exactSweep (aligner_seed.cpp:856-970); returns nelt
 	BT2_HDN uint64_t exact_sweep(uint32_t mine_max, uint32_t mine[2]) {
-		const DevEbwt<TOff>& e = ix.fw;
+		const DevEbwt<TOff>& e = IX.fw;
 		const uint32_t len = HOT.len, ftab_len = e.ftab_chars;
 		uint64_t nelt = 0;
 		HOT.exact[0].top = HOT.exact[0].bot = 0;
@@ -265,7 +267,7 @@ struct Aligner {
 				if (nedit == 0 && bot > top) {
 					EEHit& h = HOT.exact[fwi];
 					h.top = top; h.bot = bot; h.fw = fw ? 1 : 0; h.has_edit = 0;
-					h.score = (int32_t)((int64_t)len * P.match_bonus);
+					h.score = (int32_t)((int64_t)len * PRM.match_bonus);
 					nelt += (uint64_t)(bot - top);
 				}
 			}
@@ -302,7 +304,7 @@ struct Aligner {
 			const bool fw = fwi == 0;
 			if ((fw && nofw) || (!fw && norc)) continue;
 			for (int ebwtfwi = 0; ebwtfwi < 2; ebwtfwi++) {
-				fm_one_mm_dir(ix, P, minsc, rp.nceil, rd, len, ns, fw, ebwtfwi == 0,   // minsc[mate] as tightened so far (bt2_search.cpp:3712)
+				fm_one_mm_dir(IX, PRM, minsc, RPR.nceil, rd, len, ns, fw, ebwtfwi == 0,   // minsc[mate] as tightened so far (bt2_search.cpp:3712)
 					[&](const Mm1Hit& m) { add_mm1(m, fw); }, cnt);
 			}
 		}
@@ -331,7 +333,7 @@ struct Aligner {
 		HOT.n_rank = 0;
 		uint32_t ninst = 0;
 		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i + offset;
-		const uint32_t fc = ix.fw.ftab_chars;
+		const uint32_t fc = IX.fw.ftab_chars;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
 			for (uint32_t i = 0; i < nseeds; i++) {
@@ -356,14 +358,14 @@ struct Aligner {
 						kf = (kf << 2) | (uint64_t)getc(L - fc + k);
 						kb = (kb << 2) | (uint64_t)getc(L - 1 - k);
 					}
-					topf = ftab_hi(ix.fw, kf); botf = ftab_lo(ix.fw, kf + 1);
+					topf = ftab_hi(IX.fw, kf); botf = ftab_lo(IX.fw, kf + 1);
 					if (botf <= topf) continue;
-					topb = ftab_hi(ix.bw, kb); botb = topb + (botf - topf);
+					topb = ftab_hi(IX.bw, kb); botb = topb + (botf - topf);
 					step = fc;
 				} else {
 					const int c = getc(L - 1);
-					topf = topb = ix.fw.fchr[c];
-					botf = botb = ix.fw.fchr[c + 1];
+					topf = topb = IX.fw.fchr[c];
+					botf = botb = IX.fw.fchr[c + 1];
 					if (botf <= topf) continue;
 					step = 1;
 				}
@@ -372,14 +374,14 @@ struct Aligner {
 					if (botf - topf > 1) {
 						TOff t[4], b[4];
 						HOT.n_bwops_seed++;
-						HOT.n_sides += rank4_pair(ix.fw, topf, botf, t, b);
+						HOT.n_sides += rank4_pair(IX.fw, topf, botf, t, b);
 						TOff tp = topb;
 						for (int j = 0; j < c; j++) tp += b[j] - t[j];
 						if (b[c] == t[c]) { ok = false; break; }
 						topf = t[c]; botf = b[c]; topb = tp; botb = tp + (b[c] - t[c]);
 					} else {
 						HOT.n_bwops_seed++;
-						const TOff t = lf1c(ix.fw, topf, c);
+						const TOff t = lf1c(IX.fw, topf, c);
 						if (t == kOffMask) { ok = false; break; }
 						topf = t; botf = t + 1;
 					}
@@ -410,7 +412,7 @@ struct Aligner {
 		HOT.n_rank = 0;
 		uint32_t ninst = 0, nsr = 0;
 		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i + offset;
-		const uint32_t fc = ix.fw.ftab_chars;
+		const uint32_t fc = IX.fw.ftab_chars;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
 			for (uint32_t i = 0; i < nseeds; i++) {
@@ -447,7 +449,7 @@ struct Aligner {
 					// maxjump: leading steps that stay in zone 0 (for the right-to-left seed the insertion zone changes at the same step)
 					uint32_t maxjump = 0;
 					while (maxjump < L && !zone1(maxjump)) maxjump++;
-					const DevEbwt<TOff>& e = ltr ? ix.bw : ix.fw;
+					const DevEbwt<TOff>& e = ltr ? IX.bw : IX.fw;
 					TOff topf = 0, botf = 0, topb = 0, botb = 0;
 					uint32_t step = 0;
 					if (fc > 1 && fc <= maxjump) {
@@ -457,19 +459,19 @@ struct Aligner {
 							kf = (kf << 2) | (uint64_t)getc(off + k);
 							kb = (kb << 2) | (uint64_t)getc(off + fc - 1 - k);
 						}
-						topf = ftab_hi(ix.fw, kf); botf = ftab_lo(ix.fw, kf + 1);
+						topf = ftab_hi(IX.fw, kf); botf = ftab_lo(IX.fw, kf + 1);
 						if (botf <= topf) continue;
-						topb = ftab_hi(ix.bw, kb); botb = topb + (botf - topf);
+						topb = ftab_hi(IX.bw, kb); botb = topb + (botf - topf);
 						step = fc;
 					} else if (maxjump > 0) {
 						const int c = getc(pos(0));
-						topf = topb = ix.fw.fchr[c];
-						botf = botb = ix.fw.fchr[c + 1];
+						topf = topb = IX.fw.fchr[c];
+						botf = botb = IX.fw.fchr[c + 1];
 						if (botf <= topf) continue;
 						step = 1;
 					} else {
 						topf = topb = 0;
-						botf = botb = ix.fw.fchr[4];
+						botf = botb = IX.fw.fchr[4];
 					}
 					if (step == L) { report(topf, botf, topb); continue; }
 					// exact continuation after the mismatch (the recursive searchSeedBi call: every zone is used up)
@@ -559,7 +561,7 @@ struct Aligner {
 	// SeedResults::rankSeedHits, all=false (aligner_seed.h:1019-1080)
 	BT2_HDN void rank_seed_hits() {
 		HOT.n_rank = 0;
-		if (P.all_hits) {
+		if (PRM.all_hits) {
 			// rankSeedHits(all = true): no random draws; offsets 1.. first (fw then rc), offset 0 last (aligner_seed.h:1020-1038)
 			auto push = [&](uint32_t i, bool fw) {
 				if (HOT.n_rank >= (uint32_t)kMaxRanges) { ovf(6); return; }
@@ -635,7 +637,7 @@ struct Aligner {
 		// seen-list mode (n >= 128)
 		// the seen list can never hold more entries than rows are drawn for one read (max_iters), however large the range:
 		// a 100 000-row repeat range has thresh = 10 000 but is asked for a few hundred rows at most
-		if (r.seen_len == 0 && r.cur == 0) { const uint32_t cap = (uint32_t)P.max_iters + 2; r.seen_off = lists_alloc(r.thresh + 1 < cap ? r.thresh + 1 : cap); }
+		if (r.seen_len == 0 && r.cur == 0) { const uint32_t cap = (uint32_t)PRM.max_iters + 2; r.seen_off = lists_alloc(r.thresh + 1 < cap ? r.thresh + 1 : cap); }
 		uint32_t* seen = w.lists + r.seen_off;
 		const uint32_t seen_sz = r.seen_len;
 		uint32_t rn = 0;
@@ -645,7 +647,7 @@ struct Aligner {
 			again = false;
 			for (uint32_t i = 0; i < seen_sz; i++) if (seen[i] == rn) { again = true; break; }
 		}
-		{ const uint32_t cap = (uint32_t)P.max_iters + 2; if (r.seen_len >= (r.thresh + 1 < cap ? r.thresh + 1 : cap)) { ovf(29); r.cur++; return rn; } }
+		{ const uint32_t cap = (uint32_t)PRM.max_iters + 2; if (r.seen_len >= (r.thresh + 1 < cap ? r.thresh + 1 : cap)) { ovf(29); r.cur++; return rn; } }
 		seen[r.seen_len++] = rn;
 		r.cur++;
 		if (r.seen_len >= r.thresh && r.cur < r.n) {
@@ -686,48 +688,46 @@ struct Aligner {
 		r.thresh = (uint16_t)(th > 0xffffu ? 0xffffu : th);      // only ever compared with seen_len <= max_iters
 		r.inited = 1;
 	}
-	BT2_HDN uint32_t r1c_next(R1C& r) {
-		if (r.cur == 0 && !r.converted) {
-			if (r.n == 1) { r.cur = 1; return 0; }
-			if (r.swaplist) { r.list_off = lists_alloc(r.n); Plat::iota_u32(w.lists + r.list_off, r.n); }
-		}
-		if (r.swaplist) {
+	BT2_HDN uint32_t r1c_next(uint32_t which) {
+		// The record is taken by index and worked on in registers (a reference parameter would make every field access a FLAT
+		// load, and a record left in LDS is re-read after every store to the lists); written back once.
+		R1C r = HOT.samp.r[which];
+		uint32_t* const lists = w.lists;
+		uint32_t ret;
+		const bool first = r.cur == 0 && !r.converted;
+		if (first && r.n == 1) { r.cur = 1; ret = 0; }
+		else if (r.swaplist) {
+			if (first) { r.list_off = lists_alloc(r.n); Plat::iota_u32(lists + r.list_off, r.n); }
 			const uint32_t rr = r.cur + (rnd.nextU32() % (r.n - r.cur));
-			uint32_t* l = w.lists + r.list_off;
-			const uint32_t a = l[r.cur], b = l[rr];
-			if (rr != r.cur) { l[r.cur] = b; l[rr] = a; }
+			uint32_t* l = lists + r.list_off;
+			const uint32_t a = gld(l + r.cur), b = gld(l + rr);
+			if (rr != r.cur) { gst(l + r.cur, b); gst(l + rr, a); }
 			r.cur++;
-			return b;
-		}
-		const uint32_t cap = (uint32_t)P.max_iters + 2, room = (uint32_t)r.thresh + 1 < cap ? (uint32_t)r.thresh + 1 : cap;
-		if (r.seen_len == 0 && r.cur == 0) r.seen_off = lists_alloc(room);
-		uint32_t* seen = w.lists + r.seen_off;
-		const uint32_t seen_sz = r.seen_len;
-		uint32_t rn;
-		do { rn = rnd.nextU32() % r.n; } while (Plat::contains_u32(seen, seen_sz, rn));
-		if (r.seen_len >= room) { ovf(29); r.cur++; return rn; }
-		seen[r.seen_len++] = rn;
-		r.cur++;
-		if (r.seen_len >= r.thresh && r.cur < r.n) {
-			// convert to a swap list of everything not yet seen (rare: a mid-sized range asked for >= thresh rows)
-			for (uint32_t i = 1; i < r.seen_len; i++) {
-				const uint32_t v = seen[i];
-				uint32_t j = i;
-				while (j > 0 && seen[j - 1] > v) { seen[j] = seen[j - 1]; j--; }
-				seen[j] = v;
+			ret = b;
+		} else {
+			const uint32_t cap = (uint32_t)PRM.max_iters + 2, room = (uint32_t)r.thresh + 1 < cap ? (uint32_t)r.thresh + 1 : cap;
+			if (r.seen_len == 0 && r.cur == 0) r.seen_off = lists_alloc(room);
+			uint32_t* seen = lists + r.seen_off;
+			const uint32_t seen_sz = r.seen_len;
+			uint32_t rn;
+			do { rn = rnd.nextU32() % r.n; } while (Plat::contains_u32(seen, seen_sz, rn));
+			ret = rn;
+			if (r.seen_len >= room) { ovf(29); r.cur++; }
+			else {
+				gst(seen + r.seen_len, rn); r.seen_len++;
+				r.cur++;
+				if (r.seen_len >= r.thresh && r.cur < r.n) {
+					// convert to a swap list of everything not yet seen, ascending (Random1toN::next, random_util.h:133-158).  Not
+					// rare on repeats: a 200-copy family hit by every seed of a read crosses thresh = 20 in each of its ranges.
+					const uint32_t nl = r.n - r.cur;
+					r.list_off = lists_alloc(nl);
+					Plat::unseen_list(seen, r.seen_len, r.n, lists + r.list_off);
+					r.seen_len = 0; r.cur = 0; r.n = nl; r.converted = 1; r.swaplist = 1;
+				}
 			}
-			const uint32_t nl = r.n - r.cur;
-			r.list_off = lists_alloc(nl);
-			uint32_t* l = w.lists + r.list_off;
-			uint32_t prev = 0, cur = 0;
-			for (uint32_t i = 0; i < seen_sz + 1; i++) {
-				for (uint32_t j = prev; j < seen[i]; j++) l[cur++] = j;
-				prev = seen[i] + 1;
-			}
-			for (uint32_t j = prev; j < r.n; j++) l[cur++] = j;
-			r.seen_len = 0; r.cur = 0; r.n = nl; r.converted = 1; r.swaplist = 1;
 		}
-		return rn;
+		HOT.samp.r[which] = r;
+		return ret;
 	}
 
 	// Entry i of the extension list for the consumer loops: whole records as they are, sampled rows expanded into w.sp_view
@@ -739,7 +739,7 @@ struct Aligner {
 		SatPos& s = w.sp_view;
 		Plat::copy_words(&s, &w.satpos2[sr.src], (uint32_t)(sizeof(SatPos) / 4));
 		s.topf = sr.topf; s.topb = (uint64_t)kOffMask; s.size = 1;
-		r1n_init(s.rnd, 1, P.all_hits != 0);
+		r1n_init(s.rnd, 1, PRM.all_hits != 0);
 		return s;
 	}
 	BT2_HD void satpos_commit(uint32_t i, const SatPos& sp) { if (i >= HOT.n_satpos_full) w.srows[i - HOT.n_satpos_full].done = r1n_done(sp.rnd) ? 1u : 0u; }
@@ -752,15 +752,15 @@ struct Aligner {
 	                       uint32_t& nlex, uint32_t& nrex) {
 		FmCount cnt; cnt.bwops = 0; cnt.sides = 0;
 		HotRd rd;
-		fm_extend_hit(ix, rd, HOT.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt, (P.do_extend & 2) == 0);
+		fm_extend_hit(IX, rd, HOT.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt, (PRM.do_extend & 2) == 0);
 		HOT.n_bwops_ext += cnt.bwops; HOT.n_sides += cnt.sides;
 #ifdef BT2G_CHECK_EXTEND_TEXT
 		// test builds: the text-comparison form the batch kernel uses for one-row hits must agree with the LF walk
 		if (botf - topf == 1) {
 			uint32_t st_ = 0, l2 = 0, r2 = 0;
-			const TOff jo = get_offset(ix.fw, topf, st_);
-			if ((uint64_t)jo < (uint64_t)ix.fw.len) {
-				fm_extend_hit_text(ix, rd, HOT.len, (uint64_t)jo, fw, off, len, l2, r2, (P.do_extend & 2) == 0);
+			const TOff jo = get_offset(IX.fw, topf, st_);
+			if ((uint64_t)jo < (uint64_t)IX.fw.len) {
+				fm_extend_hit_text(IX, rd, HOT.len, (uint64_t)jo, fw, off, len, l2, r2, (PRM.do_extend & 2) == 0);
 				if (l2 != nlex || r2 != nrex) { fprintf(stderr, "extend mismatch: LF %u/%u text %u/%u\n", nlex, nrex, l2, r2); abort(); }
 			}
 		}
@@ -797,7 +797,7 @@ struct Aligner {
 			s.topf = top; s.topb = (uint64_t)kOffMask; s.size = (uint32_t)width; s.orig_sz = (uint32_t)width;
 			s.fw = hit.fw; s.offidx = 0; s.rdoff = 0; s.seedlen = HOT.len; s.nlex = s.nrex = 0;
 			s.ee = ee_idx;
-			r1n_init(s.rnd, (uint32_t)width, P.all_hits != 0);
+			r1n_init(s.rnd, (uint32_t)width, PRM.all_hits != 0);
 			nelt_out += width;
 			if (nelt_out >= maxelt) done = true;
 		};
@@ -806,7 +806,7 @@ struct Aligner {
 			const uint64_t width = hit.bot - hit.top;
 			if (nelt_out + width > maxelt) {
 				const uint64_t trim = (nelt_out + width) - maxelt;
-				const uint64_t rn = (P.large_index ? rnd.nextU64() : (uint64_t)rnd.nextU32()) % width;
+				const uint64_t rn = (PRM.large_index ? rnd.nextU64() : (uint64_t)rnd.nextU32()) % width;
 				const uint64_t newwidth = width - trim;
 				if (hit.top + rn + newwidth > hit.bot) {
 					tops[0] = hit.top + rn; bots[0] = hit.bot;
@@ -822,7 +822,7 @@ struct Aligner {
 		};
 		if (tot > 0) {
 			bool fw_first = true;
-			const uint64_t rn = (P.large_index ? rnd.nextU64() : (uint64_t)rnd.nextU32()) % tot;
+			const uint64_t rn = (PRM.large_index ? rnd.nextU64() : (uint64_t)rnd.nextU32()) % tot;
 			if (rn >= szfw) fw_first = false;
 			for (int fwi = 0; fwi < 2 && !done; fwi++) {
 				const bool fw = ((fwi == 0) == fw_first);
@@ -876,7 +876,7 @@ struct Aligner {
 			const bool fw = HOT.rank_fw[i] != 0;
 			const uint32_t offidx = HOT.rank_offs[i];
 			const uint32_t rdoff = HOT.off_idx2off[offidx];
-			const uint32_t seedlen = rp.seedlen < (int32_t)HOT.len ? (uint32_t)rp.seedlen : HOT.len;
+			const uint32_t seedlen = RPR.seedlen < (int32_t)HOT.len ? (uint32_t)RPR.seedlen : HOT.len;
 			const HotHit& h = HOT.hits[fw ? 0 : 1][offidx];
 			const uint32_t nr_here = seedmms > 0 ? (uint32_t)h.topb : 1u;      // ca.queryQval: one SATuple per reference string
 			for (uint32_t ri = 0; ri < nr_here; ri++) {
@@ -885,7 +885,7 @@ struct Aligner {
 			else if (sz == 0) continue;
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
-				const bool m2 = P.paired && HOT.pe.cur == 1;     // seedExRangeFw_[matei] / seedExRangeRc_[matei]
+				const bool m2 = PRM.paired && HOT.pe.cur == 1;     // seedExRangeFw_[matei] / seedExRangeRc_[matei]
 				const Work::ExtRange* range = m2 ? (fw ? w.ex_fw2 : w.ex_rc2) : (fw ? w.ex_fw : w.ex_rc);
 				const uint32_t nr = m2 ? (fw ? HOT.pe.n_ex_fw2 : HOT.pe.n_ex_rc2) : (fw ? HOT.n_ex_fw : HOT.n_ex_rc);
 				bool skip = false;
@@ -902,16 +902,16 @@ struct Aligner {
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
 			uint32_t nlex = 0, nrex = 0;
-			if (P.do_extend) {
+			if (PRM.do_extend) {
 				if (ext_pre && seedmms == 0 && h.esize == h.size) {      // (a range the cache cut short is extended as the shorter range)
-					const uint32_t e = pre_ext_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + offidx];
+					const uint32_t e = pre_ext_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + offidx];
 					nlex = e & 0xffffu; nrex = e >> 16;
 				} else extend_hit((TOff)h_topf, (TOff)(h_topf + sz), (TOff)h_topb, (TOff)(h_topb + sz), fw, rdoff, seedlen, nlex, nrex);
 			}
 			s.nlex = nlex; s.nrex = nrex;
 			HOT.n_ext_left += nlex; HOT.n_ext_right += nrex;
 			if (seedmms == 0 && (nlex > 0 || nrex > 0)) {
-				const bool m2 = P.paired && HOT.pe.cur == 1;
+				const bool m2 = PRM.paired && HOT.pe.cur == 1;
 				Work::ExtRange* range = m2 ? (fw ? w.ex_fw2 : w.ex_rc2) : (fw ? w.ex_fw : w.ex_rc);
 				uint32_t& nr = m2 ? (fw ? HOT.pe.n_ex_fw2 : HOT.pe.n_ex_rc2) : (fw ? HOT.n_ex_fw : HOT.n_ex_rc);
 				if (nr < (uint32_t)(kMaxRanges * 2)) {
@@ -940,7 +940,7 @@ struct Aligner {
 				w.satpos2[j] = v;
 			}
 		}
-		if (P.det_seeds) {
+		if (PRM.det_seeds) {
 			// prioritizeSATupsIdxs (aligner_sw_driver.cpp:741-866): every range in sorted order until maxelt elements are in
 			uint64_t added = 0;
 			for (uint32_t j = 0; j < HOT.n_satpos2 && added < maxelt; j++) {
@@ -960,7 +960,7 @@ struct Aligner {
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(12); break; }
 			SatPos& s = w.satpos[HOT.n_satpos++];
 			s = w.satpos2[j];
-			r1n_init(s.rnd, s.size, P.all_hits != 0);
+			r1n_init(s.rnd, s.size, PRM.all_hits != 0);
 			nelt_added += s.size;
 		}
 		HOT.n_satpos_full = HOT.n_resolved = HOT.n_satpos;
@@ -982,7 +982,7 @@ struct Aligner {
 		// in play on chip: the sums are formed by the same left-to-right additions as RowSampler::next's scan, so "first index
 		// whose running sum exceeds rd" is the same index -- found by all lanes at once instead of a chain of dependent loads.
 		const bool fast = HOT.n_masses <= (uint32_t)kFastSamp;
-		if (fast) for (uint32_t j = 0; j < HOT.n_masses; j++) { R1C& r = HOT.samp.r[j]; r.n = r.cur = 0; r.swaplist = r.converted = r.inited = 0; r.seen_len = 0; r.thresh = 0; r.list_off = r.seen_off = 0; }
+		if (fast) for (uint32_t j = 0; j < HOT.n_masses; j++) { R1C& r = HOT.samp.r[j]; r.topf = 0; r.n = r.cur = 0; r.swaplist = r.converted = r.inited = 0; r.seen_len = 0; r.thresh = 0; r.list_off = r.seen_off = 0; }
 		auto rebuild = [&]() {
 			double acc = 0.0;
 			for (uint32_t i = 0; i < HOT.n_masses; i++) { if (!w.elim[i]) acc += w.masses[i]; HOT.samp.prefix[i] = acc; HOT.samp.elim[i] = w.elim[i]; }
@@ -1009,25 +1009,28 @@ struct Aligner {
 			const uint32_t ri = pick + sai;
 			uint32_t r;
 			bool exhausted;
+			uint64_t row_topf;
 			if (fast) {
 				R1C& r2 = HOT.samp.r[pick];
-				if (!r2.inited) r1c_init(r2, w.satpos2[ri].size, P.all_hits != 0);
+				if (!r2.inited) { r1c_init(r2, w.satpos2[ri].size, PRM.all_hits != 0); r2.topf = w.satpos2[ri].topf; }
 				const uint64_t tn_ = now();
 				HOT.t_phase[21] += r2.swaplist ? 1ull : (1ull | (1ull << 32));      // profile: draws | draws on the seen-list path << 32
-				r = r1c_next(r2);
+				r = r1c_next(pick);
 				HOT.t_phase[20] += now() - tn_;      // profile: Random1toN::next
 				exhausted = r2.n > 0 && r2.cur >= r2.n;
+				row_topf = r2.topf;
 			} else {
 				R1N& r2 = w.rands2[ri];
-				if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, P.all_hits != 0);
+				if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, PRM.all_hits != 0);
 				r = r1n_next(r2);
 				exhausted = r1n_done(r2);
+				row_topf = w.satpos2[ri].topf;
 			}
 			if (exhausted) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; if (fast) rebuild(); }
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(13); break; }
-			SampRow& sr = w.srows[HOT.n_satpos - HOT.n_satpos_full];
+			SampRow* const sr = &w.srows[HOT.n_satpos - HOT.n_satpos_full];
 			HOT.n_satpos++;
-			sr.topf = w.satpos2[ri].topf + r; sr.src = ri; sr.done = 0;
+			gst(&sr->topf, (uint64_t)(row_topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
 			nelt_added++;
 		}
 		HOT.t_phase[18] += now() - ts_;       // profile: the row-sampling loop
@@ -1130,8 +1133,8 @@ struct Aligner {
 		HOT.n_alns++;
 		if (!HOT.done_unpair1) {
 			// ReportingState::areDone
-			if (P.mhits <= 0 && !P.all_hits && HOT.n_alns >= (uint32_t)P.khits) { HOT.done_unpair1 = 1; HOT.exit_k = 1; }
-			else if (P.mhits > 0 && HOT.n_alns > (uint32_t)P.mhits) { HOT.done_unpair1 = 1; HOT.exit_m = 1; }
+			if (PRM.mhits <= 0 && !PRM.all_hits && HOT.n_alns >= (uint32_t)PRM.khits) { HOT.done_unpair1 = 1; HOT.exit_k = 1; }
+			else if (PRM.mhits > 0 && HOT.n_alns > (uint32_t)PRM.mhits) { HOT.done_unpair1 = 1; HOT.exit_m = 1; }
 		}
 		const int64_t score = r.score;
 		if (score > HOT.best_unp1) { HOT.best2_unp1 = HOT.best_unp1; HOT.best_unp1 = score; }
@@ -1143,7 +1146,7 @@ struct Aligner {
 	// E. DP: reference window, fill, gather, backtrace
 	// =================================================================================
 	// SwAligner::initRef (aligner_sw.cpp:155-271): masks for [rect.refl, rect.refr+1], overhang = N
-	BT2_HD void fetch_ref_window(uint64_t tidx, int64_t rfi, uint32_t count) { Plat::fetch_ref(ix.ref, w, tidx, rfi, count); }
+	BT2_HD void fetch_ref_window(uint64_t tidx, int64_t rfi, uint32_t count) { Plat::fetch_ref(IX.ref, w, tidx, rfi, count); }
 
 	// packed cell (H | E<<8 | F<<16)
 	BT2_HD uint32_t cell_get(uint32_t R, uint32_t i, uint32_t j) const { return dp.mat[dp_cell(R, i, j)]; }
@@ -1165,7 +1168,7 @@ struct Aligner {
 		} else {
 			// gatherCellsNucleotidesLocalSseU8/I16 (aligner_swsse_loc_u8.cpp:1389-1496): every cell with score >= minsc, at or
 			// below the first row that can reach minsc, that is a match whose diagonal successor is not; columns <= lastsolcol
-			const int64_t bonus = P.match_bonus;
+			const int64_t bonus = PRM.match_bonus;
 			const uint32_t minrow = (uint32_t)(((minsc_dp + bonus - 1) / bonus) - 1);
 			nc = Plat::gather_local(dp.mat, cand_list(), (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow, w.cand_hist);
 		}
@@ -1200,9 +1203,9 @@ struct Aligner {
 		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
 		uint32_t row = Plat::uni(row_), col = Plat::uni(col_);
 		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
-		S.gapbar = Plat::uni(P.gapbar); S.rdgapo = Plat::uni(P.rdgapo); S.rdgape = Plat::uni(P.rdgape);
-		S.rfgapo = Plat::uni(P.rfgapo); S.rfgape = Plat::uni(P.rfgape); S.match_bonus = Plat::uni(P.match_bonus);
-		S.mm_type = Plat::uni(P.mm_type); S.mm_max = Plat::uni(P.mm_max); S.mm_min = Plat::uni(P.mm_min); S.n_pen = Plat::uni(P.n_pen);
+		S.gapbar = Plat::uni(PRM.gapbar); S.rdgapo = Plat::uni(PRM.rdgapo); S.rdgape = Plat::uni(PRM.rdgape);
+		S.rfgapo = Plat::uni(PRM.rfgapo); S.rfgape = Plat::uni(PRM.rfgape); S.match_bonus = Plat::uni(PRM.match_bonus);
+		S.mm_type = Plat::uni(PRM.mm_type); S.mm_max = Plat::uni(PRM.mm_max); S.mm_min = Plat::uni(PRM.mm_min); S.n_pen = Plat::uni(PRM.n_pen);
 		const int r_triml = (int)Plat::uni(rect.triml), r_corel = (int)Plat::uni(rect.corel), r_corer = (int)Plat::uni(rect.corer);
 		const uint32_t R = dp_R(rows);
 		// `this` lives in private memory: read what the loop needs once, into scalar registers
@@ -1432,7 +1435,7 @@ struct Aligner {
 			} else score += S.match_bonus;
 			if (m == -1) ns++;
 		}
-		if (ns > rp.nceil) return false;
+		if (ns > RPR.nceil) return false;
 		// res.reverse(), while copying the edits out of LDS
 		for (uint32_t i = 0; i < nned; i++) res.ned[i] = ned[nned - 1 - i];
 		res.nned = (uint16_t)nned;
@@ -1578,24 +1581,24 @@ struct Aligner {
 		const uint32_t len = HOT.len;
 		const int64_t rfi = refoff, rff = refoff + (int64_t)len;
 		// overhanging ends are only scored (as Ns) with --overhang, and count against the N ceiling (aligner_sw.cpp:306-325)
-		if ((rfi < 0 || rff > reflen) && !P.overhang) return 0;
-		if ((rfi < 0 ? -rfi : 0) + (rff > reflen ? rff - reflen : 0) > (int64_t)rp.nceil) return 0;
+		if ((rfi < 0 || rff > reflen) && !PRM.overhang) return 0;
+		if ((rfi < 0 ? -rfi : 0) + (rff > reflen ? rff - reflen : 0) > (int64_t)RPR.nceil) return 0;
 		int64_t score = 0;
 		int ns = 0;
-		Plat::fetch_ref_codes(ix.ref, tidx, rfi, len);   // codes here, not masks
+		Plat::fetch_ref_codes(IX.ref, tidx, rfi, len);   // codes here, not masks
 		uint32_t rowi = 0, rowf = len - 1;
 		auto step = [&](uint32_t i) {
 			const int rdc = rd_char(HOT, HOT.len, fw, i);
 			const int rfc = HOT.rf[i];
 			const int q = rd_qual(HOT, HOT.len, fw, i) - 33;
-			if (rdc > 3 || rfc > 3) { ns++; score -= P.n_pen; }
-			else if (rdc == rfc) score += P.match_bonus;
-			else score -= mm_penalty(P, q < 0 ? 0 : q);
+			if (rdc > 3 || rfc > 3) { ns++; score -= PRM.n_pen; }
+			else if (rdc == rfc) score += PRM.match_bonus;
+			else score -= mm_penalty(PRM, q < 0 ? 0 : q);
 		};
-		if (P.match_bonus == 0) {
+		if (PRM.match_bonus == 0) {
 			for (uint32_t i = 0; i < len; i++) {
 				step(i);
-				if (score < minsc || ns > rp.nceil) return 0;
+				if (score < minsc || ns > RPR.nceil) return 0;
 			}
 		} else {
 			// local flavour (aligner_sw.cpp:400-436): best-scoring stretch of the diagonal; more than one -> leave it to the DP
@@ -1610,7 +1613,7 @@ struct Aligner {
 				}
 				if (score <= 0) { score = 0; lastfloor = i + 1; }
 			}
-			if (ns > rp.nceil || score_max < minsc) return 0;
+			if (ns > RPR.nceil || score_max < minsc) return 0;
 			if (sols > 1) return -1;
 			score = score_max;
 		}
@@ -1641,7 +1644,7 @@ struct Aligner {
 	BT2_HDN int extend_seeds(int seedmms, int seedlen, int seedival) {
 		(void)seedlen; (void)seedival;
 		const uint32_t rdlen = HOT.len;
-		const int64_t perfect = (int64_t)rdlen * P.match_bonus;       // Scoring::perfectScore: 0 end to end
+		const int64_t perfect = (int64_t)rdlen * PRM.match_bonus;       // Scoring::perfectScore: 0 end to end
 		const uint32_t nsm = 5;
 		const uint32_t nonz = HOT.nonz_tot;
 		const uint64_t ee_hits = (HOT.exact[0].bot - HOT.exact[0].top) + (HOT.exact[1].bot - HOT.exact[1].top) + HOT.mm1_elt;
@@ -1650,7 +1653,7 @@ struct Aligner {
 		HOT.n_ee_fail = HOT.n_ug_fail = HOT.n_dp_fail = 0;
 		uint64_t nelt = 0, nelt_left = 0;
 		const uint32_t rows = rdlen;
-		const uint32_t max_iters = (uint32_t)P.max_iters;
+		const uint32_t max_iters = (uint32_t)PRM.max_iters;
 		AlnRes& res = w.res;
 		while (true) {
 			if (ee_mode) {
@@ -1677,7 +1680,7 @@ struct Aligner {
 				SatPos& sp = satpos_view(i);
 				const EEHit* eh = ee_mode ? &ee_hit(sp.ee) : nullptr;
 				if (ee_mode && eh->score < minsc) return EXT_PERFECT_SCORE;
-				const bool is_small = P.det_seeds ? true : sp.size < nsm;
+				const bool is_small = PRM.det_seeds ? true : sp.size < nsm;
 				const bool fw = sp.fw != 0;
 				uint32_t rdoff = sp.rdoff;
 				const uint32_t seedhitlen = sp.seedlen;
@@ -1689,8 +1692,8 @@ struct Aligner {
 					} else if (ee_mode && eh->score < minsc) {
 						break;
 					}
-					if (HOT.n_ex_dps >= (uint32_t)P.max_dp) return EXT_HARD_LIMIT;
-					if (HOT.n_ex_ugs >= (uint32_t)P.max_ug) return EXT_HARD_LIMIT;
+					if (HOT.n_ex_dps >= (uint32_t)PRM.max_dp) return EXT_HARD_LIMIT;
+					if (HOT.n_ex_ugs >= (uint32_t)PRM.max_ug) return EXT_HARD_LIMIT;
 					if (HOT.n_ex_iters >= max_iters) return EXT_HARD_LIMIT;
 					HOT.n_ex_iters++;
 					first = false;
@@ -1702,34 +1705,34 @@ struct Aligner {
 					uint64_t jc = kJoffNone;
 					// a one-row hit of the pre-computed seed round was resolved by the batch kernel that extended it
 					if (!ee_mode && ext_pre && seedmms == 0 && sp.orig_sz == 1 && pre_joff_cur)
-						jc = pre_joff_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * pre->max_seeds + sp.offidx];
+						jc = pre_joff_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + sp.offidx];
 					if (jc == kJoffNone && !ee_mode && i >= HOT.n_satpos_full) {
 						// a sampled row: the walks to the SA sample of this row and the next 63 run side by side, one per lane
 						// (the extension loop takes the rows in list order, so the look-ahead is rarely wasted)
 						if (i >= HOT.n_resolved) {
 							const uint32_t k0 = i - HOT.n_satpos_full, cnt = HOT.n_satpos - i < 64u ? HOT.n_satpos - i : 64u;
-							Plat::resolve_rows(ix.fw, &w.srows[k0], cnt, &w.srow_joff[k0]);
+							Plat::resolve_rows(IX.fw, &w.srows[k0], cnt, &w.srow_joff[k0]);
 							HOT.n_resolved = i + cnt;
 						}
 						jc = w.srow_joff[i - HOT.n_satpos_full];
 						if (jc != kJoffNone) HOT.n_sides += (uint32_t)(jc >> 48);
 					}
 					if (jc != kJoffNone) { joff = (TOff)(jc & 0xffffffffffffull); steps = (uint32_t)(jc >> 48); }
-					else { joff = Plat::get_offset(ix.fw, (TOff)(sp.topf + elt), steps); HOT.n_sides += steps; }
+					else { joff = Plat::get_offset(IX.fw, (TOff)(sp.topf + elt), steps); HOT.n_sides += steps; }
 					HOT.t_phase[4] += now() - tr_;
 					HOT.n_bwops_ext += steps; HOT.n_resolve_steps += steps;
 					if (!ee_mode) nelt_left--;
 					TOff tidx = 0, toff = 0, tlen = 0;
 					bool straddled = false;
-					joined_to_text_off(ix, (TOff)seedhitlen, joff, tidx, toff, tlen, ee_mode, straddled);
+					joined_to_text_off(IX, (TOff)seedhitlen, joff, tidx, toff, tlen, ee_mode, straddled);
 					if (tidx == kOffMask) continue;
 					const int64_t refoff = (int64_t)toff - (int64_t)rdoff;
 					if (diag_present((int32_t)tidx, refoff, fw)) { HOT.n_redundants++; continue; }
 					int read_gaps = 0, ref_gaps = 0;
 					bool ungapped = false;
 					if (!ee_mode) {
-						read_gaps = max_read_gaps(P, minsc, rdlen);
-						ref_gaps = max_ref_gaps(P, minsc, rdlen);
+						read_gaps = max_read_gaps(PRM, minsc, rdlen);
+						ref_gaps = max_ref_gaps(PRM, minsc, rdlen);
 						ungapped = (read_gaps == 0 && ref_gaps == 0);
 					}
 					int state = 0;   // 0 none, 1 ee, 2 ungapped
@@ -1761,7 +1764,7 @@ struct Aligner {
 						res.refns = (uint16_t)hrefns;
 						state = 1; found = true;
 						diag_add((int32_t)tidx, refoff, fw, 1);
-					} else if (P.do_ungapped && ungapped) {
+					} else if (PRM.do_ungapped && ungapped) {
 						const uint64_t tu_ = now();
 						const int al = ungapped_align(fw, tidx, refoff, (int64_t)tlen, res);
 						HOT.t_phase[10] += now() - tu_;
@@ -1769,12 +1772,12 @@ struct Aligner {
 						HOT.n_ex_ugs++;
 						if (al == 0) {
 							HOT.n_ug_fail++;
-							if (HOT.n_ug_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
+							if (HOT.n_ug_fail >= (uint32_t)PRM.max_dp_streak) return EXT_SOFT_LIMIT;
 							continue;
 						}
 						if (al == -1) {           // several equally good stretches on this diagonal: count a failure, let the DP decide (:1250-1256)
 							HOT.n_ug_fail++;
-							if (HOT.n_ug_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
+							if (HOT.n_ug_fail >= (uint32_t)PRM.max_dp_streak) return EXT_SOFT_LIMIT;
 						} else {
 							HOT.n_ug_fail = 0;
 							found = true; state = 2;
@@ -1783,13 +1786,13 @@ struct Aligner {
 					if (state == 0) {
 						// DynProgFramer::frameSeedExtensionRect (dp_framer.cpp:81-129), trimToRef
 						uint32_t maxgap = (uint32_t)imax(read_gaps, ref_gaps);
-						if (maxgap > (uint32_t)P.maxhalf) maxgap = (uint32_t)P.maxhalf;
+						if (maxgap > (uint32_t)PRM.maxhalf) maxgap = (uint32_t)PRM.maxhalf;
 						const int64_t refl = refoff - 2 * (int64_t)maxgap;
 						const int64_t refr = refoff + ((int64_t)rows - 1) + 2 * (int64_t)maxgap;
 						uint64_t triml = 0, trimr = 0;
 						// trimToRef_ = !gReportOverhangs; otherwise up to nceil columns of N past either end stay in the window
 						int64_t maxns = 0;
-						if (P.overhang) { maxns = rp.nceil; if (maxns == (int64_t)rows) maxns--; }
+						if (PRM.overhang) { maxns = RPR.nceil; if (maxns == (int64_t)rows) maxns--; }
 						if (refr >= (int64_t)tlen + maxns) trimr = (uint64_t)(refr - ((int64_t)tlen + maxns - 1));
 						if (refl < -maxns) triml = (uint64_t)(-refl) - (uint64_t)maxns;
 						rect.refl_pretrim = refl; rect.refr_pretrim = refr;
@@ -1808,15 +1811,15 @@ struct Aligner {
 						const uint64_t td_ = now();
 						fetch_ref_window(tidx, rect.refl, cols + 1);
 						int64_t best;
-						if (P.match_bonus > 0) {
+						if (PRM.match_bonus > 0) {
 							mode = 2;
 							uint32_t sat8 = 0;
-							best = Plat::dp_fill_local(P, w, fw, rows, cols, dp.mat, minsc, lastsolcol, sat8);
+							best = Plat::dp_fill_local(PRM, w, fw, rows, cols, dp.mat, minsc, lastsolcol, sat8);
 							sse16 = sat8 != 0;
 						} else {
 							mode = minsc < -254 ? 1 : 0;
 							sse16 = mode == 1;
-							best = Plat::dp_fill_ee(P, w, fw, rows, cols, dp, mode != 0, minsc);
+							best = Plat::dp_fill_ee(PRM, w, fw, rows, cols, dp, mode != 0, minsc);
 							if (best == INT64_MIN) { ovf(30); return EXT_HARD_LIMIT; }
 						}
 						HOT.t_phase[5] += now() - td_;
@@ -1825,7 +1828,7 @@ struct Aligner {
 						if (found) { const uint64_t tg_ = now(); gather_cells(fw, rows, cols, minsc, mode, lastsolcol); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
 						if (!found) {
 							HOT.n_dp_fail++;
-							if (HOT.n_dp_fail >= (uint32_t)P.max_dp_streak) return EXT_SOFT_LIMIT;
+							if (HOT.n_dp_fail >= (uint32_t)PRM.max_dp_streak) return EXT_SOFT_LIMIT;
 							continue;
 						}
 						if (HOT.n_dp_fail > HOT.n_dp_fail_streak) HOT.n_dp_fail_streak = HOT.n_dp_fail;
@@ -1846,7 +1849,7 @@ struct Aligner {
 						const uint64_t tp_ = now();
 						struct PostTimer { uint64_t t0; uint64_t& acc; BT2_HD ~PostTimer() { acc += Plat::clock() - t0; } } post_timer_{tp_, HOT.t_phase[9]};
 						// --overhang: soft-clip what hangs off either end (aligner_sw_driver.cpp:1396-1403)
-						if (P.overhang && (res.refoff < 0 || res.refoff + (int64_t)res.rfextent > (int64_t)tlen)) {
+						if (PRM.overhang && (res.refoff < 0 || res.refoff + (int64_t)res.rfextent > (int64_t)tlen)) {
 							clip_outside(res, 0, (int64_t)tlen);
 							if (res.rfextent == 0) continue;
 						}
@@ -1860,13 +1863,13 @@ struct Aligner {
 						if (red_overlap(res)) continue;
 						red_add(res);
 						{ const uint64_t t1_ = now(); const bool sr_ = sink_report(res); HOT.t_phase[19] += now() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
-						if (P.tighten > 0 && P.mhits > 0 && HOT.best2_unp1 != INT64_MIN) {
-							if (P.tighten == 1) {
+						if (PRM.tighten > 0 && PRM.mhits > 0 && HOT.best2_unp1 != INT64_MIN) {
+							if (PRM.tighten == 1) {
 								if (HOT.best_unp1 >= minsc) {
 									minsc = HOT.best_unp1;
 									if (minsc < perfect && HOT.best_unp1 == HOT.best2_unp1) minsc++;
 								}
-							} else if (P.tighten == 2) {
+							} else if (PRM.tighten == 2) {
 								if (HOT.best2_unp1 >= minsc) { minsc = HOT.best2_unp1; if (minsc < perfect) minsc++; }
 							} else {
 								const int64_t diff = HOT.best_unp1 - HOT.best2_unp1;
@@ -1878,7 +1881,7 @@ struct Aligner {
 				}
 				satpos_commit(i, sp);
 			}
-			if (P.det_seeds) break;      // useCurrIdx: always one pass (aligner_sw_driver.cpp:1490)
+			if (PRM.det_seeds) break;      // useCurrIdx: always one pass (aligner_sw_driver.cpp:1490)
 		}
 		return EXT_EXHAUSTED;
 	}
@@ -1903,18 +1906,18 @@ struct Aligner {
 		const uint64_t t_run0_ = now();
 		HOT.n_mm1 = 0; HOT.mm1_elt = 0; HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_offs = 0; HOT.num_elts = 0;
 		HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
-		minsc = rp.minsc;
-		const bool filt = (rp.filt & 15u) == 15u;
+		minsc = RPR.minsc;
+		const bool filt = (RPR.filt & 15u) == 15u;
 		bool done = !filt;
-		const int64_t perfect = (int64_t)len * P.match_bonus;
+		const int64_t perfect = (int64_t)len * PRM.match_bonus;
 		if (!done) {
-			rnd.init(rp.seed);
-			const uint32_t interval = (uint32_t)rp.interval;
-			uint32_t nrounds = (uint32_t)P.n_seed_rounds;
+			rnd.init(RPR.seed);
+			const uint32_t interval = (uint32_t)RPR.interval;
+			uint32_t nrounds = (uint32_t)PRM.n_seed_rounds;
 			uint32_t mine[2] = {0, 0};
 			uint64_t nelt = 0;
-			if (P.do_exact_upfront) {
-				{ const uint64_t t0_ = now(); nelt = (pre && pre->sweep) ? exact_sweep_pre(mine) : exact_sweep(2, mine); HOT.t_phase[0] += now() - t0_; }
+			if (PRM.do_exact_upfront) {
+				{ const uint64_t t0_ = now(); nelt = (PRE && PRE->sweep) ? exact_sweep_pre(mine) : exact_sweep(2, mine); HOT.t_phase[0] += now() - t0_; }
 				if (nelt == 0) { HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0; }
 				else {
 					const int ret = extend_seeds(-1, 0, 0);
@@ -1923,14 +1926,14 @@ struct Aligner {
 					if (!done && minsc == perfect) done = true;
 				}
 			}
-			if (P.do_1mm_upfront) {
+			if (PRM.do_1mm_upfront) {
 				if (!done) {
 					const bool yfw = mine[0] <= 1 && !m_nofw;
 					const bool yrc = mine[1] <= 1 && !m_norc;
 					nelt = 0;
 					if (yfw || yrc) {
 						const uint64_t t0_ = now();
-						if (!(pre && pre->mm1 && one_mm_pre(!yfw, !yrc))) one_mm_search(!yfw, !yrc);
+						if (!(PRE && PRE->mm1 && one_mm_pre(!yfw, !yrc))) one_mm_search(!yfw, !yrc);
 						nelt = HOT.mm1_elt; HOT.t_phase[1] += now() - t0_;
 					}
 					if (nelt > 0) {
@@ -1943,34 +1946,34 @@ struct Aligner {
 				HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 			}
 			if (nrounds > interval) nrounds = interval;
-			for (uint32_t roundi = 0; roundi < (uint32_t)P.n_seed_rounds; roundi++) {
+			for (uint32_t roundi = 0; roundi < (uint32_t)PRM.n_seed_rounds; roundi++) {
 				HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_elts = 0; HOT.num_offs = 0;
 				if (done || HOT.done_unpair1) { done = true; continue; }
 				if (roundi >= nrounds) continue;
 				if (interval <= roundi) continue;
 				const uint32_t offset = (interval * roundi) / nrounds;
-				if (offset > 0 && (uint32_t)rp.seedlen + offset > len) continue;
+				if (offset > 0 && (uint32_t)RPR.seedlen + offset > len) continue;
 				const uint64_t ts_ = now();
 				ext_pre = false;
 				cache_reset();          // ca.nextRead() (bt2_search.cpp:3882)
 				uint32_t ninst;
-				if (P.seed_mms > 0) ninst = seed_round_mm1(offset, interval, (uint32_t)rp.seedlen);
-				else if (offset == 0 && pre && pre->seeds && 1 + (len > (uint32_t)rp.seedlen ? (len - (uint32_t)rp.seedlen) / interval : 0u) <= pre->max_seeds) {
-					ninst = seed_round_pre(pre->seeds, 0, interval, (uint32_t)rp.seedlen);
-					ext_pre = pre->ext != nullptr; pre_ext_cur = pre->ext; pre_joff_cur = pre->joff;
-				} else if (roundi > 0 && roundi < kMaxPreRounds && pre && pre->seeds_r[roundi] && pre->seeds_r[roundi][(uint64_t)ridx * 2 * pre->max_seeds].topf != ~0ull) {
+				if (PRM.seed_mms > 0) ninst = seed_round_mm1(offset, interval, (uint32_t)RPR.seedlen);
+				else if (offset == 0 && PRE && PRE->seeds && 1 + (len > (uint32_t)RPR.seedlen ? (len - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds) {
+					ninst = seed_round_pre(PRE->seeds, 0, interval, (uint32_t)RPR.seedlen);
+					ext_pre = PRE->ext != nullptr; pre_ext_cur = PRE->ext; pre_joff_cur = PRE->joff;
+				} else if (roundi > 0 && roundi < kMaxPreRounds && PRE && PRE->seeds_r[roundi] && PRE->seeds_r[roundi][(uint64_t)ridx * 2 * PRE->max_seeds].topf != ~0ull) {
 					// a re-seeding round the batch kernels searched (they saw the same "previous round was repetitive" condition:
 					// a read only gets here when it held); fewer seeds than round 0, so they fit the table
-					ninst = seed_round_pre(pre->seeds_r[roundi], offset, interval, (uint32_t)rp.seedlen);
-					ext_pre = pre->ext_r[roundi] != nullptr; pre_ext_cur = pre->ext_r[roundi]; pre_joff_cur = pre->joff_r[roundi];
-				} else ninst = seed_round(offset, interval, (uint32_t)rp.seedlen);
+					ninst = seed_round_pre(PRE->seeds_r[roundi], offset, interval, (uint32_t)RPR.seedlen);
+					ext_pre = PRE->ext_r[roundi] != nullptr; pre_ext_cur = PRE->ext_r[roundi]; pre_joff_cur = PRE->joff_r[roundi];
+				} else ninst = seed_round(offset, interval, (uint32_t)RPR.seedlen);
 				HOT.t_phase[2] += now() - ts_;
 				if (ninst == 0) { done = true; HOT.nonz_tot = 0; continue; }
 				if (HOT.nonz_tot == 0) { done = true; continue; }
 				{ const uint64_t t0_ = now(); rank_seed_hits(); HOT.t_phase[3] += now() - t0_; }
-				const int ret = extend_seeds(P.seed_mms, rp.seedlen, (int)interval);
+				const int ret = extend_seeds(PRM.seed_mms, RPR.seedlen, (int)interval);
 				handle_ret(ret, done);
-				if (!done && HOT.nonz_tot > 0 && (HOT.num_elts / HOT.nonz_tot) < (uint64_t)P.seed_boost_thresh) done = true;
+				if (!done && HOT.nonz_tot > 0 && (HOT.num_elts / HOT.nonz_tot) < (uint64_t)PRM.seed_boost_thresh) done = true;
 			}
 		}
 		finish(out);
@@ -1993,7 +1996,7 @@ struct Aligner {
 	// getReport, selectByScore (RNG!), and what the SAM line needs.
 	BT2_HDN void finish(ReadResult& out) {
 		out.status = (uint8_t)HOT.err;
-		out.filt = (uint8_t)rp.filt;
+		out.filt = (uint8_t)RPR.filt;
 		out.exhausted = 0;
 		out.nalns = HOT.n_alns;
 		out.n_ex_iters = HOT.n_ex_iters; out.n_ex_dps = HOT.n_ex_dps; out.n_ex_ugs = HOT.n_ex_ugs;
@@ -2003,9 +2006,9 @@ struct Aligner {
 		uint32_t nunpair1 = 0;
 		bool maxed = false;
 		if (HOT.n_alns > 0) {
-			if (HOT.exit_k) nunpair1 = (uint32_t)P.khits;
+			if (HOT.exit_k) nunpair1 = (uint32_t)PRM.khits;
 			else if (HOT.exit_m) { maxed = true; nunpair1 = 1; }
-			else nunpair1 = HOT.n_alns < (uint32_t)P.khits ? HOT.n_alns : (uint32_t)P.khits;
+			else nunpair1 = HOT.n_alns < (uint32_t)PRM.khits ? HOT.n_alns : (uint32_t)PRM.khits;
 		}
 		out.aligned = nunpair1 > 0 ? 1 : 0;
 		out.maxed = maxed ? 1 : 0;

@@ -16,6 +16,12 @@
 namespace bt2g {
 
 __shared__ HotWork g_hot;    // one wavefront per workgroup: the hot per-read state lives in LDS
+// control blocks of the launch / of the read in flight, also in LDS and also reached by name (DevPlat::params() ...): see the
+// note at the PRM / RPR / IX / PRE macros in bt2g_align_core.hpp
+__shared__ AlignParams g_P;
+__shared__ ReadParams g_rp;
+__shared__ PreComp g_pre;
+alignas(16) __shared__ unsigned char g_ix_raw[sizeof(DevIndex<uint64_t>) > sizeof(DevIndex<uint32_t>) ? sizeof(DevIndex<uint64_t>) : sizeof(DevIndex<uint32_t>)];
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
@@ -369,6 +375,10 @@ __device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, ui
 
 struct DevPlat {
 	static __device__ __forceinline__ HotWork& hot() { return g_hot; }
+	static __device__ __forceinline__ const AlignParams& params() { return g_P; }
+	static __device__ __forceinline__ ReadParams& rparams() { return g_rp; }
+	static __device__ __forceinline__ const PreComp* pre() { return &g_pre; }
+	template <typename TOff> static __device__ __forceinline__ const DevIndex<TOff>& index() { return *reinterpret_cast<const DevIndex<TOff>*>(g_ix_raw); }
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
 	// The worker's control code computes the same value in every lane; uni() moves such a value into a
 	// scalar register so that what is derived from it runs on the scalar ALU instead of 64 redundant lanes.
@@ -428,20 +438,49 @@ struct DevPlat {
 		const uint32_t lane = threadIdx.x & 63;
 		for (uint32_t base = 0; base < n; base += 64) {
 			const uint32_t i = base + lane;
-			if (__ballot(i < n && p[i] == v)) return true;
+			if (__ballot(i < n && gld(p + (i < n ? i : 0)) == v)) return true;
 		}
 		return false;
 	}
+	// out[] <- the values of [0, n) that are not in seen[0..nseen), ascending (the swap list a Random1toN converts to).
+	// 2048 values per pass: lane l keeps bitmap word l of the pass (built from the seen list, which every lane walks through
+	// register broadcasts), then 64 values at a time are tested and compacted with ballot / popcount.
+	static __device__ __attribute__((noinline)) void unseen_list(const uint32_t* seen, uint32_t nseen, uint32_t n, uint32_t* out) {
+		wave_fence();
+		const uint32_t lane = threadIdx.x & 63;
+		uint32_t count = 0;
+		for (uint32_t p0 = 0; p0 < n; p0 += 2048) {
+			uint32_t bm = 0;
+			for (uint32_t base = 0; base < nseen; base += 64) {
+				const uint32_t mine = base + lane < nseen ? gld(seen + base + lane) : 0xffffffffu;
+				const uint32_t cnt = nseen - base < 64u ? nseen - base : 64u;
+				for (uint32_t t = 0; t < cnt; t++) {
+					const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)t) - p0;
+					if (v < 2048u && (v >> 5) == lane) bm |= 1u << (v & 31);
+				}
+			}
+			const uint32_t pend = n - p0 < 2048u ? n - p0 : 2048u;
+			for (uint32_t b = 0; b < pend; b += 64) {
+				const uint32_t j = b + lane;
+				const uint32_t word = (uint32_t)__shfl((int)bm, (int)(j >> 5));
+				const bool unseen = j < pend && !((word >> (j & 31)) & 1u);
+				const unsigned long long m = __ballot(unseen);
+				if (unseen) gst(out + count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), p0 + j);
+				count += (uint32_t)__popcll(m);
+			}
+		}
+		wave_fence();
+	}
 	static __device__ __forceinline__ void iota_u32(uint32_t* p, uint32_t n) {
 		wave_fence();
-		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) p[i] = i;
+		for (uint32_t i = threadIdx.x & 63; i < n; i += 64) gst(p + i, i);
 		wave_fence();
 	}
 	static __device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t nwords) {
 		wave_fence();
 		const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
 		uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-		for (uint32_t i = threadIdx.x & 63; i < nwords; i += 64) d[i] = s[i];
+		for (uint32_t i = threadIdx.x & 63; i < nwords; i += 64) gst(d + i, gld(s + i));      // (both records live in the arena)
 		wave_fence();
 	}
 	static __device__ __forceinline__ void set_epoch(uint32_t* p, uint32_t e) { if ((threadIdx.x & 63) == 0) *p = e; wave_fence(); }
@@ -455,8 +494,8 @@ struct DevPlat {
 		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo);      // the tile runs along one diagonal
 		if (d <= row && d <= col && dd < band_w) {
 			const uint64_t idx = (uint64_t)(row - d) * band_w + dd;
-			p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
-			const uint32_t w = dp.pmask[idx];
+			p = gld(reinterpret_cast<const uint8_t*>(dp.mat) + idx);
+			const uint32_t w = gld(dp.pmask + idx);
 			m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
 		}
 		pr = p; mk = m;
@@ -744,12 +783,8 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	Work& w = *reinterpret_cast<Work*>(base);
 	DpScratch dp;
 	carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes);
-	__shared__ DevIndex<TOff> s_ix;
-	__shared__ AlignParams s_P;
-	__shared__ ReadParams s_rp;
-	__shared__ PreComp s_pre;
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
-	s_ix = ix; s_P = P; s_pre = pre;
+	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	wave_fence();
 	for (;;) {
 		unsigned int r = 0;
@@ -770,9 +805,9 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		wave_fence();
 		// The control state (`this`, the parameter blocks) is kept in LDS: the worker's member functions
 		// are real calls, and anything they reach through a pointer would otherwise be a private-memory load.
-		s_rp = rparams[r];
+		g_rp = rparams[r];
 		wave_fence();
-		Aligner<TOff, DevPlat>& al = *new (s_al) Aligner<TOff, DevPlat>(s_ix, s_P, s_rp, w, dp, &s_pre, r);
+		Aligner<TOff, DevPlat>& al = *new (s_al) Aligner<TOff, DevPlat>(w, dp, r);
 		wave_fence();
 		al.run(out);
 		wave_fence();
@@ -798,12 +833,8 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	Work& w = *reinterpret_cast<Work*>(base);
 	DpScratch dp, dp2;
 	carve_scratch(dp2, carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes), mat_bytes, mask_bytes, pmask_bytes);
-	__shared__ DevIndex<TOff> s_ix;
-	__shared__ AlignParams s_P;
-	__shared__ ReadParams s_rp;
-	__shared__ PreComp s_pre;
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
-	s_ix = ix; s_P = P; s_pre = pre;
+	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	wave_fence();
 	const unsigned int n_pairs = rd.n_reads / 2;
 	for (;;) {
@@ -823,9 +854,9 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 			continue;
 		}
 		wave_fence();
-		s_rp = rparams[2 * r];
+		g_rp = rparams[2 * r];
 		wave_fence();
-		Aligner<TOff, DevPlat>& al = *new (s_al) Aligner<TOff, DevPlat>(s_ix, s_P, s_rp, w, dp, &s_pre, 2 * r);
+		Aligner<TOff, DevPlat>& al = *new (s_al) Aligner<TOff, DevPlat>(w, dp, 2 * r);
 		al.dp_main = dp; al.dp_opp = dp2;
 		al.pe_seq[0] = rd.d_seq + o0; al.pe_qual[0] = rd.d_qual + o0; al.pe_len[0] = len0;
 		al.pe_seq[1] = rd.d_seq + o1; al.pe_qual[1] = rd.d_qual + o1; al.pe_len[1] = len1;

@@ -35,6 +35,18 @@
 struct ulonglong2 { unsigned long long x, y; };   // host-side stand-in (test builds only)
 #endif
 
+// Scalar loads / stores for pointers that are KNOWN to point into the wave's arena in HBM.  Through a plain (generic)
+// pointer the compiler must issue FLAT instructions: it then has to assume the access may alias LDS (so every LDS value it
+// holds in registers is reloaded after a store) and the wait for a FLAT load also drains the LDS counter.  The device
+// version names the global address space; the host twin (tests/hostsim) is an ordinary dereference.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T> __host__ __device__ __forceinline__ T gld(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
+template <typename T> __host__ __device__ __forceinline__ void gst(T* p, T v) { *(__attribute__((address_space(1))) T*)p = v; }
+#else
+template <typename T> BT2_HD T gld(const T* p) { return *p; }
+template <typename T> BT2_HD void gst(T* p, T v) { *p = v; }
+#endif
+
 namespace bt2g {
 
 template <typename TOff> struct OffTraits;

@@ -21,10 +21,17 @@
 using namespace bt2g;
 
 static HotWork g_hot;
+static const AlignParams* g_Pp = nullptr;      // the control blocks the device keeps in LDS
+static ReadParams g_rp;
+static const void* g_ixp = nullptr;
 static CliExtra g_ex;
 
 struct HostPlat {
 	static HotWork& hot() { return g_hot; }
+	static const AlignParams& params() { return *g_Pp; }
+	static ReadParams& rparams() { return g_rp; }
+	static const PreComp* pre() { return nullptr; }
+	template <typename TOff> static const DevIndex<TOff>& index() { return *reinterpret_cast<const DevIndex<TOff>*>(g_ixp); }
 	static uint64_t clock() { return 0; }
 	template <typename T> static T uni(T v) { return v; }
 	template <typename T> static T* uni_ptr(T* p) { return p; }
@@ -44,6 +51,12 @@ struct HostPlat {
 		for (uint32_t l = 0; l < n; l++) { uint32_t steps = 0; const TOff joff = bt2g::get_offset(e, (TOff)rows[l].topf, steps); out[l] = joff_pack((uint64_t)joff, steps); }
 	}
 	static bool contains_u32(const uint32_t* p, uint32_t n, uint32_t v) { for (uint32_t i = 0; i < n; i++) if (p[i] == v) return true; return false; }
+	static void unseen_list(const uint32_t* seen, uint32_t nseen, uint32_t n, uint32_t* out) {
+		std::vector<bool> in(n, false);
+		for (uint32_t i = 0; i < nseen; i++) if (seen[i] < n) in[seen[i]] = true;
+		uint32_t c = 0;
+		for (uint32_t j = 0; j < n; j++) if (!in[j]) out[c++] = j;
+	}
 	static void iota_u32(uint32_t* p, uint32_t n) { for (uint32_t i = 0; i < n; i++) p[i] = i; }
 	static void copy_words(void* dst, const void* src, uint32_t nwords) { memcpy(dst, src, (size_t)nwords * 4); }
 	static uint32_t pick_mass(const double* prefix, const uint8_t* elim, uint32_t n, double rd) {
@@ -343,11 +356,11 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 			fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", rd.name.str().c_str(), kMaxLen);
 			return 1;
 		}
-		ReadParams rp = hb.rp[ri];
+		g_rp = hb.rp[ri]; g_Pp = &P; g_ixp = &ix;
 		g_hot.len = (uint32_t)rd.seq.size();
 		memcpy(g_hot.seq, rd.seq.data(), rd.seq.size());
 		memcpy(g_hot.qual, rd.qual.data(), rd.qual.size());
-		Aligner<TOff, HostPlat> al(ix, P, rp, *w, dp);
+		Aligner<TOff, HostPlat> al(*w, dp);
 		al.run(rr);
 		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d, site %u)\n", rd.name.str().c_str(), rr.status, rr.pad2);
 		summ.add(rr);
@@ -417,8 +430,8 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 			if (r1.seq.size() > (size_t)kMaxLen || r2.seq.size() > (size_t)kMaxLen) { fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", r1.name.str().c_str(), kMaxLen); return 1; }
 			ReadResult& rr1 = *(ReadResult*)resbuf.data();
 			ReadResult& rr2 = *(ReadResult*)(resbuf.data() + rec_bytes);
-			ReadParams rp = hb.rp[pi];
-			Aligner<TOff, HostPlat> al(ix, P, rp, *w, dp);
+			g_rp = hb.rp[pi]; g_Pp = &P; g_ixp = &ix;
+			Aligner<TOff, HostPlat> al(*w, dp);
 			al.dp_main = dp; al.dp_opp = dp2;
 			al.pe_seq[0] = (const uint8_t*)r1.seq.data(); al.pe_qual[0] = (const uint8_t*)r1.qual.data(); al.pe_len[0] = (uint32_t)r1.seq.size();
 			al.pe_seq[1] = (const uint8_t*)r2.seq.data(); al.pe_qual[1] = (const uint8_t*)r2.qual.data(); al.pe_len[1] = (uint32_t)r2.seq.size();
