@@ -1254,6 +1254,30 @@ struct Aligner {
 		auto fl = [&](int v) -> bool { return !local || v > 0; };     // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
 		HOT.n_bt_attempts++;
 		while ((int)row >= 0) {
+			if (pred && ct == 0 && td < tile_len && row > 0) {
+				// a run of plain diagonal steps (unvisited cells whose only consistent predecessor is the diagonal one) is walked
+				// by all lanes at once: same marks, same edits, same counters as the step-by-step loop below
+				const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
+				const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
+				typename Plat::LaneReg inf;
+				uint64_t mm;
+				const uint32_t L = Plat::uni(Plat::bt_diag_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, fw, rdlen, room_c < room_e ? room_c : room_e, inf, mm));
+				if (L > 0) {
+					olap |= in_core(row, col); ncells += L; prof.steps += L;
+					while (mm) {
+						const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+						mm &= mm - 1;
+						const uint32_t v = Plat::lane(inf, d);
+						const int e_readc = (int)((v >> 4) & 7), e_refm = (int)((v >> 8) & 0xff), e_q = (int)((v >> 16) & 0xff);
+						Edit& e = ned[nned++];
+						e.pos = (uint16_t)(row - (d - td)); e.chr = (uint8_t)mask2chr(e_refm); e.qchr = code2chr(e_readc); e.type = EDIT_MM;
+						score -= sc_mm(S, e_readc, e_refm, e_q - 33);
+						if (v & 2u) ns++;
+					}
+					row -= L; col -= L; td += L;
+					continue;
+				}
+			}
 			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
 			const int refm = byte_of(rfw, 3, col - rf_c0);
 			const int readq = byte_of(qlw, 2, fw ? row : rdlen - 1 - row);

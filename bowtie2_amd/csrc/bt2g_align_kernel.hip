@@ -500,6 +500,38 @@ struct DevPlat {
 		}
 		pr = p; mk = m;
 	}
+	// Backtrace fast path (pred format, H state): the cells of the tile from lane td on that are "plain diagonal steps" --
+	// not visited yet, HD the only consistent predecessor, not row 0 -- are walked in one go.  Every lane marks its own cell
+	// (reportedThrough + the H choice, the word the step-by-step walk would leave: 3) and classifies its read/reference pair;
+	// returns the run length, `info` = per lane readc << 4 | refm << 8 | qual << 16 | (N involved) << 1, `mm` = lanes whose
+	// pair is not a match (they become edits, in lane order).
+	static __device__ __forceinline__ uint32_t bt_diag_run(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t tile, uint32_t tile_hi,
+	                                                       uint32_t td, uint32_t row, uint32_t col, bool fw, uint32_t rdlen, uint32_t maxl,
+	                                                       uint32_t& info, uint64_t& mm) {
+		const uint32_t d = threadIdx.x & 63;
+		const uint32_t k = d - td;
+		const bool in = d >= td && k < row && k <= col && k < maxl;
+		const uint32_t pb = tile;
+		const bool he = (pb & PB_HE) != 0, hf = (pb & PB_HF) != 0;
+		const bool simple = in && tile_hi == 0 && (pb & PB_HD) && !(hf && (pb & (PB_FO | PB_FE))) && !(he && (pb & (PB_EO | PB_EE)));
+		const unsigned long long sm = __ballot(simple) >> td;
+		const uint32_t L = ~sm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~sm);
+		info = 0; mm = 0;
+		if (L == 0) return 0;
+		bool edit = false;
+		if (in && k < L) {
+			const uint32_t r = row - k, c = col - k;
+			const int readc = rd_char(g_hot, rdlen, fw, r);
+			const int refm = g_hot.rf[c];
+			const int readq = rd_qual(g_hot, rdlen, fw, r);
+			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
+			edit = m != 1;
+			info = ((uint32_t)readc << 4) | ((uint32_t)refm << 8) | ((uint32_t)readq << 16) | (m == -1 ? 2u : 0u);
+			gst(dp.pmask + pred_idx(band_lo, band_w, r, c), 3u | (epoch << kEpochShift));
+		}
+		mm = __ballot(edit);
+		return L;
+	}
 	// scores of the last DP row -> LDS (clamped at -32768; only scores >= minsc matter afterwards)
 	static __device__ __forceinline__ void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols, bool wide) {
 		wave_fence();

@@ -115,6 +115,29 @@ struct HostPlat {
 			lo.v[ln] = v; hi.v[ln] = vh;
 		}
 	}
+	static uint32_t bt_diag_run(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, const LaneReg& tile, const LaneReg& tile_hi,
+	                            uint32_t td, uint32_t row, uint32_t col, bool fw, uint32_t rdlen, uint32_t maxl, LaneReg& info, uint64_t& mm) {
+		mm = 0;
+		uint32_t L = 0;
+		for (uint32_t d = td; d < 64; d++, L++) {
+			const uint32_t k = d - td;
+			if (!(k < row && k <= col && k < maxl)) break;
+			const uint32_t pb = tile.v[d];
+			const bool he = (pb & PB_HE) != 0, hf = (pb & PB_HF) != 0;
+			if (!(tile_hi.v[d] == 0 && (pb & PB_HD) && !(hf && (pb & (PB_FO | PB_FE))) && !(he && (pb & (PB_EO | PB_EE))))) break;
+		}
+		for (uint32_t k = 0; k < L; k++) {
+			const uint32_t r = row - k, c = col - k;
+			const int readc = rd_char(g_hot, rdlen, fw, r);
+			const int refm = g_hot.rf[c];
+			const int readq = rd_qual(g_hot, rdlen, fw, r);
+			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
+			if (m != 1) mm |= 1ull << (td + k);
+			info.v[td + k] = ((uint32_t)readc << 4) | ((uint32_t)refm << 8) | ((uint32_t)readq << 16) | (m == -1 ? 2u : 0u);
+			dp.pmask[pred_idx(band_lo, band_w, r, c)] = 3u | (epoch << kEpochShift);
+		}
+		return L;
+	}
 	static void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, LaneReg& pr, LaneReg& mk) {
 		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo);
 		for (uint32_t d = 0; d < 64; d++) {
