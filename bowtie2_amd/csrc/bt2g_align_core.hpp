@@ -1043,11 +1043,7 @@ struct Aligner {
 	// seenDiags1_ / seenDiags2_ share the list; the mate rides in bit 1 of the orientation
 	BT2_HD bool diag_present_m(int32_t ref, int64_t off, bool fw, int mate) const {
 		const int orient = (fw ? 1 : 0) | (mate << 1);
-		for (uint32_t i = 0; i < HOT.n_diags; i++) {
-			const DiagIval& d = w.diags[i];
-			if (d.ref == ref && d.orient == orient && off >= d.off && off < d.off + d.len) return true;
-		}
-		return false;
+		return Plat::diag_find(w.diags, HOT.n_diags, ref, off, orient);
 	}
 	BT2_HD void diag_add_m(int32_t ref, int64_t off, bool fw, int64_t len, int mate) {
 		if (HOT.n_diags >= (uint32_t)kMaxDiags) { ovf(14); return; }
@@ -1748,7 +1744,7 @@ struct Aligner {
 					if (!ee_mode) nelt_left--;
 					TOff tidx = 0, toff = 0, tlen = 0;
 					bool straddled = false;
-					joined_to_text_off(IX, (TOff)seedhitlen, joff, tidx, toff, tlen, ee_mode, straddled);
+					Plat::joined_to_text(IX, (TOff)seedhitlen, joff, tidx, toff, tlen, ee_mode, straddled);
 					if (tidx == kOffMask) continue;
 					const int64_t refoff = (int64_t)toff - (int64_t)rdoff;
 					if (diag_present((int32_t)tidx, refoff, fw)) { HOT.n_redundants++; continue; }

@@ -500,6 +500,58 @@ struct DevPlat {
 		}
 		pr = p; mk = m;
 	}
+	// Ebwt::joinedToTextOff (bt2_idx.cpp:113-171) for one wave-uniform offset: the fragment table is searched 64 ways at a time
+	// (every lane probes one fragment start, a ballot picks the stride that holds the offset) instead of by a chain of
+	// dependent binary-search reads -- 1 round for up to 64 fragments, 2 for up to 4096 -- then one gather for the record.
+	template <typename TOff>
+	static __device__ __forceinline__ void joined_to_text(const DevIndex<TOff>& ix, TOff qlen, TOff off, TOff& tidx, TOff& textoff, TOff& tlen,
+	                                                      bool reject_straddle, bool& straddled) {
+		straddled = false;
+		tidx = (TOff)OffTraits<TOff>::kMask; textoff = 0; tlen = 0;
+		const TOff n = ix.n_frag, len = ix.fw.len;
+		if (off >= len || n == 0) return;
+		const uint32_t lane = threadIdx.x & 63;
+		const TOff* rs = ix.rstarts;
+		TOff lo = 0, cnt = n;              // the answer is in [lo, lo + cnt) and rstarts[lo * 3] <= off
+		while (cnt > 1) {
+			const TOff stride = (cnt + 63) / 64;
+			const TOff p = lo + (TOff)lane * stride;
+			const bool le = p < lo + cnt && gld(rs + (uint64_t)p * 3) <= off;
+			const unsigned long long m = __ballot(le) | 1ull;
+			const uint32_t k = 63u - (uint32_t)__builtin_clzll(m);
+			const TOff nlo = lo + (TOff)k * stride, end = lo + cnt;
+			cnt = end - nlo < stride ? end - nlo : stride;
+			lo = nlo;
+		}
+		const TOff elt = lo;
+		// lanes 0-2: the record; lane 3: the start of the next fragment
+		TOff v = 0;
+		if (lane < 3) v = gld(rs + (uint64_t)elt * 3 + lane);
+		else if (lane == 3) v = (elt == n - 1) ? len : gld(rs + ((uint64_t)elt + 1) * 3);
+		const TOff lower = (TOff)__shfl((long long)v, 0), tid = (TOff)__shfl((long long)v, 1), fwoff = (TOff)__shfl((long long)v, 2), upper = (TOff)__shfl((long long)v, 3);
+		if (off + qlen > upper) {
+			straddled = true;
+			if (reject_straddle) return;
+		}
+		tidx = tid;
+		textoff = (off - lower) + fwoff;
+		tlen = gld(ix.plen + tid);
+	}
+	// is (ref, off, orient) inside one of the seen-diagonal intervals?  64 intervals per round trip
+	static __device__ __forceinline__ bool diag_find(const DiagIval* d, uint32_t n, int32_t ref, int64_t off, int32_t orient) {
+		const uint32_t lane = threadIdx.x & 63;
+		for (uint32_t base = 0; base < n; base += 64) {
+			const uint32_t i = base + lane;
+			bool hit = false;
+			if (i < n) {
+				const int64_t o = gld(&d[i].off), l = gld(&d[i].len);
+				const int32_t r = gld(&d[i].ref), t = gld(&d[i].orient);
+				hit = r == ref && t == orient && off >= o && off < o + l;
+			}
+			if (__ballot(hit)) return true;
+		}
+		return false;
+	}
 	// Backtrace fast path (pred format, H state): the cells of the tile from lane td on that are "plain diagonal steps" --
 	// not visited yet, HD the only consistent predecessor, not row 0 -- are walked in one go.  Every lane marks its own cell
 	// (reportedThrough + the H choice, the word the step-by-step walk would leave: 3) and classifies its read/reference pair;

@@ -17,6 +17,15 @@
 #include "bt2g_kernels.hpp"
 #include "bt2g_fm_search.hpp"
 
+// Register budget of the lane-per-task FM kernels.  Measured on MI355X (tools/fm_wpe_sweep.sh, profiles/r02_fm_wpe_sweep.txt):
+// asking the compiler for more waves per SIMD (fewer registers) makes every one of them slower -- the spills cost more than
+// the extra lanes in flight hide -- except that the 1-mismatch scan is fastest when it is pinned to 2 waves per SIMD.
+#ifndef BT2G_MM1_WPE
+#define BT2G_MM1_WPE 2
+#endif
+#define BT2G_FM_BOUNDS __launch_bounds__(256)
+#define BT2G_MM1_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT2G_MM1_WPE, BT2G_MM1_WPE)))
+
 namespace bt2g {
 
 // ------------------------------------------------------------------------------------
@@ -52,7 +61,7 @@ __device__ __forceinline__ bool ftab_key(GetC getc, uint32_t off, uint32_t fc, b
 // exact end-to-end sweep
 // ------------------------------------------------------------------------------------
 template <typename TOff>
-__global__ void __launch_bounds__(256)
+__global__ void BT2G_FM_BOUNDS
 k_exact_sweep(DevIndex<TOff> ix, bt2g_reads rd, int nofw, int norc, uint32_t mine_max,
               bt2g_sweep_out* __restrict__ out, DevCounters* cnt) {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,7 +163,7 @@ hipError_t launch_exact_sweep(const DevIndex<TOff>& ix, const bt2g_reads& rd, in
 // exact (-N 0) multiseed search
 // ------------------------------------------------------------------------------------
 template <typename TOff>
-__global__ void __launch_bounds__(256)
+__global__ void BT2G_FM_BOUNDS
 k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict__ d_seedlen,
                     const uint32_t* __restrict__ d_interval, const uint32_t* __restrict__ d_offset,
                     const bt2g_read_params* __restrict__ rparams,
@@ -514,7 +523,7 @@ struct GlobRd {
 };
 
 template <typename TOff>
-__global__ void __launch_bounds__(256)
+__global__ void BT2G_FM_BOUNDS
 k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t max_seeds, int right,
               const bt2g_seed_hit* __restrict__ hits, uint32_t* __restrict__ ext, uint64_t* __restrict__ joffs, DevCounters* cnt,
               uint32_t roundi, uint32_t n_seed_rounds) {
@@ -583,7 +592,7 @@ hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, co
 template <typename TOff> struct Mm1Task { uint32_t list; uint16_t dep; uint8_t j, pad; TOff top, bot, topp, botp; };
 
 template <typename TOff>
-__global__ void __launch_bounds__(256)
+__global__ void BT2G_MM1_BOUNDS
 k_one_mm_scan(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams,
               const bt2g_sweep_out* __restrict__ sweep, uint32_t cap, Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt,
               Mm1Task<TOff>* __restrict__ queue, unsigned int* __restrict__ qcount, uint32_t qcap, DevCounters* cnt) {
@@ -627,7 +636,7 @@ k_one_mm_scan(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_
 }
 
 template <typename TOff>
-__global__ void __launch_bounds__(256)
+__global__ void BT2G_MM1_BOUNDS
 k_one_mm_cont(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t cap,
               Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt, const Mm1Task<TOff>* __restrict__ queue,
               const unsigned int* __restrict__ qcount, uint32_t qcap, DevCounters* cnt) {

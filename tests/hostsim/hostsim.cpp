@@ -115,6 +115,14 @@ struct HostPlat {
 			lo.v[ln] = v; hi.v[ln] = vh;
 		}
 	}
+	template <typename TOff>
+	static void joined_to_text(const DevIndex<TOff>& ix, TOff qlen, TOff off, TOff& tidx, TOff& textoff, TOff& tlen, bool reject_straddle, bool& straddled) {
+		joined_to_text_off(ix, qlen, off, tidx, textoff, tlen, reject_straddle, straddled);
+	}
+	static bool diag_find(const DiagIval* d, uint32_t n, int32_t ref, int64_t off, int32_t orient) {
+		for (uint32_t i = 0; i < n; i++) if (d[i].ref == ref && d[i].orient == orient && off >= d[i].off && off < d[i].off + d[i].len) return true;
+		return false;
+	}
 	static uint32_t bt_diag_run(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, const LaneReg& tile, const LaneReg& tile_hi,
 	                            uint32_t td, uint32_t row, uint32_t col, bool fw, uint32_t rdlen, uint32_t maxl, LaneReg& info, uint64_t& mm) {
 		mm = 0;
