@@ -88,18 +88,9 @@ struct Aligner {
 		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
 		HOT.n_rank = 0;
 		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i + offset;
-		for (int fwi = 0; fwi < 2; fwi++) {
-			const bool fw = fwi == 0;
-			const bool skip = (fw && m_nofw) || (!fw && m_norc);
-			const bt2g_seed_hit* src = src_all + ((uint64_t)ridx * 2 + fwi) * PRE->max_seeds;
-			for (uint32_t i = 0; i < nseeds; i++) {
-				HotHit& h = HOT.hits[fwi][i];
-				HOT.sorted[fwi][i] = 0;
-				h.topf = h.topb = 0; h.size = h.esize = 0;
-				if (skip) continue;
-				const bt2g_seed_hit sh = src[i];
-				if (sh.botf > sh.topf) { h.topf = sh.topf; h.topb = sh.topb; h.size = h.esize = (uint32_t)(sh.botf - sh.topf); }
-			}
+		{
+			const bt2g_seed_hit* src = src_all + (uint64_t)ridx * 2 * PRE->max_seeds;
+			Plat::load_seed_hits(src, src + PRE->max_seeds, nseeds, m_nofw != 0, m_norc != 0);
 		}
 		cache_filter(interval, offset, seedlen);
 		return 1;   // # instantiated seeds only matters when no seed hit (run() ends the read either way)
@@ -130,15 +121,10 @@ struct Aligner {
 				HotHit& h = HOT.hits[fwi][i];
 				const uint32_t depth = i * interval + offset;
 				// the seed as it aligns to the Watson strand, packed; a seed with an N is never instantiated (no cache traffic)
-				uint64_t key = 0;
-				bool inst = L <= 32;
-				for (uint32_t k = 0; k < L && inst; k++) {
-					const int ch = fw ? (int)HOT.seq[depth + k] : comp4(HOT.seq[depth + L - 1 - k]);
-					if (ch > 3) inst = false; else key = (key << 2) | (uint64_t)ch;
-				}
-				if (!inst) { if (L > 32) { /* uncacheable keys (-L > 32 cannot occur) */ } h.size = h.esize = 0; continue; }
-				uint32_t e = 0;
-				while (e < c.nkeys && !(w.ck_key[e] == key && w.ck_len[e] == (uint8_t)L)) e++;
+				bool inst = L <= 32;      // (-L > 32 cannot occur)
+				const uint64_t key = inst ? Plat::seed_key(fw, depth, L, inst) : 0;
+				if (!inst) { h.size = h.esize = 0; continue; }
+				const uint32_t e = Plat::find_key(w.ck_key, w.ck_len, c.nkeys, key, (uint8_t)L);
 				bool drop = false;
 				// beginAlign: the seed sequence enters the QKey map
 				if (e == c.nkeys || !(w.ck_flags[e] & 1)) {
@@ -1840,7 +1826,7 @@ struct Aligner {
 							mode = minsc < -254 ? 1 : 0;
 							sse16 = mode == 1;
 							best = Plat::dp_fill_ee(PRM, w, fw, rows, cols, dp, mode != 0, minsc);
-							if (best == INT64_MIN) { ovf(30); return EXT_HARD_LIMIT; }
+							if (best == INT64_MIN) { ovf(31); return EXT_HARD_LIMIT; }
 						}
 						HOT.t_phase[5] += now() - td_;
 						HOT.n_ex_dps++;

@@ -500,6 +500,50 @@ struct DevPlat {
 		}
 		pr = p; mk = m;
 	}
+	// seed hits of one pre-computed round (both strands) -> HOT.hits, one seed per lane
+	static __device__ __forceinline__ void load_seed_hits(const bt2g_seed_hit* src_fw, const bt2g_seed_hit* src_rc, uint32_t nseeds, bool skip_fw, bool skip_rc) {
+		for (int fwi = 0; fwi < 2; fwi++) {
+			const bt2g_seed_hit* src = fwi == 0 ? src_fw : src_rc;
+			const bool skip = fwi == 0 ? skip_fw : skip_rc;
+			for (uint32_t i = threadIdx.x & 63; i < nseeds; i += 64) {
+				HotHit h; h.topf = h.topb = 0; h.size = h.esize = 0;
+				if (!skip) {
+					const uint64_t topf = gld(&src[i].topf), botf = gld(&src[i].botf);
+					if (botf > topf) { h.topf = topf; h.topb = gld(&src[i].topb); h.size = h.esize = (uint32_t)(botf - topf); }
+				}
+				g_hot.hits[fwi][i] = h;
+				g_hot.sorted[fwi][i] = 0;
+			}
+		}
+	}
+	// The L <= 32 read characters of a seed as it aligns to the Watson strand, 2 bits each, first character in the top bits;
+	// ok = no N among them.  One character per lane, OR-reduced.
+	static __device__ __forceinline__ uint64_t seed_key(bool fw, uint32_t depth, uint32_t L, bool& ok) {
+		const uint32_t k = threadIdx.x & 63;
+		uint64_t part = 0;
+		bool bad = false;
+		if (k < L) {
+			const int ch = fw ? (int)g_hot.seq[depth + k] : comp4(g_hot.seq[depth + L - 1 - k]);
+			bad = ch > 3;
+			part = (uint64_t)(ch & 3) << (2 * (L - 1 - k));
+		}
+		ok = __ballot(bad) == 0ull;
+		uint32_t lo = (uint32_t)part, hi = (uint32_t)(part >> 32);
+#pragma unroll
+		for (int s = 32; s > 0; s >>= 1) { lo |= (uint32_t)__shfl_xor((int)lo, s); hi |= (uint32_t)__shfl_xor((int)hi, s); }
+		return ((uint64_t)hi << 32) | lo;
+	}
+	// index of (key, len) among the n cached seed sequences, n if absent; 64 entries per round trip
+	static __device__ __forceinline__ uint32_t find_key(const uint64_t* keys, const uint8_t* lens, uint32_t n, uint64_t key, uint8_t len) {
+		const uint32_t lane = threadIdx.x & 63;
+		for (uint32_t base = 0; base < n; base += 64) {
+			const uint32_t i = base + lane;
+			const bool hit = i < n && gld(keys + i) == key && gld(lens + i) == len;
+			const unsigned long long m = __ballot(hit);
+			if (m) return base + (uint32_t)__builtin_ctzll(m);
+		}
+		return n;
+	}
 	// Ebwt::joinedToTextOff (bt2_idx.cpp:113-171) for one wave-uniform offset: the fragment table is searched 64 ways at a time
 	// (every lane probes one fragment start, a ballot picks the stride that holds the offset) instead of by a chain of
 	// dependent binary-search reads -- 1 round for up to 64 fragments, 2 for up to 4096 -- then one gather for the record.

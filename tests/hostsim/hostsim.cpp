@@ -115,6 +115,35 @@ struct HostPlat {
 			lo.v[ln] = v; hi.v[ln] = vh;
 		}
 	}
+	static void load_seed_hits(const bt2g_seed_hit* src_fw, const bt2g_seed_hit* src_rc, uint32_t nseeds, bool skip_fw, bool skip_rc) {
+		for (int fwi = 0; fwi < 2; fwi++) {
+			const bt2g_seed_hit* src = fwi == 0 ? src_fw : src_rc;
+			const bool skip = fwi == 0 ? skip_fw : skip_rc;
+			for (uint32_t i = 0; i < nseeds; i++) {
+				HotHit& h = g_hot.hits[fwi][i];
+				g_hot.sorted[fwi][i] = 0;
+				h.topf = h.topb = 0; h.size = h.esize = 0;
+				if (skip) continue;
+				const bt2g_seed_hit sh = src[i];
+				if (sh.botf > sh.topf) { h.topf = sh.topf; h.topb = sh.topb; h.size = h.esize = (uint32_t)(sh.botf - sh.topf); }
+			}
+		}
+	}
+	static uint64_t seed_key(bool fw, uint32_t depth, uint32_t L, bool& ok) {
+		uint64_t key = 0;
+		ok = true;
+		for (uint32_t k = 0; k < L; k++) {
+			const int ch = fw ? (int)g_hot.seq[depth + k] : comp4(g_hot.seq[depth + L - 1 - k]);
+			if (ch > 3) { ok = false; return 0; }
+			key = (key << 2) | (uint64_t)ch;
+		}
+		return key;
+	}
+	static uint32_t find_key(const uint64_t* keys, const uint8_t* lens, uint32_t n, uint64_t key, uint8_t len) {
+		uint32_t e = 0;
+		while (e < n && !(keys[e] == key && lens[e] == len)) e++;
+		return e;
+	}
 	template <typename TOff>
 	static void joined_to_text(const DevIndex<TOff>& ix, TOff qlen, TOff off, TOff& tidx, TOff& textoff, TOff& tlen, bool reject_straddle, bool& straddled) {
 		joined_to_text_off(ix, qlen, off, tidx, textoff, tlen, reject_straddle, straddled);
