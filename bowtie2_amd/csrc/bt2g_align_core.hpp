@@ -22,7 +22,7 @@ struct Aligner {
 #define RPR (Plat::rparams())                     // ReadParams& of the loaded read (paired-end mode swaps the mate's in)
 #define IX  (Plat::template index<TOff>())        // const DevIndex<TOff>&
 #define PRE (Plat::pre())                         // const PreComp*: batch pre-computation (may be null)
-	BT2_HD static uint64_t now() { return Plat::clock(); }
+	BT2_HD static uint64_t now() { return PRM.profile ? Plat::clock() : 0ull; }      // phase timers only when asked for (bt2g_align_params::profile)
 
 	Work& w;
 	DpScratch dp;
@@ -1853,7 +1853,7 @@ struct Aligner {
 						}
 						first_inner = false;
 						const uint64_t tp_ = now();
-						struct PostTimer { uint64_t t0; uint64_t& acc; BT2_HD ~PostTimer() { acc += Plat::clock() - t0; } } post_timer_{tp_, HOT.t_phase[9]};
+						struct PostTimer { uint64_t t0; uint64_t& acc; BT2_HD ~PostTimer() { acc += now() - t0; } } post_timer_{tp_, HOT.t_phase[9]};
 						// --overhang: soft-clip what hangs off either end (aligner_sw_driver.cpp:1396-1403)
 						if (PRM.overhang && (res.refoff < 0 || res.refoff + (int64_t)res.rfextent > (int64_t)tlen)) {
 							clip_outside(res, 0, (int64_t)tlen);

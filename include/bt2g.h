@@ -220,6 +220,8 @@ typedef struct {
 	int32_t det_seeds;             /* -d: seed-hit ranges in sorted order, rows in index order, no sampling (prioritizeSATupsIdxs) */
 	int32_t seed_cache_mb;         /* --seed-cache-sz (default 20): size of the reference's per-read seed-hit cache, whose exhaustion on
 	                                  reads with millions of seed-hit rows is part of its output (0 = 20)                       */
+	int32_t profile;               /* 1: the worker reads the device clock around every phase (what bt2g_align_profile_read reports);
+	                                  0: no clock reads, the time slots of the profile stay 0                                    */
 } bt2g_align_params;
 #define BT2G_PE_DOVETAIL_OK  1     /* --dovetail                       */
 #define BT2G_PE_CONTAIN_OK   2     /* cleared by --no-contain          */

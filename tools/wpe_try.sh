@@ -11,5 +11,5 @@ python - <<P
 import json
 d=json.loads(open("$O/bench.json").read()); c=d["config"]
 print("WPE=$W", round(d["value"]), c["kernel_ms_per_step"], "parity", c.get("parity_identical"), c.get("parity_differing_sam_lines"))
-print(c["worker_phase_us_per_read"])
+print(c["worker_phase_us_per_read_profiled_pass"])
 P
