@@ -336,6 +336,17 @@ int bt2g_index_build(const char *const *fasta_paths, uint32_t n_paths, const cha
 int bt2g_index_build_mem(const char *const *names, const char *const *seqs, const uint64_t *lens, uint32_t n_seqs,
                          const char *out_base, const bt2g_build_params *params, bt2g_build_stats *stats);
 
+/* ---- the whole aligner as one call --------------------------------------- */
+/*
+ * The reference's library-style entry point, same name and signature: `extern "C" int bowtie(int argc, const char **argv)`
+ * (bt2_search.cpp:5223; bowtie_main.cpp:30-67 is the main() around it).  argv is the bowtie2-align-{s,l} command line
+ * (argv[0] = program name); SAM goes to -S or stdout, the summary to stderr, the return value is the exit status.
+ * bowtie2_amd/bin/bowtie2-align-{s,l} are a main() around this function.  Conditions found before the pipeline starts
+ * (bad arguments, no index, no gfx950 device, unreadable files) return non-zero; a malformed record met while the
+ * reader/worker threads are running ends the process from that thread, as in the reference.
+ */
+int bowtie(int argc, const char **argv);
+
 /* ---- instrumentation ---------------------------------------------------- */
 typedef struct {
 	uint64_t rank_queries;    /* # sides read (SURVEY.md 8d unit)             */

@@ -29,6 +29,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(n for n, _, _ in bowtie2_amd.ABI) == syms
 
 
+def test_bowtie_entry_point_returns_status():
+    """extern "C" int bowtie(argc, argv) (the reference's bt2_search.cpp:5223): exported, and an argument error comes back as
+    a return value instead of ending the calling process."""
+    import bowtie2_amd
+    L = C.CDLL(bowtie2_amd.LIB_PATH)
+    assert hasattr(L, "bowtie")
+    argv = (C.c_char_p * 4)(b"bowtie2-align-s", b"-x", b"/nonexistent/index", b"--no-such-option")
+    assert L.bowtie(4, argv) == 1
+    argv = (C.c_char_p * 2)(b"bowtie2-align-s", b"--version")
+    assert L.bowtie(2, argv) == 0
+
+
 def test_struct_layouts_match_header():
     import bowtie2_amd as b
     assert C.sizeof(b.SweepOut) == 48
