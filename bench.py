@@ -276,6 +276,10 @@ def sam_body(path):
 
 
 def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, threads, preset, work):
+    # fq_all / fq_tiny: one FASTQ path (unpaired) or a pair of paths (mate 1, mate 2)
+    def rd_args(fq):
+        return ["-U", fq] if isinstance(fq, str) else ["-1", fq[0], "-2", fq[1]]
+    paired = not isinstance(fq_all, str)
     """Reference bowtie2-align (AVX2 build when present) on the sample: reads/s from wall clock minus the wall clock of
     an index-load-dominated run (n_tiny reads), median of 3.  The first pass writes SAM; the product binary aligns the
     same FASTQ on the GPU and the two SAM files are compared byte for byte (minus @PG)."""
@@ -291,14 +295,14 @@ def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, thre
     ref_sam = os.path.join(work, "sample.ref.sam")
     t_load = []
     for _ in range(2):
-        t, p = run_timed([exe] + common + ["-U", fq_tiny, "-S", "/dev/null"])
+        t, p = run_timed([exe] + common + rd_args(fq_tiny) + ["-S", "/dev/null"])
         if p.returncode != 0:
             log("[bench] cpu baseline failed:", p.stderr[-500:]); return None, None
         t_load.append(t)
     t_full = []
     al = None
     for k in range(3):
-        t, p = run_timed([exe] + common + ["-U", fq_all, "-S", ref_sam if k == 0 else "/dev/null"])
+        t, p = run_timed([exe] + common + rd_args(fq_all) + ["-S", ref_sam if k == 0 else "/dev/null"])
         if p.returncode != 0:
             log("[bench] cpu baseline failed:", p.stderr[-500:]); return None, None
         t_full.append(t)
@@ -306,14 +310,14 @@ def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, thre
     t_full.sort(); tl = min(t_load)
     search = t_full[1] - tl
     cb = {"value": (n_sample - n_tiny) / search, "unit": "reads/s", "cores": threads, "kind": "reference",
-          "sample": "%d of the same synthetic 150 bp reads, unmodified bowtie2-align-%s v2.5.5 (oracle/_ref, -O3, %s) %s -p %d --reorder; "
-                    "time = wall clock (median of 3: %s s) minus the wall clock of a %d-read run that is all index load (%.2f s); CPU: %s; "
-                    "overall alignment rate %s%%" % (n_sample, sfx, simd, preset, threads, "/".join("%.2f" % x for x in t_full), n_tiny, tl, cpu_model(),
-                                                     al.group(1) if al else "?")}
+          "sample": ("%d of the same synthetic 150 bp reads" + (" (as pairs, -1/-2)" if paired else "") + ", unmodified bowtie2-align-%s v2.5.5 (oracle/_ref, -O3, %s) %s -p %d --reorder; "
+                     "time = wall clock (median of 3: %s s) minus the wall clock of a %d-read run that is all index load (%.2f s); CPU: %s; "
+                     "overall alignment rate %s%%") % (n_sample, sfx, simd, preset, threads, "/".join("%.2f" % x for x in t_full), n_tiny, tl, cpu_model(),
+                                                      al.group(1) if al else "?")}
     # parity: the product binary (GPU) on the same FASTQ
     ours = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-%s" % sfx)
     our_sam = os.path.join(work, "sample.gpu.sam")
-    t, p = run_timed([ours] + common + ["-U", fq_all, "-S", our_sam])
+    t, p = run_timed([ours] + common + rd_args(fq_all) + ["-S", our_sam])
     par = {"parity_checked_reads": 0, "parity_identical": False}
     if p.returncode != 0:
         log("[bench] product binary failed on the parity sample:", p.stderr[-800:])
@@ -331,7 +335,7 @@ def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, thre
                     if x != y and len(names) < 200:
                         f.write(b"REF " + x + b"GPU " + y)
                         names.add(x.split(b"\t", 1)[0]); names.add(y.split(b"\t", 1)[0])
-            with open(fq_all, "rb") as f, open(os.path.join(dd, "reads.fq"), "wb") as g:
+            with open(fq_all if not paired else fq_all[0], "rb") as f, open(os.path.join(dd, "reads.fq"), "wb") as g:
                 while True:
                     rec = [f.readline() for _ in range(4)]
                     if not rec[0]:
@@ -552,17 +556,26 @@ def main():
         fm_ms = sum(v for k, v in kavg.items() if k != "k_align_reads")
         fm_bytes = (cnt.rank_queries * side + cnt.ftab_lookups * 2 * off_sz + cnt.sa_lookups * off_sz) / float(args.steps) + n * args.readlen * 2
         fm_achieved = fm_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("k_align_reads", n)
+        kname = "k_align_pairs" if args.paired else "k_align_reads"
+        traffic, traffic_src = pmc_traffic(kname, n)
         cb, par = None, None
-        if not args.no_cpu_baseline and world == 1 and not args.paired:      # reported at N=1 only (the paired mode is a kernel study, no CPU leg)
-            ns = min(args.cpu_sample, n)
+        if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
+            ns = min(args.cpu_sample, n) & ~1
             ntiny = 1000
             work = cache_dir()
-            fq_all, fq_tiny = os.path.join(work, "sample.fq"), os.path.join(work, "tiny.fq")
-            write_fastq_fixed(fq_all, seq[:ns], qual[:ns], names[:ns])
-            write_fastq_fixed(fq_tiny, seq[:ntiny], qual[:ntiny], names[:ntiny])
+            if args.paired:
+                # mates interleaved in the batch: read 2i = mate 1, 2i+1 = mate 2 of pair i
+                fq_all = (os.path.join(work, "sample_1.fq"), os.path.join(work, "sample_2.fq"))
+                fq_tiny = (os.path.join(work, "tiny_1.fq"), os.path.join(work, "tiny_2.fq"))
+                for m in (0, 1):
+                    write_fastq_fixed(fq_all[m], seq[m:ns:2], qual[m:ns:2], names[m:ns:2])
+                    write_fastq_fixed(fq_tiny[m], seq[m:ntiny:2], qual[m:ntiny:2], names[m:ntiny:2])
+            else:
+                fq_all, fq_tiny = os.path.join(work, "sample.fq"), os.path.join(work, "tiny.fq")
+                write_fastq_fixed(fq_all, seq[:ns], qual[:ns], names[:ns])
+                write_fastq_fixed(fq_tiny, seq[:ntiny], qual[:ntiny], names[:ntiny])
             cb, par = cpu_baseline_and_parity(base, large, fq_all, fq_tiny, ns, ntiny, threads, "--sensitive", work)
-            if par is not None and "parity_sample_aligned_reads" in par:
+            if par is not None and "parity_sample_aligned_reads" in par and not args.paired:
                 # the timed batch starts with the same reads, same parameters, same per-read seeds: its records must agree
                 par["timed_batch_aligned_reads_same_sample"] = int(h["aligned"][:ns].sum())
         res = {
@@ -599,7 +612,7 @@ def main():
                 "fm_kernels_sides_per_read": cnt.rank_queries / float(n * args.steps),
                 "sides_per_read": prof[8] / max(1, prof[9]),
             },
-            "roofline": {"bound": "hbm", "kernel": "k_align_reads", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": kern_ms,
                          "dp_gcups": dp_cells / (kern_ms * 1e-3) / 1e9,
