@@ -20,6 +20,7 @@ for (k, c), v in agg.items():
     short = k.split("<")[0].split("::")[-1]
     kern[short][c] = kern[short].get(c, 0) + v
     kern[short]["dispatches_" + c] = len(nd[(k, c)])
+launches = max([len(v) for (k, c), v in nd.items() if "k_align" in k] or [launches])      # dispatches actually profiled
 json.dump({"reads_per_launch": reads, "launches": launches, "unit": "FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them", "kernels": kern},
           open(O + "/pmc_traffic.json", "w"), indent=1)
 print(open(O + "/summary.csv").read())
