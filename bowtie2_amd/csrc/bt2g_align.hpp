@@ -3,7 +3,7 @@
 // Execution model on MI355X: ONE WAVEFRONT PER READ.  All 64 lanes run this control code in
 // lock-step on identical values (it is wave-uniform, so the compiler keeps most of it on the
 // scalar unit); the lanes only take different roles inside the explicitly wave-parallel
-// sections (the DP fill, row zeroing).  Per-read working state lives in a per-wave arena in
+// sections (the DP fill, the backtrace's tile fetches and diagonal runs, list and table scans).  Per-read working state lives in a per-wave arena in
 // HBM (`Work`), sized for 288 GB parts: nothing is allocated dynamically.
 //
 // What it restates (behaviour, not code) -- cited where each piece starts:
@@ -18,8 +18,9 @@
 //   RedundantAlns, EIvalMergeListBinned      aligner_result.cpp:929, ival_list.h
 //   AlnSinkWrap::report/finishRead/selectByScore, ReportingState          aln_sink.cpp
 //
-// Scope of this file: unpaired reads, end-to-end mode, -N 0, default -M
-// reporting (also -k N), reads up to kMaxLen.  Anything else is rejected up front by the host.
+// Scope: unpaired reads and pairs (bt2g_align_pe.inc), end-to-end and --local, -N 0/1, -M / -k / -a
+// reporting, reads up to kMaxLen.  Anything else is rejected up front by the host; a read that outgrows one of the fixed
+// capacities below is flagged in its result record.
 //
 // The same source also compiles for the host (tests/hostsim) -- there the wave-parallel
 // sections fall back to plain loops -- which is how the control logic was debugged against the
