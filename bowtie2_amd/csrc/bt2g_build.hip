@@ -195,3 +195,12 @@ int bt2g_build_cli_main(int argc, const char** argv, int large_default) {
 	if (rc == 0 && !DevBk::last_error().empty()) { fprintf(stderr, "bowtie2-build: %s\n", DevBk::last_error().c_str()); return 1; }
 	return rc;
 }
+
+// The reference's library-style entry point of the builder, same name and signature (bt2_build.cpp:556-560).  The index width
+// follows the program name in argv[0] ("...build-l" -> .bt2l), as for the executables; --large-index forces .bt2l.
+extern "C" int bowtie_build(int argc, const char** argv) {
+	const std::string me = argc > 0 && argv[0] ? argv[0] : "";
+	const size_t sl = me.find_last_of('/');
+	const std::string base = sl == std::string::npos ? me : me.substr(sl + 1);
+	return bt2g_build_cli_main(argc, argv, base.find("build-l") != std::string::npos ? 1 : 0);
+}

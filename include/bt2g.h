@@ -346,6 +346,9 @@ int bt2g_index_build_mem(const char *const *names, const char *const *seqs, cons
  * reader/worker threads are running ends the process from that thread, as in the reference.
  */
 int bowtie(int argc, const char **argv);
+/* Likewise for the index builder: the reference's `extern "C" int bowtie_build(int argc, const char **argv)` (bt2_build.cpp:556-560).
+ * argv[0] ending in "build-l" (or --large-index) selects the .bt2l format. */
+int bowtie_build(int argc, const char **argv);
 
 /* ---- instrumentation ---------------------------------------------------- */
 typedef struct {

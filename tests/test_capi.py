@@ -39,6 +39,9 @@ def test_bowtie_entry_point_returns_status():
     assert L.bowtie(4, argv) == 1
     argv = (C.c_char_p * 2)(b"bowtie2-align-s", b"--version")
     assert L.bowtie(2, argv) == 0
+    assert hasattr(L, "bowtie_build")
+    argv = (C.c_char_p * 2)(b"bowtie2-build-s", b"--no-such-option")
+    assert L.bowtie_build(2, argv) != 0
 
 
 def test_struct_layouts_match_header():
