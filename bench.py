@@ -469,10 +469,12 @@ def main():
                       khits=1, mhits=50, max_dp_streak=15, max_ug=300, max_dp=300, max_iters=400, n_seed_rounds=2,
                       seed_boost_thresh=300, tighten=3, maxhalf=15, nofw=0, norc=0, do_exact_upfront=1, do_1mm_upfront=1,
                       do_ungapped=1, do_extend=1, large_index=1 if info.off_size == 8 else 0)
+    P.max_seeds = 1 + max(0, args.readlen - L) // interval      # every read has this many seed positions per strand: with the bound given, bt2g_align_batch does not synchronise
     if args.paired:
         # default pair policy: --fr, -I 0 -X 500, mixed + discordant reporting, containment and overlap allowed (bt2_search.cpp:303-502)
         P.paired, P.pe_policy, P.pe_maxfrag, P.pe_minfrag, P.pe_flags, P.max_mate_streak = 1, 3, 500, 0, 2 | 4 | 8 | 32 | 64 | 128, 10
         interval = max(1, int(interval * 1.2 + 0.5))       # both mates pass their filters (bt2_search.cpp:3427-3434)
+        P.max_seeds = 1 + max(0, args.readlen - L) // interval
     # per-read parameters exactly as the drop-in binary derives them for these reads: minsc = (long)(-0.6 + -0.6*len),
     # nceil = 0.15*len, seed = genRandSeed(name, seq, qual) -- so the timed batch is the verified configuration
     minsc = int(-0.6 + -0.6 * args.readlen)

@@ -1967,9 +1967,10 @@ struct Aligner {
 				else if (offset == 0 && PRE && PRE->seeds && 1 + (len > (uint32_t)RPR.seedlen ? (len - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds) {
 					ninst = seed_round_pre(PRE->seeds, 0, interval, (uint32_t)RPR.seedlen);
 					ext_pre = PRE->ext != nullptr; pre_ext_cur = PRE->ext; pre_joff_cur = PRE->joff;
-				} else if (roundi > 0 && roundi < kMaxPreRounds && PRE && PRE->seeds_r[roundi] && PRE->seeds_r[roundi][(uint64_t)ridx * 2 * PRE->max_seeds].topf != ~0ull) {
+				} else if (roundi > 0 && roundi < kMaxPreRounds && PRE && PRE->seeds_r[roundi] && 1 + (len > offset + (uint32_t)RPR.seedlen ? (len - offset - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds &&
+				           PRE->seeds_r[roundi][(uint64_t)ridx * 2 * PRE->max_seeds].topf != ~0ull) {
 					// a re-seeding round the batch kernels searched (they saw the same "previous round was repetitive" condition:
-					// a read only gets here when it held); fewer seeds than round 0, so they fit the table
+					// a read only gets here when it held); a read with more seed positions than the tables hold searches them itself
 					ninst = seed_round_pre(PRE->seeds_r[roundi], offset, interval, (uint32_t)RPR.seedlen);
 					ext_pre = PRE->ext_r[roundi] != nullptr; pre_ext_cur = PRE->ext_r[roundi]; pre_joff_cur = PRE->joff_r[roundi];
 				} else ninst = seed_round(offset, interval, (uint32_t)RPR.seedlen);

@@ -332,11 +332,14 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	auto mark = [&](int i) { (void)hipEventRecord(c->ev[i], st); };
 	mark(0);
 	if (c->precomp) {
-		unsigned int max_seeds = 0;
-		e = launch_max_seeds(*reads, d_rparams, c->d_next + 8, st);
-		if (e == hipSuccess) e = hipMemcpyAsync(&max_seeds, c->d_next + 8, sizeof(max_seeds), hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess) e = hipStreamSynchronize(st);
-		if (e != hipSuccess) return hip_fail(c, e, "k_max_seeds");
+		unsigned int max_seeds = params->max_seeds > 0 ? (unsigned int)params->max_seeds : 0u;
+		if (max_seeds == 0) {
+			// no bound from the caller: count on the device and wait for the number (the only host-device round trip of a batch)
+			e = launch_max_seeds(*reads, d_rparams, c->d_next + 8, st);
+			if (e == hipSuccess) e = hipMemcpyAsync(&max_seeds, c->d_next + 8, sizeof(max_seeds), hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess) e = hipStreamSynchronize(st);
+			if (e != hipSuccess) return hip_fail(c, e, "k_max_seeds");
+		}
 		if (max_seeds < 1) max_seeds = 1;
 		if (max_seeds > 64) max_seeds = 64;       // kMaxOffs: longer seed lists are flagged by the worker
 		const uint32_t cap = 8;

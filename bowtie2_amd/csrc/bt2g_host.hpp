@@ -146,6 +146,7 @@ struct Options {
 		P.det_seeds = det_seeds ? 1 : 0;
 		P.seed_cache_mb = seed_cache_mb;
 		P.profile = 0;      // the drop-in binary never asks for the worker's phase timers
+		P.max_seeds = 0;    // set per batch by the driver (bt2g_search.cpp)
 		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
 		if (all_hits) {
 			// -a lifts every effort limit (bt2_search.cpp:3457-3463)

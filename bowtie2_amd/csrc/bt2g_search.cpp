@@ -237,7 +237,18 @@ static int run_search(int argc, char** argv) {
 				{
 					std::lock_guard<std::mutex> g(ctx_mu[d]);
 					auto ta = std::chrono::steady_clock::now();
-					int rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &P, b->max_len, d_res.p, st);
+					// the host derived every read's seed parameters, so it knows the widest seed table of the batch: with the bound in
+					// the parameters bt2g_align_batch does not have to wait for the device to count them
+					AlignParams Pb = P;
+					uint32_t max_seeds = 1;
+					for (size_t i = 0; i < n; i++) {
+						const uint32_t len = (uint32_t)(b->off[i + 1] - b->off[i]);
+						const uint32_t L = (uint32_t)b->rp[i].seedlen, iv = (uint32_t)(b->rp[i].interval > 0 ? b->rp[i].interval : 1);
+						const uint32_t ns = 1 + (len > L ? (len - L) / iv : 0u);
+						if (ns > max_seeds) max_seeds = ns;
+					}
+					Pb.max_seeds = (int32_t)(max_seeds > 64 ? 64 : max_seeds);      // kMaxOffs: the worker flags reads beyond it
+					int rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &Pb, b->max_len, d_res.p, st);
 					if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
 					rc = bt2g_results_pack(ctx, d_res.p, (uint32_t)n, (uint32_t)P.khits, d_packed.p, (uint64_t*)d_poff.p, st);
 					if (rc) die(std::string("bt2g_results_pack: ") + bt2g_last_error(ctx));

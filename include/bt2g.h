@@ -222,6 +222,10 @@ typedef struct {
 	                                  reads with millions of seed-hit rows is part of its output (0 = 20)                       */
 	int32_t profile;               /* 1: the worker reads the device clock around every phase (what bt2g_align_profile_read reports);
 	                                  0: no clock reads, the time slots of the profile stay 0                                    */
+	int32_t max_seeds;             /* > 0: an upper bound the caller vouches for on the seed positions per strand of any read in the batch
+	                                  (1 + (len - seedlen) / interval for every read): bt2g_align_batch sizes its seed tables from it and
+	                                  returns WITHOUT synchronising the stream (reads that exceed it are searched inline by the worker, still
+	                                  exact).  0: the bound is computed on the device and bt2g_align_batch waits for it (one 4-byte D2H)   */
 } bt2g_align_params;
 #define BT2G_PE_DOVETAIL_OK  1     /* --dovetail                       */
 #define BT2G_PE_CONTAIN_OK   2     /* cleared by --no-contain          */
