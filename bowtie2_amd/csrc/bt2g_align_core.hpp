@@ -2002,6 +2002,8 @@ struct Aligner {
 	// AlnSinkWrap::finishRead for an unpaired read (aln_sink.cpp:643-1384): ReportingState::finish,
 	// getReport, selectByScore (RNG!), and what the SAM line needs.
 	BT2_HDN void finish(ReadResult& out) {
+		// -a: the reference reports every alignment found; this build's result record holds khits (64) of them
+		if (PRM.all_hits && HOT.n_alns > (uint32_t)PRM.khits) ovf(32);
 		out.status = (uint8_t)HOT.err;
 		out.filt = (uint8_t)RPR.filt;
 		out.exhausted = 0;
