@@ -633,8 +633,7 @@ def main():
                                                       "bt_tile_fetch", "gather_lastrow", "gather_zero_masks", "prioritize_collect_extend", "prioritize_row_sampling", "sink_report"],
                                                      [round(prof[i] / 100.0 / max(1, prof[9]), 1) for i in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 16, 17, 18, 19, 20, 21)])),
                 "worker_counts_per_read": {"bt_steps": prof[13] / max(1, prof[9]), "bt_tiles": prof[14] / max(1, prof[9]), "cand_cells": prof[15] / max(1, prof[9]),
-                                           "sampled_rows": (prof[23] & 0xffffffff) / max(1, prof[9]), "sampled_rows_seen_list": (prof[23] >> 32) / max(1, prof[9]),
-                                           "random1ton_next_us": round(prof[22] / 100.0 / max(1, prof[9]), 1)},
+                                           "sampled_rows": (prof[23] & 0xffffffff) / max(1, prof[9]), "sampled_rows_seen_list": (prof[23] >> 32) / max(1, prof[9])},
                 "kernel_ms_per_step": {k: round(v, 3) for k, v in kavg.items()}, "batch_ms_events": round(batch_ms, 3),
                 "fm_kernels_sides_per_read": cnt.rank_queries / float(n * args.steps),
                 "sides_per_read": prof[8] / max(1, prof[9]),

@@ -674,17 +674,17 @@ struct Aligner {
 		r.thresh = (uint16_t)(th > 0xffffu ? 0xffffu : th);      // only ever compared with seen_len <= max_iters
 		r.inited = 1;
 	}
-	BT2_HDN uint32_t r1c_next(uint32_t which) {
-		// The record is taken by index and worked on in registers (a reference parameter would make every field access a FLAT
-		// load, and a record left in LDS is re-read after every store to the lists); written back once.
-		R1C r = HOT.samp.r[which];
+	// One draw.  `r` is the caller's REGISTER copy of the range's record and `g` its copy of the RNG (the sampling loop keeps
+	// both, and its counters, out of LDS for the whole loop: every LDS access of the draw is a round trip the next instruction
+	// waits for, and they used to be ~40 per draw).
+	BT2_HD uint32_t r1c_next(R1C& r, Rng& g) {
 		uint32_t* const lists = w.lists;
 		uint32_t ret;
 		const bool first = r.cur == 0 && !r.converted;
 		if (first && r.n == 1) { r.cur = 1; ret = 0; }
 		else if (r.swaplist) {
 			if (first) { r.list_off = lists_alloc(r.n); Plat::iota_u32(lists + r.list_off, r.n); }
-			const uint32_t rr = r.cur + (rnd.nextU32() % (r.n - r.cur));
+			const uint32_t rr = r.cur + (g.nextU32() % (r.n - r.cur));
 			uint32_t* l = lists + r.list_off;
 			const uint32_t a = gld(l + r.cur), b = gld(l + rr);
 			if (rr != r.cur) { gst(l + r.cur, b); gst(l + rr, a); }
@@ -696,7 +696,7 @@ struct Aligner {
 			uint32_t* seen = lists + r.seen_off;
 			const uint32_t seen_sz = r.seen_len;
 			uint32_t rn;
-			do { rn = rnd.nextU32() % r.n; } while (Plat::contains_u32(seen, seen_sz, rn));
+			do { rn = g.nextU32() % r.n; } while (Plat::contains_u32(seen, seen_sz, rn));
 			ret = rn;
 			if (r.seen_len >= room) { ovf(29); r.cur++; }
 			else {
@@ -712,7 +712,6 @@ struct Aligner {
 				}
 			}
 		}
-		HOT.samp.r[which] = r;
 		return ret;
 	}
 
@@ -975,48 +974,64 @@ struct Aligner {
 		};
 		if (fast) rebuild();
 		const uint64_t ts_ = now();
+		if (fast) {
+			// loop state in registers: RNG, total mass, list length, profile counts; written back once
+			Rng g = rnd;
+			double mass = HOT.mass;
+			uint32_t n_satpos = HOT.n_satpos;
+			const uint32_t n_full = HOT.n_satpos_full, n_masses = HOT.n_masses;
+			SampRow* const srows = w.srows;
+			const SatPos* const sat2 = w.satpos2;
+			const bool all_hits = PRM.all_hits != 0;
+			uint64_t draws = 0;
+			bool full = false;
+			while (nelt_added < maxelt && nelt_added < nelt) {
+				// RowSampler::next
+				const double rd = (double)(g.nextFloat() * mass);
+				const uint32_t pick = Plat::pick_mass(HOT.samp.prefix, HOT.samp.elim, n_masses, rd);
+				const uint32_t ri = pick + sai;
+				R1C r2 = HOT.samp.r[pick];
+				if (!r2.inited) { r1c_init(r2, gld(&sat2[ri].size), all_hits); r2.topf = gld(&sat2[ri].topf); }
+				draws += r2.swaplist ? 1ull : (1ull | (1ull << 32));      // profile: draws | draws on the seen-list path << 32
+				const uint32_t r = r1c_next(r2, g);
+				HOT.samp.r[pick] = r2;
+				if (r2.n > 0 && r2.cur >= r2.n) {      // the range is used up: out of the sampler
+					w.elim[ri - sai] = 1; mass -= w.masses[ri - sai];
+					rebuild();
+				}
+				if (n_satpos >= (uint32_t)kMaxSatpos) { full = true; break; }
+				SampRow* const sr = &srows[n_satpos - n_full];
+				n_satpos++;
+				gst(&sr->topf, (uint64_t)(r2.topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
+				nelt_added++;
+			}
+			rnd = g; HOT.mass = mass; HOT.n_satpos = n_satpos;
+			HOT.t_phase[21] += draws;
+			if (full) ovf(13);
+		} else
 		while (nelt_added < maxelt && nelt_added < nelt) {
-			// RowSampler::next
+			// RowSampler::next, more ranges than the on-chip sampler holds (-N 1): everything through the arena
 			const double rd = (double)(rnd.nextFloat() * HOT.mass);
 			uint32_t pick = 0xffffffffu;
-			if (fast) pick = Plat::pick_mass(HOT.samp.prefix, HOT.samp.elim, HOT.n_masses, rd);
-			else {
-				double mass_sofar = 0.0;
-				uint32_t last_unelim = 0xffffffffu;
-				for (uint32_t i = 0; i < HOT.n_masses; i++) {
-					if (!w.elim[i]) {
-						last_unelim = i;
-						mass_sofar += w.masses[i];
-						if (rd < mass_sofar) { pick = i; break; }
-					}
+			double mass_sofar = 0.0;
+			uint32_t last_unelim = 0xffffffffu;
+			for (uint32_t i = 0; i < HOT.n_masses; i++) {
+				if (!w.elim[i]) {
+					last_unelim = i;
+					mass_sofar += w.masses[i];
+					if (rd < mass_sofar) { pick = i; break; }
 				}
-				if (pick == 0xffffffffu) pick = last_unelim;
 			}
+			if (pick == 0xffffffffu) pick = last_unelim;
 			const uint32_t ri = pick + sai;
-			uint32_t r;
-			bool exhausted;
-			uint64_t row_topf;
-			if (fast) {
-				R1C& r2 = HOT.samp.r[pick];
-				if (!r2.inited) { r1c_init(r2, w.satpos2[ri].size, PRM.all_hits != 0); r2.topf = w.satpos2[ri].topf; }
-				const uint64_t tn_ = now();
-				HOT.t_phase[21] += r2.swaplist ? 1ull : (1ull | (1ull << 32));      // profile: draws | draws on the seen-list path << 32
-				r = r1c_next(pick);
-				HOT.t_phase[20] += now() - tn_;      // profile: Random1toN::next
-				exhausted = r2.n > 0 && r2.cur >= r2.n;
-				row_topf = r2.topf;
-			} else {
-				R1N& r2 = w.rands2[ri];
-				if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, PRM.all_hits != 0);
-				r = r1n_next(r2);
-				exhausted = r1n_done(r2);
-				row_topf = w.satpos2[ri].topf;
-			}
-			if (exhausted) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; if (fast) rebuild(); }
+			R1N& r2 = w.rands2[ri];
+			if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, PRM.all_hits != 0);
+			const uint32_t r = r1n_next(r2);
+			if (r1n_done(r2)) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; }
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(13); break; }
 			SampRow* const sr = &w.srows[HOT.n_satpos - HOT.n_satpos_full];
 			HOT.n_satpos++;
-			gst(&sr->topf, (uint64_t)(row_topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
+			gst(&sr->topf, (uint64_t)(w.satpos2[ri].topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
 			nelt_added++;
 		}
 		HOT.t_phase[18] += now() - ts_;       // profile: the row-sampling loop
