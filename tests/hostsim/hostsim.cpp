@@ -271,6 +271,10 @@ struct HostPlat {
 	static int64_t fill_ee_u8_band(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, const DpScratch& dp, int64_t minsc) {
 		EeBand band;
 		if (!ee_band(P.rfgapo, P.rfgape, rows, cols, minsc, band)) return -0xff;
+		// test hook (tests/test_band_fill.py): fill every diagonal of the rectangle instead of the band -- the two must agree on
+		// everything the worker can observe
+		static const bool full_rect = getenv("BT2G_HOST_FULL_RECT") != nullptr;
+		if (full_rect) { band.lo = (int32_t)rows - 1; band.nd = rows + cols - 1; }
 		const uint32_t rp = ee_band_rp(band.nd);
 		if (rp == 0) return INT64_MIN;
 		const int32_t lo = band.lo;
