@@ -163,6 +163,7 @@ inline std::string apply_policy_string(Options& opt, const std::string& pol) {
 
 // Returns "" on success, else the error text (exit code 1).
 inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) {
+	bool saw_bam = false;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		std::string inline_val;
@@ -212,8 +213,9 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "-u" || a == "--upto" || a == "--qupto") { opt.upto = strtoull(need().c_str(), nullptr, 10); if (opt.upto == 0) opt.upto = UINT64_MAX; }
 		else if (a == "-5" || a == "--trim5") opt.trim5 = atoi(need().c_str());
 		else if (a == "-3" || a == "--trim3") opt.trim3 = atoi(need().c_str());
-		else if (a == "--phred33" || a == "--phred33-quals") opt.phred64 = false;
-		else if (a == "--phred64" || a == "--phred64-quals") opt.phred64 = true;
+		else if (a == "--phred33" || a == "--phred33-quals") { opt.phred64 = false; opt.solexa_quals = false; }      // bt2_search.cpp:1176
+		else if (a == "--phred64" || a == "--phred64-quals" || a == "--solexa1.3-quals") opt.phred64 = true;
+		else if (a == "--solexa-quals") opt.solexa_quals = true;
 		else if (a == "--seed") opt.seed = (uint32_t)strtoul(need().c_str(), nullptr, 10);
 		else if (a == "--nofw") opt.nofw = true;
 		else if (a == "--norc") opt.norc = true;
@@ -319,13 +321,25 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--rdg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rdg"; else { opt.rdg_const = iv[0]; opt.rdg_linear = iv.size() > 1 ? iv[1] : 3; } }   // a missing extension penalty falls back to the default (aligner_seed_policy.cpp:490-500)
 		else if (a == "--rfg") { if (!split_ints(need(), ',', iv) || iv.size() > 2) err = "bad --rfg"; else { opt.rfg_const = iv[0]; opt.rfg_linear = iv.size() > 1 ? iv[1] : 3; } }
 		else if (a.size() > 2 && a.substr(0, 2) == "--" && !has_inline && opt.apply_preset(a.substr(2))) {}
-		else if (a == "-b" ||
-		         a == "--int-quals" || a == "--solexa-quals")
-			return "option " + a + " is outside the MI355X hot path implemented so far (unpaired FASTQ/FASTA/raw reads, -k <= 64)";
+		else if (a == "--int-quals" || a == "--integer-quals")
+			// the reference's own parser folds the separating blank into the next number and aborts with "Saw negative Phred quality"
+			// on any record with two or more values (pat.cpp:1191-1204); there is no behaviour to reproduce
+			return "option " + a + " is not supported (bowtie2's parser aborts on space-separated integer qualities)";
+		else if (a == "-b") { opt.format = 7; saw_bam = true; }
+		else if (a == "--preserve-tags") { opt.preserve_tags = true; }
+		else if (a == "--align-paired-reads") { opt.align_paired_reads = true; }
+		else if (a == "--sam-append-comment") opt.sam_append_comment = true;
+		else if (a == "--soft-clipped-unmapped-tlen") opt.sc_unmapped = true;
 		else return "unsupported option " + a;
 		if (!err.empty()) return err;
 	}
 	if (opt.khits > 64) return "-k above 64 is not supported by this build";
+	// bt2_search.cpp:1699-1718, 1804-1807
+	if (!opt.local && opt.sc_unmapped) return "ERROR: --soft-clipped-unmapped-tlen can only be set for local alignments.";
+	if (!saw_bam && opt.preserve_tags) return "--preserve_tags can only be used when aligning BAM reads.";
+	if (!saw_bam && opt.align_paired_reads) return "--align-paired-reads can only be used when aligning BAM reads.";
+	if (opt.sam_append_comment && opt.format != 0 && opt.format != 1) return "Error --sam-append-comment only works with FASTA (-f) and FASTQ (-q) formats. ";
+	if (opt.format == 7 && !opt.interleaved_file.empty()) return "-b with --interleaved is not supported by this build (give the BAM file to -1 and -2 with --align-paired-reads)";
 	if (opt.det_seeds) {      // bt2_search.cpp:1778-1791
 		if (!opt.no_exact_upfront || !opt.no_1mm_upfront) return "Error: -d must be used with --no-exact-upfront and --no-1mm-upfront.";
 		if (!opt.all_hits) return "Error: -d can only be used with -a.";

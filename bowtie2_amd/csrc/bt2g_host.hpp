@@ -14,6 +14,7 @@
 #ifndef BT2G_HOST_HPP_
 #define BT2G_HOST_HPP_
 
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -69,7 +70,12 @@ struct Options {
 	bool nofw = false, norc = false;
 	bool sam_no_qname_trunc = false;
 	bool qc_filter = false, ignore_quals = false, no_1mm_upfront = false, xeq = false, omit_sec_seq = false, phred64 = false;
-	int format = 0;               // 0 FASTQ, 1 FASTA (-f), 2 raw (-r), 3 -c, 4 tab5/6, 5 qseq, 6 FASTA-continuous (-F)
+	bool solexa_quals = false;           // --solexa-quals: 64-based Solexa (log-odds) quality characters (qual.h:105-123)
+	int format = 0;               // 0 FASTQ, 1 FASTA (-f), 2 raw (-r), 3 -c, 4 tab5/6, 5 qseq, 6 FASTA-continuous (-F), 7 unaligned BAM (-b)
+	bool preserve_tags = false;   // --preserve-tags: a BAM record's optional fields are printed after the aligner's (pat.cpp:1503, sam.cpp:881)
+	bool align_paired_reads = false;   // --align-paired-reads: take the paired records of a BAM file instead of the unpaired ones (pat.cpp:1417-1427)
+	bool sam_append_comment = false;   // --sam-append-comment: the FASTA/FASTQ comment (name after the first blank) closes the SAM record (sam.h:415)
+	bool sc_unmapped = false;     // --soft-clipped-unmapped-tlen: TLEN without the soft-clipped ends (aligner_result.h:894-909)
 	int fc_len = 0, fc_freq = 1;  // -F k:<len>,i:<freq>
 	int trim5 = 0, trim3 = 0;
 	int trim_to_side = 3, trim_to_len = -1;   // --trim-to [3:|5:]<len>
@@ -185,6 +191,7 @@ struct ReadRec {
 	StrView seq;        // codes 0..4
 	StrView qual;       // ASCII phred+33
 	StrView orig;       // --passthrough: the record's original text (Read::readOrigBuf)
+	StrView tags;       // --preserve-tags: the optional fields of the BAM record, in BAM's binary form (Read::preservedOptFlags)
 	char filter = '1';  // QSEQ filter field ('0' = failed the instrument's QC; --qc-filter)
 };
 
@@ -368,9 +375,10 @@ struct MateOut {
 };
 
 // TLEN (AlnRes::setFragmentLength, aligner_result.h:1311-1345): extents include soft-trimmed bases
-inline int64_t sam_fragment_length(const AlnRes& a, const AlnRes& b, bool a_is_mate1) {
-	auto ext = [](const AlnRes& r, int64_t& st, int64_t& en) {
+inline int64_t sam_fragment_length(const AlnRes& a, const AlnRes& b, bool a_is_mate1, bool sc_unmapped = false) {
+	auto ext = [sc_unmapped](const AlnRes& r, int64_t& st, int64_t& en) {
 		st = r.refoff; en = r.refoff + (int64_t)r.rfextent - 1;
+		if (sc_unmapped) return;          // --soft-clipped-unmapped-tlen (getExtendedCoords, aligner_result.h:900)
 		st -= r.fw ? r.trim5p : r.trim3p;
 		en += r.fw ? r.trim3p : r.trim5p;
 	};
@@ -382,6 +390,81 @@ inline int64_t sam_fragment_length(const AlnRes& a, const AlnRes& b, bool a_is_m
 	const int64_t lo = std::min(st, ost), hi = std::max(en, oen);
 	const int64_t fl = 1 + hi - lo;
 	return up ? fl : -fl;
+}
+
+
+// --preserve-tags: the optional fields of a BAM record as SAM text (SamConfig::printPreservedOptFlags, sam.cpp:881-955).
+// Integer types all print as "i"; a B array prints its element type and the comma-separated values; anything else ends the field list
+// the way the reference's switch falls through (no value, next tag read from the following byte).
+inline void sam_print_bam_tags(std::string& o, const StrView& t) {
+	const char* b = t.data();
+	size_t i = 0;
+	const size_t len = t.size();
+	uint32_t count = 1;                  // a B array's length stays in force for the fields after it, as in the reference
+	auto put = [&](auto proto) {
+		typedef decltype(proto) T;
+		for (uint32_t k = 0; k < (count ? count : 1u); k++) {
+			if (i + (k + 1) * sizeof(T) > len) break;          // (the reference reads on past the record here)
+			T v; memcpy(&v, b + i + k * sizeof(T), sizeof(T));
+			o += std::to_string(v);
+			if (k + 1 < count) o.push_back(',');
+		}
+		i += sizeof(T) * count;
+	};
+	while (i + 3 <= len) {
+		o.push_back('\t');
+		o.append(b + i, 2); i += 2;
+		char ty = b[i];
+		if (ty == 'B') {
+			ty = b[i + 1]; i += 2;
+			memcpy(&count, b + i, 4); i += 4;
+			o += ":B:"; o.push_back(ty); o.push_back(',');
+		} else {
+			o.push_back(':');
+			o.push_back((ty == 'c' || ty == 'C' || ty == 'i' || ty == 'I' || ty == 's' || ty == 'S') ? 'i' : ty);
+			i += 1;
+			o.push_back(':');
+		}
+		switch (ty) {
+			case 'A': put((char)0); break;
+			case 'c': put((int8_t)0); break;
+			case 'C': put((uint8_t)0); break;
+			case 's': put((int16_t)0); break;
+			case 'S': put((uint16_t)0); break;
+			case 'i': put((int32_t)0); break;
+			case 'I': put((uint32_t)0); break;
+			case 'f': put((float)0); break;
+			case 'Z': while (i < len && b[i]) o.push_back(b[i++]); i++; break;
+			default: break;
+		}
+	}
+}
+
+// --sam-append-comment (SamConfig::printComment / isIllumina, sam.h:415-463): what follows the first blank of the read name closes the
+// record; a CASAVA 1.8 comment "<1|2>:<Y|N>:<even number>:<barcode>" gets the BC:Z: tag name, anything else is taken as written
+inline void sam_print_comment(std::string& o, const StrView& name) {
+	size_t i = 0;
+	while (i < name.size() && !isspace((unsigned char)name[i])) i++;
+	o.push_back('\t');
+	if (i >= name.size()) return;
+	const std::string c(name.data() + i + 1, name.size() - i - 1);
+	bool illumina = true;
+	{
+		int field = 0;
+		size_t start = 0;
+		for (size_t e = 0; e < c.size() && c[e] != ' ' && illumina; e++) {
+			if (c[e] != ':') continue;
+			const std::string f = c.substr(start, e - start);
+			char* endp = nullptr;
+			if (field == 0) { const long v = strtol(f.c_str(), &endp, 10); if (*endp || (v != 1 && v != 2)) illumina = false; }
+			else if (field == 1) { if (c[start] != 'N' && c[start] != 'Y') illumina = false; }
+			else if (field == 2) { const long v = strtol(f.c_str(), &endp, 10); if (*endp || v % 2 != 0) illumina = false; }
+			else illumina = false;
+			start = e + 1; field++;
+		}
+	}
+	if (illumina) o += "BC:Z:";
+	o += c;
 }
 
 inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, const ReadRec& rd,
@@ -481,7 +564,7 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		if (mo->rso && aln->refid != mo->rso->refid) { sam_print_name(o, ref.names[mo->rso->refid], true); o.push_back('\t'); } else o += "=\t";
 		app_int(o, (mo->rso ? mo->rso->refoff : aln->refoff) + 1); o.push_back('\t');
 		// fragment length only for pairs (setMateParams with the other mate), on the same reference or concordant
-		if (mo->kind != 0 && mo->rso && (aln->refid == mo->rso->refid || mo->kind == 1)) app_int(o, sam_fragment_length(*aln, *mo->rso, mo->mate1));
+		if (mo->kind != 0 && mo->rso && (aln->refid == mo->rso->refid || mo->kind == 1)) app_int(o, sam_fragment_length(*aln, *mo->rso, mo->mate1, opt.sc_unmapped));
 		else o.push_back('0');
 		o.push_back('\t');
 	} else if (mo && mo->orefid != -1) { o += "=\t"; app_int(o, mo->orefoff + 1); o += "\t0\t"; }
@@ -557,6 +640,8 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		if (flag[0]) { o += "\tYF:Z:"; o += flag; }
 	}
 	if (!opt.rg_optflag.empty()) { o.push_back('\t'); o += opt.rg_optflag; }
+	if (!rd.tags.empty()) sam_print_bam_tags(o, rd.tags);
+	if (opt.sam_append_comment) sam_print_comment(o, rd.name);
 	o.push_back('\n');
 	if (opt.passthrough) {      // samc_.passthrough() (aln_sink.cpp:2118): newlines and '%' percent-encoded (sam.h:290)
 		for (size_t i = 0; i < rd.orig.size(); i++) {

@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <deque>
 #include <fstream>
@@ -92,7 +93,7 @@ private:
 
 // One batch travelling through the pipeline
 struct HostBatch {
-	struct Chunk { std::string names, seq, qual, orig, error; };   // arenas of 4096 reads: names stay here, seq/qual are copied to the packed arrays
+	struct Chunk { std::string names, seq, qual, orig, tags, error; };   // arenas of 4096 reads: names stay here, seq/qual are copied to the packed arrays
 	std::vector<Chunk> chunks;
 	std::vector<ReadRec> reads;                       // views into `chunks` (names) and `seq`/`qual` (packed arrays)
 	std::vector<uint8_t> seq, qual;       // packed device arrays
@@ -228,11 +229,72 @@ private:
 	bool eof_ = false;
 };
 
+// Byte stream over a list of BAM files.  BAM is a series of BGZF blocks = concatenated gzip members, which gzread() inflates one after
+// the other (the reference walks the blocks itself, BAMPatternSource::nextBGZFBlockFromFile, pat.cpp:1270-1323; the empty end-of-file
+// block inflates to nothing either way).
+class BamStream {
+public:
+	explicit BamStream(const std::string& path) {
+		for (size_t a = 0; a <= path.size();) { size_t b = path.find(',', a); if (b == std::string::npos) b = path.size(); if (b > a) paths_.push_back(path.substr(a, b - a)); a = b + 1; }
+		// Of a comma-separated list the reference reads the first file only: BAMPatternSource::nextBatch (pat.cpp:1325-1360) reports the end
+		// of the input at the first file's last block and never opens the next one.  Same here, so that the output is the same.
+		if (paths_.size() > 1) paths_.resize(1);
+	}
+	~BamStream() { if (f_) gzclose(f_); }
+	// positions the stream on the first alignment record of the next file that has one; false when the list is exhausted
+	bool next_file(std::string& err) {
+		if (f_) { gzclose(f_); f_ = nullptr; }
+		if (next_ >= paths_.size()) return false;
+		const std::string& p = paths_[next_++];
+		f_ = p == "-" ? gzdopen(0, "rb") : gzopen(p.c_str(), "rb");
+		if (!f_) { err = "cannot open reads file " + p; return false; }
+		gzbuffer(f_, 1 << 20);
+		// magic, header text, reference dictionary (get_alignments, pat.cpp:1366-1385)
+		char magic[4]; uint32_t l_text = 0, nref = 0;
+		std::string skip;
+		if (!read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { err = "reads file " + p + " is not a BAM file"; return false; }
+		if (!read(&l_text, 4) || !read_skip(l_text) || !read(&nref, 4)) { err = "truncated BAM header in " + p; return false; }
+		for (uint32_t j = 0; j < nref; j++) {
+			uint32_t l_name = 0;
+			if (!read(&l_name, 4) || !read_skip((size_t)l_name + 4)) { err = "truncated BAM header in " + p; return false; }
+		}
+		return true;
+	}
+	bool open() const { return f_ != nullptr; }
+	// exactly n bytes, or false (clean end of file when nothing was left; `partial` tells a record cut short)
+	bool read(void* dst, size_t n) {
+		partial_ = false;
+		size_t got = 0;
+		while (got < n) {
+			const int r = gzread(f_, (char*)dst + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
+			if (r < 0) { io_error_ = true; return false; }
+			if (r == 0) { partial_ = got > 0; return false; }
+			got += (size_t)r;
+		}
+		return true;
+	}
+	bool partial() const { return partial_; }
+	bool io_error() const { return io_error_; }
+private:
+	bool read_skip(size_t n) { tmp_.resize(n); return n == 0 || read(&tmp_[0], n); }
+	std::vector<std::string> paths_;
+	size_t next_ = 0;
+	gzFile f_ = nullptr;
+	bool partial_ = false, io_error_ = false;
+	std::string tmp_;
+};
+
 // FASTQ records following FastqPatternSource::parse (pat.cpp): 4-line records, '.' -> N, non-letters dropped
 class FastqBatcher {
 public:
-	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_(opt.format == 3 ? std::string("/dev/null") : path), cmd_(path), opt_(opt), threads_(threads) { unit_ = (!opt.interleaved_file.empty() && path == opt.interleaved_file) ? 2 : 1; }
-	bool ok() const { return src_.ok(); }
+	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_((opt.format == 3 || opt.format == 7) ? std::string("/dev/null") : path), cmd_(path), bam_(opt.format == 7 ? path : std::string()), opt_(opt), threads_(threads) {
+		unit_ = (!opt.interleaved_file.empty() && path == opt.interleaved_file) ? 2 : 1;
+		if (opt.format == 7) bam_ok_ = bam_.next_file(bam_err_);
+	}
+	bool ok() const { return opt_.format == 7 ? (bam_ok_ || bam_err_.empty()) : src_.ok(); }
+	// -b with -1/-2: which mate's records this source keeps (--align-paired-reads: flag 0x40 for mate 1, 0x80 for mate 2, pat.cpp:1422-1427)
+	void set_bam_mate(int m) { bam_mate_ = m; }
+	std::string open_error(const std::string& dflt) const { return bam_err_.empty() ? dflt : bam_err_; }
 
 	double t_split = 0, t_parse = 0, t_pack = 0;      // seconds spent in each part of next() (-t)
 	// Fill `b` with up to max_reads reads; sets b.last at end of input (or at -u).
@@ -353,6 +415,47 @@ public:
 				r.seq_off = arena_.size(); r.seq_len = sq.size(); arena_.append(sq);
 				r.qual_off = arena_.size(); r.qual_len = ql.size(); arena_.append(ql); r.has_qual = true;
 				r.filter = fl[0];
+			} else if (opt_.format == 7) {             // -b: unaligned BAM (BAMPatternSource::get_alignments / parse, pat.cpp:1362-1515)
+				bool got = false;
+				while (bam_ok_ && !got) {
+					uint32_t block_size = 0;
+					if (!bam_.read(&block_size, 4)) {
+						if (bam_.partial() || bam_.io_error()) { b.bad_input = "error while reading the BAM file (truncated or corrupt)"; break; }
+						bam_ok_ = bam_.next_file(bam_err_);
+						if (!bam_ok_ && !bam_err_.empty()) b.bad_input = bam_err_;
+						continue;
+					}
+					if (block_size == 0) { bam_ok_ = bam_.next_file(bam_err_); if (!bam_ok_ && !bam_err_.empty()) b.bad_input = bam_err_; continue; }
+					bam_rec_.resize(block_size);
+					if (block_size < 32 || !bam_.read(&bam_rec_[0], block_size)) { b.bad_input = "error while reading the BAM file (truncated or corrupt)"; break; }
+					uint16_t flag; memcpy(&flag, bam_rec_.data() + 14, 2);
+					// only unaligned records are reads; unpaired ones by default, with --align-paired-reads the paired ones of this source's mate
+					if (!(flag & 0x4)) continue;
+					if (!opt_.align_paired_reads && (flag & 0x1)) continue;
+					if (opt_.align_paired_reads && bam_mate_ && !(flag & (bam_mate_ == 1 ? 0x40 : 0x80))) continue;
+					const uint8_t l_read_name = (uint8_t)bam_rec_[8];
+					uint16_t n_cigar; memcpy(&n_cigar, bam_rec_.data() + 12, 2);
+					int32_t l_seq; memcpy(&l_seq, bam_rec_.data() + 16, 4);
+					size_t off = 32;
+					const size_t need = off + l_read_name + 4u * n_cigar + (size_t)((l_seq + 1) / 2) + (size_t)l_seq;
+					if (l_seq < 0 || l_read_name == 0 || need > block_size) { b.bad_input = "malformed BAM record"; break; }
+					r.name_off = arena_.size(); r.name_len = (size_t)l_read_name - 1; arena_.append(bam_rec_.data() + off, r.name_len);
+					off += l_read_name + 4u * n_cigar;
+					const unsigned char* sq = (const unsigned char*)bam_rec_.data() + off;
+					off += (size_t)((l_seq + 1) / 2);
+					r.seq_off = arena_.size(); r.seq_len = (size_t)l_seq;
+					// 4-bit codes; everything but A/C/G/T becomes N downstream, as asc2dna does (pat.cpp:1494-1495): '=' is spelled N here
+					for (int32_t k = 0; k < l_seq; k++) arena_.push_back("NACMGRSVTWYHKDBN"[(sq[k / 2] >> (4 * (1 - (k % 2)))) & 0xf]);
+					r.qual_off = arena_.size(); r.qual_len = (size_t)l_seq; r.has_qual = true;
+					for (int32_t k = 0; k < l_seq; k++) arena_.push_back((char)(bam_rec_[off + (size_t)k] + 33));
+					off += (size_t)l_seq;
+					r.tag_off = arena_.size(); r.tag_len = opt_.preserve_tags ? block_size - off : 0;
+					if (r.tag_len) arena_.append(bam_rec_.data() + off, r.tag_len);
+					if (pt) orig_.append(bam_rec_.data(), block_size);
+					got = true;
+				}
+				if (!got) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 			} else if (opt_.format == 6) {             // -F k:<len>,i:<freq>: every <freq>-th <len>-mer of a FASTA file (FastaContinuousPatternSource, pat.cpp:913-1036)
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
 				bool emitted = false;
@@ -419,6 +522,8 @@ public:
 		b.rp.resize(nrec);
 		b.chunks.assign(nchunks, HostBatch::Chunk());
 		std::vector<uint32_t> name_off(nrec), name_len(nrec), rlen(nrec), orig_off(pt ? nrec : 0), orig_len(pt ? nrec : 0);
+		const bool tg = opt_.preserve_tags;
+		std::vector<uint32_t> tag_off(tg ? nrec : 0), tag_len(tg ? nrec : 0);
 		parallel_for(nchunks, threads_, [&](size_t c) {
 			HostBatch::Chunk& ch = b.chunks[c];
 			std::string tseq, tqual;
@@ -430,7 +535,16 @@ public:
 				for (size_t k = 0; k < r.seq_len; k++) { char chh = s[k]; if (chh == '.') chh = 'N'; if (isalpha((unsigned char)chh)) tseq.push_back((char)asc2code(chh)); }
 				if (r.has_qual) {
 					tqual.assign(arena_.data() + r.qual_off, r.qual_len);
-					if (opt_.phred64) for (char& q : tqual) q = (char)((int)q - 64 + 33 < 33 ? 33 : (int)q - 64 + 33);
+					if (opt_.format == 7) {}          // BAM qualities are Phred values, whatever scale options say (pat.cpp:1493)
+					else if (opt_.solexa_quals) {
+						// charToPhred33 with solQuals (qual.h:112-123): Solexa log-odds Q_s = c - 64 -> Phred = 10 log10(1 + 10^(Q_s/10)), rounded;
+						// the two scales agree from 10 up, and anything below -10 is Phred 0
+						for (char& q : tqual) {
+							const int sol = (int)q - 64;
+							const int ph = sol >= 10 ? sol : sol < -10 ? 0 : (int)(10.0 * log10(1.0 + pow(10.0, sol / 10.0)) + 0.5);
+							q = (char)(ph + 33);
+						}
+					} else if (opt_.phred64) for (char& q : tqual) q = (char)((int)q - 64 + 33 < 33 ? 33 : (int)q - 64 + 33);
 					// tooFewQualities / tooManyQualities (pat.cpp:1736-1748): the reference aborts, and so do we
 					if (tqual.size() != tseq.size() && ch.error.empty()) {
 						const std::string nm = r.name_len ? std::string(arena_.data() + r.name_off, r.name_len) : std::to_string(r.rdid);
@@ -460,6 +574,7 @@ public:
 				rlen[i] = (uint32_t)tseq.size();
 				ch.seq += tseq; ch.qual += tqual;
 				if (pt) { orig_off[i] = (uint32_t)ch.orig.size(); ch.orig.append(orig_.data() + r.orig_off, r.orig_len); orig_len[i] = (uint32_t)r.orig_len; }
+				if (tg) { tag_off[i] = (uint32_t)ch.tags.size(); ch.tags.append(arena_.data() + r.tag_off, r.tag_len); tag_len[i] = (uint32_t)r.tag_len; }
 				b.reads[i].filter = r.filter;
 			}
 		});
@@ -483,6 +598,7 @@ public:
 				ReadRec& rd = b.reads[i];
 				rd.name.set(ch.names.data() + name_off[i], name_len[i]);
 				if (pt) rd.orig.set(ch.orig.data() + orig_off[i], orig_len[i]);
+				if (tg) rd.tags.set(ch.tags.data() + tag_off[i], tag_len[i]);
 				rd.seq.set((const char*)b.seq.data() + b.off[i], rlen[i]);
 				rd.qual.set((const char*)b.qual.data() + b.off[i], rlen[i]);
 				b.rp[i] = compute_read_params(opt_, rd);
@@ -494,7 +610,8 @@ public:
 		t_pack += tnow() - t2_;
 	}
 private:
-	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; };
+	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; size_t tag_off = 0, tag_len = 0; };
+	BamStream bam_; bool bam_ok_ = false; std::string bam_err_, bam_rec_; int bam_mate_ = 0;     // -b state
 	std::string fc_line_, fc_prefix_, fc_win_;     // -F state
 	size_t fc_pos_ = 0, fc_eat_ = 0; uint64_t fc_cur_ = 0, fc_last_ = 0; bool fc_beginning_ = true;
 	std::string orig_, pending_raw_;   // --passthrough: the records' original text (Read::readOrigBuf)

@@ -129,9 +129,9 @@ static int run_search(int argc, char** argv) {
 	const bool inter = !opt.interleaved_file.empty();
 	const std::string src1 = inter ? opt.interleaved_file : (opt.paired ? opt.mate1_file : opt.reads_file);
 	FastqBatcher fq(src1, opt, host_threads);
-	if (!fq.ok()) die("cannot open reads file " + src1);
+	if (!fq.ok()) die(fq.open_error("cannot open reads file " + src1));
 	std::unique_ptr<FastqBatcher> fq2;
-	if (opt.paired && !inter) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die("cannot open reads file " + opt.mate2_file); }
+	if (opt.paired && !inter) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die(fq2->open_error("cannot open reads file " + opt.mate2_file)); fq.set_bam_mate(1); fq2->set_bam_mate(2); }
 	PairSummary psumm;
 	AlnSummary summ;
 	std::mutex align_mu;

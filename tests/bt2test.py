@@ -270,3 +270,38 @@ def cached_synth_index(n_refs=3, total=60000, seed=7, large=False):
 
 def sha(b):
     return hashlib.sha256(b).hexdigest()
+
+
+# ---- unaligned BAM writer for the -b tests (SAM spec 4.2; BGZF = gzip members with a "BC" extra field, 4.1) ----
+def bam_record(name, flag, seq, qual, tags=b""):
+    """one alignment record, unmapped layout: refID/pos/next = -1, no CIGAR; `qual` = Phred+33 text; `tags` = BAM-encoded optional fields"""
+    import struct
+    codes = "=ACMGRSVTWYHKDBN"
+    nib = [codes.index(c) for c in seq.upper()]
+    if len(nib) % 2:
+        nib.append(0)
+    packed = bytes((nib[i] << 4) | nib[i + 1] for i in range(0, len(nib), 2))
+    body = struct.pack("<iiBBHHHiiii", -1, -1, len(name) + 1, 0, 4680, 0, flag, len(seq), -1, -1, 0)
+    body += name.encode() + b"\0" + packed + bytes(ord(c) - 33 for c in qual) + tags
+    return struct.pack("<I", len(body)) + body
+
+
+def write_bam(path, records, block=600, refs=(("chrT", 1000),)):
+    """records: bam_record() blobs.  `block` = uncompressed bytes per BGZF block (small, so that records straddle blocks)"""
+    import struct
+    import zlib
+    text = b"@HD\tVN:1.6\tSO:queryname\n"
+    raw = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(refs))
+    for nm, ln in refs:
+        raw += struct.pack("<I", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<I", ln)
+    raw += b"".join(records)
+
+    def bgzf(chunk):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        data = c.compress(chunk) + c.flush()
+        hdr = struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, len(data) + 25)
+        return hdr + data + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    with open(path, "wb") as f:
+        for i in range(0, len(raw), block):
+            f.write(bgzf(raw[i:i + block]))
+        f.write(bgzf(b""))      # the end-of-file marker block

@@ -465,6 +465,7 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 	fwrite(o.data(), 1, o.size(), out);
 	const bool inter = !opt.interleaved_file.empty();
 	FastqBatcher fq1(inter ? opt.interleaved_file : opt.mate1_file, opt, 1), fq2(inter ? std::string("/dev/null") : opt.mate2_file, opt, 1);
+	if (!inter) { fq1.set_bam_mate(1); fq2.set_bam_mate(2); }
 	if (!fq1.ok() || !fq2.ok()) { fprintf(stderr, "cannot open the mate files\n"); return 1; }
 	Work* w = new Work();
 	DpScratch dp, dp2;

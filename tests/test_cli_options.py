@@ -63,6 +63,9 @@ def input_variants(tmp):
     open(fa, "w").write("".join(">%s\n%s\n" % (n, s) for n, s, _ in recs))
     open(raw, "w").write("".join("%s\n" % s for _, s, _ in recs if s))
     open(p64, "w").write("".join("@%s\n%s\n+\n%s\n" % (n, s, "".join(chr(ord(c) + 31) for c in q)) for n, s, q in recs))
+    # 64-based Solexa (log-odds) qualities over the whole range the old pipelines wrote, -5 .. 40 (--solexa-quals, qual.h:105-123)
+    sol = os.path.join(tmp, "rsol.fq")
+    open(sol, "w").write("".join("@%s\n%s\n+\n%s\n" % (n, s, "".join(chr(59 + (7 * k + 3 * len(n) + ord(c)) % 46) for k, c in enumerate(q))) for n, s, q in recs))
     with gzip.open(gz, "wt") as f:
         f.write(open(FQ).read())
     tab = os.path.join(tmp, "r.tab5")
@@ -71,7 +74,7 @@ def input_variants(tmp):
     # a comma-separated list of inputs, plain and gzipped mixed
     half = os.path.join(tmp, "half.fq")
     open(half, "w").write("".join("@%s\n%s\n+\n%s\n" % r for r in recs[:len(recs) // 2]))
-    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), ([], gz), (["--tab5"], tab), (["--tab6"], tab), (["-c"], cmdline), ([], half + "," + gz),
+    return [(["-f"], fa), (["-r"], raw), (["--phred64"], p64), (["--solexa1.3-quals"], p64), (["--solexa-quals"], sol), (["--solexa-quals", "--phred33"], FQ), ([], gz), (["--tab5"], tab), (["--tab6"], tab), (["-c"], cmdline), ([], half + "," + gz),
             (["-f", "--passthrough"], fa), (["--tab5", "--passthrough"], tab), (["-c", "--passthrough"], cmdline)]
 
 
