@@ -97,12 +97,14 @@ inline void print_version(const char* argv0) {
 }
 inline void print_usage(const char* argv0) {
 	printf("Usage: %s [options] -x <bt2-idx> {-1 <m1> -2 <m2> | -U <r> | --interleaved <i> | --tab5/--tab6 <f>} [-S <sam>]\n", argv0);
-	printf("  inputs: -q -f -r -c --qseq (plain or gzipped, comma-separated lists)   -s/-u -5/-3 --trim-to --phred33/--phred64\n"
+	printf("  inputs: -q -f -r -c --qseq (plain or gzipped, comma-separated lists)  -b <unaligned BAM> [--align-paired-reads] [--preserve-tags]\n"
+	       "          -s/-u -5/-3 --trim-to --phred33/--phred64/--solexa-quals\n"
 	       "  presets: --very-fast --fast --sensitive --very-sensitive (and -local)   --end-to-end | --local\n"
 	       "  alignment: -N 0|1 -L -i --n-ceil --dpad --gbar --ignore-quals --nofw --norc --no-1mm-upfront --no-exact-upfront -d --overhang\n"
 	       "  scoring: --ma --mp --np --rdg --rfg --score-min --policy --bwa-sw-like      effort: -D -R     reporting: -k <=64 | -a | -M\n"
 	       "  pairs: -I -X --fr/--rf/--ff --no-mixed --no-discordant --dovetail --no-contain --no-overlap\n"
-	       "  SAM: --no-unal --no-hd --no-sq --rg-id --rg --omit-sec-seq --sam-no-qname-trunc --xeq --passthrough   other: -p --reorder -t --quiet --seed --qc-filter --gpu a,b --batch n\n"
+	       "  SAM: --no-unal --no-hd --no-sq --rg-id --rg --omit-sec-seq --sam-no-qname-trunc --sam-append-comment --soft-clipped-unmapped-tlen --xeq --passthrough\n"
+	       "  other: -p --reorder -t --quiet --seed --qc-filter --gpu a,b --batch n\n"
 	       "  Options of bowtie2 outside this list are refused, never approximated.\n");
 }
 

@@ -7,7 +7,7 @@ our side did not flag as over a capacity limit.  usage: fuzz_vs_reference.py <se
 import sys, os, subprocess, random, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from bt2test import ref_bin, write_fasta, write_fastq, build_index, revcomp
+from bt2test import ref_bin, write_fasta, write_fastq, build_index, revcomp, bam_record, write_bam
 HS = os.environ.get('BT2G_HOSTSIM', os.path.join(ROOT, 'tests', 'hostsim', 'hostsim'))
 os.makedirs('/tmp/fuzz', exist_ok=True)
 seed0=int(sys.argv[1]); nit=int(sys.argv[2])
@@ -41,8 +41,8 @@ def mut(rnd,s,sub,indel):
 POOL_SE=[[],["--local"],["-k","2"],["-k","7"],["-a"],["--very-fast"],["--very-sensitive"],["--fast-local"],["--very-sensitive-local"],["-N","1"],["-L","12"],["-L","28"],["-i","C,5,0"],["-i","L,2,0.1"],
  ["--ignore-quals"],["--mp","4,1"],["--np","3"],["--rdg","3,2"],["--rfg","7,4"],["--score-min","L,-3,-0.3"],["--n-ceil","L,2,0.3"],["--nofw"],["--norc"],["--no-1mm-upfront"],["--no-exact-upfront"],
  ["-D","4"],["-R","1"],["-R","3"],["--gbar","8"],["--dpad","6"],["-5","3"],["-3","4"],["--overhang"],["--seed","17"],["-M","2"],["--xeq"],["--no-unal"],
- ["-d","-a","--no-exact-upfront","--no-1mm-upfront"],["--bwa-sw-like"],["--policy","MMP=C3;NP=C2"],["--trim-to","5:40"],["--trim-to","60"],["--passthrough"],["--omit-sec-seq","-k","3"],["--ma","3","--local"],["--qc-filter"],["--phred64"],["--policy","MMP=R"],["--policy","NP=Q;RDG=4"],["-F","30,7"]]
-POOL_PE=[["--ff"],["--rf"],["--no-mixed"],["--no-discordant"],["--dovetail"],["--no-contain"],["--no-overlap"],["-I","80"],["-X","300"],["-X","700"]]
+ ["-d","-a","--no-exact-upfront","--no-1mm-upfront"],["--bwa-sw-like"],["--policy","MMP=C3;NP=C2"],["--trim-to","5:40"],["--trim-to","60"],["--passthrough"],["--omit-sec-seq","-k","3"],["--ma","3","--local"],["--qc-filter"],["--phred64"],["--policy","MMP=R"],["--policy","NP=Q;RDG=4"],["-F","30,7"],["--sam-append-comment"],["--solexa-quals"]]
+POOL_PE=[["--ff"],["--rf"],["--no-mixed"],["--no-discordant"],["--dovetail"],["--no-contain"],["--no-overlap"],["-I","80"],["-X","300"],["-X","700"],["--soft-clipped-unmapped-tlen"]]
 def conflicts(a):
     flat=" ".join(" ".join(x) for x in a)
     if "--local" in flat or "-local" in flat:
@@ -56,6 +56,7 @@ def conflicts(a):
     if "--phred64" in flat: return True      # the generated qualities are phred33
     if "-F " in flat+" ": return True         # needs FASTA input (covered by the regression table)
     if flat.count("--policy")>1: return True
+    if "--soft-clipped-unmapped-tlen" in flat and not ("--local" in flat or "-local" in flat or "--bwa-sw-like" in flat): return True
     return False
 nfail=0; t0=time.time()
 for it in range(nit):
@@ -92,8 +93,21 @@ for it in range(nit):
             if rnd.random()<0.5: m1,m2=m2,m1
             m1=mut(rnd,m1,sub,indel); m2=mut(rnd,m2,sub,indel)
             r1.append(("p%d/1"%i,m1,"".join(rnd.choice("IIIH?5#") for _ in m1))); r2.append(("p%d/2"%i,m2,"".join(rnd.choice("IIIH?5#") for _ in m2)))
-        write_fastq(d+"/1.fq",r1); write_fastq(d+"/2.fq",r2)
-        inp=["-1",d+"/1.fq","-2",d+"/2.fq"]
+        if "--sam-append-comment" in args:
+            cm=lambda m: rnd.choice(["", " %d:N:0:ACGT"%m, " %d:Y:18:TTAGGC x"%m, " free text", " 3:N:0:A"])
+            r1=[(n+cm(1),s_,q) for n,s_,q in r1]; r2=[(n+cm(2),s_,q) for n,s_,q in r2]
+        if rnd.random()<0.15 and "--sam-append-comment" not in args:
+            # the same pairs as an unaligned BAM file (mates flagged 0x40 / 0x80, records to be skipped in between)
+            recs=[]
+            for (n1,s1,q1),(n2,s2,q2) in zip(r1,r2):
+                recs.append(bam_record(n1,77,s1,q1,b"BCZAC\0"))
+                if rnd.random()<0.1: recs.append(bam_record("solo",4,s1,q1))
+                recs.append(bam_record(n2,141,s2,q2))
+            write_bam(d+"/p.bam",recs,block=rnd.choice([300,4000,60000]))
+            inp=["-b","--align-paired-reads"]+(["--preserve-tags"] if rnd.random()<0.5 else [])+["-1",d+"/p.bam","-2",d+"/p.bam"]
+        else:
+            write_fastq(d+"/1.fq",r1); write_fastq(d+"/2.fq",r2)
+            inp=["-1",d+"/1.fq","-2",d+"/2.fq"]
     else:
         rs=[]
         for i in range(n):
@@ -104,9 +118,16 @@ for it in range(nit):
             if rnd.random()<0.05: m="".join(rnd.choice("ACGT") for _ in range(L))
             m=mut(rnd,m,sub,indel)
             rs.append(("r%d"%i,m,"".join(rnd.choice("IIIH?5#") for _ in m)))
-        write_fastq(d+"/r.fq",rs); inp=["-U",d+"/r.fq"]
-    a=subprocess.run([exe]+args+["-x",base]+inp+["-p","2","--reorder"],capture_output=True,text=True)
-    b=subprocess.run([HS]+args+["-x",base]+inp,capture_output=True,text=True)
+        if "--sam-append-comment" in args:
+            rs=[(n+rnd.choice(["", " 1:N:0:ACGT", " 2:Y:18:TTAGGC x", " free text", " nocolon"]),s_,q) for n,s_,q in rs]
+        if rnd.random()<0.15 and "--sam-append-comment" not in args:
+            recs=[bam_record(n_,rnd.choice([4,4,4,4,0,69]),s_,q,rnd.choice([b"",b"NHC\x03",b"RGZg1\0XSs\xf9\xff"])) for n_,s_,q in rs]
+            write_bam(d+"/r.bam",recs,block=rnd.choice([300,4000,60000]))
+            inp=["-b"]+(["--preserve-tags"] if rnd.random()<0.5 else [])+["-U",d+"/r.bam"]
+        else:
+            write_fastq(d+"/r.fq",rs); inp=["-U",d+"/r.fq"]
+    a=subprocess.run([exe]+args+["-x",base]+inp+["-p","2","--reorder"],capture_output=True,text=True,errors="replace")
+    b=subprocess.run([HS]+args+["-x",base]+inp,capture_output=True,text=True,errors="replace")
     body=lambda t:[l for l in t.splitlines() if not l.startswith("@PG")]
     if a.returncode!=0: continue
     warn="Warning: " in b.stderr and ("overflow" in b.stderr or "exceeded" in b.stderr)
