@@ -101,7 +101,8 @@ inline void print_usage(const char* argv0) {
 	       "          -s/-u -5/-3 --trim-to --phred33/--phred64/--solexa-quals\n"
 	       "  presets: --very-fast --fast --sensitive --very-sensitive (and -local)   --end-to-end | --local\n"
 	       "  alignment: -N 0|1 -L -i --n-ceil --dpad --gbar --ignore-quals --nofw --norc --no-1mm-upfront --no-exact-upfront -d --overhang\n"
-	       "  scoring: --ma --mp --np --rdg --rfg --score-min --policy --bwa-sw-like      effort: -D -R     reporting: -k <=64 | -a | -M\n"
+	       "  scoring: --ma --mp --np --rdg --rfg --score-min --policy --bwa-sw-like      effort: -D -R --extends --dp-fails --ug-fails --seed-boost --tighten --no-extend --[no-]ungapped\n"
+	       "  reporting: -k <=64 | -a | -M\n"
 	       "  pairs: -I -X --fr/--rf/--ff --no-mixed --no-discordant --dovetail --no-contain --no-overlap\n"
 	       "  SAM: --no-unal --no-hd --no-sq --rg-id --rg --omit-sec-seq --sam-no-qname-trunc --sam-append-comment --soft-clipped-unmapped-tlen --xeq --passthrough\n"
 	       "  other: -p --reorder -t --quiet --seed --qc-filter --gpu a,b --batch n\n"
@@ -173,6 +174,12 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		if (a.size() > 2 && a[0] == '-' && a[1] == '-') {           // --opt=value
 			const size_t eq = a.find('=');
 			if (eq != std::string::npos) { inline_val = a.substr(eq + 1); a = a.substr(0, eq); has_inline = true; }
+		}
+		// long spellings of the short options (the getopt table, bt2_search.cpp:505-705)
+		{
+			static const char* const alias[][2] = {{"--khits", "-k"}, {"--seedlen", "-L"}, {"--seedmms", "-N"}, {"--seedival", "-i"}, {"--index", "-x"}, {"--unpaired", "-U"},
+				{"--usage", "-h"}, {"--seed-rounds", "-R"}, {"--fail-streak", "-D"}, {"--12", "--tab5"}, {"--minins", "-I"}, {"--maxins", "-X"}};
+			for (const auto& al : alias) if (a == al[0]) { a = al[1]; break; }
 		}
 		std::string err;
 		auto need = [&]() -> std::string {
@@ -276,6 +283,20 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--no-dovetail") opt.dovetail = false;
 		else if (a == "--no-contain") opt.no_contain = true;
 		else if (a == "--no-overlap") opt.no_overlap = true;
+		else if (a == "--contain") opt.no_contain = false;
+		else if (a == "--overlap") opt.no_overlap = false;
+		// effort knobs (bt2_search.cpp:1274-1310, 1461-1477)
+		else if (a == "--extends") { opt.max_iters = atoi(need().c_str()); if (opt.max_iters < 0) err = "--extends must not be negative"; }
+		else if (a == "--dp-fails") { opt.max_dp = atoi(need().c_str()); if (opt.max_dp < 0) err = "--dp-fails must not be negative"; }
+		else if (a == "--ug-fails") { opt.max_ug = atoi(need().c_str()); if (opt.max_ug < 0) err = "--ug-fails must not be negative"; }
+		else if (a == "--seed-boost") { opt.seed_boost_thresh = atoi(need().c_str()); if (opt.seed_boost_thresh < 0) err = "--seed-boost must not be negative"; }
+		else if (a == "--tighten") opt.tighten = atoi(need().c_str());
+		else if (a == "--no-extend") opt.do_extend = false;
+		else if (a == "--ungapped") opt.do_ungapped = true;
+		else if (a == "--no-ungapped") opt.do_ungapped = false;
+		// accepted and without effect on the output, here as in the reference: batching / thread-pool housekeeping of the CPU program, and
+		// --1mm-minlen, which bt2_search.cpp parses (:1477) and never reads
+		else if (a == "--reads-per-batch" || a == "--thread-ceiling" || a == "--thread-piddir" || a == "--1mm-minlen") { (void)need(); }
 		else if (a == "-N") { const std::string v = need(); opt.seed_mms = atoi(v.c_str()); if (opt.seed_mms < 0 || opt.seed_mms > 1) err = "Error: -N was set to " + v + ", but cannot be set higher than 1 or less than 0"; }
 		else if (a == "-i") { opt.set_i = true; if (!opt.ms_ival.parse(need())) err = "bad -i function"; }
 		else if (a == "--score-min" || a == "--min-score") { opt.set_score_min = true; if (!opt.score_min.parse(need())) err = "bad --score-min function"; }

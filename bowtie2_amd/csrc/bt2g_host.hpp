@@ -75,6 +75,9 @@ struct Options {
 	bool preserve_tags = false;   // --preserve-tags: a BAM record's optional fields are printed after the aligner's (pat.cpp:1503, sam.cpp:881)
 	bool align_paired_reads = false;   // --align-paired-reads: take the paired records of a BAM file instead of the unpaired ones (pat.cpp:1417-1427)
 	bool sam_append_comment = false;   // --sam-append-comment: the FASTA/FASTQ comment (name after the first blank) closes the SAM record (sam.h:415)
+	// effort knobs behind the presets (bt2_search.cpp:463-492, 1274-1310, 1461-1477); -k scales the limits further (to_params)
+	int max_iters = 400, max_ug = 300, max_dp = 300, seed_boost_thresh = 300, tighten = 3;
+	bool do_ungapped = true, do_extend = true;
 	bool sc_unmapped = false;     // --soft-clipped-unmapped-tlen: TLEN without the soft-clipped ends (aligner_result.h:894-909)
 	int fc_len = 0, fc_freq = 1;  // -F k:<len>,i:<freq>
 	int trim5 = 0, trim3 = 0;
@@ -153,7 +156,7 @@ struct Options {
 		P.seed_cache_mb = seed_cache_mb;
 		P.profile = 0;      // the drop-in binary never asks for the worker's phase timers
 		P.max_seeds = 0;    // set per batch by the driver (bt2g_search.cpp)
-		P.max_dp_streak = max_dp_streak; P.max_ug = 300; P.max_dp = 300; P.max_iters = 400;
+		P.max_dp_streak = max_dp_streak; P.max_ug = max_ug; P.max_dp = max_dp; P.max_iters = max_iters;
 		if (all_hits) {
 			// -a lifts every effort limit (bt2_search.cpp:3457-3463)
 			P.max_dp_streak = P.max_ug = P.max_dp = P.max_iters = P.max_mate_streak = 0x7fffffff;
@@ -162,12 +165,12 @@ struct Options {
 			P.max_dp_streak += (khits - 1) * 10; P.max_mate_streak += (khits - 1) * 10;
 			P.max_ug += (khits - 1) * 20; P.max_dp += (khits - 1) * 20; P.max_iters += (khits - 1) * 20;
 		}
-		P.n_seed_rounds = n_seed_rounds; P.seed_boost_thresh = 300; P.tighten = 3; P.maxhalf = maxhalf;
+		P.n_seed_rounds = n_seed_rounds; P.seed_boost_thresh = seed_boost_thresh; P.tighten = tighten; P.maxhalf = maxhalf;
 		P.nofw = nofw; P.norc = norc;
-		P.do_exact_upfront = no_exact_upfront ? 0 : 1; P.do_1mm_upfront = no_1mm_upfront ? 0 : 1; P.do_ungapped = 1;
+		P.do_exact_upfront = no_exact_upfront ? 0 : 1; P.do_1mm_upfront = no_1mm_upfront ? 0 : 1; P.do_ungapped = do_ungapped ? 1 : 0;
 		// bit 0: extend seed hits; bit 1: left only -- the reference loads the mirror index only for -N > 0 or the 1-mm
 		// up-front search (bt2_search.cpp:4841) and SwDriver::extend skips the right extension without it (:403)
-		P.do_extend = 1 | ((seed_mms == 0 && no_1mm_upfront) ? 2 : 0);
+		P.do_extend = do_extend ? (1 | ((seed_mms == 0 && no_1mm_upfront) ? 2 : 0)) : 0;
 		P.large_index = large_index ? 1 : 0;
 	}
 };
