@@ -3,7 +3,8 @@
  *
  * Scalar plain-C restatement of the reference's FM-index rank/LF, exact
  * sweep, exact seed search, offset resolution, reference fetch, RNG and the
- * end-to-end u8 DP fixed point.  Written from the behaviour documented in
+ * four DP fills (end-to-end 8/16-bit, local 8/16-bit) as their fixed points in
+ * saturating arithmetic.  Written from the behaviour documented in
  * SURVEY.md Appendix A-C; every function names the reference lines it follows.
  * No code is copied: the reference's byte-LUT + SSE formulation is replaced by
  * straight loops over 2-bit characters.
@@ -588,4 +589,84 @@ int bt2o_sw_fill_ee_u8(const bt2o_scoring *sc, const uint8_t *rd, const uint8_t 
 		if (H[(rows - 1) * cols + j] > lrmax) lrmax = H[(rows - 1) * cols + j];
 	}
 	return lrmax - 0xff;
+}
+
+/* ------------------------------------------------------------------ */
+/* the other three DP fills of the path                                */
+/* ------------------------------------------------------------------ */
+/* kind 1: end-to-end 16-bit  (alignNucleotidesEnd2EndSseI16, aligner_swsse_ee_i16.cpp:780-1170)
+ * kind 2: local 8-bit        (alignNucleotidesLocalSseU8,    aligner_swsse_loc_u8.cpp:927-1330)
+ * kind 3: local 16-bit       (alignNucleotidesLocalSseI16,   aligner_swsse_loc_i16.cpp:938-1375)
+ * The striped SSE kernels compute, cell by cell, the recurrences below in SATURATING arithmetic over the word's range [lo, hi]:
+ * unsigned 8-bit for kind 2 (a biased profile: +(sc+bias) then -bias, so an overflow clips at 255-bias), signed 16-bit with
+ * 0x8000 standing for "zero"/"minus infinity" for kinds 1 and 3.  A gap-barrier row forces the gap term to lo (the 0xff subtrahend,
+ * or 0x8000 added twice).  Cells are stored as the kernels hold them (SSEMatrix::elt), so they can be compared word for word.
+ * Local fills stop early: at a column whose maximum saturates (flag -2), or when the rest of the columns cannot lift the score
+ * to minsc any more (colstop); cells of later columns are not written.
+ * Returns the kernel's return value; *flag: 0 ok, -1 below minsc, -2 saturated; *colstop: columns filled. */
+static inline int sat_i(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+int64_t bt2o_sw_fill_kind(int kind, const bt2o_scoring *sc, const uint8_t *rd, const uint8_t *qu, int rows,
+                          const uint8_t *rf, int cols, int64_t minsc, int32_t *H, int32_t *E, int32_t *F, int *flag, int *colstop) {
+	const int rdgapo = sc->rd_gap_const + sc->rd_gap_linear, rdgape = sc->rd_gap_linear;
+	const int rfgapo = sc->rf_gap_const + sc->rf_gap_linear, rfgape = sc->rf_gap_linear;
+	const int lo = kind == 2 ? 0 : -32768, hi = kind == 2 ? 255 : 32767;
+	const int local = kind != 1;
+	int bias = 0;
+	if (kind == 2) {     /* buildQueryProfileLocalSseU8: the largest penalty any (read position, reference character) pair can draw */
+		for (int refc = 0; refc < 5; refc++)
+			for (int i = 0; i < rows; i++) { int s = bt2o_score(sc, rd[i], 1 << refc, qu[i]); if (-s > bias) bias = -s; }
+	}
+	int64_t vmax = lo, lrmax = lo;
+	*flag = 0;
+	*colstop = cols;
+	for (int j = 0; j < cols; j++) {
+		int m = rf[j], refc = 4;
+		for (int b = 0; b < 5; b++) if (m & (1 << b)) { refc = b; break; }       /* firsts5[mask] */
+		int f = lo, colmax = lo;
+		for (int i = 0; i < rows; i++) {
+			const int barrier = (i < sc->gapbar || rows - i - 1 < sc->gapbar);
+			const int s = bt2o_score(sc, rd[i], 1 << refc, qu[i]);
+			int hdiag = (i == 0) ? (local ? lo : hi) : (j == 0 ? lo : H[(i - 1) * cols + (j - 1)]);
+			int hd = kind == 2 ? sat_i(sat_i(hdiag + s + bias, lo, hi) - bias, lo, hi) : sat_i(hdiag + s, lo, hi);
+			int e = lo;
+			if (j > 0) {
+				int open = barrier ? lo : sat_i(H[i * cols + j - 1] - rdgapo, lo, hi);
+				int ext = sat_i(E[i * cols + j - 1] - rdgape, lo, hi);
+				e = open > ext ? open : ext;
+			}
+			if (i == 0) f = lo;
+			else {
+				int open = sat_i(H[(i - 1) * cols + j] - rfgapo, lo, hi), ext = sat_i(f - rfgape, lo, hi);
+				f = barrier ? lo : (open > ext ? open : ext);
+			}
+			int h = hd;
+			if (e > h) h = e;
+			if (f > h) h = f;
+			H[i * cols + j] = h; E[i * cols + j] = e; F[i * cols + j] = f;
+			if (h > colmax) colmax = h;
+		}
+		if (H[(rows - 1) * cols + j] > lrmax) lrmax = H[(rows - 1) * cols + j];
+		if (colmax > vmax) vmax = colmax;
+		if (local) {
+			if (kind == 2 && colmax + bias >= 255) { *flag = -2; *colstop = j + 1; return INT64_MIN; }
+			const int64_t score = kind == 2 ? colmax : (int64_t)colmax + 32768;
+			if (score < minsc && score + (int64_t)(cols - j - 1) * sc->match_bonus < minsc) { *colstop = j + 1; break; }
+		}
+	}
+	if (kind == 1) {
+		const int64_t score = lrmax - 0x7fff;
+		if (score < minsc) { *flag = -1; return score; }
+		if (lrmax == -32768) { *flag = -2; return INT64_MIN; }
+		return score;
+	}
+	if (kind == 2) {
+		if (vmax + bias >= 255) { *flag = -2; return INT64_MIN; }
+		if (vmax == 0 || vmax < minsc) { *flag = -1; return vmax; }
+		return vmax;
+	}
+	if (vmax == -32768) { *flag = -1; return INT64_MIN; }
+	if (vmax + 32768 < minsc) { *flag = -1; return vmax + 32768; }
+	if (vmax == 32767) { *flag = -2; return INT64_MIN; }
+	return vmax + 32768;
 }

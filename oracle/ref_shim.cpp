@@ -278,6 +278,52 @@ int64_t ref_sw_fill_ee_u8(void *h, const char *seq, const char *qual, const uint
 	return best;
 }
 
+/*
+ * The other three fills of the path on the same explicit problem: end-to-end 16-bit (alignNucleotidesEnd2EndSseI16,
+ * aligner_swsse_ee_i16.cpp:780), local 8-bit (alignNucleotidesLocalSseU8, aligner_swsse_loc_u8.cpp:927) and local 16-bit
+ * (alignNucleotidesLocalSseI16, aligner_swsse_loc_i16.cpp:938).  kind: 1 = ee i16, 2 = local u8, 3 = local i16.  H/E/F come back as
+ * the matrix holds them (SSEMatrix::elt: u8 or i16 words, biased as the kernel stores them), row-major int32; returns the kernel's score.
+ */
+int64_t ref_sw_fill_kind(void *h, int kind, const char *seq, const char *qual, const uint8_t *rf, int cols,
+                         int64_t minsc, int32_t *H, int32_t *Eo, int32_t *F, int *flag_out) {
+	RefCtx *c = (RefCtx*)h;
+	Read rd("r", seq, qual);
+	SwAligner sw(NULL);
+	size_t rows = rd.length();
+	sw.initRead(rd.patFw, rd.patRc, rd.qual, rd.qualRev, 0, rows, *c->sc);
+	DPRect rect;
+	rect.refl = rect.refl_pretrim = 0;
+	rect.refr = rect.refr_pretrim = cols - 1;
+	rect.triml = rect.trimr = 0;
+	rect.corel = 0; rect.corer = cols - 1; rect.maxgap = 15;
+	std::vector<char> rfbuf(rf, rf + cols + 1);
+	sw.initRef(true, 0, rect, rfbuf.data(), 0, (size_t)cols, 1000000, *c->sc, minsc,
+	           true, 2000, 4, true, true);
+	int flag = 0;
+	sw.sse8succ_ = false;
+	sw.sse16succ_ = false;
+	int64_t best = kind == 1 ? sw.alignNucleotidesEnd2EndSseI16(flag, false)
+	             : kind == 2 ? sw.alignNucleotidesLocalSseU8(flag, false)
+	                         : sw.alignNucleotidesLocalSseI16(flag, false);
+	if(flag_out) *flag_out = flag;
+	SSEData& d = kind == 2 ? sw.sseU8fw_ : sw.sseI16fw_;
+	for(size_t i = 0; i < rows; i++) {
+		for(int j = 0; j < cols; j++) {
+			H[i * cols + j]  = d.mat_.helt(i, j);
+			Eo[i * cols + j] = d.mat_.eelt(i, j);
+			F[i * cols + j]  = d.mat_.felt(i, j);
+		}
+	}
+	return best;
+}
+
+/* the shim's scoring scheme switched to local mode and back (match bonus; SwAligner reads monotone_ off the scheme) */
+void ref_set_match_bonus(void *h, int bonus) {
+	RefCtx *c = (RefCtx*)h;
+	c->sc->setMatchBonus(bonus);
+	c->sc->monotone = (bonus == 0);      // Scoring's constructor derives it once (scoring.h:168)
+}
+
 /* RandomSource stream check: fills out[n] following ops[i]: 0=nextU32 1=nextBool 2=nextU2 3=nextFloat(bits) 4=nextU64(lo32^hi32) */
 void ref_rng_stream(uint32_t seed, const uint8_t *ops, int n, uint32_t *out) {
 	RandomSource r;

@@ -137,6 +137,10 @@ def refshim(large=False):
         L.ref_sw_fill_ee_u8.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int64,
                                         C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
         L.ref_sw_fill_ee_u8.restype = C.c_int64
+        i32p = C.POINTER(C.c_int32)
+        L.ref_sw_fill_kind.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int64, i32p, i32p, i32p, C.POINTER(C.c_int)]
+        L.ref_sw_fill_kind.restype = C.c_int64
+        L.ref_set_match_bonus.argtypes = [C.c_void_p, C.c_int]
         L.ref_rng_stream.argtypes = [C.c_uint32, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         L.ref_score.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]; L.ref_score.restype = C.c_int64
         _refshim[key] = L

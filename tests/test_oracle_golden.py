@@ -138,3 +138,34 @@ def test_ref_fetch_matches_fasta(golden_dir):
         L.bt2o_ref_get_stretch(C.byref(idx.ref), buf, ti, -10, len(s) + 20)
         got = "".join("ACGTN"[b] for b in buf.raw)
         assert got == "N" * 10 + s + "N" * 10
+
+
+def test_dp_fill_other_kinds(golden_dir):
+    """16-bit end-to-end, local 8-bit and local 16-bit fills of the restatement against vectors recorded from the reference's SSE kernels
+    (tests/golden/make_dp_kinds_golden.py): score, flag (0 / -1 below the minimum / -2 saturated), columns filled, sha256 of H|E|F."""
+    import hashlib
+    import struct
+    L = oracle()
+    i32p = C.POINTER(C.c_int32)
+    L.bt2o_sw_fill_kind.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int64, i32p, i32p, i32p,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bt2o_sw_fill_kind.restype = C.c_int64
+    with open(os.path.join(golden_dir, "dp_kinds_golden.json")) as f:
+        probs = json.load(f)
+    assert {p["kind"] for p in probs} == {1, 2, 3}
+    for p in probs:
+        sc = Scoring()
+        L.bt2o_scoring_default(C.byref(sc))
+        sc.match_bonus = p["match_bonus"]
+        rows, cols = p["rows"], p["cols"]
+        rf = bytes(1 << "ACGTN".index(c) for c in p["rf"])
+        bufs = [(C.c_int32 * (rows * cols))() for _ in range(3)]
+        flag, colstop = C.c_int(), C.c_int()
+        got = L.bt2o_sw_fill_kind(p["kind"], C.byref(sc), encode(p["rd"]), bytes(ord(c) - 33 for c in p["qu"]), rows, rf, cols, p["minsc"],
+                                  bufs[0], bufs[1], bufs[2], C.byref(flag), C.byref(colstop))
+        assert (None if got == -2**63 else got, flag.value, colstop.value) == (p["score"], p["flag"], p["ncol"]), (p["kind"], rows, cols)
+        h = hashlib.sha256()
+        for b in bufs:
+            for i in range(rows):
+                h.update(struct.pack("<%di" % p["ncol"], *b[i * cols:i * cols + p["ncol"]]))
+        assert h.hexdigest() == p["sha"], (p["kind"], rows, cols)

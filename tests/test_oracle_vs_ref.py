@@ -107,3 +107,70 @@ def test_dp_fill_random(ctx):
         assert [b.raw for b in bufs[:3]] == [b.raw for b in bufs[3:]]
         if flag.value == 0:
             assert best == best_ref
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3], ids=["ee_i16", "local_u8", "local_i16"])
+def test_dp_fill_other_kinds_random(ctx, kind):
+    """The 16-bit end-to-end fill and the two local fills of the restatement against the reference's own SSE kernels
+    (aligner_swsse_ee_i16.cpp:780, aligner_swsse_loc_u8.cpp:927, aligner_swsse_loc_i16.cpp:938): every H, E and F word of every column
+    the kernel filled, the returned score, the flag (below the minimum / saturated) -- on windows drawn from the genome with reads of
+    20-400 rows, sparse and dense mismatches, Ns, low and high minimum scores (early column stop), and 8-bit saturation."""
+    L, R, idx, h, refs = ctx
+    i32p = C.POINTER(C.c_int32)
+    L.bt2o_sw_fill_kind.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int64, i32p, i32p, i32p,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bt2o_sw_fill_kind.restype = C.c_int64
+    sc = Scoring()
+    L.bt2o_scoring_default(C.byref(sc))
+    local = kind != 1
+    if local:
+        sc.match_bonus = 2
+        R.ref_set_match_bonus(h, 2)
+    try:
+        rnd = random.Random(80 + kind)
+        g = refs[0][1].replace("N", "A")
+        seen_flags = set()
+        stopped_early = 0
+        for t in range(60):
+            rows = rnd.choice([20, 33, 50, 100, 150, 250, 400] if kind != 2 else [20, 33, 50, 100, 120, 150, 250])
+            cols = rows + rnd.choice([0, 12, 60])
+            pos = rnd.randrange(0, len(g) - cols - 2)
+            window = g[pos:pos + cols + 1]
+            rd = list(window[(cols - rows) // 2:(cols - rows) // 2 + rows])
+            mm = rnd.choice([0.0, 0.04, 0.04, 0.3, 0.75])
+            for i in range(rows):
+                if rnd.random() < mm:
+                    rd[i] = rnd.choice("ACGTN")
+            if rnd.random() < 0.3:      # an indel, so that E and F carry the best path somewhere
+                p = rnd.randrange(5, rows - 5)
+                rd = rd[:p] + rd[p + rnd.randrange(1, 4):] + list("ACG")
+                rd = rd[:rows]
+            rd = "".join(rd)
+            rows = len(rd)
+            qu = "".join(rnd.choice("GGG?5-I#") for _ in range(rows))
+            rf = bytes(1 << "ACGTN".index(c) for c in window)
+            if local:
+                minsc = rnd.choice([0, 20 + 8 * 5, int(20 + 8.0 * __import__("math").log(rows)), 2 * rows - 10, 2 * rows + 50])
+            else:
+                minsc = rnd.choice([-30000, int(-0.6 - 0.6 * rows), -20, -600])
+            n = rows * cols
+            bufs = [(C.c_int32 * n)() for _ in range(6)]
+            flag, flag2, colstop = C.c_int(), C.c_int(), C.c_int()
+            want = R.ref_sw_fill_kind(h, kind, rd.encode(), qu.encode(), rf, cols, minsc, bufs[0], bufs[1], bufs[2], C.byref(flag))
+            got = L.bt2o_sw_fill_kind(kind, C.byref(sc), encode(rd), bytes(ord(c) - 33 for c in qu), rows, rf, cols, minsc, bufs[3], bufs[4], bufs[5],
+                                      C.byref(flag2), C.byref(colstop))
+            assert (got, flag2.value) == (want, flag.value), (t, rows, cols, minsc)
+            ncol = colstop.value
+            stopped_early += ncol < cols
+            seen_flags.add(flag.value)
+            for a, b in zip(bufs[:3], bufs[3:]):
+                for i in range(rows):
+                    assert a[i * cols:i * cols + ncol] == b[i * cols:i * cols + ncol], (t, rows, cols, i)
+        assert 0 in seen_flags and -1 in seen_flags
+        if kind == 2:
+            assert -2 in seen_flags          # 8-bit saturation seen
+        if local:
+            assert stopped_early > 0
+    finally:
+        if local:
+            R.ref_set_match_bonus(h, 0)
