@@ -96,6 +96,7 @@ struct Options {
 	// paired-end input and policy (bt2_search.cpp:1185-1215; PairedEndPolicy pe.h:169)
 	std::string mate1_file, mate2_file, interleaved_file;
 	bool paired = false;
+	bool mixed_unpaired = false;      // -U next to -1/-2 (or --interleaved): the pairs first, then the unpaired reads, one summary (pat.cpp:305-420)
 	int min_insert = 0, max_insert = 500;
 	bool mate1fw = true, mate2fw = false;         // --fr (default) / --rf / --ff
 	bool no_mixed = false, no_discordant = false, dovetail = false, no_contain = false, no_overlap = false;
@@ -766,6 +767,44 @@ struct PairSummary {
 		fprintf(f, "%s overall alignment rate\n", pct(tot_al, npair * 2).c_str());
 	}
 };
+
+// Alignment summary of a run that had pairs AND unpaired reads (AlnSink::printAlSumm, aln_sink.cpp:349-560): one "reads" total in which a
+// pair counts once, both sections with their share of it, one overall rate over mates + unpaired reads.
+inline void print_mixed_summary(FILE* f, const PairSummary& p, const AlnSummary& u, bool discord, bool mixed) {
+	auto pct = [](uint64_t a, uint64_t b) { char buf[32]; snprintf(buf, sizeof buf, "%.2f%%", b ? 100.0 * (double)a / (double)b : 0.0); return std::string(buf); };
+	auto L = [](uint64_t v) { return (unsigned long long)v; };
+	const uint64_t tot = p.npair + u.nread;
+	if (tot > 0) fprintf(f, "%llu reads; of these:\n", L(tot)); else fprintf(f, "0 reads\n");
+	if (p.npair > 0) {
+		fprintf(f, "  %llu (%s) were paired; of these:\n", L(p.npair), pct(p.npair, tot).c_str());
+		fprintf(f, "    %llu (%s) aligned concordantly 0 times\n", L(p.conc0), pct(p.conc0, p.npair).c_str());
+		fprintf(f, "    %llu (%s) aligned concordantly exactly 1 time\n", L(p.conc_uni1), pct(p.conc_uni1, p.npair).c_str());
+		fprintf(f, "    %llu (%s) aligned concordantly >1 times\n", L(p.conc_uni2 + p.conc_rep), pct(p.conc_uni2 + p.conc_rep, p.npair).c_str());
+		if (discord) {
+			fprintf(f, "    ----\n");
+			fprintf(f, "    %llu pairs aligned concordantly 0 times; of these:\n", L(p.conc0));
+			fprintf(f, "      %llu (%s) aligned discordantly 1 time\n", L(p.ndiscord), pct(p.ndiscord, p.conc0).c_str());
+		}
+		const uint64_t ncd0 = p.conc0 - p.ndiscord;
+		if (mixed) {
+			fprintf(f, "    ----\n");
+			fprintf(f, "    %llu pairs aligned 0 times concordantly or discordantly; of these:\n", L(ncd0));
+			fprintf(f, "      %llu mates make up the pairs; of these:\n", L(ncd0 * 2));
+			fprintf(f, "        %llu (%s) aligned 0 times\n", L(p.unp00), pct(p.unp00, ncd0 * 2).c_str());
+			fprintf(f, "        %llu (%s) aligned exactly 1 time\n", L(p.unp0_uni1), pct(p.unp0_uni1, ncd0 * 2).c_str());
+			fprintf(f, "        %llu (%s) aligned >1 times\n", L(p.unp0_uni2 + p.unp0_rep), pct(p.unp0_uni2 + p.unp0_rep, ncd0 * 2).c_str());
+		}
+	}
+	if (u.nread > 0) {
+		fprintf(f, "  %llu (%s) were unpaired; of these:\n", L(u.nread), pct(u.nread, tot).c_str());
+		fprintf(f, "    %llu (%s) aligned 0 times\n", L(u.n0), pct(u.n0, u.nread).c_str());
+		fprintf(f, "    %llu (%s) aligned exactly 1 time\n", L(u.nuni), pct(u.nuni, u.nread).c_str());
+		fprintf(f, "    %llu (%s) aligned >1 times\n", L(u.nrep), pct(u.nrep, u.nread).c_str());
+	}
+	const uint64_t cand = u.nread + p.npair * 2;
+	const uint64_t al = (p.conc_uni1 + p.conc_uni2 + p.conc_rep) * 2 + p.ndiscord * 2 + p.unp0_uni1 + p.unp0_uni2 + p.unp0_rep + u.nuni + u.nrep;
+	fprintf(f, "%s overall alignment rate\n", pct(al, cand).c_str());
+}
 
 } // namespace bt2g
 #endif

@@ -132,6 +132,9 @@ static int run_search(int argc, char** argv) {
 	if (!fq.ok()) die(fq.open_error("cannot open reads file " + src1));
 	std::unique_ptr<FastqBatcher> fq2;
 	if (opt.paired && !inter) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die(fq2->open_error("cannot open reads file " + opt.mate2_file)); fq.set_bam_mate(1); fq2->set_bam_mate(2); }
+	// -U next to -1/-2: the unpaired reads follow the pairs (same reader thread, batches marked paired or not one by one)
+	std::unique_ptr<FastqBatcher> fq_unp;
+	if (opt.mixed_unpaired) { fq_unp.reset(new FastqBatcher(opt.reads_file, opt, host_threads)); if (!fq_unp->ok()) die("cannot open reads file " + opt.reads_file); }
 	PairSummary psumm;
 	AlnSummary summ;
 	std::mutex align_mu;
@@ -144,8 +147,11 @@ static int run_search(int argc, char** argv) {
 	if (!ex.shard_index.empty()) { shard_idx = fopen(ex.shard_index.c_str(), "w"); if (!shard_idx) die("cannot open " + ex.shard_index); }
 	std::thread reader([&]() {
 		uint64_t seq = 0, blk = 0;
+		bool unp_phase = false;          // mixed input: the pair sources are exhausted, the -U files are being read
 		for (;;) {
 			BatchPtr b(new HostBatch());
+			if (unp_phase) fq_unp->next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
+			else
 			if (inter) { fq.next(*b, batch_reads & ~(size_t)1, (size_t)BT2G_MAX_READ_LEN); finalize_interleaved(*b, opt); }
 			else if (opt.paired) {
 				// one batch per mate file in lockstep, interleaved into a batch of pairs
@@ -155,6 +161,7 @@ static int run_search(int argc, char** argv) {
 				merge_mate_batches(std::move(b1), std::move(b2), *b, opt);
 			} else
 			fq.next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
+			if (fq_unp && !unp_phase && b->last && b->bad_input.empty() && b->too_long.empty()) { b->last = false; unp_phase = true; }   // the run goes on with the unpaired reads
 			// --shard r/N: batch k is block k of the input; this rank keeps blocks r, r+N, ... (an emptied batch still carries
 			// the end-of-input marker and any input error)
 			b->block_id = blk++;
@@ -240,6 +247,7 @@ static int run_search(int argc, char** argv) {
 					// the host derived every read's seed parameters, so it knows the widest seed table of the batch: with the bound in
 					// the parameters bt2g_align_batch does not have to wait for the device to count them
 					AlignParams Pb = P;
+					Pb.paired = b->paired ? 1 : 0;       // (differs from P.paired only for the unpaired batches of a mixed run)
 					uint32_t max_seeds = 1;
 					for (size_t i = 0; i < n; i++) {
 						const uint32_t len = (uint32_t)(b->off[i + 1] - b->off[i]);
@@ -292,7 +300,7 @@ static int run_search(int argc, char** argv) {
 		fprintf(shard_idx, "F %llu\n", n_flagged);
 		fclose(shard_idx);
 	}
-	if (!opt.quiet && ex.shard_world == 1) { if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198); sharded: rank 0 of the driver prints the merged summary
+	if (!opt.quiet && ex.shard_world == 1) { if (opt.mixed_unpaired) print_mixed_summary(stderr, psumm, summ, !opt.no_discordant, !opt.no_mixed); else if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198); sharded: rank 0 of the driver prints the merged summary
 	for (bt2g_ctx* c : ctxs) bt2g_ctx_destroy(c);
 	if (n_flagged) {
 		// never pass off a capacity-limited result as the reference's

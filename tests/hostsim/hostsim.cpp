@@ -379,7 +379,7 @@ static void make_dev_index(const HostIndex& h, DevIndex<TOff>& d) {
 }
 
 template <typename TOff>
-static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metrics) {
+static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metrics, bool header = true, AlnSummary* keep = nullptr) {
 	DevIndex<TOff> ix;
 	make_dev_index(hidx, ix);
 	AlignParams P;
@@ -388,7 +388,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	ref.names = hidx.fw.refnames;
 	for (uint64_t i = 0; i < hidx.fw.n_pat; i++) ref.lens.push_back(hidx.plen_at(i));
 	std::string o;
-	if (!opt.sam_no_hd) sam_header(o, ref, opt.cmdline, true, !opt.sam_no_sq, opt.rg_id, opt.rgs);   // --no-hd drops every header line (bt2_search.cpp:5126-5130)
+	if (!opt.sam_no_hd && header) sam_header(o, ref, opt.cmdline, true, !opt.sam_no_sq, opt.rg_id, opt.rgs);   // --no-hd drops every header line (bt2_search.cpp:5126-5130)
 	fwrite(o.data(), 1, o.size(), out);
 	FastqBatcher fq(opt.reads_file, opt, 1);       // the product's reader, single-threaded
 	if (!fq.ok()) { fprintf(stderr, "cannot open %s\n", opt.reads_file.c_str()); return 1; }
@@ -446,13 +446,14 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		fprintf(shard_idx, "S %llu %llu %llu %llu\nP 0 0 0 0 0 0 0 0 0 0\nF 0\n", (unsigned long long)summ.nread, (unsigned long long)summ.n0, (unsigned long long)summ.nuni, (unsigned long long)summ.nrep);
 		fclose(shard_idx);
 	}
-	if (!opt.quiet && g_ex.shard_world == 1) summ.print(stderr);
+	if (keep) *keep = summ;
+	else if (!opt.quiet && g_ex.shard_world == 1) summ.print(stderr);
 	return 0;
 }
 
 // paired-end flavour of run(): two single-mate readers, one pair at a time through Aligner::run_pair
 template <typename TOff>
-static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool metrics) {
+static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool metrics, PairSummary* keep = nullptr) {
 	DevIndex<TOff> ix;
 	make_dev_index(hidx, ix);
 	AlignParams P;
@@ -515,7 +516,8 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 			                     rr1.n_ex_iters, rr1.n_ex_dps, rr1.n_mate_dps, rr1.n_ex_ugs, rr1.n_redundants, rr1.n_bt_attempts, rr1.nalns, rr2.nalns, rr1.pair_type);
 		}
 	}
-	if (!opt.quiet) summ.print(stderr, !opt.no_discordant, !opt.no_mixed);
+	if (keep) *keep = summ;
+	else if (!opt.quiet) summ.print(stderr, !opt.no_discordant, !opt.no_mixed);
 	return 0;
 }
 
@@ -535,6 +537,15 @@ int main(int argc, char** argv) {
 	if (load_index(opt.index_base, hidx, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
 	FILE* out = opt.out_file.empty() ? stdout : fopen(opt.out_file.c_str(), "wb");
 	int rc;
+	if (opt.mixed_unpaired) {
+		// pairs first, then the unpaired reads, one summary (the product's reader thread does the same, bt2g_search.cpp)
+		PairSummary ps; AlnSummary us;
+		Options po = opt; po.reads_file.clear();
+		Options uo = opt; uo.paired = false; uo.mate1_file.clear(); uo.mate2_file.clear(); uo.interleaved_file.clear();
+		rc = hidx.off_size == 4 ? run_pairs<uint32_t>(hidx, po, out, metrics, &ps) : run_pairs<uint64_t>(hidx, po, out, metrics, &ps);
+		if (rc == 0) rc = hidx.off_size == 4 ? run<uint32_t>(hidx, uo, out, metrics, false, &us) : run<uint64_t>(hidx, uo, out, metrics, false, &us);
+		if (rc == 0 && !opt.quiet) print_mixed_summary(stderr, ps, us, !opt.no_discordant, !opt.no_mixed);
+	} else
 	if (opt.paired) rc = hidx.off_size == 4 ? run_pairs<uint32_t>(hidx, opt, out, metrics) : run_pairs<uint64_t>(hidx, opt, out, metrics);
 	else rc = hidx.off_size == 4 ? run<uint32_t>(hidx, opt, out, metrics) : run<uint64_t>(hidx, opt, out, metrics);
 	if (out != stdout) fclose(out);
