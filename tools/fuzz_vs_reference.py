@@ -41,7 +41,7 @@ def mut(rnd,s,sub,indel):
 POOL_SE=[[],["--local"],["-k","2"],["-k","7"],["-a"],["--very-fast"],["--very-sensitive"],["--fast-local"],["--very-sensitive-local"],["-N","1"],["-L","12"],["-L","28"],["-i","C,5,0"],["-i","L,2,0.1"],
  ["--ignore-quals"],["--mp","4,1"],["--np","3"],["--rdg","3,2"],["--rfg","7,4"],["--score-min","L,-3,-0.3"],["--n-ceil","L,2,0.3"],["--nofw"],["--norc"],["--no-1mm-upfront"],["--no-exact-upfront"],
  ["-D","4"],["-R","1"],["-R","3"],["--gbar","8"],["--dpad","6"],["-5","3"],["-3","4"],["--overhang"],["--seed","17"],["-M","2"],["--xeq"],["--no-unal"],
- ["-d","-a","--no-exact-upfront","--no-1mm-upfront"],["--bwa-sw-like"],["--policy","MMP=C3;NP=C2"],["--trim-to","5:40"],["--trim-to","60"],["--passthrough"],["--omit-sec-seq","-k","3"],["--ma","3","--local"],["--qc-filter"],["--phred64"],["--policy","MMP=R"],["--policy","NP=Q;RDG=4"],["-F","30,7"],["--sam-append-comment"],["--solexa-quals"]]
+ ["-d","-a","--no-exact-upfront","--no-1mm-upfront"],["--bwa-sw-like"],["--policy","MMP=C3;NP=C2"],["--trim-to","5:40"],["--trim-to","60"],["--passthrough"],["--omit-sec-seq","-k","3"],["--ma","3","--local"],["--qc-filter"],["--phred64"],["--policy","MMP=R"],["--policy","NP=Q;RDG=4"],["-F","30,7"],["--sam-append-comment"],["--solexa-quals"],["--extends","30"],["--dp-fails","8"],["--ug-fails","5"],["--seed-boost","50"],["--tighten","1"],["--tighten","2"],["--no-extend"],["--no-ungapped"]]
 POOL_PE=[["--ff"],["--rf"],["--no-mixed"],["--no-discordant"],["--dovetail"],["--no-contain"],["--no-overlap"],["-I","80"],["-X","300"],["-X","700"],["--soft-clipped-unmapped-tlen"]]
 def conflicts(a):
     flat=" ".join(" ".join(x) for x in a)
@@ -69,6 +69,7 @@ for it in range(nit):
         if f.startswith("g."): os.unlink(d+"/"+f)
     write_fasta(fa,refs); build_index(fa,base,large)
     paired=rnd.random()<0.5
+    mixed_run=False
     n=rnd.randrange(20,120)
     sub=rnd.choice([0.0,0.01,0.03,0.08]); indel=rnd.choice([0.0,0.002,0.01])
     opts=[]
@@ -108,6 +109,10 @@ for it in range(nit):
         else:
             write_fastq(d+"/1.fq",r1); write_fastq(d+"/2.fq",r2)
             inp=["-1",d+"/1.fq","-2",d+"/2.fq"]
+            if rnd.random()<0.15:
+                # pairs and unpaired reads in one run (the reference only finishes on such input single-threaded)
+                us=[("u%d"%i,s_,q) for i,(_,s_,q) in enumerate(r1[:rnd.randrange(1,40)])]
+                write_fastq(d+"/u.fq",us); inp+=["-U",d+"/u.fq"]; mixed_run=True
     else:
         rs=[]
         for i in range(n):
@@ -126,7 +131,7 @@ for it in range(nit):
             inp=["-b"]+(["--preserve-tags"] if rnd.random()<0.5 else [])+["-U",d+"/r.bam"]
         else:
             write_fastq(d+"/r.fq",rs); inp=["-U",d+"/r.fq"]
-    a=subprocess.run([exe]+args+["-x",base]+inp+["-p","2","--reorder"],capture_output=True,text=True,errors="replace")
+    a=subprocess.run([exe]+args+["-x",base]+inp+(["-p","1"] if mixed_run else ["-p","2","--reorder"]),capture_output=True,text=True,errors="replace")
     b=subprocess.run([HS]+args+["-x",base]+inp,capture_output=True,text=True,errors="replace")
     body=lambda t:[l for l in t.splitlines() if not l.startswith("@PG")]
     if a.returncode!=0: continue
