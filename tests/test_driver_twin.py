@@ -1,0 +1,94 @@
+"""The product's aligner driver on the CPU: bowtie2_amd/csrc/bt2g_search.cpp (the code behind extern "C" bowtie() and the drop-in
+executables) compiled unchanged into tests/hostsim/driver_twin -- against a dozen HIP runtime calls on host memory and the C ABI of
+include/bt2g.h backed by the host-compiled worker.  Checked here, without a GPU, is what the driver adds around the kernels: reader /
+device-stage / writer threads with several batches in flight and ordered output, small --batch values, packed result records, the switch
+from pair batches to unpaired batches of a mixed run, --shard blocks + the shard index the N-GPU driver (bowtie2_amd.mgpu) merges."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from bt2test import have_ref, ref_bin
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+HS = os.path.join(ROOT, "tests", "hostsim")
+M1, M2, FQ = (os.path.join(GOLD, n) for n in ("pe_reads_1.fq", "pe_reads_2.fq", "align_reads.fq"))
+
+
+@pytest.fixture(scope="module")
+def twin():
+    exe = os.path.join(HS, "hostsim_driver_twin")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(HS, "fakehip"), "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(HS, "driver_twin.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    return exe
+
+
+def run(exe, args):
+    p = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-1500:]
+    return [l for l in p.stdout.splitlines() if not l.startswith("@PG")], [l for l in p.stderr.splitlines() if not l.startswith("Warning")]
+
+
+def golden(name):
+    return open(os.path.join(GOLD, name)).read().splitlines()
+
+
+@pytest.mark.parametrize("extra", [[], ["-p", "4", "--batch", "64"], ["-p", "2", "--batch", "2"], ["-p", "3", "--batch", "1000"]], ids=["default", "b64", "b2", "b1000"])
+def test_golden_sam_through_the_driver(twin, extra):
+    """several batches in flight on three device-stage threads, host threads for parsing / formatting: the SAM is the reference's golden SAM"""
+    for w in ("s", "l"):
+        base = os.path.join(GOLD, "tiny_" + w)
+        assert run(twin, ["--sensitive", "-x", base, "-U", FQ] + extra)[0] == golden("align_golden_%s_sens.sam" % w)
+        assert run(twin, ["--local", "-x", base, "-U", FQ] + extra)[0] == golden("align_golden_%s_local.sam" % w)
+        assert run(twin, ["-k", "5", "-x", base, "-U", FQ] + extra)[0] == golden("align_golden_%s_k5.sam" % w)
+        assert run(twin, ["--sensitive", "-x", base, "-1", M1, "-2", M2] + extra)[0] == golden("pe_golden_%s_sens.sam" % w)
+        assert run(twin, ["--local", "-k", "2", "-x", base, "-1", M1, "-2", M2] + extra)[0] == golden("pe_golden_%s_local.sam" % w)
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+def test_mixed_inputs_through_the_driver(twin):
+    """pairs, then unpaired reads, in one run of the driver: the kernel is chosen per batch, the summary is the mixed one
+    (the reference runs with -p 1: 2.5.5 does not finish on mixed input with more threads)"""
+    for opts in ([], ["--local", "-k", "3"], ["--no-mixed", "--no-unal"]):
+        a = opts + ["-x", os.path.join(GOLD, "tiny_s"), "-1", M1, "-2", M2, "-U", FQ + "," + FQ]
+        p = subprocess.run([ref_bin("bowtie2-align-s")] + a + ["-p", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        want = ([l for l in p.stdout.splitlines() if not l.startswith("@PG")], [l for l in p.stderr.splitlines() if not l.startswith("Warning")])
+        for extra in ([], ["-p", "3", "--batch", "64"], ["--batch", "2"]):
+            assert run(twin, a + extra) == want, (opts, extra)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("inp", ["unpaired", "paired"])
+def test_sharded_ranks_through_the_driver(twin, inp, tmp_path):
+    """bowtie2_amd.mgpu, world size 2 on gloo, every rank running the product's driver (--shard r/N, --shard-index): the SAM rank 0
+    reassembles and the summary it sums equal the one-process run and the golden SAM"""
+    src = ["-U", FQ] if inp == "unpaired" else ["-1", M1, "-2", M2]
+    common = ["--sensitive", "--batch", "64", "-x", os.path.join(GOLD, "tiny_s")] + src
+    one = run(twin, common)
+    port = free_port()
+    out = tmp_path / "merged.sam"
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-m", "bowtie2_amd.mgpu", "--engine", twin, "--backend", "gloo", "--"] + common + ["-S", str(out)],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for p in procs:
+        _, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        errs.append(se)
+    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    assert got == one[0] == golden("align_golden_s_sens.sam" if inp == "unpaired" else "pe_golden_s_sens.sam")
+    nsum = len(one[1])
+    assert [l for l in errs[0].strip().splitlines() if not l.startswith("Warning")][-nsum:] == one[1]
