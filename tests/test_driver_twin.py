@@ -92,3 +92,29 @@ def test_sharded_ranks_through_the_driver(twin, inp, tmp_path):
     assert got == one[0] == golden("align_golden_s_sens.sam" if inp == "unpaired" else "pe_golden_s_sens.sam")
     nsum = len(one[1])
     assert [l for l in errs[0].strip().splitlines() if not l.startswith("Warning")][-nsum:] == one[1]
+
+
+def test_two_device_contexts_keep_input_order(twin):
+    """--gpu 0,1: one context and three device-stage threads per listed device, batches dealt to whichever is free; the writer puts
+    them back in input order (with 16-read batches every device sees dozens of them)"""
+    base = os.path.join(GOLD, "tiny_s")
+    for extra in (["--gpu", "0,1", "--batch", "16", "-p", "4"], ["--gpu", "0,1,2", "--batch", "2"]):
+        assert run(twin, ["--sensitive", "-x", base, "-U", FQ] + extra)[0] == golden("align_golden_s_sens.sam")
+        assert run(twin, ["--sensitive", "-x", base, "-1", M1, "-2", M2] + extra)[0] == golden("pe_golden_s_sens.sam")
+
+
+def test_input_errors_end_the_run_with_an_error(twin, tmp_path):
+    """malformed input met by the reader thread while other stages are running: exit status 1 and an error message, never a short SAM with status 0"""
+    lines = open(FQ).read().splitlines()
+    cut = tmp_path / "cut.fq"
+    cut.write_text("\n".join(lines[:4 * 300 + 2]) + "\n")             # ends inside record 301
+    shortq = tmp_path / "shortq.fq"
+    bad = list(lines)
+    bad[4 * 200 + 3] = bad[4 * 200 + 3][:-3]                           # record 201: fewer qualities than bases
+    shortq.write_text("\n".join(bad) + "\n")
+    m2short = tmp_path / "m2.fq"
+    m2short.write_text("\n".join(open(M2).read().splitlines()[:4 * 100]) + "\n")
+    base = os.path.join(GOLD, "tiny_s")
+    for a in (["-U", str(cut)], ["-U", str(shortq)], ["-1", M1, "-2", str(m2short)], ["-U", str(tmp_path / "missing.fq")]):
+        p = subprocess.run([twin, "-x", base, "--batch", "64", "-p", "3"] + a, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 1 and "Error" in p.stderr, (a, p.returncode, p.stderr[-300:])
