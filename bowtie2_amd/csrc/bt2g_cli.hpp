@@ -391,7 +391,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		// FASTQ only: with FASTA input the reference loses the first unpaired record after the pairs, with BAM input its -U source takes paired
 		// records (observed on 2.5.5) -- behaviour this build does not reproduce, so those combinations stay refused
 		if (opt.format != 0) return "mixing paired and unpaired inputs in one run is supported for FASTQ input only in this build";
-		if (opt.skip != 0 || opt.upto != std::numeric_limits<uint64_t>::max()) return "-s/-u together with mixed paired and unpaired inputs is not supported by this build";
+		// (-s/-u count within each source, as in the reference: every PatternSource numbers its own reads)
 		if (ex.shard_world > 1) return "--shard together with mixed paired and unpaired inputs is not supported by this build";
 		opt.mixed_unpaired = true;
 	}

@@ -111,6 +111,7 @@ struct HostBatch {
 	std::string too_long;                 // name of a read over the length limit (fatal), if any
 	std::string bad_input;                // malformed or unsupported input record (fatal), if any
 	bool last = false;                    // end-of-input marker (may still carry reads)
+	bool upto_hit = false;                // ... and the end is -u's, not the file's: a mixed run then stops instead of going on to the unpaired files
 	bool terminator = false;              // tells one device worker to stop (carries nothing)
 	uint64_t seqno = 0;                   // position in the input, for ordered output with several devices
 	uint64_t block_id = 0;                // --shard: which block of the input this batch is
@@ -126,6 +127,7 @@ struct HostBatch {
 inline void merge_mate_batches(std::unique_ptr<HostBatch> b1, std::unique_ptr<HostBatch> b2, HostBatch& out, const Options& opt) {
 	out.paired = true;
 	out.last = b1->last || b2->last;
+	out.upto_hit = b1->upto_hit || b2->upto_hit;
 	out.bad_input = !b1->bad_input.empty() ? b1->bad_input : b2->bad_input;
 	out.too_long = !b1->too_long.empty() ? b1->too_long : b2->too_long;
 	if (out.bad_input.empty() && b1->reads.size() != b2->reads.size())
@@ -316,7 +318,7 @@ public:
 				do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
 				if (!got) { b.last = true; break; }
 				if (p[0] != '@') { b.bad_input = "reads file does not look like a FASTQ file"; b.last = true; break; }   // pat.cpp:1070
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
 				if (pt) orig_.append(p, src_.last_raw_len());
 				// a record cut short by the end of the file is malformed input (the reference aborts: pat.cpp:1100-1180), not the end of the run
@@ -337,7 +339,7 @@ public:
 					if (got) { pending_.assign(p, n); if (pt) pending_raw_.assign(p, src_.last_raw_len()); }
 				}
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				have_pending_ = false;
 				r.name_off = arena_.size(); r.name_len = pending_.size() - 1; arena_.append(pending_.data() + 1, pending_.size() - 1);
 				r.seq_off = arena_.size(); r.seq_len = 0;
@@ -351,7 +353,7 @@ public:
 				}
 			} else if (opt_.format == 3) {             // -c: reads given on the command line, "SEQ[:QUALS]" separated by commas
 				if (cmd_pos_ > cmd_.size() || cmd_.empty()) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				size_t e = cmd_.find(',', cmd_pos_);
 				if (e == std::string::npos) e = cmd_.size();
 				const std::string tok = cmd_.substr(cmd_pos_, e - cmd_pos_);
@@ -365,7 +367,7 @@ public:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				if (pt) orig_.append(p, n);
 				const char* t1 = (const char*)memchr(p, '\t', n);
 				const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(p + n - t1 - 1)) : nullptr;
@@ -399,7 +401,7 @@ public:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				const char* f[12]; int nf = 0; f[nf++] = p;
 				for (size_t k = 0; k < n && nf < 12; k++) if (p[k] == '\t') f[nf++] = p + k + 1;
 				if (nf != 11) { b.bad_input = "malformed QSEQ record (expected 11 fields)"; b.last = true; break; }
@@ -455,9 +457,9 @@ public:
 					got = true;
 				}
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 			} else if (opt_.format == 6) {             // -F k:<len>,i:<freq>: every <freq>-th <len>-mer of a FASTA file (FastaContinuousPatternSource, pat.cpp:913-1036)
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				bool emitted = false;
 				while (!emitted) {
 					if (fc_pos_ >= fc_line_.size()) {
@@ -497,7 +499,7 @@ public:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; break; }
+				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				r.name_off = arena_.size(); r.name_len = 0;
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
 				if (pt) orig_.append(p, n);

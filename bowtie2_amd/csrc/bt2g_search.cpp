@@ -161,7 +161,7 @@ static int run_search(int argc, char** argv) {
 				merge_mate_batches(std::move(b1), std::move(b2), *b, opt);
 			} else
 			fq.next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
-			if (fq_unp && !unp_phase && b->last && b->bad_input.empty() && b->too_long.empty()) { b->last = false; unp_phase = true; }   // the run goes on with the unpaired reads
+			if (fq_unp && !unp_phase && b->last && !b->upto_hit && b->bad_input.empty() && b->too_long.empty()) { b->last = false; unp_phase = true; }   // the run goes on with the unpaired reads
 			// --shard r/N: batch k is block k of the input; this rank keeps blocks r, r+N, ... (an emptied batch still carries
 			// the end-of-input marker and any input error)
 			b->block_id = blk++;

@@ -453,7 +453,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 
 // paired-end flavour of run(): two single-mate readers, one pair at a time through Aligner::run_pair
 template <typename TOff>
-static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool metrics, PairSummary* keep = nullptr) {
+static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool metrics, PairSummary* keep = nullptr, bool* upto_hit = nullptr) {
 	DevIndex<TOff> ix;
 	make_dev_index(hidx, ix);
 	AlignParams P;
@@ -490,6 +490,7 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 			merge_mate_batches(std::move(b1), std::move(b2), hb, opt);
 		}
 		last = hb.last;
+		if (upto_hit && hb.upto_hit) *upto_hit = true;
 		if (!hb.bad_input.empty()) { fprintf(stderr, "Error: %s\n", hb.bad_input.c_str()); return 1; }
 		for (size_t pi = 0; pi + 1 < hb.reads.size(); pi += 2, pair_no++) {
 			const ReadRec& r1 = hb.reads[pi]; const ReadRec& r2 = hb.reads[pi + 1];
@@ -542,8 +543,9 @@ int main(int argc, char** argv) {
 		PairSummary ps; AlnSummary us;
 		Options po = opt; po.reads_file.clear();
 		Options uo = opt; uo.paired = false; uo.mate1_file.clear(); uo.mate2_file.clear(); uo.interleaved_file.clear();
-		rc = hidx.off_size == 4 ? run_pairs<uint32_t>(hidx, po, out, metrics, &ps) : run_pairs<uint64_t>(hidx, po, out, metrics, &ps);
-		if (rc == 0) rc = hidx.off_size == 4 ? run<uint32_t>(hidx, uo, out, metrics, false, &us) : run<uint64_t>(hidx, uo, out, metrics, false, &us);
+		bool upto_hit = false;      // -u ended the pairs: the run ends there (the reference's composer reports "done")
+		rc = hidx.off_size == 4 ? run_pairs<uint32_t>(hidx, po, out, metrics, &ps, &upto_hit) : run_pairs<uint64_t>(hidx, po, out, metrics, &ps, &upto_hit);
+		if (rc == 0 && !upto_hit) rc = hidx.off_size == 4 ? run<uint32_t>(hidx, uo, out, metrics, false, &us) : run<uint64_t>(hidx, uo, out, metrics, false, &us);
 		if (rc == 0 && !opt.quiet) print_mixed_summary(stderr, ps, us, !opt.no_discordant, !opt.no_mixed);
 	} else
 	if (opt.paired) rc = hidx.off_size == 4 ? run_pairs<uint32_t>(hidx, opt, out, metrics) : run_pairs<uint64_t>(hidx, opt, out, metrics);

@@ -17,7 +17,9 @@ HS = os.path.join(ROOT, "tests", "hostsim")
 EXE = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-s")
 M1, M2, FQ = (os.path.join(GOLD, n) for n in ("pe_reads_1.fq", "pe_reads_2.fq", "align_reads.fq"))
 
-OPTION_SETS = [[], ["--local", "-k", "3"], ["--no-mixed", "--no-discordant"], ["--very-fast", "--no-unal"], ["-N", "1", "-L", "18", "--ff"]]
+# -s/-u count within each source (every PatternSource numbers its own reads); a -u that ends the pairs ends the run (160 pairs in the fixture)
+OPTION_SETS = [[], ["--local", "-k", "3"], ["--no-mixed", "--no-discordant"], ["--very-fast", "--no-unal"], ["-N", "1", "-L", "18", "--ff"],
+               ["-u", "200"], ["-u", "100"], ["-u", "160"], ["-u", "159"], ["-s", "100", "-u", "61"], ["-s", "170", "-u", "20"], ["-s", "1000"]]
 
 
 @pytest.fixture(scope="module")
@@ -46,7 +48,8 @@ def check(exe, idx, tmp, extra):
         for src in (["-1", M1, "-2", M2], ["--interleaved", inter]):
             a = opts + ["-x", base] + src + ["-U", FQ + "," + FQ]
             want = run(ref, a, ["-p", "1"])
-            assert any("were paired" in l for l in want[1]) and any("were unpaired" in l for l in want[1])
+            if not any(o in opts for o in ("-s", "-u")):
+                assert any("were paired" in l for l in want[1]) and any("were unpaired" in l for l in want[1])
             assert run(exe, a, extra) == want, (opts, src[0])
 
 
@@ -59,7 +62,7 @@ def test_mixed_inputs_match_reference_hostsim(hostsim, idx, tmp_path):
 def test_mixed_inputs_refused_where_the_reference_misbehaves(hostsim, tmp_path):
     fa = os.path.join(str(tmp_path), "r.fa")
     open(fa, "w").write(">a\nACGTACGTACGTACGTACGTACGTAACC\n>b\nACGTACGTACGTACGTACGTACGTAACC\n")
-    for a in (["-f", "-1", fa, "-2", fa, "-U", fa], ["-1", M1, "-2", M2, "-U", FQ, "-s", "3"], ["-1", M1, "-2", M2, "-U", FQ, "-u", "30"]):
+    for a in (["-f", "-1", fa, "-2", fa, "-U", fa], ["-b", "--align-paired-reads", "-1", fa, "-2", fa, "-U", fa], ["--tab5", fa, "-1", M1, "-2", M2]):
         p = subprocess.run([hostsim] + a + ["-x", os.path.join(GOLD, "tiny_s")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert p.returncode != 0 and p.stdout == "", a
 
