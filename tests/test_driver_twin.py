@@ -52,7 +52,7 @@ def test_golden_sam_through_the_driver(twin, extra):
 def test_mixed_inputs_through_the_driver(twin):
     """pairs, then unpaired reads, in one run of the driver: the kernel is chosen per batch, the summary is the mixed one
     (the reference runs with -p 1: 2.5.5 does not finish on mixed input with more threads)"""
-    for opts in ([], ["--local", "-k", "3"], ["--no-mixed", "--no-unal"]):
+    for opts in ([], ["--local", "-k", "3"], ["--no-mixed", "--no-unal"], ["-u", "100"], ["-u", "200"], ["-s", "100", "-u", "61"]):
         a = opts + ["-x", os.path.join(GOLD, "tiny_s"), "-1", M1, "-2", M2, "-U", FQ + "," + FQ]
         p = subprocess.run([ref_bin("bowtie2-align-s")] + a + ["-p", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         want = ([l for l in p.stdout.splitlines() if not l.startswith("@PG")], [l for l in p.stderr.splitlines() if not l.startswith("Warning")])
