@@ -420,6 +420,7 @@ inline void sam_print_bam_tags(std::string& o, const StrView& t) {
 		o.append(b + i, 2); i += 2;
 		char ty = b[i];
 		if (ty == 'B') {
+			if (i + 6 > len) break;              // array header cut short: malformed record, stop here
 			ty = b[i + 1]; i += 2;
 			memcpy(&count, b + i, 4); i += 4;
 			o += ":B:"; o.push_back(ty); o.push_back(',');

@@ -428,6 +428,7 @@ public:
 						continue;
 					}
 					if (block_size == 0) { bam_ok_ = bam_.next_file(bam_err_); if (!bam_ok_ && !bam_err_.empty()) b.bad_input = bam_err_; continue; }
+					if (block_size > (1u << 28)) { b.bad_input = "error while reading the BAM file (implausible record length: corrupt input?)"; break; }
 					bam_rec_.resize(block_size);
 					if (block_size < 32 || !bam_.read(&bam_rec_[0], block_size)) { b.bad_input = "error while reading the BAM file (truncated or corrupt)"; break; }
 					uint16_t flag; memcpy(&flag, bam_rec_.data() + 14, 2);
