@@ -118,3 +118,31 @@ def test_input_errors_end_the_run_with_an_error(twin, tmp_path):
     for a in (["-U", str(cut)], ["-U", str(shortq)], ["-1", M1, "-2", str(m2short)], ["-U", str(tmp_path / "missing.fq")]):
         p = subprocess.run([twin, "-x", base, "--batch", "64", "-p", "3"] + a, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         assert p.returncode == 1 and "Error" in p.stderr, (a, p.returncode, p.stderr[-300:])
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+def test_option_surface_through_the_driver(twin, tmp_path):
+    """every option set, input format and paired option set of tests/test_cli_options.py / tests/test_paired.py, this time through the
+    product's driver (48-read batches, three host threads) against the reference binary: SAM and summary"""
+    import test_cli_options as t
+    import test_paired as tp
+    ref = ref_bin("bowtie2-align-s")
+    base = os.path.join(GOLD, "tiny_s")
+    extra = ["--batch", "48", "-p", "3"]
+    tmp = str(tmp_path)
+
+    def both(args, all_mode=False):
+        a = t.run(ref, args, tmp)
+        out = os.path.join(tmp, "o.sam")
+        p = subprocess.run([twin] + args + extra + ["-S", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        # -a on the 3-bp read "short" is over the record capacity: the driver flags it and exits 1 by design, every other read must agree
+        assert p.returncode == 0 or (all_mode and "exceeded a limit of this build" in p.stderr), p.stderr[-1500:]
+        sam = [l for l in open(out).read().splitlines() if not l.startswith("@PG") and not (all_mode and l.startswith("short\t"))]
+        summ = [] if all_mode else [l for l in p.stderr.splitlines() if not l.startswith("Warning")]
+        assert (sam, summ) == a, args
+    for opts in t.OPTION_SETS:
+        both(opts + ["-x", base, "-U", t.FQ], "-a" in opts or "--all" in opts)
+    for opts, path in t.input_variants(tmp):
+        both((opts[:1] + [path] + opts[1:] + ["-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path]))
+    for opts in tp.OPTION_SETS:
+        both(list(opts) + ["-x", base, "-1", M1, "-2", M2])
