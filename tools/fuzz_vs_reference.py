@@ -3,7 +3,9 @@
 low-complexity stretches), random unpaired or paired reads (substitutions, indels, junk and mis-oriented mates), a random
 subset of options, either index width.  Runs the host-compiled worker (tests/hostsim -- build it first, e.g. by running
 pytest tests/test_hostsim_golden.py) and the reference on the same input and logs every case whose SAM differs and that
-our side did not flag as over a capacity limit.  usage: fuzz_vs_reference.py <seed> <iterations>   (scratch under /tmp/fuzz)"""
+our side did not flag as over a capacity limit.  usage: fuzz_vs_reference.py <seed> <iterations>   (scratch under /tmp/fuzz)
+BT2G_HOSTSIM=<exe> picks the engine: tests/hostsim/hostsim (the worker under a plain main) or tests/hostsim/hostsim_driver_twin (the product's
+driver, bt2g_search.cpp, on the CPU -- built by tests/test_driver_twin.py; wrap it in a script to add e.g. --batch 16 -p 3)."""
 import sys, os, subprocess, random, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
