@@ -100,8 +100,23 @@ extern "C" {
 int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_params* d_rparams, const bt2g_align_params* params, uint32_t, void* d_results, void*) {
 	if (!c->loaded) { c->err = "no index loaded"; return 1; }
 	if (params->paired && (reads->n_reads & 1u)) { c->err = "paired mode needs an even number of reads (mates interleaved)"; return 1; }
-	std::lock_guard<std::mutex> g(g_twin_mu);
 	const AlignParams& P = *(const AlignParams*)params;
+	if (getenv("BT2G_TWIN_NULL_ALIGNER")) {
+		// host-pipeline profiling aid (tools/host_pipeline_rate.sh): no alignment at all, every read "aligns" end to end without edits at a
+		// position made up from its index, so that parsing, packing, SAM formatting and writing can be timed at their own speed
+		const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
+		bt2g_index_info inf; bt2g_index_info_get(c, &inf);
+		for (uint32_t i = 0; i < reads->n_reads; i++) {
+			ReadResult* rr = (ReadResult*)((uint8_t*)d_results + (uint64_t)i * stride);
+			memset(rr, 0, offsetof(ReadResult, alns) + sizeof(AlnRes));
+			const uint32_t len = (uint32_t)(reads->d_off[i + 1] - reads->d_off[i]);
+			rr->aligned = 1; rr->nalns = 1; rr->nreport = 1; rr->filt = 15; rr->best = 0; rr->secbest = 0;
+			AlnRes& a = rr->alns[0];
+			a.refid = 0; a.refoff = (int64_t)((uint64_t)i * 97 % (c->hidx.plen_at(0) > len ? c->hidx.plen_at(0) - len : 1)); a.reflen = (int64_t)c->hidx.plen_at(0); a.rdlen = (uint16_t)len; a.rfextent = (uint16_t)len; a.rdextent = (uint16_t)len; a.fw = (i & 1); a.score = 0; a.nned = 0;
+		}
+		return 0;
+	}
+	std::lock_guard<std::mutex> g(g_twin_mu);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	if (c->hidx.off_size == 4) twin_align<uint32_t>(c, c->ix32, reads, (const ReadParams*)d_rparams, P, (uint8_t*)d_results, stride);
 	else twin_align<uint64_t>(c, c->ix64, reads, (const ReadParams*)d_rparams, P, (uint8_t*)d_results, stride);
