@@ -212,7 +212,8 @@ typedef struct {
 	                                  the N ceiling, overhanging read ends come back soft-clipped                    */
 	/* paired-end mode (extendSeedsPaired, PairedEndPolicy pe.h:169).  With paired != 0 the batch holds mates
 	   interleaved (read 2i = mate 1, read 2i+1 = mate 2 of pair i) and result record 2i / 2i+1 belong together */
-	int32_t paired;
+	int32_t paired;                /* may differ from one bt2g_align_batch call to the next on the same context (a run with -1/-2 AND -U sends
+	                                  its pair batches first, then unpaired ones): the context re-initialises its work arena when the mode changes */
 	int32_t pe_policy;             /* PE_POLICY_FF 1, RR 2, FR 3 (default), RF 4 (pe.h:33-36)                   */
 	int32_t pe_maxfrag, pe_minfrag;/* -X / -I                                                                    */
 	int32_t pe_flags;              /* BT2G_PE_* below                                                            */
