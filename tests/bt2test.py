@@ -309,3 +309,23 @@ def write_bam(path, records, block=600, refs=(("chrT", 1000),)):
         for i in range(0, len(raw), block):
             f.write(bgzf(raw[i:i + block]))
         f.write(bgzf(b""))      # the end-of-file marker block
+
+
+# ---- the host-compiled worker (tests/hostsim/hostsim.cpp): one compilation per test session ----
+_hostsim_built = {}
+
+
+def build_hostsim(exe):
+    """Compile tests/hostsim/hostsim.cpp (the worker source under a plain main(), test-only) to `exe`.  Every test module used to compile
+    its own copy (12 s each, a dozen modules); the first call of a session compiles, later ones copy the binary."""
+    import shutil
+    import subprocess
+    hs = os.path.join(ROOT, "tests", "hostsim")
+    first = _hostsim_built.get("exe")
+    if first is None or not os.path.exists(first):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                               os.path.join(hs, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+        _hostsim_built["exe"] = exe
+    elif os.path.abspath(first) != os.path.abspath(exe):
+        shutil.copy2(first, exe)
+    return exe

@@ -4,7 +4,7 @@ import subprocess
 
 import pytest
 
-from bt2test import build_index
+from bt2test import build_index, build_hostsim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "all_hits")
@@ -37,8 +37,7 @@ def check(exe, tmp_path, want_rc):
 @pytest.fixture(scope="module")
 def hostsim():
     exe = os.path.join(HS, "hostsim_allhits")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    build_hostsim(exe)
     return exe
 
 

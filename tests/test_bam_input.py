@@ -8,7 +8,7 @@ import subprocess
 
 import pytest
 
-from bt2test import bam_record, have_ref, ref_bin, write_bam
+from bt2test import bam_record, have_ref, ref_bin, write_bam, build_hostsim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -19,8 +19,7 @@ EXE = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-s")
 @pytest.fixture(scope="module")
 def hostsim():
     exe = os.path.join(HS, "hostsim")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    build_hostsim(exe)
     return exe
 
 

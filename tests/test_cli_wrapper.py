@@ -8,7 +8,7 @@ import subprocess
 
 import pytest
 
-from bt2test import have_ref, ref_bin
+from bt2test import have_ref, ref_bin, build_hostsim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "bowtie2_amd", "bin")
@@ -65,8 +65,7 @@ def test_perl_wrapper_un_al_conc_with_host_build(tmp_path):
     wrapper is run twice on the same pairs -- once over the reference binaries, once over our host-compiled worker standing in
     as bowtie2-align-s/-l (test infrastructure; the product binary needs a GPU) -- and every output file must be identical."""
     hs = os.path.join(ROOT, "tests", "hostsim", "hostsim")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", hs,
-                           os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    build_hostsim(hs)
     outs = {}
     for tag in ("ref", "ours"):
         d = tmp_path / tag

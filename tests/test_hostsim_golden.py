@@ -5,6 +5,8 @@ import subprocess
 
 import pytest
 
+from bt2test import build_hostsim
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 HS = os.path.join(ROOT, "tests", "hostsim")
@@ -13,8 +15,7 @@ HS = os.path.join(ROOT, "tests", "hostsim")
 @pytest.fixture(scope="module")
 def hostsim():
     exe = os.path.join(HS, "hostsim")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    build_hostsim(exe)
     return exe
 
 

@@ -7,6 +7,8 @@ import socket
 import subprocess
 import sys
 
+from bt2test import build_hostsim
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
@@ -118,8 +120,7 @@ def test_sharded_driver_two_ranks_sam_identical(tmp_path):
     byte-identical to the reference's golden SAM / the 1-rank run."""
     gold = os.path.join(ROOT, "tests", "golden")
     hs = os.path.join(ROOT, "tests", "hostsim", "hostsim")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", hs,
-                           os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    build_hostsim(hs)
     common = ["--sensitive", "--batch", "64", "-x", os.path.join(gold, "tiny_s"), "-U", os.path.join(gold, "align_reads.fq")]
     one = subprocess.run([hs] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
     port = free_port()

@@ -7,7 +7,7 @@ import subprocess
 
 import pytest
 
-from bt2test import CACHE_DIR, build_index, have_ref, ref_bin, revcomp, write_fasta, write_fastq
+from bt2test import CACHE_DIR, build_index, have_ref, ref_bin, revcomp, write_fasta, write_fastq, build_hostsim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HS = os.path.join(ROOT, "tests", "hostsim")
@@ -68,8 +68,7 @@ def check(exe_s, exe_l):
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 def test_overhang_hostsim():
     exe = os.path.join(HS, "hostsim")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    build_hostsim(exe)
     check(exe, exe)
 
 

@@ -15,7 +15,7 @@ import subprocess
 
 import pytest
 
-from bt2test import CACHE_DIR, build_index, have_ref, ref_bin, write_fasta, write_fastq
+from bt2test import CACHE_DIR, build_index, have_ref, ref_bin, write_fasta, write_fastq, build_hostsim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HS = os.path.join(ROOT, "tests", "hostsim")
@@ -76,8 +76,7 @@ def check(exe, large, args, host_twin):
 @pytest.fixture(scope="module")
 def hostsim():
     exe = os.path.join(HS, "hostsim_met")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    build_hostsim(exe)
     return exe
 
 

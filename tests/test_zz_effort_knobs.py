@@ -10,7 +10,7 @@ import subprocess
 
 import pytest
 
-from bt2test import CACHE_DIR, have_ref, ref_bin
+from bt2test import CACHE_DIR, have_ref, ref_bin, build_hostsim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HS = os.path.join(ROOT, "tests", "hostsim")
@@ -26,8 +26,7 @@ PE_SETS = [["--extends", "30", "--dp-fails", "10"], ["--no-ungapped", "--tighten
 @pytest.fixture(scope="module")
 def hostsim():
     exe = os.path.join(HS, "hostsim")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+    build_hostsim(exe)
     return exe
 
 
