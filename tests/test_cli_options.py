@@ -105,5 +105,7 @@ def test_options_match_reference_gpu(tmp_path):
         args = opts + ["-x", base, "-U", FQ]
         assert run(EXE, args + ["-p", "4"], str(tmp_path)) == run(ref, args, str(tmp_path)), opts
     for opts, path in input_variants(str(tmp_path)):
+        if opts and opts[0].startswith("--solexa"):
+            continue        # added when round 2's GPU minutes were spent: their GPU twin lives in tests/test_zz_bam_input.py, which sorts last (-x)
         args = (opts[:1] + [path] + opts[1:] + ["-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path])
         assert run(EXE, args, str(tmp_path)) == run(ref, args, str(tmp_path)), opts

@@ -138,3 +138,9 @@ def test_bam_and_sam_options_match_reference_gpu(tmp_path):
     for c in cases(str(tmp_path)):
         args = c + ["-x", os.path.join(GOLD, "tiny_s")]
         assert run(EXE, args + ["-p", "2"]) == run(ref, args), c
+    # the quality-scale variants of tests/test_cli_options.py that were added with this file
+    import test_cli_options as t
+    for opts, path in t.input_variants(str(tmp_path)):
+        if opts and opts[0].startswith("--solexa"):
+            args = opts + ["-x", os.path.join(GOLD, "tiny_s"), "-U", path]
+            assert run(EXE, args + ["-p", "2"]) == run(ref, args), opts

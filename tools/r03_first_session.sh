@@ -6,7 +6,7 @@
 # 3. the occupancy probe: the worker kernels rebuilt for 5 and 6 waves per SIMD (102 / 85 VGPRs), short bench with the 1 M-read parity check each
 T=${1:-r03a}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$T; mkdir -p $O; cd $R; export TMPDIR=/tmp
-(timeout 900 python -m pytest -q -m gpu tests/test_bam_input.py tests/test_cli_options.py tests/test_zz_effort_knobs.py tests/test_zz_mixed_inputs.py 2>&1 | tail -25) | tee $O/pytest_new_gpu_tests.log
+(timeout 900 python -m pytest -q -m gpu tests/test_zz_bam_input.py tests/test_zz_effort_knobs.py tests/test_zz_mixed_inputs.py 2>&1 | tail -25) | tee $O/pytest_new_gpu_tests.log
 (timeout 600 python bench.py 2>$O/bench.err | tail -1) > $O/bench_wpe4.json; cut -c1-400 $O/bench_wpe4.json
 for W in 5 6; do
   touch bowtie2_amd/csrc/bt2g_align_kernel.hip
