@@ -708,11 +708,14 @@ struct AlnSummary {
 	void add(const ReadResult& r) { nread++; if (!r.aligned) n0++; else if (r.maxed || r.nalns > 1) nrep++; else nuni++; }
 	void print(FILE* f) const {
 		auto pct = [](uint64_t a, uint64_t b) { char buf[32]; snprintf(buf, sizeof buf, "%.2f%%", b ? 100.0 * (double)a / (double)b : 0.0); return std::string(buf); };
-		fprintf(f, "%llu reads; of these:\n", (unsigned long long)nread);
-		fprintf(f, "  %llu (%s) were unpaired; of these:\n", (unsigned long long)nread, pct(nread, nread).c_str());
-		fprintf(f, "    %llu (%s) aligned 0 times\n", (unsigned long long)n0, pct(n0, nread).c_str());
-		fprintf(f, "    %llu (%s) aligned exactly 1 time\n", (unsigned long long)nuni, pct(nuni, nread).c_str());
-		fprintf(f, "    %llu (%s) aligned >1 times\n", (unsigned long long)nrep, pct(nrep, nread).c_str());
+		if (nread == 0) fprintf(f, "0 reads\n");        // no "of these" and no section for an empty run (aln_sink.cpp:364-370, 457)
+		else {
+			fprintf(f, "%llu reads; of these:\n", (unsigned long long)nread);
+			fprintf(f, "  %llu (%s) were unpaired; of these:\n", (unsigned long long)nread, pct(nread, nread).c_str());
+			fprintf(f, "    %llu (%s) aligned 0 times\n", (unsigned long long)n0, pct(n0, nread).c_str());
+			fprintf(f, "    %llu (%s) aligned exactly 1 time\n", (unsigned long long)nuni, pct(nuni, nread).c_str());
+			fprintf(f, "    %llu (%s) aligned >1 times\n", (unsigned long long)nrep, pct(nrep, nread).c_str());
+		}
 		fprintf(f, "%s overall alignment rate\n", pct(nuni + nrep, nread).c_str());
 	}
 };

@@ -28,11 +28,14 @@ def print_summary(S, P, paired, discord, mixed, f=sys.stderr):
     """The alignment summary as AlnSink::printAlSumm writes it (aln_sink.cpp:377-528), from summed counters."""
     if not paired:
         nread, n0, nuni, nrep = S
-        f.write("%d reads; of these:\n" % nread)
-        f.write("  %d (%s) were unpaired; of these:\n" % (nread, pct(nread, nread)))
-        f.write("    %d (%s) aligned 0 times\n" % (n0, pct(n0, nread)))
-        f.write("    %d (%s) aligned exactly 1 time\n" % (nuni, pct(nuni, nread)))
-        f.write("    %d (%s) aligned >1 times\n" % (nrep, pct(nrep, nread)))
+        if nread == 0:
+            f.write("0 reads\n")      # an empty run has no "of these" and no section (aln_sink.cpp:364-370)
+        else:
+            f.write("%d reads; of these:\n" % nread)
+            f.write("  %d (%s) were unpaired; of these:\n" % (nread, pct(nread, nread)))
+            f.write("    %d (%s) aligned 0 times\n" % (n0, pct(n0, nread)))
+            f.write("    %d (%s) aligned exactly 1 time\n" % (nuni, pct(nuni, nread)))
+            f.write("    %d (%s) aligned >1 times\n" % (nrep, pct(nrep, nread)))
         f.write("%s overall alignment rate\n" % pct(nuni + nrep, nread))
         return
     npair, conc0, cu1, cu2, crep, ndisc, u00, u1, u2, urep = P

@@ -140,7 +140,7 @@ def test_option_surface_through_the_driver(twin, tmp_path):
         sam = [l for l in open(out).read().splitlines() if not l.startswith("@PG") and not (all_mode and l.startswith("short\t"))]
         summ = [] if all_mode else [l for l in p.stderr.splitlines() if not l.startswith("Warning")]
         assert (sam, summ) == a, args
-    for opts in t.OPTION_SETS:
+    for opts in t.OPTION_SETS + t.LATE_SETS:
         both(opts + ["-x", base, "-U", t.FQ], "-a" in opts or "--all" in opts)
     for opts, path in t.input_variants(tmp):
         both((opts[:1] + [path] + opts[1:] + ["-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path]))
