@@ -315,8 +315,11 @@ public:
 			r2 = r;
 			if (opt_.format == 0) {                    // FASTQ: 4-line records
 				bool got;
-				do { got = src_.next(p, n); } while (got && n == 0);        // blank lines between records
-				if (!got) { b.last = true; break; }
+				size_t nblank = 0;
+				do { got = src_.next(p, n); if (got && n == 0) nblank++; } while (got && n == 0);        // blank lines between records
+				// a file of nothing but blank lines is not an empty FASTQ file: the reference looks for '@' after them and aborts (pat.cpp:1070)
+				if (!got) { if (!fastq_started_ && nblank > 0) b.bad_input = "reads file does not look like a FASTQ file"; b.last = true; break; }
+				fastq_started_ = true;
 				if (p[0] != '@') { b.bad_input = "reads file does not look like a FASTQ file"; b.last = true; break; }   // pat.cpp:1070
 				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
@@ -614,6 +617,7 @@ public:
 	}
 private:
 	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; size_t tag_off = 0, tag_len = 0; };
+	bool fastq_started_ = false;     // a FASTQ record (or a line that should have been one) has been seen
 	BamStream bam_; bool bam_ok_ = false; std::string bam_err_, bam_rec_; int bam_mate_ = 0;     // -b state
 	std::string fc_line_, fc_prefix_, fc_win_;     // -F state
 	size_t fc_pos_ = 0, fc_eat_ = 0; uint64_t fc_cur_ = 0, fc_last_ = 0; bool fc_beginning_ = true;

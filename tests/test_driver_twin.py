@@ -146,3 +146,22 @@ def test_option_surface_through_the_driver(twin, tmp_path):
         both((opts[:1] + [path] + opts[1:] + ["-x", base]) if opts and opts[0].startswith("--tab") else (opts + ["-x", base, "-U", path]))
     for opts in tp.OPTION_SETS:
         both(list(opts) + ["-x", base, "-1", M1, "-2", M2])
+
+
+def test_degenerate_fastq_files(twin, tmp_path):
+    """an empty file is an empty run ("0 reads"); a file of nothing but blank lines is not FASTQ (the reference aborts on it, pat.cpp:1070);
+    blank lines before the first or after the last record are skipped; a last line without its newline and CRLF line ends are read"""
+    base = os.path.join(GOLD, "tiny_s")
+    rec = "@r1\nACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII"
+    files = {"empty": "", "blank": "\n\n\n", "lead": "\n\n" + rec + "\n", "trail": rec + "\n\n\n\n", "nonl": rec, "crlf": rec.replace("\n", "\r\n") + "\r\n"}
+    for name, text in files.items():
+        p = tmp_path / (name + ".fq")
+        p.write_bytes(text.encode())
+        r = subprocess.run([twin, "-x", base, "-U", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        body = [l for l in r.stdout.splitlines() if not l.startswith("@")]
+        if name == "blank":
+            assert r.returncode == 1 and "does not look like a FASTQ file" in r.stderr
+        elif name == "empty":
+            assert r.returncode == 0 and body == [] and r.stderr.splitlines()[-2:] == ["0 reads", "0.00% overall alignment rate"]
+        else:
+            assert r.returncode == 0 and len(body) == 1 and body[0].startswith("r1\t"), name
