@@ -337,7 +337,11 @@ public:
 			} else if (opt_.format == 1) {             // FASTA: '>' name, sequence possibly over several lines
 				bool got = true;
 				if (!have_pending_) {
-					do { got = src_.next(p, n); } while (got && n == 0);
+					size_t nblank = 0;
+					do { got = src_.next(p, n); if (got && n == 0) nblank++; } while (got && n == 0);
+					// nothing but blank lines: not an empty FASTA file for the reference, which looks for '>' after them (pat.cpp:785-796)
+					if (!got && !fasta_started_ && nblank > 0) { b.bad_input = "reads file does not look like a FASTA file"; b.last = true; break; }
+					fasta_started_ = true;
 					if (got && p[0] != '>') { b.bad_input = "reads file does not look like a FASTA file"; b.last = true; break; }   // pat.cpp:794
 					if (got) { pending_.assign(p, n); if (pt) pending_raw_.assign(p, src_.last_raw_len()); }
 				}
@@ -508,6 +512,9 @@ public:
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
 				if (pt) orig_.append(p, n);
 			}
+			// a FASTA record without a single sequence character is not a read for the reference ("FASTA ended prematurely", pat.cpp:849-851):
+			// it takes its number in the input and is dropped (unpaired input only: a pair loses both mates there)
+			if (opt_.format == 1 && !opt_.paired && r.seq_len == 0) { orig_.resize(r.orig_off); rdid_++; continue; }
 			r.orig_len = orig_.size() - r.orig_off;
 			r.rdid = rdid_ / unit_;
 			const bool skip1 = (rdid_++) / unit_ < opt_.skip;
@@ -617,6 +624,7 @@ public:
 	}
 private:
 	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; size_t tag_off = 0, tag_len = 0; };
+	bool fasta_started_ = false;
 	bool fastq_started_ = false;     // a FASTQ record (or a line that should have been one) has been seen
 	BamStream bam_; bool bam_ok_ = false; std::string bam_err_, bam_rec_; int bam_mate_ = 0;     // -b state
 	std::string fc_line_, fc_prefix_, fc_win_;     // -F state

@@ -165,3 +165,25 @@ def test_degenerate_fastq_files(twin, tmp_path):
             assert r.returncode == 0 and body == [] and r.stderr.splitlines()[-2:] == ["0 reads", "0.00% overall alignment rate"]
         else:
             assert r.returncode == 0 and len(body) == 1 and body[0].startswith("r1\t"), name
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+def test_degenerate_fasta_files(twin, tmp_path):
+    """FASTA records without a single sequence character are not reads for the reference (pat.cpp:849-851: they take their number and are
+    dropped), a last line without its newline loses its last character, a file of blank lines only is an error: SAM and summary equal the reference's"""
+    base = os.path.join(GOLD, "tiny_s")
+    files = {"holes": ">a\n\n>b\nACGTACGTACGTAGCTAGCTAGCTAGCTAGCATCGAT\n>c\n>d\n\n\n>e\nTTTTGACGATCGATCGATGCTAGCTAGCTAG\n>f\n",
+             "tail1": ">a\nACGTACGTACGTAGCTAGCTAGCTAGC\n>z\nA", "nonl": ">a\nACGTACGTACGTACGTACGTACGTACGTAAAC", "multi": ">a\nACGTACGTACGTACGTACGT\nACGTACGTACGTAAAC\n>b desc\nTTGACGATCGATCGATCGATTTAGCAGCG\n",
+             "empty": ""}
+    for name, text in files.items():
+        p = tmp_path / (name + ".fa")
+        p.write_text(text)
+        a = ["-f", "-x", base, "-U", str(p)]
+        r = subprocess.run([ref_bin("bowtie2-align-s")] + a + ["-p", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        want = ([l for l in r.stdout.splitlines() if not l.startswith("@PG")], [l for l in r.stderr.splitlines() if "reads" in l or "aligned" in l or "overall" in l])
+        got = run(twin, a + ["--batch", "2"])
+        assert (got[0], [l for l in got[1] if "reads" in l or "aligned" in l or "overall" in l]) == want, name
+    p = tmp_path / "blank.fa"
+    p.write_text("\n\n")
+    r = subprocess.run([twin, "-f", "-x", base, "-U", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 1 and "does not look like a FASTA file" in r.stderr
