@@ -263,6 +263,21 @@ def write_fastq_fixed(path, seq, qual, names):
         f.write(rec.tobytes())
 
 
+# BASELINE.json configs[2..4] (+ the round-2 paired line).  `args` is the bowtie2-align command line of the configuration: the timed
+# batches take their parameters from it through bt2g_cli_params (the drop-in binary's own option parser), the reference and the product
+# binary of the parity check are run with it.
+CONFIGS = {
+    "se150":    {"args": ["--sensitive"], "paired": False, "readlen": 150, "reads": 2_000_000, "cpu_sample": 1_000_000,
+                 "what": "--sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"},
+    "pe-sens":  {"args": ["--sensitive"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 400_000,
+                 "what": "pairs, --sensitive, --fr -I 0 -X 500"},
+    "pe-vsens": {"args": ["--very-sensitive", "-X", "500"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 200_000,
+                 "what": "pairs, --very-sensitive (-D 20 -R 3 -N 0 -L 20 -i S,1,0.50), --fr -I 0 -X 500 (mate rescue)"},
+    "local400": {"args": ["--local"], "paired": False, "readlen": 400, "reads": 200_000, "cpu_sample": 100_000,
+                 "what": "--local = --sensitive-local (-D 15 -R 2 -N 0 -L 20 -i S,1,0.75, --ma 2, --score-min G,20,8)"},
+}
+
+
 # ---------------------------------------------------------------------------------- CPU baseline + parity ----
 def run_timed(cmd):
     t0 = time.perf_counter()
@@ -275,7 +290,7 @@ def sam_body(path):
         return [l for l in f if not l.startswith(b"@PG")]
 
 
-def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, threads, preset, work):
+def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, threads, preset, work, readlen=150, parity_only=False):
     # fq_all / fq_tiny: one FASTQ path (unpaired) or a pair of paths (mate 1, mate 2)
     def rd_args(fq):
         return ["-U", fq] if isinstance(fq, str) else ["-1", fq[0], "-2", fq[1]]
@@ -291,7 +306,8 @@ def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, thre
         simd = "SSE2"
     if not os.path.exists(exe):
         return None, None
-    common = [preset, "-p", str(threads), "--reorder", "-x", base]
+    common = list(preset) + ["-p", str(threads), "--reorder", "-x", base]
+    preset = " ".join(preset)
     ref_sam = os.path.join(work, "sample.ref.sam")
     t_load = []
     for _ in range(2):
@@ -301,18 +317,18 @@ def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, thre
         t_load.append(t)
     t_full = []
     al = None
-    for k in range(3):
+    for k in range(1 if parity_only else 3):
         t, p = run_timed([exe] + common + rd_args(fq_all) + ["-S", ref_sam if k == 0 else "/dev/null"])
         if p.returncode != 0:
             log("[bench] cpu baseline failed:", p.stderr[-500:]); return None, None
         t_full.append(t)
         al = re.search(r"([\d.]+)% overall alignment rate", p.stderr)
     t_full.sort(); tl = min(t_load)
-    search = t_full[1] - tl
+    search = t_full[len(t_full) // 2] - tl
     cb = {"value": (n_sample - n_tiny) / search, "unit": "reads/s", "cores": threads, "kind": "reference",
-          "sample": ("%d of the same synthetic 150 bp reads" + (" (as pairs, -1/-2)" if paired else "") + ", unmodified bowtie2-align-%s v2.5.5 (oracle/_ref, -O3, %s) %s -p %d --reorder; "
-                     "time = wall clock (median of 3: %s s) minus the wall clock of a %d-read run that is all index load (%.2f s); CPU: %s; "
-                     "overall alignment rate %s%%") % (n_sample, sfx, simd, preset, threads, "/".join("%.2f" % x for x in t_full), n_tiny, tl, cpu_model(),
+          "sample": ("%d of the same synthetic %d bp reads" + (" (as pairs, -1/-2)" if paired else "") + ", unmodified bowtie2-align-%s v2.5.5 (oracle/_ref, -O3, %s) %s -p %d --reorder; "
+                     "time = wall clock (median of %d: %s s) minus the wall clock of a %d-read run that is all index load (%.2f s); CPU: %s; "
+                     "overall alignment rate %s%%") % (n_sample, readlen, sfx, simd, preset, threads, len(t_full), "/".join("%.2f" % x for x in t_full), n_tiny, tl, cpu_model(),
                                                       al.group(1) if al else "?")}
     # parity: the product binary (GPU) on the same FASTQ
     ours = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-%s" % sfx)
@@ -427,15 +443,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BT2_BENCH_MBP", "1024")))
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="se150",
+                    help="se150 = the headline (BASELINE.json configs[2]); pe-vsens = configs[3]; local400 = configs[4]")
+    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BT2_BENCH_MBP", "3100")), help="3100 = hg38 scale")
     ap.add_argument("--small-index", action="store_true", help="build a .bt2 (32-bit) index instead of the headline .bt2l")
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("BT2_BENCH_READS", "2000000")), help="reads per GPU per step")
-    ap.add_argument("--readlen", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BT2_BENCH_CPU_SAMPLE", "1000000")))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--paired", action="store_true",
-                    help="measure the paired-end kernel instead: --reads/2 pairs of 2 x --readlen, fragments N(300,30), --fr (not the headline metric)")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BT2_BENCH_READS", "0")), help="reads per GPU per step (0: the config's default)")
+    ap.add_argument("--readlen", type=int, default=0, help="0: the config's read length")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BT2_BENCH_CPU_SAMPLE", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference run (no cpu_baseline, no SAM parity)")
+    ap.add_argument("--parity-only", action="store_true", help="run the reference once, for the SAM comparison only (cpu_baseline then comes from one run)")
+    ap.add_argument("--paired", action="store_true", help="same as --config pe-sens: the paired kernel at --sensitive (round-2 line)")
     args = ap.parse_args()
+    if args.paired:
+        args.config = "pe-sens"
+    cfg = CONFIGS[args.config]
+    args.paired = cfg["paired"]
+    if not args.reads:
+        args.reads = cfg["reads"]
+    if not args.readlen:
+        args.readlen = cfg["readlen"]
+    if not args.cpu_sample:
+        args.cpu_sample = cfg["cpu_sample"]
 
     import numpy as np
     import torch
@@ -484,25 +512,15 @@ def main():
     off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * args.readlen)
     batch = b.ReadBatch(seq.view(-1), qual.view(-1), off, n)
 
-    # --sensitive, 150 bp: -L 22, -i S,1,1.15 -> interval 1+1.15*sqrt(150) = 15 (bt2_search.cpp:3443-3450)
+    # batch and per-read parameters exactly as the drop-in binary derives them from this command line (bt2g_cli_params = its own parser):
+    # --sensitive at 150 bp gives -L 22, interval 1 + 1.15*sqrt(150) = 15, minsc = (long)(-0.6 + -0.6*len), nceil = 0.15*len;
+    # the per-read seed is genRandSeed(name, seq, qual) -- so the timed batch is the verified configuration
     import ctypes as C
-    L = 22
-    interval = max(1, int(1 + 1.15 * math.sqrt(args.readlen)))
-    P = b.AlignParams(mm_type=3, mm_max=6, mm_min=2, n_pen=1, rdgapo=8, rdgape=3, rfgapo=8, rfgape=3, gapbar=4, match_bonus=0,
-                      khits=1, mhits=50, max_dp_streak=15, max_ug=300, max_dp=300, max_iters=400, n_seed_rounds=2,
-                      seed_boost_thresh=300, tighten=3, maxhalf=15, nofw=0, norc=0, do_exact_upfront=1, do_1mm_upfront=1,
-                      do_ungapped=1, do_extend=1, large_index=1 if info.off_size == 8 else 0)
-    P.max_seeds = 1 + max(0, args.readlen - L) // interval      # every read has this many seed positions per strand: with the bound given, bt2g_align_batch does not synchronise
-    if args.paired:
-        # default pair policy: --fr, -I 0 -X 500, mixed + discordant reporting, containment and overlap allowed (bt2_search.cpp:303-502)
-        P.paired, P.pe_policy, P.pe_maxfrag, P.pe_minfrag, P.pe_flags, P.max_mate_streak = 1, 3, 500, 0, 2 | 4 | 8 | 32 | 64 | 128, 10
-        interval = max(1, int(interval * 1.2 + 0.5))       # both mates pass their filters (bt2_search.cpp:3427-3434)
-        P.max_seeds = 1 + max(0, args.readlen - L) // interval
-    # per-read parameters exactly as the drop-in binary derives them for these reads: minsc = (long)(-0.6 + -0.6*len),
-    # nceil = 0.15*len, seed = genRandSeed(name, seq, qual) -- so the timed batch is the verified configuration
-    minsc = int(-0.6 + -0.6 * args.readlen)
+    cli = list(cfg["args"]) + (["-1", "a", "-2", "b"] if args.paired else ["-U", "a"])
+    P, rp1 = b.cli_params(cli, args.readlen, large_index=info.off_size == 8, both_mates_pass=args.paired)
+    P.max_seeds = 1 + max(0, args.readlen - rp1.seedlen) // rp1.interval      # every read has this many seed positions per strand: with the bound given, bt2g_align_batch does not synchronise
     rp = np.zeros(n, dtype=[("minsc", "<i4"), ("interval", "<i4"), ("nceil", "<i4"), ("seedlen", "<i4"), ("seed", "<u4"), ("filt", "<u4")])
-    rp["minsc"] = minsc; rp["interval"] = interval; rp["nceil"] = int(0.15 * args.readlen); rp["seedlen"] = L; rp["filt"] = 15
+    rp["minsc"] = rp1.minsc; rp["interval"] = rp1.interval; rp["nceil"] = rp1.nceil; rp["seedlen"] = rp1.seedlen; rp["filt"] = rp1.filt
     rp["seed"] = gen_rand_seeds(seq, qual, names_t).cpu().numpy().astype(np.uint32)
     rp_t = torch.from_numpy(rp.view(np.uint8).copy()).to(dev)
 
@@ -573,11 +591,13 @@ def main():
         side = info.side_sz
         off_sz = info.off_size
         rankq = float(h["n_bwops_seed"].sum() + h["n_bwops_ext"].sum())
-        sides_per_launch = prof[8] / float(args.steps)
-        dp_cells = float(h["n_ex_dps"].sum()) * args.readlen * (args.readlen + 61)
+        sides_per_launch = float(prof[8])        # the profiled pass is ONE launch over the same batch (the profile was reset before it)
+        dp_cells = float(prof[24] + prof[25])   # DP cells actually computed in that launch: band cells of the score-only passes (up to their early exit) + of the fills that store a matrix
         # Algorithmic bytes.  k_align_reads, the dominant kernel: the rank queries it still issues itself
         # (offset resolution, re-seeding rounds) * side_sz + DP reference windows + reads in + result records out.
-        alg_bytes = sides_per_launch * side + h["n_ex_dps"].sum() * ((args.readlen + 61 + 3) // 4) + n * args.readlen * 2 + n * stride
+        dp_windows = float(h["n_ex_dps"].sum() + h["n_mate_dps"].sum())
+        win_cols = args.readlen + 4 * 15 + 1     # seed-extension windows; opposite-mate windows are wider (counted at the same size: a lower bound)
+        alg_bytes = sides_per_launch * side + dp_windows * ((win_cols + 3) // 4) + n * args.readlen * 2 + n * stride
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         # The four lane-per-task FM kernels in front of it carry most of the rank queries of the path.
         fm_ms = sum(v for k, v in kavg.items() if k != "k_align_reads")
@@ -601,13 +621,13 @@ def main():
                 fq_all, fq_tiny = os.path.join(work, "sample.fq"), os.path.join(work, "tiny.fq")
                 write_fastq_fixed(fq_all, seq[:ns], qual[:ns], names[:ns])
                 write_fastq_fixed(fq_tiny, seq[:ntiny], qual[:ntiny], names[:ntiny])
-            cb, par = cpu_baseline_and_parity(base, large, fq_all, fq_tiny, ns, ntiny, threads, "--sensitive", work)
+            cb, par = cpu_baseline_and_parity(base, large, fq_all, fq_tiny, ns, ntiny, threads, cfg["args"], work, args.readlen, args.parity_only)
             if par is not None and "parity_sample_aligned_reads" in par and not args.paired:
                 # the timed batch starts with the same reads, same parameters, same per-read seeds: its records must agree
                 par["timed_batch_aligned_reads_same_sample"] = int(h["aligned"][:ns].sum())
         res = {
-            "metric": ("aligned reads/sec (whole node), 2 x 150 bp PE (mates counted as reads), hg38-like synthetic genome" if args.paired else
-                       "aligned reads/sec (whole node), 150 bp SE vs hg38-like synthetic genome (hg38 unavailable offline), large index"),
+            "metric": ("aligned reads/sec (whole node), 2 x %d bp PE (mates counted as reads), hg38-like synthetic genome" % args.readlen if args.paired else
+                       "aligned reads/sec (whole node), %d bp SE vs hg38-like synthetic genome (hg38 unavailable offline), large index" % args.readlen),
             "value": shard.throughput(world, n, steps, dt),
             "unit": "reads/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -615,10 +635,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32" if off_sz == 4 else "u8/u64", "data": "synthetic",
             "config": {
-                "workload": "hg38-like synthetic %d Mbp genome (%d chromosomes; ~45 %% repeats: Alu-/L1-like and older diverged families, simple repeats, segmental duplications; N gaps), "
-                            ".%s index (side %d B, %d-byte offsets) built in this run by the GPU index builder, %d x %d bp SE reads per GPU per step, "
-                            "--sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"
-                            % (args.genome_mbp, N_CHROMS, ext, side, off_sz, n, args.readlen),
+                "workload": "BASELINE.json %s: hg38-like synthetic %d Mbp genome%s (%d chromosomes; ~45 %% repeats: Alu-/L1-like and older diverged families, simple repeats, segmental duplications; N gaps), "
+                            ".%s index (side %d B, %d-byte offsets) built in this run by the GPU index builder, %d x %d bp %s per GPU per step, %s"
+                            % ({"se150": "configs[2]", "pe-vsens": "configs[3]", "local400": "configs[4]"}.get(args.config, "(extra) " + args.config), args.genome_mbp,
+                               " = hg38 scale" if args.genome_mbp >= 3000 else "", N_CHROMS, ext, side, off_sz, n, args.readlen,
+                               "reads as %d pairs" % (n // 2) if args.paired else "SE reads", cfg["what"]),
+                "config_name": args.config, "command_line": " ".join(cfg["args"]),
                 "stages_timed": "one bt2g_align_batch per step = the whole per-read worker: k_exact_sweep, k_one_mm, k_seed_search_exact, k_extend_hits (lane-per-task FM kernels) then k_align_reads "
                                 "(rank+prioritise, offset resolution, re-seeding, SW fill + backtrace, -M reporting)",
                 "not_in_timed_region": "FASTQ parse and SAM text formatting (host side, SURVEY.md 8f)",
@@ -638,10 +660,13 @@ def main():
                 "fm_kernels_sides_per_read": cnt.rank_queries / float(n * args.steps),
                 "sides_per_read": prof[8] / max(1, prof[9]),
             },
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "sides_per_launch": sides_per_launch, "dp_windows_per_launch": dp_windows, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": kern_ms,
                          "dp_gcups": dp_cells / (kern_ms * 1e-3) / 1e9,
+                         "dp_cells_note": "cells computed per launch (band cells; score-only passes up to their early exit: %d, matrix-storing fills: %d), over the whole kernel time"
+                                          % (prof[24], prof[25]),
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                          "instruction_issue": pmc_issue(kname, kern_ms, n, torch.cuda.get_device_properties(dev).multi_processor_count),
                          "fm_kernels": {"kernels": ["k_exact_sweep", "k_one_mm", "k_seed_search_exact", "k_extend_hits"], "bound": "hbm",
                                         "ms_per_launch_sum": fm_ms, "algorithmic_bytes_per_launch": int(fm_bytes),

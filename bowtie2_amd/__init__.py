@@ -134,6 +134,7 @@ ABI = [
     ("bt2g_results_pack", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     ("bt2g_build_params_default", None, [C.POINTER(BuildParams)]),
     ("bt2g_index_build", C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.POINTER(BuildParams), C.POINTER(BuildStats)]),
+    ("bt2g_cli_params", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.c_int, C.POINTER(AlignParams), C.POINTER(ReadParams)]),
     ("bt2g_index_build_mem", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_char_p,
                                        C.POINTER(BuildParams), C.POINTER(BuildStats)]),
 ]
@@ -287,7 +288,7 @@ class Context:
         return dict(zip(["k_exact_sweep", "k_one_mm", "k_seed_search_exact", "k_extend_hits", "k_align_reads"], [float(x) for x in out]))
 
     def align_profile(self, reset=False):
-        out = (C.c_uint64 * 24)()
+        out = (C.c_uint64 * 32)()
         _check(self._h, lib().bt2g_align_profile_read(self._h, out, int(reset), _stream_ptr()), "bt2g_align_profile_read")
         return list(out)
 
@@ -295,6 +296,16 @@ class Context:
         c = Counters()
         _check(self._h, lib().bt2g_counters_read(self._h, C.byref(c), int(reset), _stream_ptr()), "bt2g_counters_read")
         return c
+
+
+def cli_params(args, read_len, large_index=True, both_mates_pass=False):
+    """(AlignParams, ReadParams) as the drop-in binary derives them from its command line (bt2g_cli_params): `args` is a list of
+    bowtie2-align options, e.g. ["--very-sensitive", "-X", "500", "-1", "a", "-2", "b"]; ReadParams.seed is left 0."""
+    av = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    P, rp = AlignParams(), ReadParams()
+    if lib().bt2g_cli_params(len(args), av, read_len, int(large_index), int(both_mates_pass), C.byref(P), C.byref(rp)) != 0:
+        raise Bt2gError("bt2g_cli_params rejected %r" % (args,))
+    return P, rp
 
 
 def _build_params(large, off_rate, ftab_chars, device):

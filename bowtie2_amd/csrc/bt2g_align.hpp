@@ -33,8 +33,15 @@
 
 namespace bt2g {
 
+#ifdef BT2G_PROBE_SMALL
+// occupancy probe builds only (tools/r03_session1.sh): capacities cut to what 150-bp unpaired reads need, to see what the
+// worker gains from an LDS footprint that admits more waves per CU.  Never shipped: longer reads would be flagged.
+constexpr int kMaxLen      = 256;
+constexpr int kMaxOffs     = BT2G_PROBE_SMALL;
+#else
 constexpr int kMaxLen      = 512;   // longest read (DP rows)
 constexpr int kMaxOffs     = 64;    // seed offsets per strand
+#endif
 constexpr int kMaxMm1      = 1024;  // 1-mismatch end-to-end hits kept (a simple-repeat read has hundreds)
 constexpr int kMaxRanges   = 2 * kMaxOffs;   // seed positions (both strands)
 constexpr int kMaxSat2     = 4096;  // seed-hit ranges of one round: one per position with -N 0, up to ~100 per position with -N 1
@@ -46,7 +53,11 @@ constexpr int kMaxAlns     = 160;   // alignments kept by the sink (-M 50 -> at 
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 65536; // uint32 slots for Random1toN lists (swap lists of small ranges, seen lists bounded by max_iters, converted lists)
 constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
+#ifdef BT2G_PROBE_SMALL
+constexpr int kMaxCols     = 340;
+#else
 constexpr int kMaxCols     = 1100;  // DP columns: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*15
+#endif
 
 enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
 enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMIT, EXT_HARD_LIMIT };
@@ -60,7 +71,9 @@ using ReadParams  = bt2g_read_params;
 using Edit        = bt2g_edit;
 using AlnRes      = bt2g_aln;
 using ReadResult  = bt2g_read_result;
+#ifndef BT2G_PROBE_SMALL
 static_assert(kMaxLen == BT2G_MAX_READ_LEN && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
+#endif
 
 // ---------------------------------------------------------------------------------------
 // RandomSource (random_source.h:34-159)
@@ -222,6 +235,7 @@ struct HotWork {
 	uint32_t n_ext_left, n_ext_right, n_resolve_steps;
 	uint32_t n_sides;           // sides (64/128-byte lines) actually read -- roofline accounting
 	uint32_t n_sranges;         // -N 1: entries of Work::sranges in use
+	uint32_t n_dp_cells_score, n_dp_cells_full, n_dp_pass;   // measurement: DP cells computed by score-only passes / by fills that store a matrix; windows that reached minsc
 	CacheModel cm;              // seed cache pool of the current seeding round
 	PeHot    pe;                // paired-end reporting state (unused for unpaired reads)
 	uint64_t t_phase[22];       // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other

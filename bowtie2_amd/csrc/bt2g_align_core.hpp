@@ -1923,6 +1923,7 @@ struct Aligner {
 		HOT.n_diags = 0; HOT.n_ex_fw = HOT.n_ex_rc = 0;
 		HOT.n_ex_iters = HOT.n_ex_dps = HOT.n_ex_ugs = HOT.n_dp_fail = HOT.n_ug_fail = HOT.n_ee_fail = HOT.n_dp_fail_streak = 0;
 		HOT.n_redundants = HOT.n_bwops_seed = HOT.n_bwops_ext = HOT.n_bt_attempts = 0; HOT.n_sides = 0; HOT.n_ext_left = HOT.n_ext_right = HOT.n_resolve_steps = 0;
+		HOT.n_dp_cells_score = HOT.n_dp_cells_full = HOT.n_dp_pass = 0;
 		for (int i_ = 0; i_ < 22; i_++) HOT.t_phase[i_] = 0;
 		const uint64_t t_run0_ = now();
 		HOT.n_mm1 = 0; HOT.mm1_elt = 0; HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_offs = 0; HOT.num_elts = 0;

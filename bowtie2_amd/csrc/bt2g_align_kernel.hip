@@ -71,7 +71,8 @@ __device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builti
 constexpr int kDppRowShr = 0x110, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
 
 template <int RP, bool PRED>
-__device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, int lo, int thr, uint8_t* __restrict__ pm) {
+__device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, int lo, int thr, uint8_t* __restrict__ pm, uint32_t& rows_done) {
+	rows_done = rows;
 	constexpr int N2 = 2 * RP;
 	constexpr uint32_t W = 128u * RP;
 	const int lane = threadIdx.x & 63;
@@ -195,7 +196,7 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 				u16x2 m = HP[0];
 #pragma unroll
 				for (int k = 1; k < RP; k++) m = p_max(m, HP[k]);
-				if (!__any((int)s_max(m.x, m.y) >= thr)) return 0;
+				if (!__any((int)s_max(m.x, m.y) >= thr)) { rows_done = i + 1; return 0; }
 			}
 			{
 				int jc = jin < 0 ? 0 : jin; if (jc > (int)cols) jc = (int)cols;      // outside the window: any character will do (see above)
@@ -763,6 +764,7 @@ struct DevPlat {
 			default: best = fill_local_wave<8>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
 		}
 		wave_fence();
+		g_hot.n_dp_cells_full += rows * cols;
 		return (int64_t)best;
 	}
 	// Candidate cells of a local fill (gatherCellsNucleotidesLocalSseU8), ordered score desc, row desc, col desc.
@@ -839,29 +841,32 @@ struct DevPlat {
 			if (rp == 0) return INT64_MIN;
 			const int lo = band.lo;
 			const int thr = (int)(minsc + 0xff);      // biased score an alignment must keep (>= 1: the 8-bit kernel is only used while minsc >= -254)
+			uint32_t rows_done = rows;
 			// pass 1: can any end-to-end alignment in this window reach the minimum score at all?
 			switch (rp) {
-				case 1: best = fill_ee_u8_band<1, false>(P, fw, rows, cols, lo, thr, pm); break;
-				case 2: best = fill_ee_u8_band<2, false>(P, fw, rows, cols, lo, thr, pm); break;
-				case 3: best = fill_ee_u8_band<3, false>(P, fw, rows, cols, lo, thr, pm); break;
-				case 4: best = fill_ee_u8_band<4, false>(P, fw, rows, cols, lo, thr, pm); break;
-				case 6: best = fill_ee_u8_band<6, false>(P, fw, rows, cols, lo, thr, pm); break;
-				case 8: best = fill_ee_u8_band<8, false>(P, fw, rows, cols, lo, thr, pm); break;
-				case 12: best = fill_ee_u8_band<12, false>(P, fw, rows, cols, lo, thr, pm); break;
-				default: best = fill_ee_u8_band<16, false>(P, fw, rows, cols, lo, thr, pm); break;
+				case 1: best = fill_ee_u8_band<1, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 2: best = fill_ee_u8_band<2, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 3: best = fill_ee_u8_band<3, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 4: best = fill_ee_u8_band<4, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 6: best = fill_ee_u8_band<6, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 8: best = fill_ee_u8_band<8, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 12: best = fill_ee_u8_band<12, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				default: best = fill_ee_u8_band<16, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
 			}
+			g_hot.n_dp_cells_score += rows_done * band.nd;
 			if ((int64_t)best - 0xff < minsc) { wave_fence(); return (int64_t)best - 0xff; }
+			g_hot.n_dp_cells_full += rows * band.nd; g_hot.n_dp_pass++;
 			// pass 2: the matrix of predecessor bits (same scores, so `best` is unchanged)
 			if ((threadIdx.x & 63) == 0) { dp.epoch[1] = (uint32_t)lo; dp.epoch[2] = 128u * rp; }
 			switch (rp) {
-				case 1: best = fill_ee_u8_band<1, true>(P, fw, rows, cols, lo, thr, pm); break;
-				case 2: best = fill_ee_u8_band<2, true>(P, fw, rows, cols, lo, thr, pm); break;
-				case 3: best = fill_ee_u8_band<3, true>(P, fw, rows, cols, lo, thr, pm); break;
-				case 4: best = fill_ee_u8_band<4, true>(P, fw, rows, cols, lo, thr, pm); break;
-				case 6: best = fill_ee_u8_band<6, true>(P, fw, rows, cols, lo, thr, pm); break;
-				case 8: best = fill_ee_u8_band<8, true>(P, fw, rows, cols, lo, thr, pm); break;
-				case 12: best = fill_ee_u8_band<12, true>(P, fw, rows, cols, lo, thr, pm); break;
-				default: best = fill_ee_u8_band<16, true>(P, fw, rows, cols, lo, thr, pm); break;
+				case 1: best = fill_ee_u8_band<1, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 2: best = fill_ee_u8_band<2, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 3: best = fill_ee_u8_band<3, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 4: best = fill_ee_u8_band<4, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 6: best = fill_ee_u8_band<6, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 8: best = fill_ee_u8_band<8, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 12: best = fill_ee_u8_band<12, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				default: best = fill_ee_u8_band<16, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
 			}
 			best -= 0xff;
 		} else {
@@ -877,6 +882,7 @@ struct DevPlat {
 				default: best = fill_ee_i16_wave<8>(P, w, fw, rows, cols, m64); break;
 			}
 			best -= 0x7fff;
+			g_hot.n_dp_cells_full += rows * cols;
 		}
 		wave_fence();     // matrix written lane-parallel -> visible to the scalar backtrace
 		return (int64_t)best;
@@ -944,6 +950,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)g_hot.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
 			atomicAdd(&prof[9], 1ull);
+			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass);
 		}
 	}
 }
@@ -997,6 +1004,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)g_hot.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
 			atomicAdd(&prof[9], 2ull);
+			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass);
 		}
 	}
 }

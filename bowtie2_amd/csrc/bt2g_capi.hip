@@ -319,9 +319,9 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		c->arena_layout = layout;
 	}
 	if (!c->d_next) {
-		e = hipMalloc((void**)&c->d_next, 256);
+		e = hipMalloc((void**)&c->d_next, 1024);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(queue head)");
-		(void)hipMemset(c->d_next, 0, 256);
+		(void)hipMemset(c->d_next, 0, 1024);
 	}
 	// The pure FM phases of every read (exact sweep, 1-mismatch search, seed round 0 and its seed-hit
 	// extension) run first as lane-per-task kernels; the per-read worker then consumes their output.
@@ -464,14 +464,14 @@ int bt2g_align_timing_read(bt2g_ctx* c, float* out_ms5) {
 	return 0;
 }
 
-int bt2g_align_profile_read(bt2g_ctx* c, uint64_t* out24, int reset, void* stream) {
-	if (!c || !out24) return BT2G_ERR_ARG;
+int bt2g_align_profile_read(bt2g_ctx* c, uint64_t* out32, int reset, void* stream) {
+	if (!c || !out32) return BT2G_ERR_ARG;
 	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
 	hipStream_t st = (hipStream_t)stream;
-	memset(out24, 0, 24 * 8);
+	memset(out32, 0, 32 * 8);
 	if (!c->d_next) return 0;
-	hipError_t e = hipMemcpyAsync(out24, c->d_next + 16, 24 * 8, hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_next + 16, 0, 24 * 8, st);
+	hipError_t e = hipMemcpyAsync(out32, c->d_next + 16, 32 * 8, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_next + 16, 0, 32 * 8, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	return e == hipSuccess ? 0 : hip_fail(c, e, "read profile");
 }

@@ -316,3 +316,29 @@ extern "C" int bowtie(int argc, const char** argv) {
 	catch (const CliExit& e) { return e.code; }
 	catch (const std::exception& e) { fprintf(stderr, "Error: %s\n", e.what()); return 1; }
 }
+
+// The option -> parameter mapping of the executable for a caller that feeds bt2g_align_batch itself (bench.py's timed batches, the
+// tests): argv as bowtie2-align-{s,l} takes it (index / read / output files may be left out), `read_len` the length of the reads the
+// batch will hold.  *P = the batch parameters Options::to_params derives, *rp = the per-read parameters of an N-free read of that length
+// (minimum score, seed interval -- times 1.2 when `both_mates_pass` --, N ceiling, seed length, all filters passed; the per-read RNG seed
+// is the caller's to fill in, gen_rand_seed needs the read).  Returns 0, or 1 with the parser's message on stderr.
+extern "C" int bt2g_cli_params(int argc, const char** argv, uint32_t read_len, int large_index, int both_mates_pass, bt2g_align_params* P, bt2g_read_params* rp) {
+	if (!P || !rp) return 1;
+	Options opt;
+	CliExtra ex;
+	ex.allow_paired = true;
+	std::vector<char*> av;
+	static char prog[] = "bowtie2-align";
+	av.push_back(prog);
+	for (int i = 0; i < argc; i++) av.push_back(const_cast<char*>(argv[i]));
+	const std::string err = parse_cli((int)av.size(), av.data(), opt, ex);
+	if (!err.empty()) { fprintf(stderr, "Error: %s\n", err.c_str()); return 1; }
+	opt.to_params(*P, large_index != 0);
+	const std::string bases(read_len, (char)0), quals(read_len, 'I');
+	ReadRec r;
+	r.seq.set(bases.data(), bases.size()); r.qual.set(quals.data(), quals.size());
+	*rp = compute_read_params(opt, r);
+	rp->seed = 0;
+	if (both_mates_pass) { int iv = (int)(rp->interval * 1.2 + 0.5); rp->interval = iv < 1 ? 1 : iv; }
+	return 0;
+}

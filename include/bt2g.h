@@ -311,7 +311,7 @@ int bt2g_align_timing_read(bt2g_ctx *ctx, float *out_ms5);
  * reset: [0] exact sweep [1] 1-mm search [2] seed search [3] rank+prioritise [4] offset resolution
  * [5] ref fetch + DP fill [6] gather + backtrace [7] whole read; [8] sides read; [9] reads.
  */
-int bt2g_align_profile_read(bt2g_ctx *ctx, uint64_t *out24, int reset, void *stream);
+int bt2g_align_profile_read(bt2g_ctx *ctx, uint64_t *out32, int reset, void *stream);
 
 /* ---- index construction ---------------------------------- */
 /*
@@ -354,6 +354,12 @@ int bowtie(int argc, const char **argv);
 /* Likewise for the index builder: the reference's `extern "C" int bowtie_build(int argc, const char **argv)` (bt2_build.cpp:556-560).
  * argv[0] ending in "build-l" (or --large-index) selects the .bt2l format. */
 int bowtie_build(int argc, const char **argv);
+/* The executable's option -> parameter mapping (bt2_search.cpp:504-1850 parseOption / parseOptions and the per-read derivations of
+ * multiseedSearchWorker, :3341-3450) for callers that drive bt2g_align_batch themselves: argv as bowtie2-align takes it (files may be
+ * left out), read_len = length of the reads of the batch.  *params as the drop-in binary would pass them, *rp = per-read parameters of
+ * an N-free read of that length (RNG seed left 0: it depends on the read).  both_mates_pass: the x1.2 seed interval of a pair. */
+int bt2g_cli_params(int argc, const char **argv, uint32_t read_len, int large_index, int both_mates_pass,
+                    bt2g_align_params *params, bt2g_read_params *rp);
 
 /* ---- instrumentation ---------------------------------------------------- */
 typedef struct {
