@@ -677,36 +677,12 @@ struct DevPlat {
 		wave_fence();
 		return total;
 	}
-	// Ebwt::getOffset for a wave-uniform row: the side is fetched with scalar loads (one s_load per 16/32/64 bytes of a
-	// constant-address-space pointer) and ranked on the scalar ALU instead of 64 identical vector loads and popcounts.
+	// Ebwt::getOffset for a wave-uniform row: one entry of the full suffix array (bt2g_device.hpp)
 	template <typename TOff>
 	static __device__ __forceinline__ TOff get_offset(const DevEbwt<TOff>& e, TOff row_, uint32_t& nsteps) {
-		typedef const __attribute__((address_space(4))) uint64_t* cptr64;
-		constexpr uint32_t NW = OffTraits<TOff>::kBwtWords;
-		const uint8_t* ebwt = uni_ptr(e.ebwt);
-		const TOff zoff = (TOff)uni((uint64_t)e.zoff);
-		const uint32_t off_rate = uni((uint32_t)e.off_rate);
-		const TOff samp_mask = (TOff)(((TOff)OffTraits<TOff>::kMask) << off_rate);
-		TOff row = (TOff)uni((uint64_t)row_);
-		TOff jumps = 0;
-		for (;;) {
-			if (row == zoff) { nsteps = (uint32_t)jumps; return jumps; }
-			if ((row & samp_mask) == row) { nsteps = (uint32_t)jumps; return (TOff)(jumps + e.offs[row >> off_rate]); }
-			const uint64_t side_num = (uint64_t)row / OffTraits<TOff>::kSideBwtLen;
-			const uint32_t char_off = (uint32_t)((uint64_t)row % OffTraits<TOff>::kSideBwtLen);
-			cptr64 p = (cptr64)(uintptr_t)(ebwt + side_num * OffTraits<TOff>::kSideSz);
-			Side<TOff> s;
-#pragma unroll
-			for (uint32_t i = 0; i < NW; i++) s.w[i] = p[i];
-			if (sizeof(TOff) == 4) {
-				const uint64_t a = p[NW], b = p[NW + 1];
-				s.occ[0] = (TOff)(a & 0xffffffffull); s.occ[1] = (TOff)(a >> 32); s.occ[2] = (TOff)(b & 0xffffffffull); s.occ[3] = (TOff)(b >> 32);
-			} else {
-				s.occ[0] = (TOff)p[NW]; s.occ[1] = (TOff)p[NW + 1]; s.occ[2] = (TOff)p[NW + 2]; s.occ[3] = (TOff)p[NW + 3];
-			}
-			row = (TOff)uni((uint64_t)rank_in_side(e, s, side_num, char_off, side_char(s, char_off)));
-			jumps++;
-		}
+		const uint64_t v = uni(gld(uni_ptr(e.sa) + uni((uint64_t)row_)));
+		nsteps = (uint32_t)(v >> 48);
+		return (TOff)(v & 0xffffffffffffull);
 	}
 	// A value per lane, kept in a vector register; lane(r, i) reads lane i's copy into a scalar register.
 	using LaneReg = uint32_t;

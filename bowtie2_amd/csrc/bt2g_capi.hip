@@ -8,6 +8,7 @@
 #include "bt2g_index.hpp"
 #include "bt2g_kernels.hpp"
 #include "bt2g_align_kernel.hpp"
+#include "bt2g_rankidx.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -67,17 +68,64 @@ int upload(bt2g_ctx* c, const void* src, uint64_t nbytes, const T** dst) {
 	return 0;
 }
 
+// a temporary device copy of a file section (freed once it has been transcoded)
+struct TmpDev {
+	void* p = nullptr;
+	~TmpDev() { if (p) (void)hipFree(p); }
+	int put(bt2g_ctx* c, const void* src, uint64_t nbytes) {
+		hipError_t e = hipMalloc(&p, nbytes ? nbytes : 256);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(index section)");
+		if (nbytes && (e = hipMemcpy(p, src, nbytes, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(c, e, "hipMemcpy(index section)");
+		return 0;
+	}
+};
+
+template <typename T>
+int alloc_index(bt2g_ctx* c, uint64_t nbytes, T** dst) {
+	void* p = nullptr;
+	const uint64_t alloc = nbytes ? ((nbytes + 255) & ~255ull) : 256;
+	hipError_t e = hipMalloc(&p, alloc);
+	if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(index)");
+	c->allocs.push_back(p);
+	c->hbm_bytes += alloc;
+	*dst = reinterpret_cast<T*>(p);
+	return 0;
+}
+
+// One direction of the index.  The BWT sides and (forward index) the SA sample go to the device as they are in the files and are
+// transcoded there into the layout the kernels query: rank blocks and the full suffix array (bt2g_device.hpp, bt2g_rankidx.hpp).
 template <typename TOff>
 int upload_ebwt(bt2g_ctx* c, const HostEbwt& h, bool fw, DevEbwt<TOff>& d) {
 	int rc;
-	if ((rc = upload(c, h.ebwt.data(), h.ebwt.size(), &d.ebwt))) return rc;
 	if ((rc = upload(c, h.ftab.data(), h.ftab.size(), &d.ftab))) return rc;
 	if ((rc = upload(c, h.eftab.data(), h.eftab.size(), &d.eftab))) return rc;
-	d.offs = nullptr;
-	if (fw && (rc = upload(c, h.offs.data(), h.offs.size(), &d.offs))) return rc;
+	d.sa = nullptr;
 	d.len = (TOff)h.len; d.zoff = (TOff)h.zoff;
+	d.zblk = (uint64_t)h.zoff >> kBlkShift; d.zchar = (uint32_t)((uint64_t)h.zoff & (kBlkLen - 1));
 	for (int i = 0; i < 5; i++) d.fchr[i] = (TOff)h.fchr[i];
 	d.ftab_chars = (uint32_t)h.ftab_chars; d.off_rate = (uint32_t)h.off_rate; d.is_fw = fw ? 1 : 0;
+	{
+		TmpDev sides;
+		if ((rc = sides.put(c, h.ebwt.data(), h.ebwt.size()))) return rc;
+		const uint64_t n_sides = h.ebwt.size() / OffTraits<TOff>::kSideSz;
+		const uint64_t n_blocks = rank_block_count(n_sides, OffTraits<TOff>::kSideBwtLen);
+		RankBlock* blk = nullptr;
+		if ((rc = alloc_index(c, n_blocks * sizeof(RankBlock), &blk))) return rc;
+		hipError_t e = launch_make_rank_blocks<TOff>((const uint8_t*)sides.p, n_sides, d.fchr, d.zoff, blk, n_blocks, nullptr);
+		if (e == hipSuccess) e = hipDeviceSynchronize();
+		if (e != hipSuccess) return hip_fail(c, e, "k_make_rank_blocks");
+		d.blk = blk;
+	}
+	if (fw) {
+		TmpDev offs;
+		if ((rc = offs.put(c, h.offs.data(), h.offs.size()))) return rc;
+		uint64_t* sa = nullptr;
+		if ((rc = alloc_index(c, ((uint64_t)h.len + 1) * sizeof(uint64_t), &sa))) return rc;
+		hipError_t e = launch_make_full_sa<TOff>(d, (const TOff*)offs.p, sa, nullptr);
+		if (e == hipSuccess) e = hipDeviceSynchronize();
+		if (e != hipSuccess) return hip_fail(c, e, "k_sa_segments");
+		d.sa = sa;
+	}
 	return 0;
 }
 

@@ -1,10 +1,17 @@
 // bt2g_device.hpp -- device-side view of the FM index and the rank/LF primitives.
 //
-// HBM layout: the .1.bt2[l] "sides" are kept exactly as on disk -- each side is one
-// 64-byte (.bt2) or 128-byte (.bt2l) line holding 48/96 bytes of 2-bit BWT followed by
-// occ[A,C,G,T] -- so one rank query is one aligned line read (SURVEY.md section 8d:
-// algorithmic bytes per rank query = side_sz).  ftab/eftab/offs/rstarts/plen are uploaded
-// verbatim at index width TOff (uint32_t for .bt2, uint64_t for .bt2l).
+// HBM layout (built once per bt2g_index_load from the verbatim .1.bt2[l] / .2.bt2[l] sections, bt2g_rankidx.hpp):
+//  * the BWT as RANK BLOCKS: one aligned 64-byte line per 128 characters = absolute occ[A,C,G,T] (64-bit, fchr folded in, the '$'
+//    row already discounted) + the characters as two bit planes of 4 x 32 bits.  One rank query is one line read; matching a
+//    character is two XORs and an AND per 32 positions, counting one v_bcnt per word; row -> block is a shift.  The on-disk side
+//    (48/96 bytes of 2-bit pairs + occ per 192/384 rows, bt2_idx.h:133-167) costs ~8x the vector instructions per query (12 x 64-bit
+//    words to mask per character, division by 384), which is what bound the FM kernels in round 2 (profiles/r02z_pmc_*).
+//  * the suffix array in FULL: sa[row] = joined-text offset of the row | (LF steps the reference's walk to its SA sample takes) << 48.
+//    The file keeps every 2^offRate-th row (Ebwt::getOffset walks LF to the next sampled row, bt2_idx.cpp:150-171: 16 dependent
+//    side reads on average); 288 GB of HBM hold the whole array (8 bytes x 3.1 G rows = 25 GB for hg38), so resolving a row is ONE
+//    8-byte read.  The step count is kept because the path's work counters and the roofline accounting (one side per
+//    LF step) are defined by the reference's walk.
+// ftab/eftab/rstarts/plen are uploaded verbatim at index width TOff (uint32_t for .bt2, uint64_t for .bt2l).
 //
 // Reference semantics restated here (never copied):
 //   rank  = Ebwt::countBt2Side / countBt2SideEx   bt2_idx.h:1758,1887
@@ -32,7 +39,8 @@
 #endif
 
 #if !defined(__HIPCC__)
-struct ulonglong2 { unsigned long long x, y; };   // host-side stand-in (test builds only)
+struct ulonglong2 { unsigned long long x, y; };   // host-side stand-ins (test builds only)
+struct uint4 { unsigned int x, y, z, w; };
 #endif
 
 // Scalar loads / stores for pointers that are KNOWN to point into the wave's arena in HBM.  Through a plain (generic)
@@ -49,26 +57,41 @@ template <typename T> BT2_HD void gst(T* p, T v) { *p = v; }
 
 namespace bt2g {
 
+// geometry of the on-disk sides: what one rank query costs in the path's accounting
 template <typename TOff> struct OffTraits;
 template <> struct OffTraits<uint32_t> {
 	static constexpr uint32_t kSideSz = 64, kSideBwtLen = 192, kBwtWords = 6; // 48 B of BWT = 6 x u64
 	static constexpr uint32_t kMask = 0xffffffffu;
+	static constexpr uint32_t kSideShift = 6;    // kSideBwtLen = 3 << kSideShift
 };
 template <> struct OffTraits<uint64_t> {
 	static constexpr uint32_t kSideSz = 128, kSideBwtLen = 384, kBwtWords = 12; // 96 B of BWT = 12 x u64
 	static constexpr uint64_t kMask = ~0ull;
+	static constexpr uint32_t kSideShift = 7;
 };
+
+// One rank block: 128 BWT characters.  Character i of the block has bit (i & 31) of p0[i >> 5] = low bit of its code and of
+// p1[i >> 5] = high bit.  occ[c] = fchr[c] + (# of c in the BWT before this block), the '$' row (stored as A in the file,
+// bt2_idx.h:1766-1774) not counted.
+struct alignas(64) RankBlock { uint64_t occ[4]; uint32_t p0[4], p1[4]; };
+constexpr uint32_t kBlkShift = 7, kBlkLen = 128;
+
+// full suffix array entry: joined offset in the low 48 bits, LF steps of the reference's walk in the high 16
+constexpr uint64_t kJoffNone = ~0ull;
+BT2_HD uint64_t joff_pack(uint64_t joff, uint32_t steps) { return (joff >> 48) == 0 && steps < 0xffffu ? (joff | ((uint64_t)steps << 48)) : kJoffNone; }
 
 template <typename TOff>
 struct DevEbwt {
-	const uint8_t* ebwt;   // sides
+	const RankBlock* blk;  // rank blocks
 	const TOff*    ftab;
 	const TOff*    eftab;
-	const TOff*    offs;   // SA sample (forward index only)
+	const uint64_t* sa;    // full suffix array (forward index only), joff_pack format
 	TOff len, zoff;
-	TOff fchr[5];
+	uint64_t zblk;         // block and position within it of the '$' row
+	uint32_t zchar;
 	uint32_t ftab_chars, off_rate;
 	uint32_t is_fw;
+	TOff fchr[5];
 };
 
 struct DevRef {
@@ -95,172 +118,144 @@ struct DevCounters {
 };
 
 // ---------------------------------------------------------------------------------------
-// 2-bit counting.  A u64 word holds 32 BWT characters, char i at bits [2i,2i+1].
-// eq_mask(w,c): bit 2i set iff char i == c.
-BT2_HD uint64_t eq_mask(uint64_t w, int c) {
-	// XOR with the complement pattern of c so that matching pairs become 0b11
-	const uint64_t pat = (c == 0) ? ~0ull : (c == 1) ? 0xaaaaaaaaaaaaaaaaull : (c == 2) ? 0x5555555555555555ull : 0ull;
-	const uint64_t x = w ^ pat;
-	return x & (x >> 1) & 0x5555555555555555ull;
-}
-
-BT2_HD int popc64(uint64_t x) {
+BT2_HD int popc32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return __popcll(x);
+	return __popc(x);
 #else
-	return __builtin_popcountll(x);
+	return __builtin_popcount(x);
 #endif
 }
 
-// Low-bit mask selecting the first n (0..32) characters of a word, on the 0x55.. lattice.
-BT2_HD uint64_t first_chars_mask(uint32_t n) {
-	return n >= 32 ? 0x5555555555555555ull : (((1ull << (2 * n)) - 1ull) & 0x5555555555555555ull);
+// One block, loaded into registers: four 16-byte loads of one aligned 64-byte line.
+struct Blk { uint64_t occ[4]; uint32_t p0[4], p1[4]; };
+
+BT2_HD void load_blk(const RankBlock* blks, uint64_t b, Blk& o) {
+	const uint4* p = reinterpret_cast<const uint4*>(blks + b);
+	const uint4 a = p[0], c = p[1], d = p[2], e = p[3];
+	o.occ[0] = (uint64_t)a.x | ((uint64_t)a.y << 32); o.occ[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+	o.occ[2] = (uint64_t)c.x | ((uint64_t)c.y << 32); o.occ[3] = (uint64_t)c.z | ((uint64_t)c.w << 32);
+	o.p0[0] = d.x; o.p0[1] = d.y; o.p0[2] = d.z; o.p0[3] = d.w;
+	o.p1[0] = e.x; o.p1[1] = e.y; o.p1[2] = e.z; o.p1[3] = e.w;
 }
 
-// One side, loaded into registers.  kBwtWords u64 of BWT + 4 occ counters.
-template <typename TOff>
-struct Side {
-	uint64_t w[OffTraits<TOff>::kBwtWords];
-	TOff occ[4];
-};
-
-template <typename TOff>
-BT2_HD void load_side(const uint8_t* ebwt, uint64_t side_num, Side<TOff>& s) {
-	constexpr uint32_t NW = OffTraits<TOff>::kBwtWords;
-	// 16-byte vector loads: 4 per .bt2 side, 8 per .bt2l side -- one full aligned line
-	const ulonglong2* p = reinterpret_cast<const ulonglong2*>(ebwt + side_num * OffTraits<TOff>::kSideSz);
-#pragma unroll
-	for (uint32_t i = 0; i < NW / 2; i++) {
-		ulonglong2 v = p[i];
-		s.w[2 * i] = v.x;
-		s.w[2 * i + 1] = v.y;
-	}
-	if (sizeof(TOff) == 4) {
-		ulonglong2 v = p[NW / 2];
-		s.occ[0] = (TOff)(v.x & 0xffffffffull); s.occ[1] = (TOff)(v.x >> 32);
-		s.occ[2] = (TOff)(v.y & 0xffffffffull); s.occ[3] = (TOff)(v.y >> 32);
-	} else {
-		ulonglong2 v0 = p[NW / 2], v1 = p[NW / 2 + 1];
-		s.occ[0] = (TOff)v0.x; s.occ[1] = (TOff)v0.y; s.occ[2] = (TOff)v1.x; s.occ[3] = (TOff)v1.y;
-	}
+// bits 0..n-1 of word w of a block prefix of `off` characters (off in 0..128)
+BT2_HD uint32_t prefix_mask(uint32_t off, uint32_t w) {
+	const int n = (int)off - (int)(32 * w);
+	const uint32_t nn = n < 0 ? 0u : (n > 32 ? 32u : (uint32_t)n);
+	return ~(uint32_t)(~0ull << nn);
 }
 
-// # of chars == c among the first char_off chars of the side
-template <typename TOff>
-BT2_HD uint32_t side_count(const Side<TOff>& s, uint32_t char_off, int c) {
-	constexpr uint32_t NW = OffTraits<TOff>::kBwtWords;
+// # of chars == c among the first `off` chars of the block
+BT2_HD uint32_t blk_count(const Blk& s, uint32_t off, int c) {
+	const uint32_t k0 = (c & 1) ? 0u : ~0u, k1 = (c & 2) ? 0u : ~0u;
 	uint32_t cnt = 0;
 #pragma unroll
-	for (uint32_t i = 0; i < NW; i++) {
-		const uint32_t lo = i * 32;
-		const uint32_t n = char_off > lo ? char_off - lo : 0;  // chars of this word that count
-		cnt += popc64(eq_mask(s.w[i], c) & first_chars_mask(n));
-	}
+	for (uint32_t w = 0; w < 4; w++) cnt += (uint32_t)popc32((s.p0[w] ^ k0) & (s.p1[w] ^ k1) & prefix_mask(off, w));
 	return cnt;
 }
 
-template <typename TOff>
-BT2_HD int side_char(const Side<TOff>& s, uint32_t char_off) {
-	constexpr uint32_t NW = OffTraits<TOff>::kBwtWords;
-	uint64_t w = 0;
-#pragma unroll
-	for (uint32_t i = 0; i < NW; i++) if ((char_off >> 5) == i) w = s.w[i];
-	return (int)((w >> ((char_off & 31) * 2)) & 3);
+BT2_HD int blk_char(const Blk& s, uint32_t off) {
+	uint32_t a = s.p0[0], b = s.p1[0];
+	const uint32_t w = off >> 5;
+	if (w == 1) { a = s.p0[1]; b = s.p1[1]; }
+	if (w == 2) { a = s.p0[2]; b = s.p1[2]; }
+	if (w == 3) { a = s.p0[3]; b = s.p1[3]; }
+	const uint32_t sh = off & 31;
+	return (int)(((a >> sh) & 1u) | (((b >> sh) & 1u) << 1));
 }
 
 // rank_c(row) = fchr[c] + occ_side[c] + count - ['$' fix]   (countBt2Side, bt2_idx.h:1758)
 template <typename TOff>
-BT2_HD TOff rank_in_side(const DevEbwt<TOff>& e, const Side<TOff>& s, uint64_t side_num, uint32_t char_off, int c) {
-	uint32_t cnt = side_count(s, char_off, c);
-	if (c == 0) {
-		const uint64_t zside = (uint64_t)e.zoff / OffTraits<TOff>::kSideBwtLen;
-		const uint32_t zchar = (uint32_t)((uint64_t)e.zoff % OffTraits<TOff>::kSideBwtLen);
-		if (side_num == zside && char_off > zchar) cnt--;   // '$' is stored as 'A' (bt2_idx.h:1766-1774)
-	}
-	return (TOff)(e.fchr[c] + s.occ[c] + cnt);
-}
-
-template <typename TOff>
-BT2_HD TOff rank1(const DevEbwt<TOff>& e, TOff row, int c) {
-	const uint64_t side_num = (uint64_t)row / OffTraits<TOff>::kSideBwtLen;
-	const uint32_t char_off = (uint32_t)((uint64_t)row % OffTraits<TOff>::kSideBwtLen);
-	Side<TOff> s;
-	load_side<TOff>(e.ebwt, side_num, s);
-	return rank_in_side(e, s, side_num, char_off, c);
+BT2_HD TOff rank_in_blk(const DevEbwt<TOff>& e, const Blk& s, uint64_t b, uint32_t off, int c) {
+	uint32_t cnt = blk_count(s, off, c);
+	if (c == 0 && b == e.zblk && off > e.zchar) cnt--;   // '$' is stored as 'A' (bt2_idx.h:1766-1774)
+	return (TOff)(s.occ[c] + cnt);
 }
 
 // all four characters at once (countBt2SideEx, bt2_idx.h:1887)
 template <typename TOff>
-BT2_HD void rank4_in_side(const DevEbwt<TOff>& e, const Side<TOff>& s, uint64_t side_num, uint32_t char_off, TOff out[4]) {
-	uint32_t c1 = side_count(s, char_off, 1), c2 = side_count(s, char_off, 2), c3 = side_count(s, char_off, 3);
-	uint32_t c0 = char_off - c1 - c2 - c3;
-	const uint64_t zside = (uint64_t)e.zoff / OffTraits<TOff>::kSideBwtLen;
-	const uint32_t zchar = (uint32_t)((uint64_t)e.zoff % OffTraits<TOff>::kSideBwtLen);
-	if (side_num == zside && char_off > zchar) c0--;
-	out[0] = (TOff)(e.fchr[0] + s.occ[0] + c0);
-	out[1] = (TOff)(e.fchr[1] + s.occ[1] + c1);
-	out[2] = (TOff)(e.fchr[2] + s.occ[2] + c2);
-	out[3] = (TOff)(e.fchr[3] + s.occ[3] + c3);
+BT2_HD void rank4_in_blk(const DevEbwt<TOff>& e, const Blk& s, uint64_t b, uint32_t off, TOff out[4]) {
+	uint32_t c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < 4; w++) {
+		const uint32_t m = prefix_mask(off, w), a = s.p0[w], h = s.p1[w];
+		c1 += (uint32_t)popc32(a & ~h & m);
+		c2 += (uint32_t)popc32(~a & h & m);
+		c3 += (uint32_t)popc32(a & h & m);
+	}
+	uint32_t c0 = off - c1 - c2 - c3;
+	if (b == e.zblk && off > e.zchar) c0--;
+	out[0] = (TOff)(s.occ[0] + c0);
+	out[1] = (TOff)(s.occ[1] + c1);
+	out[2] = (TOff)(s.occ[2] + c2);
+	out[3] = (TOff)(s.occ[3] + c3);
+}
+
+// the side of the on-disk layout a row falls into: what the accounting of "sides read" is defined on (one rank query = one side,
+// two loci in one side = one read: SideLocus::initFromTopBot, bt2_idx.h:325-348)
+template <typename TOff>
+BT2_HD uint32_t side_of(TOff row) { return (uint32_t)(((uint64_t)row >> OffTraits<TOff>::kSideShift) / 3u); }
+
+template <typename TOff>
+BT2_HD TOff rank1(const DevEbwt<TOff>& e, TOff row, int c) {
+	const uint64_t b = (uint64_t)row >> kBlkShift;
+	Blk s;
+	load_blk(e.blk, b, s);
+	return rank_in_blk(e, s, b, (uint32_t)row & (kBlkLen - 1), c);
 }
 
 template <typename TOff>
 BT2_HD void rank4(const DevEbwt<TOff>& e, TOff row, TOff out[4]) {
-	const uint64_t side_num = (uint64_t)row / OffTraits<TOff>::kSideBwtLen;
-	const uint32_t char_off = (uint32_t)((uint64_t)row % OffTraits<TOff>::kSideBwtLen);
-	Side<TOff> s;
-	load_side<TOff>(e.ebwt, side_num, s);
-	rank4_in_side(e, s, side_num, char_off, out);
+	const uint64_t b = (uint64_t)row >> kBlkShift;
+	Blk s;
+	load_blk(e.blk, b, s);
+	rank4_in_blk(e, s, b, (uint32_t)row & (kBlkLen - 1), out);
 }
 
-// Pair query rank_c(top), rank_c(bot): one side read when both loci share a side
-// (SideLocus::initFromTopBot, bt2_idx.h:325-348), else two.  Returns # sides read.
+// Pair query rank_c(top), rank_c(bot).  Returns the # of sides the reference reads for it (1 when both loci share a side).
 template <typename TOff>
 BT2_HD int rank1_pair(const DevEbwt<TOff>& e, TOff top, TOff bot, int c, TOff& otop, TOff& obot) {
-	const uint64_t st = (uint64_t)top / OffTraits<TOff>::kSideBwtLen, sb = (uint64_t)bot / OffTraits<TOff>::kSideBwtLen;
-	const uint32_t ct = (uint32_t)((uint64_t)top % OffTraits<TOff>::kSideBwtLen), cb = (uint32_t)((uint64_t)bot % OffTraits<TOff>::kSideBwtLen);
-	Side<TOff> s;
-	load_side<TOff>(e.ebwt, st, s);
-	otop = rank_in_side(e, s, st, ct, c);
-	if (sb == st) { obot = rank_in_side(e, s, sb, cb, c); return 1; }
-	load_side<TOff>(e.ebwt, sb, s);
-	obot = rank_in_side(e, s, sb, cb, c);
-	return 2;
+	const uint64_t bt = (uint64_t)top >> kBlkShift, bb = (uint64_t)bot >> kBlkShift;
+	Blk s;
+	load_blk(e.blk, bt, s);
+	otop = rank_in_blk(e, s, bt, (uint32_t)top & (kBlkLen - 1), c);
+	if (bb != bt) load_blk(e.blk, bb, s);
+	obot = rank_in_blk(e, s, bb, (uint32_t)bot & (kBlkLen - 1), c);
+	return side_of(top) == side_of(bot) ? 1 : 2;
 }
 
 template <typename TOff>
 BT2_HD int rank4_pair(const DevEbwt<TOff>& e, TOff top, TOff bot, TOff t[4], TOff b[4]) {
-	const uint64_t st = (uint64_t)top / OffTraits<TOff>::kSideBwtLen, sb = (uint64_t)bot / OffTraits<TOff>::kSideBwtLen;
-	const uint32_t ct = (uint32_t)((uint64_t)top % OffTraits<TOff>::kSideBwtLen), cb = (uint32_t)((uint64_t)bot % OffTraits<TOff>::kSideBwtLen);
-	Side<TOff> s;
-	load_side<TOff>(e.ebwt, st, s);
-	rank4_in_side(e, s, st, ct, t);
-	if (sb == st) { rank4_in_side(e, s, sb, cb, b); return 1; }
-	load_side<TOff>(e.ebwt, sb, s);
-	rank4_in_side(e, s, sb, cb, b);
-	return 2;
+	const uint64_t bt = (uint64_t)top >> kBlkShift, bb = (uint64_t)bot >> kBlkShift;
+	Blk s;
+	load_blk(e.blk, bt, s);
+	rank4_in_blk(e, s, bt, (uint32_t)top & (kBlkLen - 1), t);
+	if (bb != bt) load_blk(e.blk, bb, s);
+	rank4_in_blk(e, s, bb, (uint32_t)bot & (kBlkLen - 1), b);
+	return side_of(top) == side_of(bot) ? 1 : 2;
 }
 
 // mapLF1(row, l, c) (bt2_idx.h:2420): all-ones if BWT[row] != c or row is the '$' row
 template <typename TOff>
 BT2_HD TOff map_lf1c(const DevEbwt<TOff>& e, TOff row, int c) {
-	const uint64_t side_num = (uint64_t)row / OffTraits<TOff>::kSideBwtLen;
-	const uint32_t char_off = (uint32_t)((uint64_t)row % OffTraits<TOff>::kSideBwtLen);
-	Side<TOff> s;
-	load_side<TOff>(e.ebwt, side_num, s);
-	if (side_char(s, char_off) != c || row == e.zoff) return (TOff)OffTraits<TOff>::kMask;
-	return rank_in_side(e, s, side_num, char_off, c);
+	const uint64_t b = (uint64_t)row >> kBlkShift;
+	const uint32_t off = (uint32_t)row & (kBlkLen - 1);
+	Blk s;
+	load_blk(e.blk, b, s);
+	if (blk_char(s, off) != c || row == e.zoff) return (TOff)OffTraits<TOff>::kMask;
+	return rank_in_blk(e, s, b, off, c);
 }
 
 // mapLF1(row&, l) (bt2_idx.h:2451): returns BWT char (or -1 at '$') and advances row
 template <typename TOff>
 BT2_HD int map_lf1(const DevEbwt<TOff>& e, TOff& row) {
 	if (row == e.zoff) return -1;
-	const uint64_t side_num = (uint64_t)row / OffTraits<TOff>::kSideBwtLen;
-	const uint32_t char_off = (uint32_t)((uint64_t)row % OffTraits<TOff>::kSideBwtLen);
-	Side<TOff> s;
-	load_side<TOff>(e.ebwt, side_num, s);
-	const int c = side_char(s, char_off);
-	row = rank_in_side(e, s, side_num, char_off, c);
+	const uint64_t b = (uint64_t)row >> kBlkShift;
+	const uint32_t off = (uint32_t)row & (kBlkLen - 1);
+	Blk s;
+	load_blk(e.blk, b, s);
+	const int c = blk_char(s, off);
+	row = rank_in_blk(e, s, b, off, c);
 	return c;
 }
 
@@ -280,22 +275,13 @@ BT2_HD TOff ftab_lo(const DevEbwt<TOff>& e, uint64_t i) {
 	return e.eftab[(uint64_t)ef * 2];
 }
 
-// Ebwt::getOffset (bt2_idx.cpp:150): LF-walk to a sampled row; nsteps = # LF steps taken
+// Ebwt::getOffset (bt2_idx.cpp:150): the joined-text offset of a row and the number of LF steps the reference's walk to its
+// SA sample takes -- one read of the full suffix array (bt2g_rankidx.hpp derives it from the sample with that very walk).
 template <typename TOff>
 BT2_HD TOff get_offset(const DevEbwt<TOff>& e, TOff row, uint32_t& nsteps) {
-	const TOff samp_mask = (TOff)(((TOff)OffTraits<TOff>::kMask) << e.off_rate);
-	TOff jumps = 0;
-	for (;;) {
-		if (row == e.zoff) { nsteps = (uint32_t)jumps; return jumps; }
-		if ((row & samp_mask) == row) { nsteps = (uint32_t)jumps; return (TOff)(jumps + e.offs[row >> e.off_rate]); }
-		// mapLF(l): rank of the row's own BWT char
-		const uint64_t side_num = (uint64_t)row / OffTraits<TOff>::kSideBwtLen;
-		const uint32_t char_off = (uint32_t)((uint64_t)row % OffTraits<TOff>::kSideBwtLen);
-		Side<TOff> s;
-		load_side<TOff>(e.ebwt, side_num, s);
-		row = rank_in_side(e, s, side_num, char_off, side_char(s, char_off));
-		jumps++;
-	}
+	const uint64_t v = e.sa[(uint64_t)row];
+	nsteps = (uint32_t)(v >> 48);
+	return (TOff)(v & 0xffffffffffffull);
 }
 
 // Ebwt::joinedToTextOff (bt2_idx.cpp:54) for the forward index.  tidx = all-ones if rejected.

@@ -118,9 +118,7 @@ BT2_HD void fm_extend_hit_text(const DevIndex<TOff>& ix, const RD& rd, uint32_t 
 	}
 }
 
-// cached offset resolution of a one-row seed hit: joined offset in the low 48 bits, LF steps it took in the high 16
-constexpr uint64_t kJoffNone = ~0ull;
-BT2_HD uint64_t joff_pack(uint64_t joff, uint32_t steps) { return (joff >> 48) == 0 && steps < 0xffffu ? (joff | ((uint64_t)steps << 48)) : kJoffNone; }
+// (cached offset resolution of a one-row seed hit: joff_pack / kJoffNone, bt2g_device.hpp)
 
 // 1-mismatch end-to-end hit as oneMmSearch reports it (EEHit with one Edit)
 struct Mm1Hit {

@@ -14,6 +14,7 @@
 
 #include "../../bowtie2_amd/csrc/bt2g_index.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_align_core.hpp"
+#include "../../bowtie2_amd/csrc/bt2g_rankidx.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_host.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_pipeline.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_cli.hpp"
@@ -359,14 +360,27 @@ struct HostPlat {
 
 template <typename TOff>
 static void make_dev_index(const HostIndex& h, DevIndex<TOff>& d) {
+	// the layout bt2g_index_load builds on the device (rank blocks, full suffix array), built here by the same per-block /
+	// per-segment functions in plain loops (bt2g_rankidx.hpp); the buffers live as long as the process
 	auto fill = [&](const HostEbwt& e, DevEbwt<TOff>& o, bool fw) {
-		o.ebwt = e.ebwt.data();
 		o.ftab = (const TOff*)e.ftab.data();
 		o.eftab = (const TOff*)e.eftab.data();
-		o.offs = fw ? (const TOff*)e.offs.data() : nullptr;
+		o.sa = nullptr;
 		o.len = (TOff)e.len; o.zoff = (TOff)e.zoff;
+		o.zblk = (uint64_t)e.zoff >> kBlkShift; o.zchar = (uint32_t)((uint64_t)e.zoff & (kBlkLen - 1));
 		for (int i = 0; i < 5; i++) o.fchr[i] = (TOff)e.fchr[i];
 		o.ftab_chars = e.ftab_chars; o.off_rate = e.off_rate; o.is_fw = fw;
+		const uint64_t n_sides = e.ebwt.size() / OffTraits<TOff>::kSideSz;
+		const uint64_t n_blocks = rank_block_count(n_sides, OffTraits<TOff>::kSideBwtLen);
+		RankBlock* blk = (RankBlock*)aligned_alloc(64, n_blocks * sizeof(RankBlock));
+		host_make_rank_blocks<TOff>(e.ebwt.data(), n_sides, o.fchr, o.zoff, blk, n_blocks);
+		o.blk = blk;
+		if (fw) {
+			uint64_t* sa = (uint64_t*)malloc(((uint64_t)e.len + 1) * sizeof(uint64_t));
+			for (uint64_t r = 0; r <= (uint64_t)e.len; r++) sa[r] = kJoffNone;
+			host_make_full_sa<TOff>(o, (const TOff*)e.offs.data(), sa);
+			o.sa = sa;
+		}
 	};
 	fill(h.fw, d.fw, true);
 	fill(h.bw, d.bw, false);
@@ -536,6 +550,29 @@ int main(int argc, char** argv) {
 	HostIndex hidx;
 	std::string err;
 	if (load_index(opt.index_base, hidx, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+	if (getenv("BT2G_INDEX_DUMP")) {
+		// tests/test_rank_index.py: every row's view through the HBM layout (rank blocks, full suffix array), to be compared with the oracle
+		auto dump = [&](auto tag) {
+			using TOff = decltype(tag);
+			DevIndex<TOff> ix;
+			make_dev_index(hidx, ix);
+			for (uint64_t r = 0; r <= (uint64_t)ix.fw.len; r++) {
+				uint32_t steps = 0;
+				const TOff jo = get_offset(ix.fw, (TOff)r, steps);
+				TOff f4[4], b4[4];
+				rank4(ix.fw, (TOff)r, f4); rank4(ix.bw, (TOff)r, b4);
+				TOff rr = (TOff)r;
+				const int ch = map_lf1(ix.fw, rr);
+				TOff t1 = 0, b1 = 0;
+				const int ns = rank1_pair(ix.fw, (TOff)r, (TOff)(r + 37 <= (uint64_t)ix.fw.len ? r + 37 : ix.fw.len), (int)(r & 3), t1, b1);
+				printf("%llu %llu %u %llu %llu %llu %llu %d %llu %llu %llu %llu %llu %llu %llu %d\n", (unsigned long long)r, (unsigned long long)jo, steps,
+				       (unsigned long long)f4[0], (unsigned long long)f4[1], (unsigned long long)f4[2], (unsigned long long)f4[3], ch, (unsigned long long)(ch < 0 ? 0 : rr),
+				       (unsigned long long)b4[0], (unsigned long long)b4[1], (unsigned long long)b4[2], (unsigned long long)b4[3], (unsigned long long)t1, (unsigned long long)b1, ns);
+			}
+		};
+		if (hidx.off_size == 4) dump((uint32_t)0); else dump((uint64_t)0);
+		return 0;
+	}
 	FILE* out = opt.out_file.empty() ? stdout : fopen(opt.out_file.c_str(), "wb");
 	int rc;
 	if (opt.mixed_unpaired) {

@@ -1,0 +1,43 @@
+"""The HBM layout of the FM index (bowtie2_amd/csrc/bt2g_device.hpp: 64-byte rank blocks, the full suffix array) against the oracle's
+plain restatement of the on-disk layout (oracle/bt2_oracle.c: countBt2Side over the sides, getOffset by LF walk to the SA sample),
+EVERY row of the tiny golden indexes, both widths and both index directions.  The layout is built by bt2g_rankidx.hpp -- on the device
+by the kernels of bt2g_rankidx.hip, here by the same per-block / per-segment functions in host loops (tests/hostsim, test-only)."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from bt2test import ROOT, Index, build_hostsim, oracle, u64
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_every_row_matches_the_oracle(golden_dir, tmp_path, large):
+    exe = build_hostsim(os.path.join(ROOT, "tests", "hostsim", "hostsim"))
+    base = os.path.join(golden_dir, "tiny_l" if large else "tiny_s")
+    env = dict(os.environ, BT2G_INDEX_DUMP="1")
+    out = subprocess.run([exe, "-x", base, "-U", "/dev/null"], stdout=subprocess.PIPE, env=env, check=True, text=True).stdout.splitlines()
+    L = oracle()
+    idx = Index()
+    assert L.bt2o_index_load(C.byref(idx), base.encode()) == 0
+    n = idx.fwd.len
+    assert len(out) == n + 1
+    a = (u64 * 4)()
+    ns = u64()
+    side_len = 384 if large else 192
+    for line in out:
+        v = [int(x) for x in line.split()]
+        row = v[0]
+        assert L.bt2o_get_offset(C.byref(idx.fwd), row, C.byref(ns)) == v[1], row
+        assert ns.value == v[2], ("steps of the reference's walk", row)
+        L.bt2o_rank4(C.byref(idx.fwd), row, a)
+        assert list(a) == v[3:7], ("rank4 fw", row)
+        r = u64(row)
+        ch = L.bt2o_map_lf1(C.byref(idx.fwd), C.byref(r))
+        assert ch == v[7] and (ch < 0 or r.value == v[8]), ("mapLF1", row)
+        L.bt2o_rank4(C.byref(idx.bwd), row, a)
+        assert list(a) == v[9:13], ("rank4 bw", row)
+        bot = min(row + 37, n)
+        c = row & 3
+        assert [L.bt2o_rank(C.byref(idx.fwd), row, c), L.bt2o_rank(C.byref(idx.fwd), bot, c)] == v[13:15], ("rank pair", row)
+        assert v[15] == (1 if row // side_len == bot // side_len else 2), ("sides the reference reads for the pair", row)
