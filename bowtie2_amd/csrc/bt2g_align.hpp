@@ -235,6 +235,9 @@ struct HotWork {
 	uint32_t n_ext_left, n_ext_right, n_resolve_steps;
 	uint32_t n_sides;           // sides (64/128-byte lines) actually read -- roofline accounting
 	uint32_t n_sranges;         // -N 1: entries of Work::sranges in use
+	// the N-free fragment of the reference (rstarts record) the last resolved seed hit lies in: joined-text start, length, offset of its
+	// first base within reference frag_tidx.  A DP window inside it is a contiguous piece of the joined text (= the .4 buffer).
+	uint64_t frag_jlo, frag_len, frag_toff, frag_tidx;
 	uint32_t n_dp_cells_score, n_dp_cells_full, n_dp_pass;   // measurement: DP cells computed by score-only passes / by fills that store a matrix; windows that reached minsc
 	CacheModel cm;              // seed cache pool of the current seeding round
 	PeHot    pe;                // paired-end reporting state (unused for unpaired reads)

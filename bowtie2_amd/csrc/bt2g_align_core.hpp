@@ -1143,7 +1143,19 @@ struct Aligner {
 	// E. DP: reference window, fill, gather, backtrace
 	// =================================================================================
 	// SwAligner::initRef (aligner_sw.cpp:155-271): masks for [rect.refl, rect.refr+1], overhang = N
-	BT2_HD void fetch_ref_window(uint64_t tidx, int64_t rfi, uint32_t count) { Plat::fetch_ref(IX.ref, w, tidx, rfi, count); }
+	BT2_HD void fetch_ref_window(uint64_t tidx, int64_t rfi, uint32_t count) {
+		// inside the fragment the seed hit was resolved in (nearly always): a contiguous piece of the joined text
+		const int64_t rel = rfi - (int64_t)HOT.frag_toff;
+		if (tidx == HOT.frag_tidx && rel >= 0 && (uint64_t)rel + count <= HOT.frag_len) {
+			Plat::fetch_ref_joined(IX.ref, HOT.frag_jlo + (uint64_t)rel, count);
+#ifdef BT2G_CHECK_REF_JOINED
+			// test builds: the joined-text form must give what the record search gives
+			{ uint8_t a[kMaxCols + 8]; memcpy(a, HOT.rf, count); Plat::fetch_ref(IX.ref, w, tidx, rfi, count); static unsigned long n_ = 0; n_++;
+			  if (memcmp(a, HOT.rf, count)) { fprintf(stderr, "fetch_ref_joined mismatch (tidx %llu rfi %lld count %u)\n", (unsigned long long)tidx, (long long)rfi, count); abort(); }
+			  if ((n_ & (n_ - 1)) == 0) fprintf(stderr, "fetch_ref_joined checked %lu windows\n", n_); }
+#endif
+		} else Plat::fetch_ref(IX.ref, w, tidx, rfi, count);
+	}
 
 	// packed cell (H | E<<8 | F<<16)
 	BT2_HD uint32_t cell_get(uint32_t R, uint32_t i, uint32_t j) const { return dp.mat[dp_cell(R, i, j)]; }
@@ -1181,292 +1193,6 @@ struct Aligner {
 			} else Plat::zero_masks(dp.masks, rows * cols);
 			HOT.t_phase[16] += now() - tz_;
 		}
-	}
-
-	// backtraceNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1283-1877).  fw = orientation aligned.
-	// WIN: the start column lies past the 768 columns the reference-window registers hold (opposite-mate windows only),
-	// so the registers are loaded from a later base column; unpaired windows never need it
-	template <int MODE, bool WIN = false>
-	BT2_HDN bool backtrace(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen,
-	                      int32_t escore, uint32_t row_, uint32_t col_, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi,
-	                      AlnRes& res) {
-		(void)escore;
-		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
-		const bool fw = Plat::uni((int)fw_) != 0;
-		// cell format: 0 = e2e 8-bit (bias 0xff), 1 = e2e 16-bit (bias 0x7fff), 2 = local (16-bit fields holding plain scores, floor 0)
-		constexpr bool wide = MODE != 0, local = MODE == 2;
-		constexpr bool pred = MODE == 0;                 // 8-bit end-to-end: one byte of predecessor bits per cell (PB_*), tile = kPredTile diagonal steps
-		constexpr uint32_t tile_len = pred ? kPredTile : kBtTile;
-		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
-		uint32_t row = Plat::uni(row_), col = Plat::uni(col_);
-		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
-		S.gapbar = Plat::uni(PRM.gapbar); S.rdgapo = Plat::uni(PRM.rdgapo); S.rdgape = Plat::uni(PRM.rdgape);
-		S.rfgapo = Plat::uni(PRM.rfgapo); S.rfgape = Plat::uni(PRM.rfgape); S.match_bonus = Plat::uni(PRM.match_bonus);
-		S.mm_type = Plat::uni(PRM.mm_type); S.mm_max = Plat::uni(PRM.mm_max); S.mm_min = Plat::uni(PRM.mm_min); S.n_pen = Plat::uni(PRM.n_pen);
-		const int r_triml = (int)Plat::uni(rect.triml), r_corel = (int)Plat::uni(rect.corel), r_corer = (int)Plat::uni(rect.corer);
-		const uint32_t R = dp_R(rows);
-		// `this` lives in private memory: read what the loop needs once, into scalar registers
-		DpScratch dpl;
-		dpl.mat = Plat::uni_ptr(dp.mat); dpl.masks = Plat::uni_ptr(dp.masks); dpl.pmask = Plat::uni_ptr(dp.pmask); dpl.epoch = Plat::uni_ptr(dp.epoch); dpl.pmask_words = 0;
-		const uint32_t epoch = pred ? Plat::uni(*dpl.epoch) : 0u;
-		const int32_t band_lo = pred ? (int32_t)Plat::uni(dpl.epoch[1]) : 0;       // geometry of the band the fill stored (pred_idx)
-		const uint32_t band_w = pred ? Plat::uni(dpl.epoch[2]) : 0u;
-		BtFrame* const btstack = Plat::uni_ptr(&w.btstack[0]);
-		struct Prof {      // profile counters stay in registers until the function returns
-			Aligner& a; uint32_t steps, tiles; uint64_t tile_t;
-			BT2_HD ~Prof() { a.pf_steps += steps; a.pf_tiles += tiles; a.pf_tile_t += tile_t; }
-		} prof{*this, 0, 0, 0};
-		// read, qualities and reference window as per-lane registers (4 bytes per lane per register): the step
-		// loop then reads them with v_readlane instead of going to LDS
-		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
-		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
-		// the walk moves left from the start column by at most rows + gaps columns: three registers (768 columns) ending
-		// at the start column cover it even when an opposite-mate window is wider than that
-		const uint32_t rf_c0 = WIN ? ((col + 1 - 768u + 3u) & ~3u) : 0u;   // `col` is still the start column here
-		if (rf_c0 > 0 && rows + 250u > 764u) { ovf(17); return false; }   // the walk could leave the 768-column window (rows + read gaps)
-		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64 + (rf_c0 >> 2));
-		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
-			const uint32_t word = idx >> 2;
-			uint32_t v = Plat::lane(arr[0], word & 63);
-			if (nreg > 1 && (word >> 6) == 1) v = Plat::lane(arr[1], word & 63);
-			if (nreg > 2 && (word >> 6) == 2) v = Plat::lane(arr[2], word & 63);
-			return (int)((v >> ((idx & 3) * 8)) & 0xff);
-		};
-		uint32_t td = 0;     // the caller fetched the tile anchored at (row, col); td = steps taken along its diagonal
-		const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
-		int olap = 0;        // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
-		auto in_core = [&](uint32_t r_, uint32_t c_) -> int {
-			const int diagi = (int)c_ - (int)r_ + r_triml;          // rows, columns and trims are all < 2^16
-			return (int)(diagi >= r_corel) & (int)(diagi <= r_corer);     // corel >= 0, so diagi >= 0 is implied
-		};
-		uint32_t nstack = 0, ncells = 0, nned = 0;
-		int32_t score = 0, ns = 0;
-		const uint32_t orig_col = col;
-		uint32_t gaps = 0, read_gaps = 0, ref_gaps = 0;
-		const uint32_t trim_end = rows - row - 1;
-		uint32_t trim_beg = 0;
-		int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
-		Edit* ned = HOT.ned;
-		const int offsetsc = local ? 0 : (wide ? -0x7fff : -0xff);
-		auto fl = [&](int v) -> bool { return !local || v > 0; };     // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
-		HOT.n_bt_attempts++;
-		while ((int)row >= 0) {
-			if (pred && ct == 0 && td < tile_len && row > 0) {
-				// a run of plain diagonal steps (unvisited cells whose only consistent predecessor is the diagonal one) is walked
-				// by all lanes at once: same marks, same edits, same counters as the step-by-step loop below
-				const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
-				const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
-				typename Plat::LaneReg inf;
-				uint64_t mm;
-				const uint32_t L = Plat::uni(Plat::bt_diag_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, fw, rdlen, room_c < room_e ? room_c : room_e, inf, mm));
-				if (L > 0) {
-					olap |= in_core(row, col); ncells += L; prof.steps += L;
-					while (mm) {
-						const uint32_t d = (uint32_t)__builtin_ctzll(mm);
-						mm &= mm - 1;
-						const uint32_t v = Plat::lane(inf, d);
-						const int e_readc = (int)((v >> 4) & 7), e_refm = (int)((v >> 8) & 0xff), e_q = (int)((v >> 16) & 0xff);
-						Edit& e = ned[nned++];
-						e.pos = (uint16_t)(row - (d - td)); e.chr = (uint8_t)mask2chr(e_refm); e.qchr = code2chr(e_readc); e.type = EDIT_MM;
-						score -= sc_mm(S, e_readc, e_refm, e_q - 33);
-						if (v & 2u) ns++;
-					}
-					row -= L; col -= L; td += L;
-					continue;
-				}
-			}
-			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
-			const int refm = byte_of(rfw, 3, col - rf_c0);
-			const int readq = byte_of(qlw, 2, fw ? row : rdlen - 1 - row);
-			// Flags are ints combined with & and |: the control code is wave-uniform and this keeps it on 32-bit scalar
-			// compares/selects instead of 64-bit lane-mask juggling.
-			int empty = 0, can_move_thru = 1, branch = 0;
-			int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
-			prof.steps++;
-			if (td >= tile_len) {
-				const uint64_t tt_ = now();
-				if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
-				td = 0; prof.tiles++; prof.tile_t += now() - tt_;
-			}
-			const uint32_t mk0 = pred ? Plat::lane(tile_hi, td) : (Plat::lane(tile, 48 + td) & 0xffffu);
-			uint32_t mk = mk0;
-			if (mk0 & 1) {                    // reportedThrough
-				can_move_thru = 0;
-			} else if (row > 0) {
-				int mask, orig_mask, sel = -1;
-				if (pred) {
-					// the fill already answered "which predecessors are score-consistent" (PB_* bits, gap barrier folded in)
-					const int pb = (int)Plat::lane(tile, td);
-					if (ct == 1) {
-						mask = (pb >> 3) & 3;
-						orig_mask = mask;
-						if (mk & (1u << 7)) mask = (int)((mk >> 8) & 3);
-						branch = (int)(mask == 3);
-						if (mask != 0) { cur = (mask == 2) ? 4 : 3; mk = (mk & ~(7u << 7)) | (1u << 7) | (branch ? (2u << 8) : 0u); sel = 0; }
-					} else if (ct == 2) {
-						mask = (pb >> 5) & 3;
-						orig_mask = mask;
-						if (mk & (1u << 10)) mask = (int)((mk >> 11) & 3);
-						branch = (int)(mask == 3);
-						if (mask != 0) { cur = (mask == 2) ? 2 : 1; mk = (mk & ~(7u << 10)) | (1u << 10) | (branch ? (2u << 11) : 0u); sel = 0; }
-					} else {
-						const int he = (pb >> 1) & 1, hf = (pb >> 2) & 1;
-						mask = (hf & (pb >> 5) & 1) | ((he & (pb >> 3) & 1) << 1) | ((hf & (pb >> 6) & 1) << 2) | ((he & (pb >> 4) & 1) << 3) | ((pb & 1) << 4);
-						orig_mask = mask;
-						if (mk & (1u << 1)) mask = (int)((mk >> 2) & 31);
-						if (mask != 0) {
-							sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
-							branch = (int)((mask & (mask - 1)) != 0);
-							mk = (mk & ~(31u << 1)) | (1u << 1) | (branch ? (uint32_t)(mask & ~(1 << sel)) << 2 : 0u);
-							cur = (int)((0x04231u >> (4 * sel)) & 7);
-						}
-					}
-				} else {
-				const uint32_t row_from_end = rows - row - 1;
-				const int ga = (int)(row >= (uint32_t)S.gapbar) & (int)(row_from_end >= (uint32_t)S.gapbar);     // gaps allowed
-				auto cell = [&](uint32_t ln) -> uint64_t { return (uint64_t)Plat::lane(tile, ln) | (wide ? (uint64_t)Plat::lane(tile_hi, ln) << 32 : 0ull); };
-				const uint64_t c_cur = cell(td);
-				const uint64_t c_up = cell(16 + td);
-				const uint64_t c_left = cell(32 + td);
-				const uint64_t c_upleft = cell(td + 1);
-				auto Hc = [&](uint64_t c) -> int { return local ? (int)(c & 0xffff) : wide ? (int)(int16_t)(uint16_t)(c & 0xffff) : (int)(c & 0xff); };
-				auto Ec = [&](uint64_t c) -> int { return local ? (int)((c >> 16) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 16) & 0xffff) : (int)((c >> 8) & 0xff); };
-				auto Fc = [&](uint64_t c) -> int { return local ? (int)((c >> 32) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 32) & 0xffff) : (int)((c >> 16) & 0xff); };
-				auto fl = [&](int v) -> int { return local ? (int)(v > 0) : 1; };    // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
-				const int hasl = (int)(col > 0);
-				if (ct == 1) {          // E: came from the left (H-left open = bit 0, E-left extend = bit 1)
-					const int sc_cur = Ec(c_cur) + offsetsc, sc_h_left = Hc(c_left) + offsetsc, sc_e_left = Ec(c_left) + offsetsc;
-					mask = (fl(sc_h_left) & (int)(sc_h_left - S.rdgapo == sc_cur)) | ((fl(sc_e_left) & (int)(sc_e_left - S.rdgape == sc_cur)) << 1);
-					orig_mask = mask;
-					if (mk & (1u << 7)) mask = (int)((mk >> 8) & 3);
-					// both -> take the open (cur 3) and leave the extension for later; else the one there is
-					branch = (int)(mask == 3);
-					if (mask != 0) { cur = (mask == 2) ? 4 : 3; mk = (mk & ~(7u << 7)) | (1u << 7) | (branch ? (2u << 8) : 0u); sel = 0; }
-				} else if (ct == 2) {   // F: came from above (H-up open = bit 0, F-up extend = bit 1)
-					const int sc_cur = Fc(c_cur) + offsetsc, sc_h_up = Hc(c_up) + offsetsc, sc_f_up = Fc(c_up) + offsetsc;
-					mask = (fl(sc_h_up) & (int)(sc_h_up - S.rfgapo == sc_cur)) | ((fl(sc_f_up) & (int)(sc_f_up - S.rfgape == sc_cur)) << 1);
-					orig_mask = mask;
-					if (mk & (1u << 10)) mask = (int)((mk >> 11) & 3);
-					branch = (int)(mask == 3);
-					if (mask != 0) { cur = (mask == 2) ? 2 : 1; mk = (mk & ~(7u << 10)) | (1u << 10) | (branch ? (2u << 11) : 0u); sel = 0; }
-				} else {                // H: bit 0 ref-gap open, 1 read-gap open, 2 ref-gap extend, 3 read-gap extend, 4 diagonal
-					const int sc_cur = Hc(c_cur) + offsetsc;
-					const int sc_f_up = Fc(c_up) + offsetsc, sc_h_up = Hc(c_up) + offsetsc;
-					const int sc_h_left = Hc(c_left) + offsetsc, sc_e_left = Ec(c_left) + offsetsc, sc_h_upleft = Hc(c_upleft) + offsetsc;
-					const int sc_diag = sc_score(S, readc, refm, readq - 33);
-					mask = (ga & fl(sc_h_up) & (int)(sc_cur == sc_h_up - S.rfgapo))
-					     | ((ga & hasl & fl(sc_h_left) & (int)(sc_cur == sc_h_left - S.rdgapo)) << 1)
-					     | ((ga & fl(sc_f_up) & (int)(sc_cur == sc_f_up - S.rfgape)) << 2)
-					     | ((ga & hasl & fl(sc_e_left) & (int)(sc_cur == sc_e_left - S.rdgape)) << 3)
-					     | ((hasl & fl(sc_h_upleft) & (int)(sc_cur == sc_h_upleft + sc_diag)) << 4);
-					orig_mask = mask;
-					if (mk & (1u << 1)) mask = (int)((mk >> 2) & 31);
-					if (mask != 0) {
-						// preference: diagonal, ref-gap open, ref-gap extend, read-gap open, read-gap extend (the only option if there is one)
-						sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
-						branch = (int)((mask & (mask - 1)) != 0);           // more than one option: remember the others
-						mk = (mk & ~(31u << 1)) | (1u << 1) | (branch ? (uint32_t)(mask & ~(1 << sel)) << 2 : 0u);
-						cur = (int)((0x04231u >> (4 * sel)) & 7);          // sel 0,1,2,3,4 -> cur 1,3,2,4,0
-					}
-				}
-				}
-				if (sel < 0) { empty = 1; can_move_thru = (int)(orig_mask == 0); }
-			}
-			mk |= 1;                         // setReportedThrough
-			if (mk != mk0) {
-				if (pred) dpl.pmask[pred_idx(band_lo, band_w, row, col)] = mk | (epoch << kEpochShift);
-				else dpl.masks[(uint64_t)row * cols + col] = (uint16_t)mk;
-			}
-			if (!can_move_thru) {
-				if (nstack > 0) {
-					td = tile_len;           // resume elsewhere: the tile is stale
-					const BtFrame& f = btstack[--nstack];
-					const uint32_t cz_ = Plat::uni(f.celsz);
-					ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31); nned = Plat::uni(f.nedsz);
-					row = Plat::uni((uint32_t)f.row); col = Plat::uni((uint32_t)f.col);
-					gaps = Plat::uni((uint32_t)f.gaps); read_gaps = Plat::uni((uint32_t)f.read_gaps); ref_gaps = Plat::uni((uint32_t)f.ref_gaps);
-					score = Plat::uni(f.score); ns = Plat::uni(f.ns); ct = Plat::uni((int)f.ct);
-					continue;
-				}
-				return false;
-			}
-			if (empty || row == 0) {
-				olap |= in_core(row, col); ncells++;
-				trim_beg = row;
-				break;
-			}
-			if (branch) {
-				if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { ovf(18); return false; }
-				BtFrame& f = btstack[nstack++];
-				f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
-				f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
-				f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
-			}
-			if (ncells >= (uint32_t)(kMaxLen + 64)) { ovf(19); return false; }
-			olap |= in_core(row, col); ncells++;
-			if (nned + 1 >= (uint32_t)kMaxEdits) { ovf(20); return false; }
-			switch (cur) {
-				case 0: {   // diagonal
-					const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
-					ct = 0;
-					if (m != 1) {
-						Edit& e = ned[nned++];
-						e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = code2chr(readc); e.type = EDIT_MM;
-						score -= sc_mm(S, readc, refm, readq - 33);
-					} else {
-						score += S.match_bonus;
-					}
-					if (m == -1) ns++;
-					row--; col--;
-					td++;
-					break;
-				}
-				case 1: case 2: {   // ref gap (move up): open from H / extend from F
-					Edit& e = ned[nned++];
-					e.pos = (uint16_t)row; e.chr = '-'; e.qchr = code2chr(readc); e.type = EDIT_REF_GAP;
-					row--;
-					td = tile_len;
-					ct = (cur == 1) ? 0 : 2;
-					score -= (cur == 1) ? S.rfgapo : S.rfgape;
-					gaps++; ref_gaps++;
-					break;
-				}
-				default: {          // read gap (move left): open from H / extend from E
-					Edit& e = ned[nned++];
-					e.pos = (uint16_t)(row + 1); e.chr = (uint8_t)mask2chr(refm); e.qchr = '-'; e.type = EDIT_READ_GAP;
-					col--;
-					td = tile_len;
-					ct = (cur == 3) ? 0 : 1;
-					score -= (cur == 3) ? S.rdgapo : S.rdgape;
-					gaps++; read_gaps++;
-					break;
-				}
-			}
-		}
-		if (!olap) return false;
-		{
-			const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
-			if (col < rf_c0) { ovf(21); return false; }
-			const int refm = byte_of(rfw, 3, col - rf_c0);
-			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
-			if (m != 1) {
-				Edit& e = ned[nned++];
-				e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = code2chr(readc); e.type = EDIT_MM;
-				score -= sc_mm(S, readc, refm, byte_of(qlw, 2, fw ? row : rdlen - 1 - row) - 33);
-			} else score += S.match_bonus;
-			if (m == -1) ns++;
-		}
-		if (ns > RPR.nceil) return false;
-		// res.reverse(), while copying the edits out of LDS
-		for (uint32_t i = 0; i < nned; i++) res.ned[i] = ned[nned - 1 - i];
-		res.nned = (uint16_t)nned;
-		res.score = score; res.ns = (int16_t)ns; res.gaps = (int16_t)gaps; res.edits = (int16_t)nned;
-		res.bases_aligned = (int16_t)((int)rows - (int)trim_beg - (int)trim_end - (int)nned);
-		uint32_t refns = 0;
-		for (uint32_t i = col; i <= orig_col; i++) if (HOT.rf[i] > 15) refns++;
-		res.refns = (uint16_t)refns;
-		set_shape(res, (int32_t)tidx, (int64_t)col + rect.refl, tlen, fw, rows, fw ? trim_beg : trim_end, fw ? trim_end : trim_beg);
-		return true;
 	}
 
 	BT2_HD static int mask2chr(int m) {
@@ -1542,22 +1268,306 @@ struct Aligner {
 		}
 	}
 
-	// SwAligner::nextAlignment, end-to-end u8 branch (aligner_sw.cpp:737-1146)
-	BT2_HDN bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, int mode, bool sse16, AlnRes& res) {
-		const bool wide = mode != 0;
+	// SwAligner::nextAlignment (aligner_sw.cpp:737-1146) with the backtrace (backtraceNucleotidesEnd2EndSseU8, aligner_swsse_ee_u8.cpp:1283-1877,
+	// and its 16-bit / local counterparts) inside its candidate loop.  Most candidates of a window fail within a few cells -- they run
+	// into the cells an earlier alignment of the same window went through -- so what a backtrace needs before its first step (scoring
+	// and rectangle constants in scalar registers, the read / qualities / reference window in lane registers, the geometry of the stored
+	// band) is set up ONCE per call, not once per candidate.  fw = orientation aligned.
+	// MODE: cell format -- 0 = e2e 8-bit (bias 0xff), 1 = e2e 16-bit (bias 0x7fff), 2 = local (16-bit fields holding plain scores, floor 0)
+	template <int MODE>
+	BT2_HDN bool next_alignment_m(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen, bool sse16, AlnRes& res) {
 		if (HOT.cural == HOT.n_cands) return false;
+		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
+		const bool fw = Plat::uni((int)fw_) != 0;
+		constexpr bool wide = MODE != 0, local = MODE == 2;
+		constexpr bool pred = MODE == 0;                 // 8-bit end-to-end: one byte of predecessor bits per cell (PB_*), tile = kPredTile diagonal steps
+		constexpr uint32_t tile_len = pred ? kPredTile : kBtTile;
+		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
+		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
+		S.gapbar = Plat::uni(PRM.gapbar); S.rdgapo = Plat::uni(PRM.rdgapo); S.rdgape = Plat::uni(PRM.rdgape);
+		S.rfgapo = Plat::uni(PRM.rfgapo); S.rfgape = Plat::uni(PRM.rfgape); S.match_bonus = Plat::uni(PRM.match_bonus);
+		S.mm_type = Plat::uni(PRM.mm_type); S.mm_max = Plat::uni(PRM.mm_max); S.mm_min = Plat::uni(PRM.mm_min); S.n_pen = Plat::uni(PRM.n_pen);
+		const int r_triml = (int)Plat::uni(rect.triml), r_corel = (int)Plat::uni(rect.corel), r_corer = (int)Plat::uni(rect.corer);
+		const uint32_t R = dp_R(rows);
+		// `this` lives in private memory: read what the loop needs once, into scalar registers
+		DpScratch dpl;
+		dpl.mat = Plat::uni_ptr(dp.mat); dpl.masks = Plat::uni_ptr(dp.masks); dpl.pmask = Plat::uni_ptr(dp.pmask); dpl.epoch = Plat::uni_ptr(dp.epoch); dpl.pmask_words = 0;
+		const uint32_t epoch = pred ? Plat::uni(*dpl.epoch) : 0u;
+		const int32_t band_lo = pred ? (int32_t)Plat::uni(dpl.epoch[1]) : 0;       // geometry of the band the fill stored (pred_idx)
+		const uint32_t band_w = pred ? Plat::uni(dpl.epoch[2]) : 0u;
+		BtFrame* const btstack = Plat::uni_ptr(&w.btstack[0]);
+		BtCand* const cands = Plat::uni_ptr(cand_list());
+		struct Prof {      // profile counters stay in registers until the function returns
+			Aligner& a; uint32_t steps, tiles; uint64_t tile_t;
+			BT2_HD ~Prof() { a.pf_steps += steps; a.pf_tiles += tiles; a.pf_tile_t += tile_t; }
+		} prof{*this, 0, 0, 0};
+		// read, qualities and reference window as per-lane registers (4 bytes per lane per register): the step
+		// loop then reads them with v_readlane instead of going to LDS
+		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
+		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
+		// the walk moves left from its start column by at most rows + gaps columns: three registers (768 columns) cover every window of an
+		// unpaired read from column 0 (rf_c0 = 0); only a candidate past column 767 of a wide opposite-mate window needs them re-based
+		uint32_t rf_c0 = 0;
+		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64);
+		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
+			const uint32_t word = idx >> 2;
+			uint32_t v = Plat::lane(arr[0], word & 63);
+			if (nreg > 1 && (word >> 6) == 1) v = Plat::lane(arr[1], word & 63);
+			if (nreg > 2 && (word >> 6) == 2) v = Plat::lane(arr[2], word & 63);
+			return (int)((v >> ((idx & 3) * 8)) & 0xff);
+		};
+		// one backtrace from cell (row, col), whose tile the caller fetched
+		auto walk = [&](uint32_t row, uint32_t col, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi) __attribute__((always_inline)) -> bool {
+			row = Plat::uni(row); col = Plat::uni(col);
+			uint32_t td = 0;     // td = steps taken along the tile's diagonal
+			const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
+			int olap = 0;        // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
+			auto in_core = [&](uint32_t r_, uint32_t c_) -> int {
+				const int diagi = (int)c_ - (int)r_ + r_triml;          // rows, columns and trims are all < 2^16
+				return (int)(diagi >= r_corel) & (int)(diagi <= r_corer);     // corel >= 0, so diagi >= 0 is implied
+			};
+			uint32_t nstack = 0, ncells = 0, nned = 0;
+			int32_t score = 0, ns = 0;
+			const uint32_t orig_col = col;
+			uint32_t gaps = 0, read_gaps = 0, ref_gaps = 0;
+			const uint32_t trim_end = rows - row - 1;
+			uint32_t trim_beg = 0;
+			int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
+			Edit* ned = HOT.ned;
+			const int offsetsc = local ? 0 : (wide ? -0x7fff : -0xff);
+			auto fl = [&](int v) -> bool { return !local || v > 0; };     // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
+			HOT.n_bt_attempts++;
+			while ((int)row >= 0) {
+				if (pred && ct == 0 && td < tile_len && row > 0) {
+					// a run of plain diagonal steps (unvisited cells whose only consistent predecessor is the diagonal one) is walked
+					// by all lanes at once: same marks, same edits, same counters as the step-by-step loop below
+					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
+					const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
+					typename Plat::LaneReg inf;
+					uint64_t mm;
+					const uint32_t L = Plat::uni(Plat::bt_diag_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, fw, rdlen, room_c < room_e ? room_c : room_e, inf, mm));
+					if (L > 0) {
+						olap |= in_core(row, col); ncells += L; prof.steps += L;
+						while (mm) {
+							const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+							mm &= mm - 1;
+							const uint32_t v = Plat::lane(inf, d);
+							const int e_readc = (int)((v >> 4) & 7), e_refm = (int)((v >> 8) & 0xff), e_q = (int)((v >> 16) & 0xff);
+							Edit& e = ned[nned++];
+							e.pos = (uint16_t)(row - (d - td)); e.chr = (uint8_t)mask2chr(e_refm); e.qchr = code2chr(e_readc); e.type = EDIT_MM;
+							score -= sc_mm(S, e_readc, e_refm, e_q - 33);
+							if (v & 2u) ns++;
+						}
+						row -= L; col -= L; td += L;
+						continue;
+					}
+				}
+				const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
+				const int refm = byte_of(rfw, 3, col - rf_c0);
+				const int readq = byte_of(qlw, 2, fw ? row : rdlen - 1 - row);
+				// Flags are ints combined with & and |: the control code is wave-uniform and this keeps it on 32-bit scalar
+				// compares/selects instead of 64-bit lane-mask juggling.
+				int empty = 0, can_move_thru = 1, branch = 0;
+				int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
+				prof.steps++;
+				if (td >= tile_len) {
+					const uint64_t tt_ = now();
+					if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
+					td = 0; prof.tiles++; prof.tile_t += now() - tt_;
+				}
+				const uint32_t mk0 = pred ? Plat::lane(tile_hi, td) : (Plat::lane(tile, 48 + td) & 0xffffu);
+				uint32_t mk = mk0;
+				if (mk0 & 1) {                    // reportedThrough
+					can_move_thru = 0;
+				} else if (row > 0) {
+					int mask, orig_mask, sel = -1;
+					if (pred) {
+						// the fill already answered "which predecessors are score-consistent" (PB_* bits, gap barrier folded in)
+						const int pb = (int)Plat::lane(tile, td);
+						if (ct == 1) {
+							mask = (pb >> 3) & 3;
+							orig_mask = mask;
+							if (mk & (1u << 7)) mask = (int)((mk >> 8) & 3);
+							branch = (int)(mask == 3);
+							if (mask != 0) { cur = (mask == 2) ? 4 : 3; mk = (mk & ~(7u << 7)) | (1u << 7) | (branch ? (2u << 8) : 0u); sel = 0; }
+						} else if (ct == 2) {
+							mask = (pb >> 5) & 3;
+							orig_mask = mask;
+							if (mk & (1u << 10)) mask = (int)((mk >> 11) & 3);
+							branch = (int)(mask == 3);
+							if (mask != 0) { cur = (mask == 2) ? 2 : 1; mk = (mk & ~(7u << 10)) | (1u << 10) | (branch ? (2u << 11) : 0u); sel = 0; }
+						} else {
+							const int he = (pb >> 1) & 1, hf = (pb >> 2) & 1;
+							mask = (hf & (pb >> 5) & 1) | ((he & (pb >> 3) & 1) << 1) | ((hf & (pb >> 6) & 1) << 2) | ((he & (pb >> 4) & 1) << 3) | ((pb & 1) << 4);
+							orig_mask = mask;
+							if (mk & (1u << 1)) mask = (int)((mk >> 2) & 31);
+							if (mask != 0) {
+								sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
+								branch = (int)((mask & (mask - 1)) != 0);
+								mk = (mk & ~(31u << 1)) | (1u << 1) | (branch ? (uint32_t)(mask & ~(1 << sel)) << 2 : 0u);
+								cur = (int)((0x04231u >> (4 * sel)) & 7);
+							}
+						}
+					} else {
+					const uint32_t row_from_end = rows - row - 1;
+					const int ga = (int)(row >= (uint32_t)S.gapbar) & (int)(row_from_end >= (uint32_t)S.gapbar);     // gaps allowed
+					auto cell = [&](uint32_t ln) -> uint64_t { return (uint64_t)Plat::lane(tile, ln) | (wide ? (uint64_t)Plat::lane(tile_hi, ln) << 32 : 0ull); };
+					const uint64_t c_cur = cell(td);
+					const uint64_t c_up = cell(16 + td);
+					const uint64_t c_left = cell(32 + td);
+					const uint64_t c_upleft = cell(td + 1);
+					auto Hc = [&](uint64_t c) -> int { return local ? (int)(c & 0xffff) : wide ? (int)(int16_t)(uint16_t)(c & 0xffff) : (int)(c & 0xff); };
+					auto Ec = [&](uint64_t c) -> int { return local ? (int)((c >> 16) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 16) & 0xffff) : (int)((c >> 8) & 0xff); };
+					auto Fc = [&](uint64_t c) -> int { return local ? (int)((c >> 32) & 0xffff) : wide ? (int)(int16_t)(uint16_t)((c >> 32) & 0xffff) : (int)((c >> 16) & 0xff); };
+					auto fl = [&](int v) -> int { return local ? (int)(v > 0) : 1; };    // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
+					const int hasl = (int)(col > 0);
+					if (ct == 1) {          // E: came from the left (H-left open = bit 0, E-left extend = bit 1)
+						const int sc_cur = Ec(c_cur) + offsetsc, sc_h_left = Hc(c_left) + offsetsc, sc_e_left = Ec(c_left) + offsetsc;
+						mask = (fl(sc_h_left) & (int)(sc_h_left - S.rdgapo == sc_cur)) | ((fl(sc_e_left) & (int)(sc_e_left - S.rdgape == sc_cur)) << 1);
+						orig_mask = mask;
+						if (mk & (1u << 7)) mask = (int)((mk >> 8) & 3);
+						// both -> take the open (cur 3) and leave the extension for later; else the one there is
+						branch = (int)(mask == 3);
+						if (mask != 0) { cur = (mask == 2) ? 4 : 3; mk = (mk & ~(7u << 7)) | (1u << 7) | (branch ? (2u << 8) : 0u); sel = 0; }
+					} else if (ct == 2) {   // F: came from above (H-up open = bit 0, F-up extend = bit 1)
+						const int sc_cur = Fc(c_cur) + offsetsc, sc_h_up = Hc(c_up) + offsetsc, sc_f_up = Fc(c_up) + offsetsc;
+						mask = (fl(sc_h_up) & (int)(sc_h_up - S.rfgapo == sc_cur)) | ((fl(sc_f_up) & (int)(sc_f_up - S.rfgape == sc_cur)) << 1);
+						orig_mask = mask;
+						if (mk & (1u << 10)) mask = (int)((mk >> 11) & 3);
+						branch = (int)(mask == 3);
+						if (mask != 0) { cur = (mask == 2) ? 2 : 1; mk = (mk & ~(7u << 10)) | (1u << 10) | (branch ? (2u << 11) : 0u); sel = 0; }
+					} else {                // H: bit 0 ref-gap open, 1 read-gap open, 2 ref-gap extend, 3 read-gap extend, 4 diagonal
+						const int sc_cur = Hc(c_cur) + offsetsc;
+						const int sc_f_up = Fc(c_up) + offsetsc, sc_h_up = Hc(c_up) + offsetsc;
+						const int sc_h_left = Hc(c_left) + offsetsc, sc_e_left = Ec(c_left) + offsetsc, sc_h_upleft = Hc(c_upleft) + offsetsc;
+						const int sc_diag = sc_score(S, readc, refm, readq - 33);
+						mask = (ga & fl(sc_h_up) & (int)(sc_cur == sc_h_up - S.rfgapo))
+						     | ((ga & hasl & fl(sc_h_left) & (int)(sc_cur == sc_h_left - S.rdgapo)) << 1)
+						     | ((ga & fl(sc_f_up) & (int)(sc_cur == sc_f_up - S.rfgape)) << 2)
+						     | ((ga & hasl & fl(sc_e_left) & (int)(sc_cur == sc_e_left - S.rdgape)) << 3)
+						     | ((hasl & fl(sc_h_upleft) & (int)(sc_cur == sc_h_upleft + sc_diag)) << 4);
+						orig_mask = mask;
+						if (mk & (1u << 1)) mask = (int)((mk >> 2) & 31);
+						if (mask != 0) {
+							// preference: diagonal, ref-gap open, ref-gap extend, read-gap open, read-gap extend (the only option if there is one)
+							sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
+							branch = (int)((mask & (mask - 1)) != 0);           // more than one option: remember the others
+							mk = (mk & ~(31u << 1)) | (1u << 1) | (branch ? (uint32_t)(mask & ~(1 << sel)) << 2 : 0u);
+							cur = (int)((0x04231u >> (4 * sel)) & 7);          // sel 0,1,2,3,4 -> cur 1,3,2,4,0
+						}
+					}
+					}
+					if (sel < 0) { empty = 1; can_move_thru = (int)(orig_mask == 0); }
+				}
+				mk |= 1;                         // setReportedThrough
+				if (mk != mk0) {
+					if (pred) dpl.pmask[pred_idx(band_lo, band_w, row, col)] = mk | (epoch << kEpochShift);
+					else dpl.masks[(uint64_t)row * cols + col] = (uint16_t)mk;
+				}
+				if (!can_move_thru) {
+					if (nstack > 0) {
+						td = tile_len;           // resume elsewhere: the tile is stale
+						const BtFrame& f = btstack[--nstack];
+						const uint32_t cz_ = Plat::uni(f.celsz);
+						ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31); nned = Plat::uni(f.nedsz);
+						row = Plat::uni((uint32_t)f.row); col = Plat::uni((uint32_t)f.col);
+						gaps = Plat::uni((uint32_t)f.gaps); read_gaps = Plat::uni((uint32_t)f.read_gaps); ref_gaps = Plat::uni((uint32_t)f.ref_gaps);
+						score = Plat::uni(f.score); ns = Plat::uni(f.ns); ct = Plat::uni((int)f.ct);
+						continue;
+					}
+					return false;
+				}
+				if (empty || row == 0) {
+					olap |= in_core(row, col); ncells++;
+					trim_beg = row;
+					break;
+				}
+				if (branch) {
+					if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { ovf(18); return false; }
+					BtFrame& f = btstack[nstack++];
+					f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
+					f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
+					f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
+				}
+				if (ncells >= (uint32_t)(kMaxLen + 64)) { ovf(19); return false; }
+				olap |= in_core(row, col); ncells++;
+				if (nned + 1 >= (uint32_t)kMaxEdits) { ovf(20); return false; }
+				switch (cur) {
+					case 0: {   // diagonal
+						const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
+						ct = 0;
+						if (m != 1) {
+							Edit& e = ned[nned++];
+							e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = code2chr(readc); e.type = EDIT_MM;
+							score -= sc_mm(S, readc, refm, readq - 33);
+						} else {
+							score += S.match_bonus;
+						}
+						if (m == -1) ns++;
+						row--; col--;
+						td++;
+						break;
+					}
+					case 1: case 2: {   // ref gap (move up): open from H / extend from F
+						Edit& e = ned[nned++];
+						e.pos = (uint16_t)row; e.chr = '-'; e.qchr = code2chr(readc); e.type = EDIT_REF_GAP;
+						row--;
+						td = tile_len;
+						ct = (cur == 1) ? 0 : 2;
+						score -= (cur == 1) ? S.rfgapo : S.rfgape;
+						gaps++; ref_gaps++;
+						break;
+					}
+					default: {          // read gap (move left): open from H / extend from E
+						Edit& e = ned[nned++];
+						e.pos = (uint16_t)(row + 1); e.chr = (uint8_t)mask2chr(refm); e.qchr = '-'; e.type = EDIT_READ_GAP;
+						col--;
+						td = tile_len;
+						ct = (cur == 3) ? 0 : 1;
+						score -= (cur == 3) ? S.rdgapo : S.rdgape;
+						gaps++; read_gaps++;
+						break;
+					}
+				}
+			}
+			if (!olap) return false;
+			{
+				const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
+				if (col < rf_c0) { ovf(21); return false; }
+				const int refm = byte_of(rfw, 3, col - rf_c0);
+				const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
+				if (m != 1) {
+					Edit& e = ned[nned++];
+					e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = code2chr(readc); e.type = EDIT_MM;
+					score -= sc_mm(S, readc, refm, byte_of(qlw, 2, fw ? row : rdlen - 1 - row) - 33);
+				} else score += S.match_bonus;
+				if (m == -1) ns++;
+			}
+			if (ns > RPR.nceil) return false;
+			// res.reverse(), while copying the edits out of LDS
+			for (uint32_t i = 0; i < nned; i++) res.ned[i] = ned[nned - 1 - i];
+			res.nned = (uint16_t)nned;
+			res.score = score; res.ns = (int16_t)ns; res.gaps = (int16_t)gaps; res.edits = (int16_t)nned;
+			res.bases_aligned = (int16_t)((int)rows - (int)trim_beg - (int)trim_end - (int)nned);
+			uint32_t refns = 0;
+			for (uint32_t i = col; i <= orig_col; i++) if (HOT.rf[i] > 15) refns++;
+			res.refns = (uint16_t)refns;
+			set_shape(res, (int32_t)tidx, (int64_t)col + rect.refl, tlen, fw, rows, fw ? trim_beg : trim_end, fw ? trim_end : trim_beg);
+			return true;
+	
+		};
 		bool found = false;
 		while (HOT.cural < HOT.n_cands) {
-			BtCand c = cand_list()[HOT.cural];
-			if (mode == 2) c.score &= ~kCandDone;
+			BtCand c = gld(&cands[HOT.cural]);
+			if (MODE == 2) c.score &= ~kCandDone;
 			if (c.score < minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
-			if (mode == 2) {
+			if (MODE == 2) {
 				// local: skip candidates "dominated" by one already tried -- within SQ = rows/16 rows and columns of it
 				// (aligner_sw.cpp:754-755,936-960)
 				uint32_t SQ = rows >> 4; if (SQ == 0) SQ = 1;
 				bool dom = false;
 				for (uint32_t k = 0; k < HOT.cural && !dom; k++) {
-					const BtCand& o = cand_list()[k];
+					const BtCand o = gld(&cands[k]);
 					if (!(o.score & kCandDone)) continue;
 					const uint32_t rhi = c.row > o.row ? c.row - o.row : o.row - c.row, chi = c.col > o.col ? c.col - o.col : o.col - c.col;
 					if (chi <= SQ && rhi <= SQ) dom = true;
@@ -1567,10 +1577,10 @@ struct Aligner {
 			typename Plat::LaneReg tile, tile_hi;
 			{
 				const uint64_t tt_ = now();      // also the first tile of the backtrace
-				if (mode == 0) Plat::bt_tile_pred(dp, (int32_t)Plat::uni(dp.epoch[1]), Plat::uni(dp.epoch[2]), c.row, c.col, Plat::uni(*dp.epoch), tile, tile_hi); else Plat::bt_tile(dp, dp_R(rows), cols, c.row, c.col, wide, tile, tile_hi);
-				pf_tiles++; pf_tile_t += now() - tt_;
+				if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, c.row, c.col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, c.row, c.col, wide, tile, tile_hi);
+				prof.tiles++; prof.tile_t += now() - tt_;
 			}
-			if ((mode == 0 ? Plat::lane(tile_hi, 0) : Plat::lane(tile, 48)) & 1) { HOT.cural++; continue; }
+			if ((pred ? Plat::lane(tile_hi, 0) : Plat::lane(tile, 48)) & 1) { HOT.cural++; continue; }
 			// reseeding protocol: 8-bit kernels init(reseed) ... init(reseed+1); 16-bit kernels only init(reseed) afterwards
 			// (aligner_sw.cpp:796-933 end-to-end, :962-1110 local)
 			const uint32_t reseed = rnd.nextU32() + 1;
@@ -1578,16 +1588,14 @@ struct Aligner {
 			res.nned = 0;
 			const int32_t cscore = c.score;
 			bool ret;
-			if (c.col + 1u > 768u) {
-				if (mode == 0) ret = backtrace<0, true>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
-				else if (mode == 1) ret = backtrace<1, true>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
-				else ret = backtrace<2, true>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
-			} else
-			if (mode == 0) ret = backtrace<0>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
-			else if (mode == 1) ret = backtrace<1>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
-			else ret = backtrace<2>(fw, rows, cols, rect, tidx, tlen, cscore, c.row, c.col, tile, tile_hi, res);
+			const uint32_t need_c0 = (c.col + 1u > 768u) ? (((uint32_t)c.col + 1u - 768u + 3u) & ~3u) : 0u;
+			if (need_c0 > 0 && rows + 250u > 764u) { ovf(17); ret = false; }   // the walk could leave the 768-column window (rows + read gaps)
+			else {
+				if (need_c0 != rf_c0) { rf_c0 = need_c0; for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64 + (rf_c0 >> 2)); }
+				ret = walk(c.row, c.col, tile, tile_hi);
+			}
 			rnd.init(sse16 ? reseed : reseed + 1);
-			if (mode == 2) cand_list()[HOT.cural].score = cscore | kCandDone;       // btncanddone_: tried, succeeded or not
+			if (MODE == 2) gst(&cands[HOT.cural].score, cscore | kCandDone);       // btncanddone_: tried, succeeded or not
 			if (ret) { found = true; break; }
 			HOT.cural++;
 		}
@@ -1595,6 +1603,11 @@ struct Aligner {
 		if (!fw) invert_edits(res);
 		HOT.cural++;
 		return true;
+	}
+	BT2_HD bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, int mode, bool sse16, AlnRes& res) {
+		if (mode == 0) return next_alignment_m<0>(fw, rows, cols, rect, tidx, tlen, sse16, res);
+		if (mode == 1) return next_alignment_m<1>(fw, rows, cols, rect, tidx, tlen, sse16, res);
+		return next_alignment_m<2>(fw, rows, cols, rect, tidx, tlen, sse16, res);
 	}
 
 	// SwAligner::ungappedAlign, monotone branch (aligner_sw.cpp:286-494); returns 0 / 1
@@ -1924,6 +1937,7 @@ struct Aligner {
 		HOT.n_ex_iters = HOT.n_ex_dps = HOT.n_ex_ugs = HOT.n_dp_fail = HOT.n_ug_fail = HOT.n_ee_fail = HOT.n_dp_fail_streak = 0;
 		HOT.n_redundants = HOT.n_bwops_seed = HOT.n_bwops_ext = HOT.n_bt_attempts = 0; HOT.n_sides = 0; HOT.n_ext_left = HOT.n_ext_right = HOT.n_resolve_steps = 0;
 		HOT.n_dp_cells_score = HOT.n_dp_cells_full = HOT.n_dp_pass = 0;
+		HOT.frag_tidx = ~0ull; HOT.frag_len = 0;
 		for (int i_ = 0; i_ < 22; i_++) HOT.t_phase[i_] = 0;
 		const uint64_t t_run0_ = now();
 		HOT.n_mm1 = 0; HOT.mm1_elt = 0; HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_offs = 0; HOT.num_elts = 0;

@@ -581,6 +581,7 @@ struct DevPlat {
 		tidx = tid;
 		textoff = (off - lower) + fwoff;
 		tlen = gld(ix.plen + tid);
+		g_hot.frag_jlo = (uint64_t)lower; g_hot.frag_len = (uint64_t)(upper - lower); g_hot.frag_toff = (uint64_t)fwoff; g_hot.frag_tidx = (uint64_t)tid;
 	}
 	// is (ref, off, orient) inside one of the seen-diagonal intervals?  64 intervals per round trip
 	static __device__ __forceinline__ bool diag_find(const DiagIval* d, uint32_t n, int32_t ref, int64_t off, int32_t orient) {
@@ -714,6 +715,13 @@ struct DevPlat {
 		wave_fence();
 		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);      // the window's first record: one search for the whole window
 		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)(1 << ref_base_at(ref, tidx, rfi + (int64_t)i, rec0));
+		wave_fence();
+	}
+	// a window that lies inside one N-free fragment is `count` consecutive characters of the joined text: no record search
+	static __device__ __forceinline__ void fetch_ref_joined(const DevRef& ref, uint64_t jpos, uint32_t count) {
+		wave_fence();
+		const uint8_t* buf = uni_ptr(ref.buf);
+		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) { const uint64_t p = jpos + i; g_hot.rf[i] = (uint8_t)(1u << ((gld(buf + (p >> 2)) >> ((p & 3) << 1)) & 3)); }
 		wave_fence();
 	}
 	// the same window as base codes 0..4 (ungappedAlign compares characters, aligner_sw.cpp:330-380)

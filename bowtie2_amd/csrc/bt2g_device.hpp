@@ -287,7 +287,7 @@ BT2_HD TOff get_offset(const DevEbwt<TOff>& e, TOff row, uint32_t& nsteps) {
 // Ebwt::joinedToTextOff (bt2_idx.cpp:54) for the forward index.  tidx = all-ones if rejected.
 template <typename TOff>
 BT2_HD void joined_to_text_off(const DevIndex<TOff>& ix, TOff qlen, TOff off, TOff& tidx, TOff& textoff, TOff& tlen,
-                               bool reject_straddle, bool& straddled) {
+                               bool reject_straddle, bool& straddled, uint64_t* frag = nullptr) {      // frag: -> {joined start, length, text offset, reference} of the fragment
 	TOff top = 0, bot = ix.n_frag;
 	straddled = false;
 	tidx = (TOff)OffTraits<TOff>::kMask; textoff = 0; tlen = 0;
@@ -306,6 +306,7 @@ BT2_HD void joined_to_text_off(const DevIndex<TOff>& ix, TOff qlen, TOff off, TO
 				}
 				tidx = ix.rstarts[(uint64_t)elt * 3 + 1];
 				textoff = (off - lower) + ix.rstarts[(uint64_t)elt * 3 + 2];
+				if (frag) { frag[0] = (uint64_t)lower; frag[1] = (uint64_t)(upper - lower); frag[2] = (uint64_t)ix.rstarts[(uint64_t)elt * 3 + 2]; frag[3] = (uint64_t)tidx; }
 				break;
 			}
 			top = elt;

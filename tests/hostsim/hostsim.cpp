@@ -147,7 +147,12 @@ struct HostPlat {
 	}
 	template <typename TOff>
 	static void joined_to_text(const DevIndex<TOff>& ix, TOff qlen, TOff off, TOff& tidx, TOff& textoff, TOff& tlen, bool reject_straddle, bool& straddled) {
-		joined_to_text_off(ix, qlen, off, tidx, textoff, tlen, reject_straddle, straddled);
+		uint64_t frag[4] = {0, 0, 0, ~0ull};
+		joined_to_text_off(ix, qlen, off, tidx, textoff, tlen, reject_straddle, straddled, frag);
+		g_hot.frag_jlo = frag[0]; g_hot.frag_len = frag[1]; g_hot.frag_toff = frag[2]; g_hot.frag_tidx = frag[3];
+	}
+	static void fetch_ref_joined(const DevRef& ref, uint64_t jpos, uint32_t count) {
+		for (uint32_t i = 0; i < count; i++) { const uint64_t p = jpos + i; g_hot.rf[i] = (uint8_t)(1u << ((ref.buf[p >> 2] >> ((p & 3) << 1)) & 3)); }
 	}
 	static bool diag_find(const DiagIval* d, uint32_t n, int32_t ref, int64_t off, int32_t orient) {
 		for (uint32_t i = 0; i < n; i++) if (d[i].ref == ref && d[i].orient == orient && off >= d[i].off && off < d[i].off + d[i].len) return true;
