@@ -241,6 +241,7 @@ struct HotWork {
 	uint32_t n_dp_cells_score, n_dp_cells_full, n_dp_pass;   // measurement: DP cells computed by score-only passes / by fills that store a matrix; windows that reached minsc
 	CacheModel cm;              // seed cache pool of the current seeding round
 	PeHot    pe;                // paired-end reporting state (unused for unpaired reads)
+	uint64_t t_bt[5];           // profile of the backtraces: ticks in all walks, in successful walks, # successful, ticks after the trace of a successful walk, scalar steps
 	uint64_t t_phase[22];       // device clock ticks per phase (profiling): 0 sweep 1 mm1 2 seeds 3 rank+prioritise 4 resolve 5 dp fill 6 gather+backtrace 7 other
 };
 // Backtrace tile: the cells a run of kBtTile diagonal steps starting at (row, col) can look at, gathered with one

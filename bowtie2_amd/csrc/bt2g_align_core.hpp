@@ -1298,9 +1298,9 @@ struct Aligner {
 		BtFrame* const btstack = Plat::uni_ptr(&w.btstack[0]);
 		BtCand* const cands = Plat::uni_ptr(cand_list());
 		struct Prof {      // profile counters stay in registers until the function returns
-			Aligner& a; uint32_t steps, tiles; uint64_t tile_t;
-			BT2_HD ~Prof() { a.pf_steps += steps; a.pf_tiles += tiles; a.pf_tile_t += tile_t; }
-		} prof{*this, 0, 0, 0};
+			Aligner& a; uint32_t steps, tiles; uint64_t tile_t; uint32_t scalar_steps;
+			BT2_HD ~Prof() { a.pf_steps += steps; a.pf_tiles += tiles; a.pf_tile_t += tile_t; HOT.t_bt[4] += scalar_steps; }
+		} prof{*this, 0, 0, 0, 0};
 		// read, qualities and reference window as per-lane registers (4 bytes per lane per register): the step
 		// loop then reads them with v_readlane instead of going to LDS
 		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
@@ -1369,7 +1369,7 @@ struct Aligner {
 				// compares/selects instead of 64-bit lane-mask juggling.
 				int empty = 0, can_move_thru = 1, branch = 0;
 				int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
-				prof.steps++;
+				prof.steps++; prof.scalar_steps++;
 				if (td >= tile_len) {
 					const uint64_t tt_ = now();
 					if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
@@ -1531,6 +1531,8 @@ struct Aligner {
 				}
 			}
 			if (!olap) return false;
+			const uint64_t tt0_ = now();
+			struct TailTimer { uint64_t t0; BT2_HD ~TailTimer() { if (PRM.profile) HOT.t_bt[3] += now() - t0; } } tail_timer_{tt0_};
 			{
 				const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
 				if (col < rf_c0) { ovf(21); return false; }
@@ -1592,7 +1594,9 @@ struct Aligner {
 			if (need_c0 > 0 && rows + 250u > 764u) { ovf(17); ret = false; }   // the walk could leave the 768-column window (rows + read gaps)
 			else {
 				if (need_c0 != rf_c0) { rf_c0 = need_c0; for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64 + (rf_c0 >> 2)); }
+				const uint64_t tw_ = now();
 				ret = walk(c.row, c.col, tile, tile_hi);
+				if (PRM.profile) { const uint64_t dt_ = now() - tw_; HOT.t_bt[0] += dt_; if (ret) { HOT.t_bt[1] += dt_; HOT.t_bt[2]++; } }
 			}
 			rnd.init(sse16 ? reseed : reseed + 1);
 			if (MODE == 2) gst(&cands[HOT.cural].score, cscore | kCandDone);       // btncanddone_: tried, succeeded or not
@@ -1939,6 +1943,7 @@ struct Aligner {
 		HOT.n_dp_cells_score = HOT.n_dp_cells_full = HOT.n_dp_pass = 0;
 		HOT.frag_tidx = ~0ull; HOT.frag_len = 0;
 		for (int i_ = 0; i_ < 22; i_++) HOT.t_phase[i_] = 0;
+		for (int i_ = 0; i_ < 5; i_++) HOT.t_bt[i_] = 0;
 		const uint64_t t_run0_ = now();
 		HOT.n_mm1 = 0; HOT.mm1_elt = 0; HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_offs = 0; HOT.num_elts = 0;
 		HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;

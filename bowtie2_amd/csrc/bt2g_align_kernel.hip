@@ -934,7 +934,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)g_hot.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
 			atomicAdd(&prof[9], 1ull);
-			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass);
+			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass); for (int i = 0; i < 5; i++) atomicAdd(&prof[27 + i], (unsigned long long)g_hot.t_bt[i]);
 		}
 	}
 }
@@ -988,7 +988,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)g_hot.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
 			atomicAdd(&prof[9], 2ull);
-			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass);
+			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass); for (int i = 0; i < 5; i++) atomicAdd(&prof[27 + i], (unsigned long long)g_hot.t_bt[i]);
 		}
 	}
 }
