@@ -28,6 +28,16 @@ struct CliExtra {
 	// the ordered SAM (bowtie2_amd/mgpu.py gathers the pieces over RCCL).
 	int shard_rank = 0, shard_world = 1;
 	std::string shard_index;
+	// --shard-bytes a:b[,a2:b2]: this process aligns the records in bytes [a, b) of the -U file (pairs: of the -1 file, and [a2, b2)
+	// of the -2 file) and nothing else -- it never reads another rank's bytes.  The ranges are record-aligned and computed by the
+	// launcher (bowtie2_amd/mgpu.py: newline counts of every rank's slice, all-gathered).  --shard-first-read K: number of the first
+	// read / pair of the range within the whole input (reads without a name are named by their number).  The SAM pieces of ranks
+	// 0..N-1 concatenate to the one-process output; the summary counters go to --shard-index as for --shard.
+	bool shard_bytes = false;
+	uint64_t range_a[2] = {0, 0}, range_b[2] = {0, 0};
+	int n_ranges = 0;
+	uint64_t first_read = 0;
+	std::string pg_cmdline;        // --pg-cmdline TEXT: the command line to show in @PG (the launcher passes the user's own)
 };
 
 inline bool split_ints(const std::string& s, char sep, std::vector<int>& out) {
@@ -257,6 +267,15 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 			if (sscanf(v.c_str(), "%d/%d", &ex.shard_rank, &ex.shard_world) != 2 || ex.shard_world < 1 || ex.shard_rank < 0 || ex.shard_rank >= ex.shard_world) err = "--shard needs r/N with 0 <= r < N";
 		}
 		else if (a == "--shard-index") ex.shard_index = need();
+		else if (a == "--shard-bytes") {
+			const std::string v = need();
+			unsigned long long x[4] = {0, 0, 0, 0};
+			const int k = sscanf(v.c_str(), "%llu:%llu,%llu:%llu", &x[0], &x[1], &x[2], &x[3]);
+			if (k != 2 && k != 4) err = "--shard-bytes needs a:b or a:b,a2:b2";
+			else { ex.shard_bytes = true; ex.n_ranges = k / 2; for (int j = 0; j < ex.n_ranges; j++) { ex.range_a[j] = x[2 * j]; ex.range_b[j] = x[2 * j + 1]; } }
+		}
+		else if (a == "--shard-first-read") ex.first_read = strtoull(need().c_str(), nullptr, 10);
+		else if (a == "--pg-cmdline") ex.pg_cmdline = need();
 		else if (a == "-D") { opt.max_dp_streak = atoi(need().c_str()); opt.set_D = true; }
 		else if (a == "-R") { opt.n_seed_rounds = atoi(need().c_str()); opt.set_R = true; }
 		else if (a == "-L") { opt.seed_len = atoi(need().c_str()); opt.set_L = true; if (opt.seed_len < 1 || opt.seed_len > 32) err = "-L argument must be in [1, 32]"; }
@@ -394,6 +413,11 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		// (-s/-u count within each source, as in the reference: every PatternSource numbers its own reads)
 		if (ex.shard_world > 1) return "--shard together with mixed paired and unpaired inputs is not supported by this build";
 		opt.mixed_unpaired = true;
+	}
+	if (ex.shard_bytes) {
+		if (opt.format != 0 || !opt.interleaved_file.empty() || opt.mixed_unpaired || opt.skip > 0 || opt.upto != std::numeric_limits<uint64_t>::max() || ex.shard_world > 1)
+			return "--shard-bytes is for plain FASTQ files given with -U or -1/-2, without -s/-u, --interleaved, mixed input or --shard";
+		if (ex.n_ranges != (opt.paired ? 2 : 1)) return "--shard-bytes needs one byte range per reads file";
 	}
 	if (opt.paired && !ex.allow_paired) return "paired-end input (-1/-2) is not enabled in this build of the device path yet";
 	if (opt.paired && opt.max_insert < opt.min_insert) return "-X must not be smaller than -I";

@@ -168,6 +168,16 @@ public:
 	}
 	~LineSource() { if (f_) gzclose(f_); }
 	bool ok() const { return f_ != nullptr; }
+	// Restrict the source to bytes [a, b) of its (single, uncompressed, seekable) file: what one rank of a byte-sharded run reads
+	// (--shard-bytes).  The caller vouches that `a` is the start of a line and that the line ending at b - 1 ends a record.
+	bool set_range(uint64_t a, uint64_t b, std::string& err) {
+		if (paths_.size() != 1 || paths_[0] == "-" || !f_) { err = "--shard-bytes needs one regular reads file per -U / -1 / -2"; return false; }
+		if (!gzdirect(f_)) { err = "--shard-bytes cannot be used with compressed input (" + paths_[0] + ")"; return false; }
+		if (b < a || gzseek(f_, (z_off_t)a, SEEK_SET) < 0) { err = "--shard-bytes: cannot seek in " + paths_[0]; return false; }
+		ranged_ = true; left_ = b - a; bytes_read_ = 0;
+		return true;
+	}
+	uint64_t bytes_read() const { return bytes_read_; }      // bytes taken from the file(s) so far
 	// next line without its terminator ('\n' or "\r\n"); false at end of input.  The view is valid until the next call.
 	bool next(const char*& p, size_t& n) {
 		for (;;) {
@@ -195,10 +205,13 @@ public:
 private:
 	void refill() {
 		if (pos_ > 0) { buf_.erase(0, pos_); pos_ = 0; }
-		const size_t old = buf_.size(), want = 8u << 20;
+		const size_t old = buf_.size();
+		size_t want = 8u << 20;
+		if (ranged_ && (uint64_t)want > left_) want = (size_t)left_;
 		buf_.resize(old + want);
-		int got = gzread(f_, &buf_[old], (unsigned)want);
+		int got = want ? gzread(f_, &buf_[old], (unsigned)want) : 0;
 		buf_.resize(old + (got > 0 ? (size_t)got : 0));
+		if (got > 0) { bytes_read_ += (uint64_t)got; if (ranged_) left_ -= (uint64_t)got; }
 		if (got < 0) io_error_ = true;          // corrupt / truncated .gz: the run must fail, not end early (the reference aborts too)
 		if (got <= 0) {
 			if (next_path_ < paths_.size()) {
@@ -219,6 +232,8 @@ private:
 	size_t next_path_ = 0;
 	bool unterminated_ = false;
 	bool io_error_ = false;
+	bool ranged_ = false;
+	uint64_t left_ = 0, bytes_read_ = 0;
 public:
 	bool last_line_unterminated() const { return unterminated_; }
 	bool io_error() const { return io_error_; }
@@ -294,6 +309,14 @@ public:
 		if (opt.format == 7) bam_ok_ = bam_.next_file(bam_err_);
 	}
 	bool ok() const { return opt_.format == 7 ? (bam_ok_ || bam_err_.empty()) : src_.ok(); }
+	// byte-sharded run: this source reads bytes [a, b) of its file, whose first record is read / pair number `first_read` of the input
+	bool set_range(uint64_t a, uint64_t b, uint64_t first_read, std::string& err) {
+		if (opt_.format != 0) { err = "--shard-bytes is for FASTQ input"; return false; }
+		if (!src_.set_range(a, b, err)) return false;
+		rdid_ = first_read * unit_;
+		return true;
+	}
+	uint64_t bytes_read() const { return src_.bytes_read(); }
 	// -b with -1/-2: which mate's records this source keeps (--align-paired-reads: flag 0x40 for mate 1, 0x80 for mate 2, pat.cpp:1422-1427)
 	void set_bam_mate(int m) { bam_mate_ = m; }
 	std::string open_error(const std::string& dflt) const { return bam_err_.empty() ? dflt : bam_err_; }

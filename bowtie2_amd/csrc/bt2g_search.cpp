@@ -82,6 +82,7 @@ static int run_search(int argc, char** argv) {
 		if (ex.help) { print_usage(argv[0]); return 0; }
 		if (!err.empty()) die(err, 1);
 	}
+	if (!ex.pg_cmdline.empty()) opt.cmdline = ex.pg_cmdline;
 	const bool metrics = ex.metrics;
 	unsigned long long n_flagged = 0;
 	if (opt.index_base.empty() || (opt.reads_file.empty() && !opt.paired)) die("usage: bowtie2-align-s [options] -x <index> {-U <reads.fq> | -1 <m1.fq> -2 <m2.fq>} [-S out.sam]");
@@ -132,6 +133,11 @@ static int run_search(int argc, char** argv) {
 	if (!fq.ok()) die(fq.open_error("cannot open reads file " + src1));
 	std::unique_ptr<FastqBatcher> fq2;
 	if (opt.paired && !inter) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die(fq2->open_error("cannot open reads file " + opt.mate2_file)); fq.set_bam_mate(1); fq2->set_bam_mate(2); }
+	if (ex.shard_bytes) {
+		std::string e;
+		if (!fq.set_range(ex.range_a[0], ex.range_b[0], ex.first_read, e)) die(e);
+		if (fq2 && !fq2->set_range(ex.range_a[1], ex.range_b[1], ex.first_read, e)) die(e);
+	}
 	// -U next to -1/-2: the unpaired reads follow the pairs (same reader thread, batches marked paired or not one by one)
 	std::unique_ptr<FastqBatcher> fq_unp;
 	if (opt.mixed_unpaired) { fq_unp.reset(new FastqBatcher(opt.reads_file, opt, host_threads)); if (!fq_unp->ok()) die("cannot open reads file " + opt.reads_file); }
@@ -298,6 +304,7 @@ static int run_search(int argc, char** argv) {
 		        (unsigned long long)psumm.conc_uni2, (unsigned long long)psumm.conc_rep, (unsigned long long)psumm.ndiscord, (unsigned long long)psumm.unp00,
 		        (unsigned long long)psumm.unp0_uni1, (unsigned long long)psumm.unp0_uni2, (unsigned long long)psumm.unp0_rep);
 		fprintf(shard_idx, "F %llu\n", n_flagged);
+		fprintf(shard_idx, "R %llu\n", (unsigned long long)(fq.bytes_read() + (fq2 ? fq2->bytes_read() : 0)));      // bytes of reads files this rank took in
 		fclose(shard_idx);
 	}
 	if (!opt.quiet && ex.shard_world == 1) { if (opt.mixed_unpaired) print_mixed_summary(stderr, psumm, summ, !opt.no_discordant, !opt.no_mixed); else if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198); sharded: rank 0 of the driver prints the merged summary

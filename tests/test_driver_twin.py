@@ -68,30 +68,126 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("inp", ["unpaired", "paired"])
-def test_sharded_ranks_through_the_driver(twin, inp, tmp_path):
-    """bowtie2_amd.mgpu, world size 2 on gloo, every rank running the product's driver (--shard r/N, --shard-index): the SAM rank 0
-    reassembles and the summary it sums equal the one-process run and the golden SAM"""
-    src = ["-U", FQ] if inp == "unpaired" else ["-1", M1, "-2", M2]
-    common = ["--sensitive", "--batch", "64", "-x", os.path.join(GOLD, "tiny_s")] + src
-    one = run(twin, common)
+def mgpu_run(twin, common, out, world, sharding=None, env_extra=None):
     port = free_port()
-    out = tmp_path / "merged.sam"
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    pre = ["--sharding", sharding] if sharding else []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", PYTHONPATH=ROOT)
-        procs.append(subprocess.Popen([sys.executable, "-m", "bowtie2_amd.mgpu", "--engine", twin, "--backend", "gloo", "--"] + common + ["-S", str(out)],
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, "-m", "bowtie2_amd.mgpu", "--engine", twin, "--backend", "gloo"] + pre + ["--"] + common + ["-S", str(out)],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     errs = []
     for p in procs:
         _, se = p.communicate(timeout=600)
         assert p.returncode == 0, se[-2000:]
         errs.append(se)
-    got = [l for l in open(out).read().splitlines() if not l.startswith("@PG")]
+    return errs
+
+
+@pytest.mark.parametrize("inp", ["unpaired", "paired"])
+@pytest.mark.parametrize("sharding,world", [("blocks", 2), ("bytes", 2), ("bytes", 3)])
+def test_sharded_ranks_through_the_driver(twin, inp, sharding, world, tmp_path):
+    """bowtie2_amd.mgpu on gloo, every rank running the product's driver.  blocks: --shard r/N, SAM pieces gathered over the process group.
+    bytes: --shard-bytes, every rank parses its own byte range of the reads file(s) only and the pieces concatenate.  Either way the merged
+    SAM and the summed summary equal the one-process run and the reference's golden SAM -- including the @PG line, which shows the user's
+    command line, not a rank's."""
+    src = ["-U", FQ] if inp == "unpaired" else ["-1", M1, "-2", M2]
+    common = ["--sensitive", "--batch", "64", "-x", os.path.join(GOLD, "tiny_s")] + src
+    one = run(twin, common)
+    out = tmp_path / "merged.sam"
+    errs = mgpu_run(twin, common, out, world, sharding, {"BT2G_MGPU_REPORT_BYTES": "1"})
+    text = open(out).read().splitlines()
+    got = [l for l in text if not l.startswith("@PG")]
     assert got == one[0] == golden("align_golden_s_sens.sam" if inp == "unpaired" else "pe_golden_s_sens.sam")
+    pg = [l for l in text if l.startswith("@PG")]
+    assert len(pg) == 1 and "--shard" not in pg[0] and "piece" not in pg[0] and " ".join(common) in pg[0]
     nsum = len(one[1])
-    assert [l for l in errs[0].strip().splitlines() if not l.startswith("Warning")][-nsum:] == one[1]
+    lines0 = [l for l in errs[0].strip().splitlines() if not l.startswith("Warning") and not l.startswith("[mgpu]")]
+    assert lines0[-nsum:] == one[1]
+    rep = [l for l in errs[0].splitlines() if l.startswith("[mgpu]")][0].split()
+    vals = dict(kv.split("=") for kv in rep[1:])
+    total = sum(os.path.getsize(p) for p in src[1::2])
+    if sharding == "bytes":
+        # no rank parses another rank's bytes: together they read the input once, each about 1/N of it
+        assert vals["sharding"] == "bytes" and int(vals["parsed_bytes_all"]) == total
+        assert abs(int(vals["parsed_bytes_this_rank"]) - total / world) < 0.02 * total + 2000
+    else:
+        assert vals["sharding"] == "blocks" and int(vals["parsed_bytes_all"]) == world * total       # the fallback reads everything on every rank
+
+
+def test_byte_sharding_falls_back_for_gzip_and_odd_files(twin, tmp_path):
+    """gzip'ed input, or a file that is not strict 4-line FASTQ (a blank line between records), cannot be cut by byte ranges: the ranks
+    agree on block mode and the output is still the one-process output"""
+    import gzip
+    gz = tmp_path / "reads.fq.gz"
+    with open(FQ, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    odd = tmp_path / "blank.fq"
+    lines = open(FQ).read().splitlines()
+    odd.write_text("\n".join(lines[:400]) + "\n\n" + "\n".join(lines[400:]) + "\n")
+    want = golden("align_golden_s_sens.sam")
+    for k, path in enumerate((gz, odd)):
+        common = ["--sensitive", "--batch", "64", "-x", os.path.join(GOLD, "tiny_s"), "-U", str(path)]
+        out = tmp_path / ("m%d.sam" % k)
+        errs = mgpu_run(twin, common, out, 2, None, {"BT2G_MGPU_REPORT_BYTES": "1"})
+        assert "sharding=blocks" in errs[0]
+        assert [l for l in open(out).read().splitlines() if not l.startswith("@PG")] == want
+
+
+def test_byte_ranges_partition_any_file(tmp_path):
+    """plan_byte_ranges on one process per 'rank' emulated in-process: for many rank counts the ranges tile the file, start on record
+    boundaries, agree between the two mate files on the record number, and tiny files with more ranks than records still work"""
+    sys.path.insert(0, ROOT)
+    from bowtie2_amd import mgpu
+    import random
+    rng = random.Random(7)
+    recs1, recs2 = [], []
+    for i in range(257):
+        L = rng.randint(1, 180)
+        nm = "r%d" % rng.randint(0, 10 ** rng.randint(1, 9))
+        recs1.append("@%s/1\n%s\n+\n%s\n" % (nm, "A" * L, "@" * L))          # quality lines that start with '@'
+        L2 = rng.randint(1, 180)
+        recs2.append("@%s/2 extra words\n%s\n+%s\n%s\n" % (nm, "C" * L2, nm, "+" * L2))
+    f1, f2 = tmp_path / "a.fq", tmp_path / "b.fq"
+    f1.write_text("".join(recs1)); f2.write_text("".join(recs2)[:-1])             # the second file ends without a newline
+    off1 = [0]; off2 = [0]
+    for a, b in zip(recs1, recs2):
+        off1.append(off1[-1] + len(a)); off2.append(off2[-1] + len(b))
+    off2[-1] -= 1
+
+    class FakeDist:       # all_gather over ranks emulated by computing every rank's contribution in this process
+        def __init__(self, files, world):
+            self.files, self.world = files, world
+        def all_gather(self, outs, t):
+            import torch
+            for q in range(self.world):
+                sizes = [os.path.getsize(p) for p in self.files]
+                vals = [mgpu.count_newlines(p, sz * q // self.world, sz * (q + 1) // self.world) for p, sz in zip(self.files, sizes)]
+                tails = []
+                for p, sz in zip(self.files, sizes):
+                    tl = 0
+                    if q == self.world - 1 and sz > 0:
+                        with open(p, "rb") as f:
+                            f.seek(sz - 1); tl = 0 if f.read(1) == b"\n" else 1
+                    tails.append(tl)
+                outs[q].copy_(torch.tensor(vals + tails, dtype=torch.int64))
+    import torch
+    for files, offs in (([str(f1)], [off1]), ([str(f1), str(f2)], [off1, off2])):
+        for world in (1, 2, 3, 7, 64, 300):
+            prev_end = [0] * len(files)
+            nxt = 0
+            for rank in range(world):
+                plan = mgpu.plan_byte_ranges(FakeDist(files, world), files, rank, world, torch.device("cpu"))
+                assert plan is not None
+                ranges, first, count = plan
+                assert first == nxt
+                for k, (a, b) in enumerate(ranges):
+                    assert a == prev_end[k] and a == offs[k][first] and b == offs[k][first + count]
+                    prev_end[k] = b
+                nxt = first + count
+            assert nxt == 257 and prev_end == [o[-1] for o in offs]
 
 
 def test_two_device_contexts_keep_input_order(twin):

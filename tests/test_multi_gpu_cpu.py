@@ -129,7 +129,7 @@ def test_sharded_driver_two_ranks_sam_identical(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", PYTHONPATH=ROOT)
-        procs.append(subprocess.Popen([sys.executable, "-m", "bowtie2_amd.mgpu", "--engine", hs, "--backend", "gloo", "--"] + common + ["-S", str(out)],
+        procs.append(subprocess.Popen([sys.executable, "-m", "bowtie2_amd.mgpu", "--engine", hs, "--backend", "gloo", "--sharding", "blocks", "--"] + common + ["-S", str(out)],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     errs = []
     for p in procs:
