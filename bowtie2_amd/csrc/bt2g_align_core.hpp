@@ -1319,7 +1319,8 @@ struct Aligner {
 		// one backtrace from cell (row, col), whose tile the caller fetched
 		auto walk = [&](uint32_t row, uint32_t col, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi) __attribute__((always_inline)) -> bool {
 			row = Plat::uni(row); col = Plat::uni(col);
-			uint32_t td = 0;     // td = steps taken along the tile's diagonal
+			uint32_t td = 0;     // td = steps taken along the tile
+			uint32_t tdir = 0, ndir = 0;      // pred format: direction of the tile in hand / of the next fetch (0 diagonal, 1 left along the row, 2 up the column)
 			const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
 			int olap = 0;        // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
 			auto in_core = [&](uint32_t r_, uint32_t c_) -> int {
@@ -1338,7 +1339,7 @@ struct Aligner {
 			auto fl = [&](int v) -> bool { return !local || v > 0; };     // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
 			HOT.n_bt_attempts++;
 			while ((int)row >= 0) {
-				if (pred && ct == 0 && td < tile_len && row > 0) {
+				if (pred && ct == 0 && tdir == 0 && td < tile_len && row > 0) {
 					// a run of plain diagonal steps (unvisited cells whose only consistent predecessor is the diagonal one) is walked
 					// by all lanes at once: same marks, same edits, same counters as the step-by-step loop below
 					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
@@ -1372,7 +1373,7 @@ struct Aligner {
 				prof.steps++; prof.scalar_steps++;
 				if (td >= tile_len) {
 					const uint64_t tt_ = now();
-					if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
+					if (pred) { Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, ndir, tile, tile_hi); tdir = ndir; } else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
 					td = 0; prof.tiles++; prof.tile_t += now() - tt_;
 				}
 				const uint32_t mk0 = pred ? Plat::lane(tile_hi, td) : (Plat::lane(tile, 48 + td) & 0xffffu);
@@ -1466,7 +1467,7 @@ struct Aligner {
 				}
 				if (!can_move_thru) {
 					if (nstack > 0) {
-						td = tile_len;           // resume elsewhere: the tile is stale
+						td = tile_len; ndir = 0;     // resume elsewhere: the tile is stale
 						const BtFrame& f = btstack[--nstack];
 						const uint32_t cz_ = Plat::uni(f.celsz);
 						ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31); nned = Plat::uni(f.nedsz);
@@ -1505,15 +1506,16 @@ struct Aligner {
 						}
 						if (m == -1) ns++;
 						row--; col--;
-						td++;
+						if (pred && tdir != 0) { td = tile_len; ndir = 0; } else td++;
 						break;
 					}
 					case 1: case 2: {   // ref gap (move up): open from H / extend from F
 						Edit& e = ned[nned++];
 						e.pos = (uint16_t)row; e.chr = '-'; e.qchr = code2chr(readc); e.type = EDIT_REF_GAP;
 						row--;
-						td = tile_len;
 						ct = (cur == 1) ? 0 : 2;
+						// inside a reference gap (F state: the next move is up again) one tile runs up the column for the whole gap
+						if (pred && ct == 2 && tdir == 2) td++; else { td = tile_len; ndir = (pred && ct == 2) ? 2u : 0u; }
 						score -= (cur == 1) ? S.rfgapo : S.rfgape;
 						gaps++; ref_gaps++;
 						break;
@@ -1522,8 +1524,9 @@ struct Aligner {
 						Edit& e = ned[nned++];
 						e.pos = (uint16_t)(row + 1); e.chr = (uint8_t)mask2chr(refm); e.qchr = '-'; e.type = EDIT_READ_GAP;
 						col--;
-						td = tile_len;
 						ct = (cur == 3) ? 0 : 1;
+						// inside a read gap (E state: the next move is left again) one tile runs left along the row
+						if (pred && ct == 1 && tdir == 1) td++; else { td = tile_len; ndir = (pred && ct == 1) ? 1u : 0u; }
 						score -= (cur == 3) ? S.rdgapo : S.rdgape;
 						gaps++; read_gaps++;
 						break;
@@ -1559,8 +1562,18 @@ struct Aligner {
 	
 		};
 		bool found = false;
+		// end-to-end: the next 64 candidates wait in lane registers (one gather instead of one dependent load per candidate)
+		typename Plat::LaneReg cw0, cw1;
+		uint32_t cbase = 0xffffff00u;
 		while (HOT.cural < HOT.n_cands) {
-			BtCand c = gld(&cands[HOT.cural]);
+			BtCand c;
+			if (MODE != 2) {
+				const uint32_t ci = HOT.cural;
+				if (ci - cbase >= 64u) { cbase = ci; Plat::lanes_load_cands(cands, cbase, HOT.n_cands, cw0, cw1); }
+				c.score = (int32_t)Plat::lane(cw0, ci - cbase);
+				const uint32_t rc_ = Plat::lane(cw1, ci - cbase);
+				c.row = (uint16_t)(rc_ & 0xffffu); c.col = (uint16_t)(rc_ >> 16);
+			} else c = gld(&cands[HOT.cural]);
 			if (MODE == 2) c.score &= ~kCandDone;
 			if (c.score < minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
 			if (MODE == 2) {
@@ -1579,7 +1592,7 @@ struct Aligner {
 			typename Plat::LaneReg tile, tile_hi;
 			{
 				const uint64_t tt_ = now();      // also the first tile of the backtrace
-				if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, c.row, c.col, epoch, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, c.row, c.col, wide, tile, tile_hi);
+				if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, c.row, c.col, epoch, 0u, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, c.row, c.col, wide, tile, tile_hi);
 				prof.tiles++; prof.tile_t += now() - tt_;
 			}
 			if ((pred ? Plat::lane(tile_hi, 0) : Plat::lane(tile, 48)) & 1) { HOT.cural++; continue; }

@@ -485,16 +485,19 @@ struct DevPlat {
 		wave_fence();
 	}
 	static __device__ __forceinline__ void set_epoch(uint32_t* p, uint32_t e) { if ((threadIdx.x & 63) == 0) *p = e; wave_fence(); }
-	// Tile of the pred format anchored at (row, col): lane d <- predecessor byte and (epoch-checked) mask of cell (row-d, col-d).
-	// One gather per plane: a single memory latency for up to 64 diagonal steps.
-	static __device__ __forceinline__ void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch,
+	// Tile of the pred format anchored at (row, col): lane d <- predecessor byte and (epoch-checked) mask of the d-th cell from there in
+	// direction `dir`: 0 = up the diagonal (row-d, col-d), 1 = left along the row (row, col-d), 2 = up the column (row-d, col).
+	// One gather per plane: a single memory latency for up to 64 steps of a diagonal run -- or of a gap (the candidates next to an
+	// alignment's end column all walk a gap of growing length back to its path; a tile per gap, not per gap position).
+	static __device__ __forceinline__ void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, uint32_t dir,
 	                                                    uint32_t& pr, uint32_t& mk) {
 		wave_fence();        // mask stores of earlier steps -> visible to whichever lane re-reads them
 		const uint32_t d = threadIdx.x & 63;
 		uint32_t p = 0, m = 0;
-		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo);      // the tile runs along one diagonal
-		if (d <= row && d <= col && dd < band_w) {
-			const uint64_t idx = (uint64_t)(row - d) * band_w + dd;
+		const uint32_t dr = dir == 1 ? 0u : d, dc = dir == 2 ? 0u : d;
+		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo) + dr - dc;      // diagonal of the lane's cell (wraps past the band's edge)
+		if (dr <= row && dc <= col && dd < band_w) {
+			const uint64_t idx = (uint64_t)(row - dr) * band_w + dd;
 			p = gld(reinterpret_cast<const uint8_t*>(dp.mat) + idx);
 			const uint32_t w = gld(dp.pmask + idx);
 			m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
@@ -692,6 +695,13 @@ struct DevPlat {
 	static __device__ __forceinline__ LaneReg lanes_load(const uint8_t* base, uint32_t nbytes, uint32_t word0) {
 		const uint32_t wd = word0 + (threadIdx.x & 63);
 		return (wd * 4 + 4 <= nbytes) ? *reinterpret_cast<const uint32_t*>(base + wd * 4) : 0u;
+	}
+	// lane i <- candidate base + i (score; row | col << 16), 0 past the end of the list
+	static __device__ __forceinline__ void lanes_load_cands(const BtCand* cands, uint32_t base, uint32_t n, LaneReg& w0, LaneReg& w1) {
+		const uint32_t i = base + (threadIdx.x & 63);
+		uint32_t a = 0, b = 0;
+		if (i < n) { const uint32_t* p = reinterpret_cast<const uint32_t*>(cands + i); a = gld(p); b = gld(p + 1); }
+		w0 = a; w1 = b;
 	}
 	// Backtrace tile anchored at (row, col): lanes 0-15 cell(row-d, col-d), 16-31 cell(row-d-1, col-d),
 	// 32-47 cell(row-d, col-d-1), 48-63 mask(row-d, col-d); one load instruction per array, one latency.

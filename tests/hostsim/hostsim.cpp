@@ -101,6 +101,13 @@ struct HostPlat {
 		}
 		return r;
 	}
+	static void lanes_load_cands(const BtCand* cands, uint32_t base, uint32_t n, LaneReg& w0, LaneReg& w1) {
+		for (uint32_t l = 0; l < 64; l++) {
+			const uint32_t i = base + l;
+			w0.v[l] = i < n ? (uint32_t)cands[i].score : 0u;
+			w1.v[l] = i < n ? ((uint32_t)cands[i].row | ((uint32_t)cands[i].col << 16)) : 0u;
+		}
+	}
 	static void bt_tile(const DpScratch& dp, uint32_t R, uint32_t cols, uint32_t row, uint32_t col, bool wide, LaneReg& lo, LaneReg& hi) {
 		for (uint32_t ln = 0; ln < 64; ln++) {
 			const uint32_t d = ln & 15, g = ln >> 4;
@@ -181,12 +188,13 @@ struct HostPlat {
 		}
 		return L;
 	}
-	static void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, LaneReg& pr, LaneReg& mk) {
-		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo);
+	static void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, uint32_t dir, LaneReg& pr, LaneReg& mk) {
 		for (uint32_t d = 0; d < 64; d++) {
 			uint32_t p = 0, m = 0;
-			if (d <= row && d <= col && dd < band_w) {
-				const uint64_t idx = pred_idx(band_lo, band_w, row - d, col - d);
+			const uint32_t dr = dir == 1 ? 0u : d, dc = dir == 2 ? 0u : d;
+			const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo) + dr - dc;
+			if (dr <= row && dc <= col && dd < band_w) {
+				const uint64_t idx = pred_idx(band_lo, band_w, row - dr, col - dc);
 				p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
 				const uint32_t w = dp.pmask[idx];
 				m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
