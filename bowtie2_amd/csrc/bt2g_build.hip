@@ -83,6 +83,7 @@ struct DevBk {
 #endif
 	}
 	static std::string& last_error() { static std::string e; return e; }
+	static const std::string& error() { return last_error(); }      // first device / allocation error since the build started ("" = none)
 private:
 	template <class In, typename T> static uint64_t select_impl(In in, const uint8_t* f, T* out, uint64_t n) {
 		if (n == 0) return 0;
@@ -99,7 +100,14 @@ private:
 	// temporary storage of the rocPRIM calls: one buffer, grown on demand, kept for the life of the process
 	static void* scratch(size_t bytes) {
 		static void* p = nullptr; static size_t cap = 0;
-		if (bytes > cap) { if (p) (void)hipFree(p); p = nullptr; cap = 0; if (hipMalloc(&p, bytes + 256) == hipSuccess) cap = bytes + 256; else last_error() = "out of device memory (rocPRIM scratch)"; }
+		if (bytes > cap) {
+			if (p) (void)hipFree(p);
+			p = nullptr; cap = 0;
+			if (hipMalloc(&p, bytes + 256) == hipSuccess) cap = bytes + 256;
+			else { p = nullptr; if (last_error().empty()) last_error() = "out of device memory (rocPRIM scratch)"; }
+		}
+		// (with a null pointer rocPRIM would read the call as a size query and return success without doing any work: the error latched
+		// above makes build_index_files stop before anything derived from that non-result reaches a file)
 		return p;
 	}
 	static void* scratch_small() { static void* p = nullptr; if (!p) (void)hipMalloc(&p, 256); return p; }
@@ -144,8 +152,9 @@ int bt2g_index_build(const char* const* fasta_paths, uint32_t n_paths, const cha
 	for (uint32_t i = 0; i < n_paths; i++) {
 		GzSource src(fasta_paths[i]);
 		if (!src.ok()) return BT2G_ERR_IO;
-		if (src.at_end()) continue;
+		if (src.at_end()) { if (src.io_error()) return BT2G_ERR_IO; continue; }
 		if (!scan_fasta(src, in, seqs, err)) return BT2G_ERR_FORMAT;
+		if (src.io_error()) { fprintf(stderr, "bt2g_index_build: reading %s failed (corrupt or truncated compressed file?)\n", fasta_paths[i]); return BT2G_ERR_IO; }
 	}
 	return run_build(in, out_base, bp, wall_now() - t0, stats);
 }

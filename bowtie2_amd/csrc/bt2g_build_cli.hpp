@@ -87,9 +87,13 @@ inline bool read_build_input(const CliOpts& o, RefInput& in, std::string& err) {
 	for (const std::string& p : items) {
 		GzSource src(p);
 		if (!src.ok()) { err = "Error: could not open " + p; return false; }
-		if (src.at_end()) { std::cerr << "Warning: Empty fasta file: '" << p << "'" << std::endl; continue; }
+		if (src.at_end()) {
+			if (src.io_error()) { err = "Error: reading " + p + " failed (corrupt or truncated compressed file?); no index written"; return false; }
+			std::cerr << "Warning: Empty fasta file: '" << p << "'" << std::endl; continue;
+		}
 		any = true;
 		if (!scan_fasta(src, in, seqs, err)) return false;
+		if (src.io_error()) { err = "Error: reading " + p + " failed (corrupt or truncated compressed file?); no index written"; return false; }
 	}
 	if (!any) { err = "Warning: All fasta inputs were empty"; return false; }
 	return true;

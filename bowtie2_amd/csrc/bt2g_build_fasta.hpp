@@ -52,6 +52,9 @@ public:
 	// bulk access for the base-reading loop: the bytes buffered right now (0 at the end of input), and a way to consume them
 	size_t window(const uint8_t*& p) { if (cur_ == n_ && !fill()) return 0; p = buf_ + cur_; return n_ - cur_; }
 	void advance(size_t k) { cur_ += k; }
+	// the input ended because reading failed (corrupt or truncated compressed file), not because it was read to its end: the
+	// caller must not build an index of what happened to come through
+	virtual bool io_error() const { return false; }
 protected:
 	virtual size_t read_some(uint8_t* dst, size_t cap) = 0;
 private:
@@ -65,10 +68,20 @@ public:
 	explicit GzSource(const std::string& p) { f_ = gzopen(p.c_str(), "rb"); if (f_) gzbuffer(f_, 1 << 20); }
 	~GzSource() override { if (f_) gzclose(f_); }
 	bool ok() const { return f_ != nullptr; }
+	bool io_error() const override { return io_error_; }
 protected:
-	size_t read_some(uint8_t* dst, size_t cap) override { const int n = gzread(f_, dst, (unsigned)cap); return n > 0 ? (size_t)n : 0; }
+	size_t read_some(uint8_t* dst, size_t cap) override {
+		const int n = gzread(f_, dst, (unsigned)cap);
+		if (n > 0) return (size_t)n;
+		// 0 = end of input, but zlib also returns 0 for a gzip stream that stops short (Z_BUF_ERROR); < 0 = corrupt data
+		int zerr = Z_OK;
+		(void)gzerror(f_, &zerr);
+		if (n < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) io_error_ = true;
+		return 0;
+	}
 private:
 	gzFile f_ = nullptr;
+	bool io_error_ = false;
 };
 class MemSource : public ByteSource {      // -c sequences and in-memory genomes: ">name\nSEQ\n" per entry
 public:

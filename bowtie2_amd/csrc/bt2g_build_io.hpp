@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <unistd.h>
 #include <vector>
 
 namespace bt2g { namespace build {
@@ -99,10 +100,26 @@ bool build_index_files(const RefInput& in, const std::string& out_base, const Pa
 	if (len > max_len) { err = "Error: Reference sequence has more than 2^32-1 characters!  Please build a large index instead (bowtie2-build-l)."; return false; }
 	const std::string ext = P.off_size == 4 ? "bt2" : "bt2l";
 	st.len = len;
+	// Every file is written under a temporary name and gets its real name only when the whole build has succeeded: a build that fails
+	// half way (device error, out of memory, full disk) leaves no index files behind, complete-looking or not.
+	struct Outputs {
+		std::vector<std::pair<std::string, std::string>> files;      // (temporary, final)
+		bool committed = false;
+		std::string tmp(const std::string& final_name) { files.emplace_back(final_name + ".tmp" + std::to_string((long)getpid()), final_name); return files.back().first; }
+		bool commit(std::string& err) {
+			for (auto& f : files) if (rename(f.first.c_str(), f.second.c_str()) != 0) { err = "Could not move index file into place: \"" + f.second + "\""; return false; }
+			committed = true;
+			return true;
+		}
+		~Outputs() { if (!committed) for (auto& f : files) { (void)remove(f.first.c_str()); } }
+	} outs;
 	double t0 = now();
-	if (P.write_ref && !write_ref_files(out_base + ".3." + ext, out_base + ".4." + ext, P.off_size, in, err)) return false;
+	if (P.write_ref) {
+		const std::string t3 = outs.tmp(out_base + ".3." + ext), t4 = outs.tmp(out_base + ".4." + ext);
+		if (!write_ref_files(t3, t4, P.off_size, in, err)) return false;
+	}
 	st.t_write += now() - t0;
-	if (P.just_ref) return true;
+	if (P.just_ref) return outs.commit(err);
 	std::vector<RefRec> rrecs;
 	reverse_records(in.recs, rrecs);
 	JoinInfo ji_fw, ji_bw;
@@ -115,16 +132,19 @@ bool build_index_files(const RefInput& in, const std::string& out_base, const Pa
 			EbwtImage im;
 			t0 = now();
 			if (!builder.build(dir == 1, im)) { err = builder.err; builder.release_text(); return false; }
+			// a primitive of the backend failed somewhere on the way (the builder's own checks cannot see a kernel or copy that did nothing)
+			if (!Bk::error().empty()) { err = "index build failed: " + Bk::error(); builder.release_text(); return false; }
 			(dir ? st.t_bw : st.t_fw) = now() - t0;
 			(dir ? st.rounds_bw : st.rounds_fw) = im.rounds;
 			(dir ? st.tied_bw : st.tied_fw) = im.tied_after_first;
 			t0 = now();
 			const std::string b = dir ? out_base + ".rev" : out_base;
-			if (!write_ebwt_files(b + ".1." + ext, b + ".2." + ext, P, dir == 1, len, dir ? ji_bw : ji_fw, im, in.names, err)) { builder.release_text(); return false; }
+			const std::string t1 = outs.tmp(b + ".1." + ext), t2 = outs.tmp(b + ".2." + ext);
+			if (!write_ebwt_files(t1, t2, P, dir == 1, len, dir ? ji_bw : ji_fw, im, in.names, err)) { builder.release_text(); return false; }
 			st.t_write += now() - t0;
 		}
 		builder.release_text();
-		return true;
+		return outs.commit(err);
 	};
 	// 32-bit text positions while they fit (BT2G_BUILD_FORCE_IDX64: test hook for the 64-bit path on small inputs)
 	if (len < 0xfffffffeull && !getenv("BT2G_BUILD_FORCE_IDX64")) { Builder<Bk, uint32_t> b(P); return run(b); }

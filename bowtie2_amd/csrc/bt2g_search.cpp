@@ -307,7 +307,7 @@ static int run_search(int argc, char** argv) {
 		fprintf(shard_idx, "R %llu\n", (unsigned long long)(fq.bytes_read() + (fq2 ? fq2->bytes_read() : 0)));      // bytes of reads files this rank took in
 		fclose(shard_idx);
 	}
-	if (!opt.quiet && ex.shard_world == 1) { if (opt.mixed_unpaired) print_mixed_summary(stderr, psumm, summ, !opt.no_discordant, !opt.no_mixed); else if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198); sharded: rank 0 of the driver prints the merged summary
+	if (!opt.quiet && ex.shard_world == 1 && !ex.shard_bytes) { if (opt.mixed_unpaired) print_mixed_summary(stderr, psumm, summ, !opt.no_discordant, !opt.no_mixed); else if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198); sharded: rank 0 of the driver prints the merged summary
 	for (bt2g_ctx* c : ctxs) bt2g_ctx_destroy(c);
 	if (n_flagged) {
 		// never pass off a capacity-limited result as the reference's

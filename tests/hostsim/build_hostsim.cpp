@@ -15,6 +15,7 @@ namespace {
 
 struct HostBk {
 	static const char* name() { return "host twin"; }
+	static const std::string& error() { static const std::string none; return none; }
 	static bool init(int, std::string&) { return true; }
 	template <typename T> static T* alloc(uint64_t n) { return static_cast<T*>(malloc((n ? n : 1) * sizeof(T))); }
 	static void release(void* p) { free(p); }

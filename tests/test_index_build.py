@@ -128,6 +128,35 @@ def test_rejects_bad_input(build_hostsim, tmp_path):
     assert subprocess.run([build_hostsim, "-q", str(q), str(tmp_path / "y")], capture_output=True).returncode != 0
 
 
+def test_failed_build_leaves_no_index_files(build_hostsim, tmp_path):
+    """a gzip'ed FASTA cut short (or corrupted) must fail the build before anything is written -- it used to end the input early and
+    produce an index of the truncated genome with exit status 0; and a build that fails for any reason leaves no files behind
+    (every file is written under a temporary name and renamed when the whole build has succeeded)"""
+    import glob
+    import gzip
+    import random
+    rng = random.Random(3)
+    fa = ">chr1\n" + "\n".join("".join(rng.choice("ACGT") for _ in range(60)) for _ in range(4000)) + "\n"
+    whole = tmp_path / "g.fa.gz"
+    with gzip.open(whole, "wb") as g:
+        g.write(fa.encode())
+    data = whole.read_bytes()
+    cut = tmp_path / "cut.fa.gz"
+    cut.write_bytes(data[:len(data) // 2])
+    bad = tmp_path / "bad.fa.gz"
+    bad.write_bytes(data[:3000] + bytes(64) + data[3064:])
+    ok = subprocess.run([build_hostsim, "-q", str(whole), str(tmp_path / "ok")], capture_output=True, text=True)
+    assert ok.returncode == 0 and len(glob.glob(str(tmp_path / "ok.*"))) == 6
+    for k, f in enumerate((cut, bad)):
+        r = subprocess.run([build_hostsim, "-q", str(f), str(tmp_path / ("x%d" % k))], capture_output=True, text=True)
+        assert r.returncode != 0 and "corrupt or truncated" in r.stderr, r.stderr[-300:]
+        assert glob.glob(str(tmp_path / ("x%d.*" % k))) == []
+    # an output directory that does not exist: the failure comes when the first file is opened; nothing is left anywhere
+    r = subprocess.run([build_hostsim, "-q", str(whole), str(tmp_path / "nodir" / "y")], capture_output=True, text=True)
+    assert r.returncode != 0
+    assert not os.path.exists(tmp_path / "nodir")
+
+
 # ------------------------------------------------------------------ GPU ----
 BIN_S = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-build-s")
 BIN_L = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-build-l")
