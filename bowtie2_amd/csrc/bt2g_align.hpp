@@ -354,6 +354,32 @@ BT2_HD uint64_t pred_idx(int32_t lo, uint32_t w, uint32_t i, uint32_t j) { retur
 // bytes of the widest band a rows x cols problem can have (every diagonal of the rectangle)
 BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { uint32_t rp = ee_band_rp(rows + cols); if (rp == 0) rp = 16; return (uint64_t)rows * rp * 128; }
 
+// The worker's own state (what used to be the data members of Aligner).  On the device ONE instance per wavefront lives in LDS and is
+// reached by name (Plat::st()), never through a pointer: see the note at ST in bt2g_align_core.hpp.
+struct AlState {
+	Work*     wp;            // the wave's work area in HBM
+	DpScratch dp;            // the DP scratch in use (pairs: dp_main or dp_opp)
+	Rng       rnd;
+	int64_t   minsc;         // current (possibly tightened) minimum score
+	uint32_t  ridx;          // index of this read in the batch
+	bool      ext_pre;       // HOT.hits came from pre->seeds, so pre->ext holds their extensions
+	const uint32_t* pre_ext_cur;      // extension / resolved-offset tables of the seed round in HOT.hits
+	const uint64_t* pre_joff_cur;
+	uint32_t  pf_steps, pf_tiles;     // profile: backtrace steps / tile fetches of this read
+	uint64_t  pf_tile_t;
+	uint8_t   m_nofw, m_norc;         // --nofw / --norc as they apply to the loaded read (mate 2 of an --fr pair sees them swapped)
+	// ---- pairs (bt2g_align_pe.inc); inputs set by the launcher before run_pair ----
+	const uint8_t* pe_seq[2];
+	const uint8_t* pe_qual[2];
+	uint32_t  pe_len[2];
+	ReadParams pe_rp[2];
+	int64_t   pe_minsc[2];
+	DpScratch dp_main, dp_opp;        // anchor / opposite-mate matrices (dp selects the one in use)
+	BtCand*   cands_cur;              // candidate list in use (Work::cands, or Work::cands2 during an opposite-mate DP)
+	uint32_t  pe_streak;
+	uint32_t  pe_pair;                // index of the pair in the batch (reads 2*pe_pair, 2*pe_pair + 1)
+};
+
 // ---------------------------------------------------------------------------------------
 // small helpers
 BT2_HD int comp4(int c) { return c < 4 ? 3 - c : 4; }

@@ -24,23 +24,19 @@ struct Aligner {
 #define PRE (Plat::pre())                         // const PreComp*: batch pre-computation (may be null)
 	BT2_HD static uint64_t now() { return PRM.profile ? Plat::clock() : 0ull; }      // phase timers only when asked for (bt2g_align_params::profile)
 
-	Work& w;
-	DpScratch dp;
-	Rng rnd;
-	int64_t minsc;       // current (possibly tightened) minimum score
+	// The worker's own state -- RNG, current minimum score, DP scratch pointers, pair inputs ... (struct AlState, bt2g_align.hpp) -- is an
+	// object in LDS the platform hands out by name (ST), like HOT and the parameter blocks: as members of this class they were reached
+	// through `this`, a generic pointer, i.e. by FLAT loads whose wait also drains every global store in flight.  The per-wave work
+	// area in HBM is reached through WK.  The class itself has no data members.
+#define ST (Plat::st())
+#define WK (Plat::work())
 	static constexpr TOff kOffMask = (TOff)OffTraits<TOff>::kMask;
 
-	uint32_t ridx;       // index of this read in the batch
-	bool ext_pre;        // HOT.hits came from pre->seeds, so pre->ext holds their extensions
-	const uint32_t* pre_ext_cur = nullptr;    // extension / resolved-offset tables of the seed round in HOT.hits
-	const uint64_t* pre_joff_cur = nullptr;
-	uint32_t pf_steps = 0, pf_tiles = 0;   // profile: backtrace steps / tile fetches of this read
-	uint64_t pf_tile_t = 0;
-
-	uint8_t m_nofw, m_norc;   // --nofw / --norc as they apply to the loaded read (mate 2 of an --fr pair sees them swapped)
-
-	BT2_HD Aligner(Work& w_, DpScratch dp_, uint32_t ridx_ = 0)
-		: w(w_), dp(dp_), ridx(ridx_), ext_pre(false), m_nofw(PRM.nofw != 0), m_norc(PRM.norc != 0), cands_cur(w_.cands) {}
+	BT2_HD Aligner(Work& w_, DpScratch dp_, uint32_t ridx_ = 0) {
+		ST.wp = &w_; ST.dp = dp_; ST.ridx = ridx_; ST.ext_pre = false; ST.pre_ext_cur = nullptr; ST.pre_joff_cur = nullptr;
+		ST.pf_steps = ST.pf_tiles = 0; ST.pf_tile_t = 0;
+		ST.m_nofw = PRM.nofw != 0; ST.m_norc = PRM.norc != 0; ST.cands_cur = w_.cands;
+	}
 
 	// a fixed-capacity buffer is full: flag the read (its result is not passed off as the reference's) and remember which site
 	// noticed first (result record field pad2: diagnostics only)
@@ -48,7 +44,7 @@ struct Aligner {
 
 	// exact_sweep() from the batch kernel's output
 	BT2_HD uint64_t exact_sweep_pre(uint32_t mine[2]) {
-		const bt2g_sweep_out& s = PRE->sweep[ridx];
+		const bt2g_sweep_out& s = PRE->sweep[ST.ridx];
 		uint64_t nelt = 0;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			mine[fwi] = s.mine[fwi];
@@ -65,15 +61,15 @@ struct Aligner {
 
 	// one_mm_search() from the batch kernel's output; false if a list overflowed
 	BT2_HD bool one_mm_pre(bool nofw, bool norc) {
-		const uint8_t* n = PRE->mm1_n + (uint64_t)ridx * 4;
+		const uint8_t* n = PRE->mm1_n + (uint64_t)ST.ridx * 4;
 		if ((!nofw && (n[0] == 255 || n[1] == 255)) || (!norc && (n[2] == 255 || n[3] == 255))) return false;
 		HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 		for (int k = 0; k < 4; k++) {
 			const bool fw = k < 2;
 			if ((fw && nofw) || (!fw && norc)) continue;
-			const Mm1Hit* src = PRE->mm1 + ((uint64_t)ridx * 4 + k) * PRE->mm1_cap;
+			const Mm1Hit* src = PRE->mm1 + ((uint64_t)ST.ridx * 4 + k) * PRE->mm1_cap;
 			// the batch kernel searched with the read's original minimum score; the worker's may have been tightened since
-			for (uint32_t i = 0; i < n[k]; i++) if ((int64_t)src[i].score >= minsc) add_mm1(src[i], fw);
+			for (uint32_t i = 0; i < n[k]; i++) if ((int64_t)src[i].score >= ST.minsc) add_mm1(src[i], fw);
 		}
 		return true;
 	}
@@ -89,8 +85,8 @@ struct Aligner {
 		HOT.n_rank = 0;
 		for (uint32_t i = 0; i < nseeds; i++) HOT.off_idx2off[i] = interval * i + offset;
 		{
-			const bt2g_seed_hit* src = src_all + (uint64_t)ridx * 2 * PRE->max_seeds;
-			Plat::load_seed_hits(src, src + PRE->max_seeds, nseeds, m_nofw != 0, m_norc != 0);
+			const bt2g_seed_hit* src = src_all + (uint64_t)ST.ridx * 2 * PRE->max_seeds;
+			Plat::load_seed_hits(src, src + PRE->max_seeds, nseeds, ST.m_nofw != 0, ST.m_norc != 0);
 		}
 		cache_filter(interval, offset, seedlen);
 		return 1;   // # instantiated seeds only matters when no seed hit (run() ends the read either way)
@@ -116,7 +112,7 @@ struct Aligner {
 		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
-			if ((fw && m_nofw) || (!fw && m_norc)) continue;
+			if ((fw && ST.m_nofw) || (!fw && ST.m_norc)) continue;
 			for (uint32_t i = 0; i < HOT.num_offs; i++) {
 				HotHit& h = HOT.hits[fwi][i];
 				const uint32_t depth = i * interval + offset;
@@ -124,18 +120,18 @@ struct Aligner {
 				bool inst = L <= 32;      // (-L > 32 cannot occur)
 				const uint64_t key = inst ? Plat::seed_key(fw, depth, L, inst) : 0;
 				if (!inst) { h.size = h.esize = 0; continue; }
-				const uint32_t e = Plat::find_key(w.ck_key, w.ck_len, c.nkeys, key, (uint8_t)L);
+				const uint32_t e = Plat::find_key(WK.ck_key, WK.ck_len, c.nkeys, key, (uint8_t)L);
 				bool drop = false;
 				// beginAlign: the seed sequence enters the QKey map
-				if (e == c.nkeys || !(w.ck_flags[e] & 1)) {
+				if (e == c.nkeys || !(WK.ck_flags[e] & 1)) {
 					if (c.qn % q_per == 0 && !cache_page()) drop = true;
 					else {
 						c.qn++;
 						if (e == c.nkeys) {
 							if (c.nkeys >= (uint32_t)kCacheKeys) { ovf(30); h.size = h.esize = 0; continue; }
-							w.ck_key[e] = key; w.ck_len[e] = (uint8_t)L; w.ck_flags[e] = 0; w.ck_eff[e] = 0; c.nkeys++;
+							WK.ck_key[e] = key; WK.ck_len[e] = (uint8_t)L; WK.ck_flags[e] = 0; WK.ck_eff[e] = 0; c.nkeys++;
 						}
-						w.ck_flags[e] |= 1;
+						WK.ck_flags[e] |= 1;
 					}
 				}
 				if (!drop && h.size > 0) {
@@ -143,19 +139,19 @@ struct Aligner {
 					if (c.ql % ql_per == 0 && !cache_page()) drop = true;
 					else {
 						c.ql++;
-						if (!(w.ck_flags[e] & 2)) {
+						if (!(WK.ck_flags[e] & 2)) {
 							if (c.san % sa_per == 0 && !cache_page()) drop = true;
 							else {
 								c.san++;
-								w.ck_flags[e] |= 2;
+								WK.ck_flags[e] |= 2;
 								const uint64_t full = h.size;
 								const uint64_t room = (sl_per - c.sl % sl_per) % sl_per + (uint64_t)(c.pool_total - c.pool_used) * sl_per;
 								if (full <= room) {
 									const uint64_t in_page = (sl_per - c.sl % sl_per) % sl_per;
 									if (full > in_page) c.pool_used += (uint32_t)((full - in_page + sl_per - 1) / sl_per);
-									c.sl += full; w.ck_eff[e] = (uint32_t)full;
+									c.sl += full; WK.ck_eff[e] = (uint32_t)full;
 								} else {
-									c.sl += room; c.pool_used = c.pool_total; w.ck_eff[e] = (uint32_t)room;      // the range is cut, this seed is dropped
+									c.sl += room; c.pool_used = c.pool_total; WK.ck_eff[e] = (uint32_t)room;      // the range is cut, this seed is dropped
 									drop = true;
 								}
 							}
@@ -163,7 +159,7 @@ struct Aligner {
 					}
 				}
 				if (drop || h.size == 0) { h.size = h.esize = 0; continue; }
-				h.esize = w.ck_eff[e];
+				h.esize = WK.ck_eff[e];
 				// (esize 0: the pool was already empty when the sequence's range was first stored.  The seed still counts and is
 				// ranked, but AlignmentCache::queryQvalImpl hands out no range for it, aligner_cache.h:646)
 				HOT.nonz_tot++;
@@ -205,7 +201,7 @@ struct Aligner {
 		mine[0] = mine[1] = 0;
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
-			if ((fw && m_nofw) || (!fw && m_norc)) continue;
+			if ((fw && ST.m_nofw) || (!fw && ST.m_norc)) continue;
 			uint32_t dep = 0, nedit = 0;
 			bool done = false, do_init = true;
 			TOff top = 0, bot = 0;
@@ -290,7 +286,7 @@ struct Aligner {
 			const bool fw = fwi == 0;
 			if ((fw && nofw) || (!fw && norc)) continue;
 			for (int ebwtfwi = 0; ebwtfwi < 2; ebwtfwi++) {
-				fm_one_mm_dir(IX, PRM, minsc, RPR.nceil, rd, len, ns, fw, ebwtfwi == 0,   // minsc[mate] as tightened so far (bt2_search.cpp:3712)
+				fm_one_mm_dir(IX, PRM, ST.minsc, RPR.nceil, rd, len, ns, fw, ebwtfwi == 0,   // ST.minsc[mate] as tightened so far (bt2_search.cpp:3712)
 					[&](const Mm1Hit& m) { add_mm1(m, fw); }, cnt);
 			}
 		}
@@ -299,7 +295,7 @@ struct Aligner {
 
 	BT2_HD void add_mm1(const Mm1Hit& m, bool fw) {
 		if (HOT.n_mm1 >= (uint32_t)kMaxMm1) { ovf(2); return; }
-		EEHit& h = w.mm1[HOT.n_mm1++];
+		EEHit& h = WK.mm1[HOT.n_mm1++];
 		h.top = m.top; h.bot = m.bot; h.score = m.score;
 		h.epos = m.epos; h.echr = m.echr; h.eqchr = m.eqchr;
 		h.fw = fw ? 1 : 0; h.has_edit = 1;
@@ -327,7 +323,7 @@ struct Aligner {
 				h.topf = h.topb = 0; h.size = h.esize = 0;
 				HOT.sorted[fwi][i] = 0;
 			}
-			if ((fw && m_nofw) || (!fw && m_norc)) continue;
+			if ((fw && ST.m_nofw) || (!fw && ST.m_norc)) continue;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				const uint32_t depth = i * interval + offset;
 				// seed char k as it aligns to the Watson strand (instantiateSeq :463-485)
@@ -406,7 +402,7 @@ struct Aligner {
 				h.topf = h.topb = 0; h.size = h.esize = 0;
 				HOT.sorted[fwi][i] = 0;
 			}
-			if ((fw && m_nofw) || (!fw && m_norc)) continue;
+			if ((fw && ST.m_nofw) || (!fw && ST.m_norc)) continue;
 			for (uint32_t i = 0; i < nseeds; i++) {
 				const uint32_t depth = i * interval + offset;
 				auto getc = [&](uint32_t k) -> int { return fw ? (int)HOT.seq[depth + k] : comp4(HOT.seq[depth + L - 1 - k]); };
@@ -414,7 +410,7 @@ struct Aligner {
 				uint64_t elts = 0;
 				auto report = [&](TOff topf, TOff botf, TOff topb) {
 					if (nsr >= (uint32_t)kMaxSat2) { ovf(5); return; }
-					SeedRange& r = w.sranges[nsr++];
+					SeedRange& r = WK.sranges[nsr++];
 					r.topf = topf; r.topb = topb; r.size = (uint32_t)(botf - topf);
 					elts += (uint64_t)(botf - topf);
 				};
@@ -561,11 +557,11 @@ struct Aligner {
 			uint64_t minsz = 0xffffffffull;      // MAX_U32 even for large indexes, as in the reference
 			uint32_t minidx = 0;
 			bool minfw = true;
-			const bool rb = rnd.nextBool();
+			const bool rb = ST.rnd.nextBool();
 			for (int fwi = 0; fwi <= 1; fwi++) {
 				const bool fw = (fwi == (rb ? 1 : 0));
 				const int s = fw ? 0 : 1;
-				uint32_t i = rnd.nextU32() % HOT.num_offs;
+				uint32_t i = ST.rnd.nextU32() % HOT.num_offs;
 				for (uint32_t ii = 0; ii < HOT.num_offs; ii++) {
 					const uint64_t ne = hit_elts(s, i);
 					if (ne > 0 && !HOT.sorted[s][i] && (TOff)ne < (TOff)minsz) {
@@ -611,12 +607,12 @@ struct Aligner {
 			if (r.swaplist) {
 				r.list_off = lists_alloc(r.n);
 				r.list_len = r.n;
-				for (uint32_t i = 0; i < r.n; i++) w.lists[r.list_off + i] = i;
+				for (uint32_t i = 0; i < r.n; i++) WK.lists[r.list_off + i] = i;
 			}
 		}
 		if (r.swaplist) {
-			const uint32_t rr = r.cur + (rnd.nextU32() % (r.n - r.cur));
-			uint32_t* l = w.lists + r.list_off;
+			const uint32_t rr = r.cur + (ST.rnd.nextU32() % (r.n - r.cur));
+			uint32_t* l = WK.lists + r.list_off;
 			if (rr != r.cur) { const uint32_t tmp = l[r.cur]; l[r.cur] = l[rr]; l[rr] = tmp; }
 			return l[r.cur++];
 		}
@@ -624,12 +620,12 @@ struct Aligner {
 		// the seen list can never hold more entries than rows are drawn for one read (max_iters), however large the range:
 		// a 100 000-row repeat range has thresh = 10 000 but is asked for a few hundred rows at most
 		if (r.seen_len == 0 && r.cur == 0) { const uint32_t cap = (uint32_t)PRM.max_iters + 2; r.seen_off = lists_alloc(r.thresh + 1 < cap ? r.thresh + 1 : cap); }
-		uint32_t* seen = w.lists + r.seen_off;
+		uint32_t* seen = WK.lists + r.seen_off;
 		const uint32_t seen_sz = r.seen_len;
 		uint32_t rn = 0;
 		bool again = true;
 		while (again) {
-			rn = rnd.nextU32() % r.n;
+			rn = ST.rnd.nextU32() % r.n;
 			again = false;
 			for (uint32_t i = 0; i < seen_sz; i++) if (seen[i] == rn) { again = true; break; }
 		}
@@ -647,7 +643,7 @@ struct Aligner {
 			const uint32_t nl = r.n - r.cur;
 			r.list_off = lists_alloc(nl);
 			r.list_len = nl;
-			uint32_t* l = w.lists + r.list_off;
+			uint32_t* l = WK.lists + r.list_off;
 			uint32_t prev = 0, cur = 0;
 			for (uint32_t i = 0; i <= seen_sz; i++) {
 				for (uint32_t j = prev; j < seen[i]; j++) l[cur++] = j;
@@ -678,7 +674,7 @@ struct Aligner {
 	// both, and its counters, out of LDS for the whole loop: every LDS access of the draw is a round trip the next instruction
 	// waits for, and they used to be ~40 per draw).
 	BT2_HD uint32_t r1c_next(R1C& r, Rng& g) {
-		uint32_t* const lists = w.lists;
+		uint32_t* const lists = WK.lists;
 		uint32_t ret;
 		const bool first = r.cur == 0 && !r.converted;
 		if (first && r.n == 1) { r.cur = 1; ret = 0; }
@@ -715,19 +711,19 @@ struct Aligner {
 		return ret;
 	}
 
-	// Entry i of the extension list for the consumer loops: whole records as they are, sampled rows expanded into w.sp_view
+	// Entry i of the extension list for the consumer loops: whole records as they are, sampled rows expanded into WK.sp_view
 	// (satpos_commit() remembers that the row has been taken)
-	BT2_HD bool satpos_taken(uint32_t i) const { return i >= HOT.n_satpos_full && w.srows[i - HOT.n_satpos_full].done != 0; }
+	BT2_HD bool satpos_taken(uint32_t i) const { return i >= HOT.n_satpos_full && WK.srows[i - HOT.n_satpos_full].done != 0; }
 	BT2_HD SatPos& satpos_view(uint32_t i) {
-		if (i < HOT.n_satpos_full) return w.satpos[i];
-		const SampRow sr = w.srows[i - HOT.n_satpos_full];
-		SatPos& s = w.sp_view;
-		Plat::copy_words(&s, &w.satpos2[sr.src], (uint32_t)(sizeof(SatPos) / 4));
+		if (i < HOT.n_satpos_full) return WK.satpos[i];
+		const SampRow sr = WK.srows[i - HOT.n_satpos_full];
+		SatPos& s = WK.sp_view;
+		Plat::copy_words(&s, &WK.satpos2[sr.src], (uint32_t)(sizeof(SatPos) / 4));
 		s.topf = sr.topf; s.topb = (uint64_t)kOffMask; s.size = 1;
 		r1n_init(s.rnd, 1, PRM.all_hits != 0);
 		return s;
 	}
-	BT2_HD void satpos_commit(uint32_t i, const SatPos& sp) { if (i >= HOT.n_satpos_full) w.srows[i - HOT.n_satpos_full].done = r1n_done(sp.rnd) ? 1u : 0u; }
+	BT2_HD void satpos_commit(uint32_t i, const SatPos& sp) { if (i >= HOT.n_satpos_full) WK.srows[i - HOT.n_satpos_full].done = r1n_done(sp.rnd) ? 1u : 0u; }
 
 	// =================================================================================
 	// C. seed-hit extension bookkeeping
@@ -778,7 +774,7 @@ struct Aligner {
 		bool done = false;
 		auto add = [&](const EEHit& hit, int ee_idx, uint64_t top, uint64_t width) {
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(8); done = true; return; }
-			SatPos& s = w.satpos[HOT.n_satpos++];
+			SatPos& s = WK.satpos[HOT.n_satpos++];
 			s.topf = top; s.topb = (uint64_t)kOffMask; s.size = (uint32_t)width; s.orig_sz = (uint32_t)width;
 			s.fw = hit.fw; s.offidx = 0; s.rdoff = 0; s.seedlen = HOT.len; s.nlex = s.nrex = 0;
 			s.ee = ee_idx;
@@ -791,7 +787,7 @@ struct Aligner {
 			const uint64_t width = hit.bot - hit.top;
 			if (nelt_out + width > maxelt) {
 				const uint64_t trim = (nelt_out + width) - maxelt;
-				const uint64_t rn = (PRM.large_index ? rnd.nextU64() : (uint64_t)rnd.nextU32()) % width;
+				const uint64_t rn = (PRM.large_index ? ST.rnd.nextU64() : (uint64_t)ST.rnd.nextU32()) % width;
 				const uint64_t newwidth = width - trim;
 				if (hit.top + rn + newwidth > hit.bot) {
 					tops[0] = hit.top + rn; bots[0] = hit.bot;
@@ -807,7 +803,7 @@ struct Aligner {
 		};
 		if (tot > 0) {
 			bool fw_first = true;
-			const uint64_t rn = (PRM.large_index ? rnd.nextU64() : (uint64_t)rnd.nextU32()) % tot;
+			const uint64_t rn = (PRM.large_index ? ST.rnd.nextU64() : (uint64_t)ST.rnd.nextU32()) % tot;
 			if (rn >= szfw) fw_first = false;
 			for (int fwi = 0; fwi < 2 && !done; fwi++) {
 				const bool fw = ((fwi == 0) == fw_first);
@@ -819,23 +815,23 @@ struct Aligner {
 		if (!done && HOT.n_mm1 > 0) {
 			// sort1mmEe: stable sort by score descending, then shuffle equal-score streaks (aligner_seed.h:1223)
 			for (uint32_t i = 1; i < HOT.n_mm1; i++) {
-				const EEHit v = w.mm1[i];
+				const EEHit v = WK.mm1[i];
 				uint32_t j = i;
-				while (j > 0 && w.mm1[j - 1].score < v.score) { w.mm1[j] = w.mm1[j - 1]; j--; }
-				w.mm1[j] = v;
+				while (j > 0 && WK.mm1[j - 1].score < v.score) { WK.mm1[j] = WK.mm1[j - 1]; j--; }
+				WK.mm1[j] = v;
 			}
 			auto shuffle = [&](uint32_t begin, uint32_t num) {
 				if (num < 2) return;
 				uint32_t left = num;
 				for (uint32_t i = begin; i < begin + num - 1; i++) {
-					const uint64_t rndi = rnd.nextU64() % left;
-					if (rndi > 0) { const EEHit tmp = w.mm1[i]; w.mm1[i] = w.mm1[i + rndi]; w.mm1[i + rndi] = tmp; }
+					const uint64_t rndi = ST.rnd.nextU64() % left;
+					if (rndi > 0) { const EEHit tmp = WK.mm1[i]; WK.mm1[i] = WK.mm1[i + rndi]; WK.mm1[i + rndi] = tmp; }
 					left--;
 				}
 			};
 			uint32_t streak = 0;
 			for (uint32_t i = 1; i < HOT.n_mm1; i++) {
-				if (w.mm1[i].score == w.mm1[i - 1].score) {
+				if (WK.mm1[i].score == WK.mm1[i - 1].score) {
 					if (streak == 0) streak = 1;
 					streak++;
 				} else {
@@ -844,12 +840,12 @@ struct Aligner {
 				}
 			}
 			if (streak > 1) shuffle(HOT.n_mm1 - streak, streak);
-			for (uint32_t i = 0; i < HOT.n_mm1 && !done; i++) add_trimmed(w.mm1[i], (int)i);
+			for (uint32_t i = 0; i < HOT.n_mm1 && !done; i++) add_trimmed(WK.mm1[i], (int)i);
 		}
 		HOT.n_satpos_full = HOT.n_resolved = HOT.n_satpos;
 	}
 
-	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? HOT.exact[0] : (idx == -3 ? HOT.exact[1] : w.mm1[idx]); }
+	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? HOT.exact[0] : (idx == -3 ? HOT.exact[1] : WK.mm1[idx]); }
 
 	// SwDriver::prioritizeSATupsRands (aligner_sw_driver.cpp:492-738)
 	BT2_HDN void prioritize(int seedmms, uint64_t maxelt, uint64_t& nelt_out) {
@@ -866,12 +862,12 @@ struct Aligner {
 			const uint32_t nr_here = seedmms > 0 ? (uint32_t)h.topb : 1u;      // ca.queryQval: one SATuple per reference string
 			for (uint32_t ri = 0; ri < nr_here; ri++) {
 			uint64_t h_topf = h.topf, h_topb = h.topb, sz = h.esize;      // the range as the seed cache holds it
-			if (seedmms > 0) { const SeedRange& sr = w.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.size; }
+			if (seedmms > 0) { const SeedRange& sr = WK.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.size; }
 			else if (sz == 0) continue;
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
 				const bool m2 = PRM.paired && HOT.pe.cur == 1;     // seedExRangeFw_[matei] / seedExRangeRc_[matei]
-				const Work::ExtRange* range = m2 ? (fw ? w.ex_fw2 : w.ex_rc2) : (fw ? w.ex_fw : w.ex_rc);
+				const Work::ExtRange* range = m2 ? (fw ? WK.ex_fw2 : WK.ex_rc2) : (fw ? WK.ex_fw : WK.ex_rc);
 				const uint32_t nr = m2 ? (fw ? HOT.pe.n_ex_fw2 : HOT.pe.n_ex_rc2) : (fw ? HOT.n_ex_fw : HOT.n_ex_rc);
 				bool skip = false;
 				for (uint32_t k = 0; k < nr; k++) {
@@ -882,14 +878,14 @@ struct Aligner {
 				if (skip) { nrange--; nelt -= sz; continue; }
 			}
 			if (HOT.n_satpos2 >= (uint32_t)kMaxSat2) { ovf(9); break; }
-			SatPos& s = w.satpos2[HOT.n_satpos2++];
+			SatPos& s = WK.satpos2[HOT.n_satpos2++];
 			s.topf = h_topf; s.topb = h_topb; s.size = (uint32_t)sz; s.orig_sz = (uint32_t)sz;
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
 			uint32_t nlex = 0, nrex = 0;
 			if (PRM.do_extend) {
-				if (ext_pre && seedmms == 0 && h.esize == h.size) {      // (a range the cache cut short is extended as the shorter range)
-					const uint32_t e = pre_ext_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + offidx];
+				if (ST.ext_pre && seedmms == 0 && h.esize == h.size) {      // (a range the cache cut short is extended as the shorter range)
+					const uint32_t e = ST.pre_ext_cur[((uint64_t)ST.ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + offidx];
 					nlex = e & 0xffffu; nrex = e >> 16;
 				} else extend_hit((TOff)h_topf, (TOff)(h_topf + sz), (TOff)h_topb, (TOff)(h_topb + sz), fw, rdoff, seedlen, nlex, nrex);
 			}
@@ -897,7 +893,7 @@ struct Aligner {
 			HOT.n_ext_left += nlex; HOT.n_ext_right += nrex;
 			if (seedmms == 0 && (nlex > 0 || nrex > 0)) {
 				const bool m2 = PRM.paired && HOT.pe.cur == 1;
-				Work::ExtRange* range = m2 ? (fw ? w.ex_fw2 : w.ex_rc2) : (fw ? w.ex_fw : w.ex_rc);
+				Work::ExtRange* range = m2 ? (fw ? WK.ex_fw2 : WK.ex_rc2) : (fw ? WK.ex_fw : WK.ex_rc);
 				uint32_t& nr = m2 ? (fw ? HOT.pe.n_ex_fw2 : HOT.pe.n_ex_rc2) : (fw ? HOT.n_ex_fw : HOT.n_ex_rc);
 				if (nr < (uint32_t)(kMaxRanges * 2)) {
 					range[nr].off = rdoff - (fw ? nlex : nrex);
@@ -918,11 +914,11 @@ struct Aligner {
 			const uint32_t gap = gaps[gi];
 			if (gap >= HOT.n_satpos2) continue;
 			for (uint32_t i = gap; i < HOT.n_satpos2; i++) {
-				if (!satpos_less(w.satpos2[i], w.satpos2[i - gap])) continue;
-				const SatPos v = w.satpos2[i];
+				if (!satpos_less(WK.satpos2[i], WK.satpos2[i - gap])) continue;
+				const SatPos v = WK.satpos2[i];
 				uint32_t j = i;
-				while (j >= gap && satpos_less(v, w.satpos2[j - gap])) { w.satpos2[j] = w.satpos2[j - gap]; j -= gap; }
-				w.satpos2[j] = v;
+				while (j >= gap && satpos_less(v, WK.satpos2[j - gap])) { WK.satpos2[j] = WK.satpos2[j - gap]; j -= gap; }
+				WK.satpos2[j] = v;
 			}
 		}
 		if (PRM.det_seeds) {
@@ -930,8 +926,8 @@ struct Aligner {
 			uint64_t added = 0;
 			for (uint32_t j = 0; j < HOT.n_satpos2 && added < maxelt; j++) {
 				if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(11); break; }
-				SatPos& s = w.satpos[HOT.n_satpos++];
-				s = w.satpos2[j];
+				SatPos& s = WK.satpos[HOT.n_satpos++];
+				s = WK.satpos2[j];
 				r1n_init_seq(s.rnd, s.size);
 				added += s.size;
 			}
@@ -943,8 +939,8 @@ struct Aligner {
 		// 1. the smalls, whole
 		for (uint64_t j = 0; j < nsmall && nelt_added < maxelt; j++) {
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(12); break; }
-			SatPos& s = w.satpos[HOT.n_satpos++];
-			s = w.satpos2[j];
+			SatPos& s = WK.satpos[HOT.n_satpos++];
+			s = WK.satpos2[j];
 			r1n_init(s.rnd, s.size, PRM.all_hits != 0);
 			nelt_added += s.size;
 		}
@@ -955,14 +951,14 @@ struct Aligner {
 		HOT.n_masses = saf - sai;
 		HOT.mass = 0.0;
 		for (uint32_t i = sai; i < saf; i++) {
-			const uint32_t ln = w.satpos2[i].nlex + w.satpos2[i].nrex + 1;
+			const uint32_t ln = WK.satpos2[i].nlex + WK.satpos2[i].nrex + 1;
 			double num = (double)ln; num *= num;
-			double denom = (double)w.satpos2[i].size; denom *= denom;
-			w.masses[i - sai] = num / denom;
-			w.elim[i - sai] = 0;
-			HOT.mass += w.masses[i - sai];
+			double denom = (double)WK.satpos2[i].size; denom *= denom;
+			WK.masses[i - sai] = num / denom;
+			WK.elim[i - sai] = 0;
+			HOT.mass += WK.masses[i - sai];
 		}
-		for (uint32_t j = 0; j < HOT.n_satpos2; j++) r1n_reset(w.rands2[j]);
+		for (uint32_t j = 0; j < HOT.n_satpos2; j++) r1n_reset(WK.rands2[j]);
 		// With at most kMaxRanges candidates (always, for -N 0) the sampler keeps the running sums of the masses that are still
 		// in play on chip: the sums are formed by the same left-to-right additions as RowSampler::next's scan, so "first index
 		// whose running sum exceeds rd" is the same index -- found by all lanes at once instead of a chain of dependent loads.
@@ -970,18 +966,18 @@ struct Aligner {
 		if (fast) for (uint32_t j = 0; j < HOT.n_masses; j++) { R1C& r = HOT.samp.r[j]; r.topf = 0; r.n = r.cur = 0; r.swaplist = r.converted = r.inited = 0; r.seen_len = 0; r.thresh = 0; r.list_off = r.seen_off = 0; }
 		auto rebuild = [&]() {
 			double acc = 0.0;
-			for (uint32_t i = 0; i < HOT.n_masses; i++) { if (!w.elim[i]) acc += w.masses[i]; HOT.samp.prefix[i] = acc; HOT.samp.elim[i] = w.elim[i]; }
+			for (uint32_t i = 0; i < HOT.n_masses; i++) { if (!WK.elim[i]) acc += WK.masses[i]; HOT.samp.prefix[i] = acc; HOT.samp.elim[i] = WK.elim[i]; }
 		};
 		if (fast) rebuild();
 		const uint64_t ts_ = now();
 		if (fast) {
 			// loop state in registers: RNG, total mass, list length, profile counts; written back once
-			Rng g = rnd;
+			Rng g = ST.rnd;
 			double mass = HOT.mass;
 			uint32_t n_satpos = HOT.n_satpos;
 			const uint32_t n_full = HOT.n_satpos_full, n_masses = HOT.n_masses;
-			SampRow* const srows = w.srows;
-			const SatPos* const sat2 = w.satpos2;
+			SampRow* const srows = WK.srows;
+			const SatPos* const sat2 = WK.satpos2;
 			const bool all_hits = PRM.all_hits != 0;
 			uint64_t draws = 0;
 			bool full = false;
@@ -996,7 +992,7 @@ struct Aligner {
 				const uint32_t r = r1c_next(r2, g);
 				HOT.samp.r[pick] = r2;
 				if (r2.n > 0 && r2.cur >= r2.n) {      // the range is used up: out of the sampler
-					w.elim[ri - sai] = 1; mass -= w.masses[ri - sai];
+					WK.elim[ri - sai] = 1; mass -= WK.masses[ri - sai];
 					rebuild();
 				}
 				if (n_satpos >= (uint32_t)kMaxSatpos) { full = true; break; }
@@ -1005,33 +1001,33 @@ struct Aligner {
 				gst(&sr->topf, (uint64_t)(r2.topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
 				nelt_added++;
 			}
-			rnd = g; HOT.mass = mass; HOT.n_satpos = n_satpos;
+			ST.rnd = g; HOT.mass = mass; HOT.n_satpos = n_satpos;
 			HOT.t_phase[21] += draws;
 			if (full) ovf(13);
 		} else
 		while (nelt_added < maxelt && nelt_added < nelt) {
 			// RowSampler::next, more ranges than the on-chip sampler holds (-N 1): everything through the arena
-			const double rd = (double)(rnd.nextFloat() * HOT.mass);
+			const double rd = (double)(ST.rnd.nextFloat() * HOT.mass);
 			uint32_t pick = 0xffffffffu;
 			double mass_sofar = 0.0;
 			uint32_t last_unelim = 0xffffffffu;
 			for (uint32_t i = 0; i < HOT.n_masses; i++) {
-				if (!w.elim[i]) {
+				if (!WK.elim[i]) {
 					last_unelim = i;
-					mass_sofar += w.masses[i];
+					mass_sofar += WK.masses[i];
 					if (rd < mass_sofar) { pick = i; break; }
 				}
 			}
 			if (pick == 0xffffffffu) pick = last_unelim;
 			const uint32_t ri = pick + sai;
-			R1N& r2 = w.rands2[ri];
-			if (!r2.inited) r1n_init(r2, w.satpos2[ri].size, PRM.all_hits != 0);
+			R1N& r2 = WK.rands2[ri];
+			if (!r2.inited) r1n_init(r2, WK.satpos2[ri].size, PRM.all_hits != 0);
 			const uint32_t r = r1n_next(r2);
-			if (r1n_done(r2)) { w.elim[ri - sai] = 1; HOT.mass -= w.masses[ri - sai]; }
+			if (r1n_done(r2)) { WK.elim[ri - sai] = 1; HOT.mass -= WK.masses[ri - sai]; }
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(13); break; }
-			SampRow* const sr = &w.srows[HOT.n_satpos - HOT.n_satpos_full];
+			SampRow* const sr = &WK.srows[HOT.n_satpos - HOT.n_satpos_full];
 			HOT.n_satpos++;
-			gst(&sr->topf, (uint64_t)(w.satpos2[ri].topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
+			gst(&sr->topf, (uint64_t)(WK.satpos2[ri].topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
 			nelt_added++;
 		}
 		HOT.t_phase[18] += now() - ts_;       // profile: the row-sampling loop
@@ -1044,16 +1040,16 @@ struct Aligner {
 	// seenDiags1_ / seenDiags2_ share the list; the mate rides in bit 1 of the orientation
 	BT2_HD bool diag_present_m(int32_t ref, int64_t off, bool fw, int mate) const {
 		const int orient = (fw ? 1 : 0) | (mate << 1);
-		return Plat::diag_find(w.diags, HOT.n_diags, ref, off, orient);
+		return Plat::diag_find(WK.diags, HOT.n_diags, ref, off, orient);
 	}
 	BT2_HD void diag_add_m(int32_t ref, int64_t off, bool fw, int64_t len, int mate) {
 		if (HOT.n_diags >= (uint32_t)kMaxDiags) { ovf(14); return; }
-		DiagIval& d = w.diags[HOT.n_diags++];
+		DiagIval& d = WK.diags[HOT.n_diags++];
 		d.ref = ref; d.off = off; d.orient = (fw ? 1 : 0) | (mate << 1); d.len = len;
 	}
 
 	// RedundantAlns cell enumeration (aligner_result.cpp:929-1032): per read row, the half-open
-	// column range [left,right) the alignment occupies, edits taken w.r.t. the upstream end.
+	// column range [left,right) the alignment occupies, edits taken WK.r.t. the upstream end.
 	struct RowIt {
 		const AlnRes& r;
 		uint32_t n, nedidx, i, end;
@@ -1065,7 +1061,7 @@ struct Aligner {
 			end = i + r.rdextent;                   // readExtentRows()
 			left = r.refoff;
 		}
-		// edits w.r.t. the upstream end: for rc alignments positions are inverted (invertPoss) and the order reversed
+		// edits WK.r.t. the upstream end: for rc alignments positions are inverted (invertPoss) and the order reversed
 		BT2_HD uint32_t epos(uint32_t k) const {
 			if (fw) return r.ned[k].pos;
 			const Edit& e = r.ned[n - 1 - k];
@@ -1094,17 +1090,17 @@ struct Aligner {
 		dmin = d0 - nrf - 1; dmax = d0 + nrd + 1;
 	}
 
-	// RedundantAlns::overlap against every alignment reported so far (they are all kept in w.alns)
+	// RedundantAlns::overlap against every alignment reported so far (they are all kept in WK.alns)
 	BT2_HDN bool red_overlap(const AlnRes& r) const {
 		const uint32_t nst = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;
 		if (nst == 0) return false;
 		int64_t dmin, dmax;
 		diag_bounds(r, dmin, dmax);
 		for (uint32_t a = 0; a < nst; a++) {
-			const AlnRes& o = w.alns[a];
+			const AlnRes& o = WK.alns[a];
 			if (o.refid != r.refid || (o.fw != 0) != (r.fw != 0)) continue;
 			// alignments whose diagonal ranges are disjoint share no cell
-			if (dmin > w.red_dmax[a] || w.red_dmin[a] > dmax) continue;
+			if (dmin > WK.red_dmax[a] || WK.red_dmin[a] > dmax) continue;
 			RowIt ia(o), ir(r);
 			int64_t l1 = 0, r1 = 0, l2 = 0, r2 = 0;
 			while (!ia.done() && !ir.done()) {
@@ -1116,17 +1112,17 @@ struct Aligner {
 		}
 		return false;
 	}
-	// RedundantAlns::add: the cells are re-derived from w.alns[k] on demand; only the prefilter bounds are kept
+	// RedundantAlns::add: the cells are re-derived from WK.alns[k] on demand; only the prefilter bounds are kept
 	BT2_HDN void red_add(const AlnRes& r) {
 		if (HOT.n_alns >= (uint32_t)kMaxAlns) return;      // sink_report flags the overflow
-		diag_bounds(r, w.red_dmin[HOT.n_alns], w.red_dmax[HOT.n_alns]);
+		diag_bounds(r, WK.red_dmin[HOT.n_alns], WK.red_dmax[HOT.n_alns]);
 	}
 
 	// =================================================================================
 	// D. sink (AlnSinkWrap::report, ReportingState::foundUnpaired; aln_sink.cpp:103-130,1395-1445)
 	// =================================================================================
 	BT2_HD bool sink_report(const AlnRes& r) {
-		if (HOT.n_alns < (uint32_t)kMaxAlns) Plat::copy_aln(w.alns[HOT.n_alns], r); else ovf(15);
+		if (HOT.n_alns < (uint32_t)kMaxAlns) Plat::copy_aln(WK.alns[HOT.n_alns], r); else ovf(15);
 		HOT.n_alns++;
 		if (!HOT.done_unpair1) {
 			// ReportingState::areDone
@@ -1150,18 +1146,18 @@ struct Aligner {
 			Plat::fetch_ref_joined(IX.ref, HOT.frag_jlo + (uint64_t)rel, count);
 #ifdef BT2G_CHECK_REF_JOINED
 			// test builds: the joined-text form must give what the record search gives
-			{ uint8_t a[kMaxCols + 8]; memcpy(a, HOT.rf, count); Plat::fetch_ref(IX.ref, w, tidx, rfi, count); static unsigned long n_ = 0; n_++;
+			{ uint8_t a[kMaxCols + 8]; memcpy(a, HOT.rf, count); Plat::fetch_ref(IX.ref, WK, tidx, rfi, count); static unsigned long n_ = 0; n_++;
 			  if (memcmp(a, HOT.rf, count)) { fprintf(stderr, "fetch_ref_joined mismatch (tidx %llu rfi %lld count %u)\n", (unsigned long long)tidx, (long long)rfi, count); abort(); }
 			  if ((n_ & (n_ - 1)) == 0) fprintf(stderr, "fetch_ref_joined checked %lu windows\n", n_); }
 #endif
-		} else Plat::fetch_ref(IX.ref, w, tidx, rfi, count);
+		} else Plat::fetch_ref(IX.ref, WK, tidx, rfi, count);
 	}
 
 	// packed cell (H | E<<8 | F<<16)
-	BT2_HD uint32_t cell_get(uint32_t R, uint32_t i, uint32_t j) const { return dp.mat[dp_cell(R, i, j)]; }
+	BT2_HD uint32_t cell_get(uint32_t R, uint32_t i, uint32_t j) const { return ST.dp.mat[dp_cell(R, i, j)]; }
 
 	// masks_ helpers (aligner_swsse.h:255-330,418-490)
-	BT2_HD uint16_t& mask_at(uint32_t row, uint32_t col, uint32_t cols) { return dp.masks[(uint64_t)row * cols + col]; }
+	BT2_HD uint16_t& mask_at(uint32_t row, uint32_t col, uint32_t cols) { return ST.dp.masks[(uint64_t)row * cols + col]; }
 
 	// gatherCellsNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1176-1208) + btncand_.sort()
 	BT2_HDN void gather_cells(bool fw, uint32_t rows, uint32_t cols, int64_t minsc_dp, int mode, uint32_t lastsolcol) {
@@ -1170,16 +1166,16 @@ struct Aligner {
 		const uint64_t tl_ = now();
 		uint32_t nc;
 		if (mode != 2) {
-			if (mode != 0) Plat::load_last_row(dp.mat, R, rows, cols, true);      // the 8-bit fill leaves the last row in HOT.lastrow itself
+			if (mode != 0) Plat::load_last_row(ST.dp.mat, R, rows, cols, true);      // the 8-bit fill leaves the last row in HOT.lastrow itself
 			HOT.t_phase[15] += now() - tl_;
 			// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
 			nc = Plat::gather_sort(cand_list(), (uint32_t)kMaxCands, rows, cols, minsc_dp);
 		} else {
-			// gatherCellsNucleotidesLocalSseU8/I16 (aligner_swsse_loc_u8.cpp:1389-1496): every cell with score >= minsc, at or
-			// below the first row that can reach minsc, that is a match whose diagonal successor is not; columns <= lastsolcol
+			// gatherCellsNucleotidesLocalSseU8/I16 (aligner_swsse_loc_u8.cpp:1389-1496): every cell with score >= ST.minsc, at or
+			// below the first row that can reach ST.minsc, that is a match whose diagonal successor is not; columns <= lastsolcol
 			const int64_t bonus = PRM.match_bonus;
 			const uint32_t minrow = (uint32_t)(((minsc_dp + bonus - 1) / bonus) - 1);
-			nc = Plat::gather_local(dp.mat, cand_list(), (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow, w.cand_hist);
+			nc = Plat::gather_local(ST.dp.mat, cand_list(), (uint32_t)kMaxCands, fw, R, rows, lastsolcol + 1, minsc_dp, minrow, WK.cand_hist);
 		}
 		if (nc > (uint32_t)kMaxCands) { ovf(16); HOT.n_cands = kMaxCands; } else HOT.n_cands = nc;
 		HOT.t_phase[13] += HOT.n_cands;      // profile: candidate cells
@@ -1187,10 +1183,10 @@ struct Aligner {
 			const uint64_t tz_ = now();
 			if (mode == 0) {
 				// pred format: a new epoch invalidates every mask word of earlier DPs; the plane is only cleared when the tag wraps
-				uint32_t e = Plat::uni(*dp.epoch) + 1;
-				if (e > kEpochMax) { Plat::zero_u32(dp.pmask, dp.pmask_words); e = 1; }
-				Plat::set_epoch(dp.epoch, e);
-			} else Plat::zero_masks(dp.masks, rows * cols);
+				uint32_t e = Plat::uni(*ST.dp.epoch) + 1;
+				if (e > kEpochMax) { Plat::zero_u32(ST.dp.pmask, ST.dp.pmask_words); e = 1; }
+				Plat::set_epoch(ST.dp.epoch, e);
+			} else Plat::zero_masks(ST.dp.masks, rows * cols);
 			HOT.t_phase[16] += now() - tz_;
 		}
 	}
@@ -1201,7 +1197,7 @@ struct Aligner {
 		return (m == 1 || m == 2 || m == 4 || m == 8) ? (int)code2chr(__builtin_ctz((unsigned)m)) : 'N';
 	}
 
-	// AlnRes::setShape (aligner_result.cpp:72-122) -- edits arrive w.r.t. DP rows (upstream end)
+	// AlnRes::setShape (aligner_result.cpp:72-122) -- edits arrive WK.r.t. DP rows (upstream end)
 	BT2_HD void set_shape(AlnRes& r, int32_t id, int64_t off, int64_t reflen, bool fw, uint32_t rdlen, uint32_t trim5p, uint32_t trim3p) {
 		r.refid = id; r.refoff = off; r.reflen = reflen; r.fw = fw ? 1 : 0; r.rdlen = (uint16_t)rdlen;
 		r.trim5p = (uint16_t)trim5p; r.trim3p = (uint16_t)trim3p;
@@ -1239,7 +1235,7 @@ struct Aligner {
 		}
 	}
 	BT2_HD uint32_t clip_read_chars(AlnRes& r, bool from_left, uint32_t rf_amt) {
-		// walk the edits from the clipped end (positions w.r.t. that end of the Watson-oriented read)
+		// walk the edits from the clipped end (positions WK.r.t. that end of the Watson-oriented read)
 		const bool inv = from_left ? !r.fw : (r.fw != 0);
 		uint32_t rf_i = rf_amt;
 		if (inv) invert_edits(r);
@@ -1291,16 +1287,16 @@ struct Aligner {
 		const uint32_t R = dp_R(rows);
 		// `this` lives in private memory: read what the loop needs once, into scalar registers
 		DpScratch dpl;
-		dpl.mat = Plat::uni_ptr(dp.mat); dpl.masks = Plat::uni_ptr(dp.masks); dpl.pmask = Plat::uni_ptr(dp.pmask); dpl.epoch = Plat::uni_ptr(dp.epoch); dpl.pmask_words = 0;
+		dpl.mat = Plat::uni_ptr(ST.dp.mat); dpl.masks = Plat::uni_ptr(ST.dp.masks); dpl.pmask = Plat::uni_ptr(ST.dp.pmask); dpl.epoch = Plat::uni_ptr(ST.dp.epoch); dpl.pmask_words = 0;
 		const uint32_t epoch = pred ? Plat::uni(*dpl.epoch) : 0u;
 		const int32_t band_lo = pred ? (int32_t)Plat::uni(dpl.epoch[1]) : 0;       // geometry of the band the fill stored (pred_idx)
 		const uint32_t band_w = pred ? Plat::uni(dpl.epoch[2]) : 0u;
-		BtFrame* const btstack = Plat::uni_ptr(&w.btstack[0]);
+		BtFrame* const btstack = Plat::uni_ptr(&WK.btstack[0]);
 		BtCand* const cands = Plat::uni_ptr(cand_list());
 		struct Prof {      // profile counters stay in registers until the function returns
-			Aligner& a; uint32_t steps, tiles; uint64_t tile_t; uint32_t scalar_steps;
-			BT2_HD ~Prof() { a.pf_steps += steps; a.pf_tiles += tiles; a.pf_tile_t += tile_t; HOT.t_bt[4] += scalar_steps; }
-		} prof{*this, 0, 0, 0, 0};
+			uint32_t steps, tiles; uint64_t tile_t; uint32_t scalar_steps;
+			BT2_HD ~Prof() { ST.pf_steps += steps; ST.pf_tiles += tiles; ST.pf_tile_t += tile_t; HOT.t_bt[4] += scalar_steps; }
+		} prof{0, 0, 0, 0};
 		// read, qualities and reference window as per-lane registers (4 bytes per lane per register): the step
 		// loop then reads them with v_readlane instead of going to LDS
 		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
@@ -1575,7 +1571,7 @@ struct Aligner {
 				c.row = (uint16_t)(rc_ & 0xffffu); c.col = (uint16_t)(rc_ >> 16);
 			} else c = gld(&cands[HOT.cural]);
 			if (MODE == 2) c.score &= ~kCandDone;
-			if (c.score < minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
+			if (c.score < ST.minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
 			if (MODE == 2) {
 				// local: skip candidates "dominated" by one already tried -- within SQ = rows/16 rows and columns of it
 				// (aligner_sw.cpp:754-755,936-960)
@@ -1598,8 +1594,8 @@ struct Aligner {
 			if ((pred ? Plat::lane(tile_hi, 0) : Plat::lane(tile, 48)) & 1) { HOT.cural++; continue; }
 			// reseeding protocol: 8-bit kernels init(reseed) ... init(reseed+1); 16-bit kernels only init(reseed) afterwards
 			// (aligner_sw.cpp:796-933 end-to-end, :962-1110 local)
-			const uint32_t reseed = rnd.nextU32() + 1;
-			if (!sse16) rnd.init(reseed);
+			const uint32_t reseed = ST.rnd.nextU32() + 1;
+			if (!sse16) ST.rnd.init(reseed);
 			res.nned = 0;
 			const int32_t cscore = c.score;
 			bool ret;
@@ -1611,7 +1607,7 @@ struct Aligner {
 				ret = walk(c.row, c.col, tile, tile_hi);
 				if (PRM.profile) { const uint64_t dt_ = now() - tw_; HOT.t_bt[0] += dt_; if (ret) { HOT.t_bt[1] += dt_; HOT.t_bt[2]++; } }
 			}
-			rnd.init(sse16 ? reseed : reseed + 1);
+			ST.rnd.init(sse16 ? reseed : reseed + 1);
 			if (MODE == 2) gst(&cands[HOT.cural].score, cscore | kCandDone);       // btncanddone_: tried, succeeded or not
 			if (ret) { found = true; break; }
 			HOT.cural++;
@@ -1649,7 +1645,7 @@ struct Aligner {
 		if (PRM.match_bonus == 0) {
 			for (uint32_t i = 0; i < len; i++) {
 				step(i);
-				if (score < minsc || ns > RPR.nceil) return 0;
+				if (score < ST.minsc || ns > RPR.nceil) return 0;
 			}
 		} else {
 			// local flavour (aligner_sw.cpp:400-436): best-scoring stretch of the diagonal; more than one -> leave it to the DP
@@ -1658,13 +1654,13 @@ struct Aligner {
 			rowi = 0xffffffffu;
 			for (uint32_t i = 0; i < len; i++) {
 				step(i);
-				if (score >= minsc && score >= score_max) {
+				if (score >= ST.minsc && score >= score_max) {
 					score_max = score; rowf = i;
 					if (rowi != lastfloor) { rowi = lastfloor; sols++; }
 				}
 				if (score <= 0) { score = 0; lastfloor = i + 1; }
 			}
-			if (ns > RPR.nceil || score_max < minsc) return 0;
+			if (ns > RPR.nceil || score_max < ST.minsc) return 0;
 			if (sols > 1) return -1;
 			score = score_max;
 		}
@@ -1705,7 +1701,7 @@ struct Aligner {
 		uint64_t nelt = 0, nelt_left = 0;
 		const uint32_t rows = rdlen;
 		const uint32_t max_iters = (uint32_t)PRM.max_iters;
-		AlnRes& res = w.res;
+		AlnRes& res = WK.res;
 		while (true) {
 			if (ee_mode) {
 				if (first_ee) {
@@ -1716,7 +1712,7 @@ struct Aligner {
 			}
 			if (!ee_mode) {
 				if (nonz == 0) return EXT_EXHAUSTED;
-				if (minsc == perfect) return EXT_PERFECT_SCORE;
+				if (ST.minsc == perfect) return EXT_PERFECT_SCORE;
 				if (first_extend) {
 					nelt = 0;
 					{ const uint64_t t0_ = now(); prioritize(seedmms, max_iters, nelt); HOT.t_phase[3] += now() - t0_; }
@@ -1730,7 +1726,7 @@ struct Aligner {
 				if (satpos_taken(i)) continue;
 				SatPos& sp = satpos_view(i);
 				const EEHit* eh = ee_mode ? &ee_hit(sp.ee) : nullptr;
-				if (ee_mode && eh->score < minsc) return EXT_PERFECT_SCORE;
+				if (ee_mode && eh->score < ST.minsc) return EXT_PERFECT_SCORE;
 				const bool is_small = PRM.det_seeds ? true : sp.size < nsm;
 				const bool fw = sp.fw != 0;
 				uint32_t rdoff = sp.rdoff;
@@ -1738,9 +1734,9 @@ struct Aligner {
 				if (!fw) rdoff = rdlen - rdoff - seedhitlen;
 				bool first = true;
 				while (!r1n_done(sp.rnd) && (first || is_small || ee_mode)) {
-					if (minsc == perfect) {
+					if (ST.minsc == perfect) {
 						if (!ee_mode || eh->score < perfect) return EXT_PERFECT_SCORE;
-					} else if (ee_mode && eh->score < minsc) {
+					} else if (ee_mode && eh->score < ST.minsc) {
 						break;
 					}
 					if (HOT.n_ex_dps >= (uint32_t)PRM.max_dp) return EXT_HARD_LIMIT;
@@ -1755,17 +1751,17 @@ struct Aligner {
 					TOff joff;
 					uint64_t jc = kJoffNone;
 					// a one-row hit of the pre-computed seed round was resolved by the batch kernel that extended it
-					if (!ee_mode && ext_pre && seedmms == 0 && sp.orig_sz == 1 && pre_joff_cur)
-						jc = pre_joff_cur[((uint64_t)ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + sp.offidx];
+					if (!ee_mode && ST.ext_pre && seedmms == 0 && sp.orig_sz == 1 && ST.pre_joff_cur)
+						jc = ST.pre_joff_cur[((uint64_t)ST.ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + sp.offidx];
 					if (jc == kJoffNone && !ee_mode && i >= HOT.n_satpos_full) {
 						// a sampled row: the walks to the SA sample of this row and the next 63 run side by side, one per lane
 						// (the extension loop takes the rows in list order, so the look-ahead is rarely wasted)
 						if (i >= HOT.n_resolved) {
 							const uint32_t k0 = i - HOT.n_satpos_full, cnt = HOT.n_satpos - i < 64u ? HOT.n_satpos - i : 64u;
-							Plat::resolve_rows(IX.fw, &w.srows[k0], cnt, &w.srow_joff[k0]);
+							Plat::resolve_rows(IX.fw, &WK.srows[k0], cnt, &WK.srow_joff[k0]);
 							HOT.n_resolved = i + cnt;
 						}
-						jc = w.srow_joff[i - HOT.n_satpos_full];
+						jc = WK.srow_joff[i - HOT.n_satpos_full];
 						if (jc != kJoffNone) HOT.n_sides += (uint32_t)(jc >> 48);
 					}
 					if (jc != kJoffNone) { joff = (TOff)(jc & 0xffffffffffffull); steps = (uint32_t)(jc >> 48); }
@@ -1782,8 +1778,8 @@ struct Aligner {
 					int read_gaps = 0, ref_gaps = 0;
 					bool ungapped = false;
 					if (!ee_mode) {
-						read_gaps = max_read_gaps(PRM, minsc, rdlen);
-						ref_gaps = max_ref_gaps(PRM, minsc, rdlen);
+						read_gaps = max_read_gaps(PRM, ST.minsc, rdlen);
+						ref_gaps = max_ref_gaps(PRM, ST.minsc, rdlen);
 						ungapped = (read_gaps == 0 && ref_gaps == 0);
 					}
 					int state = 0;   // 0 none, 1 ee, 2 ungapped
@@ -1856,7 +1852,7 @@ struct Aligner {
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
 						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { ovf(23); return EXT_HARD_LIMIT; }
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
-						// SwAligner::align (aligner_sw.cpp:500-729).  End to end: 8-bit kernel while minsc >= -254, else 16-bit (:517).
+						// SwAligner::align (aligner_sw.cpp:500-729).  End to end: 8-bit kernel while ST.minsc >= -254, else 16-bit (:517).
 						// Local: the 8-bit kernel unless it saturates, then the 16-bit one (:568-600); the fill below is exact and
 						// reports whether the 8-bit kernel would have saturated, which only matters for the RNG protocol.
 						const uint64_t td_ = now();
@@ -1865,18 +1861,18 @@ struct Aligner {
 						if (PRM.match_bonus > 0) {
 							mode = 2;
 							uint32_t sat8 = 0;
-							best = Plat::dp_fill_local(PRM, w, fw, rows, cols, dp.mat, minsc, lastsolcol, sat8);
+							best = Plat::dp_fill_local(PRM, WK, fw, rows, cols, ST.dp.mat, ST.minsc, lastsolcol, sat8);
 							sse16 = sat8 != 0;
 						} else {
-							mode = minsc < -254 ? 1 : 0;
+							mode = ST.minsc < -254 ? 1 : 0;
 							sse16 = mode == 1;
-							best = Plat::dp_fill_ee(PRM, w, fw, rows, cols, dp, mode != 0, minsc);
+							best = Plat::dp_fill_ee(PRM, WK, fw, rows, cols, ST.dp, mode != 0, ST.minsc);
 							if (best == INT64_MIN) { ovf(31); return EXT_HARD_LIMIT; }
 						}
 						HOT.t_phase[5] += now() - td_;
 						HOT.n_ex_dps++;
-						found = best >= minsc;
-						if (found) { const uint64_t tg_ = now(); gather_cells(fw, rows, cols, minsc, mode, lastsolcol); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
+						found = best >= ST.minsc;
+						if (found) { const uint64_t tg_ = now(); gather_cells(fw, rows, cols, ST.minsc, mode, lastsolcol); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
 						if (!found) {
 							HOT.n_dp_fail++;
 							if (HOT.n_dp_fail >= (uint32_t)PRM.max_dp_streak) return EXT_SOFT_LIMIT;
@@ -1916,16 +1912,16 @@ struct Aligner {
 						{ const uint64_t t1_ = now(); const bool sr_ = sink_report(res); HOT.t_phase[19] += now() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
 						if (PRM.tighten > 0 && PRM.mhits > 0 && HOT.best2_unp1 != INT64_MIN) {
 							if (PRM.tighten == 1) {
-								if (HOT.best_unp1 >= minsc) {
-									minsc = HOT.best_unp1;
-									if (minsc < perfect && HOT.best_unp1 == HOT.best2_unp1) minsc++;
+								if (HOT.best_unp1 >= ST.minsc) {
+									ST.minsc = HOT.best_unp1;
+									if (ST.minsc < perfect && HOT.best_unp1 == HOT.best2_unp1) ST.minsc++;
 								}
 							} else if (PRM.tighten == 2) {
-								if (HOT.best2_unp1 >= minsc) { minsc = HOT.best2_unp1; if (minsc < perfect) minsc++; }
+								if (HOT.best2_unp1 >= ST.minsc) { ST.minsc = HOT.best2_unp1; if (ST.minsc < perfect) ST.minsc++; }
 							} else {
 								const int64_t diff = HOT.best_unp1 - HOT.best2_unp1;
 								const int64_t bot = HOT.best2_unp1 + ((diff * 3) / 4);
-								if (bot >= minsc) { minsc = bot; if (minsc < perfect) minsc++; }
+								if (bot >= ST.minsc) { ST.minsc = bot; if (ST.minsc < perfect) ST.minsc++; }
 							}
 						}
 					}
@@ -1960,12 +1956,12 @@ struct Aligner {
 		const uint64_t t_run0_ = now();
 		HOT.n_mm1 = 0; HOT.mm1_elt = 0; HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_offs = 0; HOT.num_elts = 0;
 		HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
-		minsc = RPR.minsc;
+		ST.minsc = RPR.minsc;
 		const bool filt = (RPR.filt & 15u) == 15u;
 		bool done = !filt;
 		const int64_t perfect = (int64_t)len * PRM.match_bonus;
 		if (!done) {
-			rnd.init(RPR.seed);
+			ST.rnd.init(RPR.seed);
 			const uint32_t interval = (uint32_t)RPR.interval;
 			uint32_t nrounds = (uint32_t)PRM.n_seed_rounds;
 			uint32_t mine[2] = {0, 0};
@@ -1977,13 +1973,13 @@ struct Aligner {
 					const int ret = extend_seeds(-1, 0, 0);
 					HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
 					handle_ret(ret, done);
-					if (!done && minsc == perfect) done = true;
+					if (!done && ST.minsc == perfect) done = true;
 				}
 			}
 			if (PRM.do_1mm_upfront) {
 				if (!done) {
-					const bool yfw = mine[0] <= 1 && !m_nofw;
-					const bool yrc = mine[1] <= 1 && !m_norc;
+					const bool yfw = mine[0] <= 1 && !ST.m_nofw;
+					const bool yrc = mine[1] <= 1 && !ST.m_norc;
 					nelt = 0;
 					if (yfw || yrc) {
 						const uint64_t t0_ = now();
@@ -1994,7 +1990,7 @@ struct Aligner {
 						const int ret = extend_seeds(-1, 0, 0);
 						HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 						handle_ret(ret, done);
-						if (!done && minsc == perfect) done = true;
+						if (!done && ST.minsc == perfect) done = true;
 					}
 				}
 				HOT.n_mm1 = 0; HOT.mm1_elt = 0;
@@ -2008,19 +2004,19 @@ struct Aligner {
 				const uint32_t offset = (interval * roundi) / nrounds;
 				if (offset > 0 && (uint32_t)RPR.seedlen + offset > len) continue;
 				const uint64_t ts_ = now();
-				ext_pre = false;
+				ST.ext_pre = false;
 				cache_reset();          // ca.nextRead() (bt2_search.cpp:3882)
 				uint32_t ninst;
 				if (PRM.seed_mms > 0) ninst = seed_round_mm1(offset, interval, (uint32_t)RPR.seedlen);
 				else if (offset == 0 && PRE && PRE->seeds && 1 + (len > (uint32_t)RPR.seedlen ? (len - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds) {
 					ninst = seed_round_pre(PRE->seeds, 0, interval, (uint32_t)RPR.seedlen);
-					ext_pre = PRE->ext != nullptr; pre_ext_cur = PRE->ext; pre_joff_cur = PRE->joff;
+					ST.ext_pre = PRE->ext != nullptr; ST.pre_ext_cur = PRE->ext; ST.pre_joff_cur = PRE->joff;
 				} else if (roundi > 0 && roundi < kMaxPreRounds && PRE && PRE->seeds_r[roundi] && 1 + (len > offset + (uint32_t)RPR.seedlen ? (len - offset - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds &&
-				           PRE->seeds_r[roundi][(uint64_t)ridx * 2 * PRE->max_seeds].topf != ~0ull) {
+				           PRE->seeds_r[roundi][(uint64_t)ST.ridx * 2 * PRE->max_seeds].topf != ~0ull) {
 					// a re-seeding round the batch kernels searched (they saw the same "previous round was repetitive" condition:
 					// a read only gets here when it held); a read with more seed positions than the tables hold searches them itself
 					ninst = seed_round_pre(PRE->seeds_r[roundi], offset, interval, (uint32_t)RPR.seedlen);
-					ext_pre = PRE->ext_r[roundi] != nullptr; pre_ext_cur = PRE->ext_r[roundi]; pre_joff_cur = PRE->joff_r[roundi];
+					ST.ext_pre = PRE->ext_r[roundi] != nullptr; ST.pre_ext_cur = PRE->ext_r[roundi]; ST.pre_joff_cur = PRE->joff_r[roundi];
 				} else ninst = seed_round(offset, interval, (uint32_t)RPR.seedlen);
 				HOT.t_phase[2] += now() - ts_;
 				if (ninst == 0) { done = true; HOT.nonz_tot = 0; continue; }
@@ -2032,7 +2028,7 @@ struct Aligner {
 			}
 		}
 		finish(out);
-		HOT.t_phase[11] = pf_steps; HOT.t_phase[12] = pf_tiles; HOT.t_phase[14] = pf_tile_t;
+		HOT.t_phase[11] = ST.pf_steps; HOT.t_phase[12] = ST.pf_tiles; HOT.t_phase[14] = ST.pf_tile_t;
 		HOT.t_phase[7] = now() - t_run0_;
 #ifdef BT2G_DEBUG_SATPOS
 		{
@@ -2040,7 +2036,7 @@ struct Aligner {
 			uint32_t k = 0;
 			dbg[k++] = HOT.n_satpos2;
 			for (uint32_t i = 0; i < HOT.n_satpos2 && k + 6 < 290; i++) {
-				const SatPos& s = w.satpos2[i];
+				const SatPos& s = WK.satpos2[i];
 				dbg[k++] = (uint32_t)s.topf; dbg[k++] = (uint32_t)s.topb; dbg[k++] = s.size; dbg[k++] = s.nlex; dbg[k++] = s.nrex; dbg[k++] = s.offidx * 2 + s.fw;
 			}
 		}
@@ -2075,34 +2071,34 @@ struct Aligner {
 		// selectByScore: sort (score, index) ascending, reverse, shuffle equal-score streaks
 		const uint32_t sz = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;
 		uint32_t num = nunpair1 < sz ? nunpair1 : sz;
-		uint32_t* idx = w.lists;      // scratch (Random1toN lists are dead by now)
+		uint32_t* idx = WK.lists;      // scratch (Random1toN lists are dead by now)
 		for (uint32_t i = 0; i < sz; i++) idx[i] = i;
 		for (uint32_t i = 1; i < sz; i++) {          // descending by (score, index)
 			const uint32_t v = idx[i];
 			uint32_t j = i;
-			while (j > 0 && (w.alns[idx[j - 1]].score < w.alns[v].score ||
-			                 (w.alns[idx[j - 1]].score == w.alns[v].score && idx[j - 1] < v))) { idx[j] = idx[j - 1]; j--; }
+			while (j > 0 && (WK.alns[idx[j - 1]].score < WK.alns[v].score ||
+			                 (WK.alns[idx[j - 1]].score == WK.alns[v].score && idx[j - 1] < v))) { idx[j] = idx[j - 1]; j--; }
 			idx[j] = v;
 		}
 		auto shuffle = [&](uint32_t begin, uint32_t n) {
 			if (n < 2) return;
 			uint32_t left = n;
 			for (uint32_t i = begin; i < begin + n - 1; i++) {
-				const uint64_t rndi = rnd.nextU64() % left;
+				const uint64_t rndi = ST.rnd.nextU64() % left;
 				if (rndi > 0) { const uint32_t t = idx[i]; idx[i] = idx[i + rndi]; idx[i + rndi] = t; }
 				left--;
 			}
 		};
 		uint32_t streak = 0;
 		for (uint32_t i = 1; i < sz; i++) {
-			if (w.alns[idx[i]].score == w.alns[idx[i - 1]].score) { if (streak == 0) streak = 1; streak++; }
+			if (WK.alns[idx[i]].score == WK.alns[idx[i - 1]].score) { if (streak == 0) streak = 1; streak++; }
 			else { if (streak > 1) shuffle(i - streak, streak); streak = 0; }
 		}
 		if (streak > 1) shuffle(sz - streak, streak);
-		out.best = w.alns[idx[0]].score;
-		if (sz > 1) { out.has_secbest = 1; out.secbest = w.alns[idx[1]].score; }
+		out.best = WK.alns[idx[0]].score;
+		if (sz > 1) { out.has_secbest = 1; out.secbest = WK.alns[idx[1]].score; }
 		out.nreport = num;
-		for (uint32_t i = 0; i < num; i++) Plat::copy_aln(out.alns[i], w.alns[idx[i]]);
+		for (uint32_t i = 0; i < num; i++) Plat::copy_aln(out.alns[i], WK.alns[idx[i]]);
 	}
 
 #include "bt2g_align_pe.inc"

@@ -21,6 +21,7 @@ __shared__ HotWork g_hot;    // one wavefront per workgroup: the hot per-read st
 __shared__ AlignParams g_P;
 __shared__ ReadParams g_rp;
 __shared__ PreComp g_pre;
+__shared__ AlState g_st;     // the worker's own state (Aligner has no data members)
 alignas(16) __shared__ unsigned char g_ix_raw[sizeof(DevIndex<uint64_t>) > sizeof(DevIndex<uint32_t>) ? sizeof(DevIndex<uint64_t>) : sizeof(DevIndex<uint32_t>)];
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -379,6 +380,11 @@ struct DevPlat {
 	static __device__ __forceinline__ const AlignParams& params() { return g_P; }
 	static __device__ __forceinline__ ReadParams& rparams() { return g_rp; }
 	static __device__ __forceinline__ const PreComp* pre() { return &g_pre; }
+	static __device__ __forceinline__ AlState& st() { return g_st; }
+	// the wave's work area in HBM.  (The reference is a generic one: accesses through it are flat_* instructions unless the site names the
+	// global address space itself -- gld / gst, bt2g_device.hpp -- as the hot loops do.  Neither __builtin_assume(!is_shared && !is_private)
+	// nor a cast through address_space(1) makes this compiler infer it, ROCm 7.2.)
+	static __device__ __forceinline__ Work& work() { return *g_st.wp; }
 	template <typename TOff> static __device__ __forceinline__ const DevIndex<TOff>& index() { return *reinterpret_cast<const DevIndex<TOff>*>(g_ix_raw); }
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
 	// The worker's control code computes the same value in every lane; uni() moves such a value into a
@@ -986,11 +992,11 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		g_rp = rparams[2 * r];
 		wave_fence();
 		Aligner<TOff, DevPlat>& al = *new (s_al) Aligner<TOff, DevPlat>(w, dp, 2 * r);
-		al.dp_main = dp; al.dp_opp = dp2;
-		al.pe_seq[0] = rd.d_seq + o0; al.pe_qual[0] = rd.d_qual + o0; al.pe_len[0] = len0;
-		al.pe_seq[1] = rd.d_seq + o1; al.pe_qual[1] = rd.d_qual + o1; al.pe_len[1] = len1;
-		al.pe_rp[0] = rparams[2 * r]; al.pe_rp[1] = rparams[2 * r + 1];
-		al.pe_pair = r;
+		g_st.dp_main = dp; g_st.dp_opp = dp2;
+		g_st.pe_seq[0] = rd.d_seq + o0; g_st.pe_qual[0] = rd.d_qual + o0; g_st.pe_len[0] = len0;
+		g_st.pe_seq[1] = rd.d_seq + o1; g_st.pe_qual[1] = rd.d_qual + o1; g_st.pe_len[1] = len1;
+		g_st.pe_rp[0] = rparams[2 * r]; g_st.pe_rp[1] = rparams[2 * r + 1];
+		g_st.pe_pair = r;
 		wave_fence();
 		al.run_pair(out0, out1);
 		wave_fence();

@@ -74,9 +74,9 @@ static void twin_align(bt2g_ctx* c, const DevIndex<TOff>& ix, const bt2g_reads* 
 			ReadResult& rr2 = *(ReadResult*)(resbuf.data() + rec_bytes);
 			g_rp = rp[i]; g_Pp = &P; g_ixp = &ix;
 			Aligner<TOff, HostPlat> al(*c->w, c->dp);
-			al.dp_main = c->dp; al.dp_opp = c->dp2;
-			for (int m = 0; m < 2; m++) { al.pe_seq[m] = seq(i + m); al.pe_qual[m] = qual(i + m); al.pe_len[m] = len(i + m); al.pe_rp[m] = rp[i + m]; }
-			al.pe_pair = 0;
+			g_st.dp_main = c->dp; g_st.dp_opp = c->dp2;
+			for (int m = 0; m < 2; m++) { g_st.pe_seq[m] = seq(i + m); g_st.pe_qual[m] = qual(i + m); g_st.pe_len[m] = len(i + m); g_st.pe_rp[m] = rp[i + m]; }
+			g_st.pe_pair = 0;
 			al.run_pair(rr1, rr2);
 			memcpy(results + (uint64_t)i * stride, &rr1, std::min<uint64_t>(stride, rec_bytes));
 			memcpy(results + (uint64_t)(i + 1) * stride, &rr2, std::min<uint64_t>(stride, rec_bytes));

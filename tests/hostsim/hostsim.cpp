@@ -22,6 +22,7 @@
 using namespace bt2g;
 
 static HotWork g_hot;
+static AlState g_st;
 static const AlignParams* g_Pp = nullptr;      // the control blocks the device keeps in LDS
 static ReadParams g_rp;
 static const void* g_ixp = nullptr;
@@ -32,6 +33,8 @@ struct HostPlat {
 	static const AlignParams& params() { return *g_Pp; }
 	static ReadParams& rparams() { return g_rp; }
 	static const PreComp* pre() { return nullptr; }
+	static AlState& st() { return g_st; }
+	static Work& work() { return *g_st.wp; }
 	template <typename TOff> static const DevIndex<TOff>& index() { return *reinterpret_cast<const DevIndex<TOff>*>(g_ixp); }
 	static uint64_t clock() { return 0; }
 	template <typename T> static T uni(T v) { return v; }
@@ -526,11 +529,11 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 			ReadResult& rr2 = *(ReadResult*)(resbuf.data() + rec_bytes);
 			g_rp = hb.rp[pi]; g_Pp = &P; g_ixp = &ix;
 			Aligner<TOff, HostPlat> al(*w, dp);
-			al.dp_main = dp; al.dp_opp = dp2;
-			al.pe_seq[0] = (const uint8_t*)r1.seq.data(); al.pe_qual[0] = (const uint8_t*)r1.qual.data(); al.pe_len[0] = (uint32_t)r1.seq.size();
-			al.pe_seq[1] = (const uint8_t*)r2.seq.data(); al.pe_qual[1] = (const uint8_t*)r2.qual.data(); al.pe_len[1] = (uint32_t)r2.seq.size();
-			al.pe_rp[0] = hb.rp[pi]; al.pe_rp[1] = hb.rp[pi + 1];
-			al.pe_pair = 0;
+			g_st.dp_main = dp; g_st.dp_opp = dp2;
+			g_st.pe_seq[0] = (const uint8_t*)r1.seq.data(); g_st.pe_qual[0] = (const uint8_t*)r1.qual.data(); g_st.pe_len[0] = (uint32_t)r1.seq.size();
+			g_st.pe_seq[1] = (const uint8_t*)r2.seq.data(); g_st.pe_qual[1] = (const uint8_t*)r2.qual.data(); g_st.pe_len[1] = (uint32_t)r2.seq.size();
+			g_st.pe_rp[0] = hb.rp[pi]; g_st.pe_rp[1] = hb.rp[pi + 1];
+			g_st.pe_pair = 0;
 			al.run_pair(rr1, rr2);
 			if (rr1.status || rr2.status) fprintf(stderr, "Warning: pair %s overflowed a fixed-capacity buffer (status %d, site %u %u)\n", r1.name.str().c_str(), rr1.status | rr2.status, rr1.pad2, rr2.pad2);
 			summ.add(rr1, rr2);
