@@ -1300,6 +1300,11 @@ struct Aligner {
 		// read, qualities and reference window as per-lane registers (4 bytes per lane per register): the step
 		// loop then reads them with v_readlane instead of going to LDS
 		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
+		// the first 64 frames of the backtrace's branch stack (DpNucFrame) live in the lanes of seven registers: a dead end pops its frame
+		// with v_readlane instead of a round trip to the arena (a candidate next to an earlier alignment's end tries a few branches, each a
+		// dead end within a cell or two, before it gives up); deeper frames go to WK.btstack
+		typename Plat::LaneReg sk0, sk1, sk2, sk3, sk4, sk5, sk6;
+		Plat::lanes_zero(sk0); Plat::lanes_zero(sk1); Plat::lanes_zero(sk2); Plat::lanes_zero(sk3); Plat::lanes_zero(sk4); Plat::lanes_zero(sk5); Plat::lanes_zero(sk6);
 		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
 		// the walk moves left from its start column by at most rows + gaps columns: three registers (768 columns) cover every window of an
 		// unpaired read from column 0 (rf_c0 = 0); only a candidate past column 767 of a wide opposite-mate window needs them re-based
@@ -1464,7 +1469,17 @@ struct Aligner {
 				if (!can_move_thru) {
 					if (nstack > 0) {
 						td = tile_len; ndir = 0;     // resume elsewhere: the tile is stale
-						const BtFrame& f = btstack[--nstack];
+						--nstack;
+						if (nstack < 64u) {
+							nned = Plat::lane(sk0, nstack);
+							const uint32_t cz_ = Plat::lane(sk1, nstack), rc_ = Plat::lane(sk2, nstack), g1_ = Plat::lane(sk3, nstack), g2_ = Plat::lane(sk4, nstack);
+							ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31);
+							row = rc_ & 0xffffu; col = rc_ >> 16;
+							gaps = g1_ & 0xffffu; read_gaps = g1_ >> 16; ref_gaps = g2_ & 0xffffu; ct = (int)(g2_ >> 16);
+							score = (int32_t)Plat::lane(sk5, nstack); ns = (int32_t)Plat::lane(sk6, nstack);
+							continue;
+						}
+						const BtFrame& f = btstack[nstack];
 						const uint32_t cz_ = Plat::uni(f.celsz);
 						ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31); nned = Plat::uni(f.nedsz);
 						row = Plat::uni((uint32_t)f.row); col = Plat::uni((uint32_t)f.col);
@@ -1481,10 +1496,17 @@ struct Aligner {
 				}
 				if (branch) {
 					if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { ovf(18); return false; }
-					BtFrame& f = btstack[nstack++];
-					f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
-					f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
-					f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
+					if (nstack < 64u) {
+						Plat::set_lane(sk0, nstack, nned); Plat::set_lane(sk1, nstack, ncells | (olap ? 0x80000000u : 0u)); Plat::set_lane(sk2, nstack, (row & 0xffffu) | (col << 16));
+						Plat::set_lane(sk3, nstack, (gaps & 0xffffu) | (read_gaps << 16)); Plat::set_lane(sk4, nstack, (ref_gaps & 0xffffu) | ((uint32_t)ct << 16));
+						Plat::set_lane(sk5, nstack, (uint32_t)score); Plat::set_lane(sk6, nstack, (uint32_t)ns);
+					} else {
+						BtFrame& f = btstack[nstack];
+						f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
+						f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
+						f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
+					}
+					nstack++;
 				}
 				if (ncells >= (uint32_t)(kMaxLen + 64)) { ovf(19); return false; }
 				olap |= in_core(row, col); ncells++;

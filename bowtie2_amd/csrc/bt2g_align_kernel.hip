@@ -62,6 +62,7 @@ __device__ __forceinline__ u16x2 p_min(u16x2 a, u16x2 b) { return __builtin_elem
 __device__ __forceinline__ u16x2 p_ne(u16x2 a, u16x2 b) { return p_min(a ^ b, p_splat(1)); }     // 1 where different, else 0
 __device__ __forceinline__ unsigned short s_subs(unsigned short a, unsigned short b) { return __builtin_elementwise_sub_sat(a, b); }
 __device__ __forceinline__ unsigned short s_max(unsigned short a, unsigned short b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t p_bits(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ u16x2 p_from(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 // (lo.y, hi.x): the pair one diagonal further along
@@ -100,9 +101,12 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 	const u16x2 rdoP = p_splat(rdgapo), rfoP = p_splat(P.rfgapo), rfeP = p_splat(P.rfgape);
 	const uint32_t npen_word = (uint32_t)P.n_pen & 0xffu;
 	auto cap = [](uint32_t v) -> unsigned short { return (unsigned short)(v > 1023u ? 1023u : v); };     // scores are <= 255: any larger decay is "to zero"
+	// The scan over the lanes' carries: E decays by D = 2RP * rdgape from one lane to the next, so with Y_l = carry_l + l * D the decayed
+	// maximum  max_{l' <= l} (carry_l' - (l - l') D)  is  (prefix-max of Y)_l - l * D  -- a PLAIN prefix maximum, whose DPP steps are
+	// single v_max_u32 instructions with a DPP operand (no subtraction between the move and the max).  No saturation is needed: the term
+	// l' = l alone keeps the maximum >= 0, and terms that would have saturated to 0 cannot win.
 	const uint32_t D = (uint32_t)N2 * (uint32_t)rdgape;
-	const unsigned short d1 = cap(D), d2 = cap(2 * D), d4 = cap(4 * D), d8 = cap(8 * D);
-	const unsigned short c15 = cap(((uint32_t)(lane & 15) + 1u) * D), c31 = cap((uint32_t)(lane > 31 ? lane - 31 : 0) * D);
+	const uint32_t lD = (uint32_t)lane * D, lDprev = lane ? lD - D : 0u;
 	u16x2 decP[RP];                           // decay of the carry-in on its way to each of the lane's diagonals
 #pragma unroll
 	for (int k = 0; k < RP; k++) decP[k] = p_make(cap((uint32_t)(2 * k) * (uint32_t)rdgape), cap((uint32_t)(2 * k + 1) * (uint32_t)rdgape));
@@ -150,14 +154,15 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 					e0[c] = carry;
 					carry = s_max(s_subs(carry, (unsigned short)rdgape), (c & 1) ? u.y : u.x);
 				}
-				uint32_t X = carry;
-				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppRowShr + 1, 0xf>(X), d1));
-				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppRowShr + 2, 0xf>(X), d2));
-				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppRowShr + 4, 0xf>(X), d4));
-				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppRowShr + 8, 0xf>(X), d8));
-				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppBcast15, 0xa>(X), c15));
-				X = s_max((unsigned short)X, s_subs((unsigned short)dpp0<kDppBcast31, 0xc>(X), c31));
-				const u16x2 einP = p_splat((int)dpp0<kDppWaveShr1, 0xf>(X));
+				uint32_t Y = (uint32_t)carry + lD;
+				Y = umax32(Y, dpp0<kDppRowShr + 1, 0xf>(Y));
+				Y = umax32(Y, dpp0<kDppRowShr + 2, 0xf>(Y));
+				Y = umax32(Y, dpp0<kDppRowShr + 4, 0xf>(Y));
+				Y = umax32(Y, dpp0<kDppRowShr + 8, 0xf>(Y));
+				Y = umax32(Y, dpp0<kDppBcast15, 0xa>(Y));
+				Y = umax32(Y, dpp0<kDppBcast31, 0xc>(Y));
+				const uint32_t Pprev = dpp0<kDppWaveShr1, 0xf>(Y);      // prefix maximum up to the previous lane (0 into lane 0)
+				const u16x2 einP = p_splat((int)(lane ? Pprev - lDprev : 0u));
 #pragma unroll
 				for (int k = 0; k < RP; k++) EP[k] = p_max(p_make(e0[2 * k], e0[2 * k + 1]), p_subs(einP, decP[k]));
 			} else {
@@ -697,6 +702,12 @@ struct DevPlat {
 	// A value per lane, kept in a vector register; lane(r, i) reads lane i's copy into a scalar register.
 	using LaneReg = uint32_t;
 	static __device__ __forceinline__ uint32_t lane(LaneReg r, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane((int)r, (int)uni(i)); }
+	static __device__ __forceinline__ void set_lane(LaneReg& r, uint32_t i, uint32_t v) {
+		// (this clang has no __builtin_amdgcn_writelane; value and lane select are wave-uniform, i.e. scalar registers)
+		// (gfx9 allows one scalar register per VALU instruction on the constant bus: the lane select goes through M0)
+		asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(uni(v)), "s"(uni(i)) : "m0");
+	}
+	static __device__ __forceinline__ void lanes_zero(LaneReg& r) { r = 0; }
 	// lane i <- the 4 bytes at base[(word0 + i) * 4 ...] (0 past the end of the array); base is an LDS array
 	static __device__ __forceinline__ LaneReg lanes_load(const uint8_t* base, uint32_t nbytes, uint32_t word0) {
 		const uint32_t wd = word0 + (threadIdx.x & 63);

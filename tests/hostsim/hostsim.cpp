@@ -94,6 +94,8 @@ struct HostPlat {
 	}
 	struct LaneReg { uint32_t v[64]; };
 	static uint32_t lane(const LaneReg& r, uint32_t i) { return r.v[i]; }
+	static void set_lane(LaneReg& r, uint32_t i, uint32_t v) { r.v[i] = v; }
+	static void lanes_zero(LaneReg& r) { memset(r.v, 0, sizeof(r.v)); }
 	static LaneReg lanes_load(const uint8_t* base, uint32_t nbytes, uint32_t word0) {
 		LaneReg r;
 		for (uint32_t l = 0; l < 64; l++) {
