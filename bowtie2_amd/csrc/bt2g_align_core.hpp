@@ -102,7 +102,8 @@ struct Aligner {
 	BT2_HD bool cache_page() { CacheModel& c = HOT.cm; if (c.pool_used == c.pool_total) return false; c.pool_used++; return true; }
 	// Seeds of the round in HOT.hits (size = what the search found) -> what SeedResults ends up holding: hits of dropped seeds
 	// cleared, esize set, tallies (nonz_*, num_elts) formed.  Exact seeds only: a -N 1 round is tallied unmodelled.
-	BT2_HDN void cache_filter(uint32_t interval, uint32_t offset, uint32_t seedlen) {
+	BT2_HDN void cache_filter(uint32_t interval_, uint32_t offset_, uint32_t seedlen_) {
+		const uint32_t interval = Plat::uni(interval_), offset = Plat::uni(offset_), seedlen = Plat::uni(seedlen_);
 		CacheModel& c = HOT.cm;
 		const uint32_t len = HOT.len, L = seedlen < len ? seedlen : len;
 		constexpr uint32_t q_per = sizeof(TOff) == 4 ? 256u : 227u;     // 16 KB / sizeof(RedBlackNode<QKey,QVal>)  (64 / 72 bytes)
@@ -304,7 +305,8 @@ struct Aligner {
 
 	// One -N 0 seeding round: Seed::mmSeeds + instantiateSeeds + searchAllSeeds
 	// (aligner_seed.cpp:498-720,1638-2037).  Returns # instantiated seeds.
-	BT2_HDN uint32_t seed_round(uint32_t offset, uint32_t interval, uint32_t seedlen) {
+	BT2_HDN uint32_t seed_round(uint32_t offset_, uint32_t interval_, uint32_t seedlen_) {
+		const uint32_t interval = Plat::uni(interval_), offset = Plat::uni(offset_), seedlen = Plat::uni(seedlen_);
 		const uint32_t len = HOT.len;
 		uint32_t L = seedlen < len ? seedlen : len;
 		uint32_t nseeds = 1;
@@ -765,7 +767,8 @@ struct Aligner {
 	}
 
 	// SwDriver::eeSaTups (aligner_sw_driver.cpp:66-291)
-	BT2_HDN void ee_sa_tups(uint64_t& nelt_out, uint64_t maxelt) {
+	BT2_HDN void ee_sa_tups(uint64_t& nelt_out, uint64_t maxelt_) {
+		const uint64_t maxelt = Plat::uni(maxelt_);
 		HOT.n_satpos = 0;
 		HOT.lists_used = 0;
 		nelt_out = 0;
@@ -848,7 +851,9 @@ struct Aligner {
 	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? HOT.exact[0] : (idx == -3 ? HOT.exact[1] : WK.mm1[idx]); }
 
 	// SwDriver::prioritizeSATupsRands (aligner_sw_driver.cpp:492-738)
-	BT2_HDN void prioritize(int seedmms, uint64_t maxelt, uint64_t& nelt_out) {
+	BT2_HDN void prioritize(int seedmms_, uint64_t maxelt_, uint64_t& nelt_out) {
+		const int seedmms = Plat::uni(seedmms_);
+		const uint64_t maxelt = Plat::uni(maxelt_);
 		const uint32_t nsm = 5;
 		HOT.n_satpos = 0; HOT.n_satpos2 = 0; HOT.lists_used = 0;
 		uint64_t nrange = 0, nelt = 0, nsmall = 0, nsmall_elts = 0;
@@ -1160,7 +1165,12 @@ struct Aligner {
 	BT2_HD uint16_t& mask_at(uint32_t row, uint32_t col, uint32_t cols) { return ST.dp.masks[(uint64_t)row * cols + col]; }
 
 	// gatherCellsNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:1176-1208) + btncand_.sort()
-	BT2_HDN void gather_cells(bool fw, uint32_t rows, uint32_t cols, int64_t minsc_dp, int mode, uint32_t lastsolcol) {
+	BT2_HDN void gather_cells(bool fw_, uint32_t rows_, uint32_t cols_, int64_t minsc_dp_, int mode_, uint32_t lastsolcol_) {
+		// (arguments of a real call are lane-varying to the compiler: say that they are not, see DevPlat::dp_fill_ee)
+		const bool fw = Plat::uni((int)fw_) != 0;
+		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_), lastsolcol = Plat::uni(lastsolcol_);
+		const int64_t minsc_dp = Plat::uni(minsc_dp_);
+		const int mode = Plat::uni(mode_);
 		const uint32_t R = dp_R(rows);
 		HOT.n_cands = 0; HOT.cural = 0;
 		const uint64_t tl_ = now();
@@ -1710,8 +1720,9 @@ struct Aligner {
 	// =================================================================================
 	// F. SwDriver::extendSeeds (aligner_sw_driver.cpp:921-1494)
 	// =================================================================================
-	BT2_HDN int extend_seeds(int seedmms, int seedlen, int seedival) {
+	BT2_HDN int extend_seeds(int seedmms_, int seedlen, int seedival) {
 		(void)seedlen; (void)seedival;
+		const int seedmms = Plat::uni(seedmms_);
 		const uint32_t rdlen = HOT.len;
 		const int64_t perfect = (int64_t)rdlen * PRM.match_bonus;       // Scoring::perfectScore: 0 end to end
 		const uint32_t nsm = 5;

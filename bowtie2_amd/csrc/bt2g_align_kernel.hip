@@ -457,8 +457,10 @@ struct DevPlat {
 	// out[] <- the values of [0, n) that are not in seen[0..nseen), ascending (the swap list a Random1toN converts to).
 	// 2048 values per pass: lane l keeps bitmap word l of the pass (built from the seen list, which every lane walks through
 	// register broadcasts), then 64 values at a time are tested and compacted with ballot / popcount.
-	static __device__ __attribute__((noinline)) void unseen_list(const uint32_t* seen, uint32_t nseen, uint32_t n, uint32_t* out) {
+	static __device__ __attribute__((noinline)) void unseen_list(const uint32_t* seen_, uint32_t nseen_, uint32_t n_, uint32_t* out_) {
 		wave_fence();
+		const uint32_t* seen = uni_ptr(seen_); uint32_t* out = uni_ptr(out_);
+		const uint32_t nseen = uni(nseen_), n = uni(n_);
 		const uint32_t lane = threadIdx.x & 63;
 		uint32_t count = 0;
 		for (uint32_t p0 = 0; p0 < n; p0 += 2048) {
@@ -758,9 +760,14 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)ref_base_at(ref, tidx, rfi + (int64_t)i, rec0);
 		wave_fence();
 	}
-	static __device__ __attribute__((noinline)) int64_t dp_fill_local(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat,
-	                                                                  int64_t minsc, uint32_t& lastsolcol, uint32_t& sat8) {
+	static __device__ __attribute__((noinline)) int64_t dp_fill_local(const AlignParams&, Work& w, bool fw_, uint32_t rows_, uint32_t cols_, uint32_t* mat_,
+	                                                                  int64_t minsc_, uint32_t& lastsolcol, uint32_t& sat8) {
 		wave_fence();
+		const AlignParams& P = g_P;
+		const bool fw = uni((int)fw_) != 0;
+		const uint32_t rows = uni(rows_), cols = uni(cols_);
+		const int64_t minsc = uni(minsc_);
+		uint32_t* mat = uni_ptr(mat_);
 		uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
 		const int ms = minsc > 0x7fff ? 0x7fff : (int)minsc;
 		int best;
@@ -781,8 +788,12 @@ struct DevPlat {
 	// Candidate cells of a local fill (gatherCellsNucleotidesLocalSseU8), ordered score desc, row desc, col desc.
 	// Lanes scan columns; a counting sort on the score places each candidate in its score bucket, then every bucket
 	// (a handful of cells) is ordered by insertion.  hist: 2 * kMaxLocalScore + 2 words of per-wave scratch.
-	static __device__ __attribute__((noinline)) uint32_t gather_local(const uint32_t* mat, BtCand* cands, uint32_t cap, bool fw, uint32_t R, uint32_t rows,
-	                                                                  uint32_t ncol, int64_t minsc, uint32_t minrow, uint32_t* hist) {
+	static __device__ __attribute__((noinline)) uint32_t gather_local(const uint32_t* mat_, BtCand* cands_, uint32_t cap_, bool fw_, uint32_t R_, uint32_t rows_,
+	                                                                  uint32_t ncol_, int64_t minsc_, uint32_t minrow_, uint32_t* hist_) {
+		const uint32_t* mat = uni_ptr(mat_); BtCand* cands = uni_ptr(cands_); uint32_t* hist = uni_ptr(hist_);
+		const bool fw = uni((int)fw_) != 0;
+		const uint32_t cap = uni(cap_), R = uni(R_), rows = uni(rows_), ncol = uni(ncol_), minrow = uni(minrow_);
+		const int64_t minsc = uni(minsc_);
 		const uint64_t* m64 = reinterpret_cast<const uint64_t*>(mat);
 		const uint32_t lane = threadIdx.x & 63;
 		const uint32_t nb = (uint32_t)kMaxLocalScore + 1;
@@ -840,9 +851,18 @@ struct DevPlat {
 		return total;
 	}
 	// returns the best last-row score (de-biased)
-	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, const DpScratch& dp, bool wide, int64_t minsc) {
+	// (Arguments of a real call arrive in vector registers and a load through a generic reference could be a per-lane scratch access: the
+	// compiler must treat both as lane-varying, and every loop bound or condition derived from them becomes exec-mask control flow and
+	// vector arithmetic.  So: the parameter block and the scratch descriptor are read from their LDS objects BY NAME, the scalar arguments
+	// go through v_readfirstlane once.)
+	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams&, Work& w, bool fw_, uint32_t rows_, uint32_t cols_, const DpScratch&, bool wide_, int64_t minsc_) {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
-		uint32_t* mat = dp.mat;
+		const AlignParams& P = g_P;
+		const DpScratch& dp = g_st.dp;
+		const bool fw = uni((int)fw_) != 0, wide = uni((int)wide_) != 0;
+		const uint32_t rows = uni(rows_), cols = uni(cols_);
+		const int64_t minsc = uni(minsc_);
+		uint32_t* mat = uni_ptr(dp.mat);
 		int best;
 		if (!wide) {
 			uint8_t* pm = reinterpret_cast<uint8_t*>(mat);
