@@ -312,10 +312,10 @@ struct Work {
 //  * 16-bit end-to-end and local mode: wavefront-major packed H|E|F cells (dp_cell) + a 16-bit mask plane that is zeroed
 //    after every fill that has candidate cells.
 struct DpScratch {
-	uint32_t* mat;      // pred bytes (8-bit end-to-end) or packed cells
-	uint16_t* masks;    // [rows][cols] masks of the packed-cell formats
-	uint32_t* pmask;    // masks of the pred format: bits 0-12 as SSEMatrix::masks_, bits 13-31 = epoch of the DP that wrote them
-	uint32_t* epoch;    // -> [0] epoch of the DP currently in this scratch (lives in the arena, survives launches), [1] band lo, [2] band row width
+	BT2_G uint32_t* mat;      // pred bytes (8-bit end-to-end) or packed cells
+	BT2_G uint16_t* masks;    // [rows][cols] masks of the packed-cell formats
+	BT2_G uint32_t* pmask;    // masks of the pred format: bits 0-12 as SSEMatrix::masks_, bits 13-31 = epoch of the DP that wrote them
+	BT2_G uint32_t* epoch;    // -> [0] epoch of the DP currently in this scratch (lives in the arena, survives launches), [1] band lo, [2] band row width
 	uint32_t  pmask_words;
 };
 // predecessor bits of one cell (aligner_swsse_ee_u8.cpp:1330-1520 asks these questions during the backtrace):
@@ -357,25 +357,25 @@ BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { uint32_t rp = ee_band
 // The worker's own state (what used to be the data members of Aligner).  On the device ONE instance per wavefront lives in LDS and is
 // reached by name (Plat::st()), never through a pointer: see the note at ST in bt2g_align_core.hpp.
 struct AlState {
-	Work*     wp;            // the wave's work area in HBM
+	BT2_G Work* wp;          // the wave's work area in HBM
 	DpScratch dp;            // the DP scratch in use (pairs: dp_main or dp_opp)
 	Rng       rnd;
 	int64_t   minsc;         // current (possibly tightened) minimum score
 	uint32_t  ridx;          // index of this read in the batch
 	bool      ext_pre;       // HOT.hits came from pre->seeds, so pre->ext holds their extensions
-	const uint32_t* pre_ext_cur;      // extension / resolved-offset tables of the seed round in HOT.hits
-	const uint64_t* pre_joff_cur;
+	const BT2_G uint32_t* pre_ext_cur;      // extension / resolved-offset tables of the seed round in HOT.hits
+	const BT2_G uint64_t* pre_joff_cur;
 	uint32_t  pf_steps, pf_tiles;     // profile: backtrace steps / tile fetches of this read
 	uint64_t  pf_tile_t;
 	uint8_t   m_nofw, m_norc;         // --nofw / --norc as they apply to the loaded read (mate 2 of an --fr pair sees them swapped)
 	// ---- pairs (bt2g_align_pe.inc); inputs set by the launcher before run_pair ----
-	const uint8_t* pe_seq[2];
-	const uint8_t* pe_qual[2];
+	const BT2_G uint8_t* pe_seq[2];
+	const BT2_G uint8_t* pe_qual[2];
 	uint32_t  pe_len[2];
 	ReadParams pe_rp[2];
 	int64_t   pe_minsc[2];
 	DpScratch dp_main, dp_opp;        // anchor / opposite-mate matrices (dp selects the one in use)
-	BtCand*   cands_cur;              // candidate list in use (Work::cands, or Work::cands2 during an opposite-mate DP)
+	BT2_G BtCand* cands_cur;          // candidate list in use (Work::cands, or Work::cands2 during an opposite-mate DP)
 	uint32_t  pe_streak;
 	uint32_t  pe_pair;                // index of the pair in the batch (reads 2*pe_pair, 2*pe_pair + 1)
 };

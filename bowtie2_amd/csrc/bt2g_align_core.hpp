@@ -32,7 +32,7 @@ struct Aligner {
 #define WK (Plat::work())
 	static constexpr TOff kOffMask = (TOff)OffTraits<TOff>::kMask;
 
-	BT2_HD Aligner(Work& w_, DpScratch dp_, uint32_t ridx_ = 0) {
+	BT2_HD Aligner(BT2_G Work& w_, DpScratch dp_, uint32_t ridx_ = 0) {
 		ST.wp = &w_; ST.dp = dp_; ST.ridx = ridx_; ST.ext_pre = false; ST.pre_ext_cur = nullptr; ST.pre_joff_cur = nullptr;
 		ST.pf_steps = ST.pf_tiles = 0; ST.pf_tile_t = 0;
 		ST.m_nofw = PRM.nofw != 0; ST.m_norc = PRM.norc != 0; ST.cands_cur = w_.cands;
@@ -296,7 +296,7 @@ struct Aligner {
 
 	BT2_HD void add_mm1(const Mm1Hit& m, bool fw) {
 		if (HOT.n_mm1 >= (uint32_t)kMaxMm1) { ovf(2); return; }
-		EEHit& h = WK.mm1[HOT.n_mm1++];
+		BT2_G EEHit& h = WK.mm1[HOT.n_mm1++];
 		h.top = m.top; h.bot = m.bot; h.score = m.score;
 		h.epos = m.epos; h.echr = m.echr; h.eqchr = m.eqchr;
 		h.fw = fw ? 1 : 0; h.has_edit = 1;
@@ -412,7 +412,7 @@ struct Aligner {
 				uint64_t elts = 0;
 				auto report = [&](TOff topf, TOff botf, TOff topb) {
 					if (nsr >= (uint32_t)kMaxSat2) { ovf(5); return; }
-					SeedRange& r = WK.sranges[nsr++];
+					BT2_G SeedRange& r = WK.sranges[nsr++];
 					r.topf = topf; r.topb = topb; r.size = (uint32_t)(botf - topf);
 					elts += (uint64_t)(botf - topf);
 				};
@@ -582,7 +582,7 @@ struct Aligner {
 	// =================================================================================
 	// B. Random1toN / RowSampler
 	// =================================================================================
-	BT2_HD void r1n_init(R1N& r, uint32_t n, bool without_replacement) {
+	BT2_HD void r1n_init(BT2_G R1N& r, uint32_t n, bool without_replacement) {
 		r.sz = r.n = n;
 		r.converted = 0;
 		r.swaplist = (n < 128 || without_replacement) ? 1 : 0;
@@ -592,17 +592,18 @@ struct Aligner {
 		r.thresh = th > 16 ? th : 16;
 		r.inited = 1;
 	}
-	BT2_HD void r1n_reset(R1N& r) { r.sz = r.n = r.cur = 0; r.swaplist = r.converted = 0; r.list_len = r.seen_len = 0; r.thresh = 0; r.inited = 0; }
-	BT2_HD bool r1n_done(const R1N& r) const { return r.n > 0 && r.cur >= r.n; }
-	BT2_HD void r1n_set_done(R1N& r) { r.cur = r.n; }
-	BT2_HD void r1n_init_seq(R1N& r, uint32_t n) { r1n_reset(r); r.sz = r.n = n; r.swaplist = 2; r.inited = 1; }
+	BT2_HD void r1n_reset(BT2_G R1N& r) { r.sz = r.n = r.cur = 0; r.swaplist = r.converted = 0; r.list_len = r.seen_len = 0; r.thresh = 0; r.inited = 0; }
+	BT2_HD bool r1n_done(const BT2_G R1N& r) const { return r.n > 0 && r.cur >= r.n; }
+	BT2_HD void r1n_set_done(BT2_G R1N& r) { r.cur = r.n; }
+	BT2_HD void r1n_init_seq(BT2_G R1N& r, uint32_t n) { r1n_reset(r); r.sz = r.n = n; r.swaplist = 2; r.inited = 1; }
 	BT2_HD uint32_t lists_alloc(uint32_t n) {
 		if (HOT.lists_used + n > (uint32_t)kListArena) { ovf(7); return 0; }
 		const uint32_t o = HOT.lists_used;
 		HOT.lists_used += n;
 		return o;
 	}
-	BT2_HDN uint32_t r1n_next(R1N& r) {
+	BT2_HDN uint32_t r1n_next(BT2_G R1N& r_) {
+		BT2_G R1N& r = *Plat::uni_ptr(&r_);      // (a call argument: lane-varying to the compiler unless told otherwise)
 		if (r.swaplist == 2) return r.cur++;          // -d: rows in index order (currIdx++, aligner_sw_driver.cpp:1120)
 		if (r.cur == 0 && !r.converted) {
 			if (r.n == 1) { r.cur = 1; return 0; }
@@ -614,7 +615,7 @@ struct Aligner {
 		}
 		if (r.swaplist) {
 			const uint32_t rr = r.cur + (ST.rnd.nextU32() % (r.n - r.cur));
-			uint32_t* l = WK.lists + r.list_off;
+			BT2_G uint32_t* l = WK.lists + r.list_off;
 			if (rr != r.cur) { const uint32_t tmp = l[r.cur]; l[r.cur] = l[rr]; l[rr] = tmp; }
 			return l[r.cur++];
 		}
@@ -622,7 +623,7 @@ struct Aligner {
 		// the seen list can never hold more entries than rows are drawn for one read (max_iters), however large the range:
 		// a 100 000-row repeat range has thresh = 10 000 but is asked for a few hundred rows at most
 		if (r.seen_len == 0 && r.cur == 0) { const uint32_t cap = (uint32_t)PRM.max_iters + 2; r.seen_off = lists_alloc(r.thresh + 1 < cap ? r.thresh + 1 : cap); }
-		uint32_t* seen = WK.lists + r.seen_off;
+		BT2_G uint32_t* seen = WK.lists + r.seen_off;
 		const uint32_t seen_sz = r.seen_len;
 		uint32_t rn = 0;
 		bool again = true;
@@ -645,7 +646,7 @@ struct Aligner {
 			const uint32_t nl = r.n - r.cur;
 			r.list_off = lists_alloc(nl);
 			r.list_len = nl;
-			uint32_t* l = WK.lists + r.list_off;
+			BT2_G uint32_t* l = WK.lists + r.list_off;
 			uint32_t prev = 0, cur = 0;
 			for (uint32_t i = 0; i <= seen_sz; i++) {
 				for (uint32_t j = prev; j < seen[i]; j++) l[cur++] = j;
@@ -676,7 +677,7 @@ struct Aligner {
 	// both, and its counters, out of LDS for the whole loop: every LDS access of the draw is a round trip the next instruction
 	// waits for, and they used to be ~40 per draw).
 	BT2_HD uint32_t r1c_next(R1C& r, Rng& g) {
-		uint32_t* const lists = WK.lists;
+		BT2_G uint32_t* const lists = WK.lists;
 		uint32_t ret;
 		const bool first = r.cur == 0 && !r.converted;
 		if (first && r.n == 1) { r.cur = 1; ret = 0; }
@@ -716,16 +717,16 @@ struct Aligner {
 	// Entry i of the extension list for the consumer loops: whole records as they are, sampled rows expanded into WK.sp_view
 	// (satpos_commit() remembers that the row has been taken)
 	BT2_HD bool satpos_taken(uint32_t i) const { return i >= HOT.n_satpos_full && WK.srows[i - HOT.n_satpos_full].done != 0; }
-	BT2_HD SatPos& satpos_view(uint32_t i) {
+	BT2_HD BT2_G SatPos& satpos_view(uint32_t i) {
 		if (i < HOT.n_satpos_full) return WK.satpos[i];
 		const SampRow sr = WK.srows[i - HOT.n_satpos_full];
-		SatPos& s = WK.sp_view;
+		BT2_G SatPos& s = WK.sp_view;
 		Plat::copy_words(&s, &WK.satpos2[sr.src], (uint32_t)(sizeof(SatPos) / 4));
 		s.topf = sr.topf; s.topb = (uint64_t)kOffMask; s.size = 1;
 		r1n_init(s.rnd, 1, PRM.all_hits != 0);
 		return s;
 	}
-	BT2_HD void satpos_commit(uint32_t i, const SatPos& sp) { if (i >= HOT.n_satpos_full) WK.srows[i - HOT.n_satpos_full].done = r1n_done(sp.rnd) ? 1u : 0u; }
+	BT2_HD void satpos_commit(uint32_t i, const BT2_G SatPos& sp) { if (i >= HOT.n_satpos_full) WK.srows[i - HOT.n_satpos_full].done = r1n_done(sp.rnd) ? 1u : 0u; }
 
 	// =================================================================================
 	// C. seed-hit extension bookkeeping
@@ -751,7 +752,7 @@ struct Aligner {
 	}
 
 	// SATupleAndPos::operator< (aligner_sw_driver.h:150-160)
-	BT2_HD static bool satpos_less(const SatPos& a, const SatPos& o) {
+	template <typename SA, typename SB> BT2_HD static bool satpos_less(const SA& a, const SB& o) {
 		if (a.size < o.size) return true;
 		if (a.size > o.size) return false;
 		if (a.topf < o.topf) return true;
@@ -777,7 +778,7 @@ struct Aligner {
 		bool done = false;
 		auto add = [&](const EEHit& hit, int ee_idx, uint64_t top, uint64_t width) {
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(8); done = true; return; }
-			SatPos& s = WK.satpos[HOT.n_satpos++];
+			BT2_G SatPos& s = WK.satpos[HOT.n_satpos++];
 			s.topf = top; s.topb = (uint64_t)kOffMask; s.size = (uint32_t)width; s.orig_sz = (uint32_t)width;
 			s.fw = hit.fw; s.offidx = 0; s.rdoff = 0; s.seedlen = HOT.len; s.nlex = s.nrex = 0;
 			s.ee = ee_idx;
@@ -848,7 +849,7 @@ struct Aligner {
 		HOT.n_satpos_full = HOT.n_resolved = HOT.n_satpos;
 	}
 
-	BT2_HD const EEHit& ee_hit(int idx) const { return idx == -2 ? HOT.exact[0] : (idx == -3 ? HOT.exact[1] : WK.mm1[idx]); }
+	BT2_HD EEHit ee_hit(int idx) const { if (idx == -2) return HOT.exact[0]; if (idx == -3) return HOT.exact[1]; return WK.mm1[idx]; }      // (a copy: the exact hits live in LDS, the 1-mismatch hits in HBM)
 
 	// SwDriver::prioritizeSATupsRands (aligner_sw_driver.cpp:492-738)
 	BT2_HDN void prioritize(int seedmms_, uint64_t maxelt_, uint64_t& nelt_out) {
@@ -867,7 +868,7 @@ struct Aligner {
 			const uint32_t nr_here = seedmms > 0 ? (uint32_t)h.topb : 1u;      // ca.queryQval: one SATuple per reference string
 			for (uint32_t ri = 0; ri < nr_here; ri++) {
 			uint64_t h_topf = h.topf, h_topb = h.topb, sz = h.esize;      // the range as the seed cache holds it
-			if (seedmms > 0) { const SeedRange& sr = WK.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.size; }
+			if (seedmms > 0) { const BT2_G SeedRange& sr = WK.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.size; }
 			else if (sz == 0) continue;
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
@@ -883,7 +884,7 @@ struct Aligner {
 				if (skip) { nrange--; nelt -= sz; continue; }
 			}
 			if (HOT.n_satpos2 >= (uint32_t)kMaxSat2) { ovf(9); break; }
-			SatPos& s = WK.satpos2[HOT.n_satpos2++];
+			BT2_G SatPos& s = WK.satpos2[HOT.n_satpos2++];
 			s.topf = h_topf; s.topb = h_topb; s.size = (uint32_t)sz; s.orig_sz = (uint32_t)sz;
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
@@ -931,7 +932,7 @@ struct Aligner {
 			uint64_t added = 0;
 			for (uint32_t j = 0; j < HOT.n_satpos2 && added < maxelt; j++) {
 				if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(11); break; }
-				SatPos& s = WK.satpos[HOT.n_satpos++];
+				BT2_G SatPos& s = WK.satpos[HOT.n_satpos++];
 				s = WK.satpos2[j];
 				r1n_init_seq(s.rnd, s.size);
 				added += s.size;
@@ -944,7 +945,7 @@ struct Aligner {
 		// 1. the smalls, whole
 		for (uint64_t j = 0; j < nsmall && nelt_added < maxelt; j++) {
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(12); break; }
-			SatPos& s = WK.satpos[HOT.n_satpos++];
+			BT2_G SatPos& s = WK.satpos[HOT.n_satpos++];
 			s = WK.satpos2[j];
 			r1n_init(s.rnd, s.size, PRM.all_hits != 0);
 			nelt_added += s.size;
@@ -981,8 +982,8 @@ struct Aligner {
 			double mass = HOT.mass;
 			uint32_t n_satpos = HOT.n_satpos;
 			const uint32_t n_full = HOT.n_satpos_full, n_masses = HOT.n_masses;
-			SampRow* const srows = WK.srows;
-			const SatPos* const sat2 = WK.satpos2;
+			BT2_G SampRow* const srows = WK.srows;
+			const BT2_G SatPos* const sat2 = WK.satpos2;
 			const bool all_hits = PRM.all_hits != 0;
 			uint64_t draws = 0;
 			bool full = false;
@@ -1001,7 +1002,7 @@ struct Aligner {
 					rebuild();
 				}
 				if (n_satpos >= (uint32_t)kMaxSatpos) { full = true; break; }
-				SampRow* const sr = &srows[n_satpos - n_full];
+				BT2_G SampRow* const sr = &srows[n_satpos - n_full];
 				n_satpos++;
 				gst(&sr->topf, (uint64_t)(r2.topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
 				nelt_added++;
@@ -1025,12 +1026,12 @@ struct Aligner {
 			}
 			if (pick == 0xffffffffu) pick = last_unelim;
 			const uint32_t ri = pick + sai;
-			R1N& r2 = WK.rands2[ri];
+			BT2_G R1N& r2 = WK.rands2[ri];
 			if (!r2.inited) r1n_init(r2, WK.satpos2[ri].size, PRM.all_hits != 0);
 			const uint32_t r = r1n_next(r2);
 			if (r1n_done(r2)) { WK.elim[ri - sai] = 1; HOT.mass -= WK.masses[ri - sai]; }
 			if (HOT.n_satpos >= (uint32_t)kMaxSatpos) { ovf(13); break; }
-			SampRow* const sr = &WK.srows[HOT.n_satpos - HOT.n_satpos_full];
+			BT2_G SampRow* const sr = &WK.srows[HOT.n_satpos - HOT.n_satpos_full];
 			HOT.n_satpos++;
 			gst(&sr->topf, (uint64_t)(WK.satpos2[ri].topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
 			nelt_added++;
@@ -1049,18 +1050,18 @@ struct Aligner {
 	}
 	BT2_HD void diag_add_m(int32_t ref, int64_t off, bool fw, int64_t len, int mate) {
 		if (HOT.n_diags >= (uint32_t)kMaxDiags) { ovf(14); return; }
-		DiagIval& d = WK.diags[HOT.n_diags++];
+		BT2_G DiagIval& d = WK.diags[HOT.n_diags++];
 		d.ref = ref; d.off = off; d.orient = (fw ? 1 : 0) | (mate << 1); d.len = len;
 	}
 
 	// RedundantAlns cell enumeration (aligner_result.cpp:929-1032): per read row, the half-open
 	// column range [left,right) the alignment occupies, edits taken WK.r.t. the upstream end.
 	struct RowIt {
-		const AlnRes& r;
+		const BT2_G AlnRes& r;
 		uint32_t n, nedidx, i, end;
 		int64_t left;
 		bool fw;
-		BT2_HD explicit RowIt(const AlnRes& r_) : r(r_) {
+		BT2_HD explicit RowIt(const BT2_G AlnRes& r_) : r(r_) {
 			fw = r.fw != 0; n = r.nned; nedidx = 0;
 			i = fw ? r.trim5p : r.trim3p;           // trimmedLeft(true)
 			end = i + r.rdextent;                   // readExtentRows()
@@ -1088,7 +1089,7 @@ struct Aligner {
 	};
 
 	// conservative bounds on (column - row) over the cells of r
-	BT2_HD void diag_bounds(const AlnRes& r, int64_t& dmin, int64_t& dmax) const {
+	BT2_HD void diag_bounds(const BT2_G AlnRes& r, int64_t& dmin, int64_t& dmax) const {
 		const int64_t d0 = r.refoff - (int64_t)(r.fw ? r.trim5p : r.trim3p);
 		int64_t nrd = 0, nrf = 0;
 		for (uint32_t k = 0; k < r.nned; k++) { const int t = r.ned[k].type; if (t == EDIT_READ_GAP) nrd++; else if (t == EDIT_REF_GAP) nrf++; }
@@ -1096,13 +1097,14 @@ struct Aligner {
 	}
 
 	// RedundantAlns::overlap against every alignment reported so far (they are all kept in WK.alns)
-	BT2_HDN bool red_overlap(const AlnRes& r) const {
+	BT2_HDN bool red_overlap(const BT2_G AlnRes& r_) const {
+		const BT2_G AlnRes& r = *Plat::uni_ptr(&r_);
 		const uint32_t nst = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;
 		if (nst == 0) return false;
 		int64_t dmin, dmax;
 		diag_bounds(r, dmin, dmax);
 		for (uint32_t a = 0; a < nst; a++) {
-			const AlnRes& o = WK.alns[a];
+			const BT2_G AlnRes& o = WK.alns[a];
 			if (o.refid != r.refid || (o.fw != 0) != (r.fw != 0)) continue;
 			// alignments whose diagonal ranges are disjoint share no cell
 			if (dmin > WK.red_dmax[a] || WK.red_dmin[a] > dmax) continue;
@@ -1118,7 +1120,8 @@ struct Aligner {
 		return false;
 	}
 	// RedundantAlns::add: the cells are re-derived from WK.alns[k] on demand; only the prefilter bounds are kept
-	BT2_HDN void red_add(const AlnRes& r) {
+	BT2_HDN void red_add(const BT2_G AlnRes& r_) {
+		const BT2_G AlnRes& r = *Plat::uni_ptr(&r_);
 		if (HOT.n_alns >= (uint32_t)kMaxAlns) return;      // sink_report flags the overflow
 		diag_bounds(r, WK.red_dmin[HOT.n_alns], WK.red_dmax[HOT.n_alns]);
 	}
@@ -1126,7 +1129,7 @@ struct Aligner {
 	// =================================================================================
 	// D. sink (AlnSinkWrap::report, ReportingState::foundUnpaired; aln_sink.cpp:103-130,1395-1445)
 	// =================================================================================
-	BT2_HD bool sink_report(const AlnRes& r) {
+	BT2_HD bool sink_report(const BT2_G AlnRes& r) {
 		if (HOT.n_alns < (uint32_t)kMaxAlns) Plat::copy_aln(WK.alns[HOT.n_alns], r); else ovf(15);
 		HOT.n_alns++;
 		if (!HOT.done_unpair1) {
@@ -1208,7 +1211,7 @@ struct Aligner {
 	}
 
 	// AlnRes::setShape (aligner_result.cpp:72-122) -- edits arrive WK.r.t. DP rows (upstream end)
-	BT2_HD void set_shape(AlnRes& r, int32_t id, int64_t off, int64_t reflen, bool fw, uint32_t rdlen, uint32_t trim5p, uint32_t trim3p) {
+	BT2_HD void set_shape(BT2_G AlnRes& r, int32_t id, int64_t off, int64_t reflen, bool fw, uint32_t rdlen, uint32_t trim5p, uint32_t trim3p) {
 		r.refid = id; r.refoff = off; r.reflen = reflen; r.fw = fw ? 1 : 0; r.rdlen = (uint16_t)rdlen;
 		r.trim5p = (uint16_t)trim5p; r.trim3p = (uint16_t)trim3p;
 		const uint32_t trim_beg = fw ? trim5p : trim3p;
@@ -1223,7 +1226,7 @@ struct Aligner {
 	}
 
 	// Edit::invertPoss over the whole list (edit.cpp:50-88): reverse order, pos -> sz - pos - (readgap?0:1)
-	BT2_HD void invert_edits(AlnRes& r) {
+	BT2_HD void invert_edits(BT2_G AlnRes& r) {
 		const uint32_t n = r.nned, sz = r.rdextent;
 		for (uint32_t i = 0; i < n / 2; i++) { const Edit t = r.ned[i]; r.ned[i] = r.ned[n - 1 - i]; r.ned[n - 1 - i] = t; }
 		for (uint32_t i = 0; i < n; i++) r.ned[i].pos = (uint16_t)(sz - r.ned[i].pos - (r.ned[i].type == EDIT_READ_GAP ? 0 : 1));
@@ -1231,20 +1234,20 @@ struct Aligner {
 
 	// AlnRes::clipOutside / clipLeft / clipRight with soft clipping (aligner_result.cpp:208-303); Edit::clipLo / clipHi
 	// (edit.cpp:438-471).  Clipping is counted in read characters: reference gaps inside the overhang widen it.
-	BT2_HD void clip_edits_lo(AlnRes& r, uint32_t amt) {
+	BT2_HD void clip_edits_lo(BT2_G AlnRes& r, uint32_t amt) {
 		uint32_t nrm = 0;
 		for (uint32_t i = 0; i < r.nned; i++) { if (r.ned[i].pos < amt) nrm++; else r.ned[i].pos = (uint16_t)(r.ned[i].pos - amt); }
 		for (uint32_t i = nrm; i < r.nned; i++) r.ned[i - nrm] = r.ned[i];
 		r.nned = (uint16_t)(r.nned - nrm);
 	}
-	BT2_HD void clip_edits_hi(AlnRes& r, uint32_t len, uint32_t amt) {
+	BT2_HD void clip_edits_hi(BT2_G AlnRes& r, uint32_t len, uint32_t amt) {
 		const uint32_t mx = len - amt;
 		while (r.nned > 0) {
 			const Edit& e = r.ned[r.nned - 1];
 			if (e.pos > mx || (e.pos == mx && e.type != EDIT_READ_GAP)) r.nned--; else break;
 		}
 	}
-	BT2_HD uint32_t clip_read_chars(AlnRes& r, bool from_left, uint32_t rf_amt) {
+	BT2_HD uint32_t clip_read_chars(BT2_G AlnRes& r, bool from_left, uint32_t rf_amt) {
 		// walk the edits from the clipped end (positions WK.r.t. that end of the Watson-oriented read)
 		const bool inv = from_left ? !r.fw : (r.fw != 0);
 		uint32_t rf_i = rf_amt;
@@ -1253,7 +1256,9 @@ struct Aligner {
 		if (inv) invert_edits(r);
 		return rf_i < r.rdextent ? rf_i : r.rdextent;
 	}
-	BT2_HDN void clip_outside(AlnRes& r, int64_t refi, int64_t reff) {
+	BT2_HDN void clip_outside(BT2_G AlnRes& r_, int64_t refi_, int64_t reff_) {
+		BT2_G AlnRes& r = *Plat::uni_ptr(&r_);
+		const int64_t refi = Plat::uni(refi_), reff = Plat::uni(reff_);
 		if (r.refoff < refi) {
 			uint32_t rf_amt = (uint32_t)(refi - r.refoff);
 			if (rf_amt > r.rfextent) rf_amt = r.rfextent;
@@ -1281,7 +1286,10 @@ struct Aligner {
 	// band) is set up ONCE per call, not once per candidate.  fw = orientation aligned.
 	// MODE: cell format -- 0 = e2e 8-bit (bias 0xff), 1 = e2e 16-bit (bias 0x7fff), 2 = local (16-bit fields holding plain scores, floor 0)
 	template <int MODE>
-	BT2_HDN bool next_alignment_m(bool fw_, uint32_t rows_, uint32_t cols_, const DPRect& rect, uint64_t tidx, int64_t tlen, bool sse16, AlnRes& res) {
+	BT2_HDN bool next_alignment_m(bool fw_, uint32_t rows_, uint32_t cols_, uint32_t rect_triml, uint32_t rect_corel, uint32_t rect_corer, int64_t rect_refl_,
+	                              uint64_t tidx_, int64_t tlen_, bool sse16_, BT2_G AlnRes& res_) {
+		BT2_G AlnRes& res = *Plat::uni_ptr(&res_);
+		const uint64_t tidx = Plat::uni(tidx_); const int64_t tlen = Plat::uni(tlen_); const bool sse16 = Plat::uni((int)sse16_) != 0;
 		if (HOT.cural == HOT.n_cands) return false;
 		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
 		const bool fw = Plat::uni((int)fw_) != 0;
@@ -1293,7 +1301,9 @@ struct Aligner {
 		S.gapbar = Plat::uni(PRM.gapbar); S.rdgapo = Plat::uni(PRM.rdgapo); S.rdgape = Plat::uni(PRM.rdgape);
 		S.rfgapo = Plat::uni(PRM.rfgapo); S.rfgape = Plat::uni(PRM.rfgape); S.match_bonus = Plat::uni(PRM.match_bonus);
 		S.mm_type = Plat::uni(PRM.mm_type); S.mm_max = Plat::uni(PRM.mm_max); S.mm_min = Plat::uni(PRM.mm_min); S.n_pen = Plat::uni(PRM.n_pen);
-		const int r_triml = (int)Plat::uni(rect.triml), r_corel = (int)Plat::uni(rect.corel), r_corer = (int)Plat::uni(rect.corer);
+		// (the rectangle's fields arrive by value: a reference to the caller's DPRect would force it into scratch memory)
+		const int r_triml = (int)Plat::uni(rect_triml), r_corel = (int)Plat::uni(rect_corel), r_corer = (int)Plat::uni(rect_corer);
+		const int64_t rect_refl = Plat::uni(rect_refl_);
 		const uint32_t R = dp_R(rows);
 		// `this` lives in private memory: read what the loop needs once, into scalar registers
 		DpScratch dpl;
@@ -1585,7 +1595,7 @@ struct Aligner {
 			uint32_t refns = 0;
 			for (uint32_t i = col; i <= orig_col; i++) if (HOT.rf[i] > 15) refns++;
 			res.refns = (uint16_t)refns;
-			set_shape(res, (int32_t)tidx, (int64_t)col + rect.refl, tlen, fw, rows, fw ? trim_beg : trim_end, fw ? trim_end : trim_beg);
+			set_shape(res, (int32_t)tidx, (int64_t)col + rect_refl, tlen, fw, rows, fw ? trim_beg : trim_end, fw ? trim_end : trim_beg);
 			return true;
 	
 		};
@@ -1649,14 +1659,18 @@ struct Aligner {
 		HOT.cural++;
 		return true;
 	}
-	BT2_HD bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, int mode, bool sse16, AlnRes& res) {
-		if (mode == 0) return next_alignment_m<0>(fw, rows, cols, rect, tidx, tlen, sse16, res);
-		if (mode == 1) return next_alignment_m<1>(fw, rows, cols, rect, tidx, tlen, sse16, res);
-		return next_alignment_m<2>(fw, rows, cols, rect, tidx, tlen, sse16, res);
+	BT2_HD bool next_alignment(bool fw, uint32_t rows, uint32_t cols, const DPRect& rect, uint64_t tidx, int64_t tlen, int mode, bool sse16, BT2_G AlnRes& res) {
+		bool r;
+		if (mode == 0) r = next_alignment_m<0>(fw, rows, cols, rect.triml, rect.corel, rect.corer, rect.refl, tidx, tlen, sse16, res);
+		else if (mode == 1) r = next_alignment_m<1>(fw, rows, cols, rect.triml, rect.corel, rect.corer, rect.refl, tidx, tlen, sse16, res);
+		else r = next_alignment_m<2>(fw, rows, cols, rect.triml, rect.corel, rect.corer, rect.refl, tidx, tlen, sse16, res);
+		return Plat::uni((int)r) != 0;      // (the result of a real call is lane-varying to the compiler)
 	}
 
 	// SwAligner::ungappedAlign, monotone branch (aligner_sw.cpp:286-494); returns 0 / 1
-	BT2_HDN int ungapped_align(bool fw, uint64_t tidx, int64_t refoff, int64_t reflen, AlnRes& res) {
+	BT2_HDN int ungapped_align(bool fw_, uint64_t tidx_, int64_t refoff_, int64_t reflen_, BT2_G AlnRes& res_) {
+		BT2_G AlnRes& res = *Plat::uni_ptr(&res_);
+		const bool fw = Plat::uni((int)fw_) != 0; const uint64_t tidx = Plat::uni(tidx_); const int64_t refoff = Plat::uni(refoff_), reflen = Plat::uni(reflen_);
 		const uint32_t len = HOT.len;
 		const int64_t rfi = refoff, rff = refoff + (int64_t)len;
 		// overhanging ends are only scored (as Ns) with --overhang, and count against the N ceiling (aligner_sw.cpp:306-325)
@@ -1734,7 +1748,7 @@ struct Aligner {
 		uint64_t nelt = 0, nelt_left = 0;
 		const uint32_t rows = rdlen;
 		const uint32_t max_iters = (uint32_t)PRM.max_iters;
-		AlnRes& res = WK.res;
+		BT2_G AlnRes& res = WK.res;
 		while (true) {
 			if (ee_mode) {
 				if (first_ee) {
@@ -1757,8 +1771,10 @@ struct Aligner {
 			const uint32_t maxi = HOT.n_satpos;
 			for (uint32_t i = 0; i < maxi; i++) {
 				if (satpos_taken(i)) continue;
-				SatPos& sp = satpos_view(i);
-				const EEHit* eh = ee_mode ? &ee_hit(sp.ee) : nullptr;
+				BT2_G SatPos& sp = satpos_view(i);
+				EEHit eh_v; eh_v.score = 0;
+				if (ee_mode) eh_v = ee_hit(sp.ee);
+				const EEHit* eh = &eh_v;
 				if (ee_mode && eh->score < ST.minsc) return EXT_PERFECT_SCORE;
 				const bool is_small = PRM.det_seeds ? true : sp.size < nsm;
 				const bool fw = sp.fw != 0;
@@ -1777,7 +1793,7 @@ struct Aligner {
 					if (HOT.n_ex_iters >= max_iters) return EXT_HARD_LIMIT;
 					HOT.n_ex_iters++;
 					first = false;
-					const uint32_t elt = r1n_next(sp.rnd);
+					const uint32_t elt = Plat::uni(r1n_next(sp.rnd));
 					// GroupWalk2S::advanceElement == Ebwt::getOffset(topf + elt)
 					uint32_t steps = 0;
 					const uint64_t tr_ = now();
@@ -1805,6 +1821,7 @@ struct Aligner {
 					TOff tidx = 0, toff = 0, tlen = 0;
 					bool straddled = false;
 					Plat::joined_to_text(IX, (TOff)seedhitlen, joff, tidx, toff, tlen, ee_mode, straddled);
+					tidx = (TOff)Plat::uni((uint64_t)tidx); toff = (TOff)Plat::uni((uint64_t)toff); tlen = (TOff)Plat::uni((uint64_t)tlen);      // (shuffle results are lane-varying to the compiler)
 					if (tidx == kOffMask) continue;
 					const int64_t refoff = (int64_t)toff - (int64_t)rdoff;
 					if (diag_present((int32_t)tidx, refoff, fw)) { HOT.n_redundants++; continue; }
@@ -1846,7 +1863,7 @@ struct Aligner {
 						diag_add((int32_t)tidx, refoff, fw, 1);
 					} else if (PRM.do_ungapped && ungapped) {
 						const uint64_t tu_ = now();
-						const int al = ungapped_align(fw, tidx, refoff, (int64_t)tlen, res);
+						const int al = Plat::uni(ungapped_align(fw, tidx, refoff, (int64_t)tlen, res));
 						HOT.t_phase[10] += now() - tu_;
 						diag_add((int32_t)tidx, refoff, fw, 1);
 						HOT.n_ex_ugs++;
@@ -1894,12 +1911,12 @@ struct Aligner {
 						if (PRM.match_bonus > 0) {
 							mode = 2;
 							uint32_t sat8 = 0;
-							best = Plat::dp_fill_local(PRM, WK, fw, rows, cols, ST.dp.mat, ST.minsc, lastsolcol, sat8);
+							best = Plat::uni(Plat::dp_fill_local(PRM, WK, fw, rows, cols, ST.dp.mat, ST.minsc, lastsolcol, sat8));
 							sse16 = sat8 != 0;
 						} else {
 							mode = ST.minsc < -254 ? 1 : 0;
 							sse16 = mode == 1;
-							best = Plat::dp_fill_ee(PRM, WK, fw, rows, cols, ST.dp, mode != 0, ST.minsc);
+							best = Plat::uni(Plat::dp_fill_ee(PRM, WK, fw, rows, cols, ST.dp, mode != 0, ST.minsc));
 							if (best == INT64_MIN) { ovf(31); return EXT_HARD_LIMIT; }
 						}
 						HOT.t_phase[5] += now() - td_;
@@ -1940,7 +1957,7 @@ struct Aligner {
 							const bool ov = (b0 <= a0 && b1 > a0) || (b0 <= a1 && b1 > a1) || (a0 <= b0 && a1 > b0) || (a0 <= b1 && a1 > b1);
 							if (!ov) continue;
 						}
-						if (red_overlap(res)) continue;
+						if (Plat::uni((int)red_overlap(res)) != 0) continue;
 						red_add(res);
 						{ const uint64_t t1_ = now(); const bool sr_ = sink_report(res); HOT.t_phase[19] += now() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
 						if (PRM.tighten > 0 && PRM.mhits > 0 && HOT.best2_unp1 != INT64_MIN) {
@@ -1975,7 +1992,7 @@ struct Aligner {
 		else if (ret == EXT_HARD_LIMIT) done = true;
 	}
 
-	BT2_HD void run(ReadResult& out) {
+	BT2_HD void run(BT2_G ReadResult& out) {
 		const uint32_t len = HOT.len;
 		HOT.err = 0;
 		HOT.n_alns = 0; HOT.best_unp1 = HOT.best2_unp1 = INT64_MIN; HOT.done_unpair1 = 0; HOT.exit_m = HOT.exit_k = 0;
@@ -2003,7 +2020,7 @@ struct Aligner {
 				{ const uint64_t t0_ = now(); nelt = (PRE && PRE->sweep) ? exact_sweep_pre(mine) : exact_sweep(2, mine); HOT.t_phase[0] += now() - t0_; }
 				if (nelt == 0) { HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0; }
 				else {
-					const int ret = extend_seeds(-1, 0, 0);
+					const int ret = Plat::uni(extend_seeds(-1, 0, 0));
 					HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
 					handle_ret(ret, done);
 					if (!done && ST.minsc == perfect) done = true;
@@ -2020,7 +2037,7 @@ struct Aligner {
 						nelt = HOT.mm1_elt; HOT.t_phase[1] += now() - t0_;
 					}
 					if (nelt > 0) {
-						const int ret = extend_seeds(-1, 0, 0);
+						const int ret = Plat::uni(extend_seeds(-1, 0, 0));
 						HOT.n_mm1 = 0; HOT.mm1_elt = 0;
 						handle_ret(ret, done);
 						if (!done && ST.minsc == perfect) done = true;
@@ -2040,7 +2057,7 @@ struct Aligner {
 				ST.ext_pre = false;
 				cache_reset();          // ca.nextRead() (bt2_search.cpp:3882)
 				uint32_t ninst;
-				if (PRM.seed_mms > 0) ninst = seed_round_mm1(offset, interval, (uint32_t)RPR.seedlen);
+				if (PRM.seed_mms > 0) ninst = Plat::uni(seed_round_mm1(offset, interval, (uint32_t)RPR.seedlen));
 				else if (offset == 0 && PRE && PRE->seeds && 1 + (len > (uint32_t)RPR.seedlen ? (len - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds) {
 					ninst = seed_round_pre(PRE->seeds, 0, interval, (uint32_t)RPR.seedlen);
 					ST.ext_pre = PRE->ext != nullptr; ST.pre_ext_cur = PRE->ext; ST.pre_joff_cur = PRE->joff;
@@ -2050,12 +2067,12 @@ struct Aligner {
 					// a read only gets here when it held); a read with more seed positions than the tables hold searches them itself
 					ninst = seed_round_pre(PRE->seeds_r[roundi], offset, interval, (uint32_t)RPR.seedlen);
 					ST.ext_pre = PRE->ext_r[roundi] != nullptr; ST.pre_ext_cur = PRE->ext_r[roundi]; ST.pre_joff_cur = PRE->joff_r[roundi];
-				} else ninst = seed_round(offset, interval, (uint32_t)RPR.seedlen);
+				} else ninst = Plat::uni(seed_round(offset, interval, (uint32_t)RPR.seedlen));
 				HOT.t_phase[2] += now() - ts_;
 				if (ninst == 0) { done = true; HOT.nonz_tot = 0; continue; }
 				if (HOT.nonz_tot == 0) { done = true; continue; }
 				{ const uint64_t t0_ = now(); rank_seed_hits(); HOT.t_phase[3] += now() - t0_; }
-				const int ret = extend_seeds(PRM.seed_mms, RPR.seedlen, (int)interval);
+				const int ret = Plat::uni(extend_seeds(PRM.seed_mms, RPR.seedlen, (int)interval));
 				handle_ret(ret, done);
 				if (!done && HOT.nonz_tot > 0 && (HOT.num_elts / HOT.nonz_tot) < (uint64_t)PRM.seed_boost_thresh) done = true;
 			}
@@ -2069,7 +2086,7 @@ struct Aligner {
 			uint32_t k = 0;
 			dbg[k++] = HOT.n_satpos2;
 			for (uint32_t i = 0; i < HOT.n_satpos2 && k + 6 < 290; i++) {
-				const SatPos& s = WK.satpos2[i];
+				const BT2_G SatPos& s = WK.satpos2[i];
 				dbg[k++] = (uint32_t)s.topf; dbg[k++] = (uint32_t)s.topb; dbg[k++] = s.size; dbg[k++] = s.nlex; dbg[k++] = s.nrex; dbg[k++] = s.offidx * 2 + s.fw;
 			}
 		}
@@ -2078,7 +2095,8 @@ struct Aligner {
 
 	// AlnSinkWrap::finishRead for an unpaired read (aln_sink.cpp:643-1384): ReportingState::finish,
 	// getReport, selectByScore (RNG!), and what the SAM line needs.
-	BT2_HDN void finish(ReadResult& out) {
+	BT2_HDN void finish(BT2_G ReadResult& out_) {
+		BT2_G ReadResult& out = *Plat::uni_ptr(&out_);
 		// -a: the reference reports every alignment found; this build's result record holds khits (64) of them
 		if (PRM.all_hits && HOT.n_alns > (uint32_t)PRM.khits) ovf(32);
 		out.status = (uint8_t)HOT.err;
@@ -2104,7 +2122,7 @@ struct Aligner {
 		// selectByScore: sort (score, index) ascending, reverse, shuffle equal-score streaks
 		const uint32_t sz = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;
 		uint32_t num = nunpair1 < sz ? nunpair1 : sz;
-		uint32_t* idx = WK.lists;      // scratch (Random1toN lists are dead by now)
+		BT2_G uint32_t* idx = WK.lists;      // scratch (Random1toN lists are dead by now)
 		for (uint32_t i = 0; i < sz; i++) idx[i] = i;
 		for (uint32_t i = 1; i < sz; i++) {          // descending by (score, index)
 			const uint32_t v = idx[i];

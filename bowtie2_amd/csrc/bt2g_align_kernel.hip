@@ -386,10 +386,8 @@ struct DevPlat {
 	static __device__ __forceinline__ ReadParams& rparams() { return g_rp; }
 	static __device__ __forceinline__ const PreComp* pre() { return &g_pre; }
 	static __device__ __forceinline__ AlState& st() { return g_st; }
-	// the wave's work area in HBM.  (The reference is a generic one: accesses through it are flat_* instructions unless the site names the
-	// global address space itself -- gld / gst, bt2g_device.hpp -- as the hot loops do.  Neither __builtin_assume(!is_shared && !is_private)
-	// nor a cast through address_space(1) makes this compiler infer it, ROCm 7.2.)
-	static __device__ __forceinline__ Work& work() { return *g_st.wp; }
+	// the wave's work area in HBM, typed as such (BT2_G, bt2g_device.hpp)
+	static __device__ __forceinline__ BT2_G Work& work() { return *(BT2_G Work*)g_st.wp; }
 	template <typename TOff> static __device__ __forceinline__ const DevIndex<TOff>& index() { return *reinterpret_cast<const DevIndex<TOff>*>(g_ix_raw); }
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
 	// The worker's control code computes the same value in every lane; uni() moves such a value into a
@@ -664,11 +662,11 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < len; i += 64) { g_hot.seq[i] = seq[i]; g_hot.qual[i] = qual[i]; }
 		wave_fence();
 	}
-	static __device__ __forceinline__ void copy_aln(AlnRes& dst, const AlnRes& src) {
+	static __device__ __forceinline__ void copy_aln(BT2_G AlnRes& dst, const BT2_G AlnRes& src) {
 		wave_fence();
 		const uint32_t nw = ((uint32_t)offsetof(AlnRes, ned) + (uint32_t)uni((uint32_t)src.nned) * (uint32_t)sizeof(Edit) + 3u) / 4u;
-		const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
-		uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+		const BT2_G uint32_t* s = (const BT2_G uint32_t*)&src;
+		BT2_G uint32_t* d = (BT2_G uint32_t*)&dst;
 		for (uint32_t i = threadIdx.x & 63; i < nw; i += 64) d[i] = s[i];
 		wave_fence();
 	}
@@ -922,10 +920,10 @@ struct DevPlat {
 
 // one DP scratch inside a wave's arena: [matrix][16-bit masks][256 B header holding the epoch][32-bit epoch-tagged masks]
 __device__ __forceinline__ uint8_t* carve_scratch(DpScratch& dp, uint8_t* p, uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes) {
-	dp.mat = reinterpret_cast<uint32_t*>(p); p += mat_bytes;
-	dp.masks = reinterpret_cast<uint16_t*>(p); p += mask_bytes;
-	dp.epoch = reinterpret_cast<uint32_t*>(p);
-	dp.pmask = reinterpret_cast<uint32_t*>(p + 256);
+	dp.mat = (BT2_G uint32_t*)p; p += mat_bytes;
+	dp.masks = (BT2_G uint16_t*)p; p += mask_bytes;
+	dp.epoch = (BT2_G uint32_t*)p;
+	dp.pmask = (BT2_G uint32_t*)(p + 256);
 	dp.pmask_words = (uint32_t)((pmask_bytes - 256) / 4);
 	return p + pmask_bytes;
 }
@@ -945,7 +943,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
               PreComp pre, uint32_t max_read_len) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
-	Work& w = *reinterpret_cast<Work*>(base);
+	BT2_G Work& w = *(BT2_G Work*)base;
 	DpScratch dp;
 	carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes);
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
@@ -958,7 +956,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		if (r >= rd.n_reads) break;
 		const uint64_t o0 = rd.d_off[r];
 		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
-		ReadResult& out = *reinterpret_cast<ReadResult*>(results + (uint64_t)r * result_stride);
+		BT2_G ReadResult& out = *(BT2_G ReadResult*)(results + (uint64_t)r * result_stride);
 		if (len > max_read_len || !read_params_ok(rparams[r])) {      // the DP scratch of this launch is sized for max_read_len rows
 			if (lane == 0) { out.status = ERR_OVERFLOW; out.aligned = 0; out.nreport = 0; out.nalns = 0; out.filt = (uint8_t)rparams[r].filt; out.maxed = 0; out.has_secbest = 0; }
 			continue;
@@ -996,7 +994,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
               PreComp pre, uint32_t max_read_len) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
-	Work& w = *reinterpret_cast<Work*>(base);
+	BT2_G Work& w = *(BT2_G Work*)base;
 	DpScratch dp, dp2;
 	carve_scratch(dp2, carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes), mat_bytes, mask_bytes, pmask_bytes);
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
@@ -1010,11 +1008,11 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		if (r >= n_pairs) break;
 		const uint64_t o0 = rd.d_off[2 * r], o1 = rd.d_off[2 * r + 1], o2 = rd.d_off[2 * r + 2];
 		const uint32_t len0 = (uint32_t)(o1 - o0), len1 = (uint32_t)(o2 - o1);
-		ReadResult& out0 = *reinterpret_cast<ReadResult*>(results + (uint64_t)(2 * r) * result_stride);
-		ReadResult& out1 = *reinterpret_cast<ReadResult*>(results + (uint64_t)(2 * r + 1) * result_stride);
+		BT2_G ReadResult& out0 = *(BT2_G ReadResult*)(results + (uint64_t)(2 * r) * result_stride);
+		BT2_G ReadResult& out1 = *(BT2_G ReadResult*)(results + (uint64_t)(2 * r + 1) * result_stride);
 		if (len0 > max_read_len || len1 > max_read_len || !read_params_ok(rparams[2 * r]) || !read_params_ok(rparams[2 * r + 1])) {
 			if (lane == 0) {
-				ReadResult* o[2] = {&out0, &out1};
+				BT2_G ReadResult* o[2] = {&out0, &out1};
 				for (int m = 0; m < 2; m++) { o[m]->status = ERR_OVERFLOW; o[m]->aligned = 0; o[m]->nreport = 0; o[m]->nalns = 0; o[m]->filt = (uint8_t)rparams[2 * r + m].filt; o[m]->maxed = 0; o[m]->has_secbest = 0; o[m]->pair_type = 0; o[m]->pair_flags = 0; }
 			}
 			continue;
@@ -1024,8 +1022,8 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		wave_fence();
 		Aligner<TOff, DevPlat>& al = *new (s_al) Aligner<TOff, DevPlat>(w, dp, 2 * r);
 		g_st.dp_main = dp; g_st.dp_opp = dp2;
-		g_st.pe_seq[0] = rd.d_seq + o0; g_st.pe_qual[0] = rd.d_qual + o0; g_st.pe_len[0] = len0;
-		g_st.pe_seq[1] = rd.d_seq + o1; g_st.pe_qual[1] = rd.d_qual + o1; g_st.pe_len[1] = len1;
+		g_st.pe_seq[0] = (const BT2_G uint8_t*)(rd.d_seq + o0); g_st.pe_qual[0] = (const BT2_G uint8_t*)(rd.d_qual + o0); g_st.pe_len[0] = len0;
+		g_st.pe_seq[1] = (const BT2_G uint8_t*)(rd.d_seq + o1); g_st.pe_qual[1] = (const BT2_G uint8_t*)(rd.d_qual + o1); g_st.pe_len[1] = len1;
 		g_st.pe_rp[0] = rparams[2 * r]; g_st.pe_rp[1] = rparams[2 * r + 1];
 		g_st.pe_pair = r;
 		wave_fence();

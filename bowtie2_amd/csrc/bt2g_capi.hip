@@ -428,7 +428,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			e = s ? launch_exact_sweep(c->ix32, *reads, params->nofw, params->norc, 2, d_sweep, c->d_cnt, st)
 			      : launch_exact_sweep(c->ix64, *reads, params->nofw, params->norc, 2, d_sweep, c->d_cnt, st);
 			if (e != hipSuccess) return hip_fail(c, e, "k_exact_sweep");
-			pre.sweep = d_sweep;
+			pre.sweep = (decltype(pre.sweep))d_sweep;
 			mark(1);
 			if (params->do_1mm_upfront) {
 				unsigned int* d_mm1c = (unsigned int*)(d_mm1n + b_mm1n);
@@ -436,7 +436,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, c->d_cnt, st)
 				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, c->d_cnt, st);
 				if (e != hipSuccess) return hip_fail(c, e, "k_one_mm");
-				pre.mm1 = d_mm1; pre.mm1_n = d_mm1n;
+				pre.mm1 = (decltype(pre.mm1))d_mm1; pre.mm1_n = (decltype(pre.mm1_n))d_mm1n;
 			}
 		} else mark(1);
 		mark(2);
@@ -444,13 +444,13 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			e = s ? launch_seed_search_exact(c->ix32, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st)
 			      : launch_seed_search_exact(c->ix64, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, d_seeds, c->d_cnt, st);
 			if (e != hipSuccess) return hip_fail(c, e, "k_seed_search_exact");
-			pre.seeds = d_seeds;
+			pre.seeds = (decltype(pre.seeds))d_seeds;
 			mark(3);
 			if (params->do_extend) {
 				e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, d_joff, c->d_cnt, st)
 				      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, d_seeds, d_ext, d_joff, c->d_cnt, st);
 				if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits");
-				pre.ext = d_ext; pre.joff = d_joff;
+				pre.ext = (decltype(pre.ext))d_ext; pre.joff = (decltype(pre.joff))d_joff;
 			}
 			// rounds 1..: the same kernels on the shifted seeds, for the reads repetitive enough to be re-seeded
 			const bt2g_seed_hit* prev = d_seeds;
@@ -463,12 +463,12 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 				e = s ? launch_seed_search_exact(c->ix32, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, sr, c->d_cnt, st, ri, &ctl)
 				      : launch_seed_search_exact(c->ix64, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, sr, c->d_cnt, st, ri, &ctl);
 				if (e != hipSuccess) return hip_fail(c, e, "k_seed_search_exact (re-seed)");
-				pre.seeds_r[ri] = sr;
+				pre.seeds_r[ri] = (decltype(pre.seeds_r[ri]))sr;
 				if (params->do_extend) {
 					e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, sr, er, jr, c->d_cnt, st, ri, (uint32_t)params->n_seed_rounds)
 					      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, sr, er, jr, c->d_cnt, st, ri, (uint32_t)params->n_seed_rounds);
 					if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits (re-seed)");
-					pre.ext_r[ri] = er; pre.joff_r[ri] = jr;
+					pre.ext_r[ri] = (decltype(pre.ext_r[ri]))er; pre.joff_r[ri] = (decltype(pre.joff_r[ri]))jr;
 				}
 				prev = sr;
 			}

@@ -43,6 +43,20 @@ struct ulonglong2 { unsigned long long x, y; };   // host-side stand-ins (test b
 struct uint4 { unsigned int x, y, z, w; };
 #endif
 
+// BT2_G qualifies a type as living in device global memory (HBM).  An access through a BT2_G pointer or reference is a global_*
+// instruction; through a plain (generic) one it is a flat_* instruction, and -- worse for a worker whose control code is wave-uniform --
+// the compiler must treat every value loaded through a generic pointer as lane-varying (the address could be per-lane scratch), so that
+// everything computed from it runs on the vector ALU and every branch on it becomes exec-mask control flow.  The worker therefore
+// reaches its work area, its alignment records and its result records through BT2_G types.  (Only the device compilation knows address
+// spaces; for the host pass and the CPU test twin the qualifier is empty.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BT2_G __attribute__((address_space(1)))
+#else
+#define BT2_G
+#endif
+// a BT2_G pointer as the generic pointer the lane-parallel platform helpers take (they name the address space again per access)
+template <typename T> BT2_HD T* gen_ptr(BT2_G T* p) { return (T*)p; }
+
 // Scalar loads / stores for pointers that are KNOWN to point into the wave's arena in HBM.  Through a plain (generic)
 // pointer the compiler must issue FLAT instructions: it then has to assume the access may alias LDS (so every LDS value it
 // holds in registers is reloaded after a store) and the wait for a FLAT load also drains the LDS counter.  The device
@@ -50,6 +64,8 @@ struct uint4 { unsigned int x, y, z, w; };
 #if defined(__HIP_DEVICE_COMPILE__)
 template <typename T> __host__ __device__ __forceinline__ T gld(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
 template <typename T> __host__ __device__ __forceinline__ void gst(T* p, T v) { *(__attribute__((address_space(1))) T*)p = v; }
+template <typename T> __host__ __device__ __forceinline__ T gld(const BT2_G T* p) { return *p; }        // (pointers already typed as global)
+template <typename T> __host__ __device__ __forceinline__ void gst(BT2_G T* p, T v) { *p = v; }
 #else
 template <typename T> BT2_HD T gld(const T* p) { return *p; }
 template <typename T> BT2_HD void gst(T* p, T v) { *p = v; }

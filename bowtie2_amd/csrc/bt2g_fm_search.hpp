@@ -131,19 +131,19 @@ struct Mm1Hit {
 // Batch-wide results of the pure FM phases, computed by lane-per-task kernels before the fused
 // worker runs (bt2g_kernels.hip).  Any pointer may be null: the worker then computes that phase itself.
 struct PreComp {
-	const bt2g_sweep_out* sweep;   // [n_reads]                       exactSweep
-	const bt2g_seed_hit*  seeds;   // [n_reads][2][max_seeds]         seed round 0 (offset 0)
-	const uint32_t*       ext;     // [n_reads][2][max_seeds]         nlex | nrex << 16 of each non-empty seed hit
-	const uint64_t*       joff;    // [n_reads][2][max_seeds]         joff_pack() of every one-row seed hit (kJoffNone otherwise): resolved while extending
-	const Mm1Hit*         mm1;     // [n_reads][2 strands][2 dirs][mm1_cap]
-	const uint8_t*        mm1_n;   // [n_reads][4]   hits per list; 255 = list overflowed
+	const BT2_G bt2g_sweep_out* sweep;   // [n_reads]                       exactSweep
+	const BT2_G bt2g_seed_hit*  seeds;   // [n_reads][2][max_seeds]         seed round 0 (offset 0)
+	const BT2_G uint32_t*       ext;     // [n_reads][2][max_seeds]         nlex | nrex << 16 of each non-empty seed hit
+	const BT2_G uint64_t*       joff;    // [n_reads][2][max_seeds]         joff_pack() of every one-row seed hit (kJoffNone otherwise): resolved while extending
+	const BT2_G Mm1Hit*         mm1;     // [n_reads][2 strands][2 dirs][mm1_cap]
+	const BT2_G uint8_t*        mm1_n;   // [n_reads][4]   hits per list; 255 = list overflowed
 	uint32_t max_seeds, mm1_cap;
 	// re-seeding rounds 1..kMaxPreRounds-1 (bt2_search.cpp:3881-4160: same seeds shifted by interval*round/nrounds), computed
 	// only for reads whose previous round averaged >= seed_boost_thresh hits per seed -- the one condition for a further round
 	// that does not depend on what the worker has reported by then.  [round][...] with the layout of seeds/ext/joff above.
-	const bt2g_seed_hit*  seeds_r[4];
-	const uint32_t*       ext_r[4];
-	const uint64_t*       joff_r[4];
+	const BT2_G bt2g_seed_hit*  seeds_r[4];
+	const BT2_G uint32_t*       ext_r[4];
+	const BT2_G uint64_t*       joff_r[4];
 };
 constexpr uint32_t kMaxPreRounds = 4;
 
