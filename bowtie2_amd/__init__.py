@@ -51,8 +51,16 @@ class Scoring(C.Structure):
 
 
 class DpProblem(C.Structure):
-    _fields_ = [("rd_off", C.c_uint64), ("rows", C.c_uint32), ("rf_off", C.c_uint64), ("cols", C.c_uint32),
-                ("mat_off", C.c_uint64)]
+    _fields_ = [("rd_off", C.c_uint64), ("rf_off", C.c_uint64), ("rows", C.c_uint32), ("cols", C.c_uint32),
+                ("minsc", C.c_int32), ("kind", C.c_uint32), ("out_off", C.c_uint64)]
+
+
+class DpOut(C.Structure):
+    _fields_ = [("best", C.c_int64), ("lastsolcol", C.c_uint32), ("sat8", C.c_uint32), ("band_lo", C.c_int32), ("band_w", C.c_uint32),
+                ("has_matrix", C.c_uint32), ("pad", C.c_uint32)]
+
+
+DP_EE_U8, DP_EE_I16, DP_LOCAL = 0, 1, 2
 
 
 class AlignParams(C.Structure):
@@ -125,7 +133,8 @@ ABI = [
     ("bt2g_seed_search_exact", C.c_int, [_vp, C.POINTER(Reads), _vp, _vp, _vp, C.c_uint32, _vp, _vp]),
     ("bt2g_resolve_offsets", C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, _vp, _vp]),
     ("bt2g_scoring_default", None, [C.POINTER(Scoring)]),
-    ("bt2g_sw_fill_ee_u8", C.c_int, [_vp, C.POINTER(Scoring), _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("bt2g_dp_out_bytes", C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("bt2g_dp_fill", C.c_int, [_vp, C.POINTER(Scoring), _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     ("bt2g_counters_read", C.c_int, [_vp, C.POINTER(Counters), C.c_int, _vp]),
     ("bt2g_align_profile_read", C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
     ("bt2g_align_timing_read", C.c_int, [_vp, C.POINTER(C.c_float)]),
@@ -252,15 +261,16 @@ class Context:
                                                     out.data_ptr(), _stream_ptr()), "bt2g_resolve_offsets")
         return out
 
-    def sw_fill_ee_u8(self, probs, rd, qu, rf, mat, best, scoring=None):
+    def dp_fill(self, probs, rd, qu, rf, out, scoring=None):
+        """probs: uint8 device tensor holding DpProblem[n]; rd/qu/rf: uint8 device tensors; out: uint8 device tensor of output blocks
+        (bt2g_dp_fill: the worker's own fills as a stage)."""
         sc = scoring
         if sc is None:
             sc = Scoring()
             lib().bt2g_scoring_default(C.byref(sc))
         n = probs.numel() // C.sizeof(DpProblem)
-        _check(self._h, lib().bt2g_sw_fill_ee_u8(self._h, C.byref(sc), probs.data_ptr(), n, rd.data_ptr(), qu.data_ptr(),
-                                                  rf.data_ptr(), mat.data_ptr() if mat is not None else None,
-                                                  best.data_ptr(), _stream_ptr()), "bt2g_sw_fill_ee_u8")
+        _check(self._h, lib().bt2g_dp_fill(self._h, C.byref(sc), probs.data_ptr(), n, rd.data_ptr(), qu.data_ptr(), rf.data_ptr(),
+                                           out.data_ptr(), _stream_ptr()), "bt2g_dp_fill")
 
     def align_batch(self, batch, rparams, params, max_read_len):
         """rparams: uint8 device tensor holding ReadParams[n]; returns a uint8 device tensor of result records."""

@@ -229,6 +229,7 @@ struct HotWork {
 	uint8_t  done_unpair1;
 	uint8_t  exit_m, exit_k;
 	uint32_t n_cands, cural;
+	uint32_t n_cdone;           // local mode: candidates of the window in hand that have been tried (btncanddone_), listed in Work::cand_hist
 	uint32_t err;
 	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail, n_ug_fail, n_ee_fail, n_dp_fail_streak;
 	uint32_t n_redundants, n_bwops_seed, n_bwops_ext, n_bt_attempts;
@@ -358,6 +359,7 @@ BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { uint32_t rp = ee_band
 // reached by name (Plat::st()), never through a pointer: see the note at ST in bt2g_align_core.hpp.
 struct AlState {
 	BT2_G Work* wp;          // the wave's work area in HBM
+	BT2_HD Work* wp_generic() const { return (Work*)wp; }
 	DpScratch dp;            // the DP scratch in use (pairs: dp_main or dp_opp)
 	Rng       rnd;
 	int64_t   minsc;         // current (possibly tightened) minimum score

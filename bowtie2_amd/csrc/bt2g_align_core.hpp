@@ -1175,7 +1175,7 @@ struct Aligner {
 		const int64_t minsc_dp = Plat::uni(minsc_dp_);
 		const int mode = Plat::uni(mode_);
 		const uint32_t R = dp_R(rows);
-		HOT.n_cands = 0; HOT.cural = 0;
+		HOT.n_cands = 0; HOT.cural = 0; HOT.n_cdone = 0;
 		const uint64_t tl_ = now();
 		uint32_t nc;
 		if (mode != 2) {
@@ -1360,6 +1360,23 @@ struct Aligner {
 			auto fl = [&](int v) -> bool { return !local || v > 0; };     // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
 			HOT.n_bt_attempts++;
 			while ((int)row >= 0) {
+				if (pred && ct != 0 && tdir == (uint32_t)ct && td < tile_len && row > 0) {
+					// inside a gap: the cells that can only EXTEND it (unvisited, E consistent with E-left alone / F with F-up alone) are walked
+					// by all lanes at once -- same marks, same edits, same counters as the step-by-step loop below.  (The candidates next to an
+					// alignment's end column each walk a gap of growing length back to its path; the cell that opens the gap and whatever
+					// follows go through the scalar step.)
+					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
+					const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
+					uint32_t core = 0;
+					const uint32_t L = Plat::uni(Plat::bt_gap_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, ct == 1, fw, rdlen, room_c < room_e ? room_c : room_e,
+					                                              nned, r_triml, r_corel, r_corer, core));
+					if (L > 0) {
+						olap |= (int)(Plat::uni(core) != 0); ncells += L; prof.steps += L; nned += L; gaps += L; td += L;
+						if (ct == 1) { read_gaps += L; col -= L; score -= (int32_t)L * S.rdgape; }
+						else { ref_gaps += L; row -= L; score -= (int32_t)L * S.rfgape; }
+						continue;
+					}
+				}
 				if (pred && ct == 0 && tdir == 0 && td < tile_len && row > 0) {
 					// a run of plain diagonal steps (unvisited cells whose only consistent predecessor is the diagonal one) is walked
 					// by all lanes at once: same marks, same edits, same counters as the step-by-step loop below
@@ -1600,31 +1617,33 @@ struct Aligner {
 	
 		};
 		bool found = false;
-		// end-to-end: the next 64 candidates wait in lane registers (one gather instead of one dependent load per candidate)
+		// the next 64 candidates wait in lane registers (one gather instead of one dependent load per candidate)
 		typename Plat::LaneReg cw0, cw1;
 		uint32_t cbase = 0xffffff00u;
+		// local mode: the candidates of this window that have been tried (btncanddone_: a few dozen of the thousands a 400-bp window can
+		// have) as row | col << 16, listed in the arena and mirrored in two lane registers (the first 128): a candidate is tested against
+		// all of them at once instead of against every earlier candidate one dependent load at a time
+		BT2_G uint32_t* const donel = Plat::uni_ptr(&WK.cand_hist[0]) + (ST.cands_cur == WK.cands2 ? (uint32_t)(kMaxLocalScore + 1) : 0u);
+		uint32_t ndone = MODE == 2 ? HOT.n_cdone : 0u;
+		typename Plat::LaneReg dn0, dn1;
+		Plat::lanes_zero(dn0); Plat::lanes_zero(dn1);
+		if (MODE == 2 && ndone > 0) { dn0 = Plat::lanes_load_u32(donel, 0, ndone); if (ndone > 64u) dn1 = Plat::lanes_load_u32(donel, 64, ndone); }
 		while (HOT.cural < HOT.n_cands) {
 			BtCand c;
-			if (MODE != 2) {
+			{
 				const uint32_t ci = HOT.cural;
 				if (ci - cbase >= 64u) { cbase = ci; Plat::lanes_load_cands(cands, cbase, HOT.n_cands, cw0, cw1); }
 				c.score = (int32_t)Plat::lane(cw0, ci - cbase);
 				const uint32_t rc_ = Plat::lane(cw1, ci - cbase);
 				c.row = (uint16_t)(rc_ & 0xffffu); c.col = (uint16_t)(rc_ >> 16);
-			} else c = gld(&cands[HOT.cural]);
-			if (MODE == 2) c.score &= ~kCandDone;
+			}
 			if (c.score < ST.minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
 			if (MODE == 2) {
 				// local: skip candidates "dominated" by one already tried -- within SQ = rows/16 rows and columns of it
 				// (aligner_sw.cpp:754-755,936-960)
 				uint32_t SQ = rows >> 4; if (SQ == 0) SQ = 1;
-				bool dom = false;
-				for (uint32_t k = 0; k < HOT.cural && !dom; k++) {
-					const BtCand o = gld(&cands[k]);
-					if (!(o.score & kCandDone)) continue;
-					const uint32_t rhi = c.row > o.row ? c.row - o.row : o.row - c.row, chi = c.col > o.col ? c.col - o.col : o.col - c.col;
-					if (chi <= SQ && rhi <= SQ) dom = true;
-				}
+				bool dom = Plat::near_any(dn0, ndone < 64u ? ndone : 64u, c.row, c.col, SQ) || (ndone > 64u && Plat::near_any(dn1, ndone - 64u < 64u ? ndone - 64u : 64u, c.row, c.col, SQ));
+				for (uint32_t k0 = 128; k0 < ndone && !dom; k0 += 64) dom = Plat::near_any(Plat::lanes_load_u32(donel, k0, ndone), ndone - k0 < 64u ? ndone - k0 : 64u, c.row, c.col, SQ);
 				if (dom) { HOT.cural++; continue; }
 			}
 			typename Plat::LaneReg tile, tile_hi;
@@ -1650,7 +1669,12 @@ struct Aligner {
 				if (PRM.profile) { const uint64_t dt_ = now() - tw_; HOT.t_bt[0] += dt_; if (ret) { HOT.t_bt[1] += dt_; HOT.t_bt[2]++; } }
 			}
 			ST.rnd.init(sse16 ? reseed : reseed + 1);
-			if (MODE == 2) gst(&cands[HOT.cural].score, cscore | kCandDone);       // btncanddone_: tried, succeeded or not
+			if (MODE == 2) {       // btncanddone_: tried, succeeded or not
+				const uint32_t v_ = (uint32_t)c.row | ((uint32_t)c.col << 16);
+				if (ndone >= (uint32_t)(kMaxLocalScore + 1)) ovf(33);
+				else { gst(donel + ndone, v_); if (ndone < 64u) Plat::set_lane(dn0, ndone, v_); else if (ndone < 128u) Plat::set_lane(dn1, ndone - 64u, v_); ndone++; HOT.n_cdone = ndone; }
+			}
+			(void)cscore;
 			if (ret) { found = true; break; }
 			HOT.cural++;
 		}

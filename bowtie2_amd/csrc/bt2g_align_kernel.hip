@@ -644,6 +644,38 @@ struct DevPlat {
 		mm = __ballot(edit);
 		return L;
 	}
+	// Backtrace fast path inside a gap (pred format, E or F state, row / column tile): the cells from lane td on that can only extend the gap
+	// -- not visited, no stored choice, E consistent with E-left alone (read gap) / F with F-up alone (reference gap) -- are walked in one go.
+	// Every lane marks its cell (the word the step-by-step walk leaves: reportedThrough + "choice made, nothing else to try") and writes its
+	// edit to ned[nned + k].  Returns the run length; core = some cell of the run lies on a core diagonal.
+	static __device__ __forceinline__ uint32_t bt_gap_run(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t tile, uint32_t tile_hi,
+	                                                      uint32_t td, uint32_t row, uint32_t col, bool read_gap, bool fw, uint32_t rdlen, uint32_t maxl,
+	                                                      uint32_t nned, int r_triml, int r_corel, int r_corer, uint32_t& core) {
+		const uint32_t d = threadIdx.x & 63;
+		const uint32_t k = d - td;
+		const bool in = d >= td && k < maxl && (read_gap ? k <= col : k < row);
+		const uint32_t pb = tile;
+		const uint32_t m = read_gap ? (pb >> 3) & 3u : (pb >> 5) & 3u;
+		const bool ext = in && tile_hi == 0 && m == 2u;
+		const unsigned long long sm = __ballot(ext) >> td;
+		const uint32_t L = ~sm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~sm);
+		core = 0;
+		if (L == 0) return 0;
+		bool incore = false;
+		if (in && k < L) {
+			const uint32_t r = read_gap ? row : row - k, c = read_gap ? col - k : col;
+			Edit e;
+			if (read_gap) { const int refm = g_hot.rf[c]; e.pos = (uint16_t)(r + 1); e.chr = (uint8_t)((refm == 1 || refm == 2 || refm == 4 || refm == 8) ? code2chr(__builtin_ctz((unsigned)refm)) : 'N'); e.qchr = '-'; e.type = EDIT_READ_GAP; }
+			else { e.pos = (uint16_t)r; e.chr = '-'; e.qchr = code2chr(rd_char(g_hot, rdlen, fw, r)); e.type = EDIT_REF_GAP; }
+			e.pad = 0;
+			g_hot.ned[nned + k] = e;
+			gst(dp.pmask + pred_idx(band_lo, band_w, r, c), (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift));
+			const int diagi = (int)c - (int)r + r_triml;
+			incore = diagi >= r_corel && diagi <= r_corer;
+		}
+		core = __ballot(incore) != 0ull ? 1u : 0u;
+		return L;
+	}
 	// scores of the last DP row -> LDS (clamped at -32768; only scores >= minsc matter afterwards)
 	static __device__ __forceinline__ void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols, bool wide) {
 		wave_fence();
@@ -719,6 +751,18 @@ struct DevPlat {
 		uint32_t a = 0, b = 0;
 		if (i < n) { const uint32_t* p = reinterpret_cast<const uint32_t*>(cands + i); a = gld(p); b = gld(p + 1); }
 		w0 = a; w1 = b;
+	}
+	// lane i <- p[base + i] (0 past n)
+	static __device__ __forceinline__ LaneReg lanes_load_u32(const BT2_G uint32_t* p, uint32_t base, uint32_t n) {
+		const uint32_t i = base + (threadIdx.x & 63);
+		return i < n ? gld(p + i) : 0u;
+	}
+	// is (row, col) within sq rows and sq columns of one of the first n cells (row | col << 16) held in the lanes of r?
+	static __device__ __forceinline__ bool near_any(LaneReg r, uint32_t n, uint32_t row, uint32_t col, uint32_t sq) {
+		const uint32_t l = threadIdx.x & 63;
+		const uint32_t orow = r & 0xffffu, ocol = r >> 16;
+		const uint32_t dr = row > orow ? row - orow : orow - row, dc = col > ocol ? col - ocol : ocol - col;
+		return __ballot(l < n && dr <= sq && dc <= sq) != 0ull;
 	}
 	// Backtrace tile anchored at (row, col): lanes 0-15 cell(row-d, col-d), 16-31 cell(row-d-1, col-d),
 	// 32-47 cell(row-d, col-d-1), 48-63 mask(row-d, col-d); one load instruction per array, one latency.
@@ -1052,6 +1096,77 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 	else
 	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
 	                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fills as a stage (bt2g_dp_fill, include/bt2g.h): every problem goes through DevPlat::dp_fill_ee / dp_fill_local -- the
+// functions the worker calls -- on a wave's private scratch, and what they leave behind is copied to the problem's output block.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(128)))
+k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, const uint8_t* __restrict__ d_rd, const uint8_t* __restrict__ d_qu,
+          const uint8_t* __restrict__ d_rf, uint8_t* __restrict__ d_out, uint8_t* __restrict__ scratch, uint64_t scratch_stride,
+          uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes) {
+	const uint32_t lane = threadIdx.x & 63;
+	g_P = P;
+	DpScratch dp;
+	carve_scratch(dp, scratch + (uint64_t)blockIdx.x * scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
+	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch;      // (the fills do not touch the work area)
+	wave_fence();
+	for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
+		const bt2g_dp_problem pr = probs[p];
+		const uint32_t rows = pr.rows, cols = pr.cols;
+		BT2_G bt2g_dp_out* out = (BT2_G bt2g_dp_out*)(d_out + pr.out_off);
+		wave_fence();
+		g_hot.len = rows;
+		for (uint32_t i = lane; i < rows; i += 64) { g_hot.seq[i] = d_rd[pr.rd_off + i]; g_hot.qual[i] = d_qu[pr.rd_off + i]; }
+		for (uint32_t j = lane; j < cols + 1; j += 64) g_hot.rf[j] = d_rf[pr.rf_off + j];
+		g_hot.n_dp_cells_score = g_hot.n_dp_cells_full = g_hot.n_dp_pass = 0;
+		wave_fence();
+		int64_t best;
+		uint32_t lastsolcol = 0, sat8 = 0;
+		if (pr.kind == BT2G_DP_LOCAL) best = DevPlat::dp_fill_local(g_P, *g_st.wp_generic(), true, rows, cols, (uint32_t*)dp.mat, (int64_t)pr.minsc, lastsolcol, sat8);
+		else best = DevPlat::dp_fill_ee(g_P, *g_st.wp_generic(), true, rows, cols, dp, pr.kind == BT2G_DP_EE_I16, (int64_t)pr.minsc);
+		wave_fence();
+		const bool has_mat = pr.kind != BT2G_DP_EE_U8 || (best != INT64_MIN && best >= (int64_t)pr.minsc);
+		const int32_t band_lo = (int32_t)dp.epoch[1];
+		const uint32_t band_w = dp.epoch[2];
+		if (lane == 0) {
+			out->best = best; out->lastsolcol = lastsolcol; out->sat8 = sat8; out->pad = 0;
+			out->band_lo = pr.kind == BT2G_DP_EE_U8 && has_mat ? band_lo : 0; out->band_w = pr.kind == BT2G_DP_EE_U8 && has_mat ? band_w : 0;
+			out->has_matrix = has_mat ? 1u : 0u;
+		}
+		BT2_G uint8_t* body = (BT2_G uint8_t*)(d_out + pr.out_off + sizeof(bt2g_dp_out));
+		if (pr.kind == BT2G_DP_EE_U8) {
+			const uint32_t c4 = (cols + 3u) & ~3u;
+			BT2_G int16_t* lr = (BT2_G int16_t*)body;
+			for (uint32_t j = lane; j < c4; j += 64) lr[j] = (has_mat && j < cols) ? g_hot.lastrow[j] : (int16_t)-0xff;
+			if (has_mat) {
+				BT2_G uint8_t* pm = body + (uint64_t)c4 * 2;
+				const BT2_G uint8_t* src = (const BT2_G uint8_t*)dp.mat;
+				for (uint64_t k = lane; k < (uint64_t)rows * band_w; k += 64) pm[k] = src[k];
+			}
+		} else {
+			const uint32_t R = dp_R(rows);
+			const BT2_G uint64_t* m64 = (const BT2_G uint64_t*)dp.mat;
+			BT2_G int32_t* H = (BT2_G int32_t*)body;
+			const uint64_t ncell = (uint64_t)rows * cols;
+			for (uint64_t k = lane; k < ncell; k += 64) {
+				const uint32_t i = (uint32_t)(k / cols), j = (uint32_t)(k % cols);
+				const uint64_t c = m64[dp_cell(R, i, j)];
+				const uint32_t h = (uint32_t)(c & 0xffff), e = (uint32_t)((c >> 16) & 0xffff), f = (uint32_t)((c >> 32) & 0xffff);
+				if (pr.kind == BT2G_DP_EE_I16) { H[k] = (int32_t)(int16_t)h; H[ncell + k] = (int32_t)(int16_t)e; H[2 * ncell + k] = (int32_t)(int16_t)f; }
+				else { H[k] = (int32_t)h; H[ncell + k] = (int32_t)e; H[2 * ncell + k] = (int32_t)f; }
+			}
+		}
+		wave_fence();
+	}
+}
+
+hipError_t launch_dp_fill(const AlignParams& P, const bt2g_dp_problem* d_probs, uint32_t n, const uint8_t* d_rd, const uint8_t* d_qu, const uint8_t* d_rf,
+                          uint8_t* d_out, uint8_t* d_scratch, uint64_t scratch_stride, uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes,
+                          uint32_t n_waves, hipStream_t st) {
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_dp_fill, dim3(n < n_waves ? n : n_waves), dim3(64), 0, st, P, d_probs, n, d_rd, d_qu, d_rf, d_out, d_scratch, scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
 	return hipGetLastError();
 }
 

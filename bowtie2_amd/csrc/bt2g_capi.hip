@@ -288,30 +288,38 @@ void bt2g_scoring_default(bt2g_scoring* sc) {
 	sc->rd_gap_const = 5; sc->rd_gap_linear = 3; sc->rf_gap_const = 5; sc->rf_gap_linear = 3; sc->gapbar = 4;
 }
 
-int bt2g_sw_fill_ee_u8(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_problem* d_probs, uint32_t n,
-                       const uint8_t* d_rd, const uint8_t* d_qu, const uint8_t* d_rf, uint8_t* d_mat, int32_t* d_best,
-                       void* stream) {
+uint64_t bt2g_dp_out_bytes(uint32_t kind, uint32_t rows, uint32_t cols) {
+	uint64_t b = sizeof(bt2g_dp_out);
+	if (kind == BT2G_DP_EE_U8) b += (uint64_t)((cols + 3u) & ~3u) * 2 + pred_cells(rows ? rows : 1, cols ? cols : 1);      // the widest band the problem can have
+	else b += (uint64_t)rows * cols * 3 * 4;
+	return (b + 7) & ~(uint64_t)7;
+}
+
+int bt2g_dp_fill(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_problem* d_probs, uint32_t n,
+                 const uint8_t* d_rd, const uint8_t* d_qu, const uint8_t* d_rf, uint8_t* d_out, void* stream) {
 	if (!c) return BT2G_ERR_ARG;
 	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
-	if (!sc || (!d_probs && n) || !d_best) return fail(c, BT2G_ERR_ARG, "bad argument");
+	if (!sc || (!d_probs && n) || (!d_out && n)) return fail(c, BT2G_ERR_ARG, "bad argument");
 	if (n == 0) return 0;
 	hipStream_t st = (hipStream_t)stream;
-	// size the per-wave scratch from the problem shapes (this entry point is the stand-alone /
-	// inspection form of the fill; the fused aligner sizes its scratch once per batch)
+	// the per-wave scratch is sized from the problem shapes (this entry point is the inspection form of the fills; the worker sizes
+	// its scratch once per batch)
 	std::vector<bt2g_dp_problem> hp(n);
 	hipError_t e = hipMemcpyAsync(hp.data(), d_probs, sizeof(bt2g_dp_problem) * n, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	if (e != hipSuccess) return hip_fail(c, e, "copy DP problems");
-	uint64_t per_wave = 0;
+	uint32_t max_rows = 1;
 	for (const auto& p : hp) {
-		if (p.rows > 512) return fail(c, BT2G_ERR_UNSUPPORTED, "DP rows > 512");
-		const uint64_t b = dp_scratch_bytes(p.rows ? p.rows : 1, p.cols ? p.cols : 1);
-		if (b > per_wave) per_wave = b;
+		if (p.rows == 0 || p.cols == 0 || p.rows > BT2G_MAX_READ_LEN || p.cols + 1 > (uint32_t)kMaxCols) return fail(c, BT2G_ERR_UNSUPPORTED, "DP problem outside 1..512 rows x 1..1099 columns");
+		if (p.kind > BT2G_DP_LOCAL || (p.out_off & 7)) return fail(c, BT2G_ERR_ARG, "bad DP problem (kind / output offset)");
+		if (p.rows > max_rows) max_rows = p.rows;
 	}
-	per_wave = (per_wave + 255) & ~255ull;
-	uint32_t n_waves = c->n_cu * 8;
+	uint64_t mat_bytes, mask_bytes, pmask_bytes, stride;
+	align_scratch_sizes(max_rows, true, 255, mat_bytes, mask_bytes, pmask_bytes, stride);      // "paired": windows up to kMaxCols columns
+	stride = (mat_bytes + mask_bytes + pmask_bytes + 4095) & ~(uint64_t)4095;
+	uint32_t n_waves = c->n_cu * 4;
 	if (n_waves > n) n_waves = n;
-	const uint64_t need = per_wave * n_waves;
+	const uint64_t need = stride * n_waves;
 	if (need > c->dp_scratch_bytes) {
 		if (c->d_dp_scratch) (void)hipFree(c->d_dp_scratch);
 		c->d_dp_scratch = nullptr; c->dp_scratch_bytes = 0;
@@ -319,8 +327,15 @@ int bt2g_sw_fill_ee_u8(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_proble
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(dp scratch)");
 		c->dp_scratch_bytes = need;
 	}
-	e = launch_sw_fill_ee_u8(*sc, d_probs, n, d_rd, d_qu, d_rf, d_mat, d_best, c->d_dp_scratch, per_wave, n_waves, c->d_cnt, st);
-	return e == hipSuccess ? 0 : hip_fail(c, e, "k_sw_fill_ee_u8");
+	e = hipMemsetAsync(c->d_dp_scratch, 0, need, st);      // epoch words and tagged masks start from zero
+	if (e != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(dp scratch)");
+	AlignParams P;
+	memset(&P, 0, sizeof(P));
+	P.mm_type = sc->mm_pen_type; P.mm_max = sc->mm_max; P.mm_min = sc->mm_min; P.n_pen = sc->n_pen;
+	P.rdgapo = sc->rd_gap_const + sc->rd_gap_linear; P.rdgape = sc->rd_gap_linear; P.rfgapo = sc->rf_gap_const + sc->rf_gap_linear; P.rfgape = sc->rf_gap_linear;
+	P.gapbar = sc->gapbar; P.match_bonus = sc->match_bonus;
+	e = launch_dp_fill(P, d_probs, n, d_rd, d_qu, d_rf, d_out, c->d_dp_scratch, stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, st);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "k_dp_fill");
 }
 
 uint64_t bt2g_align_result_stride(uint32_t khits) {

@@ -4,16 +4,11 @@
 //   k_seed_search_exact  one lane per (read, strand, seed): startSearchSeedBi + searchSeedBi for
 //                        SEED_TYPE_EXACT seeds (aligner_seed.cpp:1638-2037)
 //   k_resolve_offsets    one lane per SA row: Ebwt::getOffset + joinedToTextOff (bt2_idx.cpp:54-171)
-//   k_sw_fill_ee_u8      one wavefront per DP problem: the fixed point computed by
-//                        alignNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:775-1146)
+//   (the DP fills live in bt2g_align_kernel.hip: the worker's own device functions, also reachable as a stage through bt2g_dp_fill)
 //
 // The FM kernels are latency/HBM-bound random 64/128-byte line reads: every lane owns an
 // independent backward-search chain so a wave keeps 64-128 line fetches in flight; no LDS
-// staging is used because no two lanes share a side except by accident.  The DP kernel is
-// VALU/shuffle-bound: the anti-diagonal wavefront is mapped onto the 64 lanes (lane = block
-// of consecutive read rows), H/F/ref-char flow lane-to-lane with __shfl_up, and the matrix
-// is written in "wavefront-major" order so that every store instruction writes 64 contiguous
-// bytes.
+// staging is used because no two lanes share a block except by accident.
 #include "bt2g_kernels.hpp"
 #include "bt2g_fm_search.hpp"
 
@@ -330,186 +325,6 @@ hipError_t launch_resolve_offsets(const DevIndex<TOff>& ix, const uint64_t* d_ro
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
 	hipLaunchKernelGGL(k_resolve_offsets<TOff>, dim3((uint32_t)grid), dim3(block), 0, st, ix, d_rows, d_qlen, n,
 	                   reject_straddle, d_out, d_cnt);
-	return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------
-// end-to-end u8 DP fill, one wavefront per problem
-// ------------------------------------------------------------------------------------
-//
-// Lane l owns read rows [l*R, l*R+R); at step t it computes column j = t - l for its R rows.
-// Cross-lane inputs (last row of the lane above, previous step) arrive by __shfl_up:
-//   H[lR-1][j]   -> F / gap-open source for row lR
-//   F[lR-1][j]
-//   H[lR-1][j-1] -> diagonal for row lR   (what we received one step earlier)
-//   ref char j   -> handed down the lanes, lane 0 fetches rf[t]
-// Wavefront-major scratch layout (coalesced 64-byte stores):
-//   byte address of matrix m (0=H,1=E,2=F), row i, column j  =  ((t*3 + m)*R + (i%R))*64 + (i/R),  t = j + i/R
-//
-__host__ __device__ inline uint32_t dp_rows_per_lane(uint32_t rows) { return (rows + 63) / 64; }
-
-uint64_t dp_scratch_bytes(uint32_t rows, uint32_t cols) {
-	const uint32_t R = dp_rows_per_lane(rows);
-	const uint32_t lanes = (rows + R - 1) / R;
-	const uint64_t steps = (uint64_t)cols + lanes - 1;
-	return steps * 3 * R * 64;
-}
-
-struct DpScoring {
-	int mm_type, mm_max, mm_min, n_pen, rdgapo, rdgape, rfgapo, rfgape, gapbar, match_bonus;
-};
-
-__device__ __forceinline__ int subs_u8(int a, int b) { const int r = a - b; return r < 0 ? 0 : r; }
-
-template <int R>
-__device__ __forceinline__ int sw_fill_ee_u8_wave(const DpScoring& sc, const uint8_t* __restrict__ rd,
-                                                   const uint8_t* __restrict__ qu, uint32_t rows,
-                                                   const uint8_t* __restrict__ rf, uint32_t cols,
-                                                   uint8_t* __restrict__ scratch) {
-	const int lane = threadIdx.x & 63;
-	const uint32_t nlanes = (rows + R - 1) / R;
-	// per-row constants
-	int rdc[R], mmp[R], veto[R];
-	bool valid[R];
-#pragma unroll
-	for (int r = 0; r < R; r++) {
-		const uint32_t i = (uint32_t)lane * R + r;
-		valid[r] = i < rows;
-		const int c = valid[r] ? rd[i] : 4;
-		int q = valid[r] ? qu[i] : 0;
-		rdc[r] = c;
-		if (sc.mm_type == 3) {   // COST_MODEL_QUAL (scoring.h:106-114)
-			const int qq = q < 40 ? q : 40;
-			const float frac = (float)qq / 40.0f;
-			mmp[r] = sc.mm_min + (int)(frac * (float)(sc.mm_max - sc.mm_min));
-		} else {
-			mmp[r] = sc.mm_max;
-		}
-		veto[r] = (valid[r] && ((int)i < sc.gapbar || (int)(rows - i - 1) < sc.gapbar)) ? 0xff : 0;
-	}
-	int Hprev[R], Eprev[R];     // column j-1 of my rows
-#pragma unroll
-	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
-	int myHlast = 0, myFlast = 0;      // my last row, previous step (column j-1 for me == column j for lane+1 ... see shuffles)
-	int upHdiag = 0;                   // H[lR-1][j-1]
-	int refm = 0;                      // reference mask of my current column
-	int best = 0;
-	const uint32_t steps = cols + nlanes - 1;
-	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
-	const int last_r = (int)((rows - 1) % R);
-	for (uint32_t t = 0; t < steps; t++) {
-		// hand values down one lane
-		const int upH = __shfl_up(myHlast, 1);
-		const int upF = __shfl_up(myFlast, 1);
-		int upRef = __shfl_up(refm, 1);
-		if (lane == 0) upRef = (t < cols) ? rf[t] : 16;
-		refm = upRef;
-		const int j = (int)t - lane;
-		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
-		int refc = 4;   // lowest set bit picks the profile row; N (16) -> 4 (mask.cpp:31)
-		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
-		int hdiag = (lane == 0) ? 0xff : (j == 0 ? 0 : upHdiag);
-		int fin_h = upH, fin_f = upF;   // row above my first row, same column
-		int Hnew[R], Enew[R], Fnew[R];
-#pragma unroll
-		for (int r = 0; r < R; r++) {
-			// match / mismatch / N penalty for (row, ref char)
-			int pen;
-			if (rdc[r] > 3 || refc > 3) pen = sc.n_pen;
-			else pen = (rdc[r] == refc) ? -sc.match_bonus : mmp[r];
-			const int e = (j == 0) ? 0 : max(subs_u8(Eprev[r], sc.rdgape), subs_u8(subs_u8(Hprev[r], sc.rdgapo), veto[r]));
-			int f;
-			if (lane == 0 && r == 0) f = 0;
-			else f = subs_u8(max(subs_u8(fin_f, sc.rfgape), subs_u8(fin_h, sc.rfgapo)), veto[r]);
-			const int h = max(max(subs_u8(hdiag, pen), e), f);
-			Hnew[r] = h; Enew[r] = e; Fnew[r] = f;
-			hdiag = Hprev[r];      // diagonal for the next row = H[i][j-1]
-			fin_h = h; fin_f = f;
-		}
-		if (active) {
-			uint8_t* base = scratch + ((uint64_t)t * 3 * R) * 64 + lane;
-#pragma unroll
-			for (int r = 0; r < R; r++) {
-				base[(0 * R + r) * 64] = (uint8_t)Hnew[r];
-				base[(1 * R + r) * 64] = (uint8_t)Enew[r];
-				base[(2 * R + r) * 64] = (uint8_t)Fnew[r];
-			}
-#pragma unroll
-			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
-			if (lane_has_last) best = max(best, Hnew[last_r]);
-		}
-		// what the lane below needs next step: my last row at this column, and (one step later) as its diagonal
-		upHdiag = upH;
-		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
-	}
-	// broadcast the best last-row score from the lane that owns the last row
-	best = __shfl(best, (int)((rows - 1) / R));
-	return best - 0xff;
-}
-
-__global__ void __launch_bounds__(64)
-k_sw_fill_ee_u8(DpScoring sc, const bt2g_dp_problem* __restrict__ probs, uint32_t n, const uint8_t* __restrict__ d_rd,
-                const uint8_t* __restrict__ d_qu, const uint8_t* __restrict__ d_rf, uint8_t* __restrict__ d_mat,
-                int32_t* __restrict__ d_best, uint8_t* __restrict__ d_scratch, uint64_t scratch_per_wave,
-                uint32_t n_waves, DevCounters* cnt) {
-	const int lane = threadIdx.x & 63;
-	unsigned long long cells = 0;
-	// persistent waves: wave w handles problems w, w+n_waves, ...
-	for (uint32_t p = blockIdx.x; p < n; p += n_waves) {
-		const bt2g_dp_problem pr = probs[p];
-		uint8_t* scratch = d_scratch + (uint64_t)blockIdx.x * scratch_per_wave;
-		const uint8_t* rd = d_rd + pr.rd_off;
-		const uint8_t* qu = d_qu + pr.rd_off;
-		const uint8_t* rf = d_rf + pr.rf_off;
-		const uint32_t R = dp_rows_per_lane(pr.rows);
-		int best = -0xff;
-		if (pr.rows > 0 && pr.cols > 0) {
-			switch (R) {
-				case 1: best = sw_fill_ee_u8_wave<1>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
-				case 2: best = sw_fill_ee_u8_wave<2>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
-				case 3: best = sw_fill_ee_u8_wave<3>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
-				case 4: best = sw_fill_ee_u8_wave<4>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
-				case 5: best = sw_fill_ee_u8_wave<5>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
-				case 6: best = sw_fill_ee_u8_wave<6>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
-				case 7: best = sw_fill_ee_u8_wave<7>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
-				default: best = sw_fill_ee_u8_wave<8>(sc, rd, qu, pr.rows, rf, pr.cols, scratch); break;
-			}
-		}
-		if (lane == 0) d_best[p] = best;
-		cells += (lane == 0) ? (unsigned long long)pr.rows * pr.cols : 0;
-		// export to canonical row-major H|E|F for inspection / parity tests
-		if (pr.mat_off != ~0ull && pr.rows > 0 && pr.cols > 0) {
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // other lanes' scratch stores -> visible
-			const uint64_t ncell = (uint64_t)pr.rows * pr.cols;
-			uint8_t* dst = d_mat + pr.mat_off;
-			for (uint64_t k = lane; k < ncell; k += 64) {
-				const uint32_t i = (uint32_t)(k / pr.cols), j = (uint32_t)(k % pr.cols);
-				const uint32_t l = i / R, r = i % R;
-				const uint64_t t = (uint64_t)j + l;
-				const uint8_t* src = scratch + (t * 3 * R) * 64 + l;
-				dst[k] = src[(0 * R + r) * 64];
-				dst[ncell + k] = src[(1 * R + r) * 64];
-				dst[2 * ncell + k] = src[(2 * R + r) * 64];
-			}
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // reads done before the next problem overwrites
-		}
-	}
-	if (lane == 0 && cells) atomicAdd(&cnt->dp_cells, cells);
-}
-
-hipError_t launch_sw_fill_ee_u8(const bt2g_scoring& s, const bt2g_dp_problem* d_probs, uint32_t n, const uint8_t* d_rd,
-                                const uint8_t* d_qu, const uint8_t* d_rf, uint8_t* d_mat, int32_t* d_best,
-                                uint8_t* d_scratch, uint64_t scratch_per_wave, uint32_t n_waves,
-                                DevCounters* d_cnt, hipStream_t st) {
-	if (n == 0) return hipSuccess;
-	DpScoring sc;
-	sc.mm_type = s.mm_pen_type; sc.mm_max = s.mm_max; sc.mm_min = s.mm_min; sc.n_pen = s.n_pen;
-	sc.rdgapo = s.rd_gap_const + s.rd_gap_linear; sc.rdgape = s.rd_gap_linear;
-	sc.rfgapo = s.rf_gap_const + s.rf_gap_linear; sc.rfgape = s.rf_gap_linear;
-	sc.gapbar = s.gapbar; sc.match_bonus = s.match_bonus;
-	const uint32_t grid = n < n_waves ? n : n_waves;
-	hipLaunchKernelGGL(k_sw_fill_ee_u8, dim3(grid), dim3(64), 0, st, sc, d_probs, n, d_rd, d_qu, d_rf, d_mat, d_best,
-	                   d_scratch, scratch_per_wave, grid, d_cnt);
 	return hipGetLastError();
 }
 

@@ -40,19 +40,12 @@ template <typename TOff>
 hipError_t launch_resolve_offsets(const DevIndex<TOff>& ix, const uint64_t* d_rows, const uint32_t* d_qlen, uint64_t n,
                                   int reject_straddle, bt2g_resolved* d_out, DevCounters* d_cnt, hipStream_t st);
 
-hipError_t launch_sw_fill_ee_u8(const bt2g_scoring& sc, const bt2g_dp_problem* d_probs, uint32_t n, const uint8_t* d_rd,
-                                const uint8_t* d_qu, const uint8_t* d_rf, uint8_t* d_mat, int32_t* d_best,
-                                uint8_t* d_scratch, uint64_t scratch_per_wave, uint32_t n_waves,
-                                DevCounters* d_cnt, hipStream_t st);
-
 // index transcoding at load time (bt2g_rankidx.hip): rank blocks from the verbatim sides, the full suffix array from its sample
 template <typename TOff>
 hipError_t launch_make_rank_blocks(const uint8_t* d_ebwt, uint64_t n_sides, const TOff fchr[5], TOff zoff, RankBlock* d_out, uint64_t n_blocks, hipStream_t st);
 template <typename TOff>
 hipError_t launch_make_full_sa(const DevEbwt<TOff>& e, const TOff* d_offs, uint64_t* d_sa, hipStream_t st);
 
-// bytes of wavefront-layout DP scratch needed for one problem of the given shape
-uint64_t dp_scratch_bytes(uint32_t rows, uint32_t cols);
 
 } // namespace bt2g
 #endif

@@ -148,9 +148,9 @@ typedef struct {
 int bt2g_resolve_offsets(bt2g_ctx *ctx, const uint64_t *d_rows, const uint32_t *d_qlen, uint64_t n,
                          int reject_straddle, bt2g_resolved *d_out, void *stream);
 
-/* ---- stage 4: end-to-end u8 DP fill ------------------------------------ */
+/* ---- stage 4: the DP fills ----------------------------------------------- */
 typedef struct {
-	int32_t match_bonus;      /* 0 in end-to-end mode                         */
+	int32_t match_bonus;      /* 0 in end-to-end mode, --ma in local mode     */
 	int32_t mm_pen_type;      /* 3 = quality-aware (default), 1 = constant    */
 	int32_t mm_max, mm_min;   /* --mp 6,2                                     */
 	int32_t n_pen;            /* --np 1                                       */
@@ -160,24 +160,47 @@ typedef struct {
 
 void bt2g_scoring_default(bt2g_scoring *sc);
 
-/* One DP problem: read rows in alignment orientation + reference masks. */
+/* One DP problem: the read in the orientation being aligned + the reference window as masks (1 << base, 16 = N). */
 typedef struct {
-	uint64_t rd_off;          /* offset into d_rd / d_qu (phred, i.e. ASCII-33) */
-	uint32_t rows;
-	uint64_t rf_off;          /* offset into d_rf (masks 1<<base, 16 = N)    */
-	uint32_t cols;
-	uint64_t mat_off;         /* offset (bytes) of this problem's H then E then F (each rows*cols, row-major) in d_mat; UINT64_MAX = don't export */
+	uint64_t rd_off;          /* offset into d_rd (codes 0..4) and d_qu (ASCII qualities, Phred+33) */
+	uint64_t rf_off;          /* offset into d_rf: cols + 1 masks (the column past the window is looked at by the local candidate test) */
+	uint32_t rows, cols;
+	int32_t  minsc;           /* minimum score: sets the band of the 8-bit fill, the local fill's bail-out column */
+	uint32_t kind;            /* BT2G_DP_EE_U8, BT2G_DP_EE_I16 or BT2G_DP_LOCAL */
+	uint64_t out_off;         /* offset (bytes, multiple of 8) of this problem's output block in d_out */
 } bt2g_dp_problem;
+#define BT2G_DP_EE_U8   0     /* alignNucleotidesEnd2EndSseU8  (aligner_swsse_ee_u8.cpp:775-1146)  */
+#define BT2G_DP_EE_I16  1     /* alignNucleotidesEnd2EndSseI16 (aligner_swsse_ee_i16.cpp:780-1170) */
+#define BT2G_DP_LOCAL   2     /* alignNucleotidesLocalSseU8 / ...I16 (aligner_swsse_loc_u8.cpp:927, aligner_swsse_loc_i16.cpp:938) */
+
+/* what a problem's output block starts with */
+typedef struct {
+	int64_t  best;            /* best score (last row end to end, any cell local), de-biased; INT64_MIN = the band exceeds this build */
+	uint32_t lastsolcol;      /* local: last column whose maximum reaches minsc before the fill's bail-out point (lastsolcol_) */
+	uint32_t sat8;            /* local: the reference's 8-bit kernel would have saturated (it then redoes the fill in 16 bits) */
+	int32_t  band_lo;         /* BT2G_DP_EE_U8: cell (i, j) of the matrix is byte i * band_w + (j - i + band_lo)              */
+	uint32_t band_w;
+	uint32_t has_matrix;      /* 0: end-to-end fill that did not reach minsc -- no matrix was stored                          */
+	uint32_t pad;
+} bt2g_dp_out;
 
 /*
- * Replaces SwAligner::align's end-to-end 8-bit fill,
- * alignNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:775-1146): fills
- * H/E/F to the same fixed point and returns per problem best = max last-row
- * H - 0xff in d_best[n].  One wavefront per problem.  rows <= 512.
+ * The fills of the worker (`SwAligner::align`, aligner_sw.cpp:500-729) as a stage: every problem is filled by the same device
+ * functions k_align_reads uses, one wavefront per problem, and what they leave behind is written to the problem's output block:
+ *   bt2g_dp_out, then
+ *   BT2G_DP_EE_U8 : int16 lastrow[cols rounded up to 4] (scores of the last row, de-biased, -255 where the band does not reach),
+ *                   then, if has_matrix, rows * band_w bytes of predecessor bits (1 H-diagonal, 2 H==E, 4 H==F, 8 E opens from
+ *                   H-left, 16 E extends E-left, 32 F opens from H-up, 64 F extends F-up: what the reference's backtrace asks of
+ *                   H/E/F, aligner_swsse_ee_u8.cpp:1330-1520); only cells inside the band are meaningful;
+ *   BT2G_DP_EE_I16: int32 H[rows*cols], E[...], F[...] row-major, the cell values of the reference's 16-bit kernel
+ *                   (0x7fff = perfect, -32768 = minus infinity);
+ *   BT2G_DP_LOCAL : the same three arrays with plain local scores (floor 0) -- the reference's 16-bit kernel holds score - 32768,
+ *                   its 8-bit kernel the score itself wherever it does not saturate.
+ * bt2g_dp_out_bytes() gives the size of a block.  rows <= BT2G_MAX_READ_LEN, cols <= 1100.
  */
-int bt2g_sw_fill_ee_u8(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_problem *d_probs, uint32_t n,
-                       const uint8_t *d_rd, const uint8_t *d_qu, const uint8_t *d_rf,
-                       uint8_t *d_mat, int32_t *d_best, void *stream);
+uint64_t bt2g_dp_out_bytes(uint32_t kind, uint32_t rows, uint32_t cols);
+int bt2g_dp_fill(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_problem *d_probs, uint32_t n,
+                 const uint8_t *d_rd, const uint8_t *d_qu, const uint8_t *d_rf, uint8_t *d_out, void *stream);
 
 
 /* ---- the fused per-read worker ------------------------------------------ */

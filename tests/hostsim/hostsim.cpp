@@ -106,6 +106,19 @@ struct HostPlat {
 		}
 		return r;
 	}
+	static LaneReg lanes_load_u32(const uint32_t* p, uint32_t base, uint32_t n) {
+		LaneReg r;
+		for (uint32_t l = 0; l < 64; l++) r.v[l] = base + l < n ? p[base + l] : 0u;
+		return r;
+	}
+	static bool near_any(const LaneReg& r, uint32_t n, uint32_t row, uint32_t col, uint32_t sq) {
+		for (uint32_t l = 0; l < n && l < 64; l++) {
+			const uint32_t orow = r.v[l] & 0xffffu, ocol = r.v[l] >> 16;
+			const uint32_t dr = row > orow ? row - orow : orow - row, dc = col > ocol ? col - ocol : ocol - col;
+			if (dr <= sq && dc <= sq) return true;
+		}
+		return false;
+	}
 	static void lanes_load_cands(const BtCand* cands, uint32_t base, uint32_t n, LaneReg& w0, LaneReg& w1) {
 		for (uint32_t l = 0; l < 64; l++) {
 			const uint32_t i = base + l;
@@ -190,6 +203,30 @@ struct HostPlat {
 			if (m != 1) mm |= 1ull << (td + k);
 			info.v[td + k] = ((uint32_t)readc << 4) | ((uint32_t)refm << 8) | ((uint32_t)readq << 16) | (m == -1 ? 2u : 0u);
 			dp.pmask[pred_idx(band_lo, band_w, r, c)] = 3u | (epoch << kEpochShift);
+		}
+		return L;
+	}
+	static uint32_t bt_gap_run(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, const LaneReg& tile, const LaneReg& tile_hi, uint32_t td, uint32_t row,
+	                           uint32_t col, bool read_gap, bool fw, uint32_t rdlen, uint32_t maxl, uint32_t nned, int r_triml, int r_corel, int r_corer, uint32_t& core) {
+		core = 0;
+		uint32_t L = 0;
+		for (uint32_t d = td; d < 64; d++, L++) {
+			const uint32_t k = d - td;
+			if (!(k < maxl && (read_gap ? k <= col : k < row))) break;
+			const uint32_t pb = tile.v[d];
+			const uint32_t m = read_gap ? (pb >> 3) & 3u : (pb >> 5) & 3u;
+			if (!(tile_hi.v[d] == 0 && m == 2u)) break;
+		}
+		for (uint32_t k = 0; k < L; k++) {
+			const uint32_t r = read_gap ? row : row - k, c = read_gap ? col - k : col;
+			Edit e;
+			if (read_gap) { const int refm = g_hot.rf[c]; e.pos = (uint16_t)(r + 1); e.chr = (uint8_t)((refm == 1 || refm == 2 || refm == 4 || refm == 8) ? code2chr(__builtin_ctz((unsigned)refm)) : 'N'); e.qchr = '-'; e.type = EDIT_READ_GAP; }
+			else { e.pos = (uint16_t)r; e.chr = '-'; e.qchr = code2chr(rd_char(g_hot, rdlen, fw, r)); e.type = EDIT_REF_GAP; }
+			e.pad = 0;
+			g_hot.ned[nned + k] = e;
+			dp.pmask[pred_idx(band_lo, band_w, r, c)] = (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift);
+			const int diagi = (int)c - (int)r + r_triml;
+			if (diagi >= r_corel && diagi <= r_corer) core = 1;
 		}
 		return L;
 	}

@@ -49,7 +49,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(b.SweepOut) == 48
     assert C.sizeof(b.SeedHit) == 32
     assert C.sizeof(b.Resolved) == 40
-    assert C.sizeof(b.DpProblem) == 40
+    assert C.sizeof(b.DpProblem) == 40 and C.sizeof(b.DpOut) == 32
     assert C.sizeof(b.Scoring) == 40
     assert C.sizeof(b.Counters) == 40
 

@@ -154,69 +154,211 @@ def test_resolve_offsets(case):
                 assert (out[k].toff, out[k].tlen) == (t[1].value, t[2].value)
 
 
-def run_dp(ctx, probs):
-    """probs: list of (rd codes bytes, phred bytes, rf masks bytes[cols]) -> list of (best, H|E|F bytes)"""
+def run_dp_fill(ctx, probs, scoring=None):
+    """probs: list of (kind, rd codes bytes, quality ASCII bytes, rf masks bytes [cols + 1], minsc) through bt2g_dp_fill -- the worker's own
+    fill functions as a stage.  Returns per problem a dict: header fields + lastrow / pred (kind 0) or H, E, F (kinds 1, 2)."""
     import numpy as np
     import torch
     dev = torch.device("cuda", 0)
-    rd = b"".join(p[0] for p in probs)
-    qu = b"".join(p[1] for p in probs)
-    rf = b"".join(p[2] for p in probs)
+    L = b.lib()
+    rd = b"".join(p[1] for p in probs)
+    qu = b"".join(p[2] for p in probs)
+    rf = b"".join(p[3] for p in probs)
     arr = (b.DpProblem * len(probs))()
-    ro = fo = mo = 0
+    ro = fo = oo = 0
     for k, p in enumerate(probs):
-        rows, cols = len(p[0]), len(p[2])
-        arr[k] = b.DpProblem(ro, rows, fo, cols, mo)
+        rows, cols = len(p[1]), len(p[3]) - 1
+        arr[k] = b.DpProblem(ro, fo, rows, cols, p[4], p[0], oo)
         ro += rows
-        fo += cols
-        mo += 3 * rows * cols
+        fo += cols + 1
+        oo += L.bt2g_dp_out_bytes(p[0], rows, cols)
     to = lambda x: torch.from_numpy(np.frombuffer(bytes(x) + b"\0", dtype=np.uint8).copy()).to(dev)
-    d_probs = to(bytes(arr))
-    mat = torch.zeros(mo + 1, dtype=torch.uint8, device=dev)
-    best = torch.zeros(len(probs), dtype=torch.int32, device=dev)
-    ctx.sw_fill_ee_u8(d_probs[:-1], to(rd), to(qu), to(rf), mat, best)
-    m = mat.cpu().numpy().tobytes()
-    bs = best.cpu().tolist()
+    out = torch.zeros(oo + 8, dtype=torch.uint8, device=dev)
+    ctx.dp_fill(to(bytes(arr))[:-1], to(rd), to(qu), to(rf), out, scoring)
+    torch.cuda.synchronize()
+    raw = out.cpu().numpy().tobytes()
     res = []
     for k, p in enumerate(probs):
-        sz = 3 * len(p[0]) * len(p[2])
-        res.append((bs[k], m[arr[k].mat_off:arr[k].mat_off + sz]))
+        rows, cols = len(p[1]), len(p[3]) - 1
+        o = arr[k].out_off
+        hdr = b.DpOut.from_buffer_copy(raw[o:o + C.sizeof(b.DpOut)])
+        body = o + C.sizeof(b.DpOut)
+        r = {"best": hdr.best, "lastsolcol": hdr.lastsolcol, "sat8": hdr.sat8, "band_lo": hdr.band_lo, "band_w": hdr.band_w, "has_matrix": hdr.has_matrix}
+        if p[0] == b.DP_EE_U8:
+            c4 = (cols + 3) & ~3
+            r["lastrow"] = np.frombuffer(raw[body:body + 2 * c4], dtype="<i2")[:cols]
+            if hdr.has_matrix:
+                r["pred"] = np.frombuffer(raw[body + 2 * c4:body + 2 * c4 + rows * hdr.band_w], dtype=np.uint8).reshape(rows, hdr.band_w)
+        else:
+            m = np.frombuffer(raw[body:body + 12 * rows * cols], dtype="<i4").reshape(3, rows, cols)
+            r["H"], r["E"], r["F"] = m[0], m[1], m[2]
+        res.append(r)
     return res
 
 
-def test_dp_fill_golden_and_random(case):
+def oracle_fill_kind(L, kind, sc, rd, phred, rf, cols, minsc):
+    import numpy as np
+    i32p = C.POINTER(C.c_int32)
+    L.bt2o_sw_fill_kind.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int64, i32p, i32p, i32p,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bt2o_sw_fill_kind.restype = C.c_int64
+    rows = len(rd)
+    bufs = [(C.c_int32 * (rows * cols))() for _ in range(3)]
+    flag, colstop = C.c_int(), C.c_int()
+    got = L.bt2o_sw_fill_kind(kind, C.byref(sc), rd, phred, rows, rf, cols, minsc, bufs[0], bufs[1], bufs[2], C.byref(flag), C.byref(colstop))
+    return got, flag.value, colstop.value, [np.frombuffer(x, dtype="<i4").reshape(rows, cols) for x in bufs]
+
+
+def pred_bits_from_hef(sc, rd, phred, rf, H, E, F, L):
+    """The predecessor byte of every cell from the oracle's H/E/F (the reference's u8 encoding): the questions the reference's backtrace
+    asks of its matrices (aligner_swsse_ee_u8.cpp:1330-1520), as the band fill answers them while the neighbours are in registers
+    (PB_* in bt2g_align.hpp): 1 H came diagonally, 2 H == E, 4 H == F (both only where gaps are allowed), 8 E opens from H-left,
+    16 E extends E-left, 32 F opens from H-up, 64 F extends F-up."""
+    import numpy as np
+    rows, cols = H.shape
+    rdo, rde = sc.rd_gap_const + sc.rd_gap_linear, sc.rd_gap_linear
+    rfo, rfe = sc.rf_gap_const + sc.rf_gap_linear, sc.rf_gap_linear
+    out = np.zeros((rows, cols), dtype=np.uint8)
+    for i in range(rows):
+        ga = not (i < sc.gapbar or rows - i - 1 < sc.gapbar)
+        for j in range(cols):
+            m = rf[j]
+            pen = -L.bt2o_score(C.byref(sc), rd[i], m, phred[i])
+            h, e, f = int(H[i, j]), int(E[i, j]), int(F[i, j])
+            hdiag = 0xff if i == 0 else (0 if j == 0 else int(H[i - 1, j - 1]))
+            hl, el = (int(H[i, j - 1]), int(E[i, j - 1])) if j > 0 else (0, 0)
+            hu, fu = (int(H[i - 1, j]), int(F[i - 1, j])) if i > 0 else (0, 0)
+            c = 1 if hdiag - pen == h else 0
+            c |= 2 if ga and h == e else 0
+            c |= 4 if ga and h == f else 0
+            c |= 8 if hl - rdo == e else 0
+            c |= 16 if el - rde == e else 0
+            c |= 32 if hu - rfo == f else 0
+            c |= 64 if fu - rfe == f else 0
+            out[i, j] = c
+    return out
+
+
+def test_dp_fills_that_ship(case):
+    """The fills k_align_reads runs -- the banded 8-bit end-to-end fill that stores predecessor bits (every pairs-per-lane class the window
+    sizes allow), the 16-bit end-to-end fill, the local fill -- through bt2g_dp_fill, against the oracle's restatement of the reference's
+    kernels (pinned to reference-recorded matrices by tests/test_oracle_golden.py)."""
+    import numpy as np
     ctx, L, idx, refs = case
     sc = Scoring()
     L.bt2o_scoring_default(C.byref(sc))
-    with open(os.path.join(GOLD, "dp_golden.json")) as f:
-        gold = json.load(f)
-    probs = [(encode(p["rd"]), bytes(ord(c) - 33 for c in p["qu"]), bytes(1 << "ACGTN".index(c) for c in p["rf"])) for p in gold]
-    res = run_dp(ctx, probs)
-    for p, (best, mat) in zip(gold, res):
-        assert best == p["best"], (p["rows"], p["cols"])
-        assert sha(mat) == p["sha"], (p["rows"], p["cols"])   # bit-exact H, E and F vs the reference's SSE fill
-    # random shapes incl. every rows-per-lane class (1..8), ragged
-    rnd = random.Random(6)
-    probs = []
-    for rows in [1, 2, 3, 63, 64, 65, 127, 129, 150, 191, 193, 250, 256, 300, 400, 449, 512]:
-        cols = rows + rnd.choice([0, 1, 30, 60])
+    rnd = random.Random(11)
+
+    def problem(rows, cols, match=0.9, n_at=None):
         rdc = bytes(rnd.choice([0, 1, 2, 3, 0, 1, 2, 3, 4]) for _ in range(rows))
-        rfm = bytearray(1 << rnd.randrange(4) for _ in range(cols))
-        for i in range(min(rows, cols)):   # make the diagonal mostly match so scores stay off the floor
-            if rnd.random() < 0.9 and rdc[i] < 4:
-                rfm[i + (cols - rows) // 2] = 1 << rdc[i]
-        if rnd.random() < 0.5:
-            rfm[rnd.randrange(cols)] = 16
-        probs.append((rdc, bytes(rnd.choice([2, 12, 20, 30, 38, 40, 41]) for _ in range(rows)), bytes(rfm)))
-    res = run_dp(ctx, probs)
-    for (rdc, q, rfm), (best, mat) in zip(probs, res):
-        rows, cols = len(rdc), len(rfm)
-        H = C.create_string_buffer(rows * cols)
-        E = C.create_string_buffer(rows * cols)
-        F = C.create_string_buffer(rows * cols)
-        want = L.bt2o_sw_fill_ee_u8(C.byref(sc), rdc, q, rows, rfm, cols, H, E, F)
-        assert best == want, (rows, cols)
-        assert mat == H.raw + E.raw + F.raw, (rows, cols)
+        phred = bytes(rnd.choice([2, 12, 20, 30, 38, 40]) for _ in range(rows))
+        rfm = bytearray(1 << rnd.randrange(4) for _ in range(cols + 1))
+        off = max(0, (cols - rows) // 2)
+        for i in range(min(rows, cols - off)):
+            if rnd.random() < match and rdc[i] < 4:
+                rfm[i + off] = 1 << rdc[i]
+        if n_at is not None:
+            rfm[n_at] = 16
+        return rdc, phred, bytes(rfm)
+
+    # ---- 8-bit end to end, band = the whole rectangle (minsc -254 allows 83 reference gaps: every diagonal of a <= 84-row problem is in
+    #      the band), so EVERY stored predecessor byte can be checked; columns chosen to hit each pairs-per-lane class (RP 1,2,3,4,6,8,12)
+    probs, shapes = [], []
+    for rows, cols in [(1, 1), (2, 5), (30, 61), (64, 64), (84, 100), (70, 200), (80, 300), (84, 400), (60, 640), (84, 900), (50, 1090)]:
+        rdc, phred, rfm = problem(rows, cols, n_at=(cols // 3 if cols > 40 else None))
+        probs.append((b.DP_EE_U8, rdc, bytes(q + 33 for q in phred), rfm, -254))
+        shapes.append((rdc, phred, rfm))
+    res = run_dp_fill(ctx, probs)
+    rp_seen = set()
+    for (kind, rdc, qa, rfm, minsc), (rdc_, phred, _), r in zip(probs, shapes, res):
+        rows, cols = len(rdc), len(rfm) - 1
+        Hb, Eb, Fb = (C.create_string_buffer(rows * cols) for _ in range(3))
+        want = L.bt2o_sw_fill_ee_u8(C.byref(sc), rdc, phred, rows, rfm, cols, Hb, Eb, Fb)
+        H, E, F = (np.frombuffer(x.raw, dtype=np.uint8).reshape(rows, cols) for x in (Hb, Eb, Fb))
+        assert r["best"] == want and r["has_matrix"] == (1 if want >= minsc else 0), (rows, cols, r["best"], want)
+        if not r["has_matrix"]:
+            continue
+        assert r["band_lo"] == rows - 1 and r["band_w"] >= rows + cols - 1, (rows, cols, r["band_lo"], r["band_w"])
+        rp_seen.add(r["band_w"] // 128)
+        assert list(r["lastrow"]) == [int(v) - 0xff for v in H[rows - 1]], (rows, cols)
+        want_pred = pred_bits_from_hef(sc, rdc, phred, rfm, H, E, F, L)
+        got = np.zeros((rows, cols), dtype=np.uint8)
+        for i in range(rows):
+            got[i] = r["pred"][i, rows - 1 - i:rows - 1 - i + cols]       # cell (i, j) at byte j - i + band_lo
+        assert (got == want_pred).all(), (rows, cols, np.argwhere(got != want_pred)[:5])
+    assert rp_seen >= {1, 2, 3, 4, 6, 8}, rp_seen
+    # ---- 8-bit end to end, a real band (the worker's case: 150-bp read, minsc -90 and tighter): best and every last-row score that
+    #      reaches minsc equal the full-rectangle fill's
+    probs, shapes = [], []
+    for rows, cols, minsc, match in [(150, 211, -90, 0.93), (150, 211, -90, 0.6), (150, 211, -30, 0.97), (100, 161, -60, 0.9), (250, 311, -150, 0.92), (400, 461, -240, 0.95),
+                                     (150, 700, -90, 0.93), (36, 97, -22, 0.95)]:
+        for _ in range(3):
+            rdc, phred, rfm = problem(rows, cols, match)
+            probs.append((b.DP_EE_U8, rdc, bytes(q + 33 for q in phred), rfm, minsc))
+            shapes.append(phred)
+    res = run_dp_fill(ctx, probs)
+    n_pass = 0
+    for (kind, rdc, qa, rfm, minsc), phred, r in zip(probs, shapes, res):
+        rows, cols = len(rdc), len(rfm) - 1
+        Hb, Eb, Fb = (C.create_string_buffer(rows * cols) for _ in range(3))
+        want = L.bt2o_sw_fill_ee_u8(C.byref(sc), rdc, phred, rows, rfm, cols, Hb, Eb, Fb)
+        H = np.frombuffer(Hb.raw, dtype=np.uint8).reshape(rows, cols)
+        if want >= minsc:
+            n_pass += 1
+            assert r["best"] == want and r["has_matrix"] == 1, (rows, cols, minsc, r["best"], want)
+            for j in range(cols):
+                if int(H[rows - 1, j]) - 0xff >= minsc:
+                    assert int(r["lastrow"][j]) == int(H[rows - 1, j]) - 0xff, (rows, cols, j)
+                else:
+                    assert int(r["lastrow"][j]) < minsc, (rows, cols, j)
+        else:
+            assert r["best"] < minsc and r["has_matrix"] == 0, (rows, cols, minsc, r["best"], want)
+    assert n_pass >= 8
+    # ---- 16-bit end to end and local: every cell, on the reference-recorded problems of tests/golden/dp_kinds_golden.json + random shapes
+    with open(os.path.join(GOLD, "dp_kinds_golden.json")) as f:
+        gold = json.load(f)
+    probs, meta = [], []
+    for p in gold:
+        rows, cols = p["rows"], p["cols"]
+        rdc, phred = encode(p["rd"]), bytes(ord(c) - 33 for c in p["qu"])
+        rfm = bytes(1 << "ACGTN".index(c) for c in p["rf"]) + b"\x10"
+        kind = b.DP_EE_I16 if p["kind"] == 1 else b.DP_LOCAL
+        probs.append((kind, rdc, p["qu"].encode(), rfm, p["minsc"]))
+        meta.append((p["match_bonus"], phred))
+    for rows in (1, 3, 64, 65, 129, 200, 330, 449, 512):      # every rows-per-lane class of the anti-diagonal fills
+        cols = rows + rnd.choice([1, 30, 61])
+        rdc, phred, rfm = problem(rows, cols, 0.92)
+        probs.append((b.DP_EE_I16, rdc, bytes(q + 33 for q in phred), rfm, -int(0.6 * rows) - 1)); meta.append((0, phred))
+        probs.append((b.DP_LOCAL, rdc, bytes(q + 33 for q in phred), rfm, 20 + int(8 * np.log(rows))) if rows > 2 else (b.DP_LOCAL, rdc, bytes(q + 33 for q in phred), rfm, 1)); meta.append((2, phred))
+    by_bonus = {}
+    for k, (pr, (ma, phred)) in enumerate(zip(probs, meta)):
+        by_bonus.setdefault((ma, pr[0]), []).append(k)
+    out = [None] * len(probs)
+    for (ma, kind), ks in by_bonus.items():
+        dsc = b.Scoring()
+        b.lib().bt2g_scoring_default(C.byref(dsc))
+        dsc.match_bonus = ma
+        for k, r in zip(ks, run_dp_fill(ctx, [probs[k] for k in ks], dsc)):
+            out[k] = r
+    for (kind, rdc, qa, rfm, minsc), (ma, phred), r in zip(probs, meta, out):
+        rows, cols = len(rdc), len(rfm) - 1
+        osc = Scoring()
+        L.bt2o_scoring_default(C.byref(osc))
+        osc.match_bonus = ma
+        if kind == b.DP_EE_I16:
+            got, flag, colstop, (H, E, F) = oracle_fill_kind(L, 1, osc, rdc, phred, rfm, cols, minsc)
+            assert (r["H"] == H).all() and (r["E"] == E).all() and (r["F"] == F).all(), (rows, cols)
+            assert r["best"] == int(H[rows - 1].max()) - 0x7fff, (rows, cols)
+        else:
+            got3, flag3, colstop3, (H, E, F) = oracle_fill_kind(L, 3, osc, rdc, phred, rfm, cols, minsc)
+            got2, flag2, colstop2, _ = oracle_fill_kind(L, 2, osc, rdc, phred, rfm, cols, minsc)
+            n = colstop3
+            assert (r["H"][:, :n] == H[:, :n] + 32768).all() and (r["E"][:, :n] == E[:, :n] + 32768).all() and (r["F"][:, :n] == F[:, :n] + 32768).all(), (rows, cols)
+            colmax = (H[:, :n] + 32768).max(axis=0)
+            assert r["best"] == int(colmax.max()), (rows, cols)
+            sol = [j for j in range(n) if colmax[j] >= minsc]
+            assert r["lastsolcol"] == (sol[-1] if sol else 0), (rows, cols)
+            assert r["sat8"] == (1 if flag2 == -2 else 0), (rows, cols, flag2)
 
 
 def test_roundtrip_property_large(case):
