@@ -143,7 +143,7 @@ struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };
 
 struct BtCand { int32_t score; uint16_t row, col; };
 constexpr int kMaxLocalScore = 2047;      // counting-sort table of the local candidate gather (scores above share the top bucket)
-constexpr int32_t kCandDone = 1 << 30;   // local mode: candidate already tried (btncanddone_); local scores are small and non-negative
+constexpr int kMaxCandDone = 1024;       // local mode: candidates of one window that can be tried (btncanddone_) before the read is flagged
 
 struct BtFrame {          // DpNucFrame
 	uint32_t nedsz, celsz;    // celsz: # cells on the path so far | core-diagonal-touched flag << 31
@@ -229,7 +229,7 @@ struct HotWork {
 	uint8_t  done_unpair1;
 	uint8_t  exit_m, exit_k;
 	uint32_t n_cands, cural;
-	uint32_t n_cdone;           // local mode: candidates of the window in hand that have been tried (btncanddone_), listed in Work::cand_hist
+	uint32_t n_cdone;           // local mode: candidates of the window in hand that have been tried (btncanddone_), listed in Work::cand_done
 	uint32_t err;
 	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail, n_ug_fail, n_ee_fail, n_dp_fail_streak;
 	uint32_t n_redundants, n_bwops_seed, n_bwops_ext, n_bt_attempts;
@@ -279,6 +279,7 @@ struct Work {
 	// ---- DP ----
 	BtCand   cands[kMaxCands];
 	uint32_t cand_hist[2 * (kMaxLocalScore + 1)];   // scratch of the local gather's counting sort
+	uint32_t cand_done[2][kMaxCandDone];            // local mode: tried candidates (row | col << 16) of the anchor's window and of the opposite mate's
 	BtFrame  btstack[kMaxLen + kMaxCols];
 	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
 	// ---- paired-end (extendSeedsPaired; unused for unpaired reads) ----

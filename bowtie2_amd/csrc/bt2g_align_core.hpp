@@ -1623,7 +1623,7 @@ struct Aligner {
 		// local mode: the candidates of this window that have been tried (btncanddone_: a few dozen of the thousands a 400-bp window can
 		// have) as row | col << 16, listed in the arena and mirrored in two lane registers (the first 128): a candidate is tested against
 		// all of them at once instead of against every earlier candidate one dependent load at a time
-		BT2_G uint32_t* const donel = Plat::uni_ptr(&WK.cand_hist[0]) + (ST.cands_cur == WK.cands2 ? (uint32_t)(kMaxLocalScore + 1) : 0u);
+		BT2_G uint32_t* const donel = Plat::uni_ptr(&WK.cand_done[ST.cands_cur == WK.cands2 ? 1 : 0][0]);
 		uint32_t ndone = MODE == 2 ? HOT.n_cdone : 0u;
 		typename Plat::LaneReg dn0, dn1;
 		Plat::lanes_zero(dn0); Plat::lanes_zero(dn1);
@@ -1671,7 +1671,7 @@ struct Aligner {
 			ST.rnd.init(sse16 ? reseed : reseed + 1);
 			if (MODE == 2) {       // btncanddone_: tried, succeeded or not
 				const uint32_t v_ = (uint32_t)c.row | ((uint32_t)c.col << 16);
-				if (ndone >= (uint32_t)(kMaxLocalScore + 1)) ovf(33);
+				if (ndone >= (uint32_t)kMaxCandDone) ovf(33);
 				else { gst(donel + ndone, v_); if (ndone < 64u) Plat::set_lane(dn0, ndone, v_); else if (ndone < 128u) Plat::set_lane(dn1, ndone - 64u, v_); ndone++; HOT.n_cdone = ndone; }
 			}
 			(void)cscore;

@@ -297,7 +297,8 @@ struct HostPlat {
 	}
 	// Candidate cells of a local fill, sorted score desc, row desc, col desc
 	static uint32_t gather_local(const uint32_t* mat, BtCand* cands, uint32_t cap, bool fw, uint32_t R, uint32_t rows, uint32_t ncol,
-	                             int64_t minsc, uint32_t minrow, uint32_t* /*hist*/) {
+	                             int64_t minsc, uint32_t minrow, uint32_t* hist) {
+		memset(hist, 0xa5, sizeof(uint32_t) * 2 * (kMaxLocalScore + 1));      // the device's counting sort scribbles over its scratch: nothing may live there across a gather
 		const uint64_t* m64 = reinterpret_cast<const uint64_t*>(mat);
 		uint32_t n = 0, total = 0;
 		for (uint32_t j = 0; j < ncol; j++) {
