@@ -652,8 +652,8 @@ def main():
                 "backtraces_per_read": float(h["n_bt_attempts"].sum()) / n,
                 "reads_overflowed": int((h["status"] != 0).sum()),
                 "worker_phase_us_per_read_profiled_pass": dict(zip(["sweep", "mm1", "seeds", "rank_prioritise", "resolve", "dp_fill", "backtrace", "whole_read", "gather_cells", "report", "ungapped",
-                                                      "bt_tile_fetch", "gather_lastrow", "gather_zero_masks", "prioritize_collect_extend", "prioritize_row_sampling", "sink_report"],
-                                                     [round(prof[i] / 100.0 / max(1, prof[9]), 1) for i in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 16, 17, 18, 19, 20, 21)])),
+                                                      "bt_tile_fetch", "gather_lastrow", "gather_zero_masks", "prioritize_collect_extend", "prioritize_row_sampling", "sink_report", "opposite_mate_total"],
+                                                     [round(prof[i] / 100.0 / max(1, prof[9]), 1) for i in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 16, 17, 18, 19, 20, 21, 22)])),
                 "backtrace_profile_per_read": {"walk_us": round(prof[27] / 100.0 / max(1, prof[9]), 1), "walk_us_successful": round(prof[28] / 100.0 / max(1, prof[9]), 1),
                                                "successful_walks": prof[29] / max(1, prof[9]), "tail_us_after_successful_trace": round(prof[30] / 100.0 / max(1, prof[9]), 1),
                                                "scalar_steps": prof[31] / max(1, prof[9])},

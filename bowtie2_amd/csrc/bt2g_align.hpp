@@ -138,6 +138,24 @@ struct SampRow { uint64_t topf; uint32_t src; uint32_t done; };
 // Random1toN of a sampled range, kept in LDS while prioritize() runs (same fields as R1N, narrower where the values allow)
 struct R1C { uint64_t topf; uint32_t n, cur, list_off, seen_off; uint16_t seen_len, thresh; uint8_t swaplist, converted, inited, pad; };      // topf: first row of the range being sampled
 constexpr int kFastSamp = 64;      // ranges the on-chip sampler state holds
+// Random1toN::init (random_util.h:97-110) of a range of n rows starting at row topf
+BT2_HD R1C r1c_make(uint64_t topf, uint32_t n, bool without_replacement) {
+	R1C r;
+	r.topf = topf; r.n = n; r.cur = 0; r.list_off = r.seen_off = 0; r.seen_len = 0;
+	uint32_t th = (uint32_t)(0.10f * (float)n);
+	th = th > 16 ? th : 16;
+	r.thresh = (uint16_t)(th > 0xffffu ? 0xffffu : th);      // only ever compared with seen_len <= max_iters
+	r.swaplist = (n < 128 || without_replacement) ? 1 : 0;
+	r.converted = 0; r.inited = 1; r.pad = 0;
+	return r;
+}
+// RowSampler::init's weight of a range (aligner_sw_driver.h:176-200, lensq = szsq = true)
+BT2_HD double samp_mass(uint32_t nlex, uint32_t nrex, uint32_t size) {
+	double num = (double)(nlex + nrex + 1); num *= num;
+	double denom = (double)size; denom *= denom;
+	return num / denom;
+}
+BT2_HD double f64_of(uint32_t lo, uint32_t hi) { const uint64_t u = (uint64_t)lo | ((uint64_t)hi << 32); double d; __builtin_memcpy(&d, &u, 8); return d; }
 
 struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };
 
@@ -301,6 +319,7 @@ struct Work {
 	int64_t  reda_dmin[kMaxRedAnchor], reda_dmax[kMaxRedAnchor];
 	AlnRes   ores;                      // oresGap_
 	BtCand   cands2[kMaxCands];         // candidates of the opposite-mate DP (the anchor's stay live in `cands`)
+	BtCand   cands_tmp[kMaxCands];      // device, local mode: the candidate cells as the fill meets them; the gather sorts them into cands / cands2
 	uint32_t mate_streaks[kMaxSatpos];  // mateStreaks_
 	// ---- status / metrics ----
 };
@@ -381,6 +400,9 @@ struct AlState {
 	BT2_G BtCand* cands_cur;          // candidate list in use (Work::cands, or Work::cands2 during an opposite-mate DP)
 	uint32_t  pe_streak;
 	uint32_t  pe_pair;                // index of the pair in the batch (reads 2*pe_pair, 2*pe_pair + 1)
+	uint32_t  n_emit;                 // device, local mode: candidate cells the last fill wrote to Work::cands_tmp (unsorted; may exceed its capacity)
+	int32_t   emit_vmax;              //   ... and the largest score among them
+	uint32_t  emit_on;                // 1 in the workers (Aligner's constructor); 0 in the stage kernel, whose waves have no work area
 };
 
 // ---------------------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct Aligner {
 		ST.wp = &w_; ST.dp = dp_; ST.ridx = ridx_; ST.ext_pre = false; ST.pre_ext_cur = nullptr; ST.pre_joff_cur = nullptr;
 		ST.pf_steps = ST.pf_tiles = 0; ST.pf_tile_t = 0;
 		ST.m_nofw = PRM.nofw != 0; ST.m_norc = PRM.norc != 0; ST.cands_cur = w_.cands;
+		ST.n_emit = 0; ST.emit_vmax = 0; ST.emit_on = 1;
 	}
 
 	// a fixed-capacity buffer is full: flag the read (its result is not passed off as the reference's) and remember which site
@@ -662,20 +663,11 @@ struct Aligner {
 		return rn;
 	}
 
-	// Random1toN with its state in LDS (R1C) -- the same draws as r1n_next, with the seen-list scan and the swap-list fill done
-	// by all lanes at once
-	BT2_HD void r1c_init(R1C& r, uint32_t n, bool without_replacement) {
-		r.n = n; r.converted = 0;
-		r.swaplist = (n < 128 || without_replacement) ? 1 : 0;
-		r.cur = 0; r.list_off = r.seen_off = 0; r.seen_len = 0;
-		uint32_t th = (uint32_t)(0.10f * (float)n);
-		th = th > 16 ? th : 16;
-		r.thresh = (uint16_t)(th > 0xffffu ? 0xffffu : th);      // only ever compared with seen_len <= max_iters
-		r.inited = 1;
-	}
-	// One draw.  `r` is the caller's REGISTER copy of the range's record and `g` its copy of the RNG (the sampling loop keeps
-	// both, and its counters, out of LDS for the whole loop: every LDS access of the draw is a round trip the next instruction
-	// waits for, and they used to be ~40 per draw).
+	// Random1toN with its state in LDS (R1C): the same draws as r1n_next.  `r` is the caller's REGISTER copy of the range's record and
+	// `g` its copy of the RNG (the sampling loop keeps both, and its counters, out of LDS for the whole loop); the seen-list scan and
+	// the swap-list fill are done by all lanes at once.
+	// (Measured, round 3: mirroring the lists' recent contents in lane registers so that a draw waits for no memory at all made no
+	// difference to the loop's time -- it is bound by its own instruction stream, ~1.4 us per draw, not by the list loads.)
 	BT2_HD uint32_t r1c_next(R1C& r, Rng& g) {
 		BT2_G uint32_t* const lists = WK.lists;
 		uint32_t ret;
@@ -955,36 +947,21 @@ struct Aligner {
 		// 2. the non-smalls: RowSampler::init(satpos2_, nsmall, size, lensq=true, szsq=true)
 		const uint32_t sai = (uint32_t)nsmall, saf = HOT.n_satpos2;
 		HOT.n_masses = saf - sai;
-		HOT.mass = 0.0;
-		for (uint32_t i = sai; i < saf; i++) {
-			const uint32_t ln = WK.satpos2[i].nlex + WK.satpos2[i].nrex + 1;
-			double num = (double)ln; num *= num;
-			double denom = (double)WK.satpos2[i].size; denom *= denom;
-			WK.masses[i - sai] = num / denom;
-			WK.elim[i - sai] = 0;
-			HOT.mass += WK.masses[i - sai];
-		}
-		for (uint32_t j = 0; j < HOT.n_satpos2; j++) r1n_reset(WK.rands2[j]);
-		// With at most kMaxRanges candidates (always, for -N 0) the sampler keeps the running sums of the masses that are still
-		// in play on chip: the sums are formed by the same left-to-right additions as RowSampler::next's scan, so "first index
-		// whose running sum exceeds rd" is the same index -- found by all lanes at once instead of a chain of dependent loads.
+		// With at most kFastSamp candidates (always, for -N 0) the whole sampler lives on chip: the ranges' weights in a lane register
+		// pair, their running sums (formed by the same left-to-right additions as RowSampler::next's scan, so "first index whose
+		// running sum exceeds rd" is the same index, found by all lanes at once) and Random1toN records in LDS.
 		const bool fast = HOT.n_masses <= (uint32_t)kFastSamp;
-		if (fast) for (uint32_t j = 0; j < HOT.n_masses; j++) { R1C& r = HOT.samp.r[j]; r.topf = 0; r.n = r.cur = 0; r.swaplist = r.converted = r.inited = 0; r.seen_len = 0; r.thresh = 0; r.list_off = r.seen_off = 0; }
-		auto rebuild = [&]() {
-			double acc = 0.0;
-			for (uint32_t i = 0; i < HOT.n_masses; i++) { if (!WK.elim[i]) acc += WK.masses[i]; HOT.samp.prefix[i] = acc; HOT.samp.elim[i] = WK.elim[i]; }
-		};
-		if (fast) rebuild();
 		const uint64_t ts_ = now();
 		if (fast) {
 			// loop state in registers: RNG, total mass, list length, profile counts; written back once
 			Rng g = ST.rnd;
-			double mass = HOT.mass;
 			uint32_t n_satpos = HOT.n_satpos;
 			const uint32_t n_full = HOT.n_satpos_full, n_masses = HOT.n_masses;
 			BT2_G SampRow* const srows = WK.srows;
-			const BT2_G SatPos* const sat2 = WK.satpos2;
 			const bool all_hits = PRM.all_hits != 0;
+			typename Plat::LaneReg mlo, mhi;      // lane j: weight of range sai + j
+			Plat::samp_setup(&WK.satpos2[sai], n_masses, all_hits, HOT.samp.r, HOT.samp.elim, mlo, mhi);
+			double mass = Plat::mass_prefix(mlo, mhi, HOT.samp.elim, n_masses, HOT.samp.prefix);
 			uint64_t draws = 0;
 			bool full = false;
 			while (nelt_added < maxelt && nelt_added < nelt) {
@@ -993,13 +970,12 @@ struct Aligner {
 				const uint32_t pick = Plat::pick_mass(HOT.samp.prefix, HOT.samp.elim, n_masses, rd);
 				const uint32_t ri = pick + sai;
 				R1C r2 = HOT.samp.r[pick];
-				if (!r2.inited) { r1c_init(r2, gld(&sat2[ri].size), all_hits); r2.topf = gld(&sat2[ri].topf); }
 				draws += r2.swaplist ? 1ull : (1ull | (1ull << 32));      // profile: draws | draws on the seen-list path << 32
 				const uint32_t r = r1c_next(r2, g);
 				HOT.samp.r[pick] = r2;
 				if (r2.n > 0 && r2.cur >= r2.n) {      // the range is used up: out of the sampler
-					WK.elim[ri - sai] = 1; mass -= WK.masses[ri - sai];
-					rebuild();
+					HOT.samp.elim[pick] = 1; mass -= f64_of(Plat::lane(mlo, pick), Plat::lane(mhi, pick));
+					Plat::mass_prefix(mlo, mhi, HOT.samp.elim, n_masses, HOT.samp.prefix);
 				}
 				if (n_satpos >= (uint32_t)kMaxSatpos) { full = true; break; }
 				BT2_G SampRow* const sr = &srows[n_satpos - n_full];
@@ -1010,7 +986,14 @@ struct Aligner {
 			ST.rnd = g; HOT.mass = mass; HOT.n_satpos = n_satpos;
 			HOT.t_phase[21] += draws;
 			if (full) ovf(13);
-		} else
+		} else {
+		HOT.mass = 0.0;
+		for (uint32_t i = sai; i < saf; i++) {
+			WK.masses[i - sai] = samp_mass(WK.satpos2[i].nlex, WK.satpos2[i].nrex, WK.satpos2[i].size);
+			WK.elim[i - sai] = 0;
+			HOT.mass += WK.masses[i - sai];
+		}
+		for (uint32_t j = 0; j < HOT.n_satpos2; j++) r1n_reset(WK.rands2[j]);
 		while (nelt_added < maxelt && nelt_added < nelt) {
 			// RowSampler::next, more ranges than the on-chip sampler holds (-N 1): everything through the arena
 			const double rd = (double)(ST.rnd.nextFloat() * HOT.mass);
@@ -1035,6 +1018,7 @@ struct Aligner {
 			HOT.n_satpos++;
 			gst(&sr->topf, (uint64_t)(WK.satpos2[ri].topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
 			nelt_added++;
+		}
 		}
 		HOT.t_phase[18] += now() - ts_;       // profile: the row-sampling loop
 		nelt_out = nelt_added;

@@ -301,13 +301,18 @@ __device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, const Work
 // plain scores in 16-bit fields, floor 0.  The column maximum travels down the lanes with the column; the lane that
 // owns the last rows sees every column complete, in order, and replays the kernels' per-column bookkeeping
 // (best score, lastsolcol, bail-out point, "the 8-bit kernel would have saturated").
-template <int R>
+// EMIT: the candidate cells of the gather (gatherCellsNucleotidesLocalSseU8, aligner_swsse_loc_u8.cpp:1389-1496: score >= minsc, at or
+// below the first row that can reach minsc, a match whose diagonal successor is not) are recognised while the cell is in registers and
+// appended to `emit` (unsorted, columns beyond lastsolcol included: the gather drops those) -- the matrix is not read again to find them.
+template <int R, bool EMIT>
 __device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint64_t* __restrict__ scratch,
-                                               int minsc, uint32_t& lastsolcol, uint32_t& sat8) {
+                                               int minsc, uint32_t& lastsolcol, uint32_t& sat8, BT2_G BtCand* emit, uint32_t emit_cap, uint32_t& n_emit) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t nlanes = (rows + R - 1) / R;
 	int rdc[R], mmp[R], veto[R];
 	int bias = P.n_pen;
+	uint32_t nem = 0;
+	const uint32_t minrow = EMIT ? (uint32_t)(((minsc + P.match_bonus - 1) / P.match_bonus) - 1) : 0u;
 #pragma unroll
 	for (int r = 0; r < R; r++) {
 		const uint32_t i = (uint32_t)lane * R + r;
@@ -319,6 +324,15 @@ __device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, ui
 		if (valid && rdc[r] <= 3 && mmp[r] > bias) bias = mmp[r];
 	}
 	for (int o = 32; o > 0; o >>= 1) bias = imax(bias, __shfl_xor(bias, o));     // bias of the 8-bit query profile
+	int rdn[R];       // EMIT: 1 << character of the row below (0 for the last row: nothing follows it)
+	if (EMIT) {
+		const int below = __shfl_down(rdc[0], 1);
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			const uint32_t i = (uint32_t)lane * R + r;
+			rdn[r] = (i + 1 < rows) ? (1 << (r + 1 < R ? rdc[r + 1 < R ? r + 1 : 0] : below)) : 0;
+		}
+	}
 	int Hprev[R], Eprev[R];
 #pragma unroll
 	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
@@ -371,12 +385,27 @@ __device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, ui
 				else lastsol = j;
 			}
 		}
+		if (EMIT) {
+			const int refn = active ? (int)g_hot.rf[j + 1] : 0;       // (column `cols` is padding, as in the scan of the matrix this replaces)
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const uint32_t i = (uint32_t)lane * R + r;
+				const bool c = active && i >= minrow && i < rows && Hnew[r] >= minsc && (refm & (1 << rdc[r])) != 0 && (refn & rdn[r]) == 0;
+				const unsigned long long m = __ballot(c);
+				if (m) {        // (wave-uniform)
+					const uint32_t pos = nem + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+					if (c && pos < emit_cap) { BtCand v; v.score = Hnew[r]; v.row = (uint16_t)i; v.col = (uint16_t)j; gst(emit + pos, v); }
+					nem += (uint32_t)__popcll(m);
+				}
+			}
+		}
 		upHdiag = upH;
 		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
 	}
 	const int src = (int)nlanes - 1;
 	lastsolcol = (uint32_t)__shfl(lastsol, src);
 	sat8 = (uint32_t)__shfl(sat, src);
+	n_emit = nem;
 	return __shfl(vmax, src);
 }
 
@@ -429,6 +458,37 @@ struct DevPlat {
 			if (lv) last = base + 63u - (uint32_t)__builtin_clzll(lv);
 		}
 		return last;
+	}
+	// RowSampler::init + Random1toN::init of up to 64 ranges at once: lane j reads range j, keeps its weight (mlo/mhi: the double's
+	// halves) and writes its record and "still in play" flag to LDS -- one memory round trip for all ranges
+	static __device__ __forceinline__ void samp_setup(const BT2_G SatPos* sat, uint32_t n, bool all_hits, R1C*, uint8_t*, uint32_t& mlo, uint32_t& mhi) {
+		wave_fence();
+		const uint32_t l = threadIdx.x & 63;
+		double m = 0.0;
+		if (l < n) {
+			const BT2_G SatPos* s = sat + l;
+			const uint32_t size = gld(&s->size);
+			m = samp_mass(gld(&s->nlex), gld(&s->nrex), size);
+			g_hot.samp.r[l] = r1c_make(gld(&s->topf), size, all_hits);
+			g_hot.samp.elim[l] = 0;
+		}
+		const uint64_t u = (uint64_t)__double_as_longlong(m);
+		mlo = (uint32_t)u; mhi = (uint32_t)(u >> 32);
+		wave_fence();
+	}
+	// running sums of the weights still in play, added left to right as RowSampler::next's scan adds them; returns the total
+	static __device__ __forceinline__ double mass_prefix(uint32_t mlo, uint32_t mhi, const uint8_t*, uint32_t n, double*) {
+		wave_fence();
+		const uint32_t l = threadIdx.x & 63;
+		const unsigned long long live = __ballot(l < n && !g_hot.samp.elim[l]);
+		double acc = 0.0, mine = 0.0;
+		for (uint32_t i = 0; i < n; i++) {
+			if ((live >> i) & 1ull) acc += f64_of((uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)i), (uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)i));
+			if (l == i) mine = acc;
+		}
+		if (l < n) g_hot.samp.prefix[l] = mine;
+		wave_fence();
+		return acc;
 	}
 	// Ebwt::getOffset for up to 64 rows at once, one LF walk per lane (joff_pack: offset + steps taken)
 	template <typename TOff>
@@ -813,84 +873,125 @@ struct DevPlat {
 		uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
 		const int ms = minsc > 0x7fff ? 0x7fff : (int)minsc;
 		int best;
-		switch (dp_R(rows)) {
-			case 1: best = fill_local_wave<1>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
-			case 2: best = fill_local_wave<2>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
-			case 3: best = fill_local_wave<3>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
-			case 4: best = fill_local_wave<4>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
-			case 5: best = fill_local_wave<5>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
-			case 6: best = fill_local_wave<6>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
-			case 7: best = fill_local_wave<7>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
-			default: best = fill_local_wave<8>(P, fw, rows, cols, m64, ms, lastsolcol, sat8); break;
+		uint32_t nem = 0;
+		// the worker's fills leave their candidate cells in Work::cands_tmp for gather_local; the stage kernel (k_dp_fill) has no arena
+		BT2_G BtCand* const emit = g_st.emit_on ? &DevPlat::work().cands_tmp[0] : (BT2_G BtCand*)nullptr;
+		const uint32_t ecap = (uint32_t)kMaxCands;
+		if (emit) switch (dp_R(rows)) {
+			case 1: best = fill_local_wave<1, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 2: best = fill_local_wave<2, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 3: best = fill_local_wave<3, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 4: best = fill_local_wave<4, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 5: best = fill_local_wave<5, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 6: best = fill_local_wave<6, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 7: best = fill_local_wave<7, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			default: best = fill_local_wave<8, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+		} else switch (dp_R(rows)) {
+			case 1: best = fill_local_wave<1, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 2: best = fill_local_wave<2, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 3: best = fill_local_wave<3, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 4: best = fill_local_wave<4, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 5: best = fill_local_wave<5, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 6: best = fill_local_wave<6, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 7: best = fill_local_wave<7, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			default: best = fill_local_wave<8, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
 		}
+		if ((threadIdx.x & 63) == 0) { g_st.n_emit = nem; g_st.emit_vmax = best; }
 		wave_fence();
 		g_hot.n_dp_cells_full += rows * cols;
 		return (int64_t)best;
 	}
-	// Candidate cells of a local fill (gatherCellsNucleotidesLocalSseU8), ordered score desc, row desc, col desc.
-	// Lanes scan columns; a counting sort on the score places each candidate in its score bucket, then every bucket
-	// (a handful of cells) is ordered by insertion.  hist: 2 * kMaxLocalScore + 2 words of per-wave scratch.
-	static __device__ __attribute__((noinline)) uint32_t gather_local(const uint32_t* mat_, BtCand* cands_, uint32_t cap_, bool fw_, uint32_t R_, uint32_t rows_,
-	                                                                  uint32_t ncol_, int64_t minsc_, uint32_t minrow_, uint32_t* hist_) {
-		const uint32_t* mat = uni_ptr(mat_); BtCand* cands = uni_ptr(cands_); uint32_t* hist = uni_ptr(hist_);
-		const bool fw = uni((int)fw_) != 0;
-		const uint32_t cap = uni(cap_), R = uni(R_), rows = uni(rows_), ncol = uni(ncol_), minrow = uni(minrow_);
-		const int64_t minsc = uni(minsc_);
-		const uint64_t* m64 = reinterpret_cast<const uint64_t*>(mat);
+	// Candidate cells of a local fill (gatherCellsNucleotidesLocalSseU8), ordered score desc, row desc, col desc (DpBtCandidate::operator<).
+	// The fill left them in Work::cands_tmp in the order it met them (fill_local_wave<R, true>); this sorts them into `cands`: a stable
+	// LSD radix sort, 10 bits per pass, on  key = score : row : col  (each field as wide as this window needs), complemented so that
+	// ascending passes give the descending order.  The 1024 counters of a pass are 16-bit words in LDS (the last-row buffer, idle here;
+	// the capacity keeps every count below 65536).  Per batch of 64 records: ten ballots tell every lane which lanes hold the same digit,
+	// so ranks within the batch need no atomics and the scatter is stable.  An odd number of passes ends in `cands`.
+	// Candidates in columns beyond lastsolcol (ncol - 1) are dropped by the first pass.
+	static __device__ __attribute__((noinline)) uint32_t gather_local(const uint32_t*, BtCand* cands_, uint32_t cap_, bool, uint32_t, uint32_t rows_,
+	                                                                  uint32_t ncol_, int64_t, uint32_t, uint32_t*) {
+		BT2_G BtCand* const dst = (BT2_G BtCand*)uni_ptr(cands_);
+		BT2_G BtCand* const tmp = &DevPlat::work().cands_tmp[0];
+		const uint32_t rows = uni(rows_), ncol = uni(ncol_);
+		uint32_t cap = uni(cap_); if (cap > 65535u) cap = 65535u;
+		uint32_t n = uni(g_st.n_emit);
+		if (n > cap) return (uint32_t)kMaxCands + 1u;      // more cells than the lists hold: the caller flags the read
+		if (n == 0) return 0;
 		const uint32_t lane = threadIdx.x & 63;
-		const uint32_t nb = (uint32_t)kMaxLocalScore + 1;
-		uint32_t* start = hist + nb;
-		wave_fence();
-		for (uint32_t i = lane; i < 2 * nb; i += 64) hist[i] = 0;
-		wave_fence();
-		auto is_cand = [&](uint32_t i, uint32_t j, int& sc) -> bool {
-			sc = (int)(m64[dp_cell(R, i, j)] & 0xffff);
-			if (sc < minsc) return false;
-			const int rdc = rd_char(g_hot, g_hot.len, fw, i);
-			if ((g_hot.rf[j] & (1 << rdc)) == 0) return false;            // as the reference: a read N "matches" the N mask
-			if (i < rows - 1) { const int rs = rd_char(g_hot, g_hot.len, fw, i + 1); if ((g_hot.rf[j + 1] & (1 << rs)) != 0) return false; }
-			return true;
-		};
-		// pass 1: histogram
-		for (uint32_t j = lane; j < ncol; j += 64)
-			for (uint32_t i = minrow; i < rows; i++) { int sc; if (is_cand(i, j, sc)) atomicAdd(&hist[sc > kMaxLocalScore ? kMaxLocalScore : sc], 1u); }
-		wave_fence();
-		// bucket starts, highest score first (one lane; ~1k adds)
-		uint32_t total = 0;
-		if (lane == 0) { uint32_t acc = 0; for (int sc = kMaxLocalScore; sc >= 0; sc--) { start[sc] = acc; acc += hist[sc]; } total = acc; }
-		total = __shfl(total, 0);
-		wave_fence();
-		if (total > cap) return total;          // the caller flags the overflow
-		// pass 2: scatter (order inside a bucket is arbitrary here); hist[] becomes the per-bucket cursor
-		for (uint32_t i = lane; i < nb; i += 64) hist[i] = 0;
-		wave_fence();
-		for (uint32_t j = lane; j < ncol; j += 64)
-			for (uint32_t i = minrow; i < rows; i++) {
-				int sc;
-				if (!is_cand(i, j, sc)) continue;
-				const int b = sc > kMaxLocalScore ? kMaxLocalScore : sc;
-				const uint32_t pos = start[b] + atomicAdd(&hist[b], 1u);
-				BtCand c; c.score = sc; c.row = (uint16_t)i; c.col = (uint16_t)j;
-				cands[pos] = c;
+		const unsigned long long lt = (1ull << lane) - 1ull;
+		auto nbits = [](uint32_t v) -> uint32_t { return v ? 32u - (uint32_t)__builtin_clz(v) : 1u; };
+		const uint32_t cb = nbits(ncol - 1), rb = nbits(rows - 1), sb = nbits((uint32_t)uni(g_st.emit_vmax));
+		const uint32_t tot = cb + rb + sb;
+		uint32_t npass = (tot + 9u) / 10u; if (!(npass & 1u)) npass++;
+		const uint64_t kmask = tot >= 64u ? ~0ull : ((1ull << tot) - 1ull);
+		uint16_t* const cnt = reinterpret_cast<uint16_t*>(g_hot.lastrow);       // 1024 counters (kMaxCols + 8 >= 1024 int16)
+		static_assert(sizeof(g_hot.lastrow) >= 2048, "radix counters");
+		uint32_t* const cnt32 = reinterpret_cast<uint32_t*>(g_hot.lastrow);
+		for (uint32_t p = 0; p < npass; p++) {
+			BT2_G BtCand* const src = (p & 1u) ? dst : tmp;
+			BT2_G BtCand* const out = (p & 1u) ? tmp : dst;
+			const uint32_t sh = 10u * p;
+			wave_fence();
+			for (uint32_t i = lane; i < 512u; i += 64) cnt32[i] = 0;
+			wave_fence();
+			auto digit_of = [&](const BtCand& c) -> uint32_t {
+				const uint64_t key = (((uint64_t)(uint32_t)c.score << (rb + cb)) | ((uint64_t)c.row << cb) | (uint64_t)c.col) ^ kmask;
+				return sh >= 64u ? 0u : (uint32_t)((key >> sh) & 1023ull);
+			};
+			// lanes holding the same digit as this lane (among the valid ones)
+			auto same_digit = [&](bool valid, uint32_t d) -> unsigned long long {
+				unsigned long long m = __ballot(valid);
+#pragma unroll
+				for (uint32_t b = 0; b < 10; b++) { const bool bit = ((d >> b) & 1u) != 0; const unsigned long long bal = __ballot(valid && bit); m &= bit ? bal : ~bal; }
+				return m;
+			};
+			// histogram
+			for (uint32_t base = 0; base < n; base += 64) {
+				const uint32_t i = base + lane;
+				BtCand c; c.score = 0; c.row = 0; c.col = 0;
+				if (i < n) c = gld(src + i);
+				const bool valid = i < n && (p > 0 || (uint32_t)c.col < ncol);
+				const uint32_t d = digit_of(c);
+				const unsigned long long m = same_digit(valid, d);
+				if (valid && (m & lt) == 0) cnt[d] = (uint16_t)(cnt[d] + (uint32_t)__popcll(m));
+				wave_fence();
 			}
-		wave_fence();
-		// pass 3: order every bucket by (row desc, col desc); the top bucket also by score (scores above the table share it)
-		for (uint32_t b = lane; b < nb; b += 64) {
-			const uint32_t s0 = start[b], m = hist[b];
-			for (uint32_t x = 1; x < m; x++) {
-				const BtCand v = cands[s0 + x];
-				uint32_t y = x;
-				while (y > 0) {
-					const BtCand o = cands[s0 + y - 1];
-					const bool o_later = o.score != v.score ? o.score < v.score : (o.row != v.row ? o.row < v.row : o.col < v.col);
-					if (!o_later) break;
-					cands[s0 + y] = o; y--;
+			// exclusive prefix over the 1024 counters: lane l owns counters 16 l .. 16 l + 15
+			uint32_t mine[16], sum = 0;
+#pragma unroll
+			for (uint32_t q = 0; q < 16; q++) { mine[q] = cnt[16u * lane + q]; sum += mine[q]; }
+			uint32_t incl = sum;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += t; }
+			uint32_t run = incl - sum;
+			const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+			wave_fence();
+#pragma unroll
+			for (uint32_t q = 0; q < 16; q++) { cnt[16u * lane + q] = (uint16_t)run; run += mine[q]; }
+			wave_fence();
+			// stable scatter
+			for (uint32_t base = 0; base < n; base += 64) {
+				const uint32_t i = base + lane;
+				BtCand c; c.score = 0; c.row = 0; c.col = 0;
+				if (i < n) c = gld(src + i);
+				const bool valid = i < n && (p > 0 || (uint32_t)c.col < ncol);
+				const uint32_t d = digit_of(c);
+				const unsigned long long m = same_digit(valid, d);
+				uint32_t s0 = 0;
+				if (valid) s0 = cnt[d];
+				wave_fence();
+				if (valid) {
+					const uint32_t rank = (uint32_t)__popcll(m & lt), grp = (uint32_t)__popcll(m);
+					gst(out + s0 + rank, c);
+					if (rank + 1u == grp) cnt[d] = (uint16_t)(s0 + grp);
 				}
-				cands[s0 + y] = v;
+				wave_fence();
 			}
+			n = total;       // (the first pass dropped the columns beyond lastsolcol)
+			if (n == 0) break;
 		}
 		wave_fence();
-		return total;
+		return n;
 	}
 	// returns the best last-row score (de-biased)
 	// (Arguments of a real call arrive in vector registers and a load through a generic reference could be a per-lane scratch access: the
@@ -1075,6 +1176,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 		wave_fence();
 		if (lane == 0 && prof) {
 			for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)g_hot.t_phase[i]);
+			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)g_hot.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
 			atomicAdd(&prof[9], 2ull);
 			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass); for (int i = 0; i < 5; i++) atomicAdd(&prof[27 + i], (unsigned long long)g_hot.t_bt[i]);
@@ -1110,7 +1212,7 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 	g_P = P;
 	DpScratch dp;
 	carve_scratch(dp, scratch + (uint64_t)blockIdx.x * scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
-	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch;      // (the fills do not touch the work area)
+	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch; g_st.emit_on = 0;      // (the fills do not touch the work area)
 	wave_fence();
 	for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
 		const bt2g_dp_problem pr = probs[p];

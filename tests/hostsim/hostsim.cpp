@@ -106,6 +106,19 @@ struct HostPlat {
 		}
 		return r;
 	}
+	static void samp_setup(const SatPos* sat, uint32_t n, bool all_hits, R1C* r, uint8_t* elim, LaneReg& mlo, LaneReg& mhi) {
+		for (uint32_t l = 0; l < 64; l++) {
+			double m = 0.0;
+			if (l < n) { m = samp_mass(sat[l].nlex, sat[l].nrex, sat[l].size); r[l] = r1c_make(sat[l].topf, sat[l].size, all_hits); elim[l] = 0; }
+			uint64_t u; memcpy(&u, &m, 8);
+			mlo.v[l] = (uint32_t)u; mhi.v[l] = (uint32_t)(u >> 32);
+		}
+	}
+	static double mass_prefix(const LaneReg& mlo, const LaneReg& mhi, const uint8_t* elim, uint32_t n, double* prefix) {
+		double acc = 0.0;
+		for (uint32_t i = 0; i < n; i++) { if (!elim[i]) acc += f64_of(mlo.v[i], mhi.v[i]); prefix[i] = acc; }
+		return acc;
+	}
 	static LaneReg lanes_load_u32(const uint32_t* p, uint32_t base, uint32_t n) {
 		LaneReg r;
 		for (uint32_t l = 0; l < 64; l++) r.v[l] = base + l < n ? p[base + l] : 0u;
