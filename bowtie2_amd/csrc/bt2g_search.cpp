@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -76,8 +77,6 @@ static int run_search(int argc, char** argv) {
 	{
 		const std::string err = parse_cli(argc, argv, opt, ex);
 		if (ex.arg_desc) { print_arg_desc(); return 0; }
-	if (ex.version) { print_version(argv[0]); return 0; }
-	if (ex.help) { print_usage(argv[0]); return 0; }
 		if (ex.version) { print_version(argv[0]); return 0; }
 		if (ex.help) { print_usage(argv[0]); return 0; }
 		if (!err.empty()) die(err, 1);
@@ -87,12 +86,34 @@ static int run_search(int argc, char** argv) {
 	unsigned long long n_flagged = 0;
 	if (opt.index_base.empty() || (opt.reads_file.empty() && !opt.paired)) die("usage: bowtie2-align-s [options] -x <index> {-U <reads.fq> | -1 <m1.fq> -2 <m2.fq>} [-S out.sam]");
 
+	// The read sources are opened first: a reads file that cannot be opened is reported before 28 GB of index go to the device.
+	// -p: host threads for FASTQ parsing and SAM formatting (the alignment itself is on the device)
+	const unsigned host_threads = opt.threads > 0 ? (unsigned)opt.threads : 1u;
+	const bool inter = !opt.interleaved_file.empty();
+	const std::string src1 = inter ? opt.interleaved_file : (opt.paired ? opt.mate1_file : opt.reads_file);
+	FastqBatcher fq(src1, opt, host_threads);
+	if (!fq.ok()) die(fq.open_error("cannot open reads file " + src1));
+	std::unique_ptr<FastqBatcher> fq2;
+	if (opt.paired && !inter) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die(fq2->open_error("cannot open reads file " + opt.mate2_file)); fq.set_bam_mate(1); fq2->set_bam_mate(2); }
+	if (ex.shard_bytes) {
+		std::string e;
+		if (!fq.set_range(ex.range_a[0], ex.range_b[0], ex.first_read, e)) die(e);
+		if (fq2 && !fq2->set_range(ex.range_a[1], ex.range_b[1], ex.first_read, e)) die(e);
+	}
+	// -U next to -1/-2: the unpaired reads follow the pairs (same reader thread, batches marked paired or not one by one)
+	std::unique_ptr<FastqBatcher> fq_unp;
+	if (opt.mixed_unpaired) { fq_unp.reset(new FastqBatcher(opt.reads_file, opt, host_threads)); if (!fq_unp->ok()) die("cannot open reads file " + opt.reads_file); }
 	// --gpu a[,b,...]: one context (full index replica) per listed device; read batches are dealt to whichever device
 	// is free and the writer puts them back in input order (reads are independent: SURVEY.md 8e)
 	std::vector<int> devices = ex.devices;
 	if (devices.empty()) devices.push_back(0);
 	const size_t ndev = devices.size();
 	std::vector<bt2g_ctx*> ctxs(ndev, nullptr);
+	// a fatal error on this thread unwinds to bowtie() (die()): the contexts (index replicas in HBM) and the output file go with it
+	struct Cleanup {
+		std::vector<bt2g_ctx*>& ctxs; FILE* out = nullptr; FILE* idx = nullptr;
+		~Cleanup() { for (bt2g_ctx*& c : ctxs) if (c) { bt2g_ctx_destroy(c); c = nullptr; } if (out && out != stdout) fclose(out); if (idx) fclose(idx); }
+	} cleanup{ctxs};
 	auto t0 = std::chrono::steady_clock::now();
 	{
 		std::vector<std::thread> loaders;
@@ -115,9 +136,12 @@ static int run_search(int argc, char** argv) {
 	}
 	FILE* out = opt.out_file.empty() ? stdout : fopen(opt.out_file.c_str(), "wb");
 	if (!out) die("cannot open output " + opt.out_file);
+	cleanup.out = out;
+	// every write of the SAM stream is checked: a full disk ends the run with an error, not with a truncated file and exit status 0
+	auto put = [&](const char* p_, size_t n_) { if (n_ && fwrite(p_, 1, n_, out) != n_) die(std::string("could not write SAM output: ") + strerror(errno)); };
 	std::string o;
 	if (!opt.sam_no_hd) sam_header(o, ref, opt.cmdline, true, !opt.sam_no_sq, opt.rg_id, opt.rgs);   // --no-hd drops every header line (bt2_search.cpp:5126-5130)
-	fwrite(o.data(), 1, o.size(), out);
+	put(o.data(), o.size());
 
 	AlignParams P;
 	opt.to_params(P, info.off_size == 8);
@@ -125,22 +149,6 @@ static int run_search(int argc, char** argv) {
 	// keep the result records of one batch within ~2 GB (a record holds up to -k alignments of 1.2 KB each)
 	const size_t batch_reads = std::max<size_t>(2, std::min<size_t>(ex.batch_reads, (size_t)((2ull << 30) / stride)) & ~(size_t)1);   // even: pairs stay together
 
-	// -p: host threads for FASTQ parsing and SAM formatting (the alignment itself is on the device)
-	const unsigned host_threads = opt.threads > 0 ? (unsigned)opt.threads : 1u;
-	const bool inter = !opt.interleaved_file.empty();
-	const std::string src1 = inter ? opt.interleaved_file : (opt.paired ? opt.mate1_file : opt.reads_file);
-	FastqBatcher fq(src1, opt, host_threads);
-	if (!fq.ok()) die(fq.open_error("cannot open reads file " + src1));
-	std::unique_ptr<FastqBatcher> fq2;
-	if (opt.paired && !inter) { fq2.reset(new FastqBatcher(opt.mate2_file, opt, host_threads)); if (!fq2->ok()) die(fq2->open_error("cannot open reads file " + opt.mate2_file)); fq.set_bam_mate(1); fq2->set_bam_mate(2); }
-	if (ex.shard_bytes) {
-		std::string e;
-		if (!fq.set_range(ex.range_a[0], ex.range_b[0], ex.first_read, e)) die(e);
-		if (fq2 && !fq2->set_range(ex.range_a[1], ex.range_b[1], ex.first_read, e)) die(e);
-	}
-	// -U next to -1/-2: the unpaired reads follow the pairs (same reader thread, batches marked paired or not one by one)
-	std::unique_ptr<FastqBatcher> fq_unp;
-	if (opt.mixed_unpaired) { fq_unp.reset(new FastqBatcher(opt.reads_file, opt, host_threads)); if (!fq_unp->ok()) die("cannot open reads file " + opt.reads_file); }
 	PairSummary psumm;
 	AlnSummary summ;
 	std::mutex align_mu;
@@ -150,7 +158,7 @@ static int run_search(int argc, char** argv) {
 	BoundedQueue<BatchPtr> q_in(ndev * kWorkersPerDev + 1), q_out(ndev * kWorkersPerDev + 1);
 
 	FILE* shard_idx = nullptr;
-	if (!ex.shard_index.empty()) { shard_idx = fopen(ex.shard_index.c_str(), "w"); if (!shard_idx) die("cannot open " + ex.shard_index); }
+	if (!ex.shard_index.empty()) { shard_idx = fopen(ex.shard_index.c_str(), "w"); if (!shard_idx) die("cannot open " + ex.shard_index); cleanup.idx = shard_idx; }
 	std::thread reader([&]() {
 		uint64_t seq = 0, blk = 0;
 		bool unp_phase = false;          // mixed input: the pair sources are exhausted, the -U files are being read
@@ -209,7 +217,7 @@ static int run_search(int argc, char** argv) {
 				}
 				const auto tf1_ = std::chrono::steady_clock::now();
 				uint64_t nbytes = 0;
-				for (const std::string& part : parts) { fwrite(part.data(), 1, part.size(), out); nbytes += part.size(); }
+				for (const std::string& part : parts) { put(part.data(), part.size()); nbytes += part.size(); }
 				if (shard_idx && !b->reads.empty()) fprintf(shard_idx, "B %llu %llu %llu\n", (unsigned long long)b->block_id, (unsigned long long)nbytes, (unsigned long long)b->reads.size());
 				t_format += std::chrono::duration<double>(tf1_ - tf0_).count();
 				t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf1_).count();
@@ -289,7 +297,8 @@ static int run_search(int argc, char** argv) {
 	}
 	reader.join();
 	writer.join();
-	if (out != stdout) fclose(out);
+	cleanup.out = nullptr;
+	if (out != stdout ? fclose(out) != 0 : fflush(out) != 0) die(std::string("could not write SAM output: ") + strerror(errno));
 	if (opt.timing) {
 		auto hms = [](double s) { char b[64]; int h = (int)(s / 3600); int m = (int)(s / 60) % 60; int sec = (int)s % 60; snprintf(b, sizeof b, "%02d:%02d:%02d", h, m, sec); return std::string(b); };
 		fprintf(stderr, "Time loading forward index: %s\n", hms(std::chrono::duration<double>(t1 - t0).count()).c_str());
@@ -305,10 +314,12 @@ static int run_search(int argc, char** argv) {
 		        (unsigned long long)psumm.unp0_uni1, (unsigned long long)psumm.unp0_uni2, (unsigned long long)psumm.unp0_rep);
 		fprintf(shard_idx, "F %llu\n", n_flagged);
 		fprintf(shard_idx, "R %llu\n", (unsigned long long)(fq.bytes_read() + (fq2 ? fq2->bytes_read() : 0)));      // bytes of reads files this rank took in
-		fclose(shard_idx);
+		cleanup.idx = nullptr;
+		const bool idx_bad = ferror(shard_idx) != 0;
+		if (fclose(shard_idx) != 0 || idx_bad) die("could not write " + ex.shard_index);
 	}
 	if (!opt.quiet && ex.shard_world == 1 && !ex.shard_bytes) { if (opt.mixed_unpaired) print_mixed_summary(stderr, psumm, summ, !opt.no_discordant, !opt.no_mixed); else if (opt.paired) psumm.print(stderr, !opt.no_discordant, !opt.no_mixed); else summ.print(stderr); }   // gQuiet (bt2_search.cpp:5198); sharded: rank 0 of the driver prints the merged summary
-	for (bt2g_ctx* c : ctxs) bt2g_ctx_destroy(c);
+	for (bt2g_ctx*& c : ctxs) { bt2g_ctx_destroy(c); c = nullptr; }
 	if (n_flagged) {
 		// never pass off a capacity-limited result as the reference's
 		fprintf(stderr, "Error: %llu read(s) exceeded a limit of this build (see the warnings above); their SAM records may differ from bowtie2's\n", (unsigned long long)n_flagged);

@@ -215,6 +215,20 @@ def test_input_errors_end_the_run_with_an_error(twin, tmp_path):
         assert p.returncode == 1 and "Error" in p.stderr, (a, p.returncode, p.stderr[-300:])
 
 
+def test_output_errors_end_the_run_with_an_error(twin, tmp_path):
+    """a SAM stream that cannot be written (full device) is an error with exit status 1, not a truncated file and status 0; a reads file
+    that cannot be opened is reported before the index is loaded"""
+    base = os.path.join(GOLD, "tiny_s")
+    if os.path.exists("/dev/full"):
+        p = subprocess.run([twin, "-x", base, "-U", FQ, "-S", "/dev/full"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 1 and "could not write SAM output" in p.stderr, (p.returncode, p.stderr[-300:])
+        with open("/dev/full", "w") as full:
+            p = subprocess.run([twin, "-x", base, "-U", FQ], stdout=full, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 1 and "could not write SAM output" in p.stderr, (p.returncode, p.stderr[-300:])
+    p = subprocess.run([twin, "-x", str(tmp_path / "no_such_index"), "-U", str(tmp_path / "missing.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 1 and "missing.fq" in p.stderr and "index" not in p.stderr.lower().replace("no_such_index", ""), p.stderr[-300:]
+
+
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 def test_option_surface_through_the_driver(twin, tmp_path):
     """every option set, input format and paired option set of tests/test_cli_options.py / tests/test_paired.py, this time through the
