@@ -103,16 +103,30 @@ BT2_HD void fm_extend_hit_text(const DevIndex<TOff>& ix, const RD& rd, uint32_t 
 		if (!left && !right) continue;
 		const uint32_t lim = left ? (fw ? off : rdlen - len - off) : (fw ? rdlen - len - off : off);
 		uint32_t cnt = 0;
-		for (uint32_t ii = 0; ii < lim; ii++) {
-			uint32_t i;
-			if (left) i = fw ? off - ii - 1 : rdlen - off - len - 1 - ii;
-			else      i = fw ? ii + len + off : rdlen - off + ii;
-			const int rdc = fm_rd_char(rd, rdlen, fw, i);
-			int c = -1;
-			if (left) { if (p >= (uint64_t)ii + 1) c = joined_char(ix.ref, p - ii - 1); }
-			else { const uint64_t q = p + len + ii; if (q < n) c = joined_char(ix.ref, q); }
-			if (c != rdc && rdc <= 3) break;
-			if (++cnt == 255) break;
+		bool stop = false;
+		// eight positions per trip: their read and text characters are fetched together (independent loads), then looked at in order --
+		// one memory round trip per eight characters instead of one per character
+		for (uint32_t i0 = 0; i0 < lim && !stop; i0 += 8) {
+			int rdc[8], c[8];
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++) {
+				const uint32_t ii = i0 + k;
+				rdc[k] = 4; c[k] = -1;
+				if (ii < lim) {
+					uint32_t i;
+					if (left) i = fw ? off - ii - 1 : rdlen - off - len - 1 - ii;
+					else      i = fw ? ii + len + off : rdlen - off + ii;
+					rdc[k] = fm_rd_char(rd, rdlen, fw, i);
+					if (left) { if (p >= (uint64_t)ii + 1) c[k] = joined_char(ix.ref, p - ii - 1); }
+					else { const uint64_t q = p + len + ii; if (q < n) c[k] = joined_char(ix.ref, q); }
+				}
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++) {
+				if (stop || i0 + k >= lim) continue;
+				if (c[k] != rdc[k] && rdc[k] <= 3) { stop = true; continue; }
+				if (++cnt == 255) stop = true;
+			}
 		}
 		if (left) nlex = cnt; else nrex = cnt;
 	}
