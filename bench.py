@@ -370,12 +370,19 @@ def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, thre
     return cb, par
 
 
-def pmc_traffic(kernel, reads_per_launch):
+def pmc_files(config):
+    """committed PMC summaries of this configuration, oldest first: profiles/*pmc_traffic.json is the headline's (se150), the others carry
+    the configuration's name (profiles/*pmc_traffic_<config>.json) -- per-read traffic and instruction counts do not transfer between them"""
+    import glob
+    pat = "*pmc_traffic.json" if config == "se150" else "*pmc_traffic_%s.json" % config
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+
+
+def pmc_traffic(kernel, reads_per_launch, config="se150"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, KiB),
     scaled from the reads-per-launch of that profile run to this run's.  PMC collection needs rocprofv3 around the
     process, so it cannot be taken inside the timed run; profiles/README.md has the recipe."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    files = pmc_files(config)
     if not files:
         return None, None
     try:
@@ -390,11 +397,10 @@ def pmc_traffic(kernel, reads_per_launch):
         return None, None
 
 
-def pmc_issue(kernel, kern_ms, reads_per_launch, n_cu):
+def pmc_issue(kernel, kern_ms, reads_per_launch, n_cu, config="se150"):
     """What actually bounds the worker kernel: instructions issued per read (committed --pmc pass) against the SIMD-cycles the
     launch had (4 SIMDs per CU, a wave64 vector instruction occupies its SIMD for 4 cycles; 2.4 GHz engine clock)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    files = pmc_files(config)
     if not files:
         return None
     try:
@@ -604,7 +610,7 @@ def main():
         fm_bytes = (cnt.rank_queries * side + cnt.ftab_lookups * 2 * off_sz + cnt.sa_lookups * off_sz) / float(args.steps) + n * args.readlen * 2
         fm_achieved = fm_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
         kname = "k_align_pairs" if args.paired else "k_align_reads"
-        traffic, traffic_src = pmc_traffic(kname, n)
+        traffic, traffic_src = pmc_traffic(kname, n, args.config)
         cb, par = None, None
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
             ns = min(args.cpu_sample, n) & ~1
@@ -670,7 +676,7 @@ def main():
                          "dp_cells_note": "cells computed per launch (band cells; score-only passes up to their early exit: %d, matrix-storing fills: %d), over the whole kernel time"
                                           % (prof[24], prof[25]),
                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
-                         "instruction_issue": pmc_issue(kname, kern_ms, n, torch.cuda.get_device_properties(dev).multi_processor_count),
+                         "instruction_issue": pmc_issue(kname, kern_ms, n, torch.cuda.get_device_properties(dev).multi_processor_count, args.config),
                          "fm_kernels": {"kernels": ["k_exact_sweep", "k_one_mm", "k_seed_search_exact", "k_extend_hits"], "bound": "hbm",
                                         "ms_per_launch_sum": fm_ms, "algorithmic_bytes_per_launch": int(fm_bytes),
                                         "achieved": fm_achieved, "unit": "GB/s", "frac": fm_achieved / HBM_PEAK_GBS}},
