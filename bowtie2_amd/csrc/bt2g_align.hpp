@@ -198,7 +198,7 @@ struct PeHot {
 // later seeds with a new sequence are dropped too, and later seeds with an already-stored sequence see the cut range.
 // SAM parity needs exactly that, so the worker replays the pool accounting per seeding round: pages handed to the QKey map,
 // the SAKey list, the SAKey map and the element list, in seed order (fw offsets, then rc offsets).
-constexpr int kCacheKeys = 2 * kMaxOffs * 2;      // distinct seed sequences of one round (both mates of a pair)
+constexpr int kCacheKeys = 2 * kMaxOffs * 2 + kMaxSat2;      // distinct seed sequences of one round (both mates of a pair) + with -N 1 the distinct reference strings they hit
 struct CacheModel {
 	uint32_t pool_total, pool_used;
 	uint32_t qn, ql, san;          // nodes in the QKey map, entries in the SAKey list, nodes in the SAKey map
@@ -209,7 +209,7 @@ struct CacheModel {
 // `size` = elements the seed search found (what SeedResults tallies and ranks by); `esize` = elements of the range as the
 // per-read seed cache holds it: smaller when the cache's page pool ran out while the range was stored (struct CacheModel)
 struct HotHit { uint64_t topf, topb; uint32_t size; uint32_t esize; };   // exact seed hit: one range.  With -N 1: topf = first entry in Work::sranges, topb = # ranges, size = total elements
-struct SeedRange { uint64_t topf, topb; uint32_t size; uint32_t pad; };   // one BW range of a 1-mismatch seed (SATuple, aligner_cache.h:370)
+struct SeedRange { uint64_t topf, topb; uint32_t size; uint32_t esize; };   // one BW range of a 1-mismatch seed (SATuple, aligner_cache.h:370); esize: elements the seed cache holds for its reference string (CacheModel)
 struct HotWork {
 	uint8_t  seq[kMaxLen];     // read, codes 0..4, 5'->3'
 	uint8_t  qual[kMaxLen];    // ASCII
@@ -279,6 +279,7 @@ struct Work {
 	EEHit    mm1[kMaxMm1];
 	// ---- extension phase ----
 	SeedRange sranges[kMaxSat2];       // -N 1: the ranges behind HotWork::hits
+	uint64_t srange_key[kMaxSat2];     // -N 1: the reference string of each range (the seed with its substitution), packed like ck_key
 	SatPos   satpos2[kMaxSat2];
 	R1N      rands2[kMaxSat2];
 	SatPos   satpos[kMaxSatpos];

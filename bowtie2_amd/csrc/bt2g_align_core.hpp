@@ -386,6 +386,62 @@ struct Aligner {
 	// index, exact over the right floor(L/2) characters and exactly one mismatch over the rest.  Every hit (one BW
 	// range per distinct reference string) is kept; HOT.hits[..] then indexes a run of Work::sranges.
 	// An N may only fall in a policy's mismatch zone, where it stands for the one mismatch (Seed::instantiate :325-345).
+	// -N 1: what the reference's per-round seed cache does with the hits [first, last) of one seed (see cache_filter for the exact-seed
+	// form).  Returns false when the seed is dropped (out of memory in beginAlign or in any addOnTheFly: searchAllSeeds counts an "oom" and
+	// skips sr.add, aligner_seed.cpp:672-690); the pool, the maps and the ranges stored so far keep what was spent.  Sets
+	// SeedRange::esize = elements the cache holds for the range's reference string (cut when the pool ran out while it was stored;
+	// the first stored copy decides for every later seed that hits the same string).
+	BT2_HD bool cache_account_mm1(uint32_t first, uint32_t last, uint64_t qkey, bool qcacheable, uint32_t L) {
+		CacheModel& c = HOT.cm;
+		constexpr uint32_t q_per = sizeof(TOff) == 4 ? 256u : 227u;
+		constexpr uint32_t sa_per = sizeof(TOff) == 4 ? 256u : 204u;
+		constexpr uint32_t ql_per = 1024u;
+		constexpr uint64_t sl_per = 16384u / sizeof(TOff);
+		// beginAlign: a seed without N enters the QKey map (one with an N is not cacheable: no node)
+		if (qcacheable) {
+			const uint32_t e = Plat::find_key(WK.ck_key, WK.ck_len, c.nkeys, qkey, (uint8_t)L);
+			if (e == c.nkeys || !(WK.ck_flags[e] & 1)) {
+				if (c.qn % q_per == 0 && !cache_page()) return false;
+				c.qn++;
+				if (e == c.nkeys) {
+					if (c.nkeys >= (uint32_t)kCacheKeys) { ovf(30); return false; }
+					WK.ck_key[e] = qkey; WK.ck_len[e] = (uint8_t)L; WK.ck_flags[e] = 0; WK.ck_eff[e] = 0; c.nkeys++;
+				}
+				WK.ck_flags[e] |= 1;
+			}
+		}
+		bool ok = true;
+		for (uint32_t r = first; r < last; r++) {
+			BT2_G SeedRange& sr = WK.sranges[r];
+			// addOnTheFly: SAKey list entry, SAKey map node, one element-list slot per row
+			if (c.ql % ql_per == 0 && !cache_page()) { ok = false; sr.esize = 0; continue; }
+			c.ql++;
+			const uint64_t key = WK.srange_key[r];
+			uint32_t e = Plat::find_key(WK.ck_key, WK.ck_len, c.nkeys, key, (uint8_t)L);
+			if (e == c.nkeys) {
+				if (c.nkeys >= (uint32_t)kCacheKeys) { ovf(30); ok = false; sr.esize = 0; continue; }
+				WK.ck_key[e] = key; WK.ck_len[e] = (uint8_t)L; WK.ck_flags[e] = 0; WK.ck_eff[e] = 0; c.nkeys++;
+			}
+			if (!(WK.ck_flags[e] & 2)) {
+				if (c.san % sa_per == 0 && !cache_page()) { ok = false; sr.esize = 0; continue; }
+				c.san++;
+				WK.ck_flags[e] |= 2;
+				const uint64_t full = sr.size;
+				const uint64_t room = (sl_per - c.sl % sl_per) % sl_per + (uint64_t)(c.pool_total - c.pool_used) * sl_per;
+				if (full <= room) {
+					const uint64_t in_page = (sl_per - c.sl % sl_per) % sl_per;
+					if (full > in_page) c.pool_used += (uint32_t)((full - in_page + sl_per - 1) / sl_per);
+					c.sl += full; WK.ck_eff[e] = (uint32_t)full;
+				} else {
+					c.sl += room; c.pool_used = c.pool_total; WK.ck_eff[e] = (uint32_t)room;      // the range is cut
+					ok = false;
+				}
+			}
+			sr.esize = WK.ck_eff[e];
+		}
+		return ok;
+	}
+
 	BT2_HDN uint32_t seed_round_mm1(uint32_t offset, uint32_t interval, uint32_t seedlen) {
 		const uint32_t len = HOT.len;
 		const uint32_t L = seedlen < len ? seedlen : len;
@@ -411,30 +467,45 @@ struct Aligner {
 				auto getc = [&](uint32_t k) -> int { return fw ? (int)HOT.seq[depth + k] : comp4(HOT.seq[depth + L - 1 - k]); };
 				const uint32_t first = nsr;
 				uint64_t elts = 0;
-				auto report = [&](TOff topf, TOff botf, TOff topb) {
+				uint32_t inst_here = 0;
+				// the seed as a packed key (an N as 0); the reference string of a hit is the seed with position `sp` replaced by `sc`
+				bool qcacheable = true;
+				const uint64_t qkey = L <= 32 ? Plat::seed_key(fw, depth, L, qcacheable) : 0ull;
+				auto report = [&](TOff topf, TOff botf, TOff topb, uint32_t sp, int sc) {
 					if (nsr >= (uint32_t)kMaxSat2) { ovf(5); return; }
+					uint64_t key = qkey;
+					if (sp < L) { const uint32_t sh = 2u * (L - 1u - sp); key = (key & ~(3ull << sh)) | ((uint64_t)(sc & 3) << sh); }
+					WK.srange_key[nsr] = key;
 					BT2_G SeedRange& r = WK.sranges[nsr++];
-					r.topf = topf; r.topb = topb; r.size = (uint32_t)(botf - topf);
+					r.topf = topf; r.topb = topb; r.size = r.esize = (uint32_t)(botf - topf);
 					elts += (uint64_t)(botf - topf);
 				};
+				// The reference advances the searches of a seed's two policies in LOCKSTEP, one step each per turn (searchSeedBi's loop over
+				// paramVec, aligner_seed.cpp:1878-2037; a mismatch branch runs to its end at once, :1964), so the hits of a seed are discovered
+				// interleaved -- which is the order the seed cache stores them in, and when its pool runs out, the order decides which
+				// ranges are cut (cache_account_mm1).
+				struct PolState { bool live; uint32_t step; int mms; TOff topf, botf, topb, botb; } ps[2];
+				auto pos_of = [&](int pol, uint32_t k) -> uint32_t { return pol == 0 ? k : L - 1 - k; };
+				auto zone1_of = [&](int pol, uint32_t k) -> bool { const uint32_t z0 = pol == 0 ? (L + 1) / 2 : L / 2; return k >= z0 || k == L - 1; };
+				// startSearchSeedBi of both policies, in order
 				for (int pol = 0; pol < 2; pol++) {
 					const bool ltr = pol == 0;
+					PolState& s = ps[pol];
+					s.live = false; s.step = 0; s.mms = 1; s.topf = s.botf = s.topb = s.botb = 0;
 					// step k reads seed character pos(k); zone(k) = 1 once past the exact half (Seed::instantiate :256-276)
-					auto pos = [&](uint32_t k) -> uint32_t { return ltr ? k : L - 1 - k; };
-					const uint32_t z0 = ltr ? (L + 1) / 2 : L / 2;       // steps [0, z0) are zone 0, except that the last step always closes zone 1
-					auto zone1 = [&](uint32_t k) -> bool { return k >= z0 || k == L - 1; };
-					const int ceil1 = ltr ? 0x7fffffff : 0;               // mmsCeil of zone 1: the right-to-left policy must have spent its mismatch
+					auto pos = [&](uint32_t k) -> uint32_t { return pos_of(pol, k); };
+					auto zone1 = [&](uint32_t k) -> bool { return zone1_of(pol, k); };       // steps [0, z0) are zone 0, except that the last step always closes zone 1
 					int mms = 1;
 					bool inst = true;
 					for (uint32_t k = 0; k < L && inst; k++) {
 						if (getc(pos(k)) > 3) { if (zone1(k) && mms > 0) mms--; else inst = false; }
 					}
 					if (!inst) continue;
-					ninst++;
+					ninst++; inst_here++;
+					s.mms = mms;
 					// maxjump: leading steps that stay in zone 0 (for the right-to-left seed the insertion zone changes at the same step)
 					uint32_t maxjump = 0;
 					while (maxjump < L && !zone1(maxjump)) maxjump++;
-					const DevEbwt<TOff>& e = ltr ? IX.bw : IX.fw;
 					TOff topf = 0, botf = 0, topb = 0, botb = 0;
 					uint32_t step = 0;
 					if (fc > 1 && fc <= maxjump) {
@@ -458,9 +529,21 @@ struct Aligner {
 						topf = topb = 0;
 						botf = botb = IX.fw.fchr[4];
 					}
-					if (step == L) { report(topf, botf, topb); continue; }
+					if (step == L) { report(topf, botf, topb, L, 0); continue; }
+					s.live = true; s.step = step; s.topf = topf; s.botf = botf; s.topb = topb; s.botb = botb;
+				}
+				// one step of one policy
+				auto do_step = [&](int pol) {
+					const bool ltr = pol == 0;
+					PolState& s = ps[pol];
+					auto pos = [&](uint32_t k) -> uint32_t { return pos_of(pol, k); };
+					auto zone1 = [&](uint32_t k) -> bool { return zone1_of(pol, k); };
+					const int ceil1 = ltr ? 0x7fffffff : 0;               // mmsCeil of zone 1: the right-to-left policy must have spent its mismatch
+					const int mms = s.mms;
+					const DevEbwt<TOff>& e = ltr ? IX.bw : IX.fw;
+					TOff& topf = s.topf; TOff& botf = s.botf; TOff& topb = s.topb; TOff& botb = s.botb;
 					// exact continuation after the mismatch (the recursive searchSeedBi call: every zone is used up)
-					auto finish_exact = [&](uint32_t st, TOff tf_, TOff bf_, TOff tb_, TOff bb_) {
+					auto finish_exact = [&](uint32_t st, TOff tf_, TOff bf_, TOff tb_, TOff bb_, uint32_t sp, int sc) {
 						for (; st < L; st++) {
 							const int c = getc(pos(st));
 							TOff& top = ltr ? tb_ : tf_; TOff& bot = ltr ? bb_ : bf_;
@@ -477,57 +560,61 @@ struct Aligner {
 								top = t; bot = t + 1;
 							}
 						}
-						report(tf_, bf_, tb_);
+						report(tf_, bf_, tb_, sp, sc);
 					};
-					bool alive = true;
-					for (; alive && step < L; step++) {
-						const uint32_t k = step;
-						const int c = getc(pos(k));
-						const bool z1 = zone1(k), leave = k == L - 1;
-						TOff& top = ltr ? topb : topf; TOff& bot = ltr ? botb : botf;      // range in the index being walked
-						TOff& topp = ltr ? topf : topb; TOff& botp = ltr ? botf : botb;    // and in the other one
-						TOff t[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, tp[4], bp[4];
-						tp[0] = tp[1] = tp[2] = tp[3] = topp; bp[0] = bp[1] = bp[2] = bp[3] = botp;
-						const bool wide = bot - top > 1;
-						if (wide) { HOT.n_bwops_seed++; bi_lf(e, top, bot, topp, t, b, tp, bp); }
-						bool probed = false;     // single-row range whose character was looked up by the edit branch
-						TOff row1 = top;
-						if ((z1 && mms > 0) || c > 3) {
-							bool bail = false;
-							if (!wide) {
-								HOT.n_bwops_seed++;
-								const int cc = lf1(e, row1);
-								if (cc < 0) bail = true; else { t[cc] = row1; b[cc] = row1 + 1; probed = true; }
-							}
-							if (!bail) {
-								const int after = c > 3 ? mms : mms - 1;
-								if (!leave || after <= ceil1) {
-									for (int j = 0; j < 4; j++) {
-										if (j == c || b[j] == t[j]) continue;
-										const TOff jt = t[j], jb = b[j], jtp = tp[j], jbp = bp[j];
-										if (ltr) finish_exact(k + 1, jtp, jbp, jt, jb); else finish_exact(k + 1, jt, jb, jtp, jbp);
-									}
+					const uint32_t k = s.step;
+					const int c = getc(pos(k));
+					const bool z1 = zone1(k), leave = k == L - 1;
+					TOff& top = ltr ? topb : topf; TOff& bot = ltr ? botb : botf;      // range in the index being walked
+					TOff& topp = ltr ? topf : topb; TOff& botp = ltr ? botf : botb;    // and in the other one
+					TOff t[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, tp[4], bp[4];
+					tp[0] = tp[1] = tp[2] = tp[3] = topp; bp[0] = bp[1] = bp[2] = bp[3] = botp;
+					const bool wide = bot - top > 1;
+					if (wide) { HOT.n_bwops_seed++; bi_lf(e, top, bot, topp, t, b, tp, bp); }
+					bool probed = false;     // single-row range whose character was looked up by the edit branch
+					TOff row1 = top;
+					if ((z1 && mms > 0) || c > 3) {
+						bool bail = false;
+						if (!wide) {
+							HOT.n_bwops_seed++;
+							const int cc = lf1(e, row1);
+							if (cc < 0) bail = true; else { t[cc] = row1; b[cc] = row1 + 1; probed = true; }
+						}
+						if (!bail) {
+							const int after = c > 3 ? mms : mms - 1;
+							if (!leave || after <= ceil1) {
+								for (int j = 0; j < 4; j++) {
+									if (j == c || b[j] == t[j]) continue;
+									const TOff jt = t[j], jb = b[j], jtp = tp[j], jbp = bp[j];
+									if (ltr) finish_exact(k + 1, jtp, jbp, jt, jb, pos(k), j); else finish_exact(k + 1, jt, jb, jtp, jbp, pos(k), j);
 								}
 							}
 						}
-						if (c > 3) { alive = false; break; }
-						if (leave && z1 && mms > ceil1) { alive = false; break; }
-						if (!wide) {
-							HOT.n_bwops_seed++;
-							if (probed) {
-								// mapLF1(ntop, tloc, c) after mapLF1(ntop&, tloc): the row test sees the already-advanced row (:1995 after :1918)
-								if (t[c] == b[c] || row1 == e.zoff) { alive = false; break; }
-							} else {
-								const TOff r = lf1c(e, top, c);
-								if (r == kOffMask) { alive = false; break; }
-								t[c] = r; b[c] = r + 1;
-							}
-						}
-						if (b[c] == t[c]) { alive = false; break; }
-						top = t[c]; bot = b[c]; topp = tp[c]; botp = bp[c];
 					}
-					if (alive) report(topf, botf, topb);
+					if (c > 3) { s.live = false; return; }
+					if (leave && z1 && mms > ceil1) { s.live = false; return; }
+					if (!wide) {
+						HOT.n_bwops_seed++;
+						if (probed) {
+							// mapLF1(ntop, tloc, c) after mapLF1(ntop&, tloc): the row test sees the already-advanced row (:1995 after :1918)
+							if (t[c] == b[c] || row1 == e.zoff) { s.live = false; return; }
+						} else {
+							const TOff r = lf1c(e, top, c);
+							if (r == kOffMask) { s.live = false; return; }
+							t[c] = r; b[c] = r + 1;
+						}
+					}
+					if (b[c] == t[c]) { s.live = false; return; }
+					top = t[c]; bot = b[c]; topp = tp[c]; botp = bp[c];
+					s.step++;
+					if (s.step == L) { report(topf, botf, topb, L, 0); s.live = false; }
+				};
+				while (ps[0].live || ps[1].live) {
+					for (int pol = 0; pol < 2; pol++) if (ps[pol].live) do_step(pol);
 				}
+				// the seed cache's page accounting for this seed (CacheModel): SeedSearchCache::beginAlign, then addOnTheFly per hit in
+				// discovery order (aligner_seed.h:1483-1510, aligner_cache.cpp:53-105); a seed whose hits did not all fit is dropped
+				if (inst_here > 0 && L <= 32 && !cache_account_mm1(first, nsr, qkey, qcacheable, L)) continue;
 				if (nsr > first && elts > 0) {
 					HotHit& h = HOT.hits[fwi][i];
 					h.topf = first; h.topb = nsr - first; h.size = h.esize = (uint32_t)elts;
@@ -860,8 +947,8 @@ struct Aligner {
 			const uint32_t nr_here = seedmms > 0 ? (uint32_t)h.topb : 1u;      // ca.queryQval: one SATuple per reference string
 			for (uint32_t ri = 0; ri < nr_here; ri++) {
 			uint64_t h_topf = h.topf, h_topb = h.topb, sz = h.esize;      // the range as the seed cache holds it
-			if (seedmms > 0) { const BT2_G SeedRange& sr = WK.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.size; }
-			else if (sz == 0) continue;
+			if (seedmms > 0) { const BT2_G SeedRange& sr = WK.sranges[h.topf + ri]; h_topf = sr.topf; h_topb = sr.topb; sz = sr.esize; }      // (queryQval: what the cache holds)
+			if (sz == 0) continue;
 			nrange++; nelt += sz;
 			if (seedmms == 0) {
 				const bool m2 = PRM.paired && HOT.pe.cur == 1;     // seedExRangeFw_[matei] / seedExRangeRc_[matei]

@@ -173,8 +173,8 @@ struct HostPlat {
 		ok = true;
 		for (uint32_t k = 0; k < L; k++) {
 			const int ch = fw ? (int)g_hot.seq[depth + k] : comp4(g_hot.seq[depth + L - 1 - k]);
-			if (ch > 3) { ok = false; return 0; }
-			key = (key << 2) | (uint64_t)ch;
+			if (ch > 3) ok = false;      // (the key is still formed, with the N as 0: seed_round_mm1 substitutes that position)
+			key = (key << 2) | (uint64_t)(ch & 3);
 		}
 		return key;
 	}
