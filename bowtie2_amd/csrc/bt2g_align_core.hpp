@@ -112,6 +112,21 @@ struct Aligner {
 		constexpr uint32_t ql_per = 1024u;                              // 16 KB / sizeof(SAKey)
 		constexpr uint64_t sl_per = 16384u / sizeof(TOff);              // 16 KB / sizeof(TIndexOffU)
 		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
+		// The key table lives in the arena; its first 64 entries (all of them for an unpaired 150-bp read) are mirrored in lane registers
+		// for the duration of this call -- key, length | flags << 8, elements held -- so that a seed costs no memory round trip (it used
+		// to cost two: the search of the table and the entry's flags).  Every change is also stored, the arena copy stays complete.
+		typename Plat::LaneReg klo, khi, klf, kef;
+		Plat::lanes_load_keys(WK.ck_key, WK.ck_len, WK.ck_flags, WK.ck_eff, c.nkeys < 64u ? c.nkeys : 64u, klo, khi, klf, kef);
+		auto find = [&](uint64_t key, uint8_t len) -> uint32_t {
+			const uint32_t n64 = c.nkeys < 64u ? c.nkeys : 64u;
+			const uint32_t e = Plat::find_key_lanes(klo, khi, klf, n64, key, len);
+			if (e < n64 || c.nkeys <= 64u) return e < n64 ? e : c.nkeys;
+			return 64u + Plat::find_key(WK.ck_key + 64, WK.ck_len + 64, c.nkeys - 64u, key, len);
+		};
+		auto flags_of = [&](uint32_t e) -> uint32_t { return e < 64u ? (Plat::lane(klf, e) >> 8) & 0xffu : (uint32_t)WK.ck_flags[e]; };
+		auto eff_of = [&](uint32_t e) -> uint32_t { return e < 64u ? Plat::lane(kef, e) : WK.ck_eff[e]; };
+		auto set_flags = [&](uint32_t e, uint32_t f, uint8_t len) { WK.ck_flags[e] = (uint8_t)f; if (e < 64u) Plat::set_lane(klf, e, (uint32_t)len | (f << 8)); };
+		auto set_eff = [&](uint32_t e, uint32_t v) { WK.ck_eff[e] = v; if (e < 64u) Plat::set_lane(kef, e, v); };
 		for (int fwi = 0; fwi < 2; fwi++) {
 			const bool fw = fwi == 0;
 			if ((fw && ST.m_nofw) || (!fw && ST.m_norc)) continue;
@@ -122,18 +137,20 @@ struct Aligner {
 				bool inst = L <= 32;      // (-L > 32 cannot occur)
 				const uint64_t key = inst ? Plat::seed_key(fw, depth, L, inst) : 0;
 				if (!inst) { h.size = h.esize = 0; continue; }
-				const uint32_t e = Plat::find_key(WK.ck_key, WK.ck_len, c.nkeys, key, (uint8_t)L);
+				const uint32_t e = find(key, (uint8_t)L);
 				bool drop = false;
 				// beginAlign: the seed sequence enters the QKey map
-				if (e == c.nkeys || !(WK.ck_flags[e] & 1)) {
+				if (e == c.nkeys || !(flags_of(e) & 1)) {
 					if (c.qn % q_per == 0 && !cache_page()) drop = true;
 					else {
 						c.qn++;
 						if (e == c.nkeys) {
 							if (c.nkeys >= (uint32_t)kCacheKeys) { ovf(30); h.size = h.esize = 0; continue; }
-							WK.ck_key[e] = key; WK.ck_len[e] = (uint8_t)L; WK.ck_flags[e] = 0; WK.ck_eff[e] = 0; c.nkeys++;
+							WK.ck_key[e] = key; WK.ck_len[e] = (uint8_t)L;
+							if (e < 64u) { Plat::set_lane(klo, e, (uint32_t)key); Plat::set_lane(khi, e, (uint32_t)(key >> 32)); }
+							set_flags(e, 0, (uint8_t)L); set_eff(e, 0); c.nkeys++;
 						}
-						WK.ck_flags[e] |= 1;
+						set_flags(e, flags_of(e) | 1u, (uint8_t)L);
 					}
 				}
 				if (!drop && h.size > 0) {
@@ -141,19 +158,19 @@ struct Aligner {
 					if (c.ql % ql_per == 0 && !cache_page()) drop = true;
 					else {
 						c.ql++;
-						if (!(WK.ck_flags[e] & 2)) {
+						if (!(flags_of(e) & 2)) {
 							if (c.san % sa_per == 0 && !cache_page()) drop = true;
 							else {
 								c.san++;
-								WK.ck_flags[e] |= 2;
+								set_flags(e, flags_of(e) | 2u, (uint8_t)L);
 								const uint64_t full = h.size;
 								const uint64_t room = (sl_per - c.sl % sl_per) % sl_per + (uint64_t)(c.pool_total - c.pool_used) * sl_per;
 								if (full <= room) {
 									const uint64_t in_page = (sl_per - c.sl % sl_per) % sl_per;
 									if (full > in_page) c.pool_used += (uint32_t)((full - in_page + sl_per - 1) / sl_per);
-									c.sl += full; WK.ck_eff[e] = (uint32_t)full;
+									c.sl += full; set_eff(e, (uint32_t)full);
 								} else {
-									c.sl += room; c.pool_used = c.pool_total; WK.ck_eff[e] = (uint32_t)room;      // the range is cut, this seed is dropped
+									c.sl += room; c.pool_used = c.pool_total; set_eff(e, (uint32_t)room);      // the range is cut, this seed is dropped
 									drop = true;
 								}
 							}
@@ -161,7 +178,7 @@ struct Aligner {
 					}
 				}
 				if (drop || h.size == 0) { h.size = h.esize = 0; continue; }
-				h.esize = WK.ck_eff[e];
+				h.esize = eff_of(e);
 				// (esize 0: the pool was already empty when the sequence's range was first stored.  The seed still counts and is
 				// ranked, but AlignmentCache::queryQvalImpl hands out no range for it, aligner_cache.h:646)
 				HOT.nonz_tot++;

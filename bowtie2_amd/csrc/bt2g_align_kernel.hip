@@ -817,6 +817,20 @@ struct DevPlat {
 		const uint32_t i = base + (threadIdx.x & 63);
 		return i < n ? gld(p + i) : 0u;
 	}
+	// the first 64 entries of the seed cache's key table as lane registers (key halves, length | flags << 8, elements held)
+	static __device__ __forceinline__ void lanes_load_keys(const BT2_G uint64_t* keys, const BT2_G uint8_t* lens, const BT2_G uint8_t* flags, const BT2_G uint32_t* eff, uint32_t n,
+	                                                       LaneReg& klo, LaneReg& khi, LaneReg& klf, LaneReg& kef) {
+		wave_fence();
+		const uint32_t l = threadIdx.x & 63;
+		klo = khi = klf = kef = 0;
+		if (l < n) { const uint64_t k = gld(keys + l); klo = (uint32_t)k; khi = (uint32_t)(k >> 32); klf = (uint32_t)gld(lens + l) | ((uint32_t)gld(flags + l) << 8); kef = gld(eff + l); }
+	}
+	// index of (key, len) among the first n entries mirrored in the lanes, n if absent
+	static __device__ __forceinline__ uint32_t find_key_lanes(LaneReg klo, LaneReg khi, LaneReg klf, uint32_t n, uint64_t key, uint8_t len) {
+		const uint32_t l = threadIdx.x & 63;
+		const unsigned long long m = __ballot(l < n && klo == (uint32_t)key && khi == (uint32_t)(key >> 32) && (klf & 0xffu) == (uint32_t)len);
+		return m ? (uint32_t)__builtin_ctzll(m) : n;
+	}
 	// is (row, col) within sq rows and sq columns of one of the first n cells (row | col << 16) held in the lanes of r?
 	static __device__ __forceinline__ bool near_any(LaneReg r, uint32_t n, uint32_t row, uint32_t col, uint32_t sq) {
 		const uint32_t l = threadIdx.x & 63;

@@ -124,6 +124,16 @@ struct HostPlat {
 		for (uint32_t l = 0; l < 64; l++) r.v[l] = base + l < n ? p[base + l] : 0u;
 		return r;
 	}
+	static void lanes_load_keys(const uint64_t* keys, const uint8_t* lens, const uint8_t* flags, const uint32_t* eff, uint32_t n, LaneReg& klo, LaneReg& khi, LaneReg& klf, LaneReg& kef) {
+		for (uint32_t l = 0; l < 64; l++) {
+			klo.v[l] = khi.v[l] = klf.v[l] = kef.v[l] = 0;
+			if (l < n) { klo.v[l] = (uint32_t)keys[l]; khi.v[l] = (uint32_t)(keys[l] >> 32); klf.v[l] = (uint32_t)lens[l] | ((uint32_t)flags[l] << 8); kef.v[l] = eff[l]; }
+		}
+	}
+	static uint32_t find_key_lanes(const LaneReg& klo, const LaneReg& khi, const LaneReg& klf, uint32_t n, uint64_t key, uint8_t len) {
+		for (uint32_t l = 0; l < n && l < 64; l++) if (klo.v[l] == (uint32_t)key && khi.v[l] == (uint32_t)(key >> 32) && (klf.v[l] & 0xffu) == (uint32_t)len) return l;
+		return n;
+	}
 	static bool near_any(const LaneReg& r, uint32_t n, uint32_t row, uint32_t col, uint32_t sq) {
 		for (uint32_t l = 0; l < n && l < 64; l++) {
 			const uint32_t orow = r.v[l] & 0xffffu, ocol = r.v[l] >> 16;
