@@ -501,6 +501,9 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	static thread_local std::string stRef, stRel, stRead, md;
 	static thread_local std::vector<Edit> ed;
 	stRef.clear(); stRel.clear(); stRead.clear();
+	// An alignment without gaps (nearly all of them) needs no stacked alignment: its CIGAR and MD:Z follow from the mismatch positions.
+	bool nogap = aln != nullptr;
+	if (aln) for (uint32_t i = 0; i < aln->nned; i++) if (aln->ned[i].type != EDIT_MM) { nogap = false; break; }
 	if (aln) {
 		// edits w.r.t. the upstream end: invert for rc (AlnRes::initStacked)
 		ed.assign(aln->ned, aln->ned + aln->nned);
@@ -513,14 +516,14 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		}
 		auto s = [&](size_t i) -> int { return aln->fw ? (int)rd.seq[i] : comp4((int)rd.seq[len - 1 - i]); };
 		size_t rdoff = trimLS;
-		for (const auto& e : ed) {
+		if (!nogap) for (const auto& e : ed) {
 			const size_t pos = e.pos + trimLS;
 			while (rdoff < pos) { const int c = s(rdoff++); stRef.push_back(DNA[c]); stRel.push_back('='); stRead.push_back(DNA[c]); }
 			if (e.type == EDIT_MM) { const int c = s(rdoff++); stRef.push_back((char)e.chr); stRel.push_back('X'); stRead.push_back(DNA[c]); }
 			else if (e.type == EDIT_REF_GAP) { const int c = s(rdoff++); stRef.push_back('-'); stRel.push_back('I'); stRead.push_back(DNA[c]); }
 			else { stRef.push_back((char)e.chr); stRel.push_back('D'); stRead.push_back('-'); }
 		}
-		while (rdoff < len - trimRS) { const int c = s(rdoff++); stRef.push_back(DNA[c]); stRel.push_back('='); stRead.push_back(DNA[c]); }
+		if (!nogap) while (rdoff < len - trimRS) { const int c = s(rdoff++); stRef.push_back(DNA[c]); stRel.push_back('='); stRead.push_back(DNA[c]); }
 		// leftAlign(false)
 		const size_t ln = stRef.size();
 		for (size_t i = 0; i < ln; i++) {
@@ -551,6 +554,35 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		o.push_back('\t');
 		// CIGAR
 		if (trimLS > 0) { app_int(o, (int64_t)(trimLS)); o.push_back('S'); }
+		if (nogap) {
+			if (!opt.xeq) { if (len_trimmed > 0) { app_int(o, (int64_t)len_trimmed); o.push_back('M'); } }
+			else {
+				size_t at = 0;
+				for (size_t i = 0; i < ed.size();) {
+					const size_t p0 = ed[i].pos;
+					if (p0 > at) { app_int(o, (int64_t)(p0 - at)); o.push_back('='); }
+					size_t run = 1;
+					while (i + run < ed.size() && (size_t)ed[i + run].pos == p0 + run) run++;
+					app_int(o, (int64_t)run); o.push_back('X');
+					at = p0 + run; i += run;
+				}
+				if (len_trimmed > at) { app_int(o, (int64_t)(len_trimmed - at)); o.push_back('='); }
+			}
+			// MD:Z (buildMdz + writeMdz) for the no-gap case: match runs and mismatched reference characters, a 0 between adjacent
+			// mismatches, before a leading and after a trailing one
+			md.clear();
+			size_t at = 0;
+			bool mm_last = false, first_print = true;
+			for (const auto& e : ed) {
+				if ((size_t)e.pos > at) { app_int(md, (int64_t)((size_t)e.pos - at)); first_print = false; mm_last = false; }
+				if (mm_last || first_print) md.push_back('0');
+				md.push_back((char)e.chr);
+				first_print = false; mm_last = true;
+				at = (size_t)e.pos + 1;
+			}
+			if (len_trimmed > at) app_int(md, (int64_t)(len_trimmed - at));
+			else if (mm_last) md.push_back('0');
+		} else
 		for (size_t i = 0; i < ln; i++) {
 			char op = stRel[i];
 			if (!opt.xeq && (op == 'X' || op == '=')) op = 'M';
@@ -577,13 +609,23 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 	// SEQ / QUAL
 	if (len == 0) o.push_back('*');
 	else if (!primary && opt.omit_sec_seq) o.push_back('*');
-	else if (!aln || aln->fw) for (size_t i = 0; i < len; i++) o.push_back(DNA[(int)rd.seq[i]]);
-	else for (size_t i = 0; i < len; i++) o.push_back(DNA[comp4((int)rd.seq[len - 1 - i])]);
+	else {
+		const size_t o0 = o.size();
+		o.resize(o0 + len);
+		char* w = &o[o0];
+		if (!aln || aln->fw) for (size_t i = 0; i < len; i++) w[i] = DNA[(int)rd.seq[i]];
+		else for (size_t i = 0; i < len; i++) w[i] = DNA[comp4((int)rd.seq[len - 1 - i])];
+	}
 	o.push_back('\t');
 	if (len == 0) o.push_back('*');
 	else if (!primary && opt.omit_sec_seq) o.push_back('*');
 	else if (!aln || aln->fw) o.append(rd.qual.data(), rd.qual.size());
-	else for (size_t i = len; i > 0; i--) o.push_back(rd.qual[i - 1]);
+	else {
+		const size_t o0 = o.size();
+		o.resize(o0 + len);
+		char* w = &o[o0];
+		for (size_t i = 0; i < len; i++) w[i] = rd.qual[len - 1 - i];
+	}
 	o.push_back('\t');
 	// optional fields
 	if (aln) {
@@ -607,8 +649,8 @@ inline void sam_record(std::string& o, const Options& opt, const RefInfo& ref, c
 		o += "\tXM:i:"; app_int(o, (int64_t)num_mm); o += "\tXO:i:"; app_int(o, (int64_t)num_go); o += "\tXG:i:"; app_int(o, (int64_t)num_gx);
 		o += "\tNM:i:"; app_int(o, aln->nned);
 		// MD:Z (buildMdz + writeMdz); the reference prints it before YT:Z
-		md.clear();
-		{
+		if (!nogap) {
+			md.clear();
 			bool mm_last = false, rdgap_last = false, first_print = true;
 			const size_t ln = stRef.size();
 			for (size_t i = 0; i < ln; i++) {

@@ -22,6 +22,7 @@
 #include <deque>
 #include <fstream>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -323,11 +324,34 @@ public:
 
 	double t_split = 0, t_parse = 0, t_pack = 0;      // seconds spent in each part of next() (-t)
 	// Fill `b` with up to max_reads reads; sets b.last at end of input (or at -u).
+	// Two stages.  split(): the serial scan of the input into records (one thread: it is a scan of a byte stream).  finish(): records ->
+	// codes, qualities, names and per-read parameters, parallel over chunks.  While the caller finishes batch k, a helper thread already
+	// splits batch k + 1 into the other RawBatch -- the serial scan no longer adds to the time of a batch, it only has to keep up.
 	void next(HostBatch& b, size_t max_reads, size_t max_read_len) {
-		auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		RawBatch* cur;
+		if (prefetch_.valid()) { prefetch_.get(); cur = &raw_[cur_ ^= 1]; }
+		else { cur = &raw_[cur_]; split(*cur, max_reads); }
+		if (!cur->last && cur->bad_input.empty()) {
+			RawBatch* nxt = &raw_[cur_ ^ 1];
+			prefetch_ = std::async(std::launch::async, [this, nxt, max_reads]() { split(*nxt, max_reads); });
+		}
+		finish(*cur, b, max_read_len);
+	}
+private:
+	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; size_t tag_off = 0, tag_len = 0; };
+	// what split() hands to finish(): the records of one batch as offsets into one arena, and how the scan ended
+	struct RawBatch { std::string arena, orig; std::vector<Raw> recs; bool last = false, upto_hit = false, io_error = false; std::string bad_input; };
+	RawBatch raw_[2];
+	int cur_ = 0;
+	std::future<void> prefetch_;
+	static double tnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+	void split(RawBatch& rb, size_t max_reads) {
 		const double t0_ = tnow();
 		// ---- serial part: split the text into records (line copies into one arena)
+		std::string& arena_ = rb.arena; std::vector<Raw>& recs_ = rb.recs; std::string& orig_ = rb.orig;
+		RawBatch& b = rb;       // (the scan's verdicts -- last, upto_hit, bad_input -- travel with the records)
 		arena_.clear(); recs_.clear(); orig_.clear();
+		b.last = b.upto_hit = b.io_error = false; b.bad_input.clear();
 		const bool pt = opt_.passthrough;
 		while (recs_.size() < max_reads) {
 			const char* p; size_t n;
@@ -549,8 +573,14 @@ public:
 			}
 			if (skip1) continue;
 		}
+		b.io_error = src_.io_error();
+		t_split += tnow() - t0_;
+	}
+	void finish(RawBatch& rb, HostBatch& b, size_t max_read_len) {
 		const double t1_ = tnow();
-		t_split += t1_ - t0_;
+		const std::string& arena_ = rb.arena; const std::vector<Raw>& recs_ = rb.recs; const std::string& orig_ = rb.orig;
+		const bool pt = opt_.passthrough;
+		b.last = rb.last; b.upto_hit = rb.upto_hit; b.bad_input = rb.bad_input;
 		// ---- parallel part 1: records -> names, codes and qualities in per-chunk arenas (no per-read allocations)
 		const size_t nrec = recs_.size();
 		const size_t chunk = 4096, nchunks = (nrec + chunk - 1) / chunk;
@@ -642,25 +672,22 @@ public:
 		});
 		for (size_t i = 0; i < nrec; i++) if (rlen[i] > max_read_len) { b.too_long = b.reads[i].name.str(); break; }
 		if (b.bad_input.empty()) for (const HostBatch::Chunk& ch : b.chunks) if (!ch.error.empty()) { b.bad_input = ch.error; break; }
-		if (b.bad_input.empty() && src_.io_error()) b.bad_input = "error while reading the reads file (corrupt or truncated compressed input?)";
+		if (b.bad_input.empty() && rb.io_error) b.bad_input = "error while reading the reads file (corrupt or truncated compressed input?)";
 		t_pack += tnow() - t2_;
 	}
-private:
-	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; size_t tag_off = 0, tag_len = 0; };
 	bool fasta_started_ = false;
 	bool fastq_started_ = false;     // a FASTQ record (or a line that should have been one) has been seen
 	BamStream bam_; bool bam_ok_ = false; std::string bam_err_, bam_rec_; int bam_mate_ = 0;     // -b state
 	std::string fc_line_, fc_prefix_, fc_win_;     // -F state
 	size_t fc_pos_ = 0, fc_eat_ = 0; uint64_t fc_cur_ = 0, fc_last_ = 0; bool fc_beginning_ = true;
-	std::string orig_, pending_raw_;   // --passthrough: the records' original text (Read::readOrigBuf)
+	std::string pending_raw_;   // --passthrough: the text of a FASTA header read ahead (Read::readOrigBuf)
 	LineSource src_;
 	const Options& opt_;
 	unsigned threads_;
-	std::string arena_, pending_;
+	std::string pending_;
 	bool have_pending_ = false;
 	size_t cmd_pos_ = 0;
 	std::string cmd_;            // -c: the comma-separated reads of this source (the -U, -1 or -2 argument)
-	std::vector<Raw> recs_;
 	uint64_t rdid_ = 0;
 	uint64_t unit_ = 1;          // records per read id: 2 for --interleaved mates (-s/-u and default names count pairs)
 };
