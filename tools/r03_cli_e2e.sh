@@ -8,7 +8,8 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$T; mkdir -p $O; cd $R; export TMPDIR=/tmp
 C=/tmp/bt2_amd_bench; B=$C/hg38like_3100mbp_s2_bt2l; FQ=/tmp/e2e_4m.fq
 cat $C/sample.fq $C/sample.fq $C/sample.fq $C/sample.fq > $FQ
 N=$(( $(wc -l < $FQ) / 4 ))
-for run in "-p 16 -S /tmp/e2e.sam" "-p 16 -S /dev/null" "-p 8 -S /dev/null"; do
+runs=("-p 16 -S /tmp/e2e.sam" "-p 16 -S /dev/null" "-p 16 --batch 1048576 -S /dev/null" "-p 16 --batch 2000000 -S /dev/null")
+for run in "${runs[@]}"; do
   s=$(date +%s.%N)
   timeout 200 bowtie2_amd/bin/bowtie2-align-l --sensitive -t -x $B -U $FQ $run 2> $O/e2e.err
   e=$(date +%s.%N)
