@@ -665,7 +665,7 @@ def main():
                                                "scalar_steps": prof[31] / max(1, prof[9])},
                 "worker_counts_per_read": {"bt_steps": prof[13] / max(1, prof[9]), "bt_tiles": prof[14] / max(1, prof[9]), "cand_cells": prof[15] / max(1, prof[9]),
                                            "sampled_rows": (prof[23] & 0xffffffff) / max(1, prof[9]), "sampled_rows_seen_list": (prof[23] >> 32) / max(1, prof[9])},
-                "kernel_ms_per_step": {k: round(v, 3) for k, v in kavg.items()}, "batch_ms_events": round(batch_ms, 3),
+                "kernel_ms_per_step": {("k_align_pairs" if args.paired and k == "k_align_reads" else k): round(v, 3) for k, v in kavg.items()}, "batch_ms_events": round(batch_ms, 3),
                 "fm_kernels_sides_per_read": cnt.rank_queries / float(n * args.steps),
                 "sides_per_read": prof[8] / max(1, prof[9]),
             },
