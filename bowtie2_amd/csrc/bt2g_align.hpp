@@ -404,6 +404,7 @@ struct AlState {
 	uint32_t  n_emit;                 // device, local mode: candidate cells the last fill wrote to Work::cands_tmp (unsorted; may exceed its capacity)
 	int32_t   emit_vmax;              //   ... and the largest score among them
 	uint32_t  emit_on;                // 1 in the workers (Aligner's constructor); 0 in the stage kernel, whose waves have no work area
+	uint32_t  fill_rows_done, fill_lastsol, fill_sat8;   // device: what a leaf fill hands back besides its return value (row the score-only pass stopped in; lastsolcol_ / "8-bit kernel saturated" of a local fill)
 };
 
 // ---------------------------------------------------------------------------------------

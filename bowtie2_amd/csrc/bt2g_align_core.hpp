@@ -1846,7 +1846,7 @@ struct Aligner {
 	// =================================================================================
 	// F. SwDriver::extendSeeds (aligner_sw_driver.cpp:921-1494)
 	// =================================================================================
-	BT2_HDN int extend_seeds(int seedmms_, int seedlen, int seedival) {
+	BT2_HDI int extend_seeds(int seedmms_, int seedlen, int seedival) {
 		(void)seedlen; (void)seedival;
 		const int seedmms = Plat::uni(seedmms_);
 		const uint32_t rdlen = HOT.len;
@@ -2126,67 +2126,73 @@ struct Aligner {
 			ST.rnd.init(RPR.seed);
 			const uint32_t interval = (uint32_t)RPR.interval;
 			uint32_t nrounds = (uint32_t)PRM.n_seed_rounds;
+			if (nrounds > interval) nrounds = interval;
 			uint32_t mine[2] = {0, 0};
 			uint64_t nelt = 0;
-			if (PRM.do_exact_upfront) {
-				{ const uint64_t t0_ = now(); nelt = (PRE && PRE->sweep) ? exact_sweep_pre(mine) : exact_sweep(2, mine); HOT.t_phase[0] += now() - t0_; }
-				if (nelt == 0) { HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0; }
-				else {
-					const int ret = Plat::uni(extend_seeds(-1, 0, 0));
-					HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
-					handle_ret(ret, done);
-					if (!done && ST.minsc == perfect) done = true;
-				}
-			}
-			if (PRM.do_1mm_upfront) {
-				if (!done) {
-					const bool yfw = mine[0] <= 1 && !ST.m_nofw;
-					const bool yrc = mine[1] <= 1 && !ST.m_norc;
+			// The three stages of the worker -- exact end-to-end hits, 1-mismatch end-to-end hits, the seeding rounds -- all end in
+			// extendSeeds.  They run as the iterations of ONE loop so that extend_seeds has a single call site and is inlined into the
+			// kernel: as a real function it saved and restored every callee-saved vector register in its prologue and epilogue and spilled
+			// what it kept across its own calls (a 900-byte frame per lane, ~60 KB of scratch traffic per call and direction).
+			const uint32_t n_stage = 2u + (uint32_t)PRM.n_seed_rounds;
+			for (uint32_t stage = 0; stage < n_stage; stage++) {
+				int ext_mms = -1;
+				if (stage == 0) {
+					if (!PRM.do_exact_upfront) continue;
+					{ const uint64_t t0_ = now(); nelt = (PRE && PRE->sweep) ? exact_sweep_pre(mine) : exact_sweep(2, mine); HOT.t_phase[0] += now() - t0_; }
+					if (nelt == 0) { HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0; continue; }
+				} else if (stage == 1) {
+					if (!PRM.do_1mm_upfront) continue;
 					nelt = 0;
-					if (yfw || yrc) {
-						const uint64_t t0_ = now();
-						if (!(PRE && PRE->mm1 && one_mm_pre(!yfw, !yrc))) one_mm_search(!yfw, !yrc);
-						nelt = HOT.mm1_elt; HOT.t_phase[1] += now() - t0_;
+					if (!done) {
+						const bool yfw = mine[0] <= 1 && !ST.m_nofw;
+						const bool yrc = mine[1] <= 1 && !ST.m_norc;
+						if (yfw || yrc) {
+							const uint64_t t0_ = now();
+							if (!(PRE && PRE->mm1 && one_mm_pre(!yfw, !yrc))) one_mm_search(!yfw, !yrc);
+							nelt = HOT.mm1_elt; HOT.t_phase[1] += now() - t0_;
+						}
 					}
-					if (nelt > 0) {
-						const int ret = Plat::uni(extend_seeds(-1, 0, 0));
-						HOT.n_mm1 = 0; HOT.mm1_elt = 0;
-						handle_ret(ret, done);
-						if (!done && ST.minsc == perfect) done = true;
-					}
+					if (nelt == 0) { HOT.n_mm1 = 0; HOT.mm1_elt = 0; continue; }
+				} else {
+					const uint32_t roundi = stage - 2u;
+					HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_elts = 0; HOT.num_offs = 0;
+					if (done || HOT.done_unpair1) { done = true; continue; }
+					if (roundi >= nrounds) continue;
+					if (interval <= roundi) continue;
+					const uint32_t offset = (interval * roundi) / nrounds;
+					if (offset > 0 && (uint32_t)RPR.seedlen + offset > len) continue;
+					const uint64_t ts_ = now();
+					ST.ext_pre = false;
+					cache_reset();          // ca.nextRead() (bt2_search.cpp:3882)
+					uint32_t ninst;
+					if (PRM.seed_mms > 0) ninst = Plat::uni(seed_round_mm1(offset, interval, (uint32_t)RPR.seedlen));
+					else if (offset == 0 && PRE && PRE->seeds && 1 + (len > (uint32_t)RPR.seedlen ? (len - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds) {
+						ninst = seed_round_pre(PRE->seeds, 0, interval, (uint32_t)RPR.seedlen);
+						ST.ext_pre = PRE->ext != nullptr; ST.pre_ext_cur = PRE->ext; ST.pre_joff_cur = PRE->joff;
+					} else if (roundi > 0 && roundi < kMaxPreRounds && PRE && PRE->seeds_r[roundi] && 1 + (len > offset + (uint32_t)RPR.seedlen ? (len - offset - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds &&
+					           PRE->seeds_r[roundi][(uint64_t)ST.ridx * 2 * PRE->max_seeds].topf != ~0ull) {
+						// a re-seeding round the batch kernels searched (they saw the same "previous round was repetitive" condition:
+						// a read only gets here when it held); a read with more seed positions than the tables hold searches them itself
+						ninst = seed_round_pre(PRE->seeds_r[roundi], offset, interval, (uint32_t)RPR.seedlen);
+						ST.ext_pre = PRE->ext_r[roundi] != nullptr; ST.pre_ext_cur = PRE->ext_r[roundi]; ST.pre_joff_cur = PRE->joff_r[roundi];
+					} else ninst = Plat::uni(seed_round(offset, interval, (uint32_t)RPR.seedlen));
+					HOT.t_phase[2] += now() - ts_;
+					if (ninst == 0) { done = true; HOT.nonz_tot = 0; continue; }
+					if (HOT.nonz_tot == 0) { done = true; continue; }
+					{ const uint64_t t0_ = now(); rank_seed_hits(); HOT.t_phase[3] += now() - t0_; }
+					ext_mms = PRM.seed_mms;
 				}
-				HOT.n_mm1 = 0; HOT.mm1_elt = 0;
-			}
-			if (nrounds > interval) nrounds = interval;
-			for (uint32_t roundi = 0; roundi < (uint32_t)PRM.n_seed_rounds; roundi++) {
-				HOT.nonz_tot = 0; HOT.n_rank = 0; HOT.num_elts = 0; HOT.num_offs = 0;
-				if (done || HOT.done_unpair1) { done = true; continue; }
-				if (roundi >= nrounds) continue;
-				if (interval <= roundi) continue;
-				const uint32_t offset = (interval * roundi) / nrounds;
-				if (offset > 0 && (uint32_t)RPR.seedlen + offset > len) continue;
-				const uint64_t ts_ = now();
-				ST.ext_pre = false;
-				cache_reset();          // ca.nextRead() (bt2_search.cpp:3882)
-				uint32_t ninst;
-				if (PRM.seed_mms > 0) ninst = Plat::uni(seed_round_mm1(offset, interval, (uint32_t)RPR.seedlen));
-				else if (offset == 0 && PRE && PRE->seeds && 1 + (len > (uint32_t)RPR.seedlen ? (len - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds) {
-					ninst = seed_round_pre(PRE->seeds, 0, interval, (uint32_t)RPR.seedlen);
-					ST.ext_pre = PRE->ext != nullptr; ST.pre_ext_cur = PRE->ext; ST.pre_joff_cur = PRE->joff;
-				} else if (roundi > 0 && roundi < kMaxPreRounds && PRE && PRE->seeds_r[roundi] && 1 + (len > offset + (uint32_t)RPR.seedlen ? (len - offset - (uint32_t)RPR.seedlen) / interval : 0u) <= PRE->max_seeds &&
-				           PRE->seeds_r[roundi][(uint64_t)ST.ridx * 2 * PRE->max_seeds].topf != ~0ull) {
-					// a re-seeding round the batch kernels searched (they saw the same "previous round was repetitive" condition:
-					// a read only gets here when it held); a read with more seed positions than the tables hold searches them itself
-					ninst = seed_round_pre(PRE->seeds_r[roundi], offset, interval, (uint32_t)RPR.seedlen);
-					ST.ext_pre = PRE->ext_r[roundi] != nullptr; ST.pre_ext_cur = PRE->ext_r[roundi]; ST.pre_joff_cur = PRE->joff_r[roundi];
-				} else ninst = Plat::uni(seed_round(offset, interval, (uint32_t)RPR.seedlen));
-				HOT.t_phase[2] += now() - ts_;
-				if (ninst == 0) { done = true; HOT.nonz_tot = 0; continue; }
-				if (HOT.nonz_tot == 0) { done = true; continue; }
-				{ const uint64_t t0_ = now(); rank_seed_hits(); HOT.t_phase[3] += now() - t0_; }
-				const int ret = Plat::uni(extend_seeds(PRM.seed_mms, RPR.seedlen, (int)interval));
+				const int ret = Plat::uni(extend_seeds(ext_mms, RPR.seedlen, (int)interval));
 				handle_ret(ret, done);
-				if (!done && HOT.nonz_tot > 0 && (HOT.num_elts / HOT.nonz_tot) < (uint64_t)PRM.seed_boost_thresh) done = true;
+				if (stage == 0) {
+					HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
+					if (!done && ST.minsc == perfect) done = true;
+				} else if (stage == 1) {
+					HOT.n_mm1 = 0; HOT.mm1_elt = 0;
+					if (!done && ST.minsc == perfect) done = true;
+				} else {
+					if (!done && HOT.nonz_tot > 0 && (HOT.num_elts / HOT.nonz_tot) < (uint64_t)PRM.seed_boost_thresh) done = true;
+				}
 			}
 		}
 		finish(out);

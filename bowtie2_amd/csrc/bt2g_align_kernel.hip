@@ -236,7 +236,7 @@ constexpr int kLo = -32768;
 __device__ __forceinline__ int subs16(int a, int b) { const int v = a - b; return v < kLo ? kLo : v; }
 
 template <int R>
-__device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, const Work& w, bool fw, uint32_t rows, uint32_t cols,
+__device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols,
                                                uint64_t* __restrict__ scratch) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t nlanes = (rows + R - 1) / R;
@@ -407,6 +407,53 @@ __device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, ui
 	sat8 = (uint32_t)__shfl(sat, src);
 	n_emit = nem;
 	return __shfl(vmax, src);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fills as LEAF functions, one real function per instantiation.  Why not one big dispatcher that inlines all of them: a function
+// that is really called saves every callee-saved vector register it touches ANYWHERE in its body (v40-47, v56-63, ... 48 of the first
+// 128) in its prologue and reloads them in its epilogue -- 256 bytes of scratch traffic per register and direction.  The dispatcher
+// with all sixteen band fills inlined used all 128 registers (the RP = 16 instantiation needs them), so each of the ~8 DP windows of
+// a read cost 2 x 25 KB of scratch traffic for nothing: round 3's PMC passes booked ~200 KB written per read to exactly this.  A leaf
+// is allocated caller-saved registers first and the common instantiations (RP <= 2, R <= 3) fit into those 80: no prologue stores.
+// Arguments of a real call arrive in vector registers and are lane-varying to the compiler: every leaf passes them through
+// v_readfirstlane once; the parameter block is read from its LDS object by name.  The row the score-only pass stopped in comes back
+// through g_st.fill_rows_done.
+template <int RP, bool PRED>
+__device__ __attribute__((noinline)) int fill_ee_u8_leaf(bool fw_, uint32_t rows_, uint32_t cols_, int lo_, int thr_, uint8_t* pm_) {
+	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
+	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
+	const int lo = __builtin_amdgcn_readfirstlane(lo_), thr = __builtin_amdgcn_readfirstlane(thr_);
+	const uint64_t pa = (uint64_t)reinterpret_cast<uintptr_t>(pm_);
+	uint8_t* pm = reinterpret_cast<uint8_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa));
+	uint32_t rows_done = rows;
+	const int best = fill_ee_u8_band<RP, PRED>(g_P, fw, rows, cols, lo, thr, pm, rows_done);
+	if (!PRED && (threadIdx.x & 63) == 0) g_st.fill_rows_done = rows_done;
+	return best;
+}
+template <int R>
+__device__ __attribute__((noinline)) int fill_ee_i16_leaf(bool fw_, uint32_t rows_, uint32_t cols_, uint64_t* m64_) {
+	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
+	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
+	const uint64_t pa = (uint64_t)reinterpret_cast<uintptr_t>(m64_);
+	uint64_t* m64 = reinterpret_cast<uint64_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa));
+	return fill_ee_i16_wave<R>(g_P, fw, rows, cols, m64);
+}
+// local fill: lastsolcol / sat8 / the number of emitted candidates come back through g_st (fill_lastsol, fill_sat8, n_emit)
+template <int R, bool EMIT>
+__device__ __attribute__((noinline)) int fill_local_leaf(bool fw_, uint32_t rows_, uint32_t cols_, uint64_t* m64_, int ms_, BT2_G BtCand* emit_, uint32_t ecap_) {
+	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
+	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
+	const int ms = __builtin_amdgcn_readfirstlane(ms_);
+	const uint32_t ecap = (uint32_t)__builtin_amdgcn_readfirstlane((int)ecap_);
+	const uint64_t pa = (uint64_t)reinterpret_cast<uintptr_t>(m64_);
+	uint64_t* m64 = reinterpret_cast<uint64_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa));
+	const uint64_t ea = (uint64_t)emit_;
+	BT2_G BtCand* emit = (BT2_G BtCand*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ea >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ea));
+	uint32_t lastsolcol = 0, sat8 = 0, nem = 0;
+	const int best = fill_local_wave<R, EMIT>(g_P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem);
+	if ((threadIdx.x & 63) == 0) { g_st.fill_lastsol = lastsolcol; g_st.fill_sat8 = sat8; g_st.n_emit = nem; g_st.emit_vmax = best; }
+	return best;
 }
 
 struct DevPlat {
@@ -876,42 +923,41 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)ref_base_at(ref, tidx, rfi + (int64_t)i, rec0);
 		wave_fence();
 	}
-	static __device__ __attribute__((noinline)) int64_t dp_fill_local(const AlignParams&, Work& w, bool fw_, uint32_t rows_, uint32_t cols_, uint32_t* mat_,
+	// (a thin dispatcher: the fills themselves are leaf functions, see fill_ee_u8_leaf)
+	static __device__ __attribute__((noinline)) int64_t dp_fill_local(const AlignParams&, Work&, bool fw_, uint32_t rows_, uint32_t cols_, uint32_t* mat_,
 	                                                                  int64_t minsc_, uint32_t& lastsolcol, uint32_t& sat8) {
-		wave_fence();
-		const AlignParams& P = g_P;
+	wave_fence();
 		const bool fw = uni((int)fw_) != 0;
 		const uint32_t rows = uni(rows_), cols = uni(cols_);
 		const int64_t minsc = uni(minsc_);
-		uint32_t* mat = uni_ptr(mat_);
-		uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
+		uint64_t* m64 = reinterpret_cast<uint64_t*>(uni_ptr(mat_));
 		const int ms = minsc > 0x7fff ? 0x7fff : (int)minsc;
 		int best;
-		uint32_t nem = 0;
 		// the worker's fills leave their candidate cells in Work::cands_tmp for gather_local; the stage kernel (k_dp_fill) has no arena
 		BT2_G BtCand* const emit = g_st.emit_on ? &DevPlat::work().cands_tmp[0] : (BT2_G BtCand*)nullptr;
 		const uint32_t ecap = (uint32_t)kMaxCands;
 		if (emit) switch (dp_R(rows)) {
-			case 1: best = fill_local_wave<1, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 2: best = fill_local_wave<2, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 3: best = fill_local_wave<3, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 4: best = fill_local_wave<4, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 5: best = fill_local_wave<5, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 6: best = fill_local_wave<6, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 7: best = fill_local_wave<7, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			default: best = fill_local_wave<8, true>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 1: best = fill_local_leaf<1, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 2: best = fill_local_leaf<2, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 3: best = fill_local_leaf<3, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 4: best = fill_local_leaf<4, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 5: best = fill_local_leaf<5, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 6: best = fill_local_leaf<6, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 7: best = fill_local_leaf<7, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			default: best = fill_local_leaf<8, true>(fw, rows, cols, m64, ms, emit, ecap); break;
 		} else switch (dp_R(rows)) {
-			case 1: best = fill_local_wave<1, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 2: best = fill_local_wave<2, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 3: best = fill_local_wave<3, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 4: best = fill_local_wave<4, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 5: best = fill_local_wave<5, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 6: best = fill_local_wave<6, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			case 7: best = fill_local_wave<7, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
-			default: best = fill_local_wave<8, false>(P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem); break;
+			case 1: best = fill_local_leaf<1, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 2: best = fill_local_leaf<2, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 3: best = fill_local_leaf<3, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 4: best = fill_local_leaf<4, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 5: best = fill_local_leaf<5, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 6: best = fill_local_leaf<6, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 7: best = fill_local_leaf<7, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			default: best = fill_local_leaf<8, false>(fw, rows, cols, m64, ms, emit, ecap); break;
 		}
-		if ((threadIdx.x & 63) == 0) { g_st.n_emit = nem; g_st.emit_vmax = best; }
+		best = uni(best);
 		wave_fence();
+		lastsolcol = uni(g_st.fill_lastsol); sat8 = uni(g_st.fill_sat8);
 		g_hot.n_dp_cells_full += rows * cols;
 		return (int64_t)best;
 	}
@@ -1011,8 +1057,8 @@ struct DevPlat {
 	// (Arguments of a real call arrive in vector registers and a load through a generic reference could be a per-lane scratch access: the
 	// compiler must treat both as lane-varying, and every loop bound or condition derived from them becomes exec-mask control flow and
 	// vector arithmetic.  So: the parameter block and the scratch descriptor are read from their LDS objects BY NAME, the scalar arguments
-	// go through v_readfirstlane once.)
-	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams&, Work& w, bool fw_, uint32_t rows_, uint32_t cols_, const DpScratch&, bool wide_, int64_t minsc_) {
+	// go through v_readfirstlane once.)  A thin dispatcher: the fills themselves are leaf functions (fill_ee_u8_leaf).
+	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams&, Work&, bool fw_, uint32_t rows_, uint32_t cols_, const DpScratch&, bool wide_, int64_t minsc_) {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
 		const AlignParams& P = g_P;
 		const DpScratch& dp = g_st.dp;
@@ -1029,47 +1075,49 @@ struct DevPlat {
 			if (rp == 0) return INT64_MIN;
 			const int lo = band.lo;
 			const int thr = (int)(minsc + 0xff);      // biased score an alignment must keep (>= 1: the 8-bit kernel is only used while minsc >= -254)
-			uint32_t rows_done = rows;
 			// pass 1: can any end-to-end alignment in this window reach the minimum score at all?
 			switch (rp) {
-				case 1: best = fill_ee_u8_band<1, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 2: best = fill_ee_u8_band<2, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 3: best = fill_ee_u8_band<3, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 4: best = fill_ee_u8_band<4, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 6: best = fill_ee_u8_band<6, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 8: best = fill_ee_u8_band<8, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 12: best = fill_ee_u8_band<12, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				default: best = fill_ee_u8_band<16, false>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 1: best = fill_ee_u8_leaf<1, false>(fw, rows, cols, lo, thr, pm); break;
+				case 2: best = fill_ee_u8_leaf<2, false>(fw, rows, cols, lo, thr, pm); break;
+				case 3: best = fill_ee_u8_leaf<3, false>(fw, rows, cols, lo, thr, pm); break;
+				case 4: best = fill_ee_u8_leaf<4, false>(fw, rows, cols, lo, thr, pm); break;
+				case 6: best = fill_ee_u8_leaf<6, false>(fw, rows, cols, lo, thr, pm); break;
+				case 8: best = fill_ee_u8_leaf<8, false>(fw, rows, cols, lo, thr, pm); break;
+				case 12: best = fill_ee_u8_leaf<12, false>(fw, rows, cols, lo, thr, pm); break;
+				default: best = fill_ee_u8_leaf<16, false>(fw, rows, cols, lo, thr, pm); break;
 			}
+			best = uni(best);
+			wave_fence();
+			const uint32_t rows_done = uni(g_st.fill_rows_done);
 			g_hot.n_dp_cells_score += rows_done * band.nd;
 			if ((int64_t)best - 0xff < minsc) { wave_fence(); return (int64_t)best - 0xff; }
 			g_hot.n_dp_cells_full += rows * band.nd; g_hot.n_dp_pass++;
 			// pass 2: the matrix of predecessor bits (same scores, so `best` is unchanged)
 			if ((threadIdx.x & 63) == 0) { dp.epoch[1] = (uint32_t)lo; dp.epoch[2] = 128u * rp; }
 			switch (rp) {
-				case 1: best = fill_ee_u8_band<1, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 2: best = fill_ee_u8_band<2, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 3: best = fill_ee_u8_band<3, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 4: best = fill_ee_u8_band<4, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 6: best = fill_ee_u8_band<6, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 8: best = fill_ee_u8_band<8, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				case 12: best = fill_ee_u8_band<12, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
-				default: best = fill_ee_u8_band<16, true>(P, fw, rows, cols, lo, thr, pm, rows_done); break;
+				case 1: best = fill_ee_u8_leaf<1, true>(fw, rows, cols, lo, thr, pm); break;
+				case 2: best = fill_ee_u8_leaf<2, true>(fw, rows, cols, lo, thr, pm); break;
+				case 3: best = fill_ee_u8_leaf<3, true>(fw, rows, cols, lo, thr, pm); break;
+				case 4: best = fill_ee_u8_leaf<4, true>(fw, rows, cols, lo, thr, pm); break;
+				case 6: best = fill_ee_u8_leaf<6, true>(fw, rows, cols, lo, thr, pm); break;
+				case 8: best = fill_ee_u8_leaf<8, true>(fw, rows, cols, lo, thr, pm); break;
+				case 12: best = fill_ee_u8_leaf<12, true>(fw, rows, cols, lo, thr, pm); break;
+				default: best = fill_ee_u8_leaf<16, true>(fw, rows, cols, lo, thr, pm); break;
 			}
-			best -= 0xff;
+			best = uni(best) - 0xff;
 		} else {
 			uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
 			switch (dp_R(rows)) {
-				case 1: best = fill_ee_i16_wave<1>(P, w, fw, rows, cols, m64); break;
-				case 2: best = fill_ee_i16_wave<2>(P, w, fw, rows, cols, m64); break;
-				case 3: best = fill_ee_i16_wave<3>(P, w, fw, rows, cols, m64); break;
-				case 4: best = fill_ee_i16_wave<4>(P, w, fw, rows, cols, m64); break;
-				case 5: best = fill_ee_i16_wave<5>(P, w, fw, rows, cols, m64); break;
-				case 6: best = fill_ee_i16_wave<6>(P, w, fw, rows, cols, m64); break;
-				case 7: best = fill_ee_i16_wave<7>(P, w, fw, rows, cols, m64); break;
-				default: best = fill_ee_i16_wave<8>(P, w, fw, rows, cols, m64); break;
+				case 1: best = fill_ee_i16_leaf<1>(fw, rows, cols, m64); break;
+				case 2: best = fill_ee_i16_leaf<2>(fw, rows, cols, m64); break;
+				case 3: best = fill_ee_i16_leaf<3>(fw, rows, cols, m64); break;
+				case 4: best = fill_ee_i16_leaf<4>(fw, rows, cols, m64); break;
+				case 5: best = fill_ee_i16_leaf<5>(fw, rows, cols, m64); break;
+				case 6: best = fill_ee_i16_leaf<6>(fw, rows, cols, m64); break;
+				case 7: best = fill_ee_i16_leaf<7>(fw, rows, cols, m64); break;
+				default: best = fill_ee_i16_leaf<8>(fw, rows, cols, m64); break;
 			}
-			best -= 0x7fff;
+			best = uni(best) - 0x7fff;
 			g_hot.n_dp_cells_full += rows * cols;
 		}
 		wave_fence();     // matrix written lane-parallel -> visible to the scalar backtrace
@@ -1094,8 +1142,11 @@ __device__ __forceinline__ bool read_params_ok(const ReadParams& rp) { return rp
 #ifndef BT2G_WAVES_PER_EU
 #define BT2G_WAVES_PER_EU 2
 #endif
+#ifndef BT2G_NUM_VGPR
+#define BT2G_NUM_VGPR 128      // architectural vector registers of the worker kernels (512 / 4 waves per SIMD)
+#endif
 template <typename TOff>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(128)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(BT2G_NUM_VGPR)))
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
@@ -1146,7 +1197,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 // Paired-end flavour: one wavefront per pair (reads 2p and 2p+1, result records 2p and 2p+1).  A separate kernel so
 // that the unpaired kernel's register allocation and code layout do not carry the pair logic.
 template <typename TOff>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(128)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(BT2G_NUM_VGPR)))
 k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
@@ -1218,7 +1269,7 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 // ---------------------------------------------------------------------------------------------------------------------
 // The fills as a stage (bt2g_dp_fill, include/bt2g.h): every problem goes through DevPlat::dp_fill_ee / dp_fill_local -- the
 // functions the worker calls -- on a wave's private scratch, and what they leave behind is copied to the problem's output block.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(128)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(BT2G_NUM_VGPR)))
 k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, const uint8_t* __restrict__ d_rd, const uint8_t* __restrict__ d_qu,
           const uint8_t* __restrict__ d_rf, uint8_t* __restrict__ d_out, uint8_t* __restrict__ scratch, uint64_t scratch_stride,
           uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes) {

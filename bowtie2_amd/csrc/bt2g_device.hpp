@@ -31,10 +31,12 @@
 #else
 #define BT2_HDN __host__ __device__ __attribute__((noinline))   // large phase functions: real calls keep register pressure local
 #endif
+#define BT2_HDI __host__ __device__ __forceinline__   // large functions with ONE call site in a kernel body: inlined, so that no prologue saves callee-saved registers
 #define BT2_D __device__ __forceinline__
 #else
 #define BT2_HD inline
 #define BT2_HDN
+#define BT2_HDI
 #define BT2_D inline
 #endif
 
