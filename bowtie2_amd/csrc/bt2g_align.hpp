@@ -135,20 +135,6 @@ struct SatPos {           // SATupleAndPos (aligner_sw_driver.h:144)
 // them per call but the extension loop consumes a few dozen, so only the consumed ones are expanded to a SatPos.
 struct SampRow { uint64_t topf; uint32_t src; uint32_t done; };
 
-// Random1toN of a sampled range, kept in LDS while prioritize() runs (same fields as R1N, narrower where the values allow)
-struct R1C { uint64_t topf; uint32_t n, cur, list_off, seen_off; uint16_t seen_len, thresh; uint8_t swaplist, converted, inited, pad; };      // topf: first row of the range being sampled
-constexpr int kFastSamp = 64;      // ranges the on-chip sampler state holds
-// Random1toN::init (random_util.h:97-110) of a range of n rows starting at row topf
-BT2_HD R1C r1c_make(uint64_t topf, uint32_t n, bool without_replacement) {
-	R1C r;
-	r.topf = topf; r.n = n; r.cur = 0; r.list_off = r.seen_off = 0; r.seen_len = 0;
-	uint32_t th = (uint32_t)(0.10f * (float)n);
-	th = th > 16 ? th : 16;
-	r.thresh = (uint16_t)(th > 0xffffu ? 0xffffu : th);      // only ever compared with seen_len <= max_iters
-	r.swaplist = (n < 128 || without_replacement) ? 1 : 0;
-	r.converted = 0; r.inited = 1; r.pad = 0;
-	return r;
-}
 // RowSampler::init's weight of a range (aligner_sw_driver.h:176-200, lensq = szsq = true)
 BT2_HD double samp_mass(uint32_t nlex, uint32_t nrex, uint32_t size) {
 	double num = (double)(nlex + nrex + 1); num *= num;
@@ -218,10 +204,9 @@ struct HotWork {
 	uint8_t  sorted[2][kMaxOffs];
 	uint8_t  rank_offs[kMaxRanges];
 	uint8_t  rank_fw[kMaxRanges];
-	union {                    // never live at the same time: the gather reads `lastrow` before any backtrace writes `ned`; RowSampler state only exists inside prioritize()
+	union {                    // never live at the same time: the gather reads `lastrow` before any backtrace writes `ned`
 		Edit     ned[kMaxEdits];   // edits of the backtrace in progress
 		int16_t  lastrow[kMaxCols + 8];   // scores of the last DP row, clamped at -32768 (gatherCells)
-		struct { double prefix[kFastSamp]; R1C r[kFastSamp]; uint8_t elim[kFastSamp]; } samp;   // RowSampler + Random1toN state of the ranges being sampled
 	};
 	// ---- scalar control state of the read in flight (everything the control code touches often) ----
 	uint32_t len;

@@ -767,47 +767,120 @@ struct Aligner {
 		return rn;
 	}
 
-	// Random1toN with its state in LDS (R1C): the same draws as r1n_next.  `r` is the caller's REGISTER copy of the range's record and
-	// `g` its copy of the RNG (the sampling loop keeps both, and its counters, out of LDS for the whole loop); the seen-list scan and
-	// the swap-list fill are done by all lanes at once.
-	// (Measured, round 3: mirroring the lists' recent contents in lane registers so that a draw waits for no memory at all made no
-	// difference to the loop's time -- it is bound by its own instruction stream, ~1.4 us per draw, not by the list loads.)
-	BT2_HD uint32_t r1c_next(R1C& r, Rng& g) {
-		BT2_G uint32_t* const lists = WK.lists;
-		uint32_t ret;
-		const bool first = r.cur == 0 && !r.converted;
-		if (first && r.n == 1) { r.cur = 1; ret = 0; }
-		else if (r.swaplist) {
-			if (first) { r.list_off = lists_alloc(r.n); Plat::iota_u32(lists + r.list_off, r.n); }
-			const uint32_t rr = r.cur + (g.nextU32() % (r.n - r.cur));
-			uint32_t* l = lists + r.list_off;
-			const uint32_t a = gld(l + r.cur), b = gld(l + rr);
-			if (rr != r.cur) { gst(l + r.cur, b); gst(l + rr, a); }
-			r.cur++;
-			ret = b;
-		} else {
-			const uint32_t cap = (uint32_t)PRM.max_iters + 2, room = (uint32_t)r.thresh + 1 < cap ? (uint32_t)r.thresh + 1 : cap;
-			if (r.seen_len == 0 && r.cur == 0) r.seen_off = lists_alloc(room);
-			uint32_t* seen = lists + r.seen_off;
-			const uint32_t seen_sz = r.seen_len;
-			uint32_t rn;
-			do { rn = g.nextU32() % r.n; } while (Plat::contains_u32(seen, seen_sz, rn));
-			ret = rn;
-			if (r.seen_len >= room) { ovf(29); r.cur++; }
-			else {
-				gst(seen + r.seen_len, rn); r.seen_len++;
-				r.cur++;
-				if (r.seen_len >= r.thresh && r.cur < r.n) {
-					// convert to a swap list of everything not yet seen, ascending (Random1toN::next, random_util.h:133-158).  Not
-					// rare on repeats: a 200-copy family hit by every seed of a read crosses thresh = 20 in each of its ranges.
-					const uint32_t nl = r.n - r.cur;
-					r.list_off = lists_alloc(nl);
-					Plat::unseen_list(seen, r.seen_len, r.n, lists + r.list_off);
-					r.seen_len = 0; r.cur = 0; r.n = nl; r.converted = 1; r.swaplist = 1;
+	// ---------------------------------------------------------------------------------------------------------------------
+	// RowSampler + Random1toN for up to 64 ranges WITHOUT MEMORY (prioritize's second phase; aligner_sw_driver.h:179-256,
+	// random_util.h:32-219).  The draws have to be replayed one by one -- each consumes the read's RNG, and which range a draw
+	// lands in depends on the draws before it -- but nothing about them needs a list in memory:
+	//  * per range (lane j = range j, one register each): weight, running sum of the weights still in play, rows, cursor,
+	//    seen count, conversion threshold, flags, first row;
+	//  * a swap list (Random1toN of a range of < 128 rows, or after conversion) starts as 0, 1, 2 ... and a draw changes ONE
+	//    entry that is ever read again (position rr receives the value of position cur; position cur is never looked at
+	//    after the cursor has passed it).  So the list is the identity plus a sparse set of overrides;
+	//  * a seen list (range of >= 128 rows) is a set of values, at most one more per draw;
+	//  * the list a seen list is converted to -- every unseen value, ascending -- is  i -> i + #{seen s : s - rank(s) <= i};
+	//    again no list, just the seen values with their ranks subtracted.
+	// All three are entries (kind, range, position/value; payload) of ONE table kept in the lanes of kSampTabRegs register
+	// pairs: a lookup is one compare + ballot per 64 entries, an insertion one v_writelane.  One entry per draw at most, so
+	// the table holds every run with maxelt <= 64 * kSampTabRegs - 2 (-k <= 6); others take the arena path below.
+	// (Round 3 kept running sums and Random1toN records in LDS and the lists in the arena: a draw cost ~1.4 us -- two
+	// dependent LDS round trips for the pick, one for the record, a global round trip for the list, three stores for the
+	// sampled row whose completion the next wait on the vector-memory counter also waits for.)
+	static constexpr int kSampTabRegs = 8;
+	static constexpr uint32_t kTabSwap = 1u << 30, kTabSeen = 2u << 30, kTabConv = 3u << 30, kTabNone = 0xffffffffu;
+	// (entry e of the table: the platform decides where it lives -- on the device the newest entries sit in register 0 and a full register
+	// is handed down the array, so that no register is ever selected by a run-time index: Plat::tab_lookup / tab_set / tab_append)
+	struct SampTab { typename Plat::template LaneRegs<kSampTabRegs> k, v; uint32_t n; };
+	// Draws rows until maxelt (or every element) has been drawn; appends them to the extension list (Work::srows).  Returns the
+	// number of rows drawn in all (nelt_added).
+	BT2_HDN uint64_t sample_rows_fast(uint32_t sai_, uint32_t n_masses_, uint64_t maxelt_, uint64_t nelt_, uint64_t nelt_added_) {
+		const uint32_t sai = Plat::uni(sai_), n_masses = Plat::uni(n_masses_);
+		const uint64_t maxelt = Plat::uni(maxelt_), nelt = Plat::uni(nelt_);
+		uint64_t nelt_added = Plat::uni(nelt_added_);
+		Rng g; g.last = Plat::uni(ST.rnd.last); g.lastOff = Plat::uni(ST.rnd.lastOff);      // (LDS loads arrive in vector registers: lane-varying to the compiler unless told otherwise)
+		uint32_t n_satpos = Plat::uni(HOT.n_satpos);
+		const uint32_t n_full = Plat::uni(HOT.n_satpos_full);
+		BT2_G SampRow* const srows = WK.srows;
+		const bool all_hits = PRM.all_hits != 0;
+		typename Plat::LaneReg mlo, mhi, plo, phi, rn, rcur, rseen, rthr, rfl, tlo, thi;      // lane j: range sai + j
+		typename Plat::LaneReg olo, ohi, osrc;                                                // rows drawn, 64 at a time on their way to Work::srows
+		SampTab tab;
+		tab.n = 0;
+		Plat::tab_zero(tab.k); Plat::tab_zero(tab.v);
+		Plat::lanes_zero(rcur); Plat::lanes_zero(rseen); Plat::lanes_zero(olo); Plat::lanes_zero(ohi); Plat::lanes_zero(osrc);
+		Plat::lanes_zero(plo); Plat::lanes_zero(phi);
+		Plat::samp_setup(&WK.satpos2[sai], n_masses, all_hits, mlo, mhi, rn, rthr, rfl, tlo, thi);
+		uint64_t live = n_masses >= 64u ? ~0ull : ((1ull << n_masses) - 1ull);
+		double mass = Plat::prefix_live(mlo, mhi, live, plo, phi);
+		uint32_t obase = n_satpos - n_full, ocnt = 0;
+		uint64_t draws = 0;
+		bool full = false;
+		while (nelt_added < maxelt && nelt_added < nelt) {
+			// RowSampler::next: first range still in play whose running sum exceeds rd, else the last one in play
+			const double rd = (double)(g.nextFloat() * mass);
+			const uint32_t pick = Plat::pick_prefix(plo, phi, live, rd);
+			uint32_t n = Plat::lane(rn, pick), cur = Plat::lane(rcur, pick), fl = Plat::lane(rfl, pick);      // fl: bit 0 swap list, bit 1 converted
+			const uint32_t rkey = pick << 24;
+			draws += (fl & 1u) ? 1ull : (1ull | (1ull << 32));      // profile: draws | draws on the seen-list path << 32
+			uint32_t ret;
+			// Random1toN::next
+			if (fl & 1u) {
+				if (cur == 0 && !(fl & 2u) && n == 1) { cur = 1; ret = 0; }
+				else {
+					const uint32_t rr = cur + (g.nextU32() % (n - cur));
+					uint32_t a, b;
+					if (!Plat::tab_lookup(tab.k, tab.v, tab.n, kTabSwap | rkey | cur, a))
+						a = (fl & 2u) ? cur + Plat::tab_count_le(tab.k, tab.v, tab.n, kTabConv | rkey, cur) : cur;
+					if (rr == cur) b = a;
+					else {
+						const bool have = Plat::tab_lookup(tab.k, tab.v, tab.n, kTabSwap | rkey | rr, b);
+						if (have) Plat::tab_set(tab.k, tab.v, tab.n, kTabSwap | rkey | rr, a);      // (position cur gets b, and is never read again)
+						else {
+							b = (fl & 2u) ? rr + Plat::tab_count_le(tab.k, tab.v, tab.n, kTabConv | rkey, rr) : rr;
+							Plat::tab_append(tab.k, tab.v, tab.n, kTabSwap | rkey | rr, a);
+						}
+					}
+					cur++;
+					ret = b;
 				}
+			} else {
+				uint32_t rnv;
+				uint32_t dummy_;
+				do { rnv = g.nextU32() % n; } while (Plat::tab_lookup(tab.k, tab.v, tab.n, kTabSeen | rkey | rnv, dummy_));
+				ret = rnv;
+				uint32_t seen = Plat::lane(rseen, pick);
+				Plat::tab_append(tab.k, tab.v, tab.n, kTabSeen | rkey | rnv, 0u);
+				seen++; cur++;
+				if (seen >= Plat::lane(rthr, pick) && cur < n) {
+					// convert to a swap list of everything not yet seen, ascending (random_util.h:133-158): the seen values stay in the
+					// table, each with its rank subtracted.  Not rare on repeats: a 200-copy family hit by every seed of a read crosses
+					// thresh = 20 in each of its ranges.
+					Plat::tab_convert(tab.k, tab.v, tab.n, pick);
+					n -= cur; cur = 0; seen = 0; fl = 3u;
+					Plat::set_lane(rn, pick, n); Plat::set_lane(rfl, pick, fl);
+				}
+				Plat::set_lane(rseen, pick, seen);
 			}
+			Plat::set_lane(rcur, pick, cur);
+			if (n > 0 && cur >= n) {      // the range is used up: out of the sampler
+				live &= ~(1ull << pick);
+				mass -= f64_of(Plat::lane(mlo, pick), Plat::lane(mhi, pick));
+				Plat::prefix_live(mlo, mhi, live, plo, phi);
+			}
+			if (n_satpos >= (uint32_t)kMaxSatpos) { full = true; break; }
+			{
+				const uint64_t topf = (((uint64_t)Plat::lane(thi, pick) << 32) | (uint64_t)Plat::lane(tlo, pick)) + (uint64_t)ret;
+				Plat::set_lane(olo, ocnt, (uint32_t)topf); Plat::set_lane(ohi, ocnt, (uint32_t)(topf >> 32)); Plat::set_lane(osrc, ocnt, pick + sai);
+				ocnt++; n_satpos++;
+				if (ocnt == 64u) { Plat::flush_samp_rows(srows + obase, olo, ohi, osrc, 64u); obase += 64u; ocnt = 0; }
+			}
+			nelt_added++;
+			if (tab.n + 2u > 64u * (uint32_t)kSampTabRegs) { full = true; break; }      // (cannot happen: the caller checked maxelt against the table)
 		}
-		return ret;
+		if (ocnt > 0) Plat::flush_samp_rows(srows + obase, olo, ohi, osrc, ocnt);
+		ST.rnd = g; HOT.mass = mass; HOT.n_satpos = n_satpos;
+		HOT.t_phase[21] += draws;
+		if (full) ovf(13);
+		return nelt_added;
 	}
 
 	// Entry i of the extension list for the consumer loops: whole records as they are, sampled rows expanded into WK.sp_view
@@ -954,6 +1027,7 @@ struct Aligner {
 		const uint32_t nsm = 5;
 		HOT.n_satpos = 0; HOT.n_satpos2 = 0; HOT.lists_used = 0;
 		uint64_t nrange = 0, nelt = 0, nsmall = 0, nsmall_elts = 0;
+		bool big_range = false;      // a range of 2^24 rows or more (only with an enlarged --seed-cache-sz): its positions do not fit the sampler's table keys
 		const uint64_t th_ = now();
 		for (uint32_t i = 0; i < HOT.n_rank; i++) {
 			const bool fw = HOT.rank_fw[i] != 0;
@@ -984,6 +1058,7 @@ struct Aligner {
 			s.topf = h_topf; s.topb = h_topb; s.size = (uint32_t)sz; s.orig_sz = (uint32_t)sz;
 			s.fw = fw ? 1 : 0; s.offidx = offidx; s.rdoff = rdoff; s.seedlen = seedlen; s.ee = -1;
 			if (sz <= nsm) { nsmall++; nsmall_elts += sz; }
+			if (sz >= (1ull << 24)) big_range = true;
 			uint32_t nlex = 0, nrex = 0;
 			if (PRM.do_extend) {
 				if (ST.ext_pre && seedmms == 0 && h.esize == h.size) {      // (a range the cache cut short is extended as the shorter range)
@@ -1051,45 +1126,11 @@ struct Aligner {
 		// 2. the non-smalls: RowSampler::init(satpos2_, nsmall, size, lensq=true, szsq=true)
 		const uint32_t sai = (uint32_t)nsmall, saf = HOT.n_satpos2;
 		HOT.n_masses = saf - sai;
-		// With at most kFastSamp candidates (always, for -N 0) the whole sampler lives on chip: the ranges' weights in a lane register
-		// pair, their running sums (formed by the same left-to-right additions as RowSampler::next's scan, so "first index whose
-		// running sum exceeds rd" is the same index, found by all lanes at once) and Random1toN records in LDS.
-		const bool fast = HOT.n_masses <= (uint32_t)kFastSamp;
+		// With at most 64 candidate ranges (always, for -N 0) the whole sampler runs out of registers (sample_rows_fast)
+		const bool fast = HOT.n_masses <= 64u && maxelt + 2u <= 64u * (uint64_t)kSampTabRegs && !big_range;
 		const uint64_t ts_ = now();
 		if (fast) {
-			// loop state in registers: RNG, total mass, list length, profile counts; written back once
-			Rng g = ST.rnd;
-			uint32_t n_satpos = HOT.n_satpos;
-			const uint32_t n_full = HOT.n_satpos_full, n_masses = HOT.n_masses;
-			BT2_G SampRow* const srows = WK.srows;
-			const bool all_hits = PRM.all_hits != 0;
-			typename Plat::LaneReg mlo, mhi;      // lane j: weight of range sai + j
-			Plat::samp_setup(&WK.satpos2[sai], n_masses, all_hits, HOT.samp.r, HOT.samp.elim, mlo, mhi);
-			double mass = Plat::mass_prefix(mlo, mhi, HOT.samp.elim, n_masses, HOT.samp.prefix);
-			uint64_t draws = 0;
-			bool full = false;
-			while (nelt_added < maxelt && nelt_added < nelt) {
-				// RowSampler::next
-				const double rd = (double)(g.nextFloat() * mass);
-				const uint32_t pick = Plat::pick_mass(HOT.samp.prefix, HOT.samp.elim, n_masses, rd);
-				const uint32_t ri = pick + sai;
-				R1C r2 = HOT.samp.r[pick];
-				draws += r2.swaplist ? 1ull : (1ull | (1ull << 32));      // profile: draws | draws on the seen-list path << 32
-				const uint32_t r = r1c_next(r2, g);
-				HOT.samp.r[pick] = r2;
-				if (r2.n > 0 && r2.cur >= r2.n) {      // the range is used up: out of the sampler
-					HOT.samp.elim[pick] = 1; mass -= f64_of(Plat::lane(mlo, pick), Plat::lane(mhi, pick));
-					Plat::mass_prefix(mlo, mhi, HOT.samp.elim, n_masses, HOT.samp.prefix);
-				}
-				if (n_satpos >= (uint32_t)kMaxSatpos) { full = true; break; }
-				BT2_G SampRow* const sr = &srows[n_satpos - n_full];
-				n_satpos++;
-				gst(&sr->topf, (uint64_t)(r2.topf + r)); gst(&sr->src, ri); gst(&sr->done, 0u);
-				nelt_added++;
-			}
-			ST.rnd = g; HOT.mass = mass; HOT.n_satpos = n_satpos;
-			HOT.t_phase[21] += draws;
-			if (full) ovf(13);
+			nelt_added = Plat::uni(sample_rows_fast(sai, HOT.n_masses, maxelt, nelt, nelt_added));
 		} else {
 		HOT.mass = 0.0;
 		for (uint32_t i = sai; i < saf; i++) {

@@ -24,6 +24,8 @@ __shared__ PreComp g_pre;
 __shared__ AlState g_st;     // the worker's own state (Aligner has no data members)
 alignas(16) __shared__ unsigned char g_ix_raw[sizeof(DevIndex<uint64_t>) > sizeof(DevIndex<uint32_t>) ? sizeof(DevIndex<uint64_t>) : sizeof(DevIndex<uint32_t>)];
 
+// Memory written by some lanes of the wave and read by others afterwards.  (One workgroup = one wavefront: the compiler knows the largest
+// workgroup is 64 threads and lowers the workgroup-scope fence to a wavefront-scope one -- no s_waitcnt, just a barrier for its own reordering.)
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -491,51 +493,120 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < (n + 3) / 4; i += 64) q[i] = z;
 		wave_fence();
 	}
-	// RowSampler::next over running sums kept in LDS: first candidate still in play whose running sum exceeds rd, else the last
-	// one in play (aligner_sw_driver.h:215-240)
-	static __device__ __forceinline__ uint32_t pick_mass(const double* prefix, const uint8_t* elim, uint32_t n, double rd) {
-		const uint32_t lane = threadIdx.x & 63;
-		uint32_t last = 0xffffffffu;
-		for (uint32_t base = 0; base < n; base += 64) {
-			const uint32_t i = base + lane;
-			const bool live = i < n && !elim[i];
-			const unsigned long long hit = __ballot(live && rd < prefix[i]);
-			if (hit) return base + (uint32_t)__builtin_ctzll(hit);
-			const unsigned long long lv = __ballot(live);
-			if (lv) last = base + 63u - (uint32_t)__builtin_clzll(lv);
-		}
-		return last;
-	}
-	// RowSampler::init + Random1toN::init of up to 64 ranges at once: lane j reads range j, keeps its weight (mlo/mhi: the double's
-	// halves) and writes its record and "still in play" flag to LDS -- one memory round trip for all ranges
-	static __device__ __forceinline__ void samp_setup(const BT2_G SatPos* sat, uint32_t n, bool all_hits, R1C*, uint8_t*, uint32_t& mlo, uint32_t& mhi) {
+	// ---- the register-only row sampler (Aligner::sample_rows_fast): lane j = range j, table entry e = lane e & 63 of register e >> 6 ----
+	// RowSampler::init + Random1toN::init of up to 64 ranges at once: lane j reads range j -- one memory round trip for all ranges
+	static __device__ __forceinline__ void samp_setup(const BT2_G SatPos* sat, uint32_t n, bool all_hits, uint32_t& mlo, uint32_t& mhi, uint32_t& rn, uint32_t& rthr, uint32_t& rfl,
+	                                                  uint32_t& tlo, uint32_t& thi) {
 		wave_fence();
 		const uint32_t l = threadIdx.x & 63;
 		double m = 0.0;
+		rn = rthr = rfl = tlo = thi = 0;
 		if (l < n) {
 			const BT2_G SatPos* s = sat + l;
 			const uint32_t size = gld(&s->size);
+			const uint64_t topf = gld(&s->topf);
 			m = samp_mass(gld(&s->nlex), gld(&s->nrex), size);
-			g_hot.samp.r[l] = r1c_make(gld(&s->topf), size, all_hits);
-			g_hot.samp.elim[l] = 0;
+			uint32_t th = (uint32_t)(0.10f * (float)size); th = th > 16 ? th : 16;      // Random1toN::init (random_util.h:97-110)
+			rn = size; rthr = th; rfl = (size < 128 || all_hits) ? 1u : 0u;
+			tlo = (uint32_t)topf; thi = (uint32_t)(topf >> 32);
 		}
 		const uint64_t u = (uint64_t)__double_as_longlong(m);
 		mlo = (uint32_t)u; mhi = (uint32_t)(u >> 32);
-		wave_fence();
 	}
-	// running sums of the weights still in play, added left to right as RowSampler::next's scan adds them; returns the total
-	static __device__ __forceinline__ double mass_prefix(uint32_t mlo, uint32_t mhi, const uint8_t*, uint32_t n, double*) {
-		wave_fence();
+	// running sums of the weights still in play, added left to right as RowSampler::next's scan adds them (so that "first range whose
+	// running sum exceeds rd" is the same range); returns the total
+	static __device__ __forceinline__ double prefix_live(uint32_t mlo, uint32_t mhi, uint64_t live, uint32_t& plo, uint32_t& phi) {
 		const uint32_t l = threadIdx.x & 63;
-		const unsigned long long live = __ballot(l < n && !g_hot.samp.elim[l]);
-		double acc = 0.0, mine = 0.0;
-		for (uint32_t i = 0; i < n; i++) {
-			if ((live >> i) & 1ull) acc += f64_of((uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)i), (uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)i));
-			if (l == i) mine = acc;
+		double acc = 0.0;
+		uint64_t m = live;
+		while (m) {
+			const uint32_t i = (uint32_t)__builtin_ctzll(m);
+			m &= m - 1;
+			acc += f64_of((uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)i), (uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)i));
+			if (l == i) { const uint64_t u = (uint64_t)__double_as_longlong(acc); plo = (uint32_t)u; phi = (uint32_t)(u >> 32); }
 		}
-		if (l < n) g_hot.samp.prefix[l] = mine;
-		wave_fence();
 		return acc;
+	}
+	static __device__ __forceinline__ uint32_t pick_prefix(uint32_t plo, uint32_t phi, uint64_t live, double rd) {
+		const unsigned long long hit = __ballot(rd < f64_of(plo, phi)) & live;
+		if (hit) return (uint32_t)__builtin_ctzll(hit);
+		return live ? 63u - (uint32_t)__builtin_clzll(live) : 0xffffffffu;
+	}
+	// The table: K registers as ONE vector value per array (ext_vector_type: an SSA value, never memory -- a plain array of registers ends
+	// up in scratch as soon as the optimiser merges two accesses into one with a run-time index, which it does).  Entry e sits in lane
+	// e & 63 of element e >> 6; unused lanes hold key 0, which no entry has.
+	template <int K> using LaneRegs = uint32_t __attribute__((ext_vector_type(K)));
+	template <typename V> static __device__ __forceinline__ void tab_zero(V& t) { t = (V)(0u); }
+	template <typename V> static __device__ __forceinline__ bool tab_lookup(const V& k, const V& v, uint32_t n, uint32_t key, uint32_t& val) {
+		constexpr int K = sizeof(V) / 4;
+#pragma unroll
+		for (int r = 0; r < K; r++) {
+			if ((uint32_t)r * 64u >= n) break;
+			const unsigned long long m = __ballot(k[r] == key);
+			if (m) { val = (uint32_t)__builtin_amdgcn_readlane((int)v[r], (int)__builtin_ctzll(m)); return true; }
+		}
+		return false;
+	}
+	template <typename V> static __device__ __forceinline__ void tab_set(const V& k, V& v, uint32_t n, uint32_t key, uint32_t val) {
+		constexpr int K = sizeof(V) / 4;
+#pragma unroll
+		for (int r = 0; r < K; r++) {
+			if ((uint32_t)r * 64u >= n) break;
+			const unsigned long long m = __ballot(k[r] == key);
+			if (m) { uint32_t t = v[r]; set_lane(t, (uint32_t)__builtin_ctzll(m), val); v[r] = t; return; }
+		}
+	}
+	template <typename V> static __device__ __forceinline__ void tab_append(V& k, V& v, uint32_t& n, uint32_t key, uint32_t val) {
+		constexpr int K = sizeof(V) / 4;
+		const uint32_t hi = n >> 6, lo = n & 63u;
+#pragma unroll
+		for (int r = 0; r < K; r++) {
+			if ((uint32_t)r == hi) { uint32_t tk = k[r], tv = v[r]; set_lane(tk, lo, key); set_lane(tv, lo, val); k[r] = tk; v[r] = tv; }
+		}
+		n++;
+	}
+	// entries of kind | range `keyhi` whose payload is <= x
+	template <typename V> static __device__ __forceinline__ uint32_t tab_count_le(const V& k, const V& v, uint32_t n, uint32_t keyhi, uint32_t x) {
+		constexpr int K = sizeof(V) / 4;
+		uint32_t c = 0;
+#pragma unroll
+		for (int r = 0; r < K; r++) {
+			if ((uint32_t)r * 64u >= n) break;
+			c += (uint32_t)__popcll(__ballot((k[r] & 0xff000000u) == keyhi && v[r] <= x));
+		}
+		return c;
+	}
+	// the seen values of `range` (kind 2 entries) become kind 3 entries carrying value - rank: every lane counts, for each of its own
+	// entries of the range, the range's values below it while those are broadcast one by one
+	template <typename V> static __device__ __forceinline__ void tab_convert(V& k, V& v, uint32_t n, uint32_t range) {
+		constexpr int K = sizeof(V) / 4;
+		const uint32_t seenhi = (2u << 30) | (range << 24), convhi = (3u << 30) | (range << 24);
+		V cnt = (V)(0u);
+#pragma unroll
+		for (int r2 = 0; r2 < K; r2++) {
+			if ((uint32_t)r2 * 64u >= n) break;
+			unsigned long long m = __ballot((k[r2] & 0xff000000u) == seenhi);
+			while (m) {
+				const uint32_t i = (uint32_t)__builtin_ctzll(m);
+				m &= m - 1;
+				const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)k[r2], (int)i) & 0xffffffu;
+#pragma unroll
+				for (int r = 0; r < K; r++) {
+					if ((uint32_t)r * 64u >= n) break;
+					cnt[r] += ((k[r] & 0xff000000u) == seenhi && (k[r] & 0xffffffu) > sv) ? 1u : 0u;
+				}
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < K; r++) {
+			if ((uint32_t)r * 64u >= n) break;
+			if ((k[r] & 0xff000000u) == seenhi) { v[r] = (k[r] & 0xffffffu) - cnt[r]; k[r] = convhi | (k[r] & 0xffffffu); }
+		}
+	}
+	// rows drawn by the sampler -> Work::srows, one 16-byte record per lane
+	static __device__ __forceinline__ void flush_samp_rows(BT2_G SampRow* dst, uint32_t lo, uint32_t hi, uint32_t src, uint32_t cnt) {
+		const uint32_t l = threadIdx.x & 63;
+		if (l < cnt) { SampRow r; r.topf = ((uint64_t)hi << 32) | lo; r.src = src; r.done = 0; gst(dst + l, r); }
 	}
 	// Ebwt::getOffset for up to 64 rows at once, one LF walk per lane (joff_pack: offset + steps taken)
 	template <typename TOff>

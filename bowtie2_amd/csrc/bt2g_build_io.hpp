@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <string>
 #include <unistd.h>
 #include <vector>
@@ -107,7 +108,18 @@ bool build_index_files(const RefInput& in, const std::string& out_base, const Pa
 		bool committed = false;
 		std::string tmp(const std::string& final_name) { files.emplace_back(final_name + ".tmp" + std::to_string((long)getpid()), final_name); return files.back().first; }
 		bool commit(std::string& err) {
-			for (auto& f : files) if (rename(f.first.c_str(), f.second.c_str()) != 0) { err = "Could not move index file into place: \"" + f.second + "\""; return false; }
+			// the .1 files are what the aligner probes for: they are moved last, and a rename that fails takes back the ones already moved
+			std::stable_sort(files.begin(), files.end(), [](const std::pair<std::string, std::string>& a, const std::pair<std::string, std::string>& b) {
+				auto is1 = [](const std::string& n) { return n.find(".1.bt2") != std::string::npos; };
+				return !is1(a.second) && is1(b.second);
+			});
+			for (size_t i = 0; i < files.size(); i++) {
+				if (rename(files[i].first.c_str(), files[i].second.c_str()) != 0) {
+					err = "Could not move index file into place: \"" + files[i].second + "\"";
+					for (size_t k = 0; k < i; k++) (void)remove(files[k].second.c_str());
+					return false;
+				}
+			}
 			committed = true;
 			return true;
 		}

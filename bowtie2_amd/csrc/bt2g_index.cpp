@@ -49,6 +49,9 @@ int load_ebwt(const std::string& p1, const std::string& p2, int off_size, bool f
 	if (e.line_rate < 5 || e.line_rate > 12 || e.ftab_chars < 1 || e.ftab_chars > 15 || e.off_rate < 0 || e.off_rate > 30) {
 		err = p1 + ": implausible header"; return BT2G_ERR_FORMAT;
 	}
+	// The resident suffix array keeps, per row, the LF steps the reference's getOffset would have walked in 16 bits (joff_pack,
+	// bt2g_device.hpp): a sampling rate of 2^16 rows or more could overflow that field and the row's offset would be lost silently.
+	if (e.off_rate > 15) { err = p1 + ": --offrate above 15 is not supported by this build (suffix-array sample too sparse)"; return BT2G_ERR_UNSUPPORTED; }
 	// Colorspace indexes (flags & 2) and pre-2.0 "each stretch reversed" mirrors are not supported.
 	if (e.flags < 0 && ((-e.flags) & 2)) { err = p1 + ": colorspace index"; return BT2G_ERR_UNSUPPORTED; }
 	if (!fw && !(e.flags < 0 && ((-e.flags) & 4))) { err = p1 + ": mirror index is not an entire-reverse index (built by bowtie2 < 2.0?)"; return BT2G_ERR_UNSUPPORTED; }

@@ -318,6 +318,9 @@ public:
 		return true;
 	}
 	uint64_t bytes_read() const { return src_.bytes_read(); }
+	// a split() of the next batch may still be running on the helper thread: it reads src_ and the other members, so it must have ended
+	// before any of them is destroyed (prefetch_ is declared before them and would otherwise be waited for last)
+	~FastqBatcher() { if (prefetch_.valid()) prefetch_.wait(); }
 	// -b with -1/-2: which mate's records this source keeps (--align-paired-reads: flag 0x40 for mate 1, 0x80 for mate 2, pat.cpp:1422-1427)
 	void set_bam_mate(int m) { bam_mate_ = m; }
 	std::string open_error(const std::string& dflt) const { return bam_err_.empty() ? dflt : bam_err_; }

@@ -282,6 +282,7 @@ def append_file(dst, path):
             while off < size:
                 off += os.sendfile(dst.fileno(), src.fileno(), off, min(1 << 30, size - off))
         except (OSError, AttributeError, ValueError):
+            src.seek(off)      # a partial sendfile has already delivered bytes [0, off)
             shutil.copyfileobj(src, dst, 1 << 24)
 
 
@@ -333,6 +334,7 @@ def main(argv=None):
         tmp = box[0]
     piece, idx, done = (os.path.join(tmp, "piece%d.%s" % (rank, s)) for s in ("sam", "idx", "done"))
     rc = 1
+    merge_failed = 0
     try:
         common = [engine] + args + ["--shard-index", idx, "--pg-cmdline", pg]
         if backend == "nccl":
@@ -345,26 +347,49 @@ def main(argv=None):
             direct = rank == 0 and out_path is not None
             target = out_path if direct else piece
             cmd = common + ["--shard-bytes", ",".join("%d:%d" % ab for ab in ranges), "--shard-first-read", str(first), "-S", target]
-            code, _, err = run_engine(cmd)
-            sys.stderr.write(err)
-            _, S, P, flagged, parsed = parse_index(idx) if os.path.exists(idx) else ([], [0] * 4, [0] * 10, 0, 0)
-            ok = os.path.exists(idx) and (code == 0 or (code == 1 and flagged > 0))
-            open(done, "w").write("1" if ok else "0")
+            ok, S, P, flagged, parsed = False, [0] * 4, [0] * 10, 0, 0
+            try:
+                code, _, err = run_engine(cmd)
+                sys.stderr.write(err)
+                if os.path.exists(idx):
+                    _, S, P, flagged, parsed = parse_index(idx)
+                    ok = code == 0 or (code == 1 and flagged > 0)
+            finally:
+                # the done-file appears complete or not at all (rank 0 polls for it), whatever happened above
+                with open(done + ".tmp", "w") as df:
+                    df.write("1" if ok else "0")
+                os.replace(done + ".tmp", done)
             all_ok = ok
             if rank == 0:
-                f = open(out_path, "ab") if out_path else sys.stdout.buffer
-                if not direct and ok:
-                    append_file(f, piece)
-                for r in range(1, world):
-                    other = os.path.join(tmp, "piece%d." % r)
-                    while not os.path.exists(other + "done"):       # rank r is still aligning; its piece is appended as soon as it ends
-                        time.sleep(0.05)
-                    if open(other + "done").read() != "1":
-                        all_ok = False
-                    if all_ok:
-                        append_file(f, other + "sam")
-                if out_path:
-                    f.close()
+                f = None
+                try:
+                    f = open(out_path, "ab") if out_path else sys.stdout.buffer
+                    if not direct and ok:
+                        append_file(f, piece)
+                    deadline = time.time() + float(os.environ.get("BT2G_MGPU_WAIT_S", "14400"))
+                    for r in range(1, world):
+                        other = os.path.join(tmp, "piece%d." % r)
+                        state = ""
+                        while state not in ("0", "1"):      # rank r is still aligning; its piece is appended as soon as it ends
+                            if os.path.exists(other + "done"):
+                                state = open(other + "done").read()
+                            if state not in ("0", "1"):
+                                if time.time() > deadline:
+                                    sys.stderr.write("Error: rank %d did not finish its shard within BT2G_MGPU_WAIT_S\n" % r)
+                                    state = "0"
+                                else:
+                                    time.sleep(0.05)
+                        if state != "1":
+                            all_ok = False
+                        if all_ok:
+                            append_file(f, other + "sam")
+                except OSError as e:
+                    sys.stderr.write("Error: merging the shards failed: %s\n" % e)
+                    all_ok = False
+                finally:
+                    if out_path and f is not None:
+                        f.close()
+            merge_failed = shard.reduce_sum(dist, [0 if all_ok else 1], device)[0]      # a failed merge on rank 0 fails every rank
             counters = shard.reduce_sum(dist, S + P + [flagged, 0 if ok else 1, parsed], device)
             if os.environ.get("BT2G_MGPU_REPORT_BYTES") and rank == 0:       # test aid: how many bytes of reads files each rank took in
                 sys.stderr.write("[mgpu] sharding=bytes parsed_bytes_this_rank=%d parsed_bytes_all=%d input_bytes=%d\n"
@@ -405,7 +430,7 @@ def main(argv=None):
                     f.write(bytes(pieces[r][pos:pos + nb]))
                 if out_path:
                     f.close()
-        rc = 1 if counters[15] else 0
+        rc = 1 if (counters[15] or merge_failed) else 0
         if rank == 0 and rc == 0:
             if not quiet:
                 print_summary(counters[0:4], counters[4:14], counters[4] > 0, discord, mixed)

@@ -63,11 +63,6 @@ struct HostPlat {
 	}
 	static void iota_u32(uint32_t* p, uint32_t n) { for (uint32_t i = 0; i < n; i++) p[i] = i; }
 	static void copy_words(void* dst, const void* src, uint32_t nwords) { memcpy(dst, src, (size_t)nwords * 4); }
-	static uint32_t pick_mass(const double* prefix, const uint8_t* elim, uint32_t n, double rd) {
-		uint32_t last = 0xffffffffu;
-		for (uint32_t i = 0; i < n; i++) if (!elim[i]) { last = i; if (rd < prefix[i]) return i; }
-		return last;
-	}
 	static void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols, bool wide) {
 		for (uint32_t j = 0; j < cols; j++) {
 			int sc;
@@ -106,18 +101,62 @@ struct HostPlat {
 		}
 		return r;
 	}
-	static void samp_setup(const SatPos* sat, uint32_t n, bool all_hits, R1C* r, uint8_t* elim, LaneReg& mlo, LaneReg& mhi) {
+	// ---- the register-only row sampler (Aligner::sample_rows_fast): plain-loop forms of the lane-parallel primitives ----
+	static void samp_setup(const SatPos* sat, uint32_t n, bool all_hits, LaneReg& mlo, LaneReg& mhi, LaneReg& rn, LaneReg& rthr, LaneReg& rfl, LaneReg& tlo, LaneReg& thi) {
 		for (uint32_t l = 0; l < 64; l++) {
 			double m = 0.0;
-			if (l < n) { m = samp_mass(sat[l].nlex, sat[l].nrex, sat[l].size); r[l] = r1c_make(sat[l].topf, sat[l].size, all_hits); elim[l] = 0; }
+			rn.v[l] = rthr.v[l] = rfl.v[l] = tlo.v[l] = thi.v[l] = 0;
+			if (l < n) {
+				m = samp_mass(sat[l].nlex, sat[l].nrex, sat[l].size);
+				const uint32_t sz = sat[l].size;
+				uint32_t th = (uint32_t)(0.10f * (float)sz); th = th > 16 ? th : 16;      // Random1toN::init (random_util.h:97-110)
+				rn.v[l] = sz; rthr.v[l] = th; rfl.v[l] = (sz < 128 || all_hits) ? 1u : 0u;
+				tlo.v[l] = (uint32_t)sat[l].topf; thi.v[l] = (uint32_t)(sat[l].topf >> 32);
+			}
 			uint64_t u; memcpy(&u, &m, 8);
 			mlo.v[l] = (uint32_t)u; mhi.v[l] = (uint32_t)(u >> 32);
 		}
 	}
-	static double mass_prefix(const LaneReg& mlo, const LaneReg& mhi, const uint8_t* elim, uint32_t n, double* prefix) {
+	static double prefix_live(const LaneReg& mlo, const LaneReg& mhi, uint64_t live, LaneReg& plo, LaneReg& phi) {
 		double acc = 0.0;
-		for (uint32_t i = 0; i < n; i++) { if (!elim[i]) acc += f64_of(mlo.v[i], mhi.v[i]); prefix[i] = acc; }
+		for (uint32_t i = 0; i < 64; i++) if ((live >> i) & 1ull) { acc += f64_of(mlo.v[i], mhi.v[i]); uint64_t u; memcpy(&u, &acc, 8); plo.v[i] = (uint32_t)u; phi.v[i] = (uint32_t)(u >> 32); }
 		return acc;
+	}
+	static uint32_t pick_prefix(const LaneReg& plo, const LaneReg& phi, uint64_t live, double rd) {
+		uint32_t last = 0xffffffffu;
+		for (uint32_t i = 0; i < 64; i++) if ((live >> i) & 1ull) { last = i; if (rd < f64_of(plo.v[i], phi.v[i])) return i; }
+		return last;
+	}
+	// (the host keeps entry e in lane e & 63 of register e >> 6)
+	template <int K> struct LaneRegs { LaneReg r[K]; LaneReg& operator[](uint32_t i) { return r[i]; } const LaneReg& operator[](uint32_t i) const { return r[i]; } };
+	template <int K> static void tab_zero(LaneRegs<K>& t) { memset(&t, 0, sizeof(t)); }
+	template <typename T> static bool tab_lookup(const T& k, const T& v, uint32_t n, uint32_t key, uint32_t& val) {
+		for (uint32_t i = 0; i < n; i++) if (k[i >> 6].v[i & 63] == key) { val = v[i >> 6].v[i & 63]; return true; }
+		return false;
+	}
+	template <typename T> static void tab_set(const T& k, T& v, uint32_t n, uint32_t key, uint32_t val) {
+		for (uint32_t i = 0; i < n; i++) if (k[i >> 6].v[i & 63] == key) { v[i >> 6].v[i & 63] = val; return; }
+	}
+	template <typename T> static void tab_append(T& k, T& v, uint32_t& n, uint32_t key, uint32_t val) { k[n >> 6].v[n & 63] = key; v[n >> 6].v[n & 63] = val; n++; }
+	template <typename T> static uint32_t tab_count_le(const T& k, const T& v, uint32_t n, uint32_t keyhi, uint32_t x) {
+		uint32_t c = 0;
+		for (uint32_t i = 0; i < n; i++) if ((k[i >> 6].v[i & 63] & 0xff000000u) == keyhi && v[i >> 6].v[i & 63] <= x) c++;
+		return c;
+	}
+	// the seen values of `range` (kind 2 entries) become kind 3 entries carrying value - rank
+	template <typename T> static void tab_convert(T& k, T& v, uint32_t n, uint32_t range) {
+		const uint32_t seenhi = (2u << 30) | (range << 24), convhi = (3u << 30) | (range << 24);
+		for (uint32_t i = 0; i < n; i++) {
+			const uint32_t ki = k[i >> 6].v[i & 63];
+			if ((ki & 0xff000000u) != seenhi) continue;
+			uint32_t rank = 0;
+			for (uint32_t j = 0; j < n; j++) { const uint32_t kj = k[j >> 6].v[j & 63]; if ((kj & 0xff000000u) == seenhi && (kj & 0xffffffu) < (ki & 0xffffffu)) rank++; }
+			v[i >> 6].v[i & 63] = (ki & 0xffffffu) - rank;
+		}
+		for (uint32_t i = 0; i < n; i++) { uint32_t& ki = k[i >> 6].v[i & 63]; if ((ki & 0xff000000u) == seenhi) ki = convhi | (ki & 0xffffffu); }
+	}
+	static void flush_samp_rows(SampRow* dst, const LaneReg& lo, const LaneReg& hi, const LaneReg& src, uint32_t cnt) {
+		for (uint32_t l = 0; l < cnt; l++) { dst[l].topf = ((uint64_t)hi.v[l] << 32) | lo.v[l]; dst[l].src = src.v[l]; dst[l].done = 0; }
 	}
 	static LaneReg lanes_load_u32(const uint32_t* p, uint32_t base, uint32_t n) {
 		LaneReg r;
