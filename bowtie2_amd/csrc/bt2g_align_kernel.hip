@@ -1146,8 +1146,27 @@ struct DevPlat {
 			if (rp == 0) return INT64_MIN;
 			const int lo = band.lo;
 			const int thr = (int)(minsc + 0xff);      // biased score an alignment must keep (>= 1: the 8-bit kernel is only used while minsc >= -254)
-			// pass 1: can any end-to-end alignment in this window reach the minimum score at all?
-			switch (rp) {
+			// pass 1: can any end-to-end alignment in this window reach the minimum score at all?  A lower bound on the best score costs
+			// almost nothing: the gap-free alignment along the window's middle diagonal (the seed's own diagonal unless the window was
+			// trimmed at a reference end) is one of the alignments the fill maximises over -- it lies inside the band, and while its score
+			// stays >= minsc >= -254 nothing on it saturates.  When it already reaches minsc (a read without an indel at its true locus, or
+			// at a close copy: most windows that succeed at all) the score-only pass has nothing left to decide and is skipped.
+			bool skip1 = false;
+			if (cols >= rows) {
+				const uint32_t dd = (cols - rows) >> 1;
+				int pen = 0;
+				for (uint32_t i = threadIdx.x & 63; i < rows; i += 64) {
+					const int c = rd_char(g_hot, g_hot.len, fw, i);
+					const int rfm = g_hot.rf[i + dd];
+					if (c > 3 || rfm > 15) pen += P.n_pen;
+					else if (!((rfm >> c) & 1)) { const int q = rd_qual(g_hot, g_hot.len, fw, i) - 33; pen += mm_penalty(P, q < 0 ? 0 : q); }
+				}
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) pen += __shfl_xor(pen, o);
+				skip1 = (int64_t)(-uni(pen)) >= minsc;
+			}
+			if (skip1) best = thr;      // (any value that passes the test below: the matrix pass computes the real one)
+			else switch (rp) {
 				case 1: best = fill_ee_u8_leaf<1, false>(fw, rows, cols, lo, thr, pm); break;
 				case 2: best = fill_ee_u8_leaf<2, false>(fw, rows, cols, lo, thr, pm); break;
 				case 3: best = fill_ee_u8_leaf<3, false>(fw, rows, cols, lo, thr, pm); break;
@@ -1159,7 +1178,7 @@ struct DevPlat {
 			}
 			best = uni(best);
 			wave_fence();
-			const uint32_t rows_done = uni(g_st.fill_rows_done);
+			const uint32_t rows_done = skip1 ? 0u : uni(g_st.fill_rows_done);
 			g_hot.n_dp_cells_score += rows_done * band.nd;
 			if ((int64_t)best - 0xff < minsc) { wave_fence(); return (int64_t)best - 0xff; }
 			g_hot.n_dp_cells_full += rows * band.nd; g_hot.n_dp_pass++;
