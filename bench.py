@@ -156,6 +156,30 @@ def synth_genome_gpu(mbp, seed, device):
     return G, [per] * N_CHROMS
 
 
+def synth_genome_bacterial(seed, device):
+    """E. coli K-12-like stand-in (the real sequence is not available offline): one 4.64 Mbp chromosome of random sequence with what a
+    bacterial genome has by way of repeats -- seven copies of a 5 kbp rRNA-operon-like element (0.1-1 % divergence) and forty copies of
+    three IS-like elements of 0.8-1.4 kbp (0-2 %); no N."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = 4_640_000
+    G = torch.randint(0, 4, (n,), generator=g, device=device, dtype=torch.uint8)
+
+    def plant(L, copies, div_hi):
+        cons = torch.randint(0, 4, (L,), generator=g, device=device, dtype=torch.uint8)
+        for _ in range(copies):
+            a = int(torch.rand(1, generator=g, device=device).item() * (n - L - 1))
+            div = torch.rand(1, generator=g, device=device).item() * div_hi
+            mut = torch.rand(L, generator=g, device=device) < div
+            rb = torch.randint(1, 4, (L,), generator=g, device=device, dtype=torch.uint8)
+            G[a:a + L] = torch.where(mut, (cons + rb) % 4, cons)
+    plant(5000, 7, 0.01)
+    for L, c in ((1400, 14), (1200, 13), (800, 13)):
+        plant(L, c, 0.02)
+    return G, [n]
+
+
 def build_index_gpu(base, G, chrom_lens, large, device_index):
     """The GPU index builder on the in-memory genome -> <base>.{1,2,3,4,rev.1,rev.2}.bt2[l]; returns its stats."""
     import numpy as np
@@ -275,6 +299,9 @@ CONFIGS = {
                  "what": "pairs, --very-sensitive (-D 20 -R 3 -N 0 -L 20 -i S,1,0.50), --fr -I 0 -X 500 (mate rescue)"},
     "local400": {"args": ["--local"], "paired": False, "readlen": 400, "reads": 200_000, "cpu_sample": 100_000,
                  "what": "--local = --sensitive-local (-D 15 -R 2 -N 0 -L 20 -i S,1,0.75, --ma 2, --score-min G,20,8)"},
+    # BASELINE.json configs[1]: a bacterial genome behind a small (.bt2: 64-byte sides, 32-bit offsets) index -- the uint32_t instantiations
+    "ecoli100": {"args": ["--sensitive"], "paired": False, "readlen": 100, "reads": 1_000_000, "cpu_sample": 1_000_000, "genome": "ecoli",
+                 "what": "default preset = --sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"},
 }
 
 
@@ -450,7 +477,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="se150",
-                    help="se150 = the headline (BASELINE.json configs[2]); pe-vsens = configs[3]; local400 = configs[4]")
+                    help="se150 = the headline (BASELINE.json configs[2]); ecoli100 = configs[1]; pe-vsens = configs[3]; local400 = configs[4]")
     ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BT2_BENCH_MBP", "3100")), help="3100 = hg38 scale")
     ap.add_argument("--small-index", action="store_true", help="build a .bt2 (32-bit) index instead of the headline .bt2l")
     ap.add_argument("--reads", type=int, default=int(os.environ.get("BT2_BENCH_READS", "0")), help="reads per GPU per step (0: the config's default)")
@@ -484,14 +511,19 @@ def main():
     dist = shard.init("nccl", dev)      # RCCL; None when WORLD_SIZE == 1
 
     threads = nproc()
-    large = not args.small_index
+    bacterial = cfg.get("genome") == "ecoli"
+    large = not (args.small_index or bacterial)
     ext = "bt2l" if large else "bt2"
-    base = os.path.join(cache_dir(), "hg38like_%dmbp_s2_%s" % (args.genome_mbp, ext))
+    base = os.path.join(cache_dir(), "ecolilike_s3_%s" % ext if bacterial else "hg38like_%dmbp_s2_%s" % (args.genome_mbp, ext))
     # ---- workload: genome (every rank, same seed) + index (rank 0 builds it on its GPU, the others wait) ----
     t0 = time.time()
-    G, chrom_lens = synth_genome_gpu(args.genome_mbp, 2, dev)
+    if bacterial:
+        G, chrom_lens = synth_genome_bacterial(3, dev)
+        args.genome_mbp = G.numel() / 1e6
+    else:
+        G, chrom_lens = synth_genome_gpu(args.genome_mbp, 2, dev)
     torch.cuda.synchronize()
-    log("[bench] genome: %d Mbp generated in %.1fs" % (args.genome_mbp, time.time() - t0))
+    log("[bench] genome: %.4g Mbp generated in %.1fs" % (args.genome_mbp, time.time() - t0))
     build_info = None
     if rank == 0 and not os.path.exists(base + ".rev.2." + ext):
         torch.cuda.empty_cache()       # the builder allocates ~30 bytes per base with hipMalloc, next to torch's caching allocator
@@ -633,6 +665,7 @@ def main():
                 par["timed_batch_aligned_reads_same_sample"] = int(h["aligned"][:ns].sum())
         res = {
             "metric": ("aligned reads/sec (whole node), 2 x %d bp PE (mates counted as reads), hg38-like synthetic genome" % args.readlen if args.paired else
+                       "aligned reads/sec (whole node), %d bp SE vs E. coli K-12-like synthetic genome, small index" % args.readlen if bacterial else
                        "aligned reads/sec (whole node), %d bp SE vs hg38-like synthetic genome (hg38 unavailable offline), large index" % args.readlen),
             "value": shard.throughput(world, n, steps, dt),
             "unit": "reads/s",
@@ -641,7 +674,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32" if off_sz == 4 else "u8/u64", "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json %s: hg38-like synthetic %d Mbp genome%s (%d chromosomes; ~45 %% repeats: Alu-/L1-like and older diverged families, simple repeats, segmental duplications; N gaps), "
+                "workload": ("BASELINE.json configs[1]: E. coli K-12-like synthetic %.2f Mbp genome (one chromosome; 7 rRNA-operon-like and 40 IS-like repeat copies; the real sequence is not available offline), "
+                             ".%s index (side %d B, %d-byte offsets) built in this run by the GPU index builder, %d x %d bp SE reads per GPU per step, %s"
+                             % (args.genome_mbp, ext, side, off_sz, n, args.readlen, cfg["what"])) if bacterial else
+                            "BASELINE.json %s: hg38-like synthetic %d Mbp genome%s (%d chromosomes; ~45 %% repeats: Alu-/L1-like and older diverged families, simple repeats, segmental duplications; N gaps), "
                             ".%s index (side %d B, %d-byte offsets) built in this run by the GPU index builder, %d x %d bp %s per GPU per step, %s"
                             % ({"se150": "configs[2]", "pe-vsens": "configs[3]", "local400": "configs[4]"}.get(args.config, "(extra) " + args.config), args.genome_mbp,
                                " = hg38 scale" if args.genome_mbp >= 3000 else "", N_CHROMS, ext, side, off_sz, n, args.readlen,

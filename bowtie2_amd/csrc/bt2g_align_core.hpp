@@ -290,6 +290,10 @@ struct Aligner {
 	struct HotRd {
 		BT2_HD int seq(uint32_t i) const { return Plat::hot().seq[i]; }
 		BT2_HD int qual(uint32_t i) const { return Plat::hot().qual[i]; }
+		BT2_HD void window16(uint32_t lo, uint32_t (&o)[4]) const {
+			o[0] = o[1] = o[2] = o[3] = 0;
+			for (uint32_t k = 0; k < 16u && lo + k < Plat::hot().len; k++) o[k >> 2] |= (uint32_t)Plat::hot().seq[lo + k] << ((k & 3u) * 8u);
+		}
 	};
 
 	// SeedAligner::oneMmSearch with repex=false, rep1mm=true (aligner_seed.cpp:975-1325)
@@ -908,13 +912,16 @@ struct Aligner {
 		fm_extend_hit(IX, rd, HOT.len, topf, botf, topb, botb, fw, off, len, nlex, nrex, cnt, (PRM.do_extend & 2) == 0);
 		HOT.n_bwops_ext += cnt.bwops; HOT.n_sides += cnt.sides;
 #ifdef BT2G_CHECK_EXTEND_TEXT
-		// test builds: the text-comparison form the batch kernel uses for one-row hits must agree with the LF walk
-		if (botf - topf == 1) {
-			uint32_t st_ = 0, l2 = 0, r2 = 0;
-			const TOff jo = get_offset(IX.fw, topf, st_);
-			if ((uint64_t)jo < (uint64_t)IX.fw.len) {
-				fm_extend_hit_text(IX, rd, HOT.len, (uint64_t)jo, fw, off, len, l2, r2, (PRM.do_extend & 2) == 0);
-				if (l2 != nlex || r2 != nrex) { fprintf(stderr, "extend mismatch: LF %u/%u text %u/%u\n", nlex, nrex, l2, r2); abort(); }
+		// test builds: the text-comparison form the batch kernel uses for hits of up to kExtRows rows must agree with the LF walk
+		if (botf - topf >= 1 && (uint64_t)(botf - topf) <= kExtRows) {
+			uint64_t p_[kExtRows]; bool in_text = true;
+			for (uint32_t k = 0; k < kExtRows; k++) { p_[k] = 0; if (k < (uint32_t)(botf - topf)) { uint32_t st_ = 0; p_[k] = (uint64_t)get_offset(IX.fw, (TOff)(topf + k), st_); if (p_[k] >= (uint64_t)IX.fw.len) in_text = false; } }
+			if (in_text) {
+				uint32_t l2 = 0, r2 = 0, wk = 0;
+				fm_extend_rows_text(IX, rd, HOT.len, p_, (uint32_t)(botf - topf), fw, off, len, l2, r2, wk, (PRM.do_extend & 2) == 0);
+				static unsigned long n_ = 0, nm_ = 0; n_++; if (botf - topf > 1) nm_++;
+				if (l2 != nlex || r2 != nrex) { fprintf(stderr, "extend mismatch: rows %u LF %u/%u text %u/%u (fw %d off %u len %u)\n", (unsigned)(botf - topf), nlex, nrex, l2, r2, (int)fw, off, len); abort(); }
+				if ((n_ & (n_ - 1)) == 0) fprintf(stderr, "extend text form checked on %lu hits (%lu with several rows)\n", n_, nm_);
 			}
 		}
 #endif

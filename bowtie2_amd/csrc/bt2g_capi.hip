@@ -185,8 +185,8 @@ int bt2g_ctx_create(int device, bt2g_ctx** out) {
 	c->device = device;
 	c->n_cu = (uint32_t)prop.multiProcessorCount;
 	{ const char* v = std::getenv("BT2G_NO_PRECOMP"); c->precomp = !(v && v[0] == '1'); }
-	if (hipMalloc((void**)&c->d_cnt, sizeof(DevCounters)) != hipSuccess) { delete c; return BT2G_ERR_HIP; }
-	(void)hipMemset(c->d_cnt, 0, sizeof(DevCounters));
+	if (hipMalloc((void**)&c->d_cnt, kCntSlots * sizeof(DevCounters)) != hipSuccess) { delete c; return BT2G_ERR_HIP; }
+	(void)hipMemset(c->d_cnt, 0, kCntSlots * sizeof(DevCounters));
 	*out = c;
 	return 0;
 }
@@ -419,10 +419,11 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		const uint64_t b_mm1c = al(n * 4 * sizeof(unsigned int));
 		const uint64_t qcap64 = n * 16 < 0xfffffff0ull ? n * 16 : 0xfffffff0ull;
 		const uint64_t b_mm1q = al(qcap64 * one_mm_task_bytes(c->off_size));
+		const uint64_t b_mm1t = al(n * 4 * sizeof(uint32_t));      // the scan's task list: the (read, strand, direction) combinations that are searched at all
 		// re-seeding rounds are pre-computed for unpaired batches (the pair worker keeps searching them itself)
 		uint32_t pre_rounds = 1;
 		if (params->seed_mms == 0 && !params->paired && params->n_seed_rounds > 1) pre_rounds = (uint32_t)params->n_seed_rounds < kMaxPreRounds ? (uint32_t)params->n_seed_rounds : kMaxPreRounds;
-		const uint64_t tot = b_sweep + (b_seeds + b_ext + b_joff) * pre_rounds + b_mm1 + b_mm1n + b_mm1c + b_mm1q;
+		const uint64_t tot = b_sweep + (b_seeds + b_ext + b_joff) * pre_rounds + b_mm1 + b_mm1n + b_mm1c + b_mm1q + b_mm1t;
 		if (tot > c->pre_bytes) {
 			if (c->d_pre) (void)hipFree(c->d_pre);
 			c->d_pre = nullptr; c->pre_bytes = 0;
@@ -448,8 +449,9 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			if (params->do_1mm_upfront) {
 				unsigned int* d_mm1c = (unsigned int*)(d_mm1n + b_mm1n);
 				void* d_mm1q = d_mm1n + b_mm1n + b_mm1c;
-				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, c->d_cnt, st)
-				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, c->d_cnt, st);
+				uint32_t* d_mm1t = (uint32_t*)(d_mm1n + b_mm1n + b_mm1c + b_mm1q);
+				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, d_mm1t, c->d_cnt, st)
+				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, d_mm1t, c->d_cnt, st);
 				if (e != hipSuccess) return hip_fail(c, e, "k_one_mm");
 				pre.mm1 = (decltype(pre.mm1))d_mm1; pre.mm1_n = (decltype(pre.mm1_n))d_mm1n;
 			}
@@ -469,7 +471,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			}
 			// rounds 1..: the same kernels on the shifted seeds, for the reads repetitive enough to be re-seeded
 			const bt2g_seed_hit* prev = d_seeds;
-			uint8_t* q = d_mm1n + b_mm1n + b_mm1c + b_mm1q;
+			uint8_t* q = d_mm1n + b_mm1n + b_mm1c + b_mm1q + b_mm1t;
 			for (uint32_t ri = 1; ri < pre_rounds; ri++) {
 				bt2g_seed_hit* sr = (bt2g_seed_hit*)q; q += b_seeds;
 				uint64_t* jr = (uint64_t*)q; q += b_joff;
@@ -543,11 +545,13 @@ int bt2g_counters_read(bt2g_ctx* c, bt2g_counters* out, int reset, void* stream)
 	if (!c || !out) return BT2G_ERR_ARG;
 	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
 	hipStream_t st = (hipStream_t)stream;
-	DevCounters h;
-	hipError_t e = hipMemcpyAsync(&h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_cnt, 0, sizeof(h), st);
+	std::vector<DevCounters> hs(kCntSlots);
+	hipError_t e = hipMemcpyAsync(hs.data(), c->d_cnt, kCntSlots * sizeof(DevCounters), hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_cnt, 0, kCntSlots * sizeof(DevCounters), st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	if (e != hipSuccess) return hip_fail(c, e, "read counters");
+	DevCounters h; h.rank_queries = h.sa_lookups = h.ftab_lookups = h.dp_cells = h.bwops = 0;
+	for (const DevCounters& k : hs) { h.rank_queries += k.rank_queries; h.sa_lookups += k.sa_lookups; h.ftab_lookups += k.ftab_lookups; h.dp_cells += k.dp_cells; h.bwops += k.bwops; }
 	out->rank_queries = h.rank_queries; out->sa_lookups = h.sa_lookups; out->ftab_lookups = h.ftab_lookups;
 	out->dp_cells = h.dp_cells; out->bwops = h.bwops;
 	return 0;

@@ -131,9 +131,14 @@ struct DevIndex {
 	DevRef ref;
 };
 
-struct DevCounters {
+// Work counters of the stage kernels (roofline accounting).  The device holds kCntSlots copies, one cache line each, and a wave adds to the
+// copy its workgroup index selects: with ONE copy every wave of a launch sent its atomics to the same three words of one line, and the L2
+// channel that owns the line serialised them -- 1.9 M atomics per launch of 40 M lanes, ~14 ns each: 27 of the 43 ms k_extend_hits took in
+// rounds 1-3, and half of k_seed_search_exact, were this.  The host sums the copies when it reads them.
+struct alignas(64) DevCounters {
 	unsigned long long rank_queries, sa_lookups, ftab_lookups, dp_cells, bwops;
 };
+constexpr unsigned kCntSlots = 256;
 
 // ---------------------------------------------------------------------------------------
 BT2_HD int popc32(uint32_t x) {
@@ -144,8 +149,19 @@ BT2_HD int popc32(uint32_t x) {
 #endif
 }
 
-// One block, loaded into registers: four 16-byte loads of one aligned 64-byte line.
-struct Blk { uint64_t occ[4]; uint32_t p0[4], p1[4]; };
+// One block, loaded into registers: four 16-byte loads of one aligned 64-byte line.  The planes and the counts are VECTOR values on the
+// device (ext_vector_type): a rank query picks a plane word by the row's position and a count by the character, both run-time indices,
+// and the optimiser turns any such pick from a plain array -- even one written as a chain of compares -- into an indexed load, which
+// puts the whole block into scratch memory (64 bytes stored and re-read per lane and rank query; every FM kernel of rounds 1-3 did).
+// An element picked from a vector value is a register select.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t blk_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t blk_u64x4 __attribute__((ext_vector_type(4)));
+#else
+struct blk_u32x4 { uint32_t v[4]; BT2_HD uint32_t& operator[](uint32_t i) { return v[i]; } BT2_HD const uint32_t& operator[](uint32_t i) const { return v[i]; } };
+struct blk_u64x4 { uint64_t v[4]; BT2_HD uint64_t& operator[](uint32_t i) { return v[i]; } BT2_HD const uint64_t& operator[](uint32_t i) const { return v[i]; } };
+#endif
+struct Blk { blk_u64x4 occ; blk_u32x4 p0, p1; };
 
 BT2_HD void load_blk(const RankBlock* blks, uint64_t b, Blk& o) {
 	const uint4* p = reinterpret_cast<const uint4*>(blks + b);
@@ -173,11 +189,8 @@ BT2_HD uint32_t blk_count(const Blk& s, uint32_t off, int c) {
 }
 
 BT2_HD int blk_char(const Blk& s, uint32_t off) {
-	uint32_t a = s.p0[0], b = s.p1[0];
 	const uint32_t w = off >> 5;
-	if (w == 1) { a = s.p0[1]; b = s.p1[1]; }
-	if (w == 2) { a = s.p0[2]; b = s.p1[2]; }
-	if (w == 3) { a = s.p0[3]; b = s.p1[3]; }
+	const uint32_t a = s.p0[w], b = s.p1[w];
 	const uint32_t sh = off & 31;
 	return (int)(((a >> sh) & 1u) | (((b >> sh) & 1u) << 1));
 }

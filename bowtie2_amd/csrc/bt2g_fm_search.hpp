@@ -89,45 +89,111 @@ BT2_HD void fm_extend_hit(const DevIndex<TOff>& ix, const RD& rd, uint32_t rdlen
 // The joined text (every unambiguous reference base, in index order) is what <base>.4 stores, two bits per base.
 BT2_HD int joined_char(const DevRef& r, uint64_t p) { return (r.buf[p >> 2] >> ((p & 3) << 1)) & 3; }
 
-// fm_extend_hit for a range of exactly ONE row whose joined-text offset p is known.  A one-row range cannot shrink, so the LF
-// walk of SwDriver::extend degenerates into comparing the read with the text on either side of the hit; it ends where the walk
-// ends: at a mismatch (a read N never mismatches, as in the walk), after 255 characters, at the read's end, or at either end
-// of the joined text, where mapLF1 fails.  ~lim/4 bytes of contiguous text instead of lim dependent side reads.
+// ---------------------------------------------------------------------------------------------------------------------
+// SwDriver::extend for a range of 1..kExtRows rows whose joined-text offsets are known, sixteen characters per step.
+//
+// While the walk of fm_extend_hit keeps a range of several rows, every row of it is preceded (left, forward index) or followed
+// (right, mirror index) by the same character -- that is what "the range keeps its size" means -- and that character equals the
+// read's unless the read has an N there.  In text terms: position ii is accepted iff the rows' texts all hold the same character
+// there and (read N or character == read character); a row that has run out of text (the '$' row leaves the range) ends it.  For
+// one row: out of text (mapLF1 fails at either end of the joined text) counts as a mismatch, which a read N forgives, exactly as in the walk.
+// The LF walk is a chain of dependent rank queries, up to 255 long on either side, and one such chain in a wave of short ones keeps
+// the whole workgroup resident for its duration (identical segmental-duplication copies: 2-row ranges that extend for a hundred
+// characters); here the only dependent loads are the rows' suffix-array entries.
+// Sixteen characters are packed two bits each into one word per row and one for the read (RD::window16 -> multiply trick), XORed, and
+// the first set bit pair is the first position that ends the extension.
+constexpr uint32_t kExtRows = 8;
+// the four 2-bit codes in the bytes of x (values 0..3; bit 2 = N) -> bits 0-7; and their N flags -> bits 0-3
+BT2_HD uint32_t pack4_codes(uint32_t x) { return (uint32_t)(((x & 0x03030303u) * 0x01041040u) >> 24); }
+BT2_HD uint32_t pack4_nflags(uint32_t x) { return (uint32_t)((((x >> 2) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu; }
+// reverse the order of the sixteen 2-bit groups of a word
+BT2_HD uint32_t rev_groups(uint32_t x) {
+	x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+	x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+	x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+	return (x >> 16) | (x << 16);
+}
+BT2_HD uint32_t rev16(uint32_t x) {
+	x = ((x >> 1) & 0x5555u) | ((x & 0x5555u) << 1); x = ((x >> 2) & 0x3333u) | ((x & 0x3333u) << 2);
+	x = ((x >> 4) & 0x0f0fu) | ((x & 0x0f0fu) << 4); return ((x >> 8) | (x << 8)) & 0xffffu;
+}
+// bit i of a 16-bit mask -> both bits of group i
+BT2_HD uint32_t spread_groups(uint32_t m) {
+	m = (m | (m << 8)) & 0x00ff00ffu; m = (m | (m << 4)) & 0x0f0f0f0fu; m = (m | (m << 2)) & 0x33333333u; m = (m | (m << 1)) & 0x55555555u;
+	return m * 3u;
+}
+// sixteen joined-text characters starting at position q (ascending), two bits each, first character in bits 0-1; positions outside
+// [0, n) read as 0 and are flagged in `bad` (one bit per position)
+BT2_HD uint32_t text16(const DevRef& r, uint64_t n, int64_t q, uint32_t& bad) {
+	bad = 0;
+	if (q < 0) { const uint32_t k = (uint32_t)(-q); if (k >= 16u) { bad = 0xffffu; return 0; } bad = (1u << k) - 1u; }
+	if (q + 16 > (int64_t)n) { const int64_t ok = (int64_t)n - q; if (ok <= 0) { bad = 0xffffu; return 0; } bad |= (0xffffu << (uint32_t)ok) & 0xffffu; }
+	const uint64_t q0 = q < 0 ? 0 : (uint64_t)q;           // first position that exists
+	const uint64_t nbytes = (n + 3) >> 2;
+	uint64_t b0 = q0 >> 2;
+	uint64_t v = 0;
+	if (b0 + 8 <= nbytes) __builtin_memcpy(&v, r.buf + b0, 8);
+	else for (uint32_t k = 0; b0 + k < nbytes && k < 8; k++) v |= (uint64_t)r.buf[b0 + k] << (8 * k);
+	uint32_t w = (uint32_t)(v >> ((q0 & 3) << 1));        // characters q0, q0+1, ... (40 bits held: 16 characters + 3 of slack)
+	if (q < 0) w <<= 2u * (uint32_t)(-q);                 // (fewer than 16 missing)
+	return w & ~spread_groups(bad);
+}
 template <typename TOff, typename RD>
-BT2_HD void fm_extend_hit_text(const DevIndex<TOff>& ix, const RD& rd, uint32_t rdlen, uint64_t p, bool fw, uint32_t off, uint32_t len,
-                               uint32_t& nlex, uint32_t& nrex, bool right = true) {
+BT2_HD void fm_extend_rows_text(const DevIndex<TOff>& ix, const RD& rd, uint32_t rdlen, const uint64_t (&p)[kExtRows], uint32_t nrows, bool fw, uint32_t off, uint32_t len,
+                                uint32_t& nlex, uint32_t& nrex, uint32_t& steps_walked, bool right = true) {
 	const uint64_t n = (uint64_t)ix.fw.len;
-	nlex = nrex = 0;
+	nlex = nrex = 0; steps_walked = 0;
 	for (int side = 0; side < 2; side++) {
 		const bool left = side == 0;
 		if (!left && !right) continue;
 		const uint32_t lim = left ? (fw ? off : rdlen - len - off) : (fw ? rdlen - len - off : off);
+		// In the coordinates of the read as stored (5' -> 3'), the walk goes DOWN from off - 1 (left of a fw seed, right of an rc seed) or
+		// UP from off + len (right of a fw seed, left of an rc seed); an rc seed compares complemented characters.
+		const bool down = left == fw;
 		uint32_t cnt = 0;
 		bool stop = false;
-		// eight positions per trip: their read and text characters are fetched together (independent loads), then looked at in order --
-		// one memory round trip per eight characters instead of one per character
-		for (uint32_t i0 = 0; i0 < lim && !stop; i0 += 8) {
-			int rdc[8], c[8];
+		for (uint32_t i0 = 0; i0 < lim && !stop; i0 += 16) {
+			// ---- the read's sixteen characters, position ii = i0 + k in bit pair k ----
+			uint32_t w4[4];
+			const uint32_t lo = down ? (off - i0 >= 16u ? off - i0 - 16u : 0u) : off + len + i0;      // first stored position of the window
+			rd.window16(lo, w4);
+			uint32_t R = pack4_codes(w4[0]) | (pack4_codes(w4[1]) << 8) | (pack4_codes(w4[2]) << 16) | (pack4_codes(w4[3]) << 24);
+			uint32_t N = pack4_nflags(w4[0]) | (pack4_nflags(w4[1]) << 4) | (pack4_nflags(w4[2]) << 8) | (pack4_nflags(w4[3]) << 12);
+			if (down) {
+				// the window ends at stored position off - i0 - 1 = ii i0; when fewer than 16 characters are left it starts at 0 and its
+				// top groups lie beyond the seed's side: shift them out so that ii i0 sits in the top group before reversing
+				const uint32_t have = off - i0 >= 16u ? 16u : off - i0;
+				R <<= 2u * (16u - have); N = (N << (16u - have)) & 0xffffu;
+				R = rev_groups(R);
+				N = rev16(N);
+			}
+			if (!fw) R = ~R;
+			const uint32_t N2 = spread_groups(N);
+			// ---- the rows' texts ----
+			uint32_t mism = 0, T0 = 0;
 #pragma unroll
-			for (uint32_t k = 0; k < 8; k++) {
-				const uint32_t ii = i0 + k;
-				rdc[k] = 4; c[k] = -1;
-				if (ii < lim) {
-					uint32_t i;
-					if (left) i = fw ? off - ii - 1 : rdlen - off - len - 1 - ii;
-					else      i = fw ? ii + len + off : rdlen - off + ii;
-					rdc[k] = fm_rd_char(rd, rdlen, fw, i);
-					if (left) { if (p >= (uint64_t)ii + 1) c[k] = joined_char(ix.ref, p - ii - 1); }
-					else { const uint64_t q = p + len + ii; if (q < n) c[k] = joined_char(ix.ref, q); }
+			for (uint32_t r = 0; r < kExtRows; r++) {
+				if (r >= nrows) continue;
+				uint32_t bad;
+				uint32_t T;
+				if (left) { T = text16(ix.ref, n, (int64_t)p[r] - (int64_t)i0 - 16, bad); T = rev_groups(T); bad = rev16(bad); }
+				else T = text16(ix.ref, n, (int64_t)(p[r] + len + i0), bad);
+				const uint32_t bad2 = spread_groups(bad);
+				if (nrows == 1) mism |= (((T ^ R) | bad2) & ~N2);        // out of text: a mismatch that a read N forgives (mapLF1 at the '$' row)
+				else {
+					mism |= ((T ^ R) & ~N2) | bad2;                         // a row out of text leaves the range
+					if (r == 0) T0 = T; else mism |= T ^ T0;                // the rows must agree with each other, read N or not
 				}
 			}
-#pragma unroll
-			for (uint32_t k = 0; k < 8; k++) {
-				if (stop || i0 + k >= lim) continue;
-				if (c[k] != rdc[k] && rdc[k] <= 3) { stop = true; continue; }
-				if (++cnt == 255) stop = true;
-			}
+			// groups: any set bit in a pair ends the extension there
+			const uint32_t g = (mism | (mism >> 1)) & 0x55555555u;
+			uint32_t k = g ? (uint32_t)__builtin_ctz(g) >> 1 : 16u;
+			if (i0 + k > lim) k = lim - i0;
+			if (k < 16u && i0 + k < lim) stop = true;
+			if (cnt + k >= 255u) { cnt = 255u; stop = true; break; }
+			cnt += k;
 		}
+		steps_walked += cnt + ((stop && cnt < 255u) ? 1u : 0u);
 		if (left) nlex = cnt; else nrex = cnt;
 	}
 }

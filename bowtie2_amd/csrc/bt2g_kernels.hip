@@ -33,11 +33,66 @@ __device__ __forceinline__ int read_char(const uint8_t* seq, uint32_t len, uint3
 	return rc ? comp_base(seq[len - 1 - p]) : seq[p];
 }
 
+// the copy of the counters this workgroup adds to (DevCounters, bt2g_device.hpp)
+__device__ __forceinline__ DevCounters* cnt_slot(DevCounters* cnt) { return cnt + (blockIdx.x & (kCntSlots - 1)); }
 __device__ __forceinline__ void wave_add_counter(unsigned long long* ctr, unsigned long long v) {
 	// sum over the wave with DPP-free shuffles, one atomic per wave
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
 	if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
 }
+
+// The read as the FM search functions see it: characters through a 16-byte window held in registers.  The searches walk the read
+// position by position, so one (unaligned) 16-byte load serves sixteen steps -- a wave's byte load touches 64 different cache lines (one
+// per lane) and costs the L1 as much as its 64-byte rank block reads do; rounds 1-3 issued one per step.  The window never reaches past
+// the read (the last read of a batch ends where the buffer ends); reads shorter than a window are read byte by byte.
+struct GlobRd {
+	const uint8_t* s; const uint8_t* q;
+	uint32_t len;
+	mutable uint32_t base;
+	mutable uint4 w;
+	__device__ __forceinline__ void init(const uint8_t* s_, const uint8_t* q_, uint32_t len_) { s = s_; q = q_; len = len_; base = 0x80000000u; w = make_uint4(0, 0, 0, 0); }      // (base: no index is within 16 of it)
+	__device__ __forceinline__ int seq(uint32_t i) const {
+		if (len < 16u) return s[i];
+		uint32_t k = i - base;
+		if (k >= 16u) {
+			base = i & ~15u;
+			if (base > len - 16u) base = len - 16u;
+			__builtin_memcpy(&w, s + base, 16);
+			k = i - base;
+		}
+		const uint32_t v = (k & 8u) ? ((k & 4u) ? w.w : w.z) : ((k & 4u) ? w.y : w.x);
+		return (int)((v >> ((k & 3u) * 8u)) & 0xffu);
+	}
+	__device__ __forceinline__ int qual(uint32_t i) const { return q[i]; }
+	// the sixteen characters lo .. lo + 15 as stored, one per byte (0 past the end of the read)
+	__device__ __forceinline__ void window16(uint32_t lo, uint32_t (&o)[4]) const {
+		if (len >= 16u) {
+			// one 16-byte load in every case: a window that would reach past the read is loaded from the read's last 16 bytes and shifted down
+			const uint32_t b = lo + 16u <= len ? lo : len - 16u;
+			uint4 v; __builtin_memcpy(&v, s + b, 16);
+			uint64_t l64 = (uint64_t)v.x | ((uint64_t)v.y << 32), h64 = (uint64_t)v.z | ((uint64_t)v.w << 32);
+			const uint32_t sh = lo - b;                    // 0..15 bytes (lo < len), >= 16: nothing left
+			if (sh >= 16u) { l64 = h64 = 0; }
+			else if (sh >= 8u) { l64 = h64 >> (8u * (sh - 8u)); h64 = 0; }
+			else if (sh > 0u) { l64 = (l64 >> (8u * sh)) | (h64 << (64u - 8u * sh)); h64 >>= 8u * sh; }
+			o[0] = (uint32_t)l64; o[1] = (uint32_t)(l64 >> 32); o[2] = (uint32_t)h64; o[3] = (uint32_t)(h64 >> 32);
+			return;
+		}
+		o[0] = o[1] = o[2] = o[3] = 0;
+		for (uint32_t k = 0; k < 16u && lo + k < len; k++) o[k >> 2] |= (uint32_t)s[lo + k] << ((k & 3u) * 8u);
+	}
+	// # of Ns (codes > 3) in the read, sixteen characters per load
+	__device__ __forceinline__ uint32_t count_n() const {
+		uint32_t ns = 0, i = 0;
+		for (; i + 16u <= len; i += 16u) {
+			uint4 v; __builtin_memcpy(&v, s + i, 16);
+			// a code is 0..4: bit 2 set <=> N
+			ns += (uint32_t)__popc(v.x & 0x04040404u) + (uint32_t)__popc(v.y & 0x04040404u) + (uint32_t)__popc(v.z & 0x04040404u) + (uint32_t)__popc(v.w & 0x04040404u);
+		}
+		for (; i < len; i++) if (s[i] > 3) ns++;
+		return ns;
+	}
+};
 
 // key of the ftabChars-mer seq[off .. off+fc) read in text order (forward index) or reversed
 // (mirror index): Ebwt::ftabSeqToInt (bt2_idx.h:1374).  Returns false if an N is present.
@@ -77,7 +132,8 @@ k_exact_sweep(DevIndex<TOff> ix, bt2g_reads rd, int nofw, int norc, uint32_t min
 			const uint32_t ftab_len = e.ftab_chars;
 			uint32_t dep = 0, nedit = 0;
 			bool done = false, do_init = true;
-			auto getc = [&](uint32_t p) { return read_char(seq, len, p, rc); };
+			GlobRd g; g.init(seq, nullptr, len);
+			auto getc = [&](uint32_t p) -> int { return rc ? comp_base(g.seq(len - 1 - p)) : g.seq(p); };
 			while (dep < len && !done) {
 				if (do_init) {
 					// exactSweepInit (aligner_seed.cpp:752-791)
@@ -138,9 +194,9 @@ k_exact_sweep(DevIndex<TOff> ix, bt2g_reads rd, int nofw, int norc, uint32_t min
 		o->hit[fwi] = hit;
 		if (fwi == 0) { for (int i = 0; i < 6; i++) o->pad[i] = 0; }
 	}
-	wave_add_counter(&cnt->rank_queries, nrank);
-	wave_add_counter(&cnt->ftab_lookups, nftab);
-	wave_add_counter(&cnt->bwops, bwops);
+	wave_add_counter(&cnt_slot(cnt)->rank_queries, nrank);
+	wave_add_counter(&cnt_slot(cnt)->ftab_lookups, nftab);
+	wave_add_counter(&cnt_slot(cnt)->bwops, bwops);
 }
 
 template <typename TOff>
@@ -207,8 +263,9 @@ k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict
 		if (ok) {
 			// Seed sequence as it aligns to the Watson strand: fw -> read[depth, depth+L);
 			// rc -> revcomp of that window (instantiateSeq :463-485), i.e. k-th char = comp(read[depth+L-1-k]).
+			GlobRd g; g.init(seq, nullptr, len);
 			auto getc = [&](uint32_t k) -> int {
-				return rc ? comp_base(seq[depth + L - 1 - k]) : (int)seq[depth + k];
+				return rc ? comp_base(g.seq(depth + L - 1 - k)) : g.seq(depth + k);
 			};
 			// An N anywhere disqualifies an exact seed (Constraint::exact cannot absorb it, :338-347)
 			for (uint32_t k = 0; k < L; k++) if (getc(k) > 3) { ok = false; break; }
@@ -260,9 +317,9 @@ k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict
 		if (!want) h.topf = ~0ull;       // "this round was not searched for this read": the worker searches it itself should it get there
 		out[gid] = h;
 	}
-	wave_add_counter(&cnt->rank_queries, nrank);
-	wave_add_counter(&cnt->ftab_lookups, nftab);
-	wave_add_counter(&cnt->bwops, bwops);
+	wave_add_counter(&cnt_slot(cnt)->rank_queries, nrank);
+	wave_add_counter(&cnt_slot(cnt)->ftab_lookups, nftab);
+	wave_add_counter(&cnt_slot(cnt)->bwops, bwops);
 }
 
 template <typename TOff>
@@ -312,8 +369,8 @@ k_resolve_offsets(DevIndex<TOff> ix, const uint64_t* __restrict__ d_rows, const 
 		o.steps = steps;
 		out[gid] = o;
 	}
-	wave_add_counter(&cnt->rank_queries, nrank);
-	wave_add_counter(&cnt->sa_lookups, nsa);
+	wave_add_counter(&cnt_slot(cnt)->rank_queries, nrank);
+	wave_add_counter(&cnt_slot(cnt)->sa_lookups, nsa);
 }
 
 template <typename TOff>
@@ -331,14 +388,56 @@ hipError_t launch_resolve_offsets(const DevIndex<TOff>& ix, const uint64_t* d_ro
 // ------------------------------------------------------------------------------------
 // seed-hit extension (SwDriver::extend) for every non-empty round-0 seed hit, one lane per hit
 // ------------------------------------------------------------------------------------
-struct GlobRd {
-	const uint8_t* s; const uint8_t* q;
-	__device__ __forceinline__ int seq(uint32_t i) const { return s[i]; }
-	__device__ __forceinline__ int qual(uint32_t i) const { return q[i]; }
-};
+// fm_extend_rows_text for ONE row whose compare region lies well inside the joined text and a read of >= 16 characters: the common case of
+// k_extend_hits, stripped of every boundary rule (no position can run out of text), with both sides walked by ONE loop -- a lane moves on
+// to its right side as soon as its left side ends, so a wave makes as many trips as its longest lane needs in total (~9), not the longest
+// left walk plus the longest right walk (~17).  The FM kernels are bound by their instruction stream (profiles/r03zz_pmc_traffic.json:
+// 3.7 k vector + 2.2 k scalar wave instructions per READ for this kernel, i.e. ~19 k per wave): what counts is instructions per trip.
+__device__ __forceinline__ void extend_one_row_fast(const DevRef& ref, const GlobRd& rd, uint32_t rdlen, uint64_t p, bool fw, uint32_t off, uint32_t len,
+                                                    bool right, uint32_t& nlex, uint32_t& nrex, uint32_t& steps_walked) {
+	const uint32_t limL = fw ? off : rdlen - len - off, limR = right ? (fw ? rdlen - len - off : off) : 0u;
+	uint32_t cnt[2] = {0, 0};
+	bool stopped[2] = {false, false};
+	uint32_t side = limL > 0 ? 0u : 1u, i0 = 0;
+	bool active = (side == 0u ? limL : limR) > 0;
+	while (active) {
+		const bool left = side == 0u;
+		const uint32_t lim = left ? limL : limR;
+		const bool down = left == fw;
+		uint32_t w4[4];
+		const uint32_t lo = down ? (off - i0 >= 16u ? off - i0 - 16u : 0u) : off + len + i0;
+		rd.window16(lo, w4);
+		uint32_t R = pack4_codes(w4[0]) | (pack4_codes(w4[1]) << 8) | (pack4_codes(w4[2]) << 16) | (pack4_codes(w4[3]) << 24);
+		uint32_t N2 = 0;
+		if ((w4[0] | w4[1] | w4[2] | w4[3]) & 0x04040404u) {      // an N in the window: rare
+			uint32_t N = pack4_nflags(w4[0]) | (pack4_nflags(w4[1]) << 4) | (pack4_nflags(w4[2]) << 8) | (pack4_nflags(w4[3]) << 12);
+			if (down) { const uint32_t have = off - i0 >= 16u ? 16u : off - i0; N = rev16((N << (16u - have)) & 0xffffu); }
+			N2 = spread_groups(N);
+		}
+		if (down) { const uint32_t have = off - i0 >= 16u ? 16u : off - i0; R = rev_groups(R << (2u * (16u - have))); }
+		if (!fw) R = ~R;
+		// the text: sixteen characters in walk order
+		const uint64_t q = left ? p - i0 - 16u : p + len + i0;
+		uint64_t v; __builtin_memcpy(&v, ref.buf + (q >> 2), 8);
+		uint32_t T = (uint32_t)(v >> ((q & 3) << 1));
+		if (left) T = rev_groups(T);
+		const uint32_t mism = (T ^ R) & ~N2;
+		const uint32_t gm = (mism | (mism >> 1)) & 0x55555555u;
+		uint32_t k = gm ? (uint32_t)__builtin_ctz(gm) >> 1 : 16u;
+		bool end_side = false;
+		if (i0 + k >= lim) { k = lim - i0; end_side = true; }            // the side's limit
+		else if (k < 16u) { end_side = true; stopped[side] = true; }     // a mismatch
+		if (cnt[side] + k >= 255u) { cnt[side] = 255u; end_side = true; stopped[side] = false; } else cnt[side] += k;
+		if (!end_side) i0 += 16u;
+		else if (left && limR > 0) { side = 1u; i0 = 0; }
+		else active = false;
+	}
+	nlex = cnt[0]; nrex = cnt[1];
+	steps_walked = cnt[0] + cnt[1] + (stopped[0] ? 1u : 0u) + (stopped[1] ? 1u : 0u);
+}
 
 template <typename TOff>
-__global__ void BT2G_FM_BOUNDS
+__global__ void __launch_bounds__(64)
 k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t max_seeds, int right,
               const bt2g_seed_hit* __restrict__ hits, uint32_t* __restrict__ ext, uint64_t* __restrict__ joffs, DevCounters* cnt,
               uint32_t roundi, uint32_t n_seed_rounds) {
@@ -362,25 +461,44 @@ k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restri
 			uint32_t roff = 0;
 			if (roundi > 0) reseed_offset(roundi, n_seed_rounds, (uint32_t)rparams[r].interval, (uint32_t)rparams[r].seedlen, len, roff);
 			const uint32_t rdoff = i * (uint32_t)rparams[r].interval + roff;
-			GlobRd g; g.s = rd.d_seq + o0; g.q = rd.d_qual + o0;
+			GlobRd g; g.init(rd.d_seq + o0, rd.d_qual + o0, len);
 			uint32_t nlex = 0, nrex = 0;
-			if (h.botf - h.topf == 1) {
-				// a unique seed hit: resolve its text offset (the worker needs it anyway) and extend by comparing with the text
-				uint32_t steps = 0;
-				const TOff joff = get_offset(ix.fw, (TOff)h.topf, steps);
-				c.sides += steps; c.bwops += steps; sa++;
-				jo = joff_pack((uint64_t)joff, steps);
-				if ((uint64_t)joff < (uint64_t)ix.fw.len) fm_extend_hit_text(ix, g, len, (uint64_t)joff, fw, rdoff, L, nlex, nrex, right != 0);
-				else fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c, right != 0);
+			const uint64_t nrows = (uint64_t)(h.botf - h.topf);
+			if (nrows <= kExtRows) {
+				// up to kExtRows rows: resolve their text offsets (the worker needs a unique hit's anyway) and extend by comparing the read with
+				// the text of every row (fm_extend_rows_text) -- no chain of rank queries
+				uint64_t p[kExtRows];
+				bool in_text = true;
+				uint32_t steps1 = 0;
+#pragma unroll
+				for (uint32_t k = 0; k < kExtRows; k++) {
+					p[k] = 0;
+					if (k < nrows) {
+						uint32_t steps = 0;
+						const TOff joff = get_offset(ix.fw, (TOff)(h.topf + k), steps);
+						p[k] = (uint64_t)joff;
+						if (k == 0) steps1 = steps;
+						if ((uint64_t)joff >= (uint64_t)ix.fw.len) in_text = false;      // the row of the empty suffix: leave it to the walk
+					}
+				}
+				if (nrows == 1) { c.sides += steps1; c.bwops += steps1; sa++; jo = joff_pack(p[0], steps1); }
+				if (in_text) {
+					uint32_t walked = 0;
+					if (nrows == 1 && len >= 16u && p[0] >= 272u && p[0] + 600u < (uint64_t)ix.fw.len)      // (255 characters either way + the loads' slack)
+						extend_one_row_fast(ix.ref, g, len, p[0], fw, rdoff, L, right != 0, nlex, nrex, walked);
+					else
+					fm_extend_rows_text(ix, g, len, p, (uint32_t)nrows, fw, rdoff, L, nlex, nrex, walked, right != 0);
+					if (nrows > 1) { c.bwops += walked; c.sides += walked; sa += (uint32_t)nrows; }
+				} else fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c, right != 0);
 			} else fm_extend_hit(ix, g, len, (TOff)h.topf, (TOff)h.botf, (TOff)h.topb, (TOff)h.botb, fw, rdoff, L, nlex, nrex, c, right != 0);
 			e = nlex | (nrex << 16);
 		}
 		ext[gid] = e;
 		joffs[gid] = jo;
 	}
-	wave_add_counter(&cnt->sa_lookups, sa);
-	wave_add_counter(&cnt->rank_queries, c.sides);
-	wave_add_counter(&cnt->bwops, c.bwops);
+	wave_add_counter(&cnt_slot(cnt)->sa_lookups, sa);
+	wave_add_counter(&cnt_slot(cnt)->rank_queries, c.sides);
+	wave_add_counter(&cnt_slot(cnt)->bwops, c.bwops);
 }
 
 template <typename TOff>
@@ -389,16 +507,21 @@ hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, co
                               uint32_t roundi, uint32_t n_seed_rounds) {
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	if (total == 0) return hipSuccess;
-	const uint64_t grid = (total + 255) / 256;
+	// one wavefront per workgroup: a workgroup's slot is held until its slowest lane is done, and the multi-row hits that are still walked
+	// (more than kExtRows rows) have a long tail
+	const uint64_t grid = (total + 63) / 64;
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, rd, d_rparams, max_seeds, right, d_hits, d_ext, d_joff, d_cnt, roundi, n_seed_rounds);
+	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(64), 0, st, ix, rd, d_rparams, max_seeds, right, d_hits, d_ext, d_joff, d_cnt, roundi, n_seed_rounds);
 	return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------
 // 1-mismatch end-to-end search, one lane per (read, strand, index direction)
 // ------------------------------------------------------------------------------------
-// Three kernels.  (1) k_one_mm_scan: one lane per (read, strand, index direction) walks the exact part of oneMmSearch and,
+// Four kernels.  (0) k_one_mm_tasks: one lane per (read, strand) decides whether oneMmSearch runs for it at all -- the worker only
+// searches a strand whose exact sweep proved <= 1 edit possible, i.e. about one lane in four -- and lists the (read, strand, index
+// direction) combinations that do: the scan then runs on a dense list instead of leaving three quarters of every wave idle.
+// (1) k_one_mm_scan: one lane per listed combination walks the exact part of oneMmSearch and,
 // wherever a mismatching reference character keeps a non-empty range, queues that branch (Mm1Task) instead of following it.
 // (2) k_one_mm_cont: one lane per queued branch finishes it (exact match of the rest of the read).  (3) k_one_mm_fin: per list,
 // restore discovery order (increasing depth, then reference character) and publish the count.  On repeat-rich reads the
@@ -406,48 +529,78 @@ hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, co
 // the machine; nested inside the scan they left most lanes of a wave waiting for the slowest.
 template <typename TOff> struct Mm1Task { uint32_t list; uint16_t dep; uint8_t j, pad; TOff top, bot, topp, botp; };
 
+// entry of the scan's task list: list id = read * 4 + strand * 2 + index direction, bit 31 = the read holds one N
+__global__ void __launch_bounds__(256)
+k_one_mm_tasks(bt2g_align_params P, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, const bt2g_sweep_out* __restrict__ sweep,
+               uint32_t* __restrict__ tasks, unsigned int* __restrict__ tcount) {
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool want = false;
+	uint32_t ns = 0;
+	if (gid < (uint64_t)rd.n_reads * 2) {
+		const uint32_t r = (uint32_t)(gid >> 1);
+		const bool fw = (gid & 1) == 0;
+		const uint64_t o0 = rd.d_off[r];
+		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
+		// the worker only searches a strand whose exact sweep proved <= 1 edit possible (bt2_search.cpp:3704-3706)
+		want = (rparams[r].filt & 15u) == 15u && len >= 2 && sweep[r].mine[fw ? 0 : 1] <= 1 && !(fw ? P.nofw : P.norc);
+		if (want) {
+			GlobRd g; g.init(rd.d_seq + o0, rd.d_qual + o0, len);
+			ns = g.count_n();
+			want = ns <= 1;
+		}
+	}
+	// one atomic per wave; the two directions of a strand sit next to each other
+	const unsigned long long act = __ballot(want);
+	if (act) {
+		const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)act) - 1;
+		unsigned int base = 0;
+		if (lane == leader) base = atomicAdd(tcount, 2u * (unsigned int)__popcll(act));
+		base = (unsigned int)__shfl((int)base, leader);
+		if (want) {
+			const unsigned int idx = base + 2u * (unsigned int)__popcll(act & ((1ull << lane) - 1ull));
+			const uint32_t list = (uint32_t)gid * 2u;
+			tasks[idx] = list | (ns << 31); tasks[idx + 1] = (list + 1u) | (ns << 31);
+		}
+	}
+}
+
 template <typename TOff>
 __global__ void BT2G_MM1_BOUNDS
 k_one_mm_scan(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams,
-              const bt2g_sweep_out* __restrict__ sweep, uint32_t cap, Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt,
+              const uint32_t* __restrict__ tasks, const unsigned int* __restrict__ tcount, uint32_t cap, Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt,
               Mm1Task<TOff>* __restrict__ queue, unsigned int* __restrict__ qcount, uint32_t qcap, DevCounters* cnt) {
-	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	FmCount c; c.bwops = 0; c.sides = 0;
-	if (gid < (uint64_t)rd.n_reads * 4) {
-		const uint32_t r = (uint32_t)(gid >> 2);
+	const unsigned int nt = *tcount;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t ti = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ti < nt; ti += stride) {
+		const uint32_t task = tasks[ti];
+		const uint32_t gid = task & 0x7fffffffu, ns = task >> 31;
+		const uint32_t r = gid >> 2;
 		const bool fw = ((gid >> 1) & 1) == 0;
 		const bool ebwtfw = (gid & 1) == 0;
 		const uint64_t o0 = rd.d_off[r];
 		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
 		const bt2g_read_params rp = rparams[r];
-		// the worker only searches a strand whose exact sweep proved <= 1 edit possible (bt2_search.cpp:3704-3706)
-		const bool want = (rp.filt & 15u) == 15u && len >= 2 && sweep[r].mine[fw ? 0 : 1] <= 1 && !(fw ? P.nofw : P.norc);
-		if (want) {
-			GlobRd g; g.s = rd.d_seq + o0; g.q = rd.d_qual + o0;
-			uint32_t ns = 0;
-			for (uint32_t i = 0; i < len; i++) if (g.s[i] > 3) ns++;
-			if (ns <= 1) {
-				Mm1Hit* dst = out + gid * cap;
-				auto emit = [&](const Mm1Hit& m) { const unsigned int pos = atomicAdd(&out_cnt[gid], 1u); if (pos < cap) dst[pos] = m; };
-				auto defer = [&](uint32_t dep, int j, TOff t, TOff b, TOff tp, TOff bp) -> bool {
-					// one atomic per group of lanes that arrive here together
-					const unsigned long long act = __ballot(1);
-					const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)act) - 1;
-					unsigned int base = 0;
-					if (lane == leader) base = atomicAdd(qcount, (unsigned int)__popcll(act));
-					base = (unsigned int)__shfl((int)base, leader);
-					const unsigned int idx = base + (unsigned int)__popcll(act & ((1ull << lane) - 1ull));
-					if (idx >= qcap) return false;          // queue full: this branch is followed right here
-					Mm1Task<TOff> tk; tk.list = (uint32_t)gid; tk.dep = (uint16_t)dep; tk.j = (uint8_t)j; tk.pad = 0; tk.top = t; tk.bot = b; tk.topp = tp; tk.botp = bp;
-					queue[idx] = tk;
-					return true;
-				};
-				fm_one_mm_dir(ix, P, (int64_t)rp.minsc, rp.nceil, g, len, ns, fw, ebwtfw, emit, c, defer);
-			}
-		}
+		GlobRd g; g.init(rd.d_seq + o0, rd.d_qual + o0, len);
+		Mm1Hit* dst = out + (uint64_t)gid * cap;
+		auto emit = [&](const Mm1Hit& m) { const unsigned int pos = atomicAdd(&out_cnt[gid], 1u); if (pos < cap) dst[pos] = m; };
+		auto defer = [&](uint32_t dep, int j, TOff t, TOff b, TOff tp, TOff bp) -> bool {
+			// one atomic per group of lanes that arrive here together
+			const unsigned long long act = __ballot(1);
+			const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)act) - 1;
+			unsigned int base = 0;
+			if (lane == leader) base = atomicAdd(qcount, (unsigned int)__popcll(act));
+			base = (unsigned int)__shfl((int)base, leader);
+			const unsigned int idx = base + (unsigned int)__popcll(act & ((1ull << lane) - 1ull));
+			if (idx >= qcap) return false;          // queue full: this branch is followed right here
+			Mm1Task<TOff> tk; tk.list = gid; tk.dep = (uint16_t)dep; tk.j = (uint8_t)j; tk.pad = 0; tk.top = t; tk.bot = b; tk.topp = tp; tk.botp = bp;
+			queue[idx] = tk;
+			return true;
+		};
+		fm_one_mm_dir(ix, P, (int64_t)rp.minsc, rp.nceil, g, len, ns, fw, ebwtfw, emit, c, defer);
 	}
-	wave_add_counter(&cnt->rank_queries, c.sides);
-	wave_add_counter(&cnt->bwops, c.bwops);
+	wave_add_counter(&cnt_slot(cnt)->rank_queries, c.sides);
+	wave_add_counter(&cnt_slot(cnt)->bwops, c.bwops);
 }
 
 template <typename TOff>
@@ -464,13 +617,13 @@ k_one_mm_cont(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_
 		const bool fw = ((tk.list >> 1) & 1) == 0, ebwtfw = (tk.list & 1) == 0;
 		const uint64_t o0 = rd.d_off[r];
 		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
-		GlobRd g; g.s = rd.d_seq + o0; g.q = rd.d_qual + o0;
+		GlobRd g; g.init(rd.d_seq + o0, rd.d_qual + o0, len);
 		Mm1Hit* dst = out + (uint64_t)tk.list * cap;
 		fm_one_mm_cont(ix, P, (int64_t)rparams[r].minsc, g, len, fw, ebwtfw, (uint32_t)tk.dep, (int)tk.j, tk.top, tk.bot, tk.topp, tk.botp,
 			[&](const Mm1Hit& m) { const unsigned int pos = atomicAdd(&out_cnt[tk.list], 1u); if (pos < cap) dst[pos] = m; }, c);
 	}
-	wave_add_counter(&cnt->rank_queries, c.sides);
-	wave_add_counter(&cnt->bwops, c.bwops);
+	wave_add_counter(&cnt_slot(cnt)->rank_queries, c.sides);
+	wave_add_counter(&cnt_slot(cnt)->bwops, c.bwops);
 }
 
 // discovery order of a list = increasing depth from the end the search direction starts at, then reference character; the
@@ -501,14 +654,17 @@ k_one_mm_fin(uint32_t n_lists, uint32_t cap, Mm1Hit* __restrict__ out, const uns
 template <typename TOff>
 hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, const bt2g_reads& rd, const bt2g_read_params* d_rparams,
                          const bt2g_sweep_out* d_sweep, uint32_t cap, void* d_out, uint8_t* d_out_n, unsigned int* d_out_cnt,
-                         void* d_queue, uint32_t qcap, unsigned int* d_qcount, DevCounters* d_cnt, hipStream_t st) {
+                         void* d_queue, uint32_t qcap, unsigned int* d_qcount, uint32_t* d_tasks, DevCounters* d_cnt, hipStream_t st) {
 	const uint64_t total = (uint64_t)rd.n_reads * 4;
 	if (total == 0) return hipSuccess;
+	if (total >= 0x80000000ull) return hipErrorInvalidValue;      // (list ids carry a flag in bit 31)
+	unsigned int* d_tcount = d_qcount + 1;      // the two counters of a launch sit side by side (bt2g_capi.hip hands out d_next + 12)
 	hipError_t e = hipMemsetAsync(d_out_cnt, 0, total * sizeof(unsigned int), st);
-	if (e == hipSuccess) e = hipMemsetAsync(d_qcount, 0, sizeof(unsigned int), st);
+	if (e == hipSuccess) e = hipMemsetAsync(d_qcount, 0, 2 * sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
 	const uint64_t grid = (total + 255) / 256;
-	hipLaunchKernelGGL(k_one_mm_scan<TOff>, dim3((uint32_t)grid), dim3(256), 0, st, ix, P, rd, d_rparams, d_sweep, cap, (Mm1Hit*)d_out, d_out_cnt,
+	hipLaunchKernelGGL(k_one_mm_tasks, dim3((uint32_t)((total / 2 + 255) / 256)), dim3(256), 0, st, P, rd, d_rparams, d_sweep, d_tasks, d_tcount);
+	hipLaunchKernelGGL(k_one_mm_scan<TOff>, dim3(256 * 8), dim3(256), 0, st, ix, P, rd, d_rparams, (const uint32_t*)d_tasks, (const unsigned int*)d_tcount, cap, (Mm1Hit*)d_out, d_out_cnt,
 	                   (Mm1Task<TOff>*)d_queue, d_qcount, qcap, d_cnt);
 	hipLaunchKernelGGL(k_one_mm_cont<TOff>, dim3(256 * 32), dim3(256), 0, st, ix, P, rd, d_rparams, cap, (Mm1Hit*)d_out, d_out_cnt,
 	                   (const Mm1Task<TOff>*)d_queue, (const unsigned int*)d_qcount, qcap, d_cnt);
@@ -519,8 +675,8 @@ uint64_t one_mm_task_bytes(int off_size) { return off_size == 4 ? sizeof(Mm1Task
 
 template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t);
 template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t);
-template hipError_t launch_one_mm<uint32_t>(const DevIndex<uint32_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, unsigned int*, void*, uint32_t, unsigned int*, DevCounters*, hipStream_t);
-template hipError_t launch_one_mm<uint64_t>(const DevIndex<uint64_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, unsigned int*, void*, uint32_t, unsigned int*, DevCounters*, hipStream_t);
+template hipError_t launch_one_mm<uint32_t>(const DevIndex<uint32_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, unsigned int*, void*, uint32_t, unsigned int*, uint32_t*, DevCounters*, hipStream_t);
+template hipError_t launch_one_mm<uint64_t>(const DevIndex<uint64_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, unsigned int*, void*, uint32_t, unsigned int*, uint32_t*, DevCounters*, hipStream_t);
 
 // ------------------------------------------------------------------------------------
 // max over the batch of the number of round-0 seeds per strand (sizes the pre-computation buffers)

@@ -33,7 +33,7 @@ hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, co
 template <typename TOff>
 hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, const bt2g_reads& rd, const bt2g_read_params* d_rparams,
                          const bt2g_sweep_out* d_sweep, uint32_t cap, void* d_out, uint8_t* d_out_n, unsigned int* d_out_cnt,
-                         void* d_queue, uint32_t qcap, unsigned int* d_qcount, DevCounters* d_cnt, hipStream_t st);
+                         void* d_queue, uint32_t qcap, unsigned int* d_qcount, uint32_t* d_tasks, DevCounters* d_cnt, hipStream_t st);      // d_qcount: two counters (branch queue, task list); d_tasks: [n_reads * 4]
 uint64_t one_mm_task_bytes(int off_size);
 
 template <typename TOff>

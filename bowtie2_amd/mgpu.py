@@ -127,6 +127,21 @@ def split_args(argv):
     return args, found
 
 
+def usable_cores():
+    """Cores this process may run on: the affinity mask, clipped by the cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def default_engine(found):
     here = os.path.dirname(os.path.abspath(__file__))
     base = found.get("index")
@@ -337,6 +352,10 @@ def main(argv=None):
     merge_failed = 0
     try:
         common = [engine] + args + ["--shard-index", idx, "--pg-cmdline", pg]
+        if not any(a in ("-p", "--threads") or a.startswith("--threads=") for a in args):
+            # host threads (FASTQ parsing, SAM formatting) of this rank's executable: its share of the cores the job may use, so that
+            # N ranks do not each start as many threads as the node has cores
+            common += ["-p", str(max(1, usable_cores() // max(1, world)))]
         if backend == "nccl":
             common += ["--gpu", str(local_rank)]
         if rank != 0 and "--no-hd" not in args:
