@@ -527,7 +527,8 @@ hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, co
 // restore discovery order (increasing depth, then reference character) and publish the count.  On repeat-rich reads the
 // branches outnumber the scans by two orders of magnitude and have very uneven lengths: as one flat task list they fill
 // the machine; nested inside the scan they left most lanes of a wave waiting for the slowest.
-template <typename TOff> struct Mm1Task { uint32_t list; uint16_t dep; uint8_t j, pad; TOff top, bot, topp, botp; };
+template <typename TOff> struct Mm1Task { uint32_t list; uint16_t dep; uint8_t j, pad; TOff top, bot, topp, botp; };      // list = 0xffffffff: an unused slot of a chunk
+constexpr uint32_t kQChunk = 64;
 
 // entry of the scan's task list: list id = read * 4 + strand * 2 + index direction, bit 31 = the read holds one N
 __global__ void __launch_bounds__(256)
@@ -570,6 +571,9 @@ k_one_mm_scan(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_
               const uint32_t* __restrict__ tasks, const unsigned int* __restrict__ tcount, uint32_t cap, Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt,
               Mm1Task<TOff>* __restrict__ queue, unsigned int* __restrict__ qcount, uint32_t qcap, DevCounters* cnt) {
 	FmCount c; c.bwops = 0; c.sides = 0;
+	__shared__ uint32_t s_qbase[4], s_qused[4];      // per wave: the chunk of the branch queue it is filling
+	if ((threadIdx.x & 63) == 0) { s_qbase[threadIdx.x >> 6] = 0; s_qused[threadIdx.x >> 6] = kQChunk; }
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 	const unsigned int nt = *tcount;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (uint64_t ti = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ti < nt; ti += stride) {
@@ -585,19 +589,38 @@ k_one_mm_scan(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_
 		Mm1Hit* dst = out + (uint64_t)gid * cap;
 		auto emit = [&](const Mm1Hit& m) { const unsigned int pos = atomicAdd(&out_cnt[gid], 1u); if (pos < cap) dst[pos] = m; };
 		auto defer = [&](uint32_t dep, int j, TOff t, TOff b, TOff tp, TOff bp) -> bool {
-			// one atomic per group of lanes that arrive here together
+			// Queue space comes in chunks of kQChunk slots that a WAVE reserves with one atomic and then hands out from LDS: every branch of
+			// every lane used to go through one global counter (an atomic with return per group of lanes arriving together, ~2 M of them per
+			// launch, serialised by the L2 channel that owns the word).  What a wave leaves unused of a chunk is marked invalid.
 			const unsigned long long act = __ballot(1);
 			const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)act) - 1;
-			unsigned int base = 0;
-			if (lane == leader) base = atomicAdd(qcount, (unsigned int)__popcll(act));
-			base = (unsigned int)__shfl((int)base, leader);
-			const unsigned int idx = base + (unsigned int)__popcll(act & ((1ull << lane) - 1ull));
-			if (idx >= qcap) return false;          // queue full: this branch is followed right here
+			const uint32_t wv = threadIdx.x >> 6;
+			unsigned int idx0 = 0xffffffffu;
+			if (lane == leader) {
+				const uint32_t n = (uint32_t)__popcll(act);
+				uint32_t used = s_qused[wv], base = s_qbase[wv];
+				if (used + n > kQChunk) {
+					for (uint32_t k = used; k < kQChunk; k++) queue[base + k].list = 0xffffffffu;      // (used == kQChunk before the first chunk)
+					base = atomicAdd(qcount, kQChunk); used = 0;
+					if ((uint64_t)base + kQChunk > (uint64_t)qcap) { base = 0; used = kQChunk; s_qbase[wv] = 0; s_qused[wv] = kQChunk; }      // queue full
+					else s_qbase[wv] = base;
+				}
+				if (used + n <= kQChunk) { s_qused[wv] = used + n; idx0 = base + used; }
+			}
+			idx0 = (unsigned int)__shfl((int)idx0, leader);
+			if (idx0 == 0xffffffffu) return false;          // queue full: this branch is followed right here
+			const unsigned int idx = idx0 + (unsigned int)__popcll(act & ((1ull << lane) - 1ull));
 			Mm1Task<TOff> tk; tk.list = gid; tk.dep = (uint16_t)dep; tk.j = (uint8_t)j; tk.pad = 0; tk.top = t; tk.bot = b; tk.topp = tp; tk.botp = bp;
 			queue[idx] = tk;
 			return true;
 		};
 		fm_one_mm_dir(ix, P, (int64_t)rp.minsc, rp.nceil, g, len, ns, fw, ebwtfw, emit, c, defer);
+	}
+	// the rest of the wave's last chunk holds no branch
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	{
+		const uint32_t wv = threadIdx.x >> 6, used = s_qused[wv], base = s_qbase[wv];
+		for (uint32_t k = used + (threadIdx.x & 63); k < kQChunk; k += 64) queue[base + k].list = 0xffffffffu;
 	}
 	wave_add_counter(&cnt_slot(cnt)->rank_queries, c.sides);
 	wave_add_counter(&cnt_slot(cnt)->bwops, c.bwops);
@@ -609,10 +632,12 @@ k_one_mm_cont(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_
               Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt, const Mm1Task<TOff>* __restrict__ queue,
               const unsigned int* __restrict__ qcount, uint32_t qcap, DevCounters* cnt) {
 	FmCount c; c.bwops = 0; c.sides = 0;
-	const unsigned int nq = *qcount < qcap ? *qcount : qcap;
+	const unsigned int qfull = qcap & ~(kQChunk - 1u);      // whole chunks only: a chunk that did not fit was never handed out
+	const unsigned int nq = *qcount < qfull ? *qcount : qfull;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
 		const Mm1Task<TOff> tk = queue[i];
+		if (tk.list == 0xffffffffu) continue;
 		const uint32_t r = tk.list >> 2;
 		const bool fw = ((tk.list >> 1) & 1) == 0, ebwtfw = (tk.list & 1) == 0;
 		const uint64_t o0 = rd.d_off[r];
