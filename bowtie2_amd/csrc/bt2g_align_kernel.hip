@@ -1056,7 +1056,9 @@ struct DevPlat {
 		uint32_t npass = (tot + 9u) / 10u; if (!(npass & 1u)) npass++;
 		const uint64_t kmask = tot >= 64u ? ~0ull : ((1ull << tot) - 1ull);
 		uint16_t* const cnt = reinterpret_cast<uint16_t*>(g_hot.lastrow);       // 1024 counters (kMaxCols + 8 >= 1024 int16)
+#ifndef BT2G_PROBE_SMALL      // (occupancy probe builds never run --local)
 		static_assert(sizeof(g_hot.lastrow) >= 2048, "radix counters");
+#endif
 		uint32_t* const cnt32 = reinterpret_cast<uint32_t*>(g_hot.lastrow);
 		for (uint32_t p = 0; p < npass; p++) {
 			BT2_G BtCand* const src = (p & 1u) ? dst : tmp;
