@@ -293,11 +293,14 @@ def write_fastq_fixed(path, seq, qual, names):
 CONFIGS = {
     "se150":    {"args": ["--sensitive"], "paired": False, "readlen": 150, "reads": 2_000_000, "cpu_sample": 1_000_000,
                  "what": "--sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"},
-    "pe-sens":  {"args": ["--sensitive"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 400_000,
+    # "pipeline": steps in flight.  A batch of pairs or of long --local reads ends in a tail -- a few pathological reads keep a handful of the
+    # 4096 waves busy for hundreds of ms after the rest are done -- which the next batch's waves fill when two batches are in flight (as in
+    # the product driver, whose device-stage threads each issue their batch on their own stream).  The headline has no such tail: 1.
+    "pe-sens":  {"args": ["--sensitive"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 400_000, "pipeline": 3,
                  "what": "pairs, --sensitive, --fr -I 0 -X 500"},
-    "pe-vsens": {"args": ["--very-sensitive", "-X", "500"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 200_000,
+    "pe-vsens": {"args": ["--very-sensitive", "-X", "500"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 200_000, "pipeline": 3,
                  "what": "pairs, --very-sensitive (-D 20 -R 3 -N 0 -L 20 -i S,1,0.50), --fr -I 0 -X 500 (mate rescue)"},
-    "local400": {"args": ["--local"], "paired": False, "readlen": 400, "reads": 200_000, "cpu_sample": 100_000,
+    "local400": {"args": ["--local"], "paired": False, "readlen": 400, "reads": 200_000, "cpu_sample": 100_000, "pipeline": 2,
                  "what": "--local = --sensitive-local (-D 15 -R 2 -N 0 -L 20 -i S,1,0.75, --ma 2, --score-min G,20,8)"},
     # BASELINE.json configs[1]: a bacterial genome behind a small (.bt2: 64-byte sides, 32-bit offsets) index -- the uint32_t instantiations
     "ecoli100": {"args": ["--sensitive"], "paired": False, "readlen": 100, "reads": 1_000_000, "cpu_sample": 1_000_000, "genome": "ecoli",
@@ -486,6 +489,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference run (no cpu_baseline, no SAM parity)")
     ap.add_argument("--parity-only", action="store_true", help="run the reference once, for the SAM comparison only (cpu_baseline then comes from one run)")
     ap.add_argument("--paired", action="store_true", help="same as --config pe-sens: the paired kernel at --sensitive (round-2 line)")
+    ap.add_argument("--pipeline", type=int, default=0, help="steps in flight (on that many streams; the context keeps a working set per stream): 0 = the config's default")
     args = ap.parse_args()
     if args.paired:
         args.config = "pe-sens"
@@ -497,6 +501,8 @@ def main():
         args.readlen = cfg["readlen"]
     if not args.cpu_sample:
         args.cpu_sample = cfg["cpu_sample"]
+    if not args.pipeline:
+        args.pipeline = cfg.get("pipeline", 1)
 
     import numpy as np
     import torch
@@ -566,20 +572,34 @@ def main():
     stage_events = []
     last = {}
     kern_times = []
+    depth = max(1, args.pipeline) if dist is None else 1      # (the N-GPU path keeps one step in flight: its RCCL gather sits inside the step)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
+    for s_ in streams:
+        s_.wait_stream(torch.cuda.current_stream())
+    issued = [0] * depth
+    step_no = [0]
 
     def step(record):
-        e0, e1 = ev(), ev()
-        e0.record()
-        res, stride = ctx.align_batch(batch, rp_t, P, args.readlen)
-        if dist is not None:
-            # N-GPU path: the per-GPU result records are cut to size and merged on rank 0 over RCCL (the only exchange of the job)
-            packed, offs = ctx.results_pack(res, n, P.khits)
-            last["gathered"] = shard.gather_packed(dist, packed, int(offs[n].item()), dev)
-        e1.record()
-        if record:
-            stage_events.append((e0, e1))
-            kern_times.append(ctx.align_timing())      # HIP events recorded by the library around each kernel
-        last["res"], last["stride"] = res, stride
+        k = step_no[0] % depth
+        step_no[0] += 1
+        with torch.cuda.stream(streams[k]):
+            if depth > 1 and record and issued[k]:
+                # the batch issued `depth` steps ago on this stream: its kernel times (blocks until it is done -- the pipeline's backpressure)
+                kern_times.append(ctx.align_timing(on_current_stream=True))
+            e0, e1 = ev(), ev()
+            e0.record()
+            res, stride = ctx.align_batch(batch, rp_t, P, args.readlen)
+            if dist is not None:
+                # N-GPU path: the per-GPU result records are cut to size and merged on rank 0 over RCCL (the only exchange of the job)
+                packed, offs = ctx.results_pack(res, n, P.khits)
+                last["gathered"] = shard.gather_packed(dist, packed, int(offs[n].item()), dev)
+            e1.record()
+            issued[k] = 1 if record else 0
+            if record:
+                stage_events.append((e0, e1))
+                if depth == 1:
+                    kern_times.append(ctx.align_timing())      # HIP events recorded by the library around each kernel
+            last["res"], last["stride"] = res, stride
 
     def sync_all():
         torch.cuda.synchronize()
@@ -598,6 +618,12 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     dt = shard.reduce_max(dist, dt, dev)      # the slowest rank defines the step time
+    if depth > 1:
+        for k in range(depth):                # the last batch of every stream
+            if issued[k]:
+                with torch.cuda.stream(streams[k]):
+                    kern_times.append(ctx.align_timing(on_current_stream=True))
+                issued[k] = 0
     batch_ms = sum(a.elapsed_time(bb) for a, bb in stage_events) / len(stage_events)
     kavg = {k: sum(t[k] for t in kern_times) / len(kern_times) for k in kern_times[0]}
     kern_ms = kavg["k_align_reads"]
@@ -683,6 +709,8 @@ def main():
                                " = hg38 scale" if args.genome_mbp >= 3000 else "", N_CHROMS, ext, side, off_sz, n, args.readlen,
                                "reads as %d pairs" % (n // 2) if args.paired else "SE reads", cfg["what"]),
                 "config_name": args.config, "command_line": " ".join(cfg["args"]),
+                "steps_in_flight": depth,
+                "steps_in_flight_note": None if depth == 1 else "the timed steps are issued on %d alternating streams (one working set of the context each), so that a batch's tail is filled by the next batch, as in the product driver; kernel_ms_per_step are the HIP-event durations of the kernels on their own stream and overlap in time" % depth,
                 "stages_timed": "one bt2g_align_batch per step = the whole per-read worker: k_exact_sweep, k_one_mm, k_seed_search_exact, k_extend_hits (lane-per-task FM kernels) then k_align_reads "
                                 "(rank+prioritise, offset resolution, re-seeding, SW fill + backtrace, -M reporting)",
                 "not_in_timed_region": "FASTQ parse and SAM text formatting (host side, SURVEY.md 8f)",

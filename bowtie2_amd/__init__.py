@@ -138,6 +138,7 @@ ABI = [
     ("bt2g_counters_read", C.c_int, [_vp, C.POINTER(Counters), C.c_int, _vp]),
     ("bt2g_align_profile_read", C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
     ("bt2g_align_timing_read", C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ("bt2g_align_timing_read_on", C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     ("bt2g_align_result_stride", C.c_uint64, [C.c_uint32]),
     ("bt2g_align_batch", C.c_int, [_vp, C.POINTER(Reads), _vp, C.POINTER(AlignParams), C.c_uint32, _vp, _vp]),
     ("bt2g_results_pack", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
@@ -291,10 +292,14 @@ class Context:
                                                  _stream_ptr()), "bt2g_results_pack")
         return packed, offs
 
-    def align_timing(self):
-        """ms per kernel of the last align batch: dict(sweep, one_mm, seeds, extend, align)"""
+    def align_timing(self, on_current_stream=False):
+        """ms per kernel of the last align batch (of the last one issued on torch's current stream with on_current_stream):
+        dict(sweep, one_mm, seeds, extend, align)"""
         out = (C.c_float * 5)()
-        _check(self._h, lib().bt2g_align_timing_read(self._h, out), "bt2g_align_timing_read")
+        if on_current_stream:
+            _check(self._h, lib().bt2g_align_timing_read_on(self._h, _stream_ptr(), out), "bt2g_align_timing_read_on")
+        else:
+            _check(self._h, lib().bt2g_align_timing_read(self._h, out), "bt2g_align_timing_read")
         return dict(zip(["k_exact_sweep", "k_one_mm", "k_seed_search_exact", "k_extend_hits", "k_align_reads"], [float(x) for x in out]))
 
     def align_profile(self, reset=False):

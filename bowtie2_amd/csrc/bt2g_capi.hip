@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -33,14 +34,26 @@ struct bt2g_ctx {
 	uint8_t* d_dp_scratch = nullptr;     // wavefront-layout DP scratch
 	uint64_t dp_scratch_bytes = 0;
 	uint32_t n_cu = 0;
-	uint8_t* d_arena = nullptr;          // per-wave Work + DP scratch of the fused worker
-	uint64_t arena_bytes = 0;
-	uint64_t arena_layout = 0;           // fingerprint of the arena's carving (epoch-tagged masks are only valid within one)
-	unsigned int* d_next = nullptr;      // work-queue head
-	uint8_t* d_pre = nullptr;            // batch pre-computation (sweep, round-0 seed hits, extensions, 1-mm hits)
-	uint64_t pre_bytes = 0;
-	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel boundaries of the last align batch
-	bool ev_valid = false;
+	// What one bt2g_align_batch call works in.  A context keeps one such set PER STREAM it has been called on (up to kMaxSlots), so that
+	// batches issued on different streams -- the product driver's device-stage threads, bench.py's two alternating streams -- run side by
+	// side: the copies of one overlap the kernels of another, and the tail of one batch's worker kernel (a few pathological reads can keep
+	// a handful of waves busy long after the rest of the batch is done) is filled by the next batch's waves.
+	struct BatchSlot {
+		hipStream_t owner = nullptr;
+		bool used = false;
+		uint8_t* d_arena = nullptr;          // per-wave Work + DP scratch of the fused worker
+		uint64_t arena_bytes = 0;
+		uint64_t arena_layout = 0;           // fingerprint of the arena's carving (epoch-tagged masks are only valid within one)
+		unsigned int* d_next = nullptr;      // work-queue head, small counters, the worker's phase profile
+		uint8_t* d_pre = nullptr;            // batch pre-computation (sweep, round-0 seed hits, extensions, 1-mm hits)
+		uint64_t pre_bytes = 0;
+		hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel boundaries of the last align batch
+		bool ev_valid = false;
+	};
+	static constexpr int kMaxSlots = 4;
+	BatchSlot slots[kMaxSlots];
+	std::mutex slot_mu;
+	int last_slot = -1;                  // slot of the most recent bt2g_align_batch (bt2g_align_timing_read)
 	bool precomp = true;                 // BT2G_NO_PRECOMP=1: the worker computes every FM phase itself (A/B testing)
 };
 
@@ -197,10 +210,12 @@ void bt2g_ctx_destroy(bt2g_ctx* c) {
 	free_index(c);
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
 	if (c->d_dp_scratch) (void)hipFree(c->d_dp_scratch);
-	if (c->d_arena) (void)hipFree(c->d_arena);
-	if (c->d_pre) (void)hipFree(c->d_pre);
-	for (int i = 0; i < 7; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-	if (c->d_next) (void)hipFree(c->d_next);
+	for (auto& S : c->slots) {
+		if (S.d_arena) (void)hipFree(S.d_arena);
+		if (S.d_pre) (void)hipFree(S.d_pre);
+		for (int i = 0; i < 7; i++) if (S.ev[i]) (void)hipEventDestroy(S.ev[i]);
+		if (S.d_next) (void)hipFree(S.d_next);
+	}
 	delete c;
 }
 
@@ -358,6 +373,16 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (reads->n_reads == 0) return 0;
 	if (max_read_len > BT2G_MAX_READ_LEN) max_read_len = BT2G_MAX_READ_LEN;
 	hipStream_t st = (hipStream_t)stream;
+	// the working set of this stream (created on the stream's first batch)
+	int si = -1;
+	{
+		std::lock_guard<std::mutex> g(c->slot_mu);
+		for (int i = 0; i < bt2g_ctx::kMaxSlots && si < 0; i++) if (c->slots[i].used && c->slots[i].owner == st) si = i;
+		for (int i = 0; i < bt2g_ctx::kMaxSlots && si < 0; i++) if (!c->slots[i].used) { si = i; c->slots[i].used = true; c->slots[i].owner = st; }
+		if (si < 0) return fail(c, BT2G_ERR_ARG, "bt2g_align_batch has been called on more streams than a context keeps working sets for");
+		c->last_slot = si;
+	}
+	bt2g_ctx::BatchSlot& S = c->slots[si];
 	uint64_t mat_bytes, mask_bytes, pmask_bytes, arena_stride;
 	if (params->paired && (reads->n_reads & 1u)) return fail(c, BT2G_ERR_ARG, "paired mode needs an even number of reads (mates interleaved)");
 	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
@@ -366,40 +391,40 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
 	const uint64_t need = arena_stride * n_waves;
 	hipError_t e;
-	if (need > c->arena_bytes) {
-		if (c->d_arena) (void)hipFree(c->d_arena);
-		c->d_arena = nullptr; c->arena_bytes = 0;
-		e = hipMalloc((void**)&c->d_arena, need);
+	if (need > S.arena_bytes) {
+		if (S.d_arena) (void)hipFree(S.d_arena);
+		S.d_arena = nullptr; S.arena_bytes = 0;
+		e = hipMalloc((void**)&S.d_arena, need);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(worker arena)");
-		c->arena_bytes = need;
-		c->arena_layout = 0;
+		S.arena_bytes = need;
+		S.arena_layout = 0;
 	}
 	// the epoch-tagged backtrace masks live in the arena across launches: (re)start from zero whenever its layout changes
 	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0);
-	if (layout != c->arena_layout) {
-		e = hipMemsetAsync(c->d_arena, 0, c->arena_bytes, st);
+	if (layout != S.arena_layout) {
+		e = hipMemsetAsync(S.d_arena, 0, S.arena_bytes, st);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(worker arena)");
-		c->arena_layout = layout;
+		S.arena_layout = layout;
 	}
-	if (!c->d_next) {
-		e = hipMalloc((void**)&c->d_next, 1024);
+	if (!S.d_next) {
+		e = hipMalloc((void**)&S.d_next, 1024);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(queue head)");
-		(void)hipMemset(c->d_next, 0, 1024);
+		(void)hipMemset(S.d_next, 0, 1024);
 	}
 	// The pure FM phases of every read (exact sweep, 1-mismatch search, seed round 0 and its seed-hit
 	// extension) run first as lane-per-task kernels; the per-read worker then consumes their output.
 	PreComp pre;
 	memset(&pre, 0, sizeof(pre));
-	if (!c->ev[0]) for (int i = 0; i < 7; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(c, BT2G_ERR_HIP, "hipEventCreate");
-	c->ev_valid = false;
-	auto mark = [&](int i) { (void)hipEventRecord(c->ev[i], st); };
+	if (!S.ev[0]) for (int i = 0; i < 7; i++) if (hipEventCreate(&S.ev[i]) != hipSuccess) return fail(c, BT2G_ERR_HIP, "hipEventCreate");
+	S.ev_valid = false;
+	auto mark = [&](int i) { (void)hipEventRecord(S.ev[i], st); };
 	mark(0);
 	if (c->precomp) {
 		unsigned int max_seeds = params->max_seeds > 0 ? (unsigned int)params->max_seeds : 0u;
 		if (max_seeds == 0) {
 			// no bound from the caller: count on the device and wait for the number (the only host-device round trip of a batch)
-			e = launch_max_seeds(*reads, d_rparams, c->d_next + 8, st);
-			if (e == hipSuccess) e = hipMemcpyAsync(&max_seeds, c->d_next + 8, sizeof(max_seeds), hipMemcpyDeviceToHost, st);
+			e = launch_max_seeds(*reads, d_rparams, S.d_next + 8, st);
+			if (e == hipSuccess) e = hipMemcpyAsync(&max_seeds, S.d_next + 8, sizeof(max_seeds), hipMemcpyDeviceToHost, st);
 			if (e == hipSuccess) e = hipStreamSynchronize(st);
 			if (e != hipSuccess) return hip_fail(c, e, "k_max_seeds");
 		}
@@ -424,14 +449,14 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		uint32_t pre_rounds = 1;
 		if (params->seed_mms == 0 && !params->paired && params->n_seed_rounds > 1) pre_rounds = (uint32_t)params->n_seed_rounds < kMaxPreRounds ? (uint32_t)params->n_seed_rounds : kMaxPreRounds;
 		const uint64_t tot = b_sweep + (b_seeds + b_ext + b_joff) * pre_rounds + b_mm1 + b_mm1n + b_mm1c + b_mm1q + b_mm1t;
-		if (tot > c->pre_bytes) {
-			if (c->d_pre) (void)hipFree(c->d_pre);
-			c->d_pre = nullptr; c->pre_bytes = 0;
-			e = hipMalloc((void**)&c->d_pre, tot);
+		if (tot > S.pre_bytes) {
+			if (S.d_pre) (void)hipFree(S.d_pre);
+			S.d_pre = nullptr; S.pre_bytes = 0;
+			e = hipMalloc((void**)&S.d_pre, tot);
 			if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(pre-computation)");
-			c->pre_bytes = tot;
+			S.pre_bytes = tot;
 		}
-		uint8_t* p = c->d_pre;
+		uint8_t* p = S.d_pre;
 		bt2g_sweep_out* d_sweep = (bt2g_sweep_out*)p; p += b_sweep;
 		bt2g_seed_hit* d_seeds = (bt2g_seed_hit*)p; p += b_seeds;
 		uint64_t* d_joff = (uint64_t*)p; p += b_joff;
@@ -450,8 +475,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 				unsigned int* d_mm1c = (unsigned int*)(d_mm1n + b_mm1n);
 				void* d_mm1q = d_mm1n + b_mm1n + b_mm1c;
 				uint32_t* d_mm1t = (uint32_t*)(d_mm1n + b_mm1n + b_mm1c + b_mm1q);
-				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, d_mm1t, c->d_cnt, st)
-				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, c->d_next + 12, d_mm1t, c->d_cnt, st);
+				e = s ? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, S.d_next + 12, d_mm1t, c->d_cnt, st)
+				      : launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, d_mm1, d_mm1n, d_mm1c, d_mm1q, (uint32_t)qcap64, S.d_next + 12, d_mm1t, c->d_cnt, st);
 				if (e != hipSuccess) return hip_fail(c, e, "k_one_mm");
 				pre.mm1 = (decltype(pre.mm1))d_mm1; pre.mm1_n = (decltype(pre.mm1_n))d_mm1n;
 			}
@@ -496,11 +521,11 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	mark(5);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	e = (c->off_size == 4)
-		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, max_read_len, st)
-		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, c->d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, c->d_next, (unsigned long long*)(c->d_next + 16), pre, max_read_len, st);
+		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, st)
+		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, st);
 	if (e != hipSuccess) return hip_fail(c, e, "k_align_reads");
 	mark(6);
-	c->ev_valid = true;
+	S.ev_valid = true;
 	return 0;
 }
 
@@ -513,20 +538,33 @@ int bt2g_results_pack(bt2g_ctx* c, const void* d_results, uint32_t n_reads, uint
 	return e == hipSuccess ? 0 : hip_fail(c, e, "k_pack_results");
 }
 
-int bt2g_align_timing_read(bt2g_ctx* c, float* out_ms5) {
-	if (!c || !out_ms5) return BT2G_ERR_ARG;
+static int timing_of_slot(bt2g_ctx* c, int si, float* out_ms5) {
 	for (int i = 0; i < 5; i++) out_ms5[i] = 0.f;
-	if (!c->ev_valid) return fail(c, BT2G_ERR_ARG, "no align batch has been launched");
+	if (si < 0 || !c->slots[si].ev_valid) return fail(c, BT2G_ERR_ARG, "no align batch has been launched");
 	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
-	hipError_t e = hipEventSynchronize(c->ev[6]);
+	bt2g_ctx::BatchSlot& S = c->slots[si];
+	hipError_t e = hipEventSynchronize(S.ev[6]);
 	if (e != hipSuccess) return hip_fail(c, e, "hipEventSynchronize");
 	// k_exact_sweep, k_one_mm, k_seed_search_exact, k_extend_hits, k_align_reads
 	const int a[5] = {0, 1, 2, 3, 5}, b[5] = {1, 2, 3, 4, 6};
 	for (int i = 0; i < 5; i++) {
-		e = hipEventElapsedTime(&out_ms5[i], c->ev[a[i]], c->ev[b[i]]);
+		e = hipEventElapsedTime(&out_ms5[i], S.ev[a[i]], S.ev[b[i]]);
 		if (e != hipSuccess) return hip_fail(c, e, "hipEventElapsedTime");
 	}
 	return 0;
+}
+int bt2g_align_timing_read(bt2g_ctx* c, float* out_ms5) {
+	if (!c || !out_ms5) return BT2G_ERR_ARG;
+	return timing_of_slot(c, c->last_slot, out_ms5);
+}
+int bt2g_align_timing_read_on(bt2g_ctx* c, void* stream, float* out_ms5) {
+	if (!c || !out_ms5) return BT2G_ERR_ARG;
+	int si = -1;
+	{
+		std::lock_guard<std::mutex> g(c->slot_mu);
+		for (int i = 0; i < bt2g_ctx::kMaxSlots; i++) if (c->slots[i].used && c->slots[i].owner == (hipStream_t)stream) si = i;
+	}
+	return timing_of_slot(c, si, out_ms5);
 }
 
 int bt2g_align_profile_read(bt2g_ctx* c, uint64_t* out32, int reset, void* stream) {
@@ -534,11 +572,17 @@ int bt2g_align_profile_read(bt2g_ctx* c, uint64_t* out32, int reset, void* strea
 	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
 	hipStream_t st = (hipStream_t)stream;
 	memset(out32, 0, 32 * 8);
-	if (!c->d_next) return 0;
-	hipError_t e = hipMemcpyAsync(out32, c->d_next + 16, 32 * 8, hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess && reset) e = hipMemsetAsync(c->d_next + 16, 0, 32 * 8, st);
-	if (e == hipSuccess) e = hipStreamSynchronize(st);
-	return e == hipSuccess ? 0 : hip_fail(c, e, "read profile");
+	// every working set (stream) of the context has its own profile block: the sum is reported.  Call it with the batches done.
+	for (auto& S : c->slots) {
+		if (!S.d_next) continue;
+		uint64_t tmp[32];
+		hipError_t e = hipMemcpyAsync(tmp, S.d_next + 16, 32 * 8, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess && reset) e = hipMemsetAsync(S.d_next + 16, 0, 32 * 8, st);
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		if (e != hipSuccess) return hip_fail(c, e, "read profile");
+		for (int i = 0; i < 32; i++) out32[i] += tmp[i];
+	}
+	return 0;
 }
 
 int bt2g_counters_read(bt2g_ctx* c, bt2g_counters* out, int reset, void* stream) {

@@ -227,10 +227,10 @@ static int run_search(int argc, char** argv) {
 	});
 
 	// Device stage: kWorkersPerDev threads per device, each with its own stream and buffers, so that one batch's
-	// upload and another's download overlap the alignment of a third.  The context (its work arenas) is used by
-	// one thread at a time; the writer puts the batches back in input order.
+	// upload and another's download overlap the alignment of a third -- and so do the alignments themselves: the context
+	// keeps one working set per stream (bt2g_align_batch), the kernels of the batches in flight share the device, and the
+	// tail of one batch's worker kernel is filled by the next batch's waves.  The writer puts the batches back in input order.
 	PinnedPool pinned;
-	std::vector<std::mutex> ctx_mu(ndev);
 	auto device_worker = [&](size_t d) {
 		HIP_OK(hipSetDevice(devices[d]));
 		bt2g_ctx* ctx = ctxs[d];
@@ -256,7 +256,6 @@ static int run_search(int argc, char** argv) {
 				rd.d_seq = (const uint8_t*)d_seq.p; rd.d_qual = (const uint8_t*)d_qual.p; rd.d_off = (const uint64_t*)d_off.p; rd.n_reads = (uint32_t)n;
 				HIP_OK(hipStreamSynchronize(st));
 				{
-					std::lock_guard<std::mutex> g(ctx_mu[d]);
 					auto ta = std::chrono::steady_clock::now();
 					// the host derived every read's seed parameters, so it knows the widest seed table of the batch: with the bound in
 					// the parameters bt2g_align_batch does not have to wait for the device to count them

@@ -304,6 +304,10 @@ uint64_t bt2g_align_result_stride(uint32_t khits);
 /*
  * d_rparams[n_reads]; d_results: n_reads records of bt2g_align_result_stride(khits) bytes.
  * max_read_len sizes the per-wave DP scratch (longer reads come back with status 1).
+ * Concurrency: a context keeps one working set (work arena, pre-computation tables, queue head) per stream it is called on, up to 4
+ * streams; calls on DIFFERENT streams may be made from different threads and their kernels and copies overlap (the reference overlaps
+ * I/O and alignment with its read-ahead thread and -p worker threads, pat.h:1287-1301, bt2_search.cpp:4812-4900).  Calls on the same
+ * stream are ordered by the stream.
  */
 int bt2g_align_batch(bt2g_ctx *ctx, const bt2g_reads *reads, const bt2g_read_params *d_rparams,
                      const bt2g_align_params *params, uint32_t max_read_len,
@@ -328,6 +332,8 @@ int bt2g_results_pack(bt2g_ctx *ctx, const void *d_results, uint32_t n_reads, ui
  * Blocks until that batch has finished.  Measurement aid (bench.py's roofline), no reference counterpart.
  */
 int bt2g_align_timing_read(bt2g_ctx *ctx, float *out_ms5);
+/* the same for the most recent batch issued on `stream` (a context keeps one working set per stream, see bt2g_align_batch) */
+int bt2g_align_timing_read_on(bt2g_ctx *ctx, void *stream, float *out_ms5);
 
 /*
  * Device-clock ticks (100 MHz wall clock) the fused worker spent per phase, summed over reads since the last

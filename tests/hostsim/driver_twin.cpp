@@ -98,6 +98,10 @@ static void twin_align(bt2g_ctx* c, const DevIndex<TOff>& ix, const bt2g_reads* 
 extern "C" {
 
 int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_params* d_rparams, const bt2g_align_params* params, uint32_t, void* d_results, void*) {
+	// the product's C ABI keeps a working set per stream and may be called from the driver's device-stage threads at once; the host
+	// worker behind this twin has ONE (static) working set, so the calls take turns here
+	static std::mutex one_at_a_time;
+	std::lock_guard<std::mutex> guard(one_at_a_time);
 	if (!c->loaded) { c->err = "no index loaded"; return 1; }
 	if (params->paired && (reads->n_reads & 1u)) { c->err = "paired mode needs an even number of reads (mates interleaved)"; return 1; }
 	const AlignParams& P = *(const AlignParams*)params;
