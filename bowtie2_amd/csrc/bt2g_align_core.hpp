@@ -1239,19 +1239,26 @@ struct Aligner {
 		if (nst == 0) return false;
 		int64_t dmin, dmax;
 		diag_bounds(r, dmin, dmax);
-		for (uint32_t a = 0; a < nst; a++) {
-			const BT2_G AlnRes& o = WK.alns[a];
-			if (o.refid != r.refid || (o.fw != 0) != (r.fw != 0)) continue;
-			// alignments whose diagonal ranges are disjoint share no cell
-			if (dmin > WK.red_dmax[a] || WK.red_dmin[a] > dmax) continue;
-			RowIt ia(o), ir(r);
-			int64_t l1 = 0, r1 = 0, l2 = 0, r2 = 0;
-			while (!ia.done() && !ir.done()) {
-				if (ia.i < ir.i) { ia.next(l2, r2); continue; }
-				if (ir.i < ia.i) { ir.next(l1, r1); continue; }
-				ia.next(l2, r2); ir.next(l1, r1);
-				if (l1 < r2 && l2 < r1) return true;
+		const int32_t r_refid = r.refid; const bool r_fw = r.fw != 0;
+		// every lane checks its own stored alignment (-k 20 on a repeat keeps dozens)
+		for (uint32_t a0 = 0; a0 < nst; a0 += Plat::n_lanes()) {
+			const uint32_t a = a0 + Plat::lane_id();
+			bool hit = false;
+			if (a < nst) {
+				const BT2_G AlnRes& o = WK.alns[a];
+				// alignments whose diagonal ranges are disjoint share no cell
+				if (o.refid == r_refid && (o.fw != 0) == r_fw && !(dmin > WK.red_dmax[a] || WK.red_dmin[a] > dmax)) {
+					RowIt ia(o), ir(r);
+					int64_t l1 = 0, r1 = 0, l2 = 0, r2 = 0;
+					while (!hit && !ia.done() && !ir.done()) {
+						if (ia.i < ir.i) { ia.next(l2, r2); continue; }
+						if (ir.i < ia.i) { ir.next(l1, r1); continue; }
+						ia.next(l2, r2); ir.next(l1, r1);
+						if (l1 < r2 && l2 < r1) hit = true;
+					}
+				}
 			}
+			if (Plat::any(hit)) return true;
 		}
 		return false;
 	}
@@ -2246,6 +2253,9 @@ struct Aligner {
 		finish(out);
 		HOT.t_phase[11] = ST.pf_steps; HOT.t_phase[12] = ST.pf_tiles; HOT.t_phase[14] = ST.pf_tile_t;
 		HOT.t_phase[7] = now() - t_run0_;
+#ifdef BT2G_DIAG_TICKS
+		out.n_ext_left = (uint32_t)HOT.t_phase[7]; out.n_ext_right = (uint32_t)HOT.t_phase[5]; out.n_resolve_steps = (uint32_t)HOT.t_phase[6]; out.n_sides = (uint32_t)HOT.t_phase[3];      // diagnostic build: whole read / dp fill / backtrace / rank+prioritise ticks per read
+#endif
 #ifdef BT2G_DEBUG_SATPOS
 		{
 			uint32_t* dbg = reinterpret_cast<uint32_t*>(out.alns[0].ned);

@@ -470,6 +470,10 @@ struct DevPlat {
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
 	// The worker's control code computes the same value in every lane; uni() moves such a value into a
 	// scalar register so that what is derived from it runs on the scalar ALU instead of 64 redundant lanes.
+	// lane-strided loops of the worker: which lane this is, how many there are, "did any lane say yes"
+	static __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+	static __device__ __forceinline__ uint32_t n_lanes() { return 64u; }
+	static __device__ __forceinline__ bool any(bool b) { return __ballot(b) != 0ull; }
 	static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 	static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 	static __device__ __forceinline__ uint64_t uni(uint64_t v) {

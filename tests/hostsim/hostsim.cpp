@@ -38,6 +38,10 @@ struct HostPlat {
 	template <typename TOff> static const DevIndex<TOff>& index() { return *reinterpret_cast<const DevIndex<TOff>*>(g_ixp); }
 	static uint64_t clock() { return 0; }
 	template <typename T> static T uni(T v) { return v; }
+	// lane-strided loops of the worker (one "lane" on the host)
+	static uint32_t lane_id() { return 0; }
+	static uint32_t n_lanes() { return 1; }
+	static bool any(bool b) { return b; }
 	template <typename T> static T* uni_ptr(T* p) { return p; }
 	template <typename TOff> static TOff get_offset(const DevEbwt<TOff>& e, TOff row, uint32_t& nsteps) { return bt2g::get_offset(e, row, nsteps); }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
