@@ -310,13 +310,25 @@ struct Work {
 	// ---- status / metrics ----
 };
 
+// DP scratch addressing (wavefront-major, see bt2g_kernels.hip)
+BT2_HD uint32_t dp_R(uint32_t rows) { return (rows + 63) / 64; }
+// wavefront-major, one packed word per cell: H | E<<8 | F<<16 at word index (t*R + r)*64 + lane
+BT2_HD uint64_t dp_cell(uint32_t R, uint32_t i, uint32_t j) {
+	const uint32_t l = i / R, r = i % R;
+	const uint64_t t = (uint64_t)j + l;
+	return (t * R + r) * 64 + l;
+}
+
+
 // DP scratch of one wave.  Two matrix formats:
 //  * end-to-end 8-bit mode (the common case): ONE BYTE per cell holding which predecessors are score-consistent
 //    (PB_* below), computed while the cell is filled -- the backtrace never looks at scores again.  Only the band of
 //    diagonals a valid alignment can touch exists (EeBand / pred_idx), row-major over diagonals; the backtrace gathers 64
 //    diagonal steps per fetch.  Its per-cell backtrace masks (`pmask`, 32 bits) carry an epoch tag instead of being cleared
 //    for every DP;
-//  * 16-bit end-to-end and local mode: wavefront-major packed H|E|F cells (dp_cell) + a 16-bit mask plane that is zeroed
+//  * local mode: the same byte per cell (with the local kernels' `> floor` rule folded in: a predecessor whose score is 0 is none), over
+//    the whole rectangle, in anti-diagonal order (pred_at);
+//  * 16-bit end-to-end: wavefront-major packed H|E|F cells (dp_cell) + a 16-bit mask plane that is zeroed
 //    after every fill that has candidate cells.
 struct DpScratch {
 	BT2_G uint32_t* mat;      // pred bytes (8-bit end-to-end) or packed cells
@@ -358,6 +370,10 @@ BT2_HD uint32_t ee_band_rp(uint32_t nd) {
 	return need <= 4 ? need : need <= 6 ? 6u : need <= 8 ? 8u : need <= 12 ? 12u : need <= 16 ? 16u : 0u;
 }
 BT2_HD uint64_t pred_idx(int32_t lo, uint32_t w, uint32_t i, uint32_t j) { return (uint64_t)i * w + (uint32_t)((int32_t)j - (int32_t)i + lo); }
+// The predecessor-byte matrix of a LOCAL fill covers the whole rectangle and is stored in the order its anti-diagonal fill produces it
+// (dp_cell: lane = block of R rows, step = column + lane; every store of the fill is 64 consecutive bytes).  The scratch header says which
+// form a matrix has: row width w > 0 = band form with first diagonal lo; w == 0 = anti-diagonal form with lo = rows per lane.
+BT2_HD uint64_t pred_at(int32_t lo, uint32_t w, uint32_t i, uint32_t j) { return w ? pred_idx(lo, w, i, j) : dp_cell((uint32_t)lo, i, j); }
 // bytes of the widest band a rows x cols problem can have (every diagonal of the rectangle)
 BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { uint32_t rp = ee_band_rp(rows + cols); if (rp == 0) rp = 16; return (uint64_t)rows * rp * 128; }
 
@@ -453,15 +469,6 @@ BT2_HD int max_ref_gaps(const AlignParams& P, int64_t minsc, uint32_t rdlen) {
 // read accessors: patFw / patRc / qual / qualRev (read.h:73-128)
 BT2_HD int rd_char(const HotWork& h, uint32_t len, bool fw, uint32_t i) { return fw ? h.seq[i] : comp4(h.seq[len - 1 - i]); }
 BT2_HD int rd_qual(const HotWork& h, uint32_t len, bool fw, uint32_t i) { return fw ? h.qual[i] : h.qual[len - 1 - i]; }
-
-// DP scratch addressing (wavefront-major, see bt2g_kernels.hip)
-BT2_HD uint32_t dp_R(uint32_t rows) { return (rows + 63) / 64; }
-// wavefront-major, one packed word per cell: H | E<<8 | F<<16 at word index (t*R + r)*64 + lane
-BT2_HD uint64_t dp_cell(uint32_t R, uint32_t i, uint32_t j) {
-	const uint32_t l = i / R, r = i % R;
-	const uint64_t t = (uint64_t)j + l;
-	return (t * R + r) * 64 + l;
-}
 
 } // namespace bt2g
 #endif

@@ -1322,7 +1322,7 @@ struct Aligner {
 		const uint64_t tl_ = now();
 		uint32_t nc;
 		if (mode != 2) {
-			if (mode != 0) Plat::load_last_row(ST.dp.mat, R, rows, cols, true);      // the 8-bit fill leaves the last row in HOT.lastrow itself
+			if (mode != 0) Plat::load_last_row(ST.dp.mat, R, rows, cols, true);      // (mode 1, 16-bit end to end; the 8-bit fill leaves the last row in HOT.lastrow itself)
 			HOT.t_phase[15] += now() - tl_;
 			// btncand_.sort(): score desc, (row desc,) col desc (DpBtCandidate::operator<)
 			nc = Plat::gather_sort(cand_list(), (uint32_t)kMaxCands, rows, cols, minsc_dp);
@@ -1337,7 +1337,7 @@ struct Aligner {
 		HOT.t_phase[13] += HOT.n_cands;      // profile: candidate cells
 		if (HOT.n_cands > 0) {      // SSEMatrix::initMasks
 			const uint64_t tz_ = now();
-			if (mode == 0) {
+			if (mode != 1) {
 				// pred format: a new epoch invalidates every mask word of earlier DPs; the plane is only cleared when the tag wraps
 				uint32_t e = Plat::uni(*ST.dp.epoch) + 1;
 				if (e > kEpochMax) { Plat::zero_u32(ST.dp.pmask, ST.dp.pmask_words); e = 1; }
@@ -1436,8 +1436,8 @@ struct Aligner {
 		if (HOT.cural == HOT.n_cands) return false;
 		// Everything below is wave-uniform; Plat::uni() tells the compiler so (scalar registers, scalar ALU).
 		const bool fw = Plat::uni((int)fw_) != 0;
-		constexpr bool wide = MODE != 0, local = MODE == 2;
-		constexpr bool pred = MODE == 0;                 // 8-bit end-to-end: one byte of predecessor bits per cell (PB_*), tile = kPredTile diagonal steps
+		constexpr bool wide = MODE == 1, local = MODE == 2;
+		constexpr bool pred = MODE != 1;                 // 8-bit end-to-end and local: one byte of predecessor bits per cell (PB_*), tile = kPredTile steps along the direction of travel
 		constexpr uint32_t tile_len = pred ? kPredTile : kBtTile;
 		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
 		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
@@ -1530,6 +1530,7 @@ struct Aligner {
 					const uint32_t L = Plat::uni(Plat::bt_diag_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, fw, rdlen, room_c < room_e ? room_c : room_e, inf, mm));
 					if (L > 0) {
 						olap |= in_core(row, col); ncells += L; prof.steps += L;
+						if (local) score += (int32_t)(L - (uint32_t)__builtin_popcountll(mm)) * S.match_bonus;      // (end to end a match scores 0)
 						while (mm) {
 							const uint32_t d = (uint32_t)__builtin_ctzll(mm);
 							mm &= mm - 1;
@@ -1643,7 +1644,7 @@ struct Aligner {
 				}
 				mk |= 1;                         // setReportedThrough
 				if (mk != mk0) {
-					if (pred) dpl.pmask[pred_idx(band_lo, band_w, row, col)] = mk | (epoch << kEpochShift);
+					if (pred) dpl.pmask[pred_at(band_lo, band_w, row, col)] = mk | (epoch << kEpochShift);
 					else dpl.masks[(uint64_t)row * cols + col] = (uint16_t)mk;
 				}
 				if (!can_move_thru) {
@@ -1771,24 +1772,41 @@ struct Aligner {
 		typename Plat::LaneReg dn0, dn1;
 		Plat::lanes_zero(dn0); Plat::lanes_zero(dn1);
 		if (MODE == 2 && ndone > 0) { dn0 = Plat::lanes_load_u32(donel, 0, ndone); if (ndone > 64u) dn1 = Plat::lanes_load_u32(donel, 64, ndone); }
+		// local mode: which of the 64 candidates in the lanes are dominated by a candidate already tried (bit per lane, kept up to date as
+		// candidates are tried): a 400-bp window has thousands of candidate cells and all but a few dozen are dominated -- they are skipped
+		// 64 at a time (one ballot) instead of one test per candidate
+		typename Plat::LaneReg domv;
+		Plat::lanes_zero(domv);
+		uint32_t SQ = rows >> 4; if (SQ == 0) SQ = 1;      // "dominated": within SQ rows and columns of a tried candidate (aligner_sw.cpp:754-755,936-960)
 		while (HOT.cural < HOT.n_cands) {
 			BtCand c;
 			{
-				const uint32_t ci = HOT.cural;
-				if (ci - cbase >= 64u) { cbase = ci; Plat::lanes_load_cands(cands, cbase, HOT.n_cands, cw0, cw1); }
+				uint32_t ci = HOT.cural;
+				if (ci - cbase >= 64u) {
+					cbase = ci; Plat::lanes_load_cands(cands, cbase, HOT.n_cands, cw0, cw1);
+					if (MODE == 2) {
+						Plat::lanes_zero(domv);
+						for (uint32_t k = 0; k < ndone; k++) {
+							const uint32_t v_ = k < 64u ? Plat::lane(dn0, k) : k < 128u ? Plat::lane(dn1, k - 64u) : Plat::uni(gld(donel + k));
+							Plat::dom_update(domv, cw1, v_, SQ);
+						}
+					}
+				}
+				if (MODE == 2) {
+					// the next candidate that is not dominated -- unless one below the minimum score comes first (the list is sorted by score:
+					// that one ends the window, exactly where the one-by-one scan would have met it)
+					bool low_first = false;
+					const uint32_t nv = HOT.n_cands - cbase < 64u ? HOT.n_cands - cbase : 64u;
+					const uint32_t nx = Plat::next_cand(cw0, domv, ci - cbase, nv, ST.minsc, low_first);
+					if (low_first) { HOT.cural = HOT.n_cands; break; }
+					if (nx >= nv) { HOT.cural = cbase + nv; continue; }      // the rest of this batch is dominated
+					ci = cbase + nx; HOT.cural = ci;
+				}
 				c.score = (int32_t)Plat::lane(cw0, ci - cbase);
 				const uint32_t rc_ = Plat::lane(cw1, ci - cbase);
 				c.row = (uint16_t)(rc_ & 0xffffu); c.col = (uint16_t)(rc_ >> 16);
 			}
 			if (c.score < ST.minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
-			if (MODE == 2) {
-				// local: skip candidates "dominated" by one already tried -- within SQ = rows/16 rows and columns of it
-				// (aligner_sw.cpp:754-755,936-960)
-				uint32_t SQ = rows >> 4; if (SQ == 0) SQ = 1;
-				bool dom = Plat::near_any(dn0, ndone < 64u ? ndone : 64u, c.row, c.col, SQ) || (ndone > 64u && Plat::near_any(dn1, ndone - 64u < 64u ? ndone - 64u : 64u, c.row, c.col, SQ));
-				for (uint32_t k0 = 128; k0 < ndone && !dom; k0 += 64) dom = Plat::near_any(Plat::lanes_load_u32(donel, k0, ndone), ndone - k0 < 64u ? ndone - k0 : 64u, c.row, c.col, SQ);
-				if (dom) { HOT.cural++; continue; }
-			}
 			typename Plat::LaneReg tile, tile_hi;
 			{
 				const uint64_t tt_ = now();      // also the first tile of the backtrace
@@ -1815,7 +1833,7 @@ struct Aligner {
 			if (MODE == 2) {       // btncanddone_: tried, succeeded or not
 				const uint32_t v_ = (uint32_t)c.row | ((uint32_t)c.col << 16);
 				if (ndone >= (uint32_t)kMaxCandDone) ovf(33);
-				else { gst(donel + ndone, v_); if (ndone < 64u) Plat::set_lane(dn0, ndone, v_); else if (ndone < 128u) Plat::set_lane(dn1, ndone - 64u, v_); ndone++; HOT.n_cdone = ndone; }
+				else { gst(donel + ndone, v_); if (ndone < 64u) Plat::set_lane(dn0, ndone, v_); else if (ndone < 128u) Plat::set_lane(dn1, ndone - 64u, v_); ndone++; HOT.n_cdone = ndone; Plat::dom_update(domv, cw1, v_, SQ); }
 			}
 			(void)cscore;
 			if (ret) { found = true; break; }

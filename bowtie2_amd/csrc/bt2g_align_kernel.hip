@@ -307,7 +307,7 @@ __device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, bool fw, u
 // below the first row that can reach minsc, a match whose diagonal successor is not) are recognised while the cell is in registers and
 // appended to `emit` (unsorted, columns beyond lastsolcol included: the gather drops those) -- the matrix is not read again to find them.
 template <int R, bool EMIT>
-__device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint64_t* __restrict__ scratch,
+__device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm,
                                                int minsc, uint32_t& lastsolcol, uint32_t& sat8, BT2_G BtCand* emit, uint32_t emit_cap, uint32_t& n_emit) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t nlanes = (rows + R - 1) / R;
@@ -325,6 +325,9 @@ __device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, ui
 		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 1 : 0;
 		if (valid && rdc[r] <= 3 && mmp[r] > bias) bias = mmp[r];
 	}
+	uint32_t gmask[R];      // predecessor bits a row may have: no H == E / H == F in a row without gaps
+#pragma unroll
+	for (int r = 0; r < R; r++) gmask[r] = veto[r] ? ~(uint32_t)(PB_HE | PB_HF) : ~0u;
 	for (int o = 32; o > 0; o >>= 1) bias = imax(bias, __shfl_xor(bias, o));     // bias of the 8-bit query profile
 	int rdn[R];       // EMIT: 1 << character of the row below (0 for the last row: nothing follows it)
 	if (EMIT) {
@@ -354,28 +357,41 @@ __device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, ui
 		int refc = 4;
 		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
 		int hdiag = (lane == 0 || j == 0) ? 0 : upHdiag;
-		int fin_h = upH, fin_f = upF;
+		int fin_h = (lane == 0) ? 0 : upH, fin_f = (lane == 0) ? 0 : upF;      // (row 0 has nothing above it)
 		int cm = (lane == 0) ? 0 : upMax;
 		int Hnew[R], Enew[R], Fnew[R];
+		uint32_t pb[R];      // predecessor bits (PB_*), with the local kernels' `> floor` rule: a neighbour whose score is 0 is no predecessor
 #pragma unroll
 		for (int r = 0; r < R; r++) {
 			int sc;
 			if (rdc[r] > 3 || refc > 3) sc = -P.n_pen; else sc = (rdc[r] == refc) ? P.match_bonus : -mmp[r];
-			const int e = (j == 0) ? 0 : imax(subs0(Eprev[r], P.rdgape), veto[r] ? 0 : subs0(Hprev[r], P.rdgapo));
+			const int hl = (j == 0) ? 0 : Hprev[r], el = (j == 0) ? 0 : Eprev[r];
+			const int e = (j == 0) ? 0 : imax(subs0(el, P.rdgape), veto[r] ? 0 : subs0(hl, P.rdgapo));
 			int f;
 			if (lane == 0 && r == 0) f = 0;
 			else f = veto[r] ? 0 : imax(subs0(fin_f, P.rfgape), subs0(fin_h, P.rfgapo));
 			int h = hdiag + sc; if (h < 0) h = 0;
 			h = imax(imax(h, e), f);
 			Hnew[r] = h; Enew[r] = e; Fnew[r] = f;
+			// (The E / F bits are only ever looked at in a cell whose E / F is positive -- the walk enters the E state of a cell only through an
+			// E that is above the floor -- and there "neighbour - penalty == E > 0" already says the neighbour is above the floor: no separate
+			// test.  The diagonal needs it: 0 + match bonus is a score a local alignment STARTS with.  Rows without gaps mask HE / HF.)
+			uint32_t c = (hdiag > 0 && hdiag + sc == h) ? PB_HD : 0u;
+			c |= (h == e) ? PB_HE : 0u;
+			c |= (h == f) ? PB_HF : 0u;
+			c |= (hl - P.rdgapo == e) ? PB_EO : 0u;
+			c |= (el - P.rdgape == e) ? PB_EE : 0u;
+			c |= (fin_h - P.rfgapo == f) ? PB_FO : 0u;
+			c |= (fin_f - P.rfgape == f) ? PB_FE : 0u;
+			pb[r] = c & gmask[r];
 			hdiag = Hprev[r];
 			fin_h = h; fin_f = f;
 			if ((uint32_t)lane * R + r < rows) cm = imax(cm, h);
 		}
 		if (active) {
-			uint64_t* base = scratch + ((uint64_t)t * R) * 64 + lane;
+			uint8_t* base = pm + ((uint64_t)t * R) * 64 + lane;      // 64 consecutive bytes per store
 #pragma unroll
-			for (int r = 0; r < R; r++) base[r * 64] = (uint64_t)(uint16_t)Hnew[r] | ((uint64_t)(uint16_t)Enew[r] << 16) | ((uint64_t)(uint16_t)Fnew[r] << 32);
+			for (int r = 0; r < R; r++) base[r * 64] = (uint8_t)pb[r];
 #pragma unroll
 			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
 			mycolmax = cm;
@@ -443,17 +459,17 @@ __device__ __attribute__((noinline)) int fill_ee_i16_leaf(bool fw_, uint32_t row
 }
 // local fill: lastsolcol / sat8 / the number of emitted candidates come back through g_st (fill_lastsol, fill_sat8, n_emit)
 template <int R, bool EMIT>
-__device__ __attribute__((noinline)) int fill_local_leaf(bool fw_, uint32_t rows_, uint32_t cols_, uint64_t* m64_, int ms_, BT2_G BtCand* emit_, uint32_t ecap_) {
+__device__ __attribute__((noinline)) int fill_local_leaf(bool fw_, uint32_t rows_, uint32_t cols_, uint8_t* pm_, int ms_, BT2_G BtCand* emit_, uint32_t ecap_) {
 	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
 	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
 	const int ms = __builtin_amdgcn_readfirstlane(ms_);
 	const uint32_t ecap = (uint32_t)__builtin_amdgcn_readfirstlane((int)ecap_);
-	const uint64_t pa = (uint64_t)reinterpret_cast<uintptr_t>(m64_);
-	uint64_t* m64 = reinterpret_cast<uint64_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa));
+	const uint64_t pa = (uint64_t)reinterpret_cast<uintptr_t>(pm_);
+	uint8_t* pm = reinterpret_cast<uint8_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa));
 	const uint64_t ea = (uint64_t)emit_;
 	BT2_G BtCand* emit = (BT2_G BtCand*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ea >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ea));
 	uint32_t lastsolcol = 0, sat8 = 0, nem = 0;
-	const int best = fill_local_wave<R, EMIT>(g_P, fw, rows, cols, m64, ms, lastsolcol, sat8, emit, ecap, nem);
+	const int best = fill_local_wave<R, EMIT>(g_P, fw, rows, cols, pm, ms, lastsolcol, sat8, emit, ecap, nem);
 	if ((threadIdx.x & 63) == 0) { g_st.fill_lastsol = lastsolcol; g_st.fill_sat8 = sat8; g_st.n_emit = nem; g_st.emit_vmax = best; }
 	return best;
 }
@@ -689,8 +705,8 @@ struct DevPlat {
 		uint32_t p = 0, m = 0;
 		const uint32_t dr = dir == 1 ? 0u : d, dc = dir == 2 ? 0u : d;
 		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo) + dr - dc;      // diagonal of the lane's cell (wraps past the band's edge)
-		if (dr <= row && dc <= col && dd < band_w) {
-			const uint64_t idx = (uint64_t)(row - dr) * band_w + dd;
+		if (dr <= row && dc <= col && (band_w == 0u || dd < band_w)) {
+			const uint64_t idx = pred_at(band_lo, band_w, row - dr, col - dc);
 			p = gld(reinterpret_cast<const uint8_t*>(dp.mat) + idx);
 			const uint32_t w = gld(dp.pmask + idx);
 			m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
@@ -821,7 +837,7 @@ struct DevPlat {
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			edit = m != 1;
 			info = ((uint32_t)readc << 4) | ((uint32_t)refm << 8) | ((uint32_t)readq << 16) | (m == -1 ? 2u : 0u);
-			gst(dp.pmask + pred_idx(band_lo, band_w, r, c), 3u | (epoch << kEpochShift));
+			gst(dp.pmask + pred_at(band_lo, band_w, r, c), 3u | (epoch << kEpochShift));
 		}
 		mm = __ballot(edit);
 		return L;
@@ -851,7 +867,7 @@ struct DevPlat {
 			else { e.pos = (uint16_t)r; e.chr = '-'; e.qchr = code2chr(rd_char(g_hot, rdlen, fw, r)); e.type = EDIT_REF_GAP; }
 			e.pad = 0;
 			g_hot.ned[nned + k] = e;
-			gst(dp.pmask + pred_idx(band_lo, band_w, r, c), (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift));
+			gst(dp.pmask + pred_at(band_lo, band_w, r, c), (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift));
 			const int diagi = (int)c - (int)r + r_triml;
 			incore = diagi >= r_corel && diagi <= r_corer;
 		}
@@ -953,6 +969,21 @@ struct DevPlat {
 		const unsigned long long m = __ballot(l < n && klo == (uint32_t)key && khi == (uint32_t)(key >> 32) && (klf & 0xffu) == (uint32_t)len);
 		return m ? (uint32_t)__builtin_ctzll(m) : n;
 	}
+	// lane i holds candidate i of a batch as row | col << 16: flag the ones within sq rows and columns of the cell rc
+	static __device__ __forceinline__ void dom_update(LaneReg& domv, LaneReg cw1, uint32_t rc, uint32_t sq) {
+		const uint32_t orow = rc & 0xffffu, ocol = rc >> 16, row = cw1 & 0xffffu, col = cw1 >> 16;
+		const uint32_t dr = row > orow ? row - orow : orow - row, dc = col > ocol ? col - ocol : ocol - col;
+		domv |= (dr <= sq && dc <= sq) ? 1u : 0u;
+	}
+	// first candidate (lane) >= from of the nv in the batch that is not flagged, nv if none; low_first: one whose score is below minsc comes first
+	static __device__ __forceinline__ uint32_t next_cand(LaneReg cw0, LaneReg domv, uint32_t from, uint32_t nv, int64_t minsc, bool& low_first) {
+		const uint32_t l = threadIdx.x & 63;
+		const bool in = l >= from && l < nv;
+		const unsigned long long low = __ballot(in && (int64_t)(int32_t)cw0 < minsc), ok = __ballot(in && domv == 0u);
+		const uint32_t fl = low ? (uint32_t)__builtin_ctzll(low) : 64u, fo = ok ? (uint32_t)__builtin_ctzll(ok) : 64u;
+		low_first = fl < 64u && fl <= fo;
+		return fo < nv ? fo : nv;
+	}
 	// is (row, col) within sq rows and sq columns of one of the first n cells (row | col << 16) held in the lanes of r?
 	static __device__ __forceinline__ bool near_any(LaneReg r, uint32_t n, uint32_t row, uint32_t col, uint32_t sq) {
 		const uint32_t l = threadIdx.x & 63;
@@ -1005,8 +1036,9 @@ struct DevPlat {
 		const bool fw = uni((int)fw_) != 0;
 		const uint32_t rows = uni(rows_), cols = uni(cols_);
 		const int64_t minsc = uni(minsc_);
-		uint64_t* m64 = reinterpret_cast<uint64_t*>(uni_ptr(mat_));
+		uint8_t* m64 = reinterpret_cast<uint8_t*>(uni_ptr(mat_));      // one predecessor byte per cell, anti-diagonal order (pred_at)
 		const int ms = minsc > 0x7fff ? 0x7fff : (int)minsc;
+		if ((threadIdx.x & 63) == 0) { g_st.dp.epoch[1] = dp_R(rows); g_st.dp.epoch[2] = 0u; }      // geometry of the matrix in the scratch header: anti-diagonal form
 		int best;
 		// the worker's fills leave their candidate cells in Work::cands_tmp for gather_local; the stage kernel (k_dp_fill) has no arena
 		BT2_G BtCand* const emit = g_st.emit_on ? &DevPlat::work().cands_tmp[0] : (BT2_G BtCand*)nullptr;
@@ -1408,6 +1440,12 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 				const BT2_G uint8_t* src = (const BT2_G uint8_t*)dp.mat;
 				for (uint64_t k = lane; k < (uint64_t)rows * band_w; k += 64) pm[k] = src[k];
 			}
+		} else if (pr.kind == BT2G_DP_LOCAL) {
+			// the predecessor bytes of the rectangle, row-major (the fill keeps them in anti-diagonal order: pred_at)
+			const uint32_t R = dp_R(rows);
+			const BT2_G uint8_t* src = (const BT2_G uint8_t*)dp.mat;
+			const uint64_t ncell = (uint64_t)rows * cols;
+			for (uint64_t k = lane; k < ncell; k += 64) body[k] = src[dp_cell(R, (uint32_t)(k / cols), (uint32_t)(k % cols))];
 		} else {
 			const uint32_t R = dp_R(rows);
 			const BT2_G uint64_t* m64 = (const BT2_G uint64_t*)dp.mat;
@@ -1446,7 +1484,10 @@ void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64
 	const uint64_t pred_bytes = (pred_cells(rows, cols) + 255) & ~(uint64_t)255;
 	if (pred_bytes > mat_bytes) mat_bytes = pred_bytes;
 	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
-	pmask_bytes = 256 + ((pred_cells(rows, cols) * 4 + 255) & ~(uint64_t)255);
+	// masks of the pred formats: the band form of the widest band, or the anti-diagonal form of the local fill (one word per matrix byte)
+	const uint64_t wf_cells = ((uint64_t)cols + lanes) * R * 64;
+	const uint64_t mask_cells = pred_cells(rows, cols) > wf_cells ? pred_cells(rows, cols) : wf_cells;
+	pmask_bytes = 256 + ((mask_cells * 4 + 255) & ~(uint64_t)255);
 	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + (paired ? 2 : 1) * (mat_bytes + mask_bytes + pmask_bytes);
 	arena_stride = (arena_stride + 4095) & ~(uint64_t)4095;
 }

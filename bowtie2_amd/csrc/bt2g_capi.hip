@@ -306,6 +306,7 @@ void bt2g_scoring_default(bt2g_scoring* sc) {
 uint64_t bt2g_dp_out_bytes(uint32_t kind, uint32_t rows, uint32_t cols) {
 	uint64_t b = sizeof(bt2g_dp_out);
 	if (kind == BT2G_DP_EE_U8) b += (uint64_t)((cols + 3u) & ~3u) * 2 + pred_cells(rows ? rows : 1, cols ? cols : 1);      // the widest band the problem can have
+	else if (kind == BT2G_DP_LOCAL) b += (uint64_t)rows * cols;      // one predecessor byte per cell
 	else b += (uint64_t)rows * cols * 3 * 4;
 	return (b + 7) & ~(uint64_t)7;
 }

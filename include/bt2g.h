@@ -194,8 +194,10 @@ typedef struct {
  *                   H/E/F, aligner_swsse_ee_u8.cpp:1330-1520); only cells inside the band are meaningful;
  *   BT2G_DP_EE_I16: int32 H[rows*cols], E[...], F[...] row-major, the cell values of the reference's 16-bit kernel
  *                   (0x7fff = perfect, -32768 = minus infinity);
- *   BT2G_DP_LOCAL : the same three arrays with plain local scores (floor 0) -- the reference's 16-bit kernel holds score - 32768,
- *                   its 8-bit kernel the score itself wherever it does not saturate.
+ *   BT2G_DP_LOCAL : rows * cols bytes of predecessor bits, row-major, the same seven questions with the local kernels' `> floor`
+ *                   rule folded in (a neighbour whose score is 0 is no predecessor, aligner_swsse_loc_u8.cpp:1530-1660) -- what
+ *                   the worker's local fill stores instead of scores; best / lastsolcol / sat8 in the header carry what the worker
+ *                   takes from the scores themselves.
  * bt2g_dp_out_bytes() gives the size of a block.  rows <= BT2G_MAX_READ_LEN, cols <= 1100.
  */
 uint64_t bt2g_dp_out_bytes(uint32_t kind, uint32_t rows, uint32_t cols);

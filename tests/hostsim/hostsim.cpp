@@ -42,6 +42,7 @@ struct HostPlat {
 	static uint32_t lane_id() { return 0; }
 	static uint32_t n_lanes() { return 1; }
 	static bool any(bool b) { return b; }
+	static std::vector<uint16_t>& local_h() { static std::vector<uint16_t> v; return v; }      // H of the last local fill (host only)
 	template <typename T> static T* uni_ptr(T* p) { return p; }
 	template <typename TOff> static TOff get_offset(const DevEbwt<TOff>& e, TOff row, uint32_t& nsteps) { return bt2g::get_offset(e, row, nsteps); }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
@@ -177,6 +178,24 @@ struct HostPlat {
 		for (uint32_t l = 0; l < n && l < 64; l++) if (klo.v[l] == (uint32_t)key && khi.v[l] == (uint32_t)(key >> 32) && (klf.v[l] & 0xffu) == (uint32_t)len) return l;
 		return n;
 	}
+	// lane i holds candidate i of a batch as row | col << 16: flag the ones within sq rows and columns of the cell rc
+	static void dom_update(LaneReg& domv, const LaneReg& cw1, uint32_t rc, uint32_t sq) {
+		const uint32_t orow = rc & 0xffffu, ocol = rc >> 16;
+		for (uint32_t l = 0; l < 64; l++) {
+			const uint32_t row = cw1.v[l] & 0xffffu, col = cw1.v[l] >> 16;
+			const uint32_t dr = row > orow ? row - orow : orow - row, dc = col > ocol ? col - ocol : ocol - col;
+			if (dr <= sq && dc <= sq) domv.v[l] = 1;
+		}
+	}
+	// first candidate (lane) >= from of the nv in the batch that is not flagged, nv if none; low_first: one whose score is below minsc comes first
+	static uint32_t next_cand(const LaneReg& cw0, const LaneReg& domv, uint32_t from, uint32_t nv, int64_t minsc, bool& low_first) {
+		low_first = false;
+		for (uint32_t l = from; l < nv; l++) {
+			if ((int64_t)(int32_t)cw0.v[l] < minsc) { low_first = true; return l; }
+			if (!domv.v[l]) return l;
+		}
+		return nv;
+	}
 	static bool near_any(const LaneReg& r, uint32_t n, uint32_t row, uint32_t col, uint32_t sq) {
 		for (uint32_t l = 0; l < n && l < 64; l++) {
 			const uint32_t orow = r.v[l] & 0xffffu, ocol = r.v[l] >> 16;
@@ -268,7 +287,7 @@ struct HostPlat {
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) mm |= 1ull << (td + k);
 			info.v[td + k] = ((uint32_t)readc << 4) | ((uint32_t)refm << 8) | ((uint32_t)readq << 16) | (m == -1 ? 2u : 0u);
-			dp.pmask[pred_idx(band_lo, band_w, r, c)] = 3u | (epoch << kEpochShift);
+			dp.pmask[pred_at(band_lo, band_w, r, c)] = 3u | (epoch << kEpochShift);
 		}
 		return L;
 	}
@@ -290,7 +309,7 @@ struct HostPlat {
 			else { e.pos = (uint16_t)r; e.chr = '-'; e.qchr = code2chr(rd_char(g_hot, rdlen, fw, r)); e.type = EDIT_REF_GAP; }
 			e.pad = 0;
 			g_hot.ned[nned + k] = e;
-			dp.pmask[pred_idx(band_lo, band_w, r, c)] = (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift);
+			dp.pmask[pred_at(band_lo, band_w, r, c)] = (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift);
 			const int diagi = (int)c - (int)r + r_triml;
 			if (diagi >= r_corel && diagi <= r_corer) core = 1;
 		}
@@ -301,8 +320,8 @@ struct HostPlat {
 			uint32_t p = 0, m = 0;
 			const uint32_t dr = dir == 1 ? 0u : d, dc = dir == 2 ? 0u : d;
 			const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo) + dr - dc;
-			if (dr <= row && dc <= col && dd < band_w) {
-				const uint64_t idx = pred_idx(band_lo, band_w, row - dr, col - dc);
+			if (dr <= row && dc <= col && (band_w == 0u || dd < band_w)) {
+				const uint64_t idx = pred_at(band_lo, band_w, row - dr, col - dc);
 				p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
 				const uint32_t w = dp.pmask[idx];
 				m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
@@ -317,7 +336,9 @@ struct HostPlat {
 	static int64_t dp_fill_local(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, int64_t minsc,
 	                             uint32_t& lastsolcol, uint32_t& sat8) {
 		const uint32_t R = dp_R(rows);
-		uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
+		uint8_t* pm = reinterpret_cast<uint8_t*>(mat);      // one predecessor byte per cell, anti-diagonal order (pred_at with w = 0, lo = R)
+		st().dp.epoch[1] = R; st().dp.epoch[2] = 0u;
+		local_h().assign((size_t)rows * cols, 0);          // the scores themselves, for gather_local (the device's fill emits the candidates instead)
 		auto subs = [](int a, int b) { const int v = a - b; return v < 0 ? 0 : v; };
 		// bias of the 8-bit query profile: the largest penalty any (read position, reference character) pair can incur
 		int bias = P.n_pen;
@@ -342,13 +363,24 @@ struct HostPlat {
 				int sc;
 				if (rdc > 3 || refc > 3) sc = -P.n_pen; else sc = (rdc == refc) ? P.match_bonus : -mm_penalty(P, q < 0 ? 0 : q);
 				const int hdiag = (i == 0 || j == 0) ? 0 : Hp[i - 1];
-				const int e = (j == 0) ? 0 : imax(subs(Ep[i], P.rdgape), veto ? 0 : subs(Hp[i], P.rdgapo));
-				f = (i == 0) ? 0 : (veto ? 0 : imax(subs(f, P.rfgape), subs(Hc[i - 1], P.rfgapo)));
+				const int hl = (j == 0) ? 0 : Hp[i], el = (j == 0) ? 0 : Ep[i];
+				const int hu = (i == 0) ? 0 : Hc[i - 1], fu = (i == 0) ? 0 : f;
+				const int e = (j == 0) ? 0 : imax(subs(el, P.rdgape), veto ? 0 : subs(hl, P.rdgapo));
+				f = (i == 0) ? 0 : (veto ? 0 : imax(subs(fu, P.rfgape), subs(hu, P.rfgapo)));
 				int h = hdiag + sc; if (h < 0) h = 0;
 				h = imax(imax(h, e), f);
 				Hc[i] = h; Ec[i] = e; Fc[i] = f;
 				if (h > colmax) colmax = h;
-				m64[dp_cell(R, i, j)] = (uint64_t)(uint16_t)h | ((uint64_t)(uint16_t)e << 16) | ((uint64_t)(uint16_t)f << 32);
+				// predecessor bits with the local kernels' `> floor` rule (aligner_swsse_loc_u8.cpp:1530-1660): a neighbour whose score is 0 is none
+				int c = (hdiag > 0 && hdiag + sc == h) ? PB_HD : 0;
+				c |= (!veto && h == e) ? PB_HE : 0;
+				c |= (!veto && h == f) ? PB_HF : 0;
+				c |= (hl > 0 && hl - P.rdgapo == e) ? PB_EO : 0;
+				c |= (el > 0 && el - P.rdgape == e) ? PB_EE : 0;
+				c |= (hu > 0 && hu - P.rfgapo == f) ? PB_FO : 0;
+				c |= (fu > 0 && fu - P.rfgape == f) ? PB_FE : 0;
+				pm[dp_cell(R, i, j)] = (uint8_t)c;
+				local_h()[(size_t)i * cols + j] = (uint16_t)h;
 			}
 			if (!bailed) {
 				if (colmax > vmax) vmax = colmax;
@@ -365,11 +397,11 @@ struct HostPlat {
 	static uint32_t gather_local(const uint32_t* mat, BtCand* cands, uint32_t cap, bool fw, uint32_t R, uint32_t rows, uint32_t ncol,
 	                             int64_t minsc, uint32_t minrow, uint32_t* hist) {
 		memset(hist, 0xa5, sizeof(uint32_t) * 2 * (kMaxLocalScore + 1));      // the device's counting sort scribbles over its scratch: nothing may live there across a gather
-		const uint64_t* m64 = reinterpret_cast<const uint64_t*>(mat);
+		const size_t hcols = local_h().size() / (rows ? rows : 1);
 		uint32_t n = 0, total = 0;
 		for (uint32_t j = 0; j < ncol; j++) {
 			for (uint32_t i = minrow; i < rows; i++) {
-				const int sc = (int)(m64[dp_cell(R, i, j)] & 0xffff);
+				const int sc = (int)local_h()[(size_t)i * hcols + j];
 				if (sc < minsc) continue;
 				const int rdc = rd_char(g_hot, g_hot.len, fw, i);
 				const bool match = (g_hot.rf[j] & (1 << rdc)) != 0;        // as the reference: a read N "matches" a reference N mask (16)

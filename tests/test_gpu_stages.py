@@ -189,6 +189,8 @@ def run_dp_fill(ctx, probs, scoring=None):
             r["lastrow"] = np.frombuffer(raw[body:body + 2 * c4], dtype="<i2")[:cols]
             if hdr.has_matrix:
                 r["pred"] = np.frombuffer(raw[body + 2 * c4:body + 2 * c4 + rows * hdr.band_w], dtype=np.uint8).reshape(rows, hdr.band_w)
+        elif p[0] == b.DP_LOCAL:
+            r["pred"] = np.frombuffer(raw[body:body + rows * cols], dtype=np.uint8).reshape(rows, cols)
         else:
             m = np.frombuffer(raw[body:body + 12 * rows * cols], dtype="<i4").reshape(3, rows, cols)
             r["H"], r["E"], r["F"] = m[0], m[1], m[2]
@@ -235,6 +237,33 @@ def pred_bits_from_hef(sc, rd, phred, rf, H, E, F, L):
             c |= 16 if el - rde == e else 0
             c |= 32 if hu - rfo == f else 0
             c |= 64 if fu - rfe == f else 0
+            out[i, j] = c
+    return out
+
+
+def local_pred_bits_from_hef(sc, rd, phred, rf, H, E, F, L):
+    """Predecessor byte of every cell of a LOCAL fill from the oracle's plain scores: the questions of the local backtrace
+    (aligner_swsse_loc_u8.cpp:1530-1660) -- as pred_bits_from_hef, but a neighbour only counts while its score is above the floor (0)."""
+    import numpy as np
+    rows, cols = H.shape
+    rdo, rde = sc.rd_gap_const + sc.rd_gap_linear, sc.rd_gap_linear
+    rfo, rfe = sc.rf_gap_const + sc.rf_gap_linear, sc.rf_gap_linear
+    out = np.zeros((rows, cols), dtype=np.uint8)
+    for i in range(rows):
+        ga = not (i < sc.gapbar or rows - i - 1 < sc.gapbar)
+        for j in range(cols):
+            s = L.bt2o_score(C.byref(sc), rd[i], rf[j], phred[i])
+            h, e, f = int(H[i, j]), int(E[i, j]), int(F[i, j])
+            hdiag = int(H[i - 1, j - 1]) if (i > 0 and j > 0) else 0
+            hl, el = (int(H[i, j - 1]), int(E[i, j - 1])) if j > 0 else (0, 0)
+            hu, fu = (int(H[i - 1, j]), int(F[i - 1, j])) if i > 0 else (0, 0)
+            c = 1 if (hdiag > 0 and hdiag + s == h) else 0
+            c |= 2 if ga and h == e else 0
+            c |= 4 if ga and h == f else 0
+            c |= 8 if (hl > 0 and hl - rdo == e) else 0
+            c |= 16 if (el > 0 and el - rde == e) else 0
+            c |= 32 if (hu > 0 and hu - rfo == f) else 0
+            c |= 64 if (fu > 0 and fu - rfe == f) else 0
             out[i, j] = c
     return out
 
@@ -353,7 +382,14 @@ def test_dp_fills_that_ship(case):
             got3, flag3, colstop3, (H, E, F) = oracle_fill_kind(L, 3, osc, rdc, phred, rfm, cols, minsc)
             got2, flag2, colstop2, _ = oracle_fill_kind(L, 2, osc, rdc, phred, rfm, cols, minsc)
             n = colstop3
-            assert (r["H"][:, :n] == H[:, :n] + 32768).all() and (r["E"][:, :n] == E[:, :n] + 32768).all() and (r["F"][:, :n] == F[:, :n] + 32768).all(), (rows, cols)
+            # the local fill stores predecessor bits, not scores: derive them from the oracle's matrices (plain scores = the 16-bit kernel's
+            # cell + 32768) with the local kernels' rule that a neighbour at the floor (0) is no predecessor
+            Hs, Es, Fs = H[:, :n] + 32768, E[:, :n] + 32768, F[:, :n] + 32768
+            want_pred = local_pred_bits_from_hef(osc, rdc, phred, rfm, Hs, Es, Fs, L)
+            # a bit is defined where its state can be entered: H bits where H > 0, E bits where E > 0, F bits where F > 0
+            care = np.where(Hs > 0, 7, 0) | np.where(Es > 0, 24, 0) | np.where(Fs > 0, 96, 0)
+            got_pred = r["pred"][:, :n]
+            assert ((got_pred & care) == (want_pred & care)).all(), (rows, cols, np.argwhere((got_pred & care) != (want_pred & care))[:5])
             colmax = (H[:, :n] + 32768).max(axis=0)
             assert r["best"] == int(colmax.max()), (rows, cols)
             sol = [j for j in range(n) if colmax[j] >= minsc]

@@ -39,6 +39,12 @@ h = np.frombuffer(rec.tobytes(), dtype=hdr)
 step = 2 if cfg["paired"] else 1
 t = h["t_whole"][::step].astype(np.float64) / 100.0
 print(cfgname, "units", len(t), "mean us", t.mean(), "median", np.median(t), "p99", np.percentile(t, 99), "p99.9", np.percentile(t, 99.9), "max", t.max(), "sum of top 0.1% / total", np.sort(t)[-len(t) // 1000:].sum() / t.sum())
+srt = np.sort(t)[::-1]; cs = np.cumsum(srt) / t.sum()
+for f in (0.0001, 0.001, 0.01, 0.05, 0.1, 0.25, 0.5):
+    print("  slowest %.2f%% of units: %.1f%% of the time (threshold %.0f us)" % (100 * f, 100 * cs[max(0, int(len(t) * f) - 1)], srt[max(0, int(len(t) * f) - 1)]))
+for lo, hi in ((0, 200), (200, 400), (400, 800), (800, 1600), (1600, 3200), (3200, 1e9)):
+    m = (t >= lo) & (t < hi); hh = h[::step][m]
+    print("  %5.0f-%-6.0f us: %5.1f%% of units, %5.1f%% of time | mean dps %.1f bt %.1f iters %.1f dp_us %.0f bt_us %.0f prio_us %.0f" % (lo, hi, 100.0 * m.mean(), 100.0 * t[m].sum() / t.sum(), hh["n_ex_dps"].mean() if m.any() else 0, hh["n_bt_attempts"].mean() if m.any() else 0, hh["n_ex_iters"].mean() if m.any() else 0, hh["t_dp"].mean() / 100.0 if m.any() else 0, hh["t_bt"].mean() / 100.0 if m.any() else 0, hh["t_prio"].mean() / 100.0 if m.any() else 0))
 order = np.argsort(-t)[:12]
 for i in order:
     r = h[i * step]
