@@ -318,6 +318,17 @@ BT2_HD uint64_t dp_cell(uint32_t R, uint32_t i, uint32_t j) {
 	const uint64_t t = (uint64_t)j + l;
 	return (t * R + r) * 64 + l;
 }
+// Local fills compute two cells per register (bt2g_local_pk.hpp): the read is cut into blocks of RB rows, block k belongs to lane k & 63 (low
+// halves for k < 64, high halves above) and meets column j in step t = j + k.  One byte per cell; the 64 low-half lanes' bytes of a (step, row in
+// block) are consecutive, then the 64 high-half ones: every store instruction of the fill writes 64 consecutive bytes.
+BT2_HD uint32_t dp_RB(uint32_t rows) { return (rows + 127) / 128; }
+BT2_HD uint64_t dp_cell_pk(uint32_t RB, uint32_t i, uint32_t j) {
+	const uint32_t k = i / RB, r = i % RB;
+	const uint64_t t = (uint64_t)j + k;
+	return (t * RB + r) * 128 + (k >> 6) * 64 + (k & 63);
+}
+// bytes of the anti-diagonal matrix of a rows x cols local problem
+BT2_HD uint64_t dp_pk_cells(uint32_t rows, uint32_t cols) { const uint32_t RB = dp_RB(rows); return ((uint64_t)cols + (rows + RB - 1) / RB) * RB * 128; }
 
 
 // DP scratch of one wave.  Two matrix formats:
@@ -371,9 +382,9 @@ BT2_HD uint32_t ee_band_rp(uint32_t nd) {
 }
 BT2_HD uint64_t pred_idx(int32_t lo, uint32_t w, uint32_t i, uint32_t j) { return (uint64_t)i * w + (uint32_t)((int32_t)j - (int32_t)i + lo); }
 // The predecessor-byte matrix of a LOCAL fill covers the whole rectangle and is stored in the order its anti-diagonal fill produces it
-// (dp_cell: lane = block of R rows, step = column + lane; every store of the fill is 64 consecutive bytes).  The scratch header says which
-// form a matrix has: row width w > 0 = band form with first diagonal lo; w == 0 = anti-diagonal form with lo = rows per lane.
-BT2_HD uint64_t pred_at(int32_t lo, uint32_t w, uint32_t i, uint32_t j) { return w ? pred_idx(lo, w, i, j) : dp_cell((uint32_t)lo, i, j); }
+// (dp_cell_pk: block of RB rows = half a lane, step = column + block).  The scratch header says which form a matrix has: row width w > 0 = band
+// form with first diagonal lo; w == 0 = anti-diagonal form with lo = rows per block.
+BT2_HD uint64_t pred_at(int32_t lo, uint32_t w, uint32_t i, uint32_t j) { return w ? pred_idx(lo, w, i, j) : dp_cell_pk((uint32_t)lo, i, j); }
 // bytes of the widest band a rows x cols problem can have (every diagonal of the rectangle)
 BT2_HD uint64_t pred_cells(uint32_t rows, uint32_t cols) { uint32_t rp = ee_band_rp(rows + cols); if (rp == 0) rp = 16; return (uint64_t)rows * rp * 128; }
 

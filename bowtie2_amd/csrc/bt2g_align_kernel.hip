@@ -11,6 +11,7 @@
 #include <cstddef>
 #include <new>
 #include "bt2g_align_core.hpp"
+#include "bt2g_local_pk.hpp"
 #include "bt2g_align_kernel.hpp"
 
 namespace bt2g {
@@ -299,132 +300,132 @@ __device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, bool fw, u
 	return __shfl(best, (int)((rows - 1) / R));
 }
 
-// Local-mode fill (alignNucleotidesLocalSseU8 / ...I16; they agree wherever the 8-bit kernel does not saturate):
-// plain scores in 16-bit fields, floor 0.  The column maximum travels down the lanes with the column; the lane that
-// owns the last rows sees every column complete, in order, and replays the kernels' per-column bookkeeping
-// (best score, lastsolcol, bail-out point, "the 8-bit kernel would have saturated").
+// Local-mode fill (alignNucleotidesLocalSseU8 / ...I16; they agree wherever the 8-bit kernel does not saturate): plain scores, floor 0,
+// two cells per register (bt2g_local_pk.hpp: the cell arithmetic and why a lane owns block `lane` in its low halves and block `lane + 64` in
+// its high halves).  What leaves a cell is its predecessor byte (PB_*, with the local kernels' `> floor` rule: a neighbour whose score is 0 is no
+// predecessor); bits nobody can look at are not cleaned up: the E / F bits of a cell whose E / F is 0 (the walk enters the E state of a cell
+// only through an E above the floor, and there "neighbour - penalty == E > 0" already says the neighbour is above the floor) and all bits of a
+// cell whose H is 0 (no walk reaches it: the diagonal bit needs a diagonal above the floor, E / F steps need a positive E / F).
+// The column maximum travels down the blocks with the column; the last block sees every column complete, in order, and the per-column
+// bookkeeping of the kernels (best score, lastsolcol, bail-out point, "the 8-bit kernel would have saturated") is scalar code on its value.
 // EMIT: the candidate cells of the gather (gatherCellsNucleotidesLocalSseU8, aligner_swsse_loc_u8.cpp:1389-1496: score >= minsc, at or
 // below the first row that can reach minsc, a match whose diagonal successor is not) are recognised while the cell is in registers and
 // appended to `emit` (unsorted, columns beyond lastsolcol included: the gather drops those) -- the matrix is not read again to find them.
-template <int R, bool EMIT>
-__device__ __forceinline__ int fill_local_wave(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm,
-                                               int minsc, uint32_t& lastsolcol, uint32_t& sat8, BT2_G BtCand* emit, uint32_t emit_cap, uint32_t& n_emit) {
-	const int lane = threadIdx.x & 63;
-	const uint32_t nlanes = (rows + R - 1) / R;
-	int rdc[R], mmp[R], veto[R];
+template <int RB, bool EMIT>
+__device__ __forceinline__ int fill_local_pk(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm,
+                                             int minsc, uint32_t& lastsolcol, uint32_t& sat8, BT2_G BtCand* emit, uint32_t emit_cap, uint32_t& n_emit) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t nblocks = (rows + RB - 1) / RB;      // <= 128
+	LocalPkRows<RB> K;
+	uint32_t rdn[RB], cok[RB];      // EMIT: 1 << character of the row below (0 under the last row); 1 where the row can hold a candidate
 	int bias = P.n_pen;
-	uint32_t nem = 0;
 	const uint32_t minrow = EMIT ? (uint32_t)(((minsc + P.match_bonus - 1) / P.match_bonus) - 1) : 0u;
 #pragma unroll
-	for (int r = 0; r < R; r++) {
-		const uint32_t i = (uint32_t)lane * R + r;
-		const bool valid = i < rows;
-		rdc[r] = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
-		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
-		mmp[r] = mm_penalty(P, q < 0 ? 0 : q);
-		veto[r] = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 1 : 0;
-		if (valid && rdc[r] <= 3 && mmp[r] > bias) bias = mmp[r];
-	}
-	uint32_t gmask[R];      // predecessor bits a row may have: no H == E / H == F in a row without gaps
+	for (int r = 0; r < RB; r++) {
+		uint32_t km = 0, kb = 0, kn = 0, kv = 0, ko = 0, kd = 0, kc = 0;
 #pragma unroll
-	for (int r = 0; r < R; r++) gmask[r] = veto[r] ? ~(uint32_t)(PB_HE | PB_HF) : ~0u;
+		for (int half = 0; half < 2; half++) {
+			const uint32_t i = (lane + 64u * half) * RB + r;
+			const bool valid = i < rows;
+			const int rdc = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+			const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
+			const int mmp = mm_penalty(P, q < 0 ? 0 : q);
+			const bool veto = (int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar;
+			if (valid && rdc <= 3 && mmp > bias) bias = mmp;
+			const LocalPkRow1 c = local_pk_row(valid, rdc, mmp, veto, P.match_bonus, P.n_pen);
+			const uint32_t below = (i + 1 < rows) ? (1u << rd_char(g_hot, g_hot.len, fw, i + 1)) : 0u;
+			const uint32_t ok = (valid && i >= minrow) ? 1u : 0u;
+			km |= c.rowmask << (16 * half); kb |= c.bpm << (16 * half); kn |= c.nmmp << (16 * half); kv |= c.vm << (16 * half); ko |= c.okm << (16 * half);
+			kd |= below << (16 * half); kc |= ok << (16 * half);
+		}
+		K.rowmask[r] = km; K.bpm[r] = kb; K.nmmp[r] = kn; K.vm[r] = kv; K.okm[r] = ko; rdn[r] = kd; cok[r] = kc;
+	}
 	for (int o = 32; o > 0; o >>= 1) bias = imax(bias, __shfl_xor(bias, o));     // bias of the 8-bit query profile
-	int rdn[R];       // EMIT: 1 << character of the row below (0 for the last row: nothing follows it)
-	if (EMIT) {
-		const int below = __shfl_down(rdc[0], 1);
+	bias = __builtin_amdgcn_readfirstlane(bias);
+	const LocalPkPen G = local_pk_pen(P.rdgapo, P.rdgape, P.rfgapo, P.rfgape, P.n_pen);
+	// score >= minsc  <=>  (score + ge_add) -sat ge_sub != 0
+	const uint32_t ge_add = pk::both(minsc <= 0 ? 1 : 0), ge_sub = pk::both(minsc <= 0 ? 0 : minsc - 1);
+	uint32_t Hp[RB], Ep[RB];
 #pragma unroll
-		for (int r = 0; r < R; r++) {
-			const uint32_t i = (uint32_t)lane * R + r;
-			rdn[r] = (i + 1 < rows) ? (1 << (r + 1 < R ? rdc[r + 1 < R ? r + 1 : 0] : below)) : 0;
-		}
-	}
-	int Hprev[R], Eprev[R];
-#pragma unroll
-	for (int r = 0; r < R; r++) { Hprev[r] = 0; Eprev[r] = 0; }
-	int myHlast = 0, myFlast = 0, upHdiag = 0, refm = 0, mycolmax = 0;
-	int vmax = 0, lastsol = 0, sat = 0, bailed = 0;
-	const uint32_t steps = cols + nlanes - 1;
-	const bool last_lane = (uint32_t)lane == nlanes - 1;
+	for (int r = 0; r < RB; r++) { Hp[r] = 0; Ep[r] = 0; }
+	uint32_t myH = 0, myF = 0, mycm = 0, upHdiag = 0, refm = 0x00100010u;      // (a block that has not started sees reference N and zeros: it stays zero)
+	int vmax = 0, lastsol = 0, sat = 0, bailed = 0;      // scalar: the last block's lane is the same for every step
+	uint32_t nem = 0;
+	const uint32_t last_blk = nblocks - 1, last_lane = last_blk & 63u, last_half = last_blk >> 6;
+	const uint32_t steps = cols + nblocks - 1;
 	for (uint32_t t = 0; t < steps; t++) {
-		const int upH = __shfl_up(myHlast, 1);
-		const int upF = __shfl_up(myFlast, 1);
-		const int upMax = __shfl_up(mycolmax, 1);
-		int upRef = __shfl_up(refm, 1);
-		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
-		refm = upRef;
-		const int j = (int)t - lane;
-		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
-		int refc = 4;
-		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
-		int hdiag = (lane == 0 || j == 0) ? 0 : upHdiag;
-		int fin_h = (lane == 0) ? 0 : upH, fin_f = (lane == 0) ? 0 : upF;      // (row 0 has nothing above it)
-		int cm = (lane == 0) ? 0 : upMax;
-		int Hnew[R], Enew[R], Fnew[R];
-		uint32_t pb[R];      // predecessor bits (PB_*), with the local kernels' `> floor` rule: a neighbour whose score is 0 is no predecessor
-#pragma unroll
-		for (int r = 0; r < R; r++) {
-			int sc;
-			if (rdc[r] > 3 || refc > 3) sc = -P.n_pen; else sc = (rdc[r] == refc) ? P.match_bonus : -mmp[r];
-			const int hl = (j == 0) ? 0 : Hprev[r], el = (j == 0) ? 0 : Eprev[r];
-			const int e = (j == 0) ? 0 : imax(subs0(el, P.rdgape), veto[r] ? 0 : subs0(hl, P.rdgapo));
-			int f;
-			if (lane == 0 && r == 0) f = 0;
-			else f = veto[r] ? 0 : imax(subs0(fin_f, P.rfgape), subs0(fin_h, P.rfgapo));
-			int h = hdiag + sc; if (h < 0) h = 0;
-			h = imax(imax(h, e), f);
-			Hnew[r] = h; Enew[r] = e; Fnew[r] = f;
-			// (The E / F bits are only ever looked at in a cell whose E / F is positive -- the walk enters the E state of a cell only through an
-			// E that is above the floor -- and there "neighbour - penalty == E > 0" already says the neighbour is above the floor: no separate
-			// test.  The diagonal needs it: 0 + match bonus is a score a local alignment STARTS with.  Rows without gaps mask HE / HF.)
-			uint32_t c = (hdiag > 0 && hdiag + sc == h) ? PB_HD : 0u;
-			c |= (h == e) ? PB_HE : 0u;
-			c |= (h == f) ? PB_HF : 0u;
-			c |= (hl - P.rdgapo == e) ? PB_EO : 0u;
-			c |= (el - P.rdgape == e) ? PB_EE : 0u;
-			c |= (fin_h - P.rfgapo == f) ? PB_FO : 0u;
-			c |= (fin_f - P.rfgape == f) ? PB_FE : 0u;
-			pb[r] = c & gmask[r];
-			hdiag = Hprev[r];
-			fin_h = h; fin_f = f;
-			if ((uint32_t)lane * R + r < rows) cm = imax(cm, h);
+		// what the blocks above computed in the previous step: lane - 1 for both halves, except block 64 (lane 0, high) which follows block 63
+		// (lane 63, low); block 0 has nothing above it and is fed the reference
+		uint32_t upH = (uint32_t)__shfl_up((int)myH, 1), upF = (uint32_t)__shfl_up((int)myF, 1), upM = (uint32_t)__shfl_up((int)mycm, 1), upR = (uint32_t)__shfl_up((int)refm, 1);
+		{
+			const uint32_t wH = (uint32_t)__builtin_amdgcn_readlane((int)myH, 63), wF = (uint32_t)__builtin_amdgcn_readlane((int)myF, 63);
+			const uint32_t wM = (uint32_t)__builtin_amdgcn_readlane((int)mycm, 63), wR = (uint32_t)__builtin_amdgcn_readlane((int)refm, 63);
+			const uint32_t feed = (t < cols) ? (uint32_t)g_hot.rf[t] : 16u;
+			if (lane == 0) { upH = wH << 16; upF = wF << 16; upM = wM << 16; upR = (wR << 16) | feed; }
 		}
-		if (active) {
-			uint8_t* base = pm + ((uint64_t)t * R) * 64 + lane;      // 64 consecutive bytes per store
+		refm = upR;
+		uint32_t pb[RB];
+		uint32_t cm = upM;
+		local_pk_step<RB>(K, G, refm, upHdiag, upH, upF, Hp, Ep, pb, myH, myF, cm);
+		mycm = cm;
+		upHdiag = upH;
+		const uint32_t j_lo = t - lane, j_hi = t - lane - 64u;      // (unsigned: negative = huge)
+		const bool act_lo = j_lo < cols && lane < nblocks, act_hi = j_hi < cols && lane + 64u < nblocks;
+		{
+			uint8_t* base = pm + ((uint64_t)t * RB) * 128 + lane;
+			if (act_lo) {
 #pragma unroll
-			for (int r = 0; r < R; r++) base[r * 64] = (uint8_t)pb[r];
+				for (int r = 0; r < RB; r++) base[r * 128] = (uint8_t)pb[r];
+			}
+			if (act_hi) {
 #pragma unroll
-			for (int r = 0; r < R; r++) { Hprev[r] = Hnew[r]; Eprev[r] = Enew[r]; }
-			mycolmax = cm;
-			if (last_lane && !bailed) {
-				// end of column j (aligner_swsse_loc_u8.cpp:1305-1335)
-				if (cm > vmax) vmax = cm;
-				if (cm + bias >= 255) sat = 1;
-				if (cm < minsc) { if (cm + (int)(cols - (uint32_t)j - 1) * P.match_bonus < minsc) bailed = 1; }
-				else lastsol = j;
+				for (int r = 0; r < RB; r++) base[r * 128 + 64] = (uint8_t)(pb[r] >> 16);
 			}
 		}
+		// end of column j = t - last_blk (aligner_swsse_loc_u8.cpp:1305-1335)
+		if (t >= last_blk && !bailed) {
+			const int j = (int)(t - last_blk);
+			const uint32_t cmw = (uint32_t)__builtin_amdgcn_readlane((int)cm, last_lane);
+			const int c = (int)(last_half ? cmw >> 16 : cmw & 0xffffu);
+			if (c > vmax) vmax = c;
+			if (c + bias >= 255) sat = 1;
+			if (c < minsc) { if (c + (int)(cols - (uint32_t)j - 1) * P.match_bonus < minsc) bailed = 1; }
+			else lastsol = j;
+		}
 		if (EMIT) {
-			const int refn = active ? (int)g_hot.rf[j + 1] : 0;       // (column `cols` is padding, as in the scan of the matrix this replaces)
+			// any cell of this step at or above minsc?  (rarely: most of the matrix is far below)
+			uint32_t hm = Hp[0];
 #pragma unroll
-			for (int r = 0; r < R; r++) {
-				const uint32_t i = (uint32_t)lane * R + r;
-				const bool c = active && i >= minrow && i < rows && Hnew[r] >= minsc && (refm & (1 << rdc[r])) != 0 && (refn & rdn[r]) == 0;
-				const unsigned long long m = __ballot(c);
-				if (m) {        // (wave-uniform)
-					const uint32_t pos = nem + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-					if (c && pos < emit_cap) { BtCand v; v.score = Hnew[r]; v.row = (uint16_t)i; v.col = (uint16_t)j; gst(emit + pos, v); }
-					nem += (uint32_t)__popcll(m);
+			for (int r = 1; r < RB; r++) hm = pk::maxu(hm, Hp[r]);
+			const uint32_t actm = (act_lo ? 1u : 0u) | (act_hi ? 0x10000u : 0u);
+			const uint32_t anyge = pk::nz(pk::subsu(pk::add(hm, ge_add), ge_sub)) & actm;
+			if (__ballot(anyge != 0u)) {
+				const uint32_t refn = (act_lo ? (uint32_t)g_hot.rf[j_lo + 1] : 0u) | (act_hi ? (uint32_t)g_hot.rf[j_hi + 1] << 16 : 0u);      // (column `cols` is padding)
+#pragma unroll
+				for (int r = 0; r < RB; r++) {
+					const uint32_t h = Hp[r];
+					const uint32_t cnd = pk::nz(pk::subsu(pk::add(h, ge_add), ge_sub)) & actm & cok[r] & pk::nz(refm & K.rowmask[r]) & (pk::nz(refn & rdn[r]) ^ 0x00010001u);
+#pragma unroll
+					for (int half = 0; half < 2; half++) {
+						const bool c = ((cnd >> (16 * half)) & 1u) != 0u;
+						const unsigned long long m = __ballot(c);
+						if (m) {        // (wave-uniform)
+							const uint32_t pos = nem + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+							if (c && pos < emit_cap) {
+								BtCand v; v.score = (int32_t)((h >> (16 * half)) & 0xffffu); v.row = (uint16_t)((lane + 64u * half) * RB + r); v.col = (uint16_t)(half ? j_hi : j_lo);
+								gst(emit + pos, v);
+							}
+							nem += (uint32_t)__popcll(m);
+						}
+					}
 				}
 			}
 		}
-		upHdiag = upH;
-		if (active) { myHlast = Hnew[R - 1]; myFlast = Fnew[R - 1]; }
 	}
-	const int src = (int)nlanes - 1;
-	lastsolcol = (uint32_t)__shfl(lastsol, src);
-	sat8 = (uint32_t)__shfl(sat, src);
+	lastsolcol = (uint32_t)lastsol;
+	sat8 = (uint32_t)sat;
 	n_emit = nem;
-	return __shfl(vmax, src);
+	return vmax;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -458,7 +459,7 @@ __device__ __attribute__((noinline)) int fill_ee_i16_leaf(bool fw_, uint32_t row
 	return fill_ee_i16_wave<R>(g_P, fw, rows, cols, m64);
 }
 // local fill: lastsolcol / sat8 / the number of emitted candidates come back through g_st (fill_lastsol, fill_sat8, n_emit)
-template <int R, bool EMIT>
+template <int RB, bool EMIT>
 __device__ __attribute__((noinline)) int fill_local_leaf(bool fw_, uint32_t rows_, uint32_t cols_, uint8_t* pm_, int ms_, BT2_G BtCand* emit_, uint32_t ecap_) {
 	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
 	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
@@ -469,7 +470,7 @@ __device__ __attribute__((noinline)) int fill_local_leaf(bool fw_, uint32_t rows
 	const uint64_t ea = (uint64_t)emit_;
 	BT2_G BtCand* emit = (BT2_G BtCand*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ea >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ea));
 	uint32_t lastsolcol = 0, sat8 = 0, nem = 0;
-	const int best = fill_local_wave<R, EMIT>(g_P, fw, rows, cols, pm, ms, lastsolcol, sat8, emit, ecap, nem);
+	const int best = fill_local_pk<RB, EMIT>(g_P, fw, rows, cols, pm, ms, lastsolcol, sat8, emit, ecap, nem);
 	if ((threadIdx.x & 63) == 0) { g_st.fill_lastsol = lastsolcol; g_st.fill_sat8 = sat8; g_st.n_emit = nem; g_st.emit_vmax = best; }
 	return best;
 }
@@ -1038,29 +1039,21 @@ struct DevPlat {
 		const int64_t minsc = uni(minsc_);
 		uint8_t* m64 = reinterpret_cast<uint8_t*>(uni_ptr(mat_));      // one predecessor byte per cell, anti-diagonal order (pred_at)
 		const int ms = minsc > 0x7fff ? 0x7fff : (int)minsc;
-		if ((threadIdx.x & 63) == 0) { g_st.dp.epoch[1] = dp_R(rows); g_st.dp.epoch[2] = 0u; }      // geometry of the matrix in the scratch header: anti-diagonal form
+		if ((threadIdx.x & 63) == 0) { g_st.dp.epoch[1] = dp_RB(rows); g_st.dp.epoch[2] = 0u; }      // geometry of the matrix in the scratch header: anti-diagonal form
 		int best;
 		// the worker's fills leave their candidate cells in Work::cands_tmp for gather_local; the stage kernel (k_dp_fill) has no arena
 		BT2_G BtCand* const emit = g_st.emit_on ? &DevPlat::work().cands_tmp[0] : (BT2_G BtCand*)nullptr;
 		const uint32_t ecap = (uint32_t)kMaxCands;
-		if (emit) switch (dp_R(rows)) {
+		if (emit) switch (dp_RB(rows)) {
 			case 1: best = fill_local_leaf<1, true>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 2: best = fill_local_leaf<2, true>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 3: best = fill_local_leaf<3, true>(fw, rows, cols, m64, ms, emit, ecap); break;
-			case 4: best = fill_local_leaf<4, true>(fw, rows, cols, m64, ms, emit, ecap); break;
-			case 5: best = fill_local_leaf<5, true>(fw, rows, cols, m64, ms, emit, ecap); break;
-			case 6: best = fill_local_leaf<6, true>(fw, rows, cols, m64, ms, emit, ecap); break;
-			case 7: best = fill_local_leaf<7, true>(fw, rows, cols, m64, ms, emit, ecap); break;
-			default: best = fill_local_leaf<8, true>(fw, rows, cols, m64, ms, emit, ecap); break;
-		} else switch (dp_R(rows)) {
+			default: best = fill_local_leaf<4, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+		} else switch (dp_RB(rows)) {
 			case 1: best = fill_local_leaf<1, false>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 2: best = fill_local_leaf<2, false>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 3: best = fill_local_leaf<3, false>(fw, rows, cols, m64, ms, emit, ecap); break;
-			case 4: best = fill_local_leaf<4, false>(fw, rows, cols, m64, ms, emit, ecap); break;
-			case 5: best = fill_local_leaf<5, false>(fw, rows, cols, m64, ms, emit, ecap); break;
-			case 6: best = fill_local_leaf<6, false>(fw, rows, cols, m64, ms, emit, ecap); break;
-			case 7: best = fill_local_leaf<7, false>(fw, rows, cols, m64, ms, emit, ecap); break;
-			default: best = fill_local_leaf<8, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			default: best = fill_local_leaf<4, false>(fw, rows, cols, m64, ms, emit, ecap); break;
 		}
 		best = uni(best);
 		wave_fence();
@@ -1442,10 +1435,10 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 			}
 		} else if (pr.kind == BT2G_DP_LOCAL) {
 			// the predecessor bytes of the rectangle, row-major (the fill keeps them in anti-diagonal order: pred_at)
-			const uint32_t R = dp_R(rows);
+			const uint32_t RB = dp_RB(rows);
 			const BT2_G uint8_t* src = (const BT2_G uint8_t*)dp.mat;
 			const uint64_t ncell = (uint64_t)rows * cols;
-			for (uint64_t k = lane; k < ncell; k += 64) body[k] = src[dp_cell(R, (uint32_t)(k / cols), (uint32_t)(k % cols))];
+			for (uint64_t k = lane; k < ncell; k += 64) body[k] = src[dp_cell_pk(RB, (uint32_t)(k / cols), (uint32_t)(k % cols))];
 		} else {
 			const uint32_t R = dp_R(rows);
 			const BT2_G uint64_t* m64 = (const BT2_G uint64_t*)dp.mat;
@@ -1485,7 +1478,7 @@ void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64
 	if (pred_bytes > mat_bytes) mat_bytes = pred_bytes;
 	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
 	// masks of the pred formats: the band form of the widest band, or the anti-diagonal form of the local fill (one word per matrix byte)
-	const uint64_t wf_cells = ((uint64_t)cols + lanes) * R * 64;
+	const uint64_t wf_cells = ((uint64_t)cols + 128) * dp_RB(rows) * 128;      // (dp_cell_pk: at most 128 blocks of at most dp_RB(longest read) rows)
 	const uint64_t mask_cells = pred_cells(rows, cols) > wf_cells ? pred_cells(rows, cols) : wf_cells;
 	pmask_bytes = 256 + ((mask_cells * 4 + 255) & ~(uint64_t)255);
 	arena_stride = ((sizeof(Work) + 255) & ~(uint64_t)255) + (paired ? 2 : 1) * (mat_bytes + mask_bytes + pmask_bytes);

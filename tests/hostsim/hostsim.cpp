@@ -14,6 +14,7 @@
 
 #include "../../bowtie2_amd/csrc/bt2g_index.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_align_core.hpp"
+#include "../../bowtie2_amd/csrc/bt2g_local_pk.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_rankidx.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_host.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_pipeline.hpp"
@@ -43,6 +44,7 @@ struct HostPlat {
 	static uint32_t n_lanes() { return 1; }
 	static bool any(bool b) { return b; }
 	static std::vector<uint16_t>& local_h() { static std::vector<uint16_t> v; return v; }      // H of the last local fill (host only)
+	static std::vector<uint8_t>& local_ef() { static std::vector<uint8_t> v; return v; }        // BT2G_CHECK_LOCAL_PK: bit 0 = E > 0, bit 1 = F > 0 of the last local fill
 	template <typename T> static T* uni_ptr(T* p) { return p; }
 	template <typename TOff> static TOff get_offset(const DevEbwt<TOff>& e, TOff row, uint32_t& nsteps) { return bt2g::get_offset(e, row, nsteps); }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
@@ -335,9 +337,11 @@ struct HostPlat {
 	// sat8 = the 8-bit kernel would have saturated (some column maximum + bias >= 255 before its bail-out point).
 	static int64_t dp_fill_local(const AlignParams& P, Work& w, bool fw, uint32_t rows, uint32_t cols, uint32_t* mat, int64_t minsc,
 	                             uint32_t& lastsolcol, uint32_t& sat8) {
-		const uint32_t R = dp_R(rows);
-		uint8_t* pm = reinterpret_cast<uint8_t*>(mat);      // one predecessor byte per cell, anti-diagonal order (pred_at with w = 0, lo = R)
+		const uint32_t R = dp_RB(rows);
+		uint8_t* pm = reinterpret_cast<uint8_t*>(mat);      // one predecessor byte per cell, anti-diagonal order (pred_at with w = 0, lo = rows per block)
 		st().dp.epoch[1] = R; st().dp.epoch[2] = 0u;
+		static const bool check_pk = getenv("BT2G_CHECK_LOCAL_PK") != nullptr;
+		if (check_pk) local_ef().assign((size_t)rows * cols, 0);
 		local_h().assign((size_t)rows * cols, 0);          // the scores themselves, for gather_local (the device's fill emits the candidates instead)
 		auto subs = [](int a, int b) { const int v = a - b; return v < 0 ? 0 : v; };
 		// bias of the 8-bit query profile: the largest penalty any (read position, reference character) pair can incur
@@ -379,7 +383,8 @@ struct HostPlat {
 				c |= (el > 0 && el - P.rdgape == e) ? PB_EE : 0;
 				c |= (hu > 0 && hu - P.rfgapo == f) ? PB_FO : 0;
 				c |= (fu > 0 && fu - P.rfgape == f) ? PB_FE : 0;
-				pm[dp_cell(R, i, j)] = (uint8_t)c;
+				pm[dp_cell_pk(R, i, j)] = (uint8_t)c;
+				if (check_pk) local_ef()[(size_t)i * cols + j] = (uint8_t)((e > 0 ? 1 : 0) | (f > 0 ? 2 : 0));
 				local_h()[(size_t)i * cols + j] = (uint16_t)h;
 			}
 			if (!bailed) {
@@ -391,7 +396,92 @@ struct HostPlat {
 			}
 			Hp.swap(Hc); Ep.swap(Ec);
 		}
+		if (check_pk) check_local_pk(P, fw, rows, cols, pm, minsc, vmax, lastsolcol, sat8, bias);
 		return (int64_t)vmax;
+	}
+	// BT2G_CHECK_LOCAL_PK=1: the device's local fill computes two cells per register (bt2g_local_pk.hpp) and moves data between lanes; this
+	// replays it -- 64 lanes side by side, the same per-lane step function, the same lane-to-lane hand-over and per-column bookkeeping as
+	// fill_local_pk (bt2g_align_kernel.hip) -- on the window just filled and compares every predecessor byte (the bits somebody can look at:
+	// H bits where H > 0, E bits where E > 0, F bits where F > 0) and the fill's results with the scalar fill's.  Aborts on a difference.
+	template <int RB>
+	static void check_local_pk_t(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, const uint8_t* pm, int64_t minsc, int want_best, uint32_t want_lastsol, uint32_t want_sat, int bias) {
+		const uint32_t nblocks = (rows + RB - 1) / RB;
+		LocalPkRows<RB> K[64];
+		for (uint32_t lane = 0; lane < 64; lane++)
+			for (int r = 0; r < RB; r++) {
+				uint32_t km = 0, kb = 0, kn = 0, kv = 0, ko = 0;
+				for (int half = 0; half < 2; half++) {
+					const uint32_t i = (lane + 64u * half) * RB + r;
+					const bool valid = i < rows;
+					const int rdc = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+					const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
+					const int mmp = mm_penalty(P, q < 0 ? 0 : q);
+					const bool veto = (int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar;
+					const LocalPkRow1 c = local_pk_row(valid, rdc, mmp, veto, P.match_bonus, P.n_pen);
+					km |= c.rowmask << (16 * half); kb |= c.bpm << (16 * half); kn |= c.nmmp << (16 * half); kv |= c.vm << (16 * half); ko |= c.okm << (16 * half);
+				}
+				K[lane].rowmask[r] = km; K[lane].bpm[r] = kb; K[lane].nmmp[r] = kn; K[lane].vm[r] = kv; K[lane].okm[r] = ko;
+			}
+		const LocalPkPen G = local_pk_pen(P.rdgapo, P.rdgape, P.rfgapo, P.rfgape, P.n_pen);
+		uint32_t Hp[64][RB] = {}, Ep[64][RB] = {};
+		uint32_t myH[64] = {}, myF[64] = {}, mycm[64] = {}, upHdiag[64] = {}, refm[64];
+		for (auto& x : refm) x = 0x00100010u;
+		int vmax = 0, lastsol = 0, sat = 0, bailed = 0;
+		const uint32_t last_blk = nblocks - 1, last_lane = last_blk & 63u, last_half = last_blk >> 6;
+		const uint32_t steps = cols + nblocks - 1;
+		const int ms = minsc > 0x7fff ? 0x7fff : (int)minsc;
+		uint64_t nbad = 0;
+		for (uint32_t t = 0; t < steps; t++) {
+			uint32_t upH[64], upF[64], upM[64], upR[64];
+			for (uint32_t l = 1; l < 64; l++) { upH[l] = myH[l - 1]; upF[l] = myF[l - 1]; upM[l] = mycm[l - 1]; upR[l] = refm[l - 1]; }
+			upH[0] = myH[63] << 16; upF[0] = myF[63] << 16; upM[0] = mycm[63] << 16; upR[0] = (refm[63] << 16) | (t < cols ? (uint32_t)g_hot.rf[t] : 16u);
+			uint32_t cmv[64];
+			for (uint32_t l = 0; l < 64; l++) {
+				refm[l] = upR[l];
+				uint32_t pb[RB];
+				uint32_t cm = upM[l];
+				local_pk_step<RB>(K[l], G, refm[l], upHdiag[l], upH[l], upF[l], Hp[l], Ep[l], pb, myH[l], myF[l], cm);
+				mycm[l] = cm; cmv[l] = cm;
+				upHdiag[l] = upH[l];
+				for (int half = 0; half < 2; half++) {
+					const uint32_t k = l + 64u * half, j = t - k;
+					if (k >= nblocks || j >= cols) continue;
+					for (int r = 0; r < RB; r++) {
+						const uint32_t i = k * RB + r;
+						if (i >= rows) continue;
+						const uint32_t got = (pb[r] >> (16 * half)) & 0xffu, want = pm[dp_cell_pk(RB, i, j)];
+						const uint32_t h = local_h()[(size_t)i * cols + j];
+						const uint32_t hgot = (Hp[l][r] >> (16 * half)) & 0xffffu, egot = (Ep[l][r] >> (16 * half)) & 0xffffu;
+												const uint32_t ef = local_ef()[(size_t)i * cols + j];
+						const uint32_t care = (h > 0 ? 7u : 0u) | ((ef & 1u) ? 24u : 0u) | ((ef & 2u) ? 96u : 0u);
+						if ((egot > 0) != ((ef & 1u) != 0)) nbad++;
+						if (hgot != h || ((got ^ want) & care)) {
+							if (nbad++ < 5) fprintf(stderr, "local pk check: cell (%u, %u) of %u x %u: H %u vs %u, pred %02x vs %02x (care %02x)\n", i, j, rows, cols, hgot, h, got, want, care);
+						}
+					}
+				}
+			}
+			if (t >= last_blk && !bailed) {
+				const int j = (int)(t - last_blk);
+				const int c = (int)(last_half ? cmv[last_lane] >> 16 : cmv[last_lane] & 0xffffu);
+				if (c > vmax) vmax = c;
+				if (c + bias >= 255) sat = 1;
+				if (c < ms) { if (c + (int)(cols - (uint32_t)j - 1) * P.match_bonus < ms) bailed = 1; }
+				else lastsol = j;
+			}
+		}
+		if (vmax != want_best || (uint32_t)lastsol != want_lastsol || (uint32_t)sat != want_sat) { fprintf(stderr, "local pk check: best %d vs %d, lastsol %d vs %u, sat %d vs %u\n", vmax, want_best, lastsol, want_lastsol, sat, want_sat); nbad++; }
+		if (nbad) { fprintf(stderr, "local pk check: %llu differences (%u x %u, RB %d)\n", (unsigned long long)nbad, rows, cols, RB); abort(); }
+		static unsigned long n_checked = 0;
+		if (++n_checked == 1) fprintf(stderr, "[hostsim] local pk check active\n");
+	}
+	static void check_local_pk(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, const uint8_t* pm, int64_t minsc, int want_best, uint32_t want_lastsol, uint32_t want_sat, int bias) {
+		switch (dp_RB(rows)) {
+			case 1: check_local_pk_t<1>(P, fw, rows, cols, pm, minsc, want_best, want_lastsol, want_sat, bias); break;
+			case 2: check_local_pk_t<2>(P, fw, rows, cols, pm, minsc, want_best, want_lastsol, want_sat, bias); break;
+			case 3: check_local_pk_t<3>(P, fw, rows, cols, pm, minsc, want_best, want_lastsol, want_sat, bias); break;
+			default: check_local_pk_t<4>(P, fw, rows, cols, pm, minsc, want_best, want_lastsol, want_sat, bias); break;
+		}
 	}
 	// Candidate cells of a local fill, sorted score desc, row desc, col desc
 	static uint32_t gather_local(const uint32_t* mat, BtCand* cands, uint32_t cap, bool fw, uint32_t R, uint32_t rows, uint32_t ncol,

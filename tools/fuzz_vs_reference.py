@@ -14,6 +14,7 @@ HS = os.environ.get('BT2G_HOSTSIM', os.path.join(ROOT, 'tests', 'hostsim', 'host
 os.makedirs('/tmp/fuzz', exist_ok=True)
 seed0=int(sys.argv[1]); nit=int(sys.argv[2])
 MODE=int(os.environ.get('FUZZ_MODE','1'))     # 2: small repeat-dense genomes, short reads, more options per case
+LOCAL=os.environ.get('FUZZ_LOCAL')            # every case in local mode, reads up to 500 bp (with BT2G_CHECK_LOCAL_PK=1: the packed local fill replayed on every window)
 out=open('/tmp/fuzz/fail_%d.log'%seed0,'w')
 def rnd_genome(rnd):
     nref=rnd.randrange(1,4)
@@ -78,6 +79,7 @@ for it in range(nit):
     for _ in range(rnd.randrange(0,4) if MODE==1 else rnd.randrange(1,7)):
         o=rnd.choice(POOL_SE+(POOL_PE if paired else []))
         if o not in opts: opts.append(o)
+    if LOCAL and not any('local' in x for o in opts for x in o) and not any(x in ('--bwa-sw-like','--score-min') for o in opts for x in o): opts.append(['--local'])
     if conflicts(opts): continue
     args=[x for o in opts for x in o]
     exe=ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
@@ -119,7 +121,9 @@ for it in range(nit):
         rs=[]
         for i in range(n):
             _,s=refs[rnd.randrange(len(refs))]
-            L=rnd.randrange(1,260) if MODE==1 else rnd.randrange(1,80); L=min(L,len(s)-1)
+            L=rnd.randrange(1,260) if MODE==1 else rnd.randrange(1,80)
+            if LOCAL and rnd.random()<0.5: L=rnd.randrange(200,500)
+            L=min(L,len(s)-1)
             p=rnd.randrange(0,len(s)-L); m=s[p:p+L]
             if rnd.random()<0.5: m=revcomp(m)
             if rnd.random()<0.05: m="".join(rnd.choice("ACGT") for _ in range(L))
