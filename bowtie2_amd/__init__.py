@@ -63,6 +63,10 @@ class DpOut(C.Structure):
 DP_EE_U8, DP_EE_I16, DP_LOCAL = 0, 1, 2
 
 
+class Mm1Hit(C.Structure):      # bt2g_mm1_hit
+    _fields_ = [("top", C.c_uint64), ("bot", C.c_uint64), ("score", C.c_int32), ("epos", C.c_uint16), ("echr", C.c_uint8), ("eqchr", C.c_uint8)]
+
+
 class AlignParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "mm_type", "mm_max", "mm_min", "n_pen", "rdgapo", "rdgape", "rfgapo", "rfgape", "gapbar", "match_bonus",
@@ -144,6 +148,7 @@ ABI = [
     ("bt2g_results_pack", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     ("bt2g_build_params_default", None, [C.POINTER(BuildParams)]),
     ("bt2g_index_build", C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.POINTER(BuildParams), C.POINTER(BuildStats)]),
+    ("bt2g_one_mm_search", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bt2g_cli_params", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.c_int, C.POINTER(AlignParams), C.POINTER(ReadParams)]),
     ("bt2g_index_build_mem", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_char_p,
                                        C.POINTER(BuildParams), C.POINTER(BuildStats)]),
@@ -252,6 +257,17 @@ class Context:
                                                       offset.data_ptr(), max_seeds, out.data_ptr(), _stream_ptr()),
                "bt2g_seed_search_exact")
         return out
+
+    def one_mm_search(self, batch, rparams, params, sweep, cap=8):
+        """rparams: uint8 device tensor holding ReadParams[n]; sweep: the tensor exact_sweep returned.  Returns (hits, counts): uint8 device
+        tensors holding Mm1Hit[n*4*cap] and the n*4 list lengths (255 = more than cap)."""
+        import torch
+        hits = torch.zeros(batch.n * 4 * cap * C.sizeof(Mm1Hit), dtype=torch.uint8, device=batch.seq.device)
+        cnt = torch.zeros(batch.n * 4, dtype=torch.uint8, device=batch.seq.device)
+        rd = batch.struct()
+        _check(self._h, lib().bt2g_one_mm_search(self._h, C.addressof(rd), rparams.data_ptr(), C.addressof(params), sweep.data_ptr(), cap,
+                                                  hits.data_ptr(), cnt.data_ptr(), _stream_ptr()), "bt2g_one_mm_search")
+        return hits, cnt
 
     def resolve_offsets(self, rows, qlen, reject_straddle=False):
         """rows: int64 tensor [n] (SA rows), qlen: int32 tensor [n]."""

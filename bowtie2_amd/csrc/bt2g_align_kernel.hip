@@ -62,12 +62,12 @@ __device__ __forceinline__ u16x2 p_splat(int v) { return p_make((unsigned short)
 __device__ __forceinline__ u16x2 p_subs(u16x2 a, u16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
 __device__ __forceinline__ u16x2 p_max(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ u16x2 p_min(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ u16x2 p_ne(u16x2 a, u16x2 b) { return p_min(a ^ b, p_splat(1)); }     // 1 where different, else 0
 __device__ __forceinline__ unsigned short s_subs(unsigned short a, unsigned short b) { return __builtin_elementwise_sub_sat(a, b); }
 __device__ __forceinline__ unsigned short s_max(unsigned short a, unsigned short b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t p_bits(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ u16x2 p_from(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ u16x2 p_ne(u16x2 a, u16x2 b) { return p_from(pk::nz(p_bits(a ^ b))); }     // 1 where different, else 0 (pk::nz: v_pk_min_u16 spelled out, see there)
 // (lo.y, hi.x): the pair one diagonal further along
 __device__ __forceinline__ uint32_t shift_in(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 // DPP moves: lanes without a source get 0

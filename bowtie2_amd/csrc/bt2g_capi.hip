@@ -285,6 +285,39 @@ int bt2g_seed_search_exact(bt2g_ctx* c, const bt2g_reads* reads, const uint32_t*
 	return e == hipSuccess ? 0 : hip_fail(c, e, "k_seed_search_exact");
 }
 
+static_assert(sizeof(bt2g_mm1_hit) == sizeof(Mm1Hit) && offsetof(bt2g_mm1_hit, score) == offsetof(Mm1Hit, score) && offsetof(bt2g_mm1_hit, epos) == offsetof(Mm1Hit, epos) &&
+              offsetof(bt2g_mm1_hit, echr) == offsetof(Mm1Hit, echr) && offsetof(bt2g_mm1_hit, eqchr) == offsetof(Mm1Hit, eqchr), "bt2g_mm1_hit is the kernels' Mm1Hit");
+
+int bt2g_one_mm_search(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_params* d_rparams, const bt2g_align_params* params,
+                       const bt2g_sweep_out* d_sweep, uint32_t cap, bt2g_mm1_hit* d_hits, uint8_t* d_n, void* stream) {
+	int rc = need_loaded(c);
+	if (rc) return rc;
+	if (!reads || !d_rparams || !params || !d_sweep || !d_hits || !d_n || cap == 0 || cap > 254) return fail(c, BT2G_ERR_ARG, "bad argument");
+	hipStream_t st = (hipStream_t)stream;
+	const uint64_t n = reads->n_reads;
+	if (n == 0) return 0;
+	// scratch of the four kernels: per-list hit counters, the queue of deferred branches, the task list, the two queue counters
+	auto al = [](uint64_t v) { return (v + 255) & ~255ull; };
+	const uint64_t b_cnt = al(n * 4 * sizeof(unsigned int));
+	const uint64_t qcap64 = n * 16 < 0xfffffff0ull ? n * 16 : 0xfffffff0ull;
+	const uint64_t b_q = al(qcap64 * one_mm_task_bytes(c->off_size));
+	const uint64_t b_t = al(n * 4 * sizeof(uint32_t));
+	uint8_t* d_tmp = nullptr;
+	hipError_t e = hipMalloc((void**)&d_tmp, b_cnt + b_q + b_t + 256);
+	if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(one_mm scratch)");
+	unsigned int* d_cntl = (unsigned int*)d_tmp;
+	void* d_q = d_tmp + b_cnt;
+	uint32_t* d_t = (uint32_t*)(d_tmp + b_cnt + b_q);
+	unsigned int* d_qc = (unsigned int*)(d_tmp + b_cnt + b_q + b_t);
+	e = (c->off_size == 4)
+		? launch_one_mm(c->ix32, *params, *reads, d_rparams, d_sweep, cap, (void*)d_hits, d_n, d_cntl, d_q, (uint32_t)qcap64, d_qc, d_t, c->d_cnt, st)
+		: launch_one_mm(c->ix64, *params, *reads, d_rparams, d_sweep, cap, (void*)d_hits, d_n, d_cntl, d_q, (uint32_t)qcap64, d_qc, d_t, c->d_cnt, st);
+	const hipError_t e2 = hipStreamSynchronize(st);
+	(void)hipFree(d_tmp);
+	if (e != hipSuccess) return hip_fail(c, e, "k_one_mm");
+	return e2 == hipSuccess ? 0 : hip_fail(c, e2, "k_one_mm");
+}
+
 int bt2g_resolve_offsets(bt2g_ctx* c, const uint64_t* d_rows, const uint32_t* d_qlen, uint64_t n, int reject_straddle,
                          bt2g_resolved* d_out, void* stream) {
 	int rc = need_loaded(c);

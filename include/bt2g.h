@@ -315,6 +315,30 @@ int bt2g_align_batch(bt2g_ctx *ctx, const bt2g_reads *reads, const bt2g_read_par
                      const bt2g_align_params *params, uint32_t max_read_len,
                      void *d_results, void *stream);
 
+/* ---- stage 2b: 1-mismatch end-to-end search ------------------------------ */
+/* One hit of SeedAligner::oneMmSearch (aligner_seed.cpp:975-1325; EEHit, aligner_seed.h:482-560). */
+typedef struct {
+	uint64_t top, bot;        /* range in the forward index                                   */
+	int32_t  score;
+	uint16_t epos;            /* mismatch offset from the read's 5' end (Edit::pos)           */
+	uint8_t  echr, eqchr;     /* reference character 0..3 / read character 0..4               */
+} bt2g_mm1_hit;
+
+/*
+ * Replaces SeedAligner::oneMmSearch(..., repex = false, rep1mm = true, ...) as the worker calls it
+ * (bt2_search.cpp:3704-3728) for a whole batch.  Input besides the reads: the per-read parameters
+ * (minsc, nceil, filters) and the output of bt2g_exact_sweep (the reference only searches a strand
+ * whose sweep left mine <= 1).  The search of read r is four independent walks -- strand (0 fw, 1 rc)
+ * x index (0 forward, 1 mirror) -- and list l = r*4 + strand*2 + index holds the hits of one walk in
+ * the order the reference adds them: d_hits[l*cap .. l*cap + d_n[l]); the reference's hit list of
+ * the read is lists 4r .. 4r+3 concatenated.  d_n[l] = 255: the walk found more than `cap` hits
+ * (the worker then redoes that read with its inline search).  cap <= 254.  Synchronises `stream`
+ * (it frees its scratch).
+ */
+int bt2g_one_mm_search(bt2g_ctx *ctx, const bt2g_reads *reads, const bt2g_read_params *d_rparams,
+                       const bt2g_align_params *params, const bt2g_sweep_out *d_sweep, uint32_t cap,
+                       bt2g_mm1_hit *d_hits, uint8_t *d_n, void *stream);
+
 /*
  * Cuts the fixed-stride records of a finished batch down to what the host needs before they cross PCIe
  * (a record is sized for BT2G_MAX_EDITS edits per alignment; a typical read carries a handful).  Packed record

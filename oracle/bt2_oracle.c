@@ -464,6 +464,176 @@ void bt2o_seed_search_exact(const bt2o_ebwt *fw, const bt2o_ebwt *bw,
 }
 
 /* ------------------------------------------------------------------ */
+/* 1-mismatch end-to-end search                                        */
+/* ------------------------------------------------------------------ */
+/* Ebwt::mapBiLFEx (bt2_idx.h:2372-2440): ranks of all four characters at top and bot, and the sub-ranges in the other index
+ * (prefix sums in character order from topp). */
+static void bi_lf_ex(const bt2o_ebwt *e, uint64_t top, uint64_t bot, uint64_t topp, uint64_t t[4], uint64_t b[4], uint64_t tp[4], uint64_t bp[4]) {
+	bt2o_rank4(e, top, t);
+	bt2o_rank4(e, bot, b);
+	uint64_t acc = topp;
+	for (int j = 0; j < 4; j++) { tp[j] = acc; acc += b[j] - t[j]; bp[j] = acc; }
+}
+
+int bt2o_one_mm_search(const bt2o_ebwt *ebwt_fw, const bt2o_ebwt *ebwt_bw, const uint8_t *seq_in, const char *qual_in, size_t len,
+                       const bt2o_scoring *sc, int nceil, int64_t minsc, int nofw, int norc, int local, int repex, int rep1mm,
+                       bt2o_mm1_hit *out, int cap) {
+	const int match_bonus = sc->match_bonus;
+	int nout = 0;
+	size_t ns = 0;
+	for (size_t i = 0; i < len; i++) if (seq_in[i] > 3) ns++;
+	if (ns > 1) return 0;                    /* :992-998 */
+	if (ns == 1 && !rep1mm) return 0;
+	if (len < 2) return 0;
+	/* patFw, patFwRev, patRc, patRcRev and the matching quality strings (read.h) */
+	uint8_t *pat[4]; char *qu[2];
+	for (int k = 0; k < 4; k++) pat[k] = (uint8_t*)malloc(len);
+	for (int k = 0; k < 2; k++) qu[k] = (char*)malloc(len);
+	for (size_t i = 0; i < len; i++) {
+		pat[0][i] = seq_in[i];                                         /* patFw */
+		pat[1][i] = seq_in[len - 1 - i];                               /* patFwRev */
+		pat[2][i] = seq_in[len - 1 - i] > 3 ? 4 : 3 - seq_in[len - 1 - i];   /* patRc */
+		pat[3][i] = seq_in[i] > 3 ? 4 : 3 - seq_in[i];                 /* patRcRev */
+		qu[0][i] = qual_in[i]; qu[1][i] = qual_in[len - 1 - i];        /* qual, qualRev */
+	}
+	const size_t half_fw = len >> 1, half_bw = (len >> 1) + (len & 1);
+	uint64_t t[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, tp[4] = {0, 0, 0, 0}, bp[4] = {0, 0, 0, 0};
+	uint64_t top = 0, bot = 0, topp = 0, botp = 0;
+	for (int fwi = 0; fwi < 2; fwi++) {
+		const int fw = fwi == 0;
+		if (fw && nofw) continue;
+		if (!fw && norc) continue;
+		const int lim = rep1mm ? 2 : 1;
+		for (int ebwtfwi = 0; ebwtfwi < lim; ebwtfwi++) {
+			const int ebwtfw = ebwtfwi == 0;
+			const bt2o_ebwt *ebwt = ebwtfw ? ebwt_fw : ebwt_bw, *ebwtp = ebwtfw ? ebwt_bw : ebwt_fw;
+			const uint8_t *seq = fw ? (ebwtfw ? pat[0] : pat[1]) : (ebwtfw ? pat[2] : pat[3]);
+			const char *qual = fw ? (ebwtfw ? qu[0] : qu[1]) : (ebwtfw ? qu[1] : qu[0]);
+			const int ftab_len = ebwt->ftab_chars;
+			const size_t nea = ebwtfw ? half_fw : half_bw;
+			int skip = 0;
+			for (size_t dep = 0; dep < nea; dep++) if (seq[len - dep - 1] > 3) { skip = 1; break; }
+			if (skip) continue;
+			size_t dep = 0;
+			if (ftab_len > 1 && (size_t)ftab_len <= nea) {            /* :1057-1072 */
+				const int rev = !ebwtfw;
+				bt2o_ftab_lohi(ebwt, bt2o_ftab_seq_to_int(ebwt, seq, len - ftab_len, rev), &top, &bot);
+				if (rep1mm) bt2o_ftab_lohi(ebwtp, bt2o_ftab_seq_to_int(ebwtp, seq, len - ftab_len, rev), &topp, &botp);
+				if (bot - top == 0) continue;
+				const int c = seq[len - ftab_len];
+				t[c] = top; b[c] = bot; tp[c] = topp; bp[c] = botp;
+				dep = (size_t)ftab_len;
+			} else {                                                  /* :1073-1084 */
+				const int c = seq[len - 1];
+				top = topp = tp[c] = ebwt->fchr[c];
+				bot = botp = bp[c] = ebwt->fchr[c + 1];
+				if (bot - top == 0) continue;
+				dep = 1;
+			}
+			int do_continue = 0;
+			for (; dep < nea; dep++) {                                /* near half: exact, :1088-1123 */
+				const int rdc = seq[len - dep - 1];
+				if (bot - top > 1) {
+					bi_lf_ex(ebwt, top, bot, topp, t, b, tp, bp);
+					top = t[rdc]; bot = b[rdc];
+					if (bot <= top) { do_continue = 1; break; }
+					topp = tp[rdc]; botp = bp[rdc];
+				} else {
+					top = bt2o_map_lf1c(ebwt, top, rdc);
+					if (top == ebwt->off_mask) { do_continue = 1; break; }
+					bot = top + 1;
+					t[rdc] = top; b[rdc] = bot; tp[rdc] = topp; bp[rdc] = botp;
+				}
+			}
+			if (do_continue) continue;
+			for (; dep < len; dep++) {                                /* far half, :1128-1318 */
+				const int rdc = seq[len - dep - 1];
+				const int quc = qual[len - dep - 1];
+				if (rdc > 3 && nceil == 0) break;
+				tp[0] = tp[1] = tp[2] = tp[3] = topp;
+				bp[0] = bp[1] = bp[2] = bp[3] = botp;
+				int clo = 0, chi = 3, match = 1;
+				if (bot - top > 1) {
+					bi_lf_ex(ebwt, top, bot, topp, t, b, tp, bp);
+					match = rdc < 4;
+					if (rdc < 4) { top = t[rdc]; bot = b[rdc]; topp = tp[rdc]; botp = bp[rdc]; }   /* (rdc == 4: the reference reads past the arrays; the values are not used: match is false) */
+				} else {
+					clo = bt2o_map_lf1(ebwt, &top);
+					match = clo == rdc;
+					if (clo < 0) break;                                /* hit the $ */
+					t[clo] = top; b[clo] = bot = top + 1;
+					bp[clo] = botp; tp[clo] = topp;
+					chi = clo;
+				}
+				if (rep1mm && (ns == 0 || rdc > 3)) {
+					for (int j = clo; j <= chi; j++) {
+						if (j == rdc || b[j] == t[j]) continue;
+						size_t depm = dep + 1;
+						uint64_t topm = t[j], botm = b[j], topmp = tp[j], botmp = bp[j];
+						uint64_t tm[4], bm[4], tmp_[4], bmp[4];
+						for (; depm < len; depm++) {
+							const int rdcm = seq[len - depm - 1];
+							if (botm - topm > 1) {
+								bi_lf_ex(ebwt, topm, botm, topmp, tm, bm, tmp_, bmp);
+								if (rdcm > 3) { topm = botm = 0; break; }       /* (cannot happen: the only N is at dep) */
+								topm = tm[rdcm]; botm = bm[rdcm]; topmp = tmp_[rdcm]; botmp = bmp[rdcm];
+								if (botm <= topm) break;
+							} else {
+								topm = bt2o_map_lf1c(ebwt, topm, rdcm);
+								if (topm == ebwt->off_mask) break;
+								botm = topm + 1;
+							}
+						}
+						if (depm == len) {                             /* a 1-mismatch hit, :1213-1276 */
+							size_t off5p = dep;
+							if (fw == ebwtfw) off5p = len - off5p - 1;
+							int64_t score = (int64_t)(len - 1) * match_bonus;
+							const int pen = bt2o_score(sc, rdc, 1 << j, quc - 33);
+							score += pen;
+							int valid = 1;
+							if (local) {
+								int64_t lf = 0, lb = 0;
+								for (size_t i = 0; i < len; i++) {
+									if (i == dep) { if (lf + pen <= 0) { valid = 0; break; } lf += pen; } else lf += match_bonus;
+									if (len - i - 1 == dep) { if (lb + pen <= 0) { valid = 0; break; } lb += pen; } else lb += match_bonus;
+								}
+							}
+							if (valid) valid = score >= minsc;
+							if (valid) {
+								if (nout < cap) {
+									bt2o_mm1_hit *h = &out[nout];
+									memset(h, 0, sizeof(*h));
+									h->top = ebwtfw ? topm : topmp; h->bot = ebwtfw ? botm : botmp;
+									h->score = score; h->off5p = (uint32_t)off5p; h->chr = (uint8_t)j; h->qchr = (uint8_t)rdc;
+									h->fw = (uint8_t)fw; h->kind = 1; h->ebwtfw = (uint8_t)ebwtfw;
+								}
+								nout++;
+							}
+						}
+					}
+				}
+				if (bot > top && match) {
+					if (dep == len - 1) {
+						if (ebwtfw && repex) {                         /* an exact hit, :1285-1305 */
+							if (nout < cap) {
+								bt2o_mm1_hit *h = &out[nout];
+								memset(h, 0, sizeof(*h));
+								h->top = top; h->bot = bot; h->score = (int64_t)len * match_bonus; h->fw = (uint8_t)fw; h->kind = 0; h->ebwtfw = 1;
+							}
+							nout++;
+						}
+						break;
+					}
+				} else break;
+			}
+		}
+	}
+	for (int k = 0; k < 4; k++) free(pat[k]);
+	for (int k = 0; k < 2; k++) free(qu[k]);
+	return nout;
+}
+
+/* ------------------------------------------------------------------ */
 /* reference fetch                                                     */
 /* ------------------------------------------------------------------ */
 int bt2o_ref_get_base(const bt2o_ref *r, uint64_t tidx, uint64_t toff) {

@@ -194,6 +194,30 @@ void ref_exact_sweep(void *h, const char *seq, const char *qual, uint64_t *out) 
 	out[8] = nelt; out[9] = al.bwops_;
 }
 
+/* SeedAligner::oneMmSearch on an ASCII read.  Per hit, in the order the search added them: {top, bot, score, pos (from the 5' end), reference
+ * character code, read character code, fw}.  Returns the number of 1-mismatch hits (at most cap are written); out_exact = {fw hit?, top,
+ * bot, rc hit?, top, bot} for repex. */
+int ref_one_mm(void *h, const char *seq, const char *qual, int64_t minsc, int nofw, int norc, int local, int repex, int rep1mm,
+               uint64_t *out, int cap, uint64_t *out_exact) {
+	RefCtx *c = (RefCtx*)h;
+	Read rd("r", seq, qual);
+	SeedAligner al;
+	SeedResults shs;
+	SeedSearchMetrics met;
+	shs.nextRead(rd);
+	al.oneMmSearch(c->fw, c->bw, rd, *c->sc, minsc, nofw != 0, norc != 0, local != 0, repex != 0, rep1mm != 0, shs, met);
+	const EList<EEHit>& hs = shs.mm1EEHits();
+	auto code = [](int ch) -> uint64_t { switch(ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; } };
+	for(size_t i = 0; i < hs.size() && (int)i < cap; i++) {
+		uint64_t *o = out + i * 7;
+		o[0] = hs[i].top; o[1] = hs[i].bot; o[2] = (uint64_t)hs[i].score; o[3] = hs[i].e1.pos; o[4] = code(hs[i].e1.chr); o[5] = code(hs[i].e1.qchr); o[6] = hs[i].fw ? 1 : 0;
+	}
+	EEHit f = shs.exactFwEEHit(), r = shs.exactRcEEHit();
+	out_exact[0] = f.empty() ? 0 : 1; out_exact[1] = f.empty() ? 0 : f.top; out_exact[2] = f.empty() ? 0 : f.bot;
+	out_exact[3] = r.empty() ? 0 : 1; out_exact[4] = r.empty() ? 0 : r.top; out_exact[5] = r.empty() ? 0 : r.bot;
+	return (int)hs.size();
+}
+
 /*
  * One exact seeding round as the worker runs it (bt2_search.cpp:3910-3964):
  * Seed::mmSeeds(0, seedlen) -> instantiateSeeds(offset, interval) -> searchAllSeeds.

@@ -57,6 +57,11 @@ class Scoring(C.Structure):
                                         "rd_gap_const", "rd_gap_linear", "rf_gap_const", "rf_gap_linear", "gapbar")]
 
 
+class Mm1Hit(C.Structure):      # bt2o_mm1_hit (oracle/bt2_oracle.h)
+    _fields_ = [("top", C.c_uint64), ("bot", C.c_uint64), ("score", C.c_int64), ("off5p", C.c_uint32), ("chr", C.c_uint8), ("qchr", C.c_uint8),
+                ("fw", C.c_uint8), ("kind", C.c_uint8), ("ebwtfw", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
 class Rng(C.Structure):
     _fields_ = [("a", C.c_uint32), ("c", C.c_uint32), ("last", C.c_uint32), ("lastOff", C.c_uint32), ("inited", C.c_int)]
 
@@ -103,6 +108,9 @@ def oracle():
         L.bt2o_sw_fill_ee_u8.argtypes = [C.POINTER(Scoring), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                          C.c_char_p, C.c_char_p, C.c_char_p]
         L.bt2o_sw_fill_ee_u8.restype = C.c_int
+        L.bt2o_one_mm_search.argtypes = [C.POINTER(Ebwt), C.POINTER(Ebwt), C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(Scoring), C.c_int, C.c_int64,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Mm1Hit), C.c_int]
+        L.bt2o_one_mm_search.restype = C.c_int
         _oracle = L
     return _oracle
 
@@ -141,6 +149,8 @@ def refshim(large=False):
         L.ref_sw_fill_kind.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int64, i32p, i32p, i32p, C.POINTER(C.c_int)]
         L.ref_sw_fill_kind.restype = C.c_int64
         L.ref_set_match_bonus.argtypes = [C.c_void_p, C.c_int]
+        L.ref_one_mm.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_int, u64p]
+        L.ref_one_mm.restype = C.c_int
         L.ref_rng_stream.argtypes = [C.c_uint32, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         L.ref_score.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]; L.ref_score.restype = C.c_int64
         _refshim[key] = L

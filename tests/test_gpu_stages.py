@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import bowtie2_amd as b
-from bt2test import (Index, Scoring, SeedHit, SweepOut, cached_synth_index, encode, oracle, revcomp, sha,
+from bt2test import (Index, Mm1Hit, Scoring, SeedHit, SweepOut, cached_synth_index, encode, oracle, revcomp, sha,
                      synth_reads, u64)
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -86,6 +86,94 @@ def test_exact_sweep(case):
         cnt = ctx.counters()
         assert cnt.bwops == tot_bwops          # same number of BW ops as the reference counts (AlBWOp parity)
         assert cnt.rank_queries == tot_rank    # and the roofline byte accounting agrees with the oracle's
+
+
+def one_mm_reads(refs, seed):
+    """Reads oneMmSearch has something to say about (the mix of tests/test_oracle_vs_ref.py::one_mm_reads): one substitution anywhere incl. the
+    ends and around the middle, one N, exact copies, two substitutions, low complexity, very short."""
+    rnd = random.Random(seed)
+    g = [s for _, s in refs]
+    out = []
+    for k in range(600):
+        s = g[rnd.randrange(len(g))]
+        L = rnd.choice([2, 3, 5, 9, 10, 11, 12, 20, 21, 33, 50, 100, 101, 150, 250])
+        if L >= len(s):
+            continue
+        p = rnd.randrange(0, len(s) - L)
+        r = list(s[p:p + L])
+        if "N" in r:
+            continue
+        kind = k % 6
+        if kind in (0, 1):
+            i = rnd.choice([0, L - 1, L // 2, L // 2 - 1, (L + 1) // 2, rnd.randrange(L)]) % L
+            r[i] = rnd.choice([c for c in "ACGT" if c != r[i]])
+        elif kind == 2:
+            r[rnd.randrange(L)] = "N"
+        elif kind == 3:
+            for _ in range(2):
+                i = rnd.randrange(L); r[i] = rnd.choice([c for c in "ACGT" if c != r[i]])
+        elif kind == 4 and L > 4:
+            r = list(rnd.choice("ACGT") * L)
+        r = "".join(r)
+        if rnd.random() < 0.5:
+            r = revcomp(r)
+        out.append(("m%d" % k, r, "".join(rnd.choice("I5+#?") for _ in r)))
+    return out
+
+
+@pytest.mark.parametrize("mode", [["--sensitive"], ["--local"], ["--sensitive", "--nofw"], ["--sensitive", "--norc", "--ignore-quals"]], ids=["e2e", "local", "nofw", "norc"])
+def test_one_mm_search(case, mode):
+    """k_one_mm_tasks / k_one_mm_scan / k_one_mm_cont / k_one_mm_fin through bt2g_one_mm_search against bt2o_one_mm_search (which
+    tests/test_oracle_vs_ref.py pins to SeedAligner::oneMmSearch itself): per (read, strand, index direction) the same hits in the same order --
+    range, score, mismatch position from the 5' end, reference and read character.  The kernels get the parameters the product derives from
+    its command line (bt2g_cli_params) and the device's own exact sweep; a strand whose sweep proved two edits is not searched, as in the
+    reference's call site (bt2_search.cpp:3704-3706)."""
+    import numpy as np
+    import torch
+    ctx, L, idx, refs = case
+    reads = [r for r in one_mm_reads(refs, 41) if len(r[1]) >= 1]
+    batch = ctx.upload_reads([encode(s) for _, s, _ in reads], [q.encode() for _, _, q in reads])
+    large = idx.fwd.off_size == 8
+    P = None
+    rps = (b.ReadParams * len(reads))()
+    for k, (_, s, _) in enumerate(reads):
+        P, rp = b.cli_params(mode, len(s), large_index=large)
+        rps[k] = rp
+    rparams = torch.from_numpy(np.frombuffer(bytes(rps), dtype=np.uint8).copy()).to(batch.seq.device)
+    sweep_t = ctx.exact_sweep(batch, bool(P.nofw), bool(P.norc), 2)
+    sweep = b.structs_from_tensor(sweep_t, b.SweepOut)
+    cap = 16
+    hits_t, cnt_t = ctx.one_mm_search(batch, rparams, P, sweep_t, cap)
+    hits = b.structs_from_tensor(hits_t, b.Mm1Hit)
+    cnt = cnt_t.cpu().numpy()
+    sc = Scoring()
+    L.bt2o_scoring_default(C.byref(sc))
+    sc.match_bonus = P.match_bonus
+    sc.mm_pen_type, sc.mm_max, sc.mm_min, sc.n_pen = P.mm_type, P.mm_max, P.mm_min, P.n_pen      # (--ignore-quals: constant penalty MX)
+    local = P.match_bonus > 0
+    ohits = (Mm1Hit * 512)()
+    total = 0
+    for k, (_, s, q) in enumerate(reads):
+        rp = rps[k]
+        for strand in range(2):
+            searched = (rp.filt & 15) == 15 and len(s) >= 2 and sweep[k].mine[strand] <= 1 and not (P.nofw if strand == 0 else P.norc)
+            want = [[], []]
+            if searched:
+                n = L.bt2o_one_mm_search(C.byref(idx.fwd), C.byref(idx.bwd), encode(s), q.encode(), len(s), C.byref(sc), rp.nceil, rp.minsc,
+                                         int(strand != 0), int(strand != 1), int(local), 0, 1, ohits, 512)
+                assert n <= 512
+                for i in range(n):
+                    h = ohits[i]
+                    want[0 if h.ebwtfw else 1].append((h.top, h.bot, h.score, h.off5p, h.chr, h.qchr))
+            for d in range(2):
+                l = k * 4 + strand * 2 + d
+                if len(want[d]) > cap:
+                    assert cnt[l] == 255, (k, s, strand, d)
+                    continue
+                got = [(hits[l * cap + i].top, hits[l * cap + i].bot, hits[l * cap + i].score, hits[l * cap + i].epos, hits[l * cap + i].echr, hits[l * cap + i].eqchr) for i in range(int(cnt[l]))]
+                assert got == want[d], (k, s, strand, d, got, want[d])
+                total += len(got)
+    assert total > 100
 
 
 def test_seed_search(case):

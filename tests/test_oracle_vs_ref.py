@@ -5,7 +5,7 @@ import random
 
 import pytest
 
-from bt2test import (Index, Scoring, SeedHit, SweepOut, cached_synth_index, encode, have_ref, oracle, refshim,
+from bt2test import (Index, Mm1Hit, Scoring, SeedHit, SweepOut, cached_synth_index, encode, have_ref, oracle, refshim,
                      revcomp, synth_reads, u64)
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (no /root/reference)")
@@ -80,6 +80,76 @@ def test_sweep_and_seed_rounds(ctx):
                         mine = [1, sh.topf, sh.botf, sh.topb, sh.botb] if sh.botf > sh.topf else [0] * 5
                     assert mine == want
             assert mybw == bw.value
+
+
+def one_mm_reads(refs, seed):
+    """Reads that oneMmSearch has something to say about: copies of the genome with exactly one substitution (anywhere, incl. the ends and
+    the middle where the near half ends), with one N, exact copies, two substitutions (nothing to find), very short reads, homopolymers."""
+    rnd = random.Random(seed)
+    g = [s for _, s in refs]
+    out = []
+    for k in range(260):
+        s = g[rnd.randrange(len(g))]
+        L = rnd.choice([2, 3, 5, 9, 10, 11, 12, 20, 21, 33, 50, 100, 101, 150, 250])
+        p = rnd.randrange(0, len(s) - L)
+        r = list(s[p:p + L])
+        if "N" in r:
+            continue
+        kind = k % 6
+        if kind in (0, 1):
+            i = rnd.choice([0, L - 1, L // 2, L // 2 - 1, (L + 1) // 2, rnd.randrange(L)]) % L
+            r[i] = rnd.choice([c for c in "ACGT" if c != r[i]])
+        elif kind == 2:
+            r[rnd.randrange(L)] = "N"
+        elif kind == 3:
+            for _ in range(2):
+                i = rnd.randrange(L); r[i] = rnd.choice([c for c in "ACGT" if c != r[i]])
+        elif kind == 4 and L > 4:
+            r = list(rnd.choice("ACGT") * L)       # low complexity: wide ranges, many branches
+        r = "".join(r)
+        if rnd.random() < 0.5:
+            r = revcomp(r)
+        out.append(("m%d" % k, r, "".join(rnd.choice("I5+#?") for _ in r)))
+    return out
+
+
+def oracle_one_mm(L, idx, sc, s, q, nceil, minsc, nofw, norc, local, repex, rep1mm, cap=512):
+    hits = (Mm1Hit * cap)()
+    n = L.bt2o_one_mm_search(C.byref(idx.fwd), C.byref(idx.bwd), encode(s), q.encode(), len(s), C.byref(sc), nceil, minsc, nofw, norc, local, repex, rep1mm, hits, cap)
+    assert n <= cap
+    return [hits[i] for i in range(n)]
+
+
+def test_one_mm_search(ctx):
+    """SeedAligner::oneMmSearch (aligner_seed.cpp:975-1325) against bt2o_one_mm_search: same hits, same order, end to end and with the local
+    validity rule, with and without exact hits reported, one strand switched off."""
+    L, R, idx, h, refs = ctx
+    sc = Scoring()
+    L.bt2o_scoring_default(C.byref(sc))
+    out = (u64 * (7 * 512))()
+    ex = (u64 * 6)()
+    nhits = 0
+    for local in (0, 1):
+        sc.match_bonus = 2 if local else 0
+        R.ref_set_match_bonus(h, sc.match_bonus)
+        for k, (nm, s, q) in enumerate(one_mm_reads(refs, 21 + local)):
+            n = len(s)
+            nceil = min(int(0 + 0.15 * n), n)
+            minsc = (20 + int(8.0 * __import__("math").log(n))) if local else int(-0.6 - 0.6 * n)
+            nofw, norc = (k % 11 == 3), (k % 13 == 5)
+            for repex, rep1mm in ((0, 1), (1, 1), (1, 0)):
+                nref = R.ref_one_mm(h, s.encode(), q.encode(), minsc, nofw, norc, local, repex, rep1mm, out, 512, ex)
+                mine = oracle_one_mm(L, idx, sc, s, q, nceil, minsc, nofw, norc, local, repex, rep1mm)
+                m1 = [x for x in mine if x.kind == 1]
+                assert len(m1) == nref, (nm, s, local, repex, rep1mm)
+                for i, x in enumerate(m1):
+                    assert [x.top, x.bot, x.score & (2**64 - 1), x.off5p, x.chr, x.qchr, x.fw] == list(out[i * 7:i * 7 + 7]), (nm, s, i)
+                e0 = [x for x in mine if x.kind == 0]
+                want = [[1, ex[1], ex[2]]] * int(ex[0]) + [[0, ex[4], ex[5]]] * int(ex[3])
+                assert [[x.fw, x.top, x.bot] for x in e0] == want, (nm, s, repex)
+                nhits += nref
+    R.ref_set_match_bonus(h, 0)
+    assert nhits > 300
 
 
 def test_dp_fill_random(ctx):
