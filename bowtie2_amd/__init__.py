@@ -149,6 +149,7 @@ ABI = [
     ("bt2g_build_params_default", None, [C.POINTER(BuildParams)]),
     ("bt2g_index_build", C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.POINTER(BuildParams), C.POINTER(BuildStats)]),
     ("bt2g_one_mm_search", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("bt2g_index_rows", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     ("bt2g_cli_params", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.c_int, C.POINTER(AlignParams), C.POINTER(ReadParams)]),
     ("bt2g_index_build_mem", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_char_p,
                                        C.POINTER(BuildParams), C.POINTER(BuildStats)]),
@@ -256,6 +257,13 @@ class Context:
         _check(self._h, lib().bt2g_seed_search_exact(self._h, C.byref(rd), seedlen.data_ptr(), interval.data_ptr(),
                                                       offset.data_ptr(), max_seeds, out.data_ptr(), _stream_ptr()),
                "bt2g_seed_search_exact")
+        return out
+
+    def index_rows(self, first, n):
+        """int64 tensor [n, 16]: rows first .. first + n - 1 seen through the device layout (bt2g_index_rows)."""
+        import torch
+        out = torch.zeros((n, 16), dtype=torch.int64, device="cuda:%d" % self.device)
+        _check(self._h, lib().bt2g_index_rows(self._h, first, n, out.data_ptr(), _stream_ptr()), "bt2g_index_rows")
         return out
 
     def one_mm_search(self, batch, rparams, params, sweep, cap=8):

@@ -318,6 +318,16 @@ int bt2g_one_mm_search(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_par
 	return e2 == hipSuccess ? 0 : hip_fail(c, e2, "k_one_mm");
 }
 
+int bt2g_index_rows(bt2g_ctx* c, uint64_t first_row, uint64_t n_rows, uint64_t* d_out, void* stream) {
+	int rc = need_loaded(c);
+	if (rc) return rc;
+	const uint64_t len = c->off_size == 4 ? (uint64_t)c->ix32.fw.len : (uint64_t)c->ix64.fw.len;
+	if (!d_out || first_row > len || n_rows > len + 1 - first_row) return fail(c, BT2G_ERR_ARG, "bad argument");
+	hipStream_t st = (hipStream_t)stream;
+	hipError_t e = (c->off_size == 4) ? launch_index_rows(c->ix32, first_row, n_rows, d_out, st) : launch_index_rows(c->ix64, first_row, n_rows, d_out, st);
+	return e == hipSuccess ? 0 : hip_fail(c, e, "k_index_rows");
+}
+
 int bt2g_resolve_offsets(bt2g_ctx* c, const uint64_t* d_rows, const uint32_t* d_qlen, uint64_t n, int reject_straddle,
                          bt2g_resolved* d_out, void* stream) {
 	int rc = need_loaded(c);

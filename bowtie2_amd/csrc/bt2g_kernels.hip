@@ -516,6 +516,41 @@ hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, co
 }
 
 // ------------------------------------------------------------------------------------
+// Every row's view through the HBM layout (tests: bt2g_index_rows against the oracle's walk over the on-disk layout)
+// ------------------------------------------------------------------------------------
+// out[16] per row: row, joined offset (full suffix array), steps the reference's LF walk to the sample would take, rank4 in the forward
+// index, mapLF1 (character, next row), rank4 in the mirror index, the rank pair (row, min(row + 37, len)) of character row & 3 and the
+// number of reference sides that pair reads -- the columns tests/hostsim prints for BT2G_INDEX_DUMP.
+template <typename TOff>
+__global__ void __launch_bounds__(256)
+k_index_rows(DevIndex<TOff> ix, uint64_t first, uint64_t n, uint64_t* __restrict__ out) {
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= n) return;
+	const uint64_t r = first + gid;
+	uint64_t* o = out + gid * 16;
+	uint32_t steps = 0;
+	const TOff jo = get_offset(ix.fw, (TOff)r, steps);
+	TOff f4[4], b4[4];
+	rank4(ix.fw, (TOff)r, f4); rank4(ix.bw, (TOff)r, b4);
+	TOff rr = (TOff)r;
+	const int ch = map_lf1(ix.fw, rr);
+	TOff t1 = 0, b1 = 0;
+	const int ns = rank1_pair(ix.fw, (TOff)r, (TOff)(r + 37 <= (uint64_t)ix.fw.len ? r + 37 : ix.fw.len), (int)(r & 3), t1, b1);
+	o[0] = r; o[1] = (uint64_t)jo; o[2] = steps;
+	for (int k = 0; k < 4; k++) { o[3 + k] = (uint64_t)f4[k]; o[9 + k] = (uint64_t)b4[k]; }
+	o[7] = (uint64_t)(int64_t)ch; o[8] = ch < 0 ? 0 : (uint64_t)rr;
+	o[13] = (uint64_t)t1; o[14] = (uint64_t)b1; o[15] = (uint64_t)ns;
+}
+template <typename TOff>
+hipError_t launch_index_rows(const DevIndex<TOff>& ix, uint64_t first, uint64_t n, uint64_t* d_out, hipStream_t st) {
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_index_rows<TOff>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ix, first, n, d_out);
+	return hipGetLastError();
+}
+template hipError_t launch_index_rows<uint32_t>(const DevIndex<uint32_t>&, uint64_t, uint64_t, uint64_t*, hipStream_t);
+template hipError_t launch_index_rows<uint64_t>(const DevIndex<uint64_t>&, uint64_t, uint64_t, uint64_t*, hipStream_t);
+
+// ------------------------------------------------------------------------------------
 // 1-mismatch end-to-end search, one lane per (read, strand, index direction)
 // ------------------------------------------------------------------------------------
 // Four kernels.  (0) k_one_mm_tasks: one lane per (read, strand) decides whether oneMmSearch runs for it at all -- the worker only

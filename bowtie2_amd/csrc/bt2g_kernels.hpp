@@ -37,6 +37,8 @@ hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, c
 uint64_t one_mm_task_bytes(int off_size);
 
 template <typename TOff>
+hipError_t launch_index_rows(const DevIndex<TOff>& ix, uint64_t first, uint64_t n, uint64_t* d_out, hipStream_t st);
+template <typename TOff>
 hipError_t launch_resolve_offsets(const DevIndex<TOff>& ix, const uint64_t* d_rows, const uint32_t* d_qlen, uint64_t n,
                                   int reject_straddle, bt2g_resolved* d_out, DevCounters* d_cnt, hipStream_t st);
 

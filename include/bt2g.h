@@ -131,6 +131,17 @@ int bt2g_seed_search_exact(bt2g_ctx *ctx, const bt2g_reads *reads,
                            const uint32_t *d_seedlen, const uint32_t *d_interval, const uint32_t *d_offset,
                            uint32_t max_seeds, bt2g_seed_hit *d_out, void *stream);
 
+/* ---- the index as the device holds it, row by row (test hook) ------------ */
+/*
+ * The device does not keep the reference's on-disk layout (sides + sampled suffix array, bt2_idx.h:1060-1100): bt2g_index_load
+ * transcodes it into 64-byte rank blocks and a full suffix array.  This reads rows first_row .. first_row + n_rows - 1
+ * (0 <= row <= len) back through that layout, 16 values per row:
+ *   [0] row  [1] Ebwt::getOffset(row)  [2] LF steps the reference's walk takes  [3..6] rank of A,C,G,T at row, forward index
+ *   [7] character of the row (-1: the $ row)  [8] mapLF1(row)  [9..12] ranks in the mirror index
+ *   [13],[14] rank of character (row & 3) at row and at min(row + 37, len)  [15] sides the reference reads for that pair.
+ */
+int bt2g_index_rows(bt2g_ctx *ctx, uint64_t first_row, uint64_t n_rows, uint64_t *d_out, void *stream);
+
 /* ---- stage 3: SA-row -> text offset ------------------------------------ */
 typedef struct {
 	uint64_t joined_off;      /* Ebwt::getOffset(row) (bt2_idx.cpp:150)      */

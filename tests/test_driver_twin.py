@@ -87,14 +87,14 @@ def mgpu_run(twin, common, out, world, sharding=None, env_extra=None):
 
 
 @pytest.mark.parametrize("inp", ["unpaired", "paired"])
-@pytest.mark.parametrize("sharding,world", [("blocks", 2), ("bytes", 2), ("bytes", 3)])
+@pytest.mark.parametrize("sharding,world", [("blocks", 2), ("bytes", 2), ("bytes", 3), ("bytes", 8), ("blocks", 8)])      # 8: the node the scaling bench runs on
 def test_sharded_ranks_through_the_driver(twin, inp, sharding, world, tmp_path):
     """bowtie2_amd.mgpu on gloo, every rank running the product's driver.  blocks: --shard r/N, SAM pieces gathered over the process group.
     bytes: --shard-bytes, every rank parses its own byte range of the reads file(s) only and the pieces concatenate.  Either way the merged
     SAM and the summed summary equal the one-process run and the reference's golden SAM -- including the @PG line, which shows the user's
     command line, not a rank's."""
     src = ["-U", FQ] if inp == "unpaired" else ["-1", M1, "-2", M2]
-    common = ["--sensitive", "--batch", "64", "-x", os.path.join(GOLD, "tiny_s")] + src
+    common = ["--sensitive", "--batch", "64" if world < 8 else "16", "-x", os.path.join(GOLD, "tiny_s")] + src      # (8 ranks: enough blocks for every rank to own several)
     one = run(twin, common)
     out = tmp_path / "merged.sam"
     errs = mgpu_run(twin, common, out, world, sharding, {"BT2G_MGPU_REPORT_BYTES": "1"})
