@@ -73,7 +73,7 @@ class AlignParams(C.Structure):
         "khits", "mhits", "max_dp_streak", "max_ug", "max_dp", "max_iters", "n_seed_rounds", "seed_boost_thresh",
         "tighten", "maxhalf", "nofw", "norc", "do_exact_upfront", "do_1mm_upfront", "do_ungapped", "do_extend",
         "large_index", "all_hits", "seed_mms", "overhang", "paired", "pe_policy", "pe_maxfrag", "pe_minfrag", "pe_flags",
-        "max_mate_streak", "det_seeds", "seed_cache_mb", "profile", "max_seeds")]
+        "max_mate_streak", "det_seeds", "seed_cache_mb", "profile", "max_seeds", "max_dp_cols")]
 
 
 class ReadParams(C.Structure):

@@ -56,8 +56,13 @@ constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
 #ifdef BT2G_PROBE_SMALL
 constexpr int kMaxCols     = 340;
 #else
-constexpr int kMaxCols     = 1100;  // DP columns: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*15
+constexpr int kMaxCols     = 1100;  // DP columns a launch holds unless the caller asks for more: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*gaps
 #endif
+// Widest DP window any launch can hold (bt2g_align_params::max_dp_cols asks for it).  The per-column state of the window in flight -- the
+// reference masks and the last row's scores -- lives in LDS, and LDS decides how many waves a CU holds: the common batch (unpaired reads,
+// pairs with the default -X 500) is launched with kMaxCols columns of it and runs 16 waves per CU; a batch whose opposite-mate windows are
+// wider (-X 800, --local pairs of long reads, --dovetail) is launched with as many as it needs, up to this, and runs 12.
+constexpr int kMaxColsWide = 2176;
 
 enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };
 enum { EXT_EXHAUSTED = 1, EXT_POLICY_FULFILLED, EXT_PERFECT_SCORE, EXT_SOFT_LIMIT, EXT_HARD_LIMIT };
@@ -199,15 +204,12 @@ struct SeedRange { uint64_t topf, topb; uint32_t size; uint32_t esize; };   // o
 struct HotWork {
 	uint8_t  seq[kMaxLen];     // read, codes 0..4, 5'->3'
 	uint8_t  qual[kMaxLen];    // ASCII
-	uint8_t  rf[kMaxCols + 8]; // reference masks of the current DP window
+	// (the reference masks of the current DP window, the edits of the backtrace in progress and the scores of the last DP row live behind
+	// Plat::rf() / ned() / lastrow(): sized per launch, see kMaxColsWide)
 	HotHit   hits[2][kMaxOffs];// [0] fw seeds, [1] rc seeds; size==0 => no hit
 	uint8_t  sorted[2][kMaxOffs];
 	uint8_t  rank_offs[kMaxRanges];
 	uint8_t  rank_fw[kMaxRanges];
-	union {                    // never live at the same time: the gather reads `lastrow` before any backtrace writes `ned`
-		Edit     ned[kMaxEdits];   // edits of the backtrace in progress
-		int16_t  lastrow[kMaxCols + 8];   // scores of the last DP row, clamped at -32768 (gatherCells)
-	};
 	// ---- scalar control state of the read in flight (everything the control code touches often) ----
 	uint32_t len;
 	EEHit    exact[2];         // [0] fw, [1] rc; top==bot => empty
@@ -284,7 +286,7 @@ struct Work {
 	BtCand   cands[kMaxCands];
 	uint32_t cand_hist[2 * (kMaxLocalScore + 1)];   // scratch of the local gather's counting sort
 	uint32_t cand_done[2][kMaxCandDone];            // local mode: tried candidates (row | col << 16) of the anchor's window and of the opposite mate's
-	BtFrame  btstack[kMaxLen + kMaxCols];
+	BtFrame  btstack[kMaxLen + kMaxColsWide];
 	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
 	// ---- paired-end (extendSeedsPaired; unused for unpaired reads) ----
 	// seed-phase state of the mate that is not loaded (both mates are searched before either is extended)
@@ -416,8 +418,23 @@ struct AlState {
 	uint32_t  n_emit;                 // device, local mode: candidate cells the last fill wrote to Work::cands_tmp (unsorted; may exceed its capacity)
 	int32_t   emit_vmax;              //   ... and the largest score among them
 	uint32_t  emit_on;                // 1 in the workers (Aligner's constructor); 0 in the stage kernel, whose waves have no work area
+	uint32_t  max_cols;               // DP columns this launch holds (kMaxCols .. kMaxColsWide): wider windows flag the read
+	uint32_t  tail_off;               // device: where ned / lastrow start in the launch's dynamic LDS (behind rf)
 	uint32_t  fill_rows_done, fill_lastsol, fill_sat8;   // device: what a leaf fill hands back besides its return value (row the score-only pass stopped in; lastsolcol_ / "8-bit kernel saturated" of a local fill)
 };
+
+// The per-column tail of the hot state, as one launch lays it out behind the fixed part:  rf[max_cols + 8]  (rounded up to 16 bytes), then a
+// region shared by  Edit ned[kMaxEdits]  and  int16_t lastrow[max_cols + 8]  (never live at the same time: the gather reads `lastrow` before
+// any backtrace writes `ned`; the local gather's radix sort borrows 2 048 bytes of it for its counters).
+// DP columns a launch with these parameters holds (bt2g_align_params::max_dp_cols)
+BT2_HD uint32_t dp_cols_for(const AlignParams& P) { return P.max_dp_cols > kMaxCols ? (uint32_t)(P.max_dp_cols < kMaxColsWide ? P.max_dp_cols : kMaxColsWide) : (uint32_t)kMaxCols; }
+BT2_HD uint32_t hot_tail_off(uint32_t max_cols) { return (max_cols + 8 + 15) & ~15u; }
+BT2_HD uint32_t hot_tail_bytes(uint32_t max_cols) {
+	uint32_t b = (max_cols + 8) * 2;
+	if (b < (uint32_t)(kMaxEdits * sizeof(Edit))) b = (uint32_t)(kMaxEdits * sizeof(Edit));
+	if (b < 2048u) b = 2048u;
+	return hot_tail_off(max_cols) + ((b + 15) & ~15u);
+}
 
 // ---------------------------------------------------------------------------------------
 // small helpers
@@ -475,6 +492,24 @@ BT2_HD int max_ref_gaps(const AlignParams& P, int64_t minsc, uint32_t rdlen) {
 		num++;
 	}
 	return num - 1;
+}
+
+// Upper bound on the columns (+ 1 padding column) of the DP window in which a mate of length `ordlen` with minimum score `ominsc` is looked
+// for next to its aligned partner (extend_seeds_paired: pe_other_mate + pe_frame_mate_rect = otherMate, pe.cpp:237-420, and
+// frameFindMateRect, dp_framer.cpp:177-305): the span of admissible fragment ends, the mate itself, and the gap allowance on both sides.
+// The caller of bt2g_align_batch takes the maximum over the pairs of a batch for bt2g_align_params::max_dp_cols.
+BT2_HD uint32_t mate_window_bound(const AlignParams& P, int64_t ominsc, uint32_t ordlen, uint32_t len1, uint32_t len2) {
+	int64_t maxfrag = P.pe_maxfrag;
+	const int64_t minfrag = P.pe_minfrag < 1 ? 1 : P.pe_minfrag;
+	if ((int64_t)len1 > maxfrag) maxfrag = (int64_t)len1;
+	if ((int64_t)len2 > maxfrag) maxfrag = (int64_t)len2;
+	int maxgap = max_read_gaps(P, ominsc, ordlen);
+	const int rfg = max_ref_gaps(P, ominsc, ordlen);
+	if (rfg > maxgap) maxgap = rfg;
+	if (maxgap < P.maxhalf) maxgap = P.maxhalf;
+	if (maxgap < 0) maxgap = 0;
+	const int64_t w = (maxfrag - minfrag) + (int64_t)ordlen + 2 * (int64_t)maxgap + 2;
+	return w < 1 ? 1u : w > 0x7fffffff ? 0x7fffffffu : (uint32_t)w;
 }
 
 // read accessors: patFw / patRc / qual / qualRev (read.h:73-128)

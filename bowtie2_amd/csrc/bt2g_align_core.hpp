@@ -1297,8 +1297,8 @@ struct Aligner {
 			Plat::fetch_ref_joined(IX.ref, HOT.frag_jlo + (uint64_t)rel, count);
 #ifdef BT2G_CHECK_REF_JOINED
 			// test builds: the joined-text form must give what the record search gives
-			{ uint8_t a[kMaxCols + 8]; memcpy(a, HOT.rf, count); Plat::fetch_ref(IX.ref, WK, tidx, rfi, count); static unsigned long n_ = 0; n_++;
-			  if (memcmp(a, HOT.rf, count)) { fprintf(stderr, "fetch_ref_joined mismatch (tidx %llu rfi %lld count %u)\n", (unsigned long long)tidx, (long long)rfi, count); abort(); }
+			{ uint8_t a[kMaxColsWide + 8]; memcpy(a, Plat::rf(), count); Plat::fetch_ref(IX.ref, WK, tidx, rfi, count); static unsigned long n_ = 0; n_++;
+			  if (memcmp(a, Plat::rf(), count)) { fprintf(stderr, "fetch_ref_joined mismatch (tidx %llu rfi %lld count %u)\n", (unsigned long long)tidx, (long long)rfi, count); abort(); }
 			  if ((n_ & (n_ - 1)) == 0) fprintf(stderr, "fetch_ref_joined checked %lu windows\n", n_); }
 #endif
 		} else Plat::fetch_ref(IX.ref, WK, tidx, rfi, count);
@@ -1472,7 +1472,7 @@ struct Aligner {
 		// the walk moves left from its start column by at most rows + gaps columns: three registers (768 columns) cover every window of an
 		// unpaired read from column 0 (rf_c0 = 0); only a candidate past column 767 of a wide opposite-mate window needs them re-based
 		uint32_t rf_c0 = 0;
-		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64);
+		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64);
 		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
 			const uint32_t word = idx >> 2;
 			uint32_t v = Plat::lane(arr[0], word & 63);
@@ -1498,7 +1498,7 @@ struct Aligner {
 			const uint32_t trim_end = rows - row - 1;
 			uint32_t trim_beg = 0;
 			int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
-			Edit* ned = HOT.ned;
+			Edit* ned = Plat::ned();
 			const int offsetsc = local ? 0 : (wide ? -0x7fff : -0xff);
 			auto fl = [&](int v) -> bool { return !local || v > 0; };     // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
 			HOT.n_bt_attempts++;
@@ -1676,7 +1676,7 @@ struct Aligner {
 					break;
 				}
 				if (branch) {
-					if (nstack >= (uint32_t)(kMaxLen + kMaxCols)) { ovf(18); return false; }
+					if (nstack >= (uint32_t)(kMaxLen + kMaxColsWide)) { ovf(18); return false; }
 					if (nstack < 64u) {
 						Plat::set_lane(sk0, nstack, nned); Plat::set_lane(sk1, nstack, ncells | (olap ? 0x80000000u : 0u)); Plat::set_lane(sk2, nstack, (row & 0xffffu) | (col << 16));
 						Plat::set_lane(sk3, nstack, (gaps & 0xffffu) | (read_gaps << 16)); Plat::set_lane(sk4, nstack, (ref_gaps & 0xffffu) | ((uint32_t)ct << 16));
@@ -1754,7 +1754,7 @@ struct Aligner {
 			res.score = score; res.ns = (int16_t)ns; res.gaps = (int16_t)gaps; res.edits = (int16_t)nned;
 			res.bases_aligned = (int16_t)((int)rows - (int)trim_beg - (int)trim_end - (int)nned);
 			uint32_t refns = 0;
-			for (uint32_t i = col; i <= orig_col; i++) if (HOT.rf[i] > 15) refns++;
+			for (uint32_t i = col; i <= orig_col; i++) if (Plat::rf()[i] > 15) refns++;
 			res.refns = (uint16_t)refns;
 			set_shape(res, (int32_t)tidx, (int64_t)col + rect_refl, tlen, fw, rows, fw ? trim_beg : trim_end, fw ? trim_end : trim_beg);
 			return true;
@@ -1824,7 +1824,7 @@ struct Aligner {
 			const uint32_t need_c0 = (c.col + 1u > 768u) ? (((uint32_t)c.col + 1u - 768u + 3u) & ~3u) : 0u;
 			if (need_c0 > 0 && rows + 250u > 764u) { ovf(17); ret = false; }   // the walk could leave the 768-column window (rows + read gaps)
 			else {
-				if (need_c0 != rf_c0) { rf_c0 = need_c0; for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(HOT.rf, (uint32_t)sizeof(HOT.rf), k * 64 + (rf_c0 >> 2)); }
+				if (need_c0 != rf_c0) { rf_c0 = need_c0; for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64 + (rf_c0 >> 2)); }
 				const uint64_t tw_ = now();
 				ret = walk(c.row, c.col, tile, tile_hi);
 				if (PRM.profile) { const uint64_t dt_ = now() - tw_; HOT.t_bt[0] += dt_; if (ret) { HOT.t_bt[1] += dt_; HOT.t_bt[2]++; } }
@@ -1867,7 +1867,7 @@ struct Aligner {
 		uint32_t rowi = 0, rowf = len - 1;
 		auto step = [&](uint32_t i) {
 			const int rdc = rd_char(HOT, HOT.len, fw, i);
-			const int rfc = HOT.rf[i];
+			const int rfc = Plat::rf()[i];
 			const int q = rd_qual(HOT, HOT.len, fw, i) - 33;
 			if (rdc > 3 || rfc > 3) { ns++; score -= PRM.n_pen; }
 			else if (rdc == rfc) score += PRM.match_bonus;
@@ -1898,7 +1898,7 @@ struct Aligner {
 		uint32_t nned = 0, refns = 0;
 		for (uint32_t i = rowi; i <= rowf; i++) {
 			const int rdc = rd_char(HOT, HOT.len, fw, i);
-			const int rfc = HOT.rf[i];
+			const int rfc = Plat::rf()[i];
 			if (rfc > 3 || rdc != rfc) {
 				if (nned >= (uint32_t)kMaxEdits) { ovf(22); return 0; }
 				Edit& e = res.ned[nned++];
@@ -2085,7 +2085,7 @@ struct Aligner {
 						diag_add((int32_t)tidx, refoff, fw, 1);
 						if (!found) continue;
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
-						if (cols + 1 > (uint32_t)kMaxCols || rows > (uint32_t)kMaxLen) { ovf(23); return EXT_HARD_LIMIT; }
+						if (cols + 1 > ST.max_cols || rows > (uint32_t)kMaxLen) { ovf(23); return EXT_HARD_LIMIT; }
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
 						// SwAligner::align (aligner_sw.cpp:500-729).  End to end: 8-bit kernel while ST.minsc >= -254, else 16-bit (:517).
 						// Local: the 8-bit kernel unless it saturates, then the 16-bit one (:568-600); the fill below is exact and

@@ -23,6 +23,11 @@ __shared__ AlignParams g_P;
 __shared__ ReadParams g_rp;
 __shared__ PreComp g_pre;
 __shared__ AlState g_st;     // the worker's own state (Aligner has no data members)
+// The per-column tail of the hot state (hot_tail_bytes, bt2g_align.hpp): dynamic LDS, sized by the launch from the widest DP window it must hold.
+extern __shared__ __attribute__((aligned(16))) uint8_t g_tail[];
+__device__ __forceinline__ uint8_t* dev_rf() { return g_tail; }                      // reference masks of the current DP window
+__device__ __forceinline__ int16_t* dev_lastrow() { return reinterpret_cast<int16_t*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.tail_off)); }      // scores of the last DP row, clamped at -32768 (gatherCells)
+__device__ __forceinline__ Edit* dev_ned() { return reinterpret_cast<Edit*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.tail_off)); }                 // edits of the backtrace in progress
 alignas(16) __shared__ unsigned char g_ix_raw[sizeof(DevIndex<uint64_t>) > sizeof(DevIndex<uint32_t>) ? sizeof(DevIndex<uint64_t>) : sizeof(DevIndex<uint32_t>)];
 
 // Memory written by some lanes of the wave and read by others afterwards.  (One workgroup = one wavefront: the compiler knows the largest
@@ -92,13 +97,13 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 		for (int hh = 0; hh < 2; hh++) {
 			const int j = j00 + 2 * k + hh;
 			const bool real = (uint32_t)j < cols;
-			const uint32_t code = real ? (uint32_t)__builtin_ctz((uint32_t)g_hot.rf[real ? j : 0] | 16u) : 4u;
+			const uint32_t code = real ? (uint32_t)__builtin_ctz((uint32_t)dev_rf()[real ? j : 0] | 16u) : 4u;
 			sel |= (code | 0x0c00u) << (16 * hh);
 			h |= (real ? 0xffu : 0u) << (16 * hh);       // "row -1": an alignment may start in any column of row 0
 		}
 		refS[k] = sel; Hp[k] = p_from(h); Fp[k] = p_splat(0);
 	}
-	if (PRED) for (uint32_t j = (uint32_t)lane; j < cols; j += 64) g_hot.lastrow[j] = (int16_t)-0xff;      // columns the band does not reach in the last row
+	if (PRED) for (uint32_t j = (uint32_t)lane; j < cols; j += 64) dev_lastrow()[j] = (int16_t)-0xff;      // columns the band does not reach in the last row
 	int jin = j00 + N2;                       // column that enters the lane's last diagonal in the next row
 	const int rdgape = P.rdgape, rdgapo = P.rdgapo;
 	const u16x2 rdoP = p_splat(rdgapo), rfoP = p_splat(P.rfgapo), rfeP = p_splat(P.rfgape);
@@ -209,7 +214,7 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 			}
 			{
 				int jc = jin < 0 ? 0 : jin; if (jc > (int)cols) jc = (int)cols;      // outside the window: any character will do (see above)
-				const uint32_t newel = (uint32_t)__builtin_ctz((uint32_t)g_hot.rf[jc] | 16u) | 0x0c00u;
+				const uint32_t newel = (uint32_t)__builtin_ctz((uint32_t)dev_rf()[jc] | 16u) | 0x0c00u;
 #pragma unroll
 				for (int k = 0; k < RP; k++) refS[k] = shift_in(refS[k], k + 1 < RP ? refS[k + 1 < RP ? k + 1 : 0] : newel);
 				jin++;
@@ -225,7 +230,7 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 		for (int hh = 0; hh < 2; hh++) {
 			const int j = jl0 + 2 * k + hh;
 			const int h = hh ? (int)HP[k].y : (int)HP[k].x;
-			if ((uint32_t)j < cols) { best = imax(best, h); if (PRED) g_hot.lastrow[j] = (int16_t)(h - 0xff); }
+			if ((uint32_t)j < cols) { best = imax(best, h); if (PRED) dev_lastrow()[j] = (int16_t)(h - 0xff); }
 		}
 	}
 #pragma unroll
@@ -264,7 +269,7 @@ __device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, bool fw, u
 		const int upH = __shfl_up(myHlast, 1);
 		const int upF = __shfl_up(myFlast, 1);
 		int upRef = __shfl_up(refm, 1);
-		if (lane == 0) upRef = (t < cols) ? g_hot.rf[t] : 16;
+		if (lane == 0) upRef = (t < cols) ? dev_rf()[t] : 16;
 		refm = upRef;
 		const int j = (int)t - lane;
 		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
@@ -360,7 +365,7 @@ __device__ __forceinline__ int fill_local_pk(const AlignParams& P, bool fw, uint
 		{
 			const uint32_t wH = (uint32_t)__builtin_amdgcn_readlane((int)myH, 63), wF = (uint32_t)__builtin_amdgcn_readlane((int)myF, 63);
 			const uint32_t wM = (uint32_t)__builtin_amdgcn_readlane((int)mycm, 63), wR = (uint32_t)__builtin_amdgcn_readlane((int)refm, 63);
-			const uint32_t feed = (t < cols) ? (uint32_t)g_hot.rf[t] : 16u;
+			const uint32_t feed = (t < cols) ? (uint32_t)dev_rf()[t] : 16u;
 			if (lane == 0) { upH = wH << 16; upF = wF << 16; upM = wM << 16; upR = (wR << 16) | feed; }
 		}
 		refm = upR;
@@ -400,7 +405,7 @@ __device__ __forceinline__ int fill_local_pk(const AlignParams& P, bool fw, uint
 			const uint32_t actm = (act_lo ? 1u : 0u) | (act_hi ? 0x10000u : 0u);
 			const uint32_t anyge = pk::nz(pk::subsu(pk::add(hm, ge_add), ge_sub)) & actm;
 			if (__ballot(anyge != 0u)) {
-				const uint32_t refn = (act_lo ? (uint32_t)g_hot.rf[j_lo + 1] : 0u) | (act_hi ? (uint32_t)g_hot.rf[j_hi + 1] << 16 : 0u);      // (column `cols` is padding)
+				const uint32_t refn = (act_lo ? (uint32_t)dev_rf()[j_lo + 1] : 0u) | (act_hi ? (uint32_t)dev_rf()[j_hi + 1] << 16 : 0u);      // (column `cols` is padding)
 #pragma unroll
 				for (int r = 0; r < RB; r++) {
 					const uint32_t h = Hp[r];
@@ -477,6 +482,9 @@ __device__ __attribute__((noinline)) int fill_local_leaf(bool fw_, uint32_t rows
 
 struct DevPlat {
 	static __device__ __forceinline__ HotWork& hot() { return g_hot; }
+	static __device__ __forceinline__ uint8_t* rf() { return dev_rf(); }
+	static __device__ __forceinline__ Edit* ned() { return dev_ned(); }
+	static __device__ __forceinline__ int16_t* lastrow() { return dev_lastrow(); }
 	static __device__ __forceinline__ const AlignParams& params() { return g_P; }
 	static __device__ __forceinline__ ReadParams& rparams() { return g_rp; }
 	static __device__ __forceinline__ const PreComp* pre() { return &g_pre; }
@@ -833,7 +841,7 @@ struct DevPlat {
 		if (in && k < L) {
 			const uint32_t r = row - k, c = col - k;
 			const int readc = rd_char(g_hot, rdlen, fw, r);
-			const int refm = g_hot.rf[c];
+			const int refm = dev_rf()[c];
 			const int readq = rd_qual(g_hot, rdlen, fw, r);
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			edit = m != 1;
@@ -864,10 +872,10 @@ struct DevPlat {
 		if (in && k < L) {
 			const uint32_t r = read_gap ? row : row - k, c = read_gap ? col - k : col;
 			Edit e;
-			if (read_gap) { const int refm = g_hot.rf[c]; e.pos = (uint16_t)(r + 1); e.chr = (uint8_t)((refm == 1 || refm == 2 || refm == 4 || refm == 8) ? code2chr(__builtin_ctz((unsigned)refm)) : 'N'); e.qchr = '-'; e.type = EDIT_READ_GAP; }
+			if (read_gap) { const int refm = dev_rf()[c]; e.pos = (uint16_t)(r + 1); e.chr = (uint8_t)((refm == 1 || refm == 2 || refm == 4 || refm == 8) ? code2chr(__builtin_ctz((unsigned)refm)) : 'N'); e.qchr = '-'; e.type = EDIT_READ_GAP; }
 			else { e.pos = (uint16_t)r; e.chr = '-'; e.qchr = code2chr(rd_char(g_hot, rdlen, fw, r)); e.type = EDIT_REF_GAP; }
 			e.pad = 0;
-			g_hot.ned[nned + k] = e;
+			dev_ned()[nned + k] = e;
 			gst(dp.pmask + pred_at(band_lo, band_w, r, c), (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift));
 			const int diagi = (int)c - (int)r + r_triml;
 			incore = diagi >= r_corel && diagi <= r_corer;
@@ -882,7 +890,7 @@ struct DevPlat {
 			int sc;
 			if (wide) sc = (int)(int16_t)(uint16_t)(reinterpret_cast<const uint64_t*>(mat)[dp_cell(R, rows - 1, j)] & 0xffff) - 0x7fff;
 			else sc = (int)(mat[dp_cell(R, rows - 1, j)] & 0xff) - 0xff;
-			g_hot.lastrow[j] = (int16_t)(sc < -32768 ? -32768 : sc);
+			dev_lastrow()[j] = (int16_t)(sc < -32768 ? -32768 : sc);
 		}
 		wave_fence();
 	}
@@ -909,12 +917,12 @@ struct DevPlat {
 		uint32_t total = 0;
 		for (uint32_t base = 0; base < cols; base += 64) {
 			const uint32_t j = base + lane;
-			const int sc = j < cols ? (int)g_hot.lastrow[j] : -65536;
+			const int sc = j < cols ? (int)dev_lastrow()[j] : -65536;
 			const bool is = j < cols && sc >= thr;
 			if (__ballot(is) == 0ull) continue;
 			uint32_t rank = 0;
 			for (uint32_t k = 0; k < cols; k++) {
-				const int s2 = (int)g_hot.lastrow[k];
+				const int s2 = (int)dev_lastrow()[k];
 				if (s2 >= thr && (s2 > sc || (s2 == sc && k > j))) rank++;
 			}
 			if (is && rank < cap) { BtCand c; c.score = sc; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)j; cands[rank] = c; }
@@ -1013,21 +1021,21 @@ struct DevPlat {
 	static __device__ __forceinline__ void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
 		wave_fence();
 		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);      // the window's first record: one search for the whole window
-		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)(1 << ref_base_at(ref, tidx, rfi + (int64_t)i, rec0));
+		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) dev_rf()[i] = (uint8_t)(1 << ref_base_at(ref, tidx, rfi + (int64_t)i, rec0));
 		wave_fence();
 	}
 	// a window that lies inside one N-free fragment is `count` consecutive characters of the joined text: no record search
 	static __device__ __forceinline__ void fetch_ref_joined(const DevRef& ref, uint64_t jpos, uint32_t count) {
 		wave_fence();
 		const uint8_t* buf = uni_ptr(ref.buf);
-		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) { const uint64_t p = jpos + i; g_hot.rf[i] = (uint8_t)(1u << ((gld(buf + (p >> 2)) >> ((p & 3) << 1)) & 3)); }
+		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) { const uint64_t p = jpos + i; dev_rf()[i] = (uint8_t)(1u << ((gld(buf + (p >> 2)) >> ((p & 3) << 1)) & 3)); }
 		wave_fence();
 	}
 	// the same window as base codes 0..4 (ungappedAlign compares characters, aligner_sw.cpp:330-380)
 	static __device__ __forceinline__ void fetch_ref_codes(const DevRef& ref, uint64_t tidx, int64_t rfi, uint32_t count) {
 		wave_fence();
 		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);
-		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) g_hot.rf[i] = (uint8_t)ref_base_at(ref, tidx, rfi + (int64_t)i, rec0);
+		for (uint32_t i = threadIdx.x & 63; i < count; i += 64) dev_rf()[i] = (uint8_t)ref_base_at(ref, tidx, rfi + (int64_t)i, rec0);
 		wave_fence();
 	}
 	// (a thin dispatcher: the fills themselves are leaf functions, see fill_ee_u8_leaf)
@@ -1084,11 +1092,11 @@ struct DevPlat {
 		const uint32_t tot = cb + rb + sb;
 		uint32_t npass = (tot + 9u) / 10u; if (!(npass & 1u)) npass++;
 		const uint64_t kmask = tot >= 64u ? ~0ull : ((1ull << tot) - 1ull);
-		uint16_t* const cnt = reinterpret_cast<uint16_t*>(g_hot.lastrow);       // 1024 counters (kMaxCols + 8 >= 1024 int16)
+		uint16_t* const cnt = reinterpret_cast<uint16_t*>(dev_lastrow());       // 1024 counters (kMaxCols + 8 >= 1024 int16)
 #ifndef BT2G_PROBE_SMALL      // (occupancy probe builds never run --local)
-		static_assert(sizeof(g_hot.lastrow) >= 2048, "radix counters");
+		// (hot_tail_bytes keeps at least 2 048 bytes there)
 #endif
-		uint32_t* const cnt32 = reinterpret_cast<uint32_t*>(g_hot.lastrow);
+		uint32_t* const cnt32 = reinterpret_cast<uint32_t*>(dev_lastrow());
 		for (uint32_t p = 0; p < npass; p++) {
 			BT2_G BtCand* const src = (p & 1u) ? dst : tmp;
 			BT2_G BtCand* const out = (p & 1u) ? tmp : dst;
@@ -1188,7 +1196,7 @@ struct DevPlat {
 				int pen = 0;
 				for (uint32_t i = threadIdx.x & 63; i < rows; i += 64) {
 					const int c = rd_char(g_hot, g_hot.len, fw, i);
-					const int rfm = g_hot.rf[i + dd];
+					const int rfm = dev_rf()[i + dd];
 					if (c > 3 || rfm > 15) pen += P.n_pen;
 					else if (!((rfm >> c) & 1)) { const int q = rd_qual(g_hot, g_hot.len, fw, i) - 33; pen += mm_penalty(P, q < 0 ? 0 : q); }
 				}
@@ -1271,7 +1279,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre, uint32_t max_read_len) {
+              PreComp pre, uint32_t max_read_len, uint32_t max_cols) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	BT2_G Work& w = *(BT2_G Work*)base;
@@ -1279,6 +1287,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes);
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
+	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
 	wave_fence();
 	for (;;) {
 		unsigned int r = 0;
@@ -1322,7 +1331,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre, uint32_t max_read_len) {
+              PreComp pre, uint32_t max_read_len, uint32_t max_cols) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	BT2_G Work& w = *(BT2_G Work*)base;
@@ -1330,6 +1339,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	carve_scratch(dp2, carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes), mat_bytes, mask_bytes, pmask_bytes);
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
+	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
 	wave_fence();
 	const unsigned int n_pairs = rd.n_reads / 2;
 	for (;;) {
@@ -1374,16 +1384,17 @@ template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
                         uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
-                        const PreComp& pre, uint32_t max_read_len, hipStream_t st) {
+                        const PreComp& pre, uint32_t max_read_len, uint32_t max_cols, hipStream_t st) {
 	if (rd.n_reads == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
+	const uint32_t tail = hot_tail_bytes(max_cols);      // dynamic LDS: the per-column tail of the hot state
 	if (P.paired)
-		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
-		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len);
+		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), tail, st, ix, P, rd, d_rparams, d_results, result_stride,
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols);
 	else
-	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), 0, st, ix, P, rd, d_rparams, d_results, result_stride,
-	                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len);
+	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), tail, st, ix, P, rd, d_rparams, d_results, result_stride,
+	                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols);
 	return hipGetLastError();
 }
 
@@ -1393,9 +1404,10 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WAVES_PER_EU, BT2G_WAVES_PER_EU), amdgpu_num_vgpr(BT2G_NUM_VGPR)))
 k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, const uint8_t* __restrict__ d_rd, const uint8_t* __restrict__ d_qu,
           const uint8_t* __restrict__ d_rf, uint8_t* __restrict__ d_out, uint8_t* __restrict__ scratch, uint64_t scratch_stride,
-          uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes) {
+          uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t max_cols) {
 	const uint32_t lane = threadIdx.x & 63;
 	g_P = P;
+	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
 	DpScratch dp;
 	carve_scratch(dp, scratch + (uint64_t)blockIdx.x * scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
 	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch; g_st.emit_on = 0;      // (the fills do not touch the work area)
@@ -1407,7 +1419,7 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 		wave_fence();
 		g_hot.len = rows;
 		for (uint32_t i = lane; i < rows; i += 64) { g_hot.seq[i] = d_rd[pr.rd_off + i]; g_hot.qual[i] = d_qu[pr.rd_off + i]; }
-		for (uint32_t j = lane; j < cols + 1; j += 64) g_hot.rf[j] = d_rf[pr.rf_off + j];
+		for (uint32_t j = lane; j < cols + 1; j += 64) dev_rf()[j] = d_rf[pr.rf_off + j];
 		g_hot.n_dp_cells_score = g_hot.n_dp_cells_full = g_hot.n_dp_pass = 0;
 		wave_fence();
 		int64_t best;
@@ -1427,7 +1439,7 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 		if (pr.kind == BT2G_DP_EE_U8) {
 			const uint32_t c4 = (cols + 3u) & ~3u;
 			BT2_G int16_t* lr = (BT2_G int16_t*)body;
-			for (uint32_t j = lane; j < c4; j += 64) lr[j] = (has_mat && j < cols) ? g_hot.lastrow[j] : (int16_t)-0xff;
+			for (uint32_t j = lane; j < c4; j += 64) lr[j] = (has_mat && j < cols) ? dev_lastrow()[j] : (int16_t)-0xff;
 			if (has_mat) {
 				BT2_G uint8_t* pm = body + (uint64_t)c4 * 2;
 				const BT2_G uint8_t* src = (const BT2_G uint8_t*)dp.mat;
@@ -1458,19 +1470,19 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 
 hipError_t launch_dp_fill(const AlignParams& P, const bt2g_dp_problem* d_probs, uint32_t n, const uint8_t* d_rd, const uint8_t* d_qu, const uint8_t* d_rf,
                           uint8_t* d_out, uint8_t* d_scratch, uint64_t scratch_stride, uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes,
-                          uint32_t n_waves, hipStream_t st) {
+                          uint32_t n_waves, uint32_t max_cols, hipStream_t st) {
 	if (n == 0) return hipSuccess;
-	hipLaunchKernelGGL(k_dp_fill, dim3(n < n_waves ? n : n_waves), dim3(64), 0, st, P, d_probs, n, d_rd, d_qu, d_rf, d_out, d_scratch, scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
+	hipLaunchKernelGGL(k_dp_fill, dim3(n < n_waves ? n : n_waves), dim3(64), hot_tail_bytes(max_cols), st, P, d_probs, n, d_rd, d_qu, d_rf, d_out, d_scratch, scratch_stride, mat_bytes, mask_bytes, pmask_bytes, max_cols);
 	return hipGetLastError();
 }
 
-void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& pmask_bytes, uint64_t& arena_stride) {
+void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint32_t max_cols, uint64_t& mat_bytes, uint64_t& mask_bytes, uint64_t& pmask_bytes, uint64_t& arena_stride) {
 	const uint32_t rows = max_len ? max_len : 1;
 	const uint32_t R = dp_R(rows);
 	// unpaired: seed-extension windows only (rows + 4 * min(gaps, maxhalf) columns, dp_framer.cpp:81-129; the framer flags windows
-	// past kMaxCols); paired: opposite-mate windows up to kMaxCols, and a second matrix for them
-	uint32_t cols = paired ? (uint32_t)kMaxCols + 4 : rows + 4 * maxhalf + 1 + 4;
-	if (cols > (uint32_t)kMaxCols + 4) cols = (uint32_t)kMaxCols + 4;
+	// past the launch's column capacity); paired: opposite-mate windows up to that capacity, and a second matrix for them
+	uint32_t cols = paired ? max_cols + 4 : rows + 4 * maxhalf + 1 + 4;
+	if (cols > max_cols + 4) cols = max_cols + 4;
 	const uint32_t lanes = (rows + R - 1) / R;
 	// packed cells (16-bit end-to-end, local): 8 B per cell, wavefront-major; pred format (8-bit end-to-end): 1 B per cell of the band
 	mat_bytes = (((uint64_t)cols + lanes) * R * 64 * 8 + 255) & ~(uint64_t)255;
@@ -1488,7 +1500,7 @@ void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint64
 uint64_t align_work_bytes() { return sizeof(Work); }
 uint32_t align_waves_per_cu() { return 4u * BT2G_WAVES_PER_EU; }
 
-template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, hipStream_t);
-template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, hipStream_t);
+template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, uint32_t, hipStream_t);
+template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, uint32_t, hipStream_t);
 
 } // namespace bt2g

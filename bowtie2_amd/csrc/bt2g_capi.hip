@@ -367,14 +367,15 @@ int bt2g_dp_fill(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_problem* d_p
 	hipError_t e = hipMemcpyAsync(hp.data(), d_probs, sizeof(bt2g_dp_problem) * n, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	if (e != hipSuccess) return hip_fail(c, e, "copy DP problems");
-	uint32_t max_rows = 1;
+	uint32_t max_rows = 1, max_cols = (uint32_t)kMaxCols;
 	for (const auto& p : hp) {
-		if (p.rows == 0 || p.cols == 0 || p.rows > BT2G_MAX_READ_LEN || p.cols + 1 > (uint32_t)kMaxCols) return fail(c, BT2G_ERR_UNSUPPORTED, "DP problem outside 1..512 rows x 1..1099 columns");
+		if (p.rows == 0 || p.cols == 0 || p.rows > BT2G_MAX_READ_LEN || p.cols + 1 > (uint32_t)kMaxColsWide) return fail(c, BT2G_ERR_UNSUPPORTED, "DP problem outside 1..512 rows x 1..2175 columns");
+		if (p.cols + 1 > max_cols) max_cols = (uint32_t)kMaxColsWide;       // (wide windows: the launch holds more per-column state in LDS)
 		if (p.kind > BT2G_DP_LOCAL || (p.out_off & 7)) return fail(c, BT2G_ERR_ARG, "bad DP problem (kind / output offset)");
 		if (p.rows > max_rows) max_rows = p.rows;
 	}
 	uint64_t mat_bytes, mask_bytes, pmask_bytes, stride;
-	align_scratch_sizes(max_rows, true, 255, mat_bytes, mask_bytes, pmask_bytes, stride);      // "paired": windows up to kMaxCols columns
+	align_scratch_sizes(max_rows, true, 255, max_cols, mat_bytes, mask_bytes, pmask_bytes, stride);      // "paired": windows up to max_cols columns
 	stride = (mat_bytes + mask_bytes + pmask_bytes + 4095) & ~(uint64_t)4095;
 	uint32_t n_waves = c->n_cu * 4;
 	if (n_waves > n) n_waves = n;
@@ -393,7 +394,7 @@ int bt2g_dp_fill(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_problem* d_p
 	P.mm_type = sc->mm_pen_type; P.mm_max = sc->mm_max; P.mm_min = sc->mm_min; P.n_pen = sc->n_pen;
 	P.rdgapo = sc->rd_gap_const + sc->rd_gap_linear; P.rdgape = sc->rd_gap_linear; P.rfgapo = sc->rf_gap_const + sc->rf_gap_linear; P.rfgape = sc->rf_gap_linear;
 	P.gapbar = sc->gapbar; P.match_bonus = sc->match_bonus;
-	e = launch_dp_fill(P, d_probs, n, d_rd, d_qu, d_rf, d_out, c->d_dp_scratch, stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, st);
+	e = launch_dp_fill(P, d_probs, n, d_rd, d_qu, d_rf, d_out, c->d_dp_scratch, stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, max_cols, st);
 	return e == hipSuccess ? 0 : hip_fail(c, e, "k_dp_fill");
 }
 
@@ -429,7 +430,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	bt2g_ctx::BatchSlot& S = c->slots[si];
 	uint64_t mat_bytes, mask_bytes, pmask_bytes, arena_stride;
 	if (params->paired && (reads->n_reads & 1u)) return fail(c, BT2G_ERR_ARG, "paired mode needs an even number of reads (mates interleaved)");
-	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
+	const uint32_t max_cols = dp_cols_for(*params);      // DP columns this launch holds (bt2g_align_params::max_dp_cols)
+	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
 	// persistent waves (one read at a time each) pull reads from a device-side queue
 	uint32_t n_waves = c->n_cu * align_waves_per_cu();
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
@@ -565,8 +567,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	mark(5);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	e = (c->off_size == 4)
-		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, st)
-		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, st);
+		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, st)
+		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, st);
 	if (e != hipSuccess) return hip_fail(c, e, "k_align_reads");
 	mark(6);
 	S.ev_valid = true;

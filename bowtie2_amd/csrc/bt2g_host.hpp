@@ -157,6 +157,7 @@ struct Options {
 		P.seed_cache_mb = seed_cache_mb;
 		P.profile = 0;      // the drop-in binary never asks for the worker's phase timers
 		P.max_seeds = 0;    // set per batch by the driver (bt2g_search.cpp)
+		P.max_dp_cols = 0;  // likewise (paired batches: the widest opposite-mate window)
 		P.max_dp_streak = max_dp_streak; P.max_ug = max_ug; P.max_dp = max_dp; P.max_iters = max_iters;
 		if (all_hits) {
 			// -a lifts every effort limit (bt2_search.cpp:3457-3463)

@@ -269,6 +269,19 @@ static int run_search(int argc, char** argv) {
 						if (ns > max_seeds) max_seeds = ns;
 					}
 					Pb.max_seeds = (int32_t)(max_seeds > 64 ? 64 : max_seeds);      // kMaxOffs: the worker flags reads beyond it
+					Pb.max_dp_cols = 0;
+					if (b->paired) {
+						// the widest window in which any mate of this batch is looked for next to its partner: beyond the default the launch
+						// holds more per-column state (-X 800, --local pairs of long reads)
+						uint32_t wmax = 0;
+						for (size_t i = 0; i + 1 < n; i += 2) {
+							const uint32_t l1 = (uint32_t)(b->off[i + 1] - b->off[i]), l2 = (uint32_t)(b->off[i + 2] - b->off[i + 1]);
+							const uint32_t w1 = mate_window_bound(Pb, b->rp[i].minsc, l1, l1, l2), w2 = mate_window_bound(Pb, b->rp[i + 1].minsc, l2, l1, l2);
+							if (w1 > wmax) wmax = w1;
+							if (w2 > wmax) wmax = w2;
+						}
+						Pb.max_dp_cols = (int32_t)(wmax > (uint32_t)BT2G_MAX_DP_COLS ? (uint32_t)BT2G_MAX_DP_COLS : wmax);
+					}
 					int rc = bt2g_align_batch(ctx, &rd, (const bt2g_read_params*)d_rp.p, &Pb, b->max_len, d_res.p, st);
 					if (rc) die(std::string("bt2g_align_batch: ") + bt2g_last_error(ctx));
 					rc = bt2g_results_pack(ctx, d_res.p, (uint32_t)n, (uint32_t)P.khits, d_packed.p, (uint64_t*)d_poff.p, st);

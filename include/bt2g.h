@@ -209,7 +209,7 @@ typedef struct {
  *                   rule folded in (a neighbour whose score is 0 is no predecessor, aligner_swsse_loc_u8.cpp:1530-1660) -- what
  *                   the worker's local fill stores instead of scores; best / lastsolcol / sat8 in the header carry what the worker
  *                   takes from the scores themselves.
- * bt2g_dp_out_bytes() gives the size of a block.  rows <= BT2G_MAX_READ_LEN, cols <= 1100.
+ * bt2g_dp_out_bytes() gives the size of a block.  rows <= BT2G_MAX_READ_LEN, cols < 2176 (problems wider than 1099 columns make the launch hold more per-column state: BT2G_MAX_DP_COLS).
  */
 uint64_t bt2g_dp_out_bytes(uint32_t kind, uint32_t rows, uint32_t cols);
 int bt2g_dp_fill(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_problem *d_probs, uint32_t n,
@@ -224,7 +224,7 @@ int bt2g_dp_fill(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_problem *d
  * backtrace, redundancy checks, -M/-k reporting state and the final selection -- one
  * wavefront per read, the reference's RNG draw order reproduced, so that the SAM written
  * from these records is byte-identical to the reference's.  Scope (rejected otherwise by the
- * host): reads <= BT2G_MAX_READ_LEN, at most 64 alignments per read, opposite-mate windows <= 1100 columns (a read or pair
+ * host): reads <= BT2G_MAX_READ_LEN, at most 64 alignments per read, opposite-mate windows <= 1100 columns, or up to BT2G_MAX_DP_COLS when bt2g_align_params::max_dp_cols asks for it (a read or pair
  * over a limit comes back with status bit 0 set).
  */
 #define BT2G_MAX_READ_LEN 512
@@ -263,7 +263,11 @@ typedef struct {
 	                                  (1 + (len - seedlen) / interval for every read): bt2g_align_batch sizes its seed tables from it and
 	                                  returns WITHOUT synchronising the stream (reads that exceed it are searched inline by the worker, still
 	                                  exact).  0: the bound is computed on the device and bt2g_align_batch waits for it (one 4-byte D2H)   */
+	int32_t max_dp_cols;           /* > 1100: DP windows (opposite-mate windows: about -X + read length + 2 x gaps) of up to this many columns occur in
+	                                  the batch -- at most BT2G_MAX_DP_COLS; the launch then holds that much per-column state in LDS and runs 12 instead of
+	                                  16 waves per CU.  <= 1100 (0: default): windows of up to 1 100 columns; a read or pair that needs a wider one is flagged  */
 } bt2g_align_params;
+#define BT2G_MAX_DP_COLS 2176
 #define BT2G_PE_DOVETAIL_OK  1     /* --dovetail                       */
 #define BT2G_PE_CONTAIN_OK   2     /* cleared by --no-contain          */
 #define BT2G_PE_OLAP_OK      4     /* cleared by --no-overlap          */

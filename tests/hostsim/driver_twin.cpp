@@ -26,10 +26,10 @@ extern "C" {
 int bt2g_ctx_create(int, bt2g_ctx** out) {
 	bt2g_ctx* c = new bt2g_ctx();
 	c->w = new Work();
-	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 8;
+	const uint64_t mat_bytes = ((uint64_t)kMaxColsWide + 64) * dp_R(kMaxLen) * 64 * 8;
 	for (DpScratch* d : {&c->dp, &c->dp2}) {
-		d->mat = (uint32_t*)malloc(mat_bytes); d->masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
-		d->pmask_words = (uint32_t)pred_cells(kMaxLen, kMaxCols + 8);
+		d->mat = (uint32_t*)malloc(mat_bytes); d->masks = (uint16_t*)malloc((size_t)kMaxLen * (kMaxColsWide + 8) * 2);
+		d->pmask_words = (uint32_t)pred_cells(kMaxLen, kMaxColsWide + 8);
 		d->pmask = (uint32_t*)calloc(d->pmask_words, 4); d->epoch = (uint32_t*)calloc(64, 4);
 	}
 	*out = c;
@@ -73,6 +73,7 @@ static void twin_align(bt2g_ctx* c, const DevIndex<TOff>& ix, const bt2g_reads* 
 			ReadResult& rr1 = *(ReadResult*)resbuf.data();
 			ReadResult& rr2 = *(ReadResult*)(resbuf.data() + rec_bytes);
 			g_rp = rp[i]; g_Pp = &P; g_ixp = &ix;
+			g_st.max_cols = dp_cols_for(P);
 			Aligner<TOff, HostPlat> al(*c->w, c->dp);
 			g_st.dp_main = c->dp; g_st.dp_opp = c->dp2;
 			for (int m = 0; m < 2; m++) { g_st.pe_seq[m] = seq(i + m); g_st.pe_qual[m] = qual(i + m); g_st.pe_len[m] = len(i + m); g_st.pe_rp[m] = rp[i + m]; }
@@ -89,6 +90,7 @@ static void twin_align(bt2g_ctx* c, const DevIndex<TOff>& ix, const bt2g_reads* 
 		g_hot.len = len(i);
 		memcpy(g_hot.seq, seq(i), g_hot.len);
 		memcpy(g_hot.qual, qual(i), g_hot.len);
+		g_st.max_cols = dp_cols_for(P);
 		Aligner<TOff, HostPlat> al(*c->w, c->dp);
 		al.run(rr);
 		memcpy(results + (uint64_t)i * stride, &rr, std::min<uint64_t>(stride, rec_bytes));

@@ -23,6 +23,9 @@
 using namespace bt2g;
 
 static HotWork g_hot;
+static uint8_t host_rf[kMaxColsWide + 8];          // the per-column tail of the hot state (dynamic LDS on the device)
+static int16_t host_lastrow[kMaxColsWide + 8];
+static Edit host_ned[kMaxEdits];
 static AlState g_st;
 static const AlignParams* g_Pp = nullptr;      // the control blocks the device keeps in LDS
 static ReadParams g_rp;
@@ -31,6 +34,9 @@ static CliExtra g_ex;
 
 struct HostPlat {
 	static HotWork& hot() { return g_hot; }
+	static uint8_t* rf() { return host_rf; }
+	static Edit* ned() { return host_ned; }
+	static int16_t* lastrow() { return host_lastrow; }
 	static const AlignParams& params() { return *g_Pp; }
 	static ReadParams& rparams() { return g_rp; }
 	static const PreComp* pre() { return nullptr; }
@@ -49,11 +55,11 @@ struct HostPlat {
 	template <typename TOff> static TOff get_offset(const DevEbwt<TOff>& e, TOff row, uint32_t& nsteps) { return bt2g::get_offset(e, row, nsteps); }
 	static void fetch_ref(const DevRef& ref, Work& w, uint64_t tidx, int64_t rfi, uint32_t count) {
 		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);
-		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)(1 << ref_base_at(ref, tidx, rfi + (int64_t)i, rec0));
+		for (uint32_t i = 0; i < count; i++) host_rf[i] = (uint8_t)(1 << ref_base_at(ref, tidx, rfi + (int64_t)i, rec0));
 	}
 	static void fetch_ref_codes(const DevRef& ref, uint64_t tidx, int64_t rfi, uint32_t count) {
 		const uint64_t rec0 = ref_rec_find(ref, tidx, rfi);
-		for (uint32_t i = 0; i < count; i++) g_hot.rf[i] = (uint8_t)ref_base_at(ref, tidx, rfi + (int64_t)i, rec0);
+		for (uint32_t i = 0; i < count; i++) host_rf[i] = (uint8_t)ref_base_at(ref, tidx, rfi + (int64_t)i, rec0);
 	}
 	static void zero_masks(uint16_t* p, uint32_t n) { memset(p, 0, (size_t)n * 2); }
 	static void zero_u32(uint32_t* p, uint32_t n) { memset(p, 0, (size_t)n * 4); }
@@ -75,7 +81,7 @@ struct HostPlat {
 			int sc;
 			if (wide) sc = (int)(int16_t)(uint16_t)(reinterpret_cast<const uint64_t*>(mat)[dp_cell(R, rows - 1, j)] & 0xffff) - 0x7fff;
 			else sc = (int)(mat[dp_cell(R, rows - 1, j)] & 0xff) - 0xff;
-			g_hot.lastrow[j] = (int16_t)(sc < -32768 ? -32768 : sc);
+			host_lastrow[j] = (int16_t)(sc < -32768 ? -32768 : sc);
 		}
 	}
 	static void load_read(const uint8_t* seq, const uint8_t* qual, uint32_t len) { memcpy(g_hot.seq, seq, len); memcpy(g_hot.qual, qual, len); }
@@ -83,7 +89,7 @@ struct HostPlat {
 	static uint32_t gather_sort(BtCand* cands, uint32_t cap, uint32_t rows, uint32_t cols, int64_t minsc_dp) {
 		uint32_t n = 0, total = 0;
 		for (uint32_t j = 0; j < cols; j++) {
-			const int sc = (int)g_hot.lastrow[j];
+			const int sc = (int)host_lastrow[j];
 			if (sc < minsc_dp) continue;
 			total++;
 			if (n >= cap) continue;
@@ -264,7 +270,7 @@ struct HostPlat {
 		g_hot.frag_jlo = frag[0]; g_hot.frag_len = frag[1]; g_hot.frag_toff = frag[2]; g_hot.frag_tidx = frag[3];
 	}
 	static void fetch_ref_joined(const DevRef& ref, uint64_t jpos, uint32_t count) {
-		for (uint32_t i = 0; i < count; i++) { const uint64_t p = jpos + i; g_hot.rf[i] = (uint8_t)(1u << ((ref.buf[p >> 2] >> ((p & 3) << 1)) & 3)); }
+		for (uint32_t i = 0; i < count; i++) { const uint64_t p = jpos + i; host_rf[i] = (uint8_t)(1u << ((ref.buf[p >> 2] >> ((p & 3) << 1)) & 3)); }
 	}
 	static bool diag_find(const DiagIval* d, uint32_t n, int32_t ref, int64_t off, int32_t orient) {
 		for (uint32_t i = 0; i < n; i++) if (d[i].ref == ref && d[i].orient == orient && off >= d[i].off && off < d[i].off + d[i].len) return true;
@@ -284,7 +290,7 @@ struct HostPlat {
 		for (uint32_t k = 0; k < L; k++) {
 			const uint32_t r = row - k, c = col - k;
 			const int readc = rd_char(g_hot, rdlen, fw, r);
-			const int refm = g_hot.rf[c];
+			const int refm = host_rf[c];
 			const int readq = rd_qual(g_hot, rdlen, fw, r);
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) mm |= 1ull << (td + k);
@@ -307,10 +313,10 @@ struct HostPlat {
 		for (uint32_t k = 0; k < L; k++) {
 			const uint32_t r = read_gap ? row : row - k, c = read_gap ? col - k : col;
 			Edit e;
-			if (read_gap) { const int refm = g_hot.rf[c]; e.pos = (uint16_t)(r + 1); e.chr = (uint8_t)((refm == 1 || refm == 2 || refm == 4 || refm == 8) ? code2chr(__builtin_ctz((unsigned)refm)) : 'N'); e.qchr = '-'; e.type = EDIT_READ_GAP; }
+			if (read_gap) { const int refm = host_rf[c]; e.pos = (uint16_t)(r + 1); e.chr = (uint8_t)((refm == 1 || refm == 2 || refm == 4 || refm == 8) ? code2chr(__builtin_ctz((unsigned)refm)) : 'N'); e.qchr = '-'; e.type = EDIT_READ_GAP; }
 			else { e.pos = (uint16_t)r; e.chr = '-'; e.qchr = code2chr(rd_char(g_hot, rdlen, fw, r)); e.type = EDIT_REF_GAP; }
 			e.pad = 0;
-			g_hot.ned[nned + k] = e;
+			host_ned[nned + k] = e;
 			dp.pmask[pred_at(band_lo, band_w, r, c)] = (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift);
 			const int diagi = (int)c - (int)r + r_triml;
 			if (diagi >= r_corel && diagi <= r_corer) core = 1;
@@ -356,7 +362,7 @@ struct HostPlat {
 		bool bailed = false;
 		lastsolcol = 0; sat8 = 0;
 		for (uint32_t j = 0; j < cols; j++) {
-			const int m = g_hot.rf[j];
+			const int m = host_rf[j];
 			int refc = 4;
 			for (int b = 0; b < 4; b++) if (m & (1 << b)) { refc = b; break; }
 			int f = 0, colmax = 0;
@@ -434,7 +440,7 @@ struct HostPlat {
 		for (uint32_t t = 0; t < steps; t++) {
 			uint32_t upH[64], upF[64], upM[64], upR[64];
 			for (uint32_t l = 1; l < 64; l++) { upH[l] = myH[l - 1]; upF[l] = myF[l - 1]; upM[l] = mycm[l - 1]; upR[l] = refm[l - 1]; }
-			upH[0] = myH[63] << 16; upF[0] = myF[63] << 16; upM[0] = mycm[63] << 16; upR[0] = (refm[63] << 16) | (t < cols ? (uint32_t)g_hot.rf[t] : 16u);
+			upH[0] = myH[63] << 16; upF[0] = myF[63] << 16; upM[0] = mycm[63] << 16; upR[0] = (refm[63] << 16) | (t < cols ? (uint32_t)host_rf[t] : 16u);
 			uint32_t cmv[64];
 			for (uint32_t l = 0; l < 64; l++) {
 				refm[l] = upR[l];
@@ -494,9 +500,9 @@ struct HostPlat {
 				const int sc = (int)local_h()[(size_t)i * hcols + j];
 				if (sc < minsc) continue;
 				const int rdc = rd_char(g_hot, g_hot.len, fw, i);
-				const bool match = (g_hot.rf[j] & (1 << rdc)) != 0;        // as the reference: a read N "matches" a reference N mask (16)
+				const bool match = (host_rf[j] & (1 << rdc)) != 0;        // as the reference: a read N "matches" a reference N mask (16)
 				bool match_succ = false;
-				if (i < rows - 1) { const int rs = rd_char(g_hot, g_hot.len, fw, i + 1); match_succ = (g_hot.rf[j + 1] & (1 << rs)) != 0; }
+				if (i < rows - 1) { const int rs = rd_char(g_hot, g_hot.len, fw, i + 1); match_succ = (host_rf[j + 1] & (1 << rs)) != 0; }
 				if (!match || match_succ) continue;
 				total++;
 				if (n >= cap) continue;
@@ -529,7 +535,7 @@ struct HostPlat {
 		auto subs = [](int a, int b) { const int v = a - b; return v < 0 ? 0 : v; };
 		// previous / current row, indexed by column + 1 (index 0 = the column left of the window)
 		std::vector<int> Hp(cols + 2, 0), Fp(cols + 2, 0), Hc(cols + 2, 0), Ec(cols + 2, 0), Fc(cols + 2, 0);
-		for (uint32_t j = 0; j < cols; j++) g_hot.lastrow[j] = (int16_t)-0xff;
+		for (uint32_t j = 0; j < cols; j++) host_lastrow[j] = (int16_t)-0xff;
 		int lrmax = 0;
 		for (uint32_t i = 0; i < rows; i++) {
 			const bool veto = ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar);
@@ -540,7 +546,7 @@ struct HostPlat {
 			const int64_t jlo = (int64_t)i - lo, jhi = (int64_t)i - lo + (int64_t)band.nd - 1;
 			for (int64_t jj = jlo < 0 ? 0 : jlo; jj <= jhi && jj < (int64_t)cols; jj++) {
 				const uint32_t j = (uint32_t)jj;
-				const int m = g_hot.rf[j];
+				const int m = host_rf[j];
 				int refc = 4;
 				for (int b = 0; b < 4; b++) if (m & (1 << b)) { refc = b; break; }
 				int pen;
@@ -561,7 +567,7 @@ struct HostPlat {
 				c |= (fu - P.rfgape == f) ? PB_FE : 0;
 				pm[pred_idx(lo, W, i, j)] = (uint8_t)c;
 				Hc[j + 1] = h; Ec[j + 1] = e; Fc[j + 1] = f;
-				if (i == rows - 1) { g_hot.lastrow[j] = (int16_t)(h - 0xff); if (h > lrmax) lrmax = h; }
+				if (i == rows - 1) { host_lastrow[j] = (int16_t)(h - 0xff); if (h > lrmax) lrmax = h; }
 			}
 			Hp.swap(Hc); Fp.swap(Fc);
 		}
@@ -578,7 +584,7 @@ struct HostPlat {
 		std::vector<int> Hp(rows, lo), Ep(rows, lo), Hc(rows), Ec(rows), Fc(rows);
 		uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
 		for (uint32_t j = 0; j < cols; j++) {
-			const int m = g_hot.rf[j];
+			const int m = host_rf[j];
 			int refc = 4;
 			for (int b = 0; b < 4; b++) if (m & (1 << b)) { refc = b; break; }
 			int f = lo;
@@ -652,10 +658,10 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	if (!fq.ok()) { fprintf(stderr, "cannot open %s\n", opt.reads_file.c_str()); return 1; }
 	Work* w = new Work();
 	DpScratch dp;
-	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 8;
+	const uint64_t mat_bytes = ((uint64_t)kMaxColsWide + 64) * dp_R(kMaxLen) * 64 * 8;
 	dp.mat = (uint32_t*)malloc(mat_bytes);
-	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
-	dp.pmask_words = (uint32_t)pred_cells(kMaxLen, kMaxCols + 8);
+	dp.masks = (uint16_t*)malloc((size_t)kMaxLen * (kMaxColsWide + 8) * 2);
+	dp.pmask_words = (uint32_t)pred_cells(kMaxLen, kMaxColsWide + 8);
 	dp.pmask = (uint32_t*)calloc(dp.pmask_words, 4); dp.epoch = (uint32_t*)calloc(64, 4);
 	std::vector<uint8_t> resbuf(sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(P.khits + 1));
 	AlnSummary summ;
@@ -682,6 +688,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		g_hot.len = (uint32_t)rd.seq.size();
 		memcpy(g_hot.seq, rd.seq.data(), rd.seq.size());
 		memcpy(g_hot.qual, rd.qual.data(), rd.qual.size());
+		g_st.max_cols = (uint32_t)kMaxColsWide;      // (the product's driver asks bt2g_align_batch for what its pairs need, up to this: bt2g_align_params::max_dp_cols)
 		Aligner<TOff, HostPlat> al(*w, dp);
 		al.run(rr);
 		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d, site %u)\n", rd.name.str().c_str(), rr.status, rr.pad2);
@@ -728,10 +735,10 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 	if (!fq1.ok() || !fq2.ok()) { fprintf(stderr, "cannot open the mate files\n"); return 1; }
 	Work* w = new Work();
 	DpScratch dp, dp2;
-	const uint64_t mat_bytes = ((uint64_t)kMaxCols + 64) * dp_R(kMaxLen) * 64 * 8;
-	dp.mat = (uint32_t*)malloc(mat_bytes); dp.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
-	dp2.mat = (uint32_t*)malloc(mat_bytes); dp2.masks = (uint16_t*)malloc((size_t)kMaxLen * kMaxCols * 2);
-	dp.pmask_words = dp2.pmask_words = (uint32_t)pred_cells(kMaxLen, kMaxCols + 8);
+	const uint64_t mat_bytes = ((uint64_t)kMaxColsWide + 64) * dp_R(kMaxLen) * 64 * 8;
+	dp.mat = (uint32_t*)malloc(mat_bytes); dp.masks = (uint16_t*)malloc((size_t)kMaxLen * (kMaxColsWide + 8) * 2);
+	dp2.mat = (uint32_t*)malloc(mat_bytes); dp2.masks = (uint16_t*)malloc((size_t)kMaxLen * (kMaxColsWide + 8) * 2);
+	dp.pmask_words = dp2.pmask_words = (uint32_t)pred_cells(kMaxLen, kMaxColsWide + 8);
 	dp.pmask = (uint32_t*)calloc(dp.pmask_words, 4); dp.epoch = (uint32_t*)calloc(64, 4);
 	dp2.pmask = (uint32_t*)calloc(dp2.pmask_words, 4); dp2.epoch = (uint32_t*)calloc(64, 4);
 	const size_t rec_bytes = sizeof(ReadResult) + sizeof(AlnRes) * (size_t)(P.khits + 1);
@@ -756,7 +763,8 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 			ReadResult& rr1 = *(ReadResult*)resbuf.data();
 			ReadResult& rr2 = *(ReadResult*)(resbuf.data() + rec_bytes);
 			g_rp = hb.rp[pi]; g_Pp = &P; g_ixp = &ix;
-			Aligner<TOff, HostPlat> al(*w, dp);
+			g_st.max_cols = (uint32_t)kMaxColsWide;      // (the product's driver asks bt2g_align_batch for what its pairs need, up to this: bt2g_align_params::max_dp_cols)
+		Aligner<TOff, HostPlat> al(*w, dp);
 			g_st.dp_main = dp; g_st.dp_opp = dp2;
 			g_st.pe_seq[0] = (const uint8_t*)r1.seq.data(); g_st.pe_qual[0] = (const uint8_t*)r1.qual.data(); g_st.pe_len[0] = (uint32_t)r1.seq.size();
 			g_st.pe_seq[1] = (const uint8_t*)r2.seq.data(); g_st.pe_qual[1] = (const uint8_t*)r2.qual.data(); g_st.pe_len[1] = (uint32_t)r2.seq.size();

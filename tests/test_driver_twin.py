@@ -116,6 +116,24 @@ def test_sharded_ranks_through_the_driver(twin, inp, sharding, world, tmp_path):
         assert vals["sharding"] == "blocks" and int(vals["parsed_bytes_all"]) == world * total       # the fallback reads everything on every rank
 
 
+@pytest.mark.parametrize("extra", [["-X", "1500", "--dovetail"], ["--local", "-X", "1200"], ["-X", "5000"]])
+def test_wide_mate_windows_through_the_driver(twin, extra):
+    """Pairs whose opposite-mate windows are wider than the 1 100 columns a launch holds by default: the driver derives the widest window of
+    each batch from its pairs' lengths, minimum scores and -I/-X (mate_window_bound) and asks bt2g_align_batch for it
+    (bt2g_align_params::max_dp_cols, at most 2 176).  Same SAM as the worker under a plain main, which always holds the maximum; -X 5000 is
+    beyond that: both flag the same pairs (a warning; the driver exits 1) instead of printing something else."""
+    common = ["--sensitive", "--batch", "32"] + extra + ["-x", os.path.join(GOLD, "tiny_s"), "-1", M1, "-2", M2]
+    p = subprocess.run([twin] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    hs = os.path.join(HS, "hostsim")
+    q = subprocess.run([hs] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    body = lambda t: [l for l in t.splitlines() if not l.startswith("@PG")]
+    assert body(p.stdout) == body(q.stdout)
+    if "5000" in extra:
+        assert p.returncode == 1 and "Warning" in p.stderr and "Warning" in q.stderr      # (the plain main only warns)
+    else:
+        assert p.returncode == 0 and "Warning" not in p.stderr
+
+
 def test_byte_sharding_falls_back_for_gzip_and_odd_files(twin, tmp_path):
     """gzip'ed input, or a file that is not strict 4-line FASTQ (a blank line between records), cannot be cut by byte ranges: the ranks
     agree on block mode and the output is still the one-process output"""

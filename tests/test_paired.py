@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HS = os.path.join(ROOT, "tests", "hostsim")
 OPTION_SETS = ([], ["--local"], ["-k", "3"], ["--no-mixed"], ["--no-discordant"], ["-I", "200", "-X", "350"], ["--ff"],
                ["--very-sensitive", "--dovetail"], ["--no-contain", "--no-overlap"], ["-N", "1", "-L", "18"],
-               ["--very-sensitive-local", "-k", "4"], ["--rf", "-X", "700"], ["--no-unal", "--xeq", "-3", "5"], ["--passthrough"])
+               ["--very-sensitive-local", "-k", "4"], ["--rf", "-X", "700"], ["--no-unal", "--xeq", "-3", "5"], ["--passthrough"],
+               # opposite-mate windows wider than the 1 100 columns a launch holds by default (bt2g_align_params::max_dp_cols): -X + mate + 2 x gaps
+               ["--local", "-X", "1000"], ["-X", "1500", "--dovetail"])
 
 
 def make_pairs(n, seed):
