@@ -20,6 +20,7 @@ struct CliExtra {
 	bool metrics = false;          // --met: per-read work counters on stderr (test aid)
 	bool arg_desc = false;         // --arg-desc
 	size_t batch_reads = 1u << 18;
+	size_t batch_max = 0;              // --batch-max N: vary the batch size instead (ramp up from 64 K reads to N, taper off towards the end of a plain file); see bt2g_search.cpp
 	bool version = false, help = false;   // --version / -h
 	bool allow_paired = false;     // set by the caller before parsing: this front end can run pairs
 	// --shard r/N: this process is rank r of N (one process per GPU).  The input is cut into blocks of --batch
@@ -262,6 +263,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else if (a == "--gpu") { if (!split_ints(need(), ',', ex.devices)) err = "--gpu needs a comma-separated list of device indexes"; }
 		else if (a == "--met") ex.metrics = true;
 		else if (a == "--batch") ex.batch_reads = strtoull(need().c_str(), nullptr, 10);
+		else if (a == "--batch-max") ex.batch_max = strtoull(need().c_str(), nullptr, 10);
 		else if (a == "--shard") {
 			const std::string v = need();
 			if (sscanf(v.c_str(), "%d/%d", &ex.shard_rank, &ex.shard_world) != 2 || ex.shard_world < 1 || ex.shard_rank < 0 || ex.shard_rank >= ex.shard_world) err = "--shard needs r/N with 0 <= r < N";

@@ -12,6 +12,7 @@
 #define BT2G_PIPELINE_HPP_
 
 #include <zlib.h>
+#include <sys/stat.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -179,6 +180,12 @@ public:
 		return true;
 	}
 	uint64_t bytes_read() const { return bytes_read_; }      // bytes taken from the file(s) so far
+	uint64_t plain_size() const {
+		if (paths_.size() != 1 || paths_[0] == "-" || !f_ || !gzdirect(f_)) return 0;
+		struct stat st_;
+		if (stat(paths_[0].c_str(), &st_) != 0 || !S_ISREG(st_.st_mode)) return 0;
+		return ranged_ ? 0 : (uint64_t)st_.st_size;
+	}
 	// next line without its terminator ('\n' or "\r\n"); false at end of input.  The view is valid until the next call.
 	bool next(const char*& p, size_t& n) {
 		for (;;) {
@@ -330,16 +337,20 @@ public:
 	// Two stages.  split(): the serial scan of the input into records (one thread: it is a scan of a byte stream).  finish(): records ->
 	// codes, qualities, names and per-read parameters, parallel over chunks.  While the caller finishes batch k, a helper thread already
 	// splits batch k + 1 into the other RawBatch -- the serial scan no longer adds to the time of a batch, it only has to keep up.
-	void next(HostBatch& b, size_t max_reads, size_t max_read_len) {
+	// next_max_reads: size of the batch after this one (its scan starts now), when the caller varies the batch size; 0 = the same.
+	void next(HostBatch& b, size_t max_reads, size_t max_read_len, size_t next_max_reads = 0) {
 		RawBatch* cur;
 		if (prefetch_.valid()) { prefetch_.get(); cur = &raw_[cur_ ^= 1]; }
 		else { cur = &raw_[cur_]; split(*cur, max_reads); }
 		if (!cur->last && cur->bad_input.empty()) {
 			RawBatch* nxt = &raw_[cur_ ^ 1];
-			prefetch_ = std::async(std::launch::async, [this, nxt, max_reads]() { split(*nxt, max_reads); });
+			const size_t nmax = next_max_reads ? next_max_reads : max_reads;
+			prefetch_ = std::async(std::launch::async, [this, nxt, nmax]() { split(*nxt, nmax); });
 		}
 		finish(*cur, b, max_read_len);
 	}
+	// size in bytes of the input when it is one regular uncompressed file (what is left of it can then be estimated), else 0
+	uint64_t plain_size() const { return src_.plain_size(); }
 private:
 	struct Raw { uint64_t rdid; size_t name_off, name_len, seq_off, seq_len, qual_off, qual_len; bool has_qual; char filter; size_t orig_off, orig_len; size_t tag_off = 0, tag_len = 0; };
 	// what split() hands to finish(): the records of one batch as offsets into one arena, and how the scan ended

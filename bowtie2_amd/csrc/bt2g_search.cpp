@@ -152,29 +152,55 @@ static int run_search(int argc, char** argv) {
 	PairSummary psumm;
 	AlnSummary summ;
 	std::mutex align_mu;
-	double align_s = 0, t_format = 0, t_write = 0;
+	double align_s = 0, t_format = 0, t_write = 0, t_h2d = 0, t_d2h = 0;
 	typedef std::unique_ptr<HostBatch> BatchPtr;
 	const size_t kWorkersPerDev = 3;
 	BoundedQueue<BatchPtr> q_in(ndev * kWorkersPerDev + 1), q_out(ndev * kWorkersPerDev + 1);
 
 	FILE* shard_idx = nullptr;
 	if (!ex.shard_index.empty()) { shard_idx = fopen(ex.shard_index.c_str(), "w"); if (!shard_idx) die("cannot open " + ex.shard_index); cleanup.idx = shard_idx; }
+	// Batch sizes.  Fixed (--batch, default 262 144 reads: with the three launches the device threads keep in flight the device runs within
+	// 3 % of its rate on 2 M-read launches, profiles/r04af_*), or -- with --batch-max N, an experiment that did not pay on file-sized inputs --
+	// varied: ramping up from 64 K reads, doubling to N, and, when the input is one plain file so that what is left of it can be estimated,
+	// tapering off again towards the end (a run pays one batch of latency at either end).  The SAM does not depend on how the input is cut.
+	const bool vary_batches = ex.batch_max > 0 && ex.shard_world <= 1 && !inter;
+	const size_t batch_cap = std::max<size_t>(2, std::min<size_t>(std::max<size_t>(ex.batch_max, 1u << 16), (size_t)((2ull << 30) / stride)) & ~(size_t)1);
+	const uint64_t input_bytes = vary_batches ? fq.plain_size() : 0;
+	auto batch_size_for = [&](uint64_t k, uint64_t reads_done) -> size_t {
+		if (!vary_batches) return batch_reads;
+		size_t s = (size_t)65536 << (k < 8 ? k : 8);
+		if (s > batch_cap) s = batch_cap;
+		const uint64_t bytes_done = fq.bytes_read();
+		if (input_bytes && reads_done > 0 && bytes_done > 0) {
+			const uint64_t left = input_bytes > bytes_done ? input_bytes - bytes_done : 0;
+			const uint64_t est = (uint64_t)((double)left * (double)(opt.paired ? 2 * reads_done : reads_done) / (double)bytes_done);      // (paired: this is mate 1's file, a batch holds both mates)
+			size_t t = (size_t)((est / 3 + 16383) & ~(uint64_t)16383);
+			if (t < 32768) t = 32768;
+			if (t < s) s = t;
+		}
+		return s & ~(size_t)1;
+	};
 	std::thread reader([&]() {
-		uint64_t seq = 0, blk = 0;
+		uint64_t seq = 0, blk = 0, reads_done = 0;
 		bool unp_phase = false;          // mixed input: the pair sources are exhausted, the -U files are being read
+		size_t cur_size = batch_size_for(0, 0);
 		for (;;) {
 			BatchPtr b(new HostBatch());
+			// (the scan of the batch after this one starts inside next(): its size is decided now)
+			const size_t next_size = batch_size_for(blk + 1, reads_done + cur_size / (opt.paired ? 2 : 1));
 			if (unp_phase) fq_unp->next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
 			else
 			if (inter) { fq.next(*b, batch_reads & ~(size_t)1, (size_t)BT2G_MAX_READ_LEN); finalize_interleaved(*b, opt); }
 			else if (opt.paired) {
 				// one batch per mate file in lockstep, interleaved into a batch of pairs
 				BatchPtr b1(new HostBatch()), b2(new HostBatch());
-				fq.next(*b1, batch_reads / 2, (size_t)BT2G_MAX_READ_LEN);
-				fq2->next(*b2, batch_reads / 2, (size_t)BT2G_MAX_READ_LEN);
+				fq.next(*b1, cur_size / 2, (size_t)BT2G_MAX_READ_LEN, next_size / 2);
+				fq2->next(*b2, cur_size / 2, (size_t)BT2G_MAX_READ_LEN, next_size / 2);
 				merge_mate_batches(std::move(b1), std::move(b2), *b, opt);
 			} else
-			fq.next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
+			fq.next(*b, cur_size, (size_t)BT2G_MAX_READ_LEN, next_size);
+			reads_done += b->reads.size() / (opt.paired ? 2 : 1);
+			cur_size = next_size;
 			if (fq_unp && !unp_phase && b->last && !b->upto_hit && b->bad_input.empty() && b->too_long.empty()) { b->last = false; unp_phase = true; }   // the run goes on with the unpaired reads
 			// --shard r/N: batch k is block k of the input; this rank keeps blocks r, r+N, ... (an emptied batch still carries
 			// the end-of-input marker and any input error)
@@ -248,6 +274,7 @@ static int run_search(int argc, char** argv) {
 				d_seq.ensure(b->seq.size() + 16); d_qual.ensure(b->qual.size() + 16);
 				d_off.ensure(b->off.size() * 8); d_rp.ensure(n * sizeof(ReadParams));
 				d_res.ensure(n * stride); d_packed.ensure(n * stride); d_poff.ensure((n + 1) * 8);
+				const auto th0 = std::chrono::steady_clock::now();
 				HIP_OK(hipMemcpyAsync(d_seq.p, b->seq.data(), b->seq.size(), hipMemcpyHostToDevice, st));
 				HIP_OK(hipMemcpyAsync(d_qual.p, b->qual.data(), b->qual.size(), hipMemcpyHostToDevice, st));
 				HIP_OK(hipMemcpyAsync(d_off.p, b->off.data(), b->off.size() * 8, hipMemcpyHostToDevice, st));
@@ -257,6 +284,7 @@ static int run_search(int argc, char** argv) {
 				HIP_OK(hipStreamSynchronize(st));
 				{
 					auto ta = std::chrono::steady_clock::now();
+					{ std::lock_guard<std::mutex> g2(align_mu); t_h2d += std::chrono::duration<double>(ta - th0).count(); }
 					// the host derived every read's seed parameters, so it knows the widest seed table of the batch: with the bound in
 					// the parameters bt2g_align_batch does not have to wait for the device to count them
 					AlignParams Pb = P;
@@ -290,6 +318,7 @@ static int run_search(int argc, char** argv) {
 					std::lock_guard<std::mutex> g2(align_mu);
 					align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
 				}
+				const auto td0 = std::chrono::steady_clock::now();
 				HIP_OK(hipMemcpyAsync(b->res_off.data(), d_poff.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
 				HIP_OK(hipStreamSynchronize(st));
 				const size_t total = (size_t)b->res_off[n];
@@ -297,6 +326,7 @@ static int run_search(int argc, char** argv) {
 				b->res = (const uint8_t*)b->res_hold.get();
 				HIP_OK(hipMemcpyAsync(b->res_hold.get(), d_packed.p, total, hipMemcpyDeviceToHost, st));
 				HIP_OK(hipStreamSynchronize(st));
+				{ std::lock_guard<std::mutex> g2(align_mu); t_d2h += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count(); }
 			}
 			q_out.push(std::move(b));
 		}
@@ -314,8 +344,11 @@ static int run_search(int argc, char** argv) {
 	if (opt.timing) {
 		auto hms = [](double s) { char b[64]; int h = (int)(s / 3600); int m = (int)(s / 60) % 60; int sec = (int)s % 60; snprintf(b, sizeof b, "%02d:%02d:%02d", h, m, sec); return std::string(b); };
 		fprintf(stderr, "Time loading forward index: %s\n", hms(std::chrono::duration<double>(t1 - t0).count()).c_str());
-		fprintf(stderr, "Multiseed full-index search: %s\n", hms(align_s).c_str());
-		fprintf(stderr, "[bt2g] device search time %.3f s\n", align_s);
+		const double search_wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+		fprintf(stderr, "Multiseed full-index search: %s\n", hms(search_wall).c_str());
+		fprintf(stderr, "[bt2g] index load %.3f s; search %.3f s wall, %llu reads -> %.0f reads/s after the load\n", std::chrono::duration<double>(t1 - t0).count(), search_wall,
+		        (unsigned long long)(summ.nread + 2 * psumm.npair), search_wall > 0 ? (double)(summ.nread + 2 * psumm.npair) / search_wall : 0.0);
+		fprintf(stderr, "[bt2g] device stage, summed over its %zu threads: upload %.3f s, kernels + pack %.3f s, download %.3f s\n", ndev * kWorkersPerDev, t_h2d, align_s, t_d2h);
 		fprintf(stderr, "[bt2g] host stages: split %.3f s, parse %.3f s, pack %.3f s, format %.3f s, write %.3f s\n", fq.t_split, fq.t_parse, fq.t_pack, t_format, t_write);
 	}
 	if (shard_idx) {
