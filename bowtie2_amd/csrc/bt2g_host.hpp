@@ -220,9 +220,10 @@ inline uint32_t gen_rand_seed(const ReadRec& r, uint32_t seed) {
 }
 
 // per-read derived parameters (bt2_search.cpp:3352-3450)
-inline ReadParams compute_read_params(const Options& o, const ReadRec& r) {
-	ReadParams p;
-	const size_t len = r.seq.size();
+// the part of a read's parameters that depends on its length only (the reader computes it once per length, not once per read)
+struct LenParams { int64_t minsc; size_t maxns; int nceil, interval; bool scfilt, lenfilt; };
+inline LenParams compute_len_params(const Options& o, size_t len) {
+	LenParams q;
 	int64_t minsc;
 	if (o.bwa_sw_like) {
 		// "a*max{T,c*log(l)}" in float, as the reference evaluates it (bt2_search.cpp:3341-3350; T = 30, c = 5.5)
@@ -233,27 +234,34 @@ inline ReadParams compute_read_params(const Options& o, const ReadRec& r) {
 		minsc = o.score_min.f<int64_t>((double)len);
 		if (o.local) { if (minsc < 0) minsc = 0; } else if (minsc > 0) minsc = 0;          // bt2_search.cpp:3352-3372
 	}
-	p.minsc = (int32_t)minsc;
-	// N filter (Scoring::nFilter)
-	const size_t maxns = o.n_ceil.f<size_t>((double)len);
-	size_t ns = 0;
-	bool nfilt = true;
-	for (size_t i = 0; i < len; i++) if (r.seq[i] == 4) { ns++; if (ns > maxns) { nfilt = false; break; } }
-	// score filter: perfect score (0 in e2e) must reach minsc
-	const bool scfilt = (int64_t)len * (o.local ? o.ma : 0) >= minsc;       // Scoring::scoreFilter: perfect score must reach minsc
-	const bool lenfilt = !(len <= (size_t)o.seed_mms || len < 2);
-	const bool qcfilt = !(o.qc_filter && r.filter == '0');
-	p.filt = (nfilt ? 1u : 0u) | (scfilt ? 2u : 0u) | (lenfilt ? 4u : 0u) | (qcfilt ? 8u : 0u);
+	q.minsc = minsc;
+	q.maxns = o.n_ceil.f<size_t>((double)len);      // N filter (Scoring::nFilter)
+	q.scfilt = (int64_t)len * (o.local ? o.ma : 0) >= minsc;       // Scoring::scoreFilter: perfect score must reach minsc
+	q.lenfilt = !(len <= (size_t)o.seed_mms || len < 2);
 	int nceil = o.n_ceil.f<int>((double)len);
 	if (nceil > (int)len) nceil = (int)len;
-	p.nceil = nceil;
+	q.nceil = nceil;
 	int interval = o.ms_ival.f<int>((double)len);
 	if (interval < 1) interval = 1;
-	p.interval = interval;
+	q.interval = interval;
+	return q;
+}
+inline ReadParams compute_read_params(const Options& o, const ReadRec& r, const LenParams& q) {
+	ReadParams p;
+	const size_t len = r.seq.size();
+	p.minsc = (int32_t)q.minsc;
+	size_t ns = 0;
+	bool nfilt = true;
+	for (size_t i = 0; i < len; i++) if (r.seq[i] == 4) { ns++; if (ns > q.maxns) { nfilt = false; break; } }
+	const bool qcfilt = !(o.qc_filter && r.filter == '0');
+	p.filt = (nfilt ? 1u : 0u) | (q.scfilt ? 2u : 0u) | (q.lenfilt ? 4u : 0u) | (qcfilt ? 8u : 0u);
+	p.nceil = q.nceil;
+	p.interval = q.interval;
 	p.seedlen = o.seed_len;
 	p.seed = gen_rand_seed(r, o.seed);
 	return p;
 }
+inline ReadParams compute_read_params(const Options& o, const ReadRec& r) { return compute_read_params(o, r, compute_len_params(o, r.seq.size())); }
 
 // ---------------------------------------------------------------------------------------
 // SAM

@@ -118,6 +118,16 @@ struct HostBatch {
 	uint64_t seqno = 0;                   // position in the input, for ordered output with several devices
 	uint64_t block_id = 0;                // --shard: which block of the input this batch is
 	void clear_reads() { chunks.clear(); reads.clear(); seq.clear(); qual.clear(); off.assign(1, 0); rp.clear(); max_len = 0; too_long.clear(); mate_src[0].reset(); mate_src[1].reset(); }
+	// Back to the state of a new batch, but with every buffer's memory kept: a batch of 262 144 reads touches about 250 MB, and memory that
+	// comes fresh from the allocator is paid for in page faults -- about as long as the device needs for the batch.  The driver hands finished
+	// batches back to the reader instead of freeing them (bt2g_search.cpp: BatchPool).
+	void recycle() {
+		for (Chunk& c : chunks) { c.names.clear(); c.seq.clear(); c.qual.clear(); c.orig.clear(); c.tags.clear(); c.error.clear(); }
+		reads.clear(); seq.clear(); qual.clear(); off.clear(); rp.clear(); max_len = 0;
+		res = nullptr; res_off.clear(); res_hold.reset();
+		too_long.clear(); bad_input.clear();
+		last = upto_hit = terminator = false; seqno = block_id = 0; paired = false;
+	}
 	// paired-end: reads[2i] / reads[2i+1] are the mates of pair i; their text lives in the two single-mate batches
 	bool paired = false;
 	std::unique_ptr<HostBatch> mate_src[2];
@@ -189,8 +199,8 @@ public:
 	// next line without its terminator ('\n' or "\r\n"); false at end of input.  The view is valid until the next call.
 	bool next(const char*& p, size_t& n) {
 		for (;;) {
-			const char* base = buf_.data() + pos_;
-			const size_t avail = buf_.size() - pos_;
+			const char* base = buf_.get() + pos_;
+			const size_t avail = len_ - pos_;
 			const char* nl = avail ? (const char*)memchr(base, '\n', avail) : nullptr;
 			if (nl) {
 				p = base; n = (size_t)(nl - base);
@@ -201,7 +211,7 @@ public:
 			}
 			if (eof_) {
 				if (avail == 0) return false;
-				p = base; n = avail; pos_ = buf_.size();
+				p = base; n = avail; pos_ = len_;
 				raw_len_ = n;
 				unterminated_ = true;          // last line of the input has no newline
 				if (n && p[n - 1] == '\r') n--;
@@ -211,20 +221,29 @@ public:
 		}
 	}
 private:
+	// (the buffer is plain storage with its own length: a std::string would zero-fill the 8 MB of every refill before gzread overwrites them)
+	void reserve(size_t need) {
+		if (need <= cap_) return;
+		size_t nc = cap_ ? cap_ : (size_t)(16u << 20);
+		while (nc < need) nc *= 2;
+		std::unique_ptr<char[]> nb(new char[nc]);
+		if (len_) memcpy(nb.get(), buf_.get(), len_);
+		buf_ = std::move(nb); cap_ = nc;
+	}
 	void refill() {
-		if (pos_ > 0) { buf_.erase(0, pos_); pos_ = 0; }
-		const size_t old = buf_.size();
+		if (pos_ > 0) { if (len_ > pos_) memmove(buf_.get(), buf_.get() + pos_, len_ - pos_); len_ -= pos_; pos_ = 0; }
+		const size_t old = len_;
 		size_t want = 8u << 20;
 		if (ranged_ && (uint64_t)want > left_) want = (size_t)left_;
-		buf_.resize(old + want);
-		int got = want ? gzread(f_, &buf_[old], (unsigned)want) : 0;
-		buf_.resize(old + (got > 0 ? (size_t)got : 0));
+		reserve(old + want + 1);
+		int got = want ? gzread(f_, buf_.get() + old, (unsigned)want) : 0;
+		len_ = old + (got > 0 ? (size_t)got : 0);
 		if (got > 0) { bytes_read_ += (uint64_t)got; if (ranged_) left_ -= (uint64_t)got; }
 		if (got < 0) io_error_ = true;          // corrupt / truncated .gz: the run must fail, not end early (the reference aborts too)
 		if (got <= 0) {
 			if (next_path_ < paths_.size()) {
 				// next file of the list: the previous one ends a line even if its last newline is missing
-				if (!buf_.empty() && buf_.back() != '\n') buf_.push_back('\n');
+				if (len_ && buf_[len_ - 1] != '\n') { reserve(len_ + 1); buf_[len_++] = '\n'; }
 				gzclose(f_); f_ = nullptr;
 				if (!open_next()) eof_ = true;
 			} else eof_ = true;
@@ -249,10 +268,18 @@ public:
 private:
 	size_t raw_len_ = 0;
 	gzFile f_ = nullptr;
-	std::string buf_;
+	std::unique_ptr<char[]> buf_;
+	size_t cap_ = 0, len_ = 0;
 	size_t pos_ = 0;
 	bool eof_ = false;
 };
+
+// read character -> code, 255 = not part of the sequence (see FastqBatcher::finish)
+struct SeqCodeTable {
+	unsigned char t[256];
+	SeqCodeTable() { for (int c = 0; c < 256; c++) t[c] = (c == '.' || isalpha(c)) ? (unsigned char)asc2code(c == '.' ? 'N' : c) : (unsigned char)255; }
+};
+static const SeqCodeTable kSeqCode;
 
 // Byte stream over a list of BAM files.  BAM is a series of BGZF blocks = concatenated gzip members, which gzread() inflates one after
 // the other (the reference walks the blocks itself, BAMPatternSource::nextBGZFBlockFromFile, pat.cpp:1270-1323; the empty end-of-file
@@ -314,6 +341,7 @@ class FastqBatcher {
 public:
 	FastqBatcher(const std::string& path, const Options& opt, unsigned threads) : src_((opt.format == 3 || opt.format == 7) ? std::string("/dev/null") : path), cmd_(path), bam_(opt.format == 7 ? path : std::string()), opt_(opt), threads_(threads) {
 		unit_ = (!opt.interleaved_file.empty() && path == opt.interleaved_file) ? 2 : 1;
+		ushift_ = unit_ == 2 ? 1 : 0;
 		if (opt.format == 7) bam_ok_ = bam_.next_file(bam_err_);
 	}
 	bool ok() const { return opt_.format == 7 ? (bam_ok_ || bam_err_.empty()) : src_.ok(); }
@@ -333,6 +361,7 @@ public:
 	std::string open_error(const std::string& dflt) const { return bam_err_.empty() ? dflt : bam_err_; }
 
 	double t_split = 0, t_parse = 0, t_pack = 0;      // seconds spent in each part of next() (-t)
+	std::vector<LenParams> len_params_;                // per read length (filled by the first finish())
 	// Fill `b` with up to max_reads reads; sets b.last at end of input (or at -u).
 	// Two stages.  split(): the serial scan of the input into records (one thread: it is a scan of a byte stream).  finish(): records ->
 	// codes, qualities, names and per-read parameters, parallel over chunks.  While the caller finishes batch k, a helper thread already
@@ -373,7 +402,6 @@ private:
 			bool have_r2 = false;
 			r.qual_off = r.qual_len = 0; r.has_qual = false; r.filter = '1';
 			r.orig_off = orig_.size(); r.orig_len = 0;
-			r2 = r;
 			if (opt_.format == 0) {                    // FASTQ: 4-line records
 				bool got;
 				size_t nblank = 0;
@@ -382,7 +410,7 @@ private:
 				if (!got) { if (!fastq_started_ && nblank > 0) b.bad_input = "reads file does not look like a FASTQ file"; b.last = true; break; }
 				fastq_started_ = true;
 				if (p[0] != '@') { b.bad_input = "reads file does not look like a FASTQ file"; b.last = true; break; }   // pat.cpp:1070
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+				if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				r.name_off = arena_.size(); r.name_len = n - 1; arena_.append(p + 1, n - 1);
 				if (pt) orig_.append(p, src_.last_raw_len());
 				// a record cut short by the end of the file is malformed input (the reference aborts: pat.cpp:1100-1180), not the end of the run
@@ -407,7 +435,7 @@ private:
 					if (got) { pending_.assign(p, n); if (pt) pending_raw_.assign(p, src_.last_raw_len()); }
 				}
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+				if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				have_pending_ = false;
 				r.name_off = arena_.size(); r.name_len = pending_.size() - 1; arena_.append(pending_.data() + 1, pending_.size() - 1);
 				r.seq_off = arena_.size(); r.seq_len = 0;
@@ -421,7 +449,7 @@ private:
 				}
 			} else if (opt_.format == 3) {             // -c: reads given on the command line, "SEQ[:QUALS]" separated by commas
 				if (cmd_pos_ > cmd_.size() || cmd_.empty()) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+				if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				size_t e = cmd_.find(',', cmd_pos_);
 				if (e == std::string::npos) e = cmd_.size();
 				const std::string tok = cmd_.substr(cmd_pos_, e - cmd_pos_);
@@ -430,12 +458,12 @@ private:
 				r.name_off = arena_.size(); r.name_len = 0;
 				r.seq_off = arena_.size(); r.seq_len = colon == std::string::npos ? tok.size() : colon; arena_.append(tok.data(), r.seq_len);
 				if (colon != std::string::npos) { r.qual_off = arena_.size(); r.qual_len = tok.size() - colon - 1; arena_.append(tok.data() + colon + 1, r.qual_len); r.has_qual = true; }
-				if (pt) { orig_ += std::to_string(rdid_ / unit_); orig_.push_back('\t'); orig_.append(tok.data(), r.seq_len); orig_.push_back('\t'); if (r.has_qual) orig_.append(tok.data() + colon + 1, r.qual_len); else orig_.append(r.seq_len, 'I'); }
+				if (pt) { orig_ += std::to_string((rdid_ >> ushift_)); orig_.push_back('\t'); orig_.append(tok.data(), r.seq_len); orig_.push_back('\t'); if (r.has_qual) orig_.append(tok.data() + colon + 1, r.qual_len); else orig_.append(r.seq_len, 'I'); }
 			} else if (opt_.format == 4) {             // --tab5 / --tab6, unpaired form: name <tab> seq <tab> quals
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+				if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				if (pt) orig_.append(p, n);
 				const char* t1 = (const char*)memchr(p, '\t', n);
 				const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(p + n - t1 - 1)) : nullptr;
@@ -469,7 +497,7 @@ private:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+				if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				const char* f[12]; int nf = 0; f[nf++] = p;
 				for (size_t k = 0; k < n && nf < 12; k++) if (p[k] == '\t') f[nf++] = p + k + 1;
 				if (nf != 11) { b.bad_input = "malformed QSEQ record (expected 11 fields)"; b.last = true; break; }
@@ -526,9 +554,9 @@ private:
 					got = true;
 				}
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+				if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 			} else if (opt_.format == 6) {             // -F k:<len>,i:<freq>: every <freq>-th <len>-mer of a FASTA file (FastaContinuousPatternSource, pat.cpp:913-1036)
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+				if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				bool emitted = false;
 				while (!emitted) {
 					if (fc_pos_ >= fc_line_.size()) {
@@ -568,7 +596,7 @@ private:
 				bool got;
 				do { got = src_.next(p, n); } while (got && n == 0);
 				if (!got) { b.last = true; break; }
-				if (rdid_ / unit_ - std::min<uint64_t>(rdid_ / unit_, opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+				if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
 				r.name_off = arena_.size(); r.name_len = 0;
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
 				if (pt) orig_.append(p, n);
@@ -577,13 +605,13 @@ private:
 			// it takes its number in the input and is dropped (unpaired input only: a pair loses both mates there)
 			if (opt_.format == 1 && !opt_.paired && r.seq_len == 0) { orig_.resize(r.orig_off); rdid_++; continue; }
 			r.orig_len = orig_.size() - r.orig_off;
-			r.rdid = rdid_ / unit_;
-			const bool skip1 = (rdid_++) / unit_ < opt_.skip;
+			r.rdid = (rdid_ >> ushift_);
+			const bool skip1 = ((rdid_++) >> ushift_) < opt_.skip;
 			if (!skip1) recs_.push_back(r);
 			if (have_r2) {
 				have_r2 = false;
-				r2.rdid = rdid_ / unit_;
-				if (!((rdid_++) / unit_ < opt_.skip)) recs_.push_back(r2);
+				r2.rdid = (rdid_ >> ushift_);
+				if (!(((rdid_++) >> ushift_) < opt_.skip)) recs_.push_back(r2);
 			}
 			if (skip1) continue;
 		}
@@ -594,13 +622,16 @@ private:
 		const double t1_ = tnow();
 		const std::string& arena_ = rb.arena; const std::vector<Raw>& recs_ = rb.recs; const std::string& orig_ = rb.orig;
 		const bool pt = opt_.passthrough;
+		if (len_params_.empty()) { const size_t nl = std::min<size_t>(max_read_len, 4096) + 1; len_params_.resize(nl); for (size_t l = 0; l < nl; l++) len_params_[l] = compute_len_params(opt_, l); }
 		b.last = rb.last; b.upto_hit = rb.upto_hit; b.bad_input = rb.bad_input;
 		// ---- parallel part 1: records -> names, codes and qualities in per-chunk arenas (no per-read allocations)
 		const size_t nrec = recs_.size();
 		const size_t chunk = 4096, nchunks = (nrec + chunk - 1) / chunk;
 		b.reads.assign(nrec, ReadRec());
 		b.rp.resize(nrec);
-		b.chunks.assign(nchunks, HostBatch::Chunk());
+		// (a recycled batch keeps its chunks' memory: see HostBatch::recycle)
+		b.chunks.resize(nchunks);
+		for (HostBatch::Chunk& c : b.chunks) { c.names.clear(); c.seq.clear(); c.qual.clear(); c.orig.clear(); c.tags.clear(); c.error.clear(); }
 		std::vector<uint32_t> name_off(nrec), name_len(nrec), rlen(nrec), orig_off(pt ? nrec : 0), orig_len(pt ? nrec : 0);
 		const bool tg = opt_.preserve_tags;
 		std::vector<uint32_t> tag_off(tg ? nrec : 0), tag_len(tg ? nrec : 0);
@@ -611,8 +642,15 @@ private:
 			for (size_t i = c * chunk; i < e; i++) {
 				const Raw& r = recs_[i];
 				tseq.clear(); tqual.clear();
-				const char* s = arena_.data() + r.seq_off;
-				for (size_t k = 0; k < r.seq_len; k++) { char chh = s[k]; if (chh == '.') chh = 'N'; if (isalpha((unsigned char)chh)) tseq.push_back((char)asc2code(chh)); }
+				const unsigned char* s = (const unsigned char*)arena_.data() + r.seq_off;
+				// letters and '.' are bases (asc2dna: A/C/G/T either case -> 0..3, anything else -> 4), every other character is dropped
+				tseq.resize(r.seq_len);
+				{
+					char* o = &tseq[0];
+					size_t m = 0;
+					for (size_t k = 0; k < r.seq_len; k++) { const unsigned char v = kSeqCode.t[s[k]]; o[m] = (char)v; m += (v != 255); }
+					tseq.resize(m);
+				}
 				if (r.has_qual) {
 					tqual.assign(arena_.data() + r.qual_off, r.qual_len);
 					if (opt_.format == 7) {}          // BAM qualities are Phred values, whatever scale options say (pat.cpp:1493)
@@ -681,7 +719,7 @@ private:
 				if (tg) rd.tags.set(ch.tags.data() + tag_off[i], tag_len[i]);
 				rd.seq.set((const char*)b.seq.data() + b.off[i], rlen[i]);
 				rd.qual.set((const char*)b.qual.data() + b.off[i], rlen[i]);
-				b.rp[i] = compute_read_params(opt_, rd);
+				b.rp[i] = rlen[i] < len_params_.size() ? compute_read_params(opt_, rd, len_params_[rlen[i]]) : compute_read_params(opt_, rd);
 			}
 		});
 		for (size_t i = 0; i < nrec; i++) if (rlen[i] > max_read_len) { b.too_long = b.reads[i].name.str(); break; }
@@ -703,6 +741,7 @@ private:
 	size_t cmd_pos_ = 0;
 	std::string cmd_;            // -c: the comma-separated reads of this source (the -U, -1 or -2 argument)
 	uint64_t rdid_ = 0;
+	unsigned ushift_ = 0;        // log2(unit_)
 	uint64_t unit_ = 1;          // records per read id: 2 for --interleaved mates (-s/-u and default names count pairs)
 };
 

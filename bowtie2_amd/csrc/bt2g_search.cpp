@@ -153,7 +153,22 @@ static int run_search(int argc, char** argv) {
 	AlnSummary summ;
 	std::mutex align_mu;
 	double align_s = 0, t_format = 0, t_write = 0, t_h2d = 0, t_d2h = 0;
+	double ts_first_parsed = -1, ts_first_aligned = -1, ts_last_parsed = 0, ts_last_aligned = 0;      // -t: seconds after the index load
+	auto since_load = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(); };
 	typedef std::unique_ptr<HostBatch> BatchPtr;
+	// finished batches go back to the reader with their memory (HostBatch::recycle)
+	struct BatchPool {
+		std::mutex mu; std::vector<BatchPtr> free_;
+		BatchPtr get() { { std::lock_guard<std::mutex> g(mu); if (!free_.empty()) { BatchPtr b = std::move(free_.back()); free_.pop_back(); return b; } } return BatchPtr(new HostBatch()); }
+		void put(BatchPtr b) {
+			if (!b) return;
+			BatchPtr m0 = std::move(b->mate_src[0]), m1 = std::move(b->mate_src[1]);
+			b->recycle();
+			std::lock_guard<std::mutex> g(mu);
+			if (free_.size() < 24) free_.push_back(std::move(b));
+			for (BatchPtr* m : { &m0, &m1 }) if (*m) { (*m)->recycle(); if (free_.size() < 24) free_.push_back(std::move(*m)); }
+		}
+	} pool;
 	const size_t kWorkersPerDev = 3;
 	BoundedQueue<BatchPtr> q_in(ndev * kWorkersPerDev + 1), q_out(ndev * kWorkersPerDev + 1);
 
@@ -185,7 +200,7 @@ static int run_search(int argc, char** argv) {
 		bool unp_phase = false;          // mixed input: the pair sources are exhausted, the -U files are being read
 		size_t cur_size = batch_size_for(0, 0);
 		for (;;) {
-			BatchPtr b(new HostBatch());
+			BatchPtr b = pool.get();
 			// (the scan of the batch after this one starts inside next(): its size is decided now)
 			const size_t next_size = batch_size_for(blk + 1, reads_done + cur_size / (opt.paired ? 2 : 1));
 			if (unp_phase) fq_unp->next(*b, batch_reads, (size_t)BT2G_MAX_READ_LEN);
@@ -193,7 +208,7 @@ static int run_search(int argc, char** argv) {
 			if (inter) { fq.next(*b, batch_reads & ~(size_t)1, (size_t)BT2G_MAX_READ_LEN); finalize_interleaved(*b, opt); }
 			else if (opt.paired) {
 				// one batch per mate file in lockstep, interleaved into a batch of pairs
-				BatchPtr b1(new HostBatch()), b2(new HostBatch());
+				BatchPtr b1 = pool.get(), b2 = pool.get();
 				fq.next(*b1, cur_size / 2, (size_t)BT2G_MAX_READ_LEN, next_size / 2);
 				fq2->next(*b2, cur_size / 2, (size_t)BT2G_MAX_READ_LEN, next_size / 2);
 				merge_mate_batches(std::move(b1), std::move(b2), *b, opt);
@@ -211,6 +226,7 @@ static int run_search(int argc, char** argv) {
 			}
 			b->seqno = seq++;
 			const bool last = b->last;
+			{ std::lock_guard<std::mutex> g2(align_mu); const double ts = since_load(); if (ts_first_parsed < 0) ts_first_parsed = ts; ts_last_parsed = ts; }
 			q_in.push(std::move(b));
 			if (last) break;
 		}
@@ -247,7 +263,9 @@ static int run_search(int argc, char** argv) {
 				if (shard_idx && !b->reads.empty()) fprintf(shard_idx, "B %llu %llu %llu\n", (unsigned long long)b->block_id, (unsigned long long)nbytes, (unsigned long long)b->reads.size());
 				t_format += std::chrono::duration<double>(tf1_ - tf0_).count();
 				t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf1_).count();
-				if (b->last) { done = true; break; }
+				const bool was_last = b->last;
+				pool.put(std::move(b));
+				if (was_last) { done = true; break; }
 			}
 		}
 	});
@@ -326,7 +344,8 @@ static int run_search(int argc, char** argv) {
 				b->res = (const uint8_t*)b->res_hold.get();
 				HIP_OK(hipMemcpyAsync(b->res_hold.get(), d_packed.p, total, hipMemcpyDeviceToHost, st));
 				HIP_OK(hipStreamSynchronize(st));
-				{ std::lock_guard<std::mutex> g2(align_mu); t_d2h += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count(); }
+				{ std::lock_guard<std::mutex> g2(align_mu); t_d2h += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
+				  const double ts = since_load(); if (ts_first_aligned < 0) ts_first_aligned = ts; ts_last_aligned = ts; }
 			}
 			q_out.push(std::move(b));
 		}
@@ -348,6 +367,8 @@ static int run_search(int argc, char** argv) {
 		fprintf(stderr, "Multiseed full-index search: %s\n", hms(search_wall).c_str());
 		fprintf(stderr, "[bt2g] index load %.3f s; search %.3f s wall, %llu reads -> %.0f reads/s after the load\n", std::chrono::duration<double>(t1 - t0).count(), search_wall,
 		        (unsigned long long)(summ.nread + 2 * psumm.npair), search_wall > 0 ? (double)(summ.nread + 2 * psumm.npair) / search_wall : 0.0);
+		fprintf(stderr, "[bt2g] after the load: first batch parsed at %.3f s, first batch back from the device at %.3f s, last batch parsed at %.3f s, last batch back at %.3f s, output closed at %.3f s\n",
+		        ts_first_parsed, ts_first_aligned, ts_last_parsed, ts_last_aligned, search_wall);
 		fprintf(stderr, "[bt2g] device stage, summed over its %zu threads: upload %.3f s, kernels + pack %.3f s, download %.3f s\n", ndev * kWorkersPerDev, t_h2d, align_s, t_d2h);
 		fprintf(stderr, "[bt2g] host stages: split %.3f s, parse %.3f s, pack %.3f s, format %.3f s, write %.3f s\n", fq.t_split, fq.t_parse, fq.t_pack, t_format, t_write);
 	}
