@@ -4,9 +4,10 @@
 // index from a device counter, so long reads / repetitive reads do not leave a tail of idle
 // CUs.  Per-wave working state (Work + DP scratch) lives in an HBM arena sized at launch.
 //
-// The wave-parallel pieces (DevPlat): the end-to-end u8 DP fill on the anti-diagonal wavefront
-// (lane = block of read rows, H/F/ref-char handed down the lanes with __shfl_up, wavefront-major
-// scratch so every store is one 64-byte line), and the zeroing of backtrace-mask rows.
+// The wave-parallel pieces (DevPlat): the DP fills -- the end-to-end 8-bit fill over the band of diagonals an alignment can touch (lane = 2 RP
+// diagonals, packed 16-bit ALU, one predecessor byte per cell), the 16-bit end-to-end fill on the anti-diagonal wavefront, the local fill
+// (two blocks of rows per lane, packed, predecessor bytes in anti-diagonal order: bt2g_local_pk.hpp) -- each as leaf functions; the tile
+// fetches and diagonal / gap runs of the backtrace; the candidate gather and its radix sort; the row sampler's register table.
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <new>
