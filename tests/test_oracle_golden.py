@@ -169,3 +169,30 @@ def test_dp_fill_other_kinds(golden_dir):
             for i in range(rows):
                 h.update(struct.pack("<%di" % p["ncol"], *b[i * cols:i * cols + p["ncol"]]))
         assert h.hexdigest() == p["sha"], (p["kind"], rows, cols)
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_one_mm_search(golden_dir, large):
+    """bt2o_one_mm_search against what SeedAligner::oneMmSearch itself produced (tests/golden/make_one_mm_golden.py): the 1-mismatch hits in
+    the order the reference adds them and the exact hits, end to end and local, all repex / rep1mm combinations, strands switched off."""
+    from bt2test import Mm1Hit
+    L, idx, _ = load(golden_dir, large)
+    with open(os.path.join(golden_dir, "one_mm_golden.json")) as f:
+        cases = json.load(f)["l" if large else "s"]
+    sc = Scoring()
+    L.bt2o_scoring_default(C.byref(sc))
+    hits = (Mm1Hit * 512)()
+    total = 0
+    for c in cases:
+        sc.match_bonus = 2 if c["local"] else 0
+        s = c["seq"]
+        n = L.bt2o_one_mm_search(C.byref(idx.fwd), C.byref(idx.bwd), encode(s), c["qual"].encode(), len(s), C.byref(sc), c["nceil"], c["minsc"],
+                                 c["nofw"], c["norc"], c["local"], c["repex"], c["rep1mm"], hits, 512)
+        mine = [hits[i] for i in range(n)]
+        m1 = [[x.top, x.bot, x.score, x.off5p, x.chr, x.qchr, x.fw] for x in mine if x.kind == 1]
+        assert m1 == c["hits"], (s, c["local"], c["repex"], c["rep1mm"])
+        ex = c["exact"]
+        want = [[1, ex[1], ex[2]]] * ex[0] + [[0, ex[4], ex[5]]] * ex[3]
+        assert [[x.fw, x.top, x.bot] for x in mine if x.kind == 0] == want, (s, c["repex"])
+        total += len(m1)
+    assert total > 300
