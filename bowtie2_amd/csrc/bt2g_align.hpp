@@ -425,14 +425,14 @@ struct AlState {
 
 // The per-column tail of the hot state, as one launch lays it out behind the fixed part:  rf[max_cols + 8]  (rounded up to 16 bytes), then a
 // region shared by  Edit ned[kMaxEdits]  and  int16_t lastrow[max_cols + 8]  (never live at the same time: the gather reads `lastrow` before
-// any backtrace writes `ned`; the local gather's radix sort borrows 2 048 bytes of it for its counters).
+// any backtrace writes `ned`; the local gather's radix sort borrows 2 048 bytes of it for its counters: local launches keep at least that).
 // DP columns a launch with these parameters holds (bt2g_align_params::max_dp_cols)
 BT2_HD uint32_t dp_cols_for(const AlignParams& P) { return P.max_dp_cols > kMaxCols ? (uint32_t)(P.max_dp_cols < kMaxColsWide ? P.max_dp_cols : kMaxColsWide) : (uint32_t)kMaxCols; }
 BT2_HD uint32_t hot_tail_off(uint32_t max_cols) { return (max_cols + 8 + 15) & ~15u; }
-BT2_HD uint32_t hot_tail_bytes(uint32_t max_cols) {
+BT2_HD uint32_t hot_tail_bytes(uint32_t max_cols, bool local = true) {
 	uint32_t b = (max_cols + 8) * 2;
 	if (b < (uint32_t)(kMaxEdits * sizeof(Edit))) b = (uint32_t)(kMaxEdits * sizeof(Edit));
-	if (b < 2048u) b = 2048u;
+	if (local && b < 2048u) b = 2048u;      // (the radix counters of the local gather)
 	return hot_tail_off(max_cols) + ((b + 15) & ~15u);
 }
 

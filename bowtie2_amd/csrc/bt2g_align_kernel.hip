@@ -1389,7 +1389,7 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 	if (rd.n_reads == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
-	const uint32_t tail = hot_tail_bytes(max_cols);      // dynamic LDS: the per-column tail of the hot state
+	const uint32_t tail = hot_tail_bytes(max_cols, P.match_bonus > 0);      // dynamic LDS: the per-column tail of the hot state
 	if (P.paired)
 		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), tail, st, ix, P, rd, d_rparams, d_results, result_stride,
 		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols);
@@ -1505,3 +1505,33 @@ template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const Alig
 template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, uint32_t, hipStream_t);
 
 } // namespace bt2g
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A second compilation of this file is a second OCCUPANCY CLASS of the worker (Makefile: bt2g_align_kernel_w5.o, built with
+// -DBT2G_WAVES_PER_EU=5 -DBT2G_NUM_VGPR=96 -Dbt2g=bt2g_w5 -DBT2G_KCLASS_W5): the register budget of the kernels and of every device function they call
+// is a property of the translation unit, so the same source is compiled again under another namespace name and reached through the two
+// plain-C entry points below (the index descriptor, parameter blocks and pre-computation tables have the same layout in both: same headers).
+// 49 % of a wave's cycles are spent waiting on a counter and 4 waves per SIMD cannot cover that; with 96 registers and the small
+// dynamic LDS of an end-to-end batch, 5 waves per SIMD are resident.
+#ifdef BT2G_KCLASS_W5
+extern "C" hipError_t bt2g_w5_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams,
+                                           uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
+                                           uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
+                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, hipStream_t st) {
+	using namespace bt2g;
+	const PreComp& pc = *reinterpret_cast<const PreComp*>(pre);
+	return off_size == 4
+		? launch_align(*reinterpret_cast<const DevIndex<uint32_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, st)
+		: launch_align(*reinterpret_cast<const DevIndex<uint64_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, st);
+}
+extern "C" uint32_t bt2g_w5_waves_per_cu(void) { return bt2g::align_waves_per_cu(); }
+// static LDS of the unpaired worker kernels of this class (the larger of the two index widths); 0xffffffff if the runtime will not say
+extern "C" uint32_t bt2g_w5_static_lds(void) {
+	hipFuncAttributes a32, a64;
+	if (hipFuncGetAttributes(&a32, reinterpret_cast<const void*>(&bt2g::k_align_reads<uint32_t>)) != hipSuccess) return 0xffffffffu;
+	if (hipFuncGetAttributes(&a64, reinterpret_cast<const void*>(&bt2g::k_align_reads<uint64_t>)) != hipSuccess) return 0xffffffffu;
+	return (uint32_t)(a32.sharedSizeBytes > a64.sharedSizeBytes ? a32.sharedSizeBytes : a64.sharedSizeBytes);
+}
+extern "C" uint64_t bt2g_w5_work_bytes(void) { return bt2g::align_work_bytes(); }
+#endif
+

@@ -285,6 +285,15 @@ int bt2g_seed_search_exact(bt2g_ctx* c, const bt2g_reads* reads, const uint32_t*
 	return e == hipSuccess ? 0 : hip_fail(c, e, "k_seed_search_exact");
 }
 
+// the worker's second occupancy class (bt2g_align_kernel.hip compiled again with 96 registers: 5 waves per SIMD)
+extern "C" hipError_t bt2g_w5_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams,
+                                           uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
+                                           uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
+                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, hipStream_t st);
+extern "C" uint32_t bt2g_w5_waves_per_cu(void);
+extern "C" uint32_t bt2g_w5_static_lds(void);
+extern "C" uint64_t bt2g_w5_work_bytes(void);
+
 static_assert(sizeof(bt2g_mm1_hit) == sizeof(Mm1Hit) && offsetof(bt2g_mm1_hit, score) == offsetof(Mm1Hit, score) && offsetof(bt2g_mm1_hit, epos) == offsetof(Mm1Hit, epos) &&
               offsetof(bt2g_mm1_hit, echr) == offsetof(Mm1Hit, echr) && offsetof(bt2g_mm1_hit, eqchr) == offsetof(Mm1Hit, eqchr), "bt2g_mm1_hit is the kernels' Mm1Hit");
 
@@ -430,10 +439,22 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	bt2g_ctx::BatchSlot& S = c->slots[si];
 	uint64_t mat_bytes, mask_bytes, pmask_bytes, arena_stride;
 	if (params->paired && (reads->n_reads & 1u)) return fail(c, BT2G_ERR_ARG, "paired mode needs an even number of reads (mates interleaved)");
-	const uint32_t max_cols = dp_cols_for(*params);      // DP columns this launch holds (bt2g_align_params::max_dp_cols)
+	uint32_t max_cols = dp_cols_for(*params);      // DP columns this launch holds (bt2g_align_params::max_dp_cols)
+	// Occupancy class.  An end-to-end batch of unpaired reads needs DP windows of rows + 4 x maxhalf + 1 columns at most (seed extension only,
+	// dp_framer.cpp:81-129): with that little per-column state in dynamic LDS, 20 waves per CU fit, and the worker compiled for 96 registers
+	// (5 waves per SIMD) hides more of the latency its instruction stream is made of.  Local batches (2 KB of radix counters), pairs (wide
+	// opposite-mate windows, a second matrix) and BT2G_NO_W5=1 stay with the 128-register build.
+	static const bool no_w5 = getenv("BT2G_NO_W5") != nullptr;
+	static const uint32_t kStaticLdsBytes = bt2g_w5_static_lds();
+	bool w5 = false;
+	if (!no_w5 && !params->paired && params->match_bonus == 0 && params->max_dp_cols <= kMaxCols && sizeof(Work) == bt2g_w5_work_bytes()) {
+		const uint32_t need = max_read_len + 4u * (uint32_t)(params->maxhalf > 0 ? params->maxhalf : 0) + 1u + 4u;
+		const uint32_t lds_per_wave = (160u * 1024u) / (4u * 5u);
+		if (need <= (uint32_t)kMaxCols && kStaticLdsBytes + hot_tail_bytes(need, false) <= lds_per_wave) { w5 = true; max_cols = need; }
+	}
 	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
 	// persistent waves (one read at a time each) pull reads from a device-side queue
-	uint32_t n_waves = c->n_cu * align_waves_per_cu();
+	uint32_t n_waves = c->n_cu * (w5 ? bt2g_w5_waves_per_cu() : align_waves_per_cu());
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
 	const uint64_t need = arena_stride * n_waves;
 	hipError_t e;
@@ -446,7 +467,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		S.arena_layout = 0;
 	}
 	// the epoch-tagged backtrace masks live in the arena across launches: (re)start from zero whenever its layout changes
-	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0);
+	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0) ^ (w5 ? 1ull << 62 : 0);
 	if (layout != S.arena_layout) {
 		e = hipMemsetAsync(S.d_arena, 0, S.arena_bytes, st);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(worker arena)");
@@ -566,6 +587,10 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	} else { for (int i = 1; i <= 4; i++) mark(i); }
 	mark(5);
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
+	if (w5)
+		e = bt2g_w5_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
+		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, st);
+	else
 	e = (c->off_size == 4)
 		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, st)
 		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, st);
