@@ -443,7 +443,7 @@ def pmc_issue(kernel, kern_ms, reads_per_launch, n_cu, config="se150"):
         simd_cycles_per_read = kern_ms * 1e-3 * 2.4e9 * n_cu * 4 / reads_per_launch
         return {"source": "profiles/" + os.path.basename(files[-1]), "valu_per_read": round(valu), "salu_per_read": round(salu), "lds_per_read": round(lds),
                 "vmem_per_read": round(vmem), "simd_cycles_per_read": round(simd_cycles_per_read), "valu_busy_frac": round(valu * 4 / simd_cycles_per_read, 3),
-                "note": "k_align_reads is one serial instruction stream per read (one wavefront each, 4 per SIMD): it is bound by the issue rate and the "
+                "note": "k_align_reads is one serial instruction stream per read (one wavefront each, 4 or 5 per SIMD): it is bound by the issue rate and the "
                         "dependent latencies of that stream, not by HBM; the hbm fraction above is reported because the contract asks for it"}
     except Exception:
         return None
