@@ -1500,7 +1500,6 @@ struct Aligner {
 			int ct = 0;      // 0=H 1=E 2=F (SSEMatrix::H/E/F order irrelevant here)
 			Edit* ned = Plat::ned();
 			const int offsetsc = local ? 0 : (wide ? -0x7fff : -0xff);
-			auto fl = [&](int v) -> bool { return !local || v > 0; };     // `> floorsc` of the local kernels (aligner_swsse_loc_u8.cpp:1530-1660)
 			HOT.n_bt_attempts++;
 			while ((int)row >= 0) {
 				if (pred && ct != 0 && tdir == (uint32_t)ct && td < tile_len && row > 0) {

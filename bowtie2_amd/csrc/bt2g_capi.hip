@@ -450,7 +450,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (!no_w5 && !params->paired && params->match_bonus == 0 && params->max_dp_cols <= kMaxCols && sizeof(Work) == bt2g_w5_work_bytes()) {
 		const uint32_t need = max_read_len + 4u * (uint32_t)(params->maxhalf > 0 ? params->maxhalf : 0) + 1u + 4u;
 		const uint32_t lds_per_wave = (160u * 1024u) / (4u * 5u);
-		if (need <= (uint32_t)kMaxCols && kStaticLdsBytes + hot_tail_bytes(need, false) <= lds_per_wave) { w5 = true; max_cols = need; }
+		if (need <= (uint32_t)kMaxCols && kStaticLdsBytes < lds_per_wave && kStaticLdsBytes + hot_tail_bytes(need, false) <= lds_per_wave) { w5 = true; max_cols = need; }      // (kStaticLdsBytes is 0xffffffff when the runtime would not say)
 	}
 	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
 	// persistent waves (one read at a time each) pull reads from a device-side queue
