@@ -134,6 +134,33 @@ def test_wide_mate_windows_through_the_driver(twin, extra):
         assert p.returncode == 0 and "Warning" not in p.stderr
 
 
+@pytest.mark.parametrize("inp", ["unpaired", "paired"])
+def test_varied_batch_sizes_do_not_change_the_sam(twin, inp, tmp_path):
+    """--batch-max N: the reader ramps the batch size up from 64 K reads and, for one plain file, tapers it off towards the end of the input
+    (bt2g_search.cpp); batches are recycled with their memory either way (HostBatch::recycle).  However the input is cut, the SAM and the summary
+    are those of the fixed-size run.  The input here is the golden reads repeated until the ramp has several steps to take."""
+    src_files = [FQ] if inp == "unpaired" else [M1, M2]
+    big = []
+    for k, f in enumerate(src_files):
+        text = open(f).read()
+        recs = text.splitlines()
+        out = []
+        for rep in range(260 if inp == "unpaired" else 450):      # ~0.13 M unpaired reads / 2 x 72 K mates: a 64 K batch, a larger one, a taper
+            for i in range(0, len(recs), 4):
+                nm = recs[i].split()[0]
+                nm = (nm[:-2] + "_%d" % rep + nm[-2:]) if nm.endswith(("/1", "/2")) else nm + "_%d" % rep
+                out += [nm, recs[i + 1], recs[i + 2], recs[i + 3]]
+        p = tmp_path / ("big_%d.fq" % k)
+        p.write_text("\n".join(out) + "\n")
+        big.append(str(p))
+    src = ["-U", big[0]] if inp == "unpaired" else ["-1", big[0], "-2", big[1]]
+    common = ["--very-fast", "-x", os.path.join(GOLD, "tiny_s")] + src
+    fixed = run(twin, ["--batch", "50000"] + common)
+    varied = run(twin, ["--batch-max", "131072"] + common)
+    assert varied[0] == fixed[0] and len(fixed[0]) > 100000
+    assert varied[1] == fixed[1]
+
+
 def test_byte_sharding_falls_back_for_gzip_and_odd_files(twin, tmp_path):
     """gzip'ed input, or a file that is not strict 4-line FASTQ (a blank line between records), cannot be cut by byte ranges: the ranks
     agree on block mode and the output is still the one-process output"""
