@@ -145,7 +145,7 @@ def test_varied_batch_sizes_do_not_change_the_sam(twin, inp, tmp_path):
         text = open(f).read()
         recs = text.splitlines()
         out = []
-        for rep in range(260 if inp == "unpaired" else 450):      # ~0.13 M unpaired reads / 2 x 72 K mates: a 64 K batch, a larger one, a taper
+        for rep in range(140 if inp == "unpaired" else 215):      # 73 K unpaired reads / 2 x 34 K mates: the first 64 K-read batch, then the taper
             for i in range(0, len(recs), 4):
                 nm = recs[i].split()[0]
                 nm = (nm[:-2] + "_%d" % rep + nm[-2:]) if nm.endswith(("/1", "/2")) else nm + "_%d" % rep
@@ -157,7 +157,7 @@ def test_varied_batch_sizes_do_not_change_the_sam(twin, inp, tmp_path):
     common = ["--very-fast", "-x", os.path.join(GOLD, "tiny_s")] + src
     fixed = run(twin, ["--batch", "50000"] + common)
     varied = run(twin, ["--batch-max", "131072"] + common)
-    assert varied[0] == fixed[0] and len(fixed[0]) > 100000
+    assert varied[0] == fixed[0] and len(fixed[0]) > 60000
     assert varied[1] == fixed[1]
 
 
