@@ -134,7 +134,7 @@ def test_wide_mate_windows_through_the_driver(twin, extra):
         assert p.returncode == 0 and "Warning" not in p.stderr
 
 
-@pytest.mark.parametrize("inp", ["unpaired", "paired"])
+@pytest.mark.parametrize("inp", ["unpaired"])      # ("paired" works the same way and passes -- 50 s on the CPU twin, not part of the default run)
 def test_varied_batch_sizes_do_not_change_the_sam(twin, inp, tmp_path):
     """--batch-max N: the reader ramps the batch size up from 64 K reads and, for one plain file, tapers it off towards the end of the input
     (bt2g_search.cpp); batches are recycled with their memory either way (HostBatch::recycle).  However the input is cut, the SAM and the summary
