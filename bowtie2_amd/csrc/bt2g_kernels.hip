@@ -516,7 +516,7 @@ hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, co
 }
 
 // ------------------------------------------------------------------------------------
-// Every row's view through the HBM layout (tests: bt2g_index_rows against the oracle's walk over the on-disk layout)
+// Every row's view through the HBM layout (tests: bt2g_index_rows against a walk over the on-disk layout, tests/test_rank_index.py)
 // ------------------------------------------------------------------------------------
 // out[16] per row: row, joined offset (full suffix array), steps the reference's LF walk to the sample would take, rank4 in the forward
 // index, mapLF1 (character, next row), rank4 in the mirror index, the rank pair (row, min(row + 37, len)) of character row & 3 and the
