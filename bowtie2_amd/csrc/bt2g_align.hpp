@@ -33,11 +33,13 @@
 
 namespace bt2g {
 
-#ifdef BT2G_PROBE_SMALL
-// occupancy probe builds only (tools/r03_session1.sh): capacities cut to what 150-bp unpaired reads need, to see what the
-// worker gains from an LDS footprint that admits more waves per CU.  Never shipped: longer reads would be flagged.
-constexpr int kMaxLen      = 256;
-constexpr int kMaxOffs     = BT2G_PROBE_SMALL;
+#ifdef BT2G_CLASS_MAX_LEN
+// The worker's short-read class (Makefile: bt2g_align_kernel_w5.o -- the same source compiled with 96 registers under another namespace):
+// capacities cut to what batches of short unpaired reads need, so that the LDS this frees holds the backtrace's on-chip state
+// (DevPlat::rt_begin) at 20 waves per CU.  bt2g_align_batch picks the class per batch and only gives this one batches it holds
+// (longest read <= BT2G_CLASS_MAX_LEN, at most BT2G_CLASS_MAX_OFFS seed positions per strand): nothing is flagged that the general class would align.
+constexpr int kMaxLen      = BT2G_CLASS_MAX_LEN;
+constexpr int kMaxOffs     = BT2G_CLASS_MAX_OFFS;
 #else
 constexpr int kMaxLen      = 512;   // longest read (DP rows)
 constexpr int kMaxOffs     = 64;    // seed offsets per strand
@@ -53,11 +55,7 @@ constexpr int kMaxAlns     = 160;   // alignments kept by the sink (-M 50 -> at 
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 65536; // uint32 slots for Random1toN lists (swap lists of small ranges, seen lists bounded by max_iters, converted lists)
 constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
-#ifdef BT2G_PROBE_SMALL
-constexpr int kMaxCols     = 340;
-#else
 constexpr int kMaxCols     = 1100;  // DP columns a launch holds unless the caller asks for more: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*gaps
-#endif
 // Widest DP window any launch can hold (bt2g_align_params::max_dp_cols asks for it).  The per-column state of the window in flight -- the
 // reference masks and the last row's scores -- lives in LDS, and LDS decides how many waves a CU holds: the common batch (unpaired reads,
 // pairs with the default -X 500) is launched with kMaxCols columns of it and runs 16 waves per CU; a batch whose opposite-mate windows are
@@ -76,8 +74,10 @@ using ReadParams  = bt2g_read_params;
 using Edit        = bt2g_edit;
 using AlnRes      = bt2g_aln;
 using ReadResult  = bt2g_read_result;
-#ifndef BT2G_PROBE_SMALL
+#ifndef BT2G_CLASS_MAX_LEN
 static_assert(kMaxLen == BT2G_MAX_READ_LEN && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
+#else
+static_assert(kMaxLen <= BT2G_MAX_READ_LEN && kMaxLen % 4 == 0 && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -153,14 +153,6 @@ struct DiagIval { int64_t off; int64_t len; int32_t ref; int32_t orient; };
 struct BtCand { int32_t score; uint16_t row, col; };
 constexpr int kMaxLocalScore = 2047;      // counting-sort table of the local candidate gather (scores above share the top bucket)
 constexpr int kMaxCandDone = 1024;       // local mode: candidates of one window that can be tried (btncanddone_) before the read is flagged
-
-struct BtFrame {          // DpNucFrame
-	uint32_t nedsz, celsz;    // celsz: # cells on the path so far | core-diagonal-touched flag << 31
-	uint16_t row, col;
-	uint16_t gaps, read_gaps, ref_gaps;
-	uint8_t  ct, pad;
-	int32_t  score, ns;
-};
 
 struct DPRect { int64_t refl, refr, refl_pretrim, refr_pretrim; uint32_t triml, trimr, corel, corer, maxgap; };
 
@@ -286,7 +278,6 @@ struct Work {
 	BtCand   cands[kMaxCands];
 	uint32_t cand_hist[2 * (kMaxLocalScore + 1)];   // scratch of the local gather's counting sort
 	uint32_t cand_done[2][kMaxCandDone];            // local mode: tried candidates (row | col << 16) of the anchor's window and of the opposite mate's
-	BtFrame  btstack[kMaxLen + kMaxColsWide];
 	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
 	// ---- paired-end (extendSeedsPaired; unused for unpaired reads) ----
 	// seed-phase state of the mate that is not loaded (both mates are searched before either is extended)
@@ -420,6 +411,9 @@ struct AlState {
 	uint32_t  emit_on;                // 1 in the workers (Aligner's constructor); 0 in the stage kernel, whose waves have no work area
 	uint32_t  max_cols;               // DP columns this launch holds (kMaxCols .. kMaxColsWide): wider windows flag the read
 	uint32_t  tail_off;               // device: where ned / lastrow start in the launch's dynamic LDS (behind rf)
+	// device: the reportedThrough plane and the last rows' predecessor bytes of the band matrix in hand, in the launch's dynamic LDS when it has room
+	// (DevPlat::rt_begin): offsets into the tail, capacities in bytes, "this matrix's marks are on chip", first row of the copy (none: 0xffffffff)
+	uint32_t  rt_off, pt_off, rt_bytes, pt_bytes, rt_cur, pt_row0;
 	uint32_t  fill_rows_done, fill_lastsol, fill_sat8;   // device: what a leaf fill hands back besides its return value (row the score-only pass stopped in; lastsolcol_ / "8-bit kernel saturated" of a local fill)
 };
 

@@ -1342,6 +1342,7 @@ struct Aligner {
 				uint32_t e = Plat::uni(*ST.dp.epoch) + 1;
 				if (e > kEpochMax) { Plat::zero_u32(ST.dp.pmask, ST.dp.pmask_words); e = 1; }
 				Plat::set_epoch(ST.dp.epoch, e);
+				Plat::rt_begin(ST.dp, rows, mode == 0);      // (device: the marks of a band matrix live on chip when the launch has room for them)
 			} else Plat::zero_masks(ST.dp.masks, rows * cols);
 			HOT.t_phase[16] += now() - tz_;
 		}
@@ -1454,7 +1455,6 @@ struct Aligner {
 		const uint32_t epoch = pred ? Plat::uni(*dpl.epoch) : 0u;
 		const int32_t band_lo = pred ? (int32_t)Plat::uni(dpl.epoch[1]) : 0;       // geometry of the band the fill stored (pred_idx)
 		const uint32_t band_w = pred ? Plat::uni(dpl.epoch[2]) : 0u;
-		BtFrame* const btstack = Plat::uni_ptr(&WK.btstack[0]);
 		BtCand* const cands = Plat::uni_ptr(cand_list());
 		struct Prof {      // profile counters stay in registers until the function returns
 			uint32_t steps, tiles; uint64_t tile_t; uint32_t scalar_steps;
@@ -1463,11 +1463,12 @@ struct Aligner {
 		// read, qualities and reference window as per-lane registers (4 bytes per lane per register): the step
 		// loop then reads them with v_readlane instead of going to LDS
 		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
-		// the first 64 frames of the backtrace's branch stack (DpNucFrame) live in the lanes of seven registers: a dead end pops its frame
-		// with v_readlane instead of a round trip to the arena (a candidate next to an earlier alignment's end tries a few branches, each a
-		// dead end within a cell or two, before it gives up); deeper frames go to WK.btstack
-		typename Plat::LaneReg sk0, sk1, sk2, sk3, sk4, sk5, sk6;
-		Plat::lanes_zero(sk0); Plat::lanes_zero(sk1); Plat::lanes_zero(sk2); Plat::lanes_zero(sk3); Plat::lanes_zero(sk4); Plat::lanes_zero(sk5); Plat::lanes_zero(sk6);
+		// The backtrace's branch stack (btnstack_, DpNucFrame) and the per-cell H/E/F choice masks (SSEMatrix::masks_ bits 1-12) are DEAD STATE
+		// in the reference: every cell a walk visits gets reportedThrough set in the same visit that stores its choice mask
+		// (aligner_swsse_ee_u8.cpp:1331-1338 tests reportedThrough first, :1556 sets it for every visited cell), so (a) a choice mask is never read
+		// again -- any later visit stops at "reportedThru" before it looks -- and (b) a popped frame resumes in a cell this very walk has marked,
+		// fails at once and pops the next (:1560-1586): a walk that meets a marked cell fails, after one more loop iteration per frame on the
+		// stack (they count as backtrace cells, met.btcell).  What a walk needs of the matrix is the predecessor bits and ONE bit per cell.
 		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
 		// the walk moves left from its start column by at most rows + gaps columns: three registers (768 columns) cover every window of an
 		// unpaired read from column 0 (rf_c0 = 0); only a candidate past column 767 of a wide opposite-mate window needs them re-based
@@ -1481,9 +1482,10 @@ struct Aligner {
 			return (int)((v >> ((idx & 3) * 8)) & 0xff);
 		};
 		// one backtrace from cell (row, col), whose tile the caller fetched
-		auto walk = [&](uint32_t row, uint32_t col, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi) __attribute__((always_inline)) -> bool {
+		auto walk = [&](uint32_t row, uint32_t col, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi, uint32_t tvalid_) __attribute__((always_inline)) -> bool {
 			row = Plat::uni(row); col = Plat::uni(col);
 			uint32_t td = 0;     // td = steps taken along the tile
+			uint32_t tvalid = Plat::uni(tvalid_);      // cells of the tile in hand that hold data (a tile served from the on-chip copy of the last rows ends where that copy ends)
 			uint32_t tdir = 0, ndir = 0;      // pred format: direction of the tile in hand / of the next fetch (0 diagonal, 1 left along the row, 2 up the column)
 			const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
 			int olap = 0;        // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
@@ -1502,15 +1504,16 @@ struct Aligner {
 			const int offsetsc = local ? 0 : (wide ? -0x7fff : -0xff);
 			HOT.n_bt_attempts++;
 			while ((int)row >= 0) {
-				if (pred && ct != 0 && tdir == (uint32_t)ct && td < tile_len && row > 0) {
+				if (pred && ct != 0 && tdir == (uint32_t)ct && td < tvalid && row > 0) {
 					// inside a gap: the cells that can only EXTEND it (unvisited, E consistent with E-left alone / F with F-up alone) are walked
 					// by all lanes at once -- same marks, same edits, same counters as the step-by-step loop below.  (The candidates next to an
 					// alignment's end column each walk a gap of growing length back to its path; the cell that opens the gap and whatever
 					// follows go through the scalar step.)
 					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
 					const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
+					uint32_t room = room_c < room_e ? room_c : room_e; if (room > tvalid - td) room = tvalid - td;
 					uint32_t core = 0;
-					const uint32_t L = Plat::uni(Plat::bt_gap_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, ct == 1, fw, rdlen, room_c < room_e ? room_c : room_e,
+					const uint32_t L = Plat::uni(Plat::bt_gap_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, ct == 1, fw, rdlen, room,
 					                                              nned, r_triml, r_corel, r_corer, core));
 					if (L > 0) {
 						olap |= (int)(Plat::uni(core) != 0); ncells += L; prof.steps += L; nned += L; gaps += L; td += L;
@@ -1519,14 +1522,15 @@ struct Aligner {
 						continue;
 					}
 				}
-				if (pred && ct == 0 && tdir == 0 && td < tile_len && row > 0) {
+				if (pred && ct == 0 && tdir == 0 && td < tvalid && row > 0) {
 					// a run of plain diagonal steps (unvisited cells whose only consistent predecessor is the diagonal one) is walked
 					// by all lanes at once: same marks, same edits, same counters as the step-by-step loop below
 					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
 					const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
+					uint32_t room = room_c < room_e ? room_c : room_e; if (room > tvalid - td) room = tvalid - td;
 					typename Plat::LaneReg inf;
 					uint64_t mm;
-					const uint32_t L = Plat::uni(Plat::bt_diag_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, fw, rdlen, room_c < room_e ? room_c : room_e, inf, mm));
+					const uint32_t L = Plat::uni(Plat::bt_diag_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, fw, rdlen, room, inf, mm));
 					if (L > 0) {
 						olap |= in_core(row, col); ncells += L; prof.steps += L;
 						if (local) score += (int32_t)(L - (uint32_t)__builtin_popcountll(mm)) * S.match_bonus;      // (end to end a match scores 0)
@@ -1552,41 +1556,34 @@ struct Aligner {
 				int empty = 0, can_move_thru = 1, branch = 0;
 				int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
 				prof.steps++; prof.scalar_steps++;
-				if (td >= tile_len) {
+				if (td >= tvalid) {
 					const uint64_t tt_ = now();
-					if (pred) { Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, ndir, tile, tile_hi); tdir = ndir; } else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
+					if (pred) { tvalid = Plat::uni(Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, ndir, rows, tile, tile_hi)); tdir = ndir; }
+					else { Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi); tvalid = tile_len; }
 					td = 0; prof.tiles++; prof.tile_t += now() - tt_;
 				}
 				const uint32_t mk0 = pred ? Plat::lane(tile_hi, td) : (Plat::lane(tile, 48 + td) & 0xffffu);
-				uint32_t mk = mk0;
 				if (mk0 & 1) {                    // reportedThrough
 					can_move_thru = 0;
 				} else if (row > 0) {
-					int mask, orig_mask, sel = -1;
+					int mask, sel = -1;
 					if (pred) {
 						// the fill already answered "which predecessors are score-consistent" (PB_* bits, gap barrier folded in)
 						const int pb = (int)Plat::lane(tile, td);
 						if (ct == 1) {
 							mask = (pb >> 3) & 3;
-							orig_mask = mask;
-							if (mk & (1u << 7)) mask = (int)((mk >> 8) & 3);
 							branch = (int)(mask == 3);
-							if (mask != 0) { cur = (mask == 2) ? 4 : 3; mk = (mk & ~(7u << 7)) | (1u << 7) | (branch ? (2u << 8) : 0u); sel = 0; }
+							if (mask != 0) { cur = (mask == 2) ? 4 : 3; sel = 0; }
 						} else if (ct == 2) {
 							mask = (pb >> 5) & 3;
-							orig_mask = mask;
-							if (mk & (1u << 10)) mask = (int)((mk >> 11) & 3);
 							branch = (int)(mask == 3);
-							if (mask != 0) { cur = (mask == 2) ? 2 : 1; mk = (mk & ~(7u << 10)) | (1u << 10) | (branch ? (2u << 11) : 0u); sel = 0; }
+							if (mask != 0) { cur = (mask == 2) ? 2 : 1; sel = 0; }
 						} else {
 							const int he = (pb >> 1) & 1, hf = (pb >> 2) & 1;
 							mask = (hf & (pb >> 5) & 1) | ((he & (pb >> 3) & 1) << 1) | ((hf & (pb >> 6) & 1) << 2) | ((he & (pb >> 4) & 1) << 3) | ((pb & 1) << 4);
-							orig_mask = mask;
-							if (mk & (1u << 1)) mask = (int)((mk >> 2) & 31);
 							if (mask != 0) {
 								sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
 								branch = (int)((mask & (mask - 1)) != 0);
-								mk = (mk & ~(31u << 1)) | (1u << 1) | (branch ? (uint32_t)(mask & ~(1 << sel)) << 2 : 0u);
 								cur = (int)((0x04231u >> (4 * sel)) & 7);
 							}
 						}
@@ -1606,18 +1603,14 @@ struct Aligner {
 					if (ct == 1) {          // E: came from the left (H-left open = bit 0, E-left extend = bit 1)
 						const int sc_cur = Ec(c_cur) + offsetsc, sc_h_left = Hc(c_left) + offsetsc, sc_e_left = Ec(c_left) + offsetsc;
 						mask = (fl(sc_h_left) & (int)(sc_h_left - S.rdgapo == sc_cur)) | ((fl(sc_e_left) & (int)(sc_e_left - S.rdgape == sc_cur)) << 1);
-						orig_mask = mask;
-						if (mk & (1u << 7)) mask = (int)((mk >> 8) & 3);
-						// both -> take the open (cur 3) and leave the extension for later; else the one there is
+						// both -> take the open (cur 3); else the one there is
 						branch = (int)(mask == 3);
-						if (mask != 0) { cur = (mask == 2) ? 4 : 3; mk = (mk & ~(7u << 7)) | (1u << 7) | (branch ? (2u << 8) : 0u); sel = 0; }
+						if (mask != 0) { cur = (mask == 2) ? 4 : 3; sel = 0; }
 					} else if (ct == 2) {   // F: came from above (H-up open = bit 0, F-up extend = bit 1)
 						const int sc_cur = Fc(c_cur) + offsetsc, sc_h_up = Hc(c_up) + offsetsc, sc_f_up = Fc(c_up) + offsetsc;
 						mask = (fl(sc_h_up) & (int)(sc_h_up - S.rfgapo == sc_cur)) | ((fl(sc_f_up) & (int)(sc_f_up - S.rfgape == sc_cur)) << 1);
-						orig_mask = mask;
-						if (mk & (1u << 10)) mask = (int)((mk >> 11) & 3);
 						branch = (int)(mask == 3);
-						if (mask != 0) { cur = (mask == 2) ? 2 : 1; mk = (mk & ~(7u << 10)) | (1u << 10) | (branch ? (2u << 11) : 0u); sel = 0; }
+						if (mask != 0) { cur = (mask == 2) ? 2 : 1; sel = 0; }
 					} else {                // H: bit 0 ref-gap open, 1 read-gap open, 2 ref-gap extend, 3 read-gap extend, 4 diagonal
 						const int sc_cur = Hc(c_cur) + offsetsc;
 						const int sc_f_up = Fc(c_up) + offsetsc, sc_h_up = Hc(c_up) + offsetsc;
@@ -1628,45 +1621,23 @@ struct Aligner {
 						     | ((ga & fl(sc_f_up) & (int)(sc_cur == sc_f_up - S.rfgape)) << 2)
 						     | ((ga & hasl & fl(sc_e_left) & (int)(sc_cur == sc_e_left - S.rdgape)) << 3)
 						     | ((hasl & fl(sc_h_upleft) & (int)(sc_cur == sc_h_upleft + sc_diag)) << 4);
-						orig_mask = mask;
-						if (mk & (1u << 1)) mask = (int)((mk >> 2) & 31);
 						if (mask != 0) {
 							// preference: diagonal, ref-gap open, ref-gap extend, read-gap open, read-gap extend (the only option if there is one)
 							sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
-							branch = (int)((mask & (mask - 1)) != 0);           // more than one option: remember the others
-							mk = (mk & ~(31u << 1)) | (1u << 1) | (branch ? (uint32_t)(mask & ~(1 << sel)) << 2 : 0u);
+							branch = (int)((mask & (mask - 1)) != 0);           // more than one option: the reference pushes a frame
 							cur = (int)((0x04231u >> (4 * sel)) & 7);          // sel 0,1,2,3,4 -> cur 1,3,2,4,0
 						}
 					}
 					}
-					if (sel < 0) { empty = 1; can_move_thru = (int)(orig_mask == 0); }
+					if (sel < 0) empty = 1;      // (canMoveThru = origMask == 0 always holds here: the stored mask equals the computed one, see above)
 				}
-				mk |= 1;                         // setReportedThrough
-				if (mk != mk0) {
-					if (pred) dpl.pmask[pred_at(band_lo, band_w, row, col)] = mk | (epoch << kEpochShift);
-					else dpl.masks[(uint64_t)row * cols + col] = (uint16_t)mk;
+				if (!(mk0 & 1)) {                // setReportedThrough
+					if (pred) Plat::rt_mark(dpl, band_lo, band_w, epoch, row, col);
+					else dpl.masks[(uint64_t)row * cols + col] = (uint16_t)1;
 				}
 				if (!can_move_thru) {
-					if (nstack > 0) {
-						td = tile_len; ndir = 0;     // resume elsewhere: the tile is stale
-						--nstack;
-						if (nstack < 64u) {
-							nned = Plat::lane(sk0, nstack);
-							const uint32_t cz_ = Plat::lane(sk1, nstack), rc_ = Plat::lane(sk2, nstack), g1_ = Plat::lane(sk3, nstack), g2_ = Plat::lane(sk4, nstack);
-							ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31);
-							row = rc_ & 0xffffu; col = rc_ >> 16;
-							gaps = g1_ & 0xffffu; read_gaps = g1_ >> 16; ref_gaps = g2_ & 0xffffu; ct = (int)(g2_ >> 16);
-							score = (int32_t)Plat::lane(sk5, nstack); ns = (int32_t)Plat::lane(sk6, nstack);
-							continue;
-						}
-						const BtFrame& f = btstack[nstack];
-						const uint32_t cz_ = Plat::uni(f.celsz);
-						ncells = cz_ & 0x7fffffffu; olap = (int)(cz_ >> 31); nned = Plat::uni(f.nedsz);
-						row = Plat::uni((uint32_t)f.row); col = Plat::uni((uint32_t)f.col);
-						gaps = Plat::uni((uint32_t)f.gaps); read_gaps = Plat::uni((uint32_t)f.read_gaps); ref_gaps = Plat::uni((uint32_t)f.ref_gaps);
-						score = Plat::uni(f.score); ns = Plat::uni(f.ns); ct = Plat::uni((int)f.ct);
-						continue;
-					}
+					// every frame on the branch stack resumes in a cell this walk has marked: one more loop iteration each, then the walk fails
+					prof.steps += nstack; prof.scalar_steps += nstack;
 					return false;
 				}
 				if (empty || row == 0) {
@@ -1674,20 +1645,7 @@ struct Aligner {
 					trim_beg = row;
 					break;
 				}
-				if (branch) {
-					if (nstack >= (uint32_t)(kMaxLen + kMaxColsWide)) { ovf(18); return false; }
-					if (nstack < 64u) {
-						Plat::set_lane(sk0, nstack, nned); Plat::set_lane(sk1, nstack, ncells | (olap ? 0x80000000u : 0u)); Plat::set_lane(sk2, nstack, (row & 0xffffu) | (col << 16));
-						Plat::set_lane(sk3, nstack, (gaps & 0xffffu) | (read_gaps << 16)); Plat::set_lane(sk4, nstack, (ref_gaps & 0xffffu) | ((uint32_t)ct << 16));
-						Plat::set_lane(sk5, nstack, (uint32_t)score); Plat::set_lane(sk6, nstack, (uint32_t)ns);
-					} else {
-						BtFrame& f = btstack[nstack];
-						f.nedsz = nned; f.celsz = ncells | (olap ? 0x80000000u : 0u); f.row = (uint16_t)row; f.col = (uint16_t)col;
-						f.gaps = (uint16_t)gaps; f.read_gaps = (uint16_t)read_gaps; f.ref_gaps = (uint16_t)ref_gaps;
-						f.score = score; f.ns = ns; f.ct = (uint8_t)ct;
-					}
-					nstack++;
-				}
+				if (branch) nstack++;            // (a frame the reference pushes; only its count matters, see above)
 				if (ncells >= (uint32_t)(kMaxLen + 64)) { ovf(19); return false; }
 				olap |= in_core(row, col); ncells++;
 				if (nned + 1 >= (uint32_t)kMaxEdits) { ovf(20); return false; }
@@ -1807,9 +1765,10 @@ struct Aligner {
 			}
 			if (c.score < ST.minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
 			typename Plat::LaneReg tile, tile_hi;
+			uint32_t tvalid0 = tile_len;
 			{
 				const uint64_t tt_ = now();      // also the first tile of the backtrace
-				if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, c.row, c.col, epoch, 0u, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, c.row, c.col, wide, tile, tile_hi);
+				if (pred) tvalid0 = Plat::uni(Plat::bt_tile_pred(dpl, band_lo, band_w, c.row, c.col, epoch, 0u, rows, tile, tile_hi)); else Plat::bt_tile(dpl, R, cols, c.row, c.col, wide, tile, tile_hi);
 				prof.tiles++; prof.tile_t += now() - tt_;
 			}
 			if ((pred ? Plat::lane(tile_hi, 0) : Plat::lane(tile, 48)) & 1) { HOT.cural++; continue; }
@@ -1825,7 +1784,7 @@ struct Aligner {
 			else {
 				if (need_c0 != rf_c0) { rf_c0 = need_c0; for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64 + (rf_c0 >> 2)); }
 				const uint64_t tw_ = now();
-				ret = walk(c.row, c.col, tile, tile_hi);
+				ret = walk(c.row, c.col, tile, tile_hi, tvalid0);
 				if (PRM.profile) { const uint64_t dt_ = now() - tw_; HOT.t_bt[0] += dt_; if (ret) { HOT.t_bt[1] += dt_; HOT.t_bt[2]++; } }
 			}
 			ST.rnd.init(sse16 ? reseed : reseed + 1);

@@ -10,6 +10,7 @@
 // fetches and diagonal / gap runs of the backtrace; the candidate gather and its radix sort; the row sampler's register table.
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <cstdlib>
 #include <new>
 #include "bt2g_align_core.hpp"
 #include "bt2g_local_pk.hpp"
@@ -29,6 +30,13 @@ extern __shared__ __attribute__((aligned(16))) uint8_t g_tail[];
 __device__ __forceinline__ uint8_t* dev_rf() { return g_tail; }                      // reference masks of the current DP window
 __device__ __forceinline__ int16_t* dev_lastrow() { return reinterpret_cast<int16_t*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.tail_off)); }      // scores of the last DP row, clamped at -32768 (gatherCells)
 __device__ __forceinline__ Edit* dev_ned() { return reinterpret_cast<Edit*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.tail_off)); }                 // edits of the backtrace in progress
+// Behind the tail, when the launch has LDS to spare (launch_align): the reportedThrough plane of the end-to-end band matrix in hand, ONE BIT per cell
+// (bit  row * w + diagonal,  w = the band's row width), and a copy of the predecessor bytes of the matrix's last rows.  The walks that fail --
+// 23 of the 24 backtrace attempts of a read: candidates next to an alignment's end that run a gap of one to a dozen cells back into its path --
+// then touch no memory at all; with the marks in HBM each of them was three to four dependent round trips (start tile, the store of a mark
+// draining before the next tile's load, the gap's tile, the tile of the marked cell).
+__device__ __forceinline__ uint32_t* dev_rt() { return reinterpret_cast<uint32_t*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.rt_off)); }
+__device__ __forceinline__ uint8_t* dev_ptail() { return g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.pt_off); }
 alignas(16) __shared__ unsigned char g_ix_raw[sizeof(DevIndex<uint64_t>) > sizeof(DevIndex<uint32_t>) ? sizeof(DevIndex<uint64_t>) : sizeof(DevIndex<uint32_t>)];
 
 // Memory written by some lanes of the wave and read by others afterwards.  (One workgroup = one wavefront: the compiler knows the largest
@@ -708,20 +716,73 @@ struct DevPlat {
 	// direction `dir`: 0 = up the diagonal (row-d, col-d), 1 = left along the row (row, col-d), 2 = up the column (row-d, col).
 	// One gather per plane: a single memory latency for up to 64 steps of a diagonal run -- or of a gap (the candidates next to an
 	// alignment's end column all walk a gap of growing length back to its path; a tile per gap, not per gap position).
-	static __device__ __forceinline__ void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, uint32_t dir,
-	                                                    uint32_t& pr, uint32_t& mk) {
-		wave_fence();        // mask stores of earlier steps -> visible to whichever lane re-reads them
+	// Returns how many leading cells of the tile hold data: 64, except for a tile served from the on-chip copy of the last rows, which ends
+	// where the copy ends (the walk fetches again from there).  mk = the cell's reportedThrough bit.
+	static __device__ __forceinline__ uint32_t bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, uint32_t dir,
+	                                                        uint32_t, uint32_t& pr, uint32_t& mk) {
+		wave_fence();        // marks of earlier steps -> visible to whichever lane re-reads them
 		const uint32_t d = threadIdx.x & 63;
-		uint32_t p = 0, m = 0;
+		uint32_t p = 0, m = 0, nvalid = 64u;
 		const uint32_t dr = dir == 1 ? 0u : d, dc = dir == 2 ? 0u : d;
 		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo) + dr - dc;      // diagonal of the lane's cell (wraps past the band's edge)
-		if (dr <= row && dc <= col && (band_w == 0u || dd < band_w)) {
+		const bool ok = dr <= row && dc <= col && (band_w == 0u || dd < band_w);
+		if (uni(g_st.rt_cur)) {
+			// marks on chip (band form only: band_w > 0); predecessor bytes from the on-chip copy when the tile starts inside it
+			const uint32_t pt0 = uni(g_st.pt_row0);
+			const bool cached = row >= pt0;
+			if (cached && dir != 1u) { const uint32_t nv = row - pt0 + 1u; nvalid = nv < 64u ? nv : 64u; }
+			if (ok && d < nvalid) {
+				const uint32_t r = row - dr, bit = r * band_w + dd;
+				m = (dev_rt()[bit >> 5] >> (bit & 31u)) & 1u;
+				if (cached) p = dev_ptail()[(r - pt0) * band_w + dd];
+				else p = gld(reinterpret_cast<const uint8_t*>(dp.mat) + (uint64_t)r * band_w + dd);
+			}
+		} else if (ok) {
 			const uint64_t idx = pred_at(band_lo, band_w, row - dr, col - dc);
 			p = gld(reinterpret_cast<const uint8_t*>(dp.mat) + idx);
 			const uint32_t w = gld(dp.pmask + idx);
-			m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
+			m = (w >> kEpochShift) == epoch ? (w & 1u) : 0u;
 		}
 		pr = p; mk = m;
+		return nvalid;
+	}
+	// setReportedThrough of one cell (wave-uniform)
+	static __device__ __forceinline__ void rt_mark(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t row, uint32_t col) {
+		if (uni(g_st.rt_cur)) {
+			const uint32_t bit = row * band_w + (uint32_t)((int32_t)col - (int32_t)row + band_lo);
+			if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(dev_rt() + (bit >> 5), 1u << (bit & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		} else gst(dp.pmask + pred_at(band_lo, band_w, row, col), 1u | (epoch << kEpochShift));
+	}
+	// ... of one cell per lane (the runs)
+	static __device__ __forceinline__ void rt_mark_lane(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t r, uint32_t c) {
+		if (uni(g_st.rt_cur)) {
+			const uint32_t bit = r * band_w + (uint32_t)((int32_t)c - (int32_t)r + band_lo);
+			__hip_atomic_fetch_or(dev_rt() + (bit >> 5), 1u << (bit & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		} else gst(dp.pmask + pred_at(band_lo, band_w, r, c), 1u | (epoch << kEpochShift));
+	}
+	// A band matrix with candidate cells is about to be walked (gather_cells, in place of SSEMatrix::initMasks): decide where its marks live.
+	// On chip when the plane fits what the launch set aside (rows * w bits): cleared here, and the predecessor bytes of the last rows are
+	// copied next to it -- one coalesced read of the lines the fill has just written.  Otherwise the epoch-tagged words in the arena.
+	static __device__ __forceinline__ void rt_begin(const DpScratch& dp, uint32_t rows, bool band) {
+		wave_fence();
+		const uint32_t w = band ? uni(gld(dp.epoch + 2)) : 0u;
+		const uint32_t rt_bytes = uni(g_st.rt_bytes);
+		const bool on = w != 0u && rows * (w >> 3) <= rt_bytes;
+		uint32_t pt0 = 0xffffffffu;
+		if (on) {
+			const uint32_t lane = threadIdx.x & 63;
+			uint4* q = reinterpret_cast<uint4*>(dev_rt());
+			const uint32_t n16 = (rows * (w >> 3) + 15u) >> 4;
+			for (uint32_t i = lane; i < n16; i += 64) q[i] = make_uint4(0, 0, 0, 0);
+			uint32_t k = uni(g_st.pt_bytes) / w;
+			if (k > rows) k = rows;
+			pt0 = rows - k;
+			const BT2_G uint4* src = reinterpret_cast<const BT2_G uint4*>(reinterpret_cast<const BT2_G uint8_t*>(dp.mat) + (uint64_t)pt0 * w);
+			uint4* dst = reinterpret_cast<uint4*>(dev_ptail());
+			for (uint32_t i = lane; i < (k * w) >> 4; i += 64) dst[i] = src[i];
+		}
+		if ((threadIdx.x & 63) == 0) { g_st.rt_cur = on ? 1u : 0u; g_st.pt_row0 = pt0; }
+		wave_fence();
 	}
 	// seed hits of one pre-computed round (both strands) -> HOT.hits, one seed per lane
 	static __device__ __forceinline__ void load_seed_hits(const bt2g_seed_hit* src_fw, const bt2g_seed_hit* src_rc, uint32_t nseeds, bool skip_fw, bool skip_rc) {
@@ -847,7 +908,7 @@ struct DevPlat {
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			edit = m != 1;
 			info = ((uint32_t)readc << 4) | ((uint32_t)refm << 8) | ((uint32_t)readq << 16) | (m == -1 ? 2u : 0u);
-			gst(dp.pmask + pred_at(band_lo, band_w, r, c), 3u | (epoch << kEpochShift));
+			rt_mark_lane(dp, band_lo, band_w, epoch, r, c);
 		}
 		mm = __ballot(edit);
 		return L;
@@ -877,7 +938,7 @@ struct DevPlat {
 			else { e.pos = (uint16_t)r; e.chr = '-'; e.qchr = code2chr(rd_char(g_hot, rdlen, fw, r)); e.type = EDIT_REF_GAP; }
 			e.pad = 0;
 			dev_ned()[nned + k] = e;
-			gst(dp.pmask + pred_at(band_lo, band_w, r, c), (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift));
+			rt_mark_lane(dp, band_lo, band_w, epoch, r, c);
 			const int diagi = (int)c - (int)r + r_triml;
 			incore = diagi >= r_corel && diagi <= r_corer;
 		}
@@ -1094,9 +1155,7 @@ struct DevPlat {
 		uint32_t npass = (tot + 9u) / 10u; if (!(npass & 1u)) npass++;
 		const uint64_t kmask = tot >= 64u ? ~0ull : ((1ull << tot) - 1ull);
 		uint16_t* const cnt = reinterpret_cast<uint16_t*>(dev_lastrow());       // 1024 counters (kMaxCols + 8 >= 1024 int16)
-#ifndef BT2G_PROBE_SMALL      // (occupancy probe builds never run --local)
 		// (hot_tail_bytes keeps at least 2 048 bytes there)
-#endif
 		uint32_t* const cnt32 = reinterpret_cast<uint32_t*>(dev_lastrow());
 		for (uint32_t p = 0; p < npass; p++) {
 			BT2_G BtCand* const src = (p & 1u) ? dst : tmp;
@@ -1280,7 +1339,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre, uint32_t max_read_len, uint32_t max_cols) {
+              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes, uint32_t pt_bytes) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	BT2_G Work& w = *(BT2_G Work*)base;
@@ -1289,6 +1348,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
+	g_st.rt_off = hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.pt_off = g_st.rt_off + rt_bytes; g_st.pt_bytes = pt_bytes; g_st.rt_cur = 0; g_st.pt_row0 = 0xffffffffu;
 	wave_fence();
 	for (;;) {
 		unsigned int r = 0;
@@ -1332,7 +1392,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre, uint32_t max_read_len, uint32_t max_cols) {
+              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes, uint32_t pt_bytes) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	BT2_G Work& w = *(BT2_G Work*)base;
@@ -1341,6 +1401,8 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
+	g_st.rt_off = g_st.pt_off = 0; g_st.rt_bytes = g_st.pt_bytes = 0; g_st.rt_cur = 0; g_st.pt_row0 = 0xffffffffu;      // (two matrices in flight: their marks stay in the arena)
+	(void)rt_bytes; (void)pt_bytes;
 	wave_fence();
 	const unsigned int n_pairs = rd.n_reads / 2;
 	for (;;) {
@@ -1385,17 +1447,34 @@ template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
                         uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
-                        const PreComp& pre, uint32_t max_read_len, uint32_t max_cols, hipStream_t st) {
+                        const PreComp& pre, uint32_t max_read_len, uint32_t max_cols, uint32_t lds_per_wave, hipStream_t st) {
 	if (rd.n_reads == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
 	const uint32_t tail = hot_tail_bytes(max_cols, P.match_bonus > 0);      // dynamic LDS: the per-column tail of the hot state
 	if (P.paired)
 		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), tail, st, ix, P, rd, d_rparams, d_results, result_stride,
-		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols);
-	else
-	hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), tail, st, ix, P, rd, d_rparams, d_results, result_stride,
-	                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols);
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, 0u, 0u);
+	else {
+		// What is left of the wave's share of LDS (lds_per_wave: what keeps this class's waves per CU resident) goes to the on-chip backtrace
+		// state of end-to-end batches: the reportedThrough plane of a band matrix of the longest read at the narrowest band (16 bytes per row --
+		// a wider band's marks stay in the arena, DevPlat::rt_begin decides per matrix), then up to 8 rows of predecessor bytes.
+		uint32_t rt_bytes = 0, pt_bytes = 0;
+		hipFuncAttributes fa;
+		static const bool rt_off = getenv("BT2G_RT_LDS") && atoi(getenv("BT2G_RT_LDS")) == 0;          // measurement knobs: marks in the arena as before /
+		static const int pt_cap = getenv("BT2G_PT_BYTES") ? atoi(getenv("BT2G_PT_BYTES")) : 0;         // bytes of last-row predecessor copy (default none: session r05a, 1 KB of it cost a wave per SIMD)
+		if (!rt_off && P.match_bonus == 0 && lds_per_wave != 0 && hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_align_reads<TOff>)) == hipSuccess) {
+			const uint64_t used = (uint64_t)fa.sharedSizeBytes + tail;
+			const uint32_t want = ((max_read_len ? max_read_len : 1u) * 16u + 15u) & ~15u;
+			if (used + want <= lds_per_wave) {
+				rt_bytes = want;
+				const uint64_t left = lds_per_wave - used - want;
+				pt_bytes = (uint32_t)(left >= (uint64_t)pt_cap ? (uint64_t)pt_cap : left) & ~127u;
+			}
+		}
+		hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), tail + rt_bytes + pt_bytes, st, ix, P, rd, d_rparams, d_results, result_stride,
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, rt_bytes, pt_bytes);
+	}
 	return hipGetLastError();
 }
 
@@ -1409,6 +1488,7 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 	const uint32_t lane = threadIdx.x & 63;
 	g_P = P;
 	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
+	g_st.rt_off = g_st.pt_off = 0; g_st.rt_bytes = g_st.pt_bytes = 0; g_st.rt_cur = 0; g_st.pt_row0 = 0xffffffffu;
 	DpScratch dp;
 	carve_scratch(dp, scratch + (uint64_t)blockIdx.x * scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
 	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch; g_st.emit_on = 0;      // (the fills do not touch the work area)
@@ -1501,8 +1581,8 @@ void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint32
 uint64_t align_work_bytes() { return sizeof(Work); }
 uint32_t align_waves_per_cu() { return 4u * BT2G_WAVES_PER_EU; }
 
-template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, uint32_t, hipStream_t);
-template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, uint32_t, hipStream_t);
+template hipError_t launch_align<uint32_t>(const DevIndex<uint32_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, uint32_t, uint32_t, hipStream_t);
+template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const AlignParams&, const bt2g_reads&, const ReadParams*, uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, unsigned int*, unsigned long long*, const PreComp&, uint32_t, uint32_t, uint32_t, hipStream_t);
 
 } // namespace bt2g
 
@@ -1517,12 +1597,12 @@ template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const Alig
 extern "C" hipError_t bt2g_w5_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams,
                                            uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
                                            uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
-                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, hipStream_t st) {
+                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, uint32_t lds_per_wave, hipStream_t st) {
 	using namespace bt2g;
 	const PreComp& pc = *reinterpret_cast<const PreComp*>(pre);
 	return off_size == 4
-		? launch_align(*reinterpret_cast<const DevIndex<uint32_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, st)
-		: launch_align(*reinterpret_cast<const DevIndex<uint64_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, st);
+		? launch_align(*reinterpret_cast<const DevIndex<uint32_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, lds_per_wave, st)
+		: launch_align(*reinterpret_cast<const DevIndex<uint64_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, lds_per_wave, st);
 }
 extern "C" uint32_t bt2g_w5_waves_per_cu(void) { return bt2g::align_waves_per_cu(); }
 // static LDS of the unpaired worker kernels of this class (the larger of the two index widths); 0xffffffff if the runtime will not say
@@ -1533,5 +1613,8 @@ extern "C" uint32_t bt2g_w5_static_lds(void) {
 	return (uint32_t)(a32.sharedSizeBytes > a64.sharedSizeBytes ? a32.sharedSizeBytes : a64.sharedSizeBytes);
 }
 extern "C" uint64_t bt2g_w5_work_bytes(void) { return bt2g::align_work_bytes(); }
+// what the class holds: longest read, seed positions per strand
+extern "C" uint32_t bt2g_w5_max_len(void) { return (uint32_t)bt2g::kMaxLen; }
+extern "C" uint32_t bt2g_w5_max_offs(void) { return (uint32_t)bt2g::kMaxOffs; }
 #endif
 

@@ -289,10 +289,12 @@ int bt2g_seed_search_exact(bt2g_ctx* c, const bt2g_reads* reads, const uint32_t*
 extern "C" hipError_t bt2g_w5_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams,
                                            uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
                                            uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
-                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, hipStream_t st);
+                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, uint32_t lds_per_wave, hipStream_t st);
 extern "C" uint32_t bt2g_w5_waves_per_cu(void);
 extern "C" uint32_t bt2g_w5_static_lds(void);
 extern "C" uint64_t bt2g_w5_work_bytes(void);
+extern "C" uint32_t bt2g_w5_max_len(void);
+extern "C" uint32_t bt2g_w5_max_offs(void);
 
 static_assert(sizeof(bt2g_mm1_hit) == sizeof(Mm1Hit) && offsetof(bt2g_mm1_hit, score) == offsetof(Mm1Hit, score) && offsetof(bt2g_mm1_hit, epos) == offsetof(Mm1Hit, epos) &&
               offsetof(bt2g_mm1_hit, echr) == offsetof(Mm1Hit, echr) && offsetof(bt2g_mm1_hit, eqchr) == offsetof(Mm1Hit, eqchr), "bt2g_mm1_hit is the kernels' Mm1Hit");
@@ -444,10 +446,28 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	// dp_framer.cpp:81-129): with that little per-column state in dynamic LDS, 20 waves per CU fit, and the worker compiled for 96 registers
 	// (5 waves per SIMD) hides more of the latency its instruction stream is made of.  Local batches (2 KB of radix counters), pairs (wide
 	// opposite-mate windows, a second matrix) and BT2G_NO_W5=1 stay with the 128-register build.
+	// The 96-register build is also the SHORT-READ class: its capacities (longest read, seed positions per strand) are cut so that the LDS this
+	// frees holds the backtrace's on-chip state; a batch goes there only when the class holds all of it, which needs the batch's widest seed table.
+	hipError_t e;
+	if (!S.d_next) {
+		e = hipMalloc((void**)&S.d_next, 1024);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(queue head)");
+		(void)hipMemset(S.d_next, 0, 1024);
+	}
+	unsigned int max_seeds = params->max_seeds > 0 ? (unsigned int)params->max_seeds : 0u;
+	if (max_seeds == 0 && c->precomp) {
+		// no bound from the caller: count on the device and wait for the number (the only host-device round trip of a batch)
+		e = launch_max_seeds(*reads, d_rparams, S.d_next + 8, st);
+		if (e == hipSuccess) e = hipMemcpyAsync(&max_seeds, S.d_next + 8, sizeof(max_seeds), hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		if (e != hipSuccess) return hip_fail(c, e, "k_max_seeds");
+		if (max_seeds < 1) max_seeds = 1;
+	}
 	static const bool no_w5 = getenv("BT2G_NO_W5") != nullptr;
 	static const uint32_t kStaticLdsBytes = bt2g_w5_static_lds();
 	bool w5 = false;
-	if (!no_w5 && !params->paired && params->match_bonus == 0 && params->max_dp_cols <= kMaxCols && sizeof(Work) == bt2g_w5_work_bytes()) {
+	if (!no_w5 && !params->paired && params->match_bonus == 0 && params->max_dp_cols <= kMaxCols && bt2g_w5_work_bytes() <= sizeof(Work) &&
+	    max_read_len <= bt2g_w5_max_len() && max_seeds >= 1 && max_seeds <= bt2g_w5_max_offs()) {
 		const uint32_t need = max_read_len + 4u * (uint32_t)(params->maxhalf > 0 ? params->maxhalf : 0) + 1u + 4u;
 		const uint32_t lds_per_wave = (160u * 1024u) / (4u * 5u);
 		if (need <= (uint32_t)kMaxCols && kStaticLdsBytes < lds_per_wave && kStaticLdsBytes + hot_tail_bytes(need, false) <= lds_per_wave) { w5 = true; max_cols = need; }      // (kStaticLdsBytes is 0xffffffff when the runtime would not say)
@@ -457,7 +477,6 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	uint32_t n_waves = c->n_cu * (w5 ? bt2g_w5_waves_per_cu() : align_waves_per_cu());
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
 	const uint64_t need = arena_stride * n_waves;
-	hipError_t e;
 	if (need > S.arena_bytes) {
 		if (S.d_arena) (void)hipFree(S.d_arena);
 		S.d_arena = nullptr; S.arena_bytes = 0;
@@ -473,11 +492,6 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		if (e != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(worker arena)");
 		S.arena_layout = layout;
 	}
-	if (!S.d_next) {
-		e = hipMalloc((void**)&S.d_next, 1024);
-		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(queue head)");
-		(void)hipMemset(S.d_next, 0, 1024);
-	}
 	// The pure FM phases of every read (exact sweep, 1-mismatch search, seed round 0 and its seed-hit
 	// extension) run first as lane-per-task kernels; the per-read worker then consumes their output.
 	PreComp pre;
@@ -487,14 +501,6 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	auto mark = [&](int i) { (void)hipEventRecord(S.ev[i], st); };
 	mark(0);
 	if (c->precomp) {
-		unsigned int max_seeds = params->max_seeds > 0 ? (unsigned int)params->max_seeds : 0u;
-		if (max_seeds == 0) {
-			// no bound from the caller: count on the device and wait for the number (the only host-device round trip of a batch)
-			e = launch_max_seeds(*reads, d_rparams, S.d_next + 8, st);
-			if (e == hipSuccess) e = hipMemcpyAsync(&max_seeds, S.d_next + 8, sizeof(max_seeds), hipMemcpyDeviceToHost, st);
-			if (e == hipSuccess) e = hipStreamSynchronize(st);
-			if (e != hipSuccess) return hip_fail(c, e, "k_max_seeds");
-		}
 		if (max_seeds < 1) max_seeds = 1;
 		if (max_seeds > 64) max_seeds = 64;       // kMaxOffs: longer seed lists are flagged by the worker
 		const uint32_t cap = 8;
@@ -589,11 +595,11 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	if (w5)
 		e = bt2g_w5_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
-		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, st);
+		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, (160u * 1024u) / bt2g_w5_waves_per_cu(), st);
 	else
 	e = (c->off_size == 4)
-		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, st)
-		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, st);
+		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, (160u * 1024u) / align_waves_per_cu(), st)
+		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, (160u * 1024u) / align_waves_per_cu(), st);
 	if (e != hipSuccess) return hip_fail(c, e, "k_align_reads");
 	mark(6);
 	S.ev_valid = true;
