@@ -45,16 +45,19 @@ struct Aligner {
 
 	// exact_sweep() from the batch kernel's output
 	BT2_HD uint64_t exact_sweep_pre(uint32_t mine[2]) {
-		const bt2g_sweep_out& s = PRE->sweep[ST.ridx];
+		// (what is read from the batch tables is the same in every lane: Plat::uni says so, or the loads' results count as lane-varying and
+		// every decision taken on them becomes vector code under an exec mask)
+		const bt2g_sweep_out& s = PRE->sweep[Plat::uni(ST.ridx)];
 		uint64_t nelt = 0;
 		for (int fwi = 0; fwi < 2; fwi++) {
-			mine[fwi] = s.mine[fwi];
+			mine[fwi] = Plat::uni((uint32_t)s.mine[fwi]);
 			EEHit& h = HOT.exact[fwi];
 			h.top = h.bot = 0;
-			if (s.hit[fwi]) {
-				h.top = s.top[fwi]; h.bot = s.bot[fwi]; h.fw = fwi == 0 ? 1 : 0; h.has_edit = 0;
+			if (Plat::uni((uint32_t)s.hit[fwi])) {
+				const uint64_t top = Plat::uni((uint64_t)s.top[fwi]), bot = Plat::uni((uint64_t)s.bot[fwi]);
+				h.top = top; h.bot = bot; h.fw = fwi == 0 ? 1 : 0; h.has_edit = 0;
 				h.score = (int32_t)((int64_t)HOT.len * PRM.match_bonus);
-				nelt += s.bot[fwi] - s.top[fwi];
+				nelt += bot - top;
 			}
 		}
 		return nelt;
@@ -62,22 +65,26 @@ struct Aligner {
 
 	// one_mm_search() from the batch kernel's output; false if a list overflowed
 	BT2_HD bool one_mm_pre(bool nofw, bool norc) {
-		const uint8_t* n = PRE->mm1_n + (uint64_t)ST.ridx * 4;
+		const uint32_t ridx = Plat::uni(ST.ridx);
+		const uint32_t n4 = Plat::uni(*reinterpret_cast<const uint32_t*>(PRE->mm1_n + (uint64_t)ridx * 4));      // the four list lengths, one load
+		const uint32_t n[4] = {n4 & 0xffu, (n4 >> 8) & 0xffu, (n4 >> 16) & 0xffu, n4 >> 24};
 		if ((!nofw && (n[0] == 255 || n[1] == 255)) || (!norc && (n[2] == 255 || n[3] == 255))) return false;
 		HOT.n_mm1 = 0; HOT.mm1_elt = 0;
+		const int64_t minsc = Plat::uni(ST.minsc);
 		for (int k = 0; k < 4; k++) {
 			const bool fw = k < 2;
 			if ((fw && nofw) || (!fw && norc)) continue;
-			const Mm1Hit* src = PRE->mm1 + ((uint64_t)ST.ridx * 4 + k) * PRE->mm1_cap;
+			const Mm1Hit* src = PRE->mm1 + ((uint64_t)ridx * 4 + k) * PRE->mm1_cap;
 			// the batch kernel searched with the read's original minimum score; the worker's may have been tightened since
-			for (uint32_t i = 0; i < n[k]; i++) if ((int64_t)src[i].score >= ST.minsc) add_mm1(src[i], fw);
+			for (uint32_t i = 0; i < n[k]; i++) if ((int64_t)Plat::uni(src[i].score) >= minsc) add_mm1(src[i], fw);
 		}
 		return true;
 	}
 
 	// seed_round(offset, interval, seedlen) from the batch kernels' output (`src_all`: the [n_reads][2][max_seeds] table of this round)
-	BT2_HD uint32_t seed_round_pre(const bt2g_seed_hit* src_all, uint32_t offset, uint32_t interval, uint32_t seedlen) {
-		const uint32_t len = HOT.len;
+	BT2_HD uint32_t seed_round_pre(const bt2g_seed_hit* src_all, uint32_t offset_, uint32_t interval_, uint32_t seedlen_) {
+		const uint32_t offset = Plat::uni(offset_), interval = Plat::uni(interval_), seedlen = Plat::uni(seedlen_);
+		const uint32_t len = Plat::uni(HOT.len);
 		uint32_t nseeds = 1;
 		if ((int64_t)len - (int64_t)offset > (int64_t)seedlen) nseeds += (len - offset - seedlen) / interval;
 		if (nseeds > (uint32_t)kMaxOffs) { ovf(1); nseeds = kMaxOffs; }
@@ -317,8 +324,9 @@ struct Aligner {
 	}
 
 	BT2_HD void add_mm1(const Mm1Hit& m, bool fw) {
-		if (HOT.n_mm1 >= (uint32_t)kMaxMm1) { ovf(2); return; }
-		BT2_G EEHit& h = WK.mm1[HOT.n_mm1++];
+		const uint32_t nm = Plat::uni(HOT.n_mm1);
+		if (nm >= (uint32_t)kMaxMm1) { ovf(2); return; }
+		BT2_G EEHit& h = WK.mm1[nm]; HOT.n_mm1 = nm + 1;
 		h.top = m.top; h.bot = m.bot; h.score = m.score;
 		h.epos = m.epos; h.echr = m.echr; h.eqchr = m.eqchr;
 		h.fw = fw ? 1 : 0; h.has_edit = 1;
@@ -1472,7 +1480,7 @@ struct Aligner {
 		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
 		// the walk moves left from its start column by at most rows + gaps columns: three registers (768 columns) cover every window of an
 		// unpaired read from column 0 (rf_c0 = 0); only a candidate past column 767 of a wide opposite-mate window needs them re-based
-		uint32_t rf_c0 = 0;
+		uint32_t rf_c0_ = 0;
 		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64);
 		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
 			const uint32_t word = idx >> 2;
@@ -1482,10 +1490,10 @@ struct Aligner {
 			return (int)((v >> ((idx & 3) * 8)) & 0xff);
 		};
 		// one backtrace from cell (row, col), whose tile the caller fetched
-		auto walk = [&](uint32_t row, uint32_t col, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi, uint32_t tvalid_) __attribute__((always_inline)) -> bool {
+		auto walk = [&](uint32_t row, uint32_t col, typename Plat::LaneReg tile, typename Plat::LaneReg tile_hi) __attribute__((always_inline)) -> bool {
 			row = Plat::uni(row); col = Plat::uni(col);
+			const uint32_t rf_c0 = Plat::uni(rf_c0_);
 			uint32_t td = 0;     // td = steps taken along the tile
-			uint32_t tvalid = Plat::uni(tvalid_);      // cells of the tile in hand that hold data (a tile served from the on-chip copy of the last rows ends where that copy ends)
 			uint32_t tdir = 0, ndir = 0;      // pred format: direction of the tile in hand / of the next fetch (0 diagonal, 1 left along the row, 2 up the column)
 			const uint32_t rdlen = rows;   // end-to-end: one DP row per read character
 			int olap = 0;        // the path touches a core diagonal of the untrimmed rectangle (:1764-1795)
@@ -1504,14 +1512,19 @@ struct Aligner {
 			const int offsetsc = local ? 0 : (wide ? -0x7fff : -0xff);
 			HOT.n_bt_attempts++;
 			while ((int)row >= 0) {
-				if (pred && ct != 0 && tdir == (uint32_t)ct && td < tvalid && row > 0) {
+				// (the loop's own state is wave-uniform; said once per iteration, so that nothing lane-varying that feeds one of these variables on
+				// some path can turn the whole loop into vector code under exec masks)
+				row = Plat::uni(row); col = Plat::uni(col); td = Plat::uni(td); tdir = Plat::uni(tdir); ndir = Plat::uni(ndir);
+				ct = Plat::uni(ct); nned = Plat::uni(nned); ncells = Plat::uni(ncells); nstack = Plat::uni(nstack); score = Plat::uni(score); ns = Plat::uni(ns);
+				gaps = Plat::uni(gaps); olap = Plat::uni(olap);
+				if (pred && ct != 0 && tdir == (uint32_t)ct && td < tile_len && row > 0) {
 					// inside a gap: the cells that can only EXTEND it (unvisited, E consistent with E-left alone / F with F-up alone) are walked
 					// by all lanes at once -- same marks, same edits, same counters as the step-by-step loop below.  (The candidates next to an
 					// alignment's end column each walk a gap of growing length back to its path; the cell that opens the gap and whatever
 					// follows go through the scalar step.)
 					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
 					const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
-					uint32_t room = room_c < room_e ? room_c : room_e; if (room > tvalid - td) room = tvalid - td;
+					const uint32_t room = room_c < room_e ? room_c : room_e;
 					uint32_t core = 0;
 					const uint32_t L = Plat::uni(Plat::bt_gap_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, ct == 1, fw, rdlen, room,
 					                                              nned, r_triml, r_corel, r_corer, core));
@@ -1522,12 +1535,12 @@ struct Aligner {
 						continue;
 					}
 				}
-				if (pred && ct == 0 && tdir == 0 && td < tvalid && row > 0) {
+				if (pred && ct == 0 && tdir == 0 && td < tile_len && row > 0) {
 					// a run of plain diagonal steps (unvisited cells whose only consistent predecessor is the diagonal one) is walked
 					// by all lanes at once: same marks, same edits, same counters as the step-by-step loop below
 					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
 					const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
-					uint32_t room = room_c < room_e ? room_c : room_e; if (room > tvalid - td) room = tvalid - td;
+					const uint32_t room = room_c < room_e ? room_c : room_e;
 					typename Plat::LaneReg inf;
 					uint64_t mm;
 					const uint32_t L = Plat::uni(Plat::bt_diag_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, fw, rdlen, room, inf, mm));
@@ -1556,10 +1569,10 @@ struct Aligner {
 				int empty = 0, can_move_thru = 1, branch = 0;
 				int cur = 0;   // 0 diag, 1 ref-open (H up), 2 rfgap-extend (F up), 3 read-open (H left), 4 rdgap-extend (E left)
 				prof.steps++; prof.scalar_steps++;
-				if (td >= tvalid) {
+				if (td >= tile_len) {
 					const uint64_t tt_ = now();
-					if (pred) { tvalid = Plat::uni(Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, ndir, rows, tile, tile_hi)); tdir = ndir; }
-					else { Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi); tvalid = tile_len; }
+					if (pred) { Plat::bt_tile_pred(dpl, band_lo, band_w, row, col, epoch, ndir, tile, tile_hi); tdir = ndir; }
+					else Plat::bt_tile(dpl, R, cols, row, col, wide, tile, tile_hi);
 					td = 0; prof.tiles++; prof.tile_t += now() - tt_;
 				}
 				const uint32_t mk0 = pred ? Plat::lane(tile_hi, td) : (Plat::lane(tile, 48 + td) & 0xffffu);
@@ -1765,10 +1778,9 @@ struct Aligner {
 			}
 			if (c.score < ST.minsc) { HOT.cural = HOT.n_cands; break; }    // sorted by score: every later candidate is filtered too (no RNG draw involved)
 			typename Plat::LaneReg tile, tile_hi;
-			uint32_t tvalid0 = tile_len;
 			{
 				const uint64_t tt_ = now();      // also the first tile of the backtrace
-				if (pred) tvalid0 = Plat::uni(Plat::bt_tile_pred(dpl, band_lo, band_w, c.row, c.col, epoch, 0u, rows, tile, tile_hi)); else Plat::bt_tile(dpl, R, cols, c.row, c.col, wide, tile, tile_hi);
+				if (pred) Plat::bt_tile_pred(dpl, band_lo, band_w, c.row, c.col, epoch, 0u, tile, tile_hi); else Plat::bt_tile(dpl, R, cols, c.row, c.col, wide, tile, tile_hi);
 				prof.tiles++; prof.tile_t += now() - tt_;
 			}
 			if ((pred ? Plat::lane(tile_hi, 0) : Plat::lane(tile, 48)) & 1) { HOT.cural++; continue; }
@@ -1779,12 +1791,12 @@ struct Aligner {
 			res.nned = 0;
 			const int32_t cscore = c.score;
 			bool ret;
-			const uint32_t need_c0 = (c.col + 1u > 768u) ? (((uint32_t)c.col + 1u - 768u + 3u) & ~3u) : 0u;
+			const uint32_t need_c0 = Plat::uni((c.col + 1u > 768u) ? (((uint32_t)c.col + 1u - 768u + 3u) & ~3u) : 0u);
 			if (need_c0 > 0 && rows + 250u > 764u) { ovf(17); ret = false; }   // the walk could leave the 768-column window (rows + read gaps)
 			else {
-				if (need_c0 != rf_c0) { rf_c0 = need_c0; for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64 + (rf_c0 >> 2)); }
+				if (need_c0 != rf_c0_) { rf_c0_ = need_c0; for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64 + (need_c0 >> 2)); }
 				const uint64_t tw_ = now();
-				ret = walk(c.row, c.col, tile, tile_hi, tvalid0);
+				ret = walk(c.row, c.col, tile, tile_hi);
 				if (PRM.profile) { const uint64_t dt_ = now() - tw_; HOT.t_bt[0] += dt_; if (ret) { HOT.t_bt[1] += dt_; HOT.t_bt[2]++; } }
 			}
 			ST.rnd.init(sse16 ? reseed : reseed + 1);

@@ -10,6 +10,7 @@
 // fetches and diagonal / gap runs of the backtrace; the candidate gather and its radix sort; the row sampler's register table.
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 #include "bt2g_align_core.hpp"
@@ -31,12 +32,10 @@ __device__ __forceinline__ uint8_t* dev_rf() { return g_tail; }                 
 __device__ __forceinline__ int16_t* dev_lastrow() { return reinterpret_cast<int16_t*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.tail_off)); }      // scores of the last DP row, clamped at -32768 (gatherCells)
 __device__ __forceinline__ Edit* dev_ned() { return reinterpret_cast<Edit*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.tail_off)); }                 // edits of the backtrace in progress
 // Behind the tail, when the launch has LDS to spare (launch_align): the reportedThrough plane of the end-to-end band matrix in hand, ONE BIT per cell
-// (bit  row * w + diagonal,  w = the band's row width), and a copy of the predecessor bytes of the matrix's last rows.  The walks that fail --
-// 23 of the 24 backtrace attempts of a read: candidates next to an alignment's end that run a gap of one to a dozen cells back into its path --
-// then touch no memory at all; with the marks in HBM each of them was three to four dependent round trips (start tile, the store of a mark
-// draining before the next tile's load, the gap's tile, the tile of the marked cell).
+// (bit  row * w + diagonal,  w = the band's row width): the walks mark and test cells without a store to drain or a word to fetch.
+// (Session r05c also kept the predecessor bytes of the matrix's last rows there, for the 23 of 24 backtrace attempts per read that fail within
+// a few cells of the last row: 351 -> 379 ms per 2 M reads at the same occupancy -- those walks are not waiting for memory.  Dropped.)
 __device__ __forceinline__ uint32_t* dev_rt() { return reinterpret_cast<uint32_t*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.rt_off)); }
-__device__ __forceinline__ uint8_t* dev_ptail() { return g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.pt_off); }
 alignas(16) __shared__ unsigned char g_ix_raw[sizeof(DevIndex<uint64_t>) > sizeof(DevIndex<uint32_t>) ? sizeof(DevIndex<uint64_t>) : sizeof(DevIndex<uint32_t>)];
 
 // Memory written by some lanes of the wave and read by others afterwards.  (One workgroup = one wavefront: the compiler knows the largest
@@ -716,26 +715,21 @@ struct DevPlat {
 	// direction `dir`: 0 = up the diagonal (row-d, col-d), 1 = left along the row (row, col-d), 2 = up the column (row-d, col).
 	// One gather per plane: a single memory latency for up to 64 steps of a diagonal run -- or of a gap (the candidates next to an
 	// alignment's end column all walk a gap of growing length back to its path; a tile per gap, not per gap position).
-	// Returns how many leading cells of the tile hold data: 64, except for a tile served from the on-chip copy of the last rows, which ends
-	// where the copy ends (the walk fetches again from there).  mk = the cell's reportedThrough bit.
-	static __device__ __forceinline__ uint32_t bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, uint32_t dir,
-	                                                        uint32_t, uint32_t& pr, uint32_t& mk) {
+	// mk = the cell's reportedThrough bit.
+	static __device__ __forceinline__ void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, uint32_t dir,
+	                                                    uint32_t& pr, uint32_t& mk) {
 		wave_fence();        // marks of earlier steps -> visible to whichever lane re-reads them
 		const uint32_t d = threadIdx.x & 63;
-		uint32_t p = 0, m = 0, nvalid = 64u;
+		uint32_t p = 0, m = 0;
 		const uint32_t dr = dir == 1 ? 0u : d, dc = dir == 2 ? 0u : d;
 		const uint32_t dd = (uint32_t)((int32_t)col - (int32_t)row + band_lo) + dr - dc;      // diagonal of the lane's cell (wraps past the band's edge)
 		const bool ok = dr <= row && dc <= col && (band_w == 0u || dd < band_w);
 		if (uni(g_st.rt_cur)) {
-			// marks on chip (band form only: band_w > 0); predecessor bytes from the on-chip copy when the tile starts inside it
-			const uint32_t pt0 = uni(g_st.pt_row0);
-			const bool cached = row >= pt0;
-			if (cached && dir != 1u) { const uint32_t nv = row - pt0 + 1u; nvalid = nv < 64u ? nv : 64u; }
-			if (ok && d < nvalid) {
+			// marks on chip (band form only: band_w > 0)
+			if (ok) {
 				const uint32_t r = row - dr, bit = r * band_w + dd;
+				p = gld(reinterpret_cast<const uint8_t*>(dp.mat) + (uint64_t)r * band_w + dd);
 				m = (dev_rt()[bit >> 5] >> (bit & 31u)) & 1u;
-				if (cached) p = dev_ptail()[(r - pt0) * band_w + dd];
-				else p = gld(reinterpret_cast<const uint8_t*>(dp.mat) + (uint64_t)r * band_w + dd);
 			}
 		} else if (ok) {
 			const uint64_t idx = pred_at(band_lo, band_w, row - dr, col - dc);
@@ -744,7 +738,6 @@ struct DevPlat {
 			m = (w >> kEpochShift) == epoch ? (w & 1u) : 0u;
 		}
 		pr = p; mk = m;
-		return nvalid;
 	}
 	// setReportedThrough of one cell (wave-uniform)
 	static __device__ __forceinline__ void rt_mark(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t row, uint32_t col) {
@@ -761,27 +754,18 @@ struct DevPlat {
 		} else gst(dp.pmask + pred_at(band_lo, band_w, r, c), 1u | (epoch << kEpochShift));
 	}
 	// A band matrix with candidate cells is about to be walked (gather_cells, in place of SSEMatrix::initMasks): decide where its marks live.
-	// On chip when the plane fits what the launch set aside (rows * w bits): cleared here, and the predecessor bytes of the last rows are
-	// copied next to it -- one coalesced read of the lines the fill has just written.  Otherwise the epoch-tagged words in the arena.
+	// On chip when the plane fits what the launch set aside (rows * w bits): cleared here.  Otherwise the epoch-tagged words in the arena.
 	static __device__ __forceinline__ void rt_begin(const DpScratch& dp, uint32_t rows, bool band) {
 		wave_fence();
 		const uint32_t w = band ? uni(gld(dp.epoch + 2)) : 0u;
 		const uint32_t rt_bytes = uni(g_st.rt_bytes);
 		const bool on = w != 0u && rows * (w >> 3) <= rt_bytes;
-		uint32_t pt0 = 0xffffffffu;
 		if (on) {
-			const uint32_t lane = threadIdx.x & 63;
 			uint4* q = reinterpret_cast<uint4*>(dev_rt());
 			const uint32_t n16 = (rows * (w >> 3) + 15u) >> 4;
-			for (uint32_t i = lane; i < n16; i += 64) q[i] = make_uint4(0, 0, 0, 0);
-			uint32_t k = uni(g_st.pt_bytes) / w;
-			if (k > rows) k = rows;
-			pt0 = rows - k;
-			const BT2_G uint4* src = reinterpret_cast<const BT2_G uint4*>(reinterpret_cast<const BT2_G uint8_t*>(dp.mat) + (uint64_t)pt0 * w);
-			uint4* dst = reinterpret_cast<uint4*>(dev_ptail());
-			for (uint32_t i = lane; i < (k * w) >> 4; i += 64) dst[i] = src[i];
+			for (uint32_t i = threadIdx.x & 63; i < n16; i += 64) q[i] = make_uint4(0, 0, 0, 0);
 		}
-		if ((threadIdx.x & 63) == 0) { g_st.rt_cur = on ? 1u : 0u; g_st.pt_row0 = pt0; }
+		if ((threadIdx.x & 63) == 0) g_st.rt_cur = on ? 1u : 0u;
 		wave_fence();
 	}
 	// seed hits of one pre-computed round (both strands) -> HOT.hits, one seed per lane
@@ -1339,7 +1323,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes, uint32_t pt_bytes) {
+              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	BT2_G Work& w = *(BT2_G Work*)base;
@@ -1348,7 +1332,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
-	g_st.rt_off = hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.pt_off = g_st.rt_off + rt_bytes; g_st.pt_bytes = pt_bytes; g_st.rt_cur = 0; g_st.pt_row0 = 0xffffffffu;
+	g_st.rt_off = hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.rt_cur = 0;
 	wave_fence();
 	for (;;) {
 		unsigned int r = 0;
@@ -1392,7 +1376,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes, uint32_t pt_bytes) {
+              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	BT2_G Work& w = *(BT2_G Work*)base;
@@ -1401,8 +1385,8 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
-	g_st.rt_off = g_st.pt_off = 0; g_st.rt_bytes = g_st.pt_bytes = 0; g_st.rt_cur = 0; g_st.pt_row0 = 0xffffffffu;      // (two matrices in flight: their marks stay in the arena)
-	(void)rt_bytes; (void)pt_bytes;
+	g_st.rt_off = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;      // (two matrices in flight: their marks stay in the arena)
+	(void)rt_bytes;
 	wave_fence();
 	const unsigned int n_pairs = rd.n_reads / 2;
 	for (;;) {
@@ -1454,26 +1438,28 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 	const uint32_t tail = hot_tail_bytes(max_cols, P.match_bonus > 0);      // dynamic LDS: the per-column tail of the hot state
 	if (P.paired)
 		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), tail, st, ix, P, rd, d_rparams, d_results, result_stride,
-		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, 0u, 0u);
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, 0u);
 	else {
 		// What is left of the wave's share of LDS (lds_per_wave: what keeps this class's waves per CU resident) goes to the on-chip backtrace
 		// state of end-to-end batches: the reportedThrough plane of a band matrix of the longest read at the narrowest band (16 bytes per row --
-		// a wider band's marks stay in the arena, DevPlat::rt_begin decides per matrix), then up to 8 rows of predecessor bytes.
-		uint32_t rt_bytes = 0, pt_bytes = 0;
-		hipFuncAttributes fa;
-		static const bool rt_off = getenv("BT2G_RT_LDS") && atoi(getenv("BT2G_RT_LDS")) == 0;          // measurement knobs: marks in the arena as before /
-		static const int pt_cap = getenv("BT2G_PT_BYTES") ? atoi(getenv("BT2G_PT_BYTES")) : 0;         // bytes of last-row predecessor copy (default none: session r05a, 1 KB of it cost a wave per SIMD)
+		// a wider band's marks stay in the arena, DevPlat::rt_begin decides per matrix).
+		uint32_t rt_bytes = 0;
+		hipFuncAttributes fa{};
+		static const bool rt_off = getenv("BT2G_RT_LDS") && atoi(getenv("BT2G_RT_LDS")) == 0;          // measurement knob: marks in the arena, as before round 5
 		if (!rt_off && P.match_bonus == 0 && lds_per_wave != 0 && hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_align_reads<TOff>)) == hipSuccess) {
 			const uint64_t used = (uint64_t)fa.sharedSizeBytes + tail;
 			const uint32_t want = ((max_read_len ? max_read_len : 1u) * 16u + 15u) & ~15u;
-			if (used + want <= lds_per_wave) {
-				rt_bytes = want;
-				const uint64_t left = lds_per_wave - used - want;
-				pt_bytes = (uint32_t)(left >= (uint64_t)pt_cap ? (uint64_t)pt_cap : left) & ~127u;
-			}
+			if (used + want <= lds_per_wave) rt_bytes = want;
 		}
-		hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), tail + rt_bytes + pt_bytes, st, ix, P, rd, d_rparams, d_results, result_stride,
-		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, rt_bytes, pt_bytes);
+		static const bool dbg_occ = getenv("BT2G_DEBUG_OCC") != nullptr;
+		if (dbg_occ) {
+			int nb = 0;
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_align_reads<TOff>), 64, tail + rt_bytes);
+			fprintf(stderr, "[bt2g] k_align_reads: %d waves per CU resident (LDS %u static + %u tail + %u marks; budget %u per wave), %u waves launched\n",
+			        nb, (unsigned)fa.sharedSizeBytes, tail, rt_bytes, lds_per_wave, n_waves);
+		}
+		hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), tail + rt_bytes, st, ix, P, rd, d_rparams, d_results, result_stride,
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, rt_bytes);
 	}
 	return hipGetLastError();
 }
@@ -1488,7 +1474,7 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 	const uint32_t lane = threadIdx.x & 63;
 	g_P = P;
 	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
-	g_st.rt_off = g_st.pt_off = 0; g_st.rt_bytes = g_st.pt_bytes = 0; g_st.rt_cur = 0; g_st.pt_row0 = 0xffffffffu;
+	g_st.rt_off = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;
 	DpScratch dp;
 	carve_scratch(dp, scratch + (uint64_t)blockIdx.x * scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
 	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch; g_st.emit_on = 0;      // (the fills do not touch the work area)

@@ -295,7 +295,7 @@ struct HostPlat {
 			const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 			if (m != 1) mm |= 1ull << (td + k);
 			info.v[td + k] = ((uint32_t)readc << 4) | ((uint32_t)refm << 8) | ((uint32_t)readq << 16) | (m == -1 ? 2u : 0u);
-			dp.pmask[pred_at(band_lo, band_w, r, c)] = 3u | (epoch << kEpochShift);
+			dp.pmask[pred_at(band_lo, band_w, r, c)] = 1u | (epoch << kEpochShift);
 		}
 		return L;
 	}
@@ -317,12 +317,14 @@ struct HostPlat {
 			else { e.pos = (uint16_t)r; e.chr = '-'; e.qchr = code2chr(rd_char(g_hot, rdlen, fw, r)); e.type = EDIT_REF_GAP; }
 			e.pad = 0;
 			host_ned[nned + k] = e;
-			dp.pmask[pred_at(band_lo, band_w, r, c)] = (read_gap ? 0x81u : 0x401u) | (epoch << kEpochShift);
+			dp.pmask[pred_at(band_lo, band_w, r, c)] = 1u | (epoch << kEpochShift);
 			const int diagi = (int)c - (int)r + r_triml;
 			if (diagi >= r_corel && diagi <= r_corer) core = 1;
 		}
 		return L;
 	}
+	static void rt_begin(const DpScratch&, uint32_t, bool) {}
+	static void rt_mark(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t row, uint32_t col) { dp.pmask[pred_at(band_lo, band_w, row, col)] = 1u | (epoch << kEpochShift); }
 	static void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, uint32_t dir, LaneReg& pr, LaneReg& mk) {
 		for (uint32_t d = 0; d < 64; d++) {
 			uint32_t p = 0, m = 0;
@@ -332,7 +334,7 @@ struct HostPlat {
 				const uint64_t idx = pred_at(band_lo, band_w, row - dr, col - dc);
 				p = reinterpret_cast<const uint8_t*>(dp.mat)[idx];
 				const uint32_t w = dp.pmask[idx];
-				m = (w >> kEpochShift) == epoch ? (w & ((1u << kEpochShift) - 1)) : 0u;
+				m = (w >> kEpochShift) == epoch ? (w & 1u) : 0u;
 			}
 			pr.v[d] = p; mk.v[d] = m;
 		}
