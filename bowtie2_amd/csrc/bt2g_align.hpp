@@ -410,10 +410,10 @@ struct AlState {
 	int32_t   emit_vmax;              //   ... and the largest score among them
 	uint32_t  emit_on;                // 1 in the workers (Aligner's constructor); 0 in the stage kernel, whose waves have no work area
 	uint32_t  max_cols;               // DP columns this launch holds (kMaxCols .. kMaxColsWide): wider windows flag the read
-	uint32_t  tail_off;               // device: where ned / lastrow start in the launch's dynamic LDS (behind rf)
+	uint32_t  rf_at, ned_at;          // device: LDS addresses of rf and of ned / lastrow in the launch's dynamic LDS (set by the kernel, which knows where that starts)
 	// device: the reportedThrough plane of the band matrix in hand, in the launch's dynamic LDS when it has room (DevPlat::rt_begin):
-	// offset into the tail, capacity in bytes, "this matrix's marks are on chip"
-	uint32_t  rt_off, rt_bytes, rt_cur;
+	// LDS address, capacity in bytes, "this matrix's marks are on chip"
+	uint32_t  rt_at, rt_bytes, rt_cur;
 	uint32_t  fill_rows_done, fill_lastsol, fill_sat8;   // device: what a leaf fill hands back besides its return value (row the score-only pass stopped in; lastsolcol_ / "8-bit kernel saturated" of a local fill)
 };
 

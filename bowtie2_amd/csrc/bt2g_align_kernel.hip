@@ -28,14 +28,20 @@ __shared__ PreComp g_pre;
 __shared__ AlState g_st;     // the worker's own state (Aligner has no data members)
 // The per-column tail of the hot state (hot_tail_bytes, bt2g_align.hpp): dynamic LDS, sized by the launch from the widest DP window it must hold.
 extern __shared__ __attribute__((aligned(16))) uint8_t g_tail[];
-__device__ __forceinline__ uint8_t* dev_rf() { return g_tail; }                      // reference masks of the current DP window
-__device__ __forceinline__ int16_t* dev_lastrow() { return reinterpret_cast<int16_t*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.tail_off)); }      // scores of the last DP row, clamped at -32768 (gatherCells)
-__device__ __forceinline__ Edit* dev_ned() { return reinterpret_cast<Edit*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.tail_off)); }                 // edits of the backtrace in progress
+// Where the dynamic part starts depends on the kernel (its static LDS), so a function that is really called finds `g_tail` through a table in
+// memory (llvm.amdgcn.dynlds.offset.table): a vector-memory load -- and a wait on the vector-memory counter, which also waits for every store
+// in flight -- at each use.  The kernels, which know the address, leave the LDS addresses of the tail's parts in g_st (static LDS) instead.
+typedef __attribute__((address_space(3))) uint8_t lds_byte;
+__device__ __forceinline__ uint32_t lds_addr_of_tail() { return (uint32_t)reinterpret_cast<uintptr_t>((lds_byte*)g_tail); }
+__device__ __forceinline__ uint8_t* lds_at(uint32_t a) { return (uint8_t*)reinterpret_cast<lds_byte*>((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a)); }
+__device__ __forceinline__ uint8_t* dev_rf() { return lds_at(g_st.rf_at); }                      // reference masks of the current DP window
+__device__ __forceinline__ int16_t* dev_lastrow() { return reinterpret_cast<int16_t*>(lds_at(g_st.ned_at)); }      // scores of the last DP row, clamped at -32768 (gatherCells)
+__device__ __forceinline__ Edit* dev_ned() { return reinterpret_cast<Edit*>(lds_at(g_st.ned_at)); }                 // edits of the backtrace in progress
 // Behind the tail, when the launch has LDS to spare (launch_align): the reportedThrough plane of the end-to-end band matrix in hand, ONE BIT per cell
 // (bit  row * w + diagonal,  w = the band's row width): the walks mark and test cells without a store to drain or a word to fetch.
 // (Session r05c also kept the predecessor bytes of the matrix's last rows there, for the 23 of 24 backtrace attempts per read that fail within
 // a few cells of the last row: 351 -> 379 ms per 2 M reads at the same occupancy -- those walks are not waiting for memory.  Dropped.)
-__device__ __forceinline__ uint32_t* dev_rt() { return reinterpret_cast<uint32_t*>(g_tail + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_st.rt_off)); }
+__device__ __forceinline__ uint32_t* dev_rt() { return reinterpret_cast<uint32_t*>(lds_at(g_st.rt_at)); }
 alignas(16) __shared__ unsigned char g_ix_raw[sizeof(DevIndex<uint64_t>) > sizeof(DevIndex<uint32_t>) ? sizeof(DevIndex<uint64_t>) : sizeof(DevIndex<uint32_t>)];
 
 // Memory written by some lanes of the wave and read by others afterwards.  (One workgroup = one wavefront: the compiler knows the largest
@@ -1331,8 +1337,8 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes);
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
-	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
-	g_st.rt_off = hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.rt_cur = 0;
+	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
+	g_st.rt_at = g_st.rf_at + hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.rt_cur = 0;
 	wave_fence();
 	for (;;) {
 		unsigned int r = 0;
@@ -1384,8 +1390,8 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	carve_scratch(dp2, carve_scratch(dp, base + ((sizeof(Work) + 255) & ~(uint64_t)255), mat_bytes, mask_bytes, pmask_bytes), mat_bytes, mask_bytes, pmask_bytes);
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
-	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
-	g_st.rt_off = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;      // (two matrices in flight: their marks stay in the arena)
+	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
+	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;      // (two matrices in flight: their marks stay in the arena)
 	(void)rt_bytes;
 	wave_fence();
 	const unsigned int n_pairs = rd.n_reads / 2;
@@ -1473,8 +1479,8 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
           uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t max_cols) {
 	const uint32_t lane = threadIdx.x & 63;
 	g_P = P;
-	g_st.max_cols = max_cols; g_st.tail_off = hot_tail_off(max_cols);
-	g_st.rt_off = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;
+	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
+	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;
 	DpScratch dp;
 	carve_scratch(dp, scratch + (uint64_t)blockIdx.x * scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
 	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch; g_st.emit_on = 0;      // (the fills do not touch the work area)
