@@ -270,7 +270,7 @@ def gen_rand_seeds(seq, qual, names_t):
     return (acc & 0xffffffff)
 
 
-def write_fastq_fixed(path, seq, qual, names):
+def write_fastq_fixed(path, seq, qual, names, append=False):
     """FASTQ of equal-length reads, assembled as one 2-D byte array."""
     import numpy as np
     s = np.frombuffer(b"ACGT", dtype=np.uint8)[seq.cpu().numpy()]
@@ -283,7 +283,7 @@ def write_fastq_fixed(path, seq, qual, names):
     rec[:, o:o + L] = s; rec[:, o + L] = 10; rec[:, o + L + 1] = ord("+"); rec[:, o + L + 2] = 10
     o2 = o + L + 3
     rec[:, o2:o2 + L] = q; rec[:, o2 + L] = 10
-    with open(path, "wb") as f:
+    with open(path, "ab" if append else "wb") as f:
         f.write(rec.tobytes())
 
 
@@ -320,7 +320,94 @@ def sam_body(path):
         return [l for l in f if not l.startswith(b"@PG")]
 
 
-def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, threads, preset, work, readlen=150, parity_only=False):
+def write_e2e_fastq(G, seq, qual, names, n, args, dev, rank):
+    """FASTQ input of the end-to-end leg: the timed batch (whose first reads are the ones compared with the reference) followed by further batches of
+    distinct reads from the same generator, other seeds, names numbered on.  Returns the path (a pair of paths for pairs) and the read count."""
+    import shutil
+    from bowtie2_amd import shard
+    work = cache_dir()
+    per = 2 * args.readlen + 16
+    total = max(n, (args.e2e_reads // n) * n)
+    free = shutil.disk_usage(work).free
+    while total > n and total * per * 1.1 > free * 0.9:      # the input has to fit (the SAM goes to /dev/null when only the input fits)
+        total -= n
+    paths = (os.path.join(work, "e2e_1.fq"), os.path.join(work, "e2e_2.fq")) if args.paired else (os.path.join(work, "e2e.fq"),)
+    for p in paths:
+        if os.path.exists(p):
+            os.remove(p)
+    t0 = time.time()
+    done = 0
+    k = 0
+    while done < total:
+        if k == 0:
+            sq, ql, nm = seq, qual, names
+        elif args.paired:
+            sq, ql = synth_pairs_gpu(G, n // 2, args.readlen, shard.shard_seed(7000 + k, rank), dev)
+            nm = read_names(done, n)
+        else:
+            sq, ql = synth_reads_gpu(G, n, args.readlen, shard.shard_seed(7000 + k, rank), dev)
+            nm = read_names(done, n)
+        if args.paired:
+            # mates interleaved in a batch (named as the timed batch's FASTQ names them)
+            for m in (0, 1):
+                write_fastq_fixed(paths[m], sq[m::2], ql[m::2], nm[m::2], append=True)
+        else:
+            write_fastq_fixed(paths[0], sq, ql, nm, append=True)
+        done += n
+        k += 1
+    log("[bench] e2e input: %d distinct reads written as FASTQ in %.1fs" % (done, time.time() - t0))
+    return {"paths": paths, "reads": done, "batches": k, "first_batch_is_timed_batch": True}
+
+
+def e2e_leg(base, large, fq, preset, threads, resident_rate, work, par):
+    """The drop-in binary, its own process, FASTQ file -> SAM file on the e2e input; -t prints the index load, the wall time of the search after it
+    and the rate.  The SAM records of the reads that were compared with the reference (the head of the file) are compared with the reference's again."""
+    import shutil
+    sfx = "l" if large else "s"
+    exe = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-%s" % sfx)
+    paths = fq["paths"]
+    out = os.path.join(work, "e2e.sam")
+    in_bytes = sum(os.path.getsize(p) for p in paths)
+    to_file = shutil.disk_usage(work).free > in_bytes * 1.3
+    rd = ["-U", paths[0]] if len(paths) == 1 else ["-1", paths[0], "-2", paths[1]]
+    cmd = [exe] + list(preset) + ["-t", "-p", str(threads), "-x", base] + rd + ["-S", out if to_file else "/dev/null"]
+    t, p = run_timed(cmd)
+    e = {"reads": fq["reads"], "distinct_reads": True, "input": "FASTQ file%s, %d bytes" % ("s (-1/-2)" if len(paths) == 2 else "", in_bytes),
+         "output": "SAM file" if to_file else "/dev/null (no room for the SAM file next to the input)",
+         "command": " ".join(os.path.basename(c) if os.sep in c else c for c in cmd), "wall_s_process": round(t, 2), "returncode": p.returncode}
+    m = re.search(r"index load ([\d.]+) s; search ([\d.]+) s wall, (\d+) reads -> (\d+) reads/s after the load", p.stderr)
+    if p.returncode != 0 or not m:
+        e["error"] = p.stderr[-400:]
+    else:
+        e.update({"index_load_s": float(m.group(1)), "search_s": float(m.group(2)), "reads_per_s_after_load": int(m.group(4)),
+                  "frac_of_resident": int(m.group(4)) / resident_rate, "reads_per_s_whole_process": fq["reads"] / t,
+                  "stages": [l.strip() for l in p.stderr.splitlines() if l.startswith("[bt2g]")]})
+        if to_file:
+            e["sam_bytes"] = os.path.getsize(out)
+            ref = os.path.join(work, "sample.ref.sam")
+            if par and par.get("parity_identical") is not None and os.path.exists(ref):
+                # the head of the e2e input is the parity sample: same reads, same names -> the same SAM records, whatever batch they travelled in
+                a = [l for l in sam_body(ref) if not l.startswith(b"@")]
+                nd, k = 0, 0
+                with open(out, "rb") as f:
+                    for l in f:
+                        if l.startswith(b"@"):
+                            continue
+                        if k >= len(a):
+                            break
+                        nd += l != a[k]
+                        k += 1
+                e["head_records_compared_with_reference"] = k
+                e["head_records_differing"] = nd + (len(a) - k)
+    for f_ in (out, os.path.join(work, "sample.ref.sam")) + tuple(paths):
+        try:
+            os.remove(f_)
+        except OSError:
+            pass
+    return e
+
+
+def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, threads, preset, work, readlen=150, parity_only=False, keep_ref_sam=False):
     # fq_all / fq_tiny: one FASTQ path (unpaired) or a pair of paths (mate 1, mate 2)
     def rd_args(fq):
         return ["-U", fq] if isinstance(fq, str) else ["-1", fq[0], "-2", fq[1]]
@@ -392,7 +479,7 @@ def cpu_baseline_and_parity(base, large, fq_all, fq_tiny, n_sample, n_tiny, thre
                "parity_product_binary_wall_s": round(t, 2)}
         aligned_ref = sum(1 for l in a if not l.startswith(b"@") and not (int(l.split(b"\t", 2)[1]) & 4))
         par["parity_sample_aligned_reads"] = aligned_ref
-    for f in (ref_sam, our_sam):
+    for f in (our_sam,) if keep_ref_sam else (ref_sam, our_sam):
         try:
             os.remove(f)
         except OSError:
@@ -489,6 +576,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference run (no cpu_baseline, no SAM parity)")
     ap.add_argument("--parity-only", action="store_true", help="run the reference once, for the SAM comparison only (cpu_baseline then comes from one run)")
     ap.add_argument("--paired", action="store_true", help="same as --config pe-sens: the paired kernel at --sensitive (round-2 line)")
+    ap.add_argument("--e2e-reads", type=int, default=-1, help="distinct reads the product binary aligns FASTQ file -> SAM file after the timed steps (N = 1 only); "
+                    "-1: 12 batches of --reads (24 M for the headline) in the default run, none with --parity-only / --no-cpu-baseline; 0: none")
     ap.add_argument("--pipeline", type=int, default=0, help="steps in flight (on that many streams; the context keeps a working set per stream): 0 = the config's default")
     args = ap.parse_args()
     if args.paired:
@@ -549,9 +638,15 @@ def main():
         n = seq.shape[0]
     else:
         seq, qual = synth_reads_gpu(G, n, args.readlen, shard.shard_seed(1000, rank), dev)
+    names = read_names(rank * n, n)
+    # ---- the end-to-end leg's input (N = 1): the timed batch followed by further batches of DISTINCT reads of the same generator, as FASTQ ----
+    if args.e2e_reads < 0:
+        args.e2e_reads = 0 if (args.no_cpu_baseline or args.parity_only) else 12 * n
+    e2e_fq = None
+    if world == 1 and args.e2e_reads > 0:
+        e2e_fq = write_e2e_fastq(G, seq, qual, names, n, args, dev, rank)
     del G
     torch.cuda.empty_cache()
-    names = read_names(rank * n, n)
     names_t = torch.from_numpy(names).to(dev)
     off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * args.readlen)
     batch = b.ReadBatch(seq.view(-1), qual.view(-1), off, n)
@@ -689,7 +784,7 @@ def main():
                 fq_all, fq_tiny = os.path.join(work, "sample.fq"), os.path.join(work, "tiny.fq")
                 write_fastq_fixed(fq_all, seq[:ns], qual[:ns], names[:ns])
                 write_fastq_fixed(fq_tiny, seq[:ntiny], qual[:ntiny], names[:ntiny])
-            cb, par = cpu_baseline_and_parity(base, large, fq_all, fq_tiny, ns, ntiny, threads, cfg["args"], work, args.readlen, args.parity_only)
+            cb, par = cpu_baseline_and_parity(base, large, fq_all, fq_tiny, ns, ntiny, threads, cfg["args"], work, args.readlen, args.parity_only, keep_ref_sam=e2e_fq is not None)
             if par is not None and "parity_sample_aligned_reads" in par and not args.paired:
                 # the timed batch starts with the same reads, same parameters, same per-read seeds: its records must agree
                 par["timed_batch_aligned_reads_same_sample"] = int(h["aligned"][:ns].sum())
@@ -754,6 +849,13 @@ def main():
         if par:
             res["config"].update(par)
         res["cpu_baseline"] = cb
+        if e2e_fq is not None:
+            # the timed quantity of the reference is FASTQ in -> SAM out (bt2_search.cpp:4863 "Multiseed full-index search"): the drop-in binary on
+            # the e2e file, its own process (index load, reader, device stage, SAM writer), next to the resident-batch rate above
+            last.clear()
+            ctx.close()          # (index, arenas and tables of this process leave HBM before the binary loads its own)
+            torch.cuda.empty_cache()
+            res["e2e"] = e2e_leg(base, large, e2e_fq, cfg["args"], threads, res["value"], cache_dir(), par)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

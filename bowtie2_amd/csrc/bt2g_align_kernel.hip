@@ -967,6 +967,40 @@ struct DevPlat {
 		const uint32_t lane = threadIdx.x & 63;
 		const int thr = minsc_dp < -32768 ? -32768 : (int)minsc_dp;
 		uint32_t total = 0;
+		if (cols <= 256u) {
+			// the common window (a seed extension: rows + 4 * maxhalf + 1 columns): every lane keeps the cells of its columns j = lane + 64 b as
+			// keys (score | column: distinct, larger = earlier in the list; 0 = no candidate) and ranks them against the CANDIDATES only -- a few
+			// dozen register broadcasts instead of a pass over every column of the row per batch of 64
+			uint32_t key[4];
+			unsigned long long cm[4];
+#pragma unroll
+			for (uint32_t b = 0; b < 4; b++) {
+				const uint32_t j = b * 64u + lane;
+				const int sc = j < cols ? (int)dev_lastrow()[j] : -65536;
+				const bool is = j < cols && sc >= thr;
+				key[b] = is ? (((uint32_t)(sc + 32768) << 16) | j) + 1u : 0u;
+				cm[b] = __ballot(is);
+				total += (uint32_t)__popcll(cm[b]);
+			}
+			if (total == 0) { wave_fence(); return 0; }
+			uint32_t rank[4] = {0, 0, 0, 0};
+#pragma unroll
+			for (uint32_t b2 = 0; b2 < 4; b2++) {
+				unsigned long long m = cm[b2];
+				while (m) {
+					const uint32_t i = (uint32_t)__builtin_ctzll(m);
+					m &= m - 1;
+					const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key[b2], (int)i);
+#pragma unroll
+					for (uint32_t b = 0; b < 4; b++) rank[b] += k2 > key[b] ? 1u : 0u;
+				}
+			}
+#pragma unroll
+			for (uint32_t b = 0; b < 4; b++)
+				if (key[b] != 0u && rank[b] < cap) { BtCand c; c.score = (int32_t)((key[b] - 1u) >> 16) - 32768; c.row = (uint16_t)(rows - 1); c.col = (uint16_t)((key[b] - 1u) & 0xffffu); cands[rank[b]] = c; }
+			wave_fence();
+			return total;
+		}
 		for (uint32_t base = 0; base < cols; base += 64) {
 			const uint32_t j = base + lane;
 			const int sc = j < cols ? (int)dev_lastrow()[j] : -65536;
