@@ -355,6 +355,7 @@ def write_e2e_fastq(G, seq, qual, names, n, args, dev, rank):
             write_fastq_fixed(paths[0], sq, ql, nm, append=True)
         done += n
         k += 1
+    os.sync()      # (the input's dirty pages reach the disk now, not while the timed run reads it)
     log("[bench] e2e input: %d distinct reads written as FASTQ in %.1fs" % (done, time.time() - t0))
     return {"paths": paths, "reads": done, "batches": k, "first_batch_is_timed_batch": True}
 
@@ -371,12 +372,28 @@ def e2e_leg(base, large, fq, preset, threads, resident_rate, work, par):
     to_file = shutil.disk_usage(work).free > in_bytes * 1.3
     rd = ["-U", paths[0]] if len(paths) == 1 else ["-1", paths[0], "-2", paths[1]]
     cmd = [exe] + list(preset) + ["-t", "-p", str(threads), "-x", base] + rd + ["-S", out if to_file else "/dev/null"]
-    t, p = run_timed(cmd)
+    # The process that measured the resident batches has just exited and the driver is still wiping the ~100 GB of HBM it held; the wipe runs
+    # on the copy engines this binary's uploads and downloads need (session r05h: the first batch came back after 3.8 s instead of 0.25 s,
+    # with the time booked under "download").  A user's GPU is not being wiped: give it a moment, then take the median of three runs.
+    time.sleep(float(os.environ.get("BT2_BENCH_E2E_SETTLE_S", "8")))
+    runs = []
+    for _ in range(int(os.environ.get("BT2_BENCH_E2E_RUNS", "3"))):
+        t, p = run_timed(cmd)
+        mm = re.search(r"index load ([\d.]+) s; search ([\d.]+) s wall, (\d+) reads -> (\d+) reads/s after the load", p.stderr)
+        runs.append((int(mm.group(4)) if mm else -1, t, p, mm))
     e = {"reads": fq["reads"], "distinct_reads": True, "input": "FASTQ file%s, %d bytes" % ("s (-1/-2)" if len(paths) == 2 else "", in_bytes),
          "output": "SAM file" if to_file else "/dev/null (no room for the SAM file next to the input)",
-         "command": " ".join(os.path.basename(c) if os.sep in c else c for c in cmd), "wall_s_process": round(t, 2), "returncode": p.returncode}
-    m = re.search(r"index load ([\d.]+) s; search ([\d.]+) s wall, (\d+) reads -> (\d+) reads/s after the load", p.stderr)
-    if p.returncode != 0 or not m:
+         "command": " ".join(os.path.basename(c) if os.sep in c else c for c in cmd),
+         "runs_reads_per_s_after_load": [r[0] for r in runs], "protocol": "median of %d runs of the same command, in order" % len(runs)}
+    _, t, p, m = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+    e["wall_s_process"] = round(t, 2)
+    e["returncode"] = p.returncode
+    flagged = re.search(r"Error: (\d+) read\(s\) exceeded a limit of this build", p.stderr)
+    if flagged:
+        # (flagged, never approximated: the binary exits 1 and says which reads)
+        e["reads_over_a_capacity_limit"] = int(flagged.group(1))
+        e["capacity_warnings"] = [l for l in p.stderr.splitlines() if l.startswith("Warning")][:4]
+    if not m or (p.returncode != 0 and not flagged):
         e["error"] = p.stderr[-400:]
     else:
         e.update({"index_load_s": float(m.group(1)), "search_s": float(m.group(2)), "reads_per_s_after_load": int(m.group(4)),
@@ -399,7 +416,7 @@ def e2e_leg(base, large, fq, preset, threads, resident_rate, work, par):
                         k += 1
                 e["head_records_compared_with_reference"] = k
                 e["head_records_differing"] = nd + (len(a) - k)
-    for f_ in (out, os.path.join(work, "sample.ref.sam")) + tuple(paths):
+    for f_ in (out, os.path.join(work, "sample.ref.sam")) + (() if os.environ.get("BT2_BENCH_KEEP_E2E") else tuple(paths)):
         try:
             os.remove(f_)
         except OSError:
@@ -850,17 +867,36 @@ def main():
             res["config"].update(par)
         res["cpu_baseline"] = cb
         if e2e_fq is not None:
-            # the timed quantity of the reference is FASTQ in -> SAM out (bt2_search.cpp:4863 "Multiseed full-index search"): the drop-in binary on
-            # the e2e file, its own process (index load, reader, device stage, SAM writer), next to the resident-batch rate above
-            last.clear()
-            ctx.close()          # (index, arenas and tables of this process leave HBM before the binary loads its own)
-            torch.cuda.empty_cache()
-            res["e2e"] = e2e_leg(base, large, e2e_fq, cfg["args"], threads, res["value"], cache_dir(), par)
+            # the end-to-end leg runs once this process is gone (main()): what it needs travels in the line
+            res["e2e_pending"] = {"base": base, "large": large, "fq": e2e_fq, "preset": cfg["args"], "threads": threads, "work": cache_dir(),
+                                  "par": {"parity_identical": par.get("parity_identical")} if par else None}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def outer():
+    """N = 1: the measurement runs in a child process and the end-to-end leg -- the drop-in binary, FASTQ file -> SAM file, the reference's own
+    timed quantity (bt2_search.cpp:4863 "Multiseed full-index search") -- after the child has exited.  Measured (profiles/r05g_*): next to a
+    second process that merely holds a context on the same GPU (this script with its torch runtime, idle) the binary runs at 0.55 x its rate
+    on a GPU of its own (its persistent worker waves get time-sliced against the other process's queues); a user's run has the GPU to itself."""
+    if os.environ.get("BT2_BENCH_CHILD") or int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--gpus" in sys.argv and sys.argv[sys.argv.index("--gpus") + 1] != "1":
+        return main()
+    env = dict(os.environ, BT2_BENCH_CHILD="1")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], stdout=subprocess.PIPE, env=env, text=True)
+    line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
+    try:
+        res = json.loads(line)
+    except ValueError:
+        sys.stdout.write(p.stdout)
+        raise SystemExit(p.returncode or 1)
+    pend = res.pop("e2e_pending", None)
+    if pend:
+        res["e2e"] = e2e_leg(pend["base"], pend["large"], pend["fq"], pend["preset"], pend["threads"], res["value"], pend["work"], pend["par"])
+    print(json.dumps(res), flush=True)
+    raise SystemExit(p.returncode)
+
+
 if __name__ == "__main__":
-    main()
+    outer()

@@ -134,9 +134,21 @@ int upload_ebwt(bt2g_ctx* c, const HostEbwt& h, bool fw, DevEbwt<TOff>& d) {
 		if ((rc = offs.put(c, h.offs.data(), h.offs.size()))) return rc;
 		uint64_t* sa = nullptr;
 		if ((rc = alloc_index(c, ((uint64_t)h.len + 1) * sizeof(uint64_t), &sa))) return rc;
-		hipError_t e = launch_make_full_sa<TOff>(d, (const TOff*)offs.p, sa, nullptr);
+		TmpDev lost;
+		const unsigned long long zero = 0;
+		if ((rc = lost.put(c, &zero, sizeof zero))) return rc;
+		hipError_t e = launch_make_full_sa<TOff>(d, (const TOff*)offs.p, sa, (unsigned long long*)lost.p, nullptr);
 		if (e == hipSuccess) e = hipDeviceSynchronize();
 		if (e != hipSuccess) return hip_fail(c, e, "k_sa_segments");
+		unsigned long long n_lost = 0;
+		e = hipMemcpy(&n_lost, lost.p, sizeof n_lost, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMemcpy(lost rows)");
+		if (n_lost) {
+			char msg[256];
+			snprintf(msg, sizeof msg, "the suffix-array sample of this index (--offrate %d) leaves %llu rows more than 65534 LF steps from a sampled row; "
+			         "this build keeps the step count in 16 bits and will not load it (rebuild with a smaller --offrate)", (int)h.off_rate, n_lost);
+			return fail(c, BT2G_ERR_UNSUPPORTED, msg);
+		}
 		d.sa = sa;
 	}
 	return 0;

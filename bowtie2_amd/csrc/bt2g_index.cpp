@@ -50,7 +50,8 @@ int load_ebwt(const std::string& p1, const std::string& p2, int off_size, bool f
 		err = p1 + ": implausible header"; return BT2G_ERR_FORMAT;
 	}
 	// The resident suffix array keeps, per row, the LF steps the reference's getOffset would have walked in 16 bits (joff_pack,
-	// bt2g_device.hpp): a sampling rate of 2^16 rows or more could overflow that field and the row's offset would be lost silently.
+	// bt2g_device.hpp).  The sample is by row, so a walk's length is geometric with mean 2^offRate: above 15 most rows would not fit; for
+	// the rates below that, bt2g_index_load counts the rows that do not while it builds the array and refuses the index if there are any.
 	if (e.off_rate > 15) { err = p1 + ": --offrate above 15 is not supported by this build (suffix-array sample too sparse)"; return BT2G_ERR_UNSUPPORTED; }
 	// Colorspace indexes (flags & 2) and pre-2.0 "each stretch reversed" mirrors are not supported.
 	if (e.flags < 0 && ((-e.flags) & 2)) { err = p1 + ": colorspace index"; return BT2G_ERR_UNSUPPORTED; }

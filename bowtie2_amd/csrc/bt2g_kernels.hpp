@@ -46,7 +46,7 @@ hipError_t launch_resolve_offsets(const DevIndex<TOff>& ix, const uint64_t* d_ro
 template <typename TOff>
 hipError_t launch_make_rank_blocks(const uint8_t* d_ebwt, uint64_t n_sides, const TOff fchr[5], TOff zoff, RankBlock* d_out, uint64_t n_blocks, hipStream_t st);
 template <typename TOff>
-hipError_t launch_make_full_sa(const DevEbwt<TOff>& e, const TOff* d_offs, uint64_t* d_sa, hipStream_t st);
+hipError_t launch_make_full_sa(const DevEbwt<TOff>& e, const TOff* d_offs, uint64_t* d_sa, unsigned long long* d_lost, hipStream_t st);
 
 
 } // namespace bt2g

@@ -73,8 +73,12 @@ BT2_HD void sa_init_row(const DevEbwt<TOff>& e, const TOff* offs, TOff row, uint
 }
 
 // The segment headed by r0 (an SA sample, or row `len`: the row of the empty suffix heads the LF chain).  Returns its length.
+// The reference samples the suffix array by ROW ((row & mask) == row, bt2_idx.h), so a segment's length is geometric with mean 2^offRate and
+// has no upper bound: a segment longer than the 16-bit step count next to the offset holds (joff_pack) cannot be represented -- the rows past
+// that point would read as "no offset" and their seed hits would be dropped silently.  Such rows are counted (`lost`) and the index load
+// fails when there are any (bt2g_index_load; only sparse samples, --offrate 12 and up on a genome-sized text, get there at all).
 template <typename TOff>
-BT2_HD uint32_t sa_segment(const DevEbwt<TOff>& e, const TOff* offs, TOff r0, uint64_t* sa) {
+BT2_HD uint32_t sa_segment(const DevEbwt<TOff>& e, const TOff* offs, TOff r0, uint64_t* sa, uint32_t* lost = nullptr) {
 	if (r0 == e.zoff) return 0;
 	TOff r = r0;
 	uint32_t m = 0;
@@ -85,6 +89,7 @@ BT2_HD uint32_t sa_segment(const DevEbwt<TOff>& e, const TOff* offs, TOff r0, ui
 	}
 	const uint64_t base = r == e.zoff ? 0ull : (uint64_t)offs[(uint64_t)r >> e.off_rate];
 	if (!sa_sampled(e, r0)) sa[(uint64_t)r0] = joff_pack(base + m, m);      // (row len when it is not a sample itself)
+	if (lost && m >= 0xffffu) *lost += m - 0xfffeu;
 	r = r0;
 	for (uint32_t k = 1; k < m; k++) {
 		map_lf1(e, r);
@@ -113,6 +118,14 @@ inline void host_make_full_sa(const DevEbwt<TOff>& e, const TOff* offs, uint64_t
 	for (uint64_t r = 0; r <= (uint64_t)e.len; r++) sa_init_row(e, offs, (TOff)r, sa);
 	const uint64_t nh = sa_n_heads(e);
 	for (uint64_t h = 0; h < nh; h++) sa_segment(e, offs, sa_head_row(e, h), sa);
+}
+template <typename TOff>
+inline uint64_t host_make_full_sa_checked(const DevEbwt<TOff>& e, const TOff* offs, uint64_t* sa) {
+	for (uint64_t r = 0; r <= (uint64_t)e.len; r++) sa_init_row(e, offs, (TOff)r, sa);
+	const uint64_t nh = sa_n_heads(e);
+	uint64_t lost = 0;
+	for (uint64_t h = 0; h < nh; h++) { uint32_t l = 0; sa_segment(e, offs, sa_head_row(e, h), sa, &l); lost += l; }
+	return lost;
 }
 #endif
 

@@ -630,7 +630,8 @@ static void make_dev_index(const HostIndex& h, DevIndex<TOff>& d) {
 		if (fw) {
 			uint64_t* sa = (uint64_t*)malloc(((uint64_t)e.len + 1) * sizeof(uint64_t));
 			for (uint64_t r = 0; r <= (uint64_t)e.len; r++) sa[r] = kJoffNone;
-			host_make_full_sa<TOff>(o, (const TOff*)e.offs.data(), sa);
+			const uint64_t lost = host_make_full_sa_checked<TOff>(o, (const TOff*)e.offs.data(), sa);
+			if (lost) { fprintf(stderr, "Error: the suffix-array sample of this index (--offrate %d) leaves %llu rows more than 65534 LF steps from a sampled row (not supported)\n", (int)e.off_rate, (unsigned long long)lost); exit(1); }      // as bt2g_index_load
 			o.sa = sa;
 		}
 	};
