@@ -320,6 +320,102 @@ def sam_body(path):
         return [l for l in f if not l.startswith(b"@PG")]
 
 
+# ------------------------------------------------------------------------------- --dry-ranks stand-ins ----
+class _DryCuda:
+    """torch.cuda as far as main() uses it, without a device."""
+    class Event:
+        def __init__(self, enable_timing=True):
+            self.t = 0.0
+
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    class Stream:
+        def __init__(self, device=None):
+            pass
+
+        def wait_stream(self, s):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def current_stream(self):
+        return self.Stream()
+
+    def stream(self, s):
+        return s
+
+    def synchronize(self):
+        pass
+
+    def empty_cache(self):
+        pass
+
+
+def _dry_build_index(base, ext):
+    """rank 0 'builds' the index: the files the other ranks look for after the barrier, written the way the builder publishes them (last file last)"""
+    time.sleep(0.5)
+    for suf in ("1", "2", "3", "4", "rev.1", "rev.2"):
+        with open("%s.%s.%s" % (base, suf, ext), "wb") as f:
+            f.write(b"dry")
+    return {"seconds": 0.5, "dry": True}
+
+
+class _DryContext:
+    """bowtie2_amd.Context as far as main() uses it: records of the right shape, packed sizes of the right order (0.15 KB per read), no alignment."""
+    class _Info:
+        pass
+
+    def __init__(self, large):
+        self.large = large
+        self.n = 0
+
+    def load_index(self, base):
+        i = self._Info()
+        i.side_sz, i.off_size, i.hbm_bytes, i.len = (128, 8, 0, 0) if self.large else (64, 4, 0, 0)
+        return i
+
+    def align_batch(self, batch, rp_t, P, readlen):
+        import ctypes as C
+        import torch
+        import bowtie2_amd as b
+        n = batch.n
+        stride = (C.sizeof(b.ReadResult) + (max(1, P.khits) - 1) * C.sizeof(b.Aln) + 15) & ~15
+        res = torch.zeros(n * stride, dtype=torch.uint8)
+        res.view(n, stride)[:, 1] = 1          # "aligned"
+        self.n = n
+        time.sleep(0.01)
+        return res, stride
+
+    def results_pack(self, res, n, khits):
+        import torch
+        offs = torch.arange(n + 1, dtype=torch.int64) * 152
+        return torch.zeros(int(offs[n]), dtype=torch.uint8), offs
+
+    def align_timing(self, on_current_stream=False):
+        return {"k_exact_sweep": 0.0, "k_one_mm": 0.0, "k_seed_search_exact": 0.0, "k_extend_hits": 0.0, "k_align_reads": 10.0}
+
+    def align_profile(self, reset=False):
+        p = [0] * 32
+        p[9] = max(1, self.n)
+        return p
+
+    def counters(self, reset=False):
+        c = self._Info()
+        c.rank_queries = c.ftab_lookups = c.sa_lookups = 0
+        return c
+
+    def close(self):
+        pass
+
+
 def write_e2e_fastq(G, seq, qual, names, n, args, dev, rank):
     """FASTQ input of the end-to-end leg: the timed batch (whose first reads are the ones compared with the reference) followed by further batches of
     distinct reads from the same generator, other seeds, names numbered on.  Returns the path (a pair of paths for pairs) and the read count."""
@@ -595,6 +691,9 @@ def main():
     ap.add_argument("--paired", action="store_true", help="same as --config pe-sens: the paired kernel at --sensitive (round-2 line)")
     ap.add_argument("--e2e-reads", type=int, default=-1, help="distinct reads the product binary aligns FASTQ file -> SAM file after the timed steps (N = 1 only); "
                     "-1: 12 batches of --reads (24 M for the headline) in the default run, none with --parity-only / --no-cpu-baseline; 0: none")
+    ap.add_argument("--dry-ranks", action="store_true", help="no GPU: every rank runs this script's N-GPU plumbing -- rendezvous (gloo), rank 0 filling the "
+                    "index cache while the others wait, per-rank read shards, the step loop with its per-step gather of packed records to rank 0, "
+                    "barrier + max-over-ranks timing, the summed counters, rank 0's JSON line -- around a stand-in for the device (tests/test_bench_dry_ranks.py)")
     ap.add_argument("--pipeline", type=int, default=0, help="steps in flight (on that many streams; the context keeps a working set per stream): 0 = the config's default")
     args = ap.parse_args()
     if args.paired:
@@ -616,17 +715,29 @@ def main():
 
     from bowtie2_amd import shard
     rank, local_rank, world = shard.env_rank()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = shard.init("nccl", dev)      # RCCL; None when WORLD_SIZE == 1
+    dry = args.dry_ranks
+    if dry:
+        # the plumbing of the N-GPU run without the device: nothing measured here is a result (data says so), everything exchanged is
+        dev = torch.device("cpu")
+        dist = shard.init("gloo")
+        cuda = _DryCuda()
+        args.genome_mbp = min(args.genome_mbp, 1)
+        args.no_cpu_baseline = True
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dist = shard.init("nccl", dev)      # RCCL; None when WORLD_SIZE == 1
+        cuda = torch.cuda
 
     threads = nproc()
     bacterial = cfg.get("genome") == "ecoli"
     large = not (args.small_index or bacterial)
     ext = "bt2l" if large else "bt2"
     base = os.path.join(cache_dir(), "ecolilike_s3_%s" % ext if bacterial else "hg38like_%dmbp_s2_%s" % (args.genome_mbp, ext))
+    if dry:
+        base += "_dry"
     # ---- workload: genome (every rank, same seed) + index (rank 0 builds it on its GPU, the others wait) ----
     t0 = time.time()
     if bacterial:
@@ -634,16 +745,18 @@ def main():
         args.genome_mbp = G.numel() / 1e6
     else:
         G, chrom_lens = synth_genome_gpu(args.genome_mbp, 2, dev)
-    torch.cuda.synchronize()
+    cuda.synchronize()
     log("[bench] genome: %.4g Mbp generated in %.1fs" % (args.genome_mbp, time.time() - t0))
     build_info = None
     if rank == 0 and not os.path.exists(base + ".rev.2." + ext):
-        torch.cuda.empty_cache()       # the builder allocates ~30 bytes per base with hipMalloc, next to torch's caching allocator
-        build_info = build_index_gpu(base, G, chrom_lens, large, local_rank)
+        cuda.empty_cache()       # the builder allocates ~30 bytes per base with hipMalloc, next to torch's caching allocator
+        build_info = _dry_build_index(base, ext) if dry else build_index_gpu(base, G, chrom_lens, large, local_rank)
     if dist is not None:
         dist.barrier()
+    if not os.path.exists(base + ".rev.2." + ext):
+        raise SystemExit("rank %d: the index rank 0 built is not visible at %s" % (rank, base))
 
-    ctx = b.Context(local_rank)
+    ctx = _DryContext(large) if dry else b.Context(local_rank)
     t0 = time.time()
     info = ctx.load_index(base)
     log("[bench] index loaded into HBM in %.1fs (%.2f GB)" % (time.time() - t0, info.hbm_bytes / 1e9))
@@ -663,7 +776,7 @@ def main():
     if world == 1 and args.e2e_reads > 0:
         e2e_fq = write_e2e_fastq(G, seq, qual, names, n, args, dev, rank)
     del G
-    torch.cuda.empty_cache()
+    cuda.empty_cache()
     names_t = torch.from_numpy(names).to(dev)
     off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * args.readlen)
     batch = b.ReadBatch(seq.view(-1), qual.view(-1), off, n)
@@ -680,21 +793,21 @@ def main():
     rp["seed"] = gen_rand_seeds(seq, qual, names_t).cpu().numpy().astype(np.uint32)
     rp_t = torch.from_numpy(rp.view(np.uint8).copy()).to(dev)
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)
+    ev = lambda: cuda.Event(enable_timing=True)
     stage_events = []
     last = {}
     kern_times = []
     depth = max(1, args.pipeline) if dist is None else 1      # (the N-GPU path keeps one step in flight: its RCCL gather sits inside the step)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
+    streams = [cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [cuda.current_stream()]
     for s_ in streams:
-        s_.wait_stream(torch.cuda.current_stream())
+        s_.wait_stream(cuda.current_stream())
     issued = [0] * depth
     step_no = [0]
 
     def step(record):
         k = step_no[0] % depth
         step_no[0] += 1
-        with torch.cuda.stream(streams[k]):
+        with cuda.stream(streams[k]):
             if depth > 1 and record and issued[k]:
                 # the batch issued `depth` steps ago on this stream: its kernel times (blocks until it is done -- the pipeline's backpressure)
                 kern_times.append(ctx.align_timing(on_current_stream=True))
@@ -714,10 +827,10 @@ def main():
             last["res"], last["stride"] = res, stride
 
     def sync_all():
-        torch.cuda.synchronize()
+        cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            cuda.synchronize()
 
     for _ in range(args.warmup):
         step(False)
@@ -733,7 +846,7 @@ def main():
     if depth > 1:
         for k in range(depth):                # the last batch of every stream
             if issued[k]:
-                with torch.cuda.stream(streams[k]):
+                with cuda.stream(streams[k]):
                     kern_times.append(ctx.align_timing(on_current_stream=True))
                 issued[k] = 0
     batch_ms = sum(a.elapsed_time(bb) for a, bb in stage_events) / len(stage_events)
@@ -814,7 +927,7 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u32" if off_sz == 4 else "u8/u64", "data": "synthetic",
+            "dtype": "u8/u32" if off_sz == 4 else "u8/u64", "data": "DRY RUN (--dry-ranks): no device, no alignment; only the N-rank plumbing is real" if dry else "synthetic",
             "config": {
                 "workload": ("BASELINE.json configs[1]: E. coli K-12-like synthetic %.2f Mbp genome (one chromosome; 7 rRNA-operon-like and 40 IS-like repeat copies; the real sequence is not available offline), "
                              ".%s index (side %d B, %d-byte offsets) built in this run by the GPU index builder, %d x %d bp SE reads per GPU per step, %s"
@@ -856,7 +969,7 @@ def main():
                          "dp_cells_note": "cells computed per launch (band cells; score-only passes up to their early exit: %d, matrix-storing fills: %d), over the whole kernel time"
                                           % (prof[24], prof[25]),
                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
-                         "instruction_issue": pmc_issue(kname, kern_ms, n, torch.cuda.get_device_properties(dev).multi_processor_count, args.config),
+                         "instruction_issue": pmc_issue(kname, kern_ms, n, 256 if dry else torch.cuda.get_device_properties(dev).multi_processor_count, args.config),
                          "fm_kernels": {"kernels": ["k_exact_sweep", "k_one_mm", "k_seed_search_exact", "k_extend_hits"], "bound": "hbm",
                                         "ms_per_launch_sum": fm_ms, "algorithmic_bytes_per_launch": int(fm_bytes),
                                         "achieved": fm_achieved, "unit": "GB/s", "frac": fm_achieved / HBM_PEAK_GBS,

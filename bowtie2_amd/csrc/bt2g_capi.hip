@@ -49,11 +49,13 @@ struct bt2g_ctx {
 		uint64_t pre_bytes = 0;
 		hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel boundaries of the last align batch
 		bool ev_valid = false;
+		uint64_t last_use = 0;               // batch number of the slot's last bt2g_align_batch: the least recently used slot is handed to a new stream
 	};
 	static constexpr int kMaxSlots = 4;
 	BatchSlot slots[kMaxSlots];
 	std::mutex slot_mu;
-	int last_slot = -1;                  // slot of the most recent bt2g_align_batch (bt2g_align_timing_read)
+	int last_slot = -1;                  // slot of the most recent bt2g_align_batch (bt2g_align_timing_read); read and written under slot_mu
+	uint64_t n_batches = 0;
 	bool precomp = true;                 // BT2G_NO_PRECOMP=1: the worker computes every FM phase itself (A/B testing)
 };
 
@@ -447,7 +449,15 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		std::lock_guard<std::mutex> g(c->slot_mu);
 		for (int i = 0; i < bt2g_ctx::kMaxSlots && si < 0; i++) if (c->slots[i].used && c->slots[i].owner == st) si = i;
 		for (int i = 0; i < bt2g_ctx::kMaxSlots && si < 0; i++) if (!c->slots[i].used) { si = i; c->slots[i].used = true; c->slots[i].owner = st; }
-		if (si < 0) return fail(c, BT2G_ERR_ARG, "bt2g_align_batch has been called on more streams than a context keeps working sets for");
+		if (si < 0) {
+			// more streams than working sets (a caller that rotates through a stream pool, or recreates its streams): the set that has been
+			// idle longest changes hands, once its last batch is done -- its buffers stay, its kernel timings are the old owner's and are dropped
+			for (int i = 0; i < bt2g_ctx::kMaxSlots; i++) if (si < 0 || c->slots[i].last_use < c->slots[si].last_use) si = i;
+			bt2g_ctx::BatchSlot& V = c->slots[si];
+			if (V.ev_valid && hipEventSynchronize(V.ev[6]) != hipSuccess) return fail(c, BT2G_ERR_HIP, "hipEventSynchronize(working set changing streams)");
+			V.ev_valid = false; V.owner = st;
+		}
+		c->slots[si].last_use = ++c->n_batches;
 		c->last_slot = si;
 	}
 	bt2g_ctx::BatchSlot& S = c->slots[si];
@@ -488,14 +498,23 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	// persistent waves (one read at a time each) pull reads from a device-side queue
 	uint32_t n_waves = c->n_cu * (w5 ? bt2g_w5_waves_per_cu() : align_waves_per_cu());
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
-	const uint64_t need = arena_stride * n_waves;
+	uint64_t need = arena_stride * n_waves;
 	if (need > S.arena_bytes) {
+		// Every stream's working set has its own arena (Work + DP matrices per resident wave): with wide opposite-mate windows and long mates a
+		// wave's share reaches tens of MB, and three sets of 4 096 of them would not fit next to the index.  The launch is cut to the waves
+		// whose arena fits in 90 % of what is free (fewer resident waves: slower, never wrong) before the allocation is given up.
 		if (S.d_arena) (void)hipFree(S.d_arena);
-		S.d_arena = nullptr; S.arena_bytes = 0;
+		S.d_arena = nullptr; S.arena_bytes = 0; S.arena_layout = 0;
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (uint64_t)(free_b * 0.9)) {
+			const uint64_t fit = (uint64_t)(free_b * 0.9) / arena_stride;
+			if (fit < 64) return fail(c, BT2G_ERR_HIP, "not enough device memory for the worker arena of this batch (reads / mate windows this long need more per wave than is free)");
+			n_waves = (uint32_t)fit;
+			need = arena_stride * n_waves;
+		}
 		e = hipMalloc((void**)&S.d_arena, need);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(worker arena)");
 		S.arena_bytes = need;
-		S.arena_layout = 0;
 	}
 	// the epoch-tagged backtrace masks live in the arena across launches: (re)start from zero whenever its layout changes
 	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0) ^ (w5 ? 1ull << 62 : 0);
@@ -509,7 +528,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	PreComp pre;
 	memset(&pre, 0, sizeof(pre));
 	if (!S.ev[0]) for (int i = 0; i < 7; i++) if (hipEventCreate(&S.ev[i]) != hipSuccess) return fail(c, BT2G_ERR_HIP, "hipEventCreate");
-	S.ev_valid = false;
+	{ std::lock_guard<std::mutex> g(c->slot_mu); S.ev_valid = false; }
 	auto mark = [&](int i) { (void)hipEventRecord(S.ev[i], st); };
 	mark(0);
 	if (c->precomp) {
@@ -614,7 +633,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, (160u * 1024u) / align_waves_per_cu(), st);
 	if (e != hipSuccess) return hip_fail(c, e, "k_align_reads");
 	mark(6);
-	S.ev_valid = true;
+	{ std::lock_guard<std::mutex> g(c->slot_mu); S.ev_valid = true; }
 	return 0;
 }
 
@@ -629,7 +648,9 @@ int bt2g_results_pack(bt2g_ctx* c, const void* d_results, uint32_t n_reads, uint
 
 static int timing_of_slot(bt2g_ctx* c, int si, float* out_ms5) {
 	for (int i = 0; i < 5; i++) out_ms5[i] = 0.f;
-	if (si < 0 || !c->slots[si].ev_valid) return fail(c, BT2G_ERR_ARG, "no align batch has been launched");
+	bool valid = false;
+	if (si >= 0) { std::lock_guard<std::mutex> g(c->slot_mu); valid = c->slots[si].ev_valid; }
+	if (!valid) return fail(c, BT2G_ERR_ARG, "no align batch has been launched");
 	if (hipSetDevice(c->device) != hipSuccess) return BT2G_ERR_NO_DEVICE;
 	bt2g_ctx::BatchSlot& S = c->slots[si];
 	hipError_t e = hipEventSynchronize(S.ev[6]);
@@ -644,7 +665,9 @@ static int timing_of_slot(bt2g_ctx* c, int si, float* out_ms5) {
 }
 int bt2g_align_timing_read(bt2g_ctx* c, float* out_ms5) {
 	if (!c || !out_ms5) return BT2G_ERR_ARG;
-	return timing_of_slot(c, c->last_slot, out_ms5);
+	int si;
+	{ std::lock_guard<std::mutex> g(c->slot_mu); si = c->last_slot; }
+	return timing_of_slot(c, si, out_ms5);
 }
 int bt2g_align_timing_read_on(bt2g_ctx* c, void* stream, float* out_ms5) {
 	if (!c || !out_ms5) return BT2G_ERR_ARG;

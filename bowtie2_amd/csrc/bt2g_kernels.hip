@@ -606,8 +606,10 @@ k_one_mm_scan(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_
               const uint32_t* __restrict__ tasks, const unsigned int* __restrict__ tcount, uint32_t cap, Mm1Hit* __restrict__ out, unsigned int* __restrict__ out_cnt,
               Mm1Task<TOff>* __restrict__ queue, unsigned int* __restrict__ qcount, uint32_t qcap, DevCounters* cnt) {
 	FmCount c; c.bwops = 0; c.sides = 0;
-	__shared__ uint32_t s_qbase[4], s_qused[4];      // per wave: the chunk of the branch queue it is filling
-	if ((threadIdx.x & 63) == 0) { s_qbase[threadIdx.x >> 6] = 0; s_qused[threadIdx.x >> 6] = kQChunk; }
+	// per wave: the chunk of the branch queue it is filling, and "the queue is full" (sticky).  Whichever lane leads a divergent defer() reads
+	// and writes them: volatile, so that no value is carried in a register from one leader's call to another's.
+	__shared__ volatile uint32_t s_qbase[4], s_qused[4], s_qfull[4];
+	if ((threadIdx.x & 63) == 0) { s_qbase[threadIdx.x >> 6] = 0; s_qused[threadIdx.x >> 6] = kQChunk; s_qfull[threadIdx.x >> 6] = 0; }
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 	const unsigned int nt = *tcount;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -634,10 +636,11 @@ k_one_mm_scan(DevIndex<TOff> ix, bt2g_align_params P, bt2g_reads rd, const bt2g_
 			if (lane == leader) {
 				const uint32_t n = (uint32_t)__popcll(act);
 				uint32_t used = s_qused[wv], base = s_qbase[wv];
-				if (used + n > kQChunk) {
+				if (used + n > kQChunk && !s_qfull[wv]) {
 					for (uint32_t k = used; k < kQChunk; k++) queue[base + k].list = 0xffffffffu;      // (used == kQChunk before the first chunk)
 					base = atomicAdd(qcount, kQChunk); used = 0;
-					if ((uint64_t)base + kQChunk > (uint64_t)qcap) { base = 0; used = kQChunk; s_qbase[wv] = 0; s_qused[wv] = kQChunk; }      // queue full
+					// queue full: this wave stops asking (the counter must not wrap around into chunks already handed out)
+					if ((uint64_t)base + kQChunk > (uint64_t)qcap) { base = 0; used = kQChunk; s_qbase[wv] = 0; s_qused[wv] = kQChunk; s_qfull[wv] = 1; }
 					else s_qbase[wv] = base;
 				}
 				if (used + n <= kQChunk) { s_qused[wv] = used + n; idx0 = base + used; }

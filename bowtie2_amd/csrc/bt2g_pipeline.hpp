@@ -11,6 +11,7 @@
 #ifndef BT2G_PIPELINE_HPP_
 #define BT2G_PIPELINE_HPP_
 
+#include <atomic>
 #include <zlib.h>
 #include <sys/stat.h>
 
@@ -186,10 +187,10 @@ public:
 		if (paths_.size() != 1 || paths_[0] == "-" || !f_) { err = "--shard-bytes needs one regular reads file per -U / -1 / -2"; return false; }
 		if (!gzdirect(f_)) { err = "--shard-bytes cannot be used with compressed input (" + paths_[0] + ")"; return false; }
 		if (b < a || gzseek(f_, (z_off_t)a, SEEK_SET) < 0) { err = "--shard-bytes: cannot seek in " + paths_[0]; return false; }
-		ranged_ = true; left_ = b - a; bytes_read_ = 0;
+		ranged_ = true; left_ = b - a; bytes_read_.store(0, std::memory_order_relaxed);
 		return true;
 	}
-	uint64_t bytes_read() const { return bytes_read_; }      // bytes taken from the file(s) so far
+	uint64_t bytes_read() const { return bytes_read_.load(std::memory_order_relaxed); }      // bytes taken from the file(s) so far (read by the driver while the prefetch thread refills)
 	uint64_t plain_size() const {
 		if (paths_.size() != 1 || paths_[0] == "-" || !f_ || !gzdirect(f_)) return 0;
 		struct stat st_;
@@ -238,7 +239,7 @@ private:
 		reserve(old + want + 1);
 		int got = want ? gzread(f_, buf_.get() + old, (unsigned)want) : 0;
 		len_ = old + (got > 0 ? (size_t)got : 0);
-		if (got > 0) { bytes_read_ += (uint64_t)got; if (ranged_) left_ -= (uint64_t)got; }
+		if (got > 0) { bytes_read_.fetch_add((uint64_t)got, std::memory_order_relaxed); if (ranged_) left_ -= (uint64_t)got; }
 		if (got < 0) io_error_ = true;          // corrupt / truncated .gz: the run must fail, not end early (the reference aborts too)
 		if (got <= 0) {
 			if (next_path_ < paths_.size()) {
@@ -260,7 +261,8 @@ private:
 	bool unterminated_ = false;
 	bool io_error_ = false;
 	bool ranged_ = false;
-	uint64_t left_ = 0, bytes_read_ = 0;
+	uint64_t left_ = 0;
+	std::atomic<uint64_t> bytes_read_{0};
 public:
 	bool last_line_unterminated() const { return unterminated_; }
 	bool io_error() const { return io_error_; }

@@ -24,6 +24,7 @@ Either way the summary counters are all-reduced and rank 0 prints the reference'
 to the 1-rank run (tests/test_multi_gpu_cpu.py).
 """
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -352,10 +353,12 @@ def main(argv=None):
     merge_failed = 0
     try:
         common = [engine] + args + ["--shard-index", idx, "--pg-cmdline", pg]
-        if not any(a in ("-p", "--threads") or a.startswith("--threads=") for a in args):
+        if not any(a in ("-p", "--threads") or a.startswith("--threads=") or re.match(r"^-p\d+$", a) for a in args):
             # host threads (FASTQ parsing, SAM formatting) of this rank's executable: its share of the cores the job may use, so that
             # N ranks do not each start as many threads as the node has cores
-            common += ["-p", str(max(1, usable_cores() // max(1, world)))]
+            # the ranks of THIS node share its cores (a multi-node job has more ranks than that)
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0")) or world
+            common += ["-p", str(max(1, usable_cores() // max(1, local_world)))]
         if backend == "nccl":
             common += ["--gpu", str(local_rank)]
         if rank != 0 and "--no-hd" not in args:
