@@ -47,13 +47,26 @@ constexpr int kMaxOffs     = 64;    // seed offsets per strand
 constexpr int kMaxMm1      = 1024;  // 1-mismatch end-to-end hits kept (a simple-repeat read has hundreds)
 constexpr int kMaxRanges   = 2 * kMaxOffs;   // seed positions (both strands)
 constexpr int kMaxSat2     = 4096;  // seed-hit ranges of one round: one per position with -N 0, up to ~100 per position with -N 1
-constexpr int kMaxSatpos   = 1856;  // maxIters(400 + 20*(k-1), k <= 64) + ranges + slack
 constexpr int kMaxEdits    = 200;
+#ifdef BT2G_CLASS_BIG_K
+// The worker's many-alignments class (Makefile: bt2g_align_kernel_bk.o, namespace bt2g_bk): -k above 64 and -a.  The reference has no ceiling on
+// -k (aln_sink.cpp:33-326); this class holds BT2G_MAX_KHITS alignments per read (per mate and per pair list), the extension list that
+// maxIters = 400 + 20 (k - 1) rows can fill, and the sampler lists that go with it: 23 MB of arena per wave instead of 7, so bt2g_align_batch gives
+// it only the batches that ask for it (their result records are 1.3 MB per read: the driver cuts such batches to ~1 700 reads).
+constexpr int kMaxSatpos   = 20608; // maxIters(400 + 20*(k-1), k <= 1000) + ranges + slack
+constexpr int kMaxRedAnchor = 4160;
+constexpr int kMaxAlnsU    = 2080;
+constexpr int kMaxAlns     = 1040;  // BT2G_MAX_KHITS + slack (the sink stops at k; -a flags a read that has more)
+constexpr int kMaxDiags    = 8192;
+constexpr int kListArena   = 1 << 20;
+#else
+constexpr int kMaxSatpos   = 1856;  // maxIters(400 + 20*(k-1), k <= 64) + ranges + slack
 constexpr int kMaxRedAnchor = 1280;  // alignments remembered by the paired-end redundancy set
 constexpr int kMaxAlnsU    = 640;   // unpaired alignments kept per mate of a pair: every distinct opposite-mate alignment found during mate rescue lands here
-constexpr int kMaxAlns     = 160;   // alignments kept by the sink (-M 50 -> at most 51)
+constexpr int kMaxAlns     = 160;   // alignments kept by the sink (-M 50 -> at most 51; -k <= 64)
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 65536; // uint32 slots for Random1toN lists (swap lists of small ranges, seen lists bounded by max_iters, converted lists)
+#endif
 constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
 constexpr int kMaxCols     = 1100;  // DP columns a launch holds unless the caller asks for more: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*gaps
 // Widest DP window any launch can hold (bt2g_align_params::max_dp_cols asks for it).  The per-column state of the window in flight -- the

@@ -2261,7 +2261,7 @@ struct Aligner {
 	// getReport, selectByScore (RNG!), and what the SAM line needs.
 	BT2_HDN void finish(BT2_G ReadResult& out_) {
 		BT2_G ReadResult& out = *Plat::uni_ptr(&out_);
-		// -a: the reference reports every alignment found; this build's result record holds khits (64) of them
+		// -a: the reference reports every alignment found; this build's result record holds khits (BT2G_MAX_KHITS) of them
 		if (PRM.all_hits && HOT.n_alns > (uint32_t)PRM.khits) ovf(32);
 		out.status = (uint8_t)HOT.err;
 		out.filt = (uint8_t)RPR.filt;
@@ -2287,6 +2287,8 @@ struct Aligner {
 		const uint32_t sz = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;
 		uint32_t num = nunpair1 < sz ? nunpair1 : sz;
 		BT2_G uint32_t* idx = WK.lists;      // scratch (Random1toN lists are dead by now)
+		if (sz > 64u) Plat::order_by_score(WK.alns, sz, idx, idx + sz);      // (-k / -a with many alignments: every lane ranks its own)
+		else {
 		for (uint32_t i = 0; i < sz; i++) idx[i] = i;
 		for (uint32_t i = 1; i < sz; i++) {          // descending by (score, index)
 			const uint32_t v = idx[i];
@@ -2294,6 +2296,7 @@ struct Aligner {
 			while (j > 0 && (WK.alns[idx[j - 1]].score < WK.alns[v].score ||
 			                 (WK.alns[idx[j - 1]].score == WK.alns[v].score && idx[j - 1] < v))) { idx[j] = idx[j - 1]; j--; }
 			idx[j] = v;
+		}
 		}
 		auto shuffle = [&](uint32_t begin, uint32_t n) {
 			if (n < 2) return;

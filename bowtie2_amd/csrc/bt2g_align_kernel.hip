@@ -961,6 +961,23 @@ struct DevPlat {
 		for (uint32_t i = threadIdx.x & 63; i < nw; i += 64) d[i] = s[i];
 		wave_fence();
 	}
+	// idx[0..n) <- the alignments' indices, descending by (score, index) -- AlnSinkWrap::selectByScore sorts (score, index) pairs ascending and reverses:
+	// the scores go to `tmp`, every lane counts the alignments that come before each of its own
+	static __device__ __attribute__((noinline)) void order_by_score(const BT2_G AlnRes* alns_, uint32_t n_, BT2_G uint32_t* idx_, BT2_G uint32_t* tmp_) {
+		const BT2_G AlnRes* alns = uni_ptr(alns_); BT2_G uint32_t* idx = uni_ptr(idx_); BT2_G uint32_t* tmp = uni_ptr(tmp_);
+		const uint32_t n = uni(n_), lane = threadIdx.x & 63;
+		wave_fence();
+		for (uint32_t i = lane; i < n; i += 64) gst(tmp + i, (uint32_t)gld(&alns[i].score));
+		wave_fence();
+		for (uint32_t base = 0; base < n; base += 64) {
+			const uint32_t i = base + lane;
+			const int32_t si = i < n ? (int32_t)gld(tmp + i) : 0;
+			uint32_t rank = 0;
+			for (uint32_t j = 0; j < n; j++) { const int32_t sj = (int32_t)gld(tmp + j); rank += (sj > si || (sj == si && j > i)) ? 1u : 0u; }
+			if (i < n) gst(idx + rank, i);
+		}
+		wave_fence();
+	}
 	// Candidate cells of the last row, sorted by (score desc, col desc): every lane ranks its own cells
 	// against the whole row (LDS broadcast reads) and writes them straight to their final slot.
 	static __device__ __forceinline__ uint32_t gather_sort(BtCand* cands, uint32_t cap, uint32_t rows, uint32_t cols, int64_t minsc_dp) {
@@ -1619,28 +1636,39 @@ template hipError_t launch_align<uint64_t>(const DevIndex<uint64_t>&, const Alig
 // plain-C entry points below (the index descriptor, parameter blocks and pre-computation tables have the same layout in both: same headers).
 // 49 % of a wave's cycles are spent waiting on a counter and 4 waves per SIMD cannot cover that; with 96 registers and the small
 // dynamic LDS of an end-to-end batch, 5 waves per SIMD are resident.
+// (A third compilation, bt2g_align_kernel_bk.o: -Dbt2g=bt2g_bk -DBT2G_KCLASS_BK -DBT2G_CLASS_BIG_K, is the many-alignments class: -k above 64 and -a.)
+#define BT2G_CLASS_ENTRIES(PFX) \
+extern "C" hipError_t PFX##_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams, \
+                                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride, \
+                                         uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof, \
+                                         const void* pre, uint32_t max_read_len, uint32_t max_cols, uint32_t lds_per_wave, hipStream_t st) { \
+	using namespace bt2g; \
+	const PreComp& pc = *reinterpret_cast<const PreComp*>(pre); \
+	return off_size == 4 \
+		? launch_align(*reinterpret_cast<const DevIndex<uint32_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, lds_per_wave, st) \
+		: launch_align(*reinterpret_cast<const DevIndex<uint64_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, lds_per_wave, st); \
+} \
+extern "C" uint32_t PFX##_waves_per_cu(void) { return bt2g::align_waves_per_cu(); } \
+/* static LDS of the unpaired worker kernels of this class (the larger of the two index widths); 0xffffffff if the runtime will not say */ \
+extern "C" uint32_t PFX##_static_lds(void) { \
+	hipFuncAttributes a32, a64; \
+	if (hipFuncGetAttributes(&a32, reinterpret_cast<const void*>(&bt2g::k_align_reads<uint32_t>)) != hipSuccess) return 0xffffffffu; \
+	if (hipFuncGetAttributes(&a64, reinterpret_cast<const void*>(&bt2g::k_align_reads<uint64_t>)) != hipSuccess) return 0xffffffffu; \
+	return (uint32_t)(a32.sharedSizeBytes > a64.sharedSizeBytes ? a32.sharedSizeBytes : a64.sharedSizeBytes); \
+} \
+extern "C" uint64_t PFX##_work_bytes(void) { return bt2g::align_work_bytes(); } \
+/* what the class holds: longest read, seed positions per strand, alignments per read */ \
+extern "C" uint32_t PFX##_max_len(void) { return (uint32_t)bt2g::kMaxLen; } \
+extern "C" uint32_t PFX##_max_offs(void) { return (uint32_t)bt2g::kMaxOffs; } \
+extern "C" uint32_t PFX##_max_alns(void) { return (uint32_t)bt2g::kMaxAlns; } \
+/* the arena of one wave of this class (its Work is its own) */ \
+extern "C" void PFX##_scratch_sizes(uint32_t max_len, int paired, uint32_t maxhalf, uint32_t max_cols, uint64_t* mat_bytes, uint64_t* mask_bytes, uint64_t* pmask_bytes, uint64_t* arena_stride) { \
+	bt2g::align_scratch_sizes(max_len, paired != 0, maxhalf, max_cols, *mat_bytes, *mask_bytes, *pmask_bytes, *arena_stride); \
+}
 #ifdef BT2G_KCLASS_W5
-extern "C" hipError_t bt2g_w5_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams,
-                                           uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
-                                           uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
-                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, uint32_t lds_per_wave, hipStream_t st) {
-	using namespace bt2g;
-	const PreComp& pc = *reinterpret_cast<const PreComp*>(pre);
-	return off_size == 4
-		? launch_align(*reinterpret_cast<const DevIndex<uint32_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, lds_per_wave, st)
-		: launch_align(*reinterpret_cast<const DevIndex<uint64_t>*>(ix), *P, *rd, d_rparams, d_results, result_stride, d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, d_next, d_prof, pc, max_read_len, max_cols, lds_per_wave, st);
-}
-extern "C" uint32_t bt2g_w5_waves_per_cu(void) { return bt2g::align_waves_per_cu(); }
-// static LDS of the unpaired worker kernels of this class (the larger of the two index widths); 0xffffffff if the runtime will not say
-extern "C" uint32_t bt2g_w5_static_lds(void) {
-	hipFuncAttributes a32, a64;
-	if (hipFuncGetAttributes(&a32, reinterpret_cast<const void*>(&bt2g::k_align_reads<uint32_t>)) != hipSuccess) return 0xffffffffu;
-	if (hipFuncGetAttributes(&a64, reinterpret_cast<const void*>(&bt2g::k_align_reads<uint64_t>)) != hipSuccess) return 0xffffffffu;
-	return (uint32_t)(a32.sharedSizeBytes > a64.sharedSizeBytes ? a32.sharedSizeBytes : a64.sharedSizeBytes);
-}
-extern "C" uint64_t bt2g_w5_work_bytes(void) { return bt2g::align_work_bytes(); }
-// what the class holds: longest read, seed positions per strand
-extern "C" uint32_t bt2g_w5_max_len(void) { return (uint32_t)bt2g::kMaxLen; }
-extern "C" uint32_t bt2g_w5_max_offs(void) { return (uint32_t)bt2g::kMaxOffs; }
+BT2G_CLASS_ENTRIES(bt2g_w5)
+#endif
+#ifdef BT2G_KCLASS_BK
+BT2G_CLASS_ENTRIES(bt2g_bk)
 #endif
 

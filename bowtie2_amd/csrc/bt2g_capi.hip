@@ -309,6 +309,14 @@ extern "C" uint32_t bt2g_w5_static_lds(void);
 extern "C" uint64_t bt2g_w5_work_bytes(void);
 extern "C" uint32_t bt2g_w5_max_len(void);
 extern "C" uint32_t bt2g_w5_max_offs(void);
+// ... and its many-alignments class (-k above 64, -a: bt2g_align_kernel.hip compiled with BT2G_CLASS_BIG_K, its own Work and arena)
+extern "C" hipError_t bt2g_bk_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams,
+                                           uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
+                                           uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
+                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, uint32_t lds_per_wave, hipStream_t st);
+extern "C" uint32_t bt2g_bk_waves_per_cu(void);
+extern "C" uint32_t bt2g_bk_max_alns(void);
+extern "C" void bt2g_bk_scratch_sizes(uint32_t max_len, int paired, uint32_t maxhalf, uint32_t max_cols, uint64_t* mat_bytes, uint64_t* mask_bytes, uint64_t* pmask_bytes, uint64_t* arena_stride);
 
 static_assert(sizeof(bt2g_mm1_hit) == sizeof(Mm1Hit) && offsetof(bt2g_mm1_hit, score) == offsetof(Mm1Hit, score) && offsetof(bt2g_mm1_hit, epos) == offsetof(Mm1Hit, epos) &&
               offsetof(bt2g_mm1_hit, echr) == offsetof(Mm1Hit, echr) && offsetof(bt2g_mm1_hit, eqchr) == offsetof(Mm1Hit, eqchr), "bt2g_mm1_hit is the kernels' Mm1Hit");
@@ -434,7 +442,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	int rc = need_loaded(c);
 	if (rc) return rc;
 	if (!reads || !params || (!d_rparams && reads->n_reads) || (!d_results && reads->n_reads)) return fail(c, BT2G_ERR_ARG, "bad argument");
-	if (params->khits < 1 || params->khits > 64) return fail(c, BT2G_ERR_UNSUPPORTED, "-k outside [1,64]");
+	if (params->khits < 1 || params->khits > BT2G_MAX_KHITS || (uint32_t)params->khits > bt2g_bk_max_alns()) return fail(c, BT2G_ERR_UNSUPPORTED, "-k outside [1,1000]");
+	const bool bigk = params->khits > 64;      // the many-alignments class: its own per-wave capacities (and arena), see bt2g_align.hpp at BT2G_CLASS_BIG_K
 	if (params->match_bonus < 0) return fail(c, BT2G_ERR_ARG, "negative match bonus");
 	if (params->maxhalf < 0 || params->maxhalf > 255 || params->gapbar < 1 || params->rdgapo < 0 || params->rdgape < 0 || params->rfgapo < 0 || params->rfgape < 0 ||
 	    params->max_dp_streak < 0 || params->n_seed_rounds < 0 || params->seed_mms < 0 || params->seed_mms > 1)
@@ -488,15 +497,16 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	static const bool no_w5 = getenv("BT2G_NO_W5") != nullptr;
 	static const uint32_t kStaticLdsBytes = bt2g_w5_static_lds();
 	bool w5 = false;
-	if (!no_w5 && !params->paired && params->match_bonus == 0 && params->max_dp_cols <= kMaxCols && bt2g_w5_work_bytes() <= sizeof(Work) &&
+	if (!no_w5 && !bigk && !params->paired && params->match_bonus == 0 && params->max_dp_cols <= kMaxCols && bt2g_w5_work_bytes() <= sizeof(Work) &&
 	    max_read_len <= bt2g_w5_max_len() && max_seeds >= 1 && max_seeds <= bt2g_w5_max_offs()) {
 		const uint32_t need = max_read_len + 4u * (uint32_t)(params->maxhalf > 0 ? params->maxhalf : 0) + 1u + 4u;
 		const uint32_t lds_per_wave = (160u * 1024u) / (4u * 5u);
 		if (need <= (uint32_t)kMaxCols && kStaticLdsBytes < lds_per_wave && kStaticLdsBytes + hot_tail_bytes(need, false) <= lds_per_wave) { w5 = true; max_cols = need; }      // (kStaticLdsBytes is 0xffffffff when the runtime would not say)
 	}
-	align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
+	if (bigk) bt2g_bk_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, &mat_bytes, &mask_bytes, &pmask_bytes, &arena_stride);
+	else align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
 	// persistent waves (one read at a time each) pull reads from a device-side queue
-	uint32_t n_waves = c->n_cu * (w5 ? bt2g_w5_waves_per_cu() : align_waves_per_cu());
+	uint32_t n_waves = c->n_cu * (w5 ? bt2g_w5_waves_per_cu() : bigk ? bt2g_bk_waves_per_cu() : align_waves_per_cu());
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
 	uint64_t need = arena_stride * n_waves;
 	if (need > S.arena_bytes) {
@@ -517,7 +527,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		S.arena_bytes = need;
 	}
 	// the epoch-tagged backtrace masks live in the arena across launches: (re)start from zero whenever its layout changes
-	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0) ^ (w5 ? 1ull << 62 : 0);
+	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0) ^ (w5 ? 1ull << 62 : 0) ^ (bigk ? 1ull << 61 : 0);
 	if (layout != S.arena_layout) {
 		e = hipMemsetAsync(S.d_arena, 0, S.arena_bytes, st);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(worker arena)");
@@ -627,6 +637,9 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (w5)
 		e = bt2g_w5_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
 		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, (160u * 1024u) / bt2g_w5_waves_per_cu(), st);
+	else if (bigk)
+		e = bt2g_bk_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
+		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, (160u * 1024u) / bt2g_bk_waves_per_cu(), st);
 	else
 	e = (c->off_size == 4)
 		? launch_align(c->ix32, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, (160u * 1024u) / align_waves_per_cu(), st)

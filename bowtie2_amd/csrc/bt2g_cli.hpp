@@ -378,7 +378,7 @@ inline std::string parse_cli(int argc, char** argv, Options& opt, CliExtra& ex) 
 		else return "unsupported option " + a;
 		if (!err.empty()) return err;
 	}
-	if (opt.khits > 64) return "-k above 64 is not supported by this build";
+	if (opt.khits > BT2G_MAX_KHITS) return "-k above 1000 is not supported by this build";
 	// bt2_search.cpp:1699-1718, 1804-1807
 	if (!opt.local && opt.sc_unmapped) return "ERROR: --soft-clipped-unmapped-tlen can only be set for local alignments.";
 	if (!saw_bam && opt.preserve_tags) return "--preserve_tags can only be used when aligning BAM reads.";

@@ -146,7 +146,8 @@ struct Options {
 		P.mm_type = mm_rounded ? 2 : (cmm ? 1 : 3); P.mm_max = mp_max; P.mm_min = (cmm && !mm_rounded) ? mp_max : mp_min; P.n_pen = np;
 		P.rdgapo = rdg_const + rdg_linear; P.rdgape = rdg_linear; P.rfgapo = rfg_const + rfg_linear; P.rfgape = rfg_linear;
 		P.gapbar = gbar; P.match_bonus = local ? ma : 0;
-		P.khits = all_hits ? 64 : khits; P.mhits = (saw_k || all_hits) ? 0 : mhits; P.all_hits = all_hits ? 1 : 0; P.seed_mms = seed_mms; P.overhang = report_overhangs ? 1 : 0;
+		// (-a: every alignment found, up to what a result record of the many-alignments class holds)
+		P.khits = all_hits ? BT2G_MAX_KHITS : khits; P.mhits = (saw_k || all_hits) ? 0 : mhits; P.all_hits = all_hits ? 1 : 0; P.seed_mms = seed_mms; P.overhang = report_overhangs ? 1 : 0;
 		P.paired = paired ? 1 : 0;
 		P.pe_policy = (mate1fw && mate2fw) ? 1 : ((!mate1fw && !mate2fw) ? 2 : (mate1fw ? 3 : 4));   // gMate1fw/gMate2fw -> PE_POLICY_* (bt2_search.cpp:1841-1851)
 		P.pe_maxfrag = max_insert; P.pe_minfrag = min_insert;

@@ -224,11 +224,13 @@ int bt2g_dp_fill(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_problem *d
  * backtrace, redundancy checks, -M/-k reporting state and the final selection -- one
  * wavefront per read, the reference's RNG draw order reproduced, so that the SAM written
  * from these records is byte-identical to the reference's.  Scope (rejected otherwise by the
- * host): reads <= BT2G_MAX_READ_LEN, at most 64 alignments per read, opposite-mate windows <= 1100 columns, or up to BT2G_MAX_DP_COLS when bt2g_align_params::max_dp_cols asks for it (a read or pair
+ * host): reads <= BT2G_MAX_READ_LEN, at most BT2G_MAX_KHITS alignments per read (a batch with bt2g_align_params::khits above 64 runs in the worker's
+ * many-alignments class: larger per-wave capacities, result records of khits alignments each -- keep such batches small), opposite-mate windows <= 1100 columns, or up to BT2G_MAX_DP_COLS when bt2g_align_params::max_dp_cols asks for it (a read or pair
  * over a limit comes back with status bit 0 set).
  */
 #define BT2G_MAX_READ_LEN 512
 #define BT2G_MAX_EDITS    200
+#define BT2G_MAX_KHITS    1000   /* -k ceiling of this build (the reference has none, aln_sink.cpp:33-326); -a reports up to this many and flags a read that has more */
 
 /* what bt2_search.cpp keeps in file statics (:69-266), for the options that reach the worker */
 typedef struct {

@@ -75,6 +75,10 @@ struct HostPlat {
 		for (uint32_t j = 0; j < n; j++) if (!in[j]) out[c++] = j;
 	}
 	static void iota_u32(uint32_t* p, uint32_t n) { for (uint32_t i = 0; i < n; i++) p[i] = i; }
+	static void order_by_score(const AlnRes* alns, uint32_t n, uint32_t* idx, uint32_t*) {
+		for (uint32_t i = 0; i < n; i++) idx[i] = i;
+		std::sort(idx, idx + n, [&](uint32_t a, uint32_t b) { return alns[a].score != alns[b].score ? alns[a].score > alns[b].score : a > b; });      // descending by (score, index)
+	}
 	static void copy_words(void* dst, const void* src, uint32_t nwords) { memcpy(dst, src, (size_t)nwords * 4); }
 	static void load_last_row(const uint32_t* mat, uint32_t R, uint32_t rows, uint32_t cols, bool wide) {
 		for (uint32_t j = 0; j < cols; j++) {

@@ -22,7 +22,7 @@ P
 for step in "$@"; do
   IFS=: read -r what a b <<< "$step"
   case $what in
-  tests) (timeout ${PYTEST_TIMEOUT:-1500} python -m pytest -x -q -m gpu ${a:+${a//,/ }} ${a:-tests} 2>&1 | tail -8) | tee $O/pytest_${b:-gpu}.log ;;
+  tests) (timeout ${PYTEST_TIMEOUT:-1500} python -m pytest -x -q -m gpu $([ -n "$a" ] && echo "${a//,/ }" || echo tests) 2>&1 | tail -8) | tee $O/pytest_${b:-gpu}.log ;;
   smoke) (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -4) | tee $O/smoke.log ;;
   bench) n=${a:-default}; (env ${b//,/ } timeout ${BENCH_TIMEOUT:-600} python bench.py ${BENCH_ARGS:---steps 6 --warmup 2 --parity-only} 2>$O/bench_$n.err | tail -1) > $O/bench_$n.json; summ $O/bench_$n.json | tee -a $O/summary.txt ;;
   full) n=${a:-full}; (timeout ${BENCH_TIMEOUT:-1500} python bench.py 2>$O/bench_$n.err | tail -1) > $O/bench_$n.json; summ $O/bench_$n.json | tee -a $O/summary.txt ;;
