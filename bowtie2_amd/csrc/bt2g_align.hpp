@@ -87,11 +87,7 @@ using ReadParams  = bt2g_read_params;
 using Edit        = bt2g_edit;
 using AlnRes      = bt2g_aln;
 using ReadResult  = bt2g_read_result;
-#ifndef BT2G_CLASS_MAX_LEN
-static_assert(kMaxLen == BT2G_MAX_READ_LEN && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
-#else
 static_assert(kMaxLen <= BT2G_MAX_READ_LEN && kMaxLen % 4 == 0 && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
-#endif
 
 // ---------------------------------------------------------------------------------------
 // RandomSource (random_source.h:34-159)

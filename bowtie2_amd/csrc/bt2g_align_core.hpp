@@ -64,7 +64,8 @@ struct Aligner {
 	}
 
 	// one_mm_search() from the batch kernel's output; false if a list overflowed
-	BT2_HD bool one_mm_pre(bool nofw, bool norc) {
+	BT2_HD bool one_mm_pre(bool nofw_, bool norc_) {
+		const bool nofw = Plat::uni((int)nofw_) != 0, norc = Plat::uni((int)norc_) != 0;
 		const uint32_t ridx = Plat::uni(ST.ridx);
 		const uint32_t n4 = Plat::uni(*reinterpret_cast<const uint32_t*>(PRE->mm1_n + (uint64_t)ridx * 4));      // the four list lengths, one load
 		const uint32_t n[4] = {n4 & 0xffu, (n4 >> 8) & 0xffu, (n4 >> 16) & 0xffu, n4 >> 24};
@@ -1470,23 +1471,24 @@ struct Aligner {
 		} prof{0, 0, 0, 0};
 		// read, qualities and reference window as per-lane registers (4 bytes per lane per register): the step
 		// loop then reads them with v_readlane instead of going to LDS
-		typename Plat::LaneReg sqw[2], qlw[2], rfw[3];
+		constexpr uint32_t kSqRegs = ((uint32_t)kMaxLen + 255u) / 256u, kRfRegs = kSqRegs + 1u, kRfWin = 256u * kRfRegs;      // 256 bytes per register
+		typename Plat::LaneReg sqw[kSqRegs], qlw[kSqRegs], rfw[kRfRegs];
 		// The backtrace's branch stack (btnstack_, DpNucFrame) and the per-cell H/E/F choice masks (SSEMatrix::masks_ bits 1-12) are DEAD STATE
 		// in the reference: every cell a walk visits gets reportedThrough set in the same visit that stores its choice mask
 		// (aligner_swsse_ee_u8.cpp:1331-1338 tests reportedThrough first, :1556 sets it for every visited cell), so (a) a choice mask is never read
 		// again -- any later visit stops at "reportedThru" before it looks -- and (b) a popped frame resumes in a cell this very walk has marked,
 		// fails at once and pops the next (:1560-1586): a walk that meets a marked cell fails, after one more loop iteration per frame on the
 		// stack (they count as backtrace cells, met.btcell).  What a walk needs of the matrix is the predecessor bits and ONE bit per cell.
-		for (uint32_t k = 0; k < 2; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
-		// the walk moves left from its start column by at most rows + gaps columns: three registers (768 columns) cover every window of an
+		for (uint32_t k = 0; k < kSqRegs; k++) { sqw[k] = Plat::lanes_load(HOT.seq, kMaxLen, k * 64); qlw[k] = Plat::lanes_load(HOT.qual, kMaxLen, k * 64); }
+		// the walk moves left from its start column by at most rows + gaps columns: one register more than the read needs (768 columns in the general class) covers every window of an
 		// unpaired read from column 0 (rf_c0 = 0); only a candidate past column 767 of a wide opposite-mate window needs them re-based
 		uint32_t rf_c0_ = 0;
-		for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64);
+		for (uint32_t k = 0; k < kRfRegs; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64);
 		auto byte_of = [](typename Plat::LaneReg* arr, uint32_t nreg, uint32_t idx) -> int {
 			const uint32_t word = idx >> 2;
 			uint32_t v = Plat::lane(arr[0], word & 63);
-			if (nreg > 1 && (word >> 6) == 1) v = Plat::lane(arr[1], word & 63);
-			if (nreg > 2 && (word >> 6) == 2) v = Plat::lane(arr[2], word & 63);
+#pragma unroll
+			for (uint32_t k = 1; k < kRfRegs; k++) if (k < nreg && (word >> 6) == k) v = Plat::lane(arr[k], word & 63);
 			return (int)((v >> ((idx & 3) * 8)) & 0xff);
 		};
 		// one backtrace from cell (row, col), whose tile the caller fetched
@@ -1561,9 +1563,9 @@ struct Aligner {
 						continue;
 					}
 				}
-				const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
-				const int refm = byte_of(rfw, 3, col - rf_c0);
-				const int readq = byte_of(qlw, 2, fw ? row : rdlen - 1 - row);
+				const int readc = fw ? byte_of(sqw, kSqRegs, row) : comp4(byte_of(sqw, kSqRegs, rdlen - 1 - row));
+				const int refm = byte_of(rfw, kRfRegs, col - rf_c0);
+				const int readq = byte_of(qlw, kSqRegs, fw ? row : rdlen - 1 - row);
 				// Flags are ints combined with & and |: the control code is wave-uniform and this keeps it on 32-bit scalar
 				// compares/selects instead of 64-bit lane-mask juggling.
 				int empty = 0, can_move_thru = 1, branch = 0;
@@ -1706,14 +1708,14 @@ struct Aligner {
 			const uint64_t tt0_ = now();
 			struct TailTimer { uint64_t t0; BT2_HD ~TailTimer() { if (PRM.profile) HOT.t_bt[3] += now() - t0; } } tail_timer_{tt0_};
 			{
-				const int readc = fw ? byte_of(sqw, 2, row) : comp4(byte_of(sqw, 2, rdlen - 1 - row));
+				const int readc = fw ? byte_of(sqw, kSqRegs, row) : comp4(byte_of(sqw, kSqRegs, rdlen - 1 - row));
 				if (col < rf_c0) { ovf(21); return false; }
-				const int refm = byte_of(rfw, 3, col - rf_c0);
+				const int refm = byte_of(rfw, kRfRegs, col - rf_c0);
 				const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
 				if (m != 1) {
 					Edit& e = ned[nned++];
 					e.pos = (uint16_t)row; e.chr = (uint8_t)mask2chr(refm); e.qchr = code2chr(readc); e.type = EDIT_MM;
-					score -= sc_mm(S, readc, refm, byte_of(qlw, 2, fw ? row : rdlen - 1 - row) - 33);
+					score -= sc_mm(S, readc, refm, byte_of(qlw, kSqRegs, fw ? row : rdlen - 1 - row) - 33);
 				} else score += S.match_bonus;
 				if (m == -1) ns++;
 			}
@@ -1791,10 +1793,10 @@ struct Aligner {
 			res.nned = 0;
 			const int32_t cscore = c.score;
 			bool ret;
-			const uint32_t need_c0 = Plat::uni((c.col + 1u > 768u) ? (((uint32_t)c.col + 1u - 768u + 3u) & ~3u) : 0u);
-			if (need_c0 > 0 && rows + 250u > 764u) { ovf(17); ret = false; }   // the walk could leave the 768-column window (rows + read gaps)
+			const uint32_t need_c0 = Plat::uni((c.col + 1u > kRfWin) ? (((uint32_t)c.col + 1u - kRfWin + 3u) & ~3u) : 0u);
+			if (need_c0 > 0 && rows + 250u > kRfWin - 4u) { ovf(17); ret = false; }   // the walk could leave the window the registers hold (rows + read gaps)
 			else {
-				if (need_c0 != rf_c0_) { rf_c0_ = need_c0; for (uint32_t k = 0; k < 3; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64 + (need_c0 >> 2)); }
+				if (need_c0 != rf_c0_) { rf_c0_ = need_c0; for (uint32_t k = 0; k < kRfRegs; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64 + (need_c0 >> 2)); }
 				const uint64_t tw_ = now();
 				ret = walk(c.row, c.col, tile, tile_hi);
 				if (PRM.profile) { const uint64_t dt_ = now() - tw_; HOT.t_bt[0] += dt_; if (ret) { HOT.t_bt[1] += dt_; HOT.t_bt[2]++; } }

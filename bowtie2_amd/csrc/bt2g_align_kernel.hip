@@ -513,6 +513,7 @@ struct DevPlat {
 	static __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
 	static __device__ __forceinline__ uint32_t n_lanes() { return 64u; }
 	static __device__ __forceinline__ bool any(bool b) { return __ballot(b) != 0ull; }
+	static __device__ __forceinline__ void sync() { wave_fence(); }      // what the lanes wrote one entry each is read by all afterwards
 	static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 	static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 	static __device__ __forceinline__ uint64_t uni(uint64_t v) {

@@ -49,6 +49,7 @@ struct HostPlat {
 	static uint32_t lane_id() { return 0; }
 	static uint32_t n_lanes() { return 1; }
 	static bool any(bool b) { return b; }
+	static void sync() {}
 	static std::vector<uint16_t>& local_h() { static std::vector<uint16_t> v; return v; }      // H of the last local fill (host only)
 	static std::vector<uint8_t>& local_ef() { static std::vector<uint8_t> v; return v; }        // BT2G_CHECK_LOCAL_PK: bit 0 = E > 0, bit 1 = F > 0 of the last local fill
 	template <typename T> static T* uni_ptr(T* p) { return p; }
