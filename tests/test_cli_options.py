@@ -94,7 +94,7 @@ def test_options_match_reference_hostsim(hostsim, idx, tmp_path):
 
 
 def test_unsupported_options_are_refused(hostsim):
-    for opts in (["-1", "a.fq"], ["-f", "-1", "a.fa", "-2", "b.fa"], ["-N", "2"], ["-k", "100"], ["--frobnicate"], ["-d"], ["-d", "-k", "2", "--no-exact-upfront", "--no-1mm-upfront"]):
+    for opts in (["-1", "a.fq"], ["-f", "-1", "a.fa", "-2", "b.fa"], ["-N", "2"], ["-k", "1001"], ["--frobnicate"], ["-d"], ["-d", "-k", "2", "--no-exact-upfront", "--no-1mm-upfront"]):
         p = subprocess.run([hostsim] + opts + ["-x", os.path.join(GOLD, "tiny_s"), "-U", FQ], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert p.returncode != 0 and p.stdout == "", opts
 
