@@ -474,6 +474,11 @@ def e2e_leg(base, large, fq, preset, threads, resident_rate, work, par):
     time.sleep(float(os.environ.get("BT2_BENCH_E2E_SETTLE_S", "8")))
     runs = []
     for _ in range(int(os.environ.get("BT2_BENCH_E2E_RUNS", "3"))):
+        # every run writes a fresh file onto a quiet disk: truncating the previous run's 10 GB output, and its dirty pages still on their way
+        # to the disk, cost the next run a second at either end (session r05z: 5.0 M reads/s for the first run, 3.5 M for the two behind it)
+        if os.path.exists(out):
+            os.remove(out)
+        os.sync()
         t, p = run_timed(cmd)
         mm = re.search(r"index load ([\d.]+) s; search ([\d.]+) s wall, (\d+) reads -> (\d+) reads/s after the load", p.stderr)
         runs.append((int(mm.group(4)) if mm else -1, t, p, mm))
@@ -798,6 +803,10 @@ def main():
     last = {}
     kern_times = []
     depth = max(1, args.pipeline) if dist is None else 1      # (the N-GPU path keeps one step in flight: its RCCL gather sits inside the step)
+    if args.warmup < depth:
+        # every stream's working set is created (its arena allocated and zeroed) by its first batch: one untimed step per stream in flight
+        log("[bench] --warmup raised from %d to %d: one untimed step per stream in flight" % (args.warmup, depth))
+        args.warmup = depth
     streams = [cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [cuda.current_stream()]
     for s_ in streams:
         s_.wait_stream(cuda.current_stream())
