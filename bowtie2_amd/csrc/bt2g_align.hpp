@@ -87,7 +87,7 @@ using ReadParams  = bt2g_read_params;
 using Edit        = bt2g_edit;
 using AlnRes      = bt2g_aln;
 using ReadResult  = bt2g_read_result;
-static_assert(kMaxLen <= BT2G_MAX_READ_LEN && kMaxLen % 4 == 0 && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
+static_assert(kMaxLen <= ((BT2G_MAX_READ_LEN + 63) & ~63) && kMaxLen % 4 == 0 && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
 
 // ---------------------------------------------------------------------------------------
 // RandomSource (random_source.h:34-159)
@@ -323,7 +323,7 @@ BT2_HD uint64_t dp_cell(uint32_t R, uint32_t i, uint32_t j) {
 // Local fills compute two cells per register (bt2g_local_pk.hpp): the read is cut into blocks of RB rows, block k belongs to lane k & 63 (low
 // halves for k < 64, high halves above) and meets column j in step t = j + k.  One byte per cell; the 64 low-half lanes' bytes of a (step, row in
 // block) are consecutive, then the 64 high-half ones: every store instruction of the fill writes 64 consecutive bytes.
-BT2_HD uint32_t dp_RB(uint32_t rows) { return (rows + 127) / 128; }
+BT2_HD uint32_t dp_RB(uint32_t rows) { const uint32_t r = (rows + 127) / 128; return r <= 4 ? r : r <= 8 ? 8u : 16u; }      // (what the packed fill is instantiated for: 1..4 up to 512 rows; 8 and 16 in the long-read class)
 BT2_HD uint64_t dp_cell_pk(uint32_t RB, uint32_t i, uint32_t j) {
 	const uint32_t k = i / RB, r = i % RB;
 	const uint64_t t = (uint64_t)j + k;

@@ -319,6 +319,75 @@ __device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, bool fw, u
 	return __shfl(best, (int)((rows - 1) / R));
 }
 
+// The same fill for reads of more than 512 rows (the long-read class: up to 32 rows per lane).  The per-row state is indexed at run time, i.e.
+// it lives in scratch memory: instantiating the register form for 12 ... 32 rows per lane did not finish compiling (round 5), and a read this
+// long is rare and slow whatever the fill does -- it fills millions of cells per window.  Same values, same matrix layout (dp_cell).
+__device__ __attribute__((noinline)) int fill_ee_i16_leaf_long(bool fw_, uint32_t rows_, uint32_t cols_, uint64_t* m64_, uint32_t R_) {
+	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
+	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
+	const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)R_);      // <= 32
+	const uint64_t pa = (uint64_t)reinterpret_cast<uintptr_t>(m64_);
+	uint64_t* scratch = reinterpret_cast<uint64_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa));
+	const AlignParams& P = g_P;
+	const int lane = threadIdx.x & 63;
+	const uint32_t nlanes = (rows + R - 1) / R;
+	uint32_t rowc[32];       // per row: read character | mismatch penalty << 8 | gap veto << 16
+	int Hprev[32], Eprev[32];
+	for (uint32_t r = 0; r < R; r++) {
+		const uint32_t i = (uint32_t)lane * R + r;
+		const bool valid = i < rows;
+		const int rdc = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
+		const int q = valid ? rd_qual(g_hot, g_hot.len, fw, i) - 33 : 0;
+		const int mmp = mm_penalty(P, q < 0 ? 0 : q);
+		const int veto = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 1 : 0;
+		rowc[r] = (uint32_t)rdc | ((uint32_t)(mmp & 0xff) << 8) | ((uint32_t)veto << 16);
+		Hprev[r] = kLo; Eprev[r] = kLo;
+	}
+	int myHlast = kLo, myFlast = kLo, upHdiag = kLo, refm = 0, best = kLo;
+	const uint32_t steps = cols + nlanes - 1;
+	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
+	const uint32_t last_r = (rows - 1) % R;
+	for (uint32_t t = 0; t < steps; t++) {
+		const int upH = __shfl_up(myHlast, 1);
+		const int upF = __shfl_up(myFlast, 1);
+		int upRef = __shfl_up(refm, 1);
+		if (lane == 0) upRef = (t < cols) ? dev_rf()[t] : 16;
+		refm = upRef;
+		const int j = (int)t - lane;
+		const bool active = j >= 0 && j < (int)cols && (uint32_t)lane < nlanes;
+		int refc = 4;
+		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
+		int hdiag = (lane == 0) ? 0x7fff : (j == 0 ? kLo : upHdiag);
+		int fin_h = upH, fin_f = upF;
+		uint64_t* base = scratch + ((uint64_t)t * R) * 64 + lane;
+		int hlast = kLo, flast = kLo, hbest = kLo;
+		for (uint32_t r = 0; r < R; r++) {
+			const uint32_t rc = rowc[r];
+			const int rdc = (int)(rc & 0xff), mmp = (int)((rc >> 8) & 0xff), veto = (int)((rc >> 16) & 1);
+			int pen;
+			if (rdc > 3 || refc > 3) pen = P.n_pen; else pen = (rdc == refc) ? -P.match_bonus : mmp;
+			const int hp = Hprev[r], ep = Eprev[r];
+			const int e = (j == 0) ? kLo : imax(subs16(ep, P.rdgape), veto ? kLo : subs16(hp, P.rdgapo));
+			int f;
+			if (lane == 0 && r == 0) f = kLo;
+			else f = veto ? kLo : imax(subs16(fin_f, P.rfgape), subs16(fin_h, P.rfgapo));
+			const int h = imax(imax(subs16(hdiag, pen), e), f);
+			hdiag = hp;
+			fin_h = h; fin_f = f;
+			if (active) {
+				base[r * 64] = (uint64_t)(uint16_t)h | ((uint64_t)(uint16_t)e << 16) | ((uint64_t)(uint16_t)f << 32);
+				Hprev[r] = h; Eprev[r] = e;
+				if (r == last_r) hbest = h;
+			}
+			hlast = h; flast = f;
+		}
+		if (active && lane_has_last) best = imax(best, hbest);
+		upHdiag = upH;
+		if (active) { myHlast = hlast; myFlast = flast; }
+	}
+	return __shfl(best, (int)((rows - 1) / R));
+}
+
 // Local-mode fill (alignNucleotidesLocalSseU8 / ...I16; they agree wherever the 8-bit kernel does not saturate): plain scores, floor 0,
 // two cells per register (bt2g_local_pk.hpp: the cell arithmetic and why a lane owns block `lane` in its low halves and block `lane + 64` in
 // its high halves).  What leaves a cell is its predecessor byte (PB_*, with the local kernels' `> floor` rule: a neighbour whose score is 0 is no
@@ -1160,12 +1229,24 @@ struct DevPlat {
 			case 1: best = fill_local_leaf<1, true>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 2: best = fill_local_leaf<2, true>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 3: best = fill_local_leaf<3, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+#ifdef BT2G_KCLASS_LR      // (dp_RB rounds up to what is instantiated)
+			case 4: best = fill_local_leaf<4, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 8: best = fill_local_leaf<8, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+			default: best = fill_local_leaf<16, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+#else
 			default: best = fill_local_leaf<4, true>(fw, rows, cols, m64, ms, emit, ecap); break;
+#endif
 		} else switch (dp_RB(rows)) {
 			case 1: best = fill_local_leaf<1, false>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 2: best = fill_local_leaf<2, false>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 3: best = fill_local_leaf<3, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+#ifdef BT2G_KCLASS_LR
+			case 4: best = fill_local_leaf<4, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			case 8: best = fill_local_leaf<8, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+			default: best = fill_local_leaf<16, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+#else
 			default: best = fill_local_leaf<4, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+#endif
 		}
 		best = uni(best);
 		wave_fence();
@@ -1346,7 +1427,12 @@ struct DevPlat {
 				case 5: best = fill_ee_i16_leaf<5>(fw, rows, cols, m64); break;
 				case 6: best = fill_ee_i16_leaf<6>(fw, rows, cols, m64); break;
 				case 7: best = fill_ee_i16_leaf<7>(fw, rows, cols, m64); break;
+#ifdef BT2G_KCLASS_LR
+				case 8: best = fill_ee_i16_leaf<8>(fw, rows, cols, m64); break;
+				default: best = fill_ee_i16_leaf_long(fw, rows, cols, m64, dp_R(rows)); break;
+#else
 				default: best = fill_ee_i16_leaf<8>(fw, rows, cols, m64); break;
+#endif
 			}
 			best = uni(best) - 0x7fff;
 			g_hot.n_dp_cells_full += rows * cols;
@@ -1671,5 +1757,8 @@ BT2G_CLASS_ENTRIES(bt2g_w5)
 #endif
 #ifdef BT2G_KCLASS_BK
 BT2G_CLASS_ENTRIES(bt2g_bk)
+#endif
+#ifdef BT2G_KCLASS_LR      // the long-read class: reads of 513 ... 1 999 bp (Makefile: bt2g_align_kernel_lr.o)
+BT2G_CLASS_ENTRIES(bt2g_lr)
 #endif
 

@@ -317,6 +317,15 @@ extern "C" hipError_t bt2g_bk_launch_align(int off_size, const void* ix, const b
 extern "C" uint32_t bt2g_bk_waves_per_cu(void);
 extern "C" uint32_t bt2g_bk_max_alns(void);
 extern "C" void bt2g_bk_scratch_sizes(uint32_t max_len, int paired, uint32_t maxhalf, uint32_t max_cols, uint64_t* mat_bytes, uint64_t* mask_bytes, uint64_t* pmask_bytes, uint64_t* arena_stride);
+// ... and its long-read class (reads of 513 ... 1 999 bp: bt2g_align_kernel.hip compiled for 2 048 rows, 128 seed positions per strand, 2 waves per SIMD)
+extern "C" hipError_t bt2g_lr_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams,
+                                           uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
+                                           uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, uint32_t n_waves, unsigned int* d_next, unsigned long long* d_prof,
+                                           const void* pre, uint32_t max_read_len, uint32_t max_cols, uint32_t lds_per_wave, hipStream_t st);
+extern "C" uint32_t bt2g_lr_waves_per_cu(void);
+extern "C" uint32_t bt2g_lr_max_len(void);
+extern "C" uint32_t bt2g_lr_max_offs(void);
+extern "C" void bt2g_lr_scratch_sizes(uint32_t max_len, int paired, uint32_t maxhalf, uint32_t max_cols, uint64_t* mat_bytes, uint64_t* mask_bytes, uint64_t* pmask_bytes, uint64_t* arena_stride);
 
 static_assert(sizeof(bt2g_mm1_hit) == sizeof(Mm1Hit) && offsetof(bt2g_mm1_hit, score) == offsetof(Mm1Hit, score) && offsetof(bt2g_mm1_hit, epos) == offsetof(Mm1Hit, epos) &&
               offsetof(bt2g_mm1_hit, echr) == offsetof(Mm1Hit, echr) && offsetof(bt2g_mm1_hit, eqchr) == offsetof(Mm1Hit, eqchr), "bt2g_mm1_hit is the kernels' Mm1Hit");
@@ -402,7 +411,7 @@ int bt2g_dp_fill(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_problem* d_p
 	if (e != hipSuccess) return hip_fail(c, e, "copy DP problems");
 	uint32_t max_rows = 1, max_cols = (uint32_t)kMaxCols;
 	for (const auto& p : hp) {
-		if (p.rows == 0 || p.cols == 0 || p.rows > BT2G_MAX_READ_LEN || p.cols + 1 > (uint32_t)kMaxColsWide) return fail(c, BT2G_ERR_UNSUPPORTED, "DP problem outside 1..512 rows x 1..2175 columns");
+		if (p.rows == 0 || p.cols == 0 || p.rows > (uint32_t)kMaxLen || p.cols + 1 > (uint32_t)kMaxColsWide) return fail(c, BT2G_ERR_UNSUPPORTED, "DP problem outside 1..512 rows x 1..2175 columns");
 		if (p.cols + 1 > max_cols) max_cols = (uint32_t)kMaxColsWide;       // (wide windows: the launch holds more per-column state in LDS)
 		if (p.kind > BT2G_DP_LOCAL || (p.out_off & 7)) return fail(c, BT2G_ERR_ARG, "bad DP problem (kind / output offset)");
 		if (p.rows > max_rows) max_rows = p.rows;
@@ -444,6 +453,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (!reads || !params || (!d_rparams && reads->n_reads) || (!d_results && reads->n_reads)) return fail(c, BT2G_ERR_ARG, "bad argument");
 	if (params->khits < 1 || params->khits > BT2G_MAX_KHITS || (uint32_t)params->khits > bt2g_bk_max_alns()) return fail(c, BT2G_ERR_UNSUPPORTED, "-k outside [1,1000]");
 	const bool bigk = params->khits > 64;      // the many-alignments class: its own per-wave capacities (and arena), see bt2g_align.hpp at BT2G_CLASS_BIG_K
+	const bool longr = max_read_len > (uint32_t)kMaxLen;      // the long-read class
+	if (longr && (bigk || max_read_len > bt2g_lr_max_len())) return fail(c, BT2G_ERR_UNSUPPORTED, "reads longer than 512 bp with -k above 64 (or -a) are not supported by this build");
 	if (params->match_bonus < 0) return fail(c, BT2G_ERR_ARG, "negative match bonus");
 	if (params->maxhalf < 0 || params->maxhalf > 255 || params->gapbar < 1 || params->rdgapo < 0 || params->rdgape < 0 || params->rfgapo < 0 || params->rfgape < 0 ||
 	    params->max_dp_streak < 0 || params->n_seed_rounds < 0 || params->seed_mms < 0 || params->seed_mms > 1)
@@ -497,16 +508,21 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	static const bool no_w5 = getenv("BT2G_NO_W5") != nullptr;
 	static const uint32_t kStaticLdsBytes = bt2g_w5_static_lds();
 	bool w5 = false;
-	if (!no_w5 && !bigk && !params->paired && params->match_bonus == 0 && params->max_dp_cols <= kMaxCols && bt2g_w5_work_bytes() <= sizeof(Work) &&
+	if (!no_w5 && !bigk && !longr && !params->paired && params->match_bonus == 0 && params->max_dp_cols <= kMaxCols && bt2g_w5_work_bytes() <= sizeof(Work) &&
 	    max_read_len <= bt2g_w5_max_len() && max_seeds >= 1 && max_seeds <= bt2g_w5_max_offs()) {
 		const uint32_t need = max_read_len + 4u * (uint32_t)(params->maxhalf > 0 ? params->maxhalf : 0) + 1u + 4u;
 		const uint32_t lds_per_wave = (160u * 1024u) / (4u * 5u);
 		if (need <= (uint32_t)kMaxCols && kStaticLdsBytes < lds_per_wave && kStaticLdsBytes + hot_tail_bytes(need, false) <= lds_per_wave) { w5 = true; max_cols = need; }      // (kStaticLdsBytes is 0xffffffff when the runtime would not say)
 	}
-	if (bigk) bt2g_bk_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, &mat_bytes, &mask_bytes, &pmask_bytes, &arena_stride);
+	if (longr) {
+		// a seed extension window of a long read is rows + 4 x maxhalf + 1 columns: more than the default launch holds
+		const uint32_t need = max_read_len + 4u * (uint32_t)(params->maxhalf > 0 ? params->maxhalf : 0) + 1u + 4u;
+		if (need > max_cols) max_cols = need < (uint32_t)kMaxColsWide ? need : (uint32_t)kMaxColsWide;
+		bt2g_lr_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, &mat_bytes, &mask_bytes, &pmask_bytes, &arena_stride);
+	} else if (bigk) bt2g_bk_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, &mat_bytes, &mask_bytes, &pmask_bytes, &arena_stride);
 	else align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
 	// persistent waves (one read at a time each) pull reads from a device-side queue
-	uint32_t n_waves = c->n_cu * (w5 ? bt2g_w5_waves_per_cu() : bigk ? bt2g_bk_waves_per_cu() : align_waves_per_cu());
+	uint32_t n_waves = c->n_cu * (w5 ? bt2g_w5_waves_per_cu() : longr ? bt2g_lr_waves_per_cu() : bigk ? bt2g_bk_waves_per_cu() : align_waves_per_cu());
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
 	uint64_t need = arena_stride * n_waves;
 	if (need > S.arena_bytes) {
@@ -516,8 +532,11 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		if (S.d_arena) (void)hipFree(S.d_arena);
 		S.d_arena = nullptr; S.arena_bytes = 0; S.arena_layout = 0;
 		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (uint64_t)(free_b * 0.9)) {
-			const uint64_t fit = (uint64_t)(free_b * 0.9) / arena_stride;
+		// (... and to a fifth of the device: the working sets of the other streams need theirs)
+		uint64_t budget = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<uint64_t>((uint64_t)(free_b * 0.9), (uint64_t)(total_b * 0.22));
+		if (budget && need > budget) {
+			const uint64_t fit = budget / arena_stride;
 			if (fit < 64) return fail(c, BT2G_ERR_HIP, "not enough device memory for the worker arena of this batch (reads / mate windows this long need more per wave than is free)");
 			n_waves = (uint32_t)fit;
 			need = arena_stride * n_waves;
@@ -527,7 +546,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		S.arena_bytes = need;
 	}
 	// the epoch-tagged backtrace masks live in the arena across launches: (re)start from zero whenever its layout changes
-	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0) ^ (w5 ? 1ull << 62 : 0) ^ (bigk ? 1ull << 61 : 0);
+	const uint64_t layout = arena_stride ^ (mat_bytes << 1) ^ (mask_bytes << 2) ^ (pmask_bytes << 3) ^ (params->paired ? 1ull << 63 : 0) ^ (w5 ? 1ull << 62 : 0) ^ (bigk ? 1ull << 61 : 0) ^ (longr ? 1ull << 60 : 0);
 	if (layout != S.arena_layout) {
 		e = hipMemsetAsync(S.d_arena, 0, S.arena_bytes, st);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(worker arena)");
@@ -543,7 +562,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	mark(0);
 	if (c->precomp) {
 		if (max_seeds < 1) max_seeds = 1;
-		if (max_seeds > 64) max_seeds = 64;       // kMaxOffs: longer seed lists are flagged by the worker
+		{ const uint32_t offs_cap = longr ? bt2g_lr_max_offs() : 64u; if (max_seeds > offs_cap) max_seeds = offs_cap; }       // kMaxOffs of the class: longer seed lists are flagged by the worker
 		const uint32_t cap = 8;
 		const uint64_t n = reads->n_reads;
 		auto al = [](uint64_t v) { return (v + 255) & ~255ull; };
@@ -637,6 +656,9 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (w5)
 		e = bt2g_w5_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
 		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, (160u * 1024u) / bt2g_w5_waves_per_cu(), st);
+	else if (longr)
+		e = bt2g_lr_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
+		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, (160u * 1024u) / bt2g_lr_waves_per_cu(), st);
 	else if (bigk)
 		e = bt2g_bk_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
 		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, (160u * 1024u) / bt2g_bk_waves_per_cu(), st);

@@ -314,7 +314,8 @@ static int run_search(int argc, char** argv) {
 						const uint32_t ns = 1 + (len > L ? (len - L) / iv : 0u);
 						if (ns > max_seeds) max_seeds = ns;
 					}
-					Pb.max_seeds = (int32_t)(max_seeds > 64 ? 64 : max_seeds);      // kMaxOffs: the worker flags reads beyond it
+					const uint32_t offs_cap = b->max_len > 512 ? 128u : 64u;      // kMaxOffs of the worker class the batch will run in: the worker flags reads beyond it
+					Pb.max_seeds = (int32_t)(max_seeds > offs_cap ? offs_cap : max_seeds);
 					Pb.max_dp_cols = 0;
 					if (b->paired) {
 						// the widest window in which any mate of this batch is looked for next to its partner: beyond the default the launch

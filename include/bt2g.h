@@ -228,7 +228,8 @@ int bt2g_dp_fill(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_problem *d
  * many-alignments class: larger per-wave capacities, result records of khits alignments each -- keep such batches small), opposite-mate windows <= 1100 columns, or up to BT2G_MAX_DP_COLS when bt2g_align_params::max_dp_cols asks for it (a read or pair
  * over a limit comes back with status bit 0 set).
  */
-#define BT2G_MAX_READ_LEN 512
+#define BT2G_MAX_READ_LEN 1999   /* the reference changes algorithm at 2 000 bp (checkpointed backtrace, aligner_sw.cpp:514: out of scope); a batch whose longest
+                                    read is above 512 bp runs in the worker's long-read class (khits <= 64 there) */
 #define BT2G_MAX_EDITS    200
 #define BT2G_MAX_KHITS    1000   /* -k ceiling of this build (the reference has none, aln_sink.cpp:33-326); -a reports up to this many and flags a read that has more */
 

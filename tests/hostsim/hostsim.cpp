@@ -688,8 +688,8 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	for (size_t ri = 0; ri < hb.reads.size(); ri++) {
 		const ReadRec& rd = hb.reads[ri];
 		ReadResult& rr = *(ReadResult*)resbuf.data();
-		if (rd.seq.size() > (size_t)kMaxLen) {
-			fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", rd.name.str().c_str(), kMaxLen);
+		if (rd.seq.size() > (size_t)BT2G_MAX_READ_LEN || rd.seq.size() > (size_t)kMaxLen) {
+			fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", rd.name.str().c_str(), kMaxLen < BT2G_MAX_READ_LEN ? kMaxLen : BT2G_MAX_READ_LEN);
 			return 1;
 		}
 		g_rp = hb.rp[ri]; g_Pp = &P; g_ixp = &ix;
@@ -767,7 +767,8 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 		if (!hb.bad_input.empty()) { fprintf(stderr, "Error: %s\n", hb.bad_input.c_str()); return 1; }
 		for (size_t pi = 0; pi + 1 < hb.reads.size(); pi += 2, pair_no++) {
 			const ReadRec& r1 = hb.reads[pi]; const ReadRec& r2 = hb.reads[pi + 1];
-			if (r1.seq.size() > (size_t)kMaxLen || r2.seq.size() > (size_t)kMaxLen) { fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", r1.name.str().c_str(), kMaxLen); return 1; }
+			const size_t maxlen_ = (size_t)(kMaxLen < BT2G_MAX_READ_LEN ? kMaxLen : BT2G_MAX_READ_LEN);
+			if (r1.seq.size() > maxlen_ || r2.seq.size() > maxlen_) { fprintf(stderr, "Error: read %s is longer than %d bp (unsupported)\n", r1.name.str().c_str(), (int)maxlen_); return 1; }
 			ReadResult& rr1 = *(ReadResult*)resbuf.data();
 			ReadResult& rr2 = *(ReadResult*)(resbuf.data() + rec_bytes);
 			g_rp = hb.rp[pi]; g_Pp = &P; g_ixp = &ix;

@@ -1,0 +1,100 @@
+"""Reads of 513 ... 1 999 bp (first half).  The reference stays on its plain DP path up to 1 999 bp
+(aligner_sw.cpp:514: checkpointing from 2 000) -- this build's worker stopped at 512 until round 5.  A batch whose longest read is above
+512 bp now runs in the worker's long-read class (2 048 DP rows, 128 seed positions per strand, the 16-bit end-to-end fill with its per-row
+state in scratch, the packed local fill with 8 / 16 rows per block).  On 240 of the reference's own example long reads against phage lambda
+the SAM must equal the reference binary's, read by read, for every read the build does not flag; what it may still flag is an alignment
+with more than the 200 edits a result record holds (BT2G_MAX_EDITS, an ABI constant: these simulated reads carry ~10 % errors) and, with
+--local, a DP window with more than 65 535 candidate cells -- nothing else.
+Reads of 2 000 bp and more are refused."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from bt2test import CACHE_DIR, ROOT, build_hostsim, ref_bin
+
+EX = os.path.join(ROOT, "tests", "golden", "example")
+HS = os.path.join(ROOT, "tests", "hostsim")
+BIN = os.path.join(ROOT, "bowtie2_amd", "bin", "bowtie2-align-s")
+
+
+def workload():
+    d = os.path.join(CACHE_DIR, "long_reads_lambda")
+    base, fq = os.path.join(d, "lambda"), os.path.join(d, "long.fq")
+    if not os.path.exists(base + ".rev.2.bt2"):
+        os.makedirs(d, exist_ok=True)
+        subprocess.check_call([ref_bin("bowtie2-build-s"), "-q", os.path.join(EX, "lambda_virus.fa"), base], stdout=subprocess.DEVNULL)
+    if not os.path.exists(fq):
+        with gzip.open(os.path.join(EX, "longreads_513_1999.fq.gz"), "rb") as f, open(fq, "wb") as g:
+            g.write(f.read())
+    return base, fq
+
+
+def by_read(text):
+    d = {}
+    for l in text.splitlines():
+        if not l.startswith("@"):
+            d.setdefault(l.split("\t", 1)[0], []).append(l)
+    return d
+
+
+def check(exe, args, product):
+    base, fq = workload()
+    want = by_read(subprocess.run([ref_bin("bowtie2-align-s")] + args + ["-x", base, "-U", fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True).stdout)
+    p = subprocess.run([exe] + args + ["-x", base, "-U", fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
+    warns = [l for l in p.stderr.splitlines() if l.startswith("Warning: read")]
+    flagged = {l.split()[2].rstrip(":") for l in warns}
+    assert p.returncode == (1 if flagged and product else 0), p.stderr[-800:]
+    # the capacities a long read may still run into: more than BT2G_MAX_EDITS (200) edits in one alignment (site 20 of the worker) and, in
+    # local mode, more than 65 535 candidate cells in one DP window (site 16: the gather's radix sort counts in 16 bits)
+    ok_sites = ("site 20", "site 16") if any("local" in a for a in args) else ("site 20",)
+    assert all(any(s_ in l for s_ in ok_sites) for l in warns), [l for l in warns if not any(s_ in l for s_ in ok_sites)][:3]
+    got = by_read(p.stdout)
+    assert set(got) == set(want) and len(want) == 240
+    bad = [n for n in want if n not in flagged and got[n] != want[n]]
+    assert not bad, (len(bad), bad[:3])
+    # (--local: a window of a 1 000-bp read easily has more than 65 535 candidate cells -- most of the sample is flagged there, what is not must be right)
+    local = any("local" in a for a in args)
+    assert len(flagged) < (180 if local else 80), "%d flagged" % len(flagged)
+    aligned = sum(1 for n in want if n not in flagged and not int(want[n][0].split("\t")[1]) & 4)
+    assert aligned > (40 if local else 120), aligned
+
+
+@pytest.fixture(scope="module")
+def hostsim():
+    return build_hostsim(os.path.join(HS, "hostsim"))
+
+
+@pytest.mark.parametrize("args", [["--sensitive"], ["--local"], ["--very-sensitive", "-k", "3"]])
+def test_long_reads_hostsim(hostsim, args):
+    check(hostsim, args, False)
+
+
+def test_reads_of_2000_bp_are_refused(hostsim, tmp_path):
+    base, _ = workload()
+    fq = tmp_path / "r.fq"
+    fq.write_text("@too_long\n%s\n+\n%s\n" % ("ACGT" * 500, "I" * 2000))
+    p = subprocess.run([hostsim, "-x", base, "-U", str(fq)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "longer than 1999 bp" in p.stderr, p.stderr[-300:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["--sensitive"], ["--local"], ["--very-sensitive", "-k", "3"]])
+def test_long_reads_gpu(args):
+    check(BIN, args, True)
+
+
+@pytest.mark.gpu
+def test_long_and_short_batches_in_one_run_gpu(tmp_path):
+    """short reads first, long ones behind them, batches of 64: the driver hands every batch to the class that holds it"""
+    base, fq = workload()
+    short = os.path.join(ROOT, "tests", "golden", "align_reads.fq")
+    both = tmp_path / "both.fq"
+    both.write_bytes(open(short, "rb").read() + open(fq, "rb").read())
+    want = by_read(subprocess.run([ref_bin("bowtie2-align-s"), "-x", base, "-U", str(both)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True).stdout)
+    p = subprocess.run([BIN, "--batch", "64", "-x", base, "-U", str(both)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
+    flagged = {l.split()[2].rstrip(":") for l in p.stderr.splitlines() if l.startswith("Warning: read")}
+    got = by_read(p.stdout)
+    assert set(got) == set(want)
+    assert not [n for n in want if n not in flagged and got[n] != want[n]]
