@@ -50,6 +50,7 @@ struct bt2g_ctx {
 		hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel boundaries of the last align batch
 		bool ev_valid = false;
 		uint64_t last_use = 0;               // batch number of the slot's last bt2g_align_batch: the least recently used slot is handed to a new stream
+		uint64_t arena_cut_stride = 0;       // != 0: the arena holds fewer waves than a full launch of this per-wave stride wants (it was cut to the memory budget)
 	};
 	static constexpr int kMaxSlots = 4;
 	BatchSlot slots[kMaxSlots];
@@ -453,15 +454,15 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	if (!reads || !params || (!d_rparams && reads->n_reads) || (!d_results && reads->n_reads)) return fail(c, BT2G_ERR_ARG, "bad argument");
 	if (params->khits < 1 || params->khits > BT2G_MAX_KHITS || (uint32_t)params->khits > bt2g_bk_max_alns()) return fail(c, BT2G_ERR_UNSUPPORTED, "-k outside [1,1000]");
 	const bool bigk = params->khits > 64;      // the many-alignments class: its own per-wave capacities (and arena), see bt2g_align.hpp at BT2G_CLASS_BIG_K
-	const bool longr = max_read_len > (uint32_t)kMaxLen;      // the long-read class
-	if (longr && (bigk || max_read_len > bt2g_lr_max_len())) return fail(c, BT2G_ERR_UNSUPPORTED, "reads longer than 512 bp with -k above 64 (or -a) are not supported by this build");
 	if (params->match_bonus < 0) return fail(c, BT2G_ERR_ARG, "negative match bonus");
 	if (params->maxhalf < 0 || params->maxhalf > 255 || params->gapbar < 1 || params->rdgapo < 0 || params->rdgape < 0 || params->rfgapo < 0 || params->rfgape < 0 ||
 	    params->max_dp_streak < 0 || params->n_seed_rounds < 0 || params->seed_mms < 0 || params->seed_mms > 1)
 		return fail(c, BT2G_ERR_ARG, "alignment parameter out of range (maxhalf 0..255, gapbar >= 1, gap penalties >= 0, -N 0/1)");
 	if (max_read_len == 0) max_read_len = 1;
 	if (reads->n_reads == 0) return 0;
-	if (max_read_len > BT2G_MAX_READ_LEN) max_read_len = BT2G_MAX_READ_LEN;
+	if (max_read_len > BT2G_MAX_READ_LEN) max_read_len = BT2G_MAX_READ_LEN;      // (a longer read is flagged by the kernel, record by record)
+	const bool longr = max_read_len > (uint32_t)kMaxLen;      // the long-read class
+	if (longr && bigk) return fail(c, BT2G_ERR_UNSUPPORTED, "reads longer than 512 bp with -k above 64 (or -a) are not supported by this build");
 	hipStream_t st = (hipStream_t)stream;
 	// the working set of this stream (created on the stream's first batch)
 	int si = -1;
@@ -525,12 +526,17 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	uint32_t n_waves = c->n_cu * (w5 ? bt2g_w5_waves_per_cu() : longr ? bt2g_lr_waves_per_cu() : bigk ? bt2g_bk_waves_per_cu() : align_waves_per_cu());
 	if (n_waves > reads->n_reads) n_waves = reads->n_reads;
 	uint64_t need = arena_stride * n_waves;
+	if (need > S.arena_bytes && S.arena_cut_stride == arena_stride && S.arena_bytes / arena_stride >= 64) {
+		// the arena was cut to the memory budget for launches of this shape: run with the waves it holds instead of allocating again
+		n_waves = (uint32_t)(S.arena_bytes / arena_stride);
+		need = arena_stride * n_waves;
+	}
 	if (need > S.arena_bytes) {
 		// Every stream's working set has its own arena (Work + DP matrices per resident wave): with wide opposite-mate windows and long mates a
 		// wave's share reaches tens of MB, and three sets of 4 096 of them would not fit next to the index.  The launch is cut to the waves
 		// whose arena fits in 90 % of what is free (fewer resident waves: slower, never wrong) before the allocation is given up.
 		if (S.d_arena) (void)hipFree(S.d_arena);
-		S.d_arena = nullptr; S.arena_bytes = 0; S.arena_layout = 0;
+		S.d_arena = nullptr; S.arena_bytes = 0; S.arena_layout = 0; S.arena_cut_stride = 0;
 		size_t free_b = 0, total_b = 0;
 		// (... and to a fifth of the device: the working sets of the other streams need theirs)
 		uint64_t budget = 0;
@@ -540,6 +546,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 			if (fit < 64) return fail(c, BT2G_ERR_HIP, "not enough device memory for the worker arena of this batch (reads / mate windows this long need more per wave than is free)");
 			n_waves = (uint32_t)fit;
 			need = arena_stride * n_waves;
+			S.arena_cut_stride = arena_stride;
 		}
 		e = hipMalloc((void**)&S.d_arena, need);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(worker arena)");
