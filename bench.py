@@ -895,7 +895,10 @@ def main():
         # (offset resolution, re-seeding rounds) * side_sz + DP reference windows + reads in + result records out.
         dp_windows = float(h["n_ex_dps"].sum() + h["n_mate_dps"].sum())
         win_cols = args.readlen + 4 * 15 + 1     # seed-extension windows; opposite-mate windows are wider (counted at the same size: a lower bound)
-        alg_bytes = sides_per_launch * side + dp_windows * ((win_cols + 3) // 4) + n * args.readlen * 2 + n * stride
+        # (result records: header + khits alignment slots of bt2g_aln -- the record as SURVEY 8d priced it in every round; the stride of the result buffer
+        # also leaves room for the long-read class's larger slots since round 5, which is not traffic)
+        rec_bytes = (C.sizeof(b.ReadResult) + (max(1, P.khits) - 1) * C.sizeof(b.Aln) + 15) & ~15
+        alg_bytes = sides_per_launch * side + dp_windows * ((win_cols + 3) // 4) + n * args.readlen * 2 + n * rec_bytes
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         # The four lane-per-task FM kernels in front of it carry most of the rank queries of the path.
         fm_ms = sum(v for k, v in kavg.items() if k != "k_align_reads")

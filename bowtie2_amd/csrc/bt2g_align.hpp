@@ -47,7 +47,11 @@ constexpr int kMaxOffs     = 64;    // seed offsets per strand
 constexpr int kMaxMm1      = 1024;  // 1-mismatch end-to-end hits kept (a simple-repeat read has hundreds)
 constexpr int kMaxRanges   = 2 * kMaxOffs;   // seed positions (both strands)
 constexpr int kMaxSat2     = 4096;  // seed-hit ranges of one round: one per position with -N 0, up to ~100 per position with -N 1
+#ifdef BT2G_CLASS_MAX_EDITS
+constexpr int kMaxEdits    = BT2G_CLASS_MAX_EDITS;      // (the long-read class: its result records have larger alignment slots, see AlnRes below)
+#else
 constexpr int kMaxEdits    = 200;
+#endif
 #ifdef BT2G_CLASS_BIG_K
 // The worker's many-alignments class (Makefile: bt2g_align_kernel_bk.o, namespace bt2g_bk): -k above 64 and -a.  The reference has no ceiling on
 // -k (aln_sink.cpp:33-326); this class holds BT2G_MAX_KHITS alignments per read (per mate and per pair list), the extension list that
@@ -85,9 +89,41 @@ enum { ERR_NONE = 0, ERR_OVERFLOW = 1 };   // per-read status: capacity of a fix
 using AlignParams = bt2g_align_params;
 using ReadParams  = bt2g_read_params;
 using Edit        = bt2g_edit;
+#ifdef BT2G_CLASS_MAX_EDITS
+// the class's own alignment slot and result record: the ABI structs' fields, the slot with room for kMaxEdits edits (include/bt2g.h at
+// bt2g_align_result_stride: a record says how large its slots are)
+struct AlnRes {
+	int64_t  refoff, reflen;
+	int32_t  refid, score;
+	int16_t  ns, gaps, edits, bases_aligned;
+	uint16_t refns, nned, rdlen, rdextent, rfextent, trim5p, trim3p;
+	uint8_t  fw;
+	uint8_t  pad[5];
+	bt2g_edit ned[kMaxEdits];
+};
+struct ReadResult {
+	uint8_t  status;
+	uint8_t  aligned, maxed, filt, exhausted, has_secbest;
+	uint8_t  pair_type;
+	uint8_t  pair_flags;
+	int32_t  secbest, best;
+	uint32_t nalns, nreport;
+	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail_streak_max, n_bwops_seed, n_bwops_ext, n_redundants, n_bt_attempts;
+	uint32_t n_ext_left, n_ext_right, n_resolve_steps, n_sides;
+	int32_t  pair_best, pair_secbest;
+	uint32_t n_mate_dps, pad2;
+	AlnRes   alns[1];
+};
+static_assert(offsetof(AlnRes, ned) == offsetof(bt2g_aln, ned) && offsetof(AlnRes, nned) == offsetof(bt2g_aln, nned) && offsetof(AlnRes, fw) == offsetof(bt2g_aln, fw) &&
+              offsetof(ReadResult, alns) == offsetof(bt2g_read_result, alns) && offsetof(ReadResult, pad2) == offsetof(bt2g_read_result, pad2) &&
+              offsetof(ReadResult, nreport) == offsetof(bt2g_read_result, nreport) && kMaxEdits <= BT2G_MAX_EDITS_LONG && sizeof(AlnRes) % 8 == 0, "class record layout");
+#else
 using AlnRes      = bt2g_aln;
 using ReadResult  = bt2g_read_result;
-static_assert(kMaxLen <= ((BT2G_MAX_READ_LEN + 63) & ~63) && kMaxLen % 4 == 0 && kMaxEdits == BT2G_MAX_EDITS, "ABI constants out of sync");
+#endif
+// what a record says about its alignment slots (bt2g_read_result::pad2 bits 16-31)
+constexpr uint32_t kAlnSlotTag = (uint32_t)(sizeof(AlnRes) / 8) << 16;
+static_assert(kMaxLen <= ((BT2G_MAX_READ_LEN + 63) & ~63) && kMaxLen % 4 == 0 && (kMaxEdits == BT2G_MAX_EDITS || kMaxEdits == BT2G_MAX_EDITS_LONG), "ABI constants out of sync");
 
 // ---------------------------------------------------------------------------------------
 // RandomSource (random_source.h:34-159)

@@ -2283,7 +2283,7 @@ struct Aligner {
 		out.aligned = nunpair1 > 0 ? 1 : 0;
 		out.maxed = maxed ? 1 : 0;
 		out.has_secbest = 0; out.secbest = 0; out.best = 0; out.nreport = 0;
-		out.pair_type = 0; out.pair_flags = 0; out.pair_best = 0; out.pair_secbest = 0; out.n_mate_dps = 0; out.pad2 = HOT.err >> 8;
+		out.pair_type = 0; out.pair_flags = 0; out.pair_best = 0; out.pair_secbest = 0; out.n_mate_dps = 0; out.pad2 = (HOT.err >> 8) | kAlnSlotTag;
 		if (nunpair1 == 0) return;
 		// selectByScore: sort (score, index) ascending, reverse, shuffle equal-score streaks
 		const uint32_t sz = HOT.n_alns < (uint32_t)kMaxAlns ? HOT.n_alns : (uint32_t)kMaxAlns;

@@ -443,7 +443,9 @@ int bt2g_dp_fill(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_problem* d_p
 
 uint64_t bt2g_align_result_stride(uint32_t khits) {
 	if (khits == 0) khits = 1;
-	const uint64_t b = sizeof(bt2g_read_result) + (uint64_t)(khits - 1) * sizeof(bt2g_aln);
+	// room for the slots of whichever worker class the batch runs in: the long-read class's are larger (khits <= 64 there), include/bt2g.h
+	const uint64_t slot = khits > 64 ? sizeof(bt2g_aln) : (offsetof(bt2g_aln, ned) + (uint64_t)BT2G_MAX_EDITS_LONG * sizeof(bt2g_edit) + 7) & ~(uint64_t)7;
+	const uint64_t b = offsetof(bt2g_read_result, alns) + (uint64_t)khits * slot;
 	return (b + 15) & ~(uint64_t)15;
 }
 

@@ -776,6 +776,10 @@ static constexpr uint32_t kResHead = (uint32_t)offsetof(bt2g_read_result, alns);
 static constexpr uint32_t kAlnHead = (uint32_t)offsetof(bt2g_aln, ned);
 static_assert(kResHead % 8 == 0 && sizeof(bt2g_aln) % 8 == 0 && sizeof(bt2g_edit) == 6, "packed record layout");
 __device__ __forceinline__ uint32_t packed_aln_bytes(uint32_t nned) { return (kAlnHead + nned * (uint32_t)sizeof(bt2g_edit) + 7u) & ~7u; }
+// size of a record's alignment slots: the worker class that wrote the record says (bt2g_read_result::pad2 bits 16-31, in units of 8 bytes)
+__device__ __forceinline__ uint32_t slot_bytes_of(const bt2g_read_result* rr) { const uint32_t t = rr->pad2 >> 16; return t ? t * 8u : (uint32_t)sizeof(bt2g_aln); }
+__device__ __forceinline__ const bt2g_aln* slot_of(const bt2g_read_result* rr, uint32_t slot, uint32_t k) { return (const bt2g_aln*)((const uint8_t*)rr->alns + (uint64_t)k * slot); }
+__device__ __forceinline__ uint32_t slot_edits(uint32_t slot) { return (slot - kAlnHead) / (uint32_t)sizeof(bt2g_edit); }
 
 __global__ void __launch_bounds__(256)
 k_pack_sizes(const uint8_t* __restrict__ res, uint64_t stride, uint32_t n, uint32_t khits, uint64_t* __restrict__ offs) {
@@ -785,7 +789,8 @@ k_pack_sizes(const uint8_t* __restrict__ res, uint64_t stride, uint32_t n, uint3
 	const bt2g_read_result* rr = (const bt2g_read_result*)(res + (uint64_t)r * stride);
 	uint32_t bytes = kResHead;
 	const uint32_t na = rr->aligned ? min(rr->nreport, khits) : 0u;
-	for (uint32_t k = 0; k < na; k++) bytes += packed_aln_bytes(min((uint32_t)rr->alns[k].nned, (uint32_t)BT2G_MAX_EDITS));
+	const uint32_t slot = slot_bytes_of(rr);
+	for (uint32_t k = 0; k < na; k++) bytes += packed_aln_bytes(min((uint32_t)slot_of(rr, slot, k)->nned, slot_edits(slot)));
 	offs[r + 1] = bytes;
 }
 
@@ -819,9 +824,10 @@ k_pack_copy(const uint8_t* __restrict__ res, uint64_t stride, uint32_t n, uint32
 	if (lane < kResHead / 4) ((uint32_t*)dst)[lane] = ((const uint32_t*)src)[lane];
 	if (lane == 0 && na != rr->nreport) ((bt2g_read_result*)dst)->nreport = na;
 	dst += kResHead;
+	const uint32_t slot = slot_bytes_of(rr);
 	for (uint32_t k = 0; k < na; k++) {
-		const uint32_t* a = (const uint32_t*)&rr->alns[k];
-		const uint32_t words = packed_aln_bytes(min((uint32_t)rr->alns[k].nned, (uint32_t)BT2G_MAX_EDITS)) / 4;
+		const uint32_t* a = (const uint32_t*)slot_of(rr, slot, k);
+		const uint32_t words = packed_aln_bytes(min((uint32_t)slot_of(rr, slot, k)->nned, slot_edits(slot))) / 4;
 		for (uint32_t w = lane; w < words; w += 64) ((uint32_t*)dst)[w] = a[w];
 		dst += words * 4;
 	}

@@ -250,7 +250,7 @@ static int run_search(int argc, char** argv) {
 				summ.merge(tally.summ); psumm.merge(tally.psumm);
 				for (size_t i : tally.flagged) {
 					n_flagged++;
-					fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed), capacity site %u\n", b->reads[i].name.str().c_str(), (int)b->result(i).status, (unsigned)b->result(i).pad2);
+					fprintf(stderr, "Warning: read %s: device status %d (bit 0 = a work buffer overflowed), capacity site %u\n", b->reads[i].name.str().c_str(), (int)b->result(i).status, (unsigned)(b->result(i).pad2 & 0xffffu));
 				}
 				if (metrics) for (size_t i = 0; i < b->reads.size(); i++) {
 					const ReadResult& rr = b->result(i);

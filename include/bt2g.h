@@ -230,7 +230,8 @@ int bt2g_dp_fill(bt2g_ctx *ctx, const bt2g_scoring *sc, const bt2g_dp_problem *d
  */
 #define BT2G_MAX_READ_LEN 1999   /* the reference changes algorithm at 2 000 bp (checkpointed backtrace, aligner_sw.cpp:514: out of scope); a batch whose longest
                                     read is above 512 bp runs in the worker's long-read class (khits <= 64 there) */
-#define BT2G_MAX_EDITS    200
+#define BT2G_MAX_EDITS    200    /* edits an alignment slot of bt2g_aln holds */
+#define BT2G_MAX_EDITS_LONG 640  /* ... of the slots the long-read class writes (reads of 513 ... 1 999 bp: minsc -1 200 at the default --score-min) */
 #define BT2G_MAX_KHITS    1000   /* -k ceiling of this build (the reference has none, aln_sink.cpp:33-326); -a reports up to this many and flags a read that has more */
 
 /* what bt2_search.cpp keeps in file statics (:69-266), for the options that reach the worker */
@@ -315,11 +316,15 @@ typedef struct {
 	uint32_t n_ex_iters, n_ex_dps, n_ex_ugs, n_dp_fail_streak_max, n_bwops_seed, n_bwops_ext, n_redundants, n_bt_attempts;
 	uint32_t n_ext_left, n_ext_right, n_resolve_steps, n_sides;   /* seed-hit extension steps, SA-walk steps, sides read */
 	int32_t  pair_best, pair_secbest;  /* paired-end MAPQ inputs: best / second-best concordant (or discordant) pair score   */
-	uint32_t n_mate_dps, pad2;         /* opposite-mate DPs run for this anchor mate                                          */
+	uint32_t n_mate_dps, pad2;         /* opposite-mate DPs run for this anchor mate; pad2: bits 0-15 the capacity site that flagged the read (diagnostics), bits 16-31 alignment slot size / 8 */
 	bt2g_aln alns[1];              /* nreport (<= khits) entries                              */
 } bt2g_read_result;
 
-/* bytes between consecutive result records for a given -k */
+/* Bytes between consecutive result records for a given -k.  A record is the header of bt2g_read_result followed by `nreport` alignment slots.
+ * The slots of one record all have the same size, written by the worker into the record itself: (pad2 >> 16) * 8 bytes -- sizeof(bt2g_aln)
+ * except in records of the long-read class, whose slots hold BT2G_MAX_EDITS_LONG edits.  The stride leaves room for either (khits <= 64; the
+ * many-alignments class above that has bt2g_aln slots only).  bt2g_results_pack cuts every slot after its last edit: consumers of packed
+ * records walk the alignments by their `nned` and never need the slot size. */
 uint64_t bt2g_align_result_stride(uint32_t khits);
 /*
  * d_rparams[n_reads]; d_results: n_reads records of bt2g_align_result_stride(khits) bytes.

@@ -333,7 +333,7 @@ def build_hostsim(exe):
     hs = os.path.join(ROOT, "tests", "hostsim")
     first = _hostsim_built.get("exe")
     if first is None or not os.path.exists(first):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-DBT2G_CLASS_BIG_K", "-DBT2G_CLASS_MAX_LEN=2048", "-DBT2G_CLASS_MAX_OFFS=128", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-DBT2G_CLASS_BIG_K", "-DBT2G_CLASS_MAX_LEN=2048", "-DBT2G_CLASS_MAX_OFFS=128", "-DBT2G_CLASS_MAX_EDITS=640", "-I" + os.path.join(ROOT, "include"), "-o", exe,
                                os.path.join(hs, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
         _hostsim_built["exe"] = exe
     elif os.path.abspath(first) != os.path.abspath(exe):

@@ -54,7 +54,8 @@ int bt2g_index_refname(const bt2g_ctx* c, uint64_t tidx, const char** name, uint
 }
 uint64_t bt2g_align_result_stride(uint32_t khits) {       // as bt2g_capi.hip
 	if (khits == 0) khits = 1;
-	const uint64_t b = sizeof(bt2g_read_result) + (uint64_t)(khits - 1) * sizeof(bt2g_aln);
+	const uint64_t slot = sizeof(AlnRes);      // (the twin's worker is compiled with the largest capacities of every class: its slots are the long-read class's, for any -k)
+	const uint64_t b = offsetof(bt2g_read_result, alns) + (uint64_t)khits * slot;
 	return (b + 15) & ~(uint64_t)15;
 }
 
@@ -145,9 +146,11 @@ int bt2g_results_pack(bt2g_ctx*, const void* d_results, uint32_t n, uint32_t khi
 		memcpy(dst, src, head);
 		((bt2g_read_result*)dst)->nreport = na;
 		pos += head;
+		const uint32_t slot = (rr->pad2 >> 16) ? (rr->pad2 >> 16) * 8u : (uint32_t)sizeof(bt2g_aln);      // the record says how large its alignment slots are
 		for (uint32_t k = 0; k < na; k++) {
-			const uint32_t bytes = (ahead + std::min<uint32_t>(rr->alns[k].nned, BT2G_MAX_EDITS) * (uint32_t)sizeof(bt2g_edit) + 7u) & ~7u;
-			memcpy((uint8_t*)d_packed + pos, &rr->alns[k], bytes);
+			const bt2g_aln* a = (const bt2g_aln*)((const uint8_t*)rr->alns + (uint64_t)k * slot);
+			const uint32_t bytes = (ahead + std::min<uint32_t>(a->nned, (slot - ahead) / (uint32_t)sizeof(bt2g_edit)) * (uint32_t)sizeof(bt2g_edit) + 7u) & ~7u;
+			memcpy((uint8_t*)d_packed + pos, a, bytes);
 			pos += bytes;
 		}
 	}

@@ -699,7 +699,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		g_st.max_cols = (uint32_t)kMaxColsWide;      // (the product's driver asks bt2g_align_batch for what its pairs need, up to this: bt2g_align_params::max_dp_cols)
 		Aligner<TOff, HostPlat> al(*w, dp);
 		al.run(rr);
-		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d, site %u)\n", rd.name.str().c_str(), rr.status, rr.pad2);
+		if (rr.status) fprintf(stderr, "Warning: read %s overflowed a fixed-capacity buffer (status %d, site %u)\n", rd.name.str().c_str(), rr.status, rr.pad2 & 0xffffu);
 		summ.add(rr);
 		o.clear();
 		if (rr.aligned) {
@@ -780,7 +780,7 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 			g_st.pe_rp[0] = hb.rp[pi]; g_st.pe_rp[1] = hb.rp[pi + 1];
 			g_st.pe_pair = 0;
 			al.run_pair(rr1, rr2);
-			if (rr1.status || rr2.status) fprintf(stderr, "Warning: pair %s overflowed a fixed-capacity buffer (status %d, site %u %u)\n", r1.name.str().c_str(), rr1.status | rr2.status, rr1.pad2, rr2.pad2);
+			if (rr1.status || rr2.status) fprintf(stderr, "Warning: pair %s overflowed a fixed-capacity buffer (status %d, site %u %u)\n", r1.name.str().c_str(), rr1.status | rr2.status, rr1.pad2 & 0xffffu, rr2.pad2 & 0xffffu);
 			summ.add(rr1, rr2);
 			std::vector<const AlnRes*> a1, a2;
 			for (uint32_t i = 0; i < rr1.nreport; i++) a1.push_back(&rr1.alns[i]);

@@ -14,6 +14,7 @@ HS = os.environ.get('BT2G_HOSTSIM', os.path.join(ROOT, 'tests', 'hostsim', 'host
 os.makedirs('/tmp/fuzz', exist_ok=True)
 seed0=int(sys.argv[1]); nit=int(sys.argv[2])
 MODE=int(os.environ.get('FUZZ_MODE','1'))     # 2: small repeat-dense genomes, short reads, more options per case
+LONG=os.environ.get('FUZZ_LONG')              # half of the unpaired reads 513 ... 1 999 bp long
 LOCAL=os.environ.get('FUZZ_LOCAL')            # every case in local mode, reads up to 500 bp (with BT2G_CHECK_LOCAL_PK=1: the packed local fill replayed on every window)
 out=open('/tmp/fuzz/fail_%d.log'%seed0,'w')
 def rnd_genome(rnd):
@@ -22,6 +23,7 @@ def rnd_genome(rnd):
     elem="".join(rnd.choice("ACGT") for _ in range(rnd.randrange(60,400) if MODE==1 else rnd.randrange(20,150)))
     for i in range(nref):
         L=rnd.randrange(300,20000) if MODE==1 else rnd.randrange(200,3000)
+        if LONG: L=rnd.randrange(2500,20000)
         s=[rnd.choice("ACGT") for _ in range(L)]
         for _ in range(rnd.randrange(0,6) if MODE==1 else rnd.randrange(3,12)):
             p=rnd.randrange(0,max(1,L-len(elem)-1))
@@ -71,7 +73,7 @@ for it in range(nit):
     for f in os.listdir(d):
         if f.startswith("g."): os.unlink(d+"/"+f)
     write_fasta(fa,refs); build_index(fa,base,large)
-    paired=rnd.random()<0.5
+    paired=rnd.random()<0.5 and not LONG
     mixed_run=False
     n=rnd.randrange(20,120)
     sub=rnd.choice([0.0,0.01,0.03,0.08]); indel=rnd.choice([0.0,0.002,0.01])
@@ -123,6 +125,7 @@ for it in range(nit):
             _,s=refs[rnd.randrange(len(refs))]
             L=rnd.randrange(1,260) if MODE==1 else rnd.randrange(1,80)
             if LOCAL and rnd.random()<0.5: L=rnd.randrange(200,500)
+            if LONG and rnd.random()<0.5: L=rnd.randrange(513,1900)      # the long-read class (reads of 513 ... 1 999 bp)
             L=min(L,len(s)-1)
             p=rnd.randrange(0,len(s)-L); m=s[p:p+L]
             if rnd.random()<0.5: m=revcomp(m)
