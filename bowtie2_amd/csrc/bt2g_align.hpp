@@ -52,6 +52,15 @@ constexpr int kMaxEdits    = BT2G_CLASS_MAX_EDITS;      // (the long-read class:
 #else
 constexpr int kMaxEdits    = 200;
 #endif
+// Edits one backtrace walk may collect before it ends (Edit ned[] in LDS).  A walk that SUCCEEDS must fit an alignment slot (kMaxEdits); a walk of a
+// long read that wanders through hundreds of mismatches and then fails must not flag the read.  Local mode only (a local walk stays above score 0, so it
+// has at most as many mismatches as matches, plus the Ns the N ceiling admits: (cells + 0.15 L) / 2; end to end the minimum score bounds the edits).
+#ifdef BT2G_CLASS_MAX_WALK_EDITS
+constexpr int kMaxWalkEdits = BT2G_CLASS_MAX_WALK_EDITS;
+#else
+constexpr int kMaxWalkEdits = kMaxEdits;
+#endif
+static_assert(kMaxWalkEdits >= kMaxEdits, "walk buffer smaller than an alignment slot");
 #ifdef BT2G_CLASS_BIG_K
 // The worker's many-alignments class (Makefile: bt2g_align_kernel_bk.o, namespace bt2g_bk): -k above 64 and -a.  The reference has no ceiling on
 // -k (aln_sink.cpp:33-326); this class holds BT2G_MAX_KHITS alignments per read (per mate and per pair list), the extension list that
@@ -71,7 +80,13 @@ constexpr int kMaxAlns     = 160;   // alignments kept by the sink (-M 50 -> at 
 constexpr int kMaxDiags    = 2304;  // seen-diagonal intervals
 constexpr int kListArena   = 65536; // uint32 slots for Random1toN lists (swap lists of small ranges, seen lists bounded by max_iters, converted lists)
 #endif
-constexpr int kMaxCands    = 65536;  // DP backtrace candidates (<= DP columns)
+#ifdef BT2G_CLASS_MAX_CANDS
+constexpr int kMaxCands    = BT2G_CLASS_MAX_CANDS;      // (the long-read class: a local window of a 2 000-bp read has hundreds of thousands of candidate cells)
+#else
+constexpr int kMaxCands    = 65536;  // DP backtrace candidates (>= DP columns; local mode: cells, see gather_local)
+#endif
+// counters of the local gather's radix sort (DevPlat::gather_local): 1 024 of them, 16 bits wide while every count stays below 65 536
+constexpr uint32_t kRadixCntBytes = kMaxCands > 65536 ? 4096u : 2048u;
 constexpr int kMaxCols     = 1100;  // DP columns a launch holds unless the caller asks for more: seed extension needs rows + 4*15 + 1; opposite-mate windows span about -X + rows + 2*gaps
 // Widest DP window any launch can hold (bt2g_align_params::max_dp_cols asks for it).  The per-column state of the window in flight -- the
 // reference masks and the last row's scores -- lives in LDS, and LDS decides how many waves a CU holds: the common batch (unpaired reads,
@@ -463,15 +478,16 @@ struct AlState {
 };
 
 // The per-column tail of the hot state, as one launch lays it out behind the fixed part:  rf[max_cols + 8]  (rounded up to 16 bytes), then a
-// region shared by  Edit ned[kMaxEdits]  and  int16_t lastrow[max_cols + 8]  (never live at the same time: the gather reads `lastrow` before
-// any backtrace writes `ned`; the local gather's radix sort borrows 2 048 bytes of it for its counters: local launches keep at least that).
+// region shared by  Edit ned[kMaxWalkEdits]  and  int16_t lastrow[max_cols + 8]  (never live at the same time: the gather reads `lastrow` before
+// any backtrace writes `ned`; the local gather's radix sort borrows kRadixCntBytes of it for its counters: local launches keep at least that).
 // DP columns a launch with these parameters holds (bt2g_align_params::max_dp_cols)
 BT2_HD uint32_t dp_cols_for(const AlignParams& P) { return P.max_dp_cols > kMaxCols ? (uint32_t)(P.max_dp_cols < kMaxColsWide ? P.max_dp_cols : kMaxColsWide) : (uint32_t)kMaxCols; }
 BT2_HD uint32_t hot_tail_off(uint32_t max_cols) { return (max_cols + 8 + 15) & ~15u; }
 BT2_HD uint32_t hot_tail_bytes(uint32_t max_cols, bool local = true) {
 	uint32_t b = (max_cols + 8) * 2;
 	if (b < (uint32_t)(kMaxEdits * sizeof(Edit))) b = (uint32_t)(kMaxEdits * sizeof(Edit));
-	if (local && b < 2048u) b = 2048u;      // (the radix counters of the local gather)
+	if (kMaxWalkEdits > kMaxEdits && local && b < (uint32_t)(kMaxWalkEdits * sizeof(Edit))) b = (uint32_t)(kMaxWalkEdits * sizeof(Edit));      // (local walks, see kMaxWalkEdits)
+	if (local && b < kRadixCntBytes) b = kRadixCntBytes;      // (the radix counters of the local gather)
 	return hot_tail_off(max_cols) + ((b + 15) & ~15u);
 }
 

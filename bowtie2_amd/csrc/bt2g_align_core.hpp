@@ -1449,6 +1449,7 @@ struct Aligner {
 		constexpr bool wide = MODE == 1, local = MODE == 2;
 		constexpr bool pred = MODE != 1;                 // 8-bit end-to-end and local: one byte of predecessor bits per cell (PB_*), tile = kPredTile steps along the direction of travel
 		constexpr uint32_t tile_len = pred ? kPredTile : kBtTile;
+		constexpr uint32_t kWalkCap = local ? (uint32_t)kMaxWalkEdits : (uint32_t)kMaxEdits;      // edits a walk may collect (hot_tail_bytes sizes ned[] the same way)
 		const uint32_t rows = Plat::uni(rows_), cols = Plat::uni(cols_);
 		struct { int gapbar, rdgapo, rdgape, rfgapo, rfgape, match_bonus, mm_type, mm_max, mm_min, n_pen; } S;
 		S.gapbar = Plat::uni(PRM.gapbar); S.rdgapo = Plat::uni(PRM.rdgapo); S.rdgape = Plat::uni(PRM.rdgape);
@@ -1525,7 +1526,7 @@ struct Aligner {
 					// alignment's end column each walk a gap of growing length back to its path; the cell that opens the gap and whatever
 					// follows go through the scalar step.)
 					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
-					const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
+					const uint32_t room_e = nned + 2 < kWalkCap ? kWalkCap - 2 - nned : 0u;
 					const uint32_t room = room_c < room_e ? room_c : room_e;
 					uint32_t core = 0;
 					const uint32_t L = Plat::uni(Plat::bt_gap_run(dpl, band_lo, band_w, epoch, tile, tile_hi, td, row, col, ct == 1, fw, rdlen, room,
@@ -1541,7 +1542,7 @@ struct Aligner {
 					// a run of plain diagonal steps (unvisited cells whose only consistent predecessor is the diagonal one) is walked
 					// by all lanes at once: same marks, same edits, same counters as the step-by-step loop below
 					const uint32_t room_c = ncells < (uint32_t)(kMaxLen + 64) ? (uint32_t)(kMaxLen + 64) - ncells : 0u;
-					const uint32_t room_e = nned + 2 < (uint32_t)kMaxEdits ? (uint32_t)kMaxEdits - 2 - nned : 0u;
+					const uint32_t room_e = nned + 2 < kWalkCap ? kWalkCap - 2 - nned : 0u;
 					const uint32_t room = room_c < room_e ? room_c : room_e;
 					typename Plat::LaneReg inf;
 					uint64_t mm;
@@ -1663,7 +1664,7 @@ struct Aligner {
 				if (branch) nstack++;            // (a frame the reference pushes; only its count matters, see above)
 				if (ncells >= (uint32_t)(kMaxLen + 64)) { ovf(19); return false; }
 				olap |= in_core(row, col); ncells++;
-				if (nned + 1 >= (uint32_t)kMaxEdits) { ovf(20); return false; }
+				if (nned + 1 >= kWalkCap) { ovf(20); return false; }
 				switch (cur) {
 					case 0: {   // diagonal
 						const int m = (refm >= 16 || readc > 3) ? -1 : (((1 << readc) & refm) ? 1 : 0);
@@ -1720,6 +1721,7 @@ struct Aligner {
 				if (m == -1) ns++;
 			}
 			if (ns > RPR.nceil) return false;
+			if (kWalkCap > (uint32_t)kMaxEdits && nned > (uint32_t)kMaxEdits) { ovf(20); return false; }      // an alignment with more edits than a result slot holds
 			// res.reverse(), while copying the edits out of LDS
 			for (uint32_t i = 0; i < nned; i++) res.ned[i] = ned[nned - 1 - i];
 			res.nned = (uint16_t)nned;

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <new>
+#include <type_traits>
 #include "bt2g_align_core.hpp"
 #include "bt2g_local_pk.hpp"
 #include "bt2g_align_kernel.hpp"
@@ -1257,8 +1258,8 @@ struct DevPlat {
 	// Candidate cells of a local fill (gatherCellsNucleotidesLocalSseU8), ordered score desc, row desc, col desc (DpBtCandidate::operator<).
 	// The fill left them in Work::cands_tmp in the order it met them (fill_local_wave<R, true>); this sorts them into `cands`: a stable
 	// LSD radix sort, 10 bits per pass, on  key = score : row : col  (each field as wide as this window needs), complemented so that
-	// ascending passes give the descending order.  The 1024 counters of a pass are 16-bit words in LDS (the last-row buffer, idle here;
-	// the capacity keeps every count below 65536).  Per batch of 64 records: ten ballots tell every lane which lanes hold the same digit,
+	// ascending passes give the descending order.  The 1024 counters of a pass are words in LDS (the last-row buffer, idle here): 16 bits
+	// wide in the classes whose capacity keeps every count below 65536, 32 bits in the long-read class (kRadixCntBytes).  Per batch of 64 records: ten ballots tell every lane which lanes hold the same digit,
 	// so ranks within the batch need no atomics and the scatter is stable.  An odd number of passes ends in `cands`.
 	// Candidates in columns beyond lastsolcol (ncol - 1) are dropped by the first pass.
 	static __device__ __attribute__((noinline)) uint32_t gather_local(const uint32_t*, BtCand* cands_, uint32_t cap_, bool, uint32_t, uint32_t rows_,
@@ -1266,7 +1267,8 @@ struct DevPlat {
 		BT2_G BtCand* const dst = (BT2_G BtCand*)uni_ptr(cands_);
 		BT2_G BtCand* const tmp = &DevPlat::work().cands_tmp[0];
 		const uint32_t rows = uni(rows_), ncol = uni(ncol_);
-		uint32_t cap = uni(cap_); if (cap > 65535u) cap = 65535u;
+		typedef std::conditional<(kMaxCands > 65536), uint32_t, uint16_t>::type Cnt;
+		uint32_t cap = uni(cap_); if (sizeof(Cnt) == 2 && cap > 65535u) cap = 65535u;
 		uint32_t n = uni(g_st.n_emit);
 		if (n > cap) return (uint32_t)kMaxCands + 1u;      // more cells than the lists hold: the caller flags the read
 		if (n == 0) return 0;
@@ -1277,15 +1279,14 @@ struct DevPlat {
 		const uint32_t tot = cb + rb + sb;
 		uint32_t npass = (tot + 9u) / 10u; if (!(npass & 1u)) npass++;
 		const uint64_t kmask = tot >= 64u ? ~0ull : ((1ull << tot) - 1ull);
-		uint16_t* const cnt = reinterpret_cast<uint16_t*>(dev_lastrow());       // 1024 counters (kMaxCols + 8 >= 1024 int16)
-		// (hot_tail_bytes keeps at least 2 048 bytes there)
+		Cnt* const cnt = reinterpret_cast<Cnt*>(dev_lastrow());       // 1024 counters (hot_tail_bytes keeps at least kRadixCntBytes there)
 		uint32_t* const cnt32 = reinterpret_cast<uint32_t*>(dev_lastrow());
 		for (uint32_t p = 0; p < npass; p++) {
 			BT2_G BtCand* const src = (p & 1u) ? dst : tmp;
 			BT2_G BtCand* const out = (p & 1u) ? tmp : dst;
 			const uint32_t sh = 10u * p;
 			wave_fence();
-			for (uint32_t i = lane; i < 512u; i += 64) cnt32[i] = 0;
+			for (uint32_t i = lane; i < kRadixCntBytes / 4u; i += 64) cnt32[i] = 0;
 			wave_fence();
 			auto digit_of = [&](const BtCand& c) -> uint32_t {
 				const uint64_t key = (((uint64_t)(uint32_t)c.score << (rb + cb)) | ((uint64_t)c.row << cb) | (uint64_t)c.col) ^ kmask;
@@ -1306,7 +1307,7 @@ struct DevPlat {
 				const bool valid = i < n && (p > 0 || (uint32_t)c.col < ncol);
 				const uint32_t d = digit_of(c);
 				const unsigned long long m = same_digit(valid, d);
-				if (valid && (m & lt) == 0) cnt[d] = (uint16_t)(cnt[d] + (uint32_t)__popcll(m));
+				if (valid && (m & lt) == 0) cnt[d] = (Cnt)(cnt[d] + (uint32_t)__popcll(m));
 				wave_fence();
 			}
 			// exclusive prefix over the 1024 counters: lane l owns counters 16 l .. 16 l + 15
@@ -1320,7 +1321,7 @@ struct DevPlat {
 			const uint32_t total = (uint32_t)__shfl((int)incl, 63);
 			wave_fence();
 #pragma unroll
-			for (uint32_t q = 0; q < 16; q++) { cnt[16u * lane + q] = (uint16_t)run; run += mine[q]; }
+			for (uint32_t q = 0; q < 16; q++) { cnt[16u * lane + q] = (Cnt)run; run += mine[q]; }
 			wave_fence();
 			// stable scatter
 			for (uint32_t base = 0; base < n; base += 64) {
@@ -1336,7 +1337,7 @@ struct DevPlat {
 				if (valid) {
 					const uint32_t rank = (uint32_t)__popcll(m & lt), grp = (uint32_t)__popcll(m);
 					gst(out + s0 + rank, c);
-					if (rank + 1u == grp) cnt[d] = (uint16_t)(s0 + grp);
+					if (rank + 1u == grp) cnt[d] = (Cnt)(s0 + grp);
 				}
 				wave_fence();
 			}

@@ -323,6 +323,8 @@ def write_bam(path, records, block=600, refs=(("chrT", 1000),)):
 
 # ---- the host-compiled worker (tests/hostsim/hostsim.cpp): one compilation per test session ----
 _hostsim_built = {}
+# the CPU twin is compiled with the capacities of the worker's largest classes (many alignments + long reads)
+HOSTSIM_CLASS_FLAGS = ["-DBT2G_CLASS_BIG_K", "-DBT2G_CLASS_MAX_LEN=2048", "-DBT2G_CLASS_MAX_OFFS=128", "-DBT2G_CLASS_MAX_EDITS=640", "-DBT2G_CLASS_MAX_CANDS=1048576", "-DBT2G_CLASS_MAX_WALK_EDITS=1344"]
 
 
 def build_hostsim(exe):
@@ -333,9 +335,12 @@ def build_hostsim(exe):
     hs = os.path.join(ROOT, "tests", "hostsim")
     first = _hostsim_built.get("exe")
     if first is None or not os.path.exists(first):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-DBT2G_CLASS_BIG_K", "-DBT2G_CLASS_MAX_LEN=2048", "-DBT2G_CLASS_MAX_OFFS=128", "-DBT2G_CLASS_MAX_EDITS=640", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+        # (written beside the target and renamed into place: a copy of the binary that is still running somewhere is not disturbed)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w"] + HOSTSIM_CLASS_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-o", exe + ".new",
                                os.path.join(hs, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
+        os.replace(exe + ".new", exe)
         _hostsim_built["exe"] = exe
     elif os.path.abspath(first) != os.path.abspath(exe):
-        shutil.copy2(first, exe)
+        shutil.copy2(first, exe + ".new")
+        os.replace(exe + ".new", exe)
     return exe

@@ -25,7 +25,7 @@ using namespace bt2g;
 static HotWork g_hot;
 static uint8_t host_rf[kMaxColsWide + 8];          // the per-column tail of the hot state (dynamic LDS on the device)
 static int16_t host_lastrow[kMaxColsWide + 8];
-static Edit host_ned[kMaxEdits];
+static Edit host_ned[kMaxWalkEdits];
 static AlState g_st;
 static const AlignParams* g_Pp = nullptr;      // the control blocks the device keeps in LDS
 static ReadParams g_rp;

@@ -10,7 +10,7 @@ import sys
 
 import pytest
 
-from bt2test import have_ref, ref_bin
+from bt2test import HOSTSIM_CLASS_FLAGS, have_ref, ref_bin
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -21,7 +21,7 @@ M1, M2, FQ = (os.path.join(GOLD, n) for n in ("pe_reads_1.fq", "pe_reads_2.fq", 
 @pytest.fixture(scope="module")
 def twin():
     exe = os.path.join(HS, "hostsim_driver_twin")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-DBT2G_CLASS_BIG_K", "-DBT2G_CLASS_MAX_LEN=2048", "-DBT2G_CLASS_MAX_OFFS=128", "-DBT2G_CLASS_MAX_EDITS=640", "-I" + os.path.join(HS, "fakehip"), "-I" + os.path.join(ROOT, "include"), "-o", exe,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w"] + HOSTSIM_CLASS_FLAGS + ["-I" + os.path.join(HS, "fakehip"), "-I" + os.path.join(ROOT, "include"), "-o", exe,
                            os.path.join(HS, "driver_twin.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
     return exe
 

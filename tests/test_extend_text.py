@@ -4,6 +4,7 @@ both forms on every one-row hit it extends and aborts on the first disagreement.
 import os
 import subprocess
 
+from bt2test import HOSTSIM_CLASS_FLAGS
 from test_work_counters import workload
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,7 @@ HS = os.path.join(ROOT, "tests", "hostsim")
 
 def test_text_extension_equals_lf_walk(tmp_path):
     exe = str(tmp_path / "hostsim_chk")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-DBT2G_CLASS_BIG_K", "-DBT2G_CLASS_MAX_LEN=2048", "-DBT2G_CLASS_MAX_OFFS=128", "-DBT2G_CLASS_MAX_EDITS=640", "-DBT2G_CHECK_EXTEND_TEXT", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w"] + HOSTSIM_CLASS_FLAGS + ["-DBT2G_CHECK_EXTEND_TEXT", "-I" + os.path.join(ROOT, "include"), "-o", exe,
                            os.path.join(HS, "hostsim.cpp"), os.path.join(ROOT, "bowtie2_amd", "csrc", "bt2g_index.cpp"), "-lz", "-lpthread"])
     for large in (False, True):
         base, fq = workload(large)
