@@ -11,11 +11,17 @@
 #include "bt2g_rankidx.hpp"
 
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace bt2g;
@@ -84,14 +90,124 @@ int upload(bt2g_ctx* c, const void* src, uint64_t nbytes, const T** dst) {
 	return 0;
 }
 
-// a temporary device copy of a file section (freed once it has been transcoded)
-struct TmpDev {
-	void* p = nullptr;
-	~TmpDev() { if (p) (void)hipFree(p); }
-	int put(bt2g_ctx* c, const void* src, uint64_t nbytes) {
-		hipError_t e = hipMalloc(&p, nbytes ? nbytes : 256);
+// Streams sections of the index files into device memory.  kThreads reader threads pread() chunks into pinned buffers (two per thread) and
+// hand each chunk to the copy engine on the thread's own stream: the page cache is read by several cores at once, no second host copy of the
+// 4-5 GB of a genome-sized index is made, and the copies overlap the transcoding kernels of the sections already on the device.
+class FileStreamer {
+public:
+	static constexpr size_t kChunk = 8u << 20;
+	static constexpr int kThreads = 6, kBufs = 2;
+	explicit FileStreamer(int device) : device_(device) {}
+	~FileStreamer() {
+		for (void* p : pinned_) if (p) (void)hipHostFree(p);
+		for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
+		for (hipStream_t st : st_) if (st) (void)hipStreamDestroy(st);
+	}
+	bool init() {
+		for (int t = 0; t < kThreads; t++) {
+			hipStream_t st = nullptr;
+			if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+			st_.push_back(st);
+			for (int b = 0; b < kBufs; b++) {
+				void* p = nullptr; hipEvent_t e = nullptr;
+				if (hipHostMalloc(&p, kChunk, hipHostMallocDefault) != hipSuccess) return false;
+				pinned_.push_back(p);
+				if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+				ev_.push_back(e);
+			}
+		}
+		return true;
+	}
+	// file section -> dst (device); returns when every byte has arrived.  0, or 1 = read error, 2 = HIP error
+	int put(const FileSpan& sp, void* dst) {
+		if (sp.nbytes == 0) return 0;
+		const int fd = open(sp.path.c_str(), O_RDONLY);
+		if (fd < 0) return 1;
+		(void)posix_fadvise(fd, (off_t)sp.off, (off_t)sp.nbytes, POSIX_FADV_SEQUENTIAL);
+		const uint64_t nch = (sp.nbytes + kChunk - 1) / kChunk;
+		std::atomic<uint64_t> next{0};
+		std::atomic<int> bad{0};
+		auto work = [&](int t) {
+			if (hipSetDevice(device_) != hipSuccess) { bad = 2; return; }
+			bool used[kBufs] = {};
+			int b = 0;
+			for (;;) {
+				const uint64_t i = next.fetch_add(1);
+				if (i >= nch || bad.load()) break;
+				const uint64_t at = i * (uint64_t)kChunk;
+				const size_t n = (size_t)(sp.nbytes - at < (uint64_t)kChunk ? sp.nbytes - at : (uint64_t)kChunk);
+				uint8_t* buf = (uint8_t*)pinned_[t * kBufs + b];
+				if (used[b] && hipEventSynchronize(ev_[t * kBufs + b]) != hipSuccess) { bad = 2; break; }      // the copy that last used this buffer
+				size_t got = 0;
+				while (got < n) {
+					const ssize_t r = pread(fd, buf + got, n - got, (off_t)(sp.off + at + got));
+					if (r < 0 && errno == EINTR) continue;
+					if (r <= 0) { bad = 1; break; }
+					got += (size_t)r;
+				}
+				if (bad.load()) break;
+				if (hipMemcpyAsync((uint8_t*)dst + at, buf, n, hipMemcpyHostToDevice, st_[t]) != hipSuccess ||
+				    hipEventRecord(ev_[t * kBufs + b], st_[t]) != hipSuccess) { bad = 2; break; }
+				used[b] = true; b = (b + 1) % kBufs;
+			}
+			if (hipStreamSynchronize(st_[t]) != hipSuccess) bad = 2;
+		};
+		const int nt = (int)(nch < (uint64_t)kThreads ? nch : (uint64_t)kThreads);
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+		work(0);
+		for (auto& x : th) x.join();
+		close(fd);
+		return bad.load();
+	}
+private:
+	int device_;
+	std::vector<hipStream_t> st_;
+	std::vector<void*> pinned_;
+	std::vector<hipEvent_t> ev_;
+};
+
+// What one bt2g_index_load works with besides the context: the file streamer, the stream the transcoding kernels run on (non-blocking: the
+// copies of the next section overlap them), the temporary device copies of file sections (freed at the end, after one synchronisation), and
+// a stopwatch (BT2G_DEBUG_LOAD=1 prints the phases).
+struct LoadJob {
+	bt2g_ctx* c;
+	FileStreamer fs;
+	hipStream_t cs = nullptr;
+	std::vector<void*> temps;
+	unsigned long long* d_lost = nullptr;
+	int off_rate = 0;
+	bool verbose;
+	std::chrono::steady_clock::time_point t0;
+	explicit LoadJob(bt2g_ctx* ctx) : c(ctx), fs(ctx->device), verbose(getenv("BT2G_DEBUG_LOAD") != nullptr), t0(std::chrono::steady_clock::now()) {}
+	~LoadJob() {
+		if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+		for (void* p : temps) (void)hipFree(p);
+	}
+	void lap(const char* what) {
+		if (!verbose) return;
+		const auto t1 = std::chrono::steady_clock::now();
+		fprintf(stderr, "[bt2g] index load: %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+		t0 = t1;
+	}
+	// a temporary device copy of a section: from its file (lazy load) or from the host vector
+	int put(const FileSpan& sp, const std::vector<uint8_t>& v, uint64_t pad, void** out) {
+		const uint64_t nbytes = sp.path.empty() ? v.size() : sp.nbytes;
+		void* p = nullptr;
+		hipError_t e = hipMalloc(&p, nbytes + pad ? nbytes + pad : 256);
 		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(index section)");
-		if (nbytes && (e = hipMemcpy(p, src, nbytes, hipMemcpyHostToDevice)) != hipSuccess) return hip_fail(c, e, "hipMemcpy(index section)");
+		temps.push_back(p);
+		*out = p;
+		return fill(sp, v, p);
+	}
+	int fill(const FileSpan& sp, const std::vector<uint8_t>& v, void* p) {
+		if (sp.path.empty()) {
+			hipError_t e = v.empty() ? hipSuccess : hipMemcpy(p, v.data(), v.size(), hipMemcpyHostToDevice);
+			return e == hipSuccess ? 0 : hip_fail(c, e, "hipMemcpy(index section)");
+		}
+		const int r = fs.put(sp, p);
+		if (r == 1) return fail(c, BT2G_ERR_IO, "cannot read " + sp.path);
+		if (r) return fail(c, BT2G_ERR_HIP, "copying " + sp.path + " to the device failed");
 		return 0;
 	}
 };
@@ -110,8 +226,10 @@ int alloc_index(bt2g_ctx* c, uint64_t nbytes, T** dst) {
 
 // One direction of the index.  The BWT sides and (forward index) the SA sample go to the device as they are in the files and are
 // transcoded there into the layout the kernels query: rank blocks and the full suffix array (bt2g_device.hpp, bt2g_rankidx.hpp).
+// The kernels are queued on the job's stream and not waited for: the caller streams the next section meanwhile (upload_index).
 template <typename TOff>
-int upload_ebwt(bt2g_ctx* c, const HostEbwt& h, bool fw, DevEbwt<TOff>& d) {
+int upload_ebwt(LoadJob& L, const HostEbwt& h, bool fw, DevEbwt<TOff>& d) {
+	bt2g_ctx* c = L.c;
 	int rc;
 	if ((rc = upload(c, h.ftab.data(), h.ftab.size(), &d.ftab))) return rc;
 	if ((rc = upload(c, h.eftab.data(), h.eftab.size(), &d.eftab))) return rc;
@@ -121,37 +239,31 @@ int upload_ebwt(bt2g_ctx* c, const HostEbwt& h, bool fw, DevEbwt<TOff>& d) {
 	for (int i = 0; i < 5; i++) d.fchr[i] = (TOff)h.fchr[i];
 	d.ftab_chars = (uint32_t)h.ftab_chars; d.off_rate = (uint32_t)h.off_rate; d.is_fw = fw ? 1 : 0;
 	{
-		TmpDev sides;
-		if ((rc = sides.put(c, h.ebwt.data(), h.ebwt.size()))) return rc;
-		const uint64_t n_sides = h.ebwt.size() / OffTraits<TOff>::kSideSz;
+		void* sides = nullptr;
+		const uint64_t n_sides = h.ebwt_tot_len / OffTraits<TOff>::kSideSz;
 		const uint64_t n_blocks = rank_block_count(n_sides, OffTraits<TOff>::kSideBwtLen);
 		RankBlock* blk = nullptr;
 		if ((rc = alloc_index(c, n_blocks * sizeof(RankBlock), &blk))) return rc;
-		hipError_t e = launch_make_rank_blocks<TOff>((const uint8_t*)sides.p, n_sides, d.fchr, d.zoff, blk, n_blocks, nullptr);
-		if (e == hipSuccess) e = hipDeviceSynchronize();
+		if ((rc = L.put(h.ebwt_span, h.ebwt, 0, &sides))) return rc;
+		L.lap(fw ? "BWT sides -> device" : "mirror BWT sides -> device");
+		hipError_t e = launch_make_rank_blocks<TOff>((const uint8_t*)sides, n_sides, d.fchr, d.zoff, blk, n_blocks, L.cs);
 		if (e != hipSuccess) return hip_fail(c, e, "k_make_rank_blocks");
 		d.blk = blk;
 	}
 	if (fw) {
-		TmpDev offs;
-		if ((rc = offs.put(c, h.offs.data(), h.offs.size()))) return rc;
+		void* offs = nullptr;
 		uint64_t* sa = nullptr;
 		if ((rc = alloc_index(c, ((uint64_t)h.len + 1) * sizeof(uint64_t), &sa))) return rc;
-		TmpDev lost;
-		const unsigned long long zero = 0;
-		if ((rc = lost.put(c, &zero, sizeof zero))) return rc;
-		hipError_t e = launch_make_full_sa<TOff>(d, (const TOff*)offs.p, sa, (unsigned long long*)lost.p, nullptr);
-		if (e == hipSuccess) e = hipDeviceSynchronize();
+		void* lost = nullptr;
+		hipError_t e = hipMalloc(&lost, 256);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(lost rows)");
+		L.temps.push_back(lost);
+		if ((e = hipMemsetAsync(lost, 0, 256, L.cs)) != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(lost rows)");
+		if ((rc = L.put(h.offs_span, h.offs, 0, &offs))) return rc;
+		L.lap("SA sample -> device");
+		e = launch_make_full_sa<TOff>(d, (const TOff*)offs, sa, (unsigned long long*)lost, L.cs);
 		if (e != hipSuccess) return hip_fail(c, e, "k_sa_segments");
-		unsigned long long n_lost = 0;
-		e = hipMemcpy(&n_lost, lost.p, sizeof n_lost, hipMemcpyDeviceToHost);
-		if (e != hipSuccess) return hip_fail(c, e, "hipMemcpy(lost rows)");
-		if (n_lost) {
-			char msg[256];
-			snprintf(msg, sizeof msg, "the suffix-array sample of this index (--offrate %d) leaves %llu rows more than 65534 LF steps from a sampled row; "
-			         "this build keeps the step count in 16 bits and will not load it (rebuild with a smaller --offrate)", (int)h.off_rate, n_lost);
-			return fail(c, BT2G_ERR_UNSUPPORTED, msg);
-		}
+		L.d_lost = (unsigned long long*)lost; L.off_rate = (int)h.off_rate;
 		d.sa = sa;
 	}
 	return 0;
@@ -159,9 +271,12 @@ int upload_ebwt(bt2g_ctx* c, const HostEbwt& h, bool fw, DevEbwt<TOff>& d) {
 
 template <typename TOff>
 int upload_index(bt2g_ctx* c, const HostIndex& h, DevIndex<TOff>& d) {
+	LoadJob L(c);
+	if (hipStreamCreateWithFlags(&L.cs, hipStreamNonBlocking) != hipSuccess || !L.fs.init()) return fail(c, BT2G_ERR_HIP, "index load: cannot create streams / pinned buffers");
+	L.lap("streams + pinned buffers");
 	int rc;
-	if ((rc = upload_ebwt(c, h.fw, true, d.fw))) return rc;
-	if ((rc = upload_ebwt(c, h.bw, false, d.bw))) return rc;
+	if ((rc = upload_ebwt(L, h.fw, true, d.fw))) return rc;
+	if ((rc = upload_ebwt(L, h.bw, false, d.bw))) return rc;      // (streams in while the forward index's suffix array is being made)
 	if ((rc = upload(c, h.fw.rstarts.data(), h.fw.rstarts.size(), &d.rstarts))) return rc;
 	if ((rc = upload(c, h.fw.plen.data(), h.fw.plen.size(), &d.plen))) return rc;
 	d.n_frag = (TOff)h.fw.n_frag; d.n_pat = (TOff)h.fw.n_pat;
@@ -171,8 +286,32 @@ int upload_index(bt2g_ctx* c, const HostIndex& h, DevIndex<TOff>& d) {
 	if ((rc = upload(c, r.rec_len.data(), r.rec_len.size() * 8, &d.ref.rec_len))) return rc;
 	if ((rc = upload(c, r.ref_rec_offs.data(), r.ref_rec_offs.size() * 8, &d.ref.ref_rec_offs))) return rc;
 	if ((rc = upload(c, r.ref_lens.data(), r.ref_lens.size() * 8, &d.ref.ref_lens))) return rc;
-	if ((rc = upload(c, r.buf.data(), r.buf.size(), &d.ref.buf))) return rc;
+	if (r.buf_span.path.empty()) { if ((rc = upload(c, r.buf.data(), r.buf.size(), &d.ref.buf))) return rc; }
+	else {
+		// (16 bytes of slack behind the 2-bit reference: device code may read a few bytes past the end)
+		uint8_t* buf = nullptr;
+		if ((rc = alloc_index(c, r.buf_span.nbytes + 16, &buf))) return rc;
+		hipError_t e = hipMemsetAsync(buf + r.buf_span.nbytes, 0, 16, L.cs);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMemsetAsync(reference slack)");
+		if ((rc = L.fill(r.buf_span, r.buf, buf))) return rc;
+		d.ref.buf = buf;
+	}
 	d.ref.nrefs = r.nrefs;
+	L.lap("2-bit reference + tables -> device");
+	hipError_t e = hipStreamSynchronize(L.cs);
+	if (e != hipSuccess) return hip_fail(c, e, "index transcoding kernels");
+	L.lap("transcoding kernels (what is left)");
+	if (L.d_lost) {
+		unsigned long long n_lost = 0;
+		e = hipMemcpy(&n_lost, L.d_lost, sizeof n_lost, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return hip_fail(c, e, "hipMemcpy(lost rows)");
+		if (n_lost) {
+			char msg[256];
+			snprintf(msg, sizeof msg, "the suffix-array sample of this index (--offrate %d) leaves %llu rows more than 65534 LF steps from a sampled row; "
+			         "this build keeps the step count in 16 bits and will not load it (rebuild with a smaller --offrate)", L.off_rate, n_lost);
+			return fail(c, BT2G_ERR_UNSUPPORTED, msg);
+		}
+	}
 	return 0;
 }
 
@@ -242,7 +381,9 @@ int bt2g_index_load(bt2g_ctx* c, const char* base) {
 	free_index(c);
 	c->host = new HostIndex();
 	std::string err;
-	int rc = load_index(base, *c->host, err);
+	// (the large sections stay in their files and are streamed to the device; BT2G_LOAD_SERIAL=1: through host memory, as before round 5)
+	static const bool serial = getenv("BT2G_LOAD_SERIAL") != nullptr;
+	int rc = load_index(base, *c->host, err, !serial);
 	if (rc) { fail(c, rc, err); delete c->host; c->host = nullptr; return rc; }
 	c->off_size = c->host->off_size;
 	rc = (c->off_size == 4) ? upload_index(c, *c->host, c->ix32) : upload_index(c, *c->host, c->ix64);

@@ -28,6 +28,15 @@ struct File {
 		v.resize(nbytes);
 		return read(v.data(), nbytes);
 	}
+	// a large section: read into `v`, or (lazy) left in the file and described by `sp`
+	bool raw_or_span(std::vector<uint8_t>& v, FileSpan& sp, const std::string& path, uint64_t nbytes, bool lazy) {
+		if (!lazy) return raw(v, nbytes);
+		if (nbytes > remaining()) return false;
+		const off_t cur = ftello(f);
+		if (cur < 0) return false;
+		sp.path = path; sp.off = (uint64_t)cur; sp.nbytes = nbytes;
+		return skip(nbytes);
+	}
 	uint64_t remaining() {
 		const off_t cur = ftello(f);
 		struct stat st;
@@ -38,7 +47,7 @@ struct File {
 
 bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
-int load_ebwt(const std::string& p1, const std::string& p2, int off_size, bool fw, HostEbwt& e, std::string& err) {
+int load_ebwt(const std::string& p1, const std::string& p2, int off_size, bool fw, HostEbwt& e, std::string& err, bool lazy) {
 	File f(p1);
 	if (!f.ok()) { err = "cannot open " + p1; return BT2G_ERR_IO; }
 	int32_t one = 0, lines_per_side = 0;
@@ -71,7 +80,7 @@ int load_ebwt(const std::string& p1, const std::string& p2, int off_size, bool f
 	if (fw) {
 		if (!f.raw(e.rstarts, e.n_frag * 3 * off_size)) { err = p1 + ": truncated rstarts"; return BT2G_ERR_FORMAT; }
 	} else if (!f.skip(e.n_frag * 3 * off_size)) { err = p1 + ": truncated"; return BT2G_ERR_FORMAT; }
-	if (!f.raw(e.ebwt, e.ebwt_tot_len)) { err = p1 + ": truncated ebwt"; return BT2G_ERR_FORMAT; }
+	if (!f.raw_or_span(e.ebwt, e.ebwt_span, p1, e.ebwt_tot_len, lazy)) { err = p1 + ": truncated ebwt"; return BT2G_ERR_FORMAT; }
 	if (!f.off(off_size, e.zoff)) { err = p1 + ": truncated"; return BT2G_ERR_FORMAT; }
 	for (int i = 0; i < 5; i++) if (!f.off(off_size, e.fchr[i])) { err = p1 + ": truncated fchr"; return BT2G_ERR_FORMAT; }
 	if (!f.raw(e.ftab, e.ftab_len * off_size) || !f.raw(e.eftab, e.eftab_len * off_size)) {
@@ -88,14 +97,14 @@ int load_ebwt(const std::string& p1, const std::string& p2, int off_size, bool f
 		}
 		File g(p2);
 		if (!g.ok()) { err = "cannot open " + p2; return BT2G_ERR_IO; }
-		if (!g.read(&one, 4) || one != 1 || !g.raw(e.offs, e.offs_len * off_size)) {
+		if (!g.read(&one, 4) || one != 1 || !g.raw_or_span(e.offs, e.offs_span, p2, e.offs_len * off_size, lazy)) {
 			err = p2 + ": truncated SA sample"; return BT2G_ERR_FORMAT;
 		}
 	}
 	return 0;
 }
 
-int load_ref(const std::string& p3, const std::string& p4, int off_size, HostRef& r, std::string& err) {
+int load_ref(const std::string& p3, const std::string& p4, int off_size, HostRef& r, std::string& err, bool lazy) {
 	File f(p3);
 	if (!f.ok()) { err = "cannot open " + p3; return BT2G_ERR_IO; }
 	int32_t one = 0;
@@ -125,8 +134,8 @@ int load_ref(const std::string& p3, const std::string& p4, int off_size, HostRef
 	r.buf_sz = cumsz;
 	File g(p4);
 	if (!g.ok()) { err = "cannot open " + p4; return BT2G_ERR_IO; }
-	if (!g.raw(r.buf, (cumsz + 3) / 4)) { err = p4 + ": truncated"; return BT2G_ERR_FORMAT; }
-	r.buf.resize(r.buf.size() + 16, 0); // slack so device code may read a few bytes past the end
+	if (!g.raw_or_span(r.buf, r.buf_span, p4, (cumsz + 3) / 4, lazy)) { err = p4 + ": truncated"; return BT2G_ERR_FORMAT; }
+	if (!lazy) r.buf.resize(r.buf.size() + 16, 0); // slack so device code may read a few bytes past the end
 	return 0;
 }
 
@@ -137,28 +146,28 @@ uint64_t HostIndex::plen_at(uint64_t i) const {
 	uint64_t v; memcpy(&v, fw.plen.data() + i * 8, 8); return v;
 }
 
-static int load_index_impl(const std::string& base, HostIndex& out, std::string& err);
+static int load_index_impl(const std::string& base, HostIndex& out, std::string& err, bool lazy);
 
-int load_index(const std::string& base, HostIndex& out, std::string& err) {
+int load_index(const std::string& base, HostIndex& out, std::string& err, bool lazy) {
 	// no exception may cross the C ABI (bt2g_index_load): allocation failures and length errors become status codes
-	try { return load_index_impl(base, out, err); }
+	try { return load_index_impl(base, out, err, lazy); }
 	catch (const std::bad_alloc&) { err = "out of host memory while reading the index"; return BT2G_ERR_NOMEM; }
 	catch (const std::exception& e) { err = std::string("malformed index: ") + e.what(); return BT2G_ERR_FORMAT; }
 }
 
-static int load_index_impl(const std::string& base, HostIndex& out, std::string& err) {
+static int load_index_impl(const std::string& base, HostIndex& out, std::string& err, bool lazy) {
 	std::string ext = "bt2";
 	out.off_size = 4;
 	if (!exists(base + ".1.bt2")) {
 		if (!exists(base + ".1.bt2l")) { err = "no index found at " + base + ".1.bt2[l]"; return BT2G_ERR_IO; }
 		ext = "bt2l"; out.off_size = 8;
 	}
-	int rc = load_ebwt(base + ".1." + ext, base + ".2." + ext, out.off_size, true, out.fw, err);
+	int rc = load_ebwt(base + ".1." + ext, base + ".2." + ext, out.off_size, true, out.fw, err, lazy);
 	if (rc) return rc;
-	rc = load_ebwt(base + ".rev.1." + ext, "", out.off_size, false, out.bw, err);
+	rc = load_ebwt(base + ".rev.1." + ext, "", out.off_size, false, out.bw, err, lazy);
 	if (rc) return rc;
 	if (out.bw.len != out.fw.len || out.bw.ftab_chars != out.fw.ftab_chars) { err = "forward/mirror index mismatch"; return BT2G_ERR_FORMAT; }
-	rc = load_ref(base + ".3." + ext, base + ".4." + ext, out.off_size, out.ref, err);
+	rc = load_ref(base + ".3." + ext, base + ".4." + ext, out.off_size, out.ref, err, lazy);
 	if (rc) return rc;
 	if (out.ref.nrefs != out.fw.n_pat) {
 		// The .3 file may list empty (all-N) references the .1 file drops; the reference tolerates

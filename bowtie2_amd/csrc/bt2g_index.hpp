@@ -13,6 +13,11 @@
 
 namespace bt2g {
 
+// A byte range of an index file its user reads itself.  load_index(..., lazy = true) leaves the three large sections -- the BWT sides, the
+// suffix-array sample, the 2-bit reference -- in their files and says where they are: bt2g_index_load streams them to the device through
+// pinned buffers instead of through a second copy in pageable host memory.
+struct FileSpan { std::string path; uint64_t off = 0, nbytes = 0; };
+
 struct HostEbwt {
 	uint64_t len = 0;
 	int32_t  line_rate = 0, off_rate = 0, ftab_chars = 0, flags = 0;
@@ -22,6 +27,7 @@ struct HostEbwt {
 	uint64_t fchr[5] = {0, 0, 0, 0, 0};
 	std::vector<uint8_t> plen, rstarts, ebwt, ftab, eftab, offs; // raw little-endian arrays, on-disk width
 	std::vector<std::string> refnames;
+	FileSpan ebwt_span, offs_span;       // lazy load: where `ebwt` and `offs` are (the vectors stay empty)
 };
 
 struct HostRef {
@@ -31,7 +37,8 @@ struct HostRef {
 	std::vector<uint64_t> rec_refpos, rec_bufpos, rec_len;
 	std::vector<uint64_t> ref_rec_offs; // [nrefs+1]
 	std::vector<uint64_t> ref_lens;     // [nrefs]
-	std::vector<uint8_t>  buf;          // 2-bit packed
+	std::vector<uint8_t>  buf;          // 2-bit packed (+ 16 bytes of slack)
+	FileSpan buf_span;                  // lazy load: where `buf` is (without the slack)
 };
 
 struct HostIndex {
@@ -42,7 +49,7 @@ struct HostIndex {
 };
 
 // Returns 0 or a negative bt2g_status; err receives a message.
-int load_index(const std::string& base, HostIndex& out, std::string& err);
+int load_index(const std::string& base, HostIndex& out, std::string& err, bool lazy = false);
 
 } // namespace bt2g
 #endif
