@@ -63,7 +63,7 @@ def conflicts(a):
     if flat.count("--policy")>1: return True
     if "--soft-clipped-unmapped-tlen" in flat and not ("--local" in flat or "-local" in flat or "--bwa-sw-like" in flat): return True
     return False
-nfail=0; t0=time.time()
+nfail=0; nwarn=0; t0=time.time()
 for it in range(nit):
     rnd=random.Random(seed0*100003+it)
     d='/tmp/fuzz/w%d'%seed0; os.makedirs(d,exist_ok=True)
@@ -145,8 +145,9 @@ for it in range(nit):
     body=lambda t:[l for l in t.splitlines() if not l.startswith("@PG")]
     if a.returncode!=0: continue
     warn="Warning: " in b.stderr and ("overflow" in b.stderr or "exceeded" in b.stderr)
+    nwarn+=1 if warn else 0
     if body(a.stdout)!=body(b.stdout) and not warn:
         nfail+=1
         keep='/tmp/fuzz/case_%d_%d'%(seed0,it); os.system("rm -rf %s; cp -r %s %s"%(keep,d,keep))
         out.write(json.dumps({"it":it,"args":args,"paired":paired,"large":large,"rc":b.returncode,"err":b.stderr[-300:]})+"\n"); out.flush()
-print("seed",seed0,"iters",nit,"fails",nfail,"%.0fs"%(time.time()-t0))
+print("seed",seed0,"iters",nit,"fails",nfail,"flagged (not compared)",nwarn,"%.0fs"%(time.time()-t0))
