@@ -269,10 +269,14 @@ int upload_ebwt(LoadJob& L, const HostEbwt& h, bool fw, DevEbwt<TOff>& d) {
 	return 0;
 }
 
+constexpr int kLoadRetryEager = 1;      // upload_index: the streamed load could not start (no bt2g_status is positive)
+
 template <typename TOff>
 int upload_index(bt2g_ctx* c, const HostIndex& h, DevIndex<TOff>& d) {
 	LoadJob L(c);
-	if (hipStreamCreateWithFlags(&L.cs, hipStreamNonBlocking) != hipSuccess || !L.fs.init()) return fail(c, BT2G_ERR_HIP, "index load: cannot create streams / pinned buffers");
+	if (hipStreamCreateWithFlags(&L.cs, hipStreamNonBlocking) != hipSuccess) return fail(c, BT2G_ERR_HIP, "index load: cannot create a stream");
+	// (pinned buffers only when sections are to be streamed; a host that will not pin 96 MB gets the load through host memory instead)
+	if (!h.fw.ebwt_span.path.empty() && !L.fs.init()) return kLoadRetryEager;
 	L.lap("streams + pinned buffers");
 	int rc;
 	if ((rc = upload_ebwt(L, h.fw, true, d.fw))) return rc;
@@ -383,10 +387,16 @@ int bt2g_index_load(bt2g_ctx* c, const char* base) {
 	std::string err;
 	// (the large sections stay in their files and are streamed to the device; BT2G_LOAD_SERIAL=1: through host memory, as before round 5)
 	static const bool serial = getenv("BT2G_LOAD_SERIAL") != nullptr;
-	int rc = load_index(base, *c->host, err, !serial);
-	if (rc) { fail(c, rc, err); delete c->host; c->host = nullptr; return rc; }
-	c->off_size = c->host->off_size;
-	rc = (c->off_size == 4) ? upload_index(c, *c->host, c->ix32) : upload_index(c, *c->host, c->ix64);
+	int rc = 0;
+	for (int lazy = serial ? 0 : 1; lazy >= 0; lazy--) {
+		rc = load_index(base, *c->host, err, lazy != 0);
+		if (rc) { fail(c, rc, err); delete c->host; c->host = nullptr; return rc; }
+		c->off_size = c->host->off_size;
+		rc = (c->off_size == 4) ? upload_index(c, *c->host, c->ix32) : upload_index(c, *c->host, c->ix64);
+		if (rc != kLoadRetryEager) break;
+		free_index(c);
+		c->host = new HostIndex();
+	}
 	if (rc) { free_index(c); return rc; }
 	// keep only header fields, names and lengths on the host
 	HostIndex& h = *c->host;
