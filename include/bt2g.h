@@ -73,6 +73,11 @@ typedef struct {
  * in HBM.  Replaces Ebwt::Ebwt + Ebwt::loadIntoMemory for both directions
  * (bt2_search.cpp:4986,5155,4832-4854; bt2_io.cpp:39-633) and
  * BitPairReference::BitPairReference (reference.cpp:30-264).  Synchronous.
+ * The three large sections (BWT sides, SA sample, 2-bit reference) are streamed
+ * from the files to the device through pinned buffers by a few reader threads
+ * while the sections already there are transcoded (3.1 Gbp .bt2l: ~0.6 s from
+ * the page cache); a host that cannot pin the buffers gets the same load through
+ * host memory.  The files must not change while the call runs.
  */
 int bt2g_index_load(bt2g_ctx *ctx, const char *base);
 int bt2g_index_info_get(const bt2g_ctx *ctx, bt2g_index_info *out);
