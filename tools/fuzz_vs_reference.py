@@ -17,6 +17,7 @@ MODE=int(os.environ.get('FUZZ_MODE','1'))     # 2: small repeat-dense genomes, s
 LONG=os.environ.get('FUZZ_LONG')              # half of the unpaired reads 513 ... 1 999 bp long
 LOCAL=os.environ.get('FUZZ_LOCAL')            # every case in local mode, reads up to 500 bp (with BT2G_CHECK_LOCAL_PK=1: the packed local fill replayed on every window)
 out=open('/tmp/fuzz/fail_%d.log'%seed0,'w')
+flog=open('/tmp/fuzz/flagged_%d.log'%seed0,'w')
 def rnd_genome(rnd):
     nref=rnd.randrange(1,4)
     refs=[]
@@ -145,7 +146,10 @@ for it in range(nit):
     body=lambda t:[l for l in t.splitlines() if not l.startswith("@PG")]
     if a.returncode!=0: continue
     warn="Warning: " in b.stderr and ("overflow" in b.stderr or "exceeded" in b.stderr)
-    nwarn+=1 if warn else 0
+    if warn:      # which capacity: the sites of the flagged reads go to the log, the case is not compared
+        nwarn+=1
+        sites=sorted(set(l.split("site")[-1].strip(" )") for l in b.stderr.splitlines() if l.startswith("Warning: read") and "site" in l))
+        flog.write(json.dumps({"it":it,"args":args,"paired":paired,"sites":sites,"long":bool(LONG)})+"\n"); flog.flush()
     if body(a.stdout)!=body(b.stdout) and not warn:
         nfail+=1
         keep='/tmp/fuzz/case_%d_%d'%(seed0,it); os.system("rm -rf %s; cp -r %s %s"%(keep,d,keep))
