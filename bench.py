@@ -764,7 +764,8 @@ def main():
     ctx = _DryContext(large) if dry else b.Context(local_rank)
     t0 = time.time()
     info = ctx.load_index(base)
-    log("[bench] index loaded into HBM in %.1fs (%.2f GB)" % (time.time() - t0, info.hbm_bytes / 1e9))
+    index_load_s = time.time() - t0
+    log("[bench] index loaded into HBM in %.2fs (%.2f GB)" % (index_load_s, info.hbm_bytes / 1e9))
     # per-rank shard of reads (weak scaling: fixed reads per GPU)
     n = args.reads
     if args.paired:
@@ -958,7 +959,7 @@ def main():
                 "n_gpu_merge": None if world == 1 else "every step also packs the result records (bt2g_results_pack) and gathers them to rank 0 over RCCL: %d bytes arrived on rank 0 in the last step" % sum(int(t.numel()) for t in last["gathered"]),
                 "fraction_aligned": all_aligned / float(world * n),
                 "index_bytes_hbm": int(info.hbm_bytes), "side_sz": int(side), "off_size": int(off_sz),
-                "index_build": build_info,
+                "index_build": build_info, "index_load_s": round(index_load_s, 3),
                 "bw_ops_per_read": rankq / n, "dp_fills_per_read": float(h["n_ex_dps"].sum()) / n,
                 "backtraces_per_read": float(h["n_bt_attempts"].sum()) / n,
                 "reads_overflowed": int((h["status"] != 0).sum()),
