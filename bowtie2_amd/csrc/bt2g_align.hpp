@@ -364,7 +364,11 @@ struct Work {
 };
 
 // DP scratch addressing (wavefront-major, see bt2g_kernels.hip)
-BT2_HD uint32_t dp_R(uint32_t rows) { return (rows + 63) / 64; }
+// rows per lane of the wavefront-major 16-bit matrix; the long-read class rounds up to the fills it instantiates (8 and below as they are, then 16, 24, 32)
+BT2_HD uint32_t dp_R(uint32_t rows) {
+	const uint32_t r = (rows + 63) / 64;
+	return (kMaxLen > 512 && r > 8) ? (r + 7) & ~7u : r;
+}
 // wavefront-major, one packed word per cell: H | E<<8 | F<<16 at word index (t*R + r)*64 + lane
 BT2_HD uint64_t dp_cell(uint32_t R, uint32_t i, uint32_t j) {
 	const uint32_t l = i / R, r = i % R;

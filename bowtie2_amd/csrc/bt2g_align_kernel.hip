@@ -320,21 +320,24 @@ __device__ __forceinline__ int fill_ee_i16_wave(const AlignParams& P, bool fw, u
 	return __shfl(best, (int)((rows - 1) / R));
 }
 
-// The same fill for reads of more than 512 rows (the long-read class: up to 32 rows per lane).  The per-row state is indexed at run time, i.e.
-// it lives in scratch memory: instantiating the register form for 12 ... 32 rows per lane did not finish compiling (round 5), and a read this
-// long is rare and slow whatever the fill does -- it fills millions of cells per window.  Same values, same matrix layout (dp_cell).
-__device__ __attribute__((noinline)) int fill_ee_i16_leaf_long(bool fw_, uint32_t rows_, uint32_t cols_, uint64_t* m64_, uint32_t R_) {
+// The same fill for reads of more than 512 rows (the long-read class: 16, 24 or 32 rows per lane, dp_R rounds up to these).  fill_ee_i16_wave's
+// eight arrays of R registers do not fit at this R (and instantiating it for every R from 12 to 32 did not finish compiling, round 5): here a
+// row's constants are one register (read character | mismatch penalty << 8 | gap veto << 16) and its previous H and E another (two 16-bit
+// halves, as they are stored), the cells of a step are computed and stored one after the other.  Same values, same matrix layout (dp_cell).
+#ifdef BT2G_KCLASS_LR
+template <int R>
+__device__ __attribute__((noinline)) int fill_ee_i16_leaf_big(bool fw_, uint32_t rows_, uint32_t cols_, uint64_t* m64_) {
 	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
 	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
-	const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)R_);      // <= 32
 	const uint64_t pa = (uint64_t)reinterpret_cast<uintptr_t>(m64_);
 	uint64_t* scratch = reinterpret_cast<uint64_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa));
 	const AlignParams& P = g_P;
+	const int rdgapo = P.rdgapo, rdgape = P.rdgape, rfgapo = P.rfgapo, rfgape = P.rfgape, n_pen = P.n_pen, bonus = P.match_bonus;
 	const int lane = threadIdx.x & 63;
 	const uint32_t nlanes = (rows + R - 1) / R;
-	uint32_t rowc[32];       // per row: read character | mismatch penalty << 8 | gap veto << 16
-	int Hprev[32], Eprev[32];
-	for (uint32_t r = 0; r < R; r++) {
+	uint32_t rowc[R], he[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
 		const uint32_t i = (uint32_t)lane * R + r;
 		const bool valid = i < rows;
 		const int rdc = valid ? rd_char(g_hot, g_hot.len, fw, i) : 4;
@@ -342,12 +345,12 @@ __device__ __attribute__((noinline)) int fill_ee_i16_leaf_long(bool fw_, uint32_
 		const int mmp = mm_penalty(P, q < 0 ? 0 : q);
 		const int veto = (valid && ((int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar)) ? 1 : 0;
 		rowc[r] = (uint32_t)rdc | ((uint32_t)(mmp & 0xff) << 8) | ((uint32_t)veto << 16);
-		Hprev[r] = kLo; Eprev[r] = kLo;
+		he[r] = 0x80008000u;       // H = E = minus infinity
 	}
 	int myHlast = kLo, myFlast = kLo, upHdiag = kLo, refm = 0, best = kLo;
 	const uint32_t steps = cols + nlanes - 1;
 	const bool lane_has_last = ((rows - 1) / R) == (uint32_t)lane;
-	const uint32_t last_r = (rows - 1) % R;
+	const int last_r = (int)((rows - 1) % R);
 	for (uint32_t t = 0; t < steps; t++) {
 		const int upH = __shfl_up(myHlast, 1);
 		const int upF = __shfl_up(myFlast, 1);
@@ -360,34 +363,37 @@ __device__ __attribute__((noinline)) int fill_ee_i16_leaf_long(bool fw_, uint32_
 		if (refm & 1) refc = 0; else if (refm & 2) refc = 1; else if (refm & 4) refc = 2; else if (refm & 8) refc = 3;
 		int hdiag = (lane == 0) ? 0x7fff : (j == 0 ? kLo : upHdiag);
 		int fin_h = upH, fin_f = upF;
-		uint64_t* base = scratch + ((uint64_t)t * R) * 64 + lane;
-		int hlast = kLo, flast = kLo, hbest = kLo;
-		for (uint32_t r = 0; r < R; r++) {
+		uint64_t* base = scratch + ((uint64_t)t * R) * 64 + lane;     // 512 contiguous bytes per store
+		int hbest = kLo;
+#pragma unroll
+		for (int r = 0; r < R; r++) {
 			const uint32_t rc = rowc[r];
-			const int rdc = (int)(rc & 0xff), mmp = (int)((rc >> 8) & 0xff), veto = (int)((rc >> 16) & 1);
+			const int rdc = (int)(rc & 0xff), mmp = (int)((rc >> 8) & 0xff);
+			const bool veto = (rc >> 16) != 0;
+			const int hp = (int)(int16_t)(uint16_t)(he[r] & 0xffffu), ep = (int)(int16_t)(uint16_t)(he[r] >> 16);
 			int pen;
-			if (rdc > 3 || refc > 3) pen = P.n_pen; else pen = (rdc == refc) ? -P.match_bonus : mmp;
-			const int hp = Hprev[r], ep = Eprev[r];
-			const int e = (j == 0) ? kLo : imax(subs16(ep, P.rdgape), veto ? kLo : subs16(hp, P.rdgapo));
+			if (rdc > 3 || refc > 3) pen = n_pen; else pen = (rdc == refc) ? -bonus : mmp;
+			const int e = (j == 0) ? kLo : imax(subs16(ep, rdgape), veto ? kLo : subs16(hp, rdgapo));
 			int f;
 			if (lane == 0 && r == 0) f = kLo;
-			else f = veto ? kLo : imax(subs16(fin_f, P.rfgape), subs16(fin_h, P.rfgapo));
+			else f = veto ? kLo : imax(subs16(fin_f, rfgape), subs16(fin_h, rfgapo));
 			const int h = imax(imax(subs16(hdiag, pen), e), f);
 			hdiag = hp;
 			fin_h = h; fin_f = f;
+			const uint32_t lo = (uint32_t)(uint16_t)h | ((uint32_t)(uint16_t)e << 16);
 			if (active) {
-				base[r * 64] = (uint64_t)(uint16_t)h | ((uint64_t)(uint16_t)e << 16) | ((uint64_t)(uint16_t)f << 32);
-				Hprev[r] = h; Eprev[r] = e;
+				base[r * 64] = (uint64_t)lo | ((uint64_t)(uint16_t)f << 32);
+				he[r] = lo;
 				if (r == last_r) hbest = h;
 			}
-			hlast = h; flast = f;
 		}
 		if (active && lane_has_last) best = imax(best, hbest);
 		upHdiag = upH;
-		if (active) { myHlast = hlast; myFlast = flast; }
+		if (active) { myHlast = fin_h; myFlast = fin_f; }
 	}
 	return __shfl(best, (int)((rows - 1) / R));
 }
+#endif
 
 // Local-mode fill (alignNucleotidesLocalSseU8 / ...I16; they agree wherever the 8-bit kernel does not saturate): plain scores, floor 0,
 // two cells per register (bt2g_local_pk.hpp: the cell arithmetic and why a lane owns block `lane` in its low halves and block `lane + 64` in
@@ -1430,7 +1436,9 @@ struct DevPlat {
 				case 7: best = fill_ee_i16_leaf<7>(fw, rows, cols, m64); break;
 #ifdef BT2G_KCLASS_LR
 				case 8: best = fill_ee_i16_leaf<8>(fw, rows, cols, m64); break;
-				default: best = fill_ee_i16_leaf_long(fw, rows, cols, m64, dp_R(rows)); break;
+				case 16: best = fill_ee_i16_leaf_big<16>(fw, rows, cols, m64); break;      // (dp_R rounds up to what is instantiated)
+				case 24: best = fill_ee_i16_leaf_big<24>(fw, rows, cols, m64); break;
+				default: best = fill_ee_i16_leaf_big<32>(fw, rows, cols, m64); break;
 #else
 				default: best = fill_ee_i16_leaf<8>(fw, rows, cols, m64); break;
 #endif
