@@ -25,7 +25,7 @@ extern "C" {
 
 int bt2g_ctx_create(int, bt2g_ctx** out) {
 	bt2g_ctx* c = new bt2g_ctx();
-	c->w = new Work();
+	c->w = (Work*)calloc(1, sizeof(Work));      // (zero pages on first touch)
 	const uint64_t mat_bytes = ((uint64_t)kMaxColsWide + 64) * dp_R(kMaxLen) * 64 * 8;
 	for (DpScratch* d : {&c->dp, &c->dp2}) {
 		d->mat = (uint32_t*)malloc(mat_bytes); d->masks = (uint16_t*)malloc((size_t)kMaxLen * (kMaxColsWide + 8) * 2);

@@ -19,6 +19,8 @@
 #include "../../bowtie2_amd/csrc/bt2g_host.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_pipeline.hpp"
 #include "../../bowtie2_amd/csrc/bt2g_cli.hpp"
+#include <type_traits>
+static_assert(std::is_trivially_default_constructible<bt2g::Work>::value && std::is_trivially_destructible<bt2g::Work>::value, "Work is allocated with calloc");
 
 using namespace bt2g;
 
@@ -664,7 +666,7 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 	fwrite(o.data(), 1, o.size(), out);
 	FastqBatcher fq(opt.reads_file, opt, 1);       // the product's reader, single-threaded
 	if (!fq.ok()) { fprintf(stderr, "cannot open %s\n", opt.reads_file.c_str()); return 1; }
-	Work* w = new Work();
+	Work* w = (Work*)calloc(1, sizeof(Work));      // (zero pages on first touch: value-initialising the class-sized Work cost every start of the twin ~50 ms)
 	DpScratch dp;
 	const uint64_t mat_bytes = ((uint64_t)kMaxColsWide + 64) * dp_R(kMaxLen) * 64 * 8;
 	dp.mat = (uint32_t*)malloc(mat_bytes);
@@ -741,7 +743,7 @@ static int run_pairs(const HostIndex& hidx, const Options& opt, FILE* out, bool 
 	FastqBatcher fq1(inter ? opt.interleaved_file : opt.mate1_file, opt, 1), fq2(inter ? std::string("/dev/null") : opt.mate2_file, opt, 1);
 	if (!inter) { fq1.set_bam_mate(1); fq2.set_bam_mate(2); }
 	if (!fq1.ok() || !fq2.ok()) { fprintf(stderr, "cannot open the mate files\n"); return 1; }
-	Work* w = new Work();
+	Work* w = (Work*)calloc(1, sizeof(Work));      // (zero pages on first touch: value-initialising the class-sized Work cost every start of the twin ~50 ms)
 	DpScratch dp, dp2;
 	const uint64_t mat_bytes = ((uint64_t)kMaxColsWide + 64) * dp_R(kMaxLen) * 64 * 8;
 	dp.mat = (uint32_t*)malloc(mat_bytes); dp.masks = (uint16_t*)malloc((size_t)kMaxLen * (kMaxColsWide + 8) * 2);

@@ -66,7 +66,9 @@ def make_pairs(n, seed):
     return refs, r1, r2
 
 
-def check(exe_s, exe_l, n, option_sets, extra=()):
+def check(exe_s, exe_l, n, option_sets, extra=(), jobs=1):
+    """jobs > 1 (the CPU twin): the (index width, option set) runs are independent processes and go through a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
     refs, r1, r2 = make_pairs(n, 9)
     d = os.path.join(CACHE_DIR, "paired")
     os.makedirs(d, exist_ok=True)
@@ -74,24 +76,37 @@ def check(exe_s, exe_l, n, option_sets, extra=()):
     write_fasta(fa, refs)
     write_fastq(f1, r1)
     write_fastq(f2, r2)
-    kinds = set()
+    todo = []
     for large, exe in ((False, exe_s), (True, exe_l)):
         base = os.path.join(d, "g" + ("l" if large else "s"))
         build_index(fa, base, large)
+        for k, args in enumerate(option_sets):
+            todo.append((large, exe, base, args, os.path.join(d, "ref_%d_%d.sam" % (large, k))))
+
+    def one(item):
+        large, exe, base, args, rs = item
         ref_exe = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
-        for args in option_sets:
-            rs = os.path.join(d, "ref.sam")
-            pr = subprocess.run([ref_exe] + args + ["-x", base, "-1", f1, "-2", f2, "-p", "8", "--reorder", "-S", rs], stderr=subprocess.PIPE, text=True)
-            want = [l.rstrip("\n") for l in open(rs) if not l.startswith("@PG")]
-            p = subprocess.run([exe] + list(extra) + args + ["-x", base, "-1", f1, "-2", f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-            assert p.returncode == 0 and "Warning" not in p.stderr, p.stderr[-800:]
-            got = [l for l in p.stdout.splitlines() if not l.startswith("@PG")]
-            assert len(got) == len(want), (large, args)
-            bad = [i for i in range(len(got)) if got[i] != want[i]]
-            assert not bad, (large, args, len(bad), want[bad[0]], got[bad[0]])
-            keep = lambda txt: [l for l in txt.splitlines() if not l.startswith("Warning") and "amdgpu.ids" not in l and not l.startswith("[bt2g]")]
-            assert keep(p.stderr) == keep(pr.stderr), (large, args)      # the paired alignment summary
-            kinds.update(l.rsplit("YT:Z:", 1)[1][:2] for l in want if "YT:Z:" in l)
+        pr = subprocess.run([ref_exe] + args + ["-x", base, "-1", f1, "-2", f2, "-p", "8" if jobs == 1 else "2", "--reorder", "-S", rs], stderr=subprocess.PIPE, text=True)
+        want = [l.rstrip("\n") for l in open(rs) if not l.startswith("@PG")]
+        os.remove(rs)
+        p = subprocess.run([exe] + list(extra) + args + ["-x", base, "-1", f1, "-2", f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        return pr, want, p
+
+    if jobs > 1:
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            done = list(ex.map(one, todo))
+    else:
+        done = [one(t) for t in todo]
+    kinds = set()
+    for (large, exe, base, args, rs), (pr, want, p) in zip(todo, done):
+        assert p.returncode == 0 and "Warning" not in p.stderr, p.stderr[-800:]
+        got = [l for l in p.stdout.splitlines() if not l.startswith("@PG")]
+        assert len(got) == len(want), (large, args)
+        bad = [i for i in range(len(got)) if got[i] != want[i]]
+        assert not bad, (large, args, len(bad), want[bad[0]], got[bad[0]])
+        keep = lambda txt: [l for l in txt.splitlines() if not l.startswith("Warning") and "amdgpu.ids" not in l and not l.startswith("[bt2g]")]
+        assert keep(p.stderr) == keep(pr.stderr), (large, args)      # the paired alignment summary
+        kinds.update(l.rsplit("YT:Z:", 1)[1][:2] for l in want if "YT:Z:" in l)
     assert {"CP", "DP", "UP"} <= kinds
     # --interleaved: the same pairs from one file; -s/-u count pairs
     fi = os.path.join(d, "inter.fq")
@@ -109,7 +124,7 @@ def check(exe_s, exe_l, n, option_sets, extra=()):
 def test_paired_hostsim():
     exe = os.path.join(HS, "hostsim")
     build_hostsim(exe)
-    check(exe, exe, 500, OPTION_SETS)
+    check(exe, exe, 500, OPTION_SETS, jobs=min(8, os.cpu_count() or 1))
 
 
 @pytest.mark.gpu

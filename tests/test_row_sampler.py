@@ -69,12 +69,23 @@ def body(text):
     return [l for l in text.splitlines() if not l.startswith("@PG")]
 
 
-def check(exe, large):
+def check(exe, large, jobs=1):
+    """jobs > 1 (the CPU twin): the option sets are independent processes and go through a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
     base, fq = workload(large)
     ref = ref_bin("bowtie2-align-l" if large else "bowtie2-align-s")
-    for opts in OPTS:
+
+    def one(opts):
         r = subprocess.run([ref] + opts + ["-x", base, "-U", fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
         o = subprocess.run([exe] + opts + ["-x", base, "-U", fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+        return r, o
+
+    if jobs > 1:
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            done = list(ex.map(one, OPTS))
+    else:
+        done = [one(o) for o in OPTS]
+    for opts, (r, o) in zip(OPTS, done):
         assert r.returncode == 0, (opts, r.stderr[-300:])
         assert o.returncode == 0 and "Warning" not in o.stderr, (opts, o.stderr[-300:])
         a, b = body(r.stdout), body(o.stdout)
@@ -87,7 +98,7 @@ def check(exe, large):
 def test_row_sampler_host_twin(tmp_path, large):
     exe = str(tmp_path / "hostsim")
     build_hostsim(exe)
-    check(exe, large)
+    check(exe, large, jobs=min(8, os.cpu_count() or 1))
 
 
 @pytest.mark.gpu

@@ -55,22 +55,37 @@ def workloads():
     return base, fq, pbase, m1, m2
 
 
-def check(exe, extra):
+def check(exe, extra, jobs=1):
+    """jobs > 1 (the CPU twin): the option sets are independent processes and go through a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
     base, fq, pbase, m1, m2 = workloads()
     ref = ref_bin("bowtie2-align-s")
-    default = run(ref, ["-x", base, "-U", fq], ["-p", "8", "--reorder"])
-    for opts in SE_SETS:
-        want = run(ref, opts + ["--index" if "--khits" in opts else "-x", base, "--unpaired" if "--khits" in opts else "-U", fq], ["-p", "8", "--reorder"])
-        assert want[0] != default[0], opts                      # the knob binds on this workload
-        assert run(exe, opts + ["--index" if "--khits" in opts else "-x", base, "--unpaired" if "--khits" in opts else "-U", fq], extra) == want, opts
-    for opts in PE_SETS:
+    rp = ["-p", "8", "--reorder"]
+    default = run(ref, ["-x", base, "-U", fq], rp)
+
+    def se(opts):
+        a = opts + ["--index" if "--khits" in opts else "-x", base, "--unpaired" if "--khits" in opts else "-U", fq]
+        return run(ref, a, rp), run(exe, a, extra)
+
+    def pe(opts):
         a = opts + ["-x", pbase, "-1", m1, "-2", m2]
-        assert run(exe, a, extra) == run(ref, a, ["-p", "8", "--reorder"]), opts
+        return run(ref, a, rp), run(exe, a, extra)
+
+    if jobs > 1:
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            d_se, d_pe = list(ex.map(se, SE_SETS)), list(ex.map(pe, PE_SETS))
+    else:
+        d_se, d_pe = [se(o) for o in SE_SETS], [pe(o) for o in PE_SETS]
+    for opts, (want, got) in zip(SE_SETS, d_se):
+        assert want[0] != default[0], opts                      # the knob binds on this workload
+        assert got == want, opts
+    for opts, (want, got) in zip(PE_SETS, d_pe):
+        assert got == want, opts
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 def test_effort_knobs_match_reference_hostsim(hostsim):
-    check(hostsim, [])
+    check(hostsim, [], jobs=min(8, os.cpu_count() or 1))
 
 
 @pytest.mark.gpu
