@@ -180,7 +180,72 @@ def synth_genome_bacterial(seed, device):
     return G, [n]
 
 
-def build_index_gpu(base, G, chrom_lens, large, device_index):
+def load_fasta_codes(path, device):
+    """A real reference: FASTA (plain or gzip) -> codes 0..3 / 4 = anything else, as one uint8 tensor + per-sequence lengths and names.
+    Sequences of length 0 are dropped (bowtie2-build keeps them out of the index as well)."""
+    import gzip
+    import numpy as np
+    import torch
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:2] == b"\x1f\x8b":
+        raw = gzip.decompress(raw)
+    a = np.frombuffer(raw, dtype=np.uint8)
+    lut = np.full(256, 4, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+        lut[c + 32] = i
+    nl = np.flatnonzero(a == 10)
+    gt = np.flatnonzero(a == ord(">"))
+    heads = gt[(gt == 0) | (a[np.maximum(gt, 1) - 1] == 10)]
+    names, parts, lens = [], [], []
+    for k, h in enumerate(heads):
+        e = nl[np.searchsorted(nl, h)] if np.searchsorted(nl, h) < nl.size else a.size
+        stop = heads[k + 1] if k + 1 < heads.size else a.size
+        body = a[e + 1:stop]
+        body = body[(body != 10) & (body != 13) & (body != 32)]
+        if body.size == 0:
+            continue
+        names.append(bytes(a[h + 1:e]).decode("latin-1").rstrip("\r"))
+        parts.append(lut[body])
+        lens.append(int(body.size))
+    if not parts:
+        raise SystemExit("bench.py: no sequence in %s" % path)
+    G = torch.from_numpy(np.concatenate(parts)).to(device)
+    return G, lens, names
+
+
+def genome_from_index(base, ext, device):
+    """The reference sequence back out of an existing index (<base>.3.<ext> = records of {Ns before the stretch, unambiguous bases, first-of-a-sequence},
+    <base>.4.<ext> = the unambiguous bases, 2 bits each; reference.cpp:100-171) -- so that reads can be sampled from a genome given only as an index."""
+    import numpy as np
+    import torch
+    W = np.dtype("<u8") if ext == "bt2l" else np.dtype("<u4")
+    with open("%s.3.%s" % (base, ext), "rb") as f:
+        raw = f.read()
+    assert int(np.frombuffer(raw[:4], dtype="<i4")[0]) == 1, "endianness word of the .3 file"
+    nrec = int(np.frombuffer(raw[4:4 + W.itemsize], dtype=W)[0])
+    rec = np.frombuffer(raw[4 + W.itemsize:4 + W.itemsize + nrec * (2 * W.itemsize + 1)], dtype=np.dtype([("off", W), ("len", W), ("first", "u1")]))
+    two = np.fromfile("%s.4.%s" % (base, ext), dtype=np.uint8)
+    total = int(rec["off"].sum() + rec["len"].sum())
+    out = np.full(total, 4, dtype=np.uint8)
+    lens, pos, src, seq_start = [], 0, 0, 0
+    for k, r in enumerate(rec):
+        if r["first"] and k > 0:
+            lens.append(pos - seq_start)
+            seq_start = pos
+        pos += int(r["off"])
+        L = int(r["len"])
+        if L:
+            idx = np.arange(src, src + L, dtype=np.int64)
+            out[pos:pos + L] = (two[idx >> 2] >> ((idx & 3) << 1).astype(np.uint8)) & 3
+        pos += L
+        src += L
+    lens.append(pos - seq_start)
+    return torch.from_numpy(out).to(device), lens, None
+
+
+def build_index_gpu(base, G, chrom_lens, large, device_index, chrom_names=None):
     """The GPU index builder on the in-memory genome -> <base>.{1,2,3,4,rev.1,rev.2}.bt2[l]; returns its stats."""
     import numpy as np
     import torch
@@ -189,7 +254,7 @@ def build_index_gpu(base, G, chrom_lens, large, device_index):
     asc = lut[G.long()].cpu().numpy()
     names, seqs, o = [], [], 0
     for i, L in enumerate(chrom_lens):
-        names.append("chr%d" % (i + 1))
+        names.append(chrom_names[i] if chrom_names else "chr%d" % (i + 1))
         seqs.append(asc[o:o + L])
         o += L
     t0 = time.time()
@@ -244,6 +309,40 @@ def synth_reads_gpu(G, n, length, seed, device):
     return seq.contiguous(), qual.contiguous()
 
 
+def reads_from_fastq(path, n, rank, device):
+    """--reads-fastq: records [rank*n, (rank+1)*n) of a 4-line FASTQ file whose reads all have one length -> (seq codes, qualities, names padded with NUL).
+    (An N in a read becomes code 4, as the drop-in binary's parser makes it.)"""
+    import gzip
+    import numpy as np
+    import torch
+    op = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    seqs, quals, nms = [], [], []
+    with op(path, "rb") as f:
+        for k in range((rank + 1) * n):
+            rec = [f.readline() for _ in range(4)]
+            if not rec[3]:
+                break
+            if k < rank * n:
+                continue
+            nms.append(rec[0][1:].rstrip(b"\r\n")); seqs.append(rec[1].rstrip(b"\r\n")); quals.append(rec[3].rstrip(b"\r\n"))
+    if not seqs:
+        raise SystemExit("bench.py: %s holds no reads for rank %d" % (path, rank))
+    L = len(seqs[0])
+    if any(len(x) != L for x in seqs) or any(len(x) != L for x in quals):
+        raise SystemExit("bench.py: --reads-fastq needs reads of one length (the resident batch is rectangular)")
+    lut = np.full(256, 4, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+        lut[c + 32] = i
+    sq = lut[np.frombuffer(b"".join(seqs), dtype=np.uint8)].reshape(len(seqs), L)
+    ql = np.frombuffer(b"".join(quals), dtype=np.uint8).reshape(len(seqs), L).copy()
+    w = max(len(x) for x in nms)
+    nm = np.zeros((len(nms), w), dtype=np.uint8)
+    for i, x in enumerate(nms):
+        nm[i, :len(x)] = np.frombuffer(x, dtype=np.uint8)
+    return torch.from_numpy(sq).to(device), torch.from_numpy(ql).to(device), nm
+
+
 def read_names(n0, n, width=9):
     """Fixed-width names r000000123 as a [n, width+1] uint8 array."""
     import numpy as np
@@ -265,24 +364,40 @@ def gen_rand_seeds(seq, qual, names_t):
     for j in range(L):      # XOR-reduction over columns (no xor-reduce primitive); L is 150
         acc ^= (seq[:, j].long() << ((j & 15) << 1)) & 0xffffffff
         acc ^= (qual[:, j].long() << ((j & 3) << 3)) & 0xffffffff
+    names_t = names_t.masked_fill((names_t == ord("/")).cumsum(1) > 0, 0)      # the name up to the first '/' (pat.cpp:76-80); a NUL (padding) changes nothing
     for j in range(names_t.shape[1]):
         acc ^= (names_t[:, j].long() << ((j & 3) << 3)) & 0xffffffff
     return (acc & 0xffffffff)
 
 
-def write_fastq_fixed(path, seq, qual, names, append=False):
-    """FASTQ of equal-length reads, assembled as one 2-D byte array."""
+def write_fastq_fixed(path, seq, qual, names, append=False, at=None):
+    """FASTQ of equal-length reads, assembled as one 2-D byte array (`at`: written at this byte offset of an existing file instead)."""
     import numpy as np
-    s = np.frombuffer(b"ACGT", dtype=np.uint8)[seq.cpu().numpy()]
+    s = np.frombuffer(b"ACGTN", dtype=np.uint8)[seq.cpu().numpy()]
     q = qual.cpu().numpy()
     n, L = s.shape
     w = names.shape[1]
+    if (names == 0).any():
+        # names of several widths (--reads-fastq): NUL-padded rows, written record by record
+        with open(path, "ab" if append else "wb") as f:
+            for i in range(n):
+                f.write(b"@" + names[i].tobytes().rstrip(b"\0") + b"\n" + s[i].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n")
+        return
     rec = np.empty((n, 1 + w + 1 + L + 3 + L + 1), dtype=np.uint8)
     rec[:, 0] = ord("@"); rec[:, 1:1 + w] = names; rec[:, 1 + w] = 10
     o = 2 + w
     rec[:, o:o + L] = s; rec[:, o + L] = 10; rec[:, o + L + 1] = ord("+"); rec[:, o + L + 2] = 10
     o2 = o + L + 3
     rec[:, o2:o2 + L] = q; rec[:, o2 + L] = 10
+    if at is not None:
+        fd = os.open(path, os.O_WRONLY)
+        try:
+            buf, o = memoryview(rec.tobytes()), 0
+            while o < len(buf):
+                o += os.pwrite(fd, buf[o:o + (1 << 30)], at + o)
+        finally:
+            os.close(fd)
+        return
     with open(path, "ab" if append else "wb") as f:
         f.write(rec.tobytes())
 
@@ -298,7 +413,7 @@ CONFIGS = {
     # the product driver, whose device-stage threads each issue their batch on their own stream).  The headline has no such tail: 1.
     "pe-sens":  {"args": ["--sensitive"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 400_000, "pipeline": 3,
                  "what": "pairs, --sensitive, --fr -I 0 -X 500"},
-    "pe-vsens": {"args": ["--very-sensitive", "-X", "500"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 200_000, "pipeline": 3,
+    "pe-vsens": {"args": ["--very-sensitive", "-X", "500"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 200_000, "pipeline": 3, "reps": 3,
                  "what": "pairs, --very-sensitive (-D 20 -R 3 -N 0 -L 20 -i S,1,0.50), --fr -I 0 -X 500 (mate rescue)"},
     "local400": {"args": ["--local"], "paired": False, "readlen": 400, "reads": 200_000, "cpu_sample": 100_000, "pipeline": 2,
                  "what": "--local = --sensitive-local (-D 15 -R 2 -N 0 -L 20 -i S,1,0.75, --ma 2, --score-min G,20,8)"},
@@ -454,6 +569,151 @@ def write_e2e_fastq(G, seq, qual, names, n, args, dev, rank):
     os.sync()      # (the input's dirty pages reach the disk now, not while the timed run reads it)
     log("[bench] e2e input: %d distinct reads written as FASTQ in %.1fs" % (done, time.time() - t0))
     return {"paths": paths, "reads": done, "batches": k, "first_batch_is_timed_batch": True}
+
+
+def write_e2e_fastq_ranks(G, n, args, dev, rank, world, dist):
+    """The end-to-end input of an N-GPU run: ONE FASTQ file of world x (e2e_reads per rank) distinct reads, which bowtie2_amd.mgpu then shards by byte range
+    (the product's N-GPU path).  Records have one size (fixed-width names), so rank r writes its batches straight to their place in the file: rank 0 sizes
+    the file, everybody writes in parallel.  Unpaired configurations only (the paired e2e leg stays an N = 1 measurement)."""
+    import shutil
+    import torch
+    from bowtie2_amd import shard
+    work = cache_dir()
+    rec = 1 + 10 + 1 + args.readlen + 3 + args.readlen + 1
+    total = max(n, (args.e2e_reads // n) * n)
+    free = shutil.disk_usage(work).free
+    while total > n and world * total * rec * 1.1 > free * 0.9:
+        total -= n
+    if dist is not None:       # every rank must agree on the size of a rank's section
+        t = torch.tensor([total], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        total = int(t.item())
+    path = os.path.join(work, "e2e_n%d.fq" % world)
+    if rank == 0:
+        with open(path, "wb") as f:
+            f.truncate(world * total * rec)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.time()
+    done, k = 0, 0
+    while done < total:
+        sq, ql = synth_reads_gpu(G, n, args.readlen, shard.shard_seed(7000 + k, rank) + 100 * rank, dev)
+        nm = read_names(rank * total + done, n)
+        write_fastq_fixed(path, sq, ql, nm, at=(rank * total + done) * rec)
+        done += n
+        k += 1
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        os.sync()
+        log("[bench] e2e input: %d ranks x %d distinct reads written into one FASTQ file in %.1fs" % (world, total, time.time() - t0))
+    return {"paths": (path,), "reads": world * total, "reads_per_rank": total, "batches": k, "first_batch_is_timed_batch": False}
+
+
+def _clean_launcher_env():
+    """the environment for a job launched from inside a torch.distributed.run worker: without the outer job's rendezvous"""
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT",
+            "BT2_BENCH_CHILD", "OMP_NUM_THREADS")
+    return {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_") and not k.startswith("TORCH_NCCL_ASYNC")}
+
+
+def _free_port():
+    import socket
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    return port
+
+
+def e2e_leg_ranks(pend, world, resident_rate):
+    """The N-GPU end-to-end leg: `python -m torch.distributed.run ... -m bowtie2_amd.mgpu -- <options> -U e2e.fq -S e2e.sam` -- the product's own N-GPU
+    driver: one drop-in executable per GPU on its byte range of the one input file, pieces concatenated by rank 0, counters all-reduced -- after every process of
+    the resident-batch measurement has exited.  reads/s after the load = all reads / the slowest rank's search wall time (each rank's executable prints it with -t)."""
+    import shutil
+    work, fq = pend["work"], pend["fq"]
+    path = fq["paths"][0]
+    out = os.path.join(work, "e2e_n%d.sam" % world)
+    in_bytes = os.path.getsize(path)
+    # the other ranks' pieces are files next to the merged output until rank 0 has appended them (bowtie2_amd.mgpu): room for both
+    to_file = shutil.disk_usage(work).free > in_bytes * 1.3 * 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "-m", "bowtie2_amd.mgpu"] + list(pend.get("mgpu_args", [])) + ["--"] + list(pend["preset"]) + ["-t", "-x", pend["base"], "-U", path, "-S", out if to_file else "/dev/null"]
+    env = _clean_launcher_env()
+    env["TMPDIR"] = work       # (mgpu keeps the pieces in a temporary directory: on the disk the bench's cache lives on)
+    time.sleep(float(os.environ.get("BT2_BENCH_E2E_SETTLE_S", "8")))
+    runs = []
+    for _ in range(int(os.environ.get("BT2_BENCH_E2E_RUNS_N", "1"))):
+        if os.path.exists(out):
+            os.remove(out)
+        os.sync()
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+        t = time.perf_counter() - t0
+        per = [(float(a), float(b_), int(c)) for a, b_, c in re.findall(r"index load ([\d.]+) s; search ([\d.]+) s wall, (\d+) reads", p.stderr)]
+        runs.append((t, p, per))
+    t, p, per = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+    e = {"n_gpus": world, "reads": fq["reads"], "distinct_reads": True, "input": "one FASTQ file, %d bytes, sharded by byte range (bowtie2_amd.mgpu)" % in_bytes,
+         "output": "one SAM file (rank 0's executable writes into it, the other ranks' pieces are appended with sendfile)" if to_file else "/dev/null",
+         "command": " ".join(os.path.basename(c) if os.sep in c else c for c in cmd), "returncode": p.returncode, "wall_s_job": round(t, 2),
+         "host_threads_per_rank": max(1, pend["threads"] // world), "protocol": "%d run(s) of the command; search time = the slowest rank's" % len(runs)}
+    if p.returncode != 0 or len(per) != world:
+        e["error"] = p.stderr[-600:]
+    else:
+        nreads = sum(x[2] for x in per)
+        slow = max(x[1] for x in per)
+        e.update({"reads_aligned_by_the_ranks": nreads, "search_s_per_rank": [x[1] for x in per], "index_load_s_per_rank": [x[0] for x in per],
+                  "reads_per_s_after_load": nreads / slow, "frac_of_resident": (nreads / slow) / resident_rate if resident_rate else None,
+                  "reads_per_s_whole_job": nreads / t})
+        if to_file:
+            e["sam_bytes"] = os.path.getsize(out)
+            # the merged file holds every read once, in input order: count the records, look at the first and the last name
+            nrec, first, last = 0, None, None
+            with open(out, "rb") as f:
+                for l in f:
+                    if l[:1] == b"@":
+                        continue
+                    nrec += 1
+                    if first is None:
+                        first = l.split(b"\t", 1)[0]
+                    last = l
+            e["sam_records"] = nrec
+            e["sam_complete_and_in_input_order"] = bool(nrec == fq["reads"] and first == b"r%09d" % 0 and last.split(b"\t", 1)[0] == b"r%09d" % (fq["reads"] - 1))
+    for f_ in (out,) + (() if os.environ.get("BT2_BENCH_KEEP_E2E") else (path,)):
+        try:
+            os.remove(f_)
+        except OSError:
+            pass
+    return e
+
+
+def dry_engine(argv):
+    """--dry-ranks stand-in for the drop-in executable as bowtie2_amd.mgpu drives it (no device here): takes its byte range of the reads file, writes one
+    SAM-like line per record, the shard index and the -t line.  Nothing in it aligns anything; it lets the CPU suite run the N-GPU e2e leg's plumbing."""
+    a = {"--shard-bytes": None, "--shard-first-read": "0", "-S": None, "--shard-index": None, "-U": None}
+    i = 0
+    while i < len(argv):
+        if argv[i] in a and i + 1 < len(argv):
+            a[argv[i]] = argv[i + 1]
+            i += 1
+        i += 1
+    t0 = time.perf_counter()
+    lo, hi = (int(x) for x in a["--shard-bytes"].split(",")[0].split(":"))
+    with open(a["-U"], "rb") as f:
+        f.seek(lo)
+        data = f.read(hi - lo)
+    lines = data.split(b"\n")
+    names = [l[1:] for l in lines[0::4] if l]
+    with open(a["-S"], "wb") as f:
+        if "--no-hd" not in argv:
+            f.write(b"@HD\tVN:1.5\tSO:unsorted\n")
+        for nm in names:
+            f.write(nm + b"\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n")
+    with open(a["--shard-index"], "w") as f:
+        f.write("S %d %d 0 0\nF 0\nR %d\n" % (len(names), len(names), hi - lo))
+    dt = max(1e-6, time.perf_counter() - t0)
+    sys.stderr.write("[bt2g] index load 0.000 s; search %.3f s wall, %d reads -> %d reads/s after the load\n" % (dt, len(names), len(names) / dt))
+    return 0
 
 
 def e2e_leg(base, large, fq, preset, threads, resident_rate, work, par):
@@ -613,23 +873,79 @@ def pmc_files(config):
     return sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
 
 
+def lib_sha256():
+    """SHA-256 of the library this run loads (bowtie2_amd/libbt2g.so): what a committed PMC summary must have been measured on to be quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        with open(os.path.join(ROOT, "bowtie2_amd", "libbt2g.so"), "rb") as f:
+            for blk in iter(lambda: f.read(1 << 22), b""):
+                h.update(blk)
+    except OSError:
+        return None
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, reads_per_launch, config="se150"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, KiB),
-    scaled from the reads-per-launch of that profile run to this run's.  PMC collection needs rocprofv3 around the
-    process, so it cannot be taken inside the timed run; profiles/README.md has the recipe."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, KiB), scaled from the
+    reads-per-launch of that profile run to this run's -- ONLY when that file was measured on the library this run loads (its `lib_sha256`);
+    otherwise None.  The default N = 1 run replaces it with a live measurement (live_pmc_traffic: rocprofv3 needs to sit around the process)."""
     files = pmc_files(config)
     if not files:
-        return None, None
+        return None, "no committed PMC summary for %s" % config
     try:
         with open(files[-1]) as f:
             d = json.load(f)
+        have, want = d.get("lib_sha256"), lib_sha256()
+        if not have or have != want:
+            return None, "profiles/%s was measured on another build of libbt2g.so (sha256 %s, loaded %s): not quoted" % (os.path.basename(files[-1]), (have or "unrecorded")[:16], (want or "?")[:16])
         k = d["kernels"][kernel]
         # MI355X_MICROARCH.md, HBM section: rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes
         # (calibrated on wide coalesced reads) -> doubled; WRITE_SIZE is taken as reported (uncalibrated there)
         per_read = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / (d["reads_per_launch"] * d["launches"])
-        return int(per_read * reads_per_launch), "profiles/%s ((2 x FETCH_SIZE + WRITE_SIZE) per read x %d reads; FETCH_SIZE doubled as the guide prescribes for gfx950)" % (os.path.basename(files[-1]), reads_per_launch)
-    except Exception:
-        return None, None
+        return int(per_read * reads_per_launch), "profiles/%s, measured on this libbt2g.so (sha256 %s): (2 x FETCH_SIZE + WRITE_SIZE) per read x %d reads; FETCH_SIZE doubled as the guide prescribes for gfx950" % (os.path.basename(files[-1]), want[:16], reads_per_launch)
+    except Exception as e:
+        return None, "unreadable PMC summary: %s" % e
+
+
+def live_pmc_traffic(config, kernel, argv_extra, timeout_s=300):
+    """roofline.traffic as a LIVE number: this script's own measuring process once more under `rocprofv3 --kernel-trace --pmc X`,
+    one counter per pass as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass), 1 warm-up + 1 timed + 1 profiled launch of
+    the same resident batch.  Returns {"fetch_kib", "write_kib", "dispatches", "traffic_bytes_per_launch"} or {"error": ...}."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rp:
+        return {"error": "rocprofv3 not found"}
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pmc_", dir=cache_dir())
+        cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--config", config, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--e2e-reads", "0"] + list(argv_extra)
+        env = dict(os.environ, BT2_BENCH_CHILD="1", TMPDIR="/tmp")
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp", timeout=timeout_s)
+            tot, ids = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if kernel + "<" in r["Kernel_Name"] or r["Kernel_Name"].split("(")[0].endswith(kernel):
+                            if r["Counter_Name"] == ctr:
+                                tot += float(r["Counter_Value"]); ids.add(r["Dispatch_Id"])
+            if not ids:
+                return {"error": "no %s rows for %s (rc %d): %s" % (ctr, kernel, p.returncode, p.stderr[-300:])}
+            out[ctr] = tot / len(ids)
+            out["dispatches"] = len(ids)
+        except subprocess.TimeoutExpired:
+            return {"error": "rocprofv3 --pmc %s pass timed out after %d s" % (ctr, timeout_s)}
+        except Exception as e:
+            return {"error": "rocprofv3 --pmc %s pass: %s" % (ctr, e)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"fetch_kib_per_launch": out["FETCH_SIZE"], "write_kib_per_launch": out["WRITE_SIZE"], "dispatches": out["dispatches"],
+            "traffic_bytes_per_launch": int((2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0)}
 
 
 def pmc_issue(kernel, kern_ms, reads_per_launch, n_cu, config="se150"):
@@ -646,7 +962,7 @@ def pmc_issue(kernel, kern_ms, reads_per_launch, n_cu, config="se150"):
         valu, salu, lds = k["SQ_INSTS_VALU"] / per, k["SQ_INSTS_SALU"] / per, k["SQ_INSTS_LDS"] / per
         vmem = (k["SQ_INSTS_VMEM_RD"] + k["SQ_INSTS_VMEM_WR"]) / per
         simd_cycles_per_read = kern_ms * 1e-3 * 2.4e9 * n_cu * 4 / reads_per_launch
-        return {"source": "profiles/" + os.path.basename(files[-1]), "valu_per_read": round(valu), "salu_per_read": round(salu), "lds_per_read": round(lds),
+        return {"source": "profiles/" + os.path.basename(files[-1]), "measured_on_loaded_library": bool(d.get("lib_sha256")) and d.get("lib_sha256") == lib_sha256(), "valu_per_read": round(valu), "salu_per_read": round(salu), "lds_per_read": round(lds),
                 "vmem_per_read": round(vmem), "simd_cycles_per_read": round(simd_cycles_per_read), "valu_busy_frac": round(valu * 4 / simd_cycles_per_read, 3),
                 "note": "k_align_reads is one serial instruction stream per read (one wavefront each, 4 or 5 per SIMD): it is bound by the issue rate and the "
                         "dependent latencies of that stream, not by HBM; the hbm fraction above is reported because the contract asks for it"}
@@ -700,6 +1016,16 @@ def main():
                     "index cache while the others wait, per-rank read shards, the step loop with its per-step gather of packed records to rank 0, "
                     "barrier + max-over-ranks timing, the summed counters, rank 0's JSON line -- around a stand-in for the device (tests/test_bench_dry_ranks.py)")
     ap.add_argument("--pipeline", type=int, default=0, help="steps in flight (on that many streams; the context keeps a working set per stream): 0 = the config's default")
+    ap.add_argument("--reps", type=int, default=0, help="repetitions of the timed region (K steps each, barrier + synchronize around every one); value = the median, the spread is "
+                    "reported; 0: the config's default (3 for pe-vsens, whose step time is tail-dominated; 1 otherwise)")
+    ap.add_argument("--extra-configs", default=None, help="comma-separated configurations run after the headline, each in a process of its own, and reported under `configs` of the "
+                    "one JSON line (default at N = 1 for the full headline run: ecoli100,pe-vsens,local400 = BASELINE.json configs[1], [3], [4]; '' = none)")
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each extra configuration")
+    ap.add_argument("--no-pmc-pass", action="store_true", help="do not spawn the rocprofv3 --pmc passes that make roofline.traffic a live number")
+    ap.add_argument("--genome-fasta", default=None, help="a real reference (FASTA, plain or gzip) instead of the synthetic genome: indexed by the GPU builder, reads sampled from it by the "
+                    "same generator (env BT2_BENCH_HG38 for the hg38 configurations, BT2_BENCH_ECOLI for ecoli100)")
+    ap.add_argument("--index-base", default=None, help="an existing bowtie2 index (<base>.1.bt2[l] ...): used as it is; the sequence reads are sampled from is recovered from its .3/.4 files")
+    ap.add_argument("--reads-fastq", default=None, help="reads of one length from this FASTQ file (names, qualities and all) instead of the generator")
     args = ap.parse_args()
     if args.paired:
         args.config = "pe-sens"
@@ -713,6 +1039,10 @@ def main():
         args.cpu_sample = cfg["cpu_sample"]
     if not args.pipeline:
         args.pipeline = cfg.get("pipeline", 1)
+    if not args.reps:
+        args.reps = cfg.get("reps", 1)
+    if not args.genome_fasta and not args.index_base:
+        args.genome_fasta = os.environ.get("BT2_BENCH_ECOLI" if cfg.get("genome") == "ecoli" else "BT2_BENCH_HG38") or None
 
     import numpy as np
     import torch
@@ -739,23 +1069,44 @@ def main():
     threads = nproc()
     bacterial = cfg.get("genome") == "ecoli"
     large = not (args.small_index or bacterial)
+    real, chrom_names = None, None      # a real reference when the box has one (--genome-fasta / --index-base / BT2_BENCH_HG38 / BT2_BENCH_ECOLI)
+    if args.index_base:
+        if os.path.exists(args.index_base + ".1.bt2l"):
+            large = True
+        elif os.path.exists(args.index_base + ".1.bt2"):
+            large = False
+        else:
+            raise SystemExit("bench.py: no index at %s" % args.index_base)
     ext = "bt2l" if large else "bt2"
-    base = os.path.join(cache_dir(), "ecolilike_s3_%s" % ext if bacterial else "hg38like_%dmbp_s2_%s" % (args.genome_mbp, ext))
-    if dry:
-        base += "_dry"
-    # ---- workload: genome (every rank, same seed) + index (rank 0 builds it on its GPU, the others wait) ----
     t0 = time.time()
-    if bacterial:
-        G, chrom_lens = synth_genome_bacterial(3, dev)
+    if args.index_base:
+        base = args.index_base
+        G, chrom_lens, chrom_names = genome_from_index(base, ext, dev)
+        real = "index %s (%d sequences, %.1f Mbp incl. N)" % (os.path.basename(base), len(chrom_lens), G.numel() / 1e6)
+        args.genome_mbp = G.numel() / 1e6
+    elif args.genome_fasta:
+        G, chrom_lens, chrom_names = load_fasta_codes(args.genome_fasta, dev)
+        st_ = os.stat(args.genome_fasta)
+        tag = re.sub(r"[^A-Za-z0-9]+", "_", os.path.basename(args.genome_fasta))[:40]
+        base = os.path.join(cache_dir(), "real_%s_%d_%s" % (tag, st_.st_size, ext))
+        real = "%s (%d sequences, %.1f Mbp incl. N)" % (os.path.basename(args.genome_fasta), len(chrom_lens), G.numel() / 1e6)
         args.genome_mbp = G.numel() / 1e6
     else:
-        G, chrom_lens = synth_genome_gpu(args.genome_mbp, 2, dev)
+        base = os.path.join(cache_dir(), "ecolilike_s3_%s" % ext if bacterial else "hg38like_%dmbp_s2_%s" % (args.genome_mbp, ext))
+        # ---- workload: genome (every rank, same seed) + index (rank 0 builds it on its GPU, the others wait) ----
+        if bacterial:
+            G, chrom_lens = synth_genome_bacterial(3, dev)
+            args.genome_mbp = G.numel() / 1e6
+        else:
+            G, chrom_lens = synth_genome_gpu(args.genome_mbp, 2, dev)
+    if dry:
+        base += "_dry"
     cuda.synchronize()
-    log("[bench] genome: %.4g Mbp generated in %.1fs" % (args.genome_mbp, time.time() - t0))
+    log("[bench] genome: %.4g Mbp %s in %.1fs" % (args.genome_mbp, "read from " + real if real else "generated", time.time() - t0))
     build_info = None
     if rank == 0 and not os.path.exists(base + ".rev.2." + ext):
         cuda.empty_cache()       # the builder allocates ~30 bytes per base with hipMalloc, next to torch's caching allocator
-        build_info = _dry_build_index(base, ext) if dry else build_index_gpu(base, G, chrom_lens, large, local_rank)
+        build_info = _dry_build_index(base, ext) if dry else build_index_gpu(base, G, chrom_lens, large, local_rank, chrom_names)
     if dist is not None:
         dist.barrier()
     if not os.path.exists(base + ".rev.2." + ext):
@@ -768,19 +1119,28 @@ def main():
     log("[bench] index loaded into HBM in %.2fs (%.2f GB)" % (index_load_s, info.hbm_bytes / 1e9))
     # per-rank shard of reads (weak scaling: fixed reads per GPU)
     n = args.reads
-    if args.paired:
+    if args.reads_fastq:
+        seq, qual, names = reads_from_fastq(args.reads_fastq, n, rank, dev)
+        n = seq.shape[0]
+        args.readlen = seq.shape[1]
+    elif args.paired:
         # mates interleaved: read 2i = forward mate at the fragment start, read 2i+1 = reverse-complemented mate at its end
         seq, qual = synth_pairs_gpu(G, n // 2, args.readlen, shard.shard_seed(2000, rank), dev)
         n = seq.shape[0]
     else:
         seq, qual = synth_reads_gpu(G, n, args.readlen, shard.shard_seed(1000, rank), dev)
-    names = read_names(rank * n, n)
+    if not args.reads_fastq:
+        names = read_names(rank * n, n)
     # ---- the end-to-end leg's input (N = 1): the timed batch followed by further batches of DISTINCT reads of the same generator, as FASTQ ----
     if args.e2e_reads < 0:
         args.e2e_reads = 0 if (args.no_cpu_baseline or args.parity_only) else 12 * n
     e2e_fq = None
-    if world == 1 and args.e2e_reads > 0:
-        e2e_fq = write_e2e_fastq(G, seq, qual, names, n, args, dev, rank)
+    if args.e2e_reads > 0 and not args.reads_fastq:
+        if world == 1:
+            e2e_fq = write_e2e_fastq(G, seq, qual, names, n, args, dev, rank)
+        elif not args.paired:
+            # N GPUs: one input file of world x e2e_reads distinct reads for the product's N-GPU driver (bowtie2_amd.mgpu, byte-range sharding)
+            e2e_fq = write_e2e_fastq_ranks(G, n, args, dev, rank, world, dist)
     del G
     cuda.empty_cache()
     names_t = torch.from_numpy(names).to(dev)
@@ -847,22 +1207,39 @@ def main():
     sync_all()
     ctx.align_profile(reset=True)
     ctx.counters(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    sync_all()
-    dt = time.perf_counter() - t0
-    dt = shard.reduce_max(dist, dt, dev)      # the slowest rank defines the step time
-    if depth > 1:
-        for k in range(depth):                # the last batch of every stream
-            if issued[k]:
-                with cuda.stream(streams[k]):
-                    kern_times.append(ctx.align_timing(on_current_stream=True))
-                issued[k] = 0
+    # the timed region: K steps between barrier + synchronize, `reps` times over (value = the median region; pe-vsens: its step time is the
+    # tail of its slowest pairs, and one region of 10 steps ranged 1.03-1.49 M reads/s over four runs on one box in round 5)
+    rep_dts = []
+    for _rep in range(max(1, args.reps)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        sync_all()
+        rep_dts.append(shard.reduce_max(dist, time.perf_counter() - t0, dev))      # the slowest rank defines the step time
+        if depth > 1:
+            for k in range(depth):                # the last batch of every stream
+                if issued[k]:
+                    with cuda.stream(streams[k]):
+                        kern_times.append(ctx.align_timing(on_current_stream=True))
+                    issued[k] = 0
+    dt = sorted(rep_dts)[len(rep_dts) // 2]
     batch_ms = sum(a.elapsed_time(bb) for a, bb in stage_events) / len(stage_events)
     kavg = {k: sum(t[k] for t in kern_times) / len(kern_times) for k in kern_times[0]}
-    kern_ms = kavg["k_align_reads"]
     cnt = ctx.counters()
+    n_timed_steps = args.steps * max(1, args.reps)
+    # With several steps in flight the kernels of different batches overlap and their HIP-event durations are not additive: the roofline block
+    # of such a configuration is taken from extra steps issued ONE AT A TIME on one stream, outside the timed region.
+    kavg_serial = None
+    if depth > 1:
+        ks = []
+        with cuda.stream(streams[0]):
+            for _ in range(2):
+                ctx.align_batch(batch, rp_t, P, args.readlen)
+                cuda.synchronize()
+                ks.append(ctx.align_timing(on_current_stream=True))
+        kavg_serial = {k: sum(t[k] for t in ks) / len(ks) for k in ks[0]}
+    kroof = kavg_serial or kavg
+    kern_ms = kroof["k_align_reads"]
     # the worker's phase timers are off in the timed steps (measured: they cost nothing beyond run-to-run noise, but the timed
     # region is the product configuration); one more, untimed, pass over the same batch with them on gives the per-phase breakdown
     P.profile = 1
@@ -902,12 +1279,12 @@ def main():
         alg_bytes = sides_per_launch * side + dp_windows * ((win_cols + 3) // 4) + n * args.readlen * 2 + n * rec_bytes
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         # The four lane-per-task FM kernels in front of it carry most of the rank queries of the path.
-        fm_ms = sum(v for k, v in kavg.items() if k != "k_align_reads")
-        fm_bytes = (cnt.rank_queries * side + cnt.ftab_lookups * 2 * off_sz + cnt.sa_lookups * off_sz) / float(args.steps) + n * args.readlen * 2
+        fm_ms = sum(v for k, v in kroof.items() if k != "k_align_reads")
+        fm_bytes = (cnt.rank_queries * side + cnt.ftab_lookups * 2 * off_sz + cnt.sa_lookups * off_sz) / float(n_timed_steps) + n * args.readlen * 2
         fm_achieved = fm_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
         # the same requests priced at what this layout moves for them: a rank query reads ONE 64-byte block of the device rank index (occ words +
         # both bit planes, bt2g_device.hpp Blk) instead of a reference side, an offset lookup one 8-byte entry of the full suffix array
-        fm_phys = (cnt.rank_queries * 64 + cnt.ftab_lookups * 2 * off_sz + cnt.sa_lookups * 8) / float(args.steps) + n * args.readlen * 2
+        fm_phys = (cnt.rank_queries * 64 + cnt.ftab_lookups * 2 * off_sz + cnt.sa_lookups * 8) / float(n_timed_steps) + n * args.readlen * 2
         fm_phys_achieved = fm_phys / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
         kname = "k_align_pairs" if args.paired else "k_align_reads"
         traffic, traffic_src = pmc_traffic(kname, n, args.config)
@@ -931,25 +1308,33 @@ def main():
             if par is not None and "parity_sample_aligned_reads" in par and not args.paired:
                 # the timed batch starts with the same reads, same parameters, same per-read seeds: its records must agree
                 par["timed_batch_aligned_reads_same_sample"] = int(h["aligned"][:ns].sum())
+        gname = ("REAL reference " + real) if real else ("E. coli K-12-like synthetic genome" if bacterial else "hg38-like synthetic genome (hg38 unavailable offline)")
+        cfg_no = {"ecoli100": "configs[1]", "se150": "configs[2]", "pe-vsens": "configs[3]", "local400": "configs[4]"}.get(args.config, "(extra) " + args.config)
+        what_reads = "%d x %d bp %s per GPU per step, %s" % (n, args.readlen, "reads as %d pairs" % (n // 2) if args.paired else "SE reads", cfg["what"])
+        idx_txt = ".%s index (side %d B, %d-byte offsets) %s" % (ext, side, off_sz, "as given (--index-base)" if args.index_base else "built by the GPU index builder")
+        if real:
+            genome_txt = "REAL reference %s" % real
+        elif bacterial:
+            genome_txt = ("E. coli K-12-like synthetic %.2f Mbp genome (one chromosome; 7 rRNA-operon-like and 40 IS-like repeat copies; the real sequence is not available offline)" % args.genome_mbp)
+        else:
+            genome_txt = ("hg38-like synthetic %d Mbp genome%s (%d chromosomes; ~45 %% repeats: Alu-/L1-like and older diverged families, simple repeats, segmental duplications; N gaps)"
+                          % (args.genome_mbp, " = hg38 scale" if args.genome_mbp >= 3000 else "", N_CHROMS))
+        timed_volume = "timed region: %d x the same resident batch of %d reads per GPU%s" % (steps, n, " (x %d regions, median)" % len(rep_dts) if len(rep_dts) > 1 else "")
+        workload = "BASELINE.json %s: %s, %s, %s; %s" % (cfg_no, genome_txt, idx_txt, what_reads, timed_volume)
         res = {
-            "metric": ("aligned reads/sec (whole node), 2 x %d bp PE (mates counted as reads), hg38-like synthetic genome" % args.readlen if args.paired else
-                       "aligned reads/sec (whole node), %d bp SE vs E. coli K-12-like synthetic genome, small index" % args.readlen if bacterial else
-                       "aligned reads/sec (whole node), %d bp SE vs hg38-like synthetic genome (hg38 unavailable offline), large index" % args.readlen),
+            "metric": ("aligned reads/sec (whole node), 2 x %d bp PE (mates counted as reads), %s" % (args.readlen, gname) if args.paired else
+                       "aligned reads/sec (whole node), %d bp SE vs %s, %s index" % (args.readlen, gname, "large" if large else "small")),
             "value": shard.throughput(world, n, steps, dt),
             "unit": "reads/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3,
+            "reps": {"timed_regions": len(rep_dts), "reads_per_s_each": [round(shard.throughput(world, n, steps, x)) for x in rep_dts],
+                     "spread_frac": (max(rep_dts) - min(rep_dts)) / dt, "value_is": "the median region"} if len(rep_dts) > 1 else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32" if off_sz == 4 else "u8/u64", "data": "DRY RUN (--dry-ranks): no device, no alignment; only the N-rank plumbing is real" if dry else "synthetic",
             "config": {
-                "workload": ("BASELINE.json configs[1]: E. coli K-12-like synthetic %.2f Mbp genome (one chromosome; 7 rRNA-operon-like and 40 IS-like repeat copies; the real sequence is not available offline), "
-                             ".%s index (side %d B, %d-byte offsets) built in this run by the GPU index builder, %d x %d bp SE reads per GPU per step, %s"
-                             % (args.genome_mbp, ext, side, off_sz, n, args.readlen, cfg["what"])) if bacterial else
-                            "BASELINE.json %s: hg38-like synthetic %d Mbp genome%s (%d chromosomes; ~45 %% repeats: Alu-/L1-like and older diverged families, simple repeats, segmental duplications; N gaps), "
-                            ".%s index (side %d B, %d-byte offsets) built in this run by the GPU index builder, %d x %d bp %s per GPU per step, %s"
-                            % ({"se150": "configs[2]", "pe-vsens": "configs[3]", "local400": "configs[4]"}.get(args.config, "(extra) " + args.config), args.genome_mbp,
-                               " = hg38 scale" if args.genome_mbp >= 3000 else "", N_CHROMS, ext, side, off_sz, n, args.readlen,
-                               "reads as %d pairs" % (n // 2) if args.paired else "SE reads", cfg["what"]),
+                "workload": workload,
+                "genome": real or "synthetic", "reads_source": args.reads_fastq or "SURVEY 8d generator",
                 "config_name": args.config, "command_line": " ".join(cfg["args"]),
                 "steps_in_flight": depth,
                 "steps_in_flight_note": None if depth == 1 else "the timed steps are issued on %d alternating streams (one working set of the context each), so that a batch's tail is filled by the next batch, as in the product driver; kernel_ms_per_step are the HIP-event durations of the kernels on their own stream and overlap in time" % depth,
@@ -972,7 +1357,10 @@ def main():
                 "worker_counts_per_read": {"bt_steps": prof[13] / max(1, prof[9]), "bt_tiles": prof[14] / max(1, prof[9]), "cand_cells": prof[15] / max(1, prof[9]),
                                            "sampled_rows": (prof[23] & 0xffffffff) / max(1, prof[9]), "sampled_rows_seen_list": (prof[23] >> 32) / max(1, prof[9])},
                 "kernel_ms_per_step": {("k_align_pairs" if args.paired and k == "k_align_reads" else k): round(v, 3) for k, v in kavg.items()}, "batch_ms_events": round(batch_ms, 3),
-                "fm_kernels_sides_per_read": cnt.rank_queries / float(n * args.steps),
+                "kernel_ms_per_step_one_at_a_time": None if kavg_serial is None else {("k_align_pairs" if args.paired and k == "k_align_reads" else k): round(v, 3) for k, v in kavg_serial.items()},
+                "kernel_ms_note": None if kavg_serial is None else "kernel_ms_per_step are HIP-event durations inside the timed region, where the kernels of %d batches in flight overlap (not additive); "
+                                  "the roofline blocks use kernel_ms_per_step_one_at_a_time: two extra steps issued alone on one stream after the timed region" % depth,
+                "fm_kernels_sides_per_read": cnt.rank_queries / float(n * n_timed_steps),
                 "sides_per_read": prof[8] / max(1, prof[9]),
             },
             "roofline": {"bound": "hbm", "kernel": kname, "sides_per_launch": sides_per_launch, "dp_windows_per_launch": dp_windows, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -993,35 +1381,155 @@ def main():
             res["config"].update(par)
         res["cpu_baseline"] = cb
         if e2e_fq is not None:
-            # the end-to-end leg runs once this process is gone (main()): what it needs travels in the line
-            res["e2e_pending"] = {"base": base, "large": large, "fq": e2e_fq, "preset": cfg["args"], "threads": threads, "work": cache_dir(),
+            # the end-to-end leg runs once this process is gone (outer()): what it needs travels in the line
+            res["e2e_pending"] = {"base": base, "large": large, "fq": e2e_fq, "preset": cfg["args"], "threads": threads, "work": cache_dir(), "world": world,
                                   "par": {"parity_identical": par.get("parity_identical")} if par else None}
+            if dry:
+                # no device: the stand-in engine (dry_engine) behind the real bowtie2_amd.mgpu, over gloo
+                eng = os.path.join(cache_dir(), "dry_engine.sh")
+                with open(eng, "w") as f:
+                    f.write("#!/bin/sh\nexec %s %s --dry-engine \"$@\"\n" % (sys.executable, os.path.abspath(__file__)))
+                os.chmod(eng, 0o755)
+                res["e2e_pending"]["mgpu_args"] = ["--engine", eng, "--backend", "gloo"]
+        # what outer() does after this process: the live PMC passes and the other BASELINE configurations belong to the default N = 1 headline run only
+        full = world == 1 and not dry and not args.no_cpu_baseline and not args.parity_only
+        extra = args.extra_configs
+        if extra is None:
+            extra = "ecoli100,pe-vsens,local400" if (full and args.config == "se150") else ""
+        fwd = []
+        if "--genome-mbp" in sys.argv:
+            fwd += ["--genome-mbp", str(int(args.genome_mbp))]
+        res["_outer"] = {"pmc": full and not args.no_pmc_pass, "kernel": kname, "config": args.config, "reads": n,
+                         "extra_configs": [c for c in extra.split(",") if c and c != args.config], "extra_steps": args.extra_steps, "warmup": args.warmup,
+                         "forward": fwd, "genome_fasta": args.genome_fasta if "--genome-fasta" in sys.argv else None}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def outer():
-    """N = 1: the measurement runs in a child process and the end-to-end leg -- the drop-in binary, FASTQ file -> SAM file, the reference's own
-    timed quantity (bt2_search.cpp:4863 "Multiseed full-index search") -- after the child has exited.  Measured (profiles/r05g_*): next to a
-    second process that merely holds a context on the same GPU (this script with its torch runtime, idle) the binary runs at 0.55 x its rate
-    on a GPU of its own (its persistent worker waves get time-sliced against the other process's queues); a user's run has the GPU to itself."""
-    if os.environ.get("BT2_BENCH_CHILD") or int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--gpus" in sys.argv and sys.argv[sys.argv.index("--gpus") + 1] != "1":
-        return main()
+def summarize_config(d):
+    """One extra configuration's line, cut to what the headline's `configs` block carries."""
+    c, r, cb = d.get("config", {}), d.get("roofline", {}), d.get("cpu_baseline") or {}
+    return {"metric": d.get("metric"), "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"), "reps": d.get("reps"),
+            "workload": c.get("workload"), "steps_in_flight": c.get("steps_in_flight"),
+            "parity_identical": c.get("parity_identical"), "parity_checked_reads": c.get("parity_checked_reads"), "parity_differing_sam_lines": c.get("parity_differing_sam_lines"),
+            "reads_overflowed": c.get("reads_overflowed"), "fraction_aligned": c.get("fraction_aligned"),
+            "kernel_ms_per_step": c.get("kernel_ms_per_step"), "kernel_ms_per_step_one_at_a_time": c.get("kernel_ms_per_step_one_at_a_time"),
+            "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "traffic_source",
+                                               "traffic_over_algorithmic", "dp_gcups")},
+            "fm_kernels_physical_frac": (r.get("fm_kernels") or {}).get("physical_frac"),
+            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None,
+            "speedup_vs_cpu_baseline": (d.get("value") / cb["value"]) if cb.get("value") else None}
+
+
+def apply_live_traffic(res, lp):
+    r = res.get("roofline")
+    if not r:
+        return
+    if lp and "traffic_bytes_per_launch" in lp:
+        r["traffic"] = lp["traffic_bytes_per_launch"]
+        r["traffic_source"] = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) around this script's own measuring process in this run, %d dispatches of %s on the same "
+                               "resident batch; 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); libbt2g.so sha256 %s"
+                               % (lp["dispatches"], r.get("kernel"), (lib_sha256() or "?")[:16]))
+        r["traffic_live"] = lp
+        if r.get("algorithmic_bytes_per_launch"):
+            r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_launch"]
+    elif lp:
+        r["traffic_live"] = lp      # {"error": ...}: the committed summary (if it is this library's) or null stays
+
+
+def run_child(argv, timeout_s=None):
     env = dict(os.environ, BT2_BENCH_CHILD="1")
-    p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], stdout=subprocess.PIPE, env=env, text=True)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE, env=env, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return None, "timed out after %s s" % timeout_s, 124
     line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
     try:
-        res = json.loads(line)
+        return json.loads(line), None, p.returncode
     except ValueError:
-        sys.stdout.write(p.stdout)
-        raise SystemExit(p.returncode or 1)
+        return None, p.stdout[-400:], p.returncode      # (ranks other than 0 print no line)
+
+
+def outer():
+    """The measurement runs in a child process; what needs the GPU(s) to itself runs after the child has exited: the end-to-end leg -- the drop-in binary
+    (N = 1) or the product's N-GPU driver bowtie2_amd.mgpu (N > 1), FASTQ file -> SAM file, the reference's own timed quantity (bt2_search.cpp:4863
+    "Multiseed full-index search") -- then, in the default N = 1 run, the live rocprofv3 --pmc passes and the other BASELINE configurations, each a process of
+    its own.  Measured (profiles/r05g_*): next to a second process that merely holds a context on the same GPU (this script with its torch runtime, idle) the
+    binary runs at 0.55 x its rate on a GPU of its own; a user's run has the GPU to itself."""
+    if len(sys.argv) > 1 and sys.argv[1] == "--dry-engine":
+        raise SystemExit(dry_engine(sys.argv[2:]))
+    if os.environ.get("BT2_BENCH_CHILD"):
+        return main()
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    res, err, rc = run_child(sys.argv[1:])
+    if world > 1:
+        # every rank's measuring process has to be gone before the N-GPU e2e job starts: the parents meet in a directory named after their launcher
+        syncd = os.path.join(cache_dir(), "sync_%d" % os.getppid())
+        os.makedirs(syncd, exist_ok=True)
+        with open(os.path.join(syncd, "rank%d.tmp" % rank), "w") as f:
+            f.write(str(rc))
+        os.replace(os.path.join(syncd, "rank%d.tmp" % rank), os.path.join(syncd, "rank%d" % rank))
+        if rank != 0:
+            raise SystemExit(rc)
+        if res is None:
+            sys.stdout.write(err or "")
+            raise SystemExit(rc or 1)
+        deadline = time.time() + float(os.environ.get("BT2_BENCH_SYNC_WAIT_S", "1800"))
+        rcs = {}
+        while len(rcs) < world and time.time() < deadline:
+            for r in range(world):
+                fn = os.path.join(syncd, "rank%d" % r)
+                if r not in rcs and os.path.exists(fn):
+                    rcs[r] = open(fn).read().strip()
+            if len(rcs) < world:
+                time.sleep(0.1)
+        import shutil
+        shutil.rmtree(syncd, ignore_errors=True)
+        pend = res.pop("e2e_pending", None)
+        res.pop("_outer", None)
+        if pend:
+            if len(rcs) == world and all(v == "0" for v in rcs.values()):
+                res["e2e"] = e2e_leg_ranks(pend, world, res["value"])
+            else:
+                res["e2e"] = {"error": "not run: the measuring processes of the ranks did not all exit cleanly (%s)" % rcs}
+        print(json.dumps(res), flush=True)
+        raise SystemExit(rc)
+    if res is None:
+        sys.stdout.write(err or "")
+        raise SystemExit(rc or 1)
     pend = res.pop("e2e_pending", None)
+    todo = res.pop("_outer", None) or {}
     if pend:
         res["e2e"] = e2e_leg(pend["base"], pend["large"], pend["fq"], pend["preset"], pend["threads"], res["value"], pend["work"], pend["par"])
+        res["config"]["workload"] += "; e2e leg: %d distinct reads, FASTQ file -> SAM file through the drop-in binary" % pend["fq"]["reads"]
+    t_outer = time.time()
+    budget = float(os.environ.get("BT2_BENCH_EXTRA_BUDGET_S", "700"))      # the legs below stop being started once this much time has gone into them
+    if todo.get("pmc"):
+        apply_live_traffic(res, live_pmc_traffic(todo["config"], todo["kernel"], ["--reads", str(todo["reads"])] + todo["forward"]))
+    if todo.get("extra_configs"):
+        res["configs"] = {}
+        for name in todo["extra_configs"]:
+            if time.time() - t_outer > budget:
+                res["configs"][name] = {"error": "not run: the time budget of the extra legs (BT2_BENCH_EXTRA_BUDGET_S = %d s) was spent" % budget}
+                continue
+            argv = ["--config", name, "--steps", str(todo["extra_steps"]), "--warmup", str(min(todo["warmup"], 3)), "--parity-only", "--e2e-reads", "0", "--extra-configs", ""] + todo["forward"]
+            if todo.get("genome_fasta") and CONFIGS[name].get("genome") != "ecoli":
+                argv += ["--genome-fasta", todo["genome_fasta"]]
+            d, err2, rc2 = run_child(argv, timeout_s=600)
+            if d is None:
+                res["configs"][name] = {"error": (err2 or "")[-300:], "returncode": rc2}
+                continue
+            o2 = d.pop("_outer", None) or {}
+            d.pop("e2e_pending", None)
+            if todo.get("pmc") and time.time() - t_outer < budget:
+                apply_live_traffic(d, live_pmc_traffic(name, o2.get("kernel", "k_align_reads"), todo["forward"], timeout_s=240))
+            res["configs"][name] = summarize_config(d)
+        res["configs_note"] = ("BASELINE.json configs[1], [3], [4] measured in this same run, each in a process of its own after the headline: %d timed steps, one run of the unmodified "
+                               "reference on the configuration's sample for cpu_baseline and the byte-for-byte SAM comparison (--parity-only protocol: not a median of 3)" % todo["extra_steps"])
     print(json.dumps(res), flush=True)
-    raise SystemExit(p.returncode)
+    raise SystemExit(rc)
 
 
 if __name__ == "__main__":

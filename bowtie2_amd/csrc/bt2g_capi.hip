@@ -55,6 +55,8 @@ struct bt2g_ctx {
 		uint64_t pre_bytes = 0;
 		hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel boundaries of the last align batch
 		bool ev_valid = false;
+		int busy = 0;                        // bt2g_align_batch calls inside this slot right now (under slot_mu): a busy slot never changes owner
+		bool fence_pending = false;          // a batch failed after kernels were queued: the owner stream is synchronised before the slot changes owner
 		uint64_t last_use = 0;               // batch number of the slot's last bt2g_align_batch: the least recently used slot is handed to a new stream
 		uint64_t arena_cut_stride = 0;       // != 0: the arena holds fewer waves than a full launch of this per-wave stride wants (it was cut to the memory budget)
 	};
@@ -121,7 +123,7 @@ public:
 	// file section -> dst (device); returns when every byte has arrived.  0, or 1 = read error, 2 = HIP error
 	int put(const FileSpan& sp, void* dst) {
 		if (sp.nbytes == 0) return 0;
-		const int fd = open(sp.path.c_str(), O_RDONLY);
+		const int fd = open(sp.path.c_str(), O_RDONLY | O_CLOEXEC);
 		if (fd < 0) return 1;
 		(void)posix_fadvise(fd, (off_t)sp.off, (off_t)sp.nbytes, POSIX_FADV_SEQUENTIAL);
 		const uint64_t nch = (sp.nbytes + kChunk - 1) / kChunk;
@@ -154,7 +156,8 @@ public:
 		};
 		const int nt = (int)(nch < (uint64_t)kThreads ? nch : (uint64_t)kThreads);
 		std::vector<std::thread> th;
-		for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+		// (a C-ABI entry point: std::thread may throw std::system_error under a thread limit -- the chunks are then read by the threads there are)
+		try { th.reserve((size_t)nt); for (int t = 1; t < nt; t++) th.emplace_back(work, t); } catch (...) {}
 		work(0);
 		for (auto& x : th) x.join();
 		close(fd);
@@ -626,15 +629,22 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		if (si < 0) {
 			// more streams than working sets (a caller that rotates through a stream pool, or recreates its streams): the set that has been
 			// idle longest changes hands, once its last batch is done -- its buffers stay, its kernel timings are the old owner's and are dropped
-			for (int i = 0; i < bt2g_ctx::kMaxSlots; i++) if (si < 0 || c->slots[i].last_use < c->slots[si].last_use) si = i;
+			// (a set another thread is inside bt2g_align_batch with is never taken: ADVICE r5)
+			for (int i = 0; i < bt2g_ctx::kMaxSlots; i++) if (!c->slots[i].busy && (si < 0 || c->slots[i].last_use < c->slots[si].last_use)) si = i;
+			if (si < 0) return fail(c, BT2G_ERR_UNSUPPORTED, "every working set of the context is inside bt2g_align_batch: more than 4 streams at once");
 			bt2g_ctx::BatchSlot& V = c->slots[si];
-			if (V.ev_valid && hipEventSynchronize(V.ev[6]) != hipSuccess) return fail(c, BT2G_ERR_HIP, "hipEventSynchronize(working set changing streams)");
-			V.ev_valid = false; V.owner = st;
+			if (V.fence_pending) { if (hipStreamSynchronize(V.owner) != hipSuccess) return fail(c, BT2G_ERR_HIP, "hipStreamSynchronize(working set changing streams)"); }
+			else if (V.ev_valid && hipEventSynchronize(V.ev[6]) != hipSuccess) return fail(c, BT2G_ERR_HIP, "hipEventSynchronize(working set changing streams)");
+			V.ev_valid = false; V.fence_pending = false; V.owner = st;
 		}
 		c->slots[si].last_use = ++c->n_batches;
+		c->slots[si].busy++;
 		c->last_slot = si;
 	}
 	bt2g_ctx::BatchSlot& S = c->slots[si];
+	// leaves the slot on every return path; a return before the last kernel was queued (ev_valid still false) leaves work of unknown extent on
+	// the stream, which is synchronised before the set may change owner
+	struct SlotGuard { bt2g_ctx* c; bt2g_ctx::BatchSlot& S; ~SlotGuard() { std::lock_guard<std::mutex> g(c->slot_mu); S.busy--; if (!S.ev_valid) S.fence_pending = true; } } slot_guard{c, S};
 	uint64_t mat_bytes, mask_bytes, pmask_bytes, arena_stride;
 	if (params->paired && (reads->n_reads & 1u)) return fail(c, BT2G_ERR_ARG, "paired mode needs an even number of reads (mates interleaved)");
 	uint32_t max_cols = dp_cols_for(*params);      // DP columns this launch holds (bt2g_align_params::max_dp_cols)
@@ -828,7 +838,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		: launch_align(c->ix64, *params, *reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), pre, max_read_len, max_cols, (160u * 1024u) / align_waves_per_cu(), st);
 	if (e != hipSuccess) return hip_fail(c, e, "k_align_reads");
 	mark(6);
-	{ std::lock_guard<std::mutex> g(c->slot_mu); S.ev_valid = true; }
+	{ std::lock_guard<std::mutex> g(c->slot_mu); S.ev_valid = true; S.fence_pending = false; }
 	return 0;
 }
 

@@ -114,7 +114,7 @@ inline void print_usage(const char* argv0) {
 	       "  presets: --very-fast --fast --sensitive --very-sensitive (and -local)   --end-to-end | --local\n"
 	       "  alignment: -N 0|1 -L -i --n-ceil --dpad --gbar --ignore-quals --nofw --norc --no-1mm-upfront --no-exact-upfront -d --overhang\n"
 	       "  scoring: --ma --mp --np --rdg --rfg --score-min --policy --bwa-sw-like      effort: -D -R --extends --dp-fails --ug-fails --seed-boost --tighten --no-extend --[no-]ungapped\n"
-	       "  reporting: -k <=64 | -a | -M\n"
+	       "  reporting: -k <=1000 | -a | -M\n"
 	       "  pairs: -I -X --fr/--rf/--ff --no-mixed --no-discordant --dovetail --no-contain --no-overlap\n"
 	       "  SAM: --no-unal --no-hd --no-sq --rg-id --rg --omit-sec-seq --sam-no-qname-trunc --sam-append-comment --soft-clipped-unmapped-tlen --xeq --passthrough\n"
 	       "  other: -p --reorder -t --quiet --seed --qc-filter --gpu a,b --batch n\n"

@@ -89,7 +89,8 @@ BT2_HD uint32_t sa_segment(const DevEbwt<TOff>& e, const TOff* offs, TOff r0, ui
 	}
 	const uint64_t base = r == e.zoff ? 0ull : (uint64_t)offs[(uint64_t)r >> e.off_rate];
 	if (!sa_sampled(e, r0)) sa[(uint64_t)r0] = joff_pack(base + m, m);      // (row len when it is not a sample itself)
-	if (lost && m >= 0xffffu) *lost += m - 0xfffeu;
+	// rows stored with a step count: 1 .. m-1 when the head is itself a sample (it keeps its own offset), 1 .. m otherwise
+	if (lost) { const uint32_t m_eff = sa_sampled(e, r0) ? m - 1 : m; if (m_eff >= 0xffffu) *lost += m_eff - 0xfffeu; }
 	r = r0;
 	for (uint32_t k = 1; k < m; k++) {
 		map_lf1(e, r);

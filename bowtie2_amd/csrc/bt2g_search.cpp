@@ -286,6 +286,8 @@ static int run_search(int argc, char** argv) {
 			if (b->terminator) break;
 			if (!b->bad_input.empty()) die(b->bad_input);
 			if (!b->too_long.empty()) die("read " + b->too_long + " is longer than " + std::to_string(BT2G_MAX_READ_LEN) + " bp (not supported on the device path)");
+			// (said here, by name, rather than as bt2g_align_batch's refusal of the batch: ADVICE r5)
+			if (P.khits > 64 && b->max_len > 512) die("-k above 64 (and -a) is not supported for reads longer than 512 bp by this build; this input has a read of " + std::to_string(b->max_len) + " bp");
 			const size_t n = b->reads.size();
 			b->res_off.assign(n + 1, 0);
 			if (n > 0) {

@@ -54,6 +54,45 @@ def test_eight_ranks_through_bench_py(tmp_path):
     shutil.rmtree(cache, ignore_errors=True)
 
 
+def test_n_gpu_e2e_leg_through_mgpu(tmp_path):
+    """The N-GPU end-to-end leg: every rank writes its distinct reads to its place in ONE FASTQ file, the measuring processes exit, rank 0's
+    parent launches the product's N-GPU driver (python -m torch.distributed.run -m bowtie2_amd.mgpu: byte-range sharding, pieces merged in rank order) -- here
+    around bench.py's stand-in engine over gloo -- and the line carries `e2e` with the ranks' reads, the slowest rank's search time and the merged file's checks."""
+    d, err, cache = run_dry(tmp_path, 3, ["--e2e-reads", "6000"])
+    e = d["e2e"]
+    assert "error" not in e, e
+    assert e["n_gpus"] == 3 and e["reads"] == 3 * 6000 and e["reads_aligned_by_the_ranks"] == 3 * 6000
+    assert len(e["search_s_per_rank"]) == 3 and e["reads_per_s_after_load"] > 0 and e["frac_of_resident"] > 0
+    assert e["sam_records"] == 3 * 6000 and e["sam_complete_and_in_input_order"] is True
+    assert e["host_threads_per_rank"] >= 1 and "bowtie2_amd.mgpu" in e["command"]
+    assert "3 ranks x 6000 distinct reads written into one FASTQ file" in err
+    assert not [f for f in os.listdir(cache) if f.startswith("sync_")]       # the parents' meeting place is gone
+    shutil.rmtree(cache, ignore_errors=True)
+
+
+def test_real_reference_hook(tmp_path):
+    """--genome-fasta / BT2_BENCH_HG38: a real FASTA on the box replaces the synthetic genome -- parsed, indexed (here: the dry stand-in), reads
+    sampled from it by the same generator -- and the metric says which genome ran.  On the reference's own example genome."""
+    fa = os.path.join(ROOT, "tests", "golden", "example", "lambda_virus.fa")
+    d, err, cache = run_dry(tmp_path, 1, ["--genome-fasta", fa])
+    assert "REAL reference lambda_virus.fa (1 sequences, 0.0 Mbp incl. N)" in d["metric"] or "REAL reference lambda_virus.fa" in d["metric"]
+    assert d["config"]["genome"].startswith("lambda_virus.fa") and "REAL reference lambda_virus.fa" in d["config"]["workload"]
+    assert "read from lambda_virus.fa" in err
+    assert any(f.startswith("real_lambda_virus_fa_") for f in os.listdir(cache))
+    # the environment hook, and the synthetic wording without it
+    env_cache = str(tmp_path / "c2")
+    env = dict(os.environ, BT2_BENCH_CACHE=env_cache, BT2_BENCH_HG38=fa, OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-ranks", "--steps", "2", "--warmup", "1", "--reads", "2000"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d2 = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert "REAL reference lambda_virus.fa" in d2["metric"]
+    d3, _, _ = run_dry(tmp_path, 1)
+    assert "hg38-like synthetic genome" in d3["metric"] and d3["config"]["genome"] == "synthetic"
+    assert "timed region: 3 x the same resident batch of 3000 reads per GPU" in d3["config"]["workload"]
+    shutil.rmtree(cache, ignore_errors=True); shutil.rmtree(env_cache, ignore_errors=True)
+
+
 def test_pairs_config_two_ranks(tmp_path):
     d, _, cache = run_dry(tmp_path, 2, ["--config", "pe-vsens"])
     assert d["n_gpus"] == 2 and d["config"]["config_name"] == "pe-vsens" and d["config"]["steps_in_flight"] == 1      # the N-GPU path keeps one step in flight

@@ -21,6 +21,12 @@ for (k, c), v in agg.items():
     kern[short][c] = kern[short].get(c, 0) + v
     kern[short]["dispatches_" + c] = len(nd[(k, c)])
 launches = max([len(v) for (k, c), v in nd.items() if "k_align" in k] or [launches])      # dispatches actually profiled
-json.dump({"reads_per_launch": reads, "launches": launches, "unit": "FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them", "kernels": kern},
+import hashlib
+try:
+    sha = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bowtie2_amd", "libbt2g.so"), "rb").read()).hexdigest()
+except OSError:
+    sha = None
+json.dump({"lib_sha256": sha, "lib_sha256_note": "the libbt2g.so these passes ran on: bench.py quotes this file only when it loads the same library",
+           "reads_per_launch": reads, "launches": launches, "unit": "FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them", "kernels": kern},
           open(O + "/pmc_traffic.json", "w"), indent=1)
 print(open(O + "/summary.csv").read())
