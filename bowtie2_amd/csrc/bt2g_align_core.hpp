@@ -30,6 +30,11 @@ struct Aligner {
 	// area in HBM is reached through WK.  The class itself has no data members.
 #define ST (Plat::st())
 #define WK (Plat::work())
+// Lane code in one source for both platforms (round 6): a block that every lane executes for itself.  On the device the block runs once, `l` is
+// the lane's own number and a LaneReg is the lane's own register; on the host twin it is a loop over the 64 lanes of LaneReg arrays.  What
+// crosses lanes (Plat::ballot, Plat::lane, Plat::gather ...) happens between such blocks.
+#define BT2_FOR_LANES(l) for (uint32_t l = Plat::lanes_first(); l < 64u; l += Plat::lanes_step())
+#define LV(x) (Plat::lv(x, l))
 	static constexpr TOff kOffMask = (TOff)OffTraits<TOff>::kMask;
 
 	BT2_HD Aligner(BT2_G Work& w_, DpScratch dp_, uint32_t ridx_ = 0) {
@@ -826,14 +831,179 @@ struct Aligner {
 		double mass = Plat::prefix_live(mlo, mhi, live, plo, phi);
 		uint32_t obase = n_satpos - n_full, ocnt = 0;
 		uint64_t draws = 0;
+		uint32_t draws_batched = 0, nbatch_prof = 0;
 		bool full = false;
+		// ---- batched replay (round 6) ----
+		// A draw consumes the read's RNG and decides which range the next one lands in, so the draws cannot be reordered -- but up to 64 of them can be
+		// REPLAYED side by side, lane d = the d-th draw from here, as long as no draw of the batch changes what a later one sees:
+		//  * the RNG is an LCG (random_source.h:34-159): the state after k steps is A_k * s + C_k (mod 2^32).  A draw takes four steps (nextFloat's
+		//    nextU32, Random1toN's nextU32) unless a seen-list draw is rejected, so lane d starts from the state 4 d steps on (jA, jC below);
+		//  * the range a draw picks depends on the running sums of the ranges in play: unchanged until a range is used up -- the batch is committed
+		//    up to and including the draw that exhausts a range;
+		//  * a draw's cursor in its range = the range's cursor + the earlier draws of the batch in the same range (occ);
+		//  * what a draw reads from the table (positions cur and rr of a swap list, "seen before?" of a seen list) must not have been written by an
+		//    earlier draw of the batch: the batch is committed up to the first draw with such a conflict, up to the first rejected seen-list draw
+		//    and up to the first draw that converts its range (thresh reached) -- that one draw then goes through the serial code below.
+		// Everything is lane code over the same registers the serial path uses; SAM parity of every differential test pins it on the CPU twin.
+		constexpr uint32_t kLcgA = 1664525u, kLcgC = 1013904223u;
+		constexpr uint32_t kA2 = kLcgA * kLcgA, kA4 = kA2 * kA2, kC4 = kLcgC * (kLcgA * kA2 + kA2 + kLcgA + 1u);
+		constexpr uint32_t kBatchMin = 6u;
+		typename Plat::LaneReg jA, jC;
+		BT2_FOR_LANES(l) {
+			uint32_t A = 1u, C = 0u, pa = kA4, pc = kC4;
+			for (uint32_t b = 0; b < 6u; b++) {
+				if ((l >> b) & 1u) { C = C * pa + pc; A = A * pa; }
+				pc = pc * pa + pc; pa = pa * pa;
+			}
+			LV(jA) = A; LV(jC) = C;
+		}
+		bool serial_next = false;
+#ifdef BT2G_SAMP_SERIAL
+		const bool batching = false;      // A/B builds: every draw through the serial path below
+#else
+		const bool batching = true;
+#endif
 		while (nelt_added < maxelt && nelt_added < nelt) {
+			if (batching && !serial_next) {
+				const uint64_t want = (maxelt < nelt ? maxelt : nelt) - nelt_added;
+				uint32_t B = want > 64ull ? 64u : (uint32_t)want;
+				{ const uint32_t room_rows = (uint32_t)kMaxSatpos - n_satpos, room_tab = 64u * (uint32_t)kSampTabRegs - 2u > tab.n ? 64u * (uint32_t)kSampTabRegs - 2u - tab.n : 0u;
+				  if (B > room_rows) B = room_rows;
+				  if (B > room_tab) B = room_tab; }
+				if (B >= kBatchMin && live != 0ull) {
+					// (1) every lane's RNG draws and its point on the running sums
+					typename Plat::LaneReg u2r, x4r, rdlo, rdhi;
+					const uint32_t g0 = g.last;
+					BT2_FOR_LANES(l) {
+						uint32_t x = LV(jA) * g0 + LV(jC);
+						x = kLcgA * x + kLcgC; uint32_t r1 = x >> 16; x = kLcgA * x + kLcgC; r1 ^= x;
+						x = kLcgA * x + kLcgC; uint32_t r2 = x >> 16; x = kLcgA * x + kLcgC; r2 ^= x;
+						const float f = (float)r1 / (float)0xffffffffu;
+						const double rdv = (double)(f * mass);
+						uint64_t u; __builtin_memcpy(&u, &rdv, 8);
+						LV(u2r) = r2; LV(x4r) = x; LV(rdlo) = (uint32_t)u; LV(rdhi) = (uint32_t)(u >> 32);
+					}
+					// (2) RowSampler::next of every lane + how many earlier lanes picked the same range; lane i of mblo/mbhi: the lanes that picked range i
+					typename Plat::LaneReg pick, occ, mblo, mbhi, nw;
+					Plat::lanes_zero(pick); Plat::lanes_zero(occ); Plat::lanes_zero(mblo); Plat::lanes_zero(mbhi);
+					uint64_t rem = B >= 64u ? ~0ull : ((1ull << B) - 1ull);
+					const uint32_t last_live = 63u - (uint32_t)__builtin_clzll(live);
+					for (uint64_t lvm = live; lvm != 0ull && rem != 0ull; lvm &= lvm - 1ull) {
+						const uint32_t i = (uint32_t)__builtin_ctzll(lvm);
+						const double pfx = f64_of(Plat::lane(plo, i), Plat::lane(phi, i));
+						BT2_FOR_LANES(l) { LV(nw) = (((rem >> l) & 1ull) && (i == last_live || f64_of(LV(rdlo), LV(rdhi)) < pfx)) ? 1u : 0u; }
+						const uint64_t m = Plat::ballot(nw);
+						if (m) {
+							BT2_FOR_LANES(l) { if (LV(nw)) { LV(pick) = i; LV(occ) = (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull)); } }
+							Plat::set_lane(mblo, i, (uint32_t)m); Plat::set_lane(mbhi, i, (uint32_t)(m >> 32));
+							rem &= ~m;
+						}
+					}
+					// (3) the state of each lane's range, (4) its Random1toN draw and the table keys it has to look at
+					const typename Plat::LaneReg gn = Plat::gather(rn, pick), gc = Plat::gather(rcur, pick), gf = Plat::gather(rfl, pick), gs = Plat::gather(rseen, pick),
+						gt = Plat::gather(rthr, pick), gml = Plat::gather(mblo, pick), gmh = Plat::gather(mbhi, pick);
+					typename Plat::LaneReg curr, posr, keyA, keyB, convk, bad, exh, fa, va, fb, vb, eb, ca, cb;
+					BT2_FOR_LANES(l) {
+						const uint32_t n = LV(gn), c = LV(gc) + LV(occ), fl = LV(gf);
+						uint32_t bd = 0, ex = 0, pos = 0, kA = 0, kB = 0, kC = 0;
+						if (l < B) {
+							const uint32_t rkey = LV(pick) << 24;
+							if (c >= n) bd = 1u;
+							else if (fl & 1u) {
+								if (n == 1u && c == 0u && !(fl & 2u)) bd = 1u;
+								else { pos = c + LV(u2r) % (n - c); kA = kTabSwap | rkey | c; kB = kTabSwap | rkey | pos; if (fl & 2u) kC = kTabConv | rkey; }
+							} else {
+								pos = LV(u2r) % n; kB = kTabSeen | rkey | pos;
+								if (LV(gs) + LV(occ) + 1u >= LV(gt) && c + 1u < n) bd = 1u;      // this draw converts the range: serial
+							}
+							if (!bd && c + 1u >= n) ex = 1u;
+						}
+						LV(curr) = c; LV(posr) = pos; LV(keyA) = kA; LV(keyB) = kB; LV(convk) = kC; LV(bad) = bd; LV(exh) = ex;
+						LV(fa) = LV(va) = LV(fb) = LV(vb) = LV(eb) = LV(ca) = LV(cb) = 0u;
+					}
+					// (5) one pass over the table for all lanes (an entry's key is never 0)
+					Plat::tab_for_each(tab.k, tab.v, tab.n, [&](uint32_t e, uint32_t ke, uint32_t ve) {
+						BT2_FOR_LANES(l) {
+							if (ke == LV(keyA)) { LV(fa) = 1u; LV(va) = ve; }
+							if (ke == LV(keyB)) { LV(fb) = 1u; LV(vb) = ve; LV(eb) = e; }
+							if ((ke & 0xff000000u) == LV(convk)) { if (ve <= LV(curr)) LV(ca) = LV(ca) + 1u; if (ve <= LV(posr)) LV(cb) = LV(cb) + 1u; }
+						}
+					});
+					// a seen-list draw whose value is in the table is rejected (drawn again): serial
+					BT2_FOR_LANES(l) { if (l < B && !(LV(gf) & 1u) && LV(fb)) LV(bad) = 1u; }
+					// (6) conflicts inside the batch: an earlier lane of the same range wrote the position this lane reads (swap list: positions cur and rr;
+					//     seen list: the same value again)
+					{
+						typename Plat::LaneReg mult;
+						BT2_FOR_LANES(l) { LV(mult) = (l < B && __builtin_popcountll(((uint64_t)LV(gmh) << 32) | (uint64_t)LV(gml)) >= 2) ? 1u : 0u; }
+						for (uint64_t mm = Plat::ballot(mult); mm != 0ull; mm &= mm - 1ull) {
+							const uint32_t lp = (uint32_t)__builtin_ctzll(mm);
+							const uint32_t pk = Plat::lane(pick, lp), pp = Plat::lane(posr, lp), cp = Plat::lane(curr, lp), sw = Plat::lane(gf, lp) & 1u;
+							if (sw && pp == cp) continue;      // (a swap with itself writes nothing)
+							BT2_FOR_LANES(l) { if (l > lp && l < B && LV(pick) == pk && (pp == LV(posr) || (sw && pp == LV(curr)))) LV(bad) = 1u; }
+						}
+					}
+					// (7) the batch is good up to the first conflict, and up to and including the first draw that uses its range up
+					const uint64_t badm = Plat::ballot(bad), exm = Plat::ballot(exh);
+					uint32_t L = B;
+					if (badm) { const uint32_t fbad = (uint32_t)__builtin_ctzll(badm); if (fbad < L) L = fbad; }
+					bool used_up = false;
+					if (exm) { const uint32_t fex = (uint32_t)__builtin_ctzll(exm); if (fex + 1u <= L) { L = fex + 1u; used_up = true; } }
+					if (L < B && !used_up) serial_next = true;      // the draw after the batch needs the serial path
+					if (L > 0u) {
+						// (8) commit draws 0 .. L-1
+						if (ocnt > 0u) { Plat::flush_samp_rows(srows + obase, olo, ohi, osrc, ocnt); obase += ocnt; ocnt = 0u; }
+						const uint64_t cm = L >= 64u ? ~0ull : ((1ull << L) - 1ull);
+						typename Plat::LaneReg app, akey, aval, setf, wlo, whi, wsrc;
+						const typename Plat::LaneReg gtl = Plat::gather(tlo, pick), gth = Plat::gather(thi, pick);
+						BT2_FOR_LANES(l) {
+							const uint32_t fl = LV(gf), c = LV(curr), pos = LV(posr);
+							uint32_t ret = 0, ap = 0, sf = 0, av = 0;
+							if (l < L) {
+								if (fl & 1u) {
+									const uint32_t a = LV(fa) ? LV(va) : ((fl & 2u) ? c + LV(ca) : c);
+									if (pos == c) ret = a;
+									else { ret = LV(fb) ? LV(vb) : ((fl & 2u) ? pos + LV(cb) : pos); av = a; if (LV(fb)) sf = 1u; else ap = 1u; }
+								} else { ret = pos; ap = 1u; av = 0u; }
+							}
+							const uint64_t topf = (((uint64_t)LV(gth) << 32) | (uint64_t)LV(gtl)) + (uint64_t)ret;
+							LV(wlo) = (uint32_t)topf; LV(whi) = (uint32_t)(topf >> 32); LV(wsrc) = LV(pick) + sai;
+							LV(app) = ap; LV(akey) = LV(keyB); LV(aval) = av; LV(setf) = sf;
+						}
+						for (uint64_t sm = Plat::ballot(setf); sm != 0ull; sm &= sm - 1ull) {      // position rr already has an entry: it takes the value of position cur
+							const uint32_t ls = (uint32_t)__builtin_ctzll(sm);
+							Plat::tab_set_at(tab.v, Plat::lane(eb, ls), Plat::lane(aval, ls));
+						}
+						Plat::tab_append_lanes(tab.k, tab.v, tab.n, app, akey, aval);
+						Plat::flush_samp_rows(srows + obase, wlo, whi, wsrc, L);
+						obase += L; n_satpos += L; nelt_added += (uint64_t)L;
+						// cursors (and seen counts) of the ranges
+						BT2_FOR_LANES(l) {
+							const uint32_t cnt = (uint32_t)__builtin_popcountll((((uint64_t)LV(mbhi) << 32) | (uint64_t)LV(mblo)) & cm);
+							LV(rcur) = LV(rcur) + cnt;
+							if (!(LV(rfl) & 1u)) LV(rseen) = LV(rseen) + cnt;
+						}
+						{ typename Plat::LaneReg sn; BT2_FOR_LANES(l) { LV(sn) = (l < L && !(LV(gf) & 1u)) ? 1u : 0u; }
+						  draws += (uint64_t)L + ((uint64_t)__builtin_popcountll(Plat::ballot(sn)) << 32); }
+						g.last = Plat::lane(x4r, L - 1u); g.lastOff = 0u;
+						if (used_up) {
+							const uint32_t pe = Plat::lane(pick, L - 1u);
+							live &= ~(1ull << pe);
+							mass -= f64_of(Plat::lane(mlo, pe), Plat::lane(mhi, pe));
+							Plat::prefix_live(mlo, mhi, live, plo, phi);
+						}
+						nbatch_prof += 0x10000u; draws_batched += L;      // profile: batches, draws committed by batches
+						continue;
+					}
+				}
+			}
+			serial_next = false;
 			// RowSampler::next: first range still in play whose running sum exceeds rd, else the last one in play
 			const double rd = (double)(g.nextFloat() * mass);
 			const uint32_t pick = Plat::pick_prefix(plo, phi, live, rd);
 			uint32_t n = Plat::lane(rn, pick), cur = Plat::lane(rcur, pick), fl = Plat::lane(rfl, pick);      // fl: bit 0 swap list, bit 1 converted
 			const uint32_t rkey = pick << 24;
-			draws += (fl & 1u) ? 1ull : (1ull | (1ull << 32));      // profile: draws | draws on the seen-list path << 32
+			draws += 1ull;
 			uint32_t ret;
 			// Random1toN::next
 			if (fl & 1u) {
@@ -891,7 +1061,8 @@ struct Aligner {
 		}
 		if (ocnt > 0) Plat::flush_samp_rows(srows + obase, olo, ohi, osrc, ocnt);
 		ST.rnd = g; HOT.mass = mass; HOT.n_satpos = n_satpos;
-		HOT.t_phase[21] += draws;
+		HOT.t_phase[21] += draws | ((uint64_t)draws_batched << 32);      // profile: draws | draws committed by batches << 32
+		HOT.n_dp_pass += nbatch_prof;                                      // (high half: batches)
 		if (full) ovf(13);
 		return nelt_added;
 	}

@@ -723,6 +723,52 @@ struct DevPlat {
 			if ((k[r] & 0xff000000u) == seenhi) { v[r] = (k[r] & 0xffffffu) - cnt[r]; k[r] = convhi | (k[r] & 0xffffffu); }
 		}
 	}
+	// ---- lane code (BT2_FOR_LANES / LV in bt2g_align_core.hpp): on the device the block runs once, a LaneReg is the lane's own register ----
+	static __device__ __forceinline__ uint32_t lanes_first() { return threadIdx.x & 63; }
+	static __device__ __forceinline__ uint32_t lanes_step() { return 64u; }
+	static __device__ __forceinline__ uint32_t& lv(uint32_t& r, uint32_t) { return r; }
+	static __device__ __forceinline__ const uint32_t& lv(const uint32_t& r, uint32_t) { return r; }
+	static __device__ __forceinline__ uint64_t ballot(uint32_t r) { return (uint64_t)__ballot(r != 0u); }
+	static __device__ __forceinline__ uint32_t gather(uint32_t x, uint32_t idx) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)x); }
+	template <typename V, typename F> static __device__ __forceinline__ void tab_for_each(const V& k, const V& v, uint32_t n_, F f) {
+		constexpr int K = sizeof(V) / 4;
+		const uint32_t n = uni(n_);
+#pragma unroll
+		for (int r = 0; r < K; r++) {
+			if ((uint32_t)r * 64u >= n) break;
+			const uint32_t cnt = n - (uint32_t)r * 64u < 64u ? n - (uint32_t)r * 64u : 64u;
+			for (uint32_t i = 0; i < cnt; i++)
+				f((uint32_t)r * 64u + i, (uint32_t)__builtin_amdgcn_readlane((int)k[r], (int)i), (uint32_t)__builtin_amdgcn_readlane((int)v[r], (int)i));
+		}
+	}
+	template <typename V> static __device__ __forceinline__ void tab_set_at(V& v, uint32_t e_, uint32_t val) {
+		constexpr int K = sizeof(V) / 4;
+		const uint32_t e = uni(e_);
+#pragma unroll
+		for (int r = 0; r < K; r++) if ((uint32_t)r == (e >> 6)) { uint32_t t = v[r]; set_lane(t, e & 63u, val); v[r] = t; }
+	}
+	// the flagged lanes' (key, value) pairs become the next entries of the table, in lane order: destination slot n + j takes the pair of the
+	// j-th flagged lane (found per destination lane by a select on the ballot mask, fetched with ds_bpermute)
+	template <typename V> static __device__ __forceinline__ void tab_append_lanes(V& k, V& v, uint32_t& n_, uint32_t flag, uint32_t key, uint32_t val) {
+		constexpr int K = sizeof(V) / 4;
+		const uint64_t m = (uint64_t)__ballot(flag != 0u);
+		if (!m) return;
+		const uint32_t n = uni(n_), cnt = (uint32_t)__popcll(m), l = threadIdx.x & 63;
+		const uint32_t j = (l - n) & 63u;           // this lane's slot is entry n + j of the table (when j < cnt)
+		// select(m, j): the position of the j-th set bit
+		uint64_t mm = m; uint32_t jj = j, pos = 0;
+#pragma unroll
+		for (uint32_t w = 32; w >= 1; w >>= 1) {
+			const uint32_t c = (uint32_t)__popcll(mm & ((1ull << w) - 1ull));
+			if (jj >= c) { jj -= c; mm >>= w; pos += w; }
+		}
+		const uint32_t sk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pos & 63u) << 2), (int)key), sv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pos & 63u) << 2), (int)val);
+		const uint32_t slot = ((n + j) & ~63u) == (n & ~63u) ? (n & ~63u) + l : (n & ~63u) + 64u + l;      // the slot of this lane that lies in [n, n + 64)
+		const bool take = j < cnt;
+#pragma unroll
+		for (int r = 0; r < K; r++) if (take && (slot >> 6) == (uint32_t)r) { k[r] = sk; v[r] = sv; }
+		n_ = n + cnt;
+	}
 	// rows drawn by the sampler -> Work::srows, one 16-byte record per lane
 	static __device__ __forceinline__ void flush_samp_rows(BT2_G SampRow* dst, uint32_t lo, uint32_t hi, uint32_t src, uint32_t cnt) {
 		const uint32_t l = threadIdx.x & 63;
@@ -1517,7 +1563,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)g_hot.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
 			atomicAdd(&prof[9], 1ull);
-			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass); for (int i = 0; i < 5; i++) atomicAdd(&prof[27 + i], (unsigned long long)g_hot.t_bt[i]);
+			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)(g_hot.n_dp_pass & 0xffffu) | ((unsigned long long)(g_hot.n_dp_pass >> 16) << 32)); for (int i = 0; i < 5; i++) atomicAdd(&prof[27 + i], (unsigned long long)g_hot.t_bt[i]);
 		}
 	}
 }
@@ -1575,7 +1621,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 			for (int i = 8; i < 22; i++) atomicAdd(&prof[i + 2], (unsigned long long)g_hot.t_phase[i]);
 			atomicAdd(&prof[8], (unsigned long long)g_hot.n_sides);
 			atomicAdd(&prof[9], 2ull);
-			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)g_hot.n_dp_pass); for (int i = 0; i < 5; i++) atomicAdd(&prof[27 + i], (unsigned long long)g_hot.t_bt[i]);
+			atomicAdd(&prof[24], (unsigned long long)g_hot.n_dp_cells_score); atomicAdd(&prof[25], (unsigned long long)g_hot.n_dp_cells_full); atomicAdd(&prof[26], (unsigned long long)(g_hot.n_dp_pass & 0xffffu) | ((unsigned long long)(g_hot.n_dp_pass >> 16) << 32)); for (int i = 0; i < 5; i++) atomicAdd(&prof[27 + i], (unsigned long long)g_hot.t_bt[i]);
 		}
 	}
 }

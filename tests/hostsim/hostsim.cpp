@@ -175,6 +175,19 @@ struct HostPlat {
 		}
 		for (uint32_t i = 0; i < n; i++) { uint32_t& ki = k[i >> 6].v[i & 63]; if ((ki & 0xff000000u) == seenhi) ki = convhi | (ki & 0xffffffu); }
 	}
+	// ---- lane code (BT2_FOR_LANES / LV in bt2g_align_core.hpp): on the host a loop over the 64 lanes of LaneReg arrays ----
+	static uint32_t lanes_first() { return 0; }
+	static uint32_t lanes_step() { return 1; }
+	static uint32_t& lv(LaneReg& r, uint32_t l) { return r.v[l]; }
+	static const uint32_t& lv(const LaneReg& r, uint32_t l) { return r.v[l]; }
+	static uint64_t ballot(const LaneReg& r) { uint64_t m = 0; for (uint32_t l = 0; l < 64; l++) if (r.v[l]) m |= 1ull << l; return m; }
+	static LaneReg gather(const LaneReg& x, const LaneReg& idx) { LaneReg r; for (uint32_t l = 0; l < 64; l++) r.v[l] = x.v[idx.v[l] & 63u]; return r; }
+	template <typename T, typename F> static void tab_for_each(const T& k, const T& v, uint32_t n, F f) { for (uint32_t e = 0; e < n; e++) f(e, k[e >> 6].v[e & 63], v[e >> 6].v[e & 63]); }
+	template <typename T> static void tab_set_at(T& v, uint32_t e, uint32_t val) { v[e >> 6].v[e & 63] = val; }
+	// the flagged lanes' (key, value) pairs become the next entries of the table, in lane order
+	template <typename T> static void tab_append_lanes(T& k, T& v, uint32_t& n, const LaneReg& flag, const LaneReg& key, const LaneReg& val) {
+		for (uint32_t l = 0; l < 64; l++) if (flag.v[l]) { k[n >> 6].v[n & 63] = key.v[l]; v[n >> 6].v[n & 63] = val.v[l]; n++; }
+	}
 	static void flush_samp_rows(SampRow* dst, const LaneReg& lo, const LaneReg& hi, const LaneReg& src, uint32_t cnt) {
 		for (uint32_t l = 0; l < cnt; l++) { dst[l].topf = ((uint64_t)hi.v[l] << 32) | lo.v[l]; dst[l].src = src.v[l]; dst[l].done = 0; }
 	}
