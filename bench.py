@@ -1355,7 +1355,8 @@ def main():
                                                "successful_walks": prof[29] / max(1, prof[9]), "tail_us_after_successful_trace": round(prof[30] / 100.0 / max(1, prof[9]), 1),
                                                "scalar_steps": prof[31] / max(1, prof[9])},
                 "worker_counts_per_read": {"bt_steps": prof[13] / max(1, prof[9]), "bt_tiles": prof[14] / max(1, prof[9]), "cand_cells": prof[15] / max(1, prof[9]),
-                                           "sampled_rows": (prof[23] & 0xffffffff) / max(1, prof[9]), "sampled_rows_seen_list": (prof[23] >> 32) / max(1, prof[9])},
+                                           "sampled_rows": (prof[23] & 0xffffffff) / max(1, prof[9]), "sampled_rows_in_batches": (prof[23] >> 32) / max(1, prof[9]),
+                                           "sampler_batches": (prof[26] >> 32) / max(1, prof[9])},
                 "kernel_ms_per_step": {("k_align_pairs" if args.paired and k == "k_align_reads" else k): round(v, 3) for k, v in kavg.items()}, "batch_ms_events": round(batch_ms, 3),
                 "kernel_ms_per_step_one_at_a_time": None if kavg_serial is None else {("k_align_pairs" if args.paired and k == "k_align_reads" else k): round(v, 3) for k, v in kavg_serial.items()},
                 "kernel_ms_note": None if kavg_serial is None else "kernel_ms_per_step are HIP-event durations inside the timed region, where the kernels of %d batches in flight overlap (not additive); "

@@ -814,6 +814,9 @@ struct Aligner {
 		const uint32_t sai = Plat::uni(sai_), n_masses = Plat::uni(n_masses_);
 		const uint64_t maxelt = Plat::uni(maxelt_), nelt = Plat::uni(nelt_);
 		uint64_t nelt_added = Plat::uni(nelt_added_);
+#ifdef BT2G_SAMP_PROF
+		const uint64_t tcall_ = Plat::clock();
+#endif
 		Rng g; g.last = Plat::uni(ST.rnd.last); g.lastOff = Plat::uni(ST.rnd.lastOff);      // (LDS loads arrive in vector registers: lane-varying to the compiler unless told otherwise)
 		uint32_t n_satpos = Plat::uni(HOT.n_satpos);
 		const uint32_t n_full = Plat::uni(HOT.n_satpos_full);
@@ -857,20 +860,40 @@ struct Aligner {
 			}
 			LV(jA) = A; LV(jC) = C;
 		}
-		bool serial_next = false;
-#ifdef BT2G_SAMP_SERIAL
-		const bool batching = false;      // A/B builds: every draw through the serial path below
+#ifdef BT2G_SAMP_PROF
+		// experiment builds: device clocks of the batch's parts, booked under phase slots that are otherwise (nearly) empty on unpaired end-to-end batches
+#define SAMP_T(slot) do { const uint64_t t__ = Plat::clock(); HOT.t_phase[slot] += t__ - tsp_; tsp_ = t__; } while (0)
+		uint64_t tsp_ = Plat::clock();
+		HOT.t_phase[20] += tsp_ - tcall_;
 #else
-		const bool batching = true;
+#define SAMP_T(slot) do {} while (0)
 #endif
+		bool serial_next = false;
+		// The batch looks table entries up by key in hash tables that mirror the register table -- S: the seen-list keys (a set), W: swap-list key ->
+		// entry index -- and finds the draws of a batch that meet in one position through a third, per-batch table Bt (key -> the lanes writing it).
+		// They live in the launch's dynamic LDS, which holds DP-window state otherwise and is free while rows are sampled (Plat::sh_begin: slots of S
+		// and W; 0 when the launch has no room: no batching then).  A table is kept while it is at most 3/4 full; past that the call goes on serially.
+#ifdef BT2G_SAMP_SERIAL
+		const uint32_t shN = 0u;      // A/B builds: every draw through the serial path below
+#else
+		const uint32_t shN = (maxelt < nelt ? maxelt : nelt) - nelt_added >= (uint64_t)kBatchMin ? Plat::uni(Plat::sh_begin()) : 0u;
+#endif
+		const uint32_t capS = (shN & 0xffffu) - ((shN & 0xffffu) >> 2), capW = (shN >> 16) - ((shN >> 16) >> 2);
+		uint32_t nS_ent = 0, nW_ent = 0;      // entries in S / W
+		bool sh_live = shN != 0u;             // S and W still take entries
+		uint32_t n_mir = 0xffffffffu;         // once one of them is full: entries of the register table from this index on are not in S / W (the batch scans them)
 		while (nelt_added < maxelt && nelt_added < nelt) {
-			if (batching && !serial_next) {
+			if (shN != 0u && !serial_next) {
 				const uint64_t want = (maxelt < nelt ? maxelt : nelt) - nelt_added;
 				uint32_t B = want > 64ull ? 64u : (uint32_t)want;
 				{ const uint32_t room_rows = (uint32_t)kMaxSatpos - n_satpos, room_tab = 64u * (uint32_t)kSampTabRegs - 2u > tab.n ? 64u * (uint32_t)kSampTabRegs - 2u - tab.n : 0u;
 				  if (B > room_rows) B = room_rows;
-				  if (B > room_tab) B = room_tab; }
+				  if (B > room_tab) B = room_tab;
+				  if (sh_live && (nS_ent + B > capS || nW_ent + B > capW)) { sh_live = false; n_mir = tab.n; } }
 				if (B >= kBatchMin && live != 0ull) {
+#ifdef BT2G_SAMP_PROF
+					tsp_ = Plat::clock();
+#endif
 					// (1) every lane's RNG draws and its point on the running sums
 					typename Plat::LaneReg u2r, x4r, rdlo, rdhi;
 					const uint32_t g0 = g.last;
@@ -899,6 +922,7 @@ struct Aligner {
 							rem &= ~m;
 						}
 					}
+					SAMP_T(0);
 					// (3) the state of each lane's range, (4) its Random1toN draw and the table keys it has to look at
 					const typename Plat::LaneReg gn = Plat::gather(rn, pick), gc = Plat::gather(rcur, pick), gf = Plat::gather(rfl, pick), gs = Plat::gather(rseen, pick),
 						gt = Plat::gather(rthr, pick), gml = Plat::gather(mblo, pick), gmh = Plat::gather(mbhi, pick);
@@ -921,60 +945,141 @@ struct Aligner {
 						LV(curr) = c; LV(posr) = pos; LV(keyA) = kA; LV(keyB) = kB; LV(convk) = kC; LV(bad) = bd; LV(exh) = ex;
 						LV(fa) = LV(va) = LV(fb) = LV(vb) = LV(eb) = LV(ca) = LV(cb) = 0u;
 					}
-					// (5) one pass over the table for all lanes (an entry's key is never 0)
-					Plat::tab_for_each(tab.k, tab.v, tab.n, [&](uint32_t e, uint32_t ke, uint32_t ve) {
-						BT2_FOR_LANES(l) {
-							if (ke == LV(keyA)) { LV(fa) = 1u; LV(va) = ve; }
-							if (ke == LV(keyB)) { LV(fb) = 1u; LV(vb) = ve; LV(eb) = e; }
-							if ((ke & 0xff000000u) == LV(convk)) { if (ve <= LV(curr)) LV(ca) = LV(ca) + 1u; if (ve <= LV(posr)) LV(cb) = LV(cb) + 1u; }
-						}
-					});
-					// a seen-list draw whose value is in the table is rejected (drawn again): serial
-					BT2_FOR_LANES(l) { if (l < B && !(LV(gf) & 1u) && LV(fb)) LV(bad) = 1u; }
-					// (6) conflicts inside the batch: an earlier lane of the same range wrote the position this lane reads (swap list: positions cur and rr;
-					//     seen list: the same value again)
+					// (5) what the table says about positions cur and rr (swap list) / "drawn before?" (seen list): T gives the entry, the register table its word
 					{
-						typename Plat::LaneReg mult;
-						BT2_FOR_LANES(l) { LV(mult) = (l < B && __builtin_popcountll(((uint64_t)LV(gmh) << 32) | (uint64_t)LV(gml)) >= 2) ? 1u : 0u; }
-						for (uint64_t mm = Plat::ballot(mult); mm != 0ull; mm &= mm - 1ull) {
-							const uint32_t lp = (uint32_t)__builtin_ctzll(mm);
-							const uint32_t pk = Plat::lane(pick, lp), pp = Plat::lane(posr, lp), cp = Plat::lane(curr, lp), sw = Plat::lane(gf, lp) & 1u;
-							if (sw && pp == cp) continue;      // (a swap with itself writes nothing)
-							BT2_FOR_LANES(l) { if (l > lp && l < B && LV(pick) == pk && (pp == LV(posr) || (sw && pp == LV(curr)))) LV(bad) = 1u; }
+						typename Plat::LaneReg fsw, fany, ia, ib;
+						BT2_FOR_LANES(l) { LV(fsw) = (LV(keyA) != 0u) ? 1u : 0u; LV(fany) = (LV(keyB) != 0u && !LV(bad)) ? 1u : 0u; }
+						Plat::sh_get(shN, keyA, fsw, fa, ia);
+						Plat::sh_get(shN, keyB, fany, fb, ib);
+						const typename Plat::LaneReg ga_ = Plat::tab_gather(tab.v, ia), gb_ = Plat::tab_gather(tab.v, ib);
+						BT2_FOR_LANES(l) { LV(va) = LV(ga_); LV(vb) = LV(gb_); LV(eb) = LV(ib); }
+						if (tab.n > n_mir) {
+							// entries S / W had no room for: one pass over them
+							Plat::tab_for_each(tab.k, tab.v, tab.n, [&](uint32_t e, uint32_t ke, uint32_t ve) {
+								BT2_FOR_LANES(l) {
+									if (ke == LV(keyA)) { LV(fa) = 1u; LV(va) = ve; }
+									if (ke == LV(keyB)) { LV(fb) = 1u; LV(vb) = ve; LV(eb) = e; }
+								}
+							}, n_mir);
+						}
+						// converted ranges (rare): position i of the list is i + the number of seen values with value - rank <= i -- a pass over the table
+						typename Plat::LaneReg cvf;
+						BT2_FOR_LANES(l) { LV(cvf) = LV(convk) != 0u ? 1u : 0u; }
+						if (Plat::ballot(cvf)) {
+							Plat::tab_for_each(tab.k, tab.v, tab.n, [&](uint32_t e, uint32_t ke, uint32_t ve) {
+								(void)e;
+								BT2_FOR_LANES(l) { if ((ke & 0xff000000u) == LV(convk)) { if (ve <= LV(curr)) LV(ca) = LV(ca) + 1u; if (ve <= LV(posr)) LV(cb) = LV(cb) + 1u; } }
+							});
 						}
 					}
-					// (7) the batch is good up to the first conflict, and up to and including the first draw that uses its range up
+					// a seen-list draw whose value is in the table is rejected (drawn again): serial
+					BT2_FOR_LANES(l) { if (l < B && !(LV(gf) & 1u) && LV(fb)) LV(bad) = 1u; }
+					SAMP_T(1);
+					// (6) draws of the batch that meet in one position.  Every draw that writes -- a seen-list draw its value, a swap-list draw position rr
+					//     (unless rr = cur) -- joins, in Bt, the set of lanes writing that key.  A seen-list draw that finds an earlier lane under its value is
+					//     a rejection (serial).  A swap-list draw reads positions cur and rr: what the LATEST earlier draw s of the batch put there is what s
+					//     found at ITS cur (depA / depB); of several writes to one position the last committed one is the table's entry (wmlo/wmhi: the writers).
+					typename Plat::LaneReg depA, depB, wrote, wmlo, wmhi;
+					{
+						typename Plat::LaneReg wr, fsw, fany, alo, ahi;
+						BT2_FOR_LANES(l) {
+							const uint32_t ok = (l < B && !LV(bad)) ? 1u : 0u, sw = LV(gf) & 1u;
+							LV(wrote) = (ok && sw && LV(posr) != LV(curr)) ? 1u : 0u;
+							LV(wr) = (ok && (!sw || LV(posr) != LV(curr))) ? 1u : 0u;
+							LV(fsw) = (ok && sw) ? 1u : 0u; LV(fany) = ok;
+						}
+						Plat::bh_clear(shN);
+						Plat::bh_mark(shN, keyB, wr);
+						Plat::bh_get(shN, keyA, fsw, alo, ahi);
+						Plat::bh_get(shN, keyB, fany, wmlo, wmhi);
+						BT2_FOR_LANES(l) {
+							uint32_t da = 0xffffffffu, db = 0xffffffffu;
+							if (LV(fany)) {
+								const uint64_t below = (1ull << l) - 1ull;
+								const uint64_t ma = ((((uint64_t)LV(ahi)) << 32) | (uint64_t)LV(alo)) & below, mb = ((((uint64_t)LV(wmhi)) << 32) | (uint64_t)LV(wmlo)) & below;
+								if (LV(gf) & 1u) {
+									if (ma) da = 63u - (uint32_t)__builtin_clzll(ma);
+									if (mb) db = 63u - (uint32_t)__builtin_clzll(mb);
+								} else if (mb) LV(bad) = 1u;
+							}
+							LV(depA) = da; LV(depB) = db;
+						}
+					}
+					SAMP_T(15);
+					// (7) the batch is good up to the first rejection / conversion, and up to and including the first draw that uses its range up
 					const uint64_t badm = Plat::ballot(bad), exm = Plat::ballot(exh);
 					uint32_t L = B;
 					if (badm) { const uint32_t fbad = (uint32_t)__builtin_ctzll(badm); if (fbad < L) L = fbad; }
 					bool used_up = false;
 					if (exm) { const uint32_t fex = (uint32_t)__builtin_ctzll(exm); if (fex + 1u <= L) { L = fex + 1u; used_up = true; } }
 					if (L < B && !used_up) serial_next = true;      // the draw after the batch needs the serial path
+#ifdef BT2G_SAMP_STATS
+					{ static unsigned long st_[6] = {0,0,0,0,0,0}, nb_ = 0; nb_++;
+					  if (L == B) st_[0]++; else if (used_up) st_[1]++; else {
+					    const uint32_t fb_ = (uint32_t)__builtin_ctzll(badm);
+					    const uint32_t fl_ = Plat::lane(gf, fb_), c_ = Plat::lane(curr, fb_), n_ = Plat::lane(gn, fb_);
+					    if (c_ >= n_) st_[5]++; else if (!(fl_ & 1u) && Plat::lane(fb, fb_)) st_[2]++; else if (!(fl_ & 1u) && Plat::lane(gs, fb_) + Plat::lane(occ, fb_) + 1u >= Plat::lane(gt, fb_) && c_ + 1u < n_) st_[3]++; else st_[4]++; }
+					  if ((nb_ & (nb_ - 1)) == 0 || getenv("BT2G_SAMP_STATS_ALL")) fprintf(stderr, "SAMPSTAT batches %lu full %lu used_up %lu rejected %lu convert %lu seen_twice %lu past_end %lu  (B %u L %u live %d)\n", nb_, st_[0], st_[1], st_[2], st_[3], st_[4], st_[5], B, L, __builtin_popcountll(live)); }
+#endif
 					if (L > 0u) {
 						// (8) commit draws 0 .. L-1
 						if (ocnt > 0u) { Plat::flush_samp_rows(srows + obase, olo, ohi, osrc, ocnt); obase += ocnt; ocnt = 0u; }
 						const uint64_t cm = L >= 64u ? ~0ull : ((1ull << L) - 1ull);
-						typename Plat::LaneReg app, akey, aval, setf, wlo, whi, wsrc;
+						// what each swap-list draw finds at its position cur: the table's (or the identity's) word, or what an earlier draw of the batch put there --
+						// which is what THAT draw found at its own cur: chains resolve front to back, one link per round
+						typename Plat::LaneReg av, rsv;
+						BT2_FOR_LANES(l) {
+							const uint32_t fl = LV(gf), c = LV(curr);
+							LV(av) = LV(fa) ? LV(va) : ((fl & 2u) ? c + LV(ca) : c);
+							LV(rsv) = (l >= L || LV(depA) == 0xffffffffu) ? 1u : 0u;
+						}
+						for (;;) {
+							typename Plat::LaneReg unres;
+							BT2_FOR_LANES(l) { LV(unres) = LV(rsv) ? 0u : 1u; }
+							if (!Plat::ballot(unres)) break;
+							typename Plat::LaneReg dix;
+							BT2_FOR_LANES(l) { LV(dix) = LV(depA) & 63u; }
+							const typename Plat::LaneReg g_r = Plat::gather(rsv, dix), g_a = Plat::gather(av, dix);
+							BT2_FOR_LANES(l) { if (!LV(rsv) && LV(g_r)) { LV(av) = LV(g_a); LV(rsv) = 1u; } }
+						}
+						typename Plat::LaneReg app, akey, aval, setf, wlo, whi, wsrc, dixb;
+						BT2_FOR_LANES(l) { LV(dixb) = LV(depB) & 63u; }
+						const typename Plat::LaneReg g_b = Plat::gather(av, dixb);
 						const typename Plat::LaneReg gtl = Plat::gather(tlo, pick), gth = Plat::gather(thi, pick);
 						BT2_FOR_LANES(l) {
 							const uint32_t fl = LV(gf), c = LV(curr), pos = LV(posr);
-							uint32_t ret = 0, ap = 0, sf = 0, av = 0;
+							uint32_t ret = 0, ap = 0, sf = 0, avv = 0;
 							if (l < L) {
 								if (fl & 1u) {
-									const uint32_t a = LV(fa) ? LV(va) : ((fl & 2u) ? c + LV(ca) : c);
+									const uint32_t a = LV(av);
 									if (pos == c) ret = a;
-									else { ret = LV(fb) ? LV(vb) : ((fl & 2u) ? pos + LV(cb) : pos); av = a; if (LV(fb)) sf = 1u; else ap = 1u; }
-								} else { ret = pos; ap = 1u; av = 0u; }
+									else {
+										ret = LV(depB) != 0xffffffffu ? LV(g_b) : (LV(fb) ? LV(vb) : ((fl & 2u) ? pos + LV(cb) : pos));
+										avv = a;
+										// of several writes of the batch to this position the last committed one is the entry
+										const uint64_t later = (((((uint64_t)LV(wmhi)) << 32) | (uint64_t)LV(wmlo)) & cm) >> l >> 1;
+										if (!later) { if (LV(fb)) sf = 1u; else ap = 1u; }
+									}
+								} else { ret = pos; ap = 1u; avv = 0u; }
 							}
 							const uint64_t topf = (((uint64_t)LV(gth) << 32) | (uint64_t)LV(gtl)) + (uint64_t)ret;
 							LV(wlo) = (uint32_t)topf; LV(whi) = (uint32_t)(topf >> 32); LV(wsrc) = LV(pick) + sai;
-							LV(app) = ap; LV(akey) = LV(keyB); LV(aval) = av; LV(setf) = sf;
+							LV(app) = ap; LV(akey) = LV(keyB); LV(aval) = avv; LV(setf) = sf;
 						}
 						for (uint64_t sm = Plat::ballot(setf); sm != 0ull; sm &= sm - 1ull) {      // position rr already has an entry: it takes the value of position cur
 							const uint32_t ls = (uint32_t)__builtin_ctzll(sm);
 							Plat::tab_set_at(tab.v, Plat::lane(eb, ls), Plat::lane(aval, ls));
 						}
-						Plat::tab_append_lanes(tab.k, tab.v, tab.n, app, akey, aval);
+						{
+							// new entries: register table, and T (key -> entry index)
+							const uint64_t am = Plat::ballot(app);
+							typename Plat::LaneReg aidx;
+							BT2_FOR_LANES(l) { LV(aidx) = tab.n + (uint32_t)__builtin_popcountll(am & ((1ull << l) - 1ull)); }
+							if (sh_live) Plat::sh_put(shN, akey, aidx, app);
+							Plat::tab_append_lanes(tab.k, tab.v, tab.n, app, akey, aval);
+							{ typename Plat::LaneReg asn; BT2_FOR_LANES(l) { LV(asn) = (LV(app) && (LV(akey) >> 30) == 2u) ? 1u : 0u; }
+							  const uint32_t ns_ = (uint32_t)__builtin_popcountll(Plat::ballot(asn)); nS_ent += ns_; nW_ent += (uint32_t)__builtin_popcountll(am) - ns_; }
+						}
 						Plat::flush_samp_rows(srows + obase, wlo, whi, wsrc, L);
 						obase += L; n_satpos += L; nelt_added += (uint64_t)L;
 						// cursors (and seen counts) of the ranges
@@ -983,8 +1088,7 @@ struct Aligner {
 							LV(rcur) = LV(rcur) + cnt;
 							if (!(LV(rfl) & 1u)) LV(rseen) = LV(rseen) + cnt;
 						}
-						{ typename Plat::LaneReg sn; BT2_FOR_LANES(l) { LV(sn) = (l < L && !(LV(gf) & 1u)) ? 1u : 0u; }
-						  draws += (uint64_t)L + ((uint64_t)__builtin_popcountll(Plat::ballot(sn)) << 32); }
+						draws += (uint64_t)L;
 						g.last = Plat::lane(x4r, L - 1u); g.lastOff = 0u;
 						if (used_up) {
 							const uint32_t pe = Plat::lane(pick, L - 1u);
@@ -993,11 +1097,15 @@ struct Aligner {
 							Plat::prefix_live(mlo, mhi, live, plo, phi);
 						}
 						nbatch_prof += 0x10000u; draws_batched += L;      // profile: batches, draws committed by batches
+						SAMP_T(16);
 						continue;
 					}
 				}
 			}
 			serial_next = false;
+#ifdef BT2G_SAMP_PROF
+			struct SerT { uint64_t t0; BT2_HD ~SerT() { Plat::hot().t_phase[10] += Plat::clock() - t0; } } sert_{Plat::clock()};
+#endif
 			// RowSampler::next: first range still in play whose running sum exceeds rd, else the last one in play
 			const double rd = (double)(g.nextFloat() * mass);
 			const uint32_t pick = Plat::pick_prefix(plo, phi, live, rd);
@@ -1020,6 +1128,7 @@ struct Aligner {
 						else {
 							b = (fl & 2u) ? rr + Plat::tab_count_le(tab.k, tab.v, tab.n, kTabConv | rkey, rr) : rr;
 							Plat::tab_append(tab.k, tab.v, tab.n, kTabSwap | rkey | rr, a);
+							if (sh_live) { if (nW_ent < capW) { Plat::sh_put1(shN, kTabSwap | rkey | rr, tab.n - 1u); nW_ent++; } else { sh_live = false; n_mir = tab.n - 1u; } }
 						}
 					}
 					cur++;
@@ -1032,6 +1141,7 @@ struct Aligner {
 				ret = rnv;
 				uint32_t seen = Plat::lane(rseen, pick);
 				Plat::tab_append(tab.k, tab.v, tab.n, kTabSeen | rkey | rnv, 0u);
+				if (sh_live) { if (nS_ent < capS) { Plat::sh_put1(shN, kTabSeen | rkey | rnv, tab.n - 1u); nS_ent++; } else { sh_live = false; n_mir = tab.n - 1u; } }
 				seen++; cur++;
 				if (seen >= Plat::lane(rthr, pick) && cur < n) {
 					// convert to a swap list of everything not yet seen, ascending (random_util.h:133-158): the seen values stay in the
@@ -1060,6 +1170,19 @@ struct Aligner {
 			if (tab.n + 2u > 64u * (uint32_t)kSampTabRegs) { full = true; break; }      // (cannot happen: the caller checked maxelt against the table)
 		}
 		if (ocnt > 0) Plat::flush_samp_rows(srows + obase, olo, ohi, osrc, ocnt);
+#ifdef BT2G_SAMP_STATS
+		{ // per call: entries by kind, bytes a dense form of the small ranges' lists would take
+		  uint32_t nseen = 0, nsw_small = 0, nsw_conv = 0, nconv = 0, dense = 0;
+		  Plat::tab_for_each(tab.k, tab.v, tab.n, [&](uint32_t, uint32_t ke, uint32_t) {
+		    const uint32_t kind = ke >> 30, rg = (ke >> 24) & 63u;
+		    if (kind == 2) nseen++; else if (kind == 3) nconv++; else if (kind == 1) { if (Plat::lane(rfl, rg) & 2u) nsw_conv++; else nsw_small++; } });
+		  for (uint32_t i = 0; i < n_masses; i++) { const uint32_t sz = WK.satpos2[sai + i].size; if (sz < 128u) dense += sz; }
+		  static unsigned long calls_ = 0, h_[5][8]; calls_++;
+		  auto bk = [](uint32_t v) { return v == 0 ? 0 : v <= 16 ? 1 : v <= 32 ? 2 : v <= 64 ? 3 : v <= 128 ? 4 : v <= 256 ? 5 : v <= 512 ? 6 : 7; };
+		  h_[0][bk(nseen)]++; h_[1][bk(nsw_small)]++; h_[2][bk(nsw_conv)]++; h_[3][bk(dense)]++; h_[4][bk((uint32_t)draws)]++;
+		  if ((calls_ & (calls_ - 1)) == 0) { const char* nm[5] = {"seen", "swap_small", "swap_conv", "dense_bytes", "draws"};
+		    for (int a = 0; a < 5; a++) { fprintf(stderr, "SAMPHIST calls %lu %-12s 0:%lu <=16:%lu <=32:%lu <=64:%lu <=128:%lu <=256:%lu <=512:%lu more:%lu\n", calls_, nm[a], h_[a][0], h_[a][1], h_[a][2], h_[a][3], h_[a][4], h_[a][5], h_[a][6], h_[a][7]); } } }
+#endif
 		ST.rnd = g; HOT.mass = mass; HOT.n_satpos = n_satpos;
 		HOT.t_phase[21] += draws | ((uint64_t)draws_batched << 32);      // profile: draws | draws committed by batches << 32
 		HOT.n_dp_pass += nbatch_prof;                                      // (high half: batches)

@@ -730,14 +730,15 @@ struct DevPlat {
 	static __device__ __forceinline__ const uint32_t& lv(const uint32_t& r, uint32_t) { return r; }
 	static __device__ __forceinline__ uint64_t ballot(uint32_t r) { return (uint64_t)__ballot(r != 0u); }
 	static __device__ __forceinline__ uint32_t gather(uint32_t x, uint32_t idx) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)x); }
-	template <typename V, typename F> static __device__ __forceinline__ void tab_for_each(const V& k, const V& v, uint32_t n_, F f) {
+	template <typename V, typename F> static __device__ __forceinline__ void tab_for_each(const V& k, const V& v, uint32_t n_, F f, uint32_t from_ = 0u) {
 		constexpr int K = sizeof(V) / 4;
-		const uint32_t n = uni(n_);
+		const uint32_t n = uni(n_), from = uni(from_);
 #pragma unroll
 		for (int r = 0; r < K; r++) {
 			if ((uint32_t)r * 64u >= n) break;
+			if ((uint32_t)r * 64u + 64u <= from) continue;
 			const uint32_t cnt = n - (uint32_t)r * 64u < 64u ? n - (uint32_t)r * 64u : 64u;
-			for (uint32_t i = 0; i < cnt; i++)
+			for (uint32_t i = from > (uint32_t)r * 64u ? from - (uint32_t)r * 64u : 0u; i < cnt; i++)
 				f((uint32_t)r * 64u + i, (uint32_t)__builtin_amdgcn_readlane((int)k[r], (int)i), (uint32_t)__builtin_amdgcn_readlane((int)v[r], (int)i));
 		}
 	}
@@ -768,6 +769,110 @@ struct DevPlat {
 #pragma unroll
 		for (int r = 0; r < K; r++) if (take && (slot >> 6) == (uint32_t)r) { k[r] = sk; v[r] = sv; }
 		n_ = n + cnt;
+	}
+	// ---- the row sampler's hash tables in the launch's dynamic LDS (which holds per-window DP state otherwise: free while rows are being sampled) ----
+	//   S:  the keys of the seen-list entries (a set: 4 bytes per slot)
+	//   W:  swap-list entries, key -> index of the entry in the register table (8 bytes per slot)
+	//   Bt: key -> the lanes of the batch in hand that write it (12 bytes per slot; cleared per batch)
+	// Open addressing, linear probing, key 0 = empty; Bt at rf_at, W behind it, S behind that with whatever the launch has left.  sh_begin clears S and W
+	// and says how many slots they have (nS | nW << 16; 0: the launch has no room -- no batching).
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	static constexpr uint32_t kShBatchSlots = 96u;
+	static __device__ __forceinline__ lds_u32* lds_w(uint32_t a) { return (lds_u32*)(uintptr_t)a; }
+	static __device__ __forceinline__ uint32_t sh_slot0(uint32_t key, uint32_t nslots) { return (((key * 2654435761u) >> 16) * nslots) >> 16; }
+	static __device__ __forceinline__ void lds_zero(uint32_t at, uint32_t nwords) {
+		wave_fence();
+		for (uint32_t i = threadIdx.x & 63; i < nwords; i += 64) *lds_w(at + i * 4u) = 0u;
+		wave_fence();
+	}
+	static __device__ __forceinline__ uint32_t sh_begin() {
+		const uint32_t have = uni(g_st.dyn_bytes);
+		if (have < kShBatchSlots * 12u + 1024u) return 0u;
+		const uint32_t room = have - kShBatchSlots * 12u;
+		// 8-byte slots for W, 4-byte slots for S: about 3 : 2 of the room (more than half of a typical read's draws are swap-list draws)
+		uint32_t nW = (room * 3u / 5u) / 8u, nS = (room - nW * 8u) / 4u;
+		if (nW > 1024u) nW = 1024u;
+		if (nS > 4096u) nS = 4096u;
+		lds_zero(uni(g_st.rf_at) + kShBatchSlots * 12u, nW * 2u + nS);
+		return nS | (nW << 16);
+	}
+	static __device__ __forceinline__ void bh_clear(uint32_t) { lds_zero(uni(g_st.rf_at), kShBatchSlots * 3u); }
+	// flagged lanes: the entry `key` (register-table index idx) enters S (seen-list keys, kind 2) or W (swap-list keys, kind 1); a key is put once
+	static __device__ __forceinline__ void sh_put(uint32_t cfg, uint32_t key, uint32_t idx, uint32_t flag) {
+		const uint32_t nS = cfg & 0xffffu, nW = cfg >> 16, w_at = uni(g_st.rf_at) + kShBatchSlots * 12u, s_at = w_at + nW * 8u;
+		if (flag) {
+			const bool seen = (key >> 30) == 2u;
+			const uint32_t n = seen ? nS : nW, at = seen ? s_at : w_at, stride = seen ? 4u : 8u;
+			uint32_t s = sh_slot0(key, n);
+			for (uint32_t pr = 0; pr < n; pr++) {
+				lds_u32* p = lds_w(at + s * stride);
+				uint32_t expected = 0u;
+				const bool ok = __hip_atomic_compare_exchange_strong(p, &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (ok || expected == key) { if (!seen) p[1] = idx; break; }
+				s = s + 1u == n ? 0u : s + 1u;
+			}
+		}
+		wave_fence();
+	}
+	static __device__ __forceinline__ void sh_put1(uint32_t cfg, uint32_t key, uint32_t idx) { sh_put(cfg, uni(key), uni(idx), (threadIdx.x & 63) == 0 ? 1u : 0u); }
+	// flagged lanes: found = key is in its table; idx = the entry's index in the register table (swap-list keys)
+	static __device__ __forceinline__ void sh_get(uint32_t cfg, uint32_t key, uint32_t flag, uint32_t& found, uint32_t& idx) {
+		const uint32_t nS = cfg & 0xffffu, nW = cfg >> 16, w_at = uni(g_st.rf_at) + kShBatchSlots * 12u, s_at = w_at + nW * 8u;
+		found = 0u; idx = 0u;
+		if (flag) {
+			const bool seen = (key >> 30) == 2u;
+			const uint32_t n = seen ? nS : nW, at = seen ? s_at : w_at, stride = seen ? 4u : 8u;
+			uint32_t s = sh_slot0(key, n);
+			for (uint32_t pr = 0; pr < n; pr++) {
+				lds_u32* p = lds_w(at + s * stride);
+				const uint32_t k2 = p[0];
+				if (k2 == key) { found = 1u; if (!seen) idx = p[1]; break; }
+				if (k2 == 0u) break;
+				s = s + 1u == n ? 0u : s + 1u;
+			}
+		}
+	}
+	// flagged lanes: this lane joins the set of lanes that write `key` in the batch in hand
+	static __device__ __forceinline__ void bh_mark(uint32_t, uint32_t key, uint32_t flag) {
+		const uint32_t at = uni(g_st.rf_at), l = threadIdx.x & 63;
+		if (flag) {
+			uint32_t s = sh_slot0(key, kShBatchSlots);
+			for (uint32_t pr = 0; pr < kShBatchSlots; pr++) {
+				lds_u32* p = lds_w(at + s * 12u);
+				uint32_t expected = 0u;
+				const bool ok = __hip_atomic_compare_exchange_strong(p, &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (ok || expected == key) { __hip_atomic_fetch_or(p + 1u + (l >> 5), 1u << (l & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+				s = s + 1u == kShBatchSlots ? 0u : s + 1u;
+			}
+		}
+		wave_fence();
+	}
+	// flagged lanes: the lanes that write `key` in this batch (bit per lane)
+	static __device__ __forceinline__ void bh_get(uint32_t, uint32_t key, uint32_t flag, uint32_t& lo, uint32_t& hi) {
+		const uint32_t at = uni(g_st.rf_at);
+		lo = hi = 0u;
+		if (flag) {
+			uint32_t s = sh_slot0(key, kShBatchSlots);
+			for (uint32_t pr = 0; pr < kShBatchSlots; pr++) {
+				lds_u32* p = lds_w(at + s * 12u);
+				const uint32_t k2 = p[0];
+				if (k2 == key) { lo = p[1]; hi = p[2]; break; }
+				if (k2 == 0u) break;
+				s = s + 1u == kShBatchSlots ? 0u : s + 1u;
+			}
+		}
+	}
+	// per lane: the value word of table entry idx (idx < 64 K)
+	template <typename V> static __device__ __forceinline__ uint32_t tab_gather(const V& v, uint32_t idx) {
+		constexpr int K = sizeof(V) / 4;
+		uint32_t r = 0;
+#pragma unroll
+		for (int q = 0; q < K; q++) {
+			if (__ballot((idx >> 6) == (uint32_t)q) == 0ull) continue;
+			const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)v[q]);
+			if ((idx >> 6) == (uint32_t)q) r = g;
+		}
+		return r;
 	}
 	// rows drawn by the sampler -> Work::srows, one 16-byte record per lane
 	static __device__ __forceinline__ void flush_samp_rows(BT2_G SampRow* dst, uint32_t lo, uint32_t hi, uint32_t src, uint32_t cnt) {
@@ -1522,7 +1627,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes) {
+              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes, uint32_t dyn_extra) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	BT2_G Work& w = *(BT2_G Work*)base;
@@ -1532,6 +1637,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
 	g_st.rt_at = g_st.rf_at + hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.rt_cur = 0;
+	g_st.dyn_bytes = hot_tail_bytes(max_cols, P.match_bonus > 0) + rt_bytes + dyn_extra;
 	wave_fence();
 	for (;;) {
 		unsigned int r = 0;
@@ -1575,7 +1681,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT2G_WA
 k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams* __restrict__ rparams,
               uint8_t* __restrict__ results, uint64_t result_stride, uint8_t* __restrict__ arena, uint64_t arena_stride,
               uint64_t mat_bytes, uint64_t mask_bytes, uint64_t pmask_bytes, unsigned int* __restrict__ next_read, unsigned long long* __restrict__ prof,
-              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes) {
+              PreComp pre, uint32_t max_read_len, uint32_t max_cols, uint32_t rt_bytes, uint32_t dyn_extra) {
 	const int lane = threadIdx.x & 63;
 	uint8_t* base = arena + (uint64_t)blockIdx.x * arena_stride;
 	BT2_G Work& w = *(BT2_G Work*)base;
@@ -1585,6 +1691,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
 	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;      // (two matrices in flight: their marks stay in the arena)
+	g_st.dyn_bytes = hot_tail_bytes(max_cols, P.match_bonus > 0) + dyn_extra;
 	(void)rt_bytes;
 	wave_fence();
 	const unsigned int n_pairs = rd.n_reads / 2;
@@ -1635,13 +1742,21 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 	hipError_t e = hipMemsetAsync(d_next, 0, sizeof(unsigned int), st);
 	if (e != hipSuccess) return e;
 	const uint32_t tail = hot_tail_bytes(max_cols, P.match_bonus > 0);      // dynamic LDS: the per-column tail of the hot state
-	if (P.paired)
-		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), tail, st, ix, P, rd, d_rparams, d_results, result_stride,
-		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, 0u);
-	else {
-		// What is left of the wave's share of LDS (lds_per_wave: what keeps this class's waves per CU resident) goes to the on-chip backtrace
-		// state of end-to-end batches: the reportedThrough plane of a band matrix of the longest read at the narrowest band (16 bytes per row --
-		// a wider band's marks stay in the arena, DevPlat::rt_begin decides per matrix).
+	// What is left of the wave's share of LDS (lds_per_wave: what keeps this class's waves per CU resident; 512 bytes are left alone) is launched as
+	// dynamic LDS as well: the row sampler's hash tables live there between DP windows and hold the more entries the more there is (DevPlat::sh_begin).
+	auto spare = [&](const void* kfn, uint32_t dyn_used) -> uint32_t {
+		hipFuncAttributes fa2{};
+		if (lds_per_wave == 0 || hipFuncGetAttributes(&fa2, kfn) != hipSuccess) return 0u;
+		const uint64_t used = (uint64_t)fa2.sharedSizeBytes + dyn_used + 512u;
+		return used < lds_per_wave ? (uint32_t)((lds_per_wave - used) & ~15ull) : 0u;
+	};
+	if (P.paired) {
+		const uint32_t extra = spare(reinterpret_cast<const void*>(&k_align_pairs<TOff>), tail);
+		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), tail + extra, st, ix, P, rd, d_rparams, d_results, result_stride,
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, 0u, extra);
+	} else {
+		// ... and to the on-chip backtrace state of end-to-end batches: the reportedThrough plane of a band matrix of the longest read at the
+		// narrowest band (16 bytes per row -- a wider band's marks stay in the arena, DevPlat::rt_begin decides per matrix).
 		uint32_t rt_bytes = 0;
 		hipFuncAttributes fa{};
 		static const bool rt_off = getenv("BT2G_RT_LDS") && atoi(getenv("BT2G_RT_LDS")) == 0;          // measurement knob: marks in the arena, as before round 5
@@ -1650,15 +1765,16 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 			const uint32_t want = ((max_read_len ? max_read_len : 1u) * 16u + 15u) & ~15u;
 			if (used + want <= lds_per_wave) rt_bytes = want;
 		}
+		const uint32_t extra = spare(reinterpret_cast<const void*>(&k_align_reads<TOff>), tail + rt_bytes);
 		static const bool dbg_occ = getenv("BT2G_DEBUG_OCC") != nullptr;
 		if (dbg_occ) {
 			int nb = 0;
-			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_align_reads<TOff>), 64, tail + rt_bytes);
-			fprintf(stderr, "[bt2g] k_align_reads: %d waves per CU resident (LDS %u static + %u tail + %u marks; budget %u per wave), %u waves launched\n",
-			        nb, (unsigned)fa.sharedSizeBytes, tail, rt_bytes, lds_per_wave, n_waves);
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_align_reads<TOff>), 64, tail + rt_bytes + extra);
+			fprintf(stderr, "[bt2g] k_align_reads: %d waves per CU resident (LDS %u static + %u tail + %u marks + %u spare; budget %u per wave), %u waves launched\n",
+			        nb, (unsigned)fa.sharedSizeBytes, tail, rt_bytes, extra, lds_per_wave, n_waves);
 		}
-		hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), tail + rt_bytes, st, ix, P, rd, d_rparams, d_results, result_stride,
-		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, rt_bytes);
+		hipLaunchKernelGGL(k_align_reads<TOff>, dim3(n_waves), dim3(64), tail + rt_bytes + extra, st, ix, P, rd, d_rparams, d_results, result_stride,
+		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, rt_bytes, extra);
 	}
 	return hipGetLastError();
 }
@@ -1673,7 +1789,7 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 	const uint32_t lane = threadIdx.x & 63;
 	g_P = P;
 	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
-	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;
+	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0; g_st.dyn_bytes = 0;
 	DpScratch dp;
 	carve_scratch(dp, scratch + (uint64_t)blockIdx.x * scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
 	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch; g_st.emit_on = 0;      // (the fills do not touch the work area)

@@ -182,12 +182,74 @@ struct HostPlat {
 	static const uint32_t& lv(const LaneReg& r, uint32_t l) { return r.v[l]; }
 	static uint64_t ballot(const LaneReg& r) { uint64_t m = 0; for (uint32_t l = 0; l < 64; l++) if (r.v[l]) m |= 1ull << l; return m; }
 	static LaneReg gather(const LaneReg& x, const LaneReg& idx) { LaneReg r; for (uint32_t l = 0; l < 64; l++) r.v[l] = x.v[idx.v[l] & 63u]; return r; }
-	template <typename T, typename F> static void tab_for_each(const T& k, const T& v, uint32_t n, F f) { for (uint32_t e = 0; e < n; e++) f(e, k[e >> 6].v[e & 63], v[e >> 6].v[e & 63]); }
+	template <typename T, typename F> static void tab_for_each(const T& k, const T& v, uint32_t n, F f, uint32_t from = 0) { for (uint32_t e = from; e < n; e++) f(e, k[e >> 6].v[e & 63], v[e >> 6].v[e & 63]); }
 	template <typename T> static void tab_set_at(T& v, uint32_t e, uint32_t val) { v[e >> 6].v[e & 63] = val; }
 	// the flagged lanes' (key, value) pairs become the next entries of the table, in lane order
 	template <typename T> static void tab_append_lanes(T& k, T& v, uint32_t& n, const LaneReg& flag, const LaneReg& key, const LaneReg& val) {
 		for (uint32_t l = 0; l < 64; l++) if (flag.v[l]) { k[n >> 6].v[n & 63] = key.v[l]; v[n >> 6].v[n & 63] = val.v[l]; n++; }
 	}
+	// the sampler's hash tables (dynamic LDS on the device): the same open addressing with the same hash on host arrays.  BT2G_HOST_SH_BYTES = the dynamic
+	// LDS a launch would have (default: the short-read class's headline launch)
+	static constexpr uint32_t kShBatchSlots = 96u;
+	struct WSlot { uint32_t k, v; };
+	struct BhSlot { uint32_t k; uint64_t m; };
+	static uint32_t* sh_S() { static uint32_t t[4096]; return t; }
+	static WSlot* sh_W() { static WSlot t[1024]; return t; }
+	static BhSlot* sh_B() { static BhSlot t[kShBatchSlots]; return t; }
+	static uint32_t sh_slot0(uint32_t key, uint32_t nslots) { return (((key * 2654435761u) >> 16) * nslots) >> 16; }
+	static uint32_t sh_begin() {
+		static const uint32_t have = getenv("BT2G_HOST_SH_BYTES") ? (uint32_t)atoi(getenv("BT2G_HOST_SH_BYTES")) : 4528u;
+		if (have < kShBatchSlots * 12u + 1024u) return 0u;
+		const uint32_t room = have - kShBatchSlots * 12u;
+		uint32_t nW = (room * 3u / 5u) / 8u, nS = (room - nW * 8u) / 4u;
+		if (nW > 1024u) nW = 1024u;
+		if (nS > 4096u) nS = 4096u;
+		memset(sh_S(), 0, nS * 4u); memset(sh_W(), 0, sizeof(WSlot) * nW);
+		return nS | (nW << 16);
+	}
+	static void bh_clear(uint32_t) { for (uint32_t i = 0; i < kShBatchSlots; i++) { sh_B()[i].k = 0; sh_B()[i].m = 0; } }
+	static BhSlot* bh_find(uint32_t key, bool claim) {
+		uint32_t s = sh_slot0(key, kShBatchSlots);
+		for (uint32_t pr = 0; pr < kShBatchSlots; pr++) {
+			if (sh_B()[s].k == key) return &sh_B()[s];
+			if (sh_B()[s].k == 0u) { if (!claim) return nullptr; sh_B()[s].k = key; return &sh_B()[s]; }
+			s = s + 1u == kShBatchSlots ? 0u : s + 1u;
+		}
+		return nullptr;
+	}
+	static void sh_put1(uint32_t cfg, uint32_t key, uint32_t idx) {
+		const uint32_t nS = cfg & 0xffffu, nW = cfg >> 16;
+		if ((key >> 30) == 2u) {
+			uint32_t s = sh_slot0(key, nS);
+			for (uint32_t pr = 0; pr < nS; pr++) { if (sh_S()[s] == key) return; if (sh_S()[s] == 0u) { sh_S()[s] = key; return; } s = s + 1u == nS ? 0u : s + 1u; }
+		} else {
+			uint32_t s = sh_slot0(key, nW);
+			for (uint32_t pr = 0; pr < nW; pr++) { if (sh_W()[s].k == key || sh_W()[s].k == 0u) { sh_W()[s].k = key; sh_W()[s].v = idx; return; } s = s + 1u == nW ? 0u : s + 1u; }
+		}
+	}
+	static void sh_put(uint32_t cfg, const LaneReg& key, const LaneReg& idx, const LaneReg& flag) { for (uint32_t l = 0; l < 64; l++) if (flag.v[l]) sh_put1(cfg, key.v[l], idx.v[l]); }
+	static void sh_get(uint32_t cfg, const LaneReg& key, const LaneReg& flag, LaneReg& found, LaneReg& idx) {
+		const uint32_t nS = cfg & 0xffffu, nW = cfg >> 16;
+		for (uint32_t l = 0; l < 64; l++) {
+			found.v[l] = idx.v[l] = 0;
+			if (!flag.v[l]) continue;
+			const uint32_t k = key.v[l];
+			if ((k >> 30) == 2u) {
+				uint32_t s = sh_slot0(k, nS);
+				for (uint32_t pr = 0; pr < nS; pr++) { if (sh_S()[s] == k) { found.v[l] = 1; break; } if (sh_S()[s] == 0u) break; s = s + 1u == nS ? 0u : s + 1u; }
+			} else {
+				uint32_t s = sh_slot0(k, nW);
+				for (uint32_t pr = 0; pr < nW; pr++) { if (sh_W()[s].k == k) { found.v[l] = 1; idx.v[l] = sh_W()[s].v; break; } if (sh_W()[s].k == 0u) break; s = s + 1u == nW ? 0u : s + 1u; }
+			}
+		}
+	}
+	static void bh_mark(uint32_t, const LaneReg& key, const LaneReg& flag) {
+		for (uint32_t l = 0; l < 64; l++) if (flag.v[l]) { BhSlot* p = bh_find(key.v[l], true); if (p) p->m |= 1ull << l; }
+	}
+	static void bh_get(uint32_t, const LaneReg& key, const LaneReg& flag, LaneReg& lo, LaneReg& hi) {
+		for (uint32_t l = 0; l < 64; l++) { lo.v[l] = hi.v[l] = 0; if (flag.v[l]) { BhSlot* p = bh_find(key.v[l], false); if (p) { lo.v[l] = (uint32_t)p->m; hi.v[l] = (uint32_t)(p->m >> 32); } } }
+	}
+	template <typename T> static LaneReg tab_gather(const T& v, const LaneReg& idx) { LaneReg r; for (uint32_t l = 0; l < 64; l++) r.v[l] = v[(idx.v[l] >> 6) & 7u].v[idx.v[l] & 63]; return r; }
 	static void flush_samp_rows(SampRow* dst, const LaneReg& lo, const LaneReg& hi, const LaneReg& src, uint32_t cnt) {
 		for (uint32_t l = 0; l < cnt; l++) { dst[l].topf = ((uint64_t)hi.v[l] << 32) | lo.v[l]; dst[l].src = src.v[l]; dst[l].done = 0; }
 	}
@@ -724,9 +786,10 @@ static int run(const HostIndex& hidx, const Options& opt, FILE* out, bool metric
 		}
 		fwrite(o.data(), 1, o.size(), out);
 		nbytes += o.size();
-		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u btsteps=%llu tiles=%llu cands=%llu\n", rd.name.str().c_str(),
+		if (metrics) fprintf(stderr, "MET\t%s\titers=%u dps=%u ugs=%u bwseed=%u bwext=%u red=%u bt=%u nalns=%u extl=%u extr=%u res=%u btsteps=%llu tiles=%llu cands=%llu draws=%llu batched=%llu batches=%u\n", rd.name.str().c_str(),
 		                     rr.n_ex_iters, rr.n_ex_dps, rr.n_ex_ugs, rr.n_bwops_seed, rr.n_bwops_ext, rr.n_redundants, rr.n_bt_attempts, rr.nalns, rr.n_ext_left, rr.n_ext_right, rr.n_resolve_steps,
-		                     (unsigned long long)g_hot.t_phase[11], (unsigned long long)g_hot.t_phase[12], (unsigned long long)g_hot.t_phase[13]);
+		                     (unsigned long long)g_hot.t_phase[11], (unsigned long long)g_hot.t_phase[12], (unsigned long long)g_hot.t_phase[13],
+		                     (unsigned long long)(g_hot.t_phase[21] & 0xffffffffull), (unsigned long long)(g_hot.t_phase[21] >> 32), (unsigned)(g_hot.n_dp_pass >> 16));
 	}
 	if (shard_idx && !hb.reads.empty()) fprintf(shard_idx, "B %llu %llu %llu\n", (unsigned long long)block_id, (unsigned long long)nbytes, (unsigned long long)hb.reads.size());
 	}
