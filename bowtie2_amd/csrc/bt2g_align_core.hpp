@@ -2046,6 +2046,121 @@ struct Aligner {
 		typename Plat::LaneReg domv;
 		Plat::lanes_zero(domv);
 		uint32_t SQ = rows >> 4; if (SQ == 0) SQ = 1;      // "dominated": within SQ rows and columns of a tried candidate (aligner_sw.cpp:754-755,936-960)
+		// ---- the candidates that die within a few cells, side by side (round 6; end-to-end 8-bit matrices) ----
+		// Once a window has an alignment, nearly every further candidate cell of its last row fails: its backtrace runs into a cell an earlier
+		// walk went through (23 of 24 attempts of the headline workload; 4 to 30 cells in, the gap barrier keeps the first ones on the diagonal).
+		// A walk draws nothing from the read's RNG and its path is a function of the predecessor bytes alone -- only WHERE IT STOPS depends on the
+		// marks the earlier walks left.  So:
+		//  (A) every lane follows the path of its own candidate through the predecessor bytes, eight cells per memory round trip (a tile in the
+		//      direction of travel per lane), up to the first cell that is marked ALREADY (the walk cannot get past it), the cell that ends the
+		//      walk (row 0 / no predecessor), or kBwSteps cells -- and keeps the path as two bit masks: moves that go up a row, moves that go
+		//      left a column;
+		//  (B) the candidates are then taken in their order: lane i looks at cell i of the candidate's path (its position: two popcounts) -- marks
+		//      left by the candidates before it in this very batch included.  First cell marked -> skipped, no draw (aligner_sw.cpp:794-795);
+		//      a marked cell further on -> a failed attempt: the cells before it are marked, and it is booked exactly as the step loop books it
+		//      (attempt, reseeding draws, cells + one per branch frame).  No marked cell on the path: not a quick failure -- this candidate,
+		//      and whatever follows, goes through the step loop below.
+		constexpr uint32_t kBwSteps = 32u;
+		bool bw_ok = MODE == 0 && HOT.cural > 0u && Plat::marks_batchable();      // (the first candidate of a window is the one that succeeds)
+		auto batch_walks = [&]() {
+			const uint32_t first = HOT.cural - cbase;
+			const uint32_t nv = HOT.n_cands - cbase < 64u ? HOT.n_cands - cbase : 64u;
+			typename Plat::LaneReg row, col, ctr, alive, upm, lfm, ncell, brm, elig;
+			const int64_t msc = Plat::uni(ST.minsc);
+			BT2_FOR_LANES(l) {
+				const uint32_t rc_ = LV(cw1);
+				const bool e = l >= first && l < nv && (int64_t)(int32_t)LV(cw0) >= msc && (rc_ >> 16) + 1u <= kRfWin;
+				LV(elig) = e ? 1u : 0u; LV(alive) = LV(elig);
+				LV(row) = rc_ & 0xffffu; LV(col) = rc_ >> 16; LV(ctr) = 0u; LV(upm) = LV(lfm) = 0u; LV(ncell) = 1u; LV(brm) = 0u;
+			}
+			// candidates from the first one that is not eligible on are the step loop's
+			uint32_t limit = nv;
+			{ typename Plat::LaneReg ne; BT2_FOR_LANES(l) { LV(ne) = (l >= first && l < nv && !LV(elig)) ? 1u : 0u; }
+			  const uint64_t m = Plat::ballot(ne); if (m) limit = (uint32_t)__builtin_ctzll(m); }
+			if (limit < first + 2u) { bw_ok = false; return; }
+			const typename Plat::LaneReg row0 = row, col0 = col;
+			// (A) the paths
+			for (uint32_t trip = 0; trip < kBwSteps; trip++) {      // (a trip advances every live lane by at least one cell)
+				if (!Plat::ballot(alive)) break;
+				typename Plat::LaneReg plo, phi, mk8, intile;
+				const typename Plat::LaneReg tdir = ctr;      // H: up the diagonal, E: left along the row, F: up the column
+				Plat::pred_tile8(dpl, band_lo, band_w, epoch, row, col, tdir, alive, plo, phi, mk8);
+				BT2_FOR_LANES(l) { LV(intile) = LV(alive); }
+#pragma unroll
+				for (uint32_t i = 0; i < 8u; i++) {
+					BT2_FOR_LANES(l) {
+						if (LV(intile)) {
+							uint32_t r = LV(row), c = LV(col);
+							const int ct = (int)LV(ctr), pb = (int)(((i < 4u ? LV(plo) : LV(phi)) >> (8u * (i & 3u))) & 0xffu);
+							if ((LV(mk8) >> i) & 1u) { LV(alive) = 0u; LV(intile) = 0u; }      // marked already: the walk stops here at the latest
+							else {
+								int cur = -1, branch = 0;
+								if (r > 0u) {
+									if (ct == 1) { const int mask = (pb >> 3) & 3; branch = (int)(mask == 3); if (mask != 0) cur = (mask == 2) ? 4 : 3; }
+									else if (ct == 2) { const int mask = (pb >> 5) & 3; branch = (int)(mask == 3); if (mask != 0) cur = (mask == 2) ? 2 : 1; }
+									else {
+										const int he = (pb >> 1) & 1, hf = (pb >> 2) & 1;
+										const int mask = (hf & (pb >> 5) & 1) | ((he & (pb >> 3) & 1) << 1) | ((hf & (pb >> 6) & 1) << 2) | ((he & (pb >> 4) & 1) << 3) | ((pb & 1) << 4);
+										if (mask != 0) {
+											const int sel = (mask & 16) ? 4 : (mask & 1) ? 0 : (mask & 4) ? 2 : (mask & 2) ? 1 : 3;
+											branch = (int)((mask & (mask - 1)) != 0);
+											cur = (int)((0x04231u >> (4 * sel)) & 7);
+										}
+									}
+								}
+								if (cur < 0) { LV(alive) = 0u; LV(intile) = 0u; }      // the walk ends in this cell (row 0, or no predecessor)
+								else {
+									const uint32_t n = LV(ncell) - 1u;      // this cell's number = the number of its move
+									uint32_t mv;      // 0 diagonal, 1 left, 2 up
+									if (cur == 0) { mv = 0u; r--; c--; LV(ctr) = 0u; }
+									else if (cur == 1 || cur == 2) { mv = 2u; r--; LV(ctr) = cur == 1 ? 0u : 2u; }
+									else { mv = 1u; c--; LV(ctr) = cur == 3 ? 0u : 1u; }
+									if (mv != 1u) LV(upm) = LV(upm) | (1u << n);
+									if (mv != 2u) LV(lfm) = LV(lfm) | (1u << n);
+									if (branch) LV(brm) = LV(brm) | (1u << n);
+									LV(row) = r; LV(col) = c; LV(ncell) = n + 2u;
+									if (n + 1u == kBwSteps) { LV(alive) = 0u; LV(intile) = 0u; }
+									else if (mv != LV(tdir)) LV(intile) = 0u;      // the path leaves the tile's line
+								}
+							}
+						}
+					}
+				}
+			}
+			// (B) the candidates in their order, over the marks
+			uint32_t last = Plat::uni(ST.rnd.last), lastOff = Plat::uni(ST.rnd.lastOff);
+			uint32_t natt = 0, nsteps = 0, k = first;
+			for (; k < limit; k++) {
+				const uint32_t r0 = Plat::lane(row0, k), c0 = Plat::lane(col0, k), nc = Plat::lane(ncell, k), um = Plat::lane(upm, k), lm = Plat::lane(lfm, k);
+				typename Plat::LaneReg cr, cc, cf;
+				BT2_FOR_LANES(l) {
+					const uint32_t below = l >= 32u ? 0xffffffffu : (1u << l) - 1u;
+					LV(cf) = l < nc ? 1u : 0u;
+					LV(cr) = r0 - (uint32_t)__builtin_popcount(um & below); LV(cc) = c0 - (uint32_t)__builtin_popcount(lm & below);
+				}
+				const uint64_t mk = Plat::ballot(Plat::marks_of_cells(dpl, band_lo, band_w, epoch, cr, cc, cf));
+				if (mk & 1ull) continue;      // reportedThrough already: no attempt, no draw
+				if (!mk) break;               // no marked cell on the path as far as it was followed: the step loop walks this candidate
+				const uint32_t t = (uint32_t)__builtin_ctzll(mk);
+				BT2_FOR_LANES(l) { LV(cf) = l < t ? 1u : 0u; }
+				Plat::mark_cells(dpl, band_lo, band_w, epoch, cr, cc, cf);
+				// a failed attempt: reseeding draws as the step loop makes them (8-bit kernels: init(reseed) ... init(reseed + 1)); cells visited,
+				// the marked one included, + one more loop iteration per branch frame
+				{ Rng g2; g2.last = last; g2.lastOff = lastOff; const uint32_t reseed = g2.nextU32() + 1u; g2.init(reseed + 1u); last = g2.last; lastOff = g2.lastOff; }
+#ifdef BT2G_SAMP_STATS
+				{ static unsigned long h_[34], n_ = 0; h_[t < 33u ? t : 33u]++; n_++;
+				  if ((n_ & (n_ - 1)) == 0) { fprintf(stderr, "WALKSTAT batch-resolved %lu: death index", n_); for (int q = 0; q < 34; q++) fprintf(stderr, " %d:%lu", q, h_[q]); fprintf(stderr, "\n"); } }
+#endif
+				natt++;
+				nsteps += t + 1u + (uint32_t)__builtin_popcountll((uint64_t)Plat::lane(brm, k) & ((1ull << t) - 1ull));
+			}
+			if (k > first) {
+				ST.rnd.last = last; ST.rnd.lastOff = lastOff;
+				HOT.n_bt_attempts += natt; prof.steps += nsteps;
+				HOT.cural = cbase + k;
+			}
+			if (k < limit || natt == 0u) bw_ok = false;      // what stopped the batch goes through the step loop first
+		};
 		while (HOT.cural < HOT.n_cands) {
 			BtCand c;
 			{
@@ -2059,6 +2174,10 @@ struct Aligner {
 							Plat::dom_update(domv, cw1, v_, SQ);
 						}
 					}
+				}
+				if (MODE == 0 && bw_ok) {
+					batch_walks();
+					if (HOT.cural != ci) continue;
 				}
 				if (MODE == 2) {
 					// the next candidate that is not dominated -- unless one below the minimum score comes first (the list is sorted by score:
@@ -2095,6 +2214,9 @@ struct Aligner {
 				if (need_c0 != rf_c0_) { rf_c0_ = need_c0; for (uint32_t k = 0; k < kRfRegs; k++) rfw[k] = Plat::lanes_load(Plat::rf(), ST.max_cols + 8u, k * 64 + (need_c0 >> 2)); }
 				const uint64_t tw_ = now();
 				ret = walk(c.row, c.col, tile, tile_hi);
+#ifdef BT2G_SAMP_STATS
+				if (MODE == 0) { static unsigned long sw_[3] = {0, 0, 0}, n_ = 0; sw_[ret ? 0 : 1]++; n_++; if ((n_ & (n_ - 1)) == 0) fprintf(stderr, "WALKSTAT step-loop walks %lu: succeeded %lu failed %lu\n", n_, sw_[0], sw_[1]); }
+#endif
 				if (PRM.profile) { const uint64_t dt_ = now() - tw_; HOT.t_bt[0] += dt_; if (ret) { HOT.t_bt[1] += dt_; HOT.t_bt[2]++; } }
 			}
 			ST.rnd.init(sse16 ? reseed : reseed + 1);
@@ -2106,6 +2228,7 @@ struct Aligner {
 			(void)cscore;
 			if (ret) { found = true; break; }
 			HOT.cural++;
+			if (MODE == 0) bw_ok = Plat::marks_batchable();
 		}
 		if (!found) return false;
 		if (!fw) invert_edits(res);

@@ -407,6 +407,41 @@ struct HostPlat {
 	}
 	static void rt_begin(const DpScratch&, uint32_t, bool) {}
 	static void rt_mark(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t row, uint32_t col) { dp.pmask[pred_at(band_lo, band_w, row, col)] = 1u | (epoch << kEpochShift); }
+	// ---- the candidates that die within a few cells, side by side (Aligner::next_alignment_m): per-lane predecessor bytes, one-cell mark operations ----
+	static bool marks_batchable() { static const bool off = getenv("BT2G_HOST_NO_WALK_BATCH") != nullptr; return !off; }
+	static bool cell_ok(int32_t band_lo, uint32_t band_w, uint32_t r, uint32_t c) {
+		return (int32_t)r >= 0 && (int32_t)c >= 0 && (band_w == 0u || (uint32_t)((int32_t)c - (int32_t)r + band_lo) < band_w);
+	}
+	static bool mark_of(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t r, uint32_t c) {
+		if (!cell_ok(band_lo, band_w, r, c)) return false;
+		const uint32_t w = dp.pmask[pred_at(band_lo, band_w, r, c)];
+		return (w >> kEpochShift) == epoch && (w & 1u);
+	}
+	// per lane: the predecessor bytes (plo: cells 0-3, phi: cells 4-7) and reportedThrough bits (mk, bit i) of the eight cells from the lane's own cell on in
+	// its own direction (0 up the diagonal, 1 left along the row, 2 up the column); a cell outside the band reads as 0 / unmarked
+	static void pred_tile8(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, const LaneReg& row, const LaneReg& col, const LaneReg& dir, const LaneReg& flag,
+	                       LaneReg& plo, LaneReg& phi, LaneReg& mk) {
+		for (uint32_t l = 0; l < 64; l++) {
+			plo.v[l] = phi.v[l] = mk.v[l] = 0;
+			if (!flag.v[l]) continue;
+			for (uint32_t i = 0; i < 8; i++) {
+				const uint32_t r = row.v[l] - (dir.v[l] == 1u ? 0u : i), c = col.v[l] - (dir.v[l] == 2u ? 0u : i);
+				if (!cell_ok(band_lo, band_w, r, c)) continue;
+				const uint32_t p = reinterpret_cast<const uint8_t*>(dp.mat)[pred_at(band_lo, band_w, r, c)];
+				if (i < 4) plo.v[l] |= p << (8 * i); else phi.v[l] |= p << (8 * (i - 4));
+				if (mark_of(dp, band_lo, band_w, epoch, r, c)) mk.v[l] |= 1u << i;
+			}
+		}
+	}
+	// per lane: reportedThrough of the lane's own cell / set it
+	static LaneReg marks_of_cells(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, const LaneReg& row, const LaneReg& col, const LaneReg& flag) {
+		LaneReg r;
+		for (uint32_t l = 0; l < 64; l++) r.v[l] = (flag.v[l] && mark_of(dp, band_lo, band_w, epoch, row.v[l], col.v[l])) ? 1u : 0u;
+		return r;
+	}
+	static void mark_cells(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, const LaneReg& row, const LaneReg& col, const LaneReg& flag) {
+		for (uint32_t l = 0; l < 64; l++) if (flag.v[l] && cell_ok(band_lo, band_w, row.v[l], col.v[l])) dp.pmask[pred_at(band_lo, band_w, row.v[l], col.v[l])] = 1u | (epoch << kEpochShift);
+	}
 	static void bt_tile_pred(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t row, uint32_t col, uint32_t epoch, uint32_t dir, LaneReg& pr, LaneReg& mk) {
 		for (uint32_t d = 0; d < 64; d++) {
 			uint32_t p = 0, m = 0;
