@@ -279,6 +279,7 @@ struct HotWork {
 	uint32_t lists_used;
 	double   mass;
 	uint32_t n_masses;
+	uint32_t samp_sai, samp_lanes;      // first range of the row sampler in Work::satpos2; 1: at most 64 ranges (their fields fit one lane register, extend_seeds)
 	uint32_t n_ex_fw, n_ex_rc;
 	uint32_t n_diags;
 	uint32_t n_alns;

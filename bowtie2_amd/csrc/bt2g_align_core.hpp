@@ -1438,6 +1438,7 @@ struct Aligner {
 		HOT.n_masses = saf - sai;
 		// With at most 64 candidate ranges (always, for -N 0) the whole sampler runs out of registers (sample_rows_fast)
 		const bool fast = HOT.n_masses <= 64u && maxelt + 2u <= 64u * (uint64_t)kSampTabRegs && !big_range;
+		HOT.samp_sai = sai; HOT.samp_lanes = HOT.n_masses <= 64u ? 1u : 0u;
 		const uint64_t ts_ = now();
 		if (fast) {
 			nelt_added = Plat::uni(sample_rows_fast(sai, HOT.n_masses, maxelt, nelt, nelt_added));
@@ -2325,6 +2326,13 @@ struct Aligner {
 		const uint32_t rows = rdlen;
 		const uint32_t max_iters = (uint32_t)PRM.max_iters;
 		BT2_G AlnRes& res = WK.res;
+		// A sampled row (most entries of the extension list on repeats) is ONE row of a range: what the loop needs of it -- strand, seed offset and
+		// length, seed number -- are its range's fields, packed into one lane register (lane j = range samp_sai + j) when the sampler had at most 64
+		// ranges; its row and "taken" flag come in one 16-byte load.  (Expanding every such row into a SatPos with a Random1toN of one element in the
+		// arena, as rounds 1-5 did, cost six dependent memory round trips per row: 83 us per read of the headline workload.)
+		typename Plat::LaneReg rgpk;
+		Plat::lanes_zero(rgpk);
+		bool lane_rows = false;
 		while (true) {
 			if (ee_mode) {
 				if (first_ee) {
@@ -2341,24 +2349,48 @@ struct Aligner {
 					{ const uint64_t t0_ = now(); prioritize(seedmms, max_iters, nelt); HOT.t_phase[3] += now() - t0_; }
 					nelt_left = nelt;
 					first_extend = false;
+					lane_rows = !PRM.det_seeds && HOT.samp_lanes != 0u && HOT.n_satpos > HOT.n_satpos_full;
+					if (lane_rows) rgpk = Plat::range_fields(&WK.satpos2[HOT.samp_sai], HOT.n_masses);
 				}
 				if (nelt_left == 0) break;
 			}
 			const uint32_t maxi = HOT.n_satpos;
 			for (uint32_t i = 0; i < maxi; i++) {
-				if (satpos_taken(i)) continue;
-				BT2_G SatPos& sp = satpos_view(i);
+#ifdef BT2G_LOOP_PROF
+				uint64_t tl_ = Plat::clock();
+#define LOOP_T(slot) do { const uint64_t t__ = Plat::clock(); HOT.t_phase[slot] += t__ - tl_; tl_ = t__; } while (0)
+#else
+#define LOOP_T(slot) do {} while (0)
+#endif
+				// the entry: a whole range / an end-to-end hit with its Random1toN in the arena, or one sampled row
+				const bool srow = lane_rows && i >= HOT.n_satpos_full;
+				BT2_G SatPos* spp = nullptr;
+				uint64_t sp_topf; uint32_t sp_size, sp_rdoff, sp_seedlen, sp_offidx, sp_orig_sz; int32_t sp_ee; bool sp_fw;
+				bool srow_done = false;
+				if (srow) {
+					const SampRow sr = gld(&WK.srows[i - HOT.n_satpos_full]);
+					if (Plat::uni(sr.done) != 0u) continue;
+					const uint32_t pk = Plat::lane(rgpk, Plat::uni(sr.src) - HOT.samp_sai);
+					sp_topf = Plat::uni(sr.topf); sp_size = 1u; sp_orig_sz = 2u; sp_ee = -1;
+					sp_rdoff = pk & 0xfffu; sp_seedlen = (pk >> 12) & 0x3fu; sp_fw = ((pk >> 18) & 1u) != 0u; sp_offidx = pk >> 20;
+				} else {
+					if (satpos_taken(i)) continue;
+					spp = &satpos_view(i);
+					sp_topf = spp->topf; sp_size = spp->size; sp_orig_sz = spp->orig_sz; sp_ee = spp->ee;
+					sp_rdoff = spp->rdoff; sp_seedlen = spp->seedlen; sp_fw = spp->fw != 0; sp_offidx = spp->offidx;
+				}
+				LOOP_T(0);
 				EEHit eh_v; eh_v.score = 0;
-				if (ee_mode) eh_v = ee_hit(sp.ee);
+				if (ee_mode) eh_v = ee_hit(sp_ee);
 				const EEHit* eh = &eh_v;
 				if (ee_mode && eh->score < ST.minsc) return EXT_PERFECT_SCORE;
-				const bool is_small = PRM.det_seeds ? true : sp.size < nsm;
-				const bool fw = sp.fw != 0;
-				uint32_t rdoff = sp.rdoff;
-				const uint32_t seedhitlen = sp.seedlen;
+				const bool is_small = PRM.det_seeds ? true : sp_size < nsm;
+				const bool fw = sp_fw;
+				uint32_t rdoff = sp_rdoff;
+				const uint32_t seedhitlen = sp_seedlen;
 				if (!fw) rdoff = rdlen - rdoff - seedhitlen;
 				bool first = true;
-				while (!r1n_done(sp.rnd) && (first || is_small || ee_mode)) {
+				while (!(srow ? srow_done : r1n_done(spp->rnd)) && (first || is_small || ee_mode)) {
 					if (ST.minsc == perfect) {
 						if (!ee_mode || eh->score < perfect) return EXT_PERFECT_SCORE;
 					} else if (ee_mode && eh->score < ST.minsc) {
@@ -2369,15 +2401,24 @@ struct Aligner {
 					if (HOT.n_ex_iters >= max_iters) return EXT_HARD_LIMIT;
 					HOT.n_ex_iters++;
 					first = false;
-					const uint32_t elt = Plat::uni(r1n_next(sp.rnd));
+#ifdef BT2G_ITER_PROF
+					// diagnostic build: where the extension loop's own time goes -- draws that end as "seen this diagonal" / "not in a sequence" (slot 0, count x 100 in
+					// slot 16) against draws that go on to a DP problem (slot 15, the named phases included; all draws x 100 in slot 1)
+					struct IterT { uint64_t t0; bool skip; BT2_HD ~IterT() { const uint64_t d = Plat::clock() - t0; if (skip) { HOT.t_phase[0] += d; HOT.t_phase[16] += 100; } else HOT.t_phase[15] += d; HOT.t_phase[1] += 100; } } iter_t_{Plat::clock(), false};
+#define ITER_SKIP() (iter_t_.skip = true)
+#else
+#define ITER_SKIP() do {} while (0)
+#endif
+					uint32_t elt = 0;      // (a sampled row: Random1toN of one element -- no draw, random_util.h:90-94)
+					if (srow) srow_done = true; else elt = Plat::uni(r1n_next(spp->rnd));
 					// GroupWalk2S::advanceElement == Ebwt::getOffset(topf + elt)
 					uint32_t steps = 0;
 					const uint64_t tr_ = now();
 					TOff joff;
 					uint64_t jc = kJoffNone;
 					// a one-row hit of the pre-computed seed round was resolved by the batch kernel that extended it
-					if (!ee_mode && ST.ext_pre && seedmms == 0 && sp.orig_sz == 1 && ST.pre_joff_cur)
-						jc = ST.pre_joff_cur[((uint64_t)ST.ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + sp.offidx];
+					if (!ee_mode && ST.ext_pre && seedmms == 0 && sp_orig_sz == 1 && ST.pre_joff_cur)
+						jc = ST.pre_joff_cur[((uint64_t)ST.ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + sp_offidx];
 					if (jc == kJoffNone && !ee_mode && i >= HOT.n_satpos_full) {
 						// a sampled row: the walks to the SA sample of this row and the next 63 run side by side, one per lane
 						// (the extension loop takes the rows in list order, so the look-ahead is rarely wasted)
@@ -2390,17 +2431,21 @@ struct Aligner {
 						if (jc != kJoffNone) HOT.n_sides += (uint32_t)(jc >> 48);
 					}
 					if (jc != kJoffNone) { joff = (TOff)(jc & 0xffffffffffffull); steps = (uint32_t)(jc >> 48); }
-					else { joff = Plat::get_offset(IX.fw, (TOff)(sp.topf + elt), steps); HOT.n_sides += steps; }
+					else { joff = Plat::get_offset(IX.fw, (TOff)(sp_topf + elt), steps); HOT.n_sides += steps; }
 					HOT.t_phase[4] += now() - tr_;
 					HOT.n_bwops_ext += steps; HOT.n_resolve_steps += steps;
 					if (!ee_mode) nelt_left--;
 					TOff tidx = 0, toff = 0, tlen = 0;
 					bool straddled = false;
+#ifdef BT2G_LOOP_PROF
+					tl_ = Plat::clock();
+#endif
 					Plat::joined_to_text(IX, (TOff)seedhitlen, joff, tidx, toff, tlen, ee_mode, straddled);
 					tidx = (TOff)Plat::uni((uint64_t)tidx); toff = (TOff)Plat::uni((uint64_t)toff); tlen = (TOff)Plat::uni((uint64_t)tlen);      // (shuffle results are lane-varying to the compiler)
-					if (tidx == kOffMask) continue;
+					LOOP_T(1);
+					if (tidx == kOffMask) { ITER_SKIP(); continue; }
 					const int64_t refoff = (int64_t)toff - (int64_t)rdoff;
-					if (diag_present((int32_t)tidx, refoff, fw)) { HOT.n_redundants++; continue; }
+					{ const bool dp_ = diag_present((int32_t)tidx, refoff, fw); LOOP_T(15); if (dp_) { HOT.n_redundants++; ITER_SKIP(); continue; } }
 					int read_gaps = 0, ref_gaps = 0;
 					bool ungapped = false;
 					if (!ee_mode) {
@@ -2552,7 +2597,11 @@ struct Aligner {
 						}
 					}
 				}
-				satpos_commit(i, sp);
+#ifdef BT2G_LOOP_PROF
+				tl_ = Plat::clock();
+#endif
+				if (srow) gst(&WK.srows[i - HOT.n_satpos_full].done, srow_done ? 1u : 0u); else satpos_commit(i, *spp);
+				LOOP_T(16);
 			}
 			if (PRM.det_seeds) break;      // useCurrIdx: always one pass (aligner_sw_driver.cpp:1490)
 		}
@@ -2646,7 +2695,13 @@ struct Aligner {
 					{ const uint64_t t0_ = now(); rank_seed_hits(); HOT.t_phase[3] += now() - t0_; }
 					ext_mms = PRM.seed_mms;
 				}
+#ifdef BT2G_ITER_PROF
+				const uint64_t te_ = Plat::clock();
 				const int ret = Plat::uni(extend_seeds(ext_mms, RPR.seedlen, (int)interval));
+				HOT.t_phase[20] += Plat::clock() - te_;
+#else
+				const int ret = Plat::uni(extend_seeds(ext_mms, RPR.seedlen, (int)interval));
+#endif
 				handle_ret(ret, done);
 				if (stage == 0) {
 					HOT.exact[0].top = HOT.exact[0].bot = HOT.exact[1].top = HOT.exact[1].bot = 0;
@@ -2659,7 +2714,11 @@ struct Aligner {
 				}
 			}
 		}
+#ifdef BT2G_LOOP_PROF
+		{ const uint64_t tf_ = Plat::clock(); finish(out); HOT.t_phase[20] += Plat::clock() - tf_; }
+#else
 		finish(out);
+#endif
 		HOT.t_phase[11] = ST.pf_steps; HOT.t_phase[12] = ST.pf_tiles; HOT.t_phase[14] = ST.pf_tile_t;
 		HOT.t_phase[7] = now() - t_run0_;
 #ifdef BT2G_DIAG_TICKS

@@ -723,6 +723,14 @@ struct DevPlat {
 			if ((k[r] & 0xff000000u) == seenhi) { v[r] = (k[r] & 0xffffffu) - cnt[r]; k[r] = convhi | (k[r] & 0xffffffu); }
 		}
 	}
+	// lane j <- the fields of range sat[j] the extension loop needs of a sampled row: rdoff | seedlen << 12 | fw << 18 | offidx << 20
+	static __device__ __forceinline__ uint32_t range_fields(const BT2_G SatPos* sat, uint32_t n) {
+		wave_fence();
+		const uint32_t l = threadIdx.x & 63;
+		uint32_t r = 0;
+		if (l < uni(n)) { const BT2_G SatPos* s = sat + l; r = (gld(&s->rdoff) & 0xfffu) | ((gld(&s->seedlen) & 0x3fu) << 12) | ((uint32_t)(gld(&s->fw) != 0) << 18) | (gld(&s->offidx) << 20); }
+		return r;
+	}
 	// ---- lane code (BT2_FOR_LANES / LV in bt2g_align_core.hpp): on the device the block runs once, a LaneReg is the lane's own register ----
 	static __device__ __forceinline__ uint32_t lanes_first() { return threadIdx.x & 63; }
 	static __device__ __forceinline__ uint32_t lanes_step() { return 64u; }
@@ -974,15 +982,16 @@ struct DevPlat {
 		pr = p; mk = m;
 	}
 	// ---- the candidates that die within a few cells, side by side (Aligner::next_alignment_m) ----
-	// Only while the marks of the matrix in hand are on chip (band form; one bit per cell in LDS): a mark operation is then one LDS instruction.
-	static __device__ __forceinline__ bool marks_batchable() { return uni(g_st.rt_cur) != 0u; }
+	// Band matrices (w > 0).  Marks on chip (one bit per cell in LDS, rt_cur) or epoch-tagged words in the arena.
+	static __device__ __forceinline__ bool marks_batchable() { return true; }
 	// per lane: the predecessor bytes (plo: cells 0-3, phi: cells 4-7) and reportedThrough bits (mk, bit i) of the eight cells from the lane's own cell on in
 	// its own direction (0 up the diagonal, 1 left along the row, 2 up the column); a cell outside the band reads as 0 / unmarked.  Eight independent
 	// loads per plane: one memory latency for eight steps of every candidate's path.
-	static __device__ __forceinline__ void pred_tile8(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t, uint32_t row, uint32_t col, uint32_t dir, uint32_t flag,
+	static __device__ __forceinline__ void pred_tile8(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t row, uint32_t col, uint32_t dir, uint32_t flag,
 	                                                  uint32_t& plo, uint32_t& phi, uint32_t& mk) {
 		wave_fence();
 		const uint8_t* pm = reinterpret_cast<const uint8_t*>(dp.mat);
+		const bool chip = uni(g_st.rt_cur) != 0u;
 		uint32_t pb[8], mw[8];
 #pragma unroll
 		for (uint32_t i = 0; i < 8; i++) {
@@ -991,25 +1000,29 @@ struct DevPlat {
 			const bool ok = flag && (int32_t)r >= 0 && (int32_t)c >= 0 && dd < band_w;
 			const uint32_t bit = r * band_w + dd;
 			pb[i] = ok ? (uint32_t)gld(pm + (uint64_t)r * band_w + dd) : 0u;
-			mw[i] = ok ? (dev_rt()[bit >> 5] >> (bit & 31u)) & 1u : 0u;
+			if (chip) mw[i] = ok ? (dev_rt()[bit >> 5] >> (bit & 31u)) & 1u : 0u;
+			else { const uint32_t w = ok ? gld(dp.pmask + (uint64_t)r * band_w + dd) : 0u; mw[i] = (w >> kEpochShift) == epoch ? (w & 1u) : 0u; }
 		}
 		plo = pb[0] | (pb[1] << 8) | (pb[2] << 16) | (pb[3] << 24);
 		phi = pb[4] | (pb[5] << 8) | (pb[6] << 16) | (pb[7] << 24);
 		mk = mw[0] | (mw[1] << 1) | (mw[2] << 2) | (mw[3] << 3) | (mw[4] << 4) | (mw[5] << 5) | (mw[6] << 6) | (mw[7] << 7);
 	}
 	// per lane: reportedThrough of the lane's own cell / set it
-	static __device__ __forceinline__ uint32_t marks_of_cells(const DpScratch&, int32_t band_lo, uint32_t band_w, uint32_t, uint32_t r, uint32_t c, uint32_t flag) {
+	static __device__ __forceinline__ uint32_t marks_of_cells(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t r, uint32_t c, uint32_t flag) {
 		wave_fence();
 		const uint32_t dd = (uint32_t)((int32_t)c - (int32_t)r + band_lo);
 		const bool ok = flag && (int32_t)r >= 0 && (int32_t)c >= 0 && dd < band_w;
 		const uint32_t bit = r * band_w + dd;
-		return ok ? (dev_rt()[bit >> 5] >> (bit & 31u)) & 1u : 0u;
+		if (uni(g_st.rt_cur)) return ok ? (dev_rt()[bit >> 5] >> (bit & 31u)) & 1u : 0u;
+		const uint32_t w = ok ? gld(dp.pmask + (uint64_t)r * band_w + dd) : 0u;
+		return (w >> kEpochShift) == epoch ? (w & 1u) : 0u;
 	}
-	static __device__ __forceinline__ void mark_cells(const DpScratch&, int32_t band_lo, uint32_t band_w, uint32_t, uint32_t r, uint32_t c, uint32_t flag) {
+	static __device__ __forceinline__ void mark_cells(const DpScratch& dp, int32_t band_lo, uint32_t band_w, uint32_t epoch, uint32_t r, uint32_t c, uint32_t flag) {
 		const uint32_t dd = (uint32_t)((int32_t)c - (int32_t)r + band_lo);
 		const bool ok = flag && (int32_t)r >= 0 && (int32_t)c >= 0 && dd < band_w;
 		const uint32_t bit = r * band_w + dd;
-		if (ok) __hip_atomic_fetch_or(dev_rt() + (bit >> 5), 1u << (bit & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		if (uni(g_st.rt_cur)) { if (ok) __hip_atomic_fetch_or(dev_rt() + (bit >> 5), 1u << (bit & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+		else if (ok) gst(dp.pmask + (uint64_t)r * band_w + dd, 1u | (epoch << kEpochShift));
 		wave_fence();
 	}
 	// setReportedThrough of one cell (wave-uniform)

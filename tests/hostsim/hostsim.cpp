@@ -175,6 +175,12 @@ struct HostPlat {
 		}
 		for (uint32_t i = 0; i < n; i++) { uint32_t& ki = k[i >> 6].v[i & 63]; if ((ki & 0xff000000u) == seenhi) ki = convhi | (ki & 0xffffffu); }
 	}
+	// lane j <- the fields of range sat[j] the extension loop needs of a sampled row: rdoff | seedlen << 12 | fw << 18 | offidx << 20
+	static LaneReg range_fields(const SatPos* sat, uint32_t n) {
+		LaneReg r;
+		for (uint32_t l = 0; l < 64; l++) r.v[l] = l < n ? (sat[l].rdoff & 0xfffu) | ((sat[l].seedlen & 0x3fu) << 12) | ((uint32_t)(sat[l].fw != 0) << 18) | (sat[l].offidx << 20) : 0u;
+		return r;
+	}
 	// ---- lane code (BT2_FOR_LANES / LV in bt2g_align_core.hpp): on the host a loop over the 64 lanes of LaneReg arrays ----
 	static uint32_t lanes_first() { return 0; }
 	static uint32_t lanes_step() { return 1; }
