@@ -125,6 +125,23 @@ struct Aligner {
 		constexpr uint32_t ql_per = 1024u;                              // 16 KB / sizeof(SAKey)
 		constexpr uint64_t sl_per = 16384u / sizeof(TOff);              // 16 KB / sizeof(TIndexOffU)
 		HOT.nonz_tot = HOT.nonz_fw = HOT.nonz_rc = 0; HOT.num_elts = 0;
+		// Nothing of a round can be dropped or cut when the pool holds all of it even if every seed were a sequence of its own: at most 64 of them, so
+		// the three node pools take one page each, and the element list ceil(elements / sl_per).  Then what the search found is what SeedResults ends
+		// up holding (esize == size, as the search left it; a sequence that occurs twice has the same range both times), and all that is left to do
+		// is the tally -- one lane per seed.  (Only where the pool is this round's and this read's alone: the mates of a pair share one.)
+		if (!PRM.paired && Plat::uni(c.nkeys) == 0u && Plat::uni(c.pool_used) == 0u && Plat::uni(HOT.num_offs) <= 32u && L <= 32u) {
+			const uint32_t n = Plat::uni(HOT.num_offs);
+			const bool skf = ST.m_nofw != 0, skr = ST.m_norc != 0;
+			typename Plat::LaneReg sz;
+			BT2_FOR_LANES(l) { const uint32_t fwi = l >> 5, i = l & 31u; LV(sz) = (i < n && !(fwi ? skr : skf)) ? HOT.hits[fwi][i].size : 0u; }
+			const uint64_t tot = Plat::lanes_sum(sz);
+			if (3u + (tot + sl_per - 1) / sl_per <= (uint64_t)Plat::uni(c.pool_total)) {
+				const uint64_t nz = Plat::ballot(sz);
+				HOT.nonz_fw = (uint32_t)__builtin_popcountll(nz & 0xffffffffull); HOT.nonz_rc = (uint32_t)__builtin_popcountll(nz >> 32);
+				HOT.nonz_tot = HOT.nonz_fw + HOT.nonz_rc; HOT.num_elts = tot;
+				return;
+			}
+		}
 		// The key table lives in the arena; its first 64 entries (all of them for an unpaired 150-bp read) are mirrored in lane registers
 		// for the duration of this call -- key, length | flags << 8, elements held -- so that a seed costs no memory round trip (it used
 		// to cost two: the search of the table and the entry's flags).  Every change is also stored, the arena copy stays complete.
@@ -2314,17 +2331,22 @@ struct Aligner {
 	BT2_HDI int extend_seeds(int seedmms_, int seedlen, int seedival) {
 		(void)seedlen; (void)seedival;
 		const int seedmms = Plat::uni(seedmms_);
-		const uint32_t rdlen = HOT.len;
-		const int64_t perfect = (int64_t)rdlen * PRM.match_bonus;       // Scoring::perfectScore: 0 end to end
+		// (the phase timers of this function ask one scalar register whether anybody is listening, not the parameter block in LDS at every site)
+		const bool prof_ = Plat::uni((int)PRM.profile) != 0;
+		auto tnow = [prof_]() -> uint64_t { return prof_ ? Plat::clock() : 0ull; };
+		// (What this function keeps across its calls are wave-uniform scalars.  A value read from LDS arrives in a vector register and stays in one
+		// -- 64 lanes for one number, spilled to scratch around every call: a memory round trip per use -- unless it is said to be uniform.)
+		const uint32_t rdlen = Plat::uni(HOT.len);
+		const int64_t perfect = (int64_t)rdlen * Plat::uni(PRM.match_bonus);       // Scoring::perfectScore: 0 end to end
 		const uint32_t nsm = 5;
-		const uint32_t nonz = HOT.nonz_tot;
-		const uint64_t ee_hits = (HOT.exact[0].bot - HOT.exact[0].top) + (HOT.exact[1].bot - HOT.exact[1].top) + HOT.mm1_elt;
+		const uint32_t nonz = Plat::uni(HOT.nonz_tot);
+		const uint64_t ee_hits = Plat::uni((uint64_t)((HOT.exact[0].bot - HOT.exact[0].top) + (HOT.exact[1].bot - HOT.exact[1].top) + HOT.mm1_elt));
 		bool ee_mode = ee_hits > 0;
 		bool first_ee = true, first_extend = true;
 		HOT.n_ee_fail = HOT.n_ug_fail = HOT.n_dp_fail = 0;
 		uint64_t nelt = 0, nelt_left = 0;
 		const uint32_t rows = rdlen;
-		const uint32_t max_iters = (uint32_t)PRM.max_iters;
+		const uint32_t max_iters = Plat::uni((uint32_t)PRM.max_iters);
 		BT2_G AlnRes& res = WK.res;
 		// A sampled row (most entries of the extension list on repeats) is ONE row of a range: what the loop needs of it -- strand, seed offset and
 		// length, seed number -- are its range's fields, packed into one lane register (lane j = range samp_sai + j) when the sampler had at most 64
@@ -2343,18 +2365,19 @@ struct Aligner {
 			}
 			if (!ee_mode) {
 				if (nonz == 0) return EXT_EXHAUSTED;
-				if (ST.minsc == perfect) return EXT_PERFECT_SCORE;
+				if (Plat::uni(ST.minsc) == perfect) return EXT_PERFECT_SCORE;
 				if (first_extend) {
 					nelt = 0;
-					{ const uint64_t t0_ = now(); prioritize(seedmms, max_iters, nelt); HOT.t_phase[3] += now() - t0_; }
+					{ const uint64_t t0_ = tnow(); prioritize(seedmms, max_iters, nelt); HOT.t_phase[3] += tnow() - t0_; }
+					nelt = Plat::uni(nelt);
 					nelt_left = nelt;
 					first_extend = false;
-					lane_rows = !PRM.det_seeds && HOT.samp_lanes != 0u && HOT.n_satpos > HOT.n_satpos_full;
+					lane_rows = Plat::uni((int)(!PRM.det_seeds && HOT.samp_lanes != 0u && HOT.n_satpos > HOT.n_satpos_full)) != 0;
 					if (lane_rows) rgpk = Plat::range_fields(&WK.satpos2[HOT.samp_sai], HOT.n_masses);
 				}
 				if (nelt_left == 0) break;
 			}
-			const uint32_t maxi = HOT.n_satpos;
+			const uint32_t maxi = Plat::uni(HOT.n_satpos), n_full = Plat::uni(HOT.n_satpos_full), samp_sai = Plat::uni(HOT.samp_sai);
 			for (uint32_t i = 0; i < maxi; i++) {
 #ifdef BT2G_LOOP_PROF
 				uint64_t tl_ = Plat::clock();
@@ -2363,42 +2386,44 @@ struct Aligner {
 #define LOOP_T(slot) do {} while (0)
 #endif
 				// the entry: a whole range / an end-to-end hit with its Random1toN in the arena, or one sampled row
-				const bool srow = lane_rows && i >= HOT.n_satpos_full;
+				const bool srow = lane_rows && i >= n_full;
 				BT2_G SatPos* spp = nullptr;
 				uint64_t sp_topf; uint32_t sp_size, sp_rdoff, sp_seedlen, sp_offidx, sp_orig_sz; int32_t sp_ee; bool sp_fw;
 				bool srow_done = false;
 				if (srow) {
-					const SampRow sr = gld(&WK.srows[i - HOT.n_satpos_full]);
+					const SampRow sr = gld(&WK.srows[i - n_full]);
 					if (Plat::uni(sr.done) != 0u) continue;
-					const uint32_t pk = Plat::lane(rgpk, Plat::uni(sr.src) - HOT.samp_sai);
+					const uint32_t pk = Plat::lane(rgpk, Plat::uni(sr.src) - samp_sai);
 					sp_topf = Plat::uni(sr.topf); sp_size = 1u; sp_orig_sz = 2u; sp_ee = -1;
 					sp_rdoff = pk & 0xfffu; sp_seedlen = (pk >> 12) & 0x3fu; sp_fw = ((pk >> 18) & 1u) != 0u; sp_offidx = pk >> 20;
 				} else {
 					if (satpos_taken(i)) continue;
 					spp = &satpos_view(i);
-					sp_topf = spp->topf; sp_size = spp->size; sp_orig_sz = spp->orig_sz; sp_ee = spp->ee;
-					sp_rdoff = spp->rdoff; sp_seedlen = spp->seedlen; sp_fw = spp->fw != 0; sp_offidx = spp->offidx;
+					spp = Plat::uni_ptr(spp);
+					sp_topf = Plat::uni((uint64_t)spp->topf); sp_size = Plat::uni((uint32_t)spp->size); sp_orig_sz = Plat::uni((uint32_t)spp->orig_sz); sp_ee = Plat::uni((int)spp->ee);
+					sp_rdoff = Plat::uni((uint32_t)spp->rdoff); sp_seedlen = Plat::uni((uint32_t)spp->seedlen); sp_fw = Plat::uni((int)(spp->fw != 0)) != 0; sp_offidx = Plat::uni((uint32_t)spp->offidx);
 				}
 				LOOP_T(0);
 				EEHit eh_v; eh_v.score = 0;
 				if (ee_mode) eh_v = ee_hit(sp_ee);
 				const EEHit* eh = &eh_v;
-				if (ee_mode && eh->score < ST.minsc) return EXT_PERFECT_SCORE;
-				const bool is_small = PRM.det_seeds ? true : sp_size < nsm;
+				if (ee_mode && eh->score < Plat::uni(ST.minsc)) return EXT_PERFECT_SCORE;
+				const bool is_small = Plat::uni((int)PRM.det_seeds) ? true : sp_size < nsm;
 				const bool fw = sp_fw;
 				uint32_t rdoff = sp_rdoff;
 				const uint32_t seedhitlen = sp_seedlen;
 				if (!fw) rdoff = rdlen - rdoff - seedhitlen;
 				bool first = true;
 				while (!(srow ? srow_done : r1n_done(spp->rnd)) && (first || is_small || ee_mode)) {
-					if (ST.minsc == perfect) {
+					const int64_t minsc_now = Plat::uni(ST.minsc);
+					if (minsc_now == perfect) {
 						if (!ee_mode || eh->score < perfect) return EXT_PERFECT_SCORE;
-					} else if (ee_mode && eh->score < ST.minsc) {
+					} else if (ee_mode && eh->score < minsc_now) {
 						break;
 					}
-					if (HOT.n_ex_dps >= (uint32_t)PRM.max_dp) return EXT_HARD_LIMIT;
-					if (HOT.n_ex_ugs >= (uint32_t)PRM.max_ug) return EXT_HARD_LIMIT;
-					if (HOT.n_ex_iters >= max_iters) return EXT_HARD_LIMIT;
+					if (Plat::uni(HOT.n_ex_dps) >= Plat::uni((uint32_t)PRM.max_dp)) return EXT_HARD_LIMIT;
+					if (Plat::uni(HOT.n_ex_ugs) >= Plat::uni((uint32_t)PRM.max_ug)) return EXT_HARD_LIMIT;
+					if (Plat::uni(HOT.n_ex_iters) >= max_iters) return EXT_HARD_LIMIT;
 					HOT.n_ex_iters++;
 					first = false;
 #ifdef BT2G_ITER_PROF
@@ -2413,26 +2438,26 @@ struct Aligner {
 					if (srow) srow_done = true; else elt = Plat::uni(r1n_next(spp->rnd));
 					// GroupWalk2S::advanceElement == Ebwt::getOffset(topf + elt)
 					uint32_t steps = 0;
-					const uint64_t tr_ = now();
+					const uint64_t tr_ = tnow();
 					TOff joff;
 					uint64_t jc = kJoffNone;
 					// a one-row hit of the pre-computed seed round was resolved by the batch kernel that extended it
 					if (!ee_mode && ST.ext_pre && seedmms == 0 && sp_orig_sz == 1 && ST.pre_joff_cur)
-						jc = ST.pre_joff_cur[((uint64_t)ST.ridx * 2 + (fw ? 0 : 1)) * PRE->max_seeds + sp_offidx];
-					if (jc == kJoffNone && !ee_mode && i >= HOT.n_satpos_full) {
+						jc = Plat::uni((uint64_t)Plat::uni_ptr(ST.pre_joff_cur)[((uint64_t)Plat::uni(ST.ridx) * 2 + (fw ? 0 : 1)) * Plat::uni(PRE->max_seeds) + sp_offidx]);
+					if (jc == kJoffNone && !ee_mode && i >= n_full) {
 						// a sampled row: the walks to the SA sample of this row and the next 63 run side by side, one per lane
 						// (the extension loop takes the rows in list order, so the look-ahead is rarely wasted)
-						if (i >= HOT.n_resolved) {
-							const uint32_t k0 = i - HOT.n_satpos_full, cnt = HOT.n_satpos - i < 64u ? HOT.n_satpos - i : 64u;
+						if (i >= Plat::uni(HOT.n_resolved)) {
+							const uint32_t k0 = i - n_full, cnt = maxi - i < 64u ? maxi - i : 64u;
 							Plat::resolve_rows(IX.fw, &WK.srows[k0], cnt, &WK.srow_joff[k0]);
 							HOT.n_resolved = i + cnt;
 						}
-						jc = WK.srow_joff[i - HOT.n_satpos_full];
+						jc = Plat::uni((uint64_t)WK.srow_joff[i - n_full]);
 						if (jc != kJoffNone) HOT.n_sides += (uint32_t)(jc >> 48);
 					}
 					if (jc != kJoffNone) { joff = (TOff)(jc & 0xffffffffffffull); steps = (uint32_t)(jc >> 48); }
 					else { joff = Plat::get_offset(IX.fw, (TOff)(sp_topf + elt), steps); HOT.n_sides += steps; }
-					HOT.t_phase[4] += now() - tr_;
+					HOT.t_phase[4] += tnow() - tr_;
 					HOT.n_bwops_ext += steps; HOT.n_resolve_steps += steps;
 					if (!ee_mode) nelt_left--;
 					TOff tidx = 0, toff = 0, tlen = 0;
@@ -2449,8 +2474,8 @@ struct Aligner {
 					int read_gaps = 0, ref_gaps = 0;
 					bool ungapped = false;
 					if (!ee_mode) {
-						read_gaps = max_read_gaps(PRM, ST.minsc, rdlen);
-						ref_gaps = max_ref_gaps(PRM, ST.minsc, rdlen);
+						read_gaps = Plat::uni(max_read_gaps(PRM, minsc_now, rdlen));
+						ref_gaps = Plat::uni(max_ref_gaps(PRM, minsc_now, rdlen));
 						ungapped = (read_gaps == 0 && ref_gaps == 0);
 					}
 					int state = 0;   // 0 none, 1 ee, 2 ungapped
@@ -2482,10 +2507,10 @@ struct Aligner {
 						res.refns = (uint16_t)hrefns;
 						state = 1; found = true;
 						diag_add((int32_t)tidx, refoff, fw, 1);
-					} else if (PRM.do_ungapped && ungapped) {
-						const uint64_t tu_ = now();
+					} else if (ungapped && Plat::uni((int)PRM.do_ungapped)) {
+						const uint64_t tu_ = tnow();
 						const int al = Plat::uni(ungapped_align(fw, tidx, refoff, (int64_t)tlen, res));
-						HOT.t_phase[10] += now() - tu_;
+						HOT.t_phase[10] += tnow() - tu_;
 						diag_add((int32_t)tidx, refoff, fw, 1);
 						HOT.n_ex_ugs++;
 						if (al == 0) {
@@ -2504,13 +2529,13 @@ struct Aligner {
 					if (state == 0) {
 						// DynProgFramer::frameSeedExtensionRect (dp_framer.cpp:81-129), trimToRef
 						uint32_t maxgap = (uint32_t)imax(read_gaps, ref_gaps);
-						if (maxgap > (uint32_t)PRM.maxhalf) maxgap = (uint32_t)PRM.maxhalf;
+						{ const uint32_t mh_ = Plat::uni((uint32_t)PRM.maxhalf); if (maxgap > mh_) maxgap = mh_; }
 						const int64_t refl = refoff - 2 * (int64_t)maxgap;
 						const int64_t refr = refoff + ((int64_t)rows - 1) + 2 * (int64_t)maxgap;
 						uint64_t triml = 0, trimr = 0;
 						// trimToRef_ = !gReportOverhangs; otherwise up to nceil columns of N past either end stay in the window
 						int64_t maxns = 0;
-						if (PRM.overhang) { maxns = RPR.nceil; if (maxns == (int64_t)rows) maxns--; }
+						if (Plat::uni((int)PRM.overhang)) { maxns = Plat::uni((int)RPR.nceil); if (maxns == (int64_t)rows) maxns--; }
 						if (refr >= (int64_t)tlen + maxns) trimr = (uint64_t)(refr - ((int64_t)tlen + maxns - 1));
 						if (refl < -maxns) triml = (uint64_t)(-refl) - (uint64_t)maxns;
 						rect.refl_pretrim = refl; rect.refr_pretrim = refr;
@@ -2521,32 +2546,33 @@ struct Aligner {
 						diag_add((int32_t)tidx, refoff, fw, 1);
 						if (!found) continue;
 						cols = (uint32_t)(rect.refr - rect.refl + 1);
-						if (cols + 1 > ST.max_cols || rows > (uint32_t)kMaxLen) { ovf(23); return EXT_HARD_LIMIT; }
+						if (cols + 1 > Plat::uni(ST.max_cols) || rows > (uint32_t)kMaxLen) { ovf(23); return EXT_HARD_LIMIT; }
 						diag_add((int32_t)tidx, rect.refl_pretrim + (int64_t)rect.corel, fw, (int64_t)(rect.corer - rect.corel + 1));
 						// SwAligner::align (aligner_sw.cpp:500-729).  End to end: 8-bit kernel while ST.minsc >= -254, else 16-bit (:517).
 						// Local: the 8-bit kernel unless it saturates, then the 16-bit one (:568-600); the fill below is exact and
 						// reports whether the 8-bit kernel would have saturated, which only matters for the RNG protocol.
-						const uint64_t td_ = now();
+						const uint64_t td_ = tnow();
 						fetch_ref_window(tidx, rect.refl, cols + 1);
 						int64_t best;
-						if (PRM.match_bonus > 0) {
+						if (Plat::uni(PRM.match_bonus) > 0) {
 							mode = 2;
 							uint32_t sat8 = 0;
-							best = Plat::uni(Plat::dp_fill_local(PRM, WK, fw, rows, cols, ST.dp.mat, ST.minsc, lastsolcol, sat8));
-							sse16 = sat8 != 0;
+							best = Plat::uni(Plat::dp_fill_local(PRM, WK, fw, rows, cols, ST.dp.mat, minsc_now, lastsolcol, sat8));
+							lastsolcol = Plat::uni(lastsolcol);
+							sse16 = Plat::uni(sat8) != 0;
 						} else {
-							mode = ST.minsc < -254 ? 1 : 0;
+							mode = minsc_now < -254 ? 1 : 0;
 							sse16 = mode == 1;
-							best = Plat::uni(Plat::dp_fill_ee(PRM, WK, fw, rows, cols, ST.dp, mode != 0, ST.minsc));
+							best = Plat::uni(Plat::dp_fill_ee(PRM, WK, fw, rows, cols, ST.dp, mode != 0, minsc_now));
 							if (best == INT64_MIN) { ovf(31); return EXT_HARD_LIMIT; }
 						}
-						HOT.t_phase[5] += now() - td_;
+						HOT.t_phase[5] += tnow() - td_;
 						HOT.n_ex_dps++;
-						found = best >= ST.minsc;
-						if (found) { const uint64_t tg_ = now(); gather_cells(fw, rows, cols, ST.minsc, mode, lastsolcol); found = HOT.n_cands > 0; HOT.t_phase[8] += now() - tg_; }
+						found = best >= minsc_now;
+						if (found) { const uint64_t tg_ = tnow(); gather_cells(fw, rows, cols, minsc_now, mode, lastsolcol); found = Plat::uni(HOT.n_cands) > 0; HOT.t_phase[8] += tnow() - tg_; }
 						if (!found) {
 							HOT.n_dp_fail++;
-							if (HOT.n_dp_fail >= (uint32_t)PRM.max_dp_streak) return EXT_SOFT_LIMIT;
+							if (Plat::uni(HOT.n_dp_fail) >= Plat::uni((uint32_t)PRM.max_dp_streak)) return EXT_SOFT_LIMIT;
 							continue;
 						}
 						if (HOT.n_dp_fail > HOT.n_dp_fail_streak) HOT.n_dp_fail_streak = HOT.n_dp_fail;
@@ -2557,15 +2583,15 @@ struct Aligner {
 						if (state == 1 || state == 2) {
 							if (!first_inner) break;
 						} else {
-							if (HOT.cural == HOT.n_cands) break;
-							const uint64_t tb_ = now();
+							if (Plat::uni(HOT.cural) == Plat::uni(HOT.n_cands)) break;
+							const uint64_t tb_ = tnow();
 							const bool na_ = next_alignment(fw, rows, cols, rect, tidx, (int64_t)tlen, mode, sse16, res);
-							HOT.t_phase[6] += now() - tb_;
+							HOT.t_phase[6] += tnow() - tb_;
 							if (!na_) break;
 						}
 						first_inner = false;
-						const uint64_t tp_ = now();
-						struct PostTimer { uint64_t t0; uint64_t& acc; BT2_HD ~PostTimer() { acc += now() - t0; } } post_timer_{tp_, HOT.t_phase[9]};
+						const uint64_t tp_ = tnow();
+						struct PostTimer { uint64_t t0; uint64_t& acc; bool on; BT2_HD ~PostTimer() { if (on) acc += Plat::clock() - t0; } } post_timer_{tp_, HOT.t_phase[9], prof_};
 						// --overhang: soft-clip what hangs off either end (aligner_sw_driver.cpp:1396-1403)
 						if (PRM.overhang && (res.refoff < 0 || res.refoff + (int64_t)res.rfextent > (int64_t)tlen)) {
 							clip_outside(res, 0, (int64_t)tlen);
@@ -2580,7 +2606,7 @@ struct Aligner {
 						}
 						if (Plat::uni((int)red_overlap(res)) != 0) continue;
 						red_add(res);
-						{ const uint64_t t1_ = now(); const bool sr_ = sink_report(res); HOT.t_phase[19] += now() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
+						{ const uint64_t t1_ = tnow(); const bool sr_ = sink_report(res); HOT.t_phase[19] += tnow() - t1_; if (sr_) return EXT_POLICY_FULFILLED; }
 						if (PRM.tighten > 0 && PRM.mhits > 0 && HOT.best2_unp1 != INT64_MIN) {
 							if (PRM.tighten == 1) {
 								if (HOT.best_unp1 >= ST.minsc) {

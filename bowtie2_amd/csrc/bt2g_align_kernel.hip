@@ -119,17 +119,22 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 		refS[k] = sel; Hp[k] = p_from(h); Fp[k] = p_splat(0);
 	}
 	if (PRED) for (uint32_t j = (uint32_t)lane; j < cols; j += 64) dev_lastrow()[j] = (int16_t)-0xff;      // columns the band does not reach in the last row
-	int jin = j00 + N2;                       // column that enters the lane's last diagonal in the next row
-	const int rdgape = P.rdgape, rdgapo = P.rdgapo;
-	const u16x2 rdoP = p_splat(rdgapo), rfoP = p_splat(P.rfgapo), rfeP = p_splat(P.rfgape);
-	const uint32_t npen_word = (uint32_t)P.n_pen & 0xffu;
+	// (the parameter block is read from LDS: its fields arrive in vector registers and count as lane-varying until said otherwise)
+	const int rdgape = __builtin_amdgcn_readfirstlane(P.rdgape), rdgapo = __builtin_amdgcn_readfirstlane(P.rdgapo), gapbar = __builtin_amdgcn_readfirstlane(P.gapbar);
+	const u16x2 rdoP = p_splat(rdgapo), rfoP = p_splat(__builtin_amdgcn_readfirstlane(P.rfgapo)), rfeP = p_splat(__builtin_amdgcn_readfirstlane(P.rfgape));
+	uint32_t npen_word = (uint32_t)__builtin_amdgcn_readfirstlane(P.n_pen) & 0xffu;
+	uint32_t k7f = 0x007f007fu;
+	asm("" : "+v"(npen_word), "+v"(k7f));      // in vector registers: the row's v_perm_b32 / v_bitop3_b32 take another operand from a scalar one, and an instruction reads one scalar register only
+	// The column that enters a lane's last diagonal in the next row is the column of the NEXT lane's first diagonal in this row: one DPP move.
+	// Only the wave's last diagonal gets a column nobody holds yet, 64 * N2 - lo + i after row i: lane ii of every 64-row chunk fetches the one of its row.
+	const int jin63 = 64 * N2 - lo;
 	auto cap = [](uint32_t v) -> unsigned short { return (unsigned short)(v > 1023u ? 1023u : v); };     // scores are <= 255: any larger decay is "to zero"
 	// The scan over the lanes' carries: E decays by D = 2RP * rdgape from one lane to the next, so with Y_l = carry_l + l * D the decayed
 	// maximum  max_{l' <= l} (carry_l' - (l - l') D)  is  (prefix-max of Y)_l - l * D  -- a PLAIN prefix maximum, whose DPP steps are
 	// single v_max_u32 instructions with a DPP operand (no subtraction between the move and the max).  No saturation is needed: the term
 	// l' = l alone keeps the maximum >= 0, and terms that would have saturated to 0 cannot win.
 	const uint32_t D = (uint32_t)N2 * (uint32_t)rdgape;
-	const uint32_t lD = (uint32_t)lane * D, lDprev = lane ? lD - D : 0u;
+	const uint32_t lD = (uint32_t)lane * D, lDprev = lane ? lD - D : 0u;      // (lane 0: the prefix of no lane, 0 - 0)
 	u16x2 decP[RP];                           // decay of the carry-in on its way to each of the lane's diagonals
 #pragma unroll
 	for (int k = 0; k < RP; k++) decP[k] = p_make(cap((uint32_t)(2 * k) * (uint32_t)rdgape), cap((uint32_t)(2 * k + 1) * (uint32_t)rdgape));
@@ -149,12 +154,17 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 				if (c <= 3) tab &= ~(0xffu << (8 * c));
 			}
 		}
-		const uint32_t nrow = rows - c0 < 64u ? rows - c0 : 64u;
+		uint32_t chq;
+		{
+			int jc = jin63 + (int)c0 + lane; jc = jc < 0 ? 0 : jc; if (jc > (int)cols) jc = (int)cols;      // outside the window: any character will do (see above)
+			chq = (uint32_t)__builtin_ctz((uint32_t)dev_rf()[jc] | 16u) | 0x0c00u;
+		}
+		const uint32_t nrow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rows - c0 < 64u ? rows - c0 : 64u));
 		for (uint32_t ii = 0; ii < nrow; ii++) {
 			const uint32_t i = c0 + ii;
 			const uint32_t T1 = (uint32_t)__builtin_amdgcn_readlane((int)tab, (int)ii);
-			const bool bar = (int)i < P.gapbar || (int)(rows - i - 1) < P.gapbar;       // no gaps this close to either end of the read
-			const u16x2 fvetoP = p_splat((bar || i == 0) ? 0xffff : 0);
+			const bool bar = (int)i < gapbar || (int)(rows - i - 1) < gapbar;       // no gaps this close to either end of the read
+			const bool nof = bar || i == 0;      // F is vetoed: saturating subtraction of 0xffff, i.e. 0
 			// ---- diagonal and vertical predecessors ----
 			const uint32_t nxtH = dpp0<kDppWaveShl1, 0xf>(p_bits(Hp[0])), nxtF = dpp0<kDppWaveShl1, 0xf>(p_bits(Fp[0]));
 			u16x2 penP[RP], HupP[RP], FupP[RP], fP[RP], HdP[RP];
@@ -163,7 +173,7 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 				penP[k] = p_from(__builtin_amdgcn_perm(npen_word, T1, refS[k]));
 				HupP[k] = p_from(shift_in(p_bits(Hp[k]), k + 1 < RP ? p_bits(Hp[k + 1 < RP ? k + 1 : 0]) : nxtH));
 				FupP[k] = p_from(shift_in(p_bits(Fp[k]), k + 1 < RP ? p_bits(Fp[k + 1 < RP ? k + 1 : 0]) : nxtF));
-				fP[k] = p_subs(p_max(p_subs(FupP[k], rfeP), p_subs(HupP[k], rfoP)), fvetoP);
+				fP[k] = nof ? p_splat(0) : p_max(p_subs(FupP[k], rfeP), p_subs(HupP[k], rfoP));
 				HdP[k] = p_max(p_subs(Hp[k], penP[k]), fP[k]);
 			}
 			// ---- horizontal: E as a max-plus scan over the row ----
@@ -185,7 +195,7 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 				Y = umax32(Y, dpp0<kDppBcast15, 0xa>(Y));
 				Y = umax32(Y, dpp0<kDppBcast31, 0xc>(Y));
 				const uint32_t Pprev = dpp0<kDppWaveShr1, 0xf>(Y);      // prefix maximum up to the previous lane (0 into lane 0)
-				const u16x2 einP = p_splat((int)(lane ? Pprev - lDprev : 0u));
+				const u16x2 einP = p_splat((int)(Pprev - lDprev));
 #pragma unroll
 				for (int k = 0; k < RP; k++) EP[k] = p_max(p_make(e0[2 * k], e0[2 * k + 1]), p_subs(einP, decP[k]));
 			} else {
@@ -197,24 +207,24 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 			if (PRED) {
 				// left neighbours: the previous diagonal of this row
 				const uint32_t prvH = dpp0<kDppWaveShr1, 0xf>(p_bits(HP[RP - 1])), prvE = dpp0<kDppWaveShr1, 0xf>(p_bits(EP[RP - 1]));
-				const u16x2 gaP = p_splat(bar ? 0 : 1);
 				const u16x2 rdeP = p_splat(rdgape);
-				uint8_t* rowp = pm + (uint64_t)i * W + (uint32_t)dd0;
+				const uint32_t nogap = bar ? (uint32_t)(PB_HE | PB_HF) * 0x10001u : 0u;      // no gaps in this row: H is never "from E" / "from F"
+				BT2_G uint8_t* rowp = (BT2_G uint8_t*)pm + (uint64_t)i * W + (uint32_t)dd0;
 #pragma unroll
 				for (int k = 0; k < RP; k++) {
 					const u16x2 hlP = p_from(shift_in(k > 0 ? p_bits(HP[k > 0 ? k - 1 : 0]) : prvH, p_bits(HP[k])));
 					const u16x2 elP = p_from(shift_in(k > 0 ? p_bits(EP[k > 0 ? k - 1 : 0]) : prvE, p_bits(EP[k])));
 					const u16x2 h = HP[k], e = EP[k], f = fP[k];
-					// bits of "differs": inverted at the end
-					u16x2 n = p_ne(h + penP[k], Hp[k]);                                      // PB_HD
-					n |= (p_ne(h, e) | (gaP ^ p_splat(1))) << 1;                             // PB_HE
-					n |= (p_ne(h, f) | (gaP ^ p_splat(1))) << 2;                             // PB_HF
-					n |= p_ne(e + rdoP, hlP) << 3;                                           // PB_EO
-					n |= p_ne(e + rdeP, elP) << 4;                                           // PB_EE
-					n |= p_ne(f + rfoP, HupP[k]) << 5;                                       // PB_FO
-					n |= p_ne(f + rfeP, FupP[k]) << 6;                                       // PB_FE
-					const u16x2 c = n ^ p_splat(0x7f);
-					*reinterpret_cast<uint16_t*>(rowp + 2 * k) = (uint16_t)(c.x | (c.y << 8));
+					// one "differs" bit per question and half, the highest first ((n << 1) | bit: one instruction each, the halves do not meet -- 7 bits); inverted at the end
+					uint32_t n = p_bits(p_ne(f + rfeP, FupP[k]));                                  // PB_FE
+					n = pk::shl1_or(n, p_bits(p_ne(f + rfoP, HupP[k])));                           // PB_FO
+					n = pk::shl1_or(n, p_bits(p_ne(e + rdeP, elP)));                               // PB_EE
+					n = pk::shl1_or(n, p_bits(p_ne(e + rdoP, hlP)));                               // PB_EO
+					n = pk::shl1_or(n, p_bits(p_ne(h, f)));                                        // PB_HF
+					n = pk::shl1_or(n, p_bits(p_ne(h, e)));                                        // PB_HE
+					n = pk::shl1_or(n, p_bits(p_ne(h + penP[k], Hp[k])));                          // PB_HD
+					const uint32_t c = (n | nogap) ^ k7f;
+					*reinterpret_cast<BT2_G uint16_t*>(rowp + 2 * k) = (uint16_t)__builtin_amdgcn_perm(0u, c, 0x0c0c0200u);      // bytes 0 and 2
 				}
 			}
 			// ---- next row ----
@@ -228,11 +238,10 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 				if (!__any((int)s_max(m.x, m.y) >= thr)) { rows_done = i + 1; return 0; }
 			}
 			{
-				int jc = jin < 0 ? 0 : jin; if (jc > (int)cols) jc = (int)cols;      // outside the window: any character will do (see above)
-				const uint32_t newel = (uint32_t)__builtin_ctz((uint32_t)dev_rf()[jc] | 16u) | 0x0c00u;
+				uint32_t newel = dpp0<kDppWaveShl1, 0xf>(refS[0]);
+				{ const int sq = __builtin_amdgcn_readlane((int)chq, (int)ii); asm("v_writelane_b32 %0, %1, 63" : "+v"(newel) : "s"(sq)); }
 #pragma unroll
 				for (int k = 0; k < RP; k++) refS[k] = shift_in(refS[k], k + 1 < RP ? refS[k + 1 < RP ? k + 1 : 0] : newel);
-				jin++;
 			}
 		}
 	}
@@ -580,7 +589,7 @@ struct DevPlat {
 	static __device__ __forceinline__ const PreComp* pre() { return &g_pre; }
 	static __device__ __forceinline__ AlState& st() { return g_st; }
 	// the wave's work area in HBM, typed as such (BT2_G, bt2g_device.hpp)
-	static __device__ __forceinline__ BT2_G Work& work() { return *(BT2_G Work*)g_st.wp; }
+	static __device__ __forceinline__ BT2_G Work& work() { return *(BT2_G Work*)uni((uint64_t)g_st.wp); }      // (base in scalar registers: the addresses of WK's members are scalar + offset)
 	template <typename TOff> static __device__ __forceinline__ const DevIndex<TOff>& index() { return *reinterpret_cast<const DevIndex<TOff>*>(g_ix_raw); }
 	static __device__ __forceinline__ uint64_t clock() { return (uint64_t)wall_clock64(); }
 	// The worker's control code computes the same value in every lane; uni() moves such a value into a
@@ -737,6 +746,13 @@ struct DevPlat {
 	static __device__ __forceinline__ uint32_t& lv(uint32_t& r, uint32_t) { return r; }
 	static __device__ __forceinline__ const uint32_t& lv(const uint32_t& r, uint32_t) { return r; }
 	static __device__ __forceinline__ uint64_t ballot(uint32_t r) { return (uint64_t)__ballot(r != 0u); }
+	// sum of a lane register over the wave
+	static __device__ __forceinline__ uint64_t lanes_sum(uint32_t r) {
+		uint64_t v = r;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o);
+		return uni(v);
+	}
 	static __device__ __forceinline__ uint32_t gather(uint32_t x, uint32_t idx) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)x); }
 	template <typename V, typename F> static __device__ __forceinline__ void tab_for_each(const V& k, const V& v, uint32_t n_, F f, uint32_t from_ = 0u) {
 		constexpr int K = sizeof(V) / 4;
@@ -1668,6 +1684,11 @@ __device__ __forceinline__ uint8_t* carve_scratch(DpScratch& dp, uint8_t* p, uin
 // past the seed tables
 __device__ __forceinline__ bool read_params_ok(const ReadParams& rp) { return rp.seedlen >= 1 && rp.seedlen <= 32 && rp.interval >= 1 && rp.nceil >= 0; }
 
+// Reads (pairs) a persistent wave takes from the queue per atomic.
+#ifndef BT2G_QCHUNK
+#define BT2G_QCHUNK 4
+#endif
+constexpr unsigned int kQueueChunk = BT2G_QCHUNK, kQueueChunkPairs = BT2G_QCHUNK > 2 ? 2 : BT2G_QCHUNK;
 #ifndef BT2G_WAVES_PER_EU
 #define BT2G_WAVES_PER_EU 2
 #endif
@@ -1691,10 +1712,15 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	g_st.rt_at = g_st.rf_at + hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.rt_cur = 0;
 	g_st.dyn_bytes = hot_tail_bytes(max_cols, P.match_bonus > 0) + rt_bytes + dyn_extra;
 	wave_fence();
+	// The queue head is ONE word that every wave of the device adds to: the waves take reads kQueueChunk at a time (see the note at kQueueChunk)
+	unsigned int r_next = 0, r_end = 0;
 	for (;;) {
-		unsigned int r = 0;
-		if (lane == 0) r = atomicAdd(next_read, 1u);
-		r = __shfl(r, 0);
+		if (r_next == r_end) {
+			unsigned int r0 = 0;
+			if (lane == 0) r0 = atomicAdd(next_read, kQueueChunk);
+			r_next = (unsigned int)__builtin_amdgcn_readfirstlane((int)r0); r_end = r_next + kQueueChunk;
+		}
+		const unsigned int r = r_next++;
 		if (r >= rd.n_reads) break;
 		const uint64_t o0 = rd.d_off[r];
 		const uint32_t len = (uint32_t)(rd.d_off[r + 1] - o0);
@@ -1747,10 +1773,14 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	(void)rt_bytes;
 	wave_fence();
 	const unsigned int n_pairs = rd.n_reads / 2;
+	unsigned int r_next = 0, r_end = 0;
 	for (;;) {
-		unsigned int r = 0;
-		if (lane == 0) r = atomicAdd(next_read, 1u);
-		r = __shfl(r, 0);
+		if (r_next == r_end) {
+			unsigned int r0 = 0;
+			if (lane == 0) r0 = atomicAdd(next_read, kQueueChunkPairs);
+			r_next = (unsigned int)__builtin_amdgcn_readfirstlane((int)r0); r_end = r_next + kQueueChunkPairs;
+		}
+		const unsigned int r = r_next++;
 		if (r >= n_pairs) break;
 		const uint64_t o0 = rd.d_off[2 * r], o1 = rd.d_off[2 * r + 1], o2 = rd.d_off[2 * r + 2];
 		const uint32_t len0 = (uint32_t)(o1 - o0), len1 = (uint32_t)(o2 - o1);

@@ -186,6 +186,7 @@ struct HostPlat {
 	static uint32_t lanes_step() { return 1; }
 	static uint32_t& lv(LaneReg& r, uint32_t l) { return r.v[l]; }
 	static const uint32_t& lv(const LaneReg& r, uint32_t l) { return r.v[l]; }
+	static uint64_t lanes_sum(const LaneReg& r) { uint64_t v = 0; for (uint32_t l = 0; l < 64; l++) v += r.v[l]; return v; }
 	static uint64_t ballot(const LaneReg& r) { uint64_t m = 0; for (uint32_t l = 0; l < 64; l++) if (r.v[l]) m |= 1ull << l; return m; }
 	static LaneReg gather(const LaneReg& x, const LaneReg& idx) { LaneReg r; for (uint32_t l = 0; l < 64; l++) r.v[l] = x.v[idx.v[l] & 63u]; return r; }
 	template <typename T, typename F> static void tab_for_each(const T& k, const T& v, uint32_t n, F f, uint32_t from = 0) { for (uint32_t e = from; e < n; e++) f(e, k[e >> 6].v[e & 63], v[e >> 6].v[e & 63]); }
