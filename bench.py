@@ -406,11 +406,13 @@ def write_fastq_fixed(path, seq, qual, names, append=False, at=None):
 # batches take their parameters from it through bt2g_cli_params (the drop-in binary's own option parser), the reference and the product
 # binary of the parity check are run with it.
 CONFIGS = {
-    "se150":    {"args": ["--sensitive"], "paired": False, "readlen": 150, "reads": 2_000_000, "cpu_sample": 1_000_000,
+    "se150":    {"args": ["--sensitive"], "paired": False, "readlen": 150, "reads": 2_000_000, "cpu_sample": 1_000_000, "pipeline": 2,
                  "what": "--sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"},
     # "pipeline": steps in flight.  A batch of pairs or of long --local reads ends in a tail -- a few pathological reads keep a handful of the
     # 4096 waves busy for hundreds of ms after the rest are done -- which the next batch's waves fill when two batches are in flight (as in
-    # the product driver, whose device-stage threads each issue their batch on their own stream).  The headline has no such tail: 1.
+    # the product driver, whose device-stage threads each issue their batch on their own stream).  The headline has no such tail, but since round 6
+    # its worker launches 18 of the 20 waves a CU holds (the kernel's throughput saturates at 16), and the lane-per-task FM kernels of the next
+    # batch -- random index reads, no LDS -- run in the room that leaves: 330.6 -> 306.9 ms per step with two in flight (profiles/r06x_*).
     "pe-sens":  {"args": ["--sensitive"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 400_000, "pipeline": 3,
                  "what": "pairs, --sensitive, --fr -I 0 -X 500"},
     "pe-vsens": {"args": ["--very-sensitive", "-X", "500"], "paired": True, "readlen": 150, "reads": 400_000, "cpu_sample": 200_000, "pipeline": 3, "reps": 3,
@@ -418,7 +420,7 @@ CONFIGS = {
     "local400": {"args": ["--local"], "paired": False, "readlen": 400, "reads": 200_000, "cpu_sample": 100_000, "pipeline": 2,
                  "what": "--local = --sensitive-local (-D 15 -R 2 -N 0 -L 20 -i S,1,0.75, --ma 2, --score-min G,20,8)"},
     # BASELINE.json configs[1]: a bacterial genome behind a small (.bt2: 64-byte sides, 32-bit offsets) index -- the uint32_t instantiations
-    "ecoli100": {"args": ["--sensitive"], "paired": False, "readlen": 100, "reads": 1_000_000, "cpu_sample": 1_000_000, "genome": "ecoli",
+    "ecoli100": {"args": ["--sensitive"], "paired": False, "readlen": 100, "reads": 1_000_000, "cpu_sample": 1_000_000, "genome": "ecoli", "pipeline": 2,
                  "what": "default preset = --sensitive (-D 15 -R 2 -N 0 -L 22 -i S,1,1.15), end-to-end"},
 }
 

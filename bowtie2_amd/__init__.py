@@ -60,7 +60,7 @@ class DpOut(C.Structure):
                 ("has_matrix", C.c_uint32), ("pad", C.c_uint32)]
 
 
-DP_EE_U8, DP_EE_I16, DP_LOCAL = 0, 1, 2
+DP_EE_U8, DP_EE_I16, DP_LOCAL, DP_EE_I16_BAND = 0, 1, 2, 3
 
 
 class Mm1Hit(C.Structure):      # bt2g_mm1_hit

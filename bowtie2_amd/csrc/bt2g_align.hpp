@@ -479,6 +479,7 @@ struct AlState {
 	// device: the reportedThrough plane of the band matrix in hand, in the launch's dynamic LDS when it has room (DevPlat::rt_begin):
 	// LDS address, capacity in bytes, "this matrix's marks are on chip"
 	uint32_t  rt_at, rt_bytes, rt_cur;
+	uint32_t  wide_cells;             // device, the fill stage only: 1 = a 16-bit end-to-end problem is filled in the anti-diagonal cell form even where the band form fits (BT2G_DP_EE_I16)
 	uint32_t  dyn_bytes;              // device: bytes of dynamic LDS this launch has from rf_at on (tail + marks): between DP windows the row sampler keeps its hash tables there
 	uint32_t  fill_rows_done, fill_lastsol, fill_sat8;   // device: what a leaf fill hands back besides its return value (row the score-only pass stopped in; lastsolcol_ / "8-bit kernel saturated" of a local fill)
 };

@@ -2561,9 +2561,11 @@ struct Aligner {
 							lastsolcol = Plat::uni(lastsolcol);
 							sse16 = Plat::uni(sat8) != 0;
 						} else {
-							mode = minsc_now < -254 ? 1 : 0;
-							sse16 = mode == 1;
-							best = Plat::uni(Plat::dp_fill_ee(PRM, WK, fw, rows, cols, ST.dp, mode != 0, minsc_now));
+							// below -254 the reference's 16-bit kernel: the device fills it on the band like the 8-bit one wherever the band fits (matrix format 0,
+							// the 16-bit kernel's RNG protocol), else -- and on the CPU twin -- in the anti-diagonal cell format (1)
+							sse16 = minsc_now < -254;
+							mode = (sse16 && !Plat::ee_wide_band(rows, cols, minsc_now)) ? 1 : 0;
+							best = Plat::uni(Plat::dp_fill_ee(PRM, WK, fw, rows, cols, ST.dp, sse16, minsc_now));
 							if (best == INT64_MIN) { ovf(31); return EXT_HARD_LIMIT; }
 						}
 						HOT.t_phase[5] += tnow() - td_;

@@ -95,8 +95,15 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true); }
 constexpr int kDppRowShr = 0x110, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
 
-template <int RP, bool PRED>
+// W16: the same recurrence in the reference's 16-bit representation (alignNucleotidesEnd2EndSseI16, aligner_swsse_ee_i16.cpp:780-1146: scores biased
+// by 0x7fff in signed 16 bits, -32768 = minus infinity, saturating subtraction, barrier rows veto gap opens / extensions) -- as unsigned 16-bit
+// values that is a bias of 0xffff instead of 0xff and nothing else: the same saturating arithmetic, the same seven questions per cell.  (Round 6:
+// reads whose minimum score is below -254, i.e. longer than 423 bp at the default threshold, used to be filled on the anti-diagonal wavefront
+// with 8 bytes per cell of the whole rectangle, fill_ee_i16_wave below; that form stays for bands wider than 2 048 diagonals.)
+template <int RP, bool PRED, bool W16>
 __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, int lo, int thr, uint8_t* __restrict__ pm, uint32_t& rows_done) {
+	constexpr uint32_t kBias = W16 ? 0xffffu : 0xffu;
+	constexpr int kLastLo = W16 ? -32768 : -0xff;      // last-row score of a column the band does not reach (the scores go to a 16-bit row: < any minimum score)
 	rows_done = rows;
 	constexpr int N2 = 2 * RP;
 	constexpr uint32_t W = 128u * RP;
@@ -114,11 +121,11 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 			const bool real = (uint32_t)j < cols;
 			const uint32_t code = real ? (uint32_t)__builtin_ctz((uint32_t)dev_rf()[real ? j : 0] | 16u) : 4u;
 			sel |= (code | 0x0c00u) << (16 * hh);
-			h |= (real ? 0xffu : 0u) << (16 * hh);       // "row -1": an alignment may start in any column of row 0
+			h |= (real ? kBias : 0u) << (16 * hh);       // "row -1": an alignment may start in any column of row 0
 		}
 		refS[k] = sel; Hp[k] = p_from(h); Fp[k] = p_splat(0);
 	}
-	if (PRED) for (uint32_t j = (uint32_t)lane; j < cols; j += 64) dev_lastrow()[j] = (int16_t)-0xff;      // columns the band does not reach in the last row
+	if (PRED) for (uint32_t j = (uint32_t)lane; j < cols; j += 64) dev_lastrow()[j] = (int16_t)kLastLo;      // columns the band does not reach in the last row
 	// (the parameter block is read from LDS: its fields arrive in vector registers and count as lane-varying until said otherwise)
 	const int rdgape = __builtin_amdgcn_readfirstlane(P.rdgape), rdgapo = __builtin_amdgcn_readfirstlane(P.rdgapo), gapbar = __builtin_amdgcn_readfirstlane(P.gapbar);
 	const u16x2 rdoP = p_splat(rdgapo), rfoP = p_splat(__builtin_amdgcn_readfirstlane(P.rfgapo)), rfeP = p_splat(__builtin_amdgcn_readfirstlane(P.rfgape));
@@ -128,7 +135,7 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 	// The column that enters a lane's last diagonal in the next row is the column of the NEXT lane's first diagonal in this row: one DPP move.
 	// Only the wave's last diagonal gets a column nobody holds yet, 64 * N2 - lo + i after row i: lane ii of every 64-row chunk fetches the one of its row.
 	const int jin63 = 64 * N2 - lo;
-	auto cap = [](uint32_t v) -> unsigned short { return (unsigned short)(v > 1023u ? 1023u : v); };     // scores are <= 255: any larger decay is "to zero"
+	auto cap = [](uint32_t v) -> unsigned short { constexpr uint32_t m = W16 ? 0xffffu : 1023u; return (unsigned short)(v > m ? m : v); };     // scores are <= the bias: any larger decay is "to zero"
 	// The scan over the lanes' carries: E decays by D = 2RP * rdgape from one lane to the next, so with Y_l = carry_l + l * D the decayed
 	// maximum  max_{l' <= l} (carry_l' - (l - l') D)  is  (prefix-max of Y)_l - l * D  -- a PLAIN prefix maximum, whose DPP steps are
 	// single v_max_u32 instructions with a DPP operand (no subtraction between the move and the max).  No saturation is needed: the term
@@ -254,7 +261,7 @@ __device__ __forceinline__ int fill_ee_u8_band(const AlignParams& P, bool fw, ui
 		for (int hh = 0; hh < 2; hh++) {
 			const int j = jl0 + 2 * k + hh;
 			const int h = hh ? (int)HP[k].y : (int)HP[k].x;
-			if ((uint32_t)j < cols) { best = imax(best, h); if (PRED) dev_lastrow()[j] = (int16_t)(h - 0xff); }
+			if ((uint32_t)j < cols) { best = imax(best, h); if (PRED) dev_lastrow()[j] = (int16_t)imax(h - (int)kBias, kLastLo); }
 		}
 	}
 #pragma unroll
@@ -542,7 +549,7 @@ __device__ __forceinline__ int fill_local_pk(const AlignParams& P, bool fw, uint
 // Arguments of a real call arrive in vector registers and are lane-varying to the compiler: every leaf passes them through
 // v_readfirstlane once; the parameter block is read from its LDS object by name.  The row the score-only pass stopped in comes back
 // through g_st.fill_rows_done.
-template <int RP, bool PRED>
+template <int RP, bool PRED, bool W16 = false>
 __device__ __attribute__((noinline)) int fill_ee_u8_leaf(bool fw_, uint32_t rows_, uint32_t cols_, int lo_, int thr_, uint8_t* pm_) {
 	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
 	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
@@ -550,7 +557,7 @@ __device__ __attribute__((noinline)) int fill_ee_u8_leaf(bool fw_, uint32_t rows
 	const uint64_t pa = (uint64_t)reinterpret_cast<uintptr_t>(pm_);
 	uint8_t* pm = reinterpret_cast<uint8_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa));
 	uint32_t rows_done = rows;
-	const int best = fill_ee_u8_band<RP, PRED>(g_P, fw, rows, cols, lo, thr, pm, rows_done);
+	const int best = fill_ee_u8_band<RP, PRED, W16>(g_P, fw, rows, cols, lo, thr, pm, rows_done);
 	if (!PRED && (threadIdx.x & 63) == 0) g_st.fill_rows_done = rows_done;
 	return best;
 }
@@ -1577,6 +1584,26 @@ struct DevPlat {
 	// compiler must treat both as lane-varying, and every loop bound or condition derived from them becomes exec-mask control flow and
 	// vector arithmetic.  So: the parameter block and the scratch descriptor are read from their LDS objects BY NAME, the scalar arguments
 	// go through v_readfirstlane once.)  A thin dispatcher: the fills themselves are leaf functions (fill_ee_u8_leaf).
+	// Does a 16-bit end-to-end problem of this shape go through the band fill (predecessor bytes; the backtrace then takes the 8-bit fill's path,
+	// with the 16-bit kernel's RNG protocol) or -- a band of more than 2 048 diagonals -- through the anti-diagonal fill of the whole rectangle?
+	static __device__ __forceinline__ bool ee_wide_band(uint32_t rows, uint32_t cols, int64_t minsc) {
+		EeBand band;
+		if (!ee_band(uni(g_P.rfgapo), uni(g_P.rfgape), uni(rows), uni(cols), uni(minsc), band)) return true;      // (no cell can reach minsc: no matrix either way)
+		return ee_band_rp(band.nd) != 0u;
+	}
+	template <bool PRED, bool W16>
+	static __device__ __forceinline__ int band_leaf(uint32_t rp, bool fw, uint32_t rows, uint32_t cols, int lo, int thr, uint8_t* pm) {
+		switch (rp) {
+			case 1: return fill_ee_u8_leaf<1, PRED, W16>(fw, rows, cols, lo, thr, pm);
+			case 2: return fill_ee_u8_leaf<2, PRED, W16>(fw, rows, cols, lo, thr, pm);
+			case 3: return fill_ee_u8_leaf<3, PRED, W16>(fw, rows, cols, lo, thr, pm);
+			case 4: return fill_ee_u8_leaf<4, PRED, W16>(fw, rows, cols, lo, thr, pm);
+			case 6: return fill_ee_u8_leaf<6, PRED, W16>(fw, rows, cols, lo, thr, pm);
+			case 8: return fill_ee_u8_leaf<8, PRED, W16>(fw, rows, cols, lo, thr, pm);
+			case 12: return fill_ee_u8_leaf<12, PRED, W16>(fw, rows, cols, lo, thr, pm);
+			default: return fill_ee_u8_leaf<16, PRED, W16>(fw, rows, cols, lo, thr, pm);
+		}
+	}
 	static __device__ __attribute__((noinline)) int64_t dp_fill_ee(const AlignParams&, Work&, bool fw_, uint32_t rows_, uint32_t cols_, const DpScratch&, bool wide_, int64_t minsc_) {
 		wave_fence();     // w.rf / read written by the scalar code -> visible to every lane
 		const AlignParams& P = g_P;
@@ -1586,18 +1613,19 @@ struct DevPlat {
 		const int64_t minsc = uni(minsc_);
 		uint32_t* mat = uni_ptr(dp.mat);
 		int best;
-		if (!wide) {
+		if (!wide || (ee_wide_band(rows, cols, minsc) && !uni(g_st.wide_cells))) {
 			uint8_t* pm = reinterpret_cast<uint8_t*>(mat);
+			const int bias = wide ? 0xffff : 0xff;
 			EeBand band;
-			if (!ee_band(P.rfgapo, P.rfgape, rows, cols, minsc, band)) return -0xff;      // no cell can lie on an alignment that reaches minsc
+			if (!ee_band(P.rfgapo, P.rfgape, rows, cols, minsc, band)) return -(int64_t)bias;      // no cell can lie on an alignment that reaches minsc
 			const uint32_t rp = ee_band_rp(band.nd);
 			if (rp == 0) return INT64_MIN;
 			const int lo = band.lo;
-			const int thr = (int)(minsc + 0xff);      // biased score an alignment must keep (>= 1: the 8-bit kernel is only used while minsc >= -254)
+			const int thr = (int)(minsc + bias);      // biased score an alignment must keep (>= 1: the 8-bit kernel is only used while minsc >= -254, and no read is long enough for -65 534)
 			// pass 1: can any end-to-end alignment in this window reach the minimum score at all?  A lower bound on the best score costs
 			// almost nothing: the gap-free alignment along the window's middle diagonal (the seed's own diagonal unless the window was
 			// trimmed at a reference end) is one of the alignments the fill maximises over -- it lies inside the band, and while its score
-			// stays >= minsc >= -254 nothing on it saturates.  When it already reaches minsc (a read without an indel at its true locus, or
+			// stays >= minsc nothing on it saturates.  When it already reaches minsc (a read without an indel at its true locus, or
 			// at a close copy: most windows that succeed at all) the score-only pass has nothing left to decide and is skipped.
 			bool skip1 = false;
 			if (cols >= rows) {
@@ -1614,35 +1642,17 @@ struct DevPlat {
 				skip1 = (int64_t)(-uni(pen)) >= minsc;
 			}
 			if (skip1) best = thr;      // (any value that passes the test below: the matrix pass computes the real one)
-			else switch (rp) {
-				case 1: best = fill_ee_u8_leaf<1, false>(fw, rows, cols, lo, thr, pm); break;
-				case 2: best = fill_ee_u8_leaf<2, false>(fw, rows, cols, lo, thr, pm); break;
-				case 3: best = fill_ee_u8_leaf<3, false>(fw, rows, cols, lo, thr, pm); break;
-				case 4: best = fill_ee_u8_leaf<4, false>(fw, rows, cols, lo, thr, pm); break;
-				case 6: best = fill_ee_u8_leaf<6, false>(fw, rows, cols, lo, thr, pm); break;
-				case 8: best = fill_ee_u8_leaf<8, false>(fw, rows, cols, lo, thr, pm); break;
-				case 12: best = fill_ee_u8_leaf<12, false>(fw, rows, cols, lo, thr, pm); break;
-				default: best = fill_ee_u8_leaf<16, false>(fw, rows, cols, lo, thr, pm); break;
-			}
+			else best = wide ? band_leaf<false, true>(rp, fw, rows, cols, lo, thr, pm) : band_leaf<false, false>(rp, fw, rows, cols, lo, thr, pm);
 			best = uni(best);
 			wave_fence();
 			const uint32_t rows_done = skip1 ? 0u : uni(g_st.fill_rows_done);
 			g_hot.n_dp_cells_score += rows_done * band.nd;
-			if ((int64_t)best - 0xff < minsc) { wave_fence(); return (int64_t)best - 0xff; }
+			if ((int64_t)best - bias < minsc) { wave_fence(); return (int64_t)best - bias; }
 			g_hot.n_dp_cells_full += rows * band.nd; g_hot.n_dp_pass++;
 			// pass 2: the matrix of predecessor bits (same scores, so `best` is unchanged)
 			if ((threadIdx.x & 63) == 0) { dp.epoch[1] = (uint32_t)lo; dp.epoch[2] = 128u * rp; }
-			switch (rp) {
-				case 1: best = fill_ee_u8_leaf<1, true>(fw, rows, cols, lo, thr, pm); break;
-				case 2: best = fill_ee_u8_leaf<2, true>(fw, rows, cols, lo, thr, pm); break;
-				case 3: best = fill_ee_u8_leaf<3, true>(fw, rows, cols, lo, thr, pm); break;
-				case 4: best = fill_ee_u8_leaf<4, true>(fw, rows, cols, lo, thr, pm); break;
-				case 6: best = fill_ee_u8_leaf<6, true>(fw, rows, cols, lo, thr, pm); break;
-				case 8: best = fill_ee_u8_leaf<8, true>(fw, rows, cols, lo, thr, pm); break;
-				case 12: best = fill_ee_u8_leaf<12, true>(fw, rows, cols, lo, thr, pm); break;
-				default: best = fill_ee_u8_leaf<16, true>(fw, rows, cols, lo, thr, pm); break;
-			}
-			best = uni(best) - 0xff;
+			best = wide ? band_leaf<true, true>(rp, fw, rows, cols, lo, thr, pm) : band_leaf<true, false>(rp, fw, rows, cols, lo, thr, pm);
+			best = uni(best) - bias;
 		} else {
 			uint64_t* m64 = reinterpret_cast<uint64_t*>(mat);
 			switch (dp_R(rows)) {
@@ -1709,7 +1719,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
-	g_st.rt_at = g_st.rf_at + hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.rt_cur = 0;
+	g_st.rt_at = g_st.rf_at + hot_tail_bytes(max_cols, P.match_bonus > 0); g_st.rt_bytes = rt_bytes; g_st.rt_cur = 0; g_st.wide_cells = 0;
 	g_st.dyn_bytes = hot_tail_bytes(max_cols, P.match_bonus > 0) + rt_bytes + dyn_extra;
 	wave_fence();
 	// The queue head is ONE word that every wave of the device adds to: the waves take reads kQueueChunk at a time (see the note at kQueueChunk)
@@ -1768,7 +1778,7 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	__shared__ alignas(16) unsigned char s_al[sizeof(Aligner<TOff, DevPlat>)];
 	*reinterpret_cast<DevIndex<TOff>*>(g_ix_raw) = ix; g_P = P; g_pre = pre;
 	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
-	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0;      // (two matrices in flight: their marks stay in the arena)
+	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0; g_st.wide_cells = 0;      // (two matrices in flight: their marks stay in the arena)
 	g_st.dyn_bytes = hot_tail_bytes(max_cols, P.match_bonus > 0) + dyn_extra;
 	(void)rt_bytes;
 	wave_fence();
@@ -1871,7 +1881,7 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 	const uint32_t lane = threadIdx.x & 63;
 	g_P = P;
 	g_st.max_cols = max_cols; g_st.rf_at = lds_addr_of_tail(); g_st.ned_at = g_st.rf_at + hot_tail_off(max_cols);
-	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0; g_st.dyn_bytes = 0;
+	g_st.rt_at = 0; g_st.rt_bytes = 0; g_st.rt_cur = 0; g_st.dyn_bytes = 0; g_st.wide_cells = 0;
 	DpScratch dp;
 	carve_scratch(dp, scratch + (uint64_t)blockIdx.x * scratch_stride, mat_bytes, mask_bytes, pmask_bytes);
 	g_st.dp = dp; g_st.wp = (BT2_G Work*)scratch; g_st.emit_on = 0;      // (the fills do not touch the work area)
@@ -1889,21 +1899,30 @@ k_dp_fill(AlignParams P, const bt2g_dp_problem* __restrict__ probs, uint32_t n, 
 		int64_t best;
 		uint32_t lastsolcol = 0, sat8 = 0;
 		if (pr.kind == BT2G_DP_LOCAL) best = DevPlat::dp_fill_local(g_P, *g_st.wp_generic(), true, rows, cols, (uint32_t*)dp.mat, (int64_t)pr.minsc, lastsolcol, sat8);
-		else best = DevPlat::dp_fill_ee(g_P, *g_st.wp_generic(), true, rows, cols, dp, pr.kind == BT2G_DP_EE_I16, (int64_t)pr.minsc);
+		else {
+			// BT2G_DP_EE_I16: the anti-diagonal form with its H / E / F cells; BT2G_DP_EE_I16_BAND: the 16-bit arithmetic on the band (what the worker uses wherever the band fits)
+			const bool band_form = pr.kind == BT2G_DP_EE_U8 || pr.kind == BT2G_DP_EE_I16_BAND;
+			if ((threadIdx.x & 63) == 0) g_st.wide_cells = pr.kind == BT2G_DP_EE_I16 ? 1u : 0u;
+			wave_fence();
+			best = (pr.kind == BT2G_DP_EE_I16_BAND && !DevPlat::ee_wide_band(rows, cols, (int64_t)pr.minsc)) ? INT64_MIN
+			     : DevPlat::dp_fill_ee(g_P, *g_st.wp_generic(), true, rows, cols, dp, pr.kind != BT2G_DP_EE_U8, (int64_t)pr.minsc);
+			(void)band_form;
+		}
 		wave_fence();
-		const bool has_mat = pr.kind != BT2G_DP_EE_U8 || (best != INT64_MIN && best >= (int64_t)pr.minsc);
+		const bool band_kind = pr.kind == BT2G_DP_EE_U8 || pr.kind == BT2G_DP_EE_I16_BAND;
+		const bool has_mat = !band_kind || (best != INT64_MIN && best >= (int64_t)pr.minsc);
 		const int32_t band_lo = (int32_t)dp.epoch[1];
 		const uint32_t band_w = dp.epoch[2];
 		if (lane == 0) {
 			out->best = best; out->lastsolcol = lastsolcol; out->sat8 = sat8; out->pad = 0;
-			out->band_lo = pr.kind == BT2G_DP_EE_U8 && has_mat ? band_lo : 0; out->band_w = pr.kind == BT2G_DP_EE_U8 && has_mat ? band_w : 0;
+			out->band_lo = band_kind && has_mat ? band_lo : 0; out->band_w = band_kind && has_mat ? band_w : 0;
 			out->has_matrix = has_mat ? 1u : 0u;
 		}
 		BT2_G uint8_t* body = (BT2_G uint8_t*)(d_out + pr.out_off + sizeof(bt2g_dp_out));
-		if (pr.kind == BT2G_DP_EE_U8) {
+		if (band_kind) {
 			const uint32_t c4 = (cols + 3u) & ~3u;
 			BT2_G int16_t* lr = (BT2_G int16_t*)body;
-			for (uint32_t j = lane; j < c4; j += 64) lr[j] = (has_mat && j < cols) ? dev_lastrow()[j] : (int16_t)-0xff;
+			for (uint32_t j = lane; j < c4; j += 64) lr[j] = (has_mat && j < cols) ? dev_lastrow()[j] : (int16_t)(pr.kind == BT2G_DP_EE_U8 ? -0xff : -32768);
 			if (has_mat) {
 				BT2_G uint8_t* pm = body + (uint64_t)c4 * 2;
 				const BT2_G uint8_t* src = (const BT2_G uint8_t*)dp.mat;

@@ -545,7 +545,7 @@ void bt2g_scoring_default(bt2g_scoring* sc) {
 
 uint64_t bt2g_dp_out_bytes(uint32_t kind, uint32_t rows, uint32_t cols) {
 	uint64_t b = sizeof(bt2g_dp_out);
-	if (kind == BT2G_DP_EE_U8) b += (uint64_t)((cols + 3u) & ~3u) * 2 + pred_cells(rows ? rows : 1, cols ? cols : 1);      // the widest band the problem can have
+	if (kind == BT2G_DP_EE_U8 || kind == BT2G_DP_EE_I16_BAND) b += (uint64_t)((cols + 3u) & ~3u) * 2 + pred_cells(rows ? rows : 1, cols ? cols : 1);      // the widest band the problem can have
 	else if (kind == BT2G_DP_LOCAL) b += (uint64_t)rows * cols;      // one predecessor byte per cell
 	else b += (uint64_t)rows * cols * 3 * 4;
 	return (b + 7) & ~(uint64_t)7;
@@ -568,7 +568,7 @@ int bt2g_dp_fill(bt2g_ctx* c, const bt2g_scoring* sc, const bt2g_dp_problem* d_p
 	for (const auto& p : hp) {
 		if (p.rows == 0 || p.cols == 0 || p.rows > (uint32_t)kMaxLen || p.cols + 1 > (uint32_t)kMaxColsWide) return fail(c, BT2G_ERR_UNSUPPORTED, "DP problem outside 1..512 rows x 1..2175 columns");
 		if (p.cols + 1 > max_cols) max_cols = (uint32_t)kMaxColsWide;       // (wide windows: the launch holds more per-column state in LDS)
-		if (p.kind > BT2G_DP_LOCAL || (p.out_off & 7)) return fail(c, BT2G_ERR_ARG, "bad DP problem (kind / output offset)");
+		if (p.kind > BT2G_DP_EE_I16_BAND || (p.out_off & 7)) return fail(c, BT2G_ERR_ARG, "bad DP problem (kind / output offset)");
 		if (p.rows > max_rows) max_rows = p.rows;
 	}
 	uint64_t mat_bytes, mask_bytes, pmask_bytes, stride;

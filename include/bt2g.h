@@ -188,6 +188,8 @@ typedef struct {
 #define BT2G_DP_EE_U8   0     /* alignNucleotidesEnd2EndSseU8  (aligner_swsse_ee_u8.cpp:775-1146)  */
 #define BT2G_DP_EE_I16  1     /* alignNucleotidesEnd2EndSseI16 (aligner_swsse_ee_i16.cpp:780-1170) */
 #define BT2G_DP_LOCAL   2     /* alignNucleotidesLocalSseU8 / ...I16 (aligner_swsse_loc_u8.cpp:927, aligner_swsse_loc_i16.cpp:938) */
+#define BT2G_DP_EE_I16_BAND 3 /* the 16-bit end-to-end kernel's arithmetic on the band of diagonals an alignment can touch, predecessor bits stored: the form the
+                                 worker uses for reads whose minimum score is below -254 wherever the band has at most 2 048 diagonals */
 
 /* what a problem's output block starts with */
 typedef struct {
@@ -210,6 +212,8 @@ typedef struct {
  *                   H/E/F, aligner_swsse_ee_u8.cpp:1330-1520); only cells inside the band are meaningful;
  *   BT2G_DP_EE_I16: int32 H[rows*cols], E[...], F[...] row-major, the cell values of the reference's 16-bit kernel
  *                   (0x7fff = perfect, -32768 = minus infinity);
+ *   BT2G_DP_EE_I16_BAND: as BT2G_DP_EE_U8 (last row clamped at -32768, predecessor bits of the band); best = INT64_MIN where the band
+ *                   does not fit and the worker falls back to the BT2G_DP_EE_I16 form;
  *   BT2G_DP_LOCAL : rows * cols bytes of predecessor bits, row-major, the same seven questions with the local kernels' `> floor`
  *                   rule folded in (a neighbour whose score is 0 is no predecessor, aligner_swsse_loc_u8.cpp:1530-1660) -- what
  *                   the worker's local fill stores instead of scores; best / lastsolcol / sat8 in the header carry what the worker

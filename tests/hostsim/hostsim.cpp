@@ -186,6 +186,7 @@ struct HostPlat {
 	static uint32_t lanes_step() { return 1; }
 	static uint32_t& lv(LaneReg& r, uint32_t l) { return r.v[l]; }
 	static const uint32_t& lv(const LaneReg& r, uint32_t l) { return r.v[l]; }
+	static bool ee_wide_band(uint32_t, uint32_t, int64_t) { return false; }      // (the twin fills 16-bit end-to-end problems in the cell format)
 	static uint64_t lanes_sum(const LaneReg& r) { uint64_t v = 0; for (uint32_t l = 0; l < 64; l++) v += r.v[l]; return v; }
 	static uint64_t ballot(const LaneReg& r) { uint64_t m = 0; for (uint32_t l = 0; l < 64; l++) if (r.v[l]) m |= 1ull << l; return m; }
 	static LaneReg gather(const LaneReg& x, const LaneReg& idx) { LaneReg r; for (uint32_t l = 0; l < 64; l++) r.v[l] = x.v[idx.v[l] & 63u]; return r; }

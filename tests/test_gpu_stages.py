@@ -272,7 +272,7 @@ def run_dp_fill(ctx, probs, scoring=None):
         hdr = b.DpOut.from_buffer_copy(raw[o:o + C.sizeof(b.DpOut)])
         body = o + C.sizeof(b.DpOut)
         r = {"best": hdr.best, "lastsolcol": hdr.lastsolcol, "sat8": hdr.sat8, "band_lo": hdr.band_lo, "band_w": hdr.band_w, "has_matrix": hdr.has_matrix}
-        if p[0] == b.DP_EE_U8:
+        if p[0] in (b.DP_EE_U8, b.DP_EE_I16_BAND):
             c4 = (cols + 3) & ~3
             r["lastrow"] = np.frombuffer(raw[body:body + 2 * c4], dtype="<i2")[:cols]
             if hdr.has_matrix:
@@ -299,7 +299,7 @@ def oracle_fill_kind(L, kind, sc, rd, phred, rf, cols, minsc):
     return got, flag.value, colstop.value, [np.frombuffer(x, dtype="<i4").reshape(rows, cols) for x in bufs]
 
 
-def pred_bits_from_hef(sc, rd, phred, rf, H, E, F, L):
+def pred_bits_from_hef(sc, rd, phred, rf, H, E, F, L, bias=0xff):
     """The predecessor byte of every cell from the oracle's H/E/F (the reference's u8 encoding): the questions the reference's backtrace
     asks of its matrices (aligner_swsse_ee_u8.cpp:1330-1520), as the band fill answers them while the neighbours are in registers
     (PB_* in bt2g_align.hpp): 1 H came diagonally, 2 H == E, 4 H == F (both only where gaps are allowed), 8 E opens from H-left,
@@ -315,7 +315,7 @@ def pred_bits_from_hef(sc, rd, phred, rf, H, E, F, L):
             m = rf[j]
             pen = -L.bt2o_score(C.byref(sc), rd[i], m, phred[i])
             h, e, f = int(H[i, j]), int(E[i, j]), int(F[i, j])
-            hdiag = 0xff if i == 0 else (0 if j == 0 else int(H[i - 1, j - 1]))
+            hdiag = bias if i == 0 else (0 if j == 0 else int(H[i - 1, j - 1]))
             hl, el = (int(H[i, j - 1]), int(E[i, j - 1])) if j > 0 else (0, 0)
             hu, fu = (int(H[i - 1, j]), int(F[i - 1, j])) if i > 0 else (0, 0)
             c = 1 if hdiag - pen == h else 0
@@ -431,7 +431,48 @@ def test_dp_fills_that_ship(case):
         else:
             assert r["best"] < minsc and r["has_matrix"] == 0, (rows, cols, minsc, r["best"], want)
     assert n_pass >= 8
-    # ---- 16-bit end to end and local: every cell, on the reference-recorded problems of tests/golden/dp_kinds_golden.json + random shapes
+    # ---- the 16-bit end-to-end kernel's arithmetic on the band (what the worker runs for minimum scores below -254 wherever the band has at most
+    #      2 048 diagonals): band = the whole rectangle (every predecessor byte checked against the oracle's 16-bit matrices, as unsigned values
+    #      with a bias of 0xffff), and real bands of long reads (best and every last-row score that reaches minsc)
+    osc = Scoring()
+    L.bt2o_scoring_default(C.byref(osc))
+    probs, shapes = [], []
+    for rows, cols in [(1, 1), (2, 5), (30, 61), (64, 64), (84, 100), (70, 200), (84, 400), (60, 640), (84, 900)]:
+        rdc, phred, rfm = problem(rows, cols, n_at=(cols // 3 if cols > 40 else None))
+        probs.append((b.DP_EE_I16_BAND, rdc, bytes(q + 33 for q in phred), rfm, -300))      # 99 reference gaps: every diagonal of a <= 84-row problem
+        shapes.append((rdc, phred, rfm))
+    for rows, cols, minsc, match in [(300, 361, -181, 0.93), (450, 511, -271, 0.95), (450, 511, -271, 0.7), (512, 573, -308, 0.96), (500, 1200, -301, 0.94)]:
+        rdc, phred, rfm = problem(rows, cols, match)
+        probs.append((b.DP_EE_I16_BAND, rdc, bytes(q + 33 for q in phred), rfm, minsc))
+        shapes.append((rdc, phred, rfm))
+    res = run_dp_fill(ctx, probs)
+    n_full = n_pass = 0
+    for (kind, rdc, qa, rfm, minsc), (rdc_, phred, _), r in zip(probs, shapes, res):
+        rows, cols = len(rdc), len(rfm) - 1
+        got, flag, colstop, (H, E, F) = oracle_fill_kind(L, 1, osc, rdc, phred, rfm, cols, minsc)
+        want = int(H[rows - 1].max()) - 0x7fff
+        Hu, Eu, Fu = H + 32768, E + 32768, F + 32768      # signed 16-bit with bias 0x7fff -> unsigned with bias 0xffff (0 = minus infinity)
+        if want < minsc:
+            assert r["best"] < minsc and r["has_matrix"] == 0, (rows, cols, minsc, r["best"], want)
+            continue
+        assert r["best"] == want and r["has_matrix"] == 1, (rows, cols, minsc, r["best"], want)
+        n_pass += 1
+        for j in range(cols):
+            v = int(Hu[rows - 1, j]) - 0xffff
+            if v >= minsc:
+                assert int(r["lastrow"][j]) == v, (rows, cols, j)
+            else:
+                assert int(r["lastrow"][j]) < minsc, (rows, cols, j)
+        if rows <= 84:
+            assert r["band_lo"] == rows - 1 and r["band_w"] >= rows + cols - 1, (rows, cols, r["band_lo"], r["band_w"])
+            want_pred = pred_bits_from_hef(osc, rdc, phred, rfm, Hu, Eu, Fu, L, bias=0xffff)
+            gotp = np.zeros((rows, cols), dtype=np.uint8)
+            for i in range(rows):
+                gotp[i] = r["pred"][i, rows - 1 - i:rows - 1 - i + cols]
+            assert (gotp == want_pred).all(), (rows, cols, np.argwhere(gotp != want_pred)[:5])
+            n_full += 1
+    assert n_full >= 8 and n_pass >= 11, (n_full, n_pass)
+    # ---- 16-bit end to end (the anti-diagonal cell form) and local: every cell, on the reference-recorded problems of tests/golden/dp_kinds_golden.json + random shapes
     with open(os.path.join(GOLD, "dp_kinds_golden.json")) as f:
         gold = json.load(f)
     probs, meta = [], []
