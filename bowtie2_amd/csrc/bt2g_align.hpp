@@ -340,6 +340,10 @@ struct Work {
 	uint32_t cand_hist[2 * (kMaxLocalScore + 1)];   // scratch of the local gather's counting sort
 	uint32_t cand_done[2][kMaxCandDone];            // local mode: tried candidates (row | col << 16) of the anchor's window and of the opposite mate's
 	AlnRes   res;                       // resGap_ / resEe_ / resUngap_
+	BtCand   cands2[kMaxCands];         // candidates of the opposite-mate DP (the anchor's stay live in `cands`)
+	BtCand   cands_tmp[kMaxCands];      // device, local mode: the candidate cells as the fill meets them; the gather sorts them into cands / cands2
+#ifndef BT2G_NO_PAIRS      // (the short-read class aligns unpaired end-to-end batches only: its work area ends here -- 0.8 MB instead of 7 MB per wave, one or two
+	                       // 2-MB pages of address space per resident wave instead of four or five, see align_scratch_sizes)
 	// ---- paired-end (extendSeedsPaired; unused for unpaired reads) ----
 	// seed-phase state of the mate that is not loaded (both mates are searched before either is extended)
 	struct MateSave {
@@ -358,9 +362,8 @@ struct Work {
 	AlnRes   red_anchor[kMaxRedAnchor]; // redAnchor_: every alignment found for either mate while it was the anchor or the rescued mate
 	int64_t  reda_dmin[kMaxRedAnchor], reda_dmax[kMaxRedAnchor];
 	AlnRes   ores;                      // oresGap_
-	BtCand   cands2[kMaxCands];         // candidates of the opposite-mate DP (the anchor's stay live in `cands`)
-	BtCand   cands_tmp[kMaxCands];      // device, local mode: the candidate cells as the fill meets them; the gather sorts them into cands / cands2
 	uint32_t mate_streaks[kMaxSatpos];  // mateStreaks_
+#endif
 	// ---- status / metrics ----
 };
 

@@ -2827,7 +2827,11 @@ struct Aligner {
 		for (uint32_t i = 0; i < num; i++) Plat::copy_aln(out.alns[i], WK.alns[idx[i]]);
 	}
 
+#ifndef BT2G_NO_PAIRS
 #include "bt2g_align_pe.inc"
+#else
+	BT2_HD BtCand* cand_list() { return ST.cands_cur; }      // (the candidate list in use: always Work::cands in a class without pairs)
+#endif
 };
 
 } // namespace bt2g

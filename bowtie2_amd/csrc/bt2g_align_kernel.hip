@@ -1762,6 +1762,7 @@ k_align_reads(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	}
 }
 
+#ifndef BT2G_NO_PAIRS
 // Paired-end flavour: one wavefront per pair (reads 2p and 2p+1, result records 2p and 2p+1).  A separate kernel so
 // that the unpaired kernel's register allocation and code layout do not carry the pair logic.
 template <typename TOff>
@@ -1825,6 +1826,8 @@ k_align_pairs(DevIndex<TOff> ix, AlignParams P, bt2g_reads rd, const ReadParams*
 	}
 }
 
+#endif
+
 template <typename TOff>
 hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt2g_reads& rd, const ReadParams* d_rparams,
                         uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
@@ -1843,9 +1846,13 @@ hipError_t launch_align(const DevIndex<TOff>& ix, const AlignParams& P, const bt
 		return used < lds_per_wave ? (uint32_t)((lds_per_wave - used) & ~15ull) : 0u;
 	};
 	if (P.paired) {
+#ifdef BT2G_NO_PAIRS
+		return hipErrorInvalidValue;      // (this class holds no pair state: bt2g_align_batch never sends it a batch of pairs)
+#else
 		const uint32_t extra = spare(reinterpret_cast<const void*>(&k_align_pairs<TOff>), tail);
 		hipLaunchKernelGGL(k_align_pairs<TOff>, dim3(n_waves), dim3(64), tail + extra, st, ix, P, rd, d_rparams, d_results, result_stride,
 		                   d_arena, arena_stride, mat_bytes, mask_bytes, pmask_bytes, d_next, d_prof, pre, max_read_len, max_cols, 0u, extra);
+#endif
 	} else {
 		// ... and to the on-chip backtrace state of end-to-end batches: the reportedThrough plane of a band matrix of the longest read at the
 		// narrowest band (16 bytes per row -- a wider band's marks stay in the arena, DevPlat::rt_begin decides per matrix).
@@ -1972,6 +1979,11 @@ void align_scratch_sizes(uint32_t max_len, bool paired, uint32_t maxhalf, uint32
 	const uint64_t pred_bytes = (pred_cells(rows, cols) + 255) & ~(uint64_t)255;
 	if (pred_bytes > mat_bytes) mat_bytes = pred_bytes;
 	mask_bytes = ((uint64_t)rows * cols * 2 + 255) & ~(uint64_t)255;
+#ifdef BT2G_KCLASS_W5
+	// The short-read class fills end-to-end windows of reads of at most 256 bp: always on the band (8- or 16-bit arithmetic; a band of a problem
+	// this size cannot exceed 2 048 diagonals), one predecessor byte per cell -- no packed cells, no 16-bit mask plane.
+	mat_bytes = pred_bytes; mask_bytes = 256;
+#endif
 	// masks of the pred formats: the band form of the widest band, or the anti-diagonal form of the local fill (one word per matrix byte)
 	const uint64_t wf_cells = ((uint64_t)cols + 128) * dp_RB(rows) * 128;      // (dp_cell_pk: at most 128 blocks of at most dp_RB(longest read) rows)
 	const uint64_t mask_cells = pred_cells(rows, cols) > wf_cells ? pred_cells(rows, cols) : wf_cells;

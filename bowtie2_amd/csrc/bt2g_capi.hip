@@ -464,6 +464,7 @@ extern "C" uint32_t bt2g_w5_static_lds(void);
 extern "C" uint64_t bt2g_w5_work_bytes(void);
 extern "C" uint32_t bt2g_w5_max_len(void);
 extern "C" uint32_t bt2g_w5_max_offs(void);
+extern "C" void bt2g_w5_scratch_sizes(uint32_t max_len, int paired, uint32_t maxhalf, uint32_t max_cols, uint64_t* mat_bytes, uint64_t* mask_bytes, uint64_t* pmask_bytes, uint64_t* arena_stride);
 // ... and its many-alignments class (-k above 64, -a: bt2g_align_kernel.hip compiled with BT2G_CLASS_BIG_K, its own Work and arena)
 extern "C" hipError_t bt2g_bk_launch_align(int off_size, const void* ix, const bt2g_align_params* P, const bt2g_reads* rd, const bt2g_read_params* d_rparams,
                                            uint8_t* d_results, uint64_t result_stride, uint8_t* d_arena, uint64_t arena_stride,
@@ -684,6 +685,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		if (need > max_cols) max_cols = need < (uint32_t)kMaxColsWide ? need : (uint32_t)kMaxColsWide;
 		bt2g_lr_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, &mat_bytes, &mask_bytes, &pmask_bytes, &arena_stride);
 	} else if (bigk) bt2g_bk_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, &mat_bytes, &mask_bytes, &pmask_bytes, &arena_stride);
+	else if (w5) bt2g_w5_scratch_sizes(max_read_len, 0, (uint32_t)params->maxhalf, max_cols, &mat_bytes, &mask_bytes, &pmask_bytes, &arena_stride);      // (its own work area and DP scratch: no pair state, band matrices only)
 	else align_scratch_sizes(max_read_len, params->paired != 0, (uint32_t)params->maxhalf, max_cols, mat_bytes, mask_bytes, pmask_bytes, arena_stride);
 	{ static const char* skew = getenv("BT2G_ARENA_SKEW");      // measurement knob: extra bytes per wave (do the waves' working sets meet in the same memory channels?)
 	  if (skew) { arena_stride += (uint64_t)atoll(skew); if (getenv("BT2G_DEBUG_OCC")) fprintf(stderr, "[bt2g] arena stride %llu B (%llu x 4 KB)\n", (unsigned long long)arena_stride, (unsigned long long)(arena_stride >> 12)); } }
@@ -755,9 +757,9 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 		const uint64_t qcap64 = n * 16 < 0xfffffff0ull ? n * 16 : 0xfffffff0ull;
 		const uint64_t b_mm1q = al(qcap64 * one_mm_task_bytes(c->off_size));
 		const uint64_t b_mm1t = al(n * 4 * sizeof(uint32_t));      // the scan's task list: the (read, strand, direction) combinations that are searched at all
-		// re-seeding rounds are pre-computed for unpaired batches (the pair worker keeps searching them itself)
+		// re-seeding rounds are pre-computed too (round 6: for pairs as well -- a pair whose mates both pass the filters has half as many rounds, seed_rounds_of)
 		uint32_t pre_rounds = 1;
-		if (params->seed_mms == 0 && !params->paired && params->n_seed_rounds > 1) pre_rounds = (uint32_t)params->n_seed_rounds < kMaxPreRounds ? (uint32_t)params->n_seed_rounds : kMaxPreRounds;
+		if (params->seed_mms == 0 && params->n_seed_rounds > 1) pre_rounds = (uint32_t)params->n_seed_rounds < kMaxPreRounds ? (uint32_t)params->n_seed_rounds : kMaxPreRounds;
 		const uint64_t tot = b_sweep + (b_seeds + b_ext + b_joff) * pre_rounds + b_mm1 + b_mm1n + b_mm1c + b_mm1q + b_mm1t;
 		if (tot > S.pre_bytes) {
 			if (S.d_pre) (void)hipFree(S.d_pre);
@@ -811,14 +813,14 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 				bt2g_seed_hit* sr = (bt2g_seed_hit*)q; q += b_seeds;
 				uint64_t* jr = (uint64_t*)q; q += b_joff;
 				uint32_t* er = (uint32_t*)q; q += b_ext;
-				ReseedCtl ctl; ctl.prev = prev; ctl.n_seed_rounds = (uint32_t)params->n_seed_rounds; ctl.boost_thresh = (uint32_t)params->seed_boost_thresh; ctl.nofw = params->nofw; ctl.norc = params->norc;
+				ReseedCtl ctl; ctl.prev = prev; ctl.n_seed_rounds = (uint32_t)params->n_seed_rounds; ctl.boost_thresh = (uint32_t)params->seed_boost_thresh; ctl.nofw = params->nofw; ctl.norc = params->norc; ctl.paired = params->paired;
 				e = s ? launch_seed_search_exact(c->ix32, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, sr, c->d_cnt, st, ri, &ctl)
 				      : launch_seed_search_exact(c->ix64, *reads, nullptr, nullptr, nullptr, d_rparams, max_seeds, sr, c->d_cnt, st, ri, &ctl);
 				if (e != hipSuccess) return hip_fail(c, e, "k_seed_search_exact (re-seed)");
 				pre.seeds_r[ri] = (decltype(pre.seeds_r[ri]))sr;
 				if (params->do_extend) {
-					e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, sr, er, jr, c->d_cnt, st, ri, (uint32_t)params->n_seed_rounds)
-					      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, sr, er, jr, c->d_cnt, st, ri, (uint32_t)params->n_seed_rounds);
+					e = s ? launch_extend_hits(c->ix32, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, sr, er, jr, c->d_cnt, st, ri, (uint32_t)params->n_seed_rounds, params->paired)
+					      : launch_extend_hits(c->ix64, *reads, d_rparams, max_seeds, (params->do_extend & 2) ? 0 : 1, sr, er, jr, c->d_cnt, st, ri, (uint32_t)params->n_seed_rounds, params->paired);
 					if (e != hipSuccess) return hip_fail(c, e, "k_extend_hits (re-seed)");
 					pre.ext_r[ri] = (decltype(pre.ext_r[ri]))er; pre.joff_r[ri] = (decltype(pre.joff_r[ri]))jr;
 				}

@@ -238,7 +238,7 @@ k_seed_search_exact(DevIndex<TOff> ix, bt2g_reads rd, const uint32_t* __restrict
 		bool want = true;
 		if (roundi > 0) {
 			// a re-seeding round: its offset, and whether the previous round was repetitive enough to ask for it
-			want = rparams != nullptr && per > 0 && reseed_offset(roundi, rc_.n_seed_rounds, per, (uint32_t)rparams[r].seedlen, len, off);
+			want = rparams != nullptr && per > 0 && reseed_offset(roundi, seed_rounds_of(rc_.n_seed_rounds, rc_.paired, rparams, r), per, (uint32_t)rparams[r].seedlen, len, off);
 			if (want) {
 				uint64_t elts = 0; uint32_t nonz = 0;
 				for (uint32_t s_ = 0; s_ < 2; s_++) {
@@ -329,7 +329,7 @@ hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& 
                                     uint32_t roundi, const ReseedCtl* rc) {
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	if (total == 0) return hipSuccess;
-	ReseedCtl ctl; ctl.prev = nullptr; ctl.n_seed_rounds = 0; ctl.boost_thresh = 0; ctl.nofw = ctl.norc = 0;
+	ReseedCtl ctl; ctl.prev = nullptr; ctl.n_seed_rounds = 0; ctl.boost_thresh = 0; ctl.nofw = ctl.norc = 0; ctl.paired = 0;
 	if (rc) ctl = *rc;
 	const uint32_t block = 256;
 	const uint64_t grid = (total + block - 1) / block;
@@ -440,7 +440,7 @@ template <typename TOff>
 __global__ void __launch_bounds__(64)
 k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restrict__ rparams, uint32_t max_seeds, int right,
               const bt2g_seed_hit* __restrict__ hits, uint32_t* __restrict__ ext, uint64_t* __restrict__ joffs, DevCounters* cnt,
-              uint32_t roundi, uint32_t n_seed_rounds) {
+              uint32_t roundi, uint32_t n_seed_rounds, int paired) {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	FmCount c; c.bwops = 0; c.sides = 0;
@@ -459,7 +459,7 @@ k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restri
 			uint32_t L = (uint32_t)rparams[r].seedlen;
 			if (L > len) L = len;
 			uint32_t roff = 0;
-			if (roundi > 0) reseed_offset(roundi, n_seed_rounds, (uint32_t)rparams[r].interval, (uint32_t)rparams[r].seedlen, len, roff);
+			if (roundi > 0) reseed_offset(roundi, seed_rounds_of(n_seed_rounds, paired, rparams, r), (uint32_t)rparams[r].interval, (uint32_t)rparams[r].seedlen, len, roff);
 			const uint32_t rdoff = i * (uint32_t)rparams[r].interval + roff;
 			GlobRd g; g.init(rd.d_seq + o0, rd.d_qual + o0, len);
 			uint32_t nlex = 0, nrex = 0;
@@ -504,14 +504,14 @@ k_extend_hits(DevIndex<TOff> ix, bt2g_reads rd, const bt2g_read_params* __restri
 template <typename TOff>
 hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds, int right,
                               const bt2g_seed_hit* d_hits, uint32_t* d_ext, uint64_t* d_joff, DevCounters* d_cnt, hipStream_t st,
-                              uint32_t roundi, uint32_t n_seed_rounds) {
+                              uint32_t roundi, uint32_t n_seed_rounds, int paired) {
 	const uint64_t total = (uint64_t)rd.n_reads * 2 * max_seeds;
 	if (total == 0) return hipSuccess;
 	// one wavefront per workgroup: a workgroup's slot is held until its slowest lane is done, and the multi-row hits that are still walked
 	// (more than kExtRows rows) have a long tail
 	const uint64_t grid = (total + 63) / 64;
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(64), 0, st, ix, rd, d_rparams, max_seeds, right, d_hits, d_ext, d_joff, d_cnt, roundi, n_seed_rounds);
+	hipLaunchKernelGGL(k_extend_hits<TOff>, dim3((uint32_t)grid), dim3(64), 0, st, ix, rd, d_rparams, max_seeds, right, d_hits, d_ext, d_joff, d_cnt, roundi, n_seed_rounds, paired);
 	return hipGetLastError();
 }
 
@@ -736,8 +736,8 @@ hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, c
 }
 uint64_t one_mm_task_bytes(int off_size) { return off_size == 4 ? sizeof(Mm1Task<uint32_t>) : sizeof(Mm1Task<uint64_t>); }
 
-template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t);
-template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t);
+template hipError_t launch_extend_hits<uint32_t>(const DevIndex<uint32_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t, int);
+template hipError_t launch_extend_hits<uint64_t>(const DevIndex<uint64_t>&, const bt2g_reads&, const bt2g_read_params*, uint32_t, int, const bt2g_seed_hit*, uint32_t*, uint64_t*, DevCounters*, hipStream_t, uint32_t, uint32_t, int);
 template hipError_t launch_one_mm<uint32_t>(const DevIndex<uint32_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, unsigned int*, void*, uint32_t, unsigned int*, uint32_t*, DevCounters*, hipStream_t);
 template hipError_t launch_one_mm<uint64_t>(const DevIndex<uint64_t>&, const bt2g_align_params&, const bt2g_reads&, const bt2g_read_params*, const bt2g_sweep_out*, uint32_t, void*, uint8_t*, unsigned int*, void*, uint32_t, unsigned int*, uint32_t*, DevCounters*, hipStream_t);
 

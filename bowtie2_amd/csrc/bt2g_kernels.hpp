@@ -15,7 +15,12 @@ hipError_t launch_exact_sweep(const DevIndex<TOff>& ix, const bt2g_reads& rd, in
 
 // re-seeding round r > 0 of the batch pre-computation: seeds shifted by reseed_offset(), only for reads whose previous
 // round (`prev`: its seed hits) averaged >= boost_thresh elements per non-empty seed
-struct ReseedCtl { const bt2g_seed_hit* prev; uint32_t n_seed_rounds, boost_thresh; int nofw, norc; };
+struct ReseedCtl { const bt2g_seed_hit* prev; uint32_t n_seed_rounds, boost_thresh; int nofw, norc; int paired; };
+// seeding rounds of read r: a pair whose mates both pass the filters gets half of them, rounded up (multiseedSearchWorker, bt2_search.cpp:3462-3470: nrounds = ceil(nrounds / 2))
+__host__ __device__ inline uint32_t seed_rounds_of(uint32_t n_seed_rounds, int paired, const bt2g_read_params* rparams, uint32_t r) {
+	if (paired && (rparams[r].filt & 15u) == 15u && (rparams[r ^ 1u].filt & 15u) == 15u) return (n_seed_rounds + 1u) / 2u;
+	return n_seed_rounds;
+}
 template <typename TOff>
 hipError_t launch_seed_search_exact(const DevIndex<TOff>& ix, const bt2g_reads& rd, const uint32_t* d_seedlen,
                                     const uint32_t* d_interval, const uint32_t* d_offset, const bt2g_read_params* d_rparams,
@@ -29,7 +34,7 @@ hipError_t launch_max_seeds(const bt2g_reads& rd, const bt2g_read_params* d_rpar
 template <typename TOff>
 hipError_t launch_extend_hits(const DevIndex<TOff>& ix, const bt2g_reads& rd, const bt2g_read_params* d_rparams, uint32_t max_seeds, int right,
                               const bt2g_seed_hit* d_hits, uint32_t* d_ext, uint64_t* d_joff, DevCounters* d_cnt, hipStream_t st,
-                              uint32_t roundi = 0, uint32_t n_seed_rounds = 0);
+                              uint32_t roundi = 0, uint32_t n_seed_rounds = 0, int paired = 0);
 template <typename TOff>
 hipError_t launch_one_mm(const DevIndex<TOff>& ix, const bt2g_align_params& P, const bt2g_reads& rd, const bt2g_read_params* d_rparams,
                          const bt2g_sweep_out* d_sweep, uint32_t cap, void* d_out, uint8_t* d_out_n, unsigned int* d_out_cnt,

@@ -94,3 +94,33 @@ def test_long_and_short_batches_in_one_run_gpu(tmp_path):
     got = by_read(p.stdout)
     assert set(got) == set(want)
     assert not [n for n in want if n not in flagged and got[n] != want[n]]
+
+
+@pytest.mark.gpu
+def test_pairs_with_mates_in_the_16_bit_range_gpu():
+    """Mates of 430-510 bp: the anchor's and the opposite mate's windows go through the 16-bit end-to-end kernel's arithmetic (minimum score
+    below -254) -- on the band fill since round 6.  tools/long_pairs_check.py: four option sets against the reference binary."""
+    p = subprocess.run(["python3", os.path.join(ROOT, "tools", "long_pairs_check.py"), "300", "13"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-1500:]
+    assert p.stdout.count("differing 0, reads flagged 0") == 4, p.stdout[-1500:]
+
+
+@pytest.mark.gpu
+def test_reads_of_424_to_512_bp_short_read_classes_gpu(tmp_path):
+    """Unpaired reads just above the 8-bit kernel's range (424-512 bp at the default threshold) run in the general class, not the long-read one:
+    cut from the example long reads, against the reference binary."""
+    base, fq = workload()
+    lines = open(fq).read().split("\n")
+    out = []
+    for k in range(0, len(lines) - 3, 4):
+        L = 424 + (k // 4 * 7) % 89
+        if len(lines[k + 1]) >= L:
+            out += [lines[k], lines[k + 1][:L], "+", lines[k + 3][:L]]
+    cut = tmp_path / "cut.fq"
+    cut.write_text("\n".join(out) + "\n")
+    want = by_read(subprocess.run([ref_bin("bowtie2-align-s"), "-x", base, "-U", str(cut)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True).stdout)
+    p = subprocess.run([BIN, "-x", base, "-U", str(cut)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
+    assert p.returncode == 0 and "Warning: read" not in p.stderr, p.stderr[-500:]
+    got = by_read(p.stdout)
+    assert set(got) == set(want) and len(want) > 200
+    assert not [n for n in want if got[n] != want[n]]
