@@ -1028,6 +1028,7 @@ def main():
     ap.add_argument("--genome-fasta", default=None, help="a real reference (FASTA, plain or gzip) instead of the synthetic genome: indexed by the GPU builder, reads sampled from it by the "
                     "same generator (env BT2_BENCH_HG38 for the hg38 configurations, BT2_BENCH_ECOLI for ecoli100)")
     ap.add_argument("--index-base", default=None, help="an existing bowtie2 index (<base>.1.bt2[l] ...): used as it is; the sequence reads are sampled from is recovered from its .3/.4 files")
+    ap.add_argument("--check-determinism", action="store_true", help="diagnostic: align the resident batch twice more after the timed region and compare the result records byte for byte (config.determinism)")
     ap.add_argument("--reads-fastq", default=None, help="reads of one length from this FASTQ file (names, qualities and all) instead of the generator")
     args = ap.parse_args()
     if args.paired:
@@ -1243,6 +1244,24 @@ def main():
         kavg_serial = {k: sum(t[k] for t in ks) / len(ks) for k in ks[0]}
     kroof = kavg_serial or kavg
     kern_ms = kroof["k_align_reads"]
+    determinism = None
+    if args.check_determinism and not dry:
+        with cuda.stream(streams[0]):
+            ra, st_ = ctx.align_batch(batch, rp_t, P, args.readlen); cuda.synchronize(); ra = ra.view(n, st_).clone()
+            rb, _ = ctx.align_batch(batch, rp_t, P, args.readlen); cuda.synchronize(); rb = rb.view(n, st_)
+            diff = (ra != rb).any(dim=1)
+            idx = diff.nonzero().flatten()
+            first = []
+            for i in idx[:8].tolist():
+                cols = (ra[i] != rb[i]).nonzero().flatten()
+                first.append({"read": i, "first_byte": int(cols[0]), "bytes_differing": int(cols.numel()), "aligned": [int(ra[i, 1]), int(rb[i, 1])]})
+            hdr_diff = (ra[:, :135] != rb[:, :135]).any(dim=1)      # the record's header (status, counters, scores) and the first alignment's fields up to its edits
+            colhist = (ra != rb).sum(dim=0)
+            cols_ = colhist.nonzero().flatten().tolist()
+            determinism = {"records": n, "records_differing_between_two_runs": int(idx.numel()), "records_differing_in_header_or_first_alignment_fields": int(hdr_diff.sum()),
+                           "header_diff_reads": hdr_diff.nonzero().flatten()[:16].tolist(), "first": first,
+                           "differing_byte_offsets": {int(c_): int(colhist[c_]) for c_ in cols_[:64]}, "n_differing_offsets": len(cols_)}
+            log("[bench] determinism: %d of %d result records differ between two runs of the same batch" % (int(idx.numel()), n))
     # the worker's phase timers are off in the timed steps (measured: they cost nothing beyond run-to-run noise, but the timed
     # region is the product configuration); one more, untimed, pass over the same batch with them on gives the per-phase breakdown
     P.profile = 1
@@ -1338,7 +1357,7 @@ def main():
             "config": {
                 "workload": workload,
                 "genome": real or "synthetic", "reads_source": args.reads_fastq or "SURVEY 8d generator",
-                "config_name": args.config, "command_line": " ".join(cfg["args"]),
+                "config_name": args.config, "command_line": " ".join(cfg["args"]), "determinism": determinism,
                 "steps_in_flight": depth,
                 "steps_in_flight_note": None if depth == 1 else "the timed steps are issued on %d alternating streams (one working set of the context each), so that a batch's tail is filled by the next batch, as in the product driver; kernel_ms_per_step are the HIP-event durations of the kernels on their own stream and overlap in time" % depth,
                 "stages_timed": "one bt2g_align_batch per step = the whole per-read worker: k_exact_sweep, k_one_mm, k_seed_search_exact, k_extend_hits (lane-per-task FM kernels) then k_align_reads "

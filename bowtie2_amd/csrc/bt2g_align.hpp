@@ -247,6 +247,7 @@ struct CacheModel {
 	uint32_t qn, ql, san;          // nodes in the QKey map, entries in the SAKey list, nodes in the SAKey map
 	uint64_t sl;                   // elements in the element list
 	uint32_t nkeys;
+	uint32_t fast_round;           // pairs: the round's ranges of BOTH mates provably fit the pool (cache_filter): neither mate's seeds go through the model
 };
 
 // `size` = elements the seed search found (what SeedResults tallies and ranks by); `esize` = elements of the range as the

@@ -102,7 +102,8 @@ struct Aligner {
 			const bt2g_seed_hit* src = src_all + (uint64_t)ST.ridx * 2 * PRE->max_seeds;
 			Plat::load_seed_hits(src, src + PRE->max_seeds, nseeds, ST.m_nofw != 0, ST.m_norc != 0);
 		}
-		cache_filter(interval, offset, seedlen);
+		// (pairs: the other mate's row of the same table, for cache_filter's bound on what the round can take from the pool the mates share)
+		cache_filter(interval, offset, seedlen, PRM.paired ? src_all + (uint64_t)(ST.ridx ^ 1u) * 2 * PRE->max_seeds : nullptr);
 		return 1;   // # instantiated seeds only matters when no seed hit (run() ends the read either way)
 	}
 
@@ -111,12 +112,12 @@ struct Aligner {
 		CacheModel& c = HOT.cm;
 		const uint64_t bytes = (uint64_t)(PRM.seed_cache_mb > 0 ? PRM.seed_cache_mb : 20) * 1024 * 1024;
 		c.pool_total = (uint32_t)((bytes + 16383) / 16384 + 1);       // Pool::Pool (ds.h:3078)
-		c.pool_used = 0; c.qn = c.ql = c.san = 0; c.sl = 0; c.nkeys = 0;
+		c.pool_used = 0; c.qn = c.ql = c.san = 0; c.sl = 0; c.nkeys = 0; c.fast_round = 0;
 	}
 	BT2_HD bool cache_page() { CacheModel& c = HOT.cm; if (c.pool_used == c.pool_total) return false; c.pool_used++; return true; }
 	// Seeds of the round in HOT.hits (size = what the search found) -> what SeedResults ends up holding: hits of dropped seeds
 	// cleared, esize set, tallies (nonz_*, num_elts) formed.  Exact seeds only: a -N 1 round is tallied unmodelled.
-	BT2_HDN void cache_filter(uint32_t interval_, uint32_t offset_, uint32_t seedlen_) {
+	BT2_HDN void cache_filter(uint32_t interval_, uint32_t offset_, uint32_t seedlen_, const bt2g_seed_hit* other_mate_ = nullptr) {
 		const uint32_t interval = Plat::uni(interval_), offset = Plat::uni(offset_), seedlen = Plat::uni(seedlen_);
 		CacheModel& c = HOT.cm;
 		const uint32_t len = HOT.len, L = seedlen < len ? seedlen : len;
@@ -129,13 +130,42 @@ struct Aligner {
 		// the three node pools take one page each, and the element list ceil(elements / sl_per).  Then what the search found is what SeedResults ends
 		// up holding (esize == size, as the search left it; a sequence that occurs twice has the same range both times), and all that is left to do
 		// is the tally -- one lane per seed.  (Only where the pool is this round's and this read's alone: the mates of a pair share one.)
-		if (!PRM.paired && Plat::uni(c.nkeys) == 0u && Plat::uni(c.pool_used) == 0u && Plat::uni(HOT.num_offs) <= 32u && L <= 32u) {
+		// Pairs: the mates of a pair share the pool of a round.  The first mate of a round bounds the round by its own ranges plus everything the
+		// batch kernels found for the other mate in this round (the other mate's row of the same table: what it will load, or nothing, if its turn
+		// comes at all); the flag then covers the second mate's call.  Unknown (the other mate searches its seeds itself): the model runs.
+		const bool paired = PRM.paired != 0;
+		const bool fresh = Plat::uni(c.nkeys) == 0u && Plat::uni(c.pool_used) == 0u;
+		bool covered = paired && Plat::uni(c.fast_round) != 0u;      // the first mate's call of this round bounded both
+		bool bound_ok = !paired && fresh;
+		uint64_t tot_other = 0;
+		// (the other mate must be one the tables hold all seeds of -- else it searches them itself, and more of them than its row shows)
+		bool other_fits = false;
+		if (paired && PRE) {
+			const uint32_t om = (Plat::uni(ST.ridx) & 1u) ^ 1u;
+			const uint32_t len2 = Plat::uni(ST.pe_len[om]), iv2 = Plat::uni((uint32_t)ST.pe_rp[om].interval);
+			uint32_t L2 = Plat::uni((uint32_t)ST.pe_rp[om].seedlen); if (L2 > len2) L2 = len2;
+			other_fits = iv2 > 0u && 1u + (len2 > L2 ? (len2 - L2) / iv2 : 0u) <= Plat::uni(PRE->max_seeds);
+		}
+		if (paired && !covered && fresh && other_fits && other_mate_ != nullptr && Plat::uni(PRE->max_seeds) <= 32u) {
+			const bt2g_seed_hit* const other_mate = Plat::uni_ptr(other_mate_);
+			const uint32_t ms = Plat::uni(PRE->max_seeds);
+			typename Plat::LaneReg osz, unk;
+			BT2_FOR_LANES(l) {
+				const uint32_t fwi = l >> 5, i = l & 31u;
+				uint32_t v = 0, u = 0;
+				if (i < ms) { const bt2g_seed_hit h = other_mate[(uint64_t)fwi * ms + i]; if (h.topf == ~0ull) u = 1u; else if (h.botf > h.topf) v = (uint32_t)(h.botf - h.topf); }
+				LV(osz) = v; LV(unk) = u;
+			}
+			if (Plat::ballot(unk) == 0ull) { tot_other = Plat::lanes_sum(osz); bound_ok = true; }
+		}
+		if ((covered || bound_ok) && Plat::uni(HOT.num_offs) <= 32u && L <= 32u) {
 			const uint32_t n = Plat::uni(HOT.num_offs);
 			const bool skf = ST.m_nofw != 0, skr = ST.m_norc != 0;
 			typename Plat::LaneReg sz;
 			BT2_FOR_LANES(l) { const uint32_t fwi = l >> 5, i = l & 31u; LV(sz) = (i < n && !(fwi ? skr : skf)) ? HOT.hits[fwi][i].size : 0u; }
 			const uint64_t tot = Plat::lanes_sum(sz);
-			if (3u + (tot + sl_per - 1) / sl_per <= (uint64_t)Plat::uni(c.pool_total)) {
+			if (covered || 6u + (tot + tot_other + sl_per - 1) / sl_per <= (uint64_t)Plat::uni(c.pool_total)) {
+				if (paired) c.fast_round = 1;
 				const uint64_t nz = Plat::ballot(sz);
 				HOT.nonz_fw = (uint32_t)__builtin_popcountll(nz & 0xffffffffull); HOT.nonz_rc = (uint32_t)__builtin_popcountll(nz >> 32);
 				HOT.nonz_tot = HOT.nonz_fw + HOT.nonz_rc; HOT.num_elts = tot;
