@@ -1167,7 +1167,7 @@ def main():
     stage_events = []
     last = {}
     kern_times = []
-    depth = max(1, args.pipeline) if dist is None else 1      # (the N-GPU path keeps one step in flight: its RCCL gather sits inside the step)
+    depth = max(1, args.pipeline)      # (N-GPU path too, round 6: a batch's records are packed and gathered over RCCL after the NEXT batch has been issued)
     if args.warmup < depth:
         # every stream's working set is created (its arena allocated and zeroed) by its first batch: one untimed step per stream in flight
         log("[bench] --warmup raised from %d to %d: one untimed step per stream in flight" % (args.warmup, depth))
@@ -1177,6 +1177,19 @@ def main():
         s_.wait_stream(cuda.current_stream())
     issued = [0] * depth
     step_no = [0]
+    pending = []      # N-GPU path: batches issued whose records are not packed and gathered yet (oldest first)
+
+    def gather_oldest():
+        # N-GPU path: the per-GPU result records are cut to size and merged on rank 0 over RCCL (the only exchange of the job) -- on the batch's own
+        # stream; the size read-back waits for that batch alone, the batch issued after it keeps the device busy meanwhile
+        k, res, e0, record = pending.pop(0)
+        with cuda.stream(streams[k]):
+            packed, offs = ctx.results_pack(res, n, P.khits)
+            last["gathered"] = shard.gather_packed(dist, packed, int(offs[n].item()), dev)
+            e1 = ev()
+            e1.record()
+            if record:
+                stage_events.append((e0, e1))
 
     def step(record):
         k = step_no[0] % depth
@@ -1185,22 +1198,26 @@ def main():
             if depth > 1 and record and issued[k]:
                 # the batch issued `depth` steps ago on this stream: its kernel times (blocks until it is done -- the pipeline's backpressure)
                 kern_times.append(ctx.align_timing(on_current_stream=True))
-            e0, e1 = ev(), ev()
+            e0 = ev()
             e0.record()
             res, stride = ctx.align_batch(batch, rp_t, P, args.readlen)
-            if dist is not None:
-                # N-GPU path: the per-GPU result records are cut to size and merged on rank 0 over RCCL (the only exchange of the job)
-                packed, offs = ctx.results_pack(res, n, P.khits)
-                last["gathered"] = shard.gather_packed(dist, packed, int(offs[n].item()), dev)
-            e1.record()
             issued[k] = 1 if record else 0
-            if record:
-                stage_events.append((e0, e1))
-                if depth == 1:
-                    kern_times.append(ctx.align_timing())      # HIP events recorded by the library around each kernel
+            if dist is not None:
+                pending.append((k, res, e0, record))
+            else:
+                e1 = ev()
+                e1.record()
+                if record:
+                    stage_events.append((e0, e1))
+            if record and depth == 1:
+                kern_times.append(ctx.align_timing())      # HIP events recorded by the library around each kernel
             last["res"], last["stride"] = res, stride
+        while len(pending) > depth - 1:
+            gather_oldest()
 
     def sync_all():
+        while pending:
+            gather_oldest()
         cuda.synchronize()
         if dist is not None:
             dist.barrier()

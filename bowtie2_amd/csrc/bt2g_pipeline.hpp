@@ -14,6 +14,9 @@
 #include <atomic>
 #include <zlib.h>
 #include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <cerrno>
 
 #include <chrono>
 #include <condition_variable>
@@ -179,20 +182,20 @@ public:
 		if (paths_.empty()) paths_.push_back(path);
 		open_next();
 	}
-	~LineSource() { if (f_) gzclose(f_); }
-	bool ok() const { return f_ != nullptr; }
+	~LineSource() { if (f_) gzclose(f_); if (plain_fd_ >= 0) close(plain_fd_); }
+	bool ok() const { return f_ != nullptr || plain_fd_ >= 0; }
 	// Restrict the source to bytes [a, b) of its (single, uncompressed, seekable) file: what one rank of a byte-sharded run reads
 	// (--shard-bytes).  The caller vouches that `a` is the start of a line and that the line ending at b - 1 ends a record.
 	bool set_range(uint64_t a, uint64_t b, std::string& err) {
-		if (paths_.size() != 1 || paths_[0] == "-" || !f_) { err = "--shard-bytes needs one regular reads file per -U / -1 / -2"; return false; }
-		if (!gzdirect(f_)) { err = "--shard-bytes cannot be used with compressed input (" + paths_[0] + ")"; return false; }
-		if (b < a || gzseek(f_, (z_off_t)a, SEEK_SET) < 0) { err = "--shard-bytes: cannot seek in " + paths_[0]; return false; }
+		if (paths_.size() != 1 || paths_[0] == "-" || !ok()) { err = "--shard-bytes needs one regular reads file per -U / -1 / -2"; return false; }
+		if (plain_fd_ < 0 && !gzdirect(f_)) { err = "--shard-bytes cannot be used with compressed input (" + paths_[0] + ")"; return false; }
+		if (b < a || (plain_fd_ >= 0 ? lseek(plain_fd_, (off_t)a, SEEK_SET) < 0 : gzseek(f_, (z_off_t)a, SEEK_SET) < 0)) { err = "--shard-bytes: cannot seek in " + paths_[0]; return false; }
 		ranged_ = true; left_ = b - a; bytes_read_.store(0, std::memory_order_relaxed);
 		return true;
 	}
 	uint64_t bytes_read() const { return bytes_read_.load(std::memory_order_relaxed); }      // bytes taken from the file(s) so far (read by the driver while the prefetch thread refills)
 	uint64_t plain_size() const {
-		if (paths_.size() != 1 || paths_[0] == "-" || !f_ || !gzdirect(f_)) return 0;
+		if (paths_.size() != 1 || paths_[0] == "-" || !ok() || (plain_fd_ < 0 && !gzdirect(f_))) return 0;
 		struct stat st_;
 		if (stat(paths_[0].c_str(), &st_) != 0 || !S_ISREG(st_.st_mode)) return 0;
 		return ranged_ ? 0 : (uint64_t)st_.st_size;
@@ -221,6 +224,23 @@ public:
 			refill();
 		}
 	}
+	// One whole 4-line FASTQ record if all of it is in the buffer: rec -> its first byte, e[k] = offset of the k-th line's '\n' from rec.  False: fewer than
+	// four line ends are buffered (the caller falls back to next(), which refills), or a line ends in "\r\n" (left to next()).  The view is valid
+	// until the next call; nothing is consumed.  (The serial scan of the reader: one pass and one copy per record instead of four calls and three copies.)
+	bool peek_record4(const char*& rec, uint32_t (&e)[4], size_t& nbytes) const {
+		const char* base = buf_.get() + pos_;
+		size_t avail = len_ - pos_, o = 0;
+		for (int k = 0; k < 4; k++) {
+			const char* nl = avail > o ? (const char*)memchr(base + o, '\n', avail - o) : nullptr;
+			if (!nl) return false;
+			e[k] = (uint32_t)(nl - base);
+			if (e[k] > 0 && nl[-1] == '\r') return false;
+			o = (size_t)(nl - base) + 1;
+		}
+		rec = base; nbytes = o;
+		return true;
+	}
+	void consume(size_t nbytes) { pos_ += nbytes; raw_len_ = nbytes; }      // ... and take it
 private:
 	// (the buffer is plain storage with its own length: a std::string would zero-fill the 8 MB of every refill before gzread overwrites them)
 	void reserve(size_t need) {
@@ -237,7 +257,12 @@ private:
 		size_t want = 8u << 20;
 		if (ranged_ && (uint64_t)want > left_) want = (size_t)left_;
 		reserve(old + want + 1);
-		int got = want ? gzread(f_, buf_.get() + old, (unsigned)want) : 0;
+		// (a plain file is read with read(2): gzread's transparent mode copies everything once more through its own buffer)
+		int got = 0;
+		if (want) {
+			if (plain_fd_ >= 0) { ssize_t r_; do { r_ = ::read(plain_fd_, buf_.get() + old, want); } while (r_ < 0 && errno == EINTR); got = (int)r_; }
+			else got = gzread(f_, buf_.get() + old, (unsigned)want);
+		}
 		len_ = old + (got > 0 ? (size_t)got : 0);
 		if (got > 0) { bytes_read_.fetch_add((uint64_t)got, std::memory_order_relaxed); if (ranged_) left_ -= (uint64_t)got; }
 		if (got < 0) io_error_ = true;          // corrupt / truncated .gz: the run must fail, not end early (the reference aborts too)
@@ -245,13 +270,25 @@ private:
 			if (next_path_ < paths_.size()) {
 				// next file of the list: the previous one ends a line even if its last newline is missing
 				if (len_ && buf_[len_ - 1] != '\n') { reserve(len_ + 1); buf_[len_++] = '\n'; }
-				gzclose(f_); f_ = nullptr;
+				if (f_) gzclose(f_);
+				f_ = nullptr;
+				if (plain_fd_ >= 0) { close(plain_fd_); plain_fd_ = -1; }
 				if (!open_next()) eof_ = true;
 			} else eof_ = true;
 		}
 	}
 	bool open_next() {
 		const std::string& p = paths_[next_path_++];
+		if (p != "-") {
+			// a regular file that does not start with the gzip magic is read directly
+			const int fd = open(p.c_str(), O_RDONLY | O_CLOEXEC);
+			if (fd >= 0) {
+				struct stat st_;
+				unsigned char m[2] = {0, 0};
+				if (fstat(fd, &st_) == 0 && S_ISREG(st_.st_mode) && (pread(fd, m, 2, 0) < 2 || !(m[0] == 0x1f && m[1] == 0x8b))) { plain_fd_ = fd; return true; }
+				close(fd);
+			}
+		}
 		f_ = p == "-" ? gzdopen(0, "rb") : gzopen(p.c_str(), "rb");
 		if (f_) gzbuffer(f_, 1 << 20);
 		return f_ != nullptr;
@@ -270,6 +307,7 @@ public:
 private:
 	size_t raw_len_ = 0;
 	gzFile f_ = nullptr;
+	int plain_fd_ = -1;
 	std::unique_ptr<char[]> buf_;
 	size_t cap_ = 0, len_ = 0;
 	size_t pos_ = 0;
@@ -404,6 +442,21 @@ private:
 			bool have_r2 = false;
 			r.qual_off = r.qual_len = 0; r.has_qual = false; r.filter = '1';
 			r.orig_off = orig_.size(); r.orig_len = 0;
+			if (opt_.format == 0 && !pt && fastq_started_) {
+				// a whole record in the buffer (the common case): name, sequence and qualities in one copy
+				const char* rec; uint32_t e[4]; size_t nb;
+				if (src_.peek_record4(rec, e, nb) && e[0] > 0 && rec[0] == '@' && e[1] > e[0] + 1) {
+					if ((rdid_ >> ushift_) - std::min<uint64_t>((rdid_ >> ushift_), opt_.skip) >= opt_.upto) { b.last = true; b.upto_hit = true; break; }
+					src_.consume(nb);
+					const size_t a0 = arena_.size();
+					arena_.append(rec + 1, e[3] - 1);
+					r.name_off = a0; r.name_len = e[0] - 1;
+					r.seq_off = a0 + e[0]; r.seq_len = e[1] - e[0] - 1;
+					r.qual_off = a0 + e[2]; r.qual_len = e[3] - e[2] - 1; r.has_qual = true;
+					goto have_record;
+				}
+				// (a record the fast path does not take -- blank line, empty sequence, no '@', "\r\n", the end of the buffer: the line-by-line path decides)
+			}
 			if (opt_.format == 0) {                    // FASTQ: 4-line records
 				bool got;
 				size_t nblank = 0;
@@ -603,6 +656,7 @@ private:
 				r.seq_off = arena_.size(); r.seq_len = n; arena_.append(p, n);
 				if (pt) orig_.append(p, n);
 			}
+			have_record:
 			// a FASTA record without a single sequence character is not a read for the reference ("FASTA ended prematurely", pat.cpp:849-851):
 			// it takes its number in the input and is dropped (unpaired input only: a pair loses both mates there)
 			if (opt_.format == 1 && !opt_.paired && r.seq_len == 0) { orig_.resize(r.orig_off); rdid_++; continue; }

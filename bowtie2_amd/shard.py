@@ -16,8 +16,8 @@ def env_rank():
 def init(backend, device=None):
     """Join the process group if WORLD_SIZE > 1; returns the torch.distributed module or None."""
     rank, _, world = env_rank()
-    if world <= 1:
-        return None
+    if world <= 1 and not (os.environ.get("BT2G_DIST_WORLD1") == "1" and "MASTER_ADDR" in os.environ):
+        return None      # (BT2G_DIST_WORLD1=1 under torch.distributed.run: a process group of one rank -- lets a single-GPU box run the N-GPU code path, RCCL included)
     import torch.distributed as dist
     if not dist.is_initialized():
         kw = {}

@@ -15,5 +15,8 @@ run "devnull" bowtie2_amd/bin/bowtie2-align-l --sensitive -t -p 16 -x $B -U $C/e
 run "devnull again" bowtie2_amd/bin/bowtie2-align-l --sensitive -t -p 16 -x $B -U $C/e2e.fq -S /dev/null
 run "devnull sdma off" env HSA_ENABLE_SDMA=0 bowtie2_amd/bin/bowtie2-align-l --sensitive -t -p 16 -x $B -U $C/e2e.fq -S /dev/null
 run "devnull batch 524288" bowtie2_amd/bin/bowtie2-align-l --sensitive -t -p 16 --batch 524288 -x $B -U $C/e2e.fq -S /dev/null
+run "devnull batch 1048576" bowtie2_amd/bin/bowtie2-align-l --sensitive -t -p 16 --batch 1048576 -x $B -U $C/e2e.fq -S /dev/null
+run "devnull batch 131072" bowtie2_amd/bin/bowtie2-align-l --sensitive -t -p 16 --batch 131072 -x $B -U $C/e2e.fq -S /dev/null
 run "devnull p 8" bowtie2_amd/bin/bowtie2-align-l --sensitive -t -p 8 -x $B -U $C/e2e.fq -S /dev/null
+run "devnull p 4" bowtie2_amd/bin/bowtie2-align-l --sensitive -t -p 4 -x $B -U $C/e2e.fq -S /dev/null
 rm -f $C/e2e.fq $C/e2e.sam
