@@ -1442,7 +1442,7 @@ def main():
         res["_outer"] = {"pmc": full and not args.no_pmc_pass, "kernel": kname, "config": args.config, "reads": n,
                          "extra_configs": [c for c in extra.split(",") if c and c != args.config], "extra_steps": args.extra_steps, "warmup": args.warmup,
                          "forward": fwd, "genome_fasta": args.genome_fasta if "--genome-fasta" in sys.argv else None}
-        print(json.dumps(res), flush=True)
+        print_line(res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -1479,13 +1479,26 @@ def apply_live_traffic(res, lp):
         r["traffic_live"] = lp      # {"error": ...}: the committed summary (if it is this library's) or null stays
 
 
+def print_line(res):
+    """The ONE JSON line, as the last thing on stdout: whatever native libraries left in the C stdio buffer (RCCL prints a version banner there when
+    the process group is created, and it would otherwise surface at exit, behind the line) is flushed first."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(res) + "\n")
+    sys.stdout.flush()
+
+
 def run_child(argv, timeout_s=None):
     env = dict(os.environ, BT2_BENCH_CHILD="1")
     try:
         p = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE, env=env, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired:
         return None, "timed out after %s s" % timeout_s, 124
-    line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
+    js = [l for l in p.stdout.splitlines() if l.startswith("{")]      # (the line; anything a native library printed around it is not)
+    line = js[-1] if js else ""
     try:
         return json.loads(line), None, p.returncode
     except ValueError:
@@ -1534,7 +1547,7 @@ def outer():
                 res["e2e"] = e2e_leg_ranks(pend, world, res["value"])
             else:
                 res["e2e"] = {"error": "not run: the measuring processes of the ranks did not all exit cleanly (%s)" % rcs}
-        print(json.dumps(res), flush=True)
+        print_line(res)
         raise SystemExit(rc)
     if res is None:
         sys.stdout.write(err or "")
@@ -1568,7 +1581,7 @@ def outer():
             res["configs"][name] = summarize_config(d)
         res["configs_note"] = ("BASELINE.json configs[1], [3], [4] measured in this same run, each in a process of its own after the headline: %d timed steps, one run of the unmodified "
                                "reference on the configuration's sample for cpu_baseline and the byte-for-byte SAM comparison (--parity-only protocol: not a median of 3)" % todo["extra_steps"])
-    print(json.dumps(res), flush=True)
+    print_line(res)
     raise SystemExit(rc)
 
 
