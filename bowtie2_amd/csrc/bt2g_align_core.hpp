@@ -2601,6 +2601,9 @@ struct Aligner {
 						HOT.t_phase[5] += tnow() - td_;
 						HOT.n_ex_dps++;
 						found = best >= minsc_now;
+#ifdef BT2G_COUNT_FAILED_FILLS
+						if (!found) HOT.t_phase[15] += 100;      // diagnostic build: DP windows whose best score stays below the minimum (per read, in the "gather_lastrow" slot)
+#endif
 						if (found) { const uint64_t tg_ = tnow(); gather_cells(fw, rows, cols, minsc_now, mode, lastsolcol); found = Plat::uni(HOT.n_cands) > 0; HOT.t_phase[8] += tnow() - tg_; }
 						if (!found) {
 							HOT.n_dp_fail++;

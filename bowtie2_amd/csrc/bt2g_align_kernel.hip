@@ -422,7 +422,11 @@ __device__ __attribute__((noinline)) int fill_ee_i16_leaf_big(bool fw_, uint32_t
 // EMIT: the candidate cells of the gather (gatherCellsNucleotidesLocalSseU8, aligner_swsse_loc_u8.cpp:1389-1496: score >= minsc, at or
 // below the first row that can reach minsc, a match whose diagonal successor is not) are recognised while the cell is in registers and
 // appended to `emit` (unsorted, columns beyond lastsolcol included: the gather drops those) -- the matrix is not read again to find them.
-template <int RB, bool EMIT>
+// PRED = false: the score-only pass (round 6).  Nine of ten local DP windows of a repeat-rich read never reach the minimum score (11.4 of 13.0 per read
+// on the 400-bp workload) and are never backtraced: the seven predecessor flags -- 21 of the 35 instructions of a step -- and the byte stores are
+// wasted on them.  The pass computes the same scores and the same bail-out column, nothing is stored; only a window whose best score reaches the
+// minimum is filled again with PRED = true.  Both passes stop at the bail-out column (what lies behind it nobody looks at: lastsolcol_).
+template <int RB, bool EMIT, bool PRED = true>
 __device__ __forceinline__ int fill_local_pk(const AlignParams& P, bool fw, uint32_t rows, uint32_t cols, uint8_t* __restrict__ pm,
                                              int minsc, uint32_t& lastsolcol, uint32_t& sat8, BT2_G BtCand* emit, uint32_t emit_cap, uint32_t& n_emit) {
 	const uint32_t lane = threadIdx.x & 63;
@@ -482,7 +486,7 @@ __device__ __forceinline__ int fill_local_pk(const AlignParams& P, bool fw, uint
 		upHdiag = upH;
 		const uint32_t j_lo = t - lane, j_hi = t - lane - 64u;      // (unsigned: negative = huge)
 		const bool act_lo = j_lo < cols && lane < nblocks, act_hi = j_hi < cols && lane + 64u < nblocks;
-		{
+		if (PRED) {
 			uint8_t* base = pm + ((uint64_t)t * RB) * 128 + lane;
 			if (act_lo) {
 #pragma unroll
@@ -502,6 +506,7 @@ __device__ __forceinline__ int fill_local_pk(const AlignParams& P, bool fw, uint
 			if (c + bias >= 255) sat = 1;
 			if (c < minsc) { if (c + (int)(cols - (uint32_t)j - 1) * P.match_bonus < minsc) bailed = 1; }
 			else lastsol = j;
+			if (!PRED && bailed) break;      // (the score-only pass has its answer; the storing pass goes on: the stage output and the CPU twin's check cover the whole rectangle)
 		}
 		if (EMIT) {
 			// any cell of this step at or above minsc?  (rarely: most of the matrix is far below)
@@ -570,7 +575,7 @@ __device__ __attribute__((noinline)) int fill_ee_i16_leaf(bool fw_, uint32_t row
 	return fill_ee_i16_wave<R>(g_P, fw, rows, cols, m64);
 }
 // local fill: lastsolcol / sat8 / the number of emitted candidates come back through g_st (fill_lastsol, fill_sat8, n_emit)
-template <int RB, bool EMIT>
+template <int RB, bool EMIT, bool PRED = true>
 __device__ __attribute__((noinline)) int fill_local_leaf(bool fw_, uint32_t rows_, uint32_t cols_, uint8_t* pm_, int ms_, BT2_G BtCand* emit_, uint32_t ecap_) {
 	const bool fw = __builtin_amdgcn_readfirstlane((int)fw_) != 0;
 	const uint32_t rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_), cols = (uint32_t)__builtin_amdgcn_readfirstlane((int)cols_);
@@ -581,7 +586,7 @@ __device__ __attribute__((noinline)) int fill_local_leaf(bool fw_, uint32_t rows
 	const uint64_t ea = (uint64_t)emit_;
 	BT2_G BtCand* emit = (BT2_G BtCand*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ea >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ea));
 	uint32_t lastsolcol = 0, sat8 = 0, nem = 0;
-	const int best = fill_local_pk<RB, EMIT>(g_P, fw, rows, cols, pm, ms, lastsolcol, sat8, emit, ecap, nem);
+	const int best = fill_local_pk<RB, EMIT, PRED>(g_P, fw, rows, cols, pm, ms, lastsolcol, sat8, emit, ecap, nem);
 	if ((threadIdx.x & 63) == 0) { g_st.fill_lastsol = lastsolcol; g_st.fill_sat8 = sat8; g_st.n_emit = nem; g_st.emit_vmax = best; }
 	return best;
 }
@@ -1458,6 +1463,26 @@ struct DevPlat {
 		// the worker's fills leave their candidate cells in Work::cands_tmp for gather_local; the stage kernel (k_dp_fill) has no arena
 		BT2_G BtCand* const emit = g_st.emit_on ? &DevPlat::work().cands_tmp[0] : (BT2_G BtCand*)nullptr;
 		const uint32_t ecap = (uint32_t)kMaxCands;
+		if (emit) {
+			// pass 1 (workers only; the stage kernel always stores its matrix): does the window reach the minimum score at all?
+			switch (dp_RB(rows)) {
+				case 1: best = fill_local_leaf<1, false, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+				case 2: best = fill_local_leaf<2, false, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+				case 3: best = fill_local_leaf<3, false, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+#ifdef BT2G_KCLASS_LR
+				case 4: best = fill_local_leaf<4, false, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+				case 8: best = fill_local_leaf<8, false, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+				default: best = fill_local_leaf<16, false, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+#else
+				default: best = fill_local_leaf<4, false, false>(fw, rows, cols, m64, ms, emit, ecap); break;
+#endif
+			}
+			best = uni(best);
+			wave_fence();
+			g_hot.n_dp_cells_score += rows * cols;
+			if ((int64_t)best < minsc) { lastsolcol = uni(g_st.fill_lastsol); sat8 = uni(g_st.fill_sat8); return (int64_t)best; }
+			g_hot.n_dp_pass++;
+		}
 		if (emit) switch (dp_RB(rows)) {
 			case 1: best = fill_local_leaf<1, true>(fw, rows, cols, m64, ms, emit, ecap); break;
 			case 2: best = fill_local_leaf<2, true>(fw, rows, cols, m64, ms, emit, ecap); break;
