@@ -1556,16 +1556,22 @@ struct DevPlat {
 				for (uint32_t b = 0; b < 10; b++) { const bool bit = ((d >> b) & 1u) != 0; const unsigned long long bal = __ballot(valid && bit); m &= bit ? bal : ~bal; }
 				return m;
 			};
-			// histogram
-			for (uint32_t base = 0; base < n; base += 64) {
-				const uint32_t i = base + lane;
-				BtCand c; c.score = 0; c.row = 0; c.col = 0;
-				if (i < n) c = gld(src + i);
-				const bool valid = i < n && (p > 0 || (uint32_t)c.col < ncol);
-				const uint32_t d = digit_of(c);
-				const unsigned long long m = same_digit(valid, d);
-				if (valid && (m & lt) == 0) cnt[d] = (Cnt)(cnt[d] + (uint32_t)__popcll(m));
-				wave_fence();
+			// histogram (four groups of 64 candidates per round: their loads are in flight together -- one memory round trip per 256 candidates instead of four)
+			for (uint32_t base = 0; base < n; base += 256) {
+				BtCand cc[4];
+#pragma unroll
+				for (uint32_t u = 0; u < 4; u++) { const uint32_t i = base + 64u * u + lane; cc[u].score = 0; cc[u].row = 0; cc[u].col = 0; if (i < n) cc[u] = gld(src + i); }
+#pragma unroll
+				for (uint32_t u = 0; u < 4; u++) {
+					const uint32_t i = base + 64u * u + lane;
+					if (base + 64u * u >= n) break;
+					const BtCand c = cc[u];
+					const bool valid = i < n && (p > 0 || (uint32_t)c.col < ncol);
+					const uint32_t d = digit_of(c);
+					const unsigned long long m = same_digit(valid, d);
+					if (valid && (m & lt) == 0) cnt[d] = (Cnt)(cnt[d] + (uint32_t)__popcll(m));
+					wave_fence();
+				}
 			}
 			// exclusive prefix over the 1024 counters: lane l owns counters 16 l .. 16 l + 15
 			uint32_t mine[16], sum = 0;
@@ -1580,23 +1586,29 @@ struct DevPlat {
 #pragma unroll
 			for (uint32_t q = 0; q < 16; q++) { cnt[16u * lane + q] = (Cnt)run; run += mine[q]; }
 			wave_fence();
-			// stable scatter
-			for (uint32_t base = 0; base < n; base += 64) {
-				const uint32_t i = base + lane;
-				BtCand c; c.score = 0; c.row = 0; c.col = 0;
-				if (i < n) c = gld(src + i);
-				const bool valid = i < n && (p > 0 || (uint32_t)c.col < ncol);
-				const uint32_t d = digit_of(c);
-				const unsigned long long m = same_digit(valid, d);
-				uint32_t s0 = 0;
-				if (valid) s0 = cnt[d];
-				wave_fence();
-				if (valid) {
-					const uint32_t rank = (uint32_t)__popcll(m & lt), grp = (uint32_t)__popcll(m);
-					gst(out + s0 + rank, c);
-					if (rank + 1u == grp) cnt[d] = (Cnt)(s0 + grp);
+			// stable scatter (groups taken in order; loads four groups ahead as above)
+			for (uint32_t base = 0; base < n; base += 256) {
+				BtCand cc[4];
+#pragma unroll
+				for (uint32_t u = 0; u < 4; u++) { const uint32_t i = base + 64u * u + lane; cc[u].score = 0; cc[u].row = 0; cc[u].col = 0; if (i < n) cc[u] = gld(src + i); }
+#pragma unroll
+				for (uint32_t u = 0; u < 4; u++) {
+					const uint32_t i = base + 64u * u + lane;
+					if (base + 64u * u >= n) break;
+					const BtCand c = cc[u];
+					const bool valid = i < n && (p > 0 || (uint32_t)c.col < ncol);
+					const uint32_t d = digit_of(c);
+					const unsigned long long m = same_digit(valid, d);
+					uint32_t s0 = 0;
+					if (valid) s0 = cnt[d];
+					wave_fence();
+					if (valid) {
+						const uint32_t rank = (uint32_t)__popcll(m & lt), grp = (uint32_t)__popcll(m);
+						gst(out + s0 + rank, c);
+						if (rank + 1u == grp) cnt[d] = (Cnt)(s0 + grp);
+					}
+					wave_fence();
 				}
-				wave_fence();
 			}
 			n = total;       // (the first pass dropped the columns beyond lastsolcol)
 			if (n == 0) break;
