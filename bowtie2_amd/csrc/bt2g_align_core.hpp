@@ -2529,7 +2529,7 @@ struct Aligner {
 						res.ns = (int16_t)hns; res.gaps = 0;
 						if (mms) {
 							Edit& e = res.ned[0];
-							e.pos = eh->epos; e.chr = code2chr(eh->echr); e.qchr = code2chr(eh->eqchr); e.type = EDIT_MM;
+							e.pos = eh->epos; e.chr = code2chr(eh->echr); e.qchr = code2chr(eh->eqchr); e.type = EDIT_MM; e.pad = 0;
 							res.nned = 1;
 						}
 						// setShape with no trimming leaves the (already 5'-relative) edit untouched

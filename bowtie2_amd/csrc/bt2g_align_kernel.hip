@@ -1263,10 +1263,13 @@ struct DevPlat {
 	}
 	static __device__ __forceinline__ void copy_aln(BT2_G AlnRes& dst, const BT2_G AlnRes& src) {
 		wave_fence();
-		const uint32_t nw = ((uint32_t)offsetof(AlnRes, ned) + (uint32_t)uni((uint32_t)src.nned) * (uint32_t)sizeof(Edit) + 3u) / 4u;
+		const uint32_t nb = (uint32_t)offsetof(AlnRes, ned) + (uint32_t)uni((uint32_t)src.nned) * (uint32_t)sizeof(Edit);
+		const uint32_t nw = (nb + 3u) / 4u;
 		const BT2_G uint32_t* s = (const BT2_G uint32_t*)&src;
 		BT2_G uint32_t* d = (BT2_G uint32_t*)&dst;
-		for (uint32_t i = threadIdx.x & 63; i < nw; i += 64) d[i] = s[i];
+		// (an odd number of 6-byte edits ends in the middle of a word: what lies behind it in the source is whatever an earlier alignment left there -- kept
+		// out of the copy, so that the records of two runs are the same bytes)
+		for (uint32_t i = threadIdx.x & 63; i < nw; i += 64) { uint32_t v = s[i]; if (i * 4u + 4u > nb) v &= 0xffffffffu >> (8u * (i * 4u + 4u - nb)); d[i] = v; }
 		wave_fence();
 	}
 	// idx[0..n) <- the alignments' indices, descending by (score, index) -- AlnSinkWrap::selectByScore sorts (score, index) pairs ascending and reverses:

@@ -693,6 +693,8 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	// (the short-read class is built for 20 waves per CU and runs 18: the worker is bound by what a CU can issue, not by latency -- round 6 measured
 	// 293 / 285 / 286 / 296 ms per 2 M reads with 20 / 18 / 16 / 14 waves per CU resident, profiles/r06t_* -- and the LDS of the two waves left out goes to the others)
 	static const uint32_t w5_waves = []() -> uint32_t { const char* v = getenv("BT2G_W5_WAVES"); const int k = v ? atoi(v) : 18; return (uint32_t)(k >= 4 && k <= (int)bt2g_w5_waves_per_cu() ? k : (int)bt2g_w5_waves_per_cu()); }();
+	// LDS per wave of that class: its share of the CU's 160 KB, or less (BT2G_W5_LDS) -- what it leaves is where the FM kernels' blocks of the next batch fit
+	static const uint32_t w5_lds = []() -> uint32_t { const char* v = getenv("BT2G_W5_LDS"); const uint32_t full = ((160u * 1024u) / w5_waves) & ~15u; const int k = v ? atoi(v) : 0; return (k >= 6144 && (uint32_t)k <= full) ? ((uint32_t)k & ~15u) : full; }();
 	uint32_t n_waves = c->n_cu * (w5 ? w5_waves : longr ? bt2g_lr_waves_per_cu() : bigk ? bt2g_bk_waves_per_cu() : align_waves_per_cu());
 	{ static const int pct = getenv("BT2G_WAVES_PCT") ? atoi(getenv("BT2G_WAVES_PCT")) : 100;      // measurement knob: launch a fraction of the resident waves (latency- or throughput-bound?)
 	  if (pct > 0 && pct < 100) n_waves = (uint32_t)((uint64_t)n_waves * (uint32_t)pct / 100u); if (n_waves == 0) n_waves = 1; }
@@ -834,7 +836,7 @@ int bt2g_align_batch(bt2g_ctx* c, const bt2g_reads* reads, const bt2g_read_param
 	const uint64_t stride = bt2g_align_result_stride((uint32_t)params->khits);
 	if (w5)
 		e = bt2g_w5_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
-		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, ((160u * 1024u) / w5_waves) & ~15u, st);
+		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, w5_lds, st);
 	else if (longr)
 		e = bt2g_lr_launch_align(c->off_size, c->off_size == 4 ? (const void*)&c->ix32 : (const void*)&c->ix64, params, reads, d_rparams, (uint8_t*)d_results, stride, S.d_arena, arena_stride,
 		                         mat_bytes, mask_bytes, pmask_bytes, n_waves, S.d_next, (unsigned long long*)(S.d_next + 16), &pre, max_read_len, max_cols, (160u * 1024u) / bt2g_lr_waves_per_cu(), st);
